@@ -1,0 +1,115 @@
+// basis.h -- 1-D tables of the collocated Qk element dflo uses:
+// Lagrange basis at the N=k+1 Gauss points with Gauss(N) quadrature
+// (FE_DGQArbitraryNodes(QGauss<1>(k+1)), src/main.cc:40; quadrature src/claw.cc:419-422).
+// Everything the kernels need is a handful of N x N matrices; they are computed once on the
+// host in long double and uploaded as kernel arguments.
+#pragma once
+#include <cmath>
+#include <vector>
+
+namespace dflo {
+
+constexpr int kMaxN = 4;     // degree <= 3
+constexpr int kMaxGLL = 3;   // positivity point set: N_g = 2 (k=1), 3 (k=2,3)  src/positivity.cc:43
+constexpr int kTrap = 4;     // QIterated(QTrapez,3): 4 points per direction, src/claw.cc:523
+
+struct BasisTables {
+  int N;
+  int Ng;
+  double x[kMaxN];            // Gauss nodes on [0,1]
+  double w[kMaxN];            // Gauss weights
+  double D[kMaxN][kMaxN];     // D[q][a] = l_a'(x_q)
+  double L0[kMaxN];           // l_a(0)
+  double L1[kMaxN];           // l_a(1)
+  double Pg[kMaxGLL][kMaxN];  // l_a(x_g) at the Gauss-Lobatto points
+  double Pt[kTrap][kMaxN];    // l_a at 0, 1/3, 2/3, 1
+};
+
+inline void legendre_ld(int n, long double t, long double &p, long double &dp) {
+  long double p0 = 1.0L, p1 = t;
+  if (n == 0) { p = 1.0L; dp = 0.0L; return; }
+  for (int k = 2; k <= n; ++k) {
+    long double pk = ((2.0L * k - 1.0L) * t * p1 - (k - 1.0L) * p0) / k;
+    p0 = p1;
+    p1 = pk;
+  }
+  p = p1;
+  dp = n * (t * p1 - p0) / (t * t - 1.0L);
+}
+
+inline void gauss01(int n, long double *x, long double *w) {
+  const long double pi = 3.14159265358979323846264338327950288L;
+  for (int i = 0; i < n; ++i) {
+    long double t = -cosl(pi * (i + 0.75L) / (n + 0.5L));
+    for (int it = 0; it < 200; ++it) {
+      long double p, dp;
+      legendre_ld(n, t, p, dp);
+      long double dt = p / dp;
+      t -= dt;
+      if (fabsl(dt) < 1e-19L) break;
+    }
+    long double p, dp;
+    legendre_ld(n, t, p, dp);
+    x[i] = 0.5L * (1.0L + t);
+    w[i] = 1.0L / ((1.0L - t * t) * dp * dp);
+  }
+}
+
+inline void gauss_lobatto01(int n, long double *x) {
+  const long double pi = 3.14159265358979323846264338327950288L;
+  const int m = n - 1;
+  x[0] = 0.0L;
+  x[n - 1] = 1.0L;
+  for (int i = 1; i < n - 1; ++i) {
+    long double t = -cosl(pi * i / m);
+    for (int it = 0; it < 200; ++it) {
+      long double p, dp;
+      legendre_ld(m, t, p, dp);
+      long double ddp = (2.0L * t * dp - m * (m + 1.0L) * p) / (1.0L - t * t);
+      long double dt = dp / ddp;
+      t -= dt;
+      if (fabsl(dt) < 1e-19L) break;
+    }
+    x[i] = 0.5L * (1.0L + t);
+  }
+}
+
+inline long double lagrange_ld(int N, const long double *nodes, int a, long double x) {
+  long double v = 1.0L;
+  for (int m = 0; m < N; ++m)
+    if (m != a) v *= (x - nodes[m]) / (nodes[a] - nodes[m]);
+  return v;
+}
+inline long double dlagrange_ld(int N, const long double *nodes, int a, long double x) {
+  long double s = 0.0L;
+  for (int j = 0; j < N; ++j) {
+    if (j == a) continue;
+    long double v = 1.0L / (nodes[a] - nodes[j]);
+    for (int m = 0; m < N; ++m)
+      if (m != a && m != j) v *= (x - nodes[m]) / (nodes[a] - nodes[m]);
+    s += v;
+  }
+  return s;
+}
+
+inline BasisTables make_basis(int degree) {
+  BasisTables b{};
+  const int N = degree + 1;
+  b.N = N;
+  b.Ng = ((degree + 3) % 2 == 0) ? (degree + 3) / 2 : (degree + 4) / 2;  // src/positivity.cc:43
+  long double x[kMaxN], w[kMaxN], g[kMaxGLL + 1];
+  gauss01(N, x, w);
+  gauss_lobatto01(b.Ng, g);
+  for (int a = 0; a < N; ++a) {
+    b.x[a] = (double)x[a];
+    b.w[a] = (double)w[a];
+    b.L0[a] = (double)lagrange_ld(N, x, a, 0.0L);
+    b.L1[a] = (double)lagrange_ld(N, x, a, 1.0L);
+    for (int q = 0; q < N; ++q) b.D[q][a] = (double)dlagrange_ld(N, x, a, x[q]);
+    for (int p = 0; p < b.Ng; ++p) b.Pg[p][a] = (double)lagrange_ld(N, x, a, g[p]);
+    for (int p = 0; p < kTrap; ++p) b.Pt[p][a] = (double)lagrange_ld(N, x, a, (long double)p / 3.0L);
+  }
+  return b;
+}
+
+}  // namespace dflo

@@ -1,0 +1,1282 @@
+// engine.hip -- MI355X (gfx950) explicit DG residual + SSP-RK engine behind include/dflo_hip.h.
+//
+// One RK stage of dflo's iterate_explicit (src/claw.cc:732-771) is ONE kernel launch:
+//   assemble_system (volume + boundary + interior faces, src/assemble_explicit.cc:30-452)
+//   -> dt * M^-1 (src/claw.cc:702-711) -> SSP combine (src/claw.cc:757-760)
+//   -> cell average (src/claw.cc:562-597) -> CFL partial minimum (src/claw.cc:486-511)
+// followed, when enabled, by one limiter launch (TVB src/limiter.cc:225-370 + positivity
+// src/positivity.cc:17-208).
+//
+// Data layout in HBM: cells are grouped in shards of 64; a shard stores its DoFs
+// structure-of-arrays, U[(shard*ndof + dof)*64 + lane], so that one wavefront (lane = cell)
+// moves every DoF with a single fully coalesced 512-byte access and the per-cell arithmetic
+// (collocated Qk: W at a quadrature point IS a DoF, src/main.cc:40 + src/claw.cc:419-422)
+// needs no gather.  Algorithmic HBM traffic per DoF and stage: read u(s), read u(n), write
+// u(s+1) = 24 bytes (+16 when a limiter pass runs).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/dflo_hip.h"
+#include "basis.h"
+#include "physics.hpp"
+#include "plan.h"
+
+namespace dflo {
+
+// ------------------------------------------------------------------ kernel arguments
+struct KBasis {       // 1-D tables, see basis.h
+  double w[kMaxN];
+  double x[kMaxN];
+  double L0[kMaxN], L1[kMaxN];
+  double D[kMaxN][kMaxN];   // D[q][a] = l_a'(x_q)
+  double DW[kMaxN][kMaxN];  // D[q][a] * w[q]
+  double Pg[kMaxGLL][kMaxN];
+  double Pt[kTrap][kMaxN];
+  int Ng;
+};
+
+struct StageArgs {
+  const double *Ucur, *Uold;
+  double *Unew;
+  const double *avg_cur;
+  double *avg_new;
+  double *rhs_out;  // parity hook: write the assembled rhs instead of updating
+  const int32_t *shard_count, *halo_begin, *halo_cells, *face_begin;
+  const FaceRec *faces;
+  const uint16_t *cell_face;
+  const double *cell_h;
+  const double *bval;
+  const int32_t *bface_kind;
+  const double *dt_dev;   // device-resident global dt (used when dt_host < 0)
+  const double *dt_cell;  // local time stepping: per internal slot, else null
+  double *shard_res, *shard_dtmin;
+  double dt_host, ark, gravity, cfl, h_uniform;
+  int n_shards, stride, max_fp, uniform_h, want_dt, degree;
+  KBasis kb;
+};
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_min(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// blockIdx -> shard so that every XCD (block b runs on XCD b % 8) sweeps one contiguous run of
+// the Morton-ordered shards: halo re-reads then hit that XCD's own L2.
+__device__ __forceinline__ int shard_of_block(int b, int n_shards) {
+  const int chunk = (n_shards + 7) >> 3;
+  const int s = (b & 7) * chunk + (b >> 3);
+  return (b >> 3) < chunk && s < n_shards ? s : -1;
+}
+
+// ------------------------------------------------------------------ the stage kernel
+// One wavefront per shard.  LDS image: Us[ndof][stride] (own 64 cells then halo cells),
+// As[4][stride] cell averages (LxF), Fh[4][max_fp] numerical fluxes at the shard's face points.
+template <int N, int FLUX>
+__global__ __launch_bounds__(64) void stage_kernel(const StageArgs a) {
+  constexpr int NS = N * N, NDOF = 4 * NS;
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int shard = shard_of_block(blockIdx.x, a.n_shards);
+  if (shard < 0) return;
+  const int lane = threadIdx.x;
+  const int S = a.stride;
+  double *Us = lds;
+  double *As = Us + NDOF * S;
+  double *Fh = As + 4 * S;
+  const KBasis &kb = a.kb;
+
+  // ---- phase A: shard + halo -> LDS
+  {
+    const double *up = a.Ucur + (size_t)shard * NDOF * 64 + lane;
+#pragma unroll
+    for (int d = 0; d < NDOF; ++d) Us[d * S + lane] = up[d * 64];
+    if constexpr (FLUX == DFLO_FLUX_LXF) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) As[c * S + lane] = a.avg_cur[((size_t)shard * 4 + c) * 64 + lane];
+    }
+    const int hb = a.halo_begin[shard], nh = a.halo_begin[shard + 1] - hb;
+    for (int s = lane; s < nh; s += 64) {
+      const int ic = a.halo_cells[hb + s];
+      const double *hp = a.Ucur + (size_t)(ic >> 6) * NDOF * 64 + (ic & 63);
+#pragma unroll
+      for (int d = 0; d < NDOF; ++d) Us[d * S + 64 + s] = hp[d * 64];
+      if constexpr (FLUX == DFLO_FLUX_LXF) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) As[c * S + 64 + s] = a.avg_cur[((size_t)(ic >> 6) * 4 + c) * 64 + (ic & 63)];
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- phase B: one numerical flux per face point (integrate_face_term_explicit :303-341,
+  //      integrate_boundary_term_explicit :176-206)
+  {
+    const int fb = a.face_begin[shard], nfp = (a.face_begin[shard + 1] - fb) * N;
+    for (int p = lane; p < nfp; p += 64) {
+      const int k = p / N, q = p - k * N;
+      const FaceRec r = a.faces[fb + k];
+      const int slotL = r.w0 & 0xFFFF, fL = (r.w0 >> 16) & 3;
+      const bool bnd = (r.w0 >> 18) & 1, flip = (r.w0 >> 19) & 1;
+      const int fR = (r.w0 >> 20) & 3;
+      double Wp[4], Wm[4], Ap[4], Am[4], F[4];
+      {  // trace of the integrating cell: W+ = sum_m l_m(0|1) U[m,q] (x faces) or U[q,m] (y faces)
+        const int base = fL < 2 ? N * q : q, str = fL < 2 ? 1 : N;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          double v = 0;
+#pragma unroll
+          for (int m = 0; m < N; ++m) v += ((fL & 1) ? kb.L1[m] : kb.L0[m]) * Us[(c * NS + base + m * str) * S + slotL];
+          Wp[c] = v;
+        }
+      }
+      const double nx = fL == 0 ? -1.0 : (fL == 1 ? 1.0 : 0.0);
+      const double ny = fL == 2 ? -1.0 : (fL == 3 ? 1.0 : 0.0);
+      if constexpr (FLUX == DFLO_FLUX_LXF) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) Ap[c] = As[c * S + slotL];
+      }
+      if (!bnd) {
+        const int slotR = r.w1;
+        const int qr = flip ? N - 1 - q : q;
+        const int base = fR < 2 ? N * qr : qr, str = fR < 2 ? 1 : N;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          double v = 0;
+#pragma unroll
+          for (int m = 0; m < N; ++m) v += ((fR & 1) ? kb.L1[m] : kb.L0[m]) * Us[(c * NS + base + m * str) * S + slotR];
+          Wm[c] = v;
+        }
+        if constexpr (FLUX == DFLO_FLUX_LXF) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) Am[c] = As[c * S + slotR];
+        }
+      } else {
+        const int bf = r.w1;
+        const double *bv = a.bval + ((size_t)bf * N + q) * 4;
+        double bvv[4] = {bv[0], bv[1], bv[2], bv[3]};
+        compute_Wminus(a.bface_kind[bf], nx, ny, Wp, bvv, Wm);
+        if constexpr (FLUX == DFLO_FLUX_LXF) {  // both averages are the interior cell's, :200-205
+#pragma unroll
+          for (int c = 0; c < 4; ++c) Am[c] = Ap[c];
+        }
+      }
+      numerical_normal_flux<FLUX>(nx, ny, Wp, Wm, Ap, Am, F);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) Fh[c * a.max_fp + p] = F[c];
+    }
+  }
+  __syncthreads();
+
+  // ---- phase C: lane = cell
+  const int cnt = a.shard_count[shard];
+  double res = 0.0, dtmin = 1.0e20;
+  if (lane < cnt) {
+    const double h = a.uniform_h ? a.h_uniform : a.cell_h[(size_t)shard * 64 + lane];
+    double R[NDOF];
+#pragma unroll
+    for (int d = 0; d < NDOF; ++d) R[d] = 0.0;
+    // volume term (integrate_cell_term_explicit :57-115); collocation: W_q = U_q, and
+    // grad phi_(a',b)(x_(a,b)) = D[a][a']/h e_x, JxW = w_a w_b h^2
+#pragma unroll
+    for (int b = 0; b < N; ++b)
+#pragma unroll
+      for (int aa = 0; aa < N; ++aa) {
+        const int j = aa + N * b;
+        double W[4], Fx[4], Gy[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) W[c] = Us[(c * NS + j) * S + lane];
+        flux_xy(W, Fx, Gy);
+        const double wbh = kb.w[b] * h, wah = kb.w[aa] * h;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const double fx = Fx[c] * wbh, gy = Gy[c] * wah;
+#pragma unroll
+          for (int m = 0; m < N; ++m) {
+            R[c * NS + m + N * b] += fx * kb.DW[aa][m];
+            R[c * NS + aa + N * m] += gy * kb.DW[b][m];
+          }
+        }
+        if (a.gravity != 0.0) {  // forcing (src/equation.h:831-850): (0, -rho, 0, -my) * gravity
+          const double jxw = kb.w[aa] * kb.w[b] * h * h;
+          R[MY * NS + j] += a.gravity * (-1.0 * W[RHO]) * jxw;
+          R[EN * NS + j] += a.gravity * (-1.0 * W[MY]) * jxw;
+        }
+      }
+    // face terms (:209-244, :344-423): - flux * phi * JxW on the integrating side, + on the other
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      const uint16_t ref = a.cell_face[((size_t)shard * 4 + f) * 64 + lane];
+      if (ref == kNoFace) continue;
+      const int k = ref & 0x3FFF;
+      const bool flip = (ref >> 14) & 1;
+      const double sgn = (ref >> 15) ? 1.0 : -1.0;
+#pragma unroll
+      for (int q = 0; q < N; ++q) {
+        const int qq = flip ? N - 1 - q : q;
+        const double jxw = sgn * kb.w[q] * h;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const double fq = Fh[c * a.max_fp + k * N + qq] * jxw;
+#pragma unroll
+          for (int m = 0; m < N; ++m) {
+            const double lw = (f & 1) ? kb.L1[m] : kb.L0[m];
+            if (f < 2) R[c * NS + m + N * q] += fq * lw;
+            else R[c * NS + q + N * m] += fq * lw;
+          }
+        }
+      }
+    }
+    if (a.rhs_out) {
+      double *rp = a.rhs_out + (size_t)shard * NDOF * 64 + lane;
+#pragma unroll
+      for (int d = 0; d < NDOF; ++d) rp[d * 64] = R[d];
+    } else {
+      // solve() rk3 branch + SSP combine (src/claw.cc:708-710, 757-760)
+      const double dt = a.dt_cell ? a.dt_cell[(size_t)shard * 64 + lane] : (a.dt_host >= 0.0 ? a.dt_host : *a.dt_dev);
+      const double rh2 = 1.0 / (h * h);
+      const double *op = a.Uold + (size_t)shard * NDOF * 64 + lane;
+      double *np = a.Unew + (size_t)shard * NDOF * 64 + lane;
+      double avg[4] = {0, 0, 0, 0};
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int j = 0; j < NS; ++j) {
+          const int d = c * NS + j;
+          const double ww = kb.w[j % N] * kb.w[j / N];
+          const double invM = rh2 / ww;
+          res += R[d] * R[d];
+          double u = Us[d * S + lane];
+          u += dt * R[d] * invM;
+          if (a.ark != 0.0) u = (1.0 - a.ark) * u + a.ark * op[d * 64];
+          np[d * 64] = u;
+          avg[c] += ww * u;
+        }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) a.avg_new[((size_t)shard * 4 + c) * 64 + lane] = avg[c];
+      if (a.want_dt) {  // compute_time_step_cartesian, src/claw.cc:495-509
+        const double sonic = sqrt(kGamma * pressure(avg) / avg[RHO]);
+        const double maxeig = (sonic + fabs(avg[MX] / avg[RHO])) / h + (sonic + fabs(avg[MY] / avg[RHO])) / h;
+        dtmin = a.cfl / maxeig / (2.0 * a.degree + 1.0);
+      }
+    }
+  }
+  if (!a.rhs_out) {
+    res = wave_sum(res);
+    dtmin = wave_min(dtmin);
+    if (lane == 0) {
+      a.shard_res[shard] = res;
+      if (a.want_dt) a.shard_dtmin[shard] = dtmin;
+    }
+  }
+}
+
+// ------------------------------------------------------------------ limiter kernel
+struct LimArgs {
+  double *U;
+  const double *avg;
+  const int32_t *shard_count;
+  const int32_t *lrbt;
+  const double *cell_h;
+  int *flags;  // [0] negative mean state, [1] positivity root failure
+  double h_uniform, M, beta;
+  int n_shards, uniform_h, tvb, char_lim, pos_lim;
+  KBasis kb;
+};
+
+// apply_limiter_TVB_Qk (src/limiter.cc:225-370) then apply_positivity_limiter
+// (src/positivity.cc:17-208), lane = cell, all DoFs of the cell in registers.
+template <int N>
+__global__ __launch_bounds__(64) void limiter_kernel(const LimArgs a) {
+  constexpr int NS = N * N, NDOF = 4 * NS;
+  const int shard = shard_of_block(blockIdx.x, a.n_shards);
+  if (shard < 0) return;
+  const int lane = threadIdx.x;
+  if (lane >= a.shard_count[shard]) return;
+  const KBasis &kb = a.kb;
+  double *up = a.U + (size_t)shard * NDOF * 64 + lane;
+  double U[NDOF], A[4];
+#pragma unroll
+  for (int d = 0; d < NDOF; ++d) U[d] = up[d * 64];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) A[c] = a.avg[((size_t)shard * 4 + c) * 64 + lane];
+  const double h = a.uniform_h ? a.h_uniform : a.cell_h[(size_t)shard * 64 + lane];
+  bool changed = false;
+
+  if (a.tvb) {
+    const double dx = h;  // diameter/sqrt(2) of a square
+    const double Mdx2 = a.M * dx * dx;
+    double Dx[4], Dy[4], dbx[4], dfx[4], dby[4], dfy[4];
+    // cell-average gradient: (1/|K|) sum_q grad u(x_q) JxW_q, times dx  (:269-281)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      double gx = 0, gy = 0;
+#pragma unroll
+      for (int b = 0; b < N; ++b)
+#pragma unroll
+        for (int aa = 0; aa < N; ++aa) {
+          double dxu = 0, dyu = 0;
+#pragma unroll
+          for (int m = 0; m < N; ++m) {
+            dxu += kb.D[aa][m] * U[c * NS + m + N * b];
+            dyu += kb.D[b][m] * U[c * NS + aa + N * m];
+          }
+          gx += kb.w[aa] * kb.w[b] * dxu;
+          gy += kb.w[aa] * kb.w[b] * dyu;
+        }
+      Dx[c] = dx * (gx / h);
+      Dy[c] = dx * (gy / h);
+    }
+    const int il = a.lrbt[((size_t)shard * 4 + 0) * 64 + lane], ir = a.lrbt[((size_t)shard * 4 + 1) * 64 + lane];
+    const int ib = a.lrbt[((size_t)shard * 4 + 2) * 64 + lane], it = a.lrbt[((size_t)shard * 4 + 3) * 64 + lane];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      dbx[c] = il >= 0 ? A[c] - a.avg[((size_t)(il >> 6) * 4 + c) * 64 + (il & 63)] : Dx[c];
+      dfx[c] = ir >= 0 ? a.avg[((size_t)(ir >> 6) * 4 + c) * 64 + (ir & 63)] - A[c] : Dx[c];
+      dby[c] = ib >= 0 ? A[c] - a.avg[((size_t)(ib >> 6) * 4 + c) * 64 + (ib & 63)] : Dy[c];
+      dfy[c] = it >= 0 ? a.avg[((size_t)(it >> 6) * 4 + c) * 64 + (it & 63)] - A[c] : Dy[c];
+    }
+    EigenXY e;
+    if (a.char_lim) {
+      e = eigen_at(A);
+      to_char(e, 0, dbx);
+      to_char(e, 0, dfx);
+      to_char(e, 1, dby);
+      to_char(e, 1, dfy);
+      to_char(e, 0, Dx);
+      to_char(e, 1, Dy);
+    }
+    double Dxn[4], Dyn[4], change_x = 0, change_y = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      Dxn[i] = minmod(Dx[i], a.beta * dbx[i], a.beta * dfx[i], Mdx2);
+      Dyn[i] = minmod(Dy[i], a.beta * dby[i], a.beta * dfy[i], Mdx2);
+      change_x += fabs(Dxn[i] - Dx[i]);
+      change_y += fabs(Dyn[i] - Dy[i]);
+    }
+    change_x /= 4;
+    change_y /= 4;
+    if (change_x + change_y > 1.0e-10) {  // :347 -- reduce to the limited linear polynomial
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        Dxn[i] /= dx;
+        Dyn[i] /= dx;
+      }
+      if (a.char_lim) {
+        to_con(e, 0, Dxn);
+        to_con(e, 1, Dyn);
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int j = 0; j < NS; ++j) {
+          const double drx = h * (kb.x[j % N] - 0.5), dry = h * (kb.x[j / N] - 0.5);
+          U[c * NS + j] = A[c] + drx * Dxn[c] + dry * Dyn[c];
+        }
+      changed = true;
+    }
+  }
+
+  if (a.pos_lim) {
+    const double eps = 1.0e-13;
+    if (fmin(A[RHO], pressure(A)) < eps) {  // "Fatal: Negative states" :26-38
+      atomicOr(&a.flags[0], 1);
+    } else {
+      // density at GLL(Ng) x Gauss(N) and Gauss(N) x GLL(Ng)  (:43-47, :72-78)
+      double rho_min = 1.0e20;
+#pragma unroll
+      for (int l = 0; l < N; ++l)
+        for (int g = 0; g < a.kb.Ng; ++g) {
+          double vx = 0, vy = 0;
+#pragma unroll
+          for (int m = 0; m < N; ++m) {
+            vx += kb.Pg[g][m] * U[RHO * NS + m + N * l];
+            vy += kb.Pg[g][m] * U[RHO * NS + l + N * m];
+          }
+          rho_min = fmin(rho_min, fmin(vx, vy));
+        }
+      const double rat = fabs(A[RHO] - eps) / (fabs(A[RHO] - rho_min) + 1.0e-13);
+      const double theta1 = fmin(rat, 1.0);
+      if (theta1 < 1.0) {
+#pragma unroll
+        for (int j = 0; j < NS; ++j) U[RHO * NS + j] = theta1 * U[RHO * NS + j] + (1.0 - theta1) * A[RHO];
+        changed = true;
+      }
+      double theta2 = 1.0;
+      bool fail = false;
+#pragma unroll
+      for (int dir = 0; dir < 2; ++dir)
+#pragma unroll
+        for (int l = 0; l < N; ++l)
+          for (int g = 0; g < a.kb.Ng; ++g) {
+            double W[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              double v = 0;
+#pragma unroll
+              for (int m = 0; m < N; ++m) v += kb.Pg[g][m] * (dir == 0 ? U[c * NS + m + N * l] : U[c * NS + l + N * m]);
+              W[c] = v;
+            }
+            const double pre = kG1 * (W[EN] - 0.5 * (W[MX] * W[MX] + W[MY] * W[MY]) / W[RHO]);
+            if (pre < eps) {  // :138-178
+              const double drho = W[RHO] - A[RHO], dmx = W[MX] - A[MX], dmy = W[MY] - A[MY], dE = W[EN] - A[EN];
+              const double a1 = 2.0 * drho * dE - (dmx * dmx + dmy * dmy);
+              double b1 = 2.0 * drho * (A[EN] - eps / kG1) + 2.0 * A[RHO] * dE - 2.0 * (A[MX] * dmx + A[MY] * dmy);
+              double c1 = 2.0 * A[RHO] * A[EN] - (A[MX] * A[MX] + A[MY] * A[MY]) - 2.0 * eps * A[RHO] / kG1;
+              b1 /= a1;
+              c1 /= a1;
+              const double D = sqrt(fabs(b1 * b1 - 4.0 * c1));
+              const double t1 = 0.5 * (-b1 - D), t2 = 0.5 * (-b1 + D);
+              double t;
+              if (t1 > -1.0e-12 && t1 < 1.0 + 1.0e-12) t = t1;
+              else if (t2 > -1.0e-12 && t2 < 1.0 + 1.0e-12) t = t2;
+              else { fail = true; t = 0.0; }
+              t = fmin(1.0, t);
+              t = fmax(0.0, t);
+              if (fabs(1.0 - t) < 1.0e-14) t = 0.0;
+              theta2 = fmin(theta2, t);
+            }
+          }
+      if (fail) atomicOr(&a.flags[1], 1);
+      if (theta2 < 1.0) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+          for (int j = 0; j < NS; ++j) U[c * NS + j] = theta2 * U[c * NS + j] + (1.0 - theta2) * A[c];
+        changed = true;
+      }
+    }
+  }
+  if (changed) {
+#pragma unroll
+    for (int d = 0; d < NDOF; ++d) up[d * 64] = U[d];
+  }
+}
+
+// ------------------------------------------------------------------ small kernels
+// user (dflo) layout <-> shard SoA layout
+__global__ void scatter_kernel(const double *user, double *U, const int32_t *user_of, int n_slots, int ndof) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (long long)n_slots * ndof) return;
+  const int slot = (int)(t / ndof), d = (int)(t - (long long)slot * ndof);
+  const int uc = user_of[slot];
+  const int ns = ndof / 4;
+  // padding slots hold a harmless state (rho = 1, E = 1)
+  const double v = uc >= 0 ? user[(size_t)uc * ndof + d] : ((d / ns) >= 2 ? 1.0 : 0.0);
+  U[((size_t)(slot >> 6) * ndof + d) * 64 + (slot & 63)] = v;
+}
+__global__ void gather_kernel(double *user, const double *U, const int32_t *iid, int n_cells, int ndof) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (long long)n_cells * ndof) return;
+  const int c = (int)(t / ndof), d = (int)(t - (long long)c * ndof);
+  const int slot = iid[c];
+  user[t] = U[((size_t)(slot >> 6) * ndof + d) * 64 + (slot & 63)];
+}
+// pack listed cells (internal slots) cell-major: buf[k][ndof]
+__global__ void pack_kernel(double *buf, const double *U, const int32_t *slots, int n, int ndof) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (long long)n * ndof) return;
+  const int k = (int)(t / ndof), d = (int)(t - (long long)k * ndof);
+  const int slot = slots[k];
+  buf[t] = U[((size_t)(slot >> 6) * ndof + d) * 64 + (slot & 63)];
+}
+// ghost cells: staging buffer [g][ndof] -> ghost shards, and their cell averages
+__global__ void unpack_ghost_kernel(const double *buf, double *U, double *avg, int first_slot, int n_ghost, int ndof,
+                                    KBasis kb, int N) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= n_ghost) return;
+  const int slot = first_slot + g, ns = ndof / 4;
+  for (int c = 0; c < 4; ++c) {
+    double m = 0;
+    for (int j = 0; j < ns; ++j) {
+      const double v = buf[(size_t)g * ndof + c * ns + j];
+      U[((size_t)(slot >> 6) * ndof + c * ns + j) * 64 + (slot & 63)] = v;
+      m += kb.w[j % N] * kb.w[j / N] * v;
+    }
+    avg[((size_t)(slot >> 6) * 4 + c) * 64 + (slot & 63)] = m;
+  }
+}
+// compute_cell_average (src/claw.cc:562-597) for all slots (owned and ghost shards)
+__global__ void average_kernel(const double *U, double *avg, int ndof, KBasis kb, int N) {
+  const int shard = blockIdx.x;
+  const int lane = threadIdx.x;
+  const int ns = ndof / 4;
+  for (int c = 0; c < 4; ++c) {
+    double m = 0;
+    for (int j = 0; j < ns; ++j) m += kb.w[j % N] * kb.w[j / N] * U[((size_t)shard * ndof + c * ns + j) * 64 + lane];
+    avg[((size_t)shard * 4 + c) * 64 + lane] = m;
+  }
+}
+// compute_time_step_cartesian (src/claw.cc:486-511): per-shard minimum from the stored cell averages
+__global__ void dt_kernel(const double *avg, const double *cell_h, double h_uniform, int uniform_h,
+                          const int32_t *shard_count, double *shard_dtmin, double cfl, int degree) {
+  const int shard = blockIdx.x;
+  const int lane = threadIdx.x;
+  double dtmin = 1.0e20;
+  if (lane < shard_count[shard]) {
+    double A[4];
+    for (int c = 0; c < 4; ++c) A[c] = avg[((size_t)shard * 4 + c) * 64 + lane];
+    const double h = uniform_h ? h_uniform : cell_h[(size_t)shard * 64 + lane];
+    const double sonic = sqrt(kGamma * pressure(A) / A[RHO]);
+    const double maxeig = (sonic + fabs(A[MX] / A[RHO])) / h + (sonic + fabs(A[MY] / A[RHO])) / h;
+    dtmin = cfl / maxeig / (2.0 * degree + 1.0);
+  }
+  dtmin = wave_min(dtmin);
+  if (lane == 0) shard_dtmin[shard] = dtmin;
+}
+
+// reductions over shards + the global-dt rules of compute_time_step (src/claw.cc:468-476)
+struct FinalArgs {
+  const double *shard_res, *shard_dtmin;
+  double *res_sq;  // [3] per stage
+  double *dt_dev;  // [0] dt, [1] elapsed time, [2] raw min before rules
+  int n_shards, stage, do_res, do_dt, advance_time;
+  double time_step, final_time;
+};
+__global__ __launch_bounds__(256) void finalize_kernel(const FinalArgs a) {
+  __shared__ double sres[4], smin[4];
+  double r = 0.0, m = 1.0e20;
+  // fixed order -> deterministic sums
+  for (int s = threadIdx.x; s < a.n_shards; s += 256) {
+    if (a.do_res) r += a.shard_res[s];
+    if (a.do_dt) m = fmin(m, a.shard_dtmin[s]);
+  }
+  r = wave_sum(r);
+  m = wave_min(m);
+  if ((threadIdx.x & 63) == 0) {
+    sres[threadIdx.x >> 6] = r;
+    smin[threadIdx.x >> 6] = m;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (a.do_res) a.res_sq[a.stage] = sres[0] + sres[1] + sres[2] + sres[3];
+    if (a.do_dt) {
+      double t = a.dt_dev[1];
+      if (a.advance_time) {  // elapsed_time += global_dt (src/claw.cc:1072) for the step just done
+        t += a.dt_dev[0];
+        a.dt_dev[1] = t;
+      }
+      double dt = fmin(fmin(smin[0], smin[1]), fmin(smin[2], smin[3]));
+      a.dt_dev[2] = dt;
+      if (dt > 0 && a.time_step > 0) dt = fmin(dt, a.time_step);
+      if (t + dt > a.final_time) dt = a.final_time - t;
+      a.dt_dev[0] = dt;
+    }
+  }
+}
+// re-apply the rules after an external all-reduce(min) of dt_dev[2] (multi-device)
+__global__ void dt_rules_kernel(double *dt_dev, double time_step, double final_time) {
+  double dt = dt_dev[2], t = dt_dev[1];
+  if (dt > 0 && time_step > 0) dt = fmin(dt, time_step);
+  if (t + dt > final_time) dt = final_time - t;
+  dt_dev[0] = dt;
+}
+
+}  // namespace dflo
+
+// ====================================================================== host side
+using namespace dflo;
+
+struct dflo_hip_engine {
+  Plan plan;
+  BasisTables bt;
+  KBasis kb;
+  dflo_params_t prm;
+  int degree = 1, N = 2, ns = 4, ndof = 16, mapping = DFLO_MAP_CARTESIAN;
+  int n_rk = 2;
+  double ark[3] = {0, 0, 0};
+  int device = 0;
+  hipStream_t own_stream = nullptr, stream = nullptr;
+  // device buffers
+  double *U[3] = {nullptr, nullptr, nullptr};
+  int cur = 0, old = 0;
+  double *avg[2] = {nullptr, nullptr};
+  int avg_cur = 0;
+  double *rhs = nullptr, *user_buf = nullptr;
+  double *bval[2] = {nullptr, nullptr};
+  int32_t *bface_kind = nullptr;
+  int32_t *d_shard_count = nullptr, *d_halo_begin = nullptr, *d_halo_cells = nullptr, *d_face_begin = nullptr;
+  FaceRec *d_faces = nullptr;
+  uint16_t *d_cell_face = nullptr;
+  int32_t *d_lrbt = nullptr, *d_user_of = nullptr, *d_iid = nullptr;
+  double *d_cell_h = nullptr;
+  double *shard_res = nullptr, *shard_dtmin = nullptr, *res_sq = nullptr, *dt_dev = nullptr;
+  int *flags = nullptr;
+  std::vector<double> bface_xy;  // [n_bfaces][N][2]
+  int32_t *d_send_slots = nullptr;
+  int n_send = 0;
+  double *ghost_stage = nullptr;
+  size_t lds_bytes = 0;
+  int stride = 0, max_fp = 0;
+  // timing
+  bool timing = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+  size_t ev_used = 0;
+  double t_accum_ms = 0;
+  int64_t t_count = 0;
+  std::string err;
+};
+
+namespace {
+std::string g_create_error;
+
+#define HIPCHK(h, call)                                                                      \
+  do {                                                                                       \
+    hipError_t e_ = (call);                                                                  \
+    if (e_ != hipSuccess) {                                                                  \
+      (h)->err = std::string(#call) + ": " + hipGetErrorString(e_);                          \
+      return DFLO_ERR_HIP;                                                                   \
+    }                                                                                        \
+  } while (0)
+
+template <typename T>
+int upload(dflo_hip_engine *h, T **dst, const std::vector<T> &src) {
+  size_t bytes = std::max<size_t>(src.size(), 1) * sizeof(T);
+  HIPCHK(h, hipMalloc((void **)dst, bytes));
+  if (!src.empty()) HIPCHK(h, hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
+  return DFLO_OK;
+}
+
+KBasis make_kbasis(const BasisTables &b) {
+  KBasis k{};
+  for (int i = 0; i < kMaxN; ++i) {
+    k.w[i] = b.w[i];
+    k.x[i] = b.x[i];
+    k.L0[i] = b.L0[i];
+    k.L1[i] = b.L1[i];
+    for (int j = 0; j < kMaxN; ++j) {
+      k.D[i][j] = b.D[i][j];
+      k.DW[i][j] = b.D[i][j] * b.w[i];
+    }
+  }
+  for (int g = 0; g < kMaxGLL; ++g)
+    for (int j = 0; j < kMaxN; ++j) k.Pg[g][j] = b.Pg[g][j];
+  for (int g = 0; g < kTrap; ++g)
+    for (int j = 0; j < kMaxN; ++j) k.Pt[g][j] = b.Pt[g][j];
+  k.Ng = b.Ng;
+  return k;
+}
+
+typedef void (*stage_fn)(const StageArgs);
+template <int N>
+stage_fn pick_stage_n(int flux) {
+  switch (flux) {
+    case DFLO_FLUX_LXF: return stage_kernel<N, DFLO_FLUX_LXF>;
+    case DFLO_FLUX_SW: return stage_kernel<N, DFLO_FLUX_SW>;
+    case DFLO_FLUX_KFVS: return stage_kernel<N, DFLO_FLUX_KFVS>;
+    case DFLO_FLUX_ROE: return stage_kernel<N, DFLO_FLUX_ROE>;
+    default: return stage_kernel<N, DFLO_FLUX_HLLC>;
+  }
+}
+stage_fn pick_stage(int N, int flux) {
+  switch (N) {
+    case 2: return pick_stage_n<2>(flux);
+    case 3: return pick_stage_n<3>(flux);
+    default: return pick_stage_n<4>(flux);
+  }
+}
+
+int grid_for(int n_shards) { return ((n_shards + 7) / 8) * 8; }
+
+void time_begin(dflo_hip_engine *h) {
+  if (!h->timing) return;
+  if (h->ev_used == h->ev_pool.size()) {
+    hipEvent_t a, b;
+    hipEventCreate(&a);
+    hipEventCreate(&b);
+    h->ev_pool.push_back({a, b});
+  }
+  hipEventRecord(h->ev_pool[h->ev_used].first, h->stream);
+}
+void time_end(dflo_hip_engine *h) {
+  if (!h->timing) return;
+  hipEventRecord(h->ev_pool[h->ev_used].second, h->stream);
+  ++h->ev_used;
+}
+void time_collect(dflo_hip_engine *h) {
+  for (size_t i = 0; i < h->ev_used; ++i) {
+    float ms = 0;
+    hipEventSynchronize(h->ev_pool[i].second);
+    hipEventElapsedTime(&ms, h->ev_pool[i].first, h->ev_pool[i].second);
+    h->t_accum_ms += ms;
+    ++h->t_count;
+  }
+  h->ev_used = 0;
+}
+
+// one RK stage: residual + update kernel, reductions, limiter
+int launch_stage(dflo_hip_engine *h, int rk, double dt_host, double *rhs_out, int which_override) {
+  const Plan &p = h->plan;
+  const bool last = rk == h->n_rk - 1;
+  int out;
+  if (rhs_out) out = h->cur;
+  else if (last && h->cur != h->old) out = h->old;
+  else { out = 0; while (out == h->cur || out == h->old) ++out; }
+  StageArgs a{};
+  a.Ucur = h->U[h->cur];
+  a.Uold = h->U[h->old];
+  a.Unew = h->U[out];
+  a.avg_cur = h->avg[h->avg_cur];
+  a.avg_new = h->avg[1 - h->avg_cur];
+  a.rhs_out = rhs_out;
+  a.shard_count = h->d_shard_count;
+  a.halo_begin = h->d_halo_begin;
+  a.halo_cells = h->d_halo_cells;
+  a.face_begin = h->d_face_begin;
+  a.faces = h->d_faces;
+  a.cell_face = h->d_cell_face;
+  a.cell_h = h->d_cell_h;
+  const int which = which_override >= 0 ? which_override : (rk == 0 ? 0 : 1);
+  a.bval = h->bval[which];
+  a.bface_kind = h->bface_kind;
+  a.dt_dev = h->dt_dev;
+  a.dt_cell = nullptr;
+  a.shard_res = h->shard_res;
+  a.shard_dtmin = h->shard_dtmin;
+  a.dt_host = dt_host;
+  a.ark = h->ark[rk];
+  a.gravity = h->prm.gravity;
+  a.cfl = h->prm.cfl;
+  a.h_uniform = p.h;
+  a.n_shards = p.n_shards;
+  a.stride = h->stride;
+  a.max_fp = h->max_fp;
+  a.uniform_h = p.uniform_h ? 1 : 0;
+  const bool limited = h->prm.limiter_type != DFLO_LIMITER_NONE || h->prm.pos_lim;
+  a.want_dt = last ? 1 : 0;
+  a.degree = h->degree;
+  a.kb = h->kb;
+  stage_fn fn = pick_stage(h->N, h->prm.flux_type);
+  time_begin(h);
+  hipLaunchKernelGGL(fn, dim3(grid_for(p.n_shards)), dim3(64), h->lds_bytes, h->stream, a);
+  time_end(h);
+  HIPCHK(h, hipGetLastError());
+  if (rhs_out) return DFLO_OK;
+  h->cur = out;
+  h->avg_cur = 1 - h->avg_cur;
+  if (last) h->old = out;
+  if (limited) {
+    LimArgs l{};
+    l.U = h->U[h->cur];
+    l.avg = h->avg[h->avg_cur];
+    l.shard_count = h->d_shard_count;
+    l.lrbt = h->d_lrbt;
+    l.cell_h = h->d_cell_h;
+    l.flags = h->flags;
+    l.h_uniform = p.h;
+    l.M = h->prm.M;
+    l.beta = h->prm.beta;
+    l.n_shards = p.n_shards;
+    l.uniform_h = p.uniform_h ? 1 : 0;
+    l.tvb = h->prm.limiter_type == DFLO_LIMITER_TVB;
+    l.char_lim = h->prm.char_lim;
+    l.pos_lim = h->prm.pos_lim;
+    l.kb = h->kb;
+    void (*lf)(const LimArgs) = h->N == 2 ? limiter_kernel<2> : (h->N == 3 ? limiter_kernel<3> : limiter_kernel<4>);
+    hipLaunchKernelGGL(lf, dim3(grid_for(p.n_shards)), dim3(64), 0, h->stream, l);
+    HIPCHK(h, hipGetLastError());
+  }
+  FinalArgs f{};
+  f.shard_res = h->shard_res;
+  f.shard_dtmin = h->shard_dtmin;
+  f.res_sq = h->res_sq;
+  f.dt_dev = h->dt_dev;
+  f.n_shards = p.n_shards;
+  f.stage = rk;
+  f.do_res = 1;
+  f.do_dt = last ? 1 : 0;
+  f.advance_time = last ? 1 : 0;
+  f.time_step = h->prm.time_step;
+  f.final_time = h->prm.final_time;
+  hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, h->stream, f);
+  HIPCHK(h, hipGetLastError());
+  return DFLO_OK;
+}
+
+int launch_average(dflo_hip_engine *h) {
+  const Plan &p = h->plan;
+  const int all = p.n_shards + p.n_ghost_shards;
+  hipLaunchKernelGGL(average_kernel, dim3(all), dim3(64), 0, h->stream, h->U[h->cur], h->avg[h->avg_cur], h->ndof, h->kb,
+                     h->N);
+  HIPCHK(h, hipGetLastError());
+  return DFLO_OK;
+}
+
+int check_handle(dflo_hip_handle h) { return h ? DFLO_OK : DFLO_ERR_BAD_PARAM; }
+
+}  // namespace
+
+extern "C" {
+
+const char *dflo_hip_last_error(dflo_hip_handle h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int dflo_hip_create(const dflo_mesh_t *mesh, const dflo_params_t *params, int device_id, dflo_hip_handle *out) {
+  if (!mesh || !params || !out) { g_create_error = "null argument"; return DFLO_ERR_BAD_PARAM; }
+  *out = nullptr;
+  // consistency checks of the reference's parameter parsing (src/parameters.cc:536-550)
+  if (mesh->degree < 1 || mesh->degree > DFLO_MAX_DEGREE) { g_create_error = "degree must be 1..3"; return DFLO_ERR_BAD_PARAM; }
+  if (mesh->basis != DFLO_BASIS_QK) { g_create_error = "Pk basis is not implemented in the device engine yet"; return DFLO_ERR_UNSUPPORTED; }
+  if (mesh->mapping != DFLO_MAP_CARTESIAN) { g_create_error = "q1/q2 mapping is not implemented in the device engine yet"; return DFLO_ERR_UNSUPPORTED; }
+  if (params->limiter_type == DFLO_LIMITER_TVB && mesh->mapping != DFLO_MAP_CARTESIAN) {
+    g_create_error = "TVB limiter is implemented only for cartesian mapping";  // src/parameters.cc:543-544
+    return DFLO_ERR_BAD_PARAM;
+  }
+  if (params->flux_type < 0 || params->flux_type > DFLO_FLUX_HLLC) { g_create_error = "unknown flux"; return DFLO_ERR_BAD_PARAM; }
+  if (!params->global_time_step) { g_create_error = "local time stepping is not implemented in the device engine yet"; return DFLO_ERR_UNSUPPORTED; }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) {
+    g_create_error = "no HIP device available: the dflo HIP engine has no CPU fallback";
+    return DFLO_ERR_HIP;
+  }
+  if (device_id < 0 || device_id >= ndev) { g_create_error = "bad device id"; return DFLO_ERR_BAD_PARAM; }
+  dflo_hip_engine *h = new dflo_hip_engine;
+  h->device = device_id;
+  h->prm = *params;
+  h->degree = mesh->degree;
+  h->N = mesh->degree + 1;
+  h->ns = h->N * h->N;
+  h->ndof = 4 * h->ns;
+  h->mapping = mesh->mapping;
+  int rc = build_plan(*mesh, 8, 8, h->plan, h->err);
+  if (rc) { g_create_error = h->err; delete h; return rc; }
+  h->bt = make_basis(h->degree);
+  h->kb = make_kbasis(h->bt);
+  // quadrature points of the boundary faces (fe_v.get_quadrature_points(), src/assemble_explicit.cc:164)
+  h->bface_xy.resize(h->plan.bface_cell.size() * h->N * 2);
+  for (size_t b = 0; b < h->plan.bface_cell.size(); ++b) {
+    const double *v = &mesh->cell_vertices[(size_t)h->plan.bface_cell[b] * 8];
+    const int f = h->plan.bface_face[b];
+    for (int q = 0; q < h->N; ++q) {
+      const double s = h->bt.x[q];
+      const double xi = f == 0 ? 0.0 : (f == 1 ? 1.0 : s), eta = f == 2 ? 0.0 : (f == 3 ? 1.0 : s);
+      for (int d = 0; d < 2; ++d)
+        h->bface_xy[(b * h->N + q) * 2 + d] = (1 - xi) * (1 - eta) * v[d] + xi * (1 - eta) * v[2 + d] +
+                                               (1 - xi) * eta * v[4 + d] + xi * eta * v[6 + d];
+    }
+  }
+  // SSP-RK coefficients by degree (src/claw.cc:141-159)
+  h->n_rk = h->degree == 1 ? 2 : 3;
+  if (params->n_rk > 0) h->n_rk = std::min(params->n_rk, 3);
+  if (h->n_rk == 2) { h->ark[0] = 0.0; h->ark[1] = 0.5; }
+  if (h->n_rk == 3) { h->ark[0] = 0.0; h->ark[1] = 0.75; h->ark[2] = 1.0 / 3.0; }
+  auto bail = [&](int code) { g_create_error = h->err; dflo_hip_destroy(h); return code; };
+  if (hipSetDevice(device_id) != hipSuccess) { h->err = "hipSetDevice failed"; return bail(DFLO_ERR_HIP); }
+  if (hipStreamCreate(&h->own_stream) != hipSuccess) { h->err = "hipStreamCreate failed"; return bail(DFLO_ERR_HIP); }
+  h->stream = h->own_stream;
+  const Plan &p = h->plan;
+  const size_t nU = (size_t)p.n_slots * h->ndof;
+  for (int i = 0; i < 3; ++i)
+    if (hipMalloc((void **)&h->U[i], nU * sizeof(double)) != hipSuccess) { h->err = "hipMalloc(U) failed"; return bail(DFLO_ERR_NOMEM); }
+  for (int i = 0; i < 2; ++i)
+    if (hipMalloc((void **)&h->avg[i], (size_t)p.n_slots * 4 * sizeof(double)) != hipSuccess) { h->err = "hipMalloc(avg) failed"; return bail(DFLO_ERR_NOMEM); }
+  if (hipMalloc((void **)&h->rhs, nU * sizeof(double)) != hipSuccess) { h->err = "hipMalloc(rhs) failed"; return bail(DFLO_ERR_NOMEM); }
+  if (hipMalloc((void **)&h->user_buf, nU * sizeof(double)) != hipSuccess) { h->err = "hipMalloc(user_buf) failed"; return bail(DFLO_ERR_NOMEM); }
+  for (int i = 0; i < 3; ++i) hipMemset(h->U[i], 0, nU * sizeof(double));
+  std::vector<int32_t> kinds(p.bface_id.size());
+  for (size_t b = 0; b < kinds.size(); ++b) kinds[b] = params->bc_kind[p.bface_id[b]];
+  const size_t nb = std::max<size_t>(p.bface_cell.size(), 1) * h->N * 4;
+  for (int w = 0; w < 2; ++w) {
+    if (hipMalloc((void **)&h->bval[w], nb * sizeof(double)) != hipSuccess) { h->err = "hipMalloc(bval) failed"; return bail(DFLO_ERR_NOMEM); }
+    hipMemset(h->bval[w], 0, nb * sizeof(double));
+  }
+  if ((rc = upload(h, &h->bface_kind, kinds))) return bail(rc);
+  if ((rc = upload(h, &h->d_shard_count, p.shard_count))) return bail(rc);
+  if ((rc = upload(h, &h->d_halo_begin, p.halo_begin))) return bail(rc);
+  if ((rc = upload(h, &h->d_halo_cells, p.halo_cells))) return bail(rc);
+  if ((rc = upload(h, &h->d_face_begin, p.face_begin))) return bail(rc);
+  if ((rc = upload(h, &h->d_faces, p.faces))) return bail(rc);
+  if ((rc = upload(h, &h->d_cell_face, p.cell_face))) return bail(rc);
+  if ((rc = upload(h, &h->d_lrbt, p.lrbt))) return bail(rc);
+  if ((rc = upload(h, &h->d_user_of, p.user_of))) return bail(rc);
+  if ((rc = upload(h, &h->d_iid, p.iid))) return bail(rc);
+  if ((rc = upload(h, &h->d_cell_h, p.cell_h))) return bail(rc);
+  const size_t nsh = std::max(p.n_shards, 1);
+  if (hipMalloc((void **)&h->shard_res, nsh * sizeof(double)) != hipSuccess ||
+      hipMalloc((void **)&h->shard_dtmin, nsh * sizeof(double)) != hipSuccess ||
+      hipMalloc((void **)&h->res_sq, 4 * sizeof(double)) != hipSuccess ||
+      hipMalloc((void **)&h->dt_dev, 4 * sizeof(double)) != hipSuccess || hipMalloc((void **)&h->flags, 4 * sizeof(int)) != hipSuccess) {
+    h->err = "hipMalloc(scalars) failed";
+    return bail(DFLO_ERR_NOMEM);
+  }
+  hipMemset(h->res_sq, 0, 4 * sizeof(double));
+  hipMemset(h->dt_dev, 0, 4 * sizeof(double));
+  hipMemset(h->flags, 0, 4 * sizeof(int));
+  const int n_ghost = p.n_cells - p.n_owned;
+  if (n_ghost > 0 && hipMalloc((void **)&h->ghost_stage, (size_t)n_ghost * h->ndof * sizeof(double)) != hipSuccess) {
+    h->err = "hipMalloc(ghost) failed";
+    return bail(DFLO_ERR_NOMEM);
+  }
+  h->stride = 64 + p.max_halo;
+  h->max_fp = std::max(p.max_faces, 1) * h->N;
+  h->lds_bytes = ((size_t)h->ndof * h->stride + 4 * h->stride + 4 * (size_t)h->max_fp) * sizeof(double);
+  if (h->lds_bytes > 160 * 1024) { h->err = "shard halo too large for LDS"; return bail(DFLO_ERR_UNSUPPORTED); }
+  if (h->lds_bytes > 64 * 1024) {
+    stage_fn fn = pick_stage(h->N, h->prm.flux_type);
+    if (hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes) != hipSuccess) {
+      h->err = "cannot raise dynamic LDS limit";
+      return bail(DFLO_ERR_HIP);
+    }
+  }
+  *out = h;
+  return DFLO_OK;
+}
+
+int dflo_hip_destroy(dflo_hip_handle h) {
+  if (!h) return DFLO_OK;
+  hipSetDevice(h->device);
+  if (h->own_stream) hipStreamSynchronize(h->own_stream);
+  for (int i = 0; i < 3; ++i) hipFree(h->U[i]);
+  for (int i = 0; i < 2; ++i) { hipFree(h->avg[i]); hipFree(h->bval[i]); }
+  hipFree(h->rhs); hipFree(h->user_buf); hipFree(h->bface_kind);
+  hipFree(h->d_shard_count); hipFree(h->d_halo_begin); hipFree(h->d_halo_cells); hipFree(h->d_face_begin);
+  hipFree(h->d_faces); hipFree(h->d_cell_face); hipFree(h->d_lrbt); hipFree(h->d_user_of); hipFree(h->d_iid);
+  hipFree(h->d_cell_h); hipFree(h->shard_res); hipFree(h->shard_dtmin); hipFree(h->res_sq); hipFree(h->dt_dev);
+  hipFree(h->flags); hipFree(h->d_send_slots); hipFree(h->ghost_stage);
+  for (auto &e : h->ev_pool) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
+  if (h->own_stream) hipStreamDestroy(h->own_stream);
+  delete h;
+  return DFLO_OK;
+}
+
+int dflo_hip_set_stream(dflo_hip_handle h, void *s) {
+  if (check_handle(h)) return DFLO_ERR_BAD_PARAM;
+  h->stream = s ? (hipStream_t)s : h->own_stream;
+  return DFLO_OK;
+}
+
+int64_t dflo_hip_n_dofs(dflo_hip_handle h) { return h ? (int64_t)h->plan.n_cells * h->ndof : 0; }
+int32_t dflo_hip_dofs_per_cell(dflo_hip_handle h) { return h ? h->ndof : 0; }
+int32_t dflo_hip_n_rk(dflo_hip_handle h) { return h ? h->n_rk : 0; }
+int32_t dflo_hip_n_boundary_faces(dflo_hip_handle h) { return h ? (int32_t)h->plan.bface_cell.size() : 0; }
+
+int dflo_hip_set_solution(dflo_hip_handle h, const double *u) {
+  if (check_handle(h) || !u) return DFLO_ERR_BAD_PARAM;
+  hipSetDevice(h->device);
+  const Plan &p = h->plan;
+  const size_t n = (size_t)p.n_cells * h->ndof;
+  HIPCHK(h, hipMemcpyAsync(h->user_buf, u, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  const long long tot = (long long)p.n_slots * h->ndof;
+  h->cur = h->old = 0;
+  hipLaunchKernelGGL(scatter_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, h->user_buf, h->U[0],
+                     h->d_user_of, p.n_slots, h->ndof);
+  HIPCHK(h, hipGetLastError());
+  int rc = launch_average(h);
+  if (rc) return rc;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return DFLO_OK;
+}
+
+int dflo_hip_get_solution(dflo_hip_handle h, double *u) {
+  if (check_handle(h) || !u) return DFLO_ERR_BAD_PARAM;
+  hipSetDevice(h->device);
+  const Plan &p = h->plan;
+  const long long tot = (long long)p.n_cells * h->ndof;
+  hipLaunchKernelGGL(gather_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, h->user_buf,
+                     h->U[h->cur], h->d_iid, p.n_cells, h->ndof);
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipMemcpyAsync(u, h->user_buf, tot * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return DFLO_OK;
+}
+
+int dflo_hip_get_cell_average(dflo_hip_handle h, double *avg) {
+  if (check_handle(h) || !avg) return DFLO_ERR_BAD_PARAM;
+  hipSetDevice(h->device);
+  const Plan &p = h->plan;
+  std::vector<double> tmp((size_t)p.n_slots * 4);
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  HIPCHK(h, hipMemcpy(tmp.data(), h->avg[h->avg_cur], tmp.size() * sizeof(double), hipMemcpyDeviceToHost));
+  for (int c = 0; c < p.n_cells; ++c) {
+    const int s = p.iid[c];
+    for (int k = 0; k < 4; ++k) avg[(size_t)c * 4 + k] = tmp[((size_t)(s >> 6) * 4 + k) * 64 + (s & 63)];
+  }
+  return DFLO_OK;
+}
+
+int dflo_hip_boundary_faces(dflo_hip_handle h, int32_t *cell, int32_t *face, int32_t *boundary_id, double *xy) {
+  if (check_handle(h)) return DFLO_ERR_BAD_PARAM;
+  const Plan &p = h->plan;
+  for (size_t b = 0; b < p.bface_cell.size(); ++b) {
+    if (cell) cell[b] = p.bface_cell[b];
+    if (face) face[b] = p.bface_face[b];
+    if (boundary_id) boundary_id[b] = p.bface_id[b];
+  }
+  if (xy) std::memcpy(xy, h->bface_xy.data(), h->bface_xy.size() * sizeof(double));
+  return DFLO_OK;
+}
+
+int dflo_hip_set_boundary_values(dflo_hip_handle h, int which, const double *values) {
+  if (check_handle(h) || which < 0 || which > 1 || !values) return DFLO_ERR_BAD_PARAM;
+  hipSetDevice(h->device);
+  const size_t n = h->plan.bface_cell.size() * h->N * 4;
+  if (n == 0) return DFLO_OK;
+  HIPCHK(h, hipMemcpyAsync(h->bval[which], values, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return DFLO_OK;
+}
+
+int dflo_hip_residual(dflo_hip_handle h, int which, double *rhs_out) {
+  if (check_handle(h) || !rhs_out) return DFLO_ERR_BAD_PARAM;
+  hipSetDevice(h->device);
+  int rc = launch_stage(h, 0, 0.0, h->rhs, which);
+  if (rc) return rc;
+  const Plan &p = h->plan;
+  const long long tot = (long long)p.n_cells * h->ndof;
+  hipLaunchKernelGGL(gather_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, h->user_buf, h->rhs,
+                     h->d_iid, p.n_cells, h->ndof);
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipMemcpyAsync(rhs_out, h->user_buf, tot * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return DFLO_OK;
+}
+
+int dflo_hip_compute_cell_average(dflo_hip_handle h) {
+  if (check_handle(h)) return DFLO_ERR_BAD_PARAM;
+  hipSetDevice(h->device);
+  return launch_average(h);
+}
+
+int dflo_hip_compute_dt(dflo_hip_handle h, double elapsed_time, double *dt) {
+  if (check_handle(h) || !dt) return DFLO_ERR_BAD_PARAM;
+  hipSetDevice(h->device);
+  if (h->prm.global_time_step && h->prm.cfl <= 0.0) {  // src/claw.cc:456-460
+    *dt = h->prm.time_step;
+    return DFLO_OK;
+  }
+  // per-shard minima from the stored cell averages (src/claw.cc:486-511)
+  const Plan &p = h->plan;
+  hipLaunchKernelGGL(dt_kernel, dim3(p.n_shards), dim3(64), 0, h->stream, h->avg[h->avg_cur], h->d_cell_h, p.h,
+                     p.uniform_h ? 1 : 0, h->d_shard_count, h->shard_dtmin, h->prm.cfl, h->degree);
+  HIPCHK(h, hipGetLastError());
+  double tt[4] = {0, elapsed_time, 0, 0};
+  HIPCHK(h, hipMemcpyAsync(h->dt_dev, tt, sizeof(tt), hipMemcpyHostToDevice, h->stream));
+  FinalArgs f{};
+  f.shard_res = h->shard_res;
+  f.shard_dtmin = h->shard_dtmin;
+  f.res_sq = h->res_sq;
+  f.dt_dev = h->dt_dev;
+  f.n_shards = p.n_shards;
+  f.stage = 3;
+  f.do_res = 0;
+  f.do_dt = 1;
+  f.advance_time = 0;
+  f.time_step = h->prm.time_step;
+  f.final_time = h->prm.final_time;
+  hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, h->stream, f);
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipMemcpyAsync(tt, h->dt_dev, sizeof(tt), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  *dt = tt[0];
+  return DFLO_OK;
+}
+
+int dflo_hip_stage(dflo_hip_handle h, int rk, double dt) {
+  if (check_handle(h) || rk < 0 || rk >= h->n_rk) return DFLO_ERR_BAD_PARAM;
+  hipSetDevice(h->device);
+  return launch_stage(h, rk, dt, nullptr, -1);
+}
+
+int dflo_hip_end_step(dflo_hip_handle h) {
+  if (check_handle(h)) return DFLO_ERR_BAD_PARAM;
+  h->old = h->cur;  // old_solution = current_solution (src/claw.cc:1110): a pointer swap here
+  return DFLO_OK;
+}
+
+int dflo_hip_step(dflo_hip_handle h, double dt, double *res_norm0, double *res_norm) {
+  if (check_handle(h)) return DFLO_ERR_BAD_PARAM;
+  hipSetDevice(h->device);
+  for (int rk = 0; rk < h->n_rk; ++rk) {
+    int rc = launch_stage(h, rk, dt, nullptr, -1);
+    if (rc) return rc;
+  }
+  h->old = h->cur;
+  if (res_norm0 || res_norm) {
+    double r[4];
+    HIPCHK(h, hipMemcpyAsync(r, h->res_sq, sizeof(r), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (res_norm0) *res_norm0 = std::sqrt(r[0]);
+    if (res_norm) *res_norm = std::sqrt(r[h->n_rk - 1]);
+  }
+  return dflo_hip_check(h);
+}
+
+int dflo_hip_advance(dflo_hip_handle h, int n_steps, double *elapsed_time_inout) {
+  if (check_handle(h) || n_steps < 0 || !elapsed_time_inout) return DFLO_ERR_BAD_PARAM;
+  hipSetDevice(h->device);
+  // first dt from the current cell averages, then dt and time stay on the device
+  double dt0;
+  int rc = dflo_hip_compute_dt(h, *elapsed_time_inout, &dt0);
+  if (rc) return rc;
+  if (h->prm.global_time_step && h->prm.cfl <= 0.0) {
+    double tt[4] = {dt0, *elapsed_time_inout, dt0, 0};
+    HIPCHK(h, hipMemcpyAsync(h->dt_dev, tt, sizeof(tt), hipMemcpyHostToDevice, h->stream));
+  }
+  for (int s = 0; s < n_steps; ++s) {
+    for (int rk = 0; rk < h->n_rk; ++rk) {
+      rc = launch_stage(h, rk, -1.0, nullptr, -1);
+      if (rc) return rc;
+    }
+    h->old = h->cur;
+  }
+  double tt[4];
+  HIPCHK(h, hipMemcpyAsync(tt, h->dt_dev, sizeof(tt), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (h->timing) time_collect(h);
+  *elapsed_time_inout = tt[1];
+  return dflo_hip_check(h);
+}
+
+int dflo_hip_apply_limiter(dflo_hip_handle h) {
+  if (check_handle(h)) return DFLO_ERR_BAD_PARAM;
+  hipSetDevice(h->device);
+  if (h->prm.limiter_type == DFLO_LIMITER_NONE) return DFLO_OK;
+  const Plan &p = h->plan;
+  LimArgs l{};
+  l.U = h->U[h->cur];
+  l.avg = h->avg[h->avg_cur];
+  l.shard_count = h->d_shard_count;
+  l.lrbt = h->d_lrbt;
+  l.cell_h = h->d_cell_h;
+  l.flags = h->flags;
+  l.h_uniform = p.h;
+  l.M = h->prm.M;
+  l.beta = h->prm.beta;
+  l.n_shards = p.n_shards;
+  l.uniform_h = p.uniform_h ? 1 : 0;
+  l.tvb = 1;
+  l.char_lim = h->prm.char_lim;
+  l.pos_lim = 0;
+  l.kb = h->kb;
+  void (*lf)(const LimArgs) = h->N == 2 ? limiter_kernel<2> : (h->N == 3 ? limiter_kernel<3> : limiter_kernel<4>);
+  hipLaunchKernelGGL(lf, dim3(grid_for(p.n_shards)), dim3(64), 0, h->stream, l);
+  HIPCHK(h, hipGetLastError());
+  return DFLO_OK;
+}
+
+int dflo_hip_apply_positivity_limiter(dflo_hip_handle h) {
+  if (check_handle(h)) return DFLO_ERR_BAD_PARAM;
+  hipSetDevice(h->device);
+  const Plan &p = h->plan;
+  LimArgs l{};
+  l.U = h->U[h->cur];
+  l.avg = h->avg[h->avg_cur];
+  l.shard_count = h->d_shard_count;
+  l.lrbt = h->d_lrbt;
+  l.cell_h = h->d_cell_h;
+  l.flags = h->flags;
+  l.h_uniform = p.h;
+  l.M = h->prm.M;
+  l.beta = h->prm.beta;
+  l.n_shards = p.n_shards;
+  l.uniform_h = p.uniform_h ? 1 : 0;
+  l.tvb = 0;
+  l.char_lim = h->prm.char_lim;
+  l.pos_lim = 1;
+  l.kb = h->kb;
+  void (*lf)(const LimArgs) = h->N == 2 ? limiter_kernel<2> : (h->N == 3 ? limiter_kernel<3> : limiter_kernel<4>);
+  hipLaunchKernelGGL(lf, dim3(grid_for(p.n_shards)), dim3(64), 0, h->stream, l);
+  HIPCHK(h, hipGetLastError());
+  return dflo_hip_check(h);
+}
+
+int dflo_hip_check(dflo_hip_handle h) {
+  if (check_handle(h)) return DFLO_ERR_BAD_PARAM;
+  hipSetDevice(h->device);
+  int f[4];
+  HIPCHK(h, hipMemcpyAsync(f, h->flags, sizeof(f), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (f[0]) { h->err = "Fatal: Negative states"; return DFLO_ERR_NEGATIVE_MEAN_STATE; }
+  if (f[1]) { h->err = "Problem in positivity limiter"; return DFLO_ERR_POSITIVITY_NO_ROOT; }
+  return DFLO_OK;
+}
+
+int dflo_hip_synchronize(dflo_hip_handle h) {
+  if (check_handle(h)) return DFLO_ERR_BAD_PARAM;
+  hipSetDevice(h->device);
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return DFLO_OK;
+}
+
+int dflo_hip_stage_timing(dflo_hip_handle h, int enable, double *avg_ms, int64_t *n) {
+  if (check_handle(h)) return DFLO_ERR_BAD_PARAM;
+  hipSetDevice(h->device);
+  hipStreamSynchronize(h->stream);
+  time_collect(h);
+  if (avg_ms) *avg_ms = h->t_count ? h->t_accum_ms / (double)h->t_count : 0.0;
+  if (n) *n = h->t_count;
+  h->t_accum_ms = 0;
+  h->t_count = 0;
+  h->timing = enable != 0;
+  return DFLO_OK;
+}
+
+// ---------------------------------------------------------------- halo seam
+int dflo_hip_set_send_cells(dflo_hip_handle h, int32_t n, const int32_t *cells) {
+  if (check_handle(h) || n < 0 || (n > 0 && !cells)) return DFLO_ERR_BAD_PARAM;
+  hipSetDevice(h->device);
+  std::vector<int32_t> slots(n);
+  for (int i = 0; i < n; ++i) {
+    if (cells[i] < 0 || cells[i] >= h->plan.n_owned) { h->err = "send cell is not an owned cell"; return DFLO_ERR_COMM; }
+    slots[i] = h->plan.iid[cells[i]];
+  }
+  hipFree(h->d_send_slots);
+  h->d_send_slots = nullptr;
+  h->n_send = n;
+  return upload(h, &h->d_send_slots, slots);
+}
+
+int dflo_hip_pack_send(dflo_hip_handle h, void *device_buffer) {
+  if (check_handle(h) || !device_buffer) return DFLO_ERR_BAD_PARAM;
+  hipSetDevice(h->device);
+  if (h->n_send == 0) return DFLO_OK;
+  const long long tot = (long long)h->n_send * h->ndof;
+  hipLaunchKernelGGL(pack_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, (double *)device_buffer,
+                     h->U[h->cur], h->d_send_slots, h->n_send, h->ndof);
+  HIPCHK(h, hipGetLastError());
+  return DFLO_OK;
+}
+
+int dflo_hip_ghost_ptr(dflo_hip_handle h, void **device_ptr, int64_t *n_doubles) {
+  if (check_handle(h) || !device_ptr) return DFLO_ERR_BAD_PARAM;
+  *device_ptr = h->ghost_stage;
+  if (n_doubles) *n_doubles = (int64_t)(h->plan.n_cells - h->plan.n_owned) * h->ndof;
+  return DFLO_OK;
+}
+
+int dflo_hip_ghost_updated(dflo_hip_handle h) {
+  if (check_handle(h)) return DFLO_ERR_BAD_PARAM;
+  hipSetDevice(h->device);
+  const Plan &p = h->plan;
+  const int n_ghost = p.n_cells - p.n_owned;
+  if (n_ghost == 0) return DFLO_OK;
+  hipLaunchKernelGGL(unpack_ghost_kernel, dim3((n_ghost + 63) / 64), dim3(64), 0, h->stream, h->ghost_stage, h->U[h->cur],
+                     h->avg[h->avg_cur], p.n_shards * 64, n_ghost, h->ndof, h->kb, h->N);
+  HIPCHK(h, hipGetLastError());
+  return DFLO_OK;
+}
+
+int dflo_hip_scalar_ptrs(dflo_hip_handle h, void **dt_ptr, void **res_ptr) {
+  if (check_handle(h)) return DFLO_ERR_BAD_PARAM;
+  if (dt_ptr) *dt_ptr = h->dt_dev;
+  if (res_ptr) *res_ptr = h->res_sq;
+  return DFLO_OK;
+}
+
+int dflo_hip_apply_dt_rules(dflo_hip_handle h) {
+  if (check_handle(h)) return DFLO_ERR_BAD_PARAM;
+  hipSetDevice(h->device);
+  hipLaunchKernelGGL(dt_rules_kernel, dim3(1), dim3(1), 0, h->stream, h->dt_dev, h->prm.time_step, h->prm.final_time);
+  HIPCHK(h, hipGetLastError());
+  return DFLO_OK;
+}
+
+}  // extern "C"

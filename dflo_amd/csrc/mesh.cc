@@ -1,0 +1,364 @@
+// mesh.cc -- host-side construction of the flat mesh description (dflo_mesh_t).
+//
+// dflo gets its mesh from deal.II (GridIn::read_msh -> Triangulation -> DoFHandler,
+// src/claw.cc:957-967, 271-298).  The engine needs the same information as flat arrays:
+// cell vertices in deal.II's lexicographic order, face neighbours, boundary ids.  These
+// builders produce it without deal.II: a structured generator for the Cartesian example
+// meshes (what "gmsh -2" writes for the transfinite .geo files of the examples), a
+// general quad-soup importer, a Gmsh v2 reader and the owned+ghost partition that replaces
+// parallel::distributed::Triangulation (src_mpi/claw.h:220).
+#include "../../include/dflo_hip.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <sstream>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_mesh_error;
+
+struct MeshOwner {
+  dflo_mesh_t m;  // must stay the first member
+  std::vector<double> vert;
+  std::vector<int32_t> nbr, nbrf;
+  std::vector<int64_t> gid;
+  std::vector<int32_t> send_cells, send_off, recv_off;
+  void bind() {
+    m.cell_vertices = vert.data();
+    m.cell_face_neighbor = nbr.data();
+    m.cell_face_neighbor_face = nbrf.data();
+    m.cell_global_id = gid.empty() ? nullptr : gid.data();
+  }
+};
+
+int fail(int code, const std::string &msg) {
+  g_mesh_error = msg;
+  return code;
+}
+
+// local vertex pairs of the four faces, in the direction of increasing free coordinate
+const int kFaceVerts[4][2] = {{0, 2}, {1, 3}, {0, 1}, {2, 3}};
+
+}  // namespace
+
+extern "C" {
+
+const char *dflo_mesh_last_error(void) { return g_mesh_error.c_str(); }
+
+void dflo_mesh_free(dflo_mesh_t *mesh) {
+  if (mesh) delete reinterpret_cast<MeshOwner *>(mesh);
+}
+
+int dflo_mesh_cartesian(int32_t nx, int32_t ny, double x0, double y0, double h, const int32_t side_bc[4],
+                        int32_t degree, dflo_mesh_t **out) {
+  if (!out || nx < 1 || ny < 1 || !(h > 0) || !side_bc) return fail(DFLO_ERR_BAD_PARAM, "dflo_mesh_cartesian: bad arguments");
+  if (degree < 1 || degree > DFLO_MAX_DEGREE) return fail(DFLO_ERR_BAD_PARAM, "degree out of range");
+  if ((side_bc[0] < 0) != (side_bc[1] < 0) || (side_bc[2] < 0) != (side_bc[3] < 0))
+    return fail(DFLO_ERR_BAD_PARAM, "periodic sides must come in opposite pairs");
+  for (int s = 0; s < 4; ++s)
+    if (side_bc[s] >= DFLO_MAX_BOUNDARIES) return fail(DFLO_ERR_BAD_PARAM, "boundary id >= max_n_boundaries");
+  const int64_t n = (int64_t)nx * ny;
+  if (n > 2000000000LL) return fail(DFLO_ERR_BAD_PARAM, "too many cells");
+  MeshOwner *o = new MeshOwner;
+  o->vert.resize((size_t)n * 8);
+  o->nbr.resize((size_t)n * 4);
+  o->nbrf.resize((size_t)n * 4);
+  for (int j = 0; j < ny; ++j)
+    for (int i = 0; i < nx; ++i) {
+      const size_t c = (size_t)i + (size_t)nx * j;
+      const double xa = x0 + i * h, xb = x0 + (i + 1) * h, ya = y0 + j * h, yb = y0 + (j + 1) * h;
+      double *v = &o->vert[c * 8];
+      v[0] = xa; v[1] = ya; v[2] = xb; v[3] = ya; v[4] = xa; v[5] = yb; v[6] = xb; v[7] = yb;
+      int32_t *nb = &o->nbr[c * 4], *nf = &o->nbrf[c * 4];
+      // face 0: x = xa
+      if (i > 0) { nb[0] = (int32_t)(c - 1); nf[0] = 1; }
+      else if (side_bc[0] < 0) { nb[0] = (int32_t)(c + nx - 1); nf[0] = 1 | 8; }
+      else { nb[0] = DFLO_NBR_BOUNDARY(side_bc[0]); nf[0] = 0; }
+      if (i < nx - 1) { nb[1] = (int32_t)(c + 1); nf[1] = 0; }
+      else if (side_bc[1] < 0) { nb[1] = (int32_t)(c - (nx - 1)); nf[1] = 0 | 8; }
+      else { nb[1] = DFLO_NBR_BOUNDARY(side_bc[1]); nf[1] = 0; }
+      if (j > 0) { nb[2] = (int32_t)(c - nx); nf[2] = 3; }
+      else if (side_bc[2] < 0) { nb[2] = (int32_t)(c + (size_t)nx * (ny - 1)); nf[2] = 3 | 8; }
+      else { nb[2] = DFLO_NBR_BOUNDARY(side_bc[2]); nf[2] = 0; }
+      if (j < ny - 1) { nb[3] = (int32_t)(c + nx); nf[3] = 2; }
+      else if (side_bc[3] < 0) { nb[3] = (int32_t)(c - (size_t)nx * (ny - 1)); nf[3] = 2 | 8; }
+      else { nb[3] = DFLO_NBR_BOUNDARY(side_bc[3]); nf[3] = 0; }
+    }
+  o->m.n_cells = (int32_t)n;
+  o->m.n_owned_cells = (int32_t)n;
+  o->m.degree = degree;
+  o->m.basis = DFLO_BASIS_QK;
+  o->m.mapping = DFLO_MAP_CARTESIAN;
+  o->bind();
+  *out = &o->m;
+  return DFLO_OK;
+}
+
+int dflo_mesh_from_quads(int32_t n_vertices, const double *vertices, int32_t n_quads, const int32_t *quads,
+                         int32_t n_bedges, const int32_t *bedges, const int32_t *bedge_id, int32_t degree,
+                         dflo_mesh_t **out) {
+  if (!out || !vertices || !quads || n_quads < 1) return fail(DFLO_ERR_BAD_PARAM, "dflo_mesh_from_quads: bad arguments");
+  if (degree < 1 || degree > DFLO_MAX_DEGREE) return fail(DFLO_ERR_BAD_PARAM, "degree out of range");
+  MeshOwner *o = new MeshOwner;
+  o->vert.resize((size_t)n_quads * 8);
+  o->nbr.assign((size_t)n_quads * 4, DFLO_NBR_NONE);
+  o->nbrf.assign((size_t)n_quads * 4, 0);
+  std::vector<int32_t> lex((size_t)n_quads * 4);  // vertex ids in deal.II order
+  for (int c = 0; c < n_quads; ++c) {
+    int32_t q[4];
+    for (int k = 0; k < 4; ++k) {
+      q[k] = quads[c * 4 + k];
+      if (q[k] < 0 || q[k] >= n_vertices) {
+        delete o;
+        return fail(DFLO_ERR_BAD_PARAM, "quad vertex index out of range");
+      }
+    }
+    // make the loop counter-clockwise
+    double area2 = 0;
+    for (int k = 0; k < 4; ++k) {
+      const double *a = &vertices[q[k] * 2], *b = &vertices[q[(k + 1) % 4] * 2];
+      area2 += a[0] * b[1] - b[0] * a[1];
+    }
+    if (area2 < 0) std::swap(q[1], q[3]);
+    // start the loop at the lower-left-most vertex so axis-aligned cells get xi along +x
+    int s = 0;
+    for (int k = 1; k < 4; ++k) {
+      const double *a = &vertices[q[k] * 2], *b = &vertices[q[s] * 2];
+      if (a[0] + a[1] < b[0] + b[1] - 1e-14 * (std::fabs(b[0]) + std::fabs(b[1]) + 1)) s = k;
+    }
+    int32_t r[4] = {q[s], q[(s + 1) % 4], q[(s + 2) % 4], q[(s + 3) % 4]};
+    // loop (r0,r1,r2,r3) -> lexicographic (v0,v1,v2,v3) = (r0,r1,r3,r2)
+    int32_t l[4] = {r[0], r[1], r[3], r[2]};
+    for (int k = 0; k < 4; ++k) {
+      lex[c * 4 + k] = l[k];
+      o->vert[(size_t)c * 8 + k * 2 + 0] = vertices[l[k] * 2 + 0];
+      o->vert[(size_t)c * 8 + k * 2 + 1] = vertices[l[k] * 2 + 1];
+    }
+  }
+  // edge -> (cell, face) map
+  struct Half { int32_t cell, face, start; };
+  std::unordered_map<uint64_t, std::vector<Half>> edges;
+  edges.reserve((size_t)n_quads * 3);
+  auto key = [](int32_t a, int32_t b) { return ((uint64_t)(uint32_t)std::min(a, b) << 32) | (uint32_t)std::max(a, b); };
+  for (int c = 0; c < n_quads; ++c)
+    for (int f = 0; f < 4; ++f) {
+      int32_t a = lex[c * 4 + kFaceVerts[f][0]], b = lex[c * 4 + kFaceVerts[f][1]];
+      edges[key(a, b)].push_back({c, f, a});
+    }
+  std::unordered_map<uint64_t, int32_t> bid;
+  for (int e = 0; e < n_bedges; ++e) bid[key(bedges[e * 2], bedges[e * 2 + 1])] = bedge_id ? bedge_id[e] : 0;
+  for (auto &kv : edges) {
+    auto &hs = kv.second;
+    if (hs.size() == 2) {
+      for (int s = 0; s < 2; ++s) {
+        const Half &me = hs[s], &ot = hs[1 - s];
+        o->nbr[(size_t)me.cell * 4 + me.face] = ot.cell;
+        o->nbrf[(size_t)me.cell * 4 + me.face] = ot.face | (me.start != ot.start ? 4 : 0);
+      }
+    } else if (hs.size() == 1) {
+      auto it = bid.find(kv.first);
+      int32_t id = it == bid.end() ? 0 : it->second;
+      if (id < 0 || id >= DFLO_MAX_BOUNDARIES) {
+        delete o;
+        return fail(DFLO_ERR_BAD_PARAM, "boundary id out of range [0,10)");
+      }
+      o->nbr[(size_t)hs[0].cell * 4 + hs[0].face] = DFLO_NBR_BOUNDARY(id);
+    } else {
+      delete o;
+      return fail(DFLO_ERR_BAD_PARAM, "non-manifold edge in quad mesh");
+    }
+  }
+  o->m.n_cells = n_quads;
+  o->m.n_owned_cells = n_quads;
+  o->m.degree = degree;
+  o->m.basis = DFLO_BASIS_QK;
+  o->m.mapping = DFLO_MAP_Q1;
+  o->bind();
+  *out = &o->m;
+  return DFLO_OK;
+}
+
+int dflo_mesh_read_gmsh(const char *path, int32_t degree, int32_t mapping, dflo_mesh_t **out) {
+  std::ifstream in(path);
+  if (!in) return fail(DFLO_ERR_BAD_PARAM, std::string("cannot open mesh file ") + path);
+  std::string line;
+  std::vector<double> verts;
+  std::vector<int32_t> quads, bedges, bids;
+  std::unordered_map<long long, int32_t> node_index;
+  while (std::getline(in, line)) {
+    if (line.rfind("$MeshFormat", 0) == 0) {
+      double ver; int ft, ds;
+      in >> ver >> ft >> ds;
+      if (ver >= 3.0 || ft != 0) return fail(DFLO_ERR_UNSUPPORTED, "only Gmsh v2 ASCII .msh is supported");
+    } else if (line.rfind("$Nodes", 0) == 0) {
+      long long nn;
+      in >> nn;
+      verts.resize((size_t)nn * 2);
+      for (long long i = 0; i < nn; ++i) {
+        long long id; double x, y, z;
+        in >> id >> x >> y >> z;
+        node_index[id] = (int32_t)i;
+        verts[i * 2] = x;
+        verts[i * 2 + 1] = y;
+      }
+    } else if (line.rfind("$Elements", 0) == 0) {
+      long long ne;
+      in >> ne;
+      for (long long i = 0; i < ne; ++i) {
+        long long id; int type, ntags;
+        in >> id >> type >> ntags;
+        std::vector<long long> tags(ntags);
+        for (int t = 0; t < ntags; ++t) in >> tags[t];
+        int nn = type == 1 ? 2 : type == 3 ? 4 : type == 15 ? 1 : type == 2 ? 3 : -1;
+        if (nn < 0) return fail(DFLO_ERR_UNSUPPORTED, "unsupported gmsh element type");
+        long long nodes[4];
+        for (int k = 0; k < nn; ++k) in >> nodes[k];
+        if (type == 2) return fail(DFLO_ERR_UNSUPPORTED, "triangles in mesh: dflo needs all-quad meshes");
+        if (type == 1) {
+          bedges.push_back(node_index.at(nodes[0]));
+          bedges.push_back(node_index.at(nodes[1]));
+          bids.push_back(ntags > 0 ? (int32_t)tags[0] : 0);  // physical id -> boundary_id (Appendix A.11)
+        } else if (type == 3) {
+          for (int k = 0; k < 4; ++k) quads.push_back(node_index.at(nodes[k]));
+        }
+      }
+    }
+  }
+  if (quads.empty()) return fail(DFLO_ERR_BAD_PARAM, "no quadrilaterals in mesh file");
+  int rc = dflo_mesh_from_quads((int32_t)(verts.size() / 2), verts.data(), (int32_t)(quads.size() / 4), quads.data(),
+                                (int32_t)bids.size(), bedges.data(), bids.data(), degree, out);
+  if (rc) return rc;
+  MeshOwner *o = reinterpret_cast<MeshOwner *>(*out);
+  o->m.mapping = mapping;
+  return DFLO_OK;
+}
+
+int dflo_mesh_partition(const dflo_mesh_t *mesh, int32_t n_ranks, int32_t rank, dflo_mesh_t **out,
+                        const int32_t **send_cells, const int32_t **send_offsets, const int32_t **recv_offsets) {
+  if (!mesh || !out || n_ranks < 1 || rank < 0 || rank >= n_ranks) return fail(DFLO_ERR_BAD_PARAM, "dflo_mesh_partition: bad arguments");
+  const int32_t n = mesh->n_cells;
+  if (mesh->n_owned_cells != n) return fail(DFLO_ERR_BAD_PARAM, "mesh is already partitioned");
+  // order cells by centroid (x, then y): contiguous chunks are x-slabs on structured meshes
+  std::vector<int32_t> order(n);
+  std::vector<double> cx(n), cy(n);
+  for (int c = 0; c < n; ++c) {
+    order[c] = c;
+    const double *v = &mesh->cell_vertices[(size_t)c * 8];
+    cx[c] = 0.25 * (v[0] + v[2] + v[4] + v[6]);
+    cy[c] = 0.25 * (v[1] + v[3] + v[5] + v[7]);
+  }
+  double xmin = 1e300, xmax = -1e300;
+  for (int c = 0; c < n; ++c) { xmin = std::min(xmin, cx[c]); xmax = std::max(xmax, cx[c]); }
+  const double tol = 1e-9 * (xmax - xmin + 1e-300);
+  std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) {
+    if (std::fabs(cx[a] - cx[b]) > tol) return cx[a] < cx[b];
+    return cy[a] < cy[b];
+  });
+  std::vector<int32_t> owner(n);
+  for (int64_t k = 0; k < n; ++k) owner[order[k]] = (int32_t)(k * n_ranks / n);
+  // owned cells keep the global order; ghosts sorted by (source rank, global id)
+  std::vector<int32_t> local;
+  for (int c = 0; c < n; ++c)
+    if (owner[c] == rank) local.push_back(c);
+  const int32_t n_owned = (int32_t)local.size();
+  std::vector<std::vector<int32_t>> ghosts(n_ranks), sends(n_ranks);
+  std::vector<char> mark(n, 0);
+  for (int c = 0; c < n; ++c) {
+    if (owner[c] != rank) continue;
+    for (int f = 0; f < 4; ++f) {
+      int32_t nb = mesh->cell_face_neighbor[(size_t)c * 4 + f];
+      if (nb < 0 || owner[nb] == rank) continue;
+      if (!(mark[nb] & 1)) { mark[nb] |= 1; ghosts[owner[nb]].push_back(nb); }
+    }
+  }
+  // cell c (owned here) is sent to rank s iff some face neighbour of c is owned by s
+  for (int c = 0; c < n; ++c) {
+    if (owner[c] != rank) continue;
+    int32_t seen[4]; int ns = 0;
+    for (int f = 0; f < 4; ++f) {
+      int32_t nb = mesh->cell_face_neighbor[(size_t)c * 4 + f];
+      if (nb < 0 || owner[nb] == rank) continue;
+      int32_t s = owner[nb];
+      bool dup = false;
+      for (int k = 0; k < ns; ++k) dup |= seen[k] == s;
+      if (!dup) { seen[ns++] = s; sends[s].push_back(c); }
+    }
+  }
+  MeshOwner *o = new MeshOwner;
+  o->recv_off.assign(n_ranks + 1, 0);
+  o->send_off.assign(n_ranks + 1, 0);
+  for (int r = 0; r < n_ranks; ++r) {
+    std::sort(ghosts[r].begin(), ghosts[r].end());
+    std::sort(sends[r].begin(), sends[r].end());
+    o->recv_off[r + 1] = o->recv_off[r] + (int32_t)ghosts[r].size();
+    o->send_off[r + 1] = o->send_off[r] + (int32_t)sends[r].size();
+    for (int32_t g : ghosts[r]) local.push_back(g);
+  }
+  const int32_t nl = (int32_t)local.size();
+  std::unordered_map<int32_t, int32_t> g2l;
+  g2l.reserve((size_t)nl * 2);
+  for (int l = 0; l < nl; ++l) g2l[local[l]] = l;
+  for (int r = 0; r < n_ranks; ++r)
+    for (int32_t c : sends[r]) o->send_cells.push_back(g2l[c]);
+  o->vert.resize((size_t)nl * 8);
+  o->nbr.resize((size_t)nl * 4);
+  o->nbrf.resize((size_t)nl * 4);
+  o->gid.resize(nl);
+  for (int l = 0; l < nl; ++l) {
+    const int32_t c = local[l];
+    o->gid[l] = mesh->cell_global_id ? mesh->cell_global_id[c] : c;
+    std::memcpy(&o->vert[(size_t)l * 8], &mesh->cell_vertices[(size_t)c * 8], 8 * sizeof(double));
+    for (int f = 0; f < 4; ++f) {
+      int32_t nb = mesh->cell_face_neighbor[(size_t)c * 4 + f];
+      int32_t nf = mesh->cell_face_neighbor_face[(size_t)c * 4 + f];
+      if (nb >= 0) {
+        auto it = g2l.find(nb);
+        nb = it == g2l.end() ? DFLO_NBR_NONE : it->second;
+        // two ghost cells never exchange a flux
+        if (l >= n_owned && nb != DFLO_NBR_NONE && nb >= n_owned) nb = DFLO_NBR_NONE;
+      }
+      o->nbr[(size_t)l * 4 + f] = nb;
+      o->nbrf[(size_t)l * 4 + f] = nf;
+    }
+  }
+  o->m.n_cells = nl;
+  o->m.n_owned_cells = n_owned;
+  o->m.degree = mesh->degree;
+  o->m.basis = mesh->basis;
+  o->m.mapping = mesh->mapping;
+  o->bind();
+  *out = &o->m;
+  if (send_cells) *send_cells = o->send_cells.data();
+  if (send_offsets) *send_offsets = o->send_off.data();
+  if (recv_offsets) *recv_offsets = o->recv_off.data();
+  return DFLO_OK;
+}
+
+}  // extern "C"
+
+// ---- support points of the Qk DoFs (unit support points mapped to real space; what
+// VectorTools::interpolate evaluates the initial condition at, src/ic.cc:104-121)
+#include "basis.h"
+extern "C" int dflo_mesh_support_points(const dflo_mesh_t *mesh, double *xy) {
+  if (!mesh || !xy) return fail(DFLO_ERR_BAD_PARAM, "dflo_mesh_support_points: null argument");
+  if (mesh->basis != DFLO_BASIS_QK) return fail(DFLO_ERR_UNSUPPORTED, "support points exist only for the Qk basis");
+  const dflo::BasisTables b = dflo::make_basis(mesh->degree);
+  const int N = b.N;
+  for (int c = 0; c < mesh->n_cells; ++c) {
+    const double *v = &mesh->cell_vertices[(size_t)c * 8];
+    for (int j = 0; j < N * N; ++j) {
+      const double xi = b.x[j % N], eta = b.x[j / N];
+      for (int d = 0; d < 2; ++d)
+        xy[((size_t)c * N * N + j) * 2 + d] = (1 - xi) * (1 - eta) * v[d] + xi * (1 - eta) * v[2 + d] +
+                                               (1 - xi) * eta * v[4 + d] + xi * eta * v[6 + d];
+    }
+  }
+  return DFLO_OK;
+}

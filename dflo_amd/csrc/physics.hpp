@@ -1,0 +1,341 @@
+// physics.hpp -- pointwise Euler physics on the device (HIP, gfx950).
+//
+// Device restatement of EulerEquations<2> (src/equation.h): state W = [mx, my, rho, E]
+// (src/equation.h:25-28), gamma = 1.4 (src/equation.cc:33).  Each function cites the
+// reference function it replaces.  Branches of the reference that are data dependent
+// (HLLC wave pattern, Roe entropy fix) are kept as selects so that a wavefront does not
+// diverge.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace dflo {
+
+constexpr double kGamma = 1.4;
+constexpr double kG1 = kGamma - 1.0;
+constexpr int MX = 0, MY = 1, RHO = 2, EN = 3;
+
+__device__ __forceinline__ double pressure(const double *W) {  // src/equation.h:87-92
+  const double ke = (W[MX] * W[MX] + W[MY] * W[MY]) * (0.5 / W[RHO]);
+  return kG1 * (W[EN] - ke);
+}
+
+// F(W): x- and y- flux columns, src/equation.h:160-193
+__device__ __forceinline__ void flux_xy(const double *W, double *Fx, double *Gy) {
+  const double p = pressure(W);
+  Fx[MX] = W[MX] * W[MX] / W[RHO] + p;
+  Fx[MY] = W[MY] * W[MX] / W[RHO];
+  Gy[MX] = W[MX] * W[MY] / W[RHO];
+  Gy[MY] = W[MY] * W[MY] / W[RHO] + p;
+  Fx[RHO] = W[MX];
+  Gy[RHO] = W[MY];
+  Fx[EN] = W[MX] / W[RHO] * (W[EN] + p);
+  Gy[EN] = W[MY] / W[RHO] * (W[EN] + p);
+}
+
+// |v.n| + c of a (cell average) state, src/equation.h:122-137
+__device__ __forceinline__ double max_eigenvalue_n(const double *W, double nx, double ny) {
+  const double p = pressure(W);
+  const double sonic = sqrt(kGamma * p / W[RHO]);
+  double vel = W[MX] * nx + W[MY] * ny;
+  vel /= W[RHO];
+  return fabs(vel) + sonic;
+}
+// |v| + c, src/equation.h:100-114
+__device__ __forceinline__ double max_eigenvalue(const double *W) {
+  const double p = pressure(W);
+  const double vel = sqrt(W[MX] * W[MX] + W[MY] * W[MY]) / W[RHO];
+  return vel + sqrt(kGamma * p / W[RHO]);
+}
+
+// src/equation.h:326-377; lambda comes from the two CELL AVERAGES Ap, Am (src/equation.h:357-359)
+__device__ __forceinline__ void lxf_flux(double nx, double ny, const double *Wp, const double *Wm, const double *Ap,
+                                         const double *Am, double *F) {
+  const double vp = (Wp[MX] * nx + Wp[MY] * ny) / Wp[RHO];
+  const double vm = (Wm[MX] * nx + Wm[MY] * ny) / Wm[RHO];
+  const double pp = pressure(Wp), pm = pressure(Wm);
+  const double lambda = fmax(max_eigenvalue_n(Ap, nx, ny), max_eigenvalue_n(Am, nx, ny));
+  F[MX] = 0.5 * (pp * nx + Wp[MX] * vp + pm * nx + Wm[MX] * vm);
+  F[MY] = 0.5 * (pp * ny + Wp[MY] * vp + pm * ny + Wm[MY] * vm);
+  F[RHO] = 0.5 * (Wp[RHO] * vp + Wm[RHO] * vm);
+  F[EN] = 0.5 * ((Wp[EN] + pp) * vp + (Wm[EN] + pm) * vm);
+#pragma unroll
+  for (int c = 0; c < 4; ++c) F[c] += 0.5 * lambda * (Wp[c] - Wm[c]);
+}
+
+// src/equation.h:384-464
+__device__ __forceinline__ void steger_warming_flux(double nx, double ny, const double *Wp, const double *Wm, double *F) {
+  const double n[2] = {nx, ny};
+  double vp = (Wp[MX] * nx + Wp[MY] * ny) / Wp[RHO];
+  double vm = (Wm[MX] * nx + Wm[MY] * ny) / Wm[RHO];
+  double q2p = (Wp[MX] * Wp[MX] + Wp[MY] * Wp[MY]) / (Wp[RHO] * Wp[RHO]);
+  double q2m = (Wm[MX] * Wm[MX] + Wm[MY] * Wm[MY]) / (Wm[RHO] * Wm[RHO]);
+  const double pp = pressure(Wp), pm = pressure(Wm);
+  const double cp = sqrt(kGamma * pp / Wp[RHO]), cm = sqrt(kGamma * pm / Wm[RHO]);
+  const double l1p = fmax(vp, 0.0), l2p = fmax(vp + cp, 0.0), l3p = fmax(vp - cp, 0.0);
+  const double ap = 2.0 * kG1 * l1p + l2p + l3p;
+  const double fp = 0.5 * Wp[RHO] / kGamma;
+  const double l1m = fmin(vm, 0.0), l2m = fmin(vm + cm, 0.0), l3m = fmin(vm - cm, 0.0);
+  const double am = 2.0 * kG1 * l1m + l2m + l3m;
+  const double fm = 0.5 * Wm[RHO] / kGamma;
+  double pf[4], mf[4];
+#pragma unroll
+  for (int d = 0; d < 2; ++d) {
+    pf[d] = ap * Wp[d] / Wp[RHO] + cp * (l2p - l3p) * n[d];
+    mf[d] = am * Wm[d] / Wm[RHO] + cm * (l2m - l3m) * n[d];
+  }
+  pf[RHO] = ap;
+  pf[EN] = 0.5 * ap * q2p + cp * vp * (l2p - l3p) + cp * cp * (l2p + l3p) / kG1;
+  mf[RHO] = am;
+  mf[EN] = 0.5 * am * q2m + cm * vm * (l2m - l3m) + cm * cm * (l2m + l3m) / kG1;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) F[c] = fp * pf[c] + fm * mf[c];
+}
+
+// src/equation.h:471-556 (Harten entropy fix delta = 0.1 c, :529-531)
+__device__ __forceinline__ void roe_flux(double nx, double ny, const double *Wl, const double *Wr, double *F) {
+  const double n[2] = {nx, ny};
+  const double rls = sqrt(Wl[RHO]), rrs = sqrt(Wr[RHO]);
+  const double fl = rls / (rls + rrs), fr = 1.0 - fl;
+  double vl[2], vr[2], vel[2], dv[2];
+  double v2l = 0, v2r = 0, vln = 0, vrn = 0, veln = 0, v2 = 0, vdv = 0;
+#pragma unroll
+  for (int d = 0; d < 2; ++d) {
+    vl[d] = Wl[d] / Wl[RHO];
+    vr[d] = Wr[d] / Wr[RHO];
+    v2l += vl[d] * vl[d];
+    v2r += vr[d] * vr[d];
+    vln += vl[d] * n[d];
+    vrn += vr[d] * n[d];
+    vel[d] = vl[d] * fl + vr[d] * fr;
+    veln += vel[d] * n[d];
+    v2 += vel[d] * vel[d];
+    dv[d] = vr[d] - vl[d];
+    vdv += vel[d] * dv[d];
+  }
+  const double pl = kG1 * (Wl[EN] - 0.5 * Wl[RHO] * v2l);
+  const double pr = kG1 * (Wr[EN] - 0.5 * Wr[RHO] * v2r);
+  const double hl = kGamma * pl / Wl[RHO] / kG1 + 0.5 * v2l;
+  const double hr = kGamma * pr / Wr[RHO] / kG1 + 0.5 * v2r;
+  const double rho = rls * rrs;
+  const double h = hl * fl + hr * fr;
+  const double c = sqrt(kG1 * (h - 0.5 * v2));
+  const double drho = Wr[RHO] - Wl[RHO];
+  const double dp = pr - pl;
+  const double dvn = vrn - vln;
+  const double a1 = (dp - rho * c * dvn) / (2.0 * c * c);
+  const double a2 = drho - dp / (c * c);
+  const double a3 = (dp + rho * c * dvn) / (2.0 * c * c);
+  double l1 = fabs(veln - c);
+  const double l2 = fabs(veln);
+  double l3 = fabs(veln + c);
+  const double delta = 0.1 * c;
+  l1 = (l1 < delta) ? 0.5 * (l1 * l1 / delta + delta) : l1;
+  l3 = (l3 < delta) ? 0.5 * (l3 * l3 / delta + delta) : l3;
+  const double Drho = l1 * a1 + l2 * a2 + l3 * a3;
+  const double Den = l1 * a1 * (h - c * veln) + l2 * a2 * 0.5 * v2 + l2 * rho * (vdv - veln * dvn) + l3 * a3 * (h + c * veln);
+  F[RHO] = 0.5 * (Wl[RHO] * vln + Wr[RHO] * vrn - Drho);
+  F[EN] = 0.5 * (Wl[RHO] * hl * vln + Wr[RHO] * hr * vrn - Den);
+  const double pavg = 0.5 * (pl + pr);
+#pragma unroll
+  for (int d = 0; d < 2; ++d) {
+    const double Dd = (vel[d] - n[d] * c) * l1 * a1 + vel[d] * l2 * a2 + (dv[d] - n[d] * dvn) * l2 * rho + (vel[d] + n[d] * c) * l3 * a3;
+    F[d] = n[d] * pavg + 0.5 * (Wl[d] * vln + Wr[d] * vrn) - 0.5 * Dd;
+  }
+}
+
+// src/equation.h:565-681.  The four branches (:631-679) are evaluated as: left/right supersonic
+// states and the star state of the side picked by the sign of s_m, then selected.
+__device__ __forceinline__ void hllc_flux(double nx, double ny, const double *Wl, const double *Wr, double *F) {
+  const double n[2] = {nx, ny};
+  const double rls = sqrt(Wl[RHO]), rrs = sqrt(Wr[RHO]);
+  const double fl = rls / (rls + rrs), fr = 1.0 - fl;
+  double vl[2], vr[2];
+  double v2l = 0, v2r = 0, vln = 0, vrn = 0, veln = 0, v2 = 0;
+#pragma unroll
+  for (int d = 0; d < 2; ++d) {
+    vl[d] = Wl[d] / Wl[RHO];
+    vr[d] = Wr[d] / Wr[RHO];
+    v2l += vl[d] * vl[d];
+    v2r += vr[d] * vr[d];
+    vln += vl[d] * n[d];
+    vrn += vr[d] * n[d];
+    const double ve = vl[d] * fl + vr[d] * fr;
+    veln += ve * n[d];
+    v2 += ve * ve;
+  }
+  const double pl = kG1 * (Wl[EN] - 0.5 * Wl[RHO] * v2l);
+  const double pr = kG1 * (Wr[EN] - 0.5 * Wr[RHO] * v2r);
+  const double hl = (Wl[EN] + pl) / Wl[RHO];
+  const double hr = (Wr[EN] + pr) / Wr[RHO];
+  const double cl = sqrt(kGamma * pl / Wl[RHO]);
+  const double cr = sqrt(kGamma * pr / Wr[RHO]);
+  const double el = Wl[EN] / Wl[RHO];
+  const double er = Wr[EN] / Wr[RHO];
+  const double h = hl * fl + hr * fr;
+  const double c = sqrt(kG1 * (h - 0.5 * v2));
+  const double sl = fmin(veln - c, vln - cl);
+  const double sr = fmax(veln + c, vrn + cr);
+  const double sm = (pl - pr - Wl[RHO] * vln * (sl - vln) + Wr[RHO] * vrn * (sr - vrn)) /
+                    (Wr[RHO] * (sr - vrn) - Wl[RHO] * (sl - vln));
+  const double pstar = Wr[RHO] * (vrn - sr) * (vrn - sm) + pr;
+  const bool left = sm >= 0.0;                         // which side of the contact the face lies on
+  const bool supersonic = left ? (sl > 0.0) : !(sr >= 0.0);
+  // one-sided quantities of the chosen side
+  const double rK = left ? Wl[RHO] : Wr[RHO];
+  const double vKn = left ? vln : vrn;
+  const double pK = left ? pl : pr;
+  const double eK = left ? el : er;
+  const double sK = left ? sl : sr;
+  const double vK0 = left ? vl[0] : vr[0], vK1 = left ? vl[1] : vr[1];
+  // supersonic flux of that side (:634-637 / :674-677)
+  const double Fs_rho = rK * vKn;
+  const double Fs_0 = rK * vK0 * vKn + pK * n[0];
+  const double Fs_1 = rK * vK1 * vKn + pK * n[1];
+  const double Fs_en = eK * rK * vKn + pK * vKn;
+  // star state flux (:641-652 / :659-670)
+  const double inv = 1.0 / (sK - sm);
+  const double sKmu = sK - vKn;
+  const double rhoS = rK * sKmu * inv;
+  const double ru0 = (rK * vK0 * sKmu + (pstar - pK) * n[0]) * inv;
+  const double ru1 = (rK * vK1 * sKmu + (pstar - pK) * n[1]) * inv;
+  const double eS = (sKmu * eK * rK - pK * vKn + pstar * sm) * inv;
+  F[RHO] = supersonic ? Fs_rho : rhoS * sm;
+  F[MX] = supersonic ? Fs_0 : ru0 * sm + pstar * n[0];
+  F[MY] = supersonic ? Fs_1 : ru1 * sm + pstar * n[1];
+  F[EN] = supersonic ? Fs_en : (eS + pstar) * sm;
+}
+
+// Abramowitz-Stegun 7.1.26 exactly as the reference uses it (src/equation.h:688-709) -- NOT erf()
+__device__ __forceinline__ double ERF(double xarg) {
+  const double a1 = 0.254829592, a2 = -0.284496736, a3 = 1.421413741, a4 = -1.453152027, a5 = 1.061405429;
+  const double p = 0.3275911;
+  const double sign = (xarg < 0) ? -1.0 : 1.0;
+  const double x = fabs(xarg);
+  const double t = 1.0 / (1.0 + p * x);
+  const double y = 1.0 - (((((a5 * t + a4) * t) + a3) * t + a2) * t + a1) * t * exp(-x * x);
+  return sign * y;
+}
+// src/equation.h:716-751
+__device__ __forceinline__ void kinetic_split_flux(double sign, double nx, double ny, const double *W, double *F) {
+  const double vdotn = (W[MX] * nx + W[MY] * ny) / W[RHO];
+  const double p = pressure(W);
+  const double beta = 0.5 * W[RHO] / p;
+  const double s = vdotn * sqrt(beta);
+  const double A = 0.5 * (1.0 + sign * ERF(s));
+  const double B = 0.5 * sign * exp(-s * s) / sqrt(M_PI * beta);
+  const double ufact = vdotn * A + B;
+  F[MX] = p * nx * A + W[MX] * ufact;
+  F[MY] = p * ny * A + W[MY] * ufact;
+  F[RHO] = W[RHO] * ufact;
+  F[EN] = (W[EN] + p) * vdotn * A + (W[EN] + 0.5 * p) * B;
+}
+// src/equation.h:758-782
+__device__ __forceinline__ void kfvs_flux(double nx, double ny, const double *Wp, const double *Wm, double *F) {
+  double pf[4], mf[4];
+  kinetic_split_flux(+1.0, nx, ny, Wp, pf);
+  kinetic_split_flux(-1.0, nx, ny, Wm, mf);
+#pragma unroll
+  for (int c = 0; c < 4; ++c) F[c] = pf[c] + mf[c];
+}
+
+// flux dispatcher (src/claw.h:271-325) resolved at compile time
+template <int FLUX>
+__device__ __forceinline__ void numerical_normal_flux(double nx, double ny, const double *Wp, const double *Wm,
+                                                      const double *Ap, const double *Am, double *F) {
+  if constexpr (FLUX == DFLO_FLUX_LXF) lxf_flux(nx, ny, Wp, Wm, Ap, Am, F);
+  else if constexpr (FLUX == DFLO_FLUX_SW) steger_warming_flux(nx, ny, Wp, Wm, F);
+  else if constexpr (FLUX == DFLO_FLUX_KFVS) kfvs_flux(nx, ny, Wp, Wm, F);
+  else if constexpr (FLUX == DFLO_FLUX_ROE) roe_flux(nx, ny, Wp, Wm, F);
+  else hllc_flux(nx, ny, Wp, Wm, F);
+}
+
+// ghost state of a boundary face, src/equation.h:942-1033
+__device__ __forceinline__ void compute_Wminus(int kind, double nx, double ny, const double *Wp, const double *bv, double *Wm) {
+  if (kind == DFLO_BC_INFLOW || kind == DFLO_BC_FARFIELD) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) Wm[c] = bv[c];
+  } else if (kind == DFLO_BC_OUTFLOW) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) Wm[c] = Wp[c];
+  } else if (kind == DFLO_BC_PRESSURE) {
+    const double ke = (Wp[MX] * Wp[MX] + Wp[MY] * Wp[MY]) * (0.5 / Wp[RHO]);
+    Wm[MX] = Wp[MX];
+    Wm[MY] = Wp[MY];
+    Wm[RHO] = Wp[RHO];
+    Wm[EN] = bv[EN] / kG1 + ke;  // w_3 is read as a pressure, src/equation.h:992
+  } else {  // slip: reflect the normal momentum
+    const double vdotn = Wp[MX] * nx + Wp[MY] * ny;
+    Wm[MX] = Wp[MX] - 2.0 * vdotn * nx;
+    Wm[MY] = Wp[MY] - 2.0 * vdotn * ny;
+    Wm[RHO] = Wp[RHO];
+    Wm[EN] = Wp[EN];
+  }
+}
+
+// TVB minmod, src/limiter.cc:15-30
+__device__ __forceinline__ double minmod(double a, double b, double c, double Mdx2) {
+  const double aa = fabs(a);
+  if (aa < Mdx2) return a;
+  if (a * b > 0 && b * c > 0) {
+    const double s = (a > 0) ? 1.0 : -1.0;
+    return s * fmin(aa, fmin(fabs(b), fabs(c)));
+  }
+  return 0.0;
+}
+
+// characteristic projection at a cell mean.  The reference builds Rx,Lx,Ry,Ly
+// (src/equation.h:226-265) on [rho,mx,my,E]-ordered vectors and reorders inside
+// transform_to_char / transform_to_con (src/equation.h:271-306); here the matrices are
+// applied in place to W = [mx,my,rho,E].
+struct EigenXY {
+  double u, v, c, q2, h, beta, phi2, c2;
+};
+__device__ __forceinline__ EigenXY eigen_at(const double *A) {
+  EigenXY e;
+  const double rho = A[RHO];
+  e.u = A[MX] / rho;
+  e.v = A[MY] / rho;
+  e.q2 = e.u * e.u + e.v * e.v;
+  const double p = kG1 * (A[EN] - 0.5 * rho * e.q2);
+  e.c2 = kGamma * p / rho;
+  e.c = sqrt(e.c2);
+  e.beta = 0.5 / e.c2;
+  e.phi2 = 0.5 * kG1 * e.q2;
+  e.h = e.c2 / kG1 + 0.5 * e.q2;
+  return e;
+}
+// W <- L * W   (dir 0: Lx, dir 1: Ly)
+__device__ __forceinline__ void to_char(const EigenXY &e, int dir, double *W) {
+  const double V0 = W[RHO], V1 = W[MX], V2 = W[MY], V3 = W[EN];
+  const double un = dir == 0 ? e.u : e.v;
+  double r0 = (1 - e.phi2 / e.c2) * V0 + (kG1 * e.u / e.c2) * V1 + (kG1 * e.v / e.c2) * V2 + (-kG1 / e.c2) * V3;
+  double r1, r2, r3;
+  if (dir == 0) {
+    r1 = e.v * V0 + 0.0 * V1 + (-1.0) * V2 + 0.0 * V3;
+    r2 = e.beta * (e.phi2 - e.c * un) * V0 + e.beta * (e.c - kG1 * e.u) * V1 + (-e.beta * kG1 * e.v) * V2 + e.beta * kG1 * V3;
+    r3 = e.beta * (e.phi2 + e.c * un) * V0 + (-e.beta * (e.c + kG1 * e.u)) * V1 + (-e.beta * kG1 * e.v) * V2 + e.beta * kG1 * V3;
+  } else {
+    r1 = (-e.u) * V0 + 1.0 * V1 + 0.0 * V2 + 0.0 * V3;
+    r2 = e.beta * (e.phi2 - e.c * un) * V0 + (-e.beta * kG1 * e.u) * V1 + e.beta * (e.c - kG1 * e.v) * V2 + e.beta * kG1 * V3;
+    r3 = e.beta * (e.phi2 + e.c * un) * V0 + (-e.beta * kG1 * e.u) * V1 + (-e.beta * (e.c + kG1 * e.v)) * V2 + e.beta * kG1 * V3;
+  }
+  W[0] = r0; W[1] = r1; W[2] = r2; W[3] = r3;  // characteristic variables, reference index order
+}
+// W <- R * W and back to [mx,my,rho,E]
+__device__ __forceinline__ void to_con(const EigenXY &e, int dir, double *W) {
+  const double a0 = W[0], a1 = W[1], a2 = W[2], a3 = W[3];
+  double V0, V1, V2, V3;
+  V0 = a0 + 0.0 * a1 + a2 + a3;
+  if (dir == 0) {
+    V1 = e.u * a0 + 0.0 * a1 + (e.u + e.c) * a2 + (e.u - e.c) * a3;
+    V2 = e.v * a0 + (-1.0) * a1 + e.v * a2 + e.v * a3;
+    V3 = 0.5 * e.q2 * a0 + (-e.v) * a1 + (e.h + e.c * e.u) * a2 + (e.h - e.c * e.u) * a3;
+  } else {
+    V1 = e.u * a0 + 1.0 * a1 + e.u * a2 + e.u * a3;
+    V2 = e.v * a0 + 0.0 * a1 + (e.v + e.c) * a2 + (e.v - e.c) * a3;
+    V3 = 0.5 * e.q2 * a0 + e.u * a1 + (e.h + e.c * e.v) * a2 + (e.h - e.c * e.v) * a3;
+  }
+  W[RHO] = V0; W[MX] = V1; W[MY] = V2; W[EN] = V3;
+}
+
+}  // namespace dflo

@@ -1,0 +1,221 @@
+// plan.cc -- builds the shard / face index layout (see plan.h).
+#include "plan.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <unordered_map>
+
+namespace dflo {
+namespace {
+
+inline uint64_t morton2(uint32_t x, uint32_t y) {
+  auto spread = [](uint64_t v) {
+    v &= 0xFFFFFFFFull;
+    v = (v | (v << 16)) & 0x0000FFFF0000FFFFull;
+    v = (v | (v << 8)) & 0x00FF00FF00FF00FFull;
+    v = (v | (v << 4)) & 0x0F0F0F0F0F0F0F0Full;
+    v = (v | (v << 2)) & 0x3333333333333333ull;
+    v = (v | (v << 1)) & 0x5555555555555555ull;
+    return v;
+  };
+  return spread(x) | (spread(y) << 1);
+}
+
+}  // namespace
+
+int build_plan(const dflo_mesh_t &mesh, int shard_ex, int shard_ey, Plan &p, std::string &err) {
+  const int n = mesh.n_cells;
+  const int n_owned = mesh.n_owned_cells > 0 ? mesh.n_owned_cells : n;
+  if (n < 1 || n_owned > n) { err = "bad cell counts"; return DFLO_ERR_BAD_PARAM; }
+  if (shard_ex * shard_ey != kShard) { err = "shard shape must hold 64 cells"; return DFLO_ERR_BAD_PARAM; }
+  p.n_cells = n;
+  p.n_owned = n_owned;
+  const double *V = mesh.cell_vertices;
+  auto gid = [&](int c) -> int64_t { return mesh.cell_global_id ? mesh.cell_global_id[c] : c; };
+
+  // ---- geometry checks (compute_cartesian_mesh_size, src/claw.cc:197-221)
+  std::vector<double> hx(n);
+  double hmin = 1e300, hmax = 0, xmin = 1e300, ymin = 1e300;
+  for (int c = 0; c < n; ++c) {
+    const double *v = &V[(size_t)c * 8];
+    if (mesh.mapping == DFLO_MAP_CARTESIAN) {
+      const double dx = v[2] - v[0], dy = v[5] - v[1];
+      // face-centre extents as the reference measures them
+      const double fx = 0.5 * (v[2] + v[6]) - 0.5 * (v[0] + v[4]);
+      const double fy = 0.5 * (v[5] + v[7]) - 0.5 * (v[1] + v[3]);
+      if (!(std::fabs(fx - fy) < 1.0e-12) || !(dx > 0) || !(dy > 0) || std::fabs(v[3] - v[1]) > 1e-12 * dx ||
+          std::fabs(v[4] - v[0]) > 1e-12 * dx) {
+        err = "Cell is not square";
+        return DFLO_ERR_NONSQUARE_CELL;
+      }
+      hx[c] = dx;
+    } else {
+      hx[c] = std::sqrt(std::fabs((v[2] - v[0]) * (v[5] - v[1]) - (v[3] - v[1]) * (v[4] - v[0])));
+    }
+    hmin = std::min(hmin, hx[c]);
+    hmax = std::max(hmax, hx[c]);
+    xmin = std::min(xmin, v[0]);
+    ymin = std::min(ymin, v[1]);
+  }
+  p.uniform_h = mesh.mapping == DFLO_MAP_CARTESIAN && (hmax - hmin) <= 1e-10 * hmax;
+  p.h = hmin;
+
+  // ---- assign owned cells to shards
+  std::vector<int32_t> shard_of(n, -1), local_of(n, -1);
+  std::vector<std::vector<int32_t>> shard_cells;
+  if (p.uniform_h) {
+    // block shards of shard_ex x shard_ey cells on the lattice, ordered along a Morton curve
+    struct Key { uint64_t m; int32_t j, i, c; };
+    std::vector<Key> keys(n_owned);
+    for (int c = 0; c < n_owned; ++c) {
+      const double *v = &V[(size_t)c * 8];
+      int32_t i = (int32_t)std::llround((v[0] - xmin) / p.h), j = (int32_t)std::llround((v[1] - ymin) / p.h);
+      keys[c] = {morton2((uint32_t)(i / shard_ex), (uint32_t)(j / shard_ey)), j, i, c};
+    }
+    std::sort(keys.begin(), keys.end(), [](const Key &a, const Key &b) {
+      if (a.m != b.m) return a.m < b.m;
+      if (a.j != b.j) return a.j < b.j;
+      return a.i < b.i;
+    });
+    for (int k = 0; k < n_owned; ++k) {
+      if (k == 0 || keys[k].m != keys[k - 1].m || (int)shard_cells.back().size() == kShard) shard_cells.emplace_back();
+      shard_cells.back().push_back(keys[k].c);
+    }
+  } else {
+    // unstructured: Morton order of the centroids, cut into runs of 64
+    double xmax = -1e300, ymax = -1e300;
+    for (int c = 0; c < n; ++c) {
+      const double *v = &V[(size_t)c * 8];
+      for (int k = 0; k < 4; ++k) { xmax = std::max(xmax, v[2 * k]); ymax = std::max(ymax, v[2 * k + 1]); }
+    }
+    const double span = std::max(xmax - xmin, ymax - ymin) + 1e-300;
+    std::vector<std::pair<uint64_t, int32_t>> keys(n_owned);
+    for (int c = 0; c < n_owned; ++c) {
+      const double *v = &V[(size_t)c * 8];
+      double cx = 0.25 * (v[0] + v[2] + v[4] + v[6]), cy = 0.25 * (v[1] + v[3] + v[5] + v[7]);
+      uint32_t qx = (uint32_t)((cx - xmin) / span * 1048575.0), qy = (uint32_t)((cy - ymin) / span * 1048575.0);
+      keys[c] = {morton2(qx, qy), c};
+    }
+    std::sort(keys.begin(), keys.end());
+    for (int k = 0; k < n_owned; ++k) {
+      if (k % kShard == 0) shard_cells.emplace_back();
+      shard_cells.back().push_back(keys[k].second);
+    }
+  }
+  p.n_shards = (int)shard_cells.size();
+  const int n_ghost = n - n_owned;
+  p.n_ghost_shards = (n_ghost + kShard - 1) / kShard;
+  p.n_slots = (p.n_shards + p.n_ghost_shards) * kShard;
+  p.iid.assign(n, -1);
+  p.user_of.assign(p.n_slots, -1);
+  p.shard_count.resize(p.n_shards);
+  for (int s = 0; s < p.n_shards; ++s) {
+    p.shard_count[s] = (int)shard_cells[s].size();
+    for (int l = 0; l < (int)shard_cells[s].size(); ++l) {
+      const int c = shard_cells[s][l];
+      shard_of[c] = s;
+      local_of[c] = l;
+      p.iid[c] = s * kShard + l;
+      p.user_of[s * kShard + l] = c;
+    }
+  }
+  for (int g = 0; g < n_ghost; ++g) {  // ghost cells keep their (source rank, global id) order
+    p.iid[n_owned + g] = p.n_shards * kShard + g;
+    p.user_of[p.n_shards * kShard + g] = n_owned + g;
+  }
+
+  // ---- boundary faces in MeshWorker order
+  std::vector<int32_t> bface_of((size_t)n * 4, -1);
+  for (int c = 0; c < n_owned; ++c)
+    for (int f = 0; f < 4; ++f) {
+      const int nb = mesh.cell_face_neighbor[(size_t)c * 4 + f];
+      if (nb < 0 && nb != DFLO_NBR_NONE) {
+        const int id = DFLO_NBR_BOUNDARY_ID(nb);
+        if (id < 0 || id >= DFLO_MAX_BOUNDARIES) { err = "boundary id out of range"; return DFLO_ERR_BAD_PARAM; }
+        bface_of[(size_t)c * 4 + f] = (int32_t)p.bface_cell.size();
+        p.bface_cell.push_back(c);
+        p.bface_face.push_back(f);
+        p.bface_id.push_back(id);
+      }
+    }
+
+  // ---- per-shard halo and face lists
+  p.halo_begin.assign(p.n_shards + 1, 0);
+  p.face_begin.assign(p.n_shards + 1, 0);
+  p.cell_face.assign((size_t)p.n_shards * 4 * kShard, kNoFace);
+  p.lrbt.assign((size_t)p.n_shards * 4 * kShard, -1);
+  p.max_halo = p.max_faces = 0;
+  std::unordered_map<int32_t, int32_t> halo_slot;
+  for (int s = 0; s < p.n_shards; ++s) {
+    halo_slot.clear();
+    const auto &cells = shard_cells[s];
+    const int face0 = (int)p.faces.size();
+    auto slot_of = [&](int c) -> int {
+      if (shard_of[c] == s) return local_of[c];
+      auto it = halo_slot.find(c);
+      if (it != halo_slot.end()) return it->second;
+      const int sl = kShard + (int)halo_slot.size();
+      halo_slot.emplace(c, sl);
+      p.halo_cells.push_back(p.iid[c]);
+      return sl;
+    };
+    for (int l = 0; l < (int)cells.size(); ++l) {
+      const int c = cells[l];
+      for (int f = 0; f < 4; ++f) {
+        const int nb = mesh.cell_face_neighbor[(size_t)c * 4 + f];
+        const int code = mesh.cell_face_neighbor_face[(size_t)c * 4 + f];
+        const size_t ref = ((size_t)s * 4 + f) * kShard + l;
+        if (nb == DFLO_NBR_NONE) continue;
+        if (nb < 0) {
+          const int k = (int)p.faces.size() - face0;
+          p.faces.push_back({(uint32_t)l | ((uint32_t)f << 16) | (1u << 18), bface_of[(size_t)c * 4 + f]});
+          p.cell_face[ref] = (uint16_t)k;
+          continue;
+        }
+        if (nb >= n) { err = "neighbour index out of range"; return DFLO_ERR_BAD_PARAM; }
+        const int nf = code & 3;
+        const bool flip = (code & 4) != 0;
+        p.lrbt[ref] = p.iid[nb];  // cartesian meshes: faces 0..3 are the left/right/bottom/top neighbours
+        const bool integrator = gid(c) < gid(nb) || (gid(c) == gid(nb) && f < nf);
+        const bool nb_inside = shard_of[nb] == s;
+        if (nb_inside && !integrator) continue;  // the integrating cell creates the record and both references
+        const int k = (int)p.faces.size() - face0;
+        if (k >= 0x3FFF) { err = "too many faces in a shard"; return DFLO_ERR_BAD_PARAM; }
+        if (integrator) {
+          const int so = slot_of(nb);
+          p.faces.push_back({(uint32_t)l | ((uint32_t)f << 16) | ((uint32_t)flip << 19) | ((uint32_t)nf << 20), so});
+          p.cell_face[ref] = (uint16_t)k;
+          if (nb_inside)
+            p.cell_face[((size_t)s * 4 + nf) * kShard + local_of[nb]] = (uint16_t)(k | (flip ? 0x4000 : 0) | 0x8000);
+        } else {  // neighbour outside the shard integrates; we still evaluate its flux
+          const int so = slot_of(nb);
+          p.faces.push_back({(uint32_t)so | ((uint32_t)nf << 16) | ((uint32_t)flip << 19) | ((uint32_t)f << 20), l});
+          p.cell_face[ref] = (uint16_t)(k | (flip ? 0x4000 : 0) | 0x8000);
+        }
+      }
+    }
+    p.halo_begin[s + 1] = (int)p.halo_cells.size();
+    p.face_begin[s + 1] = (int)p.faces.size();
+    p.max_halo = std::max(p.max_halo, p.halo_begin[s + 1] - p.halo_begin[s]);
+    p.max_faces = std::max(p.max_faces, p.face_begin[s + 1] - p.face_begin[s]);
+  }
+
+  // ---- geometry in internal order
+  if (mesh.mapping == DFLO_MAP_CARTESIAN) {
+    p.cell_h.assign(p.n_slots, p.h);
+    for (int c = 0; c < n; ++c) p.cell_h[p.iid[c]] = hx[c];
+  } else {
+    p.cell_vert.assign((size_t)8 * p.n_slots, 0.0);
+    // padding slots get a unit square so that metric terms stay finite
+    for (int sl = 0; sl < p.n_slots; ++sl) {
+      const double unit[8] = {0, 0, 1, 0, 0, 1, 1, 1};
+      for (int k = 0; k < 8; ++k) p.cell_vert[(size_t)k * p.n_slots + sl] = unit[k];
+    }
+    for (int c = 0; c < n; ++c)
+      for (int k = 0; k < 8; ++k) p.cell_vert[(size_t)k * p.n_slots + p.iid[c]] = V[(size_t)c * 8 + k];
+  }
+  return DFLO_OK;
+}
+
+}  // namespace dflo

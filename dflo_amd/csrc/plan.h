@@ -1,0 +1,66 @@
+// plan.h -- the CSR-like element/face index layout of the device engine.
+//
+// deal.II's DoFHandler + MeshWorker::loop (src/assemble_explicit.cc:440-451) are flattened once
+// into "shards": groups of up to kShard cells stored contiguously and structure-of-arrays on the
+// device (one wavefront lane per cell).  For every shard the plan lists
+//   - its halo cells (face neighbours living in other shards or in the ghost range),
+//   - its faces, each integrated exactly once from the cell with the smaller global id as
+//     MeshWorker does; faces on the shard rim are listed by both shards with the SAME
+//     integrating side, so both evaluate a bit-identical flux,
+//   - for each cell and local face the slot of that face's numerical flux and its sign.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/dflo_hip.h"
+
+namespace dflo {
+
+constexpr int kShard = 64;  // cells per shard = lanes per wavefront
+
+// face record, 8 bytes
+//   w0: bits 0-15 slot of the integrating cell in the shard's LDS image (own cells first, then halo)
+//       bits 16-17 local face number seen from the integrating cell
+//       bit  18    1 = boundary face
+//       bit  19    1 = face points run opposite on the other side
+//       bits 20-21 local face number seen from the other cell
+//   w1: slot of the other cell, or the boundary-face index
+struct FaceRec {
+  uint32_t w0;
+  int32_t w1;
+};
+
+// per (cell, local face) reference, 16 bit:
+//   bits 0-13 face index inside the shard, bit 14 flip, bit 15: 1 = this cell is the "other" side
+//   (receives +flux), 0xFFFF = no face (ghost rim)
+constexpr uint16_t kNoFace = 0xFFFF;
+
+struct Plan {
+  int n_cells = 0, n_owned = 0;      // user numbering
+  int n_shards = 0;                  // shards of owned cells
+  int n_ghost_shards = 0;            // shards holding ghost cells (never integrated)
+  int n_slots = 0;                   // (n_shards + n_ghost_shards) * kShard internal cell slots
+  std::vector<int32_t> iid;          // user cell -> internal slot
+  std::vector<int32_t> user_of;      // internal slot -> user cell or -1 (padding)
+  std::vector<int32_t> shard_count;  // cells per owned shard
+  std::vector<int32_t> halo_begin;   // [n_shards+1]
+  std::vector<int32_t> halo_cells;   // internal slots
+  std::vector<int32_t> face_begin;   // [n_shards+1]
+  std::vector<FaceRec> faces;
+  std::vector<uint16_t> cell_face;   // [n_shards][4][kShard]
+  std::vector<int32_t> lrbt;         // [n_shards][4][kShard] internal slot of the left/right/bottom/top
+                                     // neighbour or -1 (src/claw.cc:336-380)
+  int max_halo = 0, max_faces = 0;
+  // boundary faces in MeshWorker order (cell ascending, face ascending)
+  std::vector<int32_t> bface_cell, bface_face, bface_id;
+  bool uniform_h = false;
+  double h = 0.0;
+  std::vector<double> cell_h;        // [n_slots] (cartesian)
+  std::vector<double> cell_vert;     // [8][n_slots] (q1 mapping), component-major
+};
+
+// Returns DFLO_OK or an error code with a message.
+int build_plan(const dflo_mesh_t &mesh, int shard_ex, int shard_ey, Plan &plan, std::string &err);
+
+}  // namespace dflo

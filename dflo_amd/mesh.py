@@ -1,0 +1,130 @@
+"""Flat mesh description (dflo_mesh_t) -- what Triangulation + DoFHandler hold in dflo
+(src/claw.h:178-185, src/claw.cc:957-967)."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import lib, DfloError
+
+
+class Mesh:
+    """Owns a dflo_mesh_t built by the C++ host library."""
+
+    def __init__(self, ptr, comm=None):
+        self._ptr = ptr
+        self.comm = comm  # (send_cells, send_offsets, recv_offsets) for partitioned meshes
+
+    def __del__(self):
+        try:
+            if self._ptr:
+                lib.dflo_mesh_free(self._ptr)
+                self._ptr = None
+        except Exception:
+            pass
+
+    # ---- builders
+    @staticmethod
+    def cartesian(nx, ny, x0, y0, h, side_bc, degree):
+        """nx x ny squares; side_bc = boundary ids of (x-min, x-max, y-min, y-max), -1 = periodic."""
+        out = C.POINTER(_lib.MeshStruct)()
+        bc = np.asarray(side_bc, dtype=np.int32)
+        rc = lib.dflo_mesh_cartesian(nx, ny, float(x0), float(y0), float(h), _lib.iptr(bc), degree, C.byref(out))
+        if rc:
+            raise DfloError(rc, lib.dflo_mesh_last_error().decode())
+        return Mesh(out)
+
+    @staticmethod
+    def from_quads(vertices, quads, bedges=None, bedge_id=None, degree=1):
+        v = np.ascontiguousarray(vertices, dtype=np.float64)
+        q = np.ascontiguousarray(quads, dtype=np.int32)
+        be = np.ascontiguousarray(bedges if bedges is not None else np.zeros((0, 2)), dtype=np.int32)
+        bi = np.ascontiguousarray(bedge_id if bedge_id is not None else np.zeros(len(be)), dtype=np.int32)
+        out = C.POINTER(_lib.MeshStruct)()
+        rc = lib.dflo_mesh_from_quads(len(v), _lib.dptr(v), len(q), _lib.iptr(q), len(be), _lib.iptr(be),
+                                      _lib.iptr(bi), degree, C.byref(out))
+        if rc:
+            raise DfloError(rc, lib.dflo_mesh_last_error().decode())
+        return Mesh(out)
+
+    @staticmethod
+    def read_gmsh(path, degree, mapping="cartesian"):
+        out = C.POINTER(_lib.MeshStruct)()
+        rc = lib.dflo_mesh_read_gmsh(str(path).encode(), degree, _lib.MAPPING[mapping], C.byref(out))
+        if rc:
+            raise DfloError(rc, lib.dflo_mesh_last_error().decode())
+        return Mesh(out)
+
+    def partition(self, n_ranks, rank):
+        """Owned + one ghost layer sub-mesh of `rank` (replaces parallel::distributed::Triangulation)."""
+        out = C.POINTER(_lib.MeshStruct)()
+        sc, so, ro = (C.POINTER(C.c_int32)(), C.POINTER(C.c_int32)(), C.POINTER(C.c_int32)())
+        rc = lib.dflo_mesh_partition(self._ptr, n_ranks, rank, C.byref(out), C.byref(sc), C.byref(so), C.byref(ro))
+        if rc:
+            raise DfloError(rc, lib.dflo_mesh_last_error().decode())
+        so_a = np.ctypeslib.as_array(so, shape=(n_ranks + 1,)).copy()
+        ro_a = np.ctypeslib.as_array(ro, shape=(n_ranks + 1,)).copy()
+        sc_a = np.ctypeslib.as_array(sc, shape=(max(int(so_a[-1]), 1),)).copy()[: int(so_a[-1])]
+        return Mesh(out, comm=(sc_a, so_a, ro_a))
+
+    # ---- views
+    @property
+    def struct(self):
+        return self._ptr.contents
+
+    @property
+    def n_cells(self):
+        return self.struct.n_cells
+
+    @property
+    def n_owned(self):
+        return self.struct.n_owned_cells
+
+    @property
+    def degree(self):
+        return self.struct.degree
+
+    @property
+    def n_s(self):
+        return (self.degree + 1) ** 2
+
+    @property
+    def ndof(self):
+        return 4 * self.n_s
+
+    @property
+    def vertices(self):
+        return np.ctypeslib.as_array(self.struct.cell_vertices, shape=(self.n_cells, 4, 2))
+
+    @property
+    def neighbors(self):
+        return np.ctypeslib.as_array(self.struct.cell_face_neighbor, shape=(self.n_cells, 4))
+
+    @property
+    def neighbor_faces(self):
+        return np.ctypeslib.as_array(self.struct.cell_face_neighbor_face, shape=(self.n_cells, 4))
+
+    @property
+    def global_ids(self):
+        if not self.struct.cell_global_id:
+            return np.arange(self.n_cells, dtype=np.int64)
+        return np.ctypeslib.as_array(self.struct.cell_global_id, shape=(self.n_cells,))
+
+    def set_mapping(self, mapping):
+        self.struct.mapping = _lib.MAPPING[mapping]
+
+    def support_points(self):
+        """Real-space support points of the Qk DoFs, [n_cells, n_s, 2] (src/ic.cc:104-121)."""
+        xy = np.empty((self.n_cells, self.n_s, 2))
+        rc = lib.dflo_mesh_support_points(self._ptr, _lib.dptr(xy))
+        if rc:
+            raise DfloError(rc, lib.dflo_mesh_last_error().decode())
+        return xy
+
+    def interpolate(self, fn):
+        """VectorTools::interpolate for Qk (src/ic.cc:104-121): fn(x, y) -> [mx, my, rho, E] arrays.
+        Returns the state vector in dflo's DoF order [cell][comp][node]."""
+        xy = self.support_points()
+        w = fn(xy[..., 0], xy[..., 1])  # 4 arrays [n_cells, n_s]
+        u = np.stack([np.broadcast_to(np.asarray(c, dtype=np.float64), xy.shape[:2]) for c in w], axis=1)
+        return np.ascontiguousarray(u).reshape(-1)

@@ -1,0 +1,47 @@
+"""Initial / boundary data of the example problems, evaluated on the host (the reference does this
+with FunctionParser or hard-coded Function classes; it is outside the device path)."""
+import numpy as np
+
+GAMMA = 1.4  # src/equation.cc:33
+
+
+def isentropic_vortex(x, y, beta=5.0, x0=0.0, y0=0.0):
+    """IsentropicVortex::vector_value, src/ic.cc:44-61 with (beta, x0, y0) = (5,0,0) (src/ic.cc:110)."""
+    a1 = 0.5 * beta / np.pi
+    a2 = (GAMMA - 1.0) * a1 ** 2 / 2.0
+    r2 = (x - x0) ** 2 + (y - y0) ** 2
+    rho = (1.0 - a2 * np.exp(1.0 - r2)) ** (1.0 / (GAMMA - 1.0))
+    vex = -a1 * (y - y0) * np.exp(0.5 * (1.0 - r2))
+    vey = +a1 * (x - x0) * np.exp(0.5 * (1.0 - r2))
+    pre = rho ** GAMMA
+    return rho * vex, rho * vey, rho, pre / (GAMMA - 1.0) + 0.5 * rho * (vex * vex + vey * vey)
+
+
+def sod(x, y):
+    """examples/sod_shock_tube/input.prm:39-44"""
+    left = x <= 0.5
+    z = np.zeros_like(x)
+    return z, z, np.where(left, 1.0, 0.125), np.where(left, 2.5, 0.25)
+
+
+def double_mach(x, y, t=0.0, top=False):
+    """examples/double_mach_reflection/input.prm:35-62 (IC: shock x < 1/6 + y/sqrt(3); top BC uses (1+20t))."""
+    s = (1.0 / 6.0 + (1.0 + 20.0 * t) / np.sqrt(3.0)) if top else (1.0 / 6.0 + y / np.sqrt(3.0))
+    post = x < s
+    return (np.where(post, 57.1576766498, 0.0), np.where(post, -33.0, 0.0), np.where(post, 8.0, 1.4),
+            np.where(post, 563.5, 2.5))
+
+
+def forward_step_inflow(x, y):
+    """examples/forward_step/input.prm:19-47"""
+    o = np.ones_like(x)
+    return 4.2 * o, 0.0 * o, 1.4 * o, 8.8 * o
+
+
+def smooth_perturbation(x, y, L=10.0):
+    """Seedless smooth state for residual-parity tests: uniform flow + sines."""
+    rho = 1.0 + 0.2 * np.sin(2 * np.pi * x / L + 0.3) * np.cos(2 * np.pi * y / L)
+    u = 0.5 + 0.3 * np.cos(2 * np.pi * x / L) * np.sin(2 * np.pi * y / L + 0.1)
+    v = -0.2 + 0.25 * np.sin(2 * np.pi * (x + y) / L)
+    p = 1.0 + 0.3 * np.cos(2 * np.pi * x / L + 0.7) * np.cos(2 * np.pi * y / L - 0.2)
+    return rho * u, rho * v, rho, p / (GAMMA - 1.0) + 0.5 * rho * (u * u + v * v)

@@ -1,0 +1,242 @@
+/*
+ * dflo_hip.h -- C ABI of the MI355X-native explicit DG residual + SSP-RK engine
+ * that replaces dflo's assemble_system / solve / iterate_explicit seam.
+ *
+ * The reference (cpraveen/dflo) has no plugin or FFI interface for this path:
+ * the path is a set of private member functions of ConservationLaw<2> working
+ * on member dealii::Vector<double>s.  Every entry point below names the
+ * reference function(s) it replaces (paths relative to the reference root).
+ * INTEGRATION.md shows the patch a dflo maintainer would apply to call them.
+ *
+ * Conventions
+ *   - plain C, no exceptions cross the boundary; every function returns
+ *     DFLO_OK (0) or a negative dflo_status; dflo_hip_last_error() gives text.
+ *     (reference convention replaced: AssertThrow -> catch in main ->
+ *     exit code 1, src/main.cc:56-78)
+ *   - host arrays belong to the caller, the engine copies what it needs;
+ *     device buffers belong to the handle.
+ *   - a handle is driven by one host thread (as dflo's time loop is,
+ *     src/claw.cc:1026-1129).
+ *   - state vectors use dflo's layout: component order [x-mom, y-mom, density,
+ *     energy] (src/equation.h:25-28); DoF index = cell*ndof + comp*n_s + node
+ *     with node = a + N*b (x fastest) for Qk at Gauss points
+ *     (FE_DGQArbitraryNodes(QGauss<1>(k+1)), src/main.cc:40) and
+ *     node = modal index for Pk (FE_DGP, src/claw.cc:107-113).
+ */
+#ifndef DFLO_HIP_H
+#define DFLO_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DFLO_N_COMP 4
+#define DFLO_MAX_BOUNDARIES 10 /* Parameters::AllParameters::max_n_boundaries, src/parameters.h:370 */
+#define DFLO_MAX_DEGREE 3
+
+typedef enum {
+  DFLO_OK = 0,
+  DFLO_ERR_BAD_PARAM = -1,           /* consistency checks, src/parameters.cc:536-550 */
+  DFLO_ERR_NONSQUARE_CELL = -2,      /* "Cell is not square", src/claw.cc:219 */
+  DFLO_ERR_NEGATIVE_MEAN_STATE = -3, /* "Fatal: Negative states", src/positivity.cc:28-38 */
+  DFLO_ERR_POSITIVITY_NO_ROOT = -4,  /* exit(0) in src/positivity.cc:160-169 */
+  DFLO_ERR_HIP = -5,                 /* HIP runtime failure / no device */
+  DFLO_ERR_COMM = -6,                /* halo plumbing misuse */
+  DFLO_ERR_UNSUPPORTED = -7,         /* feature outside the hot-path scope */
+  DFLO_ERR_NOMEM = -8
+} dflo_status;
+
+/* Parameters::Flux::FluxType, src/parameters.h:229 */
+typedef enum { DFLO_FLUX_LXF = 0, DFLO_FLUX_SW = 1, DFLO_FLUX_KFVS = 2, DFLO_FLUX_ROE = 3, DFLO_FLUX_HLLC = 4 } dflo_flux;
+/* EulerEquations::BoundaryKind, src/equation.h:862-869 */
+typedef enum { DFLO_BC_INFLOW = 0, DFLO_BC_OUTFLOW = 1, DFLO_BC_SLIP = 2, DFLO_BC_PRESSURE = 3, DFLO_BC_FARFIELD = 4 } dflo_bc_kind;
+/* Parameters::Limiter::LimiterType, src/parameters.h:241 */
+typedef enum { DFLO_LIMITER_NONE = 0, DFLO_LIMITER_TVB = 1 } dflo_limiter;
+/* AllParameters::BasisType / MappingType, src/parameters.h:384-387 */
+typedef enum { DFLO_BASIS_QK = 0, DFLO_BASIS_PK = 1 } dflo_basis;
+typedef enum { DFLO_MAP_Q1 = 0, DFLO_MAP_Q2 = 1, DFLO_MAP_CARTESIAN = 2 } dflo_mapping;
+
+/* face neighbour encoding: >=0 neighbour cell, DFLO_NBR_BOUNDARY(id) on a
+ * physical boundary, DFLO_NBR_NONE for a face of a ghost cell that leads
+ * outside the local halo (never integrated). */
+#define DFLO_NBR_BOUNDARY(id) (-1 - (int32_t)(id))
+#define DFLO_NBR_BOUNDARY_ID(n) (-1 - (int32_t)(n))
+#define DFLO_NBR_NONE (-1000000)
+
+/*
+ * Flat description of what dflo's Triangulation + DoFHandler hold
+ * (src/claw.h:178-185).  deal.II reference-cell conventions: vertices
+ * lexicographic v0=(0,0) v1=(1,0) v2=(0,1) v3=(1,1); faces 0:x=0 1:x=1 2:y=0
+ * 3:y=1; face quadrature points ordered by the increasing free coordinate.
+ */
+typedef struct dflo_mesh {
+  int32_t n_cells;        /* owned + ghost cells; owned cells come first */
+  int32_t n_owned_cells;  /* == n_cells on a single device */
+  int32_t degree;         /* k, 1..DFLO_MAX_DEGREE */
+  int32_t basis;          /* dflo_basis */
+  int32_t mapping;        /* dflo_mapping (q2 unsupported) */
+  const double *cell_vertices;            /* [n_cells][4][2] */
+  const int32_t *cell_face_neighbor;      /* [n_cells][4] */
+  const int32_t *cell_face_neighbor_face; /* [n_cells][4]: face number seen from the neighbour, +4 if the
+                                             face points run in the opposite direction on the two sides,
+                                             +8 if the link is a periodic identification (the MPI variant
+                                             integrates those from both sides, src_mpi/assemble_explicit.cc:186-260;
+                                             the engine treats them as interior faces) */
+  const int64_t *cell_global_id;          /* [n_cells] or NULL: id in the undecomposed mesh; the face
+                                             integrating side is the smaller id (MeshWorker visits an
+                                             interior face once, from the earlier cell) */
+} dflo_mesh_t;
+
+/* Scalars of Parameters::AllParameters the path reads (src/parameters.h:363-411). */
+typedef struct dflo_params {
+  int32_t flux_type;      /* dflo_flux */
+  int32_t limiter_type;   /* dflo_limiter */
+  int32_t char_lim;       /* "characteristic limiter" */
+  int32_t pos_lim;        /* "positivity limiter" */
+  int32_t global_time_step; /* 1: "time step type = global", 0: local */
+  int32_t n_rk;           /* 0: by degree as src/claw.cc:141-159; else override */
+  double gravity;         /* src/parameters.cc:346-348 */
+  double cfl;
+  double time_step;
+  double final_time;
+  double M;               /* TVB constant */
+  double beta;
+  int32_t bc_kind[DFLO_MAX_BOUNDARIES]; /* dflo_bc_kind per boundary id */
+} dflo_params_t;
+
+typedef struct dflo_hip_engine *dflo_hip_handle;
+
+/* ---------------------------------------------------------------- lifetime */
+
+/* Replaces setup_system() + compute_inv_mass_matrix() + neighbour maps
+ * (src/claw.cc:229-258, 271-386) and setup_mesh_worker (src/claw.cc:417-437).
+ * device_id: HIP device ordinal. */
+int dflo_hip_create(const dflo_mesh_t *mesh, const dflo_params_t *params, int device_id, dflo_hip_handle *out);
+int dflo_hip_destroy(dflo_hip_handle h);
+const char *dflo_hip_last_error(dflo_hip_handle h); /* h may be NULL: error of the last failed create */
+
+/* Launch all work of this handle on an existing HIP stream (hipStream_t passed
+ * as void*); NULL = the handle's own stream. */
+int dflo_hip_set_stream(dflo_hip_handle h, void *hip_stream);
+
+/* -------------------------------------------------------------- state I/O */
+
+int64_t dflo_hip_n_dofs(dflo_hip_handle h);     /* n_cells * ndof */
+int32_t dflo_hip_dofs_per_cell(dflo_hip_handle h);
+int32_t dflo_hip_n_rk(dflo_hip_handle h);       /* stages per step, src/claw.cc:141-159 */
+
+/* current_solution = old_solution = u  (src/ic.cc:118-120); also recomputes
+ * cell averages as run() does after the IC (src/claw.cc:997). */
+int dflo_hip_set_solution(dflo_hip_handle h, const double *u);
+int dflo_hip_get_solution(dflo_hip_handle h, double *u);
+/* cell_average, [n_cells][4] (src/claw.cc:562-597) */
+int dflo_hip_get_cell_average(dflo_hip_handle h, double *avg);
+
+/* Boundary faces in the order MeshWorker meets them (cell ascending, face
+ * ascending).  xy: [n_bfaces][N][2] quadrature points = what
+ * fe_v.get_quadrature_points() hands to FunctionParser::vector_value_list
+ * (src/assemble_explicit.cc:163-165). Any pointer may be NULL. */
+int32_t dflo_hip_n_boundary_faces(dflo_hip_handle h);
+int dflo_hip_boundary_faces(dflo_hip_handle h, int32_t *cell, int32_t *face, int32_t *boundary_id, double *xy);
+/* values: [n_bfaces][N][4] boundary function values. which=0: used by RK stage 0
+ * (bc_time = t), which=1: used by later stages (bc_time = t+dt), src/claw.cc:736-745. */
+int dflo_hip_set_boundary_values(dflo_hip_handle h, int which, const double *values);
+
+/* ------------------------------------------------------------- hot path */
+
+/* assemble_system(IntegratorExplicit&) (src/assemble_explicit.cc:433-452): rhs of the current
+ * solution with the current cell averages and boundary set `which`; rhs_out [n_dofs], dflo layout. */
+int dflo_hip_residual(dflo_hip_handle h, int which, double *rhs_out);
+
+/* compute_time_step() (src/claw.cc:444-557): global dt from the current cell
+ * averages (cartesian) or point values (q1), time_step cap and final_time clip. */
+int dflo_hip_compute_dt(dflo_hip_handle h, double elapsed_time, double *dt);
+
+/* iterate_explicit() (src/claw.cc:726-772) + old_solution = current_solution
+ * (src/claw.cc:1110): all RK stages, each = residual, dt*M^-1, SSP combine,
+ * cell average, TVB limiter, positivity limiter.  res_norm0/res_norm: l2 norm of
+ * the rhs in the first/last stage (src/claw.cc:749-750); either may be NULL. */
+int dflo_hip_step(dflo_hip_handle h, double dt, double *res_norm0, double *res_norm);
+
+/* One RK stage `rk` of iterate_explicit (fine-grained seam for multi-device
+ * drivers that exchange halos between stages). dt<0: use the device-resident dt. */
+int dflo_hip_stage(dflo_hip_handle h, int rk, double dt);
+int dflo_hip_end_step(dflo_hip_handle h); /* old_solution = current_solution */
+
+/* n_steps x { compute_time_step ; iterate_explicit ; elapsed_time += dt } with
+ * dt and time resident on the device (no host round trip inside the loop);
+ * the production loop of run() (src/claw.cc:1026-1110) without output. */
+int dflo_hip_advance(dflo_hip_handle h, int n_steps, double *elapsed_time_inout);
+
+/* compute_cell_average / apply_limiter / apply_positivity_limiter as separate
+ * calls (src/claw.cc:562, src/limiter.cc:36, src/positivity.cc:17) -- what run()
+ * does once after the initial condition (src/claw.cc:997-1001). */
+int dflo_hip_compute_cell_average(dflo_hip_handle h);
+int dflo_hip_apply_limiter(dflo_hip_handle h);
+int dflo_hip_apply_positivity_limiter(dflo_hip_handle h);
+
+/* Device-side failure flags raised by kernels, checked here (no mid-kernel abort):
+ * returns DFLO_OK, DFLO_ERR_NEGATIVE_MEAN_STATE or DFLO_ERR_POSITIVITY_NO_ROOT. */
+int dflo_hip_check(dflo_hip_handle h);
+int dflo_hip_synchronize(dflo_hip_handle h);
+
+/* Average duration (ms) of the stage kernel launches since the last reset,
+ * measured with HIP events on the engine's stream; n receives the launch count. */
+int dflo_hip_stage_timing(dflo_hip_handle h, int enable, double *avg_ms, int64_t *n);
+
+/* ------------------------------------------------ multi-device halo seam */
+/* Replaces LA::distributed::Vector::update_ghost_values() of the MPI variant
+ * (src_mpi/claw.cc:793, src_mpi/limiter.cc:232).  The engine owns cells
+ * [0,n_owned) and reads ghost cells [n_owned,n_cells).  pack gathers the DoFs
+ * of the listed owned cells into a contiguous device buffer ([n][ndof]);
+ * ghost_ptr returns the device address of the ghost range of the current
+ * solution so a transport (RCCL send/recv via torch.distributed) can receive
+ * straight into it. */
+int dflo_hip_set_send_cells(dflo_hip_handle h, int32_t n, const int32_t *cells);
+int dflo_hip_pack_send(dflo_hip_handle h, void *device_buffer);
+int dflo_hip_ghost_ptr(dflo_hip_handle h, void **device_ptr, int64_t *n_doubles);
+int dflo_hip_ghost_updated(dflo_hip_handle h); /* recompute ghost cell averages after a receive */
+/* device address of {dt, res_norm_sq} scalars for 8-byte all-reduces (src_mpi/claw.cc:579,777) */
+int dflo_hip_scalar_ptrs(dflo_hip_handle h, void **dt_ptr, void **res_ptr);
+/* dt_ptr[2] holds the raw CFL minimum of this device; after an external all-reduce(min) of that
+ * double, re-apply the time_step cap and final_time clip (src/claw.cc:468-476) into dt_ptr[0]. */
+int dflo_hip_apply_dt_rules(dflo_hip_handle h);
+
+/* ------------------------------------------- host-side mesh construction */
+/* What GridIn::read_msh + Triangulation hand to dflo (src/claw.cc:957-967),
+ * flattened.  The returned mesh owns its arrays; free with dflo_mesh_free. */
+
+/* nx x ny squares on [x0,x0+nx*h] x [y0,y0+ny*h], cell c = i + nx*j.
+ * side_bc[4] = boundary id on the faces x=min, x=max, y=min, y=max, or -1 for
+ * a periodic side (src_mpi semantics, src_mpi/assemble_explicit.cc:186-260). */
+int dflo_mesh_cartesian(int32_t nx, int32_t ny, double x0, double y0, double h, const int32_t side_bc[4],
+                        int32_t degree, dflo_mesh_t **out);
+/* General conforming quad mesh: vertices [n_vertices][2], quads [n_quads][4]
+ * (any consistent vertex order; re-ordered to deal.II's), boundary edges
+ * [n_bedges][2] vertex pairs with ids.  mapping = DFLO_MAP_Q1. */
+int dflo_mesh_from_quads(int32_t n_vertices, const double *vertices, int32_t n_quads, const int32_t *quads,
+                         int32_t n_bedges, const int32_t *bedges, const int32_t *bedge_id, int32_t degree,
+                         dflo_mesh_t **out);
+/* Gmsh v2 ASCII .msh with quads + physical lines (what "gmsh -2 file.geo" writes, README.md:70-72). */
+int dflo_mesh_read_gmsh(const char *path, int32_t degree, int32_t mapping, dflo_mesh_t **out);
+/* Sub-mesh of rank `rank` of `n_ranks` (contiguous slabs of the cell order after a
+ * coordinate sort) with one layer of face-neighbour ghost cells -- the flat
+ * equivalent of parallel::distributed::Triangulation's owned+ghost view
+ * (src_mpi/claw.h:220).  send_cells/send_offsets (size n_ranks+1) list owned cells
+ * to send per destination rank; recv_offsets the ghost ranges per source rank
+ * (ghost cells are ordered by source rank). Arrays owned by the mesh. */
+int dflo_mesh_partition(const dflo_mesh_t *mesh, int32_t n_ranks, int32_t rank, dflo_mesh_t **out,
+                        const int32_t **send_cells, const int32_t **send_offsets, const int32_t **recv_offsets);
+void dflo_mesh_free(dflo_mesh_t *mesh);
+const char *dflo_mesh_last_error(void);
+
+/* Initial condition by nodal interpolation for Qk (VectorTools::interpolate, src/ic.cc:104-121):
+ * xy [n_cells][n_s][2] = support point coordinates in dflo's DoF order. */
+int dflo_mesh_support_points(const dflo_mesh_t *mesh, double *xy);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DFLO_HIP_H */
