@@ -62,7 +62,8 @@ SYMBOLS = [
     "dflo_hip_set_boundary_values", "dflo_hip_residual", "dflo_hip_compute_dt", "dflo_hip_step", "dflo_hip_stage",
     "dflo_hip_end_step", "dflo_hip_advance", "dflo_hip_compute_cell_average", "dflo_hip_apply_limiter",
     "dflo_hip_apply_positivity_limiter", "dflo_hip_check", "dflo_hip_synchronize", "dflo_hip_stage_timing",
-    "dflo_hip_set_send_cells", "dflo_hip_pack_send", "dflo_hip_ghost_ptr", "dflo_hip_ghost_updated",
+    "dflo_hip_set_send_cells", "dflo_hip_pack_send", "dflo_hip_pack_send_avg", "dflo_hip_unpack_ghost",
+    "dflo_hip_unpack_ghost_avg", "dflo_hip_n_ghost_cells", "dflo_hip_stage_update", "dflo_hip_stage_limit",
     "dflo_hip_scalar_ptrs", "dflo_hip_apply_dt_rules",
     "dflo_mesh_cartesian", "dflo_mesh_from_quads", "dflo_mesh_read_gmsh", "dflo_mesh_partition", "dflo_mesh_free",
     "dflo_mesh_last_error", "dflo_mesh_support_points",
@@ -115,8 +116,12 @@ _sig("dflo_hip_synchronize", C.c_int, _H)
 _sig("dflo_hip_stage_timing", C.c_int, _H, C.c_int, _dp, C.POINTER(C.c_int64))
 _sig("dflo_hip_set_send_cells", C.c_int, _H, C.c_int32, _ip)
 _sig("dflo_hip_pack_send", C.c_int, _H, C.c_void_p)
-_sig("dflo_hip_ghost_ptr", C.c_int, _H, C.POINTER(C.c_void_p), C.POINTER(C.c_int64))
-_sig("dflo_hip_ghost_updated", C.c_int, _H)
+_sig("dflo_hip_pack_send_avg", C.c_int, _H, C.c_void_p)
+_sig("dflo_hip_unpack_ghost", C.c_int, _H, C.c_void_p)
+_sig("dflo_hip_unpack_ghost_avg", C.c_int, _H, C.c_void_p)
+_sig("dflo_hip_n_ghost_cells", C.c_int, _H)
+_sig("dflo_hip_stage_update", C.c_int, _H, C.c_int, C.c_double)
+_sig("dflo_hip_stage_limit", C.c_int, _H)
 _sig("dflo_hip_scalar_ptrs", C.c_int, _H, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p))
 _sig("dflo_hip_apply_dt_rules", C.c_int, _H)
 _sig("dflo_mesh_cartesian", C.c_int, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double, _ip, C.c_int32,

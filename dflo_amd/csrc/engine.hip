@@ -505,6 +505,12 @@ __global__ void unpack_ghost_kernel(const double *buf, double *U, double *avg, i
     avg[((size_t)(slot >> 6) * 4 + c) * 64 + (slot & 63)] = m;
   }
 }
+__global__ void unpack_ghost_avg_kernel(const double *buf, double *avg, int first_slot, int n_ghost) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= n_ghost) return;
+  const int slot = first_slot + g;
+  for (int c = 0; c < 4; ++c) avg[((size_t)(slot >> 6) * 4 + c) * 64 + (slot & 63)] = buf[(size_t)g * 4 + c];
+}
 // compute_cell_average (src/claw.cc:562-597) for all slots (owned and ghost shards)
 __global__ void average_kernel(const double *U, double *avg, int ndof, KBasis kb, int N) {
   const int shard = blockIdx.x;
@@ -540,7 +546,7 @@ struct FinalArgs {
   double *res_sq;  // [3] per stage
   double *dt_dev;  // [0] dt, [1] elapsed time, [2] raw min before rules
   int n_shards, stage, do_res, do_dt, advance_time;
-  double time_step, final_time;
+  double time_step, final_time, dt_host;
 };
 __global__ __launch_bounds__(256) void finalize_kernel(const FinalArgs a) {
   __shared__ double sres[4], smin[4];
@@ -562,7 +568,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(const FinalArgs a) {
     if (a.do_dt) {
       double t = a.dt_dev[1];
       if (a.advance_time) {  // elapsed_time += global_dt (src/claw.cc:1072) for the step just done
-        t += a.dt_dev[0];
+        t += a.dt_host >= 0.0 ? a.dt_host : a.dt_dev[0];
         a.dt_dev[1] = t;
       }
       double dt = fmin(fmin(smin[0], smin[1]), fmin(smin[2], smin[3]));
@@ -612,6 +618,8 @@ struct dflo_hip_engine {
   double *shard_res = nullptr, *shard_dtmin = nullptr, *res_sq = nullptr, *dt_dev = nullptr;
   int *flags = nullptr;
   std::vector<double> bface_xy;  // [n_bfaces][N][2]
+  int pending_rk = -1;
+  double pending_dt = -1.0;
   int32_t *d_send_slots = nullptr;
   int n_send = 0;
   double *ghost_stage = nullptr;
@@ -713,8 +721,8 @@ void time_collect(dflo_hip_engine *h) {
   h->ev_used = 0;
 }
 
-// one RK stage: residual + update kernel, reductions, limiter
-int launch_stage(dflo_hip_engine *h, int rk, double dt_host, double *rhs_out, int which_override) {
+// residual + update kernel of one RK stage
+int launch_update(dflo_hip_engine *h, int rk, double dt_host, double *rhs_out, int which_override) {
   const Plan &p = h->plan;
   const bool last = rk == h->n_rk - 1;
   int out;
@@ -751,7 +759,6 @@ int launch_stage(dflo_hip_engine *h, int rk, double dt_host, double *rhs_out, in
   a.stride = h->stride;
   a.max_fp = h->max_fp;
   a.uniform_h = p.uniform_h ? 1 : 0;
-  const bool limited = h->prm.limiter_type != DFLO_LIMITER_NONE || h->prm.pos_lim;
   a.want_dt = last ? 1 : 0;
   a.degree = h->degree;
   a.kb = h->kb;
@@ -761,29 +768,50 @@ int launch_stage(dflo_hip_engine *h, int rk, double dt_host, double *rhs_out, in
   time_end(h);
   HIPCHK(h, hipGetLastError());
   if (rhs_out) return DFLO_OK;
+  // ghost cells are not advanced here: carry them over so the new buffers stay consistent until
+  // the transport refreshes them
   h->cur = out;
   h->avg_cur = 1 - h->avg_cur;
   if (last) h->old = out;
+  h->pending_rk = rk;
+  h->pending_dt = dt_host;
+  return DFLO_OK;
+}
+
+int launch_limiter(dflo_hip_engine *h, int tvb, int pos) {
+  const Plan &p = h->plan;
+  LimArgs l{};
+  l.U = h->U[h->cur];
+  l.avg = h->avg[h->avg_cur];
+  l.shard_count = h->d_shard_count;
+  l.lrbt = h->d_lrbt;
+  l.cell_h = h->d_cell_h;
+  l.flags = h->flags;
+  l.h_uniform = p.h;
+  l.M = h->prm.M;
+  l.beta = h->prm.beta;
+  l.n_shards = p.n_shards;
+  l.uniform_h = p.uniform_h ? 1 : 0;
+  l.tvb = tvb;
+  l.char_lim = h->prm.char_lim;
+  l.pos_lim = pos;
+  l.kb = h->kb;
+  void (*lf)(const LimArgs) = h->N == 2 ? limiter_kernel<2> : (h->N == 3 ? limiter_kernel<3> : limiter_kernel<4>);
+  hipLaunchKernelGGL(lf, dim3(grid_for(p.n_shards)), dim3(64), 0, h->stream, l);
+  HIPCHK(h, hipGetLastError());
+  return DFLO_OK;
+}
+
+// limiter + reductions of the stage launched last
+int launch_limit_finalize(dflo_hip_engine *h) {
+  const Plan &p = h->plan;
+  const int rk = h->pending_rk;
+  if (rk < 0) { h->err = "no stage pending"; return DFLO_ERR_BAD_PARAM; }
+  const bool last = rk == h->n_rk - 1;
+  const bool limited = h->prm.limiter_type != DFLO_LIMITER_NONE || h->prm.pos_lim;
   if (limited) {
-    LimArgs l{};
-    l.U = h->U[h->cur];
-    l.avg = h->avg[h->avg_cur];
-    l.shard_count = h->d_shard_count;
-    l.lrbt = h->d_lrbt;
-    l.cell_h = h->d_cell_h;
-    l.flags = h->flags;
-    l.h_uniform = p.h;
-    l.M = h->prm.M;
-    l.beta = h->prm.beta;
-    l.n_shards = p.n_shards;
-    l.uniform_h = p.uniform_h ? 1 : 0;
-    l.tvb = h->prm.limiter_type == DFLO_LIMITER_TVB;
-    l.char_lim = h->prm.char_lim;
-    l.pos_lim = h->prm.pos_lim;
-    l.kb = h->kb;
-    void (*lf)(const LimArgs) = h->N == 2 ? limiter_kernel<2> : (h->N == 3 ? limiter_kernel<3> : limiter_kernel<4>);
-    hipLaunchKernelGGL(lf, dim3(grid_for(p.n_shards)), dim3(64), 0, h->stream, l);
-    HIPCHK(h, hipGetLastError());
+    int rc = launch_limiter(h, h->prm.limiter_type == DFLO_LIMITER_TVB, h->prm.pos_lim);
+    if (rc) return rc;
   }
   FinalArgs f{};
   f.shard_res = h->shard_res;
@@ -795,11 +823,19 @@ int launch_stage(dflo_hip_engine *h, int rk, double dt_host, double *rhs_out, in
   f.do_res = 1;
   f.do_dt = last ? 1 : 0;
   f.advance_time = last ? 1 : 0;
+  f.dt_host = h->pending_dt;
   f.time_step = h->prm.time_step;
   f.final_time = h->prm.final_time;
   hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, h->stream, f);
   HIPCHK(h, hipGetLastError());
+  h->pending_rk = -1;
   return DFLO_OK;
+}
+
+int launch_stage(dflo_hip_engine *h, int rk, double dt_host, double *rhs_out, int which_override) {
+  int rc = launch_update(h, rk, dt_host, rhs_out, which_override);
+  if (rc || rhs_out) return rc;
+  return launch_limit_finalize(h);
 }
 
 int launch_average(dflo_hip_engine *h) {
@@ -910,11 +946,6 @@ int dflo_hip_create(const dflo_mesh_t *mesh, const dflo_params_t *params, int de
   hipMemset(h->res_sq, 0, 4 * sizeof(double));
   hipMemset(h->dt_dev, 0, 4 * sizeof(double));
   hipMemset(h->flags, 0, 4 * sizeof(int));
-  const int n_ghost = p.n_cells - p.n_owned;
-  if (n_ghost > 0 && hipMalloc((void **)&h->ghost_stage, (size_t)n_ghost * h->ndof * sizeof(double)) != hipSuccess) {
-    h->err = "hipMalloc(ghost) failed";
-    return bail(DFLO_ERR_NOMEM);
-  }
   h->stride = 64 + p.max_halo;
   h->max_fp = std::max(p.max_faces, 1) * h->N;
   h->lds_bytes = ((size_t)h->ndof * h->stride + 4 * h->stride + 4 * (size_t)h->max_fp) * sizeof(double);
@@ -1069,6 +1100,7 @@ int dflo_hip_compute_dt(dflo_hip_handle h, double elapsed_time, double *dt) {
   f.do_res = 0;
   f.do_dt = 1;
   f.advance_time = 0;
+  f.dt_host = -1.0;
   f.time_step = h->prm.time_step;
   f.final_time = h->prm.final_time;
   hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, h->stream, f);
@@ -1139,53 +1171,27 @@ int dflo_hip_apply_limiter(dflo_hip_handle h) {
   if (check_handle(h)) return DFLO_ERR_BAD_PARAM;
   hipSetDevice(h->device);
   if (h->prm.limiter_type == DFLO_LIMITER_NONE) return DFLO_OK;
-  const Plan &p = h->plan;
-  LimArgs l{};
-  l.U = h->U[h->cur];
-  l.avg = h->avg[h->avg_cur];
-  l.shard_count = h->d_shard_count;
-  l.lrbt = h->d_lrbt;
-  l.cell_h = h->d_cell_h;
-  l.flags = h->flags;
-  l.h_uniform = p.h;
-  l.M = h->prm.M;
-  l.beta = h->prm.beta;
-  l.n_shards = p.n_shards;
-  l.uniform_h = p.uniform_h ? 1 : 0;
-  l.tvb = 1;
-  l.char_lim = h->prm.char_lim;
-  l.pos_lim = 0;
-  l.kb = h->kb;
-  void (*lf)(const LimArgs) = h->N == 2 ? limiter_kernel<2> : (h->N == 3 ? limiter_kernel<3> : limiter_kernel<4>);
-  hipLaunchKernelGGL(lf, dim3(grid_for(p.n_shards)), dim3(64), 0, h->stream, l);
-  HIPCHK(h, hipGetLastError());
-  return DFLO_OK;
+  return launch_limiter(h, 1, 0);
 }
 
 int dflo_hip_apply_positivity_limiter(dflo_hip_handle h) {
   if (check_handle(h)) return DFLO_ERR_BAD_PARAM;
   hipSetDevice(h->device);
-  const Plan &p = h->plan;
-  LimArgs l{};
-  l.U = h->U[h->cur];
-  l.avg = h->avg[h->avg_cur];
-  l.shard_count = h->d_shard_count;
-  l.lrbt = h->d_lrbt;
-  l.cell_h = h->d_cell_h;
-  l.flags = h->flags;
-  l.h_uniform = p.h;
-  l.M = h->prm.M;
-  l.beta = h->prm.beta;
-  l.n_shards = p.n_shards;
-  l.uniform_h = p.uniform_h ? 1 : 0;
-  l.tvb = 0;
-  l.char_lim = h->prm.char_lim;
-  l.pos_lim = 1;
-  l.kb = h->kb;
-  void (*lf)(const LimArgs) = h->N == 2 ? limiter_kernel<2> : (h->N == 3 ? limiter_kernel<3> : limiter_kernel<4>);
-  hipLaunchKernelGGL(lf, dim3(grid_for(p.n_shards)), dim3(64), 0, h->stream, l);
-  HIPCHK(h, hipGetLastError());
+  int rc = launch_limiter(h, 0, 1);
+  if (rc) return rc;
   return dflo_hip_check(h);
+}
+
+int dflo_hip_stage_update(dflo_hip_handle h, int rk, double dt) {
+  if (check_handle(h) || rk < 0 || rk >= h->n_rk) return DFLO_ERR_BAD_PARAM;
+  hipSetDevice(h->device);
+  return launch_update(h, rk, dt, nullptr, -1);
+}
+
+int dflo_hip_stage_limit(dflo_hip_handle h) {
+  if (check_handle(h)) return DFLO_ERR_BAD_PARAM;
+  hipSetDevice(h->device);
+  return launch_limit_finalize(h);
 }
 
 int dflo_hip_check(dflo_hip_handle h) {
@@ -1245,21 +1251,41 @@ int dflo_hip_pack_send(dflo_hip_handle h, void *device_buffer) {
   return DFLO_OK;
 }
 
-int dflo_hip_ghost_ptr(dflo_hip_handle h, void **device_ptr, int64_t *n_doubles) {
-  if (check_handle(h) || !device_ptr) return DFLO_ERR_BAD_PARAM;
-  *device_ptr = h->ghost_stage;
-  if (n_doubles) *n_doubles = (int64_t)(h->plan.n_cells - h->plan.n_owned) * h->ndof;
+int dflo_hip_pack_send_avg(dflo_hip_handle h, void *device_buffer) {
+  if (check_handle(h) || !device_buffer) return DFLO_ERR_BAD_PARAM;
+  hipSetDevice(h->device);
+  if (h->n_send == 0) return DFLO_OK;
+  const long long tot = (long long)h->n_send * 4;
+  hipLaunchKernelGGL(pack_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, (double *)device_buffer,
+                     h->avg[h->avg_cur], h->d_send_slots, h->n_send, 4);
+  HIPCHK(h, hipGetLastError());
   return DFLO_OK;
 }
 
-int dflo_hip_ghost_updated(dflo_hip_handle h) {
+int dflo_hip_n_ghost_cells(dflo_hip_handle h) { return h ? h->plan.n_cells - h->plan.n_owned : 0; }
+
+int dflo_hip_unpack_ghost(dflo_hip_handle h, const void *device_buffer) {
   if (check_handle(h)) return DFLO_ERR_BAD_PARAM;
   hipSetDevice(h->device);
   const Plan &p = h->plan;
   const int n_ghost = p.n_cells - p.n_owned;
   if (n_ghost == 0) return DFLO_OK;
-  hipLaunchKernelGGL(unpack_ghost_kernel, dim3((n_ghost + 63) / 64), dim3(64), 0, h->stream, h->ghost_stage, h->U[h->cur],
-                     h->avg[h->avg_cur], p.n_shards * 64, n_ghost, h->ndof, h->kb, h->N);
+  if (!device_buffer) return DFLO_ERR_BAD_PARAM;
+  hipLaunchKernelGGL(unpack_ghost_kernel, dim3((n_ghost + 63) / 64), dim3(64), 0, h->stream, (const double *)device_buffer,
+                     h->U[h->cur], h->avg[h->avg_cur], p.n_shards * 64, n_ghost, h->ndof, h->kb, h->N);
+  HIPCHK(h, hipGetLastError());
+  return DFLO_OK;
+}
+
+int dflo_hip_unpack_ghost_avg(dflo_hip_handle h, const void *device_buffer) {
+  if (check_handle(h)) return DFLO_ERR_BAD_PARAM;
+  hipSetDevice(h->device);
+  const Plan &p = h->plan;
+  const int n_ghost = p.n_cells - p.n_owned;
+  if (n_ghost == 0) return DFLO_OK;
+  if (!device_buffer) return DFLO_ERR_BAD_PARAM;
+  hipLaunchKernelGGL(unpack_ghost_avg_kernel, dim3((n_ghost + 63) / 64), dim3(64), 0, h->stream,
+                     (const double *)device_buffer, h->avg[h->avg_cur], p.n_shards * 64, n_ghost);
   HIPCHK(h, hipGetLastError());
   return DFLO_OK;
 }

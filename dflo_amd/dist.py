@@ -1,0 +1,142 @@
+"""One process per GPU: slab partition + face-neighbour halo exchange for the explicit path.
+
+Replaces what the MPI variant gets from deal.II (src_mpi/):
+  current_solution.update_ghost_values()  src_mpi/claw.cc:793, src_mpi/limiter.cc:232
+  Utilities::MPI::min(global_dt)          src_mpi/claw.cc:579
+  right_hand_side.l2_norm()               src_mpi/claw.cc:777
+  right_hand_side.compress(add)           src_mpi/assemble_explicit.cc:580  -- not needed: faces on a
+      partition boundary are integrated by both owners with the same integrating side (bit-identical flux).
+The transport is torch.distributed point-to-point (backend "nccl" = RCCL over xGMI on the GPU box;
+"gloo" with host staging in CPU tests).  The data path has exactly one exchange per RK stage (two
+when the TVB limiter needs the neighbours' fresh cell averages) and one 8-byte all-reduce per step.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import _lib
+from ._lib import lib
+from .claw import ConservationLaw
+
+
+class HaloExchange:
+    """Point-to-point exchange of per-cell records between neighbouring ranks.
+
+    send_offsets / recv_offsets (size world+1) come from Mesh.partition: cells to send to rank r are
+    send_cells[send_offsets[r]:send_offsets[r+1]]; ghost cells received from r occupy
+    [recv_offsets[r], recv_offsets[r+1]) of the ghost range."""
+
+    def __init__(self, send_offsets, recv_offsets, device):
+        self.so = [int(v) for v in send_offsets]
+        self.ro = [int(v) for v in recv_offsets]
+        self.rank = dist.get_rank()
+        self.world = dist.get_world_size()
+        self.device = device
+        self.host_staging = dist.get_backend() != "nccl" and device.type == "cuda"
+        self.peers = [r for r in range(self.world) if r != self.rank and (self.so[r + 1] > self.so[r] or self.ro[r + 1] > self.ro[r])]
+
+    def exchange(self, send, recv, width):
+        """send: [n_send*width] tensor, recv: [n_ghost*width] tensor (both on self.device)."""
+        if not self.peers:
+            return
+        if self.host_staging:
+            s, r = send.cpu(), torch.empty(recv.shape, dtype=recv.dtype)
+        else:
+            s, r = send, recv
+        ops = []
+        for p in self.peers:
+            if self.ro[p + 1] > self.ro[p]:
+                ops.append(dist.P2POp(dist.irecv, r[self.ro[p] * width:self.ro[p + 1] * width], p))
+        for p in self.peers:
+            if self.so[p + 1] > self.so[p]:
+                ops.append(dist.P2POp(dist.isend, s[self.so[p] * width:self.so[p + 1] * width], p))
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+        if self.host_staging:
+            recv.copy_(r)
+
+
+class DistributedConservationLaw:
+    """ConservationLaw on the slab of this rank (torch.distributed must be initialised)."""
+
+    def __init__(self, global_mesh, parameters, device_index=0):
+        self.rank = dist.get_rank()
+        self.world = dist.get_world_size()
+        self.global_mesh = global_mesh
+        self.mesh = global_mesh.partition(self.world, self.rank)
+        self.parameters = parameters
+        self.device = torch.device("cuda", device_index)
+        torch.cuda.set_device(self.device)
+        self.claw = ConservationLaw(self.mesh, parameters, device=device_index)
+        # run the engine on torch's current stream so that RCCL ops and kernels are ordered
+        self.claw.set_stream(torch.cuda.current_stream().cuda_stream)
+        send_cells, so, ro = self.mesh.comm
+        self.halo = HaloExchange(so, ro, self.device)
+        sc = np.ascontiguousarray(send_cells, dtype=np.int32)
+        self.claw._chk(lib.dflo_hip_set_send_cells(self.claw._h, len(sc), _lib.iptr(sc)))
+        ndof = self.claw.dofs_per_cell
+        self.n_send = len(sc)
+        self.n_ghost = self.mesh.n_cells - self.mesh.n_owned
+        self.send_u = torch.empty(max(self.n_send, 1) * ndof, dtype=torch.float64, device=self.device)
+        self.recv_u = torch.empty(max(self.n_ghost, 1) * ndof, dtype=torch.float64, device=self.device)
+        self.send_a = torch.empty(max(self.n_send, 1) * 4, dtype=torch.float64, device=self.device)
+        self.recv_a = torch.empty(max(self.n_ghost, 1) * 4, dtype=torch.float64, device=self.device)
+        self.ndof = ndof
+        self.n_rk = self.claw.n_rk
+        self.tvb = parameters.limiter == "TVB"
+        self.scal = torch.zeros(2, dtype=torch.float64, device=self.device)
+        self.elapsed_time = 0.0
+        self.n_dofs_owned = self.mesh.n_owned * ndof
+        self.n_dofs_global = global_mesh.n_cells * ndof
+
+    # ---- data movement
+    def owned_slice_of_global(self, u_global):
+        gid = np.asarray(self.mesh.global_ids)
+        return np.ascontiguousarray(np.asarray(u_global).reshape(self.global_mesh.n_cells, self.ndof)[gid]).reshape(-1)
+
+    def set_initial_condition(self, u_global):
+        self.claw.set_initial_condition(self.owned_slice_of_global(u_global))
+
+    def exchange_solution(self):
+        c = self.claw
+        c._chk(lib.dflo_hip_pack_send(c._h, C.c_void_p(self.send_u.data_ptr())))
+        self.halo.exchange(self.send_u, self.recv_u, self.ndof)
+        c._chk(lib.dflo_hip_unpack_ghost(c._h, C.c_void_p(self.recv_u.data_ptr())))
+
+    def exchange_averages(self):
+        c = self.claw
+        c._chk(lib.dflo_hip_pack_send_avg(c._h, C.c_void_p(self.send_a.data_ptr())))
+        self.halo.exchange(self.send_a, self.recv_a, 4)
+        c._chk(lib.dflo_hip_unpack_ghost_avg(c._h, C.c_void_p(self.recv_a.data_ptr())))
+
+    # ---- time stepping
+    def compute_time_step(self):
+        self.claw.elapsed_time = self.elapsed_time
+        dt = self.claw.compute_time_step()
+        t = torch.tensor([dt], dtype=torch.float64, device=self.device if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)  # Utilities::MPI::min, src_mpi/claw.cc:579
+        return float(t.item())
+
+    def iterate_explicit(self, dt):
+        c = self.claw
+        for rk in range(self.n_rk):
+            c._chk(lib.dflo_hip_stage_update(c._h, rk, dt))
+            if self.tvb:
+                self.exchange_averages()
+            c._chk(lib.dflo_hip_stage_limit(c._h))
+            self.exchange_solution()
+        c.end_step()
+        self.elapsed_time += dt
+
+    def gather_solution(self):
+        """Owned DoFs of all ranks assembled in the global cell order (on every rank; test helper)."""
+        u = self.claw.current_solution.reshape(self.mesh.n_cells, self.ndof)[: self.mesh.n_owned]
+        gid = np.asarray(self.mesh.global_ids)[: self.mesh.n_owned]
+        parts = [None] * self.world
+        dist.all_gather_object(parts, (gid, u))
+        out = np.empty((self.global_mesh.n_cells, self.ndof))
+        for g, v in parts:
+            out[g] = v
+        return out.reshape(-1)

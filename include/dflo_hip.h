@@ -190,14 +190,23 @@ int dflo_hip_stage_timing(dflo_hip_handle h, int enable, double *avg_ms, int64_t
 /* Replaces LA::distributed::Vector::update_ghost_values() of the MPI variant
  * (src_mpi/claw.cc:793, src_mpi/limiter.cc:232).  The engine owns cells
  * [0,n_owned) and reads ghost cells [n_owned,n_cells).  pack gathers the DoFs
- * of the listed owned cells into a contiguous device buffer ([n][ndof]);
- * ghost_ptr returns the device address of the ghost range of the current
- * solution so a transport (RCCL send/recv via torch.distributed) can receive
- * straight into it. */
+ * ([n][ndof]) or the cell averages ([n][4]) of the listed owned cells into a
+ * contiguous device buffer; unpack scatters a received buffer ([n_ghost][ndof] or
+ * [n_ghost][4], ghost order) into the ghost cells.  The transport between the
+ * two (RCCL send/recv through torch.distributed) is the caller's.
+ * With a TVB limiter the ghost AVERAGES must be refreshed between the update and
+ * the limiter of a stage (the MPI variant computes cell averages on owned+ghost
+ * cells after the first update_ghost_values, src_mpi/claw.cc:793,653-669):
+ *   dflo_hip_stage_update -> exchange averages -> dflo_hip_stage_limit -> exchange DoFs.
+ * dflo_hip_stage == dflo_hip_stage_update + dflo_hip_stage_limit. */
+int dflo_hip_stage_update(dflo_hip_handle h, int rk, double dt);
+int dflo_hip_stage_limit(dflo_hip_handle h);
+int dflo_hip_n_ghost_cells(dflo_hip_handle h);
 int dflo_hip_set_send_cells(dflo_hip_handle h, int32_t n, const int32_t *cells);
 int dflo_hip_pack_send(dflo_hip_handle h, void *device_buffer);
-int dflo_hip_ghost_ptr(dflo_hip_handle h, void **device_ptr, int64_t *n_doubles);
-int dflo_hip_ghost_updated(dflo_hip_handle h); /* recompute ghost cell averages after a receive */
+int dflo_hip_pack_send_avg(dflo_hip_handle h, void *device_buffer);
+int dflo_hip_unpack_ghost(dflo_hip_handle h, const void *device_buffer);     /* also recomputes ghost averages */
+int dflo_hip_unpack_ghost_avg(dflo_hip_handle h, const void *device_buffer);
 /* device address of {dt, res_norm_sq} scalars for 8-byte all-reduces (src_mpi/claw.cc:579,777) */
 int dflo_hip_scalar_ptrs(dflo_hip_handle h, void **dt_ptr, void **res_ptr);
 /* dt_ptr[2] holds the raw CFL minimum of this device; after an external all-reduce(min) of that

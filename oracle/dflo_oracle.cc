@@ -945,50 +945,63 @@ void integrate_face_term_explicit(const Oracle &o, int cell, int f, int ncell, i
 
 long long gid_of(const Oracle &o, int c) { return o.gid.empty() ? c : o.gid[c]; }
 
-// src/assemble_explicit.cc:433-452 (MeshWorker::loop + ResidualSimple assembler)
+// src/assemble_explicit.cc:433-452 (MeshWorker::loop + ResidualSimple assembler).
+// Like MeshWorker on TBB, the cell/face integrals are computed in parallel into per-cell local
+// vectors and then copied into the global vector by one thread, in cell order (deterministic).
 void assemble_system(Oracle &o, int which) {
   std::fill(o.rhs.begin(), o.rhs.end(), 0.0);  // right_hand_side = 0
   const int ndof = o.ndof;
-#pragma omp parallel for schedule(static) num_threads(o.nthreads) if (o.nthreads > 1)
-  for (int cell = 0; cell < o.n_cells; ++cell) {
-    const bool owned = cell < o.n_owned;
-    std::vector<double> local(ndof, 0.0), local_n(ndof, 0.0);
-    if (owned) integrate_cell_term_explicit(o, cell, local);
-    for (int f = 0; f < 4; ++f) {
-      const int nb = o.nbr[cell * 4 + f];
-      if (nb == DFLO_NBR_NONE) continue;
-      if (nb < 0) {
-        if (owned) integrate_boundary_term_explicit(o, cell, f, which, local);
-        continue;
-      }
-      const int code = o.nbrf[cell * 4 + f];
-      const bool periodic = (code & 8) != 0, flip = (code & 4) != 0;
-      const int nface = code & 3;
-      if (periodic) {  // boundary callback of the MPI variant: each side integrates its own flux
-        if (owned) integrate_face_term_explicit(o, cell, f, nb, nface, flip, true, local, local_n);
-        continue;
-      }
-      // interior face: integrated once, from the cell with the smaller index
-      if (!(gid_of(o, cell) < gid_of(o, nb))) continue;
-      if (!owned && !(nb < o.n_owned)) continue;
-      std::fill(local_n.begin(), local_n.end(), 0.0);
-      if (owned) {
-        integrate_face_term_explicit(o, cell, f, nb, nface, flip, false, local, local_n);
-      } else {  // ghost cell visiting a face shared with an owned cell: only the owned side is kept
-        std::vector<double> dummy(ndof, 0.0);
-        integrate_face_term_explicit(o, cell, f, nb, nface, flip, false, dummy, local_n);
-      }
-      if (nb < o.n_owned)
-        for (int i = 0; i < ndof; ++i) {
-#pragma omp atomic
-          o.rhs[(size_t)nb * ndof + i] += local_n[i];
+  const int chunk = 4096;
+  std::vector<double> loc((size_t)chunk * ndof), locn((size_t)chunk * 4 * ndof);
+  std::vector<int> tgt((size_t)chunk * 4);
+  for (int c0 = 0; c0 < o.n_cells; c0 += chunk) {
+    const int c1 = std::min(o.n_cells, c0 + chunk);
+#pragma omp parallel for schedule(dynamic, 16) num_threads(o.nthreads) if (o.nthreads > 1)
+    for (int cell = c0; cell < c1; ++cell) {
+      const bool owned = cell < o.n_owned;
+      std::vector<double> local(ndof, 0.0), local_n(ndof, 0.0);
+      for (int f = 0; f < 4; ++f) tgt[(size_t)(cell - c0) * 4 + f] = -1;
+      if (owned) integrate_cell_term_explicit(o, cell, local);
+      for (int f = 0; f < 4; ++f) {
+        const int nb = o.nbr[cell * 4 + f];
+        if (nb == DFLO_NBR_NONE) continue;
+        if (nb < 0) {
+          if (owned) integrate_boundary_term_explicit(o, cell, f, which, local);
+          continue;
         }
-    }
-    if (owned)
-      for (int i = 0; i < ndof; ++i) {
-#pragma omp atomic
-        o.rhs[(size_t)cell * ndof + i] += local[i];
+        const int code = o.nbrf[cell * 4 + f];
+        const bool periodic = (code & 8) != 0, flip = (code & 4) != 0;
+        const int nface = code & 3;
+        if (periodic) {  // boundary callback of the MPI variant: each side integrates its own flux
+          if (owned) integrate_face_term_explicit(o, cell, f, nb, nface, flip, true, local, local_n);
+          continue;
+        }
+        // interior face: integrated once, from the cell with the smaller index
+        if (!(gid_of(o, cell) < gid_of(o, nb))) continue;
+        if (!owned && !(nb < o.n_owned)) continue;
+        std::fill(local_n.begin(), local_n.end(), 0.0);
+        if (owned) {
+          integrate_face_term_explicit(o, cell, f, nb, nface, flip, false, local, local_n);
+        } else {  // ghost cell visiting a face shared with an owned cell: only the owned side is kept
+          std::vector<double> dummy(ndof, 0.0);
+          integrate_face_term_explicit(o, cell, f, nb, nface, flip, false, dummy, local_n);
+        }
+        if (nb < o.n_owned) {
+          tgt[(size_t)(cell - c0) * 4 + f] = nb;
+          std::copy(local_n.begin(), local_n.end(), &locn[((size_t)(cell - c0) * 4 + f) * ndof]);
+        }
       }
+      std::copy(local.begin(), local.end(), &loc[(size_t)(cell - c0) * ndof]);
+    }
+    for (int cell = c0; cell < c1; ++cell) {  // the "copier"
+      if (cell < o.n_owned)
+        for (int i = 0; i < ndof; ++i) o.rhs[(size_t)cell * ndof + i] += loc[(size_t)(cell - c0) * ndof + i];
+      for (int f = 0; f < 4; ++f) {
+        const int nb = tgt[(size_t)(cell - c0) * 4 + f];
+        if (nb >= 0)
+          for (int i = 0; i < ndof; ++i) o.rhs[(size_t)nb * ndof + i] += locn[((size_t)(cell - c0) * 4 + f) * ndof + i];
+      }
+    }
   }
 }
 
