@@ -64,7 +64,7 @@ SYMBOLS = [
     "dflo_hip_apply_positivity_limiter", "dflo_hip_check", "dflo_hip_synchronize", "dflo_hip_stage_timing",
     "dflo_hip_set_send_cells", "dflo_hip_pack_send", "dflo_hip_pack_send_avg", "dflo_hip_unpack_ghost",
     "dflo_hip_unpack_ghost_avg", "dflo_hip_n_ghost_cells", "dflo_hip_stage_update", "dflo_hip_stage_limit",
-    "dflo_hip_scalar_ptrs", "dflo_hip_apply_dt_rules",
+    "dflo_hip_scalar_ptrs", "dflo_hip_apply_dt_rules", "dflo_hip_debug_math",
     "dflo_mesh_cartesian", "dflo_mesh_from_quads", "dflo_mesh_read_gmsh", "dflo_mesh_partition", "dflo_mesh_free",
     "dflo_mesh_last_error", "dflo_mesh_support_points",
 ]
@@ -124,6 +124,7 @@ _sig("dflo_hip_stage_update", C.c_int, _H, C.c_int, C.c_double)
 _sig("dflo_hip_stage_limit", C.c_int, _H)
 _sig("dflo_hip_scalar_ptrs", C.c_int, _H, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p))
 _sig("dflo_hip_apply_dt_rules", C.c_int, _H)
+_sig("dflo_hip_debug_math", C.c_int, C.c_int, _dp, _dp, _dp)
 _sig("dflo_mesh_cartesian", C.c_int, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double, _ip, C.c_int32,
      C.POINTER(_MP))
 _sig("dflo_mesh_from_quads", C.c_int, C.c_int32, _dp, C.c_int32, _ip, C.c_int32, _ip, _ip, C.c_int32, C.POINTER(_MP))

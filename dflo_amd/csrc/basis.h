@@ -112,4 +112,68 @@ inline BasisTables make_basis(int degree) {
   return b;
 }
 
+
+// ---- compile-time tables for the device kernels: with the 1-D tables as constants the compiler
+// materialises them with SALU moves instead of re-loading kernel arguments through the scalar cache
+// (each such reload is an s_waitcnt lgkmcnt stall in the hot loops).
+template <int N> struct GaussLit;
+template <> struct GaussLit<2> {
+  static constexpr double x[2] = {0.2113248654051871177454, 0.7886751345948128822545};
+  static constexpr double w[2] = {0.5, 0.5};
+};
+template <> struct GaussLit<3> {
+  static constexpr double x[3] = {0.1127016653792583114820, 0.5, 0.8872983346207416885179};
+  static constexpr double w[3] = {0.2777777777777777777777, 0.4444444444444444444444, 0.2777777777777777777777};
+};
+template <> struct GaussLit<4> {
+  static constexpr double x[4] = {0.0694318442029737123880, 0.3300094782075718675986, 0.6699905217924281324013,
+                                  0.9305681557970262876119};
+  static constexpr double w[4] = {0.1739274225687269286865, 0.3260725774312730713134, 0.3260725774312730713134,
+                                  0.1739274225687269286865};
+};
+
+template <int N>
+struct CBTable {
+  double x[N], w[N], iw[N], L0[N], L1[N], D[N][N], DW[N][N];
+};
+template <int N>
+constexpr double cb_lag(int a, double t) {
+  double v = 1.0;
+  for (int m = 0; m < N; ++m)
+    if (m != a) v *= (t - GaussLit<N>::x[m]) / (GaussLit<N>::x[a] - GaussLit<N>::x[m]);
+  return v;
+}
+template <int N>
+constexpr double cb_dlag(int a, double t) {
+  double s = 0.0;
+  for (int j = 0; j < N; ++j) {
+    if (j == a) continue;
+    double v = 1.0 / (GaussLit<N>::x[a] - GaussLit<N>::x[j]);
+    for (int m = 0; m < N; ++m)
+      if (m != a && m != j) v *= (t - GaussLit<N>::x[m]) / (GaussLit<N>::x[a] - GaussLit<N>::x[m]);
+    s += v;
+  }
+  return s;
+}
+template <int N>
+constexpr CBTable<N> make_cb() {
+  CBTable<N> t{};
+  for (int a = 0; a < N; ++a) {
+    t.x[a] = GaussLit<N>::x[a];
+    t.w[a] = GaussLit<N>::w[a];
+    t.iw[a] = 1.0 / GaussLit<N>::w[a];
+    t.L0[a] = cb_lag<N>(a, 0.0);
+    t.L1[a] = cb_lag<N>(a, 1.0);
+    for (int q = 0; q < N; ++q) {
+      t.D[q][a] = cb_dlag<N>(a, GaussLit<N>::x[q]);     // l_a'(x_q)
+      t.DW[q][a] = t.D[q][a] * GaussLit<N>::w[q];
+    }
+  }
+  return t;
+}
+template <int N>
+struct CB {
+  static constexpr CBTable<N> t = make_cb<N>();
+};
+
 }  // namespace dflo

@@ -31,6 +31,7 @@ namespace dflo {
 // ------------------------------------------------------------------ kernel arguments
 struct KBasis {       // 1-D tables, see basis.h
   double w[kMaxN];
+  double iw[kMaxN];  // 1 / w
   double x[kMaxN];
   double L0[kMaxN], L1[kMaxN];
   double D[kMaxN][kMaxN];   // D[q][a] = l_a'(x_q)
@@ -40,13 +41,24 @@ struct KBasis {       // 1-D tables, see basis.h
   int Ng;
 };
 
+#ifdef DFLO_PHASE_TIMING
+#define PHASE_MARK(i) do { if (tid == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tacc[i] += t_ - tlast; tlast = t_; } } while (0)
+#else
+#define PHASE_MARK(i) do { } while (0)
+#endif
+
 struct StageArgs {
+  unsigned long long *phase_cycles;  // [grid][8], only with DFLO_PHASE_TIMING
   const double *Ucur, *Uold;
   double *Unew;
   const double *avg_cur;
   double *avg_new;
   double *rhs_out;  // parity hook: write the assembled rhs instead of updating
   const int32_t *shard_count, *halo_begin, *halo_cells, *face_begin;
+  const int4 *shard_hdr;      // {cells, faces, halo cells, 0}
+  const int32_t *halo_pad;    // [n_shards][64]
+  const FaceRec *faces_pad;   // [n_shards][face_pitch]
+  int face_pitch;
   const FaceRec *faces;
   const uint16_t *cell_face;
   const double *cell_h;
@@ -56,9 +68,16 @@ struct StageArgs {
   const double *dt_cell;  // local time stepping: per internal slot, else null
   double *shard_res, *shard_dtmin;
   double dt_host, ark, gravity, cfl, h_uniform;
-  int n_shards, stride, max_fp, uniform_h, want_dt, degree;
+  int n_shards, stride, max_fp, max_faces, max_bnd, uniform_h, want_dt, degree;
   KBasis kb;
 };
+
+// compute_time_step_cartesian for one cell, src/claw.cc:495-509
+__device__ __forceinline__ double cfl_dt(const double *A, double h, double cfl, int degree) {
+  const double sonic = sqrt(kGamma * pressure(A) / A[RHO]);
+  const double maxeig = (sonic + fabs(A[MX] / A[RHO])) / h + (sonic + fabs(A[MY] / A[RHO])) / h;
+  return cfl / maxeig / (2.0 * degree + 1.0);
+}
 
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
@@ -80,62 +99,318 @@ __device__ __forceinline__ int shard_of_block(int b, int n_shards) {
 }
 
 // ------------------------------------------------------------------ the stage kernel
-// One wavefront per shard.  LDS image: Us[ndof][stride] (own 64 cells then halo cells),
-// As[4][stride] cell averages (LxF), Fh[4][max_fp] numerical fluxes at the shard's face points.
-template <int N, int FLUX>
-__global__ __launch_bounds__(64) void stage_kernel(const StageArgs a) {
-  constexpr int NS = N * N, NDOF = 4 * NS;
-  extern __shared__ __attribute__((aligned(16))) double lds[];
-  const int shard = shard_of_block(blockIdx.x, a.n_shards);
-  if (shard < 0) return;
-  const int lane = threadIdx.x;
-  const int S = a.stride;
-  double *Us = lds;
-  double *As = Us + NDOF * S;
-  double *Fh = As + 4 * S;
-  const KBasis &kb = a.kb;
+// One workgroup of N wavefronts per shard: lane = cell, wavefront = node row b of the (k+1)^2
+// collocation nodes, so control flow is wave-uniform and every global access is a coalesced
+// 512-byte line.  LDS image: Us[ndof][stride] (own 64 cells then halo cells), As[4][stride] cell
+// averages (LxF only), Fh[4][max_fp] numerical fluxes at the shard's face points.
 
-  // ---- phase A: shard + halo -> LDS
-  {
-    const double *up = a.Ucur + (size_t)shard * NDOF * 64 + lane;
+// phase C for node row B of every cell of the shard (lane = cell)
+template <int N, int B, int MODE>
+__device__ __forceinline__ void row_update(const StageArgs &a, const double *Us, const double *Fh, double *red,
+                                           int shard, int lane, bool active, double h, const uint16_t (&cref)[4],
+                                           const double (&uold)[4][N]) {
+  constexpr int NS = N * N;
+  const int S = a.stride;
+  double R[4][N];
 #pragma unroll
-    for (int d = 0; d < NDOF; ++d) Us[d * S + lane] = up[d * 64];
-    if constexpr (FLUX == DFLO_FLUX_LXF) {
+  for (int c = 0; c < 4; ++c)
 #pragma unroll
-      for (int c = 0; c < 4; ++c) As[c * S + lane] = a.avg_cur[((size_t)shard * 4 + c) * 64 + lane];
-    }
-    const int hb = a.halo_begin[shard], nh = a.halo_begin[shard + 1] - hb;
-    for (int s = lane; s < nh; s += 64) {
-      const int ic = a.halo_cells[hb + s];
-      const double *hp = a.Ucur + (size_t)(ic >> 6) * NDOF * 64 + (ic & 63);
+    for (int m = 0; m < N; ++m) R[c][m] = 0.0;
+  double Wrow[N][4];
+  // volume term (integrate_cell_term_explicit :57-115); collocation: W_q = U_q,
+  // grad phi_(m,B)(x_(aa,B)) = D[aa][m]/h e_x, grad phi_(aa,B)(x_(aa,q)) = D[q][B]/h e_y, JxW = w w h^2
 #pragma unroll
-      for (int d = 0; d < NDOF; ++d) Us[d * S + 64 + s] = hp[d * 64];
-      if constexpr (FLUX == DFLO_FLUX_LXF) {
+  for (int aa = 0; aa < N; ++aa) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) As[c * S + 64 + s] = a.avg_cur[((size_t)(ic >> 6) * 4 + c) * 64 + (ic & 63)];
+    for (int q = 0; q < N; ++q) {
+      double W[4], Fx[4], Gy[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) W[c] = Us[(c * NS + aa + N * q) * S + lane];
+      if (q == B) flux_xy(W, Fx, Gy);
+      else flux_y(W, Gy);
+      const double wah = CB<N>::t.w[aa] * h;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) R[c][aa] += Gy[c] * wah * CB<N>::t.DW[q][B];
+      if (q == B) {
+        const double wbh = CB<N>::t.w[B] * h;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          Wrow[aa][c] = W[c];
+          const double fx = Fx[c] * wbh;
+#pragma unroll
+          for (int m = 0; m < N; ++m) R[c][m] += fx * CB<N>::t.DW[aa][m];
+        }
+        if (a.gravity != 0.0) {  // forcing (src/equation.h:831-850): (0, -rho, 0, -my) * gravity
+          const double jxw = CB<N>::t.w[aa] * CB<N>::t.w[B] * h * h;
+          R[MY][aa] += a.gravity * (-1.0 * W[RHO]) * jxw;
+          R[EN][aa] += a.gravity * (-1.0 * W[MY]) * jxw;
+        }
       }
     }
   }
-  __syncthreads();
+  // face terms (:209-244, :344-423): - flux * phi * JxW on the integrating side, + on the other
+  if (active) {
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      const uint16_t ref = cref[f];
+      if (ref == kNoFace) continue;
+      const int k = ref & 0x3FFF;
+      const bool flip = (ref >> 14) & 1;
+      const double sgn = (ref >> 15) ? 1.0 : -1.0;
+      if (f < 2) {  // x faces: face point q = B lifts to the nodes (m, B)
+        const int qq = flip ? N - 1 - B : B;
+        const double jxw = sgn * CB<N>::t.w[B] * h;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const double fq = Fh[c * a.max_fp + k * N + qq] * jxw;
+#pragma unroll
+          for (int m = 0; m < N; ++m) R[c][m] += fq * ((f & 1) ? CB<N>::t.L1[m] : CB<N>::t.L0[m]);
+        }
+      } else {  // y faces: face point q = aa lifts to the node (aa, B) with l_B(0|1)
+        const double lw = (f & 1) ? CB<N>::t.L1[B] : CB<N>::t.L0[B];
+#pragma unroll
+        for (int q = 0; q < N; ++q) {
+          const int qq = flip ? N - 1 - q : q;
+          const double jxw = sgn * (CB<N>::t.w[q] * lw) * h;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) R[c][q] += Fh[c * a.max_fp + k * N + qq] * jxw;
+        }
+      }
+    }
+  }
+  double part[5] = {0, 0, 0, 0, 0};
+  if (active) {
+    if constexpr (MODE == 2) {
+      double *rp = a.rhs_out + (size_t)shard * 4 * NS * 64 + lane;
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int m = 0; m < N; ++m) rp[(c * NS + m + N * B) * 64] = R[c][m];
+    } else {
+      // solve() rk3 branch + SSP combine (src/claw.cc:708-710, 757-760)
+      const double dt = a.dt_cell ? a.dt_cell[(size_t)shard * 64 + lane] : (a.dt_host >= 0.0 ? a.dt_host : *a.dt_dev);
+      const double rh2 = frcp(h * h);
+      double *np = a.Unew + (size_t)shard * 4 * NS * 64 + lane;
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int m = 0; m < N; ++m) {
+          const int d = c * NS + m + N * B;
+          const double ww = CB<N>::t.w[m] * CB<N>::t.w[B];
+          const double invM = rh2 * (CB<N>::t.iw[m] * CB<N>::t.iw[B]);
+          part[4] += R[c][m] * R[c][m];
+          double u = Wrow[m][c];
+          u += dt * R[c][m] * invM;
+          if constexpr (MODE == 1) u = (1.0 - a.ark) * u + a.ark * uold[c][m];
+          np[d * 64] = u;
+          part[c] += ww * u;
+        }
+    }
+  }
+  // partial cell averages / residual of this row -> LDS (red aliases Fh, see the caller's barriers)
+  if constexpr (MODE != 2) {
+    __syncthreads();  // every wave is done reading Fh
+#pragma unroll
+    for (int c = 0; c < 5; ++c) red[(B * 5 + c) * 64 + lane] = part[c];
+  }
+}
 
-  // ---- phase B: one numerical flux per face point (integrate_face_term_explicit :303-341,
-  //      integrate_boundary_term_explicit :176-206)
-  {
-    const int fb = a.face_begin[shard], nfp = (a.face_begin[shard + 1] - fb) * N;
-    for (int p = lane; p < nfp; p += 64) {
-      const int k = p / N, q = p - k * N;
-      const FaceRec r = a.faces[fb + k];
+// Persistent workgroups: a workgroup walks through the shards of its XCD's run and keeps the NEXT
+// shard's loads in flight (into registers) while it computes the current one, so HBM latency is
+// hidden behind the flux arithmetic instead of being paid once per phase.  Index data runs one more
+// shard ahead so that no address ever waits for a fresh load.
+//   halo item mapping: lane = halo slot, wave `row` moves LDS rows row, row+N, row+2N, ...
+// Per-thread index data of a shard, raw load results (nothing is computed on them at load time):
+struct ShardAhead {   // needed when the shard is staged into LDS: loaded one shard ahead
+  int4 hdr;           // {cells, faces, halo cells, boundary faces} (wave-uniform)
+  FaceRec fr[2];      // face records tid and tid + NT (a shard has <= 2*NT faces)
+};
+
+// MODE 0: first stage (ark = 0, u(n) not read)   1: later stages   2: residual only (parity hook)
+template <int N, int FLUX, int MODE>
+__global__ __launch_bounds__(64 * N, 2) void stage_kernel(const StageArgs a) {
+  constexpr int NS = N * N, NDOF = 4 * NS, NT = 64 * N;
+  constexpr int ROWS = NDOF + (FLUX == DFLO_FLUX_LXF ? 4 : 0);  // LxF: the 4 cell averages ride along
+  constexpr int HR = (ROWS + N - 1) / N;                         // halo rows per wave
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int row = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int S = a.stride;
+  double *Us = lds;                                   // [ROWS][S]
+  double *Fh = Us + ROWS * S;                         // [4][max_fp]
+  FaceRec *Fr = (FaceRec *)(Fh + 4 * a.max_fp);       // [max_faces]
+  double *Lt = (double *)(Fr + a.max_faces);          // [2][N]: l_m(0), l_m(1) -- indexed per lane in phase B
+  double *Bv = Lt + 2 * kMaxN;                        // [max_bnd][N][4] boundary values of the shard
+  int *Bk = (int *)(Bv + a.max_bnd * 4 * N);          // [max_bnd] boundary kinds
+  const KBasis &kb = a.kb;
+  if (tid == 0) {
+#pragma unroll
+    for (int m = 0; m < N; ++m) {
+      Lt[m] = CB<N>::t.L0[m];
+      Lt[N + m] = CB<N>::t.L1[m];
+    }
+  }
+
+  // shards of this workgroup: XCD x (= block % 8) owns the run [x*chunk, (x+1)*chunk)
+  const int chunk = (a.n_shards + 7) >> 3;
+  const int xcd = blockIdx.x & 7, jstride = gridDim.x >> 3;
+  int j = blockIdx.x >> 3;
+  auto shard_at = [&](int jj) { const int s = xcd * chunk + jj; return (jj < chunk && s < a.n_shards) ? s : -1; };
+
+  // Fixed-pitch per-shard tables: every address depends on the shard number only, so all of these
+  // loads issue back to back and nothing here waits for a previous load.
+  // `vzero` is a per-lane zero the compiler cannot see through: it keeps the header load an ordinary
+  // vector load whose result stays in VGPRs until it is used a shard later (a uniform load would be
+  // followed by an immediate v_readfirstlane, i.e. a full vmcnt(0) drain at the top of the loop)
+  int vzero;
+  asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
+  auto load_ahead = [&](int sh, ShardAhead &m) {
+    m.hdr = a.shard_hdr[sh + vzero];
+    const FaceRec *fp = a.faces_pad + (size_t)sh * a.face_pitch;
+    m.fr[0] = fp[tid];
+    m.fr[1] = fp[tid + NT];
+  };
+  // value of LDS row d of internal cell slot ic
+  auto src = [&](int d, int ic) -> const double * {
+    if (FLUX == DFLO_FLUX_LXF && d >= NDOF) return a.avg_cur + ((size_t)(ic >> 6) * 4 + (d - NDOF)) * 64 + (ic & 63);
+    return a.Ucur + ((size_t)(ic >> 6) * NDOF + d) * 64 + (ic & 63);
+  };
+  double pre[4][N];   // node row `row` of the shard about to be processed
+  double preA[4];     // LxF: its cell averages (wave 0)
+  double preh[HR];    // rows row, row+N, ... of halo slot `lane`
+  auto issue_prefetch = [&](int sh, int hidx) {
+    const double *up = a.Ucur + (size_t)sh * NDOF * 64 + lane;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int mm = 0; mm < N; ++mm) pre[c][mm] = up[(c * NS + mm + N * row) * 64];
+    if constexpr (FLUX == DFLO_FLUX_LXF) {
+      if (row == 0) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) preA[c] = a.avg_cur[((size_t)sh * 4 + c) * 64 + lane];
+      }
+    }
+    // lanes beyond the halo count re-read cell slot 0 (their table entry is 0): no branch, no join
+#pragma unroll
+    for (int t = 0; t < HR; ++t) {
+      const int d = row + N * t;
+      if (d < ROWS) preh[t] = *src(d, hidx);
+    }
+  };
+
+  int shard = shard_at(j);
+  if (shard < 0) return;
+#ifdef DFLO_PHASE_TIMING
+  unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
+#endif
+  // Loads are never predicated on "is there a next shard": past the end they re-read this
+  // workgroup's current shard (cache hits), which keeps the loop free of joins that drain vmcnt.
+  ShardAhead cur;
+  load_ahead(shard, cur);
+  issue_prefetch(shard, a.halo_pad[(size_t)shard * 64 + lane]);
+  j += jstride;
+  int next = shard_at(j);
+  int hidx_next = a.halo_pad[(size_t)(next >= 0 ? next : shard) * 64 + lane];
+
+  for (;;) {
+    // Everything still in flight here was issued a whole shard ago (the prefetch) or earlier; draining
+    // it costs nothing and gives the compiler an exact scoreboard: no load issued below is waited for
+    // with vmcnt(0) anywhere in the loop body.
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+    j += jstride;
+    const int next2 = shard_at(j);
+    const int sh_n = next >= 0 ? next : shard, sh_n2 = next2 >= 0 ? next2 : shard;
+    // ---- issued first, consumed late: halo indices two shards ahead, this shard's face references
+    const int hidx_next2 = a.halo_pad[(size_t)sh_n2 * 64 + lane];
+    uint16_t cref[4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) cref[f] = a.cell_face[((size_t)shard * 4 + f) * 64 + lane];
+    const double h = a.cell_h[(size_t)shard * 64 + lane];
+    const bool active = lane < cur.hdr.x;
+    const int nf = __builtin_amdgcn_readfirstlane(cur.hdr.y), nfp = nf * N;
+    const int nh = __builtin_amdgcn_readfirstlane(cur.hdr.z), nbnd = __builtin_amdgcn_readfirstlane(cur.hdr.w);
+    PHASE_MARK(0);
+
+    // ---- phase A: prefetched registers -> LDS
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int m = 0; m < N; ++m) Us[(c * NS + m + N * row) * S + lane] = pre[c][m];
+    if constexpr (FLUX == DFLO_FLUX_LXF) {
+      if (row == 0) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) Us[(NDOF + c) * S + lane] = preA[c];
+      }
+    }
+    if (lane < nh) {
+#pragma unroll
+      for (int t = 0; t < HR; ++t) {
+        const int d = row + N * t;
+        if (d < ROWS) Us[d * S + 64 + lane] = preh[t];
+      }
+    }
+    if (nh > 64) {  // oversized halo (unstructured shards): late fetch of the slots beyond the lanes
+      const int hb = a.halo_begin[shard];
+      for (int i = tid; i < (nh - 64) * ROWS; i += NT) {
+        const int d = i / (nh - 64), sl = 64 + i % (nh - 64);
+        Us[d * S + 64 + sl] = *src(d, a.halo_cells[hb + sl]);
+      }
+      for (int i = tid + 2 * NT; i < nf; i += NT) Fr[i] = a.faces_pad[(size_t)shard * a.face_pitch + i];
+    }
+    if (tid < nf) Fr[tid] = cur.fr[0];
+    if (tid + NT < nf) Fr[tid + NT] = cur.fr[1];
+    if (nbnd > 0) {  // boundary values and kinds of this shard's boundary faces (not prefetched: few shards)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const FaceRec r = cur.fr[t];
+        if (tid + t * NT < nf && ((r.w0 >> 18) & 1)) {
+          const int bl = (r.w0 >> 20) & 0x3FF, bf = r.w1;
+          Bk[bl] = a.bface_kind[bf];
+          for (int i = 0; i < 4 * N; ++i) Bv[bl * 4 * N + i] = a.bval[(size_t)bf * 4 * N + i];
+        }
+      }
+      for (int i = tid + 2 * NT; i < nf; i += NT) {
+        const FaceRec r = a.faces_pad[(size_t)shard * a.face_pitch + i];
+        if ((r.w0 >> 18) & 1) {
+          const int bl = (r.w0 >> 20) & 0x3FF, bf = r.w1;
+          Bk[bl] = a.bface_kind[bf];
+          for (int k2 = 0; k2 < 4 * N; ++k2) Bv[bl * 4 * N + k2] = a.bval[(size_t)bf * 4 * N + k2];
+        }
+      }
+    }
+    PHASE_MARK(1);
+    __syncthreads();
+    PHASE_MARK(2);
+
+    // ---- keep the next shard's loads in flight while this one is computed
+    ShardAhead nxt;
+    load_ahead(sh_n, nxt);
+    issue_prefetch(sh_n, hidx_next);
+
+    // ---- phase B: one numerical flux per face point (integrate_face_term_explicit :303-341,
+    //      integrate_boundary_term_explicit :176-206).  Face-point index p = q * nf + k: neighbouring
+    //      lanes take neighbouring faces at the same q -> same LDS rows, consecutive slots.
+    for (int p = tid; p < nfp; p += NT) {
+      const int q = p / nf, k = p - q * nf;
+      const FaceRec r = Fr[k];
       const int slotL = r.w0 & 0xFFFF, fL = (r.w0 >> 16) & 3;
       const bool bnd = (r.w0 >> 18) & 1, flip = (r.w0 >> 19) & 1;
       const int fR = (r.w0 >> 20) & 3;
       double Wp[4], Wm[4], Ap[4], Am[4], F[4];
+      double lwL[N], lwR[N];
+#pragma unroll
+      for (int m = 0; m < N; ++m) {
+        lwL[m] = Lt[(fL & 1) * N + m];
+        lwR[m] = Lt[(fR & 1) * N + m];
+      }
       {  // trace of the integrating cell: W+ = sum_m l_m(0|1) U[m,q] (x faces) or U[q,m] (y faces)
         const int base = fL < 2 ? N * q : q, str = fL < 2 ? 1 : N;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
           double v = 0;
 #pragma unroll
-          for (int m = 0; m < N; ++m) v += ((fL & 1) ? kb.L1[m] : kb.L0[m]) * Us[(c * NS + base + m * str) * S + slotL];
+          for (int m = 0; m < N; ++m) v += lwL[m] * Us[(c * NS + base + m * str) * S + slotL];
           Wp[c] = v;
         }
       }
@@ -143,7 +418,7 @@ __global__ __launch_bounds__(64) void stage_kernel(const StageArgs a) {
       const double ny = fL == 2 ? -1.0 : (fL == 3 ? 1.0 : 0.0);
       if constexpr (FLUX == DFLO_FLUX_LXF) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) Ap[c] = As[c * S + slotL];
+        for (int c = 0; c < 4; ++c) Ap[c] = Us[(NDOF + c) * S + slotL];
       }
       if (!bnd) {
         const int slotR = r.w1;
@@ -153,18 +428,18 @@ __global__ __launch_bounds__(64) void stage_kernel(const StageArgs a) {
         for (int c = 0; c < 4; ++c) {
           double v = 0;
 #pragma unroll
-          for (int m = 0; m < N; ++m) v += ((fR & 1) ? kb.L1[m] : kb.L0[m]) * Us[(c * NS + base + m * str) * S + slotR];
+          for (int m = 0; m < N; ++m) v += lwR[m] * Us[(c * NS + base + m * str) * S + slotR];
           Wm[c] = v;
         }
         if constexpr (FLUX == DFLO_FLUX_LXF) {
 #pragma unroll
-          for (int c = 0; c < 4; ++c) Am[c] = As[c * S + slotR];
+          for (int c = 0; c < 4; ++c) Am[c] = Us[(NDOF + c) * S + slotR];
         }
       } else {
-        const int bf = r.w1;
-        const double *bv = a.bval + ((size_t)bf * N + q) * 4;
+        const int bl = (r.w0 >> 20) & 0x3FF;
+        const double *bv = Bv + (bl * N + q) * 4;
         double bvv[4] = {bv[0], bv[1], bv[2], bv[3]};
-        compute_Wminus(a.bface_kind[bf], nx, ny, Wp, bvv, Wm);
+        compute_Wminus(Bk[bl], nx, ny, Wp, bvv, Wm);
         if constexpr (FLUX == DFLO_FLUX_LXF) {  // both averages are the interior cell's, :200-205
 #pragma unroll
           for (int c = 0; c < 4; ++c) Am[c] = Ap[c];
@@ -172,112 +447,74 @@ __global__ __launch_bounds__(64) void stage_kernel(const StageArgs a) {
       }
       numerical_normal_flux<FLUX>(nx, ny, Wp, Wm, Ap, Am, F);
 #pragma unroll
-      for (int c = 0; c < 4; ++c) Fh[c * a.max_fp + p] = F[c];
+      for (int c = 0; c < 4; ++c) Fh[c * a.max_fp + k * N + q] = F[c];
     }
-  }
-  __syncthreads();
+    PHASE_MARK(3);
+    __syncthreads();
+    PHASE_MARK(4);
 
-  // ---- phase C: lane = cell
-  const int cnt = a.shard_count[shard];
-  double res = 0.0, dtmin = 1.0e20;
-  if (lane < cnt) {
-    const double h = a.uniform_h ? a.h_uniform : a.cell_h[(size_t)shard * 64 + lane];
-    double R[NDOF];
-#pragma unroll
-    for (int d = 0; d < NDOF; ++d) R[d] = 0.0;
-    // volume term (integrate_cell_term_explicit :57-115); collocation: W_q = U_q, and
-    // grad phi_(a',b)(x_(a,b)) = D[a][a']/h e_x, JxW = w_a w_b h^2
-#pragma unroll
-    for (int b = 0; b < N; ++b)
-#pragma unroll
-      for (int aa = 0; aa < N; ++aa) {
-        const int j = aa + N * b;
-        double W[4], Fx[4], Gy[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) W[c] = Us[(c * NS + j) * S + lane];
-        flux_xy(W, Fx, Gy);
-        const double wbh = kb.w[b] * h, wah = kb.w[aa] * h;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const double fx = Fx[c] * wbh, gy = Gy[c] * wah;
-#pragma unroll
-          for (int m = 0; m < N; ++m) {
-            R[c * NS + m + N * b] += fx * kb.DW[aa][m];
-            R[c * NS + aa + N * m] += gy * kb.DW[b][m];
-          }
-        }
-        if (a.gravity != 0.0) {  // forcing (src/equation.h:831-850): (0, -rho, 0, -my) * gravity
-          const double jxw = kb.w[aa] * kb.w[b] * h * h;
-          R[MY * NS + j] += a.gravity * (-1.0 * W[RHO]) * jxw;
-          R[EN * NS + j] += a.gravity * (-1.0 * W[MY]) * jxw;
-        }
-      }
-    // face terms (:209-244, :344-423): - flux * phi * JxW on the integrating side, + on the other
-#pragma unroll
-    for (int f = 0; f < 4; ++f) {
-      const uint16_t ref = a.cell_face[((size_t)shard * 4 + f) * 64 + lane];
-      if (ref == kNoFace) continue;
-      const int k = ref & 0x3FFF;
-      const bool flip = (ref >> 14) & 1;
-      const double sgn = (ref >> 15) ? 1.0 : -1.0;
-#pragma unroll
-      for (int q = 0; q < N; ++q) {
-        const int qq = flip ? N - 1 - q : q;
-        const double jxw = sgn * kb.w[q] * h;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const double fq = Fh[c * a.max_fp + k * N + qq] * jxw;
-#pragma unroll
-          for (int m = 0; m < N; ++m) {
-            const double lw = (f & 1) ? kb.L1[m] : kb.L0[m];
-            if (f < 2) R[c * NS + m + N * q] += fq * lw;
-            else R[c * NS + q + N * m] += fq * lw;
-          }
-        }
-      }
-    }
-    if (a.rhs_out) {
-      double *rp = a.rhs_out + (size_t)shard * NDOF * 64 + lane;
-#pragma unroll
-      for (int d = 0; d < NDOF; ++d) rp[d * 64] = R[d];
-    } else {
-      // solve() rk3 branch + SSP combine (src/claw.cc:708-710, 757-760)
-      const double dt = a.dt_cell ? a.dt_cell[(size_t)shard * 64 + lane] : (a.dt_host >= 0.0 ? a.dt_host : *a.dt_dev);
-      const double rh2 = 1.0 / (h * h);
+    // ---- phase C: volume + lifting + RK update of node row `row`
+    double *red = Fh;  // reused after the barrier inside row_update
+    // u(n): issued behind the prefetch, consumed at the very end of the row update, by which time
+    // the (older) prefetch has landed anyway
+    double uold[4][N];
+    if constexpr (MODE == 1) {
       const double *op = a.Uold + (size_t)shard * NDOF * 64 + lane;
-      double *np = a.Unew + (size_t)shard * NDOF * 64 + lane;
-      double avg[4] = {0, 0, 0, 0};
 #pragma unroll
       for (int c = 0; c < 4; ++c)
 #pragma unroll
-        for (int j = 0; j < NS; ++j) {
-          const int d = c * NS + j;
-          const double ww = kb.w[j % N] * kb.w[j / N];
-          const double invM = rh2 / ww;
-          res += R[d] * R[d];
-          double u = Us[d * S + lane];
-          u += dt * R[d] * invM;
-          if (a.ark != 0.0) u = (1.0 - a.ark) * u + a.ark * op[d * 64];
-          np[d * 64] = u;
-          avg[c] += ww * u;
-        }
+        for (int m = 0; m < N; ++m) uold[c][m] = op[(c * NS + m + N * row) * 64];
+    }
+    if constexpr (N == 2) {
+      if (row == 0) row_update<N, 0, MODE>(a, Us, Fh, red, shard, lane, active, h, cref, uold);
+      else row_update<N, 1, MODE>(a, Us, Fh, red, shard, lane, active, h, cref, uold);
+    } else if constexpr (N == 3) {
+      if (row == 0) row_update<N, 0, MODE>(a, Us, Fh, red, shard, lane, active, h, cref, uold);
+      else if (row == 1) row_update<N, 1, MODE>(a, Us, Fh, red, shard, lane, active, h, cref, uold);
+      else row_update<N, 2, MODE>(a, Us, Fh, red, shard, lane, active, h, cref, uold);
+    } else {
+      if (row == 0) row_update<N, 0, MODE>(a, Us, Fh, red, shard, lane, active, h, cref, uold);
+      else if (row == 1) row_update<N, 1, MODE>(a, Us, Fh, red, shard, lane, active, h, cref, uold);
+      else if (row == 2) row_update<N, 2, MODE>(a, Us, Fh, red, shard, lane, active, h, cref, uold);
+      else row_update<N, 3, MODE>(a, Us, Fh, red, shard, lane, active, h, cref, uold);
+    }
+    PHASE_MARK(5);
+    __syncthreads();
+    PHASE_MARK(6);
+    if (MODE != 2 && row == 0) {  // cell averages (src/claw.cc:562-597), residual norm, CFL minimum
+      double avg[4], res = 0.0, dtmin = 1.0e20;
 #pragma unroll
-      for (int c = 0; c < 4; ++c) a.avg_new[((size_t)shard * 4 + c) * 64 + lane] = avg[c];
-      if (a.want_dt) {  // compute_time_step_cartesian, src/claw.cc:495-509
-        const double sonic = sqrt(kGamma * pressure(avg) / avg[RHO]);
-        const double maxeig = (sonic + fabs(avg[MX] / avg[RHO])) / h + (sonic + fabs(avg[MY] / avg[RHO])) / h;
-        dtmin = a.cfl / maxeig / (2.0 * a.degree + 1.0);
+      for (int c = 0; c < 4; ++c) {
+        double v = 0;
+#pragma unroll
+        for (int b = 0; b < N; ++b) v += red[(b * 5 + c) * 64 + lane];
+        avg[c] = v;
+      }
+#pragma unroll
+      for (int b = 0; b < N; ++b) res += red[(b * 5 + 4) * 64 + lane];
+      if (active) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) a.avg_new[((size_t)shard * 4 + c) * 64 + lane] = avg[c];
+        if (a.want_dt) dtmin = cfl_dt(avg, h, a.cfl, a.degree);
+      }
+      res = wave_sum(res);
+      dtmin = wave_min(dtmin);
+      if (lane == 0) {
+        a.shard_res[shard] = res;
+        if (a.want_dt) a.shard_dtmin[shard] = dtmin;
       }
     }
+    PHASE_MARK(7);
+    if (next < 0) break;
+    shard = next;
+    next = next2;
+    cur = nxt;
+    hidx_next = hidx_next2;
   }
-  if (!a.rhs_out) {
-    res = wave_sum(res);
-    dtmin = wave_min(dtmin);
-    if (lane == 0) {
-      a.shard_res[shard] = res;
-      if (a.want_dt) a.shard_dtmin[shard] = dtmin;
-    }
-  }
+#ifdef DFLO_PHASE_TIMING
+  if (tid == 0 && a.phase_cycles)
+    for (int i = 0; i < 8; ++i) a.phase_cycles[(size_t)blockIdx.x * 8 + i] = tacc[i];
+#endif
 }
 
 // ------------------------------------------------------------------ limiter kernel
@@ -462,6 +699,15 @@ __global__ __launch_bounds__(64) void limiter_kernel(const LimArgs a) {
   }
 }
 
+// accuracy probe of the reciprocal / square-root forms used by the flux functions
+__global__ void debug_math_kernel(const double *x, double *rcp, double *sq, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    rcp[i] = frcp(x[i]);
+    sq[i] = fsqrt(x[i]);
+  }
+}
+
 // ------------------------------------------------------------------ small kernels
 // user (dflo) layout <-> shard SoA layout
 __global__ void scatter_kernel(const double *user, double *U, const int32_t *user_of, int n_slots, int ndof) {
@@ -532,9 +778,7 @@ __global__ void dt_kernel(const double *avg, const double *cell_h, double h_unif
     double A[4];
     for (int c = 0; c < 4; ++c) A[c] = avg[((size_t)shard * 4 + c) * 64 + lane];
     const double h = uniform_h ? h_uniform : cell_h[(size_t)shard * 64 + lane];
-    const double sonic = sqrt(kGamma * pressure(A) / A[RHO]);
-    const double maxeig = (sonic + fabs(A[MX] / A[RHO])) / h + (sonic + fabs(A[MY] / A[RHO])) / h;
-    dtmin = cfl / maxeig / (2.0 * degree + 1.0);
+    dtmin = cfl_dt(A, h, cfl, degree);
   }
   dtmin = wave_min(dtmin);
   if (lane == 0) shard_dtmin[shard] = dtmin;
@@ -611,7 +855,10 @@ struct dflo_hip_engine {
   double *bval[2] = {nullptr, nullptr};
   int32_t *bface_kind = nullptr;
   int32_t *d_shard_count = nullptr, *d_halo_begin = nullptr, *d_halo_cells = nullptr, *d_face_begin = nullptr;
-  FaceRec *d_faces = nullptr;
+  FaceRec *d_faces = nullptr, *d_faces_pad = nullptr;
+  int4 *d_shard_hdr = nullptr;
+  int32_t *d_halo_pad = nullptr;
+  int face_pitch = 0;
   uint16_t *d_cell_face = nullptr;
   int32_t *d_lrbt = nullptr, *d_user_of = nullptr, *d_iid = nullptr;
   double *d_cell_h = nullptr;
@@ -624,6 +871,8 @@ struct dflo_hip_engine {
   int n_send = 0;
   double *ghost_stage = nullptr;
   size_t lds_bytes = 0;
+  int stage_grid = 8;
+  unsigned long long *phase_cycles = nullptr;
   int stride = 0, max_fp = 0;
   // timing
   bool timing = false;
@@ -658,6 +907,7 @@ KBasis make_kbasis(const BasisTables &b) {
   KBasis k{};
   for (int i = 0; i < kMaxN; ++i) {
     k.w[i] = b.w[i];
+    k.iw[i] = b.w[i] != 0.0 ? 1.0 / b.w[i] : 0.0;
     k.x[i] = b.x[i];
     k.L0[i] = b.L0[i];
     k.L1[i] = b.L1[i];
@@ -675,21 +925,25 @@ KBasis make_kbasis(const BasisTables &b) {
 }
 
 typedef void (*stage_fn)(const StageArgs);
+template <int N, int FLUX>
+stage_fn pick_stage_m(int mode) {
+  return mode == 0 ? stage_kernel<N, FLUX, 0> : (mode == 1 ? stage_kernel<N, FLUX, 1> : stage_kernel<N, FLUX, 2>);
+}
 template <int N>
-stage_fn pick_stage_n(int flux) {
+stage_fn pick_stage_n(int flux, int mode) {
   switch (flux) {
-    case DFLO_FLUX_LXF: return stage_kernel<N, DFLO_FLUX_LXF>;
-    case DFLO_FLUX_SW: return stage_kernel<N, DFLO_FLUX_SW>;
-    case DFLO_FLUX_KFVS: return stage_kernel<N, DFLO_FLUX_KFVS>;
-    case DFLO_FLUX_ROE: return stage_kernel<N, DFLO_FLUX_ROE>;
-    default: return stage_kernel<N, DFLO_FLUX_HLLC>;
+    case DFLO_FLUX_LXF: return pick_stage_m<N, DFLO_FLUX_LXF>(mode);
+    case DFLO_FLUX_SW: return pick_stage_m<N, DFLO_FLUX_SW>(mode);
+    case DFLO_FLUX_KFVS: return pick_stage_m<N, DFLO_FLUX_KFVS>(mode);
+    case DFLO_FLUX_ROE: return pick_stage_m<N, DFLO_FLUX_ROE>(mode);
+    default: return pick_stage_m<N, DFLO_FLUX_HLLC>(mode);
   }
 }
-stage_fn pick_stage(int N, int flux) {
+stage_fn pick_stage(int N, int flux, int mode) {
   switch (N) {
-    case 2: return pick_stage_n<2>(flux);
-    case 3: return pick_stage_n<3>(flux);
-    default: return pick_stage_n<4>(flux);
+    case 2: return pick_stage_n<2>(flux, mode);
+    case 3: return pick_stage_n<3>(flux, mode);
+    default: return pick_stage_n<4>(flux, mode);
   }
 }
 
@@ -730,6 +984,7 @@ int launch_update(dflo_hip_engine *h, int rk, double dt_host, double *rhs_out, i
   else if (last && h->cur != h->old) out = h->old;
   else { out = 0; while (out == h->cur || out == h->old) ++out; }
   StageArgs a{};
+  a.phase_cycles = h->phase_cycles;
   a.Ucur = h->U[h->cur];
   a.Uold = h->U[h->old];
   a.Unew = h->U[out];
@@ -740,6 +995,10 @@ int launch_update(dflo_hip_engine *h, int rk, double dt_host, double *rhs_out, i
   a.halo_begin = h->d_halo_begin;
   a.halo_cells = h->d_halo_cells;
   a.face_begin = h->d_face_begin;
+  a.shard_hdr = h->d_shard_hdr;
+  a.halo_pad = h->d_halo_pad;
+  a.faces_pad = h->d_faces_pad;
+  a.face_pitch = h->face_pitch;
   a.faces = h->d_faces;
   a.cell_face = h->d_cell_face;
   a.cell_h = h->d_cell_h;
@@ -758,13 +1017,15 @@ int launch_update(dflo_hip_engine *h, int rk, double dt_host, double *rhs_out, i
   a.n_shards = p.n_shards;
   a.stride = h->stride;
   a.max_fp = h->max_fp;
+  a.max_faces = std::max(h->plan.max_faces, 1);
+  a.max_bnd = h->plan.max_bnd;
   a.uniform_h = p.uniform_h ? 1 : 0;
   a.want_dt = last ? 1 : 0;
   a.degree = h->degree;
   a.kb = h->kb;
-  stage_fn fn = pick_stage(h->N, h->prm.flux_type);
+  stage_fn fn = pick_stage(h->N, h->prm.flux_type, rhs_out ? 2 : (h->ark[rk] != 0.0 ? 1 : 0));
   time_begin(h);
-  hipLaunchKernelGGL(fn, dim3(grid_for(p.n_shards)), dim3(64), h->lds_bytes, h->stream, a);
+  hipLaunchKernelGGL(fn, dim3(h->stage_grid), dim3(64 * h->N), h->lds_bytes, h->stream, a);
   time_end(h);
   HIPCHK(h, hipGetLastError());
   if (rhs_out) return DFLO_OK;
@@ -931,6 +1192,24 @@ int dflo_hip_create(const dflo_mesh_t *mesh, const dflo_params_t *params, int de
   if ((rc = upload(h, &h->d_face_begin, p.face_begin))) return bail(rc);
   if ((rc = upload(h, &h->d_faces, p.faces))) return bail(rc);
   if ((rc = upload(h, &h->d_cell_face, p.cell_face))) return bail(rc);
+  {  // fixed-pitch copies of the per-shard lists (+2 shards of slack: the kernel reads two shards ahead,
+     // and 2*64*N face slots per shard so that unconditional loads stay in bounds)
+    const int ns = p.n_shards + 2;
+    h->face_pitch = 2 * 64 * h->N;
+    if (p.max_faces > h->face_pitch) { h->err = "more than 2 faces per thread in a shard"; return bail(DFLO_ERR_UNSUPPORTED); }
+    std::vector<int4> hdr(ns, int4{0, 0, 0, 0});
+    std::vector<int32_t> hp((size_t)ns * 64, 0);
+    std::vector<FaceRec> fpad((size_t)ns * h->face_pitch, FaceRec{0, 0});
+    for (int sidx = 0; sidx < p.n_shards; ++sidx) {
+      const int nh = p.halo_begin[sidx + 1] - p.halo_begin[sidx], nf = p.face_begin[sidx + 1] - p.face_begin[sidx];
+      hdr[sidx] = int4{p.shard_count[sidx], nf, nh, p.shard_bnd[sidx]};
+      for (int k = 0; k < std::min(nh, 64); ++k) hp[(size_t)sidx * 64 + k] = p.halo_cells[p.halo_begin[sidx] + k];
+      for (int k = 0; k < nf; ++k) fpad[(size_t)sidx * h->face_pitch + k] = p.faces[p.face_begin[sidx] + k];
+    }
+    if ((rc = upload(h, &h->d_shard_hdr, hdr))) return bail(rc);
+    if ((rc = upload(h, &h->d_halo_pad, hp))) return bail(rc);
+    if ((rc = upload(h, &h->d_faces_pad, fpad))) return bail(rc);
+  }
   if ((rc = upload(h, &h->d_lrbt, p.lrbt))) return bail(rc);
   if ((rc = upload(h, &h->d_user_of, p.user_of))) return bail(rc);
   if ((rc = upload(h, &h->d_iid, p.iid))) return bail(rc);
@@ -947,15 +1226,33 @@ int dflo_hip_create(const dflo_mesh_t *mesh, const dflo_params_t *params, int de
   hipMemset(h->dt_dev, 0, 4 * sizeof(double));
   hipMemset(h->flags, 0, 4 * sizeof(int));
   h->stride = 64 + p.max_halo;
-  h->max_fp = std::max(p.max_faces, 1) * h->N;
-  h->lds_bytes = ((size_t)h->ndof * h->stride + 4 * h->stride + 4 * (size_t)h->max_fp) * sizeof(double);
+  while (h->stride % 32 != 1) ++h->stride;  // row stride = 1 mod 32 doubles: rows fall on different LDS banks
+  h->max_fp = std::max(std::max(p.max_faces, 1) * h->N, 5 * 64 * h->N / 4 + 1);  // Fh also hosts the row partials
+  h->lds_bytes = ((size_t)(h->ndof + (h->prm.flux_type == DFLO_FLUX_LXF ? 4 : 0)) * h->stride + 4 * (size_t)h->max_fp +
+                  (size_t)std::max(p.max_faces, 1) + 2 * kMaxN + (size_t)p.max_bnd * (4 * h->N + 1) + 1) * sizeof(double);
+
   if (h->lds_bytes > 160 * 1024) { h->err = "shard halo too large for LDS"; return bail(DFLO_ERR_UNSUPPORTED); }
   if (h->lds_bytes > 64 * 1024) {
-    stage_fn fn = pick_stage(h->N, h->prm.flux_type);
-    if (hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes) != hipSuccess) {
-      h->err = "cannot raise dynamic LDS limit";
-      return bail(DFLO_ERR_HIP);
+    for (int mode = 0; mode < 3; ++mode) {
+      stage_fn fn = pick_stage(h->N, h->prm.flux_type, mode);
+      if (hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes) != hipSuccess) {
+        h->err = "cannot raise dynamic LDS limit";
+        return bail(DFLO_ERR_HIP);
+      }
     }
+  }
+  {  // persistent grid: as many workgroups as stay resident, a multiple of 8 (one run of shards per XCD)
+    stage_fn fn = pick_stage(h->N, h->prm.flux_type, 1);
+    int per_cu = 0, n_cu = 0;
+    hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, device_id);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)fn, 64 * h->N, h->lds_bytes) != hipSuccess || per_cu < 1)
+      per_cu = 1;
+    if (n_cu < 1) n_cu = 256;
+    h->stage_grid = std::min(grid_for(h->plan.n_shards), std::max(8, (per_cu * n_cu) / 8 * 8));
+#ifdef DFLO_PHASE_TIMING
+    hipMalloc((void **)&h->phase_cycles, (size_t)h->stage_grid * 8 * sizeof(unsigned long long));
+    hipMemset(h->phase_cycles, 0, (size_t)h->stage_grid * 8 * sizeof(unsigned long long));
+#endif
   }
   *out = h;
   return DFLO_OK;
@@ -969,7 +1266,7 @@ int dflo_hip_destroy(dflo_hip_handle h) {
   for (int i = 0; i < 2; ++i) { hipFree(h->avg[i]); hipFree(h->bval[i]); }
   hipFree(h->rhs); hipFree(h->user_buf); hipFree(h->bface_kind);
   hipFree(h->d_shard_count); hipFree(h->d_halo_begin); hipFree(h->d_halo_cells); hipFree(h->d_face_begin);
-  hipFree(h->d_faces); hipFree(h->d_cell_face); hipFree(h->d_lrbt); hipFree(h->d_user_of); hipFree(h->d_iid);
+  hipFree(h->d_faces); hipFree(h->d_faces_pad); hipFree(h->d_shard_hdr); hipFree(h->d_halo_pad); hipFree(h->d_cell_face); hipFree(h->d_lrbt); hipFree(h->d_user_of); hipFree(h->d_iid);
   hipFree(h->d_cell_h); hipFree(h->shard_res); hipFree(h->shard_dtmin); hipFree(h->res_sq); hipFree(h->dt_dev);
   hipFree(h->flags); hipFree(h->d_send_slots); hipFree(h->ghost_stage);
   for (auto &e : h->ev_pool) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
@@ -1295,6 +1592,29 @@ int dflo_hip_scalar_ptrs(dflo_hip_handle h, void **dt_ptr, void **res_ptr) {
   if (dt_ptr) *dt_ptr = h->dt_dev;
   if (res_ptr) *res_ptr = h->res_sq;
   return DFLO_OK;
+}
+
+int dflo_hip_debug_math(int n, const double *x, double *rcp_out, double *sqrt_out) {
+  double *dx = nullptr, *dr = nullptr, *ds = nullptr;
+  if (hipMalloc((void **)&dx, n * sizeof(double)) != hipSuccess || hipMalloc((void **)&dr, n * sizeof(double)) != hipSuccess ||
+      hipMalloc((void **)&ds, n * sizeof(double)) != hipSuccess)
+    return DFLO_ERR_HIP;
+  hipMemcpy(dx, x, n * sizeof(double), hipMemcpyHostToDevice);
+  hipLaunchKernelGGL(debug_math_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, dx, dr, ds, n);
+  hipMemcpy(rcp_out, dr, n * sizeof(double), hipMemcpyDeviceToHost);
+  hipMemcpy(sqrt_out, ds, n * sizeof(double), hipMemcpyDeviceToHost);
+  hipFree(dx); hipFree(dr); hipFree(ds);
+  return hipGetLastError() == hipSuccess ? DFLO_OK : DFLO_ERR_HIP;
+}
+
+/* developer probe: per-workgroup cycle counts of the stage kernel's phases (library built with
+ * -DDFLO_PHASE_TIMING); returns the grid size, 0 when the probe is compiled out. */
+int dflo_hip_debug_phase_cycles(dflo_hip_handle h, unsigned long long *out, int max_groups) {
+  if (!h || !h->phase_cycles) return 0;
+  const int n = std::min(max_groups, h->stage_grid);
+  hipStreamSynchronize(h->stream);
+  hipMemcpy(out, h->phase_cycles, (size_t)n * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+  return h->stage_grid;
 }
 
 int dflo_hip_apply_dt_rules(dflo_hip_handle h) {

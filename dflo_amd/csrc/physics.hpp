@@ -14,45 +14,84 @@ constexpr double kGamma = 1.4;
 constexpr double kG1 = kGamma - 1.0;
 constexpr int MX = 0, MY = 1, RHO = 2, EN = 3;
 
+// ---- fp64 reciprocal / square root without the IEEE corner-case scaffolding.
+// hipcc expands a/b into v_div_scale x2 + v_rcp + 5 fma + v_div_fmas + v_div_fixup (10 issue slots of
+// 4 cycles) and sqrt into 17; states here are finite, positive and far from the exponent limits, so
+// v_rcp_f64 / v_rsq_f64 plus two Newton steps (<= 1 ulp, checked in tests/test_gpu_parity.py) do.
+__device__ __forceinline__ double frcp(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  double e = __builtin_fma(-x, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  e = __builtin_fma(-x, r, 1.0);
+  return __builtin_fma(r, e, r);
+}
+__device__ __forceinline__ double fsqrt(double x) {  // x > 0
+  const double y = __builtin_amdgcn_rsq(x);
+  double g = x * y, h = 0.5 * y;
+  const double r = __builtin_fma(-h, g, 0.5);
+  g = __builtin_fma(g, r, g);
+  h = __builtin_fma(h, r, h);
+  double d = __builtin_fma(-g, g, x);
+  g = __builtin_fma(d, h, g);
+  d = __builtin_fma(-g, g, x);
+  return __builtin_fma(d, h, g);
+}
+__device__ __forceinline__ double fsqrt0(double x) { return x > 0.0 ? fsqrt(x) : 0.0; }
+
 __device__ __forceinline__ double pressure(const double *W) {  // src/equation.h:87-92
-  const double ke = (W[MX] * W[MX] + W[MY] * W[MY]) * (0.5 / W[RHO]);
+  const double ke = (W[MX] * W[MX] + W[MY] * W[MY]) * (0.5 * frcp(W[RHO]));
   return kG1 * (W[EN] - ke);
 }
 
 // F(W): x- and y- flux columns, src/equation.h:160-193
 __device__ __forceinline__ void flux_xy(const double *W, double *Fx, double *Gy) {
-  const double p = pressure(W);
-  Fx[MX] = W[MX] * W[MX] / W[RHO] + p;
-  Fx[MY] = W[MY] * W[MX] / W[RHO];
-  Gy[MX] = W[MX] * W[MY] / W[RHO];
-  Gy[MY] = W[MY] * W[MY] / W[RHO] + p;
+  const double ri = frcp(W[RHO]);
+  const double u = W[MX] * ri, v = W[MY] * ri;
+  const double p = kG1 * (W[EN] - 0.5 * (W[MX] * u + W[MY] * v));
+  Fx[MX] = W[MX] * u + p;
+  Fx[MY] = W[MY] * u;
+  Gy[MX] = W[MX] * v;
+  Gy[MY] = W[MY] * v + p;
   Fx[RHO] = W[MX];
   Gy[RHO] = W[MY];
-  Fx[EN] = W[MX] / W[RHO] * (W[EN] + p);
-  Gy[EN] = W[MY] / W[RHO] * (W[EN] + p);
+  Fx[EN] = u * (W[EN] + p);
+  Gy[EN] = v * (W[EN] + p);
+}
+// y column only
+__device__ __forceinline__ void flux_y(const double *W, double *Gy) {
+  const double ri = frcp(W[RHO]);
+  const double u = W[MX] * ri, v = W[MY] * ri;
+  const double p = kG1 * (W[EN] - 0.5 * (W[MX] * u + W[MY] * v));
+  Gy[MX] = W[MX] * v;
+  Gy[MY] = W[MY] * v + p;
+  Gy[RHO] = W[MY];
+  Gy[EN] = v * (W[EN] + p);
 }
 
 // |v.n| + c of a (cell average) state, src/equation.h:122-137
 __device__ __forceinline__ double max_eigenvalue_n(const double *W, double nx, double ny) {
-  const double p = pressure(W);
-  const double sonic = sqrt(kGamma * p / W[RHO]);
-  double vel = W[MX] * nx + W[MY] * ny;
-  vel /= W[RHO];
+  const double ri = frcp(W[RHO]);
+  const double p = kG1 * (W[EN] - 0.5 * (W[MX] * W[MX] + W[MY] * W[MY]) * ri);
+  const double sonic = fsqrt(kGamma * p * ri);
+  const double vel = (W[MX] * nx + W[MY] * ny) * ri;
   return fabs(vel) + sonic;
 }
 // |v| + c, src/equation.h:100-114
 __device__ __forceinline__ double max_eigenvalue(const double *W) {
-  const double p = pressure(W);
-  const double vel = sqrt(W[MX] * W[MX] + W[MY] * W[MY]) / W[RHO];
-  return vel + sqrt(kGamma * p / W[RHO]);
+  const double ri = frcp(W[RHO]);
+  const double q2 = W[MX] * W[MX] + W[MY] * W[MY];
+  const double p = kG1 * (W[EN] - 0.5 * q2 * ri);
+  return fsqrt0(q2) * ri + fsqrt(kGamma * p * ri);
 }
 
 // src/equation.h:326-377; lambda comes from the two CELL AVERAGES Ap, Am (src/equation.h:357-359)
 __device__ __forceinline__ void lxf_flux(double nx, double ny, const double *Wp, const double *Wm, const double *Ap,
                                          const double *Am, double *F) {
-  const double vp = (Wp[MX] * nx + Wp[MY] * ny) / Wp[RHO];
-  const double vm = (Wm[MX] * nx + Wm[MY] * ny) / Wm[RHO];
-  const double pp = pressure(Wp), pm = pressure(Wm);
+  const double rp = frcp(Wp[RHO]), rm = frcp(Wm[RHO]);
+  const double vp = (Wp[MX] * nx + Wp[MY] * ny) * rp;
+  const double vm = (Wm[MX] * nx + Wm[MY] * ny) * rm;
+  const double pp = kG1 * (Wp[EN] - 0.5 * (Wp[MX] * Wp[MX] + Wp[MY] * Wp[MY]) * rp);
+  const double pm = kG1 * (Wm[EN] - 0.5 * (Wm[MX] * Wm[MX] + Wm[MY] * Wm[MY]) * rm);
   const double lambda = fmax(max_eigenvalue_n(Ap, nx, ny), max_eigenvalue_n(Am, nx, ny));
   F[MX] = 0.5 * (pp * nx + Wp[MX] * vp + pm * nx + Wm[MX] * vm);
   F[MY] = 0.5 * (pp * ny + Wp[MY] * vp + pm * ny + Wm[MY] * vm);
@@ -65,28 +104,29 @@ __device__ __forceinline__ void lxf_flux(double nx, double ny, const double *Wp,
 // src/equation.h:384-464
 __device__ __forceinline__ void steger_warming_flux(double nx, double ny, const double *Wp, const double *Wm, double *F) {
   const double n[2] = {nx, ny};
-  double vp = (Wp[MX] * nx + Wp[MY] * ny) / Wp[RHO];
-  double vm = (Wm[MX] * nx + Wm[MY] * ny) / Wm[RHO];
-  double q2p = (Wp[MX] * Wp[MX] + Wp[MY] * Wp[MY]) / (Wp[RHO] * Wp[RHO]);
-  double q2m = (Wm[MX] * Wm[MX] + Wm[MY] * Wm[MY]) / (Wm[RHO] * Wm[RHO]);
-  const double pp = pressure(Wp), pm = pressure(Wm);
-  const double cp = sqrt(kGamma * pp / Wp[RHO]), cm = sqrt(kGamma * pm / Wm[RHO]);
+  const double rp = frcp(Wp[RHO]), rm = frcp(Wm[RHO]);
+  const double vp = (Wp[MX] * nx + Wp[MY] * ny) * rp;
+  const double vm = (Wm[MX] * nx + Wm[MY] * ny) * rm;
+  const double q2p = (Wp[MX] * Wp[MX] + Wp[MY] * Wp[MY]) * (rp * rp);
+  const double q2m = (Wm[MX] * Wm[MX] + Wm[MY] * Wm[MY]) * (rm * rm);
+  const double pp = kG1 * (Wp[EN] - 0.5 * Wp[RHO] * q2p), pm = kG1 * (Wm[EN] - 0.5 * Wm[RHO] * q2m);
+  const double cp = fsqrt(kGamma * pp * rp), cm = fsqrt(kGamma * pm * rm);
   const double l1p = fmax(vp, 0.0), l2p = fmax(vp + cp, 0.0), l3p = fmax(vp - cp, 0.0);
   const double ap = 2.0 * kG1 * l1p + l2p + l3p;
-  const double fp = 0.5 * Wp[RHO] / kGamma;
+  const double fp = Wp[RHO] * (0.5 / kGamma);
   const double l1m = fmin(vm, 0.0), l2m = fmin(vm + cm, 0.0), l3m = fmin(vm - cm, 0.0);
   const double am = 2.0 * kG1 * l1m + l2m + l3m;
-  const double fm = 0.5 * Wm[RHO] / kGamma;
+  const double fm = Wm[RHO] * (0.5 / kGamma);
   double pf[4], mf[4];
 #pragma unroll
   for (int d = 0; d < 2; ++d) {
-    pf[d] = ap * Wp[d] / Wp[RHO] + cp * (l2p - l3p) * n[d];
-    mf[d] = am * Wm[d] / Wm[RHO] + cm * (l2m - l3m) * n[d];
+    pf[d] = ap * Wp[d] * rp + cp * (l2p - l3p) * n[d];
+    mf[d] = am * Wm[d] * rm + cm * (l2m - l3m) * n[d];
   }
   pf[RHO] = ap;
-  pf[EN] = 0.5 * ap * q2p + cp * vp * (l2p - l3p) + cp * cp * (l2p + l3p) / kG1;
+  pf[EN] = 0.5 * ap * q2p + cp * vp * (l2p - l3p) + cp * cp * (l2p + l3p) * (1.0 / kG1);
   mf[RHO] = am;
-  mf[EN] = 0.5 * am * q2m + cm * vm * (l2m - l3m) + cm * cm * (l2m + l3m) / kG1;
+  mf[EN] = 0.5 * am * q2m + cm * vm * (l2m - l3m) + cm * cm * (l2m + l3m) * (1.0 / kG1);
 #pragma unroll
   for (int c = 0; c < 4; ++c) F[c] = fp * pf[c] + fm * mf[c];
 }
@@ -94,14 +134,15 @@ __device__ __forceinline__ void steger_warming_flux(double nx, double ny, const 
 // src/equation.h:471-556 (Harten entropy fix delta = 0.1 c, :529-531)
 __device__ __forceinline__ void roe_flux(double nx, double ny, const double *Wl, const double *Wr, double *F) {
   const double n[2] = {nx, ny};
-  const double rls = sqrt(Wl[RHO]), rrs = sqrt(Wr[RHO]);
-  const double fl = rls / (rls + rrs), fr = 1.0 - fl;
+  const double rls = fsqrt(Wl[RHO]), rrs = fsqrt(Wr[RHO]);
+  const double ril = frcp(Wl[RHO]), rir = frcp(Wr[RHO]);
+  const double fl = rls * frcp(rls + rrs), fr = 1.0 - fl;
   double vl[2], vr[2], vel[2], dv[2];
   double v2l = 0, v2r = 0, vln = 0, vrn = 0, veln = 0, v2 = 0, vdv = 0;
 #pragma unroll
   for (int d = 0; d < 2; ++d) {
-    vl[d] = Wl[d] / Wl[RHO];
-    vr[d] = Wr[d] / Wr[RHO];
+    vl[d] = Wl[d] * ril;
+    vr[d] = Wr[d] * rir;
     v2l += vl[d] * vl[d];
     v2r += vr[d] * vr[d];
     vln += vl[d] * n[d];
@@ -114,23 +155,25 @@ __device__ __forceinline__ void roe_flux(double nx, double ny, const double *Wl,
   }
   const double pl = kG1 * (Wl[EN] - 0.5 * Wl[RHO] * v2l);
   const double pr = kG1 * (Wr[EN] - 0.5 * Wr[RHO] * v2r);
-  const double hl = kGamma * pl / Wl[RHO] / kG1 + 0.5 * v2l;
-  const double hr = kGamma * pr / Wr[RHO] / kG1 + 0.5 * v2r;
+  const double hl = (kGamma / kG1) * pl * ril + 0.5 * v2l;
+  const double hr = (kGamma / kG1) * pr * rir + 0.5 * v2r;
   const double rho = rls * rrs;
   const double h = hl * fl + hr * fr;
-  const double c = sqrt(kG1 * (h - 0.5 * v2));
+  const double c2 = kG1 * (h - 0.5 * v2);
+  const double c = fsqrt(c2);
+  const double ic2 = frcp(c2);
   const double drho = Wr[RHO] - Wl[RHO];
   const double dp = pr - pl;
   const double dvn = vrn - vln;
-  const double a1 = (dp - rho * c * dvn) / (2.0 * c * c);
-  const double a2 = drho - dp / (c * c);
-  const double a3 = (dp + rho * c * dvn) / (2.0 * c * c);
+  const double a1 = (dp - rho * c * dvn) * (0.5 * ic2);
+  const double a2 = drho - dp * ic2;
+  const double a3 = (dp + rho * c * dvn) * (0.5 * ic2);
   double l1 = fabs(veln - c);
   const double l2 = fabs(veln);
   double l3 = fabs(veln + c);
-  const double delta = 0.1 * c;
-  l1 = (l1 < delta) ? 0.5 * (l1 * l1 / delta + delta) : l1;
-  l3 = (l3 < delta) ? 0.5 * (l3 * l3 / delta + delta) : l3;
+  const double delta = 0.1 * c, idelta = 10.0 * frcp(c);
+  l1 = (l1 < delta) ? 0.5 * (l1 * l1 * idelta + delta) : l1;
+  l3 = (l3 < delta) ? 0.5 * (l3 * l3 * idelta + delta) : l3;
   const double Drho = l1 * a1 + l2 * a2 + l3 * a3;
   const double Den = l1 * a1 * (h - c * veln) + l2 * a2 * 0.5 * v2 + l2 * rho * (vdv - veln * dvn) + l3 * a3 * (h + c * veln);
   F[RHO] = 0.5 * (Wl[RHO] * vln + Wr[RHO] * vrn - Drho);
@@ -143,18 +186,19 @@ __device__ __forceinline__ void roe_flux(double nx, double ny, const double *Wl,
   }
 }
 
-// src/equation.h:565-681.  The four branches (:631-679) are evaluated as: left/right supersonic
-// states and the star state of the side picked by the sign of s_m, then selected.
+// src/equation.h:565-681.  The four branches (:631-679) are evaluated as: supersonic state and star
+// state of the side picked by the sign of s_m, then selected (no wavefront divergence).
 __device__ __forceinline__ void hllc_flux(double nx, double ny, const double *Wl, const double *Wr, double *F) {
   const double n[2] = {nx, ny};
-  const double rls = sqrt(Wl[RHO]), rrs = sqrt(Wr[RHO]);
-  const double fl = rls / (rls + rrs), fr = 1.0 - fl;
+  const double rls = fsqrt(Wl[RHO]), rrs = fsqrt(Wr[RHO]);
+  const double ril = frcp(Wl[RHO]), rir = frcp(Wr[RHO]);
+  const double fl = rls * frcp(rls + rrs), fr = 1.0 - fl;
   double vl[2], vr[2];
   double v2l = 0, v2r = 0, vln = 0, vrn = 0, veln = 0, v2 = 0;
 #pragma unroll
   for (int d = 0; d < 2; ++d) {
-    vl[d] = Wl[d] / Wl[RHO];
-    vr[d] = Wr[d] / Wr[RHO];
+    vl[d] = Wl[d] * ril;
+    vr[d] = Wr[d] * rir;
     v2l += vl[d] * vl[d];
     v2r += vr[d] * vr[d];
     vln += vl[d] * n[d];
@@ -165,22 +209,21 @@ __device__ __forceinline__ void hllc_flux(double nx, double ny, const double *Wl
   }
   const double pl = kG1 * (Wl[EN] - 0.5 * Wl[RHO] * v2l);
   const double pr = kG1 * (Wr[EN] - 0.5 * Wr[RHO] * v2r);
-  const double hl = (Wl[EN] + pl) / Wl[RHO];
-  const double hr = (Wr[EN] + pr) / Wr[RHO];
-  const double cl = sqrt(kGamma * pl / Wl[RHO]);
-  const double cr = sqrt(kGamma * pr / Wr[RHO]);
-  const double el = Wl[EN] / Wl[RHO];
-  const double er = Wr[EN] / Wr[RHO];
+  const double hl = (Wl[EN] + pl) * ril;
+  const double hr = (Wr[EN] + pr) * rir;
+  const double cl = fsqrt(kGamma * pl * ril);
+  const double cr = fsqrt(kGamma * pr * rir);
+  const double el = Wl[EN] * ril;
+  const double er = Wr[EN] * rir;
   const double h = hl * fl + hr * fr;
-  const double c = sqrt(kG1 * (h - 0.5 * v2));
+  const double c = fsqrt(kG1 * (h - 0.5 * v2));
   const double sl = fmin(veln - c, vln - cl);
   const double sr = fmax(veln + c, vrn + cr);
-  const double sm = (pl - pr - Wl[RHO] * vln * (sl - vln) + Wr[RHO] * vrn * (sr - vrn)) /
-                    (Wr[RHO] * (sr - vrn) - Wl[RHO] * (sl - vln));
+  const double sm = (pl - pr - Wl[RHO] * vln * (sl - vln) + Wr[RHO] * vrn * (sr - vrn)) *
+                    frcp(Wr[RHO] * (sr - vrn) - Wl[RHO] * (sl - vln));
   const double pstar = Wr[RHO] * (vrn - sr) * (vrn - sm) + pr;
-  const bool left = sm >= 0.0;                         // which side of the contact the face lies on
+  const bool left = sm >= 0.0;  // which side of the contact the face lies on
   const bool supersonic = left ? (sl > 0.0) : !(sr >= 0.0);
-  // one-sided quantities of the chosen side
   const double rK = left ? Wl[RHO] : Wr[RHO];
   const double vKn = left ? vln : vrn;
   const double pK = left ? pl : pr;
@@ -193,7 +236,8 @@ __device__ __forceinline__ void hllc_flux(double nx, double ny, const double *Wl
   const double Fs_1 = rK * vK1 * vKn + pK * n[1];
   const double Fs_en = eK * rK * vKn + pK * vKn;
   // star state flux (:641-652 / :659-670)
-  const double inv = 1.0 / (sK - sm);
+  const double dS = sK - sm;
+  const double inv = frcp(supersonic ? 1.0 : dS);
   const double sKmu = sK - vKn;
   const double rhoS = rK * sKmu * inv;
   const double ru0 = (rK * vK0 * sKmu + (pstar - pK) * n[0]) * inv;
@@ -211,18 +255,20 @@ __device__ __forceinline__ double ERF(double xarg) {
   const double p = 0.3275911;
   const double sign = (xarg < 0) ? -1.0 : 1.0;
   const double x = fabs(xarg);
-  const double t = 1.0 / (1.0 + p * x);
+  const double t = frcp(1.0 + p * x);
   const double y = 1.0 - (((((a5 * t + a4) * t) + a3) * t + a2) * t + a1) * t * exp(-x * x);
   return sign * y;
 }
 // src/equation.h:716-751
 __device__ __forceinline__ void kinetic_split_flux(double sign, double nx, double ny, const double *W, double *F) {
-  const double vdotn = (W[MX] * nx + W[MY] * ny) / W[RHO];
-  const double p = pressure(W);
-  const double beta = 0.5 * W[RHO] / p;
-  const double s = vdotn * sqrt(beta);
+  const double ri = frcp(W[RHO]);
+  const double vdotn = (W[MX] * nx + W[MY] * ny) * ri;
+  const double p = kG1 * (W[EN] - 0.5 * (W[MX] * W[MX] + W[MY] * W[MY]) * ri);
+  const double beta = 0.5 * W[RHO] * frcp(p);
+  const double sb = fsqrt(beta);
+  const double s = vdotn * sb;
   const double A = 0.5 * (1.0 + sign * ERF(s));
-  const double B = 0.5 * sign * exp(-s * s) / sqrt(M_PI * beta);
+  const double B = 0.5 * sign * exp(-s * s) * frcp(1.7724538509055160273 * sb);  // sqrt(pi*beta)
   const double ufact = vdotn * A + B;
   F[MX] = p * nx * A + W[MX] * ufact;
   F[MY] = p * ny * A + W[MY] * ufact;
@@ -258,11 +304,11 @@ __device__ __forceinline__ void compute_Wminus(int kind, double nx, double ny, c
 #pragma unroll
     for (int c = 0; c < 4; ++c) Wm[c] = Wp[c];
   } else if (kind == DFLO_BC_PRESSURE) {
-    const double ke = (Wp[MX] * Wp[MX] + Wp[MY] * Wp[MY]) * (0.5 / Wp[RHO]);
+    const double ke = (Wp[MX] * Wp[MX] + Wp[MY] * Wp[MY]) * (0.5 * frcp(Wp[RHO]));
     Wm[MX] = Wp[MX];
     Wm[MY] = Wp[MY];
     Wm[RHO] = Wp[RHO];
-    Wm[EN] = bv[EN] / kG1 + ke;  // w_3 is read as a pressure, src/equation.h:992
+    Wm[EN] = bv[EN] * (1.0 / kG1) + ke;  // w_3 is read as a pressure, src/equation.h:992
   } else {  // slip: reflect the normal momentum
     const double vdotn = Wp[MX] * nx + Wp[MY] * ny;
     Wm[MX] = Wp[MX] - 2.0 * vdotn * nx;
@@ -288,27 +334,28 @@ __device__ __forceinline__ double minmod(double a, double b, double c, double Md
 // transform_to_char / transform_to_con (src/equation.h:271-306); here the matrices are
 // applied in place to W = [mx,my,rho,E].
 struct EigenXY {
-  double u, v, c, q2, h, beta, phi2, c2;
+  double u, v, c, q2, h, beta, phi2, c2, ic2;
 };
 __device__ __forceinline__ EigenXY eigen_at(const double *A) {
   EigenXY e;
-  const double rho = A[RHO];
-  e.u = A[MX] / rho;
-  e.v = A[MY] / rho;
+  const double rho = A[RHO], ri = frcp(rho);
+  e.u = A[MX] * ri;
+  e.v = A[MY] * ri;
   e.q2 = e.u * e.u + e.v * e.v;
   const double p = kG1 * (A[EN] - 0.5 * rho * e.q2);
-  e.c2 = kGamma * p / rho;
-  e.c = sqrt(e.c2);
-  e.beta = 0.5 / e.c2;
+  e.c2 = kGamma * p * ri;
+  e.c = fsqrt(e.c2);
+  e.ic2 = frcp(e.c2);
+  e.beta = 0.5 * e.ic2;
   e.phi2 = 0.5 * kG1 * e.q2;
-  e.h = e.c2 / kG1 + 0.5 * e.q2;
+  e.h = e.c2 * (1.0 / kG1) + 0.5 * e.q2;
   return e;
 }
 // W <- L * W   (dir 0: Lx, dir 1: Ly)
 __device__ __forceinline__ void to_char(const EigenXY &e, int dir, double *W) {
   const double V0 = W[RHO], V1 = W[MX], V2 = W[MY], V3 = W[EN];
   const double un = dir == 0 ? e.u : e.v;
-  double r0 = (1 - e.phi2 / e.c2) * V0 + (kG1 * e.u / e.c2) * V1 + (kG1 * e.v / e.c2) * V2 + (-kG1 / e.c2) * V3;
+  double r0 = (1 - e.phi2 * e.ic2) * V0 + (kG1 * e.u * e.ic2) * V1 + (kG1 * e.v * e.ic2) * V2 + (-kG1 * e.ic2) * V3;
   double r1, r2, r3;
   if (dir == 0) {
     r1 = e.v * V0 + 0.0 * V1 + (-1.0) * V2 + 0.0 * V3;

@@ -143,9 +143,10 @@ int build_plan(const dflo_mesh_t &mesh, int shard_ex, int shard_ey, Plan &p, std
   // ---- per-shard halo and face lists
   p.halo_begin.assign(p.n_shards + 1, 0);
   p.face_begin.assign(p.n_shards + 1, 0);
-  p.cell_face.assign((size_t)p.n_shards * 4 * kShard, kNoFace);
+  p.cell_face.assign((size_t)(p.n_shards + 2) * 4 * kShard, kNoFace);  // +2: the stage kernel reads two shards ahead
   p.lrbt.assign((size_t)p.n_shards * 4 * kShard, -1);
-  p.max_halo = p.max_faces = 0;
+  p.max_halo = p.max_faces = p.max_bnd = 0;
+  p.shard_bnd.assign(p.n_shards, 0);
   std::unordered_map<int32_t, int32_t> halo_slot;
   for (int s = 0; s < p.n_shards; ++s) {
     halo_slot.clear();
@@ -169,7 +170,9 @@ int build_plan(const dflo_mesh_t &mesh, int shard_ex, int shard_ey, Plan &p, std
         if (nb == DFLO_NBR_NONE) continue;
         if (nb < 0) {
           const int k = (int)p.faces.size() - face0;
-          p.faces.push_back({(uint32_t)l | ((uint32_t)f << 16) | (1u << 18), bface_of[(size_t)c * 4 + f]});
+          const int bl = p.shard_bnd[s]++;
+          if (bl >= 0x3FF) { err = "too many boundary faces in a shard"; return DFLO_ERR_BAD_PARAM; }
+          p.faces.push_back({(uint32_t)l | ((uint32_t)f << 16) | (1u << 18) | ((uint32_t)bl << 20), bface_of[(size_t)c * 4 + f]});
           p.cell_face[ref] = (uint16_t)k;
           continue;
         }
@@ -199,11 +202,12 @@ int build_plan(const dflo_mesh_t &mesh, int shard_ex, int shard_ey, Plan &p, std
     p.face_begin[s + 1] = (int)p.faces.size();
     p.max_halo = std::max(p.max_halo, p.halo_begin[s + 1] - p.halo_begin[s]);
     p.max_faces = std::max(p.max_faces, p.face_begin[s + 1] - p.face_begin[s]);
+    p.max_bnd = std::max(p.max_bnd, p.shard_bnd[s]);
   }
 
   // ---- geometry in internal order
   if (mesh.mapping == DFLO_MAP_CARTESIAN) {
-    p.cell_h.assign(p.n_slots, p.h);
+    p.cell_h.assign(p.n_slots + 2 * kShard, p.h);
     for (int c = 0; c < n; ++c) p.cell_h[p.iid[c]] = hx[c];
   } else {
     p.cell_vert.assign((size_t)8 * p.n_slots, 0.0);

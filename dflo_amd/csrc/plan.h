@@ -24,7 +24,8 @@ constexpr int kShard = 64;  // cells per shard = lanes per wavefront
 //       bits 16-17 local face number seen from the integrating cell
 //       bit  18    1 = boundary face
 //       bit  19    1 = face points run opposite on the other side
-//       bits 20-21 local face number seen from the other cell
+//       bits 20-21 local face number seen from the other cell (interior faces)
+//       bits 20-29 index of the face among the shard's boundary faces (boundary faces)
 //   w1: slot of the other cell, or the boundary-face index
 struct FaceRec {
   uint32_t w0;
@@ -51,7 +52,8 @@ struct Plan {
   std::vector<uint16_t> cell_face;   // [n_shards][4][kShard]
   std::vector<int32_t> lrbt;         // [n_shards][4][kShard] internal slot of the left/right/bottom/top
                                      // neighbour or -1 (src/claw.cc:336-380)
-  int max_halo = 0, max_faces = 0;
+  std::vector<int32_t> shard_bnd;    // boundary faces per shard
+  int max_halo = 0, max_faces = 0, max_bnd = 0;
   // boundary faces in MeshWorker order (cell ascending, face ascending)
   std::vector<int32_t> bface_cell, bface_face, bface_id;
   bool uniform_h = false;

@@ -213,6 +213,10 @@ int dflo_hip_scalar_ptrs(dflo_hip_handle h, void **dt_ptr, void **res_ptr);
  * double, re-apply the time_step cap and final_time clip (src/claw.cc:468-476) into dt_ptr[0]. */
 int dflo_hip_apply_dt_rules(dflo_hip_handle h);
 
+/* Test hook: evaluates the device reciprocal / square-root forms the flux functions use
+ * (dflo_amd/csrc/physics.hpp) on n host doubles. */
+int dflo_hip_debug_math(int n, const double *x, double *rcp_out, double *sqrt_out);
+
 /* ------------------------------------------- host-side mesh construction */
 /* What GridIn::read_msh + Triangulation hand to dflo (src/claw.cc:957-967),
  * flattened.  The returned mesh owns its arrays; free with dflo_mesh_free. */

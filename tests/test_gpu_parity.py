@@ -128,3 +128,16 @@ def test_advance_matches_stepwise():
         t += dt
     assert abs(t_end - t) < 1e-12 * t
     assert rel(claw.current_solution, ora.get_solution()) < 1e-11
+
+
+def test_device_reciprocal_sqrt_accuracy():
+    """frcp / fsqrt of physics.hpp: v_rcp_f64 / v_rsq_f64 + Newton steps, <= 2 ulp on positive normals."""
+    from dflo_amd import _lib
+    rng = np.random.default_rng(7)
+    x = np.concatenate([10.0 ** rng.uniform(-30, 30, 20000), rng.uniform(0.1, 10.0, 20000), [1.0, 2.0, 0.5, 4.0, 1e-300, 1e300]])
+    r, s = np.empty_like(x), np.empty_like(x)
+    assert _lib.lib.dflo_hip_debug_math(len(x), _lib.dptr(x), _lib.dptr(r), _lib.dptr(s)) == 0
+    ulp_r = np.abs(r - 1.0 / x) / np.spacing(1.0 / x)
+    ulp_s = np.abs(s - np.sqrt(x)) / np.spacing(np.sqrt(x))
+    assert ulp_r.max() <= 2.0, ulp_r.max()
+    assert ulp_s.max() <= 2.0, ulp_s.max()

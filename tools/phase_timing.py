@@ -1,0 +1,39 @@
+"""Developer probe: build the engine with -DDFLO_PHASE_TIMING into a scratch .so and print the mean
+cycles each stage-kernel phase takes per shard iteration (wave 0 of every workgroup)."""
+import ctypes as C, os, subprocess, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+csrc = os.path.join(ROOT, "dflo_amd", "csrc")
+real = os.path.join(ROOT, "dflo_amd", "libdflo_hip.so")
+probe = os.path.join(ROOT, "gpurun_out", "libdflo_hip_probe.so")
+os.makedirs(os.path.dirname(probe), exist_ok=True)
+subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
+                       "-Wno-unused-value", "-DDFLO_PHASE_TIMING", "-o", probe, "mesh.cc", "plan.cc", "engine.hip"], cwd=csrc)
+os.replace(real, real + ".keep")
+os.symlink(probe, real)
+try:
+    import dflo_amd
+    from dflo_amd import problems, _lib
+    deg = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+    flux = sys.argv[2] if len(sys.argv) > 2 else "hllc"
+    nx = int(sys.argv[3]) if len(sys.argv) > 3 else 1024
+    mesh = dflo_amd.Mesh.cartesian(nx, nx, -5.0, -5.0, 10.0 / nx, [-1] * 4, deg)
+    claw = dflo_amd.ConservationLaw(mesh, dflo_amd.Parameters(flux=flux))
+    claw.set_initial_condition(mesh.interpolate(problems.isentropic_vortex))
+    claw.advance(3)
+    f = _lib.lib.dflo_hip_debug_phase_cycles
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    buf = np.zeros((4096, 8), dtype=np.uint64)
+    g = f(claw._h, buf.ctypes.data_as(C.c_void_p), 4096)
+    b = buf[:g].astype(np.float64)
+    n_iter = (mesh.n_cells / 64) / g
+    names = ["top(loads issue)", "A: regs->LDS", "barrier A", "B: fluxes(+prefetch issue)", "barrier B", "C: row update", "barrier C", "reduce/avg"]
+    tot = b.sum(axis=1).mean() / n_iter
+    print("grid %d, %.1f shards per workgroup, last stage launch; cycles per shard iteration: %.0f" % (g, n_iter, tot))
+    for i, n in enumerate(names):
+        print("  %-28s %8.0f  (%4.1f%%)" % (n, b[:, i].mean() / n_iter, 100 * b[:, i].mean() / n_iter / tot))
+finally:
+    os.remove(real)
+    os.replace(real + ".keep", real)
