@@ -1,0 +1,145 @@
+"""CPU: the C-ABI library loads, exports every symbol include/dflo_hip.h declares, the host-side mesh
+builders work, and the engine refuses to run without a GPU (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import dflo_amd
+from dflo_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "dflo_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(dflo_(?:hip|mesh)_\w+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    syms = declared_symbols()
+    assert len(syms) >= 40
+    for s in syms:
+        assert hasattr(_lib.lib, s), "libdflo_hip.so does not export %s" % s
+    # and the python binding lists the same set
+    assert sorted(_lib.SYMBOLS) == syms
+
+
+def test_product_does_not_touch_the_oracle():
+    """Nothing under dflo_amd/ may import, link or open anything under oracle/."""
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "dflo_amd")):
+        for f in files:
+            if f.endswith((".py", ".cc", ".hip", ".h", ".hpp")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in txt.lower(), os.path.join(dirpath, f)
+    # the shared library does not depend on the oracle library
+    out = os.popen("ldd %s" % _lib.LIB_PATH).read()
+    assert "oracle" not in out
+
+
+def test_cartesian_mesh_builder():
+    m = dflo_amd.Mesh.cartesian(4, 3, 1.0, 2.0, 0.5, [7, -1 if False else 8, -1, -1], 2)
+    assert m.n_cells == 12 and m.n_owned == 12 and m.degree == 2
+    v, nb, nf = m.vertices, m.neighbors, m.neighbor_faces
+    assert np.allclose(v[5], [[1.5, 2.5], [2.0, 2.5], [1.5, 3.0], [2.0, 3.0]])
+    assert nb[0, 0] == -1 - 7 and nb[3, 1] == -1 - 8          # boundary ids
+    assert nb[0, 2] == 8 and nf[0, 2] == (3 | 8)              # periodic in y: bottom row <-> top row
+    assert nb[5, 0] == 4 and nf[5, 0] == 1 and nb[5, 3] == 9 and nf[5, 3] == 2
+    with pytest.raises(dflo_amd.DfloError):
+        dflo_amd.Mesh.cartesian(4, 3, 0, 0, 0.5, [-1, 1, -1, -1], 1)   # periodic sides must pair up
+
+
+def test_quad_soup_builder_orientation_and_flips():
+    # two quads sharing an edge, the second one given clockwise and starting elsewhere
+    verts = np.array([[0, 0], [1, 0], [1, 1], [0, 1], [2, 0], [2, 1]], dtype=float)
+    quads = [[0, 1, 2, 3], [2, 1, 4, 5][::-1]]
+    m = dflo_amd.Mesh.from_quads(verts, quads, [[0, 1], [1, 4]], [3, 4], degree=1)
+    v = m.vertices
+    for c in range(2):   # lexicographic vertex order with positive jacobian
+        e1, e2 = v[c, 1] - v[c, 0], v[c, 2] - v[c, 0]
+        assert e1[0] * e2[1] - e1[1] * e2[0] > 0
+    assert m.neighbors[0, 1] == 1 and m.neighbors[1, 0] == 0
+    assert m.neighbor_faces[0, 1] & 3 == 0 and m.neighbor_faces[0, 1] & 4 == 0   # same direction, no flip
+    assert m.neighbors[0, 2] == -1 - 3 and m.neighbors[1, 2] == -1 - 4
+    assert m.neighbors[0, 0] == -1 - 0    # unlabelled boundary edges get id 0
+
+
+def test_gmsh_reader(tmp_path):
+    msh = tmp_path / "two.msh"
+    msh.write_text("""$MeshFormat
+2.2 0 8
+$EndMeshFormat
+$Nodes
+6
+1 0 0 0
+2 1 0 0
+3 1 1 0
+4 0 1 0
+5 2 0 0
+6 2 1 0
+$EndNodes
+$Elements
+4
+1 1 2 2 1 1 2
+2 1 2 1 2 5 6
+3 3 2 100 1 1 2 3 4
+4 3 2 100 1 2 5 6 3
+$EndElements
+""")
+    m = dflo_amd.Mesh.read_gmsh(msh, degree=2, mapping="cartesian")
+    assert m.n_cells == 2 and m.struct.mapping == _lib.MAPPING["cartesian"]
+    assert m.neighbors[0, 2] == -1 - 2 and m.neighbors[1, 1] == -1 - 1     # Physical Line id -> boundary id
+    assert m.neighbors[0, 1] == 1
+
+
+def test_support_points_are_gauss_points():
+    m = dflo_amd.Mesh.cartesian(2, 1, 0.0, 0.0, 2.0, [0, 0, 0, 0], 2)
+    xy = m.support_points()
+    g = 0.5 - np.sqrt(15) / 10
+    assert np.allclose(xy[0, 0], [2 * g, 2 * g]) and np.allclose(xy[1, 4], [3.0, 1.0])
+    assert np.allclose(xy[0, 1], [1.0, 2 * g])          # x runs fastest
+
+
+def test_partition_owned_plus_ghost_layer():
+    m = dflo_amd.Mesh.cartesian(8, 4, 0.0, 0.0, 1.0, [-1, -1, 0, 0], 1)
+    parts = [m.partition(2, r) for r in range(2)]
+    assert sum(p.n_owned for p in parts) == m.n_cells
+    for r, p in enumerate(parts):
+        gid = p.global_ids
+        assert len(set(gid)) == p.n_cells                      # no duplicates
+        own = gid[: p.n_owned]
+        assert ((own % 8 < 4) == (r == 0)).all()               # x-slabs
+        assert p.n_cells - p.n_owned == 8                       # one ghost column on each side (periodic)
+        sc, so, ro = p.comm
+        other = 1 - r
+        assert so[other + 1] - so[other] == 8 and ro[other + 1] - ro[other] == 8
+        # what I send is what the other side expects to receive, in the same order
+        q = parts[other]
+        sent_gids = gid[sc[so[other]:so[other + 1]]]
+        recv_gids = q.global_ids[q.n_owned + q.comm[2][r]: q.n_owned + q.comm[2][r + 1]]
+        assert (sent_gids == recv_gids).all()
+        # neighbours of owned cells all resolve locally
+        nb = p.neighbors[: p.n_owned]
+        assert (nb != _lib.NBR_NONE).all()
+
+
+def test_engine_fails_loudly_without_gpu():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    m = dflo_amd.Mesh.cartesian(4, 4, 0.0, 0.0, 0.25, [-1] * 4, 1)
+    with pytest.raises(dflo_amd.DfloError) as e:
+        dflo_amd.ConservationLaw(m, dflo_amd.Parameters())
+    assert e.value.code == -5 and "no CPU fallback" in str(e.value)
+
+
+def test_create_rejects_bad_parameters():
+    m = dflo_amd.Mesh.cartesian(4, 4, 0.0, 0.0, 0.25, [-1] * 4, 1)
+    p = dflo_amd.Parameters().struct()
+    h = C.c_void_p()
+    p.flux_type = 9
+    assert _lib.lib.dflo_hip_create(m._ptr, C.byref(p), 0, C.byref(h)) == -1
+    assert b"flux" in _lib.lib.dflo_hip_last_error(None)

@@ -1,0 +1,97 @@
+"""CPU, world_size 2, gloo: the partition + halo-exchange plumbing of dflo_amd.dist, driven with the
+oracle on each rank's owned+ghost sub-mesh, must reproduce the single-process oracle run.  (The HIP
+engine cannot run here; the same HaloExchange class moves the engine's buffers on the GPU box.)"""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def _worker(rank, world, port, case, ret):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, HERE)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import dflo_amd
+    from dflo_amd import problems
+    from dflo_amd.dist import HaloExchange
+    import oracle_lib as O
+
+    nx, ny, degree, flux, limiter, pos, side_bc, bnd = case
+    mesh = dflo_amd.Mesh.cartesian(nx, ny, 0.0, 0.0, 1.0 / nx, side_bc, degree)
+    prm = dflo_amd.Parameters(flux=flux, limiter=limiter, pos_lim=pos, boundary=bnd, beta=2.0)
+    ic = (lambda x, y: problems.smooth_perturbation(x, y, L=1.0)) if limiter == "none" else problems.sod
+    u0 = mesh.interpolate(ic)
+    part = mesh.partition(world, rank)
+    sc, so, ro = part.comm
+    ndof = part.ndof
+    gid = np.asarray(part.global_ids)
+    ora = O.Oracle(part, prm)
+    halo = HaloExchange(so, ro, torch.device("cpu"))
+    n_ghost = part.n_cells - part.n_owned
+
+    def bvals(o):
+        cell, face, bid, xy = o.boundary_faces()
+        if len(cell) == 0:
+            return
+        bv = np.stack(ic(xy[..., 0], xy[..., 1]), axis=-1)
+        o.set_boundary_values(0, bv)
+        o.set_boundary_values(1, bv)
+
+    def exchange(width, get, put):
+        full = get().reshape(part.n_cells, width)
+        send = torch.from_numpy(np.ascontiguousarray(full[sc]).reshape(-1))
+        recv = torch.empty(max(n_ghost, 1) * width, dtype=torch.float64)
+        halo.exchange(send, recv, width)
+        full[part.n_owned:] = recv.numpy()[: n_ghost * width].reshape(n_ghost, width)
+        put(full.reshape(-1))
+
+    ora.set_solution(u0.reshape(mesh.n_cells, ndof)[gid].reshape(-1))
+    bvals(ora)
+    dt = 0.04 / nx   # well inside the CFL limit so that round-off differences are not amplified
+    for step in range(3):
+        for rk in range(ora.n_rk):
+            ora.set_dt(dt)
+            ora.stage(rk)      # update + cell averages (+ limiter using ghost averages) on the owned cells
+            exchange(ndof, ora.get_solution, ora.set_current_only)
+            ora.compute_cell_average()
+        ora.end_step()
+    u = ora.get_solution().reshape(part.n_cells, ndof)[: part.n_owned]
+    parts = [None] * world
+    dist.all_gather_object(parts, (gid[: part.n_owned], u))
+    if rank == 0:
+        out = np.empty((mesh.n_cells, ndof))
+        for g, v in parts:
+            out[g] = v
+        ref = O.Oracle(mesh, prm)
+        ref.set_solution(u0)
+        bvals(ref)
+        for step in range(3):
+            ref.step(dt)
+        ret["err"] = float(np.abs(out.reshape(-1) - ref.get_solution()).max() / np.abs(ref.get_solution()).max())
+    dist.destroy_process_group()
+
+
+CASES = [
+    (12, 6, 2, "hllc", "none", False, [-1, -1, -1, -1], None),
+    (12, 6, 1, "lxf", "none", False, [-1, -1, 0, 0], {0: "slip"}),
+    (16, 4, 1, "roe", "none", True, [2, 1, 0, 0], {0: "slip", 1: "outflow", 2: "inflow"}),
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_two_rank_halo_exchange_matches_single_process(case):
+    import random
+    port = 29500 + random.randint(0, 2000)
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(2, port, case, ret), nprocs=2, join=True)
+    assert ret["err"] < 1e-12, ret["err"]
