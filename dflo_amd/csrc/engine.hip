@@ -56,7 +56,8 @@ struct StageArgs {
   double *rhs_out;  // parity hook: write the assembled rhs instead of updating
   const int32_t *shard_count, *halo_begin, *halo_cells, *face_begin;
   const int4 *shard_hdr;      // {cells, faces, halo cells, 0}
-  const int32_t *halo_pad;    // [n_shards][64]
+  const int32_t *halo_pad;    // [n_shards][halo_pitch]: internal cell slot | local face << 28
+  int halo_pitch, halo_stride;
   const FaceRec *faces_pad;   // [n_shards][face_pitch]
   int face_pitch;
   const FaceRec *faces;
@@ -106,11 +107,10 @@ __device__ __forceinline__ int shard_of_block(int b, int n_shards) {
 
 // phase C for node row B of every cell of the shard (lane = cell)
 template <int N, int B, int MODE>
-__device__ __forceinline__ void row_update(const StageArgs &a, const double *Us, const double *Fh, double *red,
-                                           int shard, int lane, bool active, double h, const uint16_t (&cref)[4],
-                                           const double (&uold)[4][N]) {
+__device__ __forceinline__ void row_update(const StageArgs &a, const double *Us, const int S, const double *Fh,
+                                           double *red, int shard, int lane, bool active, double h,
+                                           const uint16_t (&cref)[4], const double (&uold)[4][N]) {
   constexpr int NS = N * N;
-  const int S = a.stride;
   double R[4][N];
 #pragma unroll
   for (int c = 0; c < 4; ++c)
@@ -215,306 +215,210 @@ __device__ __forceinline__ void row_update(const StageArgs &a, const double *Us,
   }
 }
 
-// Persistent workgroups: a workgroup walks through the shards of its XCD's run and keeps the NEXT
-// shard's loads in flight (into registers) while it computes the current one, so HBM latency is
-// hidden behind the flux arithmetic instead of being paid once per phase.  Index data runs one more
-// shard ahead so that no address ever waits for a fresh load.
-//   halo item mapping: lane = halo slot, wave `row` moves LDS rows row, row+N, row+2N, ...
-// Per-thread index data of a shard, raw load results (nothing is computed on them at load time):
-struct ShardAhead {   // needed when the shard is staged into LDS: loaded one shard ahead
-  int4 hdr;           // {cells, faces, halo cells, boundary faces} (wave-uniform)
-  FaceRec fr[2];      // face records tid and tid + NT (a shard has <= 2*NT faces)
-};
-
-// MODE 0: first stage (ark = 0, u(n) not read)   1: later stages   2: residual only (parity hook)
+// One workgroup of N wavefronts per shard.  Occupancy, not software prefetch, hides HBM latency:
+// the kernel is kept under 168 VGPRs and ~40 KB of LDS so that 3 wavefronts per SIMD stay resident
+// (measured on MI355X: a persistent variant that prefetched the next shard into registers ran at 2
+// waves/SIMD and was 25 % slower).  All global loads of a shard are issued at the top, before
+// anything waits.
+//   MODE 0: first stage (ark = 0, u(n) not read)   1: later stages   2: residual only (parity hook)
 template <int N, int FLUX, int MODE>
-__global__ __launch_bounds__(64 * N, 2) void stage_kernel(const StageArgs a) {
+__global__ __launch_bounds__(64 * N, 3) void stage_kernel(const StageArgs a) {
   constexpr int NS = N * N, NDOF = 4 * NS, NT = 64 * N;
-  constexpr int ROWS = NDOF + (FLUX == DFLO_FLUX_LXF ? 4 : 0);  // LxF: the 4 cell averages ride along
-  constexpr int HR = (ROWS + N - 1) / N;                         // halo rows per wave
+  constexpr int ROWS = NDOF + (FLUX == DFLO_FLUX_LXF ? 4 : 0);   // LxF: the 4 cell averages ride along
+  constexpr int TROWS = 4 * N + (FLUX == DFLO_FLUX_LXF ? 4 : 0); // halo image: face trace (+ averages)
+  constexpr int S = 65;                                          // own-cell row stride: 1 mod 32 doubles
   extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int shard = shard_of_block(blockIdx.x, a.n_shards);
+  if (shard < 0) return;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int row = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int S = a.stride;
-  double *Us = lds;                                   // [ROWS][S]
-  double *Fh = Us + ROWS * S;                         // [4][max_fp]
+  const int HS = a.halo_stride;
+  double *Us = lds;                                   // [ROWS][S] DoFs (and averages) of the own cells
+  double *Th = Us + ROWS * S;                         // [TROWS][HS] traces of the halo cells on the shared face
+  double *Fh = Th + TROWS * HS;                       // [4][max_fp] numerical fluxes
   FaceRec *Fr = (FaceRec *)(Fh + 4 * a.max_fp);       // [max_faces]
-  double *Lt = (double *)(Fr + a.max_faces);          // [2][N]: l_m(0), l_m(1) -- indexed per lane in phase B
-  double *Bv = Lt + 2 * kMaxN;                        // [max_bnd][N][4] boundary values of the shard
+  double *Bv = (double *)(Fr + a.max_faces);          // [max_bnd][N][4] boundary values of the shard
   int *Bk = (int *)(Bv + a.max_bnd * 4 * N);          // [max_bnd] boundary kinds
-  const KBasis &kb = a.kb;
-  if (tid == 0) {
+
+  // ---- all loads of the shard, issued back to back
+  const int4 hdr = a.shard_hdr[shard];                // {cells, faces, halo entries, boundary faces}
+  const int nf = hdr.y, nfp = nf * N, nh = hdr.z, nbnd = hdr.w;
+  const bool active = lane < hdr.x;
+  double urow[4][N];                                  // node row `row` of the own cells
+  {
+    const double *up = a.Ucur + (size_t)shard * NDOF * 64 + lane;
 #pragma unroll
-    for (int m = 0; m < N; ++m) {
-      Lt[m] = CB<N>::t.L0[m];
-      Lt[N + m] = CB<N>::t.L1[m];
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int m = 0; m < N; ++m) urow[c][m] = up[(c * NS + m + N * row) * 64];
+  }
+  double uavg[4];
+  if constexpr (FLUX == DFLO_FLUX_LXF) {
+    if (row == 0) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) uavg[c] = a.avg_cur[((size_t)shard * 4 + c) * 64 + lane];
     }
   }
-
-  // shards of this workgroup: XCD x (= block % 8) owns the run [x*chunk, (x+1)*chunk)
-  const int chunk = (a.n_shards + 7) >> 3;
-  const int xcd = blockIdx.x & 7, jstride = gridDim.x >> 3;
-  int j = blockIdx.x >> 3;
-  auto shard_at = [&](int jj) { const int s = xcd * chunk + jj; return (jj < chunk && s < a.n_shards) ? s : -1; };
-
-  // Fixed-pitch per-shard tables: every address depends on the shard number only, so all of these
-  // loads issue back to back and nothing here waits for a previous load.
-  // `vzero` is a per-lane zero the compiler cannot see through: it keeps the header load an ordinary
-  // vector load whose result stays in VGPRs until it is used a shard later (a uniform load would be
-  // followed by an immediate v_readfirstlane, i.e. a full vmcnt(0) drain at the top of the loop)
-  int vzero;
-  asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
-  auto load_ahead = [&](int sh, ShardAhead &m) {
-    m.hdr = a.shard_hdr[sh + vzero];
-    const FaceRec *fp = a.faces_pad + (size_t)sh * a.face_pitch;
-    m.fr[0] = fp[tid];
-    m.fr[1] = fp[tid + NT];
-  };
-  // value of LDS row d of internal cell slot ic
-  auto src = [&](int d, int ic) -> const double * {
-    if (FLUX == DFLO_FLUX_LXF && d >= NDOF) return a.avg_cur + ((size_t)(ic >> 6) * 4 + (d - NDOF)) * 64 + (ic & 63);
-    return a.Ucur + ((size_t)(ic >> 6) * NDOF + d) * 64 + (ic & 63);
-  };
-  double pre[4][N];   // node row `row` of the shard about to be processed
-  double preA[4];     // LxF: its cell averages (wave 0)
-  double preh[HR];    // rows row, row+N, ... of halo slot `lane`
-  auto issue_prefetch = [&](int sh, int hidx) {
-    const double *up = a.Ucur + (size_t)sh * NDOF * 64 + lane;
+  const FaceRec *fp = a.faces_pad + (size_t)shard * a.face_pitch;
+  const FaceRec fr0 = fp[tid], fr1 = fp[tid + NT];
+  uint16_t cref[4];
+#pragma unroll
+  for (int f = 0; f < 4; ++f) cref[f] = a.cell_face[((size_t)shard * 4 + f) * 64 + lane];
+  const double h = a.cell_h[(size_t)shard * 64 + lane];
+  double uold[4][N];
+  if constexpr (MODE == 1) {
+    const double *op = a.Uold + (size_t)shard * NDOF * 64 + lane;
 #pragma unroll
     for (int c = 0; c < 4; ++c)
 #pragma unroll
-      for (int mm = 0; mm < N; ++mm) pre[c][mm] = up[(c * NS + mm + N * row) * 64];
-    if constexpr (FLUX == DFLO_FLUX_LXF) {
-      if (row == 0) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) preA[c] = a.avg_cur[((size_t)sh * 4 + c) * 64 + lane];
-      }
-    }
-    // lanes beyond the halo count re-read cell slot 0 (their table entry is 0): no branch, no join
-#pragma unroll
-    for (int t = 0; t < HR; ++t) {
-      const int d = row + N * t;
-      if (d < ROWS) preh[t] = *src(d, hidx);
-    }
-  };
+      for (int m = 0; m < N; ++m) uold[c][m] = op[(c * NS + m + N * row) * 64];
+  }
 
-  int shard = shard_at(j);
-  if (shard < 0) return;
-#ifdef DFLO_PHASE_TIMING
-  unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
-#endif
-  // Loads are never predicated on "is there a next shard": past the end they re-read this
-  // workgroup's current shard (cache hits), which keeps the loop free of joins that drain vmcnt.
-  ShardAhead cur;
-  load_ahead(shard, cur);
-  issue_prefetch(shard, a.halo_pad[(size_t)shard * 64 + lane]);
-  j += jstride;
-  int next = shard_at(j);
-  int hidx_next = a.halo_pad[(size_t)(next >= 0 ? next : shard) * 64 + lane];
-
-  for (;;) {
-    // Everything still in flight here was issued a whole shard ago (the prefetch) or earlier; draining
-    // it costs nothing and gives the compiler an exact scoreboard: no load issued below is waited for
-    // with vmcnt(0) anywhere in the loop body.
-    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
-    j += jstride;
-    const int next2 = shard_at(j);
-    const int sh_n = next >= 0 ? next : shard, sh_n2 = next2 >= 0 ? next2 : shard;
-    // ---- issued first, consumed late: halo indices two shards ahead, this shard's face references
-    const int hidx_next2 = a.halo_pad[(size_t)sh_n2 * 64 + lane];
-    uint16_t cref[4];
+  // ---- phase A: own rows -> LDS; halo: only the trace on the shared face is kept.
+  //      halo item i -> (entry s = i % nh, q = (i / nh) % N, comp = i / (nh N)); an entry is
+  //      (internal cell slot | local face << 28) of a face neighbour outside the shard
+  for (int i = tid; i < nh * 4 * N; i += NT) {
+    const int sl = i % nh, r = i / nh, q = r % N, c = r / N;
+    const int e = a.halo_pad[(size_t)shard * a.halo_pitch + sl];
+    const int ic = e & 0x0FFFFFFF, f = (e >> 28) & 3;
+    const double *hp = a.Ucur + ((size_t)(ic >> 6) * NDOF + c * NS) * 64 + (ic & 63);
+    const int base = f < 2 ? N * q : q, str = f < 2 ? 1 : N;
+    double v = 0.0;
 #pragma unroll
-    for (int f = 0; f < 4; ++f) cref[f] = a.cell_face[((size_t)shard * 4 + f) * 64 + lane];
-    const double h = a.cell_h[(size_t)shard * 64 + lane];
-    const bool active = lane < cur.hdr.x;
-    const int nf = __builtin_amdgcn_readfirstlane(cur.hdr.y), nfp = nf * N;
-    const int nh = __builtin_amdgcn_readfirstlane(cur.hdr.z), nbnd = __builtin_amdgcn_readfirstlane(cur.hdr.w);
-    PHASE_MARK(0);
-
-    // ---- phase A: prefetched registers -> LDS
+    for (int m = 0; m < N; ++m) v += ((f & 1) ? CB<N>::t.L1[m] : CB<N>::t.L0[m]) * hp[(base + m * str) * 64];
+    Th[(c * N + q) * HS + sl] = v;
+  }
+  if constexpr (FLUX == DFLO_FLUX_LXF) {
+    for (int i = tid; i < nh * 4; i += NT) {
+      const int sl = i % nh, c = i / nh;
+      const int ic = a.halo_pad[(size_t)shard * a.halo_pitch + sl] & 0x0FFFFFFF;
+      Th[(4 * N + c) * HS + sl] = a.avg_cur[((size_t)(ic >> 6) * 4 + c) * 64 + (ic & 63)];
+    }
+  }
 #pragma unroll
-    for (int c = 0; c < 4; ++c)
+  for (int c = 0; c < 4; ++c)
 #pragma unroll
-      for (int m = 0; m < N; ++m) Us[(c * NS + m + N * row) * S + lane] = pre[c][m];
-    if constexpr (FLUX == DFLO_FLUX_LXF) {
-      if (row == 0) {
+    for (int m = 0; m < N; ++m) Us[(c * NS + m + N * row) * S + lane] = urow[c][m];
+  if constexpr (FLUX == DFLO_FLUX_LXF) {
+    if (row == 0) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) Us[(NDOF + c) * S + lane] = preA[c];
+      for (int c = 0; c < 4; ++c) Us[(NDOF + c) * S + lane] = uavg[c];
+    }
+  }
+  if (tid < nf) Fr[tid] = fr0;
+  if (tid + NT < nf) Fr[tid + NT] = fr1;
+  for (int i = tid + 2 * NT; i < nf; i += NT) Fr[i] = fp[i];
+  if (nbnd > 0) {  // boundary values and kinds of this shard's boundary faces
+    for (int i = tid; i < nf; i += NT) {
+      const FaceRec r = fp[i];
+      if ((r.w0 >> 18) & 1) {
+        const int bl = (r.w0 >> 20) & 0x3FF, bf = r.w1;
+        Bk[bl] = a.bface_kind[bf];
+        for (int k2 = 0; k2 < 4 * N; ++k2) Bv[bl * 4 * N + k2] = a.bval[(size_t)bf * 4 * N + k2];
       }
     }
-    if (lane < nh) {
-#pragma unroll
-      for (int t = 0; t < HR; ++t) {
-        const int d = row + N * t;
-        if (d < ROWS) Us[d * S + 64 + lane] = preh[t];
-      }
-    }
-    if (nh > 64) {  // oversized halo (unstructured shards): late fetch of the slots beyond the lanes
-      const int hb = a.halo_begin[shard];
-      for (int i = tid; i < (nh - 64) * ROWS; i += NT) {
-        const int d = i / (nh - 64), sl = 64 + i % (nh - 64);
-        Us[d * S + 64 + sl] = *src(d, a.halo_cells[hb + sl]);
-      }
-      for (int i = tid + 2 * NT; i < nf; i += NT) Fr[i] = a.faces_pad[(size_t)shard * a.face_pitch + i];
-    }
-    if (tid < nf) Fr[tid] = cur.fr[0];
-    if (tid + NT < nf) Fr[tid + NT] = cur.fr[1];
-    if (nbnd > 0) {  // boundary values and kinds of this shard's boundary faces (not prefetched: few shards)
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        const FaceRec r = cur.fr[t];
-        if (tid + t * NT < nf && ((r.w0 >> 18) & 1)) {
-          const int bl = (r.w0 >> 20) & 0x3FF, bf = r.w1;
-          Bk[bl] = a.bface_kind[bf];
-          for (int i = 0; i < 4 * N; ++i) Bv[bl * 4 * N + i] = a.bval[(size_t)bf * 4 * N + i];
-        }
-      }
-      for (int i = tid + 2 * NT; i < nf; i += NT) {
-        const FaceRec r = a.faces_pad[(size_t)shard * a.face_pitch + i];
-        if ((r.w0 >> 18) & 1) {
-          const int bl = (r.w0 >> 20) & 0x3FF, bf = r.w1;
-          Bk[bl] = a.bface_kind[bf];
-          for (int k2 = 0; k2 < 4 * N; ++k2) Bv[bl * 4 * N + k2] = a.bval[(size_t)bf * 4 * N + k2];
-        }
-      }
-    }
-    PHASE_MARK(1);
-    __syncthreads();
-    PHASE_MARK(2);
+  }
+  __syncthreads();
 
-    // ---- keep the next shard's loads in flight while this one is computed
-    ShardAhead nxt;
-    load_ahead(sh_n, nxt);
-    issue_prefetch(sh_n, hidx_next);
-
-    // ---- phase B: one numerical flux per face point (integrate_face_term_explicit :303-341,
-    //      integrate_boundary_term_explicit :176-206).  Face-point index p = q * nf + k: neighbouring
-    //      lanes take neighbouring faces at the same q -> same LDS rows, consecutive slots.
-    for (int p = tid; p < nfp; p += NT) {
-      const int q = p / nf, k = p - q * nf;
-      const FaceRec r = Fr[k];
-      const int slotL = r.w0 & 0xFFFF, fL = (r.w0 >> 16) & 3;
-      const bool bnd = (r.w0 >> 18) & 1, flip = (r.w0 >> 19) & 1;
-      const int fR = (r.w0 >> 20) & 3;
-      double Wp[4], Wm[4], Ap[4], Am[4], F[4];
-      double lwL[N], lwR[N];
-#pragma unroll
-      for (int m = 0; m < N; ++m) {
-        lwL[m] = Lt[(fL & 1) * N + m];
-        lwR[m] = Lt[(fR & 1) * N + m];
-      }
-      {  // trace of the integrating cell: W+ = sum_m l_m(0|1) U[m,q] (x faces) or U[q,m] (y faces)
-        const int base = fL < 2 ? N * q : q, str = fL < 2 ? 1 : N;
+  // ---- phase B: one numerical flux per face point (integrate_face_term_explicit :303-341,
+  //      integrate_boundary_term_explicit :176-206).  Face-point index p = q * nf + k: neighbouring
+  //      lanes take neighbouring faces at the same q -> same LDS rows, consecutive slots.
+  for (int p = tid; p < nfp; p += NT) {
+    const int q = p / nf, k = p - q * nf;
+    const FaceRec r = Fr[k];
+    const int slotL = r.w0 & 0xFFFF, fL = (r.w0 >> 16) & 3;
+    const bool bnd = (r.w0 >> 18) & 1, flip = (r.w0 >> 19) & 1;
+    const int fR = (r.w0 >> 20) & 3;
+    double Wp[4], Wm[4], Ap[4], Am[4], F[4];
+    // trace of a cell on its local face f at face point qq: own cells from their DoFs,
+    // W = sum_m l_m(0|1) U[m,qq] (x faces) or U[qq,m] (y faces); halo cells from the stored trace
+    auto trace = [&](int slot, int f, int qq, double *W, double *A) {
+      if (slot < 64) {
+        const int base = f < 2 ? N * qq : qq, str = f < 2 ? 1 : N;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
           double v = 0;
 #pragma unroll
-          for (int m = 0; m < N; ++m) v += lwL[m] * Us[(c * NS + base + m * str) * S + slotL];
-          Wp[c] = v;
-        }
-      }
-      const double nx = fL == 0 ? -1.0 : (fL == 1 ? 1.0 : 0.0);
-      const double ny = fL == 2 ? -1.0 : (fL == 3 ? 1.0 : 0.0);
-      if constexpr (FLUX == DFLO_FLUX_LXF) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) Ap[c] = Us[(NDOF + c) * S + slotL];
-      }
-      if (!bnd) {
-        const int slotR = r.w1;
-        const int qr = flip ? N - 1 - q : q;
-        const int base = fR < 2 ? N * qr : qr, str = fR < 2 ? 1 : N;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          double v = 0;
-#pragma unroll
-          for (int m = 0; m < N; ++m) v += lwR[m] * Us[(c * NS + base + m * str) * S + slotR];
-          Wm[c] = v;
+          for (int m = 0; m < N; ++m)
+            v += ((f & 1) ? CB<N>::t.L1[m] : CB<N>::t.L0[m]) * Us[(c * NS + base + m * str) * S + slot];
+          W[c] = v;
         }
         if constexpr (FLUX == DFLO_FLUX_LXF) {
 #pragma unroll
-          for (int c = 0; c < 4; ++c) Am[c] = Us[(NDOF + c) * S + slotR];
+          for (int c = 0; c < 4; ++c) A[c] = Us[(NDOF + c) * S + slot];
         }
       } else {
-        const int bl = (r.w0 >> 20) & 0x3FF;
-        const double *bv = Bv + (bl * N + q) * 4;
-        double bvv[4] = {bv[0], bv[1], bv[2], bv[3]};
-        compute_Wminus(Bk[bl], nx, ny, Wp, bvv, Wm);
-        if constexpr (FLUX == DFLO_FLUX_LXF) {  // both averages are the interior cell's, :200-205
 #pragma unroll
-          for (int c = 0; c < 4; ++c) Am[c] = Ap[c];
+        for (int c = 0; c < 4; ++c) W[c] = Th[(c * N + qq) * HS + slot - 64];
+        if constexpr (FLUX == DFLO_FLUX_LXF) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) A[c] = Th[(4 * N + c) * HS + slot - 64];
         }
       }
-      numerical_normal_flux<FLUX>(nx, ny, Wp, Wm, Ap, Am, F);
-#pragma unroll
-      for (int c = 0; c < 4; ++c) Fh[c * a.max_fp + k * N + q] = F[c];
-    }
-    PHASE_MARK(3);
-    __syncthreads();
-    PHASE_MARK(4);
-
-    // ---- phase C: volume + lifting + RK update of node row `row`
-    double *red = Fh;  // reused after the barrier inside row_update
-    // u(n): issued behind the prefetch, consumed at the very end of the row update, by which time
-    // the (older) prefetch has landed anyway
-    double uold[4][N];
-    if constexpr (MODE == 1) {
-      const double *op = a.Uold + (size_t)shard * NDOF * 64 + lane;
-#pragma unroll
-      for (int c = 0; c < 4; ++c)
-#pragma unroll
-        for (int m = 0; m < N; ++m) uold[c][m] = op[(c * NS + m + N * row) * 64];
-    }
-    if constexpr (N == 2) {
-      if (row == 0) row_update<N, 0, MODE>(a, Us, Fh, red, shard, lane, active, h, cref, uold);
-      else row_update<N, 1, MODE>(a, Us, Fh, red, shard, lane, active, h, cref, uold);
-    } else if constexpr (N == 3) {
-      if (row == 0) row_update<N, 0, MODE>(a, Us, Fh, red, shard, lane, active, h, cref, uold);
-      else if (row == 1) row_update<N, 1, MODE>(a, Us, Fh, red, shard, lane, active, h, cref, uold);
-      else row_update<N, 2, MODE>(a, Us, Fh, red, shard, lane, active, h, cref, uold);
+    };
+    trace(slotL, fL, q, Wp, Ap);
+    const double nx = fL == 0 ? -1.0 : (fL == 1 ? 1.0 : 0.0);
+    const double ny = fL == 2 ? -1.0 : (fL == 3 ? 1.0 : 0.0);
+    if (!bnd) {
+      trace(r.w1, fR, flip ? N - 1 - q : q, Wm, Am);
     } else {
-      if (row == 0) row_update<N, 0, MODE>(a, Us, Fh, red, shard, lane, active, h, cref, uold);
-      else if (row == 1) row_update<N, 1, MODE>(a, Us, Fh, red, shard, lane, active, h, cref, uold);
-      else if (row == 2) row_update<N, 2, MODE>(a, Us, Fh, red, shard, lane, active, h, cref, uold);
-      else row_update<N, 3, MODE>(a, Us, Fh, red, shard, lane, active, h, cref, uold);
-    }
-    PHASE_MARK(5);
-    __syncthreads();
-    PHASE_MARK(6);
-    if (MODE != 2 && row == 0) {  // cell averages (src/claw.cc:562-597), residual norm, CFL minimum
-      double avg[4], res = 0.0, dtmin = 1.0e20;
+      const int bl = (r.w0 >> 20) & 0x3FF;
+      const double *bv = Bv + (bl * N + q) * 4;
+      double bvv[4] = {bv[0], bv[1], bv[2], bv[3]};
+      compute_Wminus(Bk[bl], nx, ny, Wp, bvv, Wm);
+      if constexpr (FLUX == DFLO_FLUX_LXF) {  // both averages are the interior cell's, :200-205
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        double v = 0;
-#pragma unroll
-        for (int b = 0; b < N; ++b) v += red[(b * 5 + c) * 64 + lane];
-        avg[c] = v;
-      }
-#pragma unroll
-      for (int b = 0; b < N; ++b) res += red[(b * 5 + 4) * 64 + lane];
-      if (active) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) a.avg_new[((size_t)shard * 4 + c) * 64 + lane] = avg[c];
-        if (a.want_dt) dtmin = cfl_dt(avg, h, a.cfl, a.degree);
-      }
-      res = wave_sum(res);
-      dtmin = wave_min(dtmin);
-      if (lane == 0) {
-        a.shard_res[shard] = res;
-        if (a.want_dt) a.shard_dtmin[shard] = dtmin;
+        for (int c = 0; c < 4; ++c) Am[c] = Ap[c];
       }
     }
-    PHASE_MARK(7);
-    if (next < 0) break;
-    shard = next;
-    next = next2;
-    cur = nxt;
-    hidx_next = hidx_next2;
+    numerical_normal_flux<FLUX>(nx, ny, Wp, Wm, Ap, Am, F);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) Fh[c * a.max_fp + k * N + q] = F[c];
   }
-#ifdef DFLO_PHASE_TIMING
-  if (tid == 0 && a.phase_cycles)
-    for (int i = 0; i < 8; ++i) a.phase_cycles[(size_t)blockIdx.x * 8 + i] = tacc[i];
-#endif
+  __syncthreads();
+
+  // ---- phase C: volume + lifting + RK update of node row `row`
+  double *red = Fh;  // reused after the barrier inside row_update
+  if constexpr (N == 2) {
+    if (row == 0) row_update<N, 0, MODE>(a, Us, S, Fh, red, shard, lane, active, h, cref, uold);
+    else row_update<N, 1, MODE>(a, Us, S, Fh, red, shard, lane, active, h, cref, uold);
+  } else if constexpr (N == 3) {
+    if (row == 0) row_update<N, 0, MODE>(a, Us, S, Fh, red, shard, lane, active, h, cref, uold);
+    else if (row == 1) row_update<N, 1, MODE>(a, Us, S, Fh, red, shard, lane, active, h, cref, uold);
+    else row_update<N, 2, MODE>(a, Us, S, Fh, red, shard, lane, active, h, cref, uold);
+  } else {
+    if (row == 0) row_update<N, 0, MODE>(a, Us, S, Fh, red, shard, lane, active, h, cref, uold);
+    else if (row == 1) row_update<N, 1, MODE>(a, Us, S, Fh, red, shard, lane, active, h, cref, uold);
+    else if (row == 2) row_update<N, 2, MODE>(a, Us, S, Fh, red, shard, lane, active, h, cref, uold);
+    else row_update<N, 3, MODE>(a, Us, S, Fh, red, shard, lane, active, h, cref, uold);
+  }
+  if constexpr (MODE == 2) return;
+  __syncthreads();
+  if (row == N - 1) {  // cell averages (src/claw.cc:562-597), residual norm, CFL minimum of the shard; on the
+                       // last wave: wave 0 carries the extra pass over the face points
+    double avg[4], res = 0.0, dtmin = 1.0e20;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      double v = 0;
+#pragma unroll
+      for (int b = 0; b < N; ++b) v += red[(b * 5 + c) * 64 + lane];
+      avg[c] = v;
+    }
+#pragma unroll
+    for (int b = 0; b < N; ++b) res += red[(b * 5 + 4) * 64 + lane];
+    if (active) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) a.avg_new[((size_t)shard * 4 + c) * 64 + lane] = avg[c];
+      if (a.want_dt) dtmin = cfl_dt(avg, h, a.cfl, a.degree);
+    }
+    res = wave_sum(res);
+    dtmin = wave_min(dtmin);
+    if (lane == 0) {
+      a.shard_res[shard] = res;
+      if (a.want_dt) a.shard_dtmin[shard] = dtmin;
+    }
+  }
 }
 
 // ------------------------------------------------------------------ limiter kernel
@@ -858,7 +762,7 @@ struct dflo_hip_engine {
   FaceRec *d_faces = nullptr, *d_faces_pad = nullptr;
   int4 *d_shard_hdr = nullptr;
   int32_t *d_halo_pad = nullptr;
-  int face_pitch = 0;
+  int face_pitch = 0, halo_pitch = 0, halo_stride = 0;
   uint16_t *d_cell_face = nullptr;
   int32_t *d_lrbt = nullptr, *d_user_of = nullptr, *d_iid = nullptr;
   double *d_cell_h = nullptr;
@@ -997,6 +901,8 @@ int launch_update(dflo_hip_engine *h, int rk, double dt_host, double *rhs_out, i
   a.face_begin = h->d_face_begin;
   a.shard_hdr = h->d_shard_hdr;
   a.halo_pad = h->d_halo_pad;
+  a.halo_pitch = h->halo_pitch;
+  a.halo_stride = h->halo_stride;
   a.faces_pad = h->d_faces_pad;
   a.face_pitch = h->face_pitch;
   a.faces = h->d_faces;
@@ -1197,13 +1103,15 @@ int dflo_hip_create(const dflo_mesh_t *mesh, const dflo_params_t *params, int de
     const int ns = p.n_shards + 2;
     h->face_pitch = 2 * 64 * h->N;
     if (p.max_faces > h->face_pitch) { h->err = "more than 2 faces per thread in a shard"; return bail(DFLO_ERR_UNSUPPORTED); }
+    h->halo_pitch = std::max(p.max_halo, 1);
     std::vector<int4> hdr(ns, int4{0, 0, 0, 0});
-    std::vector<int32_t> hp((size_t)ns * 64, 0);
+    std::vector<int32_t> hp((size_t)ns * h->halo_pitch, 0);
     std::vector<FaceRec> fpad((size_t)ns * h->face_pitch, FaceRec{0, 0});
     for (int sidx = 0; sidx < p.n_shards; ++sidx) {
       const int nh = p.halo_begin[sidx + 1] - p.halo_begin[sidx], nf = p.face_begin[sidx + 1] - p.face_begin[sidx];
       hdr[sidx] = int4{p.shard_count[sidx], nf, nh, p.shard_bnd[sidx]};
-      for (int k = 0; k < std::min(nh, 64); ++k) hp[(size_t)sidx * 64 + k] = p.halo_cells[p.halo_begin[sidx] + k];
+      for (int k = 0; k < nh; ++k)
+        hp[(size_t)sidx * h->halo_pitch + k] = p.halo_cells[p.halo_begin[sidx] + k] | (p.halo_faces[p.halo_begin[sidx] + k] << 28);
       for (int k = 0; k < nf; ++k) fpad[(size_t)sidx * h->face_pitch + k] = p.faces[p.face_begin[sidx] + k];
     }
     if ((rc = upload(h, &h->d_shard_hdr, hdr))) return bail(rc);
@@ -1225,11 +1133,15 @@ int dflo_hip_create(const dflo_mesh_t *mesh, const dflo_params_t *params, int de
   hipMemset(h->res_sq, 0, 4 * sizeof(double));
   hipMemset(h->dt_dev, 0, 4 * sizeof(double));
   hipMemset(h->flags, 0, 4 * sizeof(int));
-  h->stride = 64 + p.max_halo;
-  while (h->stride % 32 != 1) ++h->stride;  // row stride = 1 mod 32 doubles: rows fall on different LDS banks
+  h->stride = 65;
+  h->halo_stride = std::max(p.max_halo, 1) | 1;  // odd stride: the trace rows fall on different LDS banks
   h->max_fp = std::max(std::max(p.max_faces, 1) * h->N, 5 * 64 * h->N / 4 + 1);  // Fh also hosts the row partials
-  h->lds_bytes = ((size_t)(h->ndof + (h->prm.flux_type == DFLO_FLUX_LXF ? 4 : 0)) * h->stride + 4 * (size_t)h->max_fp +
-                  (size_t)std::max(p.max_faces, 1) + 2 * kMaxN + (size_t)p.max_bnd * (4 * h->N + 1) + 1) * sizeof(double);
+  {
+    const int rows = h->ndof + (h->prm.flux_type == DFLO_FLUX_LXF ? 4 : 0);
+    const int trows = 4 * h->N + (h->prm.flux_type == DFLO_FLUX_LXF ? 4 : 0);
+    h->lds_bytes = ((size_t)rows * 65 + (size_t)trows * h->halo_stride + 4 * (size_t)h->max_fp + (size_t)std::max(p.max_faces, 1) +
+                    (size_t)p.max_bnd * (4 * h->N + 1) + 2) * sizeof(double);
+  }
 
   if (h->lds_bytes > 160 * 1024) { h->err = "shard halo too large for LDS"; return bail(DFLO_ERR_UNSUPPORTED); }
   if (h->lds_bytes > 64 * 1024) {
@@ -1248,7 +1160,8 @@ int dflo_hip_create(const dflo_mesh_t *mesh, const dflo_params_t *params, int de
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)fn, 64 * h->N, h->lds_bytes) != hipSuccess || per_cu < 1)
       per_cu = 1;
     if (n_cu < 1) n_cu = 256;
-    h->stage_grid = std::min(grid_for(h->plan.n_shards), std::max(8, (per_cu * n_cu) / 8 * 8));
+    h->stage_grid = grid_for(h->plan.n_shards);  // one workgroup per shard (per_cu of them resident per CU)
+    (void)per_cu;
 #ifdef DFLO_PHASE_TIMING
     hipMalloc((void **)&h->phase_cycles, (size_t)h->stage_grid * 8 * sizeof(unsigned long long));
     hipMemset(h->phase_cycles, 0, (size_t)h->stage_grid * 8 * sizeof(unsigned long long));

@@ -37,6 +37,21 @@ __device__ __forceinline__ double fsqrt(double x) {  // x > 0
   return __builtin_fma(d, h, g);
 }
 __device__ __forceinline__ double fsqrt0(double x) { return x > 0.0 ? fsqrt(x) : 0.0; }
+// sqrt(x) and 1/x from one v_rsq_f64: g -> sqrt(x), h -> 1/(2 sqrt(x)), 1/x = 4 h^2 refined once
+__device__ __forceinline__ void fsqrt_rcp(double x, double &sq, double &rc) {
+  const double y = __builtin_amdgcn_rsq(x);
+  double g = x * y, h = 0.5 * y;
+  const double r = __builtin_fma(-h, g, 0.5);
+  g = __builtin_fma(g, r, g);
+  h = __builtin_fma(h, r, h);
+  double d = __builtin_fma(-g, g, x);
+  g = __builtin_fma(d, h, g);
+  d = __builtin_fma(-g, g, x);
+  sq = __builtin_fma(d, h, g);
+  double q = 4.0 * h * h;                      // ~ 1/x
+  const double e = __builtin_fma(-x, q, 1.0);  // one Newton step
+  rc = __builtin_fma(q, e, q);
+}
 
 __device__ __forceinline__ double pressure(const double *W) {  // src/equation.h:87-92
   const double ke = (W[MX] * W[MX] + W[MY] * W[MY]) * (0.5 * frcp(W[RHO]));
@@ -134,8 +149,9 @@ __device__ __forceinline__ void steger_warming_flux(double nx, double ny, const 
 // src/equation.h:471-556 (Harten entropy fix delta = 0.1 c, :529-531)
 __device__ __forceinline__ void roe_flux(double nx, double ny, const double *Wl, const double *Wr, double *F) {
   const double n[2] = {nx, ny};
-  const double rls = fsqrt(Wl[RHO]), rrs = fsqrt(Wr[RHO]);
-  const double ril = frcp(Wl[RHO]), rir = frcp(Wr[RHO]);
+  double rls, rrs, ril, rir;
+  fsqrt_rcp(Wl[RHO], rls, ril);
+  fsqrt_rcp(Wr[RHO], rrs, rir);
   const double fl = rls * frcp(rls + rrs), fr = 1.0 - fl;
   double vl[2], vr[2], vel[2], dv[2];
   double v2l = 0, v2r = 0, vln = 0, vrn = 0, veln = 0, v2 = 0, vdv = 0;
@@ -190,8 +206,9 @@ __device__ __forceinline__ void roe_flux(double nx, double ny, const double *Wl,
 // state of the side picked by the sign of s_m, then selected (no wavefront divergence).
 __device__ __forceinline__ void hllc_flux(double nx, double ny, const double *Wl, const double *Wr, double *F) {
   const double n[2] = {nx, ny};
-  const double rls = fsqrt(Wl[RHO]), rrs = fsqrt(Wr[RHO]);
-  const double ril = frcp(Wl[RHO]), rir = frcp(Wr[RHO]);
+  double rls, rrs, ril, rir;
+  fsqrt_rcp(Wl[RHO], rls, ril);
+  fsqrt_rcp(Wr[RHO], rrs, rir);
   const double fl = rls * frcp(rls + rrs), fr = 1.0 - fl;
   double vl[2], vr[2];
   double v2l = 0, v2r = 0, vln = 0, vrn = 0, veln = 0, v2 = 0;

@@ -147,18 +147,20 @@ int build_plan(const dflo_mesh_t &mesh, int shard_ex, int shard_ey, Plan &p, std
   p.lrbt.assign((size_t)p.n_shards * 4 * kShard, -1);
   p.max_halo = p.max_faces = p.max_bnd = 0;
   p.shard_bnd.assign(p.n_shards, 0);
-  std::unordered_map<int32_t, int32_t> halo_slot;
+  std::unordered_map<int64_t, int32_t> halo_slot;  // (cell, its face) -> halo entry
   for (int s = 0; s < p.n_shards; ++s) {
     halo_slot.clear();
     const auto &cells = shard_cells[s];
     const int face0 = (int)p.faces.size();
-    auto slot_of = [&](int c) -> int {
+    auto slot_of = [&](int c, int cface) -> int {  // cface: face of c on which the trace is needed
       if (shard_of[c] == s) return local_of[c];
-      auto it = halo_slot.find(c);
+      const int64_t key = (int64_t)c * 4 + cface;
+      auto it = halo_slot.find(key);
       if (it != halo_slot.end()) return it->second;
       const int sl = kShard + (int)halo_slot.size();
-      halo_slot.emplace(c, sl);
+      halo_slot.emplace(key, sl);
       p.halo_cells.push_back(p.iid[c]);
+      p.halo_faces.push_back(cface);
       return sl;
     };
     for (int l = 0; l < (int)cells.size(); ++l) {
@@ -186,13 +188,13 @@ int build_plan(const dflo_mesh_t &mesh, int shard_ex, int shard_ey, Plan &p, std
         const int k = (int)p.faces.size() - face0;
         if (k >= 0x3FFF) { err = "too many faces in a shard"; return DFLO_ERR_BAD_PARAM; }
         if (integrator) {
-          const int so = slot_of(nb);
+          const int so = slot_of(nb, nf);
           p.faces.push_back({(uint32_t)l | ((uint32_t)f << 16) | ((uint32_t)flip << 19) | ((uint32_t)nf << 20), so});
           p.cell_face[ref] = (uint16_t)k;
           if (nb_inside)
             p.cell_face[((size_t)s * 4 + nf) * kShard + local_of[nb]] = (uint16_t)(k | (flip ? 0x4000 : 0) | 0x8000);
         } else {  // neighbour outside the shard integrates; we still evaluate its flux
-          const int so = slot_of(nb);
+          const int so = slot_of(nb, nf);
           p.faces.push_back({(uint32_t)so | ((uint32_t)nf << 16) | ((uint32_t)flip << 19) | ((uint32_t)f << 20), l});
           p.cell_face[ref] = (uint16_t)(k | (flip ? 0x4000 : 0) | 0x8000);
         }

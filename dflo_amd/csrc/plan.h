@@ -46,7 +46,8 @@ struct Plan {
   std::vector<int32_t> user_of;      // internal slot -> user cell or -1 (padding)
   std::vector<int32_t> shard_count;  // cells per owned shard
   std::vector<int32_t> halo_begin;   // [n_shards+1]
-  std::vector<int32_t> halo_cells;   // internal slots
+  std::vector<int32_t> halo_cells;   // internal slot of the halo entry's cell
+  std::vector<int32_t> halo_faces;   // its local face shared with the shard (an entry = one (cell, face) pair)
   std::vector<int32_t> face_begin;   // [n_shards+1]
   std::vector<FaceRec> faces;
   std::vector<uint16_t> cell_face;   // [n_shards][4][kShard]
