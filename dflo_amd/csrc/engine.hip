@@ -63,6 +63,9 @@ struct StageArgs {
   const FaceRec *faces;
   const uint16_t *cell_face;
   const double *cell_h;
+  const double *cell_vert;    // GEO 1: [8][n_slots]
+  const double *fgeom_pad;    // GEO 1: [n_shards][3][face_pitch] (nx, ny, length) of each face record
+  int n_slots;
   const double *bval;
   const int32_t *bface_kind;
   const double *dt_dev;   // device-resident global dt (used when dt_host < 0)
@@ -215,14 +218,132 @@ __device__ __forceinline__ void row_update(const StageArgs &a, const double *Us,
   }
 }
 
+// phase C on bilinear (Q1-mapped) cells (the reference gets all of this from
+// FEValues with MappingQ1): J = [x_xi x_eta; y_xi y_eta] varies inside the cell,
+//   int F.grad(phi) = sum_q w_q [ d(phi)/d(xi) (y_eta F - x_eta G) + d(phi)/d(eta) (-y_xi F + x_xi G) ],
+// lumped mass M_j = w_j det J_j (src/claw.cc:223-227), face JxW = w_q |edge|.
+template <int N, int B, int MODE>
+__device__ __forceinline__ void row_update_q1(const StageArgs &a, const double *Us, const int S, const double *Fh,
+                                              const double *Fg, double *red, int shard, int lane, bool active,
+                                              const double (&vx)[8], const uint16_t (&cref)[4],
+                                              const double (&uold)[4][N]) {
+  constexpr int NS = N * N;
+  double R[4][N];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int m = 0; m < N; ++m) R[c][m] = 0.0;
+  double Wrow[N][4];
+  // metric terms of the bilinear map: x_xi depends on eta only, x_eta on xi only
+  const double ax = vx[2] - vx[0], bx = (vx[6] - vx[4]) - ax;   // x_xi(eta) = ax + eta bx
+  const double ay = vx[3] - vx[1], by = (vx[7] - vx[5]) - ay;
+  const double cx = vx[4] - vx[0], dx = (vx[6] - vx[2]) - cx;   // x_eta(xi) = cx + xi dx
+  const double cy = vx[5] - vx[1], dy = (vx[7] - vx[3]) - cy;
+#pragma unroll
+  for (int aa = 0; aa < N; ++aa) {
+    const double xeta = cx + CB<N>::t.x[aa] * dx, yeta = cy + CB<N>::t.x[aa] * dy;
+#pragma unroll
+    for (int q = 0; q < N; ++q) {
+      const double xxi = ax + CB<N>::t.x[q] * bx, yxi = ay + CB<N>::t.x[q] * by;
+      double W[4], Fx[4], Gy[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) W[c] = Us[(c * NS + aa + N * q) * S + lane];
+      flux_xy(W, Fx, Gy);
+      const double wq = CB<N>::t.w[aa] * CB<N>::t.w[q];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) R[c][aa] += (xxi * Gy[c] - yxi * Fx[c]) * (wq * CB<N>::t.D[q][B]);
+      if (q == B) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          Wrow[aa][c] = W[c];
+          const double f1 = (yeta * Fx[c] - xeta * Gy[c]) * wq;
+#pragma unroll
+          for (int m = 0; m < N; ++m) R[c][m] += f1 * CB<N>::t.D[aa][m];
+        }
+        if (a.gravity != 0.0) {
+          const double jxw = wq * (xxi * yeta - xeta * yxi);
+          R[MY][aa] += a.gravity * (-1.0 * W[RHO]) * jxw;
+          R[EN][aa] += a.gravity * (-1.0 * W[MY]) * jxw;
+        }
+      }
+    }
+  }
+  if (active) {
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      const uint16_t ref = cref[f];
+      if (ref == kNoFace) continue;
+      const int k = ref & 0x3FFF;
+      const bool flip = (ref >> 14) & 1;
+      const double sgn = (ref >> 15) ? 1.0 : -1.0;
+      const double len = Fg[2 * a.max_faces + k];
+      if (f < 2) {
+        const int qq = flip ? N - 1 - B : B;
+        const double jxw = sgn * CB<N>::t.w[B] * len;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const double fq = Fh[c * a.max_fp + k * N + qq] * jxw;
+#pragma unroll
+          for (int m = 0; m < N; ++m) R[c][m] += fq * ((f & 1) ? CB<N>::t.L1[m] : CB<N>::t.L0[m]);
+        }
+      } else {
+        const double lw = (f & 1) ? CB<N>::t.L1[B] : CB<N>::t.L0[B];
+#pragma unroll
+        for (int q = 0; q < N; ++q) {
+          const int qq = flip ? N - 1 - q : q;
+          const double jxw = sgn * (CB<N>::t.w[q] * lw) * len;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) R[c][q] += Fh[c * a.max_fp + k * N + qq] * jxw;
+        }
+      }
+    }
+  }
+  double part[5] = {0, 0, 0, 0, 0};
+  if (active) {
+    if constexpr (MODE == 2) {
+      double *rp = a.rhs_out + (size_t)shard * 4 * NS * 64 + lane;
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int m = 0; m < N; ++m) rp[(c * NS + m + N * B) * 64] = R[c][m];
+    } else {
+      const double dt = a.dt_cell ? a.dt_cell[(size_t)shard * 64 + lane] : (a.dt_host >= 0.0 ? a.dt_host : *a.dt_dev);
+      double *np = a.Unew + (size_t)shard * 4 * NS * 64 + lane;
+      const double xxi = ax + CB<N>::t.x[B] * bx, yxi = ay + CB<N>::t.x[B] * by;
+#pragma unroll
+      for (int m = 0; m < N; ++m) {
+        const double det = xxi * (cy + CB<N>::t.x[m] * dy) - (cx + CB<N>::t.x[m] * dx) * yxi;
+        const double wd = CB<N>::t.w[m] * CB<N>::t.w[B] * det;   // JxW of node (m, B) = its lumped mass
+        const double invM = frcp(wd);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int d = c * NS + m + N * B;
+          part[4] += R[c][m] * R[c][m];
+          double u = Wrow[m][c];
+          u += dt * R[c][m] * invM;
+          if constexpr (MODE == 1) u = (1.0 - a.ark) * u + a.ark * uold[c][m];
+          np[d * 64] = u;
+          part[c] += wd * u;
+        }
+      }
+    }
+  }
+  if constexpr (MODE != 2) {
+    __syncthreads();  // every wave is done reading Fh
+#pragma unroll
+    for (int c = 0; c < 5; ++c) red[(B * 5 + c) * 64 + lane] = part[c];
+  }
+}
+
 // One workgroup of N wavefronts per shard.  Occupancy, not software prefetch, hides HBM latency:
 // the kernel is kept under 168 VGPRs and ~40 KB of LDS so that 3 wavefronts per SIMD stay resident
 // (measured on MI355X: a persistent variant that prefetched the next shard into registers ran at 2
 // waves/SIMD and was 25 % slower).  All global loads of a shard are issued at the top, before
 // anything waits.
 //   MODE 0: first stage (ark = 0, u(n) not read)   1: later stages   2: residual only (parity hook)
-template <int N, int FLUX, int MODE>
-__global__ __launch_bounds__(64 * N, 3) void stage_kernel(const StageArgs a) {
+//   GEO 0: axis-aligned squares (MappingCartesian)   1: bilinear cells (MappingQ1)
+template <int N, int FLUX, int MODE, int GEO>
+__global__ __launch_bounds__(64 * N, (GEO == 1 || N == 4) ? 2 : 3) void stage_kernel(const StageArgs a) {
   constexpr int NS = N * N, NDOF = 4 * NS, NT = 64 * N;
   constexpr int ROWS = NDOF + (FLUX == DFLO_FLUX_LXF ? 4 : 0);   // LxF: the 4 cell averages ride along
   constexpr int TROWS = 4 * N + (FLUX == DFLO_FLUX_LXF ? 4 : 0); // halo image: face trace (+ averages)
@@ -240,6 +361,7 @@ __global__ __launch_bounds__(64 * N, 3) void stage_kernel(const StageArgs a) {
   FaceRec *Fr = (FaceRec *)(Fh + 4 * a.max_fp);       // [max_faces]
   double *Bv = (double *)(Fr + a.max_faces);          // [max_bnd][N][4] boundary values of the shard
   int *Bk = (int *)(Bv + a.max_bnd * 4 * N);          // [max_bnd] boundary kinds
+  double *Fg = (double *)(Bk + ((a.max_bnd + 1) & ~1)); // GEO 1: [3][max_faces] unit normal and length of the faces
 
   // ---- all loads of the shard, issued back to back
   const int4 hdr = a.shard_hdr[shard];                // {cells, faces, halo entries, boundary faces}
@@ -265,7 +387,13 @@ __global__ __launch_bounds__(64 * N, 3) void stage_kernel(const StageArgs a) {
   uint16_t cref[4];
 #pragma unroll
   for (int f = 0; f < 4; ++f) cref[f] = a.cell_face[((size_t)shard * 4 + f) * 64 + lane];
-  const double h = a.cell_h[(size_t)shard * 64 + lane];
+  double h = 0.0, vx[8];
+  if constexpr (GEO == 0) {
+    h = a.cell_h[(size_t)shard * 64 + lane];
+  } else {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) vx[k] = a.cell_vert[(size_t)k * a.n_slots + (size_t)shard * 64 + lane];
+  }
   double uold[4][N];
   if constexpr (MODE == 1) {
     const double *op = a.Uold + (size_t)shard * NDOF * 64 + lane;
@@ -278,15 +406,17 @@ __global__ __launch_bounds__(64 * N, 3) void stage_kernel(const StageArgs a) {
   // ---- phase A: own rows -> LDS; halo: only the trace on the shared face is kept.
   //      halo item i -> (entry s = i % nh, q = (i / nh) % N, comp = i / (nh N)); an entry is
   //      (internal cell slot | local face << 28) of a face neighbour outside the shard
-  for (int i = tid; i < nh * 4 * N; i += NT) {
-    const int sl = i % nh, r = i / nh, q = r % N, c = r / N;
+  for (int i = tid; i < ((nh + 31) & ~31) * 4 * N; i += NT) {
+    const int sl = (i & 31) + ((i >> 5) / (4 * N)) * 32, r = (i >> 5) % (4 * N), q = r % N, c = r / N;
+    if (sl >= nh) continue;
     const int e = a.halo_pad[(size_t)shard * a.halo_pitch + sl];
     const int ic = e & 0x0FFFFFFF, f = (e >> 28) & 3;
     const double *hp = a.Ucur + ((size_t)(ic >> 6) * NDOF + c * NS) * 64 + (ic & 63);
-    const int base = f < 2 ? N * q : q, str = f < 2 ? 1 : N;
+    const int str0 = f < 2 ? 1 : N;
+    const int base = (f < 2 ? N * q : q) + ((f & 1) ? (N - 1) * str0 : 0), str = (f & 1) ? -str0 : str0;
     double v = 0.0;
 #pragma unroll
-    for (int m = 0; m < N; ++m) v += ((f & 1) ? CB<N>::t.L1[m] : CB<N>::t.L0[m]) * hp[(base + m * str) * 64];
+    for (int m = 0; m < N; ++m) v += CB<N>::t.L0[m] * hp[(base + m * str) * 64];
     Th[(c * N + q) * HS + sl] = v;
   }
   if constexpr (FLUX == DFLO_FLUX_LXF) {
@@ -309,6 +439,13 @@ __global__ __launch_bounds__(64 * N, 3) void stage_kernel(const StageArgs a) {
   if (tid < nf) Fr[tid] = fr0;
   if (tid + NT < nf) Fr[tid + NT] = fr1;
   for (int i = tid + 2 * NT; i < nf; i += NT) Fr[i] = fp[i];
+  if constexpr (GEO == 1) {
+    const double *gp = a.fgeom_pad + (size_t)shard * 3 * a.face_pitch;
+    for (int i = tid; i < 3 * nf; i += NT) {
+      const int k = i % nf, j = i / nf;
+      Fg[j * a.max_faces + k] = gp[j * a.face_pitch + k];
+    }
+  }
   if (nbnd > 0) {  // boundary values and kinds of this shard's boundary faces
     for (int i = tid; i < nf; i += NT) {
       const FaceRec r = fp[i];
@@ -335,13 +472,17 @@ __global__ __launch_bounds__(64 * N, 3) void stage_kernel(const StageArgs a) {
     // W = sum_m l_m(0|1) U[m,qq] (x faces) or U[qq,m] (y faces); halo cells from the stored trace
     auto trace = [&](int slot, int f, int qq, double *W, double *A) {
       if (slot < 64) {
-        const int base = f < 2 ? N * qq : qq, str = f < 2 ? 1 : N;
+        // l_m(1) = l_(N-1-m)(0) (Gauss points are symmetric): walk the line of nodes backwards on the
+        // faces at 1 and use the weights l_m(0) throughout -> no per-lane weight selects
+        const int str0 = f < 2 ? 1 : N;
+        const int base = (f < 2 ? N * qq : qq) + ((f & 1) ? (N - 1) * str0 : 0);
+        const int str = (f & 1) ? -str0 : str0;
+        const double *u0 = Us + base * S + slot;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
           double v = 0;
 #pragma unroll
-          for (int m = 0; m < N; ++m)
-            v += ((f & 1) ? CB<N>::t.L1[m] : CB<N>::t.L0[m]) * Us[(c * NS + base + m * str) * S + slot];
+          for (int m = 0; m < N; ++m) v += CB<N>::t.L0[m] * u0[(c * NS + m * str) * S];
           W[c] = v;
         }
         if constexpr (FLUX == DFLO_FLUX_LXF) {
@@ -358,8 +499,14 @@ __global__ __launch_bounds__(64 * N, 3) void stage_kernel(const StageArgs a) {
       }
     };
     trace(slotL, fL, q, Wp, Ap);
-    const double nx = fL == 0 ? -1.0 : (fL == 1 ? 1.0 : 0.0);
-    const double ny = fL == 2 ? -1.0 : (fL == 3 ? 1.0 : 0.0);
+    double nx, ny;  // outward unit normal of the integrating cell
+    if constexpr (GEO == 0) {
+      nx = fL == 0 ? -1.0 : (fL == 1 ? 1.0 : 0.0);
+      ny = fL == 2 ? -1.0 : (fL == 3 ? 1.0 : 0.0);
+    } else {
+      nx = Fg[k];
+      ny = Fg[a.max_faces + k];
+    }
     if (!bnd) {
       trace(r.w1, fR, flip ? N - 1 - q : q, Wm, Am);
     } else {
@@ -380,19 +527,19 @@ __global__ __launch_bounds__(64 * N, 3) void stage_kernel(const StageArgs a) {
 
   // ---- phase C: volume + lifting + RK update of node row `row`
   double *red = Fh;  // reused after the barrier inside row_update
+#define DFLO_ROW(Bq)                                                                                     \
+  do {                                                                                                   \
+    if constexpr (GEO == 0) row_update<N, Bq, MODE>(a, Us, S, Fh, red, shard, lane, active, h, cref, uold); \
+    else row_update_q1<N, Bq, MODE>(a, Us, S, Fh, Fg, red, shard, lane, active, vx, cref, uold);           \
+  } while (0)
   if constexpr (N == 2) {
-    if (row == 0) row_update<N, 0, MODE>(a, Us, S, Fh, red, shard, lane, active, h, cref, uold);
-    else row_update<N, 1, MODE>(a, Us, S, Fh, red, shard, lane, active, h, cref, uold);
+    if (row == 0) DFLO_ROW(0); else DFLO_ROW(1);
   } else if constexpr (N == 3) {
-    if (row == 0) row_update<N, 0, MODE>(a, Us, S, Fh, red, shard, lane, active, h, cref, uold);
-    else if (row == 1) row_update<N, 1, MODE>(a, Us, S, Fh, red, shard, lane, active, h, cref, uold);
-    else row_update<N, 2, MODE>(a, Us, S, Fh, red, shard, lane, active, h, cref, uold);
+    if (row == 0) DFLO_ROW(0); else if (row == 1) DFLO_ROW(1); else DFLO_ROW(2);
   } else {
-    if (row == 0) row_update<N, 0, MODE>(a, Us, S, Fh, red, shard, lane, active, h, cref, uold);
-    else if (row == 1) row_update<N, 1, MODE>(a, Us, S, Fh, red, shard, lane, active, h, cref, uold);
-    else if (row == 2) row_update<N, 2, MODE>(a, Us, S, Fh, red, shard, lane, active, h, cref, uold);
-    else row_update<N, 3, MODE>(a, Us, S, Fh, red, shard, lane, active, h, cref, uold);
+    if (row == 0) DFLO_ROW(0); else if (row == 1) DFLO_ROW(1); else if (row == 2) DFLO_ROW(2); else DFLO_ROW(3);
   }
+#undef DFLO_ROW
   if constexpr (MODE == 2) return;
   __syncthreads();
   if (row == N - 1) {  // cell averages (src/claw.cc:562-597), residual norm, CFL minimum of the shard; on the
@@ -407,16 +554,25 @@ __global__ __launch_bounds__(64 * N, 3) void stage_kernel(const StageArgs a) {
     }
 #pragma unroll
     for (int b = 0; b < N; ++b) res += red[(b * 5 + 4) * 64 + lane];
+    if constexpr (GEO == 1) {  // cell average = sum u JxW / |K| (src/claw.cc:589-593), |K| by the shoelace formula
+      const double area = 0.5 * fabs((vx[0] * vx[3] - vx[2] * vx[1]) + (vx[2] * vx[7] - vx[6] * vx[3]) +
+                                     (vx[6] * vx[5] - vx[4] * vx[7]) + (vx[4] * vx[1] - vx[0] * vx[5]));
+      const double ia = 1.0 / area;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) avg[c] *= ia;
+    }
     if (active) {
 #pragma unroll
       for (int c = 0; c < 4; ++c) a.avg_new[((size_t)shard * 4 + c) * 64 + lane] = avg[c];
-      if (a.want_dt) dtmin = cfl_dt(avg, h, a.cfl, a.degree);
+      if constexpr (GEO == 0) {
+        if (a.want_dt) dtmin = cfl_dt(avg, h, a.cfl, a.degree);
+      }
     }
     res = wave_sum(res);
     dtmin = wave_min(dtmin);
     if (lane == 0) {
       a.shard_res[shard] = res;
-      if (a.want_dt) a.shard_dtmin[shard] = dtmin;
+      if (GEO == 0 && a.want_dt) a.shard_dtmin[shard] = dtmin;
     }
   }
 }
@@ -613,6 +769,25 @@ __global__ void debug_math_kernel(const double *x, double *rcp, double *sq, int 
 }
 
 // ------------------------------------------------------------------ small kernels
+// quadrature weight of node j for the cell average: w_a w_b (squares) or w_a w_b det J / |K| (bilinear cells)
+__device__ __forceinline__ double avg_weight(const KBasis &kb, int N, int j, const double *vert, int n_slots, int slot,
+                                             double inv_area) {
+  const double ww = kb.w[j % N] * kb.w[j / N];
+  if (!vert) return ww;
+  double v[8];
+  for (int k = 0; k < 8; ++k) v[k] = vert[(size_t)k * n_slots + slot];
+  const double xi = kb.x[j % N], eta = kb.x[j / N];
+  const double xxi = (v[2] - v[0]) + eta * ((v[6] - v[4]) - (v[2] - v[0])), yxi = (v[3] - v[1]) + eta * ((v[7] - v[5]) - (v[3] - v[1]));
+  const double xeta = (v[4] - v[0]) + xi * ((v[6] - v[2]) - (v[4] - v[0])), yeta = (v[5] - v[1]) + xi * ((v[7] - v[3]) - (v[5] - v[1]));
+  return ww * (xxi * yeta - xeta * yxi) * inv_area;
+}
+__device__ __forceinline__ double cell_inv_area(const double *vert, int n_slots, int slot) {
+  if (!vert) return 1.0;
+  double v[8];
+  for (int k = 0; k < 8; ++k) v[k] = vert[(size_t)k * n_slots + slot];
+  return 1.0 / (0.5 * fabs((v[0] * v[3] - v[2] * v[1]) + (v[2] * v[7] - v[6] * v[3]) + (v[6] * v[5] - v[4] * v[7]) +
+                           (v[4] * v[1] - v[0] * v[5])));
+}
 // user (dflo) layout <-> shard SoA layout
 __global__ void scatter_kernel(const double *user, double *U, const int32_t *user_of, int n_slots, int ndof) {
   const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -641,16 +816,17 @@ __global__ void pack_kernel(double *buf, const double *U, const int32_t *slots, 
 }
 // ghost cells: staging buffer [g][ndof] -> ghost shards, and their cell averages
 __global__ void unpack_ghost_kernel(const double *buf, double *U, double *avg, int first_slot, int n_ghost, int ndof,
-                                    KBasis kb, int N) {
+                                    KBasis kb, int N, const double *vert, int n_slots) {
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= n_ghost) return;
   const int slot = first_slot + g, ns = ndof / 4;
+  const double ia = cell_inv_area(vert, n_slots, slot);
   for (int c = 0; c < 4; ++c) {
     double m = 0;
     for (int j = 0; j < ns; ++j) {
       const double v = buf[(size_t)g * ndof + c * ns + j];
       U[((size_t)(slot >> 6) * ndof + c * ns + j) * 64 + (slot & 63)] = v;
-      m += kb.w[j % N] * kb.w[j / N] * v;
+      m += avg_weight(kb, N, j, vert, n_slots, slot, ia) * v;
     }
     avg[((size_t)(slot >> 6) * 4 + c) * 64 + (slot & 63)] = m;
   }
@@ -662,15 +838,42 @@ __global__ void unpack_ghost_avg_kernel(const double *buf, double *avg, int firs
   for (int c = 0; c < 4; ++c) avg[((size_t)(slot >> 6) * 4 + c) * 64 + (slot & 63)] = buf[(size_t)g * 4 + c];
 }
 // compute_cell_average (src/claw.cc:562-597) for all slots (owned and ghost shards)
-__global__ void average_kernel(const double *U, double *avg, int ndof, KBasis kb, int N) {
+__global__ void average_kernel(const double *U, double *avg, int ndof, KBasis kb, int N, const double *vert, int n_slots) {
+  const int shard = blockIdx.x;
+  const int lane = threadIdx.x;
+  const int ns = ndof / 4, slot = shard * 64 + lane;
+  const double ia = cell_inv_area(vert, n_slots, slot);
+  for (int c = 0; c < 4; ++c) {
+    double m = 0;
+    for (int j = 0; j < ns; ++j)
+      m += avg_weight(kb, N, j, vert, n_slots, slot, ia) * U[((size_t)shard * ndof + c * ns + j) * 64 + lane];
+    avg[((size_t)shard * 4 + c) * 64 + lane] = m;
+  }
+}
+// compute_time_step_q (src/claw.cc:520-557): max of |v| + c over the 4 x 4 points of QIterated(QTrapez,3),
+// dt = cfl h / lambda / (2k+1) with h = diameter / sqrt(2); per-shard minimum
+__global__ void dt_q_kernel(const double *U, const double *cell_h, const int32_t *shard_count, double *shard_dtmin, int ndof,
+                            KBasis kb, int N, double cfl, int degree) {
   const int shard = blockIdx.x;
   const int lane = threadIdx.x;
   const int ns = ndof / 4;
-  for (int c = 0; c < 4; ++c) {
-    double m = 0;
-    for (int j = 0; j < ns; ++j) m += kb.w[j % N] * kb.w[j / N] * U[((size_t)shard * ndof + c * ns + j) * 64 + lane];
-    avg[((size_t)shard * 4 + c) * 64 + lane] = m;
+  double dtmin = 1.0e20;
+  if (lane < shard_count[shard]) {
+    double maxeig = 0.0;
+    for (int pb = 0; pb < kTrap; ++pb)
+      for (int pa = 0; pa < kTrap; ++pa) {
+        double W[4];
+        for (int c = 0; c < 4; ++c) {
+          double v = 0;
+          for (int j = 0; j < ns; ++j) v += kb.Pt[pa][j % N] * kb.Pt[pb][j / N] * U[((size_t)shard * ndof + c * ns + j) * 64 + lane];
+          W[c] = v;
+        }
+        maxeig = fmax(maxeig, max_eigenvalue(W));
+      }
+    dtmin = cfl * cell_h[(size_t)shard * 64 + lane] / maxeig / (2.0 * degree + 1.0);
   }
+  dtmin = wave_min(dtmin);
+  if (lane == 0) shard_dtmin[shard] = dtmin;
 }
 // compute_time_step_cartesian (src/claw.cc:486-511): per-shard minimum from the stored cell averages
 __global__ void dt_kernel(const double *avg, const double *cell_h, double h_uniform, int uniform_h,
@@ -745,7 +948,7 @@ struct dflo_hip_engine {
   BasisTables bt;
   KBasis kb;
   dflo_params_t prm;
-  int degree = 1, N = 2, ns = 4, ndof = 16, mapping = DFLO_MAP_CARTESIAN;
+  int degree = 1, N = 2, ns = 4, ndof = 16, mapping = DFLO_MAP_CARTESIAN, geo = 0;
   int n_rk = 2;
   double ark[3] = {0, 0, 0};
   int device = 0;
@@ -765,7 +968,7 @@ struct dflo_hip_engine {
   int face_pitch = 0, halo_pitch = 0, halo_stride = 0;
   uint16_t *d_cell_face = nullptr;
   int32_t *d_lrbt = nullptr, *d_user_of = nullptr, *d_iid = nullptr;
-  double *d_cell_h = nullptr;
+  double *d_cell_h = nullptr, *d_cell_vert = nullptr, *d_fgeom_pad = nullptr;
   double *shard_res = nullptr, *shard_dtmin = nullptr, *res_sq = nullptr, *dt_dev = nullptr;
   int *flags = nullptr;
   std::vector<double> bface_xy;  // [n_bfaces][N][2]
@@ -830,24 +1033,25 @@ KBasis make_kbasis(const BasisTables &b) {
 
 typedef void (*stage_fn)(const StageArgs);
 template <int N, int FLUX>
-stage_fn pick_stage_m(int mode) {
-  return mode == 0 ? stage_kernel<N, FLUX, 0> : (mode == 1 ? stage_kernel<N, FLUX, 1> : stage_kernel<N, FLUX, 2>);
+stage_fn pick_stage_m(int mode, int geo) {
+  if (geo == 0) return mode == 0 ? stage_kernel<N, FLUX, 0, 0> : (mode == 1 ? stage_kernel<N, FLUX, 1, 0> : stage_kernel<N, FLUX, 2, 0>);
+  return mode == 0 ? stage_kernel<N, FLUX, 0, 1> : (mode == 1 ? stage_kernel<N, FLUX, 1, 1> : stage_kernel<N, FLUX, 2, 1>);
 }
 template <int N>
-stage_fn pick_stage_n(int flux, int mode) {
+stage_fn pick_stage_n(int flux, int mode, int geo) {
   switch (flux) {
-    case DFLO_FLUX_LXF: return pick_stage_m<N, DFLO_FLUX_LXF>(mode);
-    case DFLO_FLUX_SW: return pick_stage_m<N, DFLO_FLUX_SW>(mode);
-    case DFLO_FLUX_KFVS: return pick_stage_m<N, DFLO_FLUX_KFVS>(mode);
-    case DFLO_FLUX_ROE: return pick_stage_m<N, DFLO_FLUX_ROE>(mode);
-    default: return pick_stage_m<N, DFLO_FLUX_HLLC>(mode);
+    case DFLO_FLUX_LXF: return pick_stage_m<N, DFLO_FLUX_LXF>(mode, geo);
+    case DFLO_FLUX_SW: return pick_stage_m<N, DFLO_FLUX_SW>(mode, geo);
+    case DFLO_FLUX_KFVS: return pick_stage_m<N, DFLO_FLUX_KFVS>(mode, geo);
+    case DFLO_FLUX_ROE: return pick_stage_m<N, DFLO_FLUX_ROE>(mode, geo);
+    default: return pick_stage_m<N, DFLO_FLUX_HLLC>(mode, geo);
   }
 }
-stage_fn pick_stage(int N, int flux, int mode) {
+stage_fn pick_stage(int N, int flux, int mode, int geo) {
   switch (N) {
-    case 2: return pick_stage_n<2>(flux, mode);
-    case 3: return pick_stage_n<3>(flux, mode);
-    default: return pick_stage_n<4>(flux, mode);
+    case 2: return pick_stage_n<2>(flux, mode, geo);
+    case 3: return pick_stage_n<3>(flux, mode, geo);
+    default: return pick_stage_n<4>(flux, mode, geo);
   }
 }
 
@@ -908,6 +1112,9 @@ int launch_update(dflo_hip_engine *h, int rk, double dt_host, double *rhs_out, i
   a.faces = h->d_faces;
   a.cell_face = h->d_cell_face;
   a.cell_h = h->d_cell_h;
+  a.cell_vert = h->d_cell_vert;
+  a.fgeom_pad = h->d_fgeom_pad;
+  a.n_slots = p.n_slots;
   const int which = which_override >= 0 ? which_override : (rk == 0 ? 0 : 1);
   a.bval = h->bval[which];
   a.bface_kind = h->bface_kind;
@@ -929,7 +1136,7 @@ int launch_update(dflo_hip_engine *h, int rk, double dt_host, double *rhs_out, i
   a.want_dt = last ? 1 : 0;
   a.degree = h->degree;
   a.kb = h->kb;
-  stage_fn fn = pick_stage(h->N, h->prm.flux_type, rhs_out ? 2 : (h->ark[rk] != 0.0 ? 1 : 0));
+  stage_fn fn = pick_stage(h->N, h->prm.flux_type, rhs_out ? 2 : (h->ark[rk] != 0.0 ? 1 : 0), h->geo);
   time_begin(h);
   hipLaunchKernelGGL(fn, dim3(h->stage_grid), dim3(64 * h->N), h->lds_bytes, h->stream, a);
   time_end(h);
@@ -980,6 +1187,11 @@ int launch_limit_finalize(dflo_hip_engine *h) {
     int rc = launch_limiter(h, h->prm.limiter_type == DFLO_LIMITER_TVB, h->prm.pos_lim);
     if (rc) return rc;
   }
+  if (last && h->geo == 1) {  // bilinear cells: dt from the point values of the (limited) new solution
+    hipLaunchKernelGGL(dt_q_kernel, dim3(p.n_shards), dim3(64), 0, h->stream, h->U[h->cur], h->d_cell_h, h->d_shard_count,
+                       h->shard_dtmin, h->ndof, h->kb, h->N, h->prm.cfl, h->degree);
+    HIPCHK(h, hipGetLastError());
+  }
   FinalArgs f{};
   f.shard_res = h->shard_res;
   f.shard_dtmin = h->shard_dtmin;
@@ -1009,7 +1221,7 @@ int launch_average(dflo_hip_engine *h) {
   const Plan &p = h->plan;
   const int all = p.n_shards + p.n_ghost_shards;
   hipLaunchKernelGGL(average_kernel, dim3(all), dim3(64), 0, h->stream, h->U[h->cur], h->avg[h->avg_cur], h->ndof, h->kb,
-                     h->N);
+                     h->N, (const double *)h->d_cell_vert, p.n_slots);
   HIPCHK(h, hipGetLastError());
   return DFLO_OK;
 }
@@ -1028,7 +1240,7 @@ int dflo_hip_create(const dflo_mesh_t *mesh, const dflo_params_t *params, int de
   // consistency checks of the reference's parameter parsing (src/parameters.cc:536-550)
   if (mesh->degree < 1 || mesh->degree > DFLO_MAX_DEGREE) { g_create_error = "degree must be 1..3"; return DFLO_ERR_BAD_PARAM; }
   if (mesh->basis != DFLO_BASIS_QK) { g_create_error = "Pk basis is not implemented in the device engine yet"; return DFLO_ERR_UNSUPPORTED; }
-  if (mesh->mapping != DFLO_MAP_CARTESIAN) { g_create_error = "q1/q2 mapping is not implemented in the device engine yet"; return DFLO_ERR_UNSUPPORTED; }
+  if (mesh->mapping != DFLO_MAP_CARTESIAN && mesh->mapping != DFLO_MAP_Q1) { g_create_error = "q2 mapping is not implemented"; return DFLO_ERR_UNSUPPORTED; }
   if (params->limiter_type == DFLO_LIMITER_TVB && mesh->mapping != DFLO_MAP_CARTESIAN) {
     g_create_error = "TVB limiter is implemented only for cartesian mapping";  // src/parameters.cc:543-544
     return DFLO_ERR_BAD_PARAM;
@@ -1049,6 +1261,7 @@ int dflo_hip_create(const dflo_mesh_t *mesh, const dflo_params_t *params, int de
   h->ns = h->N * h->N;
   h->ndof = 4 * h->ns;
   h->mapping = mesh->mapping;
+  h->geo = mesh->mapping == DFLO_MAP_CARTESIAN ? 0 : 1;
   int rc = build_plan(*mesh, 8, 8, h->plan, h->err);
   if (rc) { g_create_error = h->err; delete h; return rc; }
   h->bt = make_basis(h->degree);
@@ -1117,11 +1330,24 @@ int dflo_hip_create(const dflo_mesh_t *mesh, const dflo_params_t *params, int de
     if ((rc = upload(h, &h->d_shard_hdr, hdr))) return bail(rc);
     if ((rc = upload(h, &h->d_halo_pad, hp))) return bail(rc);
     if ((rc = upload(h, &h->d_faces_pad, fpad))) return bail(rc);
+    if (h->geo == 1) {  // face geometry at the same pitch, [shard][3][face_pitch]
+      std::vector<double> gpad((size_t)ns * 3 * h->face_pitch, 0.0);
+      for (int sidx = 0; sidx < p.n_shards; ++sidx) {
+        const int nf = p.face_begin[sidx + 1] - p.face_begin[sidx];
+        for (int k = 0; k < nf; ++k)
+          for (int j2 = 0; j2 < 3; ++j2)
+            gpad[((size_t)sidx * 3 + j2) * h->face_pitch + k] = p.face_geom[((size_t)p.face_begin[sidx] + k) * 3 + j2];
+      }
+      if ((rc = upload(h, &h->d_fgeom_pad, gpad))) return bail(rc);
+    }
   }
   if ((rc = upload(h, &h->d_lrbt, p.lrbt))) return bail(rc);
   if ((rc = upload(h, &h->d_user_of, p.user_of))) return bail(rc);
   if ((rc = upload(h, &h->d_iid, p.iid))) return bail(rc);
   if ((rc = upload(h, &h->d_cell_h, p.cell_h))) return bail(rc);
+  if (h->geo == 1) {
+    if ((rc = upload(h, &h->d_cell_vert, p.cell_vert))) return bail(rc);
+  }
   const size_t nsh = std::max(p.n_shards, 1);
   if (hipMalloc((void **)&h->shard_res, nsh * sizeof(double)) != hipSuccess ||
       hipMalloc((void **)&h->shard_dtmin, nsh * sizeof(double)) != hipSuccess ||
@@ -1140,13 +1366,13 @@ int dflo_hip_create(const dflo_mesh_t *mesh, const dflo_params_t *params, int de
     const int rows = h->ndof + (h->prm.flux_type == DFLO_FLUX_LXF ? 4 : 0);
     const int trows = 4 * h->N + (h->prm.flux_type == DFLO_FLUX_LXF ? 4 : 0);
     h->lds_bytes = ((size_t)rows * 65 + (size_t)trows * h->halo_stride + 4 * (size_t)h->max_fp + (size_t)std::max(p.max_faces, 1) +
-                    (size_t)p.max_bnd * (4 * h->N + 1) + 2) * sizeof(double);
+                    (size_t)p.max_bnd * (4 * h->N + 1) + 2 + (h->geo == 1 ? 3 * (size_t)std::max(p.max_faces, 1) : 0)) * sizeof(double);
   }
 
   if (h->lds_bytes > 160 * 1024) { h->err = "shard halo too large for LDS"; return bail(DFLO_ERR_UNSUPPORTED); }
   if (h->lds_bytes > 64 * 1024) {
     for (int mode = 0; mode < 3; ++mode) {
-      stage_fn fn = pick_stage(h->N, h->prm.flux_type, mode);
+      stage_fn fn = pick_stage(h->N, h->prm.flux_type, mode, h->geo);
       if (hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes) != hipSuccess) {
         h->err = "cannot raise dynamic LDS limit";
         return bail(DFLO_ERR_HIP);
@@ -1154,7 +1380,7 @@ int dflo_hip_create(const dflo_mesh_t *mesh, const dflo_params_t *params, int de
     }
   }
   {  // persistent grid: as many workgroups as stay resident, a multiple of 8 (one run of shards per XCD)
-    stage_fn fn = pick_stage(h->N, h->prm.flux_type, 1);
+    stage_fn fn = pick_stage(h->N, h->prm.flux_type, 1, h->geo);
     int per_cu = 0, n_cu = 0;
     hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, device_id);
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)fn, 64 * h->N, h->lds_bytes) != hipSuccess || per_cu < 1)
@@ -1180,7 +1406,7 @@ int dflo_hip_destroy(dflo_hip_handle h) {
   hipFree(h->rhs); hipFree(h->user_buf); hipFree(h->bface_kind);
   hipFree(h->d_shard_count); hipFree(h->d_halo_begin); hipFree(h->d_halo_cells); hipFree(h->d_face_begin);
   hipFree(h->d_faces); hipFree(h->d_faces_pad); hipFree(h->d_shard_hdr); hipFree(h->d_halo_pad); hipFree(h->d_cell_face); hipFree(h->d_lrbt); hipFree(h->d_user_of); hipFree(h->d_iid);
-  hipFree(h->d_cell_h); hipFree(h->shard_res); hipFree(h->shard_dtmin); hipFree(h->res_sq); hipFree(h->dt_dev);
+  hipFree(h->d_cell_h); hipFree(h->d_cell_vert); hipFree(h->d_fgeom_pad); hipFree(h->shard_res); hipFree(h->shard_dtmin); hipFree(h->res_sq); hipFree(h->dt_dev);
   hipFree(h->flags); hipFree(h->d_send_slots); hipFree(h->ghost_stage);
   for (auto &e : h->ev_pool) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
   if (h->own_stream) hipStreamDestroy(h->own_stream);
@@ -1295,8 +1521,12 @@ int dflo_hip_compute_dt(dflo_hip_handle h, double elapsed_time, double *dt) {
   }
   // per-shard minima from the stored cell averages (src/claw.cc:486-511)
   const Plan &p = h->plan;
-  hipLaunchKernelGGL(dt_kernel, dim3(p.n_shards), dim3(64), 0, h->stream, h->avg[h->avg_cur], h->d_cell_h, p.h,
-                     p.uniform_h ? 1 : 0, h->d_shard_count, h->shard_dtmin, h->prm.cfl, h->degree);
+  if (h->geo == 0)
+    hipLaunchKernelGGL(dt_kernel, dim3(p.n_shards), dim3(64), 0, h->stream, h->avg[h->avg_cur], h->d_cell_h, p.h,
+                       p.uniform_h ? 1 : 0, h->d_shard_count, h->shard_dtmin, h->prm.cfl, h->degree);
+  else
+    hipLaunchKernelGGL(dt_q_kernel, dim3(p.n_shards), dim3(64), 0, h->stream, h->U[h->cur], h->d_cell_h, h->d_shard_count,
+                       h->shard_dtmin, h->ndof, h->kb, h->N, h->prm.cfl, h->degree);
   HIPCHK(h, hipGetLastError());
   double tt[4] = {0, elapsed_time, 0, 0};
   HIPCHK(h, hipMemcpyAsync(h->dt_dev, tt, sizeof(tt), hipMemcpyHostToDevice, h->stream));
@@ -1482,7 +1712,8 @@ int dflo_hip_unpack_ghost(dflo_hip_handle h, const void *device_buffer) {
   if (n_ghost == 0) return DFLO_OK;
   if (!device_buffer) return DFLO_ERR_BAD_PARAM;
   hipLaunchKernelGGL(unpack_ghost_kernel, dim3((n_ghost + 63) / 64), dim3(64), 0, h->stream, (const double *)device_buffer,
-                     h->U[h->cur], h->avg[h->avg_cur], p.n_shards * 64, n_ghost, h->ndof, h->kb, h->N);
+                     h->U[h->cur], h->avg[h->avg_cur], p.n_shards * 64, n_ghost, h->ndof, h->kb, h->N,
+                     (const double *)h->d_cell_vert, p.n_slots);
   HIPCHK(h, hipGetLastError());
   return DFLO_OK;
 }

@@ -140,6 +140,21 @@ int build_plan(const dflo_mesh_t &mesh, int shard_ex, int shard_ey, Plan &p, std
       }
     }
 
+  // outward normal (unit) and length of face f of cell c: faces are straight edges, so both are
+  // constant along the face (what FEFaceValues::normal_vector / JxW give for MappingQ1 / Cartesian)
+  auto push_geom = [&](int c, int f) {
+    static const int fv[4][2] = {{0, 2}, {1, 3}, {0, 1}, {2, 3}};
+    const double *v = &V[(size_t)c * 8];
+    const double tx = v[2 * fv[f][1]] - v[2 * fv[f][0]], ty = v[2 * fv[f][1] + 1] - v[2 * fv[f][0] + 1];
+    const double len = std::sqrt(tx * tx + ty * ty);
+    // t runs along increasing free coordinate; faces 1 (xi=1) and 2 (eta=0) have the cell on the
+    // left of t, faces 0 and 3 on the right (counter-clockwise cells)
+    const double nx = (f == 1 || f == 2) ? ty : -ty, ny = (f == 1 || f == 2) ? -tx : tx;
+    p.face_geom.push_back(nx / len);
+    p.face_geom.push_back(ny / len);
+    p.face_geom.push_back(len);
+  };
+
   // ---- per-shard halo and face lists
   p.halo_begin.assign(p.n_shards + 1, 0);
   p.face_begin.assign(p.n_shards + 1, 0);
@@ -175,6 +190,7 @@ int build_plan(const dflo_mesh_t &mesh, int shard_ex, int shard_ey, Plan &p, std
           const int bl = p.shard_bnd[s]++;
           if (bl >= 0x3FF) { err = "too many boundary faces in a shard"; return DFLO_ERR_BAD_PARAM; }
           p.faces.push_back({(uint32_t)l | ((uint32_t)f << 16) | (1u << 18) | ((uint32_t)bl << 20), bface_of[(size_t)c * 4 + f]});
+          push_geom(c, f);
           p.cell_face[ref] = (uint16_t)k;
           continue;
         }
@@ -190,12 +206,14 @@ int build_plan(const dflo_mesh_t &mesh, int shard_ex, int shard_ey, Plan &p, std
         if (integrator) {
           const int so = slot_of(nb, nf);
           p.faces.push_back({(uint32_t)l | ((uint32_t)f << 16) | ((uint32_t)flip << 19) | ((uint32_t)nf << 20), so});
+          push_geom(c, f);
           p.cell_face[ref] = (uint16_t)k;
           if (nb_inside)
             p.cell_face[((size_t)s * 4 + nf) * kShard + local_of[nb]] = (uint16_t)(k | (flip ? 0x4000 : 0) | 0x8000);
         } else {  // neighbour outside the shard integrates; we still evaluate its flux
           const int so = slot_of(nb, nf);
           p.faces.push_back({(uint32_t)so | ((uint32_t)nf << 16) | ((uint32_t)flip << 19) | ((uint32_t)f << 20), l});
+          push_geom(nb, nf);
           p.cell_face[ref] = (uint16_t)(k | (flip ? 0x4000 : 0) | 0x8000);
         }
       }
@@ -212,6 +230,12 @@ int build_plan(const dflo_mesh_t &mesh, int shard_ex, int shard_ey, Plan &p, std
     p.cell_h.assign(p.n_slots + 2 * kShard, p.h);
     for (int c = 0; c < n; ++c) p.cell_h[p.iid[c]] = hx[c];
   } else {
+    p.cell_h.assign(p.n_slots + 2 * kShard, 1.0);
+    for (int c = 0; c < n; ++c) {  // h = diameter / sqrt(2) (src/claw.cc:551), used by compute_time_step_q
+      const double *v = &V[(size_t)c * 8];
+      const double d1 = std::hypot(v[6] - v[0], v[7] - v[1]), d2 = std::hypot(v[4] - v[2], v[5] - v[3]);
+      p.cell_h[p.iid[c]] = std::max(d1, d2) / std::sqrt(2.0);
+    }
     p.cell_vert.assign((size_t)8 * p.n_slots, 0.0);
     // padding slots get a unit square so that metric terms stay finite
     for (int sl = 0; sl < p.n_slots; ++sl) {

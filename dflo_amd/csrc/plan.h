@@ -50,6 +50,7 @@ struct Plan {
   std::vector<int32_t> halo_faces;   // its local face shared with the shard (an entry = one (cell, face) pair)
   std::vector<int32_t> face_begin;   // [n_shards+1]
   std::vector<FaceRec> faces;
+  std::vector<double> face_geom;     // [n faces][3]: outward unit normal of the integrating cell, edge length
   std::vector<uint16_t> cell_face;   // [n_shards][4][kShard]
   std::vector<int32_t> lrbt;         // [n_shards][4][kShard] internal slot of the left/right/bottom/top
                                      // neighbour or -1 (src/claw.cc:336-380)

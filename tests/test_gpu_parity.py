@@ -141,3 +141,71 @@ def test_device_reciprocal_sqrt_accuracy():
     ulp_s = np.abs(s - np.sqrt(x)) / np.spacing(np.sqrt(x))
     assert ulp_r.max() <= 2.0, ulp_r.max()
     assert ulp_s.max() <= 2.0, ulp_s.max()
+
+
+# ---------------------------------------------------------------- bilinear (Q1-mapped) cells, SURVEY A.3
+def skewed_mesh(n=10, degree=2, amp=0.15, periodic=False):
+    """n x n quads on [0,1]^2 with displaced interior vertices: genuinely non-affine cells."""
+    xs = np.linspace(0, 1, n + 1)
+    X, Y = np.meshgrid(xs, xs, indexing="xy")
+    h = 1.0 / n
+    X = X + amp * h * np.sin(2 * np.pi * X) * np.sin(2 * np.pi * Y)
+    Y = Y + amp * h * np.sin(3 * np.pi * X) * np.sin(1 * np.pi * Y)
+    verts = np.stack([X.reshape(-1), Y.reshape(-1)], axis=1)
+    vid = lambda i, j: i + (n + 1) * j
+    quads = [[vid(i, j), vid(i + 1, j), vid(i + 1, j + 1), vid(i, j + 1)] for j in range(n) for i in range(n)]
+    bed, bid = [], []
+    for i in range(n):
+        bed += [[vid(i, 0), vid(i + 1, 0)], [vid(i, n), vid(i + 1, n)], [vid(0, i), vid(0, i + 1)], [vid(n, i), vid(n, i + 1)]]
+        bid += [2, 2, 1, 3]
+    return dflo_amd.Mesh.from_quads(verts, quads, bed, bid, degree)
+
+
+def mapped_pair(degree, flux, **kw):
+    mesh = skewed_mesh(10, degree)
+    bnd = {1: "inflow", 2: "slip", 3: "outflow"}
+    prm = dflo_amd.Parameters(flux=flux, boundary=bnd, cfl=0.5, **kw)
+    claw, ora = dflo_amd.ConservationLaw(mesh, prm), oracle_lib.Oracle(mesh, prm)
+    ic = lambda x, y: problems.smooth_perturbation(x, y, L=1.0)
+    u0 = mesh.interpolate(ic)
+    cell, face, bid, xy = claw.boundary_faces()
+    co, fo, bo, xyo = ora.boundary_faces()
+    assert (cell == co).all() and (face == fo).all() and np.abs(xy - xyo).max() < 1e-14
+    bv = np.stack(ic(xy[..., 0], xy[..., 1]), axis=-1)
+    for w in (0, 1):
+        claw.set_boundary_values(w, bv)
+        ora.set_boundary_values(w, bv)
+    claw.set_initial_condition(u0)
+    ora.set_solution(u0)
+    return mesh, claw, ora
+
+
+@pytest.mark.parametrize("degree", [1, 2, 3])
+@pytest.mark.parametrize("flux", FLUXES)
+def test_residual_mapped_cells(degree, flux):
+    mesh, claw, ora = mapped_pair(degree, flux)
+    assert rel(claw.cell_average, ora.get_cell_average()) < 1e-13
+    assert rel(claw.assemble_system(), ora.assemble()) < 1e-12
+
+
+@pytest.mark.parametrize("degree,flux,pos", [(1, "lxf", False), (2, "hllc", True), (3, "kfvs", True)])
+def test_rk_solution_mapped_cells(degree, flux, pos):
+    """C5-style: unstructured-type mesh data path (q1 mapping, compute_time_step_q, positivity)."""
+    mesh, claw, ora = mapped_pair(degree, flux, pos_lim=pos)
+    t = 0.0
+    for it in range(6):
+        dt = claw.compute_time_step()
+        dto = ora.compute_time_step(t)
+        assert abs(dt - dto) <= 1e-12 * dto
+        claw.iterate_explicit(dt)
+        ora.step(dt)
+        t += dt
+    assert rel(claw.current_solution, ora.get_solution()) < 1e-11
+    # device-resident dt path on mapped cells
+    t2 = claw.advance(2)
+    for it in range(2):
+        dt = ora.compute_time_step(t)
+        ora.step(dt)
+        t += dt
+    assert abs(t2 - t) < 1e-12 * t
+    assert rel(claw.current_solution, ora.get_solution()) < 1e-11
