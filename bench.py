@@ -61,7 +61,14 @@ def main():
     ap.add_argument("--degree", type=int, default=2)
     ap.add_argument("--flux", default="hllc")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--config", default="c2", choices=["c2", "c3", "c5"],
+                    help="c2 (default, the headline): periodic vortex; c3: Sod tube 2048x256 Q1 Roe TVB+positivity; "
+                         "c5: bilinear-cell mesh, Q3, KFVS, positivity (1-GPU stand-ins for BASELINE configs 3 and 5)")
     args = ap.parse_args()
+    if args.config == "c3":
+        args.degree, args.flux = 1, "roe"
+    if args.config == "c5":
+        args.degree, args.flux = 3, "kfvs"
 
     import dflo_amd
     from dflo_amd import problems
@@ -81,13 +88,53 @@ def main():
     nx, ny = args.nx * world, args.nx
     h = 10.0 / args.nx
     prm = dflo_amd.Parameters(flux=args.flux, cfl=0.9)
-    mesh = dflo_amd.Mesh.cartesian(nx, ny, -5.0, -5.0, h, [-1] * 4, args.degree)
+    ic = problems.isentropic_vortex
+    bc_fn = None
+    if args.config == "c2":
+        mesh = dflo_amd.Mesh.cartesian(nx, ny, -5.0, -5.0, h, [-1] * 4, args.degree)
+    elif args.config == "c3":   # examples/sod_shock_tube: slip walls (0), outflow right (1), inflow left (2)
+        nx, ny = 2048, 256
+        mesh = dflo_amd.Mesh.cartesian(nx, ny, 0.0, 0.0, 1.0 / nx, [2, 1, 0, 0], 1)
+        prm = dflo_amd.Parameters(flux="roe", limiter="TVB", char_lim=True, pos_lim=True, M=0.0, beta=2.0, cfl=0.9,
+                                  final_time=1e9, boundary={0: "slip", 1: "outflow", 2: "inflow"})
+        ic = bc_fn = problems.sod
+    else:                       # c5 stand-in: 512 x 512 bilinear cells (vertices displaced), q1 mapping, Q3 KFVS
+        n = 512 if args.nx == 1024 else args.nx
+        nx = ny = n
+        xs = np.linspace(0.0, 3.0, n + 1)
+        X, Y = np.meshgrid(xs, xs, indexing="xy")
+        X = X + 0.15 * (3.0 / n) * np.sin(2 * np.pi * X / 3.0) * np.sin(2 * np.pi * Y / 3.0)
+        Y = Y + 0.15 * (3.0 / n) * np.sin(3 * np.pi * X / 3.0) * np.sin(np.pi * Y / 3.0)
+        verts = np.stack([X.reshape(-1), Y.reshape(-1)], axis=1)
+        ii, jj = np.meshgrid(np.arange(n), np.arange(n), indexing="xy")
+        v0 = (ii + (n + 1) * jj).reshape(-1)
+        quads = np.stack([v0, v0 + 1, v0 + n + 2, v0 + n + 1], axis=1)
+        k = np.arange(n)
+        bed = np.concatenate([np.stack([k, k + 1], 1), np.stack([k + (n + 1) * n, k + 1 + (n + 1) * n], 1),
+                              np.stack([(n + 1) * k, (n + 1) * (k + 1)], 1), np.stack([(n + 1) * k + n, (n + 1) * (k + 1) + n], 1)])
+        bid = np.concatenate([np.full(n, 2), np.full(n, 2), np.full(n, 1), np.full(n, 3)])
+        mesh = dflo_amd.Mesh.from_quads(verts, quads, bed, bid, 3)
+        prm = dflo_amd.Parameters(flux="kfvs", pos_lim=True, cfl=0.5, final_time=1e9,
+                                  boundary={1: "inflow", 2: "slip", 3: "outflow"})   # examples/forward_step/input.prm
+        ic = bc_fn = problems.forward_step_inflow
     n_rk = 2 if args.degree == 1 else 3
     n_dofs_total = mesh.n_cells * mesh.ndof
 
     if not distributed:
         claw = dflo_amd.ConservationLaw(mesh, prm, device=local_rank)
-        claw.set_initial_condition(mesh.interpolate(problems.isentropic_vortex))
+        if bc_fn is not None:
+            cell, face, bid, xy = claw.boundary_faces()
+            bv = np.stack(bc_fn(xy[..., 0], xy[..., 1]), axis=-1)
+            claw.set_boundary_values(0, bv)
+            claw.set_boundary_values(1, bv)
+        u0 = mesh.interpolate(ic)
+        if args.config == "c5":   # a smooth bump on the free stream so that the fluxes see real jumps
+            xy = mesh.support_points()
+            bump = 1.0 + 0.1 * np.exp(-20.0 * ((xy[..., 0] - 1.5) ** 2 + (xy[..., 1] - 1.5) ** 2))
+            u0 = (u0.reshape(mesh.n_cells, 4, -1) * bump[:, None, :]).reshape(-1)
+        claw.set_initial_condition(u0)
+        if args.config == "c3":
+            claw.apply_limiter()   # run() limits the initial condition, src/claw.cc:997-1001
         claw.advance(args.warmup)
         claw.stage_timing(True)
         torch.cuda.synchronize()
@@ -126,14 +173,16 @@ def main():
 
     if rank == 0:
         value = n_dofs_total * n_rk * args.steps / sec / 1e6
-        bytes_per_update = 24.0  # read u(s), read u(n), write u(s+1)   
+        # read u(s), read u(n), write u(s+1); +16 with a limiter/positivity pass.
+        # roofline.achieved prices the stage kernel alone, so it uses 24 B in every configuration.
+        bytes_per_update = 24.0
         achieved = n_dofs_launch * bytes_per_update / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
         traffic = None
         tf = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tf):
             try:
                 rec = json.load(open(tf))
-                key = "q%d_%s_%d" % (args.degree, args.flux, args.nx)
+                key = "%s_q%d_%s_%d" % (args.config, args.degree, args.flux, args.nx)
                 traffic = rec.get(key, {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
@@ -142,13 +191,16 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": sec / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {
-                "workload": "isentropic_vortex, %dx%d quads per GPU (global %dx%d), Q%d, %s, periodic, SSP-RK %d stages"
-                            % (args.nx, args.nx, nx, ny, args.degree, args.flux.upper(), n_rk),
+                "workload": {"c2": "isentropic_vortex, %dx%d quads per GPU (global %dx%d), Q%d, %s, periodic, SSP-RK %d stages"
+                                   % (args.nx, args.nx, nx, ny, args.degree, args.flux.upper(), n_rk),
+                             "c3": "sod_shock_tube, 2048x256 quads, Q1, ROE, TVB(M=0,beta=2,char)+positivity, SSP-RK 2 stages",
+                             "c5": "free stream + bump on %dx%d bilinear quads (q1 mapping), Q3, KFVS, positivity, SSP-RK 3 stages"
+                                   % (nx, ny)}[args.config],
                 "n_dofs": n_dofs_total, "n_rk": n_rk, "parallelism": "x-slabs, %d rank(s)" % world,
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                "traffic": traffic, "kernel": "stage_kernel<%d,%s>" % (args.degree + 1, args.flux),
+                "traffic": traffic, "kernel": "stage_kernel<%d,%s,geo%d>" % (args.degree + 1, args.flux, int(args.config == "c5")),
                 "kernel_ms": kernel_ms, "launches": n_launch, "algorithmic_bytes_per_dof_update": bytes_per_update,
             },
         }

@@ -851,24 +851,48 @@ __global__ void average_kernel(const double *U, double *avg, int ndof, KBasis kb
   }
 }
 // compute_time_step_q (src/claw.cc:520-557): max of |v| + c over the 4 x 4 points of QIterated(QTrapez,3),
-// dt = cfl h / lambda / (2k+1) with h = diameter / sqrt(2); per-shard minimum
-__global__ void dt_q_kernel(const double *U, const double *cell_h, const int32_t *shard_count, double *shard_dtmin, int ndof,
-                            KBasis kb, int N, double cfl, int degree) {
+// dt = cfl h / lambda / (2k+1) with h = diameter / sqrt(2); per-shard minimum.  Lane = cell; the
+// interpolation to the 16 points is sum-factorised (xi first, then eta).
+template <int N>
+__global__ __launch_bounds__(64) void dt_q_kernel(const double *U, const double *cell_h, const int32_t *shard_count,
+                                                  double *shard_dtmin, KBasis kb, double cfl, int degree) {
+  constexpr int NS = N * N, NDOF = 4 * NS;
   const int shard = blockIdx.x;
   const int lane = threadIdx.x;
-  const int ns = ndof / 4;
   double dtmin = 1.0e20;
   if (lane < shard_count[shard]) {
-    double maxeig = 0.0;
-    for (int pb = 0; pb < kTrap; ++pb)
-      for (int pa = 0; pa < kTrap; ++pa) {
-        double W[4];
-        for (int c = 0; c < 4; ++c) {
-          double v = 0;
-          for (int j = 0; j < ns; ++j) v += kb.Pt[pa][j % N] * kb.Pt[pb][j / N] * U[((size_t)shard * ndof + c * ns + j) * 64 + lane];
-          W[c] = v;
+    double W[4][kTrap][kTrap];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      double u[NS], v[kTrap][N];
+#pragma unroll
+      for (int j = 0; j < NS; ++j) u[j] = U[((size_t)shard * NDOF + c * NS + j) * 64 + lane];
+#pragma unroll
+      for (int pa = 0; pa < kTrap; ++pa)
+#pragma unroll
+        for (int b = 0; b < N; ++b) {
+          double t = 0;
+#pragma unroll
+          for (int aa = 0; aa < N; ++aa) t += kb.Pt[pa][aa] * u[aa + N * b];
+          v[pa][b] = t;
         }
-        maxeig = fmax(maxeig, max_eigenvalue(W));
+#pragma unroll
+      for (int pa = 0; pa < kTrap; ++pa)
+#pragma unroll
+        for (int pb = 0; pb < kTrap; ++pb) {
+          double t = 0;
+#pragma unroll
+          for (int b = 0; b < N; ++b) t += kb.Pt[pb][b] * v[pa][b];
+          W[c][pa][pb] = t;
+        }
+    }
+    double maxeig = 0.0;
+#pragma unroll
+    for (int pa = 0; pa < kTrap; ++pa)
+#pragma unroll
+      for (int pb = 0; pb < kTrap; ++pb) {
+        const double w[4] = {W[0][pa][pb], W[1][pa][pb], W[2][pa][pb], W[3][pa][pb]};
+        maxeig = fmax(maxeig, max_eigenvalue(w));
       }
     dtmin = cfl * cell_h[(size_t)shard * 64 + lane] / maxeig / (2.0 * degree + 1.0);
   }
@@ -899,33 +923,52 @@ struct FinalArgs {
   int n_shards, stage, do_res, do_dt, advance_time;
   double time_step, final_time, dt_host;
 };
-__global__ __launch_bounds__(256) void finalize_kernel(const FinalArgs a) {
-  __shared__ double sres[4], smin[4];
-  double r = 0.0, m = 1.0e20;
-  // fixed order -> deterministic sums
-  for (int s = threadIdx.x; s < a.n_shards; s += 256) {
-    if (a.do_res) r += a.shard_res[s];
-    if (a.do_dt) m = fmin(m, a.shard_dtmin[s]);
+__global__ __launch_bounds__(1024) void finalize_kernel(const FinalArgs a) {
+  __shared__ double sres[16], smin[16];
+  // fixed assignment of shards to threads and a fixed combination tree -> deterministic sums;
+  // four independent loads per trip keep the (single) workgroup from serialising on latency
+  double r0 = 0.0, r1 = 0.0, r2 = 0.0, r3 = 0.0, m = 1.0e20;
+  const int n = a.n_shards, t = threadIdx.x;
+  for (int s = t; s < n; s += 4096) {
+    const int s1 = s + 1024, s2 = s + 2048, s3 = s + 3072;
+    if (a.do_res) {
+      r0 += a.shard_res[s];
+      if (s1 < n) r1 += a.shard_res[s1];
+      if (s2 < n) r2 += a.shard_res[s2];
+      if (s3 < n) r3 += a.shard_res[s3];
+    }
+    if (a.do_dt) {
+      double m0 = a.shard_dtmin[s];
+      if (s1 < n) m0 = fmin(m0, a.shard_dtmin[s1]);
+      if (s2 < n) m0 = fmin(m0, a.shard_dtmin[s2]);
+      if (s3 < n) m0 = fmin(m0, a.shard_dtmin[s3]);
+      m = fmin(m, m0);
+    }
   }
-  r = wave_sum(r);
+  double r = wave_sum((r0 + r1) + (r2 + r3));
   m = wave_min(m);
-  if ((threadIdx.x & 63) == 0) {
-    sres[threadIdx.x >> 6] = r;
-    smin[threadIdx.x >> 6] = m;
+  if ((t & 63) == 0) {
+    sres[t >> 6] = r;
+    smin[t >> 6] = m;
   }
   __syncthreads();
-  if (threadIdx.x == 0) {
-    if (a.do_res) a.res_sq[a.stage] = sres[0] + sres[1] + sres[2] + sres[3];
+  if (t == 0) {
+    if (a.do_res) {
+      double tot = 0.0;
+      for (int i = 0; i < 16; ++i) tot += sres[i];
+      a.res_sq[a.stage] = tot;
+    }
     if (a.do_dt) {
-      double t = a.dt_dev[1];
+      double tt = a.dt_dev[1];
       if (a.advance_time) {  // elapsed_time += global_dt (src/claw.cc:1072) for the step just done
-        t += a.dt_host >= 0.0 ? a.dt_host : a.dt_dev[0];
-        a.dt_dev[1] = t;
+        tt += a.dt_host >= 0.0 ? a.dt_host : a.dt_dev[0];
+        a.dt_dev[1] = tt;
       }
-      double dt = fmin(fmin(smin[0], smin[1]), fmin(smin[2], smin[3]));
+      double dt = smin[0];
+      for (int i = 1; i < 16; ++i) dt = fmin(dt, smin[i]);
       a.dt_dev[2] = dt;
       if (dt > 0 && a.time_step > 0) dt = fmin(dt, a.time_step);
-      if (t + dt > a.final_time) dt = a.final_time - t;
+      if (tt + dt > a.final_time) dt = a.final_time - tt;
       a.dt_dev[0] = dt;
     }
   }
@@ -1056,6 +1099,8 @@ stage_fn pick_stage(int N, int flux, int mode, int geo) {
 }
 
 int grid_for(int n_shards) { return ((n_shards + 7) / 8) * 8; }
+
+void launch_dt_q(dflo_hip_engine *h);
 
 void time_begin(dflo_hip_engine *h) {
   if (!h->timing) return;
@@ -1188,8 +1233,7 @@ int launch_limit_finalize(dflo_hip_engine *h) {
     if (rc) return rc;
   }
   if (last && h->geo == 1) {  // bilinear cells: dt from the point values of the (limited) new solution
-    hipLaunchKernelGGL(dt_q_kernel, dim3(p.n_shards), dim3(64), 0, h->stream, h->U[h->cur], h->d_cell_h, h->d_shard_count,
-                       h->shard_dtmin, h->ndof, h->kb, h->N, h->prm.cfl, h->degree);
+    launch_dt_q(h);
     HIPCHK(h, hipGetLastError());
   }
   FinalArgs f{};
@@ -1205,7 +1249,7 @@ int launch_limit_finalize(dflo_hip_engine *h) {
   f.dt_host = h->pending_dt;
   f.time_step = h->prm.time_step;
   f.final_time = h->prm.final_time;
-  hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, h->stream, f);
+  hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(1024), 0, h->stream, f);
   HIPCHK(h, hipGetLastError());
   h->pending_rk = -1;
   return DFLO_OK;
@@ -1215,6 +1259,13 @@ int launch_stage(dflo_hip_engine *h, int rk, double dt_host, double *rhs_out, in
   int rc = launch_update(h, rk, dt_host, rhs_out, which_override);
   if (rc || rhs_out) return rc;
   return launch_limit_finalize(h);
+}
+
+void launch_dt_q(dflo_hip_engine *h) {
+  const Plan &p = h->plan;
+  auto fn = h->N == 2 ? dt_q_kernel<2> : (h->N == 3 ? dt_q_kernel<3> : dt_q_kernel<4>);
+  hipLaunchKernelGGL(fn, dim3(p.n_shards), dim3(64), 0, h->stream, (const double *)h->U[h->cur], (const double *)h->d_cell_h,
+                     (const int32_t *)h->d_shard_count, h->shard_dtmin, h->kb, h->prm.cfl, h->degree);
 }
 
 int launch_average(dflo_hip_engine *h) {
@@ -1525,8 +1576,7 @@ int dflo_hip_compute_dt(dflo_hip_handle h, double elapsed_time, double *dt) {
     hipLaunchKernelGGL(dt_kernel, dim3(p.n_shards), dim3(64), 0, h->stream, h->avg[h->avg_cur], h->d_cell_h, p.h,
                        p.uniform_h ? 1 : 0, h->d_shard_count, h->shard_dtmin, h->prm.cfl, h->degree);
   else
-    hipLaunchKernelGGL(dt_q_kernel, dim3(p.n_shards), dim3(64), 0, h->stream, h->U[h->cur], h->d_cell_h, h->d_shard_count,
-                       h->shard_dtmin, h->ndof, h->kb, h->N, h->prm.cfl, h->degree);
+    launch_dt_q(h);
   HIPCHK(h, hipGetLastError());
   double tt[4] = {0, elapsed_time, 0, 0};
   HIPCHK(h, hipMemcpyAsync(h->dt_dev, tt, sizeof(tt), hipMemcpyHostToDevice, h->stream));
@@ -1543,7 +1593,7 @@ int dflo_hip_compute_dt(dflo_hip_handle h, double elapsed_time, double *dt) {
   f.dt_host = -1.0;
   f.time_step = h->prm.time_step;
   f.final_time = h->prm.final_time;
-  hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, h->stream, f);
+  hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(1024), 0, h->stream, f);
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipMemcpyAsync(tt, h->dt_dev, sizeof(tt), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
