@@ -951,12 +951,12 @@ long long gid_of(const Oracle &o, int c) { return o.gid.empty() ? c : o.gid[c]; 
 void assemble_system(Oracle &o, int which) {
   std::fill(o.rhs.begin(), o.rhs.end(), 0.0);  // right_hand_side = 0
   const int ndof = o.ndof;
-  const int chunk = 4096;
+  const int chunk = std::max(4096, o.nthreads * 128);
   std::vector<double> loc((size_t)chunk * ndof), locn((size_t)chunk * 4 * ndof);
   std::vector<int> tgt((size_t)chunk * 4);
   for (int c0 = 0; c0 < o.n_cells; c0 += chunk) {
     const int c1 = std::min(o.n_cells, c0 + chunk);
-#pragma omp parallel for schedule(dynamic, 16) num_threads(o.nthreads) if (o.nthreads > 1)
+#pragma omp parallel for schedule(dynamic, 8) num_threads(o.nthreads) if (o.nthreads > 1)
     for (int cell = c0; cell < c1; ++cell) {
       const bool owned = cell < o.n_owned;
       std::vector<double> local(ndof, 0.0), local_n(ndof, 0.0);
