@@ -78,12 +78,15 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the dflo HIP engine has no CPU fallback")
+    if os.environ.get("DFLO_BENCH_BACKEND") == "gloo":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
-    distributed = world > 1
+    distributed = world > 1 or os.environ.get("DFLO_BENCH_FORCE_DIST") == "1"   # developer switch: drive the multi-rank loop with one rank
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl")
+        # DFLO_BENCH_BACKEND=gloo: developer switch to exercise the multi-rank path with several ranks on ONE gpu
+        dist.init_process_group(os.environ.get("DFLO_BENCH_BACKEND", "nccl"))
 
     nx, ny = args.nx * world, args.nx
     h = 10.0 / args.nx
@@ -154,19 +157,17 @@ def main():
         u = np.ascontiguousarray(np.stack(w, axis=1)).reshape(-1)
         dclaw.claw.set_initial_condition(u)
         dclaw.exchange_solution()
-        for _ in range(args.warmup):
-            dclaw.iterate_explicit(dclaw.compute_time_step())
+        dclaw.advance(args.warmup)
         dclaw.claw.stage_timing(True)
         dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
-            dclaw.iterate_explicit(dclaw.compute_time_step())
+        dclaw.advance(args.steps)
         dist.barrier()
         torch.cuda.synchronize()
         sec = time.perf_counter() - t0
         kernel_ms, n_launch = dclaw.claw.stage_timing(False)
-        tt = torch.tensor([sec], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([sec], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         sec = float(tt.item())
         n_dofs_launch = dclaw.n_dofs_owned
@@ -212,10 +213,20 @@ def main():
             runs = [cpu_baseline(threads=t, nx=256, steps=2) for t in sorted({1, min(16, ncpu), min(32, ncpu), min(64, ncpu)})]
             out["cpu_baseline"] = max(runs, key=lambda r: r["value"])
             out["cpu_baseline"]["host_cpus"] = ncpu
-        print(json.dumps(out))
+        result_line = json.dumps(out)
+    else:
+        result_line = None
     if distributed:
         import torch.distributed as dist
         dist.destroy_process_group()
+    if result_line is not None:
+        import ctypes
+        sys.stderr.flush()
+        try:
+            ctypes.CDLL(None).fflush(None)   # RCCL prints its version banner through C stdio: flush it first
+        except Exception:
+            pass
+        print(result_line, flush=True)
 
 
 if __name__ == "__main__":

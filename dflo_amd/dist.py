@@ -21,6 +21,17 @@ from ._lib import lib
 from .claw import ConservationLaw
 
 
+class _DevPtr:
+    """Wraps a raw device address as a torch tensor (no copy) through __cuda_array_interface__."""
+
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (ptr, False), "version": 2}
+
+
+def _device_view(ptr, n, device):
+    return torch.as_tensor(_DevPtr(ptr, n), device=device)
+
+
 class HaloExchange:
     """Point-to-point exchange of per-cell records between neighbouring ranks.
 
@@ -86,7 +97,10 @@ class DistributedConservationLaw:
         self.ndof = ndof
         self.n_rk = self.claw.n_rk
         self.tvb = parameters.limiter == "TVB"
-        self.scal = torch.zeros(2, dtype=torch.float64, device=self.device)
+        # device-resident {dt, elapsed time, raw CFL minimum}: lets the step loop run without host round trips
+        dtp, resp = C.c_void_p(), C.c_void_p()
+        self.claw._chk(lib.dflo_hip_scalar_ptrs(self.claw._h, C.byref(dtp), C.byref(resp)))
+        self.dt_dev = _device_view(dtp.value, 4, self.device)
         self.elapsed_time = 0.0
         self.n_dofs_owned = self.mesh.n_owned * ndof
         self.n_dofs_global = global_mesh.n_cells * ndof
@@ -129,6 +143,31 @@ class DistributedConservationLaw:
             self.exchange_solution()
         c.end_step()
         self.elapsed_time += dt
+
+    def advance(self, n_steps):
+        """n_steps x {compute_time_step; iterate_explicit} with dt resident on the device: per step one
+        8-byte all-reduce(min) (Utilities::MPI::min, src_mpi/claw.cc:579) and no host synchronisation."""
+        c = self.claw
+        dt0 = self.compute_time_step()                 # host value for the first step only
+        nccl = dist.get_backend() == "nccl"
+        for step in range(n_steps):
+            for rk in range(self.n_rk):
+                c._chk(lib.dflo_hip_stage_update(c._h, rk, dt0 if step == 0 else -1.0))
+                if self.tvb:
+                    self.exchange_averages()
+                c._chk(lib.dflo_hip_stage_limit(c._h))
+                self.exchange_solution()
+            c.end_step()
+            # the last stage left this rank's raw CFL minimum in dt_dev[2]
+            if nccl:
+                dist.all_reduce(self.dt_dev[2:3], op=dist.ReduceOp.MIN)
+            else:
+                t = self.dt_dev[2:3].cpu()
+                dist.all_reduce(t, op=dist.ReduceOp.MIN)
+                self.dt_dev[2:3].copy_(t)
+            c._chk(lib.dflo_hip_apply_dt_rules(c._h))
+        self.elapsed_time = float(self.dt_dev[1].item())
+        return self.elapsed_time
 
     def gather_solution(self):
         """Owned DoFs of all ranks assembled in the global cell order (on every rank; test helper)."""

@@ -64,7 +64,8 @@ class Mesh:
             raise DfloError(rc, lib.dflo_mesh_last_error().decode())
         so_a = np.ctypeslib.as_array(so, shape=(n_ranks + 1,)).copy()
         ro_a = np.ctypeslib.as_array(ro, shape=(n_ranks + 1,)).copy()
-        sc_a = np.ctypeslib.as_array(sc, shape=(max(int(so_a[-1]), 1),)).copy()[: int(so_a[-1])]
+        n_send = int(so_a[-1])
+        sc_a = np.ctypeslib.as_array(sc, shape=(n_send,)).copy() if n_send > 0 else np.zeros(0, dtype=np.int32)
         return Mesh(out, comm=(sc_a, so_a, ro_a))
 
     # ---- views
