@@ -46,11 +46,22 @@ class HaloExchange:
         self.world = dist.get_world_size()
         self.device = device
         self.host_staging = dist.get_backend() != "nccl" and device.type == "cuda"
+        # RCCL: one grouped collective per exchange (all_to_all_single = grouped ncclSend/ncclRecv with the
+        # per-peer counts below) instead of 2 x peers python-level P2P ops; DFLO_HALO=p2p forces the latter
+        import os
+        self.use_a2a = dist.get_backend() == "nccl" and os.environ.get("DFLO_HALO", "a2a") != "p2p"
+        self.send_counts = [self.so[r + 1] - self.so[r] for r in range(self.world)]
+        self.recv_counts = [self.ro[r + 1] - self.ro[r] for r in range(self.world)]
         self.peers = [r for r in range(self.world) if r != self.rank and (self.so[r + 1] > self.so[r] or self.ro[r + 1] > self.ro[r])]
 
     def exchange(self, send, recv, width):
         """send: [n_send*width] tensor, recv: [n_ghost*width] tensor (both on self.device)."""
         if not self.peers:
+            return
+        if self.use_a2a:
+            n_s, n_r = self.so[-1] * width, self.ro[-1] * width
+            dist.all_to_all_single(recv[:n_r], send[:n_s], [c * width for c in self.recv_counts],
+                                   [c * width for c in self.send_counts])
             return
         if self.host_staging:
             s, r = send.cpu(), torch.empty(recv.shape, dtype=recv.dtype)
