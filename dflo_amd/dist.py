@@ -49,7 +49,7 @@ class HaloExchange:
         # RCCL: one grouped collective per exchange (all_to_all_single = grouped ncclSend/ncclRecv with the
         # per-peer counts below) instead of 2 x peers python-level P2P ops; DFLO_HALO=p2p forces the latter
         import os
-        self.use_a2a = dist.get_backend() == "nccl" and os.environ.get("DFLO_HALO", "a2a") != "p2p"
+        self.use_a2a = os.environ.get("DFLO_HALO", "a2a") != "p2p"
         self.send_counts = [self.so[r + 1] - self.so[r] for r in range(self.world)]
         self.recv_counts = [self.ro[r + 1] - self.ro[r] for r in range(self.world)]
         self.peers = [r for r in range(self.world) if r != self.rank and (self.so[r + 1] > self.so[r] or self.ro[r + 1] > self.ro[r])]
@@ -58,24 +58,24 @@ class HaloExchange:
         """send: [n_send*width] tensor, recv: [n_ghost*width] tensor (both on self.device)."""
         if not self.peers:
             return
-        if self.use_a2a:
-            n_s, n_r = self.so[-1] * width, self.ro[-1] * width
-            dist.all_to_all_single(recv[:n_r], send[:n_s], [c * width for c in self.recv_counts],
-                                   [c * width for c in self.send_counts])
-            return
-        if self.host_staging:
+        if self.host_staging:  # gloo with device buffers (tests): stage through the host
             s, r = send.cpu(), torch.empty(recv.shape, dtype=recv.dtype)
         else:
             s, r = send, recv
-        ops = []
-        for p in self.peers:
-            if self.ro[p + 1] > self.ro[p]:
-                ops.append(dist.P2POp(dist.irecv, r[self.ro[p] * width:self.ro[p + 1] * width], p))
-        for p in self.peers:
-            if self.so[p + 1] > self.so[p]:
-                ops.append(dist.P2POp(dist.isend, s[self.so[p] * width:self.so[p + 1] * width], p))
-        for w in dist.batch_isend_irecv(ops):
-            w.wait()
+        if self.use_a2a:
+            n_s, n_r = self.so[-1] * width, self.ro[-1] * width
+            dist.all_to_all_single(r[:n_r], s[:n_s], [c * width for c in self.recv_counts],
+                                   [c * width for c in self.send_counts])
+        else:
+            ops = []
+            for p in self.peers:
+                if self.ro[p + 1] > self.ro[p]:
+                    ops.append(dist.P2POp(dist.irecv, r[self.ro[p] * width:self.ro[p + 1] * width], p))
+            for p in self.peers:
+                if self.so[p + 1] > self.so[p]:
+                    ops.append(dist.P2POp(dist.isend, s[self.so[p] * width:self.so[p + 1] * width], p))
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
         if self.host_staging:
             recv.copy_(r)
 

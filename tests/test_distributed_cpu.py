@@ -14,7 +14,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 
 
-def _worker(rank, world, port, case, ret):
+def _worker(rank, world, port, case, ret, transport="a2a"):
+    os.environ["DFLO_HALO"] = transport
     sys.path.insert(0, ROOT)
     sys.path.insert(0, HERE)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -95,3 +96,15 @@ def test_two_rank_halo_exchange_matches_single_process(case):
     ret = mgr.dict()
     mp.spawn(_worker, args=(2, port, case, ret), nprocs=2, join=True)
     assert ret["err"] < 1e-12, ret["err"]
+
+
+def test_point_to_point_transport_and_three_ranks():
+    """The P2P fallback transport, and a 3-way partition (a middle slab with two different neighbours)."""
+    import random
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(2, 29500 + random.randint(0, 2000), CASES[0], ret, "p2p"), nprocs=2, join=True)
+    assert ret["err"] < 1e-12, ret["err"]
+    ret2 = mgr.dict()
+    mp.spawn(_worker, args=(3, 29500 + random.randint(0, 2000), CASES[2], ret2, "a2a"), nprocs=3, join=True)
+    assert ret2["err"] < 1e-12, ret2["err"]
