@@ -42,13 +42,13 @@ struct KBasis {       // 1-D tables, see basis.h
 };
 
 #ifdef DFLO_PHASE_TIMING
-#define PHASE_MARK(i) do { if (tid == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tacc[i] += t_ - tlast; tlast = t_; } } while (0)
+#define PHASE_MARK(i) do { if (lane == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tacc[i] += t_ - tlast; tlast = t_; } } while (0)
 #else
 #define PHASE_MARK(i) do { } while (0)
 #endif
 
 struct StageArgs {
-  unsigned long long *phase_cycles;  // [grid][8], only with DFLO_PHASE_TIMING
+  unsigned long long *phase_cycles;  // [grid][4 waves][8], only with DFLO_PHASE_TIMING
   const double *Ucur, *Uold;
   double *Unew;
   const double *avg_cur;
@@ -110,44 +110,50 @@ __device__ __forceinline__ int shard_of_block(int b, int n_shards) {
 
 // phase C for node row B of every cell of the shard (lane = cell)
 template <int N, int B, int MODE>
-__device__ __forceinline__ void row_update(const StageArgs &a, const double *Us, const int S, const double *Fh,
+__device__ __forceinline__ void row_update(const StageArgs &a, double *Us, const int S, const double *Fh,
                                            double *red, int shard, int lane, bool active, double h,
-                                           const uint16_t (&cref)[4], const double (&uold)[4][N]) {
+                                           const uint16_t (&cref)[4], const double (&uold)[4][N],
+                                           const double (&Wrow)[N][4]) {
   constexpr int NS = N * N;
   double R[4][N];
 #pragma unroll
   for (int c = 0; c < 4; ++c)
 #pragma unroll
     for (int m = 0; m < N; ++m) R[c][m] = 0.0;
-  double Wrow[N][4];
   // volume term (integrate_cell_term_explicit :57-115); collocation: W_q = U_q,
-  // grad phi_(m,B)(x_(aa,B)) = D[aa][m]/h e_x, grad phi_(aa,B)(x_(aa,q)) = D[q][B]/h e_y, JxW = w w h^2
+  // grad phi_(m,B)(x_(aa,B)) = D[aa][m]/h e_x, grad phi_(aa,B)(x_(aa,q)) = D[q][B]/h e_y, JxW = w w h^2.
+  // Every wave evaluates F and G once at the nodes of its own row (values still in registers), then
+  // overwrites its own rows of the LDS image with G: after one barrier each wave reads the G of the
+  // other rows instead of re-evaluating the flux there.
+  double Gown[N][4];
 #pragma unroll
   for (int aa = 0; aa < N; ++aa) {
+    double Fx[4];
+    flux_xy(Wrow[aa], Fx, Gown[aa]);
+    const double wbh = CB<N>::t.w[B] * h;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const double fx = Fx[c] * wbh;
+#pragma unroll
+      for (int m = 0; m < N; ++m) R[c][m] += fx * CB<N>::t.DW[aa][m];
+      Us[(c * NS + aa + N * B) * S + lane] = Gown[aa][c];
+    }
+    if (a.gravity != 0.0) {  // forcing (src/equation.h:831-850): (0, -rho, 0, -my) * gravity
+      const double jxw = CB<N>::t.w[aa] * CB<N>::t.w[B] * h * h;
+      R[MY][aa] += a.gravity * (-1.0 * Wrow[aa][RHO]) * jxw;
+      R[EN][aa] += a.gravity * (-1.0 * Wrow[aa][MY]) * jxw;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int aa = 0; aa < N; ++aa) {
+    const double wah = CB<N>::t.w[aa] * h;
 #pragma unroll
     for (int q = 0; q < N; ++q) {
-      double W[4], Fx[4], Gy[4];
 #pragma unroll
-      for (int c = 0; c < 4; ++c) W[c] = Us[(c * NS + aa + N * q) * S + lane];
-      if (q == B) flux_xy(W, Fx, Gy);
-      else flux_y(W, Gy);
-      const double wah = CB<N>::t.w[aa] * h;
-#pragma unroll
-      for (int c = 0; c < 4; ++c) R[c][aa] += Gy[c] * wah * CB<N>::t.DW[q][B];
-      if (q == B) {
-        const double wbh = CB<N>::t.w[B] * h;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          Wrow[aa][c] = W[c];
-          const double fx = Fx[c] * wbh;
-#pragma unroll
-          for (int m = 0; m < N; ++m) R[c][m] += fx * CB<N>::t.DW[aa][m];
-        }
-        if (a.gravity != 0.0) {  // forcing (src/equation.h:831-850): (0, -rho, 0, -my) * gravity
-          const double jxw = CB<N>::t.w[aa] * CB<N>::t.w[B] * h * h;
-          R[MY][aa] += a.gravity * (-1.0 * W[RHO]) * jxw;
-          R[EN][aa] += a.gravity * (-1.0 * W[MY]) * jxw;
-        }
+      for (int c = 0; c < 4; ++c) {
+        const double gy = q == B ? Gown[aa][c] : Us[(c * NS + aa + N * q) * S + lane];
+        R[c][aa] += gy * (wah * CB<N>::t.DW[q][B]);
       }
     }
   }
@@ -363,6 +369,9 @@ __global__ __launch_bounds__(64 * N, (GEO == 1 || N == 4) ? 2 : 3) void stage_ke
   int *Bk = (int *)(Bv + a.max_bnd * 4 * N);          // [max_bnd] boundary kinds
   double *Fg = (double *)(Bk + ((a.max_bnd + 1) & ~1)); // GEO 1: [3][max_faces] unit normal and length of the faces
 
+#ifdef DFLO_PHASE_TIMING
+  unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
+#endif
   // ---- all loads of the shard, issued back to back
   const int4 hdr = a.shard_hdr[shard];                // {cells, faces, halo entries, boundary faces}
   const int nf = hdr.y, nfp = nf * N, nh = hdr.z, nbnd = hdr.w;
@@ -403,6 +412,7 @@ __global__ __launch_bounds__(64 * N, (GEO == 1 || N == 4) ? 2 : 3) void stage_ke
       for (int m = 0; m < N; ++m) uold[c][m] = op[(c * NS + m + N * row) * 64];
   }
 
+  PHASE_MARK(0);
   // ---- phase A: own rows -> LDS; halo: only the trace on the shared face is kept.
   //      halo item i -> (entry s = i % nh, q = (i / nh) % N, comp = i / (nh N)); an entry is
   //      (internal cell slot | local face << 28) of a face neighbour outside the shard
@@ -456,7 +466,9 @@ __global__ __launch_bounds__(64 * N, (GEO == 1 || N == 4) ? 2 : 3) void stage_ke
       }
     }
   }
+  PHASE_MARK(1);
   __syncthreads();
+  PHASE_MARK(2);
 
   // ---- phase B: one numerical flux per face point (integrate_face_term_explicit :303-341,
   //      integrate_boundary_term_explicit :176-206).  Face-point index p = q * nf + k: neighbouring
@@ -523,13 +535,20 @@ __global__ __launch_bounds__(64 * N, (GEO == 1 || N == 4) ? 2 : 3) void stage_ke
 #pragma unroll
     for (int c = 0; c < 4; ++c) Fh[c * a.max_fp + k * N + q] = F[c];
   }
+  PHASE_MARK(3);
   __syncthreads();
+  PHASE_MARK(4);
 
   // ---- phase C: volume + lifting + RK update of node row `row`
   double *red = Fh;  // reused after the barrier inside row_update
+  double wrow[N][4];
+#pragma unroll
+  for (int m = 0; m < N; ++m)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) wrow[m][c] = urow[c][m];
 #define DFLO_ROW(Bq)                                                                                     \
   do {                                                                                                   \
-    if constexpr (GEO == 0) row_update<N, Bq, MODE>(a, Us, S, Fh, red, shard, lane, active, h, cref, uold); \
+    if constexpr (GEO == 0) row_update<N, Bq, MODE>(a, Us, S, Fh, red, shard, lane, active, h, cref, uold, wrow); \
     else row_update_q1<N, Bq, MODE>(a, Us, S, Fh, Fg, red, shard, lane, active, vx, cref, uold);           \
   } while (0)
   if constexpr (N == 2) {
@@ -540,8 +559,10 @@ __global__ __launch_bounds__(64 * N, (GEO == 1 || N == 4) ? 2 : 3) void stage_ke
     if (row == 0) DFLO_ROW(0); else if (row == 1) DFLO_ROW(1); else if (row == 2) DFLO_ROW(2); else DFLO_ROW(3);
   }
 #undef DFLO_ROW
+  PHASE_MARK(5);
   if constexpr (MODE == 2) return;
   __syncthreads();
+  PHASE_MARK(6);
   if (row == N - 1) {  // cell averages (src/claw.cc:562-597), residual norm, CFL minimum of the shard; on the
                        // last wave: wave 0 carries the extra pass over the face points
     double avg[4], res = 0.0, dtmin = 1.0e20;
@@ -575,6 +596,11 @@ __global__ __launch_bounds__(64 * N, (GEO == 1 || N == 4) ? 2 : 3) void stage_ke
       if (GEO == 0 && a.want_dt) a.shard_dtmin[shard] = dtmin;
     }
   }
+  PHASE_MARK(7);
+#ifdef DFLO_PHASE_TIMING
+  if (lane == 0 && a.phase_cycles)
+    for (int i = 0; i < 8; ++i) a.phase_cycles[((size_t)blockIdx.x * 4 + row) * 8 + i] = tacc[i];
+#endif
 }
 
 // ------------------------------------------------------------------ limiter kernel
@@ -1440,8 +1466,8 @@ int dflo_hip_create(const dflo_mesh_t *mesh, const dflo_params_t *params, int de
     h->stage_grid = grid_for(h->plan.n_shards);  // one workgroup per shard (per_cu of them resident per CU)
     (void)per_cu;
 #ifdef DFLO_PHASE_TIMING
-    hipMalloc((void **)&h->phase_cycles, (size_t)h->stage_grid * 8 * sizeof(unsigned long long));
-    hipMemset(h->phase_cycles, 0, (size_t)h->stage_grid * 8 * sizeof(unsigned long long));
+    hipMalloc((void **)&h->phase_cycles, (size_t)h->stage_grid * 32 * sizeof(unsigned long long));
+    hipMemset(h->phase_cycles, 0, (size_t)h->stage_grid * 32 * sizeof(unsigned long long));
 #endif
   }
   *out = h;
@@ -1807,7 +1833,7 @@ int dflo_hip_debug_phase_cycles(dflo_hip_handle h, unsigned long long *out, int 
   if (!h || !h->phase_cycles) return 0;
   const int n = std::min(max_groups, h->stage_grid);
   hipStreamSynchronize(h->stream);
-  hipMemcpy(out, h->phase_cycles, (size_t)n * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+  hipMemcpy(out, h->phase_cycles, (size_t)n * 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
   return h->stage_grid;
 }
 

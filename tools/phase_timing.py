@@ -25,15 +25,19 @@ try:
     f = _lib.lib.dflo_hip_debug_phase_cycles
     f.restype = C.c_int
     f.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
-    buf = np.zeros((4096, 8), dtype=np.uint64)
-    g = f(claw._h, buf.ctypes.data_as(C.c_void_p), 4096)
+    nsh = mesh.n_cells // 64 + 8
+    buf = np.zeros((nsh, 4, 8), dtype=np.uint64)
+    g = f(claw._h, buf.ctypes.data_as(C.c_void_p), nsh)
     b = buf[:g].astype(np.float64)
-    n_iter = (mesh.n_cells / 64) / g
-    names = ["top(loads issue)", "A: regs->LDS", "barrier A", "B: fluxes(+prefetch issue)", "barrier B", "C: row update", "barrier C", "reduce/avg"]
-    tot = b.sum(axis=1).mean() / n_iter
-    print("grid %d, %.1f shards per workgroup, last stage launch; cycles per shard iteration: %.0f" % (g, n_iter, tot))
-    for i, n in enumerate(names):
-        print("  %-28s %8.0f  (%4.1f%%)" % (n, b[:, i].mean() / n_iter, 100 * b[:, i].mean() / n_iter / tot))
+    names = ["issue loads", "A: wait loads, regs->LDS", "barrier A", "B: fluxes", "barrier B",
+             "C: row update (incl. its 2 barriers)", "barrier", "reduce / averages"]
+    N = deg + 1
+    print("one workgroup per shard (%d shards), last stage launch; mean cycles per wave (s_memtime ticks)" % g)
+    for w in range(N):
+        tot = b[:, w, :].sum(axis=1).mean()
+        print(" wave %d: total %.0f" % (w, tot))
+        for i, n in enumerate(names):
+            print("    %-40s %8.0f  (%4.1f%%)" % (n, b[:, w, i].mean(), 100 * b[:, w, i].mean() / tot))
 finally:
     os.remove(real)
     os.replace(real + ".keep", real)
