@@ -341,10 +341,83 @@ __device__ __forceinline__ void row_update_q1(const StageArgs &a, const double *
   }
 }
 
+// phase B: one numerical flux per face point of the shard (integrate_face_term_explicit :303-341,
+// integrate_boundary_term_explicit :176-206).  Face-point index p = q * nf + k: neighbouring lanes take
+// neighbouring faces at the same q -> same LDS rows, consecutive slots.  Reads LDS only.
+template <int N, int FLUX, int GEO>
+__device__ __forceinline__ void flux_phase(const StageArgs &a, const double *Us, const double *Th, double *Fh,
+                                           const FaceRec *Fr, const double *Bv, const int *Bk, const double *Fg,
+                                           const int HS, const int nf, const int tid) {
+  constexpr int NS = N * N, NDOF = 4 * NS, NT = 64 * N, S = 65;
+  const int nfp = nf * N;
+  for (int p = tid; p < nfp; p += NT) {
+    const int q = p / nf, k = p - q * nf;
+    const FaceRec r = Fr[k];
+    const int slotL = r.w0 & 0xFFFF, fL = (r.w0 >> 16) & 3;
+    const bool bnd = (r.w0 >> 18) & 1, flip = (r.w0 >> 19) & 1;
+    const int fR = (r.w0 >> 20) & 3;
+    double Wp[4], Wm[4], Ap[4], Am[4], F[4];
+    // trace of a cell on its local face f at face point qq: own cells from their DoFs,
+    // W = sum_m l_m(0|1) U[m,qq] (x faces) or U[qq,m] (y faces); halo cells from the stored trace
+    auto trace = [&](int slot, int f, int qq, double *W, double *A) {
+      if (slot < 64) {
+        // l_m(1) = l_(N-1-m)(0) (Gauss points are symmetric): walk the line of nodes backwards on the
+        // faces at 1 and use the weights l_m(0) throughout -> no per-lane weight selects
+        const int str0 = f < 2 ? 1 : N;
+        const int base = (f < 2 ? N * qq : qq) + ((f & 1) ? (N - 1) * str0 : 0);
+        const int str = (f & 1) ? -str0 : str0;
+        const double *u0 = Us + base * S + slot;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          double v = 0;
+#pragma unroll
+          for (int m = 0; m < N; ++m) v += CB<N>::t.L0[m] * u0[(c * NS + m * str) * S];
+          W[c] = v;
+        }
+        if constexpr (FLUX == DFLO_FLUX_LXF) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) A[c] = Us[(NDOF + c) * S + slot];
+        }
+      } else {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) W[c] = Th[(c * N + qq) * HS + slot - 64];
+        if constexpr (FLUX == DFLO_FLUX_LXF) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) A[c] = Th[(4 * N + c) * HS + slot - 64];
+        }
+      }
+    };
+    trace(slotL, fL, q, Wp, Ap);
+    double nx, ny;  // outward unit normal of the integrating cell
+    if constexpr (GEO == 0) {
+      nx = fL == 0 ? -1.0 : (fL == 1 ? 1.0 : 0.0);
+      ny = fL == 2 ? -1.0 : (fL == 3 ? 1.0 : 0.0);
+    } else {
+      nx = Fg[k];
+      ny = Fg[a.max_faces + k];
+    }
+    if (!bnd) {
+      trace(r.w1, fR, flip ? N - 1 - q : q, Wm, Am);
+    } else {
+      const int bl = (r.w0 >> 20) & 0x3FF;
+      const double *bv = Bv + (bl * N + q) * 4;
+      double bvv[4] = {bv[0], bv[1], bv[2], bv[3]};
+      compute_Wminus(Bk[bl], nx, ny, Wp, bvv, Wm);
+      if constexpr (FLUX == DFLO_FLUX_LXF) {  // both averages are the interior cell's, :200-205
+#pragma unroll
+        for (int c = 0; c < 4; ++c) Am[c] = Ap[c];
+      }
+    }
+    numerical_normal_flux<FLUX>(nx, ny, Wp, Wm, Ap, Am, F);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) Fh[c * a.max_fp + k * N + q] = F[c];
+  }
+}
+
 // One workgroup of N wavefronts per shard.  Occupancy, not software prefetch, hides HBM latency:
 // the kernel is kept under 168 VGPRs and ~40 KB of LDS so that 3 wavefronts per SIMD stay resident
-// (measured on MI355X: a persistent variant that prefetched the next shard into registers ran at 2
-// waves/SIMD and was 25 % slower).  All global loads of a shard are issued at the top, before
+// (measured on MI355X, C2: persistent workgroups that prefetch the next shard into registers need
+// > 168 VGPRs, run at 2 waves/SIMD and reach 112 GDoF/s against 139 GDoF/s for this kernel).  All global loads of a shard are issued at the top, before
 // anything waits.
 //   MODE 0: first stage (ark = 0, u(n) not read)   1: later stages   2: residual only (parity hook)
 //   GEO 0: axis-aligned squares (MappingCartesian)   1: bilinear cells (MappingQ1)
@@ -374,7 +447,7 @@ __global__ __launch_bounds__(64 * N, (GEO == 1 || N == 4) ? 2 : 3) void stage_ke
 #endif
   // ---- all loads of the shard, issued back to back
   const int4 hdr = a.shard_hdr[shard];                // {cells, faces, halo entries, boundary faces}
-  const int nf = hdr.y, nfp = nf * N, nh = hdr.z, nbnd = hdr.w;
+  const int nf = hdr.y, nh = hdr.z, nbnd = hdr.w;
   const bool active = lane < hdr.x;
   double urow[4][N];                                  // node row `row` of the own cells
   {
@@ -470,71 +543,8 @@ __global__ __launch_bounds__(64 * N, (GEO == 1 || N == 4) ? 2 : 3) void stage_ke
   __syncthreads();
   PHASE_MARK(2);
 
-  // ---- phase B: one numerical flux per face point (integrate_face_term_explicit :303-341,
-  //      integrate_boundary_term_explicit :176-206).  Face-point index p = q * nf + k: neighbouring
-  //      lanes take neighbouring faces at the same q -> same LDS rows, consecutive slots.
-  for (int p = tid; p < nfp; p += NT) {
-    const int q = p / nf, k = p - q * nf;
-    const FaceRec r = Fr[k];
-    const int slotL = r.w0 & 0xFFFF, fL = (r.w0 >> 16) & 3;
-    const bool bnd = (r.w0 >> 18) & 1, flip = (r.w0 >> 19) & 1;
-    const int fR = (r.w0 >> 20) & 3;
-    double Wp[4], Wm[4], Ap[4], Am[4], F[4];
-    // trace of a cell on its local face f at face point qq: own cells from their DoFs,
-    // W = sum_m l_m(0|1) U[m,qq] (x faces) or U[qq,m] (y faces); halo cells from the stored trace
-    auto trace = [&](int slot, int f, int qq, double *W, double *A) {
-      if (slot < 64) {
-        // l_m(1) = l_(N-1-m)(0) (Gauss points are symmetric): walk the line of nodes backwards on the
-        // faces at 1 and use the weights l_m(0) throughout -> no per-lane weight selects
-        const int str0 = f < 2 ? 1 : N;
-        const int base = (f < 2 ? N * qq : qq) + ((f & 1) ? (N - 1) * str0 : 0);
-        const int str = (f & 1) ? -str0 : str0;
-        const double *u0 = Us + base * S + slot;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          double v = 0;
-#pragma unroll
-          for (int m = 0; m < N; ++m) v += CB<N>::t.L0[m] * u0[(c * NS + m * str) * S];
-          W[c] = v;
-        }
-        if constexpr (FLUX == DFLO_FLUX_LXF) {
-#pragma unroll
-          for (int c = 0; c < 4; ++c) A[c] = Us[(NDOF + c) * S + slot];
-        }
-      } else {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) W[c] = Th[(c * N + qq) * HS + slot - 64];
-        if constexpr (FLUX == DFLO_FLUX_LXF) {
-#pragma unroll
-          for (int c = 0; c < 4; ++c) A[c] = Th[(4 * N + c) * HS + slot - 64];
-        }
-      }
-    };
-    trace(slotL, fL, q, Wp, Ap);
-    double nx, ny;  // outward unit normal of the integrating cell
-    if constexpr (GEO == 0) {
-      nx = fL == 0 ? -1.0 : (fL == 1 ? 1.0 : 0.0);
-      ny = fL == 2 ? -1.0 : (fL == 3 ? 1.0 : 0.0);
-    } else {
-      nx = Fg[k];
-      ny = Fg[a.max_faces + k];
-    }
-    if (!bnd) {
-      trace(r.w1, fR, flip ? N - 1 - q : q, Wm, Am);
-    } else {
-      const int bl = (r.w0 >> 20) & 0x3FF;
-      const double *bv = Bv + (bl * N + q) * 4;
-      double bvv[4] = {bv[0], bv[1], bv[2], bv[3]};
-      compute_Wminus(Bk[bl], nx, ny, Wp, bvv, Wm);
-      if constexpr (FLUX == DFLO_FLUX_LXF) {  // both averages are the interior cell's, :200-205
-#pragma unroll
-        for (int c = 0; c < 4; ++c) Am[c] = Ap[c];
-      }
-    }
-    numerical_normal_flux<FLUX>(nx, ny, Wp, Wm, Ap, Am, F);
-#pragma unroll
-    for (int c = 0; c < 4; ++c) Fh[c * a.max_fp + k * N + q] = F[c];
-  }
+  // ---- phase B
+  flux_phase<N, FLUX, GEO>(a, Us, Th, Fh, Fr, Bv, Bk, Fg, HS, nf, tid);
   PHASE_MARK(3);
   __syncthreads();
   PHASE_MARK(4);
