@@ -72,7 +72,7 @@ struct StageArgs {
   const double *dt_cell;  // local time stepping: per internal slot, else null
   double *shard_res, *shard_dtmin;
   double dt_host, ark, gravity, cfl, h_uniform;
-  int n_shards, stride, max_fp, max_faces, max_bnd, uniform_h, want_dt, degree;
+  int n_shards, stride, max_fp, max_faces, max_bnd, uniform_h, want_dt, degree, prefetch_ahead;
   KBasis kb;
 };
 
@@ -445,7 +445,25 @@ __global__ __launch_bounds__(64 * N, (GEO == 1 || N == 4) ? 2 : 3) void stage_ke
 #ifdef DFLO_PHASE_TIMING
   unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
 #endif
-  // ---- all loads of the shard, issued back to back
+  // ---- index data of a shard that a later workgroup of this XCD will take: touch it now so that its
+  //      (dependent) index loads hit L2.  Issued first = oldest in the in-order vmcnt queue; the result
+  //      is never used and never waited for.
+  //      The destination registers stay reserved until the loads have landed (see the asm further down):
+  //      a load issued through inline asm writes its register whenever the data arrives.
+  int pf0 = 0, pf1 = 0, pf2 = 0;
+  {
+    const int ahead = min(shard + a.prefetch_ahead, a.n_shards - 1);
+    const int32_t *p0 = a.halo_pad + (size_t)ahead * a.halo_pitch + (tid & 31);
+    const FaceRec *p1 = a.faces_pad + (size_t)ahead * a.face_pitch + tid;
+    const uint16_t *p2 = a.cell_face + (size_t)ahead * 4 * 64 + 2 * (tid & 127);
+    asm volatile("global_load_dword %0, %1, off" : "=v"(pf0) : "v"(p0));
+    asm volatile("global_load_dword %0, %1, off" : "=v"(pf1) : "v"(p1));
+    asm volatile("global_load_dword %0, %1, off" : "=v"(pf2) : "v"(p2));
+  }
+  // ---- all loads of the shard, issued back to back; the halo entries first (the halo values depend on them)
+  int hent[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) hent[t] = a.halo_pad[(size_t)shard * a.halo_pitch + ((tid + t * NT) & 31)];
   const int4 hdr = a.shard_hdr[shard];                // {cells, faces, halo entries, boundary faces}
   const int nf = hdr.y, nh = hdr.z, nbnd = hdr.w;
   const bool active = lane < hdr.x;
@@ -471,7 +489,7 @@ __global__ __launch_bounds__(64 * N, (GEO == 1 || N == 4) ? 2 : 3) void stage_ke
   for (int f = 0; f < 4; ++f) cref[f] = a.cell_face[((size_t)shard * 4 + f) * 64 + lane];
   double h = 0.0, vx[8];
   if constexpr (GEO == 0) {
-    h = a.cell_h[(size_t)shard * 64 + lane];
+    h = a.uniform_h ? a.h_uniform : a.cell_h[(size_t)shard * 64 + lane];
   } else {
 #pragma unroll
     for (int k = 0; k < 8; ++k) vx[k] = a.cell_vert[(size_t)k * a.n_slots + (size_t)shard * 64 + lane];
@@ -492,7 +510,7 @@ __global__ __launch_bounds__(64 * N, (GEO == 1 || N == 4) ? 2 : 3) void stage_ke
   for (int i = tid; i < ((nh + 31) & ~31) * 4 * N; i += NT) {
     const int sl = (i & 31) + ((i >> 5) / (4 * N)) * 32, r = (i >> 5) % (4 * N), q = r % N, c = r / N;
     if (sl >= nh) continue;
-    const int e = a.halo_pad[(size_t)shard * a.halo_pitch + sl];
+    const int e = i == tid ? hent[0] : (i == tid + NT ? hent[1] : a.halo_pad[(size_t)shard * a.halo_pitch + sl]);
     const int ic = e & 0x0FFFFFFF, f = (e >> 28) & 3;
     const double *hp = a.Ucur + ((size_t)(ic >> 6) * NDOF + c * NS) * 64 + (ic & 63);
     const int str0 = f < 2 ? 1 : N;
@@ -513,6 +531,7 @@ __global__ __launch_bounds__(64 * N, (GEO == 1 || N == 4) ? 2 : 3) void stage_ke
   for (int c = 0; c < 4; ++c)
 #pragma unroll
     for (int m = 0; m < N; ++m) Us[(c * NS + m + N * row) * S + lane] = urow[c][m];
+  asm volatile("" ::"v"(pf0), "v"(pf1), "v"(pf2));  // the touch loads (oldest in the queue) have landed by now
   if constexpr (FLUX == DFLO_FLUX_LXF) {
     if (row == 0) {
 #pragma unroll
@@ -1057,7 +1076,7 @@ struct dflo_hip_engine {
   int n_send = 0;
   double *ghost_stage = nullptr;
   size_t lds_bytes = 0;
-  int stage_grid = 8;
+  int stage_grid = 8, prefetch_ahead = 1 << 30;
   unsigned long long *phase_cycles = nullptr;
   int stride = 0, max_fp = 0;
   // timing
@@ -1213,6 +1232,7 @@ int launch_update(dflo_hip_engine *h, int rk, double dt_host, double *rhs_out, i
   a.max_fp = h->max_fp;
   a.max_faces = std::max(h->plan.max_faces, 1);
   a.max_bnd = h->plan.max_bnd;
+  a.prefetch_ahead = h->prefetch_ahead;
   a.uniform_h = p.uniform_h ? 1 : 0;
   a.want_dt = last ? 1 : 0;
   a.degree = h->degree;
@@ -1474,7 +1494,8 @@ int dflo_hip_create(const dflo_mesh_t *mesh, const dflo_params_t *params, int de
       per_cu = 1;
     if (n_cu < 1) n_cu = 256;
     h->stage_grid = grid_for(h->plan.n_shards);  // one workgroup per shard (per_cu of them resident per CU)
-    (void)per_cu;
+    // a workgroup touches the index data of the shard that the same XCD takes ~1.5 residency rounds later
+    h->prefetch_ahead = std::max(8, (per_cu * n_cu / 8) * 3 / 2);
 #ifdef DFLO_PHASE_TIMING
     hipMalloc((void **)&h->phase_cycles, (size_t)h->stage_grid * 32 * sizeof(unsigned long long));
     hipMemset(h->phase_cycles, 0, (size_t)h->stage_grid * 32 * sizeof(unsigned long long));
