@@ -209,3 +209,84 @@ def test_rk_solution_mapped_cells(degree, flux, pos):
         t += dt
     assert abs(t2 - t) < 1e-12 * t
     assert rel(claw.current_solution, ora.get_solution()) < 1e-11
+
+
+# ---------------------------------------------------------------- edge cases and full-size properties
+@pytest.mark.parametrize("nx,ny", [(1, 1), (2, 1), (3, 5), (8, 8), (9, 8), (13, 7), (17, 33)])
+def test_ragged_and_tiny_meshes(nx, ny):
+    """Partial shards, a cell that is its own periodic neighbour, meshes smaller than one shard."""
+    h = 10.0 / max(nx, ny)
+    mesh = dflo_amd.Mesh.cartesian(nx, ny, -5.0, -5.0, h, [-1] * 4, 2)
+    prm = dflo_amd.Parameters(flux="hllc")
+    claw, ora = dflo_amd.ConservationLaw(mesh, prm), oracle_lib.Oracle(mesh, prm)
+    u0 = mesh.interpolate(lambda x, y: problems.smooth_perturbation(x, y, L=10.0))
+    claw.set_initial_condition(u0)
+    ora.set_solution(u0)
+    assert rel(claw.assemble_system(), ora.assemble()) < 1e-12
+    dt = claw.compute_time_step()
+    assert abs(dt - ora.compute_time_step(0.0)) <= 1e-13 * dt
+    claw.iterate_explicit(dt)
+    ora.step(dt)
+    assert rel(claw.current_solution, ora.get_solution()) < 1e-12
+
+
+def test_mixed_boundaries_on_ragged_mesh_with_limiters():
+    bnd = {0: "slip", 1: "outflow", 2: "inflow", 3: "farfield"}
+    mesh = dflo_amd.Mesh.cartesian(19, 11, 0.0, 0.0, 1.0 / 19, [2, 1, 0, 3], 1)
+    prm = dflo_amd.Parameters(flux="lxf", limiter="TVB", char_lim=False, pos_lim=True, M=50.0, beta=1.5, boundary=bnd)
+    claw, ora = dflo_amd.ConservationLaw(mesh, prm), oracle_lib.Oracle(mesh, prm)
+    ic = lambda x, y: problems.smooth_perturbation(x, y, L=1.0)
+    u0 = mesh.interpolate(ic)
+    cell, face, bid, xy = claw.boundary_faces()
+    bv = np.stack(ic(xy[..., 0], xy[..., 1]), axis=-1)
+    for w in (0, 1):
+        claw.set_boundary_values(w, bv)
+        ora.set_boundary_values(w, bv)
+    claw.set_initial_condition(u0)
+    ora.set_solution(u0)
+    t = 0.0
+    for it in range(5):
+        dt = claw.compute_time_step()
+        assert abs(dt - ora.compute_time_step(t)) <= 1e-12 * dt
+        claw.iterate_explicit(dt)
+        ora.step(dt)
+        t += dt
+    assert rel(claw.current_solution, ora.get_solution()) < 1e-9
+
+
+def test_negative_mean_state_is_reported():
+    """'Fatal: Negative states' (src/positivity.cc:26-38) -> DFLO_ERR_NEGATIVE_MEAN_STATE, not an abort."""
+    mesh = dflo_amd.Mesh.cartesian(8, 8, 0.0, 0.0, 0.125, [-1] * 4, 1)
+    claw = dflo_amd.ConservationLaw(mesh, dflo_amd.Parameters(pos_lim=True))
+    u = mesh.interpolate(lambda x, y: problems.smooth_perturbation(x, y, L=1.0)).reshape(mesh.n_cells, 4, 4).copy()
+    u[10, 2, :] = -1.0
+    claw.set_initial_condition(u.reshape(-1))
+    with pytest.raises(dflo_amd.DfloError) as e:
+        claw.apply_positivity_limiter()
+    assert e.value.code == -3
+
+
+def test_full_size_c2_properties():
+    """BASELINE config 2 at full size (1024 x 1024 Q2 HLLC, 37.7 M DoF): size-independent properties --
+    discrete conservation of all four components over RK3 steps on the periodic mesh, a free stream
+    stays a free stream, and re-running from the same state is bit-reproducible."""
+    n = 1024
+    mesh = dflo_amd.Mesh.cartesian(n, n, -5.0, -5.0, 10.0 / n, [-1] * 4, 2)
+    claw = dflo_amd.ConservationLaw(mesh, dflo_amd.Parameters(flux="hllc", cfl=0.9))
+    u0 = mesh.interpolate(problems.isentropic_vortex)
+    claw.set_initial_condition(u0)
+    m0 = claw.cell_average.sum(axis=0)
+    claw.advance(5)
+    m1 = claw.cell_average.sum(axis=0)
+    scale = np.abs(claw.cell_average).sum(axis=0) + 1.0
+    assert np.abs(m1 - m0).max() / scale.max() < 1e-13
+    u5 = claw.current_solution
+    claw.set_initial_condition(u0)
+    claw.advance(5)
+    assert np.array_equal(u5, claw.current_solution)           # deterministic reductions, no atomics
+    o = np.ones(mesh.n_cells * 9)
+    free = np.concatenate([np.stack([0.7 * o, -0.3 * o, 1.1 * o, 2.9 * o], axis=0).reshape(4, mesh.n_cells, 9).transpose(1, 0, 2).reshape(-1)])
+    claw.set_initial_condition(free)
+    assert np.abs(claw.assemble_system()).max() < 1e-9          # h ~ 1e-2: residual entries are O(h) * eps-level sums
+    claw.advance(2)
+    assert np.abs(claw.current_solution - free).max() < 1e-12
