@@ -910,7 +910,7 @@ __global__ void average_kernel(const double *U, double *avg, int ndof, KBasis kb
 // interpolation to the 16 points is sum-factorised (xi first, then eta).
 template <int N>
 __global__ __launch_bounds__(64) void dt_q_kernel(const double *U, const double *cell_h, const int32_t *shard_count,
-                                                  double *shard_dtmin, KBasis kb, double cfl, int degree) {
+                                                  double *shard_dtmin, KBasis kb, double cfl, int degree, double *dt_cell) {
   constexpr int NS = N * N, NDOF = 4 * NS;
   const int shard = blockIdx.x;
   const int lane = threadIdx.x;
@@ -950,13 +950,14 @@ __global__ __launch_bounds__(64) void dt_q_kernel(const double *U, const double 
         maxeig = fmax(maxeig, max_eigenvalue(w));
       }
     dtmin = cfl * cell_h[(size_t)shard * 64 + lane] / maxeig / (2.0 * degree + 1.0);
+    if (dt_cell) dt_cell[(size_t)shard * 64 + lane] = dtmin;
   }
   dtmin = wave_min(dtmin);
   if (lane == 0) shard_dtmin[shard] = dtmin;
 }
 // compute_time_step_cartesian (src/claw.cc:486-511): per-shard minimum from the stored cell averages
 __global__ void dt_kernel(const double *avg, const double *cell_h, double h_uniform, int uniform_h,
-                          const int32_t *shard_count, double *shard_dtmin, double cfl, int degree) {
+                          const int32_t *shard_count, double *shard_dtmin, double cfl, int degree, double *dt_cell) {
   const int shard = blockIdx.x;
   const int lane = threadIdx.x;
   double dtmin = 1.0e20;
@@ -965,6 +966,7 @@ __global__ void dt_kernel(const double *avg, const double *cell_h, double h_unif
     for (int c = 0; c < 4; ++c) A[c] = avg[((size_t)shard * 4 + c) * 64 + lane];
     const double h = uniform_h ? h_uniform : cell_h[(size_t)shard * 64 + lane];
     dtmin = cfl_dt(A, h, cfl, degree);
+    if (dt_cell) dt_cell[(size_t)shard * 64 + lane] = dtmin;  // "time step type = local": dt(c), src/claw.cc:506
   }
   dtmin = wave_min(dtmin);
   if (lane == 0) shard_dtmin[shard] = dtmin;
@@ -975,7 +977,7 @@ struct FinalArgs {
   const double *shard_res, *shard_dtmin;
   double *res_sq;  // [3] per stage
   double *dt_dev;  // [0] dt, [1] elapsed time, [2] raw min before rules
-  int n_shards, stage, do_res, do_dt, advance_time;
+  int n_shards, stage, do_res, do_dt, advance_time, global_rules;
   double time_step, final_time, dt_host;
 };
 __global__ __launch_bounds__(1024) void finalize_kernel(const FinalArgs a) {
@@ -1022,8 +1024,10 @@ __global__ __launch_bounds__(1024) void finalize_kernel(const FinalArgs a) {
       double dt = smin[0];
       for (int i = 1; i < 16; ++i) dt = fmin(dt, smin[i]);
       a.dt_dev[2] = dt;
-      if (dt > 0 && a.time_step > 0) dt = fmin(dt, a.time_step);
-      if (tt + dt > a.final_time) dt = a.final_time - tt;
+      if (a.global_rules) {  // src/claw.cc:469-476, only for "time step type = global"
+        if (dt > 0 && a.time_step > 0) dt = fmin(dt, a.time_step);
+        if (tt + dt > a.final_time) dt = a.final_time - tt;
+      }
       a.dt_dev[0] = dt;
     }
   }
@@ -1066,7 +1070,7 @@ struct dflo_hip_engine {
   int face_pitch = 0, halo_pitch = 0, halo_stride = 0;
   uint16_t *d_cell_face = nullptr;
   int32_t *d_lrbt = nullptr, *d_user_of = nullptr, *d_iid = nullptr;
-  double *d_cell_h = nullptr, *d_cell_vert = nullptr, *d_fgeom_pad = nullptr;
+  double *d_cell_h = nullptr, *d_cell_vert = nullptr, *d_fgeom_pad = nullptr, *d_dt_cell = nullptr;
   double *shard_res = nullptr, *shard_dtmin = nullptr, *res_sq = nullptr, *dt_dev = nullptr;
   int *flags = nullptr;
   std::vector<double> bface_xy;  // [n_bfaces][N][2]
@@ -1219,7 +1223,7 @@ int launch_update(dflo_hip_engine *h, int rk, double dt_host, double *rhs_out, i
   a.bval = h->bval[which];
   a.bface_kind = h->bface_kind;
   a.dt_dev = h->dt_dev;
-  a.dt_cell = nullptr;
+  a.dt_cell = h->d_dt_cell;  // null unless "time step type = local"
   a.shard_res = h->shard_res;
   a.shard_dtmin = h->shard_dtmin;
   a.dt_host = dt_host;
@@ -1291,6 +1295,10 @@ int launch_limit_finalize(dflo_hip_engine *h) {
   if (last && h->geo == 1) {  // bilinear cells: dt from the point values of the (limited) new solution
     launch_dt_q(h);
     HIPCHK(h, hipGetLastError());
+  } else if (last && h->d_dt_cell) {  // local time stepping: the per-cell dt of the next step
+    hipLaunchKernelGGL(dt_kernel, dim3(p.n_shards), dim3(64), 0, h->stream, h->avg[h->avg_cur], h->d_cell_h, p.h,
+                       p.uniform_h ? 1 : 0, h->d_shard_count, h->shard_dtmin, h->prm.cfl, h->degree, h->d_dt_cell);
+    HIPCHK(h, hipGetLastError());
   }
   FinalArgs f{};
   f.shard_res = h->shard_res;
@@ -1305,6 +1313,7 @@ int launch_limit_finalize(dflo_hip_engine *h) {
   f.dt_host = h->pending_dt;
   f.time_step = h->prm.time_step;
   f.final_time = h->prm.final_time;
+  f.global_rules = h->prm.global_time_step;
   hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(1024), 0, h->stream, f);
   HIPCHK(h, hipGetLastError());
   h->pending_rk = -1;
@@ -1321,7 +1330,7 @@ void launch_dt_q(dflo_hip_engine *h) {
   const Plan &p = h->plan;
   auto fn = h->N == 2 ? dt_q_kernel<2> : (h->N == 3 ? dt_q_kernel<3> : dt_q_kernel<4>);
   hipLaunchKernelGGL(fn, dim3(p.n_shards), dim3(64), 0, h->stream, (const double *)h->U[h->cur], (const double *)h->d_cell_h,
-                     (const int32_t *)h->d_shard_count, h->shard_dtmin, h->kb, h->prm.cfl, h->degree);
+                     (const int32_t *)h->d_shard_count, h->shard_dtmin, h->kb, h->prm.cfl, h->degree, h->d_dt_cell);
 }
 
 int launch_average(dflo_hip_engine *h) {
@@ -1353,7 +1362,7 @@ int dflo_hip_create(const dflo_mesh_t *mesh, const dflo_params_t *params, int de
     return DFLO_ERR_BAD_PARAM;
   }
   if (params->flux_type < 0 || params->flux_type > DFLO_FLUX_HLLC) { g_create_error = "unknown flux"; return DFLO_ERR_BAD_PARAM; }
-  if (!params->global_time_step) { g_create_error = "local time stepping is not implemented in the device engine yet"; return DFLO_ERR_UNSUPPORTED; }
+
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) {
     g_create_error = "no HIP device available: the dflo HIP engine has no CPU fallback";
@@ -1452,6 +1461,10 @@ int dflo_hip_create(const dflo_mesh_t *mesh, const dflo_params_t *params, int de
   if ((rc = upload(h, &h->d_user_of, p.user_of))) return bail(rc);
   if ((rc = upload(h, &h->d_iid, p.iid))) return bail(rc);
   if ((rc = upload(h, &h->d_cell_h, p.cell_h))) return bail(rc);
+  if (!params->global_time_step) {  // per-cell time steps, src/claw.cc:453,506
+    std::vector<double> z((size_t)p.n_slots + 128, 0.0);
+    if ((rc = upload(h, &h->d_dt_cell, z))) return bail(rc);
+  }
   if (h->geo == 1) {
     if ((rc = upload(h, &h->d_cell_vert, p.cell_vert))) return bail(rc);
   }
@@ -1514,7 +1527,7 @@ int dflo_hip_destroy(dflo_hip_handle h) {
   hipFree(h->rhs); hipFree(h->user_buf); hipFree(h->bface_kind);
   hipFree(h->d_shard_count); hipFree(h->d_halo_begin); hipFree(h->d_halo_cells); hipFree(h->d_face_begin);
   hipFree(h->d_faces); hipFree(h->d_faces_pad); hipFree(h->d_shard_hdr); hipFree(h->d_halo_pad); hipFree(h->d_cell_face); hipFree(h->d_lrbt); hipFree(h->d_user_of); hipFree(h->d_iid);
-  hipFree(h->d_cell_h); hipFree(h->d_cell_vert); hipFree(h->d_fgeom_pad); hipFree(h->shard_res); hipFree(h->shard_dtmin); hipFree(h->res_sq); hipFree(h->dt_dev);
+  hipFree(h->d_cell_h); hipFree(h->d_dt_cell); hipFree(h->d_cell_vert); hipFree(h->d_fgeom_pad); hipFree(h->shard_res); hipFree(h->shard_dtmin); hipFree(h->res_sq); hipFree(h->dt_dev);
   hipFree(h->flags); hipFree(h->d_send_slots); hipFree(h->ghost_stage);
   for (auto &e : h->ev_pool) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
   if (h->own_stream) hipStreamDestroy(h->own_stream);
@@ -1631,7 +1644,7 @@ int dflo_hip_compute_dt(dflo_hip_handle h, double elapsed_time, double *dt) {
   const Plan &p = h->plan;
   if (h->geo == 0)
     hipLaunchKernelGGL(dt_kernel, dim3(p.n_shards), dim3(64), 0, h->stream, h->avg[h->avg_cur], h->d_cell_h, p.h,
-                       p.uniform_h ? 1 : 0, h->d_shard_count, h->shard_dtmin, h->prm.cfl, h->degree);
+                       p.uniform_h ? 1 : 0, h->d_shard_count, h->shard_dtmin, h->prm.cfl, h->degree, h->d_dt_cell);
   else
     launch_dt_q(h);
   HIPCHK(h, hipGetLastError());
@@ -1650,6 +1663,7 @@ int dflo_hip_compute_dt(dflo_hip_handle h, double elapsed_time, double *dt) {
   f.dt_host = -1.0;
   f.time_step = h->prm.time_step;
   f.final_time = h->prm.final_time;
+  f.global_rules = h->prm.global_time_step;
   hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(1024), 0, h->stream, f);
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipMemcpyAsync(tt, h->dt_dev, sizeof(tt), hipMemcpyDeviceToHost, h->stream));

@@ -290,3 +290,25 @@ def test_full_size_c2_properties():
     assert np.abs(claw.assemble_system()).max() < 1e-9          # h ~ 1e-2: residual entries are O(h) * eps-level sums
     claw.advance(2)
     assert np.abs(claw.current_solution - free).max() < 1e-12
+
+
+def test_gravity_source_and_local_time_stepping():
+    """Forcing term (src/equation.h:831-850, src/assemble_explicit.cc:108-111) and
+    "time step type = local" (per-cell dt in solve(), src/claw.cc:506,708)."""
+    bnd = {0: "slip"}
+    mesh = dflo_amd.Mesh.cartesian(12, 10, 0.0, 0.0, 0.1, [0, 0, 0, 0], 2)
+    prm = dflo_amd.Parameters(flux="roe", gravity=0.7, boundary=bnd, time_step_type="local", cfl=0.6)
+    claw, ora = dflo_amd.ConservationLaw(mesh, prm), oracle_lib.Oracle(mesh, prm)
+    u0 = mesh.interpolate(lambda x, y: problems.smooth_perturbation(x, y, L=1.2))
+    claw.set_initial_condition(u0)
+    ora.set_solution(u0)
+    assert rel(claw.assemble_system(), ora.assemble()) < 1e-12
+    t = 0.0
+    for it in range(4):
+        dt = claw.compute_time_step()
+        dto = ora.compute_time_step(t)          # also fills the oracle's per-cell dt
+        assert abs(dt - dto) <= 1e-13 * dto
+        claw.iterate_explicit(dt)
+        ora.step(-1.0)                            # keep the per-cell time steps
+        t += dt
+    assert rel(claw.current_solution, ora.get_solution()) < 1e-11
