@@ -23,6 +23,7 @@ vals = defaultdict(lambda: defaultdict(list))
 for f in glob.glob(os.path.join(root, "*", "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
         vals[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+traffic = {}
 print("== PMC (mean per dispatch)")
 for k in sorted(vals):
     print(k)
@@ -40,5 +41,12 @@ for k in sorted(vals):
         print("   wave-cycle split: wait_any %.1f%%  wait_inst_any %.1f%%  active_inst_any %.1f%%  active_valu %.1f%%" % (
             100 * c["SQ_WAIT_ANY"] / wc, 100 * c.get("SQ_WAIT_INST_ANY", 0) / wc, 100 * c.get("SQ_ACTIVE_INST_ANY", 0) / wc,
             100 * c.get("SQ_ACTIVE_INST_VALU", 0) / wc))
+    if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+        traffic.setdefault(k, {})["hbm_bytes_per_launch"] = 2 * c["FETCH_SIZE"] * 1024 + c["WRITE_SIZE"] * 1024
+        traffic[k]["fetch_kib_raw"] = c["FETCH_SIZE"]
+        traffic[k]["write_kib"] = c["WRITE_SIZE"]
     if "TCC_HIT_sum" in c:
         print("   L2 hit rate %.1f%%" % (100 * c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"])))
+
+import json
+json.dump(traffic, open(os.path.join(root, "traffic.json"), "w"), indent=1)
