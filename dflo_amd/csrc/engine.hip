@@ -73,6 +73,8 @@ struct StageArgs {
   double *shard_res, *shard_dtmin;
   double dt_host, ark, gravity, cfl, h_uniform;
   int n_shards, stride, max_fp, max_faces, max_bnd, uniform_h, want_dt, degree, prefetch_ahead;
+  const int32_t *shard_list;  // null: all shards; else the n_list shards of this launch (rim / interior)
+  int n_list;
   KBasis kb;
 };
 
@@ -428,8 +430,9 @@ __global__ __launch_bounds__(64 * N, (GEO == 1 || N == 4) ? 2 : 3) void stage_ke
   constexpr int TROWS = 4 * N + (FLUX == DFLO_FLUX_LXF ? 4 : 0); // halo image: face trace (+ averages)
   constexpr int S = 65;                                          // own-cell row stride: 1 mod 32 doubles
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  const int shard = shard_of_block(blockIdx.x, a.n_shards);
-  if (shard < 0) return;
+  const int sidx = shard_of_block(blockIdx.x, a.n_list);
+  if (sidx < 0) return;
+  const int shard = a.shard_list ? a.shard_list[sidx] : sidx;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int row = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -642,6 +645,8 @@ struct LimArgs {
   int *flags;  // [0] negative mean state, [1] positivity root failure
   double h_uniform, M, beta;
   int n_shards, uniform_h, tvb, char_lim, pos_lim;
+  const int32_t *shard_list;
+  int n_list;
   KBasis kb;
 };
 
@@ -650,8 +655,9 @@ struct LimArgs {
 template <int N>
 __global__ __launch_bounds__(64) void limiter_kernel(const LimArgs a) {
   constexpr int NS = N * N, NDOF = 4 * NS;
-  const int shard = shard_of_block(blockIdx.x, a.n_shards);
-  if (shard < 0) return;
+  const int sidx = shard_of_block(blockIdx.x, a.n_list);
+  if (sidx < 0) return;
+  const int shard = a.shard_list ? a.shard_list[sidx] : sidx;
   const int lane = threadIdx.x;
   if (lane >= a.shard_count[shard]) return;
   const KBasis &kb = a.kb;
@@ -1075,6 +1081,12 @@ struct dflo_hip_engine {
   int *flags = nullptr;
   std::vector<double> bface_xy;  // [n_bfaces][N][2]
   int pending_rk = -1;
+  int st_in = 0, st_old = 0, st_out = 0, st_avg_in = 0, st_rk = 0, st_which = 0;
+  double st_dt = -1.0;
+  int64_t t_stages = 0;
+  int32_t *d_rim_list = nullptr, *d_int_list = nullptr;
+  hipEvent_t ev_rim = nullptr, ev_unpack = nullptr;
+  bool unpack_pending = false;
   double pending_dt = -1.0;
   int32_t *d_send_slots = nullptr;
   int n_send = 0;
@@ -1187,21 +1199,45 @@ void time_collect(dflo_hip_engine *h) {
   h->ev_used = 0;
 }
 
-// residual + update kernel of one RK stage
-int launch_update(dflo_hip_engine *h, int rk, double dt_host, double *rhs_out, int which_override) {
-  const Plan &p = h->plan;
+// ---- one RK stage on the host side.  A stage is opened once (buffer roles are fixed), its update and
+// limiter kernels may then be launched for all shards or separately for the rim shards (those that read
+// ghost cells) and the interior shards, and it is finished by the reductions.
+int open_stage(dflo_hip_engine *h, int rk, double dt_host, bool residual_only, int which_override) {
   const bool last = rk == h->n_rk - 1;
   int out;
-  if (rhs_out) out = h->cur;
+  if (residual_only) out = h->cur;
   else if (last && h->cur != h->old) out = h->old;
   else { out = 0; while (out == h->cur || out == h->old) ++out; }
+  h->st_in = h->cur;
+  h->st_old = h->old;
+  h->st_out = out;
+  h->st_avg_in = h->avg_cur;
+  h->st_rk = rk;
+  h->st_dt = dt_host;
+  h->st_which = which_override >= 0 ? which_override : (rk == 0 ? 0 : 1);
+  if (!residual_only) {
+    h->cur = out;
+    h->avg_cur = 1 - h->avg_cur;
+    if (last) h->old = out;
+    h->pending_rk = rk;
+    h->pending_dt = dt_host;
+    ++h->t_stages;
+  }
+  return DFLO_OK;
+}
+
+// residual + update kernel of the open stage; part 0: all shards, 1: rim shards, 2: interior shards
+int launch_update(dflo_hip_engine *h, double *rhs_out, int part) {
+  const Plan &p = h->plan;
+  const int rk = h->st_rk;
+  const bool last = rk == h->n_rk - 1;
   StageArgs a{};
   a.phase_cycles = h->phase_cycles;
-  a.Ucur = h->U[h->cur];
-  a.Uold = h->U[h->old];
-  a.Unew = h->U[out];
-  a.avg_cur = h->avg[h->avg_cur];
-  a.avg_new = h->avg[1 - h->avg_cur];
+  a.Ucur = h->U[h->st_in];
+  a.Uold = h->U[h->st_old];
+  a.Unew = h->U[h->st_out];
+  a.avg_cur = h->avg[h->st_avg_in];
+  a.avg_new = h->avg[1 - h->st_avg_in];
   a.rhs_out = rhs_out;
   a.shard_count = h->d_shard_count;
   a.halo_begin = h->d_halo_begin;
@@ -1219,14 +1255,13 @@ int launch_update(dflo_hip_engine *h, int rk, double dt_host, double *rhs_out, i
   a.cell_vert = h->d_cell_vert;
   a.fgeom_pad = h->d_fgeom_pad;
   a.n_slots = p.n_slots;
-  const int which = which_override >= 0 ? which_override : (rk == 0 ? 0 : 1);
-  a.bval = h->bval[which];
+  a.bval = h->bval[h->st_which];
   a.bface_kind = h->bface_kind;
   a.dt_dev = h->dt_dev;
   a.dt_cell = h->d_dt_cell;  // null unless "time step type = local"
   a.shard_res = h->shard_res;
   a.shard_dtmin = h->shard_dtmin;
-  a.dt_host = dt_host;
+  a.dt_host = h->st_dt;
   a.ark = h->ark[rk];
   a.gravity = h->prm.gravity;
   a.cfl = h->prm.cfl;
@@ -1241,23 +1276,18 @@ int launch_update(dflo_hip_engine *h, int rk, double dt_host, double *rhs_out, i
   a.want_dt = last ? 1 : 0;
   a.degree = h->degree;
   a.kb = h->kb;
+  a.shard_list = part == 1 ? h->d_rim_list : (part == 2 ? h->d_int_list : nullptr);
+  a.n_list = part == 1 ? (int)p.rim_shards.size() : (part == 2 ? (int)p.interior_shards.size() : p.n_shards);
+  if (a.n_list == 0) return DFLO_OK;
   stage_fn fn = pick_stage(h->N, h->prm.flux_type, rhs_out ? 2 : (h->ark[rk] != 0.0 ? 1 : 0), h->geo);
   time_begin(h);
-  hipLaunchKernelGGL(fn, dim3(h->stage_grid), dim3(64 * h->N), h->lds_bytes, h->stream, a);
+  hipLaunchKernelGGL(fn, dim3(grid_for(a.n_list)), dim3(64 * h->N), h->lds_bytes, h->stream, a);
   time_end(h);
   HIPCHK(h, hipGetLastError());
-  if (rhs_out) return DFLO_OK;
-  // ghost cells are not advanced here: carry them over so the new buffers stay consistent until
-  // the transport refreshes them
-  h->cur = out;
-  h->avg_cur = 1 - h->avg_cur;
-  if (last) h->old = out;
-  h->pending_rk = rk;
-  h->pending_dt = dt_host;
   return DFLO_OK;
 }
 
-int launch_limiter(dflo_hip_engine *h, int tvb, int pos) {
+int launch_limiter(dflo_hip_engine *h, int tvb, int pos, int part) {
   const Plan &p = h->plan;
   LimArgs l{};
   l.U = h->U[h->cur];
@@ -1275,23 +1305,29 @@ int launch_limiter(dflo_hip_engine *h, int tvb, int pos) {
   l.char_lim = h->prm.char_lim;
   l.pos_lim = pos;
   l.kb = h->kb;
+  l.shard_list = part == 1 ? h->d_rim_list : (part == 2 ? h->d_int_list : nullptr);
+  l.n_list = part == 1 ? (int)p.rim_shards.size() : (part == 2 ? (int)p.interior_shards.size() : p.n_shards);
+  if (l.n_list == 0) return DFLO_OK;
   void (*lf)(const LimArgs) = h->N == 2 ? limiter_kernel<2> : (h->N == 3 ? limiter_kernel<3> : limiter_kernel<4>);
-  hipLaunchKernelGGL(lf, dim3(grid_for(p.n_shards)), dim3(64), 0, h->stream, l);
+  hipLaunchKernelGGL(lf, dim3(grid_for(l.n_list)), dim3(64), 0, h->stream, l);
   HIPCHK(h, hipGetLastError());
   return DFLO_OK;
 }
 
-// limiter + reductions of the stage launched last
-int launch_limit_finalize(dflo_hip_engine *h) {
+// limiter of the open stage on one part of the shards
+int launch_stage_limiter(dflo_hip_engine *h, int part) {
+  if (h->pending_rk < 0) { h->err = "no stage pending"; return DFLO_ERR_BAD_PARAM; }
+  const bool limited = h->prm.limiter_type != DFLO_LIMITER_NONE || h->prm.pos_lim;
+  if (!limited) return DFLO_OK;
+  return launch_limiter(h, h->prm.limiter_type == DFLO_LIMITER_TVB, h->prm.pos_lim, part);
+}
+
+// reductions of the stage launched last
+int launch_finish(dflo_hip_engine *h) {
   const Plan &p = h->plan;
   const int rk = h->pending_rk;
   if (rk < 0) { h->err = "no stage pending"; return DFLO_ERR_BAD_PARAM; }
   const bool last = rk == h->n_rk - 1;
-  const bool limited = h->prm.limiter_type != DFLO_LIMITER_NONE || h->prm.pos_lim;
-  if (limited) {
-    int rc = launch_limiter(h, h->prm.limiter_type == DFLO_LIMITER_TVB, h->prm.pos_lim);
-    if (rc) return rc;
-  }
   if (last && h->geo == 1) {  // bilinear cells: dt from the point values of the (limited) new solution
     launch_dt_q(h);
     HIPCHK(h, hipGetLastError());
@@ -1320,8 +1356,16 @@ int launch_limit_finalize(dflo_hip_engine *h) {
   return DFLO_OK;
 }
 
+int launch_limit_finalize(dflo_hip_engine *h) {
+  int rc = launch_stage_limiter(h, 0);
+  if (rc) return rc;
+  return launch_finish(h);
+}
+
 int launch_stage(dflo_hip_engine *h, int rk, double dt_host, double *rhs_out, int which_override) {
-  int rc = launch_update(h, rk, dt_host, rhs_out, which_override);
+  int rc = open_stage(h, rk, dt_host, rhs_out != nullptr, which_override);
+  if (rc) return rc;
+  rc = launch_update(h, rhs_out, 0);
   if (rc || rhs_out) return rc;
   return launch_limit_finalize(h);
 }
@@ -1458,6 +1502,8 @@ int dflo_hip_create(const dflo_mesh_t *mesh, const dflo_params_t *params, int de
     }
   }
   if ((rc = upload(h, &h->d_lrbt, p.lrbt))) return bail(rc);
+  if ((rc = upload(h, &h->d_rim_list, p.rim_shards))) return bail(rc);
+  if ((rc = upload(h, &h->d_int_list, p.interior_shards))) return bail(rc);
   if ((rc = upload(h, &h->d_user_of, p.user_of))) return bail(rc);
   if ((rc = upload(h, &h->d_iid, p.iid))) return bail(rc);
   if ((rc = upload(h, &h->d_cell_h, p.cell_h))) return bail(rc);
@@ -1527,9 +1573,11 @@ int dflo_hip_destroy(dflo_hip_handle h) {
   hipFree(h->rhs); hipFree(h->user_buf); hipFree(h->bface_kind);
   hipFree(h->d_shard_count); hipFree(h->d_halo_begin); hipFree(h->d_halo_cells); hipFree(h->d_face_begin);
   hipFree(h->d_faces); hipFree(h->d_faces_pad); hipFree(h->d_shard_hdr); hipFree(h->d_halo_pad); hipFree(h->d_cell_face); hipFree(h->d_lrbt); hipFree(h->d_user_of); hipFree(h->d_iid);
+  hipFree(h->d_rim_list); hipFree(h->d_int_list);
   hipFree(h->d_cell_h); hipFree(h->d_dt_cell); hipFree(h->d_cell_vert); hipFree(h->d_fgeom_pad); hipFree(h->shard_res); hipFree(h->shard_dtmin); hipFree(h->res_sq); hipFree(h->dt_dev);
   hipFree(h->flags); hipFree(h->d_send_slots); hipFree(h->ghost_stage);
   for (auto &e : h->ev_pool) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
+  if (h->ev_rim) { hipEventDestroy(h->ev_rim); hipEventDestroy(h->ev_unpack); }
   if (h->own_stream) hipStreamDestroy(h->own_stream);
   delete h;
   return DFLO_OK;
@@ -1732,13 +1780,13 @@ int dflo_hip_apply_limiter(dflo_hip_handle h) {
   if (check_handle(h)) return DFLO_ERR_BAD_PARAM;
   hipSetDevice(h->device);
   if (h->prm.limiter_type == DFLO_LIMITER_NONE) return DFLO_OK;
-  return launch_limiter(h, 1, 0);
+  return launch_limiter(h, 1, 0, 0);
 }
 
 int dflo_hip_apply_positivity_limiter(dflo_hip_handle h) {
   if (check_handle(h)) return DFLO_ERR_BAD_PARAM;
   hipSetDevice(h->device);
-  int rc = launch_limiter(h, 0, 1);
+  int rc = launch_limiter(h, 0, 1, 0);
   if (rc) return rc;
   return dflo_hip_check(h);
 }
@@ -1746,7 +1794,115 @@ int dflo_hip_apply_positivity_limiter(dflo_hip_handle h) {
 int dflo_hip_stage_update(dflo_hip_handle h, int rk, double dt) {
   if (check_handle(h) || rk < 0 || rk >= h->n_rk) return DFLO_ERR_BAD_PARAM;
   hipSetDevice(h->device);
-  return launch_update(h, rk, dt, nullptr, -1);
+  int rc = open_stage(h, rk, dt, false, -1);
+  if (rc) return rc;
+  return launch_update(h, nullptr, 0);
+}
+
+int dflo_hip_stage_open(dflo_hip_handle h, int rk, double dt) {
+  if (check_handle(h) || rk < 0 || rk >= h->n_rk) return DFLO_ERR_BAD_PARAM;
+  return open_stage(h, rk, dt, false, -1);
+}
+
+int dflo_hip_stage_update_part(dflo_hip_handle h, int part) {
+  if (check_handle(h) || part < 0 || part > 2 || h->pending_rk < 0) return DFLO_ERR_BAD_PARAM;
+  hipSetDevice(h->device);
+  return launch_update(h, nullptr, part);
+}
+
+int dflo_hip_stage_limit_part(dflo_hip_handle h, int part) {
+  if (check_handle(h) || part < 0 || part > 2) return DFLO_ERR_BAD_PARAM;
+  hipSetDevice(h->device);
+  return launch_stage_limiter(h, part);
+}
+
+int dflo_hip_stage_finish(dflo_hip_handle h) {
+  if (check_handle(h)) return DFLO_ERR_BAD_PARAM;
+  hipSetDevice(h->device);
+  return launch_finish(h);
+}
+
+int dflo_hip_n_rim_shards(dflo_hip_handle h) { return h ? (int)h->plan.rim_shards.size() : 0; }
+
+// ---- the overlapped stage as four host calls (main stream = compute, comm stream = halo traffic):
+//   stage_rim      main: wait for the previous unpack, open the stage, advance the rim shards
+//   stage_rim_send comm: wait for the rim shards, (TVB: receive averages,) limit them, pack
+//   stage_rim_recv comm: unpack what the transport delivered
+//   stage_interior main: interior shards, their limiter, reductions
+static int ensure_events(dflo_hip_engine *h) {
+  if (h->ev_rim) return DFLO_OK;
+  HIPCHK(h, hipEventCreateWithFlags(&h->ev_rim, hipEventDisableTiming));
+  HIPCHK(h, hipEventCreateWithFlags(&h->ev_unpack, hipEventDisableTiming));
+  return DFLO_OK;
+}
+
+int dflo_hip_stage_rim(dflo_hip_handle h, int rk, double dt, void *main_stream) {
+  if (check_handle(h) || rk < 0 || rk >= h->n_rk) return DFLO_ERR_BAD_PARAM;
+  hipSetDevice(h->device);
+  int rc = ensure_events(h);
+  if (rc) return rc;
+  h->stream = main_stream ? (hipStream_t)main_stream : h->own_stream;
+  if (h->unpack_pending) HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_unpack, 0));
+  rc = open_stage(h, rk, dt, false, -1);
+  if (rc) return rc;
+  rc = launch_update(h, nullptr, 1);
+  if (rc) return rc;
+  HIPCHK(h, hipEventRecord(h->ev_rim, h->stream));
+  return DFLO_OK;
+}
+
+// what = 0: limit the rim shards and pack their DoFs; 1: pack the cell averages (TVB, before the limiter);
+// 2: unpack received averages (TVB), then limit and pack the DoFs
+int dflo_hip_stage_rim_send(dflo_hip_handle h, void *comm_stream, int what, const void *avg_recv, void *send_buffer) {
+  if (check_handle(h) || !comm_stream) return DFLO_ERR_BAD_PARAM;
+  hipSetDevice(h->device);
+  hipStream_t main = h->stream;
+  h->stream = (hipStream_t)comm_stream;
+  int rc = DFLO_OK;
+  if (what != 2) HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_rim, 0));
+  if (what == 1) {
+    rc = dflo_hip_pack_send_avg(h, send_buffer);
+  } else {
+    if (what == 2) rc = dflo_hip_unpack_ghost_avg(h, avg_recv);
+    if (!rc) rc = launch_stage_limiter(h, 1);
+    if (!rc) rc = dflo_hip_pack_send(h, send_buffer);
+  }
+  h->stream = main;
+  return rc;
+}
+
+int dflo_hip_stage_rim_recv(dflo_hip_handle h, void *comm_stream, const void *recv_buffer) {
+  if (check_handle(h) || !comm_stream) return DFLO_ERR_BAD_PARAM;
+  hipSetDevice(h->device);
+  hipStream_t main = h->stream;
+  h->stream = (hipStream_t)comm_stream;
+  int rc = dflo_hip_unpack_ghost(h, recv_buffer);
+  if (!rc) {
+    if (hipEventRecord(h->ev_unpack, h->stream) != hipSuccess) rc = DFLO_ERR_HIP;
+    h->unpack_pending = true;
+  }
+  h->stream = main;
+  return rc;
+}
+
+int dflo_hip_stage_interior(dflo_hip_handle h) {
+  if (check_handle(h)) return DFLO_ERR_BAD_PARAM;
+  hipSetDevice(h->device);
+  int rc = launch_update(h, nullptr, 2);
+  if (!rc) rc = launch_stage_limiter(h, 2);
+  if (!rc) rc = launch_finish(h);
+  return rc;
+}
+
+// main stream waits for the last unpack (before the state is read or a non-overlapped call follows)
+int dflo_hip_stage_join(dflo_hip_handle h) {
+  if (check_handle(h)) return DFLO_ERR_BAD_PARAM;
+  hipSetDevice(h->device);
+  if (h->unpack_pending) {
+    HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_unpack, 0));
+    h->unpack_pending = false;
+  }
+  return DFLO_OK;
 }
 
 int dflo_hip_stage_limit(dflo_hip_handle h) {
@@ -1778,10 +1934,12 @@ int dflo_hip_stage_timing(dflo_hip_handle h, int enable, double *avg_ms, int64_t
   hipSetDevice(h->device);
   hipStreamSynchronize(h->stream);
   time_collect(h);
-  if (avg_ms) *avg_ms = h->t_count ? h->t_accum_ms / (double)h->t_count : 0.0;
-  if (n) *n = h->t_count;
+  // a stage may have been launched in two parts (rim + interior): the average is per stage
+  if (avg_ms) *avg_ms = h->t_stages ? h->t_accum_ms / (double)h->t_stages : 0.0;
+  if (n) *n = h->t_stages;
   h->t_accum_ms = 0;
   h->t_count = 0;
+  h->t_stages = 0;
   h->timing = enable != 0;
   return DFLO_OK;
 }

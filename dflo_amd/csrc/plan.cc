@@ -223,6 +223,9 @@ int build_plan(const dflo_mesh_t &mesh, int shard_ex, int shard_ey, Plan &p, std
     p.max_halo = std::max(p.max_halo, p.halo_begin[s + 1] - p.halo_begin[s]);
     p.max_faces = std::max(p.max_faces, p.face_begin[s + 1] - p.face_begin[s]);
     p.max_bnd = std::max(p.max_bnd, p.shard_bnd[s]);
+    bool reads_ghost = false;
+    for (int k = p.halo_begin[s]; k < p.halo_begin[s + 1]; ++k) reads_ghost |= p.halo_cells[k] >= p.n_shards * kShard;
+    (reads_ghost ? p.rim_shards : p.interior_shards).push_back(s);
   }
 
   // ---- geometry in internal order

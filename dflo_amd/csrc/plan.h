@@ -55,6 +55,8 @@ struct Plan {
   std::vector<int32_t> lrbt;         // [n_shards][4][kShard] internal slot of the left/right/bottom/top
                                      // neighbour or -1 (src/claw.cc:336-380)
   std::vector<int32_t> shard_bnd;    // boundary faces per shard
+  std::vector<int32_t> rim_shards;   // owned shards that read ghost cells (multi-device: computed first, then
+  std::vector<int32_t> interior_shards;  // their cells are exchanged while the interior shards are computed)
   int max_halo = 0, max_faces = 0, max_bnd = 0;
   // boundary faces in MeshWorker order (cell ascending, face ascending)
   std::vector<int32_t> bface_cell, bface_face, bface_id;

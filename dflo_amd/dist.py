@@ -93,7 +93,14 @@ class DistributedConservationLaw:
         torch.cuda.set_device(self.device)
         self.claw = ConservationLaw(self.mesh, parameters, device=device_index)
         # run the engine on torch's current stream so that RCCL ops and kernels are ordered
-        self.claw.set_stream(torch.cuda.current_stream().cuda_stream)
+        self.main_stream = torch.cuda.current_stream()
+        self.claw.set_stream(self.main_stream.cuda_stream)
+        # second stream for the halo traffic: the rim shards are advanced first, their cells travel while the
+        # interior shards are computed (DFLO_OVERLAP=0 switches back to the serial order)
+        import os
+        self.overlap = os.environ.get("DFLO_OVERLAP", "1") != "0"
+        self.comm_stream = torch.cuda.Stream(device=self.device)
+
         send_cells, so, ro = self.mesh.comm
         self.halo = HaloExchange(so, ro, self.device)
         sc = np.ascontiguousarray(send_cells, dtype=np.int32)
@@ -122,6 +129,7 @@ class DistributedConservationLaw:
         return np.ascontiguousarray(np.asarray(u_global).reshape(self.global_mesh.n_cells, self.ndof)[gid]).reshape(-1)
 
     def set_initial_condition(self, u_global):
+        self._join()
         self.claw.set_initial_condition(self.owned_slice_of_global(u_global))
 
     def exchange_solution(self):
@@ -144,14 +152,40 @@ class DistributedConservationLaw:
         dist.all_reduce(t, op=dist.ReduceOp.MIN)  # Utilities::MPI::min, src_mpi/claw.cc:579
         return float(t.item())
 
-    def iterate_explicit(self, dt):
+    def _stage(self, rk, dt):
+        """One RK stage with its halo exchange(s)."""
         c = self.claw
-        for rk in range(self.n_rk):
+        if not self.overlap:
             c._chk(lib.dflo_hip_stage_update(c._h, rk, dt))
             if self.tvb:
                 self.exchange_averages()
             c._chk(lib.dflo_hip_stage_limit(c._h))
             self.exchange_solution()
+            return
+        main, comm = self.main_stream, self.comm_stream
+        mainp, commp = C.c_void_p(main.cuda_stream), C.c_void_p(comm.cuda_stream)
+        c._chk(lib.dflo_hip_stage_rim(c._h, rk, dt, mainp))                      # rim shards on the main stream
+        with torch.cuda.stream(comm):
+            if self.tvb:   # the limiter of the rim cells needs the neighbours' fresh means first
+                c._chk(lib.dflo_hip_stage_rim_send(c._h, commp, 1, None, C.c_void_p(self.send_a.data_ptr())))
+                self.halo.exchange(self.send_a, self.recv_a, 4)
+                c._chk(lib.dflo_hip_stage_rim_send(c._h, commp, 2, C.c_void_p(self.recv_a.data_ptr()),
+                                                   C.c_void_p(self.send_u.data_ptr())))
+            else:
+                c._chk(lib.dflo_hip_stage_rim_send(c._h, commp, 0, None, C.c_void_p(self.send_u.data_ptr())))
+            self.halo.exchange(self.send_u, self.recv_u, self.ndof)
+            c._chk(lib.dflo_hip_stage_rim_recv(c._h, commp, C.c_void_p(self.recv_u.data_ptr())))
+        c._chk(lib.dflo_hip_stage_interior(c._h))                                # concurrently with the exchange
+
+    def _join(self):
+        if self.overlap:
+            self.claw._chk(lib.dflo_hip_stage_join(self.claw._h))
+
+    def iterate_explicit(self, dt):
+        c = self.claw
+        for rk in range(self.n_rk):
+            self._stage(rk, dt)
+        self._join()
         c.end_step()
         self.elapsed_time += dt
 
@@ -163,11 +197,7 @@ class DistributedConservationLaw:
         nccl = dist.get_backend() == "nccl"
         for step in range(n_steps):
             for rk in range(self.n_rk):
-                c._chk(lib.dflo_hip_stage_update(c._h, rk, dt0 if step == 0 else -1.0))
-                if self.tvb:
-                    self.exchange_averages()
-                c._chk(lib.dflo_hip_stage_limit(c._h))
-                self.exchange_solution()
+                self._stage(rk, dt0 if step == 0 else -1.0)
             c.end_step()
             # the last stage left this rank's raw CFL minimum in dt_dev[2]
             if nccl:
@@ -177,11 +207,13 @@ class DistributedConservationLaw:
                 dist.all_reduce(t, op=dist.ReduceOp.MIN)
                 self.dt_dev[2:3].copy_(t)
             c._chk(lib.dflo_hip_apply_dt_rules(c._h))
+        self._join()
         self.elapsed_time = float(self.dt_dev[1].item())
         return self.elapsed_time
 
     def gather_solution(self):
         """Owned DoFs of all ranks assembled in the global cell order (on every rank; test helper)."""
+        self._join()
         u = self.claw.current_solution.reshape(self.mesh.n_cells, self.ndof)[: self.mesh.n_owned]
         gid = np.asarray(self.mesh.global_ids)[: self.mesh.n_owned]
         parts = [None] * self.world
