@@ -176,4 +176,55 @@ struct CB {
   static constexpr CBTable<N> t = make_cb<N>();
 };
 
+
+// ---- Pk (FE_DGP) basis: psi_m(xi, eta) = Pt_i(xi) Pt_j(eta), Pt_n(x) = sqrt(2n+1) P_n(2x-1), orthonormal on
+// the unit square, modes ordered "for j: for i <= k-j" (src/claw.cc:107-113).  Since P_k is a subspace of
+// Q_k, a P_k function is represented exactly by its values at the N x N Gauss nodes and
+//   psi_m = sum_j psi_m(x_j) phi_j      (phi_j: the collocated Q_k Lagrange functions),
+// so the modal residual is T^T times the nodal (Q_k) residual with T[j][m] = psi_m(x_j).
+constexpr double kSqrtOdd[4] = {1.0, 1.7320508075688772935, 2.2360679774997896964, 2.6457513110645905905};
+constexpr double legendre01(int n, double x) {
+  const double t = 2.0 * x - 1.0;
+  double p0 = 1.0, p1 = t;
+  if (n == 0) return 1.0;
+  for (int k = 2; k <= n; ++k) {
+    const double pk = ((2.0 * k - 1.0) * t * p1 - (k - 1.0) * p0) / k;
+    p0 = p1;
+    p1 = pk;
+  }
+  return kSqrtOdd[n] * p1;
+}
+template <int N>
+struct PBTable {
+  static constexpr int NS = N * N, NM = N * (N + 1) / 2;
+  int mi[NM], mj[NM];
+  double T[NS][NM];     // psi_m at the Gauss node j = a + N b
+  double P0[N], P1[N];  // Pt_n(0), Pt_n(1)
+  double Px[N][N];      // Px[q][n] = Pt_n(x_q)
+};
+template <int N>
+constexpr PBTable<N> make_pb() {
+  PBTable<N> t{};
+  int m = 0;
+  for (int j = 0; j < N; ++j)
+    for (int i = 0; i < N - j; ++i) {
+      t.mi[m] = i;
+      t.mj[m] = j;
+      ++m;
+    }
+  for (int n = 0; n < N; ++n) {
+    t.P0[n] = legendre01(n, 0.0);
+    t.P1[n] = legendre01(n, 1.0);
+    for (int q = 0; q < N; ++q) t.Px[q][n] = legendre01(n, GaussLit<N>::x[q]);
+  }
+  for (int b = 0; b < N; ++b)
+    for (int a = 0; a < N; ++a)
+      for (int mm = 0; mm < PBTable<N>::NM; ++mm) t.T[a + N * b][mm] = t.Px[a][t.mi[mm]] * t.Px[b][t.mj[mm]];
+  return t;
+}
+template <int N>
+struct PB {
+  static constexpr PBTable<N> t = make_pb<N>();
+};
+
 }  // namespace dflo

@@ -38,6 +38,8 @@ struct KBasis {       // 1-D tables, see basis.h
   double DW[kMaxN][kMaxN];  // D[q][a] * w[q]
   double Pg[kMaxGLL][kMaxN];
   double Pt[kTrap][kMaxN];
+  double PLg[kMaxGLL][kMaxN];  // Pk: orthonormal Legendre Pt_n at the Gauss-Lobatto points
+  double PLx[kMaxN][kMaxN];    // Pk: Pt_n at the Gauss points
   int Ng;
 };
 
@@ -820,6 +822,460 @@ __global__ __launch_bounds__(64) void limiter_kernel(const LimArgs a) {
   }
 }
 
+// =====================================================================================================
+// Pk (FE_DGP) basis: the same shard machinery on modal DoFs.  A P_k function is a Q_k function, so it is
+// carried through phases A-C by its values at the Gauss nodes (exact), and only the two ends change:
+//   load:   u(x_j) = sum_m psi_m(x_j) U_m                      (modal -> nodal, T)
+//   store:  rhs_m  = sum_j psi_m(x_j) rhs_j, M = |K| I          (nodal residual -> modal, T^T; src/claw.cc:228-258
+//           gives 1/|K| on the diagonal for the orthonormal basis), update and SSP combine on the modes.
+// Cell average = mode 0 (psi_0 = 1).  Cartesian cells only.
+// =====================================================================================================
+template <int N, int B>
+__device__ __forceinline__ void modal_to_row(const double (&um)[4][N * (N + 1) / 2], double (&urow)[4][N]) {
+  constexpr int NM = N * (N + 1) / 2;
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int aa = 0; aa < N; ++aa) {
+      double v = 0.0;
+#pragma unroll
+      for (int m = 0; m < NM; ++m) v += PB<N>::t.T[aa + N * B][m] * um[c][m];
+      urow[c][aa] = v;
+    }
+}
+
+// phase C for node row B, then projection of the nodal residual on the modes and the modal update of the
+// modes this wave owns (m = B, B+N, ...)
+template <int N, int B, int MODE>
+__device__ __forceinline__ void row_update_pk(const StageArgs &a, double *Us, const int S, const double *Fh, double *red,
+                                              int shard, int lane, bool active, double h, const uint16_t (&cref)[4],
+                                              const double (&Wrow)[N][4], const double (&ucur)[4][(N * (N + 1) / 2 + N - 1) / N],
+                                              const double (&uold)[4][(N * (N + 1) / 2 + N - 1) / N]) {
+  constexpr int NS = N * N, NM = N * (N + 1) / 2;
+  double R[4][N];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int m = 0; m < N; ++m) R[c][m] = 0.0;
+  double Gown[N][4];
+#pragma unroll
+  for (int aa = 0; aa < N; ++aa) {
+    double Fx[4];
+    flux_xy(Wrow[aa], Fx, Gown[aa]);
+    const double wbh = CB<N>::t.w[B] * h;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const double fx = Fx[c] * wbh;
+#pragma unroll
+      for (int m = 0; m < N; ++m) R[c][m] += fx * CB<N>::t.DW[aa][m];
+      Us[(c * NS + aa + N * B) * S + lane] = Gown[aa][c];
+    }
+    if (a.gravity != 0.0) {
+      const double jxw = CB<N>::t.w[aa] * CB<N>::t.w[B] * h * h;
+      R[MY][aa] += a.gravity * (-1.0 * Wrow[aa][RHO]) * jxw;
+      R[EN][aa] += a.gravity * (-1.0 * Wrow[aa][MY]) * jxw;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int aa = 0; aa < N; ++aa) {
+    const double wah = CB<N>::t.w[aa] * h;
+#pragma unroll
+    for (int q = 0; q < N; ++q)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const double gy = q == B ? Gown[aa][c] : Us[(c * NS + aa + N * q) * S + lane];
+        R[c][aa] += gy * (wah * CB<N>::t.DW[q][B]);
+      }
+  }
+  if (active) {
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      const uint16_t ref = cref[f];
+      if (ref == kNoFace) continue;
+      const int k = ref & 0x3FFF;
+      const bool flip = (ref >> 14) & 1;
+      const double sgn = (ref >> 15) ? 1.0 : -1.0;
+      if (f < 2) {
+        const int qq = flip ? N - 1 - B : B;
+        const double jxw = sgn * CB<N>::t.w[B] * h;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const double fq = Fh[c * a.max_fp + k * N + qq] * jxw;
+#pragma unroll
+          for (int m = 0; m < N; ++m) R[c][m] += fq * ((f & 1) ? CB<N>::t.L1[m] : CB<N>::t.L0[m]);
+        }
+      } else {
+        const double lw = (f & 1) ? CB<N>::t.L1[B] : CB<N>::t.L0[B];
+#pragma unroll
+        for (int q = 0; q < N; ++q) {
+          const int qq = flip ? N - 1 - q : q;
+          const double jxw = sgn * (CB<N>::t.w[q] * lw) * h;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) R[c][q] += Fh[c * a.max_fp + k * N + qq] * jxw;
+        }
+      }
+    }
+  }
+  // ---- nodal residual -> modal residual: rhs_m = sum over rows of sum_a psi_m(x_(a,B)) R[.][a]; the rows
+  //      are added in a fixed order (row 0 first), through the now unused LDS image
+  __syncthreads();  // every wave is done with the G exchange
+  double *acc = Us;  // [4 NM][64]
+#pragma unroll
+  for (int w = 0; w < N; ++w) {
+    if (B == w) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int m = 0; m < NM; ++m) {
+          double pr = 0.0;
+#pragma unroll
+          for (int aa = 0; aa < N; ++aa) pr += PB<N>::t.T[aa + N * B][m] * R[c][aa];
+          if (w == 0) acc[(c * NM + m) * 64 + lane] = pr;
+          else acc[(c * NM + m) * 64 + lane] += pr;
+        }
+    }
+    __syncthreads();
+  }
+  double part[5] = {0, 0, 0, 0, 0};
+  if (active) {
+    const double dt = a.dt_cell ? a.dt_cell[(size_t)shard * 64 + lane] : (a.dt_host >= 0.0 ? a.dt_host : *a.dt_dev);
+    const double rh2 = frcp(h * h);  // inverse mass of the orthonormal modes: 1/|K|
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      int t = 0;
+#pragma unroll
+      for (int m = B; m < NM; m += N, ++t) {
+        const double rm = acc[(c * NM + m) * 64 + lane];
+        if constexpr (MODE == 2) {
+          a.rhs_out[((size_t)shard * 4 * NM + c * NM + m) * 64 + lane] = rm;
+        } else {
+          part[4] += rm * rm;
+          double u = ucur[c][t];
+          u += dt * rm * rh2;
+          if constexpr (MODE == 1) u = (1.0 - a.ark) * u + a.ark * uold[c][t];
+          a.Unew[((size_t)shard * 4 * NM + c * NM + m) * 64 + lane] = u;
+          if (m == 0) part[c] = u;  // the cell average is mode 0
+        }
+      }
+    }
+  }
+  if constexpr (MODE != 2) {
+    __syncthreads();  // every wave is done reading Fh
+#pragma unroll
+    for (int c = 0; c < 5; ++c) red[(B * 5 + c) * 64 + lane] = part[c];
+  }
+}
+
+template <int N, int FLUX, int MODE>
+__global__ __launch_bounds__(64 * N, N == 4 ? 2 : 3) void stage_kernel_pk(const StageArgs a) {
+  constexpr int NS = N * N, NM = N * (N + 1) / 2, NDOFM = 4 * NM, NT = 64 * N, MS = (NM + N - 1) / N;
+  constexpr int ROWS = 4 * NS + (FLUX == DFLO_FLUX_LXF ? 4 : 0);
+  constexpr int TROWS = 4 * N + (FLUX == DFLO_FLUX_LXF ? 4 : 0);
+  constexpr int S = 65;
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int sidx = shard_of_block(blockIdx.x, a.n_list);
+  if (sidx < 0) return;
+  const int shard = a.shard_list ? a.shard_list[sidx] : sidx;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int row = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int HS = a.halo_stride;
+  double *Us = lds;
+  double *Th = Us + ROWS * S;
+  double *Fh = Th + TROWS * HS;
+  FaceRec *Fr = (FaceRec *)(Fh + 4 * a.max_fp);
+  double *Bv = (double *)(Fr + a.max_faces);
+  int *Bk = (int *)(Bv + a.max_bnd * 4 * N);
+
+  // ---- loads: every wave reads all modes of its cells (the rows need all of them); the modes a wave will
+  //      update (m = row, row+N, ...) of u(s) and u(n) are requested separately and consumed at the end
+  int hent[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) hent[t] = a.halo_pad[(size_t)shard * a.halo_pitch + ((tid + t * NT) & 31)];
+  const int4 hdr = a.shard_hdr[shard];
+  const int nf = hdr.y, nh = hdr.z, nbnd = hdr.w;
+  const bool active = lane < hdr.x;
+  double umode[4][NM];
+  {
+    const double *up = a.Ucur + (size_t)shard * NDOFM * 64 + lane;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int m = 0; m < NM; ++m) umode[c][m] = up[(c * NM + m) * 64];
+  }
+  double uavg[4];
+  if constexpr (FLUX == DFLO_FLUX_LXF) {
+    if (row == 0) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) uavg[c] = a.avg_cur[((size_t)shard * 4 + c) * 64 + lane];
+    }
+  }
+  const FaceRec *fp = a.faces_pad + (size_t)shard * a.face_pitch;
+  const FaceRec fr0 = fp[tid], fr1 = fp[tid + NT];
+  uint16_t cref[4];
+#pragma unroll
+  for (int f = 0; f < 4; ++f) cref[f] = a.cell_face[((size_t)shard * 4 + f) * 64 + lane];
+  const double h = a.uniform_h ? a.h_uniform : a.cell_h[(size_t)shard * 64 + lane];
+  double ucur[4][MS], uold[4][MS];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int t = 0; t < MS; ++t) {
+      const int m = min(row + N * t, NM - 1);
+      ucur[c][t] = a.Ucur[((size_t)shard * NDOFM + c * NM + m) * 64 + lane];
+      if constexpr (MODE == 1) uold[c][t] = a.Uold[((size_t)shard * NDOFM + c * NM + m) * 64 + lane];
+    }
+
+  // ---- phase A
+  double urow[4][N];
+  if constexpr (N == 2) {
+    if (row == 0) modal_to_row<N, 0>(umode, urow); else modal_to_row<N, 1>(umode, urow);
+  } else if constexpr (N == 3) {
+    if (row == 0) modal_to_row<N, 0>(umode, urow); else if (row == 1) modal_to_row<N, 1>(umode, urow); else modal_to_row<N, 2>(umode, urow);
+  } else {
+    if (row == 0) modal_to_row<N, 0>(umode, urow); else if (row == 1) modal_to_row<N, 1>(umode, urow);
+    else if (row == 2) modal_to_row<N, 2>(umode, urow); else modal_to_row<N, 3>(umode, urow);
+  }
+  // halo: trace of the neighbour's modal expansion at the face point, psi_m = Pt_i(xi) Pt_j(eta) with
+  // (xi, eta) on face f: xi in {0, 1, x_q}
+  for (int i = tid; i < ((nh + 31) & ~31) * 4 * N; i += NT) {
+    const int sl = (i & 31) + ((i >> 5) / (4 * N)) * 32, r = (i >> 5) % (4 * N), q = r % N, c = r / N;
+    if (sl >= nh) continue;
+    const int e = i == tid ? hent[0] : (i == tid + NT ? hent[1] : a.halo_pad[(size_t)shard * a.halo_pitch + sl]);
+    const int ic = e & 0x0FFFFFFF, f = (e >> 28) & 3;
+    const double *hp = a.Ucur + ((size_t)(ic >> 6) * NDOFM + c * NM) * 64 + (ic & 63);
+    double pxi[N], peta[N];
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+      double pq = PB<N>::t.Px[0][n];
+#pragma unroll
+      for (int qq = 1; qq < N; ++qq) pq = q == qq ? PB<N>::t.Px[qq][n] : pq;
+      pxi[n] = f == 0 ? PB<N>::t.P0[n] : (f == 1 ? PB<N>::t.P1[n] : pq);
+      peta[n] = f == 2 ? PB<N>::t.P0[n] : (f == 3 ? PB<N>::t.P1[n] : pq);
+    }
+    double v = 0.0;
+#pragma unroll
+    for (int m = 0; m < NM; ++m) v += pxi[PB<N>::t.mi[m]] * peta[PB<N>::t.mj[m]] * hp[m * 64];
+    Th[(c * N + q) * HS + sl] = v;
+  }
+  if constexpr (FLUX == DFLO_FLUX_LXF) {
+    for (int i = tid; i < nh * 4; i += NT) {
+      const int sl = i % nh, c = i / nh;
+      const int ic = a.halo_pad[(size_t)shard * a.halo_pitch + sl] & 0x0FFFFFFF;
+      Th[(4 * N + c) * HS + sl] = a.avg_cur[((size_t)(ic >> 6) * 4 + c) * 64 + (ic & 63)];
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int m = 0; m < N; ++m) Us[(c * NS + m + N * row) * S + lane] = urow[c][m];
+  if constexpr (FLUX == DFLO_FLUX_LXF) {
+    if (row == 0) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) Us[(4 * NS + c) * S + lane] = uavg[c];
+    }
+  }
+  if (tid < nf) Fr[tid] = fr0;
+  if (tid + NT < nf) Fr[tid + NT] = fr1;
+  for (int i = tid + 2 * NT; i < nf; i += NT) Fr[i] = fp[i];
+  if (nbnd > 0) {
+    for (int i = tid; i < nf; i += NT) {
+      const FaceRec r = fp[i];
+      if ((r.w0 >> 18) & 1) {
+        const int bl = (r.w0 >> 20) & 0x3FF, bf = r.w1;
+        Bk[bl] = a.bface_kind[bf];
+        for (int k2 = 0; k2 < 4 * N; ++k2) Bv[bl * 4 * N + k2] = a.bval[(size_t)bf * 4 * N + k2];
+      }
+    }
+  }
+  __syncthreads();
+  flux_phase<N, FLUX, 0>(a, Us, Th, Fh, Fr, Bv, Bk, nullptr, HS, nf, tid);
+  __syncthreads();
+
+  double *red = Fh;
+  double wrow[N][4];
+#pragma unroll
+  for (int m = 0; m < N; ++m)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) wrow[m][c] = urow[c][m];
+#define DFLO_ROWPK(Bq) row_update_pk<N, Bq, MODE>(a, Us, S, Fh, red, shard, lane, active, h, cref, wrow, ucur, uold)
+  if constexpr (N == 2) {
+    if (row == 0) DFLO_ROWPK(0); else DFLO_ROWPK(1);
+  } else if constexpr (N == 3) {
+    if (row == 0) DFLO_ROWPK(0); else if (row == 1) DFLO_ROWPK(1); else DFLO_ROWPK(2);
+  } else {
+    if (row == 0) DFLO_ROWPK(0); else if (row == 1) DFLO_ROWPK(1); else if (row == 2) DFLO_ROWPK(2); else DFLO_ROWPK(3);
+  }
+#undef DFLO_ROWPK
+  if constexpr (MODE == 2) return;
+  __syncthreads();
+  if (row == N - 1) {
+    double avg[4], res = 0.0, dtmin = 1.0e20;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      double v = 0;
+#pragma unroll
+      for (int b = 0; b < N; ++b) v += red[(b * 5 + c) * 64 + lane];
+      avg[c] = v;
+    }
+#pragma unroll
+    for (int b = 0; b < N; ++b) res += red[(b * 5 + 4) * 64 + lane];
+    if (active) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) a.avg_new[((size_t)shard * 4 + c) * 64 + lane] = avg[c];
+      if (a.want_dt) dtmin = cfl_dt(avg, h, a.cfl, a.degree);
+    }
+    res = wave_sum(res);
+    dtmin = wave_min(dtmin);
+    if (lane == 0) {
+      a.shard_res[shard] = res;
+      if (a.want_dt) a.shard_dtmin[shard] = dtmin;
+    }
+  }
+}
+
+// apply_limiter_TVB_Pk (src/limiter.cc:377-516) then the Pk branch of apply_positivity_limiter
+// (src/positivity.cc:100-109, 197-205); lane = cell, all modes in registers
+template <int N>
+__global__ __launch_bounds__(64) void limiter_pk_kernel(const LimArgs a) {
+  constexpr int NM = N * (N + 1) / 2, NDOFM = 4 * NM;
+  const int sidx = shard_of_block(blockIdx.x, a.n_list);
+  if (sidx < 0) return;
+  const int shard = a.shard_list ? a.shard_list[sidx] : sidx;
+  const int lane = threadIdx.x;
+  if (lane >= a.shard_count[shard]) return;
+  double *up = a.U + (size_t)shard * NDOFM * 64 + lane;
+  double U[4][NM], A[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int m = 0; m < NM; ++m) U[c][m] = up[(c * NM + m) * 64];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) A[c] = a.avg[((size_t)shard * 4 + c) * 64 + lane];
+  const double h = a.uniform_h ? a.h_uniform : a.cell_h[(size_t)shard * 64 + lane];
+  bool changed = false;
+  const double sqrt_3 = 1.7320508075688772935;
+  if (a.tvb) {
+    const double dx = h, Mdx2 = a.M * dx * dx, beta = 0.5 * a.beta;   // :396
+    double Dx[4], Dy[4], dbx[4], dfx[4], dby[4], dfy[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      Dx[c] = U[c][1] * sqrt_3;       // mode (1,0)
+      Dy[c] = U[c][N] * sqrt_3;       // mode (0,1) = index k+1
+    }
+    const int il = a.lrbt[((size_t)shard * 4 + 0) * 64 + lane], ir = a.lrbt[((size_t)shard * 4 + 1) * 64 + lane];
+    const int ib = a.lrbt[((size_t)shard * 4 + 2) * 64 + lane], it = a.lrbt[((size_t)shard * 4 + 3) * 64 + lane];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      dbx[c] = il >= 0 ? A[c] - a.avg[((size_t)(il >> 6) * 4 + c) * 64 + (il & 63)] : Dx[c];
+      dfx[c] = ir >= 0 ? a.avg[((size_t)(ir >> 6) * 4 + c) * 64 + (ir & 63)] - A[c] : Dx[c];
+      dby[c] = ib >= 0 ? A[c] - a.avg[((size_t)(ib >> 6) * 4 + c) * 64 + (ib & 63)] : Dy[c];
+      dfy[c] = it >= 0 ? a.avg[((size_t)(it >> 6) * 4 + c) * 64 + (it & 63)] - A[c] : Dy[c];
+    }
+    EigenXY e;
+    if (a.char_lim) {
+      e = eigen_at(A);
+      to_char(e, 0, dbx); to_char(e, 0, dfx); to_char(e, 1, dby); to_char(e, 1, dfy);
+      to_char(e, 0, Dx); to_char(e, 1, Dy);
+    }
+    double Dxn[4], Dyn[4], change_x = 0, change_y = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      Dxn[i] = minmod(Dx[i], beta * dbx[i], beta * dfx[i], Mdx2);
+      Dyn[i] = minmod(Dy[i], beta * dby[i], beta * dfy[i], Mdx2);
+      change_x += fabs(Dxn[i] - Dx[i]);
+      change_y += fabs(Dyn[i] - Dy[i]);
+    }
+    change_x /= 4;
+    change_y /= 4;
+    if (change_x + change_y > 1.0e-10) {
+      if (a.char_lim) {
+        to_con(e, 0, Dxn);
+        to_con(e, 1, Dyn);
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int m = 1; m < NM; ++m) U[c][m] = m == 1 ? Dxn[c] / sqrt_3 : (m == N ? Dyn[c] / sqrt_3 : 0.0);
+      changed = true;
+    }
+  }
+  if (a.pos_lim) {
+    const double eps = 1.0e-13;
+    if (fmin(A[RHO], pressure(A)) < eps) {
+      atomicOr(&a.flags[0], 1);
+    } else {
+      // point value of component c at (Pt(xi), Pt(eta)) given the 1-D Legendre values
+      auto point = [&](int c, const double *pxi, const double *peta) {
+        double v = 0.0;
+#pragma unroll
+        for (int m = 0; m < NM; ++m) v += pxi[PB<N>::t.mi[m]] * peta[PB<N>::t.mj[m]] * U[c][m];
+        return v;
+      };
+      double rho_min = 1.0e20;
+      for (int l = 0; l < N; ++l)
+        for (int g = 0; g < a.kb.Ng; ++g) {
+          double pg[N], pl[N];
+#pragma unroll
+          for (int n = 0; n < N; ++n) { pg[n] = a.kb.PLg[g][n]; pl[n] = a.kb.PLx[l][n]; }
+          rho_min = fmin(rho_min, fmin(point(RHO, pg, pl), point(RHO, pl, pg)));
+        }
+      const double rat = fabs(A[RHO] - eps) / (fabs(A[RHO] - rho_min) + 1.0e-13);
+      const double theta1 = fmin(rat, 1.0);
+      if (theta1 < 1.0) {
+#pragma unroll
+        for (int m = 1; m < NM; ++m) U[RHO][m] *= theta1;
+        changed = true;
+      }
+      double theta2 = 1.0;
+      bool fail = false;
+      for (int dir = 0; dir < 2; ++dir)
+        for (int l = 0; l < N; ++l)
+          for (int g = 0; g < a.kb.Ng; ++g) {
+            double pg[N], pl[N], W[4];
+#pragma unroll
+            for (int n = 0; n < N; ++n) { pg[n] = a.kb.PLg[g][n]; pl[n] = a.kb.PLx[l][n]; }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) W[c] = dir == 0 ? point(c, pg, pl) : point(c, pl, pg);
+            const double pre = kG1 * (W[EN] - 0.5 * (W[MX] * W[MX] + W[MY] * W[MY]) / W[RHO]);
+            if (pre < eps) {
+              const double drho = W[RHO] - A[RHO], dmx = W[MX] - A[MX], dmy = W[MY] - A[MY], dE = W[EN] - A[EN];
+              const double a1 = 2.0 * drho * dE - (dmx * dmx + dmy * dmy);
+              double b1 = 2.0 * drho * (A[EN] - eps / kG1) + 2.0 * A[RHO] * dE - 2.0 * (A[MX] * dmx + A[MY] * dmy);
+              double c1 = 2.0 * A[RHO] * A[EN] - (A[MX] * A[MX] + A[MY] * A[MY]) - 2.0 * eps * A[RHO] / kG1;
+              b1 /= a1;
+              c1 /= a1;
+              const double D = sqrt(fabs(b1 * b1 - 4.0 * c1));
+              const double t1 = 0.5 * (-b1 - D), t2 = 0.5 * (-b1 + D);
+              double t;
+              if (t1 > -1.0e-12 && t1 < 1.0 + 1.0e-12) t = t1;
+              else if (t2 > -1.0e-12 && t2 < 1.0 + 1.0e-12) t = t2;
+              else { fail = true; t = 0.0; }
+              t = fmin(1.0, t);
+              t = fmax(0.0, t);
+              if (fabs(1.0 - t) < 1.0e-14) t = 0.0;
+              theta2 = fmin(theta2, t);
+            }
+          }
+      if (fail) atomicOr(&a.flags[1], 1);
+      if (theta2 < 1.0) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+          for (int m = 1; m < NM; ++m) U[c][m] *= theta2;
+        changed = true;
+      }
+    }
+  }
+  if (changed) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int m = 1; m < NM; ++m) up[(c * NM + m) * 64] = U[c][m];
+  }
+}
+
 // accuracy probe of the reciprocal / square-root forms used by the flux functions
 __global__ void debug_math_kernel(const double *x, double *rcp, double *sq, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -833,6 +1289,7 @@ __global__ void debug_math_kernel(const double *x, double *rcp, double *sq, int 
 // quadrature weight of node j for the cell average: w_a w_b (squares) or w_a w_b det J / |K| (bilinear cells)
 __device__ __forceinline__ double avg_weight(const KBasis &kb, int N, int j, const double *vert, int n_slots, int slot,
                                              double inv_area) {
+  if (N < 0) return j == 0 ? 1.0 : 0.0;  // Pk (flagged by N < 0): the average is mode 0
   const double ww = kb.w[j % N] * kb.w[j / N];
   if (!vert) return ww;
   double v[8];
@@ -1056,7 +1513,7 @@ struct dflo_hip_engine {
   BasisTables bt;
   KBasis kb;
   dflo_params_t prm;
-  int degree = 1, N = 2, ns = 4, ndof = 16, mapping = DFLO_MAP_CARTESIAN, geo = 0;
+  int degree = 1, N = 2, ns = 4, ndof = 16, mapping = DFLO_MAP_CARTESIAN, geo = 0, basis = DFLO_BASIS_QK;
   int n_rk = 2;
   double ark[3] = {0, 0, 0};
   int device = 0;
@@ -1142,6 +1599,14 @@ KBasis make_kbasis(const BasisTables &b) {
   for (int g = 0; g < kTrap; ++g)
     for (int j = 0; j < kMaxN; ++j) k.Pt[g][j] = b.Pt[g][j];
   k.Ng = b.Ng;
+  {
+    long double g[kMaxGLL + 1];
+    gauss_lobatto01(b.Ng, g);
+    for (int gi = 0; gi < b.Ng; ++gi)
+      for (int n = 0; n < b.N; ++n) k.PLg[gi][n] = legendre01(n, (double)g[gi]);
+    for (int q = 0; q < b.N; ++q)
+      for (int n = 0; n < b.N; ++n) k.PLx[q][n] = legendre01(n, b.x[q]);
+  }
   return k;
 }
 
@@ -1159,6 +1624,27 @@ stage_fn pick_stage_n(int flux, int mode, int geo) {
     case DFLO_FLUX_KFVS: return pick_stage_m<N, DFLO_FLUX_KFVS>(mode, geo);
     case DFLO_FLUX_ROE: return pick_stage_m<N, DFLO_FLUX_ROE>(mode, geo);
     default: return pick_stage_m<N, DFLO_FLUX_HLLC>(mode, geo);
+  }
+}
+template <int N, int FLUX>
+stage_fn pick_pk_m(int mode) {
+  return mode == 0 ? stage_kernel_pk<N, FLUX, 0> : (mode == 1 ? stage_kernel_pk<N, FLUX, 1> : stage_kernel_pk<N, FLUX, 2>);
+}
+template <int N>
+stage_fn pick_pk_n(int flux, int mode) {
+  switch (flux) {
+    case DFLO_FLUX_LXF: return pick_pk_m<N, DFLO_FLUX_LXF>(mode);
+    case DFLO_FLUX_SW: return pick_pk_m<N, DFLO_FLUX_SW>(mode);
+    case DFLO_FLUX_KFVS: return pick_pk_m<N, DFLO_FLUX_KFVS>(mode);
+    case DFLO_FLUX_ROE: return pick_pk_m<N, DFLO_FLUX_ROE>(mode);
+    default: return pick_pk_m<N, DFLO_FLUX_HLLC>(mode);
+  }
+}
+stage_fn pick_pk(int N, int flux, int mode) {
+  switch (N) {
+    case 2: return pick_pk_n<2>(flux, mode);
+    case 3: return pick_pk_n<3>(flux, mode);
+    default: return pick_pk_n<4>(flux, mode);
   }
 }
 stage_fn pick_stage(int N, int flux, int mode, int geo) {
@@ -1279,7 +1765,8 @@ int launch_update(dflo_hip_engine *h, double *rhs_out, int part) {
   a.shard_list = part == 1 ? h->d_rim_list : (part == 2 ? h->d_int_list : nullptr);
   a.n_list = part == 1 ? (int)p.rim_shards.size() : (part == 2 ? (int)p.interior_shards.size() : p.n_shards);
   if (a.n_list == 0) return DFLO_OK;
-  stage_fn fn = pick_stage(h->N, h->prm.flux_type, rhs_out ? 2 : (h->ark[rk] != 0.0 ? 1 : 0), h->geo);
+  const int mode_ = rhs_out ? 2 : (h->ark[rk] != 0.0 ? 1 : 0);
+  stage_fn fn = h->basis == DFLO_BASIS_PK ? pick_pk(h->N, h->prm.flux_type, mode_) : pick_stage(h->N, h->prm.flux_type, mode_, h->geo);
   time_begin(h);
   hipLaunchKernelGGL(fn, dim3(grid_for(a.n_list)), dim3(64 * h->N), h->lds_bytes, h->stream, a);
   time_end(h);
@@ -1309,6 +1796,7 @@ int launch_limiter(dflo_hip_engine *h, int tvb, int pos, int part) {
   l.n_list = part == 1 ? (int)p.rim_shards.size() : (part == 2 ? (int)p.interior_shards.size() : p.n_shards);
   if (l.n_list == 0) return DFLO_OK;
   void (*lf)(const LimArgs) = h->N == 2 ? limiter_kernel<2> : (h->N == 3 ? limiter_kernel<3> : limiter_kernel<4>);
+  if (h->basis == DFLO_BASIS_PK) lf = h->N == 2 ? limiter_pk_kernel<2> : (h->N == 3 ? limiter_pk_kernel<3> : limiter_pk_kernel<4>);
   hipLaunchKernelGGL(lf, dim3(grid_for(l.n_list)), dim3(64), 0, h->stream, l);
   HIPCHK(h, hipGetLastError());
   return DFLO_OK;
@@ -1381,7 +1869,7 @@ int launch_average(dflo_hip_engine *h) {
   const Plan &p = h->plan;
   const int all = p.n_shards + p.n_ghost_shards;
   hipLaunchKernelGGL(average_kernel, dim3(all), dim3(64), 0, h->stream, h->U[h->cur], h->avg[h->avg_cur], h->ndof, h->kb,
-                     h->N, (const double *)h->d_cell_vert, p.n_slots);
+                     h->basis == DFLO_BASIS_PK ? -h->N : h->N, (const double *)h->d_cell_vert, p.n_slots);
   HIPCHK(h, hipGetLastError());
   return DFLO_OK;
 }
@@ -1399,7 +1887,11 @@ int dflo_hip_create(const dflo_mesh_t *mesh, const dflo_params_t *params, int de
   *out = nullptr;
   // consistency checks of the reference's parameter parsing (src/parameters.cc:536-550)
   if (mesh->degree < 1 || mesh->degree > DFLO_MAX_DEGREE) { g_create_error = "degree must be 1..3"; return DFLO_ERR_BAD_PARAM; }
-  if (mesh->basis != DFLO_BASIS_QK) { g_create_error = "Pk basis is not implemented in the device engine yet"; return DFLO_ERR_UNSUPPORTED; }
+  if (mesh->basis != DFLO_BASIS_QK && mesh->basis != DFLO_BASIS_PK) { g_create_error = "unknown basis"; return DFLO_ERR_BAD_PARAM; }
+  if (mesh->basis == DFLO_BASIS_PK && mesh->mapping != DFLO_MAP_CARTESIAN) {
+    g_create_error = "Pk basis is implemented for cartesian mapping only";
+    return DFLO_ERR_UNSUPPORTED;
+  }
   if (mesh->mapping != DFLO_MAP_CARTESIAN && mesh->mapping != DFLO_MAP_Q1) { g_create_error = "q2 mapping is not implemented"; return DFLO_ERR_UNSUPPORTED; }
   if (params->limiter_type == DFLO_LIMITER_TVB && mesh->mapping != DFLO_MAP_CARTESIAN) {
     g_create_error = "TVB limiter is implemented only for cartesian mapping";  // src/parameters.cc:543-544
@@ -1418,7 +1910,8 @@ int dflo_hip_create(const dflo_mesh_t *mesh, const dflo_params_t *params, int de
   h->prm = *params;
   h->degree = mesh->degree;
   h->N = mesh->degree + 1;
-  h->ns = h->N * h->N;
+  h->basis = mesh->basis;
+  h->ns = mesh->basis == DFLO_BASIS_PK ? h->N * (h->N + 1) / 2 : h->N * h->N;
   h->ndof = 4 * h->ns;
   h->mapping = mesh->mapping;
   h->geo = mesh->mapping == DFLO_MAP_CARTESIAN ? 0 : 1;
@@ -1529,7 +2022,7 @@ int dflo_hip_create(const dflo_mesh_t *mesh, const dflo_params_t *params, int de
   h->halo_stride = std::max(p.max_halo, 1) | 1;  // odd stride: the trace rows fall on different LDS banks
   h->max_fp = std::max(std::max(p.max_faces, 1) * h->N, 5 * 64 * h->N / 4 + 1);  // Fh also hosts the row partials
   {
-    const int rows = h->ndof + (h->prm.flux_type == DFLO_FLUX_LXF ? 4 : 0);
+    const int rows = 4 * h->N * h->N + (h->prm.flux_type == DFLO_FLUX_LXF ? 4 : 0);  // nodal image (also for Pk)
     const int trows = 4 * h->N + (h->prm.flux_type == DFLO_FLUX_LXF ? 4 : 0);
     h->lds_bytes = ((size_t)rows * 65 + (size_t)trows * h->halo_stride + 4 * (size_t)h->max_fp + (size_t)std::max(p.max_faces, 1) +
                     (size_t)p.max_bnd * (4 * h->N + 1) + 2 + (h->geo == 1 ? 3 * (size_t)std::max(p.max_faces, 1) : 0)) * sizeof(double);
@@ -1538,7 +2031,7 @@ int dflo_hip_create(const dflo_mesh_t *mesh, const dflo_params_t *params, int de
   if (h->lds_bytes > 160 * 1024) { h->err = "shard halo too large for LDS"; return bail(DFLO_ERR_UNSUPPORTED); }
   if (h->lds_bytes > 64 * 1024) {
     for (int mode = 0; mode < 3; ++mode) {
-      stage_fn fn = pick_stage(h->N, h->prm.flux_type, mode, h->geo);
+      stage_fn fn = h->basis == DFLO_BASIS_PK ? pick_pk(h->N, h->prm.flux_type, mode) : pick_stage(h->N, h->prm.flux_type, mode, h->geo);
       if (hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes) != hipSuccess) {
         h->err = "cannot raise dynamic LDS limit";
         return bail(DFLO_ERR_HIP);
@@ -1991,8 +2484,8 @@ int dflo_hip_unpack_ghost(dflo_hip_handle h, const void *device_buffer) {
   if (n_ghost == 0) return DFLO_OK;
   if (!device_buffer) return DFLO_ERR_BAD_PARAM;
   hipLaunchKernelGGL(unpack_ghost_kernel, dim3((n_ghost + 63) / 64), dim3(64), 0, h->stream, (const double *)device_buffer,
-                     h->U[h->cur], h->avg[h->avg_cur], p.n_shards * 64, n_ghost, h->ndof, h->kb, h->N,
-                     (const double *)h->d_cell_vert, p.n_slots);
+                     h->U[h->cur], h->avg[h->avg_cur], p.n_shards * 64, n_ghost, h->ndof, h->kb,
+                     h->basis == DFLO_BASIS_PK ? -h->N : h->N, (const double *)h->d_cell_vert, p.n_slots);
   HIPCHK(h, hipGetLastError());
   return DFLO_OK;
 }

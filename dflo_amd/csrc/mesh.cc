@@ -348,7 +348,7 @@ int dflo_mesh_partition(const dflo_mesh_t *mesh, int32_t n_ranks, int32_t rank, 
 #include "basis.h"
 extern "C" int dflo_mesh_support_points(const dflo_mesh_t *mesh, double *xy) {
   if (!mesh || !xy) return fail(DFLO_ERR_BAD_PARAM, "dflo_mesh_support_points: null argument");
-  if (mesh->basis != DFLO_BASIS_QK) return fail(DFLO_ERR_UNSUPPORTED, "support points exist only for the Qk basis");
+  // for the Pk basis these are the points of QGauss<2>(k+1) the L2 projection of the initial condition uses
   const dflo::BasisTables b = dflo::make_basis(mesh->degree);
   const int N = b.N;
   for (int c = 0; c < mesh->n_cells; ++c) {

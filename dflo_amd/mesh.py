@@ -86,8 +86,13 @@ class Mesh:
         return self.struct.degree
 
     @property
+    def basis(self):
+        return "Pk" if self.struct.basis == _lib.BASIS["Pk"] else "Qk"
+
+    @property
     def n_s(self):
-        return (self.degree + 1) ** 2
+        n = self.degree + 1
+        return n * (n + 1) // 2 if self.basis == "Pk" else n * n
 
     @property
     def ndof(self):
@@ -114,9 +119,13 @@ class Mesh:
     def set_mapping(self, mapping):
         self.struct.mapping = _lib.MAPPING[mapping]
 
+    def set_basis(self, basis):
+        """"Qk" (FE_DGQArbitraryNodes at Gauss points) or "Pk" (FE_DGP, orthonormal Legendre modes), src/main.cc:36-45."""
+        self.struct.basis = _lib.BASIS[basis]
+
     def support_points(self):
-        """Real-space support points of the Qk DoFs, [n_cells, n_s, 2] (src/ic.cc:104-121)."""
-        xy = np.empty((self.n_cells, self.n_s, 2))
+        """Real-space support points of the Qk DoFs = points of QGauss<2>(k+1), [n_cells, (k+1)^2, 2] (src/ic.cc:104-121)."""
+        xy = np.empty((self.n_cells, (self.degree + 1) ** 2, 2))
         rc = lib.dflo_mesh_support_points(self._ptr, _lib.dptr(xy))
         if rc:
             raise DfloError(rc, lib.dflo_mesh_last_error().decode())
@@ -125,7 +134,33 @@ class Mesh:
     def interpolate(self, fn):
         """VectorTools::interpolate for Qk (src/ic.cc:104-121): fn(x, y) -> [mx, my, rho, E] arrays.
         Returns the state vector in dflo's DoF order [cell][comp][node]."""
+        if self.basis == "Pk":
+            return self.project(fn)
         xy = self.support_points()
         w = fn(xy[..., 0], xy[..., 1])  # 4 arrays [n_cells, n_s]
         u = np.stack([np.broadcast_to(np.asarray(c, dtype=np.float64), xy.shape[:2]) for c in w], axis=1)
+        return np.ascontiguousarray(u).reshape(-1)
+
+    def modal_matrix(self):
+        """T[j][m] = psi_m at Gauss node j = a + N b of the unit cell; psi_m = Pt_i(xi) Pt_j(eta) with
+        Pt_n(x) = sqrt(2n+1) P_n(2x-1), modes ordered "for j: for i <= k-j" (FE_DGP; src/claw.cc:107-113).
+        Also returns the tensor Gauss weights."""
+        N = self.degree + 1
+        t, w = np.polynomial.legendre.leggauss(N)
+        w = 0.5 * w
+        P = np.stack([np.sqrt(2 * n + 1) * np.polynomial.legendre.Legendre.basis(n)(t) for n in range(N)], axis=1)  # [q][n]
+        modes = [(i, j) for j in range(N) for i in range(N - j)]
+        T = np.empty((N * N, len(modes)))
+        for m, (i, j) in enumerate(modes):
+            T[:, m] = np.outer(P[:, j], P[:, i]).reshape(-1)  # node index a + N b: b (eta) slow
+        return T, np.outer(w, w).reshape(-1)
+
+    def project(self, fn):
+        """L2 projection on the Pk modes with QGauss(k+1) (set_initial_condition_Pk, src/ic.cc:128-164):
+        u_m = sum_q f(x_q) psi_m(x_q) w_q (the mass matrix of the orthonormal modes is |K| I)."""
+        xy = self.support_points()
+        T, ww = self.modal_matrix()
+        w = fn(xy[..., 0], xy[..., 1])
+        f = np.stack([np.broadcast_to(np.asarray(c, dtype=np.float64), xy.shape[:2]) for c in w], axis=1)  # [cell][4][q]
+        u = np.einsum("ncq,q,qm->ncm", f, ww, T)
         return np.ascontiguousarray(u).reshape(-1)

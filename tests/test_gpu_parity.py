@@ -312,3 +312,118 @@ def test_gravity_source_and_local_time_stepping():
         ora.step(-1.0)                            # keep the per-cell time steps
         t += dt
     assert rel(claw.current_solution, ora.get_solution()) < 1e-11
+
+
+# ---------------------------------------------------------------- Pk (FE_DGP) basis, SURVEY §8f
+def pk_pair(nx, ny, degree, flux, side_bc=(-1, -1, -1, -1), boundary=None, h=None, x0=-5.0, y0=-5.0, **kw):
+    h = 10.0 / nx if h is None else h
+    mesh = dflo_amd.Mesh.cartesian(nx, ny, x0, y0, h, list(side_bc), degree)
+    mesh.set_basis("Pk")
+    prm = dflo_amd.Parameters(flux=flux, boundary=boundary, **kw)
+    return mesh, prm, dflo_amd.ConservationLaw(mesh, prm), oracle_lib.Oracle(mesh, prm)
+
+
+@pytest.mark.parametrize("degree", [1, 2, 3])
+@pytest.mark.parametrize("flux", FLUXES)
+def test_pk_residual_periodic(degree, flux):
+    mesh, prm, claw, ora = pk_pair(20, 12, degree, flux, h=0.5)
+    u0 = mesh.project(problems.smooth_perturbation)
+    assert u0.size == mesh.n_cells * 4 * (degree + 1) * (degree + 2) // 2
+    claw.set_initial_condition(u0)
+    ora.set_solution(u0)
+    assert rel(claw.cell_average, ora.get_cell_average()) < 1e-14
+    assert rel(claw.assemble_system(), ora.assemble()) < 1e-12
+
+
+@pytest.mark.parametrize("degree,flux", [(1, "lxf"), (2, "hllc"), (3, "kfvs"), (2, "roe"), (3, "sw")])
+def test_pk_rk_solution_vortex(degree, flux):
+    mesh, prm, claw, ora = pk_pair(16, 16, degree, flux)
+    u0 = mesh.project(problems.isentropic_vortex)
+    claw.set_initial_condition(u0)
+    ora.set_solution(u0)
+    t = 0.0
+    for it in range(10):
+        dt = claw.compute_time_step()
+        dto = ora.compute_time_step(t)
+        assert abs(dt - dto) <= 1e-13 * dto
+        r0, r1 = claw.iterate_explicit(dt)
+        q0, q1 = ora.step(dt)
+        assert abs(r0 - q0) <= 1e-10 * q0 and abs(r1 - q1) <= 1e-10 * q1
+        t += dt
+    assert rel(claw.current_solution, ora.get_solution()) < 1e-11
+    assert rel(claw.cell_average, ora.get_cell_average()) < 1e-11
+
+
+@pytest.mark.parametrize("degree", [1, 2])
+def test_pk_residual_boundaries(degree):
+    bnd = {0: "farfield", 1: "outflow", 2: "inflow", 3: "slip"}
+    mesh, prm, claw, ora = pk_pair(12, 9, degree, "roe", side_bc=(0, 1, 2, 3), boundary=bnd, h=1.0 / 12, x0=0.0, y0=0.0)
+    u0 = mesh.project(lambda x, y: problems.smooth_perturbation(x, y, L=1.0))
+    claw.set_initial_condition(u0)
+    ora.set_solution(u0)
+    cell, face, bid, xy = claw.boundary_faces()
+    bv = np.stack(problems.smooth_perturbation(xy[..., 0] + 0.01, xy[..., 1] - 0.02, L=1.0), axis=-1)
+    for which in (0, 1):
+        claw.set_boundary_values(which, bv)
+        ora.set_boundary_values(which, bv)
+    assert rel(claw.assemble_system(0), ora.assemble(0)) < 1e-12
+
+
+@pytest.mark.parametrize("degree,char_lim", [(1, True), (2, True), (2, False), (3, True)])
+def test_pk_sod_tvb_positivity(degree, char_lim):
+    """apply_limiter_TVB_Pk + the Pk branch of the positivity limiter (src/limiter.cc:377, src/positivity.cc:100)."""
+    bnd = {0: "slip", 1: "outflow", 2: "inflow"}
+    nx, ny = 64, 8
+    mesh = dflo_amd.Mesh.cartesian(nx, ny, 0.0, 0.0, 1.0 / nx, [2, 1, 0, 0], degree)
+    mesh.set_basis("Pk")
+    prm = dflo_amd.Parameters(flux="hllc", limiter="TVB", char_lim=char_lim, pos_lim=True, M=0.0, beta=2.0, boundary=bnd,
+                              final_time=0.2)
+    claw = dflo_amd.ConservationLaw(mesh, prm)
+    ora = oracle_lib.Oracle(mesh, prm)
+    u0 = mesh.project(problems.sod)
+    cell, face, bid, xy = claw.boundary_faces()
+    bv = np.zeros(xy.shape[:2] + (4,))
+    bv[..., 2] = 1.0
+    bv[..., 3] = 2.5
+    for w in (0, 1):
+        claw.set_boundary_values(w, bv)
+        ora.set_boundary_values(w, bv)
+    claw.set_initial_condition(u0)
+    ora.set_solution(u0)
+    claw.apply_limiter()
+    ora.apply_limiter()
+    assert rel(claw.current_solution, ora.get_solution()) < 1e-13
+    t = 0.0
+    for it in range(25):
+        dt = claw.compute_time_step()
+        dto = ora.compute_time_step(t)
+        assert abs(dt - dto) <= 1e-12 * dto
+        claw.iterate_explicit(dt)
+        ora.step(dt)
+        t += dt
+    u, uo = claw.current_solution, ora.get_solution()
+    assert rel(claw.cell_average, ora.get_cell_average()) < 1e-9
+    assert rel(u, uo) < 1e-7   # the limiter's on/off threshold (1e-10) may flip on round-off in a few cells
+
+
+def test_pk_advance_device_dt():
+    mesh, prm, claw, ora = pk_pair(24, 24, 2, "hllc", cfl=0.8)
+    u0 = mesh.project(problems.isentropic_vortex)
+    claw.set_initial_condition(u0)
+    ora.set_solution(u0)
+    t2 = claw.advance(5)
+    t = 0.0
+    for it in range(5):
+        dt = ora.compute_time_step(t)
+        ora.step(dt)
+        t += dt
+    assert abs(t2 - t) < 1e-12 * t
+    assert rel(claw.current_solution, ora.get_solution()) < 1e-11
+
+
+def test_pk_rejects_mapped_cells():
+    mesh = dflo_amd.Mesh.cartesian(8, 8, 0.0, 0.0, 0.125, [-1, -1, -1, -1], 1)
+    mesh.set_basis("Pk")
+    mesh.set_mapping("q1")
+    with pytest.raises(dflo_amd.DfloError):
+        dflo_amd.ConservationLaw(mesh, dflo_amd.Parameters(flux="lxf"))

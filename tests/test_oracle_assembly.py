@@ -191,3 +191,33 @@ def test_nonsquare_cell_rejected():
     with pytest.raises(O.OracleError) as e:
         O.Oracle(mesh, dflo_amd.Parameters())
     assert e.value.code == -2
+
+
+@pytest.mark.parametrize("degree", [1, 2, 3])
+def test_pk_projection_matches_oracle_shape_tables(degree):
+    """Mesh.project (host mirror of set_initial_condition_Pk, src/ic.cc:128-164) uses the same modal basis, mode
+    order and mass matrix as the oracle's FE_DGP restatement; projecting a P_k polynomial reproduces it."""
+    mesh = dflo_amd.Mesh.cartesian(5, 4, -1.0, 2.0, 0.25, [-1, -1, -1, -1], degree)
+    mesh.set_basis("Pk")
+    ora = O.Oracle(mesh, dflo_amd.Parameters(flux="lxf"))
+    T, ww = mesh.modal_matrix()
+    assert np.abs(T.T - ora.cell_shape()).max() < 1e-14
+    xy, jxw = ora.cell_quadrature()
+    assert np.abs(xy - mesh.support_points()).max() < 1e-14
+    assert np.abs(jxw - ww * 0.25 ** 2).max() < 1e-16
+    inv_mass = np.empty(mesh.n_cells * mesh.ndof)
+    O._lib.dflo_oracle_get_inv_mass(ora._h, O._d(inv_mass))
+    assert np.abs(inv_mass * 0.25 ** 2 - 1.0).max() < 1e-13   # orthonormal modes: M = |K| I
+    k = degree
+
+    def poly(x, y):
+        f = 1.0 + 0.3 * x ** k - 0.2 * y ** k + (0.1 * x * y ** (k - 1) if k > 1 else 0.0)
+        return [0.1 * f, -0.2 * f, 1.0 + 0.05 * f, 2.5 + 0.1 * f]
+
+    u = mesh.project(poly).reshape(mesh.n_cells, 4, -1)
+    back = np.einsum("ncm,qm->ncq", u, T)
+    exact = np.stack(poly(xy[..., 0], xy[..., 1]), axis=1)
+    assert np.abs(back - exact).max() < 1e-12
+    # cell average = mode 0
+    ora.set_solution(u.reshape(-1))
+    assert np.abs(ora.get_cell_average() - u[:, :, 0]).max() < 1e-13
