@@ -60,9 +60,10 @@ struct StageArgs {
   const int4 *shard_hdr;      // {cells, faces, halo cells, 0}
   const int32_t *halo_pad;    // [n_shards][halo_pitch]: internal cell slot | local face << 28
   int halo_pitch, halo_stride;
-  const FaceRec *faces_pad;   // [n_shards][face_pitch]
+  const uint32_t *faces_pad;  // [n_shards][face_pitch] packed face records (pface_*)
+  const int32_t *bnd_pad;     // [n_shards][bnd_pitch] boundary-face index of the shard's l-th boundary face
+  int bnd_pitch;
   int face_pitch;
-  const FaceRec *faces;
   const uint16_t *cell_face;
   const double *cell_h;
   const double *cell_vert;    // GEO 1: [8][n_slots]
@@ -348,18 +349,36 @@ __device__ __forceinline__ void row_update_q1(const StageArgs &a, const double *
 // phase B: one numerical flux per face point of the shard (integrate_face_term_explicit :303-341,
 // integrate_boundary_term_explicit :176-206).  Face-point index p = q * nf + k: neighbouring lanes take
 // neighbouring faces at the same q -> same LDS rows, consecutive slots.  Reads LDS only.
+// packed face record (4 bytes) of the device tables; plan.h's FaceRec is the host-side form
+//   bits 0-8 slot of the integrating cell, 9-10 its local face, 11 boundary, 12 flip,
+//   interior: 13-14 local face of the other cell, 15-23 its slot;  boundary: 13-22 index among the shard's boundary faces
+__host__ __device__ __forceinline__ uint32_t pface_pack(const FaceRec &r) {
+  const uint32_t slot = r.w0 & 0xFFFF, f = (r.w0 >> 16) & 3, bnd = (r.w0 >> 18) & 1, flip = (r.w0 >> 19) & 1;
+  uint32_t w = slot | (f << 9) | (bnd << 11) | (flip << 12);
+  if (bnd) w |= ((r.w0 >> 20) & 0x3FF) << 13;
+  else w |= (((r.w0 >> 20) & 3) << 13) | ((uint32_t)r.w1 << 15);
+  return w;
+}
+__device__ __forceinline__ int pface_slot(uint32_t w) { return w & 0x1FF; }
+__device__ __forceinline__ int pface_face(uint32_t w) { return (w >> 9) & 3; }
+__device__ __forceinline__ bool pface_bnd(uint32_t w) { return (w >> 11) & 1; }
+__device__ __forceinline__ bool pface_flip(uint32_t w) { return (w >> 12) & 1; }
+__device__ __forceinline__ int pface_other_face(uint32_t w) { return (w >> 13) & 3; }
+__device__ __forceinline__ int pface_other_slot(uint32_t w) { return (w >> 15) & 0x1FF; }
+__device__ __forceinline__ int pface_bnd_local(uint32_t w) { return (w >> 13) & 0x3FF; }
+
 template <int N, int FLUX, int GEO>
 __device__ __forceinline__ void flux_phase(const StageArgs &a, const double *Us, const double *Th, double *Fh,
-                                           const FaceRec *Fr, const double *Bv, const int *Bk, const double *Fg,
+                                           const uint32_t *Fr, const double *Bv, const int *Bk, const double *Fg,
                                            const int HS, const int nf, const int tid) {
   constexpr int NS = N * N, NDOF = 4 * NS, NT = 64 * N, S = 65;
   const int nfp = nf * N;
   for (int p = tid; p < nfp; p += NT) {
     const int q = p / nf, k = p - q * nf;
-    const FaceRec r = Fr[k];
-    const int slotL = r.w0 & 0xFFFF, fL = (r.w0 >> 16) & 3;
-    const bool bnd = (r.w0 >> 18) & 1, flip = (r.w0 >> 19) & 1;
-    const int fR = (r.w0 >> 20) & 3;
+    const uint32_t r = Fr[k];
+    const int slotL = pface_slot(r), fL = pface_face(r);
+    const bool bnd = pface_bnd(r), flip = pface_flip(r);
+    const int fR = pface_other_face(r);
     double Wp[4], Wm[4], Ap[4], Am[4], F[4];
     // trace of a cell on its local face f at face point qq: own cells from their DoFs,
     // W = sum_m l_m(0|1) U[m,qq] (x faces) or U[qq,m] (y faces); halo cells from the stored trace
@@ -380,14 +399,14 @@ __device__ __forceinline__ void flux_phase(const StageArgs &a, const double *Us,
         }
         if constexpr (FLUX == DFLO_FLUX_LXF) {
 #pragma unroll
-          for (int c = 0; c < 4; ++c) A[c] = Us[(NDOF + c) * S + slot];
+          for (int c = 0; c < 3; ++c) A[c] = Us[(NDOF + c) * S + slot];
         }
       } else {
 #pragma unroll
         for (int c = 0; c < 4; ++c) W[c] = Th[(c * N + qq) * HS + slot - 64];
         if constexpr (FLUX == DFLO_FLUX_LXF) {
 #pragma unroll
-          for (int c = 0; c < 4; ++c) A[c] = Th[(4 * N + c) * HS + slot - 64];
+          for (int c = 0; c < 3; ++c) A[c] = Th[(4 * N + c) * HS + slot - 64];
         }
       }
     };
@@ -401,15 +420,15 @@ __device__ __forceinline__ void flux_phase(const StageArgs &a, const double *Us,
       ny = Fg[a.max_faces + k];
     }
     if (!bnd) {
-      trace(r.w1, fR, flip ? N - 1 - q : q, Wm, Am);
+      trace(pface_other_slot(r), fR, flip ? N - 1 - q : q, Wm, Am);
     } else {
-      const int bl = (r.w0 >> 20) & 0x3FF;
+      const int bl = pface_bnd_local(r);
       const double *bv = Bv + (bl * N + q) * 4;
       double bvv[4] = {bv[0], bv[1], bv[2], bv[3]};
       compute_Wminus(Bk[bl], nx, ny, Wp, bvv, Wm);
       if constexpr (FLUX == DFLO_FLUX_LXF) {  // both averages are the interior cell's, :200-205
 #pragma unroll
-        for (int c = 0; c < 4; ++c) Am[c] = Ap[c];
+        for (int c = 0; c < 3; ++c) Am[c] = Ap[c];
       }
     }
     numerical_normal_flux<FLUX>(nx, ny, Wp, Wm, Ap, Am, F);
@@ -428,8 +447,8 @@ __device__ __forceinline__ void flux_phase(const StageArgs &a, const double *Us,
 template <int N, int FLUX, int MODE, int GEO>
 __global__ __launch_bounds__(64 * N, (GEO == 1 || N == 4) ? 2 : 3) void stage_kernel(const StageArgs a) {
   constexpr int NS = N * N, NDOF = 4 * NS, NT = 64 * N;
-  constexpr int ROWS = NDOF + (FLUX == DFLO_FLUX_LXF ? 4 : 0);   // LxF: the 4 cell averages ride along
-  constexpr int TROWS = 4 * N + (FLUX == DFLO_FLUX_LXF ? 4 : 0); // halo image: face trace (+ averages)
+  constexpr int ROWS = NDOF + (FLUX == DFLO_FLUX_LXF ? 3 : 0);   // LxF: (u, v, c) of the cell average ride along
+  constexpr int TROWS = 4 * N + (FLUX == DFLO_FLUX_LXF ? 3 : 0); // halo image: face trace (+ the same three)
   constexpr int S = 65;                                          // own-cell row stride: 1 mod 32 doubles
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int sidx = shard_of_block(blockIdx.x, a.n_list);
@@ -442,7 +461,7 @@ __global__ __launch_bounds__(64 * N, (GEO == 1 || N == 4) ? 2 : 3) void stage_ke
   double *Us = lds;                                   // [ROWS][S] DoFs (and averages) of the own cells
   double *Th = Us + ROWS * S;                         // [TROWS][HS] traces of the halo cells on the shared face
   double *Fh = Th + TROWS * HS;                       // [4][max_fp] numerical fluxes
-  FaceRec *Fr = (FaceRec *)(Fh + 4 * a.max_fp);       // [max_faces]
+  uint32_t *Fr = (uint32_t *)(Fh + 4 * a.max_fp);     // [max_faces] (even count)
   double *Bv = (double *)(Fr + a.max_faces);          // [max_bnd][N][4] boundary values of the shard
   int *Bk = (int *)(Bv + a.max_bnd * 4 * N);          // [max_bnd] boundary kinds
   double *Fg = (double *)(Bk + ((a.max_bnd + 1) & ~1)); // GEO 1: [3][max_faces] unit normal and length of the faces
@@ -459,7 +478,7 @@ __global__ __launch_bounds__(64 * N, (GEO == 1 || N == 4) ? 2 : 3) void stage_ke
   {
     const int ahead = min(shard + a.prefetch_ahead, a.n_shards - 1);
     const int32_t *p0 = a.halo_pad + (size_t)ahead * a.halo_pitch + (tid & 31);
-    const FaceRec *p1 = a.faces_pad + (size_t)ahead * a.face_pitch + tid;
+    const uint32_t *p1 = a.faces_pad + (size_t)ahead * a.face_pitch + tid;
     const uint16_t *p2 = a.cell_face + (size_t)ahead * 4 * 64 + 2 * (tid & 127);
     asm volatile("global_load_dword %0, %1, off" : "=v"(pf0) : "v"(p0));
     asm volatile("global_load_dword %0, %1, off" : "=v"(pf1) : "v"(p1));
@@ -487,8 +506,8 @@ __global__ __launch_bounds__(64 * N, (GEO == 1 || N == 4) ? 2 : 3) void stage_ke
       for (int c = 0; c < 4; ++c) uavg[c] = a.avg_cur[((size_t)shard * 4 + c) * 64 + lane];
     }
   }
-  const FaceRec *fp = a.faces_pad + (size_t)shard * a.face_pitch;
-  const FaceRec fr0 = fp[tid], fr1 = fp[tid + NT];
+  const uint32_t *fp = a.faces_pad + (size_t)shard * a.face_pitch;
+  const uint32_t fr0 = fp[tid], fr1 = fp[tid + NT];
   uint16_t cref[4];
 #pragma unroll
   for (int f = 0; f < 4; ++f) cref[f] = a.cell_face[((size_t)shard * 4 + f) * 64 + lane];
@@ -525,11 +544,16 @@ __global__ __launch_bounds__(64 * N, (GEO == 1 || N == 4) ? 2 : 3) void stage_ke
     for (int m = 0; m < N; ++m) v += CB<N>::t.L0[m] * hp[(base + m * str) * 64];
     Th[(c * N + q) * HS + sl] = v;
   }
-  if constexpr (FLUX == DFLO_FLUX_LXF) {
-    for (int i = tid; i < nh * 4; i += NT) {
-      const int sl = i % nh, c = i / nh;
-      const int ic = a.halo_pad[(size_t)shard * a.halo_pitch + sl] & 0x0FFFFFFF;
-      Th[(4 * N + c) * HS + sl] = a.avg_cur[((size_t)(ic >> 6) * 4 + c) * 64 + (ic & 63)];
+  if constexpr (FLUX == DFLO_FLUX_LXF) {  // lambda of the LxF flux comes from the cell averages (src/equation.h:357-359):
+                                          // keep (u, v, c) of each average instead of the four components
+    for (int sl = tid; sl < nh; sl += NT) {
+      const int ic = (sl < 32 ? hent[0] : a.halo_pad[(size_t)shard * a.halo_pitch + sl]) & 0x0FFFFFFF;
+      double A[4], uvc[3];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) A[c] = a.avg_cur[((size_t)(ic >> 6) * 4 + c) * 64 + (ic & 63)];
+      wave_speed_uvc(A, uvc);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) Th[(4 * N + c) * HS + sl] = uvc[c];
     }
   }
 #pragma unroll
@@ -539,8 +563,10 @@ __global__ __launch_bounds__(64 * N, (GEO == 1 || N == 4) ? 2 : 3) void stage_ke
   asm volatile("" ::"v"(pf0), "v"(pf1), "v"(pf2));  // the touch loads (oldest in the queue) have landed by now
   if constexpr (FLUX == DFLO_FLUX_LXF) {
     if (row == 0) {
+      double uvc[3];
+      wave_speed_uvc(uavg, uvc);
 #pragma unroll
-      for (int c = 0; c < 4; ++c) Us[(NDOF + c) * S + lane] = uavg[c];
+      for (int c = 0; c < 3; ++c) Us[(NDOF + c) * S + lane] = uvc[c];
     }
   }
   if (tid < nf) Fr[tid] = fr0;
@@ -554,13 +580,11 @@ __global__ __launch_bounds__(64 * N, (GEO == 1 || N == 4) ? 2 : 3) void stage_ke
     }
   }
   if (nbnd > 0) {  // boundary values and kinds of this shard's boundary faces
-    for (int i = tid; i < nf; i += NT) {
-      const FaceRec r = fp[i];
-      if ((r.w0 >> 18) & 1) {
-        const int bl = (r.w0 >> 20) & 0x3FF, bf = r.w1;
-        Bk[bl] = a.bface_kind[bf];
-        for (int k2 = 0; k2 < 4 * N; ++k2) Bv[bl * 4 * N + k2] = a.bval[(size_t)bf * 4 * N + k2];
-      }
+    for (int i = tid; i < nbnd * 4 * N; i += NT) {
+      const int bl = i / (4 * N), k2 = i - bl * 4 * N;
+      const int bf = a.bnd_pad[(size_t)shard * a.bnd_pitch + bl];
+      if (k2 == 0) Bk[bl] = a.bface_kind[bf];
+      Bv[i] = a.bval[(size_t)bf * 4 * N + k2];
     }
   }
   PHASE_MARK(1);
@@ -970,8 +994,8 @@ __device__ __forceinline__ void row_update_pk(const StageArgs &a, double *Us, co
 template <int N, int FLUX, int MODE>
 __global__ __launch_bounds__(64 * N, N == 4 ? 2 : 3) void stage_kernel_pk(const StageArgs a) {
   constexpr int NS = N * N, NM = N * (N + 1) / 2, NDOFM = 4 * NM, NT = 64 * N, MS = (NM + N - 1) / N;
-  constexpr int ROWS = 4 * NS + (FLUX == DFLO_FLUX_LXF ? 4 : 0);
-  constexpr int TROWS = 4 * N + (FLUX == DFLO_FLUX_LXF ? 4 : 0);
+  constexpr int ROWS = 4 * NS + (FLUX == DFLO_FLUX_LXF ? 3 : 0);
+  constexpr int TROWS = 4 * N + (FLUX == DFLO_FLUX_LXF ? 3 : 0);
   constexpr int S = 65;
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int sidx = shard_of_block(blockIdx.x, a.n_list);
@@ -984,7 +1008,7 @@ __global__ __launch_bounds__(64 * N, N == 4 ? 2 : 3) void stage_kernel_pk(const 
   double *Us = lds;
   double *Th = Us + ROWS * S;
   double *Fh = Th + TROWS * HS;
-  FaceRec *Fr = (FaceRec *)(Fh + 4 * a.max_fp);
+  uint32_t *Fr = (uint32_t *)(Fh + 4 * a.max_fp);
   double *Bv = (double *)(Fr + a.max_faces);
   int *Bk = (int *)(Bv + a.max_bnd * 4 * N);
 
@@ -1011,8 +1035,8 @@ __global__ __launch_bounds__(64 * N, N == 4 ? 2 : 3) void stage_kernel_pk(const 
       for (int c = 0; c < 4; ++c) uavg[c] = a.avg_cur[((size_t)shard * 4 + c) * 64 + lane];
     }
   }
-  const FaceRec *fp = a.faces_pad + (size_t)shard * a.face_pitch;
-  const FaceRec fr0 = fp[tid], fr1 = fp[tid + NT];
+  const uint32_t *fp = a.faces_pad + (size_t)shard * a.face_pitch;
+  const uint32_t fr0 = fp[tid], fr1 = fp[tid + NT];
   uint16_t cref[4];
 #pragma unroll
   for (int f = 0; f < 4; ++f) cref[f] = a.cell_face[((size_t)shard * 4 + f) * 64 + lane];
@@ -1059,11 +1083,16 @@ __global__ __launch_bounds__(64 * N, N == 4 ? 2 : 3) void stage_kernel_pk(const 
     for (int m = 0; m < NM; ++m) v += pxi[PB<N>::t.mi[m]] * peta[PB<N>::t.mj[m]] * hp[m * 64];
     Th[(c * N + q) * HS + sl] = v;
   }
-  if constexpr (FLUX == DFLO_FLUX_LXF) {
-    for (int i = tid; i < nh * 4; i += NT) {
-      const int sl = i % nh, c = i / nh;
-      const int ic = a.halo_pad[(size_t)shard * a.halo_pitch + sl] & 0x0FFFFFFF;
-      Th[(4 * N + c) * HS + sl] = a.avg_cur[((size_t)(ic >> 6) * 4 + c) * 64 + (ic & 63)];
+  if constexpr (FLUX == DFLO_FLUX_LXF) {  // lambda of the LxF flux comes from the cell averages (src/equation.h:357-359):
+                                          // keep (u, v, c) of each average instead of the four components
+    for (int sl = tid; sl < nh; sl += NT) {
+      const int ic = (sl < 32 ? hent[0] : a.halo_pad[(size_t)shard * a.halo_pitch + sl]) & 0x0FFFFFFF;
+      double A[4], uvc[3];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) A[c] = a.avg_cur[((size_t)(ic >> 6) * 4 + c) * 64 + (ic & 63)];
+      wave_speed_uvc(A, uvc);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) Th[(4 * N + c) * HS + sl] = uvc[c];
     }
   }
 #pragma unroll
@@ -1072,21 +1101,21 @@ __global__ __launch_bounds__(64 * N, N == 4 ? 2 : 3) void stage_kernel_pk(const 
     for (int m = 0; m < N; ++m) Us[(c * NS + m + N * row) * S + lane] = urow[c][m];
   if constexpr (FLUX == DFLO_FLUX_LXF) {
     if (row == 0) {
+      double uvc[3];
+      wave_speed_uvc(uavg, uvc);
 #pragma unroll
-      for (int c = 0; c < 4; ++c) Us[(4 * NS + c) * S + lane] = uavg[c];
+      for (int c = 0; c < 3; ++c) Us[(4 * NS + c) * S + lane] = uvc[c];
     }
   }
   if (tid < nf) Fr[tid] = fr0;
   if (tid + NT < nf) Fr[tid + NT] = fr1;
   for (int i = tid + 2 * NT; i < nf; i += NT) Fr[i] = fp[i];
   if (nbnd > 0) {
-    for (int i = tid; i < nf; i += NT) {
-      const FaceRec r = fp[i];
-      if ((r.w0 >> 18) & 1) {
-        const int bl = (r.w0 >> 20) & 0x3FF, bf = r.w1;
-        Bk[bl] = a.bface_kind[bf];
-        for (int k2 = 0; k2 < 4 * N; ++k2) Bv[bl * 4 * N + k2] = a.bval[(size_t)bf * 4 * N + k2];
-      }
+    for (int i = tid; i < nbnd * 4 * N; i += NT) {
+      const int bl = i / (4 * N), k2 = i - bl * 4 * N;
+      const int bf = a.bnd_pad[(size_t)shard * a.bnd_pitch + bl];
+      if (k2 == 0) Bk[bl] = a.bface_kind[bf];
+      Bv[i] = a.bval[(size_t)bf * 4 * N + k2];
     }
   }
   __syncthreads();
@@ -1527,7 +1556,9 @@ struct dflo_hip_engine {
   double *bval[2] = {nullptr, nullptr};
   int32_t *bface_kind = nullptr;
   int32_t *d_shard_count = nullptr, *d_halo_begin = nullptr, *d_halo_cells = nullptr, *d_face_begin = nullptr;
-  FaceRec *d_faces = nullptr, *d_faces_pad = nullptr;
+  uint32_t *d_faces_pad = nullptr;
+  int32_t *d_bnd_pad = nullptr;
+  int bnd_pitch = 1;
   int4 *d_shard_hdr = nullptr;
   int32_t *d_halo_pad = nullptr;
   int face_pitch = 0, halo_pitch = 0, halo_stride = 0;
@@ -1735,7 +1766,8 @@ int launch_update(dflo_hip_engine *h, double *rhs_out, int part) {
   a.halo_stride = h->halo_stride;
   a.faces_pad = h->d_faces_pad;
   a.face_pitch = h->face_pitch;
-  a.faces = h->d_faces;
+  a.bnd_pad = h->d_bnd_pad;
+  a.bnd_pitch = h->bnd_pitch;
   a.cell_face = h->d_cell_face;
   a.cell_h = h->d_cell_h;
   a.cell_vert = h->d_cell_vert;
@@ -1755,8 +1787,8 @@ int launch_update(dflo_hip_engine *h, double *rhs_out, int part) {
   a.n_shards = p.n_shards;
   a.stride = h->stride;
   a.max_fp = h->max_fp;
-  a.max_faces = std::max(h->plan.max_faces, 1);
   a.max_bnd = h->plan.max_bnd;
+  a.max_faces = (std::max(h->plan.max_faces, 1) + 1) & ~1;
   a.prefetch_ahead = h->prefetch_ahead;
   a.uniform_h = p.uniform_h ? 1 : 0;
   a.want_dt = last ? 1 : 0;
@@ -1962,7 +1994,6 @@ int dflo_hip_create(const dflo_mesh_t *mesh, const dflo_params_t *params, int de
   if ((rc = upload(h, &h->d_halo_begin, p.halo_begin))) return bail(rc);
   if ((rc = upload(h, &h->d_halo_cells, p.halo_cells))) return bail(rc);
   if ((rc = upload(h, &h->d_face_begin, p.face_begin))) return bail(rc);
-  if ((rc = upload(h, &h->d_faces, p.faces))) return bail(rc);
   if ((rc = upload(h, &h->d_cell_face, p.cell_face))) return bail(rc);
   {  // fixed-pitch copies of the per-shard lists (+2 shards of slack: the kernel reads two shards ahead,
      // and 2*64*N face slots per shard so that unconditional loads stay in bounds)
@@ -1972,17 +2003,24 @@ int dflo_hip_create(const dflo_mesh_t *mesh, const dflo_params_t *params, int de
     h->halo_pitch = std::max(p.max_halo, 1);
     std::vector<int4> hdr(ns, int4{0, 0, 0, 0});
     std::vector<int32_t> hp((size_t)ns * h->halo_pitch, 0);
-    std::vector<FaceRec> fpad((size_t)ns * h->face_pitch, FaceRec{0, 0});
+    std::vector<uint32_t> fpad((size_t)ns * h->face_pitch, 0u);
+    h->bnd_pitch = std::max(p.max_bnd, 1);
+    std::vector<int32_t> bpad((size_t)ns * h->bnd_pitch, 0);
     for (int sidx = 0; sidx < p.n_shards; ++sidx) {
       const int nh = p.halo_begin[sidx + 1] - p.halo_begin[sidx], nf = p.face_begin[sidx + 1] - p.face_begin[sidx];
       hdr[sidx] = int4{p.shard_count[sidx], nf, nh, p.shard_bnd[sidx]};
       for (int k = 0; k < nh; ++k)
         hp[(size_t)sidx * h->halo_pitch + k] = p.halo_cells[p.halo_begin[sidx] + k] | (p.halo_faces[p.halo_begin[sidx] + k] << 28);
-      for (int k = 0; k < nf; ++k) fpad[(size_t)sidx * h->face_pitch + k] = p.faces[p.face_begin[sidx] + k];
+      for (int k = 0; k < nf; ++k) {
+        const FaceRec &r = p.faces[p.face_begin[sidx] + k];
+        fpad[(size_t)sidx * h->face_pitch + k] = pface_pack(r);
+        if ((r.w0 >> 18) & 1) bpad[(size_t)sidx * h->bnd_pitch + ((r.w0 >> 20) & 0x3FF)] = r.w1;
+      }
     }
     if ((rc = upload(h, &h->d_shard_hdr, hdr))) return bail(rc);
     if ((rc = upload(h, &h->d_halo_pad, hp))) return bail(rc);
     if ((rc = upload(h, &h->d_faces_pad, fpad))) return bail(rc);
+    if ((rc = upload(h, &h->d_bnd_pad, bpad))) return bail(rc);
     if (h->geo == 1) {  // face geometry at the same pitch, [shard][3][face_pitch]
       std::vector<double> gpad((size_t)ns * 3 * h->face_pitch, 0.0);
       for (int sidx = 0; sidx < p.n_shards; ++sidx) {
@@ -2022,10 +2060,11 @@ int dflo_hip_create(const dflo_mesh_t *mesh, const dflo_params_t *params, int de
   h->halo_stride = std::max(p.max_halo, 1) | 1;  // odd stride: the trace rows fall on different LDS banks
   h->max_fp = std::max(std::max(p.max_faces, 1) * h->N, 5 * 64 * h->N / 4 + 1);  // Fh also hosts the row partials
   {
-    const int rows = 4 * h->N * h->N + (h->prm.flux_type == DFLO_FLUX_LXF ? 4 : 0);  // nodal image (also for Pk)
-    const int trows = 4 * h->N + (h->prm.flux_type == DFLO_FLUX_LXF ? 4 : 0);
-    h->lds_bytes = ((size_t)rows * 65 + (size_t)trows * h->halo_stride + 4 * (size_t)h->max_fp + (size_t)std::max(p.max_faces, 1) +
-                    (size_t)p.max_bnd * (4 * h->N + 1) + 2 + (h->geo == 1 ? 3 * (size_t)std::max(p.max_faces, 1) : 0)) * sizeof(double);
+    const int rows = 4 * h->N * h->N + (h->prm.flux_type == DFLO_FLUX_LXF ? 3 : 0);  // nodal image (also for Pk)
+    const int trows = 4 * h->N + (h->prm.flux_type == DFLO_FLUX_LXF ? 3 : 0);
+    const size_t mf = (std::max(p.max_faces, 1) + 1) & ~1;   // = StageArgs::max_faces
+    h->lds_bytes = ((size_t)rows * 65 + (size_t)trows * h->halo_stride + 4 * (size_t)h->max_fp + mf / 2 +
+                    (size_t)p.max_bnd * 4 * h->N + (p.max_bnd + 2) / 2 + (h->geo == 1 ? 3 * mf : 0)) * sizeof(double);
   }
 
   if (h->lds_bytes > 160 * 1024) { h->err = "shard halo too large for LDS"; return bail(DFLO_ERR_UNSUPPORTED); }
@@ -2065,7 +2104,7 @@ int dflo_hip_destroy(dflo_hip_handle h) {
   for (int i = 0; i < 2; ++i) { hipFree(h->avg[i]); hipFree(h->bval[i]); }
   hipFree(h->rhs); hipFree(h->user_buf); hipFree(h->bface_kind);
   hipFree(h->d_shard_count); hipFree(h->d_halo_begin); hipFree(h->d_halo_cells); hipFree(h->d_face_begin);
-  hipFree(h->d_faces); hipFree(h->d_faces_pad); hipFree(h->d_shard_hdr); hipFree(h->d_halo_pad); hipFree(h->d_cell_face); hipFree(h->d_lrbt); hipFree(h->d_user_of); hipFree(h->d_iid);
+  hipFree(h->d_bnd_pad); hipFree(h->d_faces_pad); hipFree(h->d_shard_hdr); hipFree(h->d_halo_pad); hipFree(h->d_cell_face); hipFree(h->d_lrbt); hipFree(h->d_user_of); hipFree(h->d_iid);
   hipFree(h->d_rim_list); hipFree(h->d_int_list);
   hipFree(h->d_cell_h); hipFree(h->d_dt_cell); hipFree(h->d_cell_vert); hipFree(h->d_fgeom_pad); hipFree(h->shard_res); hipFree(h->shard_dtmin); hipFree(h->res_sq); hipFree(h->dt_dev);
   hipFree(h->flags); hipFree(h->d_send_slots); hipFree(h->ghost_stage);

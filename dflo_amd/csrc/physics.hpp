@@ -99,7 +99,17 @@ __device__ __forceinline__ double max_eigenvalue(const double *W) {
   return fsqrt0(q2) * ri + fsqrt(kGamma * p * ri);
 }
 
-// src/equation.h:326-377; lambda comes from the two CELL AVERAGES Ap, Am (src/equation.h:357-359)
+// (u, v, c) of a cell average: what max_eigenvalue(W, n) = |v.n| + c (src/equation.h:122-137) needs
+__device__ __forceinline__ void wave_speed_uvc(const double *W, double *uvc) {
+  const double ri = frcp(W[RHO]);
+  const double p = kG1 * (W[EN] - 0.5 * (W[MX] * W[MX] + W[MY] * W[MY]) * ri);
+  uvc[0] = W[MX] * ri;
+  uvc[1] = W[MY] * ri;
+  uvc[2] = fsqrt(kGamma * p * ri);
+}
+
+// src/equation.h:326-377; lambda comes from the two CELL AVERAGES (src/equation.h:357-359), handed over as
+// Ap, Am = (u, v, c) of the averages
 __device__ __forceinline__ void lxf_flux(double nx, double ny, const double *Wp, const double *Wm, const double *Ap,
                                          const double *Am, double *F) {
   const double rp = frcp(Wp[RHO]), rm = frcp(Wm[RHO]);
@@ -107,7 +117,7 @@ __device__ __forceinline__ void lxf_flux(double nx, double ny, const double *Wp,
   const double vm = (Wm[MX] * nx + Wm[MY] * ny) * rm;
   const double pp = kG1 * (Wp[EN] - 0.5 * (Wp[MX] * Wp[MX] + Wp[MY] * Wp[MY]) * rp);
   const double pm = kG1 * (Wm[EN] - 0.5 * (Wm[MX] * Wm[MX] + Wm[MY] * Wm[MY]) * rm);
-  const double lambda = fmax(max_eigenvalue_n(Ap, nx, ny), max_eigenvalue_n(Am, nx, ny));
+  const double lambda = fmax(fabs(Ap[0] * nx + Ap[1] * ny) + Ap[2], fabs(Am[0] * nx + Am[1] * ny) + Am[2]);
   F[MX] = 0.5 * (pp * nx + Wp[MX] * vp + pm * nx + Wm[MX] * vm);
   F[MY] = 0.5 * (pp * ny + Wp[MY] * vp + pm * ny + Wm[MY] * vm);
   F[RHO] = 0.5 * (Wp[RHO] * vp + Wm[RHO] * vm);
