@@ -55,8 +55,8 @@ def cpu_baseline(threads, nx=160, steps=2):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--nx", type=int, default=1024, help="cells per direction per GPU")
     ap.add_argument("--degree", type=int, default=2)
     ap.add_argument("--flux", default="hllc")

@@ -17,6 +17,7 @@ MAX_BOUNDARIES = 10
 FLUX = {"lxf": 0, "sw": 1, "kfvs": 2, "roe": 3, "hllc": 4}            # src/parameters.h:229
 BC = {"inflow": 0, "outflow": 1, "slip": 2, "pressure": 3, "farfield": 4}  # src/equation.h:862-869
 LIMITER = {"none": 0, "TVB": 1}
+SHOCK_INDICATOR = {"limiter": 0, "density": 1, "energy": 2, "u2": 3}
 BASIS = {"Qk": 0, "Pk": 1}
 MAPPING = {"q1": 0, "q2": 1, "cartesian": 2}
 NBR_NONE = -1000000
@@ -51,6 +52,7 @@ class ParamsStruct(C.Structure):
         ("gravity", C.c_double), ("cfl", C.c_double), ("time_step", C.c_double), ("final_time", C.c_double),
         ("M", C.c_double), ("beta", C.c_double),
         ("bc_kind", C.c_int32 * MAX_BOUNDARIES),
+        ("shock_indicator", C.c_int32), ("reserved_", C.c_int32),
     ]
 
 
@@ -61,7 +63,7 @@ SYMBOLS = [
     "dflo_hip_get_cell_average", "dflo_hip_n_boundary_faces", "dflo_hip_boundary_faces",
     "dflo_hip_set_boundary_values", "dflo_hip_residual", "dflo_hip_compute_dt", "dflo_hip_step", "dflo_hip_stage",
     "dflo_hip_end_step", "dflo_hip_advance", "dflo_hip_compute_cell_average", "dflo_hip_apply_limiter",
-    "dflo_hip_apply_positivity_limiter", "dflo_hip_check", "dflo_hip_synchronize", "dflo_hip_stage_timing",
+    "dflo_hip_apply_positivity_limiter", "dflo_hip_compute_shock_indicator", "dflo_hip_get_shock_indicator", "dflo_hip_check", "dflo_hip_synchronize", "dflo_hip_stage_timing",
     "dflo_hip_set_send_cells", "dflo_hip_pack_send", "dflo_hip_pack_send_avg", "dflo_hip_unpack_ghost",
     "dflo_hip_unpack_ghost_avg", "dflo_hip_n_ghost_cells", "dflo_hip_stage_update", "dflo_hip_stage_limit",
     "dflo_hip_stage_open", "dflo_hip_stage_update_part", "dflo_hip_stage_limit_part", "dflo_hip_stage_finish",
@@ -114,6 +116,8 @@ _sig("dflo_hip_advance", C.c_int, _H, C.c_int, _dp)
 _sig("dflo_hip_compute_cell_average", C.c_int, _H)
 _sig("dflo_hip_apply_limiter", C.c_int, _H)
 _sig("dflo_hip_apply_positivity_limiter", C.c_int, _H)
+_sig("dflo_hip_compute_shock_indicator", C.c_int, _H)
+_sig("dflo_hip_get_shock_indicator", C.c_int, _H, _dp)
 _sig("dflo_hip_check", C.c_int, _H)
 _sig("dflo_hip_synchronize", C.c_int, _H)
 _sig("dflo_hip_stage_timing", C.c_int, _H, C.c_int, _dp, C.POINTER(C.c_int64))

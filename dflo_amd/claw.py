@@ -118,6 +118,17 @@ class ConservationLaw:
     def apply_positivity_limiter(self):
         self._chk(lib.dflo_hip_apply_positivity_limiter(self._h))
 
+    def compute_shock_indicator(self):
+        """KXRCF indicator of the current solution (src/indicator.cc:17-198); returns shock_indicator[n_cells]."""
+        self._chk(lib.dflo_hip_compute_shock_indicator(self._h))
+        return self.shock_indicator
+
+    @property
+    def shock_indicator(self):
+        a = np.empty(self.mesh.n_cells)
+        self._chk(lib.dflo_hip_get_shock_indicator(self._h, _lib.dptr(a)))
+        return a
+
     def synchronize(self):
         self._chk(lib.dflo_hip_synchronize(self._h))
 

@@ -17,6 +17,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -673,6 +674,7 @@ struct LimArgs {
   int n_shards, uniform_h, tvb, char_lim, pos_lim;
   const int32_t *shard_list;
   int n_list;
+  const double *shock;  // KXRCF indicator per cell, or null: "shock indicator = limiter" marks every cell (1e20)
   KBasis kb;
 };
 
@@ -696,7 +698,7 @@ __global__ __launch_bounds__(64) void limiter_kernel(const LimArgs a) {
   const double h = a.uniform_h ? a.h_uniform : a.cell_h[(size_t)shard * 64 + lane];
   bool changed = false;
 
-  if (a.tvb) {
+  if (a.tvb && (!a.shock || a.shock[(size_t)shard * 64 + lane] > 1.0)) {  // src/limiter.cc:263,406
     const double dx = h;  // diameter/sqrt(2) of a square
     const double Mdx2 = a.M * dx * dx;
     double Dx[4], Dy[4], dbx[4], dfx[4], dby[4], dfy[4];
@@ -1185,7 +1187,7 @@ __global__ __launch_bounds__(64) void limiter_pk_kernel(const LimArgs a) {
   const double h = a.uniform_h ? a.h_uniform : a.cell_h[(size_t)shard * 64 + lane];
   bool changed = false;
   const double sqrt_3 = 1.7320508075688772935;
-  if (a.tvb) {
+  if (a.tvb && (!a.shock || a.shock[(size_t)shard * 64 + lane] > 1.0)) {  // src/limiter.cc:263,406
     const double dx = h, Mdx2 = a.M * dx * dx, beta = 0.5 * a.beta;   // :396
     double Dx[4], Dy[4], dbx[4], dfx[4], dby[4], dfy[4];
 #pragma unroll
@@ -1303,6 +1305,84 @@ __global__ __launch_bounds__(64) void limiter_pk_kernel(const LimArgs a) {
 #pragma unroll
       for (int m = 1; m < NM; ++m) up[(c * NM + m) * 64] = U[c][m];
   }
+}
+
+// ------------------------------------------------------------------ KXRCF troubled-cell indicator
+struct IndArgs {
+  const double *U, *avg;
+  double *shock;  // [n_slots]
+  const int32_t *shard_count, *lrbt;
+  const uint8_t *nbr_code;
+  const double *cell_h;
+  double h_uniform;
+  int uniform_h, component, degree;
+  const int32_t *shard_list;
+  int n_list;
+};
+
+// value of one component at point q of local face f: Qk from the nodes on the line through the face point,
+// Pk from all modes; u points at the component's first DoF of the cell (DoF stride 64)
+template <int N, int PK>
+__device__ __forceinline__ double face_point_value(const double *u, int f, int q) {
+  double v = 0.0;
+  if constexpr (PK == 0) {
+    const int str0 = f < 2 ? 1 : N;
+    const int base = (f < 2 ? N * q : q) + ((f & 1) ? (N - 1) * str0 : 0), str = (f & 1) ? -str0 : str0;
+#pragma unroll
+    for (int m = 0; m < N; ++m) v += CB<N>::t.L0[m] * u[(base + m * str) * 64];
+  } else {
+    constexpr int NM = N * (N + 1) / 2;
+    double pxi[N], peta[N];
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+      double pq = PB<N>::t.Px[0][n];
+#pragma unroll
+      for (int qq = 1; qq < N; ++qq) pq = q == qq ? PB<N>::t.Px[qq][n] : pq;
+      pxi[n] = f == 0 ? PB<N>::t.P0[n] : (f == 1 ? PB<N>::t.P1[n] : pq);
+      peta[n] = f == 2 ? PB<N>::t.P0[n] : (f == 3 ? PB<N>::t.P1[n] : pq);
+    }
+#pragma unroll
+    for (int m = 0; m < NM; ++m) v += pxi[PB<N>::t.mi[m]] * peta[PB<N>::t.mj[m]] * u[m * 64];
+  }
+  return v;
+}
+
+// compute_shock_indicator_kxrcf (src/indicator.cc:51-198), same-level faces, axis-aligned squares; lane = cell.
+// Runs as its own pass between the stage update and the limiter: it reads the neighbours' unlimited DoFs.
+template <int N, int PK>
+__global__ __launch_bounds__(64) void indicator_kernel(const IndArgs a) {
+  constexpr int NS = PK ? N * (N + 1) / 2 : N * N, NDOF = 4 * NS;
+  const int sidx = shard_of_block(blockIdx.x, a.n_list);
+  if (sidx < 0) return;
+  const int shard = a.shard_list ? a.shard_list[sidx] : sidx;
+  const int lane = threadIdx.x;
+  if (lane >= a.shard_count[shard]) return;
+  double A[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) A[c] = a.avg[((size_t)shard * 4 + c) * 64 + lane];
+  const double vel[2] = {A[MX] / A[RHO], A[MY] / A[RHO]};  // :106-108
+  const double h = a.uniform_h ? a.h_uniform : a.cell_h[(size_t)shard * 64 + lane];
+  const double *uo = a.U + ((size_t)shard * NDOF + a.component * NS) * 64 + lane;
+  double ind = 0.0, inflow = 0.0;
+  for (int f = 0; f < 4; ++f) {
+    const int code = a.nbr_code[((size_t)shard * 4 + f) * 64 + lane];
+    if (!(code & 8)) continue;  // boundary (or periodic) face, :169-174
+    const int ns = a.lrbt[((size_t)shard * 4 + f) * 64 + lane], nf = code & 3;
+    const bool flip = (code & 4) != 0;
+    const double *un = a.U + ((size_t)(ns >> 6) * NDOF + a.component * NS) * 64 + (ns & 63);
+    const double vn = f == 0 ? -vel[0] : (f == 1 ? vel[0] : (f == 2 ? -vel[1] : vel[1]));
+    const double inflow_status = vn < 0 ? 1.0 : 0.0;
+#pragma unroll
+    for (int q = 0; q < N; ++q) {
+      const double jxw = CB<N>::t.w[q] * h;
+      const double d = face_point_value<N, PK>(uo, f, q) - face_point_value<N, PK>(un, nf, flip ? N - 1 - q : q);
+      ind += inflow_status * d * jxw;
+      inflow += inflow_status * jxw;
+    }
+  }
+  const double diameter = h * 1.4142135623730950488;
+  const double denominator = pow(diameter, 0.5 * (a.degree + 1)) * inflow * A[a.component];  // :179-181
+  a.shock[(size_t)shard * 64 + lane] = fabs(ind) / denominator;  // 0/0 -> NaN -> "not > 1": not limited, as in the reference
 }
 
 // accuracy probe of the reciprocal / square-root forms used by the flux functions
@@ -1469,23 +1549,30 @@ struct FinalArgs {
   const double *shard_res, *shard_dtmin;
   double *res_sq;  // [3] per stage
   double *dt_dev;  // [0] dt, [1] elapsed time, [2] raw min before rules
-  int n_shards, stage, do_res, do_dt, advance_time, global_rules;
+  int n_shards, n_stages, res_stride, do_dt, advance_time, global_rules;  // shard_res: [n_stages][res_stride]
   double time_step, final_time, dt_host;
 };
 __global__ __launch_bounds__(1024) void finalize_kernel(const FinalArgs a) {
-  __shared__ double sres[16], smin[16];
+  __shared__ double sres[3][16], smin[16];
   // fixed assignment of shards to threads and a fixed combination tree -> deterministic sums;
-  // four independent loads per trip keep the (single) workgroup from serialising on latency
-  double r0 = 0.0, r1 = 0.0, r2 = 0.0, r3 = 0.0, m = 1.0e20;
+  // four independent loads per trip keep the (single) workgroup from serialising on latency.
+  // The residual partials of all stages of the step are reduced here, once per step.
+  double rs[3] = {0.0, 0.0, 0.0}, m = 1.0e20;
   const int n = a.n_shards, t = threadIdx.x;
+  for (int st = 0; st < a.n_stages; ++st) {
+    const double *sr = a.shard_res + (size_t)st * a.res_stride;
+    double r0 = 0.0, r1 = 0.0, r2 = 0.0, r3 = 0.0;
+    for (int s = t; s < n; s += 4096) {
+      const int s1 = s + 1024, s2 = s + 2048, s3 = s + 3072;
+      r0 += sr[s];
+      if (s1 < n) r1 += sr[s1];
+      if (s2 < n) r2 += sr[s2];
+      if (s3 < n) r3 += sr[s3];
+    }
+    rs[st] = (r0 + r1) + (r2 + r3);
+  }
   for (int s = t; s < n; s += 4096) {
     const int s1 = s + 1024, s2 = s + 2048, s3 = s + 3072;
-    if (a.do_res) {
-      r0 += a.shard_res[s];
-      if (s1 < n) r1 += a.shard_res[s1];
-      if (s2 < n) r2 += a.shard_res[s2];
-      if (s3 < n) r3 += a.shard_res[s3];
-    }
     if (a.do_dt) {
       double m0 = a.shard_dtmin[s];
       if (s1 < n) m0 = fmin(m0, a.shard_dtmin[s1]);
@@ -1494,18 +1581,18 @@ __global__ __launch_bounds__(1024) void finalize_kernel(const FinalArgs a) {
       m = fmin(m, m0);
     }
   }
-  double r = wave_sum((r0 + r1) + (r2 + r3));
-  m = wave_min(m);
-  if ((t & 63) == 0) {
-    sres[t >> 6] = r;
-    smin[t >> 6] = m;
+  for (int st = 0; st < a.n_stages; ++st) {
+    const double r = wave_sum(rs[st]);
+    if ((t & 63) == 0) sres[st][t >> 6] = r;
   }
+  m = wave_min(m);
+  if ((t & 63) == 0) smin[t >> 6] = m;
   __syncthreads();
   if (t == 0) {
-    if (a.do_res) {
+    for (int st = 0; st < a.n_stages; ++st) {
       double tot = 0.0;
-      for (int i = 0; i < 16; ++i) tot += sres[i];
-      a.res_sq[a.stage] = tot;
+      for (int i = 0; i < 16; ++i) tot += sres[st][i];
+      a.res_sq[st] = tot;
     }
     if (a.do_dt) {
       double tt = a.dt_dev[1];
@@ -1557,6 +1644,8 @@ struct dflo_hip_engine {
   int32_t *bface_kind = nullptr;
   int32_t *d_shard_count = nullptr, *d_halo_begin = nullptr, *d_halo_cells = nullptr, *d_face_begin = nullptr;
   uint32_t *d_faces_pad = nullptr;
+  uint8_t *d_nbr_code = nullptr;
+  double *d_shock = nullptr;  // [n_slots], only for shock indicator = density | energy
   int32_t *d_bnd_pad = nullptr;
   int bnd_pitch = 1;
   int4 *d_shard_hdr = nullptr;
@@ -1585,6 +1674,12 @@ struct dflo_hip_engine {
   int stride = 0, max_fp = 0;
   // timing
   bool timing = false;
+  // dflo_hip_advance replays a captured graph of `graph_steps` time steps (the buffer rotation repeats with
+  // that period); built lazily for the state it was captured in
+  hipGraphExec_t graph_exec = nullptr;
+  int graph_steps = 0, graph_cur = -1, graph_avg = -1;
+  hipStream_t graph_stream = nullptr;
+  bool use_graph = false;  // opt-in (DFLO_GRAPH=1): on ROCm 7.2 / MI355X replay measured no faster than plain launches
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
   size_t ev_used = 0;
   double t_accum_ms = 0;
@@ -1777,7 +1872,7 @@ int launch_update(dflo_hip_engine *h, double *rhs_out, int part) {
   a.bface_kind = h->bface_kind;
   a.dt_dev = h->dt_dev;
   a.dt_cell = h->d_dt_cell;  // null unless "time step type = local"
-  a.shard_res = h->shard_res;
+  a.shard_res = h->shard_res + (size_t)rk * std::max(h->plan.n_shards, 1);
   a.shard_dtmin = h->shard_dtmin;
   a.dt_host = h->st_dt;
   a.ark = h->ark[rk];
@@ -1806,6 +1901,34 @@ int launch_update(dflo_hip_engine *h, double *rhs_out, int part) {
   return DFLO_OK;
 }
 
+// compute_shock_indicator (src/indicator.cc:17-30): nothing to do for type "limiter" (the limiter treats a
+// missing indicator as 1e20 everywhere)
+int launch_indicator(dflo_hip_engine *h, int part) {
+  if (!h->d_shock) return DFLO_OK;
+  const Plan &p = h->plan;
+  IndArgs a{};
+  a.U = h->U[h->cur];
+  a.avg = h->avg[h->avg_cur];
+  a.shock = h->d_shock;
+  a.shard_count = h->d_shard_count;
+  a.lrbt = h->d_lrbt;
+  a.nbr_code = h->d_nbr_code;
+  a.cell_h = h->d_cell_h;
+  a.h_uniform = p.h;
+  a.uniform_h = p.uniform_h ? 1 : 0;
+  a.component = h->prm.shock_indicator == DFLO_IND_DENSITY ? RHO : EN;  // :70-82
+  a.degree = h->degree;
+  a.shard_list = part == 1 ? h->d_rim_list : (part == 2 ? h->d_int_list : nullptr);
+  a.n_list = part == 1 ? (int)p.rim_shards.size() : (part == 2 ? (int)p.interior_shards.size() : p.n_shards);
+  if (a.n_list == 0) return DFLO_OK;
+  void (*fn)(const IndArgs);
+  if (h->basis == DFLO_BASIS_PK) fn = h->N == 2 ? indicator_kernel<2, 1> : (h->N == 3 ? indicator_kernel<3, 1> : indicator_kernel<4, 1>);
+  else fn = h->N == 2 ? indicator_kernel<2, 0> : (h->N == 3 ? indicator_kernel<3, 0> : indicator_kernel<4, 0>);
+  hipLaunchKernelGGL(fn, dim3(grid_for(a.n_list)), dim3(64), 0, h->stream, a);
+  HIPCHK(h, hipGetLastError());
+  return DFLO_OK;
+}
+
 int launch_limiter(dflo_hip_engine *h, int tvb, int pos, int part) {
   const Plan &p = h->plan;
   LimArgs l{};
@@ -1824,6 +1947,7 @@ int launch_limiter(dflo_hip_engine *h, int tvb, int pos, int part) {
   l.char_lim = h->prm.char_lim;
   l.pos_lim = pos;
   l.kb = h->kb;
+  l.shock = tvb ? h->d_shock : nullptr;
   l.shard_list = part == 1 ? h->d_rim_list : (part == 2 ? h->d_int_list : nullptr);
   l.n_list = part == 1 ? (int)p.rim_shards.size() : (part == 2 ? (int)p.interior_shards.size() : p.n_shards);
   if (l.n_list == 0) return DFLO_OK;
@@ -1839,6 +1963,10 @@ int launch_stage_limiter(dflo_hip_engine *h, int part) {
   if (h->pending_rk < 0) { h->err = "no stage pending"; return DFLO_ERR_BAD_PARAM; }
   const bool limited = h->prm.limiter_type != DFLO_LIMITER_NONE || h->prm.pos_lim;
   if (!limited) return DFLO_OK;
+  if (h->prm.limiter_type == DFLO_LIMITER_TVB) {  // compute_shock_indicator(); apply_limiter();  src/claw.cc:763-764
+    const int rc = launch_indicator(h, part);
+    if (rc) return rc;
+  }
   return launch_limiter(h, h->prm.limiter_type == DFLO_LIMITER_TVB, h->prm.pos_lim, part);
 }
 
@@ -1856,16 +1984,18 @@ int launch_finish(dflo_hip_engine *h) {
                        p.uniform_h ? 1 : 0, h->d_shard_count, h->shard_dtmin, h->prm.cfl, h->degree, h->d_dt_cell);
     HIPCHK(h, hipGetLastError());
   }
+  h->pending_rk = -1;
+  if (!last) return DFLO_OK;  // ||rhs|| of every stage is reduced once, after the last stage (it is only reported, src/claw.cc:768)
   FinalArgs f{};
   f.shard_res = h->shard_res;
   f.shard_dtmin = h->shard_dtmin;
   f.res_sq = h->res_sq;
   f.dt_dev = h->dt_dev;
   f.n_shards = p.n_shards;
-  f.stage = rk;
-  f.do_res = 1;
-  f.do_dt = last ? 1 : 0;
-  f.advance_time = last ? 1 : 0;
+  f.n_stages = h->n_rk;
+  f.res_stride = std::max(p.n_shards, 1);
+  f.do_dt = 1;
+  f.advance_time = 1;
   f.dt_host = h->pending_dt;
   f.time_step = h->prm.time_step;
   f.final_time = h->prm.final_time;
@@ -1906,6 +2036,11 @@ int launch_average(dflo_hip_engine *h) {
   return DFLO_OK;
 }
 
+void drop_graph(dflo_hip_engine *h) {
+  if (h->graph_exec) hipGraphExecDestroy(h->graph_exec);
+  h->graph_exec = nullptr;
+}
+
 int check_handle(dflo_hip_handle h) { return h ? DFLO_OK : DFLO_ERR_BAD_PARAM; }
 
 }  // namespace
@@ -1925,6 +2060,14 @@ int dflo_hip_create(const dflo_mesh_t *mesh, const dflo_params_t *params, int de
     return DFLO_ERR_UNSUPPORTED;
   }
   if (mesh->mapping != DFLO_MAP_CARTESIAN && mesh->mapping != DFLO_MAP_Q1) { g_create_error = "q2 mapping is not implemented"; return DFLO_ERR_UNSUPPORTED; }
+  if (params->shock_indicator < DFLO_IND_LIMITER || params->shock_indicator >= DFLO_IND_U2) {
+    g_create_error = "shock indicator must be limiter, density or energy (u2 belongs to the MOOD scheme)";
+    return params->shock_indicator == DFLO_IND_U2 ? DFLO_ERR_UNSUPPORTED : DFLO_ERR_BAD_PARAM;
+  }
+  if (params->shock_indicator != DFLO_IND_LIMITER && (mesh->mapping != DFLO_MAP_CARTESIAN || mesh->n_owned_cells != mesh->n_cells)) {
+    g_create_error = "the KXRCF indicator is implemented for cartesian mapping on a single device";
+    return DFLO_ERR_UNSUPPORTED;
+  }
   if (params->limiter_type == DFLO_LIMITER_TVB && mesh->mapping != DFLO_MAP_CARTESIAN) {
     g_create_error = "TVB limiter is implemented only for cartesian mapping";  // src/parameters.cc:543-544
     return DFLO_ERR_BAD_PARAM;
@@ -1943,6 +2086,7 @@ int dflo_hip_create(const dflo_mesh_t *mesh, const dflo_params_t *params, int de
   h->degree = mesh->degree;
   h->N = mesh->degree + 1;
   h->basis = mesh->basis;
+  if (const char *e = std::getenv("DFLO_GRAPH")) h->use_graph = std::atoi(e) != 0;
   h->ns = mesh->basis == DFLO_BASIS_PK ? h->N * (h->N + 1) / 2 : h->N * h->N;
   h->ndof = 4 * h->ns;
   h->mapping = mesh->mapping;
@@ -2021,6 +2165,11 @@ int dflo_hip_create(const dflo_mesh_t *mesh, const dflo_params_t *params, int de
     if ((rc = upload(h, &h->d_halo_pad, hp))) return bail(rc);
     if ((rc = upload(h, &h->d_faces_pad, fpad))) return bail(rc);
     if ((rc = upload(h, &h->d_bnd_pad, bpad))) return bail(rc);
+    if (h->prm.shock_indicator != DFLO_IND_LIMITER) {
+      if ((rc = upload(h, &h->d_nbr_code, p.nbr_code))) return bail(rc);
+      std::vector<double> z((size_t)p.n_slots, 0.0);
+      if ((rc = upload(h, &h->d_shock, z))) return bail(rc);
+    }
     if (h->geo == 1) {  // face geometry at the same pitch, [shard][3][face_pitch]
       std::vector<double> gpad((size_t)ns * 3 * h->face_pitch, 0.0);
       for (int sidx = 0; sidx < p.n_shards; ++sidx) {
@@ -2046,7 +2195,7 @@ int dflo_hip_create(const dflo_mesh_t *mesh, const dflo_params_t *params, int de
     if ((rc = upload(h, &h->d_cell_vert, p.cell_vert))) return bail(rc);
   }
   const size_t nsh = std::max(p.n_shards, 1);
-  if (hipMalloc((void **)&h->shard_res, nsh * sizeof(double)) != hipSuccess ||
+  if (hipMalloc((void **)&h->shard_res, 3 * nsh * sizeof(double)) != hipSuccess ||
       hipMalloc((void **)&h->shard_dtmin, nsh * sizeof(double)) != hipSuccess ||
       hipMalloc((void **)&h->res_sq, 4 * sizeof(double)) != hipSuccess ||
       hipMalloc((void **)&h->dt_dev, 4 * sizeof(double)) != hipSuccess || hipMalloc((void **)&h->flags, 4 * sizeof(int)) != hipSuccess) {
@@ -2100,11 +2249,12 @@ int dflo_hip_destroy(dflo_hip_handle h) {
   if (!h) return DFLO_OK;
   hipSetDevice(h->device);
   if (h->own_stream) hipStreamSynchronize(h->own_stream);
+  drop_graph(h);
   for (int i = 0; i < 3; ++i) hipFree(h->U[i]);
   for (int i = 0; i < 2; ++i) { hipFree(h->avg[i]); hipFree(h->bval[i]); }
   hipFree(h->rhs); hipFree(h->user_buf); hipFree(h->bface_kind);
   hipFree(h->d_shard_count); hipFree(h->d_halo_begin); hipFree(h->d_halo_cells); hipFree(h->d_face_begin);
-  hipFree(h->d_bnd_pad); hipFree(h->d_faces_pad); hipFree(h->d_shard_hdr); hipFree(h->d_halo_pad); hipFree(h->d_cell_face); hipFree(h->d_lrbt); hipFree(h->d_user_of); hipFree(h->d_iid);
+  hipFree(h->d_bnd_pad); hipFree(h->d_nbr_code); hipFree(h->d_shock); hipFree(h->d_faces_pad); hipFree(h->d_shard_hdr); hipFree(h->d_halo_pad); hipFree(h->d_cell_face); hipFree(h->d_lrbt); hipFree(h->d_user_of); hipFree(h->d_iid);
   hipFree(h->d_rim_list); hipFree(h->d_int_list);
   hipFree(h->d_cell_h); hipFree(h->d_dt_cell); hipFree(h->d_cell_vert); hipFree(h->d_fgeom_pad); hipFree(h->shard_res); hipFree(h->shard_dtmin); hipFree(h->res_sq); hipFree(h->dt_dev);
   hipFree(h->flags); hipFree(h->d_send_slots); hipFree(h->ghost_stage);
@@ -2236,8 +2386,8 @@ int dflo_hip_compute_dt(dflo_hip_handle h, double elapsed_time, double *dt) {
   f.res_sq = h->res_sq;
   f.dt_dev = h->dt_dev;
   f.n_shards = p.n_shards;
-  f.stage = 3;
-  f.do_res = 0;
+  f.n_stages = 0;
+  f.res_stride = 0;
   f.do_dt = 1;
   f.advance_time = 0;
   f.dt_host = -1.0;
@@ -2293,7 +2443,48 @@ int dflo_hip_advance(dflo_hip_handle h, int n_steps, double *elapsed_time_inout)
     double tt[4] = {dt0, *elapsed_time_inout, dt0, 0};
     HIPCHK(h, hipMemcpyAsync(h->dt_dev, tt, sizeof(tt), hipMemcpyHostToDevice, h->stream));
   }
-  for (int s = 0; s < n_steps; ++s) {
+  int s = 0;
+  if (h->use_graph && !h->timing && h->cur == h->old) {
+    // the (solution, average) buffer indices come back to where they started after 2 steps (avg_cur flips
+    // n_rk times per step): capture those once, replay them for the bulk of the steps
+    const int period = 2;
+    if (n_steps >= 2 * period) {
+      if (h->graph_exec && (h->graph_cur != h->cur || h->graph_avg != h->avg_cur || h->graph_stream != h->stream)) drop_graph(h);
+      if (!h->graph_exec) {
+        const int cur0 = h->cur, avg0 = h->avg_cur;
+        hipGraph_t g = nullptr;
+        bool ok = hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
+        if (ok) {
+          for (int k = 0; k < period && !rc; ++k) {
+            for (int rk = 0; rk < h->n_rk && !rc; ++rk) rc = launch_stage(h, rk, -1.0, nullptr, -1);
+            h->old = h->cur;
+          }
+          ok = hipStreamEndCapture(h->stream, &g) == hipSuccess && !rc && g;
+          if (ok) ok = hipGraphInstantiate(&h->graph_exec, g, nullptr, nullptr, 0) == hipSuccess;
+          if (g) hipGraphDestroy(g);
+          // capture records, it does not run: put the indices back
+          h->cur = h->old = cur0;
+          h->avg_cur = avg0;
+          h->pending_rk = -1;
+        }
+        if (!ok || h->cur != cur0) {
+          (void)hipGetLastError();
+          h->graph_exec = nullptr;
+          h->use_graph = false;  // fall back to plain launches for good
+          rc = DFLO_OK;
+        } else {
+          h->graph_steps = period;
+          h->graph_cur = cur0;
+          h->graph_avg = avg0;
+          h->graph_stream = h->stream;
+        }
+      }
+      if (h->graph_exec) {
+        for (; s + period <= n_steps; s += period) HIPCHK(h, hipGraphLaunch(h->graph_exec, h->stream));
+      }
+    }
+  }
+  for (; s < n_steps; ++s) {
     for (int rk = 0; rk < h->n_rk; ++rk) {
       rc = launch_stage(h, rk, -1.0, nullptr, -1);
       if (rc) return rc;
@@ -2312,9 +2503,30 @@ int dflo_hip_apply_limiter(dflo_hip_handle h) {
   if (check_handle(h)) return DFLO_ERR_BAD_PARAM;
   hipSetDevice(h->device);
   if (h->prm.limiter_type == DFLO_LIMITER_NONE) return DFLO_OK;
+  const int rc = launch_indicator(h, 0);  // run(): compute_shock_indicator(); apply_limiter();  src/claw.cc:1000-1001
+  if (rc) return rc;
   return launch_limiter(h, 1, 0, 0);
 }
 
+int dflo_hip_compute_shock_indicator(dflo_hip_handle h) {
+  if (check_handle(h)) return DFLO_ERR_BAD_PARAM;
+  hipSetDevice(h->device);
+  return launch_indicator(h, 0);
+}
+int dflo_hip_get_shock_indicator(dflo_hip_handle h, double *out) {
+  if (check_handle(h) || !out) return DFLO_ERR_BAD_PARAM;
+  hipSetDevice(h->device);
+  const Plan &p = h->plan;
+  if (!h->d_shock) {  // type "limiter": shock_indicator = 1e20 (src/indicator.cc:21)
+    for (int c = 0; c < p.n_cells; ++c) out[c] = 1.0e20;
+    return DFLO_OK;
+  }
+  std::vector<double> z((size_t)p.n_slots);
+  HIPCHK(h, hipMemcpyAsync(z.data(), h->d_shock, z.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  for (int c = 0; c < p.n_cells; ++c) out[c] = z[p.iid[c]];
+  return DFLO_OK;
+}
 int dflo_hip_apply_positivity_limiter(dflo_hip_handle h) {
   if (check_handle(h)) return DFLO_ERR_BAD_PARAM;
   hipSetDevice(h->device);

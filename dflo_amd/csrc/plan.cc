@@ -160,6 +160,7 @@ int build_plan(const dflo_mesh_t &mesh, int shard_ex, int shard_ey, Plan &p, std
   p.face_begin.assign(p.n_shards + 1, 0);
   p.cell_face.assign((size_t)(p.n_shards + 2) * 4 * kShard, kNoFace);  // +2: the stage kernel reads two shards ahead
   p.lrbt.assign((size_t)p.n_shards * 4 * kShard, -1);
+  p.nbr_code.assign((size_t)p.n_shards * 4 * kShard, 0);
   p.max_halo = p.max_faces = p.max_bnd = 0;
   p.shard_bnd.assign(p.n_shards, 0);
   std::unordered_map<int64_t, int32_t> halo_slot;  // (cell, its face) -> halo entry
@@ -198,6 +199,7 @@ int build_plan(const dflo_mesh_t &mesh, int shard_ex, int shard_ey, Plan &p, std
         const int nf = code & 3;
         const bool flip = (code & 4) != 0;
         p.lrbt[ref] = p.iid[nb];  // cartesian meshes: faces 0..3 are the left/right/bottom/top neighbours
+        p.nbr_code[ref] = (uint8_t)((code & 7) | ((code & 8) ? 0 : 8));
         const bool integrator = gid(c) < gid(nb) || (gid(c) == gid(nb) && f < nf);
         const bool nb_inside = shard_of[nb] == s;
         if (nb_inside && !integrator) continue;  // the integrating cell creates the record and both references

@@ -54,6 +54,8 @@ struct Plan {
   std::vector<uint16_t> cell_face;   // [n_shards][4][kShard]
   std::vector<int32_t> lrbt;         // [n_shards][4][kShard] internal slot of the left/right/bottom/top
                                      // neighbour or -1 (src/claw.cc:336-380)
+  std::vector<uint8_t> nbr_code;     // [n_shards][4][kShard] bits 0-1 the neighbour's local face, bit 2 flip,
+                                     // bit 3: interior non-periodic face (the ones the KXRCF indicator visits)
   std::vector<int32_t> shard_bnd;    // boundary faces per shard
   std::vector<int32_t> rim_shards;   // owned shards that read ghost cells (multi-device: computed first, then
   std::vector<int32_t> interior_shards;  // their cells are exchanged while the interior shards are computed)

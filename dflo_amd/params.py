@@ -5,7 +5,8 @@ from . import _lib
 
 class Parameters:
     def __init__(self, flux="lxf", limiter="none", char_lim=True, pos_lim=False, cfl=0.9, time_step=0.0,
-                 final_time=1.0e20, M=0.0, beta=2.0, gravity=0.0, time_step_type="global", boundary=None, n_rk=0):
+                 final_time=1.0e20, M=0.0, beta=2.0, gravity=0.0, time_step_type="global", boundary=None, n_rk=0,
+                 shock_indicator="limiter"):
         self.flux = flux                    # subsection flux / flux
         self.limiter = limiter              # subsection limiter / type
         self.char_lim = char_lim            # characteristic limiter
@@ -19,6 +20,7 @@ class Parameters:
         self.time_step_type = time_step_type
         self.boundary = dict(boundary or {})  # boundary id -> kind name ("slip", "inflow", ...)
         self.n_rk = n_rk
+        self.shock_indicator = shock_indicator  # subsection limiter / shock indicator: limiter | density | energy
 
     def struct(self):
         p = _lib.ParamsStruct()
@@ -34,6 +36,7 @@ class Parameters:
         p.final_time = self.final_time
         p.M = self.M
         p.beta = self.beta
+        p.shock_indicator = _lib.SHOCK_INDICATOR[self.shock_indicator]
         for i in range(_lib.MAX_BOUNDARIES):
             p.bc_kind[i] = _lib.BC[self.boundary.get(i, "outflow")]
         return p

@@ -54,6 +54,9 @@ typedef enum { DFLO_FLUX_LXF = 0, DFLO_FLUX_SW = 1, DFLO_FLUX_KFVS = 2, DFLO_FLU
 typedef enum { DFLO_BC_INFLOW = 0, DFLO_BC_OUTFLOW = 1, DFLO_BC_SLIP = 2, DFLO_BC_PRESSURE = 3, DFLO_BC_FARFIELD = 4 } dflo_bc_kind;
 /* Parameters::Limiter::LimiterType, src/parameters.h:241 */
 typedef enum { DFLO_LIMITER_NONE = 0, DFLO_LIMITER_TVB = 1 } dflo_limiter;
+/* Parameters::Limiter::ShockIndType, src/parameters.h:244 ("limiter" marks every cell; u2 belongs to the MOOD
+ * scheme and is not part of the explicit TVB path: DFLO_ERR_UNSUPPORTED) */
+typedef enum { DFLO_IND_LIMITER = 0, DFLO_IND_DENSITY = 1, DFLO_IND_ENERGY = 2, DFLO_IND_U2 = 3 } dflo_shock_indicator;
 /* AllParameters::BasisType / MappingType, src/parameters.h:384-387 */
 typedef enum { DFLO_BASIS_QK = 0, DFLO_BASIS_PK = 1 } dflo_basis;
 typedef enum { DFLO_MAP_Q1 = 0, DFLO_MAP_Q2 = 1, DFLO_MAP_CARTESIAN = 2 } dflo_mapping;
@@ -104,6 +107,8 @@ typedef struct dflo_params {
   double M;               /* TVB constant */
   double beta;
   int32_t bc_kind[DFLO_MAX_BOUNDARIES]; /* dflo_bc_kind per boundary id */
+  int32_t shock_indicator; /* dflo_shock_indicator: "shock indicator" of subsection limiter, src/parameters.cc:228-239 */
+  int32_t reserved_;
 } dflo_params_t;
 
 typedef struct dflo_hip_engine *dflo_hip_handle;
@@ -174,8 +179,14 @@ int dflo_hip_advance(dflo_hip_handle h, int n_steps, double *elapsed_time_inout)
  * calls (src/claw.cc:562, src/limiter.cc:36, src/positivity.cc:17) -- what run()
  * does once after the initial condition (src/claw.cc:997-1001). */
 int dflo_hip_compute_cell_average(dflo_hip_handle h);
-int dflo_hip_apply_limiter(dflo_hip_handle h);
+int dflo_hip_apply_limiter(dflo_hip_handle h);   /* compute_shock_indicator(); apply_limiter(); */
 int dflo_hip_apply_positivity_limiter(dflo_hip_handle h);
+
+/* compute_shock_indicator (src/indicator.cc:17-198) from the current solution and cell averages, and the
+ * shock_indicator vector (n_cells; 1e20 everywhere for "shock indicator = limiter"). Inside a stage the
+ * engine runs it between compute_cell_average and apply_limiter as src/claw.cc:762-764 does. */
+int dflo_hip_compute_shock_indicator(dflo_hip_handle h);
+int dflo_hip_get_shock_indicator(dflo_hip_handle h, double *shock_indicator);
 
 /* Device-side failure flags raised by kernels, checked here (no mid-kernel abort):
  * returns DFLO_OK, DFLO_ERR_NEGATIVE_MEAN_STATE or DFLO_ERR_POSITIVITY_NO_ROOT. */

@@ -601,7 +601,7 @@ struct Oracle {
   ShapeTable trap;         // QIterated(QTrapez,3) (src/claw.cc:523)
   ShapeTable support;      // unit support points (Qk) (src/limiter.cc:234)
   // state
-  std::vector<double> cur, old, rhs, upd, avg, invM, dtc;
+  std::vector<double> cur, old, rhs, upd, avg, invM, dtc, shock;
   std::vector<int> lcell, rcell, bcell, tcell;
   std::vector<BFace> bfaces;
   std::vector<int> bface_of;   // [n_cells*4] -> bface index or -1
@@ -1072,13 +1072,54 @@ double compute_time_step(Oracle &o, double elapsed_time) {
   return o.global_dt;
 }
 
+// compute_shock_indicator (src/indicator.cc:17-30) and compute_shock_indicator_kxrcf (src/indicator.cc:51-198).
+// Only the same-level branch (:111-132) exists here: the meshes are not adapted.  Faces with a periodic
+// neighbour count as boundary faces, as cell->at_boundary(f) does for them in src_mpi/indicator.cc:94.
+// The jump indicator computed alongside (:126-128, :188-195) is written nowhere but its own min/max/avg; omitted.
+void compute_shock_indicator(Oracle &o) {
+  o.shock.assign(o.n_cells, 0.0);
+  if (o.prm.shock_indicator == DFLO_IND_LIMITER) {  // :19-22: mark all cells
+    std::fill(o.shock.begin(), o.shock.end(), 1.0e20);
+    return;
+  }
+  const int component = o.prm.shock_indicator == DFLO_IND_DENSITY ? DENS : ENER;   // :70-82
+  const int nq = o.N;
+  std::vector<double> W((size_t)nq * NC), Wn((size_t)nq * NC);
+  for (int c = 0; c < o.n_owned; ++c) {
+    double cell_shock_ind = 0, inflow_measure = 0;
+    const double *A = &o.avg[(size_t)c * NC];
+    const double vel[2] = {A[0] / A[DENS], A[1] / A[DENS]};   // :106-108 velocity of the cell average
+    for (int f = 0; f < 4; ++f) {
+      const int nb = o.nbr[(size_t)c * 4 + f], code = o.nbrf[(size_t)c * 4 + f];
+      if (nb < 0 || (code & 8)) continue;   // boundary (or periodic) face: nothing, :169-174
+      const int nface = code & 3;
+      const bool flip = (code & 4) != 0;
+      const ShapeTable &t = o.faceq[f];
+      face_values(o, c, f, W);
+      face_values(o, nb, nface, Wn);
+      for (int q = 0; q < nq; ++q) {
+        const int qn = flip ? nq - 1 - q : q;
+        double jac, n[2];
+        o.face_geom(c, f, t.xi[q], t.eta[q], jac, n);
+        const double JxW = jac * t.w[q];
+        const int inflow_status = (vel[0] * n[0] + vel[1] * n[1] < 0);
+        cell_shock_ind += inflow_status * (W[q * NC + component] - Wn[qn * NC + component]) * JxW;
+        inflow_measure += inflow_status * JxW;
+      }
+    }
+    const double cell_norm = A[component];
+    const double denominator = std::pow(o.diameter(c), 0.5 * (o.degree + 1)) * inflow_measure * cell_norm;   // :179-181
+    o.shock[c] = std::fabs(cell_shock_ind) / denominator;
+  }
+}
+
 // src/limiter.cc:225-370
 void apply_limiter_TVB_Qk(Oracle &o) {
   if (o.degree == 0) return;
   const int nq = o.cellq.np, ns = o.ns;
   const double beta = o.prm.beta;
   for (int c = 0; c < o.n_owned; ++c) {
-    // shock_indicator = 1e20 for indicator type "limiter" (src/indicator.cc:19-22): every cell
+    if (!(o.shock[c] > 1.0)) continue;   // src/limiter.cc:263
     const double dx = o.diameter(c) / std::sqrt(2.0);
     const double Mdx2 = o.prm.M * dx * dx;
     double *u = &o.cur[(size_t)c * o.ndof];
@@ -1158,6 +1199,7 @@ void apply_limiter_TVB_Pk(Oracle &o) {
   static const double sqrt_3 = std::sqrt(3.0);
   const double beta = 0.5 * o.prm.beta;
   for (int c = 0; c < o.n_owned; ++c) {
+    if (!(o.shock[c] > 1.0)) continue;   // src/limiter.cc:406
     const double dx = o.diameter(c) / std::sqrt(2.0);
     const double Mdx2 = o.prm.M * dx * dx;
     double *u = &o.cur[(size_t)c * o.ndof];
@@ -1208,6 +1250,7 @@ void apply_limiter_TVB_Pk(Oracle &o) {
 
 void apply_limiter(Oracle &o) {  // src/limiter.cc:36-65
   if (o.prm.limiter_type == DFLO_LIMITER_NONE) return;
+  if ((int)o.shock.size() != o.n_cells) compute_shock_indicator(o);   // run() computes it before limiting the IC, src/claw.cc:1000
   if (o.basis == DFLO_BASIS_QK) apply_limiter_TVB_Qk(o);
   else apply_limiter_TVB_Pk(o);
 }
@@ -1328,6 +1371,7 @@ int stage(Oracle &o, int rk, double *res_norm) {
   for (size_t k = 0; k < n; ++k) o.cur[k] += o.upd[k];                                          // :757
   for (size_t k = 0; k < n; ++k) o.cur[k] = (1.0 - o.ark[rk]) * o.cur[k] + o.ark[rk] * o.old[k];  // sadd :760
   compute_cell_average(o);
+  compute_shock_indicator(o);   // :763
   apply_limiter(o);
   if (o.prm.pos_lim) {
     int e = apply_positivity_limiter(o);
@@ -1452,7 +1496,21 @@ void dflo_oracle_assemble(void *h, int which, double *rhs_out) {
 }
 void dflo_oracle_compute_cell_average(void *h) { compute_cell_average(*(Oracle *)h); }
 double dflo_oracle_compute_time_step(void *h, double elapsed) { return compute_time_step(*(Oracle *)h, elapsed); }
-void dflo_oracle_apply_limiter(void *h) { apply_limiter(*(Oracle *)h); }
+void dflo_oracle_apply_limiter(void *h) {   // run(): compute_shock_indicator(); apply_limiter(); old_solution =
+  Oracle &o = *(Oracle *)h;                  // current_solution;  src/claw.cc:1000-1002
+  compute_shock_indicator(o);
+  apply_limiter(o);
+  o.old = o.cur;
+}
+void dflo_oracle_get_shock_indicator(void *h, double *out) {   // as left by the last stage / apply_limiter
+  Oracle &o = *(Oracle *)h;
+  std::copy(o.shock.begin(), o.shock.end(), out);
+}
+void dflo_oracle_compute_shock_indicator(void *h, double *out) {
+  Oracle &o = *(Oracle *)h;
+  compute_shock_indicator(o);
+  if (out) std::copy(o.shock.begin(), o.shock.end(), out);
+}
 int dflo_oracle_apply_positivity_limiter(void *h) { return apply_positivity_limiter(*(Oracle *)h); }
 
 void dflo_oracle_set_dt(void *h, double dt) {

@@ -41,6 +41,8 @@ for name, res, args in [
     ("dflo_oracle_compute_cell_average", None, [C.c_void_p]),
     ("dflo_oracle_compute_time_step", C.c_double, [C.c_void_p, C.c_double]),
     ("dflo_oracle_apply_limiter", None, [C.c_void_p]),
+    ("dflo_oracle_compute_shock_indicator", None, [C.c_void_p, _dp]),
+    ("dflo_oracle_get_shock_indicator", None, [C.c_void_p, _dp]),
     ("dflo_oracle_apply_positivity_limiter", C.c_int, [C.c_void_p]),
     ("dflo_oracle_set_dt", None, [C.c_void_p, C.c_double]),
     ("dflo_oracle_stage", C.c_int, [C.c_void_p, C.c_int, _dp]),
@@ -157,6 +159,17 @@ class Oracle:
 
     def compute_cell_average(self):
         _lib.dflo_oracle_compute_cell_average(self._h)
+
+    @property
+    def shock_indicator(self):
+        s = np.empty(self.mesh.n_cells)
+        _lib.dflo_oracle_get_shock_indicator(self._h, _d(s))
+        return s
+
+    def compute_shock_indicator(self):
+        s = np.empty(self.mesh.n_cells)
+        _lib.dflo_oracle_compute_shock_indicator(self._h, _d(s))
+        return s
 
     def compute_time_step(self, elapsed):
         return _lib.dflo_oracle_compute_time_step(self._h, elapsed)

@@ -427,3 +427,95 @@ def test_pk_rejects_mapped_cells():
     mesh.set_mapping("q1")
     with pytest.raises(dflo_amd.DfloError):
         dflo_amd.ConservationLaw(mesh, dflo_amd.Parameters(flux="lxf"))
+
+
+def test_advance_graph_replay_matches_plain_launches(monkeypatch):
+    """DFLO_GRAPH=1: dflo_hip_advance replays a captured 2-step graph; same bits as launch by launch."""
+    out = []
+    for flag in ("0", "1"):
+        monkeypatch.setenv("DFLO_GRAPH", flag)
+        mesh = dflo_amd.Mesh.cartesian(24, 16, -5.0, -5.0, 10.0 / 24, [-1] * 4, 2)
+        claw = dflo_amd.ConservationLaw(mesh, dflo_amd.Parameters(flux="hllc", cfl=0.7))
+        claw.set_initial_condition(mesh.interpolate(problems.isentropic_vortex))
+        t = claw.advance(11)     # 5 replays + 1 plain step
+        t = claw.advance(6)      # cached graph
+        out.append((t, claw.current_solution.copy()))
+    assert out[0][0] == out[1][0]
+    assert (out[0][1] == out[1][1]).all()
+
+
+# ---------------------------------------------------------------- KXRCF indicator (SURVEY §8f-2)
+def _rough_wave(x, y):
+    rho = 1.0 + 0.2 * np.sin(16 * np.pi * x) * np.cos(2 * np.pi * y) + np.where(x > 0.75, 0.8, 0.0) + np.where(y > 0.5, 0.3, 0.0)
+    u, v = 0.5 + 0.2 * np.sin(2 * np.pi * y), -0.3 + 0.5 * np.cos(2 * np.pi * x)
+    return [rho * u, rho * v, rho, 2.5 + 0.5 * rho * (u * u + v * v)]
+
+
+@pytest.mark.parametrize("basis", ["Qk", "Pk"])
+@pytest.mark.parametrize("degree", [1, 2, 3])
+@pytest.mark.parametrize("kind", ["density", "energy"])
+def test_kxrcf_indicator_matches_oracle(basis, degree, kind):
+    nx, ny = 40, 24
+    mesh = dflo_amd.Mesh.cartesian(nx, ny, 0.0, 0.0, 1.0 / nx, [0, 1, -1, -1], degree)
+    mesh.set_basis(basis)
+    prm = dflo_amd.Parameters(flux="roe", limiter="TVB", shock_indicator=kind, boundary={0: "outflow", 1: "outflow"})
+    claw, ora = dflo_amd.ConservationLaw(mesh, prm), oracle_lib.Oracle(mesh, prm)
+    u0 = mesh.interpolate(_rough_wave)
+    claw.set_initial_condition(u0)
+    ora.set_solution(u0)
+    s, so = claw.compute_shock_indicator(), ora.compute_shock_indicator()
+    assert (np.isnan(s) == np.isnan(so)).all()
+    ok = ~np.isnan(so)
+    assert np.abs(s[ok] - so[ok]).max() <= 1e-11 * np.abs(so[ok]).max()
+    assert (so[ok] > 1.0).sum() > 0 and (so[ok] < 1.0).sum() > 0
+
+
+def _oblique_front(x, y):
+    """A density/pressure front oblique to the mesh in a flow with both velocity components away from zero
+    (the indicator's inflow test `vel . n < 0` is a sign test: a velocity component that is zero up to round-off
+    would make it -- in the reference as well -- a coin toss)."""
+    s = 0.5 * (1.0 + np.tanh((x + 0.5 * y - 0.8) / 0.004))
+    rho, p = 1.0 + 0.6 * s, 1.0 + 0.9 * s
+    u, v = 0.6, 0.35
+    return [rho * u, rho * v, rho, p / 0.4 + 0.5 * rho * (u * u + v * v)]
+
+
+@pytest.mark.parametrize("basis,degree", [("Qk", 1), ("Qk", 2), ("Pk", 2)])
+def test_kxrcf_gated_tvb_run(basis, degree):
+    """The limiter gated by the density indicator: indicator pass, gate and limiter reproduce the oracle's
+    stage sequence compute_cell_average; compute_shock_indicator; apply_limiter (src/claw.cc:762-766)."""
+    nx, ny = 48, 40
+    mesh = dflo_amd.Mesh.cartesian(nx, ny, 0.0, 0.0, 1.0 / nx, [0, 0, 0, 0], degree)
+    mesh.set_basis(basis)
+    prm = dflo_amd.Parameters(flux="hllc", limiter="TVB", char_lim=True, pos_lim=True, M=0.0, beta=2.0,
+                              boundary={0: "outflow"}, shock_indicator="density")
+    claw, ora = dflo_amd.ConservationLaw(mesh, prm), oracle_lib.Oracle(mesh, prm)
+    u0 = mesh.interpolate(_oblique_front)
+    claw.set_initial_condition(u0)
+    ora.set_solution(u0)
+    claw.apply_limiter()
+    ora.apply_limiter()
+    assert rel(claw.current_solution, ora.get_solution()) < 1e-11
+    t = 0.0
+    n_flagged = 0
+    for it in range(15):
+        dt = claw.compute_time_step()
+        dto = ora.compute_time_step(t)
+        assert abs(dt - dto) <= 1e-11 * dto
+        claw.iterate_explicit(dt)
+        ora.step(dt)
+        t += dt
+    assert rel(claw.cell_average, ora.get_cell_average()) < 1e-9
+    assert rel(claw.current_solution, ora.get_solution()) < 1e-7
+    # the gate was really in play: some cells flagged, most not
+    so = ora.compute_shock_indicator()
+    assert 0 < (so > 1.0).sum() < mesh.n_cells // 3
+
+
+def test_kxrcf_unsupported_configurations():
+    mesh = dflo_amd.Mesh.cartesian(8, 8, 0.0, 0.0, 0.125, [-1] * 4, 1)
+    with pytest.raises(dflo_amd.DfloError):
+        dflo_amd.ConservationLaw(mesh, dflo_amd.Parameters(flux="lxf", shock_indicator="u2"))
+    mesh.set_mapping("q1")
+    with pytest.raises(dflo_amd.DfloError):
+        dflo_amd.ConservationLaw(mesh, dflo_amd.Parameters(flux="lxf", shock_indicator="density"))

@@ -221,3 +221,67 @@ def test_pk_projection_matches_oracle_shape_tables(degree):
     # cell average = mode 0
     ora.set_solution(u.reshape(-1))
     assert np.abs(ora.get_cell_average() - u[:, :, 0]).max() < 1e-13
+
+
+# ---------------------------------------------------------------- KXRCF indicator (src/indicator.cc)
+def _moving_jump(x, y, x_jump=0.5, rho_l=1.0, rho_r=0.4, u=0.7):
+    rho = np.where(x < x_jump, rho_l, rho_r)
+    p = 1.0
+    return [rho * u, 0.0 * x, rho, p / 0.4 + 0.5 * rho * u * u]
+
+
+@pytest.mark.parametrize("degree", [1, 2, 3])
+@pytest.mark.parametrize("basis", ["Qk", "Pk"])
+def test_kxrcf_indicator_known_answer(degree, basis):
+    """Piecewise-constant density jump moving right: only the cell right of the jump sees it through its inflow
+    (left) face: ind = |rho_r - rho_l| h / (diam^((k+1)/2) h rho_r)  (src/indicator.cc:119-124, 177-182)."""
+    nx, ny = 16, 4
+    h = 1.0 / nx
+    mesh = dflo_amd.Mesh.cartesian(nx, ny, 0.0, 0.0, h, [0, 0, 0, 0], degree)
+    mesh.set_basis(basis)
+    prm = dflo_amd.Parameters(flux="lxf", limiter="TVB", shock_indicator="density", boundary={0: "outflow"})
+    ora = O.Oracle(mesh, prm)
+    ora.set_solution(mesh.interpolate(_moving_jump))
+    ind = ora.compute_shock_indicator().reshape(ny, nx)
+    diam = h * np.sqrt(2.0)
+    expect = abs(0.4 - 1.0) / (diam ** (0.5 * (degree + 1)) * 0.4)
+    assert np.allclose(ind[:, 8], expect, rtol=1e-12)
+    others = np.delete(ind, 8, axis=1)
+    assert np.abs(others[:, 1:]).max() < 1e-12      # no jump on the inflow face
+    assert np.isnan(others[:, 0]).all()             # first column: its inflow face is a boundary face -> 0/0
+    # energy as the indicator variable
+    prm_e = dflo_amd.Parameters(flux="lxf", limiter="TVB", shock_indicator="energy", boundary={0: "outflow"})
+    ora_e = O.Oracle(mesh, prm_e)
+    ora_e.set_solution(mesh.interpolate(_moving_jump))
+    ind_e = ora_e.compute_shock_indicator().reshape(ny, nx)
+    e_l, e_r = 2.5 + 0.5 * 1.0 * 0.49, 2.5 + 0.5 * 0.4 * 0.49
+    assert np.allclose(ind_e[:, 8], abs(e_r - e_l) / (diam ** (0.5 * (degree + 1)) * e_r), rtol=1e-12)
+
+
+def test_kxrcf_indicator_gates_the_tvb_limiter():
+    """With "shock indicator = limiter" every cell is offered to the limiter; with "density" only the cells whose
+    indicator exceeds 1 (src/limiter.cc:263): the cells changed are exactly those changed before AND flagged."""
+    nx, ny = 32, 4
+    h = 1.0 / nx
+    mesh = dflo_amd.Mesh.cartesian(nx, ny, 0.0, 0.0, h, [0, 0, -1, -1], 1)
+
+    def ic(x, y):   # a rough wave (clipped by beta = 1 nearly everywhere) with two jumps
+        rho = 1.0 + 0.2 * np.sin(16 * np.pi * x) + np.where(x > 0.75, 0.8, 0.0) + np.where(x > 0.25, 0.6, 0.0)
+        return [0.5 * rho, 0.0 * x, rho, 2.5 + 0.125 * rho]
+
+    out = {}
+    for kind in ("limiter", "density"):
+        prm = dflo_amd.Parameters(flux="lxf", limiter="TVB", M=0.0, beta=1.0, shock_indicator=kind, boundary={0: "outflow"})
+        ora = O.Oracle(mesh, prm)
+        u0 = mesh.interpolate(ic)
+        ora.set_solution(u0)
+        ind = ora.compute_shock_indicator()
+        ora.apply_limiter()
+        out[kind] = (ind, np.abs(ora.get_solution() - u0).reshape(mesh.n_cells, -1).max(axis=1) > 1e-12)
+    assert (out["limiter"][0] == 1e20).all()
+    changed_all, (ind, changed_kx) = out["limiter"][1], out["density"]
+    flagged = ind > 1.0
+    assert changed_all.sum() > mesh.n_cells // 2
+    assert 0 < flagged.sum() < mesh.n_cells // 4
+    assert (changed_kx == (changed_all & flagged)).all()
+    assert changed_kx.sum() > 0
