@@ -1549,66 +1549,66 @@ struct FinalArgs {
   const double *shard_res, *shard_dtmin;
   double *res_sq;  // [3] per stage
   double *dt_dev;  // [0] dt, [1] elapsed time, [2] raw min before rules
+  double *partial; // [kFinBlocks][4] workgroup partials
+  int *counter;    // workgroups done
   int n_shards, n_stages, res_stride, do_dt, advance_time, global_rules;  // shard_res: [n_stages][res_stride]
   double time_step, final_time, dt_host;
 };
-__global__ __launch_bounds__(1024) void finalize_kernel(const FinalArgs a) {
-  __shared__ double sres[3][16], smin[16];
-  // fixed assignment of shards to threads and a fixed combination tree -> deterministic sums;
-  // four independent loads per trip keep the (single) workgroup from serialising on latency.
-  // The residual partials of all stages of the step are reduced here, once per step.
+constexpr int kFinBlocks = 32;   // workgroups of the two-level reduction
+__global__ __launch_bounds__(256) void finalize_kernel(const FinalArgs a) {
+  __shared__ double sred[4][4];
+  __shared__ int is_last;
+  // Two levels, both with a fixed assignment and a fixed combination order -> deterministic sums:
+  // workgroup b reduces the shards [b chunk, (b+1) chunk) of every array (the residual partials of all stages
+  // of the step and the CFL minima), the workgroup that finishes last combines the kFinBlocks partials in index order.
+  const int n = a.n_shards, t = threadIdx.x, b = blockIdx.x;
+  const int chunk = ((n + kFinBlocks - 1) / kFinBlocks + 255) & ~255;
+  const int lo = b * chunk, hi = min(n, lo + chunk);
   double rs[3] = {0.0, 0.0, 0.0}, m = 1.0e20;
-  const int n = a.n_shards, t = threadIdx.x;
-  for (int st = 0; st < a.n_stages; ++st) {
-    const double *sr = a.shard_res + (size_t)st * a.res_stride;
-    double r0 = 0.0, r1 = 0.0, r2 = 0.0, r3 = 0.0;
-    for (int s = t; s < n; s += 4096) {
-      const int s1 = s + 1024, s2 = s + 2048, s3 = s + 3072;
-      r0 += sr[s];
-      if (s1 < n) r1 += sr[s1];
-      if (s2 < n) r2 += sr[s2];
-      if (s3 < n) r3 += sr[s3];
-    }
-    rs[st] = (r0 + r1) + (r2 + r3);
+  for (int s = lo + t; s < hi; s += 256) {
+    for (int st = 0; st < a.n_stages; ++st) rs[st] += a.shard_res[(size_t)st * a.res_stride + s];
+    if (a.do_dt) m = fmin(m, a.shard_dtmin[s]);
   }
-  for (int s = t; s < n; s += 4096) {
-    const int s1 = s + 1024, s2 = s + 2048, s3 = s + 3072;
-    if (a.do_dt) {
-      double m0 = a.shard_dtmin[s];
-      if (s1 < n) m0 = fmin(m0, a.shard_dtmin[s1]);
-      if (s2 < n) m0 = fmin(m0, a.shard_dtmin[s2]);
-      if (s3 < n) m0 = fmin(m0, a.shard_dtmin[s3]);
-      m = fmin(m, m0);
-    }
-  }
-  for (int st = 0; st < a.n_stages; ++st) {
+  for (int st = 0; st < 3; ++st) {
     const double r = wave_sum(rs[st]);
-    if ((t & 63) == 0) sres[st][t >> 6] = r;
+    if ((t & 63) == 0) sred[st][t >> 6] = r;
   }
   m = wave_min(m);
-  if ((t & 63) == 0) smin[t >> 6] = m;
+  if ((t & 63) == 0) sred[3][t >> 6] = m;
   __syncthreads();
   if (t == 0) {
-    for (int st = 0; st < a.n_stages; ++st) {
-      double tot = 0.0;
-      for (int i = 0; i < 16; ++i) tot += sres[st][i];
-      a.res_sq[st] = tot;
+    for (int st = 0; st < 3; ++st) a.partial[b * 4 + st] = (sred[st][0] + sred[st][1]) + (sred[st][2] + sred[st][3]);
+    a.partial[b * 4 + 3] = fmin(fmin(sred[3][0], sred[3][1]), fmin(sred[3][2], sred[3][3]));
+    __threadfence();
+    is_last = atomicAdd(a.counter, 1) == (int)gridDim.x - 1;
+  }
+  __syncthreads();
+  if (!is_last) return;
+  __threadfence();
+  __shared__ double spart[kFinBlocks * 4];
+  if (t < (int)gridDim.x * 4) spart[t] = ((const volatile double *)a.partial)[t];  // one round trip for all partials
+  __syncthreads();
+  if (t != 0) return;
+  *a.counter = 0;  // ready for the next launch (launches on one stream do not overlap)
+  for (int st = 0; st < a.n_stages; ++st) {
+    double tot = 0.0;
+    for (int i = 0; i < (int)gridDim.x; ++i) tot += spart[i * 4 + st];
+    a.res_sq[st] = tot;
+  }
+  if (a.do_dt) {
+    double tt = a.dt_dev[1];
+    if (a.advance_time) {  // elapsed_time += global_dt (src/claw.cc:1072) for the step just done
+      tt += a.dt_host >= 0.0 ? a.dt_host : a.dt_dev[0];
+      a.dt_dev[1] = tt;
     }
-    if (a.do_dt) {
-      double tt = a.dt_dev[1];
-      if (a.advance_time) {  // elapsed_time += global_dt (src/claw.cc:1072) for the step just done
-        tt += a.dt_host >= 0.0 ? a.dt_host : a.dt_dev[0];
-        a.dt_dev[1] = tt;
-      }
-      double dt = smin[0];
-      for (int i = 1; i < 16; ++i) dt = fmin(dt, smin[i]);
-      a.dt_dev[2] = dt;
-      if (a.global_rules) {  // src/claw.cc:469-476, only for "time step type = global"
-        if (dt > 0 && a.time_step > 0) dt = fmin(dt, a.time_step);
-        if (tt + dt > a.final_time) dt = a.final_time - tt;
-      }
-      a.dt_dev[0] = dt;
+    double dt = spart[3];
+    for (int i = 1; i < (int)gridDim.x; ++i) dt = fmin(dt, spart[i * 4 + 3]);
+    a.dt_dev[2] = dt;
+    if (a.global_rules) {  // src/claw.cc:469-476, only for "time step type = global"
+      if (dt > 0 && a.time_step > 0) dt = fmin(dt, a.time_step);
+      if (tt + dt > a.final_time) dt = a.final_time - tt;
     }
+    a.dt_dev[0] = dt;
   }
 }
 // re-apply the rules after an external all-reduce(min) of dt_dev[2] (multi-device)
@@ -1654,7 +1654,7 @@ struct dflo_hip_engine {
   uint16_t *d_cell_face = nullptr;
   int32_t *d_lrbt = nullptr, *d_user_of = nullptr, *d_iid = nullptr;
   double *d_cell_h = nullptr, *d_cell_vert = nullptr, *d_fgeom_pad = nullptr, *d_dt_cell = nullptr;
-  double *shard_res = nullptr, *shard_dtmin = nullptr, *res_sq = nullptr, *dt_dev = nullptr;
+  double *shard_res = nullptr, *shard_dtmin = nullptr, *res_sq = nullptr, *dt_dev = nullptr, *fin_partial = nullptr;
   int *flags = nullptr;
   std::vector<double> bface_xy;  // [n_bfaces][N][2]
   int pending_rk = -1;
@@ -1971,6 +1971,12 @@ int launch_stage_limiter(dflo_hip_engine *h, int part) {
 }
 
 // reductions of the stage launched last
+// workgroups of finalize_kernel: as many chunks of >= 256 shards as there are, at most kFinBlocks
+int fin_grid(int n_shards) {
+  const int chunk = ((n_shards + kFinBlocks - 1) / kFinBlocks + 255) & ~255;
+  return std::max(1, (n_shards + chunk - 1) / chunk);
+}
+
 int launch_finish(dflo_hip_engine *h) {
   const Plan &p = h->plan;
   const int rk = h->pending_rk;
@@ -2000,7 +2006,9 @@ int launch_finish(dflo_hip_engine *h) {
   f.time_step = h->prm.time_step;
   f.final_time = h->prm.final_time;
   f.global_rules = h->prm.global_time_step;
-  hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(1024), 0, h->stream, f);
+  f.partial = h->fin_partial;
+  f.counter = h->flags + 2;
+  hipLaunchKernelGGL(finalize_kernel, dim3(fin_grid(f.n_shards)), dim3(256), 0, h->stream, f);
   HIPCHK(h, hipGetLastError());
   h->pending_rk = -1;
   return DFLO_OK;
@@ -2197,7 +2205,7 @@ int dflo_hip_create(const dflo_mesh_t *mesh, const dflo_params_t *params, int de
   const size_t nsh = std::max(p.n_shards, 1);
   if (hipMalloc((void **)&h->shard_res, 3 * nsh * sizeof(double)) != hipSuccess ||
       hipMalloc((void **)&h->shard_dtmin, nsh * sizeof(double)) != hipSuccess ||
-      hipMalloc((void **)&h->res_sq, 4 * sizeof(double)) != hipSuccess ||
+      hipMalloc((void **)&h->res_sq, 4 * sizeof(double)) != hipSuccess || hipMalloc((void **)&h->fin_partial, 4 * 32 * sizeof(double)) != hipSuccess ||
       hipMalloc((void **)&h->dt_dev, 4 * sizeof(double)) != hipSuccess || hipMalloc((void **)&h->flags, 4 * sizeof(int)) != hipSuccess) {
     h->err = "hipMalloc(scalars) failed";
     return bail(DFLO_ERR_NOMEM);
@@ -2256,7 +2264,7 @@ int dflo_hip_destroy(dflo_hip_handle h) {
   hipFree(h->d_shard_count); hipFree(h->d_halo_begin); hipFree(h->d_halo_cells); hipFree(h->d_face_begin);
   hipFree(h->d_bnd_pad); hipFree(h->d_nbr_code); hipFree(h->d_shock); hipFree(h->d_faces_pad); hipFree(h->d_shard_hdr); hipFree(h->d_halo_pad); hipFree(h->d_cell_face); hipFree(h->d_lrbt); hipFree(h->d_user_of); hipFree(h->d_iid);
   hipFree(h->d_rim_list); hipFree(h->d_int_list);
-  hipFree(h->d_cell_h); hipFree(h->d_dt_cell); hipFree(h->d_cell_vert); hipFree(h->d_fgeom_pad); hipFree(h->shard_res); hipFree(h->shard_dtmin); hipFree(h->res_sq); hipFree(h->dt_dev);
+  hipFree(h->d_cell_h); hipFree(h->d_dt_cell); hipFree(h->d_cell_vert); hipFree(h->d_fgeom_pad); hipFree(h->shard_res); hipFree(h->shard_dtmin); hipFree(h->res_sq); hipFree(h->fin_partial); hipFree(h->dt_dev);
   hipFree(h->flags); hipFree(h->d_send_slots); hipFree(h->ghost_stage);
   for (auto &e : h->ev_pool) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
   if (h->ev_rim) { hipEventDestroy(h->ev_rim); hipEventDestroy(h->ev_unpack); }
@@ -2394,7 +2402,9 @@ int dflo_hip_compute_dt(dflo_hip_handle h, double elapsed_time, double *dt) {
   f.time_step = h->prm.time_step;
   f.final_time = h->prm.final_time;
   f.global_rules = h->prm.global_time_step;
-  hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(1024), 0, h->stream, f);
+  f.partial = h->fin_partial;
+  f.counter = h->flags + 2;
+  hipLaunchKernelGGL(finalize_kernel, dim3(fin_grid(f.n_shards)), dim3(256), 0, h->stream, f);
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipMemcpyAsync(tt, h->dt_dev, sizeof(tt), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));

@@ -4,13 +4,18 @@
 # usage: tools/profile.sh <tag> [bench args...]   -> gpurun_out/prof/<tag>/
 set -u
 TAG=${1:-c2}; shift || true
-ARGS="--steps 6 --warmup 2 --no-cpu-baseline $*"
+# the trace pass runs bench.py with its default --steps/--warmup (the command the bench line comes from, so the
+# kernel's average duration is comparable); the counter passes need only a few launches
+TRACE_ARGS="--no-cpu-baseline $*"
+PMC_ARGS="--steps 6 --warmup 2 --no-cpu-baseline $*"
 OUT=$PWD/gpurun_out/prof/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 run() { # name, rocprof options...
   local name=$1; shift
-  ( cd /tmp && rocprofv3 "$@" -d $OUT/$name -o $name -f csv -- python $OLDPWD/bench.py $ARGS ) > $OUT/$name.log 2>&1
+  local args=$PMC_ARGS
+  [ "$name" = trace ] && args=$TRACE_ARGS
+  ( cd /tmp && rocprofv3 "$@" -d $OUT/$name -o $name -f csv -- python $OLDPWD/bench.py $args ) > $OUT/$name.log 2>&1
   tail -1 $OUT/$name.log | cut -c1-300
 }
 run trace --kernel-trace --stats
