@@ -70,7 +70,7 @@ SYMBOLS = [
     "dflo_hip_n_rim_shards", "dflo_hip_stage_rim", "dflo_hip_stage_rim_send", "dflo_hip_stage_rim_recv",
     "dflo_hip_stage_interior", "dflo_hip_stage_join",
     "dflo_hip_scalar_ptrs", "dflo_hip_apply_dt_rules", "dflo_hip_debug_math",
-    "dflo_mesh_cartesian", "dflo_mesh_from_quads", "dflo_mesh_read_gmsh", "dflo_mesh_partition", "dflo_mesh_free",
+    "dflo_mesh_cartesian", "dflo_mesh_from_quads", "dflo_mesh_read_gmsh", "dflo_mesh_partition", "dflo_mesh_make_periodic", "dflo_mesh_free",
     "dflo_mesh_last_error", "dflo_mesh_support_points",
 ]
 
@@ -148,6 +148,7 @@ _sig("dflo_mesh_from_quads", C.c_int, C.c_int32, _dp, C.c_int32, _ip, C.c_int32,
 _sig("dflo_mesh_read_gmsh", C.c_int, C.c_char_p, C.c_int32, C.c_int32, C.POINTER(_MP))
 _sig("dflo_mesh_partition", C.c_int, _MP, C.c_int32, C.c_int32, C.POINTER(_MP), C.POINTER(_ip), C.POINTER(_ip),
      C.POINTER(_ip))
+_sig("dflo_mesh_make_periodic", C.c_int, _MP, C.c_int32, C.c_int32, C.c_int32)
 _sig("dflo_mesh_free", None, _MP)
 _sig("dflo_mesh_last_error", C.c_char_p)
 _sig("dflo_mesh_support_points", C.c_int, _MP, _dp)

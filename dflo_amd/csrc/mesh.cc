@@ -341,6 +341,43 @@ int dflo_mesh_partition(const dflo_mesh_t *mesh, int32_t n_ranks, int32_t rank, 
   return DFLO_OK;
 }
 
+// GridTools::collect_periodic_faces + add_periodicity (src_mpi/claw.cc:156-200): the boundary faces with ids
+// id_first / id_second, offset along `direction` (0 = x, 1 = y), are matched by their extent in the other
+// coordinate and become each other's (periodic) neighbours.
+int dflo_mesh_make_periodic(dflo_mesh_t *mesh, int32_t id_first, int32_t id_second, int32_t direction) {
+  if (!mesh || direction < 0 || direction > 1 || id_first == id_second) return fail(DFLO_ERR_BAD_PARAM, "dflo_mesh_make_periodic: bad arguments");
+  if (mesh->n_owned_cells != mesh->n_cells) return fail(DFLO_ERR_BAD_PARAM, "make_periodic works on unpartitioned meshes");
+  struct PF { double lo, hi, start; int32_t cell, face; };
+  std::vector<PF> A, B;
+  const int o = 1 - direction;
+  int32_t *nbr = const_cast<int32_t *>(mesh->cell_face_neighbor), *nbrf = const_cast<int32_t *>(mesh->cell_face_neighbor_face);
+  for (int32_t c = 0; c < mesh->n_cells; ++c)
+    for (int f = 0; f < 4; ++f) {
+      const int32_t nb = nbr[(size_t)c * 4 + f];
+      if (nb != DFLO_NBR_BOUNDARY(id_first) && nb != DFLO_NBR_BOUNDARY(id_second)) continue;
+      const double *v = mesh->cell_vertices + (size_t)c * 8;
+      const double p0 = v[kFaceVerts[f][0] * 2 + o], p1 = v[kFaceVerts[f][1] * 2 + o];
+      (nb == DFLO_NBR_BOUNDARY(id_first) ? A : B).push_back({std::min(p0, p1), std::max(p0, p1), p0, c, f});
+    }
+  if (A.empty() || A.size() != B.size()) return fail(DFLO_ERR_BAD_PARAM, "periodic boundaries have different numbers of faces");
+  auto by_lo = [](const PF &x, const PF &y) { return x.lo < y.lo; };
+  std::sort(A.begin(), A.end(), by_lo);
+  std::sort(B.begin(), B.end(), by_lo);
+  for (size_t k = 0; k < A.size(); ++k) {
+    const double tol = 1.0e-10 * std::max(1.0, std::fabs(A[k].hi - A[k].lo));
+    if (std::fabs(A[k].lo - B[k].lo) > tol || std::fabs(A[k].hi - B[k].hi) > tol)
+      return fail(DFLO_ERR_BAD_PARAM, "faces of the periodic boundaries do not match");
+  }
+  for (size_t k = 0; k < A.size(); ++k) {
+    const bool flip = std::fabs(A[k].start - B[k].start) > 0.5 * (A[k].hi - A[k].lo);
+    nbr[(size_t)A[k].cell * 4 + A[k].face] = B[k].cell;
+    nbrf[(size_t)A[k].cell * 4 + A[k].face] = B[k].face | (flip ? 4 : 0) | 8;
+    nbr[(size_t)B[k].cell * 4 + B[k].face] = A[k].cell;
+    nbrf[(size_t)B[k].cell * 4 + B[k].face] = A[k].face | (flip ? 4 : 0) | 8;
+  }
+  return DFLO_OK;
+}
+
 }  // extern "C"
 
 // ---- support points of the Qk DoFs (unit support points mapped to real space; what

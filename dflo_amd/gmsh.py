@@ -1,0 +1,70 @@
+"""Gmsh `.msh` (format 2.2, ASCII) writer for the transfinite, recombined multi-block rectangles the example
+`.geo` files describe.  The reference ships only the `.geo` sources and expects `gmsh -2` to turn them into the
+`.msh` its `mesh file` entry names (README.md:70-72); gmsh is not part of this image, so the structured meshes of
+examples/{sod_shock_tube,isentropic_vortex,double_mach_reflection}/*.geo are generated here, in the same file
+format the reader (dflo_mesh_read_gmsh) and GridIn::read_msh consume: nodes, 2-node lines carrying the
+"Physical Line" id, 4-node quadrangles carrying the "Physical Surface" id.
+"""
+import numpy as np
+
+
+def write_structured_msh(path, xs, ys, boundary_id, surface_id=100):
+    """Rectangle with grid lines xs, ys.  boundary_id(side, mid) -> physical line id for the boundary edge on
+    side "bottom" | "right" | "top" | "left" whose midpoint has the running coordinate `mid`."""
+    xs, ys = np.asarray(xs, dtype=np.float64), np.asarray(ys, dtype=np.float64)
+    nx, ny = len(xs) - 1, len(ys) - 1
+    node = lambda i, j: 1 + i + (nx + 1) * j
+    lines = []
+    for i in range(nx):
+        mid = 0.5 * (xs[i] + xs[i + 1])
+        lines.append((boundary_id("bottom", mid), node(i, 0), node(i + 1, 0)))
+        lines.append((boundary_id("top", mid), node(i + 1, ny), node(i, ny)))
+    for j in range(ny):
+        mid = 0.5 * (ys[j] + ys[j + 1])
+        lines.append((boundary_id("right", mid), node(nx, j), node(nx, j + 1)))
+        lines.append((boundary_id("left", mid), node(0, j + 1), node(0, j)))
+    with open(path, "w") as f:
+        f.write("$MeshFormat\n2.2 0 8\n$EndMeshFormat\n$Nodes\n%d\n" % ((nx + 1) * (ny + 1)))
+        for j in range(ny + 1):
+            for i in range(nx + 1):
+                f.write("%d %.17g %.17g 0\n" % (node(i, j), xs[i], ys[j]))
+        f.write("$EndNodes\n$Elements\n%d\n" % (len(lines) + nx * ny))
+        e = 1
+        for pid, a, b in lines:
+            f.write("%d 1 2 %d %d %d %d\n" % (e, pid, pid, a, b))
+            e += 1
+        for j in range(ny):
+            for i in range(nx):
+                f.write("%d 3 2 %d 1 %d %d %d %d\n" % (e, surface_id, node(i, j), node(i + 1, j), node(i + 1, j + 1), node(i, j + 1)))
+                e += 1
+        f.write("$EndElements\n")
+
+
+def sod_tube(path, nx=101, ny=11, Lx=1.0):
+    """examples/sod_shock_tube/tube.geo: nx x ny points, dx = Lx/(nx-1), Ly = dx (ny-1); lines: 0 walls, 1 outlet, 2 inlet."""
+    dx = Lx / (nx - 1)
+    write_structured_msh(path, np.linspace(0.0, Lx, nx), dx * np.arange(ny),
+                         lambda side, mid: {"bottom": 0, "top": 0, "right": 1, "left": 2}[side])
+
+
+def vortex_square(path, n=101, L=10.0):
+    """examples/isentropic_vortex/grid.geo: [-L/2, L/2]^2 with n points per side; lines 1 bottom, 2 right, 3 top, 4 left."""
+    p = np.linspace(-0.5 * L, 0.5 * L, n)
+    write_structured_msh(path, p, p, lambda side, mid: {"bottom": 1, "right": 2, "top": 3, "left": 4}[side], surface_id=10)
+
+
+def double_mach(path, ny=101, Lx=4.0, Ly=1.0, x0=1.0 / 6.0):
+    """examples/double_mach_reflection/grid.geo: square cells of size dy = Ly/(ny-1), the grid line x = x0 kept;
+    lines 0 bottom (x < x0), 1 bottom (x > x0), 2 right, 3 top, 4 left."""
+    dy = Ly / (ny - 1)
+    n1 = int(np.ceil(x0 / dy))
+    n2 = int(np.ceil((Lx - x0) / dy))
+    xs = x0 + dy * np.arange(-n1, n2 + 1)
+    ys = dy * np.arange(ny)
+
+    def bid(side, mid):
+        if side == "bottom":
+            return 0 if mid < x0 else 1
+        return {"right": 2, "top": 3, "left": 4}[side]
+
+    write_structured_msh(path, xs, ys, bid)

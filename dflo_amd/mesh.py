@@ -55,6 +55,12 @@ class Mesh:
             raise DfloError(rc, lib.dflo_mesh_last_error().decode())
         return Mesh(out)
 
+    def make_periodic(self, id_first, id_second, direction):
+        """Turn the boundaries id_first / id_second (offset along direction "x" | "y") into periodic neighbours."""
+        rc = lib.dflo_mesh_make_periodic(self._ptr, id_first, id_second, {"x": 0, "y": 1}[direction])
+        if rc:
+            raise DfloError(rc, lib.dflo_mesh_last_error().decode())
+
     def partition(self, n_ranks, rank):
         """Owned + one ghost layer sub-mesh of `rank` (replaces parallel::distributed::Triangulation)."""
         out = C.POINTER(_lib.MeshStruct)()

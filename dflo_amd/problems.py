@@ -62,3 +62,29 @@ def smooth_perturbation(x, y, L=10.0):
     v = -0.2 + 0.25 * np.sin(2 * np.pi * (x + y) / L)
     p = 1.0 + 0.3 * np.cos(2 * np.pi * x / L + 0.7) * np.cos(2 * np.pi * y / L - 0.2)
     return rho * u, rho * v, rho, p / (GAMMA - 1.0) + 0.5 * rho * (u * u + v * v)
+
+
+def rayleigh_taylor(x, y, gravity=1.0, Lx=0.5, Ly=1.5, A=0.01, P0=2.5):
+    """RayleighTaylor::vector_value, src/ic.cc:12-37 (constants src/ic.h:23-26)."""
+    rho = np.where(y < 0.0, 1.0, 2.0)
+    vel = A * (1.0 + np.cos(2.0 * np.pi * x / Lx)) / 2.0 * (1.0 + np.cos(2.0 * np.pi * y / Ly)) / 2.0
+    pre = P0 - gravity * rho * y
+    return 0.0 * x, rho * vel, rho, pre / (GAMMA - 1.0) + 0.5 * rho * vel * vel
+
+
+def vortex_system(x, y, beta=5.0, Rc=4.0):
+    """VortexSystem::vector_value, src/ic.cc:68-94 (three vortices on a circle of radius Rc, src/ic.h:63-77)."""
+    a1 = 0.5 * beta / np.pi
+    a2 = (GAMMA - 1.0) * a1 ** 2 / 2.0
+    xs = [0.0, Rc * np.cos(np.pi / 6.0), -Rc * np.cos(np.pi / 6.0)]
+    ys = [-Rc, Rc * np.sin(np.pi / 6.0), Rc * np.sin(np.pi / 6.0)]
+    rho, vex, vey = 0.0, 0.0, 0.0
+    for xi, yi in zip(xs, ys):
+        r2 = (x - xi) ** 2 + (y - yi) ** 2
+        rho = rho + (1.0 - a2 * np.exp(1.0 - r2)) ** (1.0 / (GAMMA - 1.0))
+        vex = vex - a1 * (y - yi) * np.exp(0.5 * (1.0 - r2))
+        vey = vey + a1 * (x - xi) * np.exp(0.5 * (1.0 - r2))
+    rho = rho - 2.0
+    vex, vey = vex / 3.0, vey / 3.0
+    pre = np.where((np.abs(x) < 0.1) & (np.abs(y) < 0.1), 50.0, rho ** GAMMA)
+    return rho * vex, rho * vey, rho, pre / (GAMMA - 1.0) + 0.5 * rho * (vex * vex + vey * vey)

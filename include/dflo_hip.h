@@ -268,6 +268,10 @@ int dflo_mesh_from_quads(int32_t n_vertices, const double *vertices, int32_t n_q
                          dflo_mesh_t **out);
 /* Gmsh v2 ASCII .msh with quads + physical lines (what "gmsh -2 file.geo" writes, README.md:70-72). */
 int dflo_mesh_read_gmsh(const char *path, int32_t degree, int32_t mapping, dflo_mesh_t **out);
+/* Pair the boundary faces with ids id_first / id_second, offset along direction (0 = x, 1 = y), into periodic
+ * neighbours in place: GridTools::collect_periodic_faces + add_periodicity for the "type = periodic", "pair",
+ * "direction" entries of a boundary subsection (src_mpi/parameters.cc:397-410, src_mpi/claw.cc:156-200). */
+int dflo_mesh_make_periodic(dflo_mesh_t *mesh, int32_t id_first, int32_t id_second, int32_t direction);
 /* Sub-mesh of rank `rank` of `n_ranks` (contiguous slabs of the cell order after a
  * coordinate sort) with one layer of face-neighbour ghost cells -- the flat
  * equivalent of parallel::distributed::Triangulation's owned+ghost view

@@ -1,0 +1,166 @@
+"""Mini-driver (python -m dflo_amd input.prm) end to end on the GPU: .prm + .msh in, solution-NNN.vtu out,
+against the oracle driven with the same parsed input."""
+import os
+import sys
+import xml.etree.ElementTree as ET
+
+import numpy as np
+import pytest
+
+import dflo_amd
+from dflo_amd import gmsh, vtu
+from dflo_amd.prm import InputDeck
+from dflo_amd.run import Run, main
+import oracle_lib
+from test_frontend import SOD_PRM
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_run(deck, mesh, n_steps):
+    ora = oracle_lib.Oracle(mesh, deck.parameters)
+    cell, face, bid, xy = ora.boundary_faces()
+    bv = np.zeros(xy.shape[:2] + (4,))
+    for b in np.unique(bid):
+        bv[bid == b] = np.stack(deck.boundary_values[int(b)](xy[bid == b][..., 0], xy[bid == b][..., 1], 0.0), axis=-1)
+    ora.set_boundary_values(0, bv)
+    ora.set_boundary_values(1, bv)
+    ora.set_solution(mesh.interpolate(deck.initial_conditions))
+    ora.apply_limiter()
+    t = 0.0
+    for it in range(n_steps):
+        dt = ora.compute_time_step(t)
+        ora.step(dt)
+        t += dt
+    return ora, t
+
+
+@pytest.mark.parametrize("basis", ["Qk", "Pk"])
+def test_sod_from_prm_and_msh(tmp_path, basis):
+    gmsh.sod_tube(str(tmp_path / "tube.msh"), nx=41, ny=5)
+    prm = tmp_path / "input.prm"
+    prm.write_text(SOD_PRM.replace("set basis = Qk", "set basis = " + basis))
+    out = tmp_path / "out"
+    rc = main([str(prm), "4", "--outdir", str(out), "--max-steps", "12", "--quiet"])
+    assert rc == 0
+    files = sorted(os.listdir(out))
+    assert files == ["shock.vtu", "solution-000.vtu", "solution-001.vtu", "solution-002.vtu"]   # IC + every 5 iterations
+    deck = InputDeck.read(str(prm))
+    run = Run(deck, str(tmp_path / "out2"), quiet=True)
+    run.run(max_steps=10)
+    ora, t = _oracle_run(deck, run.mesh, 10)
+    assert abs(run.claw.elapsed_time - t) < 1e-12 * t
+    assert np.abs(run.claw.current_solution - ora.get_solution()).max() < 1e-8
+    # solution-002.vtu is the state after 10 iterations
+    root = ET.parse(str(out / "solution-002.vtu")).getroot()
+    da = [d for d in root.iter("DataArray") if d.get("Name") == "Density"][0]
+    rho = vtu.decode_data_array(da.text, np.float64)
+    _, _, fields = vtu.patch_fields(run.mesh, ora.get_solution())
+    assert np.abs(rho - dict(fields)["Density"]).max() < 1e-8
+
+
+def test_fast_mode_and_final_time(tmp_path):
+    """--fast advances in device-resident chunks; the last step is clipped to `final time` (src/claw.cc:473-474)."""
+    gmsh.vortex_square(str(tmp_path / "grid.msh"), n=17, L=10.0)
+    text = """
+set mesh file = grid.msh
+set degree = 2
+set mapping = cartesian
+subsection boundary_1
+   set type = periodic
+   set pair = 3
+   set direction = y
+end
+subsection boundary_2
+   set type = periodic
+   set pair = 4
+   set direction = x
+end
+subsection boundary_3
+   set type = periodic
+   set pair = 1
+   set direction = y
+end
+subsection boundary_4
+   set type = periodic
+   set pair = 2
+   set direction = x
+end
+subsection initial condition
+   set function = isenvort
+end
+subsection time stepping
+  set cfl = 0.9
+  set final time = 0.5
+end
+subsection refinement
+  set refinement = false
+end
+subsection flux
+  set flux = hllc
+end
+subsection output
+  set iter step = 1000
+end
+"""
+    prm = tmp_path / "input.prm"
+    prm.write_text(text)
+    deck = InputDeck.read(str(prm))
+    a = Run(deck, str(tmp_path / "a"), quiet=True)
+    a.run()
+    b = Run(deck, str(tmp_path / "b"), quiet=True)
+    b.run(fast=True)
+    assert abs(a.claw.elapsed_time - 0.5) < 1e-13 and abs(b.claw.elapsed_time - 0.5) < 1e-13
+    assert np.abs(a.claw.current_solution - b.claw.current_solution).max() < 1e-12
+    assert sorted(os.listdir(tmp_path / "a")) == ["shock.vtu", "solution-000.vtu", "solution-001.vtu"]   # IC and final time
+    # periodic box: the mean of every conserved variable is kept to round-off
+    u0 = a.mesh.interpolate(dflo_amd.problems.isentropic_vortex).reshape(a.mesh.n_cells, 4, -1)
+    w = np.tile(np.outer(*(2 * [np.polynomial.legendre.leggauss(3)[1] / 2])).reshape(-1), (a.mesh.n_cells, 4, 1))
+    m0 = (u0 * w).sum(axis=(0, 2))
+    m1 = (a.claw.current_solution.reshape(a.mesh.n_cells, 4, -1) * w).sum(axis=(0, 2))
+    assert np.abs(m1 - m0).max() < 1e-10 * np.abs(m0).max()
+
+
+def test_time_dependent_boundary_values(tmp_path):
+    """Boundary expressions in t are re-evaluated at t (stage 0) and t + dt (later stages), src/claw.cc:736-745."""
+    gmsh.sod_tube(str(tmp_path / "tube.msh"), nx=21, ny=5)
+    text = SOD_PRM.replace("set w_2 value = 1.0\n   set w_3 value = 2.5", "set w_2 value = 1.0 + 0.5*t\n   set w_3 value = 2.5*(1+t)")
+    text = text.replace("set type = TVB", "set type = none").replace("set positivity limiter = true", "set positivity limiter = false")
+    text = text.replace("set w_2 value = 1.0*(x<=0.5) + 0.125*(x>0.5)", "set w_2 value = 1.0 + 0.1*sin(2*pi*x)")
+    text = text.replace("set w_3 value = 2.5*(x<=0.5) + 0.250*(x>0.5)", "set w_3 value = 2.5 + 0.2*cos(2*pi*x)")
+    prm = tmp_path / "input.prm"
+    prm.write_text(text)
+    deck = InputDeck.read(str(prm))
+    assert deck.boundary_values[2].time_dependent
+    run = Run(deck, str(tmp_path / "o"), quiet=True)
+    assert run.bc_time_dependent
+    run.run(max_steps=6)
+    ora = oracle_lib.Oracle(run.mesh, deck.parameters)
+    cell, face, bid, xy = ora.boundary_faces()
+
+    def bvals(t):
+        bv = np.zeros(xy.shape[:2] + (4,))
+        for b in np.unique(bid):
+            bv[bid == b] = np.stack(deck.boundary_values[int(b)](xy[bid == b][..., 0], xy[bid == b][..., 1], t), axis=-1)
+        return bv
+
+    ora.set_solution(run.mesh.interpolate(deck.initial_conditions))
+    t = 0.0
+    for it in range(6):
+        dt = ora.compute_time_step(t)
+        ora.set_boundary_values(0, bvals(t))
+        ora.set_boundary_values(1, bvals(t + dt))
+        ora.step(dt)
+        t += dt
+    assert np.isfinite(ora.get_solution()).all()
+    assert np.abs(run.claw.current_solution - ora.get_solution()).max() < 1e-10
+    # and the time dependence was really in play
+    ora.set_boundary_values(1, bvals(0.0))
+    assert np.abs(bvals(t) - bvals(0.0)).max() > 1e-3
+
+
+def test_driver_reports_errors_like_main(tmp_path, capsys):
+    prm = tmp_path / "input.prm"
+    prm.write_text("set mesh file = missing.msh\nsubsection time stepping\n set cfl = 0.5\nend\nsubsection refinement\n set refinement = false\nend\n")
+    assert main([str(prm), "--quiet"]) == 1
+    assert "Exception on processing" in capsys.readouterr().err
