@@ -774,7 +774,7 @@ __global__ __launch_bounds__(64) void limiter_kernel(const LimArgs a) {
 
   if (a.pos_lim) {
     const double eps = 1.0e-13;
-    if (fmin(A[RHO], pressure(A)) < eps) {  // "Fatal: Negative states" :26-38
+    if (smin(A[RHO], pressure(A)) < eps) {  // "Fatal: Negative states" :26-38
       atomicOr(&a.flags[0], 1);
     } else {
       // density at GLL(Ng) x Gauss(N) and Gauss(N) x GLL(Ng)  (:43-47, :72-78)
@@ -788,10 +788,10 @@ __global__ __launch_bounds__(64) void limiter_kernel(const LimArgs a) {
             vx += kb.Pg[g][m] * U[RHO * NS + m + N * l];
             vy += kb.Pg[g][m] * U[RHO * NS + l + N * m];
           }
-          rho_min = fmin(rho_min, fmin(vx, vy));
+          rho_min = smin(smin(rho_min, vx), vy);
         }
       const double rat = fabs(A[RHO] - eps) / (fabs(A[RHO] - rho_min) + 1.0e-13);
-      const double theta1 = fmin(rat, 1.0);
+      const double theta1 = smin(rat, 1.0);
       if (theta1 < 1.0) {
 #pragma unroll
         for (int j = 0; j < NS; ++j) U[RHO * NS + j] = theta1 * U[RHO * NS + j] + (1.0 - theta1) * A[RHO];
@@ -826,10 +826,10 @@ __global__ __launch_bounds__(64) void limiter_kernel(const LimArgs a) {
               if (t1 > -1.0e-12 && t1 < 1.0 + 1.0e-12) t = t1;
               else if (t2 > -1.0e-12 && t2 < 1.0 + 1.0e-12) t = t2;
               else { fail = true; t = 0.0; }
-              t = fmin(1.0, t);
-              t = fmax(0.0, t);
+              t = smin(1.0, t);
+              t = smax(0.0, t);
               if (fabs(1.0 - t) < 1.0e-14) t = 0.0;
-              theta2 = fmin(theta2, t);
+              theta2 = smin(theta2, t);
             }
           }
       if (fail) atomicOr(&a.flags[1], 1);
@@ -1234,7 +1234,7 @@ __global__ __launch_bounds__(64) void limiter_pk_kernel(const LimArgs a) {
   }
   if (a.pos_lim) {
     const double eps = 1.0e-13;
-    if (fmin(A[RHO], pressure(A)) < eps) {
+    if (smin(A[RHO], pressure(A)) < eps) {
       atomicOr(&a.flags[0], 1);
     } else {
       // point value of component c at (Pt(xi), Pt(eta)) given the 1-D Legendre values
@@ -1250,10 +1250,10 @@ __global__ __launch_bounds__(64) void limiter_pk_kernel(const LimArgs a) {
           double pg[N], pl[N];
 #pragma unroll
           for (int n = 0; n < N; ++n) { pg[n] = a.kb.PLg[g][n]; pl[n] = a.kb.PLx[l][n]; }
-          rho_min = fmin(rho_min, fmin(point(RHO, pg, pl), point(RHO, pl, pg)));
+          rho_min = smin(smin(rho_min, point(RHO, pg, pl)), point(RHO, pl, pg));
         }
       const double rat = fabs(A[RHO] - eps) / (fabs(A[RHO] - rho_min) + 1.0e-13);
-      const double theta1 = fmin(rat, 1.0);
+      const double theta1 = smin(rat, 1.0);
       if (theta1 < 1.0) {
 #pragma unroll
         for (int m = 1; m < NM; ++m) U[RHO][m] *= theta1;
@@ -1283,10 +1283,10 @@ __global__ __launch_bounds__(64) void limiter_pk_kernel(const LimArgs a) {
               if (t1 > -1.0e-12 && t1 < 1.0 + 1.0e-12) t = t1;
               else if (t2 > -1.0e-12 && t2 < 1.0 + 1.0e-12) t = t2;
               else { fail = true; t = 0.0; }
-              t = fmin(1.0, t);
-              t = fmax(0.0, t);
+              t = smin(1.0, t);
+              t = smax(0.0, t);
               if (fabs(1.0 - t) < 1.0e-14) t = 0.0;
-              theta2 = fmin(theta2, t);
+              theta2 = smin(theta2, t);
             }
           }
       if (fail) atomicOr(&a.flags[1], 1);

@@ -37,20 +37,24 @@ __device__ __forceinline__ double fsqrt(double x) {  // x > 0
   return __builtin_fma(d, h, g);
 }
 __device__ __forceinline__ double fsqrt0(double x) { return x > 0.0 ? fsqrt(x) : 0.0; }
-// sqrt(x) and 1/x from one v_rsq_f64: g -> sqrt(x), h -> 1/(2 sqrt(x)), 1/x = 4 h^2 refined once
+// sqrt(x) and 1/x from one v_rsq_f64: g -> sqrt(|x|), h -> 1/(2 sqrt(|x|)), 1/|x| = 4 h^2 refined once.
+// For x < 0 the reference's `W/rho` is an ordinary (negative) quotient while its sqrt(rho) is NaN -- both are
+// reproduced: the reciprocal carries the sign of x, the root becomes NaN.
 __device__ __forceinline__ void fsqrt_rcp(double x, double &sq, double &rc) {
-  const double y = __builtin_amdgcn_rsq(x);
-  double g = x * y, h = 0.5 * y;
+  const double ax = fabs(x);
+  const double y = __builtin_amdgcn_rsq(ax);
+  double g = ax * y, h = 0.5 * y;
   const double r = __builtin_fma(-h, g, 0.5);
   g = __builtin_fma(g, r, g);
   h = __builtin_fma(h, r, h);
-  double d = __builtin_fma(-g, g, x);
+  double d = __builtin_fma(-g, g, ax);
   g = __builtin_fma(d, h, g);
-  d = __builtin_fma(-g, g, x);
-  sq = __builtin_fma(d, h, g);
-  double q = 4.0 * h * h;                      // ~ 1/x
-  const double e = __builtin_fma(-x, q, 1.0);  // one Newton step
-  rc = __builtin_fma(q, e, q);
+  d = __builtin_fma(-g, g, ax);
+  g = __builtin_fma(d, h, g);
+  sq = x < 0.0 ? __builtin_nan("") : g;
+  double q = 4.0 * h * h;                       // ~ 1/|x|
+  const double e = __builtin_fma(-ax, q, 1.0);  // one Newton step
+  rc = __builtin_copysign(__builtin_fma(q, e, q), x);
 }
 
 __device__ __forceinline__ double pressure(const double *W) {  // src/equation.h:87-92
@@ -82,6 +86,13 @@ __device__ __forceinline__ void flux_y(const double *W, double *Gy) {
   Gy[RHO] = W[MY];
   Gy[EN] = v * (W[EN] + p);
 }
+
+// std::min / std::max exactly as the reference calls them, (b < a) ? b : a and (a < b) ? b : a -- not fmin / fmax.
+// With a NaN operand (the square root of a negative pressure or density at a face point of an under-resolved
+// strong shock) the result depends on the argument order, every later comparison is false, and the branch the
+// reference then falls into (e.g. the one-sided supersonic flux of hllc_flux) has to be reproduced.
+__device__ __forceinline__ double smin(double a, double b) { return (b < a) ? b : a; }
+__device__ __forceinline__ double smax(double a, double b) { return (a < b) ? b : a; }
 
 // |v.n| + c of a (cell average) state, src/equation.h:122-137
 __device__ __forceinline__ double max_eigenvalue_n(const double *W, double nx, double ny) {
@@ -117,7 +128,7 @@ __device__ __forceinline__ void lxf_flux(double nx, double ny, const double *Wp,
   const double vm = (Wm[MX] * nx + Wm[MY] * ny) * rm;
   const double pp = kG1 * (Wp[EN] - 0.5 * (Wp[MX] * Wp[MX] + Wp[MY] * Wp[MY]) * rp);
   const double pm = kG1 * (Wm[EN] - 0.5 * (Wm[MX] * Wm[MX] + Wm[MY] * Wm[MY]) * rm);
-  const double lambda = fmax(fabs(Ap[0] * nx + Ap[1] * ny) + Ap[2], fabs(Am[0] * nx + Am[1] * ny) + Am[2]);
+  const double lambda = smax(fabs(Ap[0] * nx + Ap[1] * ny) + Ap[2], fabs(Am[0] * nx + Am[1] * ny) + Am[2]);
   F[MX] = 0.5 * (pp * nx + Wp[MX] * vp + pm * nx + Wm[MX] * vm);
   F[MY] = 0.5 * (pp * ny + Wp[MY] * vp + pm * ny + Wm[MY] * vm);
   F[RHO] = 0.5 * (Wp[RHO] * vp + Wm[RHO] * vm);
@@ -136,10 +147,10 @@ __device__ __forceinline__ void steger_warming_flux(double nx, double ny, const 
   const double q2m = (Wm[MX] * Wm[MX] + Wm[MY] * Wm[MY]) * (rm * rm);
   const double pp = kG1 * (Wp[EN] - 0.5 * Wp[RHO] * q2p), pm = kG1 * (Wm[EN] - 0.5 * Wm[RHO] * q2m);
   const double cp = fsqrt(kGamma * pp * rp), cm = fsqrt(kGamma * pm * rm);
-  const double l1p = fmax(vp, 0.0), l2p = fmax(vp + cp, 0.0), l3p = fmax(vp - cp, 0.0);
+  const double l1p = smax(vp, 0.0), l2p = smax(vp + cp, 0.0), l3p = smax(vp - cp, 0.0);
   const double ap = 2.0 * kG1 * l1p + l2p + l3p;
   const double fp = Wp[RHO] * (0.5 / kGamma);
-  const double l1m = fmin(vm, 0.0), l2m = fmin(vm + cm, 0.0), l3m = fmin(vm - cm, 0.0);
+  const double l1m = smin(vm, 0.0), l2m = smin(vm + cm, 0.0), l3m = smin(vm - cm, 0.0);
   const double am = 2.0 * kG1 * l1m + l2m + l3m;
   const double fm = Wm[RHO] * (0.5 / kGamma);
   double pf[4], mf[4];
@@ -244,8 +255,8 @@ __device__ __forceinline__ void hllc_flux(double nx, double ny, const double *Wl
   const double er = Wr[EN] * rir;
   const double h = hl * fl + hr * fr;
   const double c = fsqrt(kG1 * (h - 0.5 * v2));
-  const double sl = fmin(veln - c, vln - cl);
-  const double sr = fmax(veln + c, vrn + cr);
+  const double sl = smin(veln - c, vln - cl);
+  const double sr = smax(veln + c, vrn + cr);
   const double sm = (pl - pr - Wl[RHO] * vln * (sl - vln) + Wr[RHO] * vrn * (sr - vrn)) *
                     frcp(Wr[RHO] * (sr - vrn) - Wl[RHO] * (sl - vln));
   const double pstar = Wr[RHO] * (vrn - sr) * (vrn - sm) + pr;
@@ -351,7 +362,7 @@ __device__ __forceinline__ double minmod(double a, double b, double c, double Md
   if (aa < Mdx2) return a;
   if (a * b > 0 && b * c > 0) {
     const double s = (a > 0) ? 1.0 : -1.0;
-    return s * fmin(aa, fmin(fabs(b), fabs(c)));
+    return s * smin(aa, smin(fabs(b), fabs(c)));
   }
   return 0.0;
 }

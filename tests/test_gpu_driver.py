@@ -164,3 +164,97 @@ def test_driver_reports_errors_like_main(tmp_path, capsys):
     prm.write_text("set mesh file = missing.msh\nsubsection time stepping\n set cfl = 0.5\nend\nsubsection refinement\n set refinement = false\nend\n")
     assert main([str(prm), "--quiet"]) == 1
     assert "Exception on processing" in capsys.readouterr().err
+
+
+DMR_PRM = """
+set mesh file = grid.msh
+set degree = %(degree)d
+set mapping = cartesian
+set basis = %(basis)s
+subsection boundary_0
+   set type = outflow
+end
+subsection boundary_1
+   set type = slip
+end
+subsection boundary_2
+   set type = outflow
+end
+subsection boundary_3
+   set type = inflow
+   set w_0 value =  57.1576766498*(x<1.0/6.0+(1+20*t)/sqrt(3)) + 0.0
+   set w_1 value =  -33.0*(x<1.0/6.0+(1+20*t)/sqrt(3)) + 0.0
+   set w_2 value =  8.0*(x<1.0/6.0+(1+20*t)/sqrt(3)) + 1.4*(x>=1.0/6.0+(1+20*t)/sqrt(3))
+   set w_3 value =  563.5*(x<1.0/6.0+(1+20*t)/sqrt(3)) + 2.5*(x>=1.0/6.0+(1+20*t)/sqrt(3))
+end
+subsection boundary_4
+   set type = inflow
+   set w_0 value =  57.1576766498
+   set w_1 value =  -33.0
+   set w_2 value =  8.0
+   set w_3 value =  563.5
+end
+subsection initial condition
+   set w_0 value =  57.1576766498*(x<1.0/6.0+y/sqrt(3)) + 0.0
+   set w_1 value =  -33.0*(x<1.0/6.0+y/sqrt(3)) + 0.0
+   set w_2 value =  8.0*(x<1.0/6.0+y/sqrt(3)) + 1.4*(x>=1.0/6.0+y/sqrt(3))
+   set w_3 value =  563.5*(x<1.0/6.0+y/sqrt(3)) + 2.5*(x>=1.0/6.0+y/sqrt(3))
+end
+subsection time stepping
+  set cfl = 0.9
+  set final time = 0.2
+end
+subsection refinement
+  set refinement = false
+end
+subsection flux
+ set flux = hllc
+end
+subsection limiter
+   set type = TVB
+   set shock indicator = limiter
+   set characteristic limiter = true
+   set positivity limiter = %(pos)s
+   set M = 100.0
+   set beta = 1.0
+end
+"""
+
+
+@pytest.mark.parametrize("degree,basis,pos", [(1, "Pk", "false"), (2, "Qk", "true")])
+def test_double_mach_reflection_c4_style(tmp_path, degree, basis, pos):
+    """C4 path: Mach-10 shock, slip / outflow walls, the inflow state on the top boundary moving with the shock
+    (time-dependent boundary function), HLLC + TVB (+ positivity); state of the shipped input and of BASELINE's C4."""
+    gmsh.double_mach(str(tmp_path / "grid.msh"), ny=13)
+    prm = tmp_path / "input.prm"
+    prm.write_text(DMR_PRM % {"degree": degree, "basis": basis, "pos": pos})
+    deck = InputDeck.read(str(prm))
+    run = Run(deck, str(tmp_path / "o"), quiet=True)
+    assert run.bc_time_dependent and run.mesh.n_cells == 49 * 12
+    n = 12
+    run.run(max_steps=n)
+    ora = oracle_lib.Oracle(run.mesh, deck.parameters)
+    cell, face, bid, xy = ora.boundary_faces()
+
+    def bvals(t):
+        bv = np.zeros(xy.shape[:2] + (4,))
+        for b in np.unique(bid):
+            bv[bid == b] = np.stack(deck.boundary_values[int(b)](xy[bid == b][..., 0], xy[bid == b][..., 1], t), axis=-1)
+        return bv
+
+    ora.set_boundary_values(0, bvals(0.0))
+    ora.set_boundary_values(1, bvals(0.0))
+    ora.set_solution(run.mesh.interpolate(deck.initial_conditions))
+    ora.apply_limiter()
+    t = 0.0
+    for it in range(n):
+        dt = ora.compute_time_step(t)
+        ora.set_boundary_values(0, bvals(t))
+        ora.set_boundary_values(1, bvals(t + dt))
+        ora.step(dt)
+        t += dt
+    assert abs(run.claw.elapsed_time - t) < 1e-10 * t
+    u, uo = run.claw.current_solution, ora.get_solution()
+    scale = np.abs(uo).max()
+    assert np.abs(run.claw.cell_average - ora.get_cell_average()).max() < 1e-8 * scale
+    assert np.abs(u - uo).max() < 1e-6 * scale

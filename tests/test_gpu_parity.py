@@ -519,3 +519,39 @@ def test_kxrcf_unsupported_configurations():
     mesh.set_mapping("q1")
     with pytest.raises(dflo_amd.DfloError):
         dflo_amd.ConservationLaw(mesh, dflo_amd.Parameters(flux="lxf", shock_indicator="density"))
+
+
+@pytest.mark.parametrize("flux", FLUXES)
+@pytest.mark.parametrize("degree", [1, 2])
+def test_unresolved_mach10_shock_same_branches_as_reference(flux, degree):
+    """Interpolating a Mach-10 discontinuity puts negative densities / pressures at face points; the square roots
+    are NaN there and the reference then takes whatever branch `std::min/std::max/if` leave it (e.g. HLLC's one-sided
+    flux).  The device has to land in the same branch: same NaN pattern, same finite values."""
+    def ic(x, y):
+        s = x < 1.0 / 6.0 + y / np.sqrt(3.0)
+        return [57.1576766498 * s, -33.0 * s, 8.0 * s + 1.4 * (~s), 563.5 * s + 2.5 * (~s)]
+
+    mesh = dflo_amd.Mesh.cartesian(16, 8, 0.0, 0.0, 1.0 / 12, [4, 2, 1, 3], degree)
+    prm = dflo_amd.Parameters(flux=flux, boundary={1: "slip", 2: "outflow", 3: "inflow", 4: "inflow"})
+    claw, ora = dflo_amd.ConservationLaw(mesh, prm), oracle_lib.Oracle(mesh, prm)
+    cell, face, bid, xy = claw.boundary_faces()
+    bv = np.stack(ic(xy[..., 0] - 10.0, xy[..., 1]), axis=-1).astype(float)
+    for w in (0, 1):
+        claw.set_boundary_values(w, bv)
+        ora.set_boundary_values(w, bv)
+    u0 = mesh.interpolate(ic)
+    claw.set_initial_condition(u0)
+    ora.set_solution(u0)
+    r, ro = claw.assemble_system(), ora.assemble()
+    if flux in ("hllc", "lxf"):
+        # these two survive in the reference (HLLC falls into its one-sided flux, LxF takes no square root of a
+        # point value): no NaN on either side
+        assert not np.isnan(ro).any() and not np.isnan(r).any()
+    else:
+        # sw / kfvs / roe return NaN at such a point.  The reference's dense `ndof x n_q` lifting loops then spread
+        # it to every DoF of both cells (0 * NaN); the collocated device lifting touches only the DoFs that point
+        # feeds, so the device's NaN set is a subset -- the run is lost either way
+        assert np.isnan(ro).any() and (np.isnan(ro) | ~np.isnan(r)).all()
+    ok = ~np.isnan(ro)
+    assert ok.sum() > 0.7 * ok.size
+    assert np.abs(r[ok] - ro[ok]).max() <= 1e-11 * np.abs(ro[ok]).max()
