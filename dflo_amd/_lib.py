@@ -61,7 +61,7 @@ SYMBOLS = [
     "dflo_hip_create", "dflo_hip_destroy", "dflo_hip_last_error", "dflo_hip_set_stream", "dflo_hip_n_dofs",
     "dflo_hip_dofs_per_cell", "dflo_hip_n_rk", "dflo_hip_set_solution", "dflo_hip_get_solution",
     "dflo_hip_get_cell_average", "dflo_hip_n_boundary_faces", "dflo_hip_boundary_faces",
-    "dflo_hip_set_boundary_values", "dflo_hip_residual", "dflo_hip_compute_dt", "dflo_hip_step", "dflo_hip_stage",
+    "dflo_hip_set_boundary_values", "dflo_hip_set_boundary_program", "dflo_hip_get_boundary_values", "dflo_hip_residual", "dflo_hip_compute_dt", "dflo_hip_step", "dflo_hip_stage",
     "dflo_hip_end_step", "dflo_hip_advance", "dflo_hip_compute_cell_average", "dflo_hip_apply_limiter",
     "dflo_hip_apply_positivity_limiter", "dflo_hip_compute_shock_indicator", "dflo_hip_get_shock_indicator", "dflo_hip_check", "dflo_hip_synchronize", "dflo_hip_stage_timing",
     "dflo_hip_set_send_cells", "dflo_hip_pack_send", "dflo_hip_pack_send_avg", "dflo_hip_unpack_ghost",
@@ -107,6 +107,8 @@ _sig("dflo_hip_get_cell_average", C.c_int, _H, _dp)
 _sig("dflo_hip_n_boundary_faces", C.c_int32, _H)
 _sig("dflo_hip_boundary_faces", C.c_int, _H, _ip, _ip, _ip, _dp)
 _sig("dflo_hip_set_boundary_values", C.c_int, _H, C.c_int, _dp)
+_sig("dflo_hip_set_boundary_program", C.c_int, _H, C.c_int32, C.c_int32, C.c_int32, _ip, C.c_int32, _dp)
+_sig("dflo_hip_get_boundary_values", C.c_int, _H, C.c_int, _dp)
 _sig("dflo_hip_residual", C.c_int, _H, C.c_int, _dp)
 _sig("dflo_hip_compute_dt", C.c_int, _H, C.c_double, _dp)
 _sig("dflo_hip_step", C.c_int, _H, C.c_double, _dp, _dp)

@@ -74,6 +74,25 @@ class ConservationLaw:
         v = np.ascontiguousarray(values, dtype=np.float64)
         self._chk(lib.dflo_hip_set_boundary_values(self._h, which, _lib.dptr(v)))
 
+    def set_boundary_function(self, boundary_id, expressions):
+        """Evaluate the four `w_i value` expressions of boundary `boundary_id` on the device at t / t + dt of every
+        step (replaces the per-step set_boundary_values for time-dependent boundary data). None removes a program."""
+        from .expr import compile_program
+        for c, e in enumerate(expressions):
+            if e is None:
+                ops, consts = np.zeros((0, 2), dtype=np.int32), np.zeros(0)
+            else:
+                ops, consts = compile_program(e, ("x", "y", "t"))
+            ops = np.ascontiguousarray(ops, dtype=np.int32)
+            consts = np.ascontiguousarray(consts, dtype=np.float64)
+            self._chk(lib.dflo_hip_set_boundary_program(self._h, boundary_id, c, len(ops), _lib.iptr(ops), len(consts), _lib.dptr(consts)))
+
+    def get_boundary_values(self, which):
+        n = lib.dflo_hip_n_boundary_faces(self._h)
+        v = np.empty((n, self.mesh.degree + 1, 4))
+        self._chk(lib.dflo_hip_get_boundary_values(self._h, which, _lib.dptr(v)))
+        return v
+
     # ---- the hot path
     def assemble_system(self, which=0):
         """right_hand_side of the current solution (src/assemble_explicit.cc:433-452)."""

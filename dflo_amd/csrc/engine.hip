@@ -1385,6 +1385,97 @@ __global__ __launch_bounds__(64) void indicator_kernel(const IndArgs a) {
   a.shock[(size_t)shard * 64 + lane] = fabs(ind) / denominator;  // 0/0 -> NaN -> "not > 1": not limited, as in the reference
 }
 
+// ------------------------------------------------------------------ boundary functions on the device
+// The boundary values of integrate_boundary_term_explicit (FunctionParser::vector_value_list at the face
+// quadrature points with set_time(bc_time), src/assemble_explicit.cc:161-165, src/claw.cc:736-745) evaluated by
+// the device from postfix programs (dflo_hip_set_boundary_program): no host round trip per step for
+// time-dependent boundary data (C4's moving shock on the top wall).
+struct BcArgs {
+  const int32_t *ops;       // [n][2] (dflo_expr_op, constant index)
+  const double *consts;
+  const int32_t *prog;      // [DFLO_MAX_BOUNDARIES][4][2] (first op, number of ops); 0 ops = values stay as uploaded
+  const int32_t *bface_id;  // [n_bfaces]
+  const double *bxy;        // [n_bfaces][N][2]
+  double *bval;             // [n_bfaces][N][4]
+  const double *dt_dev;     // [0] dt, [1] elapsed time
+  double dt_host;
+  int add_dt, n_points, N;
+};
+constexpr int kExprStack = 16;
+__device__ double run_program(const int32_t *ops, int n, const double *consts, double x, double y, double t) {
+  double st[kExprStack];
+  int sp = 0;
+  for (int i = 0; i < n; ++i) {
+    const int op = ops[2 * i];
+    if (op <= DFLO_OP_T) {  // pushes
+      st[sp++] = op == DFLO_OP_CONST ? consts[ops[2 * i + 1]] : (op == DFLO_OP_X ? x : (op == DFLO_OP_Y ? y : t));
+      continue;
+    }
+    if (op == DFLO_OP_SEL) {
+      sp -= 2;
+      st[sp - 1] = st[sp - 1] != 0.0 ? st[sp] : st[sp + 1];
+      continue;
+    }
+    const bool binary = (op >= DFLO_OP_ADD && op <= DFLO_OP_OR) || op == DFLO_OP_MIN || op == DFLO_OP_MAX || op == DFLO_OP_ATAN2;
+    double b = 0.0;
+    if (binary) b = st[--sp];
+    const double a = st[sp - 1];
+    double r;
+    switch (op) {
+      case DFLO_OP_NEG: r = -a; break;
+      case DFLO_OP_ADD: r = a + b; break;
+      case DFLO_OP_SUB: r = a - b; break;
+      case DFLO_OP_MUL: r = a * b; break;
+      case DFLO_OP_DIV: r = a / b; break;
+      case DFLO_OP_POW: r = pow(a, b); break;
+      case DFLO_OP_LT: r = a < b ? 1.0 : 0.0; break;
+      case DFLO_OP_LE: r = a <= b ? 1.0 : 0.0; break;
+      case DFLO_OP_GT: r = a > b ? 1.0 : 0.0; break;
+      case DFLO_OP_GE: r = a >= b ? 1.0 : 0.0; break;
+      case DFLO_OP_EQ: r = a == b ? 1.0 : 0.0; break;
+      case DFLO_OP_NE: r = a != b ? 1.0 : 0.0; break;
+      case DFLO_OP_AND: r = (a != 0.0 && b != 0.0) ? 1.0 : 0.0; break;
+      case DFLO_OP_OR: r = (a != 0.0 || b != 0.0) ? 1.0 : 0.0; break;
+      case DFLO_OP_SIN: r = sin(a); break;
+      case DFLO_OP_COS: r = cos(a); break;
+      case DFLO_OP_TAN: r = tan(a); break;
+      case DFLO_OP_EXP: r = exp(a); break;
+      case DFLO_OP_LOG: r = log(a); break;
+      case DFLO_OP_SQRT: r = sqrt(a); break;
+      case DFLO_OP_ABS: r = fabs(a); break;
+      case DFLO_OP_MIN: r = fmin(a, b); break;
+      case DFLO_OP_MAX: r = fmax(a, b); break;
+      case DFLO_OP_ATAN2: r = atan2(a, b); break;
+      case DFLO_OP_TANH: r = tanh(a); break;
+      case DFLO_OP_SINH: r = sinh(a); break;
+      case DFLO_OP_COSH: r = cosh(a); break;
+      case DFLO_OP_ASIN: r = asin(a); break;
+      case DFLO_OP_ACOS: r = acos(a); break;
+      case DFLO_OP_ATAN: r = atan(a); break;
+      case DFLO_OP_FLOOR: r = floor(a); break;
+      case DFLO_OP_CEIL: r = ceil(a); break;
+      case DFLO_OP_SIGN: r = a > 0.0 ? 1.0 : (a < 0.0 ? -1.0 : 0.0); break;
+      case DFLO_OP_LOG10: r = log10(a); break;
+      case DFLO_OP_ERF: r = erf(a); break;
+      case DFLO_OP_ERFC: r = erfc(a); break;
+      default: r = __builtin_nan(""); break;
+    }
+    st[sp - 1] = r;
+  }
+  return st[0];
+}
+__global__ void bc_eval_kernel(const BcArgs a) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.n_points) return;
+  const int id = a.bface_id[i / a.N];
+  const double t = a.dt_dev[1] + (a.add_dt ? (a.dt_host >= 0.0 ? a.dt_host : a.dt_dev[0]) : 0.0);
+  const double x = a.bxy[2 * i], y = a.bxy[2 * i + 1];
+  for (int c = 0; c < 4; ++c) {
+    const int first = a.prog[(id * 4 + c) * 2], n = a.prog[(id * 4 + c) * 2 + 1];
+    if (n > 0) a.bval[(size_t)i * 4 + c] = run_program(a.ops + 2 * first, n, a.consts, x, y, t);
+  }
+}
+
 // accuracy probe of the reciprocal / square-root forms used by the flux functions
 __global__ void debug_math_kernel(const double *x, double *rcp, double *sq, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1642,6 +1733,13 @@ struct dflo_hip_engine {
   double *rhs = nullptr, *user_buf = nullptr;
   double *bval[2] = {nullptr, nullptr};
   int32_t *bface_kind = nullptr;
+  // device-evaluated boundary functions: host copies of the programs, rebuilt device tables when they change
+  std::vector<int32_t> bc_ops[DFLO_MAX_BOUNDARIES][4];
+  std::vector<double> bc_consts[DFLO_MAX_BOUNDARIES][4];
+  int n_bc_programs = 0;
+  bool bc_dirty = false;
+  int32_t *d_bc_ops = nullptr, *d_bc_prog = nullptr, *d_bface_id = nullptr;
+  double *d_bc_consts = nullptr, *d_bxy = nullptr;
   int32_t *d_shard_count = nullptr, *d_halo_begin = nullptr, *d_halo_cells = nullptr, *d_face_begin = nullptr;
   uint32_t *d_faces_pad = nullptr;
   uint8_t *d_nbr_code = nullptr;
@@ -1814,7 +1912,14 @@ void time_collect(dflo_hip_engine *h) {
 // ---- one RK stage on the host side.  A stage is opened once (buffer roles are fixed), its update and
 // limiter kernels may then be launched for all shards or separately for the rim shards (those that read
 // ghost cells) and the interior shards, and it is finished by the reductions.
+int eval_boundary_programs(dflo_hip_engine *h, int which, int add_dt, double dt_host);
+
 int open_stage(dflo_hip_engine *h, int rk, double dt_host, bool residual_only, int which_override) {
+  if (rk == 0 && !residual_only && h->n_bc_programs > 0) {  // boundary functions at t (stage 0) and t + dt (later stages)
+    int rc = eval_boundary_programs(h, 0, 0, dt_host);
+    if (!rc) rc = eval_boundary_programs(h, 1, 1, dt_host);
+    if (rc) return rc;
+  }
   const bool last = rk == h->n_rk - 1;
   int out;
   if (residual_only) out = h->cur;
@@ -1835,6 +1940,53 @@ int open_stage(dflo_hip_engine *h, int rk, double dt_host, bool residual_only, i
     h->pending_dt = dt_host;
     ++h->t_stages;
   }
+  return DFLO_OK;
+}
+
+int eval_boundary_programs(dflo_hip_engine *h, int which, int add_dt, double dt_host) {
+  const Plan &p = h->plan;
+  const int nb = (int)p.bface_cell.size();
+  if (nb == 0 || h->n_bc_programs == 0) return DFLO_OK;
+  if (h->bc_dirty) {  // flatten the programs: one op / constant pool, a (first, count) entry per (id, component)
+    std::vector<int32_t> ops, prog(DFLO_MAX_BOUNDARIES * 4 * 2, 0);
+    std::vector<double> consts;
+    for (int b = 0; b < DFLO_MAX_BOUNDARIES; ++b)
+      for (int c = 0; c < 4; ++c) {
+        const std::vector<int32_t> &o = h->bc_ops[b][c];
+        prog[(b * 4 + c) * 2] = (int32_t)(ops.size() / 2);
+        prog[(b * 4 + c) * 2 + 1] = (int32_t)(o.size() / 2);
+        for (size_t k = 0; k < o.size(); k += 2) {
+          ops.push_back(o[k]);
+          ops.push_back(o[k] == DFLO_OP_CONST ? o[k + 1] + (int32_t)consts.size() : 0);
+        }
+        consts.insert(consts.end(), h->bc_consts[b][c].begin(), h->bc_consts[b][c].end());
+      }
+    if (ops.empty()) ops.assign(2, 0);
+    if (consts.empty()) consts.assign(1, 0.0);
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    hipFree(h->d_bc_ops); hipFree(h->d_bc_consts); hipFree(h->d_bc_prog);
+    h->d_bc_ops = nullptr; h->d_bc_consts = nullptr; h->d_bc_prog = nullptr;
+    int rc;
+    if ((rc = upload(h, &h->d_bc_ops, ops)) || (rc = upload(h, &h->d_bc_consts, consts)) || (rc = upload(h, &h->d_bc_prog, prog))) return rc;
+    if (!h->d_bface_id) {
+      if ((rc = upload(h, &h->d_bface_id, p.bface_id)) || (rc = upload(h, &h->d_bxy, h->bface_xy))) return rc;
+    }
+    h->bc_dirty = false;
+  }
+  BcArgs a{};
+  a.ops = h->d_bc_ops;
+  a.consts = h->d_bc_consts;
+  a.prog = h->d_bc_prog;
+  a.bface_id = h->d_bface_id;
+  a.bxy = h->d_bxy;
+  a.bval = h->bval[which];
+  a.dt_dev = h->dt_dev;
+  a.dt_host = dt_host;
+  a.add_dt = add_dt;
+  a.n_points = nb * h->N;
+  a.N = h->N;
+  hipLaunchKernelGGL(bc_eval_kernel, dim3((a.n_points + 127) / 128), dim3(128), 0, h->stream, a);
+  HIPCHK(h, hipGetLastError());
   return DFLO_OK;
 }
 
@@ -2261,6 +2413,7 @@ int dflo_hip_destroy(dflo_hip_handle h) {
   for (int i = 0; i < 3; ++i) hipFree(h->U[i]);
   for (int i = 0; i < 2; ++i) { hipFree(h->avg[i]); hipFree(h->bval[i]); }
   hipFree(h->rhs); hipFree(h->user_buf); hipFree(h->bface_kind);
+  hipFree(h->d_bc_ops); hipFree(h->d_bc_consts); hipFree(h->d_bc_prog); hipFree(h->d_bface_id); hipFree(h->d_bxy);
   hipFree(h->d_shard_count); hipFree(h->d_halo_begin); hipFree(h->d_halo_cells); hipFree(h->d_face_begin);
   hipFree(h->d_bnd_pad); hipFree(h->d_nbr_code); hipFree(h->d_shock); hipFree(h->d_faces_pad); hipFree(h->d_shard_hdr); hipFree(h->d_halo_pad); hipFree(h->d_cell_face); hipFree(h->d_lrbt); hipFree(h->d_user_of); hipFree(h->d_iid);
   hipFree(h->d_rim_list); hipFree(h->d_int_list);
@@ -2347,6 +2500,42 @@ int dflo_hip_set_boundary_values(dflo_hip_handle h, int which, const double *val
   if (n == 0) return DFLO_OK;
   HIPCHK(h, hipMemcpyAsync(h->bval[which], values, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
+  return DFLO_OK;
+}
+
+int dflo_hip_get_boundary_values(dflo_hip_handle h, int which, double *values) {
+  if (check_handle(h) || which < 0 || which > 1 || !values) return DFLO_ERR_BAD_PARAM;
+  hipSetDevice(h->device);
+  const size_t n = h->plan.bface_cell.size() * h->N * 4;
+  if (n == 0) return DFLO_OK;
+  HIPCHK(h, hipMemcpyAsync(values, h->bval[which], n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return DFLO_OK;
+}
+
+int dflo_hip_set_boundary_program(dflo_hip_handle h, int32_t boundary_id, int32_t component, int32_t n_ops, const int32_t *ops,
+                                  int32_t n_consts, const double *consts) {
+  if (check_handle(h) || boundary_id < 0 || boundary_id >= DFLO_MAX_BOUNDARIES || component < 0 || component > 3 || n_ops < 0 ||
+      n_consts < 0 || (n_ops > 0 && !ops) || (n_consts > 0 && !consts))
+    return DFLO_ERR_BAD_PARAM;
+  // validate: known opcodes, constant indices in range, stack discipline within kExprStack, one value left
+  int sp = 0;
+  for (int i = 0; i < n_ops; ++i) {
+    const int op = ops[2 * i];
+    if (op < 0 || op >= DFLO_OP_COUNT) { h->err = "boundary program: unknown opcode"; return DFLO_ERR_BAD_PARAM; }
+    if (op == DFLO_OP_CONST && (ops[2 * i + 1] < 0 || ops[2 * i + 1] >= n_consts)) { h->err = "boundary program: constant index out of range"; return DFLO_ERR_BAD_PARAM; }
+    const bool binary = (op >= DFLO_OP_ADD && op <= DFLO_OP_OR) || op == DFLO_OP_MIN || op == DFLO_OP_MAX || op == DFLO_OP_ATAN2;
+    const int pops = op <= DFLO_OP_T ? 0 : (op == DFLO_OP_SEL ? 3 : (binary ? 2 : 1));
+    if (sp < pops) { h->err = "boundary program: stack underflow"; return DFLO_ERR_BAD_PARAM; }
+    sp += 1 - pops;
+    if (sp > kExprStack) { h->err = "boundary program: stack too deep"; return DFLO_ERR_BAD_PARAM; }
+  }
+  if (n_ops > 0 && sp != 1) { h->err = "boundary program: must leave exactly one value"; return DFLO_ERR_BAD_PARAM; }
+  std::vector<int32_t> &o = h->bc_ops[boundary_id][component];
+  h->n_bc_programs += (n_ops > 0 ? 1 : 0) - (o.empty() ? 0 : 1);
+  o.assign(ops, ops + 2 * (size_t)n_ops);
+  h->bc_consts[boundary_id][component].assign(consts, consts + (n_ops > 0 ? n_consts : 0));
+  h->bc_dirty = true;
   return DFLO_OK;
 }
 

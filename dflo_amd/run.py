@@ -14,13 +14,14 @@ import numpy as np
 
 from . import problems
 from .claw import ConservationLaw
+from .expr import ExpressionError
 from .mesh import Mesh
 from .prm import InputDeck
 from .vtu import write_shock_tecplot, write_shock_vtu, write_tecplot, write_vtu
 
 
 class Run:
-    def __init__(self, deck, outdir=".", quiet=False, device=0):
+    def __init__(self, deck, outdir=".", quiet=False, device=0, host_bc=False):
         self.deck, self.outdir, self.quiet = deck, outdir, quiet
         os.makedirs(outdir, exist_ok=True)
         if deck.mesh_type != "gmsh":
@@ -33,6 +34,18 @@ class Run:
         self.claw = ConservationLaw(mesh, deck.parameters, device=device)
         self.cell, self.face, self.bid, self.bxy = self.claw.boundary_faces()
         self.bc_time_dependent = any(deck.boundary_values[int(b)].time_dependent for b in np.unique(self.bid))
+        # time-dependent boundary functions are handed to the device as postfix programs (evaluated at t / t + dt of
+        # every step from the device clock); an expression the device evaluator lacks falls back to host evaluation
+        self.bc_on_device = False
+        if self.bc_time_dependent and not host_bc:
+            try:
+                for b in np.unique(self.bid):
+                    if deck.boundary_values[int(b)].time_dependent:
+                        self.claw.set_boundary_function(int(b), deck.boundary_values[int(b)].expressions)
+                self.bc_on_device = True
+            except ExpressionError:
+                for b in np.unique(self.bid):
+                    self.claw.set_boundary_function(int(b), [None] * 4)
         self.output_file_number = 0
         self.time_iter = 0
 
@@ -90,7 +103,7 @@ class Run:
         res_norm0 = res_norm = 1.0
         while claw.elapsed_time < final_time and (max_steps is None or self.time_iter < max_steps):
             chunk = 1
-            if fast and not self.bc_time_dependent and d.output_time_step >= 1e19:
+            if fast and (self.bc_on_device or not self.bc_time_dependent) and d.output_time_step >= 1e19:
                 chunk = max(1, min(next_output_iter - self.time_iter, 64,
                                    (max_steps - self.time_iter) if max_steps is not None else 64))
             if chunk > 1:
@@ -102,7 +115,7 @@ class Run:
             else:
                 dt = claw.compute_time_step()                  # :1029
                 self.log("\nIt=%d, T=%.12g, dt=%.12g, cfl=%g" % (self.time_iter + 1, claw.elapsed_time + dt, dt, d.parameters.cfl))
-                if self.bc_time_dependent:                     # bc_time of stage 0 / later stages, :736-745
+                if self.bc_time_dependent and not self.bc_on_device:   # bc_time of stage 0 / later stages, :736-745
                     self.set_boundary_values(claw.elapsed_time, 0)
                     self.set_boundary_values(claw.elapsed_time + dt, 1)
                 res_norm0, res_norm = claw.iterate_explicit(dt)    # :1051, advances elapsed_time
@@ -125,9 +138,10 @@ def main(argv=None):
     ap.add_argument("--fast", action="store_true", help="advance in chunks without a host round trip per step")
     ap.add_argument("--quiet", action="store_true")
     ap.add_argument("--device", type=int, default=0)
+    ap.add_argument("--host-bc", action="store_true", help="evaluate time-dependent boundary functions on the host every step")
     a = ap.parse_args(argv)
     try:
-        Run(InputDeck.read(a.input), a.outdir, a.quiet, a.device).run(a.max_steps, a.fast)
+        Run(InputDeck.read(a.input), a.outdir, a.quiet, a.device, a.host_bc).run(a.max_steps, a.fast)
     except Exception as e:   # src/main.cc:56-78: report and exit code 1
         sys.stderr.write("\n----------------------------------------------------\nException on processing:\n%s\nAborting!\n"
                          "----------------------------------------------------\n" % e)

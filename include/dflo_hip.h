@@ -111,6 +111,19 @@ typedef struct dflo_params {
   int32_t reserved_;
 } dflo_params_t;
 
+/* Opcodes of the postfix programs of dflo_hip_set_boundary_program: what deal.II's FunctionParser evaluates for the
+ * "w_i value" entries of a boundary subsection, in the variables x, y, t (src/parameters.cc:441-477). Comparisons and
+ * logical operators yield 1.0 / 0.0; SEL pops (condition, a, b) and keeps a if condition != 0, else b. */
+typedef enum {
+  DFLO_OP_CONST = 0, DFLO_OP_X = 1, DFLO_OP_Y = 2, DFLO_OP_T = 3, DFLO_OP_NEG = 4, DFLO_OP_ADD = 5, DFLO_OP_SUB = 6,
+  DFLO_OP_MUL = 7, DFLO_OP_DIV = 8, DFLO_OP_POW = 9, DFLO_OP_LT = 10, DFLO_OP_LE = 11, DFLO_OP_GT = 12, DFLO_OP_GE = 13,
+  DFLO_OP_EQ = 14, DFLO_OP_NE = 15, DFLO_OP_AND = 16, DFLO_OP_OR = 17, DFLO_OP_SEL = 18, DFLO_OP_SIN = 19, DFLO_OP_COS = 20,
+  DFLO_OP_TAN = 21, DFLO_OP_EXP = 22, DFLO_OP_LOG = 23, DFLO_OP_SQRT = 24, DFLO_OP_ABS = 25, DFLO_OP_MIN = 26,
+  DFLO_OP_MAX = 27, DFLO_OP_ATAN2 = 28, DFLO_OP_TANH = 29, DFLO_OP_SINH = 30, DFLO_OP_COSH = 31, DFLO_OP_ASIN = 32,
+  DFLO_OP_ACOS = 33, DFLO_OP_ATAN = 34, DFLO_OP_FLOOR = 35, DFLO_OP_CEIL = 36, DFLO_OP_SIGN = 37, DFLO_OP_LOG10 = 38,
+  DFLO_OP_ERF = 39, DFLO_OP_ERFC = 40, DFLO_OP_COUNT = 41
+} dflo_expr_op;
+
 typedef struct dflo_hip_engine *dflo_hip_handle;
 
 /* ---------------------------------------------------------------- lifetime */
@@ -150,6 +163,17 @@ int dflo_hip_boundary_faces(dflo_hip_handle h, int32_t *cell, int32_t *face, int
 int dflo_hip_set_boundary_values(dflo_hip_handle h, int which, const double *values);
 
 /* ------------------------------------------------------------- hot path */
+
+/* Boundary functions evaluated on the device instead of being uploaded: a postfix program per (boundary id, component)
+ * over x, y, t (ops: [n_ops][2] = (dflo_expr_op, constant index), stack depth <= 16; n_ops = 0 removes the program).
+ * At the start of every time step the engine then evaluates the programmed components at the face quadrature points
+ * at t (table of RK stage 0) and t + dt (later stages) -- FunctionParser::set_time + vector_value_list of
+ * src/claw.cc:736-745, src/assemble_explicit.cc:161-165 -- from its device-resident clock (set by dflo_hip_compute_dt,
+ * advanced by every step); components without a program keep the uploaded values. */
+int dflo_hip_set_boundary_program(dflo_hip_handle h, int32_t boundary_id, int32_t component, int32_t n_ops, const int32_t *ops,
+                                  int32_t n_consts, const double *consts);
+/* The boundary-value table in use (which = 0: stage 0, 1: later stages), [n_boundary_faces][k+1][4]. */
+int dflo_hip_get_boundary_values(dflo_hip_handle h, int which, double *values);
 
 /* assemble_system(IntegratorExplicit&) (src/assemble_explicit.cc:433-452): rhs of the current
  * solution with the current cell averages and boundary set `which`; rhs_out [n_dofs], dflo layout. */

@@ -128,7 +128,7 @@ def test_partition_owned_plus_ghost_layer():
 
 
 def test_engine_fails_loudly_without_gpu():
-    if torch.cuda.is_available():
+    if torch.cuda.is_available() or os.path.exists("/dev/kfd"):
         pytest.skip("GPU present")
     m = dflo_amd.Mesh.cartesian(4, 4, 0.0, 0.0, 0.25, [-1] * 4, 1)
     with pytest.raises(dflo_amd.DfloError) as e:

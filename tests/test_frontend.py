@@ -271,3 +271,30 @@ def test_builtin_initial_conditions():
     assert np.allclose((w[3] - ke)[inside] * 0.4, 50.0)              # src/ic.cc:87
     r = problems.rayleigh_taylor(np.array([0.0, 0.25]), np.array([-0.3, 0.3]), gravity=1.0)
     assert np.array_equal(r[2], [1.0, 2.0]) and np.allclose(r[3][0], (2.5 + 0.3) / 0.4 + 0.5 * r[1][0] ** 2 / 1.0)
+
+
+def test_postfix_programs_match_the_expression_evaluator():
+    """compile_program (what dflo_hip_set_boundary_program receives) against the AST evaluator, through the host
+    mirror of the device interpreter."""
+    from dflo_amd.expr import MAX_STACK, OP, compile_program, run_program
+    rng = np.random.default_rng(7)
+    x, y = rng.uniform(-2, 2, 200), rng.uniform(-2, 2, 200)
+    cases = [
+        "57.1576766498*(x<1.0/6.0+(1+20*t)/sqrt(3)) + 0.0",
+        "8.0*(x<1.0/6.0+(1+20*t)/sqrt(3)) + 1.4*(x>=1.0/6.0+(1+20*t)/sqrt(3))",
+        "-x^2 + 2^-1 * y - -t", "2^3^2 - (x - y) / (1 + x*x)", "if(x>0 && y<1 || t>2, sin(pi*x), max(x, min(y, t)))",
+        "x > 0 ? exp(-y*y) : -abs(tanh(x)) + atan2(y, 1+x*x)", "sqrt(abs(x)) + log(2 + cos(y)) * (x != y) + (x == x)",
+        "floor(3*x) + ceil(y) + sign(x) + log10(3 + x) + erf(y) + erfc(x)", "pow(abs(x), 1.5) + sinh(x/4) + cosh(y/4) + asin(x/2) + acos(y/2) + atan(t)",
+    ]
+    for e in cases:
+        ops, consts = compile_program(e)
+        assert ops.dtype == np.int32 and ops.shape[1] == 2 and ops[:, 0].max() < 41
+        ref = compile_expression(e)(x=x, y=y, t=0.37)
+        got = run_program(ops, consts, x, y, 0.37)
+        assert np.allclose(got, ref, rtol=1e-14, atol=1e-14), e
+    deep = "+".join(["(x" for _ in range(MAX_STACK + 2)]) + ")" * (MAX_STACK + 2)     # x+(x+(x+...)) needs a deep stack
+    with pytest.raises(ExpressionError, match="stack"):
+        compile_program(deep.replace("+(x", "+(x*(x", 1).replace(")", "))", 1) if False else "x+(" * (MAX_STACK + 1) + "x" + ")" * (MAX_STACK + 1))
+    with pytest.raises(ExpressionError):
+        compile_program("fmod(x, 2)")        # host-only function
+    assert OP["const"] == 0 and OP["sel"] == 18 and OP["erfc"] == 40   # ABI numbers of include/dflo_hip.h

@@ -258,3 +258,60 @@ def test_double_mach_reflection_c4_style(tmp_path, degree, basis, pos):
     scale = np.abs(uo).max()
     assert np.abs(run.claw.cell_average - ora.get_cell_average()).max() < 1e-8 * scale
     assert np.abs(u - uo).max() < 1e-6 * scale
+
+
+def test_device_boundary_programs_match_host_evaluation(tmp_path):
+    """dflo_hip_set_boundary_program: the engine evaluates the boundary expressions itself at t and t + dt."""
+    mesh = dflo_amd.Mesh.cartesian(12, 9, 0.0, 0.0, 1.0 / 12, [0, 1, 2, 3], 2)
+    prm = dflo_amd.Parameters(flux="roe", cfl=0.5, boundary={0: "inflow", 1: "outflow", 2: "farfield", 3: "slip"})
+    claw = dflo_amd.ConservationLaw(mesh, prm)
+    from dflo_amd.expr import VectorFunction
+    exprs = {0: ["0.3*(1+0.1*sin(3*t+y))", "0.05*cos(pi*y)*t", "1.0 + 0.2*(y<0.4+t)", "2.5 + 0.5*exp(-t)*y^2"],
+             2: ["0.1", "if(x>0.5, 0.2, -0.2*t)", "1.0 + 0.1*max(x, 0.3)", "2.5 + sqrt(abs(x-0.5))"]}
+    cell, face, bid, xy = claw.boundary_faces()
+    claw.set_initial_condition(mesh.interpolate(lambda x, y: dflo_amd.problems.smooth_perturbation(x, y, L=1.0)))
+    base = np.full(xy.shape[:2] + (4,), 7.0)
+    claw.set_boundary_values(0, base)
+    claw.set_boundary_values(1, base)
+    for b, e in exprs.items():
+        claw.set_boundary_function(b, e)
+    t0 = 0.123
+    claw.elapsed_time = t0
+    dt = claw.compute_time_step()          # sets the device clock to t0
+    claw.iterate_explicit(dt)
+    for which, t in ((0, t0), (1, t0 + dt)):
+        got = claw.get_boundary_values(which)
+        want = base.copy()
+        for b, e in exprs.items():
+            sel = bid == b
+            want[sel] = np.stack(VectorFunction(e)(xy[sel][..., 0], xy[sel][..., 1], t), axis=-1)
+        assert np.abs(got - want).max() < 1e-13
+    # same step with host-evaluated values
+    ref = dflo_amd.ConservationLaw(mesh, prm)
+    ref.set_initial_condition(mesh.interpolate(lambda x, y: dflo_amd.problems.smooth_perturbation(x, y, L=1.0)))
+    ref.set_boundary_values(0, claw.get_boundary_values(0))
+    ref.set_boundary_values(1, claw.get_boundary_values(1))
+    ref.iterate_explicit(dt)
+    assert np.abs(ref.current_solution - claw.current_solution).max() < 1e-13
+    # removing a program freezes the last values; a malformed program is refused
+    claw.set_boundary_function(0, [None] * 4)
+    bad = np.array([[5, 0]], dtype=np.int32)   # ADD on an empty stack
+    import ctypes as C
+    from dflo_amd import _lib
+    rc = _lib.lib.dflo_hip_set_boundary_program(claw._h, 1, 0, 1, _lib.iptr(bad), 0, None)
+    assert rc != 0
+
+
+def test_double_mach_fast_mode_runs_on_device_programs(tmp_path):
+    gmsh.double_mach(str(tmp_path / "grid.msh"), ny=13)
+    prm = tmp_path / "input.prm"
+    prm.write_text(DMR_PRM % {"degree": 2, "basis": "Qk", "pos": "true"})
+    deck = InputDeck.read(str(prm))
+    a = Run(deck, str(tmp_path / "a"), quiet=True, host_bc=True)
+    assert a.bc_time_dependent and not a.bc_on_device
+    a.run(max_steps=16)
+    b = Run(deck, str(tmp_path / "b"), quiet=True)
+    assert b.bc_on_device
+    b.run(max_steps=16, fast=True)          # one advance(16): no host round trip, programs evaluated every step
+    assert abs(a.claw.elapsed_time - b.claw.elapsed_time) < 1e-13
+    assert np.abs(a.claw.current_solution - b.claw.current_solution).max() < 1e-10 * np.abs(a.claw.current_solution).max()
