@@ -2224,8 +2224,8 @@ int dflo_hip_create(const dflo_mesh_t *mesh, const dflo_params_t *params, int de
     g_create_error = "shock indicator must be limiter, density or energy (u2 belongs to the MOOD scheme)";
     return params->shock_indicator == DFLO_IND_U2 ? DFLO_ERR_UNSUPPORTED : DFLO_ERR_BAD_PARAM;
   }
-  if (params->shock_indicator != DFLO_IND_LIMITER && (mesh->mapping != DFLO_MAP_CARTESIAN || mesh->n_owned_cells != mesh->n_cells)) {
-    g_create_error = "the KXRCF indicator is implemented for cartesian mapping on a single device";
+  if (params->shock_indicator != DFLO_IND_LIMITER && mesh->mapping != DFLO_MAP_CARTESIAN) {
+    g_create_error = "the KXRCF indicator is implemented for cartesian mapping";
     return DFLO_ERR_UNSUPPORTED;
   }
   if (params->limiter_type == DFLO_LIMITER_TVB && mesh->mapping != DFLO_MAP_CARTESIAN) {

@@ -115,6 +115,12 @@ class DistributedConservationLaw:
         self.ndof = ndof
         self.n_rk = self.claw.n_rk
         self.tvb = parameters.limiter == "TVB"
+        # KXRCF indicator: reads the neighbours' unlimited DoFs of the new stage, so the ghost cells are refreshed once
+        # more between update and limiter (what update_ghost_values before compute_shock_indicator does in the MPI
+        # variant); that path runs without the rim/interior overlap
+        self.kxrcf = self.tvb and parameters.shock_indicator != "limiter"
+        if self.kxrcf:
+            self.overlap = False
         # device-resident {dt, elapsed time, raw CFL minimum}: lets the step loop run without host round trips
         dtp, resp = C.c_void_p(), C.c_void_p()
         self.claw._chk(lib.dflo_hip_scalar_ptrs(self.claw._h, C.byref(dtp), C.byref(resp)))
@@ -157,7 +163,9 @@ class DistributedConservationLaw:
         c = self.claw
         if not self.overlap:
             c._chk(lib.dflo_hip_stage_update(c._h, rk, dt))
-            if self.tvb:
+            if self.kxrcf:
+                self.exchange_solution()      # ghost DoFs and their averages of the unlimited stage
+            elif self.tvb:
                 self.exchange_averages()
             c._chk(lib.dflo_hip_stage_limit(c._h))
             self.exchange_solution()

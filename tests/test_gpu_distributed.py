@@ -15,6 +15,14 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 
 
+def _front(x, y):
+    """oblique front in a flow with both velocity components away from zero (see test_gpu_parity._oblique_front)"""
+    s = 0.5 * (1.0 + np.tanh((x + 0.5 * y - 0.8) / 0.004))
+    rho, p = 1.0 + 0.6 * s, 1.0 + 0.9 * s
+    u, v = 0.6, 0.35
+    return [rho * u, rho * v, rho, p / 0.4 + 0.5 * rho * (u * u + v * v)]
+
+
 def _worker(rank, world, port, case, ret):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, HERE)
@@ -25,11 +33,12 @@ def _worker(rank, world, port, case, ret):
     from dflo_amd import problems
     from dflo_amd.dist import DistributedConservationLaw
 
-    nx, ny, degree, flux, limiter, pos, side_bc, bnd, ic_name = case
-    ic = problems.sod if ic_name == "sod" else problems.isentropic_vortex
-    x0, h = (0.0, 1.0 / nx) if ic_name == "sod" else (-5.0, 10.0 / nx)
+    nx, ny, degree, flux, limiter, pos, side_bc, bnd, ic_name = case[:9]
+    ic = {"sod": problems.sod, "vortex": problems.isentropic_vortex, "front": _front}[ic_name]
+    x0, h = (-5.0, 10.0 / nx) if ic_name == "vortex" else (0.0, 1.0 / nx)
     mesh = dflo_amd.Mesh.cartesian(nx, ny, x0, x0, h, side_bc, degree)
-    prm = dflo_amd.Parameters(flux=flux, limiter=limiter, pos_lim=pos, boundary=bnd, beta=2.0, cfl=0.8)
+    prm = dflo_amd.Parameters(flux=flux, limiter=limiter, pos_lim=pos, boundary=bnd, beta=2.0, cfl=0.8,
+                              shock_indicator=case[9] if len(case) > 9 else "limiter")
     u0 = mesh.interpolate(ic)
     d = DistributedConservationLaw(mesh, prm, device_index=0)
     cell, face, bid, xy = d.claw.boundary_faces()
@@ -56,6 +65,7 @@ def _worker(rank, world, port, case, ret):
 CASES = [
     (32, 16, 2, "hllc", "none", False, [-1, -1, -1, -1], None, "vortex"),
     (64, 8, 1, "roe", "TVB", True, [2, 1, 0, 0], {0: "slip", 1: "outflow", 2: "inflow"}, "sod"),
+    (48, 40, 1, "hllc", "TVB", True, [0, 0, 0, 0], {0: "outflow"}, "front", "density"),   # KXRCF-gated limiter across the cut
 ]
 
 
@@ -69,11 +79,12 @@ def test_two_engines_match_one(case):
     mgr = mp.Manager()
     ret = mgr.dict()
     mp.spawn(_worker, args=(2, port, case, ret), nprocs=2, join=True)
-    nx, ny, degree, flux, limiter, pos, side_bc, bnd, ic_name = case
-    ic = problems.sod if ic_name == "sod" else problems.isentropic_vortex
-    x0, h = (0.0, 1.0 / nx) if ic_name == "sod" else (-5.0, 10.0 / nx)
+    nx, ny, degree, flux, limiter, pos, side_bc, bnd, ic_name = case[:9]
+    ic = {"sod": problems.sod, "vortex": problems.isentropic_vortex, "front": _front}[ic_name]
+    x0, h = (-5.0, 10.0 / nx) if ic_name == "vortex" else (0.0, 1.0 / nx)
     mesh = dflo_amd.Mesh.cartesian(nx, ny, x0, x0, h, side_bc, degree)
-    prm = dflo_amd.Parameters(flux=flux, limiter=limiter, pos_lim=pos, boundary=bnd, beta=2.0, cfl=0.8)
+    prm = dflo_amd.Parameters(flux=flux, limiter=limiter, pos_lim=pos, boundary=bnd, beta=2.0, cfl=0.8,
+                              shock_indicator=case[9] if len(case) > 9 else "limiter")
     ora = O.Oracle(mesh, prm)
     cell, face, bid, xy = ora.boundary_faces()
     if len(cell):
