@@ -85,6 +85,9 @@ def main():
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         # DFLO_BENCH_BACKEND=gloo: developer switch to exercise the multi-rank path with several ranks on ONE gpu
         dist.init_process_group(os.environ.get("DFLO_BENCH_BACKEND", "nccl"))
 
