@@ -555,3 +555,74 @@ def test_unresolved_mach10_shock_same_branches_as_reference(flux, degree):
     ok = ~np.isnan(ro)
     assert ok.sum() > 0.7 * ok.size
     assert np.abs(r[ok] - ro[ok]).max() <= 1e-11 * np.abs(ro[ok]).max()
+
+
+# ---------------------------------------------------------------- known answers at sizes only the GPU reaches quickly
+def _sod_exact(x, t, gamma=1.4):
+    """Exact solution of Sod's Riemann problem (rho, u, p) = (1, 0, 1) | (0.125, 0, 0.1) at x = 0.5."""
+    rl, pl, rr, pr = 1.0, 1.0, 0.125, 0.1
+    cl, cr = np.sqrt(gamma * pl / rl), np.sqrt(gamma * pr / rr)
+    g1, g2 = (gamma - 1) / (2 * gamma), (gamma + 1) / (2 * gamma)
+
+    def f(p):   # shock on the right, rarefaction on the left
+        fl = 2 * cl / (gamma - 1) * ((p / pl) ** g1 - 1)
+        A, B = 2 / ((gamma + 1) * rr), (gamma - 1) / (gamma + 1) * pr
+        return fl + (p - pr) * np.sqrt(A / (p + B))
+
+    lo, hi = pr, pl
+    for _ in range(200):
+        mid = 0.5 * (lo + hi)
+        lo, hi = (mid, hi) if f(mid) < 0 else (lo, mid)
+    ps = 0.5 * (lo + hi)
+    us = 2 * cl / (gamma - 1) * (1 - (ps / pl) ** g1)
+    rsl = rl * (ps / pl) ** (1 / gamma)
+    rsr = rr * ((ps / pr + (gamma - 1) / (gamma + 1)) / ((gamma - 1) / (gamma + 1) * ps / pr + 1))
+    S = cr * np.sqrt(g2 * ps / pr + g1)          # shock speed
+    csl = cl * (ps / pl) ** g1
+    xi = (x - 0.5) / t
+    rho = np.where(xi < -cl, rl, np.where(xi < us - csl, rl * (2 / (gamma + 1) - (gamma - 1) / ((gamma + 1) * cl) * xi) ** (2 / (gamma - 1)),
+                   np.where(xi < us, rsl, np.where(xi < S, rsr, rr))))
+    return rho
+
+
+def test_sod_against_the_exact_riemann_solution():
+    """C3 physics: Q1, Roe, TVB + positivity to t = 0.2 (the shipped sod_shock_tube setting) against the exact solution."""
+    bnd = {0: "slip", 1: "outflow", 2: "inflow"}
+    err = []
+    for nx in (200, 400):
+        mesh = dflo_amd.Mesh.cartesian(nx, 4, 0.0, 0.0, 1.0 / nx, [2, 1, 0, 0], 1)
+        prm = dflo_amd.Parameters(flux="roe", limiter="TVB", char_lim=True, pos_lim=True, M=0.0, beta=2.0, boundary=bnd,
+                                  cfl=0.9, final_time=0.2)
+        claw = dflo_amd.ConservationLaw(mesh, prm)
+        cell, face, bid, xy = claw.boundary_faces()
+        bv = np.zeros(xy.shape[:2] + (4,))
+        bv[..., 2], bv[..., 3] = 1.0, 2.5
+        claw.set_boundary_values(0, bv)
+        claw.set_boundary_values(1, bv)
+        claw.set_initial_condition(mesh.interpolate(problems.sod))
+        claw.apply_limiter()
+        t = claw.advance(2000)          # the CFL rule clips the last step to final_time, then dt = 0
+        assert abs(t - 0.2) < 1e-13
+        rho = claw.cell_average[:nx, 2]
+        xc = (np.arange(nx) + 0.5) / nx
+        err.append(np.abs(rho - _sod_exact(xc, 0.2)).mean())
+        assert (rho > 0.12).all() and (rho < 1.0 + 1e-9).all()       # no over/undershoot beyond the data
+    assert err[0] < 6e-3 and err[1] < 0.62 * err[0]                  # L1 error, first-order at the discontinuities
+
+
+@pytest.mark.parametrize("degree,flux,L,sizes", [(1, "lxf", 5.0, (32, 64)), (2, "hllc", 5.0, (32, 64)), (3, "roe", 10.0, (64, 128))])
+def test_exact_vortex_convergence_order(degree, flux, L, sizes):
+    """The advected isentropic vortex of the MPI tree (exact solution) at two resolutions: order ~ k+1.  (On the
+    periodic box [-5,5]^2 the vortex tail leaves a 7e-6 floor, reached by Q3; that case runs on [-10,10]^2.)"""
+    err = []
+    for nx in sizes:
+        mesh = dflo_amd.Mesh.cartesian(nx, nx, -L, -L, 2 * L / nx, [-1] * 4, degree)
+        prm = dflo_amd.Parameters(flux=flux, cfl=0.3 if degree < 3 else 0.15, final_time=0.5)
+        claw = dflo_amd.ConservationLaw(mesh, prm)
+        claw.set_initial_condition(mesh.interpolate(lambda x, y: problems.isentropic_vortex_exact(x, y, 0.0, u0=1.0, v0=0.5)))
+        t = claw.advance(4000)
+        assert abs(t - 0.5) < 1e-13
+        ex = mesh.interpolate(lambda x, y: problems.isentropic_vortex_exact(x, y, 0.5, u0=1.0, v0=0.5))
+        err.append(np.sqrt(np.mean((claw.current_solution - ex) ** 2)))
+    order = np.log2(err[0] / err[1])
+    assert order > degree + 0.5, (err, order)
