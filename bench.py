@@ -106,22 +106,13 @@ def main():
         prm = dflo_amd.Parameters(flux="roe", limiter="TVB", char_lim=True, pos_lim=True, M=0.0, beta=2.0, cfl=0.9,
                                   final_time=1e9, boundary={0: "slip", 1: "outflow", 2: "inflow"})
         ic = bc_fn = problems.sod
-    else:                       # c5 stand-in: 512 x 512 bilinear cells (vertices displaced), q1 mapping, Q3 KFVS
-        n = 512 if args.nx == 1024 else args.nx
-        nx = ny = n
-        xs = np.linspace(0.0, 3.0, n + 1)
-        X, Y = np.meshgrid(xs, xs, indexing="xy")
-        X = X + 0.15 * (3.0 / n) * np.sin(2 * np.pi * X / 3.0) * np.sin(2 * np.pi * Y / 3.0)
-        Y = Y + 0.15 * (3.0 / n) * np.sin(3 * np.pi * X / 3.0) * np.sin(np.pi * Y / 3.0)
-        verts = np.stack([X.reshape(-1), Y.reshape(-1)], axis=1)
-        ii, jj = np.meshgrid(np.arange(n), np.arange(n), indexing="xy")
-        v0 = (ii + (n + 1) * jj).reshape(-1)
-        quads = np.stack([v0, v0 + 1, v0 + n + 2, v0 + n + 1], axis=1)
-        k = np.arange(n)
-        bed = np.concatenate([np.stack([k, k + 1], 1), np.stack([k + (n + 1) * n, k + 1 + (n + 1) * n], 1),
-                              np.stack([(n + 1) * k, (n + 1) * (k + 1)], 1), np.stack([(n + 1) * k + n, (n + 1) * (k + 1) + n], 1)])
-        bid = np.concatenate([np.full(n, 2), np.full(n, 2), np.full(n, 1), np.full(n, 3)])
+    else:                       # c5 stand-in: fully unstructured quads (Delaunay triangles cut in three), q1 mapping, Q3 KFVS
+        from dflo_amd import gmsh
+        n = 295 if args.nx == 1024 else args.nx       # 6 n^2 cells: 522 150 by default (C5 has ~200 k cells per GPU)
+        verts, quads, bed, side = gmsh.unstructured_quads(n, Lx=3.0, Ly=3.0, seed=1)
+        bid = np.array([2, 3, 2, 1], dtype=np.int32)[side]   # bottom/top slip (2), right outflow (3), left inflow (1)
         mesh = dflo_amd.Mesh.from_quads(verts, quads, bed, bid, 3)
+        nx = ny = n
         prm = dflo_amd.Parameters(flux="kfvs", pos_lim=True, cfl=0.5, final_time=1e9,
                                   boundary={1: "inflow", 2: "slip", 3: "outflow"})   # examples/forward_step/input.prm
         ic = bc_fn = problems.forward_step_inflow
@@ -198,8 +189,8 @@ def main():
                 "workload": {"c2": "isentropic_vortex, %dx%d quads per GPU (global %dx%d), %s%d, %s, periodic, SSP-RK %d stages"
                                    % (args.nx, args.nx, nx, ny, args.basis[0], args.degree, args.flux.upper(), n_rk),
                              "c3": "sod_shock_tube, 2048x256 quads, Q1, ROE, TVB(M=0,beta=2,char)+positivity, SSP-RK 2 stages",
-                             "c5": "free stream + bump on %dx%d bilinear quads (q1 mapping), Q3, KFVS, positivity, SSP-RK 3 stages"
-                                   % (nx, ny)}[args.config],
+                             "c5": "free stream + bump on %d unstructured quads (q1 mapping), Q3, KFVS, positivity, SSP-RK 3 stages"
+                                   % mesh.n_cells}[args.config],
                 "n_dofs": n_dofs_total, "n_rk": n_rk, "parallelism": "x-slabs, %d rank(s)" % world,
             },
             "roofline": {

@@ -68,3 +68,36 @@ def double_mach(path, ny=101, Lx=4.0, Ly=1.0, x0=1.0 / 6.0):
         return {"right": 2, "top": 3, "left": 4}[side]
 
     write_structured_msh(path, xs, ys, bid)
+
+
+def unstructured_quads(n, Lx=1.0, Ly=1.0, jitter=0.25, seed=0):
+    """A fully unstructured all-quadrilateral mesh of [0,Lx] x [0,Ly] (stand-in for gmsh's recombined meshes of
+    forward_step / naca0012, which need gmsh): a Delaunay triangulation of a jittered n x n point lattice, every
+    triangle cut into three quadrilaterals (centroid + edge midpoints).  Node valences 3..8, arbitrary cell
+    orientation.  -> (vertices [nv][2], quads [nq][4] counter-clockwise, boundary edges [ne][2] with side ids
+    0 bottom, 1 right, 2 top, 3 left)."""
+    from scipy.spatial import Delaunay
+    rng = np.random.default_rng(seed)
+    xs, ys = np.meshgrid(np.linspace(0.0, Lx, n + 1), np.linspace(0.0, Ly, n + 1), indexing="xy")
+    pts = np.stack([xs.reshape(-1), ys.reshape(-1)], axis=1)
+    inner = (pts[:, 0] > 0) & (pts[:, 0] < Lx) & (pts[:, 1] > 0) & (pts[:, 1] < Ly)
+    pts[inner] += jitter * np.array([Lx / n, Ly / n]) * rng.uniform(-1.0, 1.0, (inner.sum(), 2))
+    tri = Delaunay(pts).simplices
+    # orient counter-clockwise
+    a, b, c = pts[tri[:, 0]], pts[tri[:, 1]], pts[tri[:, 2]]
+    cw = (b[:, 0] - a[:, 0]) * (c[:, 1] - a[:, 1]) - (b[:, 1] - a[:, 1]) * (c[:, 0] - a[:, 0]) < 0
+    tri[cw] = tri[cw][:, ::-1]
+    npts, nt = len(pts), len(tri)
+    e = np.stack([tri[:, [0, 1]], tri[:, [1, 2]], tri[:, [2, 0]]], axis=1)              # [t][k] edge k = (t_k, t_k+1)
+    key = np.sort(e.reshape(-1, 2), axis=1)
+    uniq, inv, counts = np.unique(key, axis=0, return_inverse=True, return_counts=True)
+    mid = (npts + inv.reshape(-1)).reshape(nt, 3)                                       # midpoint node of edge k
+    cen = npts + len(uniq) + np.arange(nt)                                              # centroid node
+    verts = np.concatenate([pts, 0.5 * (pts[uniq[:, 0]] + pts[uniq[:, 1]]), pts[tri].mean(axis=1)])
+    quads = np.stack([np.stack([tri[:, k], mid[:, k], cen, mid[:, (k + 2) % 3]], axis=1) for k in range(3)], axis=1).reshape(-1, 4)
+    b = np.nonzero(counts == 1)[0]                                                      # boundary edges of the triangulation
+    pm = 0.5 * (pts[uniq[b, 0]] + pts[uniq[b, 1]])
+    side = np.where(np.abs(pm[:, 1]) < 1e-12, 0, np.where(np.abs(pm[:, 0] - Lx) < 1e-12, 1, np.where(np.abs(pm[:, 1] - Ly) < 1e-12, 2, 3)))
+    bedges = np.stack([np.stack([uniq[b, 0], npts + b], axis=1), np.stack([npts + b, uniq[b, 1]], axis=1)], axis=1).reshape(-1, 2)
+    bid = np.repeat(side, 2)
+    return verts, quads.astype(np.int32), bedges.astype(np.int32), bid.astype(np.int32)

@@ -626,3 +626,51 @@ def test_exact_vortex_convergence_order(degree, flux, L, sizes):
         err.append(np.sqrt(np.mean((claw.current_solution - ex) ** 2)))
     order = np.log2(err[0] / err[1])
     assert order > degree + 0.5, (err, order)
+
+
+# ---------------------------------------------------------------- fully unstructured quad meshes (C5's kind of mesh)
+def _unstructured(n, degree):
+    from dflo_amd import gmsh
+    verts, quads, bed, bid = gmsh.unstructured_quads(n, seed=3)
+    return dflo_amd.Mesh.from_quads(verts, quads, bed, bid, degree)
+
+
+@pytest.mark.parametrize("degree,flux", [(1, "roe"), (2, "hllc"), (3, "kfvs")])
+def test_unstructured_quad_mesh_parity(degree, flux):
+    """Delaunay triangles cut into quads: irregular valence, arbitrary cell orientation (face flips), Morton-run
+    shards with large halos; q1 mapping, compute_time_step_q, positivity -- the C5 code path."""
+    mesh = _unstructured(12, degree)
+    assert mesh.n_cells > 800 and (mesh.neighbor_faces & 4).any()        # some faces run opposite on the two sides
+    bnd = {0: "slip", 1: "outflow", 2: "slip", 3: "inflow"}
+    prm = dflo_amd.Parameters(flux=flux, boundary=bnd, cfl=0.4, pos_lim=True)
+    claw, ora = dflo_amd.ConservationLaw(mesh, prm), oracle_lib.Oracle(mesh, prm)
+    ic = lambda x, y: problems.smooth_perturbation(x, y, L=1.0)
+    cell, face, bid, xy = claw.boundary_faces()
+    bv = np.stack(ic(xy[..., 0], xy[..., 1]), axis=-1)
+    for w in (0, 1):
+        claw.set_boundary_values(w, bv)
+        ora.set_boundary_values(w, bv)
+    u0 = mesh.interpolate(ic)
+    claw.set_initial_condition(u0)
+    ora.set_solution(u0)
+    assert rel(claw.cell_average, ora.get_cell_average()) < 1e-13
+    assert rel(claw.assemble_system(), ora.assemble()) < 1e-12
+    t = 0.0
+    for it in range(5):
+        dt = claw.compute_time_step()
+        dto = ora.compute_time_step(t)
+        assert abs(dt - dto) <= 1e-12 * dto
+        claw.iterate_explicit(dt)
+        ora.step(dt)
+        t += dt
+    assert rel(claw.current_solution, ora.get_solution()) < 1e-11
+    # free stream is preserved on this mesh (geometric conservation of the bilinear map)
+    uni = lambda x, y: [0.3 + 0 * x, -0.1 + 0 * x, 1.0 + 0 * x, 2.5 + 0 * x]
+    bvu = np.stack(uni(xy[..., 0], xy[..., 1]), axis=-1)
+    prm2 = dflo_amd.Parameters(flux=flux, boundary={0: "farfield", 1: "farfield", 2: "farfield", 3: "farfield"}, cfl=0.4)
+    c2 = dflo_amd.ConservationLaw(mesh, prm2)
+    for w in (0, 1):
+        c2.set_boundary_values(w, bvu)
+    c2.set_initial_condition(mesh.interpolate(uni))
+    r = c2.assemble_system()
+    assert np.abs(r).max() < 1e-12
