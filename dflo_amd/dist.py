@@ -64,9 +64,14 @@ class HaloExchange:
             s, r = send, recv
         if self.use_a2a:
             n_s, n_r = self.so[-1] * width, self.ro[-1] * width
-            dist.all_to_all_single(r[:n_r], s[:n_s], [c * width for c in self.recv_counts],
-                                   [c * width for c in self.send_counts])
-        else:
+            try:
+                dist.all_to_all_single(r[:n_r], s[:n_s], [c * width for c in self.recv_counts],
+                                       [c * width for c in self.send_counts])
+            except RuntimeError:
+                # a backend that refuses uneven all-to-all: every rank sees the same error at the same call,
+                # so all of them switch to grouped point-to-point together
+                self.use_a2a = False
+        if not self.use_a2a:
             ops = []
             for p in self.peers:
                 if self.ro[p + 1] > self.ro[p]:
