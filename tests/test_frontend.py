@@ -298,3 +298,26 @@ def test_postfix_programs_match_the_expression_evaluator():
     with pytest.raises(ExpressionError):
         compile_program("fmod(x, 2)")        # host-only function
     assert OP["const"] == 0 and OP["sel"] == 18 and OP["erfc"] == 40   # ABI numbers of include/dflo_hip.h
+
+
+def test_example_states_follow_from_the_primitive_data():
+    """The conserved states of the example problems (examples/*/state.{py,m} print them from primitive data):
+    Mach-3 step inflow, Sod's two states, the Mach-10 post-shock state of the double Mach reflection at 30 degrees."""
+    g = 1.4
+    fs = np.array([c[0] for c in problems.forward_step_inflow(np.zeros(1), np.zeros(1))])
+    rho, ux, p = g, 3.0, 1.0                                   # examples/forward_step/state.py
+    assert np.allclose(fs, [rho * ux, 0.0, rho, p / (g - 1) + 0.5 * rho * ux * ux], atol=5e-6)
+    sl = np.array([c[0] for c in problems.sod(np.array([0.25]), np.zeros(1))])
+    sr = np.array([c[0] for c in problems.sod(np.array([0.75]), np.zeros(1))])
+    assert np.allclose(sl, [0, 0, 1.0, 1.0 / (g - 1)]) and np.allclose(sr, [0, 0, 0.125, 0.1 / (g - 1)])   # state.m
+    th = np.radians(30.0)                                      # examples/double_mach_reflection/state.py
+    rl, ul, vl, pl = 8.0, 8.25 * np.cos(th), -8.25 * np.sin(th), 116.5
+    post = np.array([c[0] for c in problems.double_mach(np.zeros(1), np.zeros(1))])
+    pre = np.array([c[0] for c in problems.double_mach(np.array([3.0]), np.zeros(1))])
+    assert np.allclose(post, [rl * ul, rl * vl, rl, pl / (g - 1) + 0.5 * rl * (ul * ul + vl * vl)], rtol=1e-9)
+    assert np.allclose(pre, [0, 0, 1.4, 1.0 / (g - 1)])
+    # Rankine-Hugoniot across the Mach-10 shock moving along its normal (cos 30, -sin 30): mass flux balance
+    M, c0 = 10.0, 1.0
+    s = M * c0
+    un_post = 8.25
+    assert abs(1.4 * (0 - s) - rl * (un_post - s)) < 1e-12
