@@ -54,6 +54,22 @@ class HaloExchange:
         self.recv_counts = [self.ro[r + 1] - self.ro[r] for r in range(self.world)]
         self.peers = [r for r in range(self.world) if r != self.rank and (self.so[r + 1] > self.so[r] or self.ro[r + 1] > self.ro[r])]
 
+    def exchange_async(self, send, recv, width):
+        """Start the exchange and return a handle; kernels launched before wait() run concurrently with the
+        transfer (the collective runs on the process group's own stream)."""
+        if not self.peers:
+            return _Pending()
+        if not self.use_a2a:          # grouped point-to-point has no cheap asynchronous form here: do it now
+            self.exchange(send, recv, width)
+            return _Pending()
+        n_s, n_r = self.so[-1] * width, self.ro[-1] * width
+        rc, sc = [c * width for c in self.recv_counts], [c * width for c in self.send_counts]
+        if self.host_staging:
+            s, r = send.cpu(), torch.empty(recv.shape, dtype=recv.dtype)
+            work = dist.all_to_all_single(r[:n_r], s[:n_s], rc, sc, async_op=True)
+            return _Pending(work, lambda: recv.copy_(r))
+        return _Pending(dist.all_to_all_single(recv[:n_r], send[:n_s], rc, sc, async_op=True))
+
     def exchange(self, send, recv, width):
         """send: [n_send*width] tensor, recv: [n_ghost*width] tensor (both on self.device)."""
         if not self.peers:
@@ -85,6 +101,20 @@ class HaloExchange:
             recv.copy_(r)
 
 
+class _Pending:
+    """Handle of an exchange in flight: wait() orders the caller's stream after the transfer (RCCL: a stream
+    dependency, no host block) and, with host staging, copies the received data to the device buffer."""
+
+    def __init__(self, work=None, after=None):
+        self.work, self.after = work, after
+
+    def wait(self):
+        if self.work is not None:
+            self.work.wait()
+        if self.after is not None:
+            self.after()
+
+
 class DistributedConservationLaw:
     """ConservationLaw on the slab of this rank (torch.distributed must be initialised)."""
 
@@ -103,7 +133,9 @@ class DistributedConservationLaw:
         # second stream for the halo traffic: the rim shards are advanced first, their cells travel while the
         # interior shards are computed (DFLO_OVERLAP=0 switches back to the serial order)
         import os
-        self.overlap = os.environ.get("DFLO_OVERLAP", "1") != "0"
+        # DFLO_OVERLAP: 1 (default) the exchange is an asynchronous collective on the process group's stream, everything
+        # else stays on one stream; 2: pack / exchange / unpack on a second stream of our own; 0: serial order
+        self.overlap = {"0": 0, "2": 2}.get(os.environ.get("DFLO_OVERLAP", "1"), 1)
         self.comm_stream = torch.cuda.Stream(device=self.device)
 
         send_cells, so, ro = self.mesh.comm
@@ -175,6 +207,30 @@ class DistributedConservationLaw:
             c._chk(lib.dflo_hip_stage_limit(c._h))
             self.exchange_solution()
             return
+        if self.overlap == 1:
+            # rim shards first; their cells travel while the interior shards are computed
+            c._chk(lib.dflo_hip_stage_open(c._h, rk, dt))
+            c._chk(lib.dflo_hip_stage_update_part(c._h, 1))
+            if self.tvb:   # the limiter of the rim cells needs the neighbours' fresh means
+                c._chk(lib.dflo_hip_pack_send_avg(c._h, C.c_void_p(self.send_a.data_ptr())))
+                pa = self.halo.exchange_async(self.send_a, self.recv_a, 4)
+                c._chk(lib.dflo_hip_stage_update_part(c._h, 2))          # overlaps the (small) exchange of the means
+                pa.wait()
+                c._chk(lib.dflo_hip_unpack_ghost_avg(c._h, C.c_void_p(self.recv_a.data_ptr())))
+                c._chk(lib.dflo_hip_stage_limit_part(c._h, 1))
+                c._chk(lib.dflo_hip_pack_send(c._h, C.c_void_p(self.send_u.data_ptr())))
+                pu = self.halo.exchange_async(self.send_u, self.recv_u, self.ndof)
+                c._chk(lib.dflo_hip_stage_limit_part(c._h, 2))
+            else:
+                c._chk(lib.dflo_hip_stage_limit_part(c._h, 1))
+                c._chk(lib.dflo_hip_pack_send(c._h, C.c_void_p(self.send_u.data_ptr())))
+                pu = self.halo.exchange_async(self.send_u, self.recv_u, self.ndof)
+                c._chk(lib.dflo_hip_stage_update_part(c._h, 2))
+                c._chk(lib.dflo_hip_stage_limit_part(c._h, 2))
+            c._chk(lib.dflo_hip_stage_finish(c._h))
+            pu.wait()
+            c._chk(lib.dflo_hip_unpack_ghost(c._h, C.c_void_p(self.recv_u.data_ptr())))
+            return
         main, comm = self.main_stream, self.comm_stream
         mainp, commp = C.c_void_p(main.cuda_stream), C.c_void_p(comm.cuda_stream)
         c._chk(lib.dflo_hip_stage_rim(c._h, rk, dt, mainp))                      # rim shards on the main stream
@@ -191,7 +247,7 @@ class DistributedConservationLaw:
         c._chk(lib.dflo_hip_stage_interior(c._h))                                # concurrently with the exchange
 
     def _join(self):
-        if self.overlap:
+        if self.overlap == 2:
             self.claw._chk(lib.dflo_hip_stage_join(self.claw._h))
 
     def iterate_explicit(self, dt):
