@@ -702,25 +702,22 @@ __global__ __launch_bounds__(64) void limiter_kernel(const LimArgs a) {
     const double dx = h;  // diameter/sqrt(2) of a square
     const double Mdx2 = a.M * dx * dx;
     double Dx[4], Dy[4], dbx[4], dfx[4], dby[4], dfy[4];
-    // cell-average gradient: (1/|K|) sum_q grad u(x_q) JxW_q, times dx  (:269-281)
+    // dx times the cell-average gradient (1/|K|) sum_q grad u(x_q) JxW_q  (:269-281).  On a square of side
+    // h = dx the quadrature of the x-derivative along a node line is exact and equals the difference of the end
+    // values: sum_a w_a l_m'(x_a) = l_m(1) - l_m(0), so Dx = sum_b w_b sum_m (l_m(1) - l_m(0)) U[m, b]
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       double gx = 0, gy = 0;
 #pragma unroll
       for (int b = 0; b < N; ++b)
 #pragma unroll
-        for (int aa = 0; aa < N; ++aa) {
-          double dxu = 0, dyu = 0;
-#pragma unroll
-          for (int m = 0; m < N; ++m) {
-            dxu += kb.D[aa][m] * U[c * NS + m + N * b];
-            dyu += kb.D[b][m] * U[c * NS + aa + N * m];
-          }
-          gx += kb.w[aa] * kb.w[b] * dxu;
-          gy += kb.w[aa] * kb.w[b] * dyu;
+        for (int m = 0; m < N; ++m) {
+          const double wd = CB<N>::t.w[b] * (CB<N>::t.L1[m] - CB<N>::t.L0[m]);
+          gx += wd * U[c * NS + m + N * b];
+          gy += wd * U[c * NS + b + N * m];
         }
-      Dx[c] = dx * (gx / h);
-      Dy[c] = dx * (gy / h);
+      Dx[c] = gx;
+      Dy[c] = gy;
     }
     const int il = a.lrbt[((size_t)shard * 4 + 0) * 64 + lane], ir = a.lrbt[((size_t)shard * 4 + 1) * 64 + lane];
     const int ib = a.lrbt[((size_t)shard * 4 + 2) * 64 + lane], it = a.lrbt[((size_t)shard * 4 + 3) * 64 + lane];
@@ -749,25 +746,20 @@ __global__ __launch_bounds__(64) void limiter_kernel(const LimArgs a) {
       change_x += fabs(Dxn[i] - Dx[i]);
       change_y += fabs(Dyn[i] - Dy[i]);
     }
-    change_x /= 4;
-    change_y /= 4;
+    change_x *= 0.25;
+    change_y *= 0.25;
     if (change_x + change_y > 1.0e-10) {  // :347 -- reduce to the limited linear polynomial
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        Dxn[i] /= dx;
-        Dyn[i] /= dx;
-      }
       if (a.char_lim) {
         to_con(e, 0, Dxn);
         to_con(e, 1, Dyn);
       }
+      // u = A + (x - x_c) Dxn/dx + (y - y_c) Dyn/dx with x - x_c = dx (xi - 1/2): the division by dx (:349) and
+      // the factor dx cancel
 #pragma unroll
       for (int c = 0; c < 4; ++c)
 #pragma unroll
-        for (int j = 0; j < NS; ++j) {
-          const double drx = h * (kb.x[j % N] - 0.5), dry = h * (kb.x[j / N] - 0.5);
-          U[c * NS + j] = A[c] + drx * Dxn[c] + dry * Dyn[c];
-        }
+        for (int j = 0; j < NS; ++j)
+          U[c * NS + j] = A[c] + (CB<N>::t.x[j % N] - 0.5) * Dxn[c] + (CB<N>::t.x[j / N] - 0.5) * Dyn[c];
       changed = true;
     }
   }
@@ -790,7 +782,7 @@ __global__ __launch_bounds__(64) void limiter_kernel(const LimArgs a) {
           }
           rho_min = smin(smin(rho_min, vx), vy);
         }
-      const double rat = fabs(A[RHO] - eps) / (fabs(A[RHO] - rho_min) + 1.0e-13);
+      const double rat = fabs(A[RHO] - eps) * frcp(fabs(A[RHO] - rho_min) + 1.0e-13);
       const double theta1 = smin(rat, 1.0);
       if (theta1 < 1.0) {
 #pragma unroll
@@ -812,7 +804,7 @@ __global__ __launch_bounds__(64) void limiter_kernel(const LimArgs a) {
               for (int m = 0; m < N; ++m) v += kb.Pg[g][m] * (dir == 0 ? U[c * NS + m + N * l] : U[c * NS + l + N * m]);
               W[c] = v;
             }
-            const double pre = kG1 * (W[EN] - 0.5 * (W[MX] * W[MX] + W[MY] * W[MY]) / W[RHO]);
+            const double pre = kG1 * (W[EN] - 0.5 * (W[MX] * W[MX] + W[MY] * W[MY]) * frcp(W[RHO]));
             if (pre < eps) {  // :138-178
               const double drho = W[RHO] - A[RHO], dmx = W[MX] - A[MX], dmy = W[MY] - A[MY], dE = W[EN] - A[EN];
               const double a1 = 2.0 * drho * dE - (dmx * dmx + dmy * dmy);
@@ -1228,7 +1220,7 @@ __global__ __launch_bounds__(64) void limiter_pk_kernel(const LimArgs a) {
 #pragma unroll
       for (int c = 0; c < 4; ++c)
 #pragma unroll
-        for (int m = 1; m < NM; ++m) U[c][m] = m == 1 ? Dxn[c] / sqrt_3 : (m == N ? Dyn[c] / sqrt_3 : 0.0);
+        for (int m = 1; m < NM; ++m) U[c][m] = m == 1 ? Dxn[c] * (1.0 / sqrt_3) : (m == N ? Dyn[c] * (1.0 / sqrt_3) : 0.0);
       changed = true;
     }
   }
@@ -1252,7 +1244,7 @@ __global__ __launch_bounds__(64) void limiter_pk_kernel(const LimArgs a) {
           for (int n = 0; n < N; ++n) { pg[n] = a.kb.PLg[g][n]; pl[n] = a.kb.PLx[l][n]; }
           rho_min = smin(smin(rho_min, point(RHO, pg, pl)), point(RHO, pl, pg));
         }
-      const double rat = fabs(A[RHO] - eps) / (fabs(A[RHO] - rho_min) + 1.0e-13);
+      const double rat = fabs(A[RHO] - eps) * frcp(fabs(A[RHO] - rho_min) + 1.0e-13);
       const double theta1 = smin(rat, 1.0);
       if (theta1 < 1.0) {
 #pragma unroll
@@ -1269,7 +1261,7 @@ __global__ __launch_bounds__(64) void limiter_pk_kernel(const LimArgs a) {
             for (int n = 0; n < N; ++n) { pg[n] = a.kb.PLg[g][n]; pl[n] = a.kb.PLx[l][n]; }
 #pragma unroll
             for (int c = 0; c < 4; ++c) W[c] = dir == 0 ? point(c, pg, pl) : point(c, pl, pg);
-            const double pre = kG1 * (W[EN] - 0.5 * (W[MX] * W[MX] + W[MY] * W[MY]) / W[RHO]);
+            const double pre = kG1 * (W[EN] - 0.5 * (W[MX] * W[MX] + W[MY] * W[MY]) * frcp(W[RHO]));
             if (pre < eps) {
               const double drho = W[RHO] - A[RHO], dmx = W[MX] - A[MX], dmy = W[MY] - A[MY], dE = W[EN] - A[EN];
               const double a1 = 2.0 * drho * dE - (dmx * dmx + dmy * dmy);
