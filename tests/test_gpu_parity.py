@@ -674,3 +674,62 @@ def test_unstructured_quad_mesh_parity(degree, flux):
     c2.set_initial_condition(mesh.interpolate(uni))
     r = c2.assemble_system()
     assert np.abs(r).max() < 1e-12
+
+
+def test_c4_full_size_double_mach_smoke():
+    """BASELINE C4 at full size on one device: 4001 x 1000 squares, Q2 (144 M DoF, 1.15 GB per state vector), HLLC,
+    TVB + positivity, the moving inflow state evaluated by the device.  Properties only: the state stays finite and
+    positive, nothing moves ahead of the shock, total mass changes by what crosses the boundaries."""
+    ny = 1000
+    dy = 1.0 / ny
+    x0 = 1.0 / 6.0
+    n1, n2 = int(np.ceil(x0 / dy)), int(np.ceil((4.0 - x0) / dy))
+    nx = n1 + n2
+    assert nx == 4001
+    mesh = dflo_amd.Mesh.cartesian(nx, ny, x0 - n1 * dy, 0.0, dy, [4, 2, 1, 3], 2)
+    nb = mesh.neighbors                      # bottom boundary left of x0 is outflow (id 0), examples/.../grid.geo
+    nb[:n1, 2] = -1 - 0
+    prm = dflo_amd.Parameters(flux="hllc", limiter="TVB", char_lim=True, pos_lim=True, M=100.0, beta=1.0, cfl=0.9,
+                              final_time=0.2, boundary={0: "outflow", 1: "slip", 2: "outflow", 3: "inflow", 4: "inflow"})
+    claw = dflo_amd.ConservationLaw(mesh, prm)
+    assert claw.n_dofs == 4001 * 1000 * 36
+    shock = "(x<1.0/6.0+(1+20*t)/sqrt(3))"
+    claw.set_boundary_function(3, ["57.1576766498*" + shock, "-33.0*" + shock, "8.0*%s + 1.4*(1-%s)" % (shock, shock),
+                                   "563.5*%s + 2.5*(1-%s)" % (shock, shock)])
+    claw.set_boundary_function(4, ["57.1576766498", "-33.0", "8.0", "563.5"])
+    cell, face, bid, xy = claw.boundary_faces()
+    bv = np.zeros(xy.shape[:2] + (4,))
+    claw.set_boundary_values(0, bv)
+    claw.set_boundary_values(1, bv)
+    # cell-wise constant initial data (the jump follows the mesh): avoids interpolating 144 M values on the host
+    xc = mesh.vertices[:, 0, 0] + 0.5 * dy
+    yc = mesh.vertices[:, 0, 1] + 0.5 * dy
+    post = xc < x0 + yc / np.sqrt(3.0)
+    w = np.where(post[:, None], np.array([57.1576766498, -33.0, 8.0, 563.5]), np.array([0.0, 0.0, 1.4, 2.5]))
+    u0 = np.repeat(w[:, :, None], 9, axis=2).reshape(-1)
+    claw.set_initial_condition(u0)
+    del u0
+    m0 = claw.cell_average[:, 2].sum() * dy * dy
+    claw.apply_limiter()
+    t = claw.advance(5)
+    avg = claw.cell_average
+    assert np.isfinite(avg).all() and t > 0
+    p = 0.4 * (avg[:, 3] - 0.5 * (avg[:, 0] ** 2 + avg[:, 1] ** 2) / avg[:, 2])
+    assert avg[:, 2].min() > 1.3 and p.min() > 0.9 and avg[:, 2].max() < 30.0
+    far = xc > x0 + (yc + 1.0) / np.sqrt(3.0) + 0.5            # well ahead of the shock: untouched
+    assert np.abs(avg[far] - np.array([0.0, 0.0, 1.4, 2.5])).max() < 1e-12
+    # mass: inflow through the left wall and the post-shock part of the top wall, 5 small steps
+    m1 = avg[:, 2].sum() * dy * dy
+    # rho u * height (left) + rho |v| * length of the post-shock part of the top wall - rho |v| * x0 leaving through
+    # the outflow part of the bottom wall
+    rate = 57.1576766498 * 1.0 + 33.0 * (x0 + 1.0 / np.sqrt(3.0)) - 33.0 * x0
+    assert abs((m1 - m0) - rate * t) < 0.01 * rate * t
+
+
+def test_degenerate_meshes_are_refused():
+    with pytest.raises(dflo_amd.DfloError):
+        dflo_amd.Mesh.cartesian(0, 4, 0.0, 0.0, 1.0, [-1] * 4, 1)
+    with pytest.raises(dflo_amd.DfloError):
+        dflo_amd.Mesh.from_quads(np.zeros((0, 2)), np.zeros((0, 4), dtype=np.int32), degree=1)
+    with pytest.raises(dflo_amd.DfloError):
+        dflo_amd.Mesh.cartesian(4, 4, 0.0, 0.0, 1.0, [-1] * 4, 4)     # degree > 3
