@@ -204,7 +204,7 @@ def main():
             # limiter passes are serial in the reference), so more threads stop paying early; the best of a
             # few thread counts is reported together with the count it used (tools/cpu_scaling.py).
             ncpu = os.cpu_count() or 1
-            runs = [cpu_baseline(threads=t, nx=256, steps=2) for t in sorted({1, min(16, ncpu), min(32, ncpu), min(64, ncpu)})]
+            runs = [cpu_baseline(threads=t, nx=512, steps=3) for t in sorted({1, min(16, ncpu), min(32, ncpu), min(64, ncpu)})]
             out["cpu_baseline"] = max(runs, key=lambda r: r["value"])
             out["cpu_baseline"]["host_cpus"] = ncpu
         result_line = json.dumps(out)
