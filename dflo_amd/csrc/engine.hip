@@ -57,7 +57,7 @@ struct StageArgs {
   const double *avg_cur;
   double *avg_new;
   double *rhs_out;  // parity hook: write the assembled rhs instead of updating
-  const int32_t *shard_count, *halo_begin, *halo_cells, *face_begin;
+  const int32_t *shard_count;
   const int4 *shard_hdr;      // {cells, faces, halo cells, 0}
   const int32_t *halo_pad;    // [n_shards][halo_pitch]: internal cell slot | local face << 28
   int halo_pitch, halo_stride;
@@ -76,7 +76,7 @@ struct StageArgs {
   const double *dt_cell;  // local time stepping: per internal slot, else null
   double *shard_res, *shard_dtmin;
   double dt_host, ark, gravity, cfl, h_uniform;
-  int n_shards, stride, max_fp, max_faces, max_bnd, uniform_h, want_dt, degree, prefetch_ahead;
+  int n_shards, max_fp, max_faces, max_bnd, uniform_h, want_dt, degree, prefetch_ahead;
   const int32_t *shard_list;  // null: all shards; else the n_list shards of this launch (rim / interior)
   int n_list;
   KBasis kb;
@@ -111,8 +111,9 @@ __device__ __forceinline__ int shard_of_block(int b, int n_shards) {
 // ------------------------------------------------------------------ the stage kernel
 // One workgroup of N wavefronts per shard: lane = cell, wavefront = node row b of the (k+1)^2
 // collocation nodes, so control flow is wave-uniform and every global access is a coalesced
-// 512-byte line.  LDS image: Us[ndof][stride] (own 64 cells then halo cells), As[4][stride] cell
-// averages (LxF only), Fh[4][max_fp] numerical fluxes at the shard's face points.
+// 512-byte line.  LDS image: Us[ndof (+3: u, v, c of the cell average for LxF)][65] the own 64 cells,
+// Th[4N (+3)][halo_stride] the traces of the halo cells on the shared faces, Fh[4][max_fp] the numerical
+// fluxes at the shard's face points, the packed face records and the shard's boundary data.
 
 // phase C for node row B of every cell of the shard (lane = cell)
 template <int N, int B, int MODE>
@@ -1732,7 +1733,7 @@ struct dflo_hip_engine {
   bool bc_dirty = false;
   int32_t *d_bc_ops = nullptr, *d_bc_prog = nullptr, *d_bface_id = nullptr;
   double *d_bc_consts = nullptr, *d_bxy = nullptr;
-  int32_t *d_shard_count = nullptr, *d_halo_begin = nullptr, *d_halo_cells = nullptr, *d_face_begin = nullptr;
+  int32_t *d_shard_count = nullptr;
   uint32_t *d_faces_pad = nullptr;
   uint8_t *d_nbr_code = nullptr;
   double *d_shock = nullptr;  // [n_slots], only for shock indicator = density | energy
@@ -1761,7 +1762,7 @@ struct dflo_hip_engine {
   size_t lds_bytes = 0;
   int stage_grid = 8, prefetch_ahead = 1 << 30;
   unsigned long long *phase_cycles = nullptr;
-  int stride = 0, max_fp = 0;
+  int max_fp = 0;
   // timing
   bool timing = false;
   // dflo_hip_advance replays a captured graph of `graph_steps` time steps (the buffer rotation repeats with
@@ -1996,9 +1997,6 @@ int launch_update(dflo_hip_engine *h, double *rhs_out, int part) {
   a.avg_new = h->avg[1 - h->st_avg_in];
   a.rhs_out = rhs_out;
   a.shard_count = h->d_shard_count;
-  a.halo_begin = h->d_halo_begin;
-  a.halo_cells = h->d_halo_cells;
-  a.face_begin = h->d_face_begin;
   a.shard_hdr = h->d_shard_hdr;
   a.halo_pad = h->d_halo_pad;
   a.halo_pitch = h->halo_pitch;
@@ -2024,7 +2022,6 @@ int launch_update(dflo_hip_engine *h, double *rhs_out, int part) {
   a.cfl = h->prm.cfl;
   a.h_uniform = p.h;
   a.n_shards = p.n_shards;
-  a.stride = h->stride;
   a.max_fp = h->max_fp;
   a.max_bnd = h->plan.max_bnd;
   a.max_faces = (std::max(h->plan.max_faces, 1) + 1) & ~1;
@@ -2287,9 +2284,6 @@ int dflo_hip_create(const dflo_mesh_t *mesh, const dflo_params_t *params, int de
   }
   if ((rc = upload(h, &h->bface_kind, kinds))) return bail(rc);
   if ((rc = upload(h, &h->d_shard_count, p.shard_count))) return bail(rc);
-  if ((rc = upload(h, &h->d_halo_begin, p.halo_begin))) return bail(rc);
-  if ((rc = upload(h, &h->d_halo_cells, p.halo_cells))) return bail(rc);
-  if ((rc = upload(h, &h->d_face_begin, p.face_begin))) return bail(rc);
   if ((rc = upload(h, &h->d_cell_face, p.cell_face))) return bail(rc);
   {  // fixed-pitch copies of the per-shard lists (+2 shards of slack: the kernel reads two shards ahead,
      // and 2*64*N face slots per shard so that unconditional loads stay in bounds)
@@ -2357,7 +2351,6 @@ int dflo_hip_create(const dflo_mesh_t *mesh, const dflo_params_t *params, int de
   hipMemset(h->res_sq, 0, 4 * sizeof(double));
   hipMemset(h->dt_dev, 0, 4 * sizeof(double));
   hipMemset(h->flags, 0, 4 * sizeof(int));
-  h->stride = 65;
   h->halo_stride = std::max(p.max_halo, 1) | 1;  // odd stride: the trace rows fall on different LDS banks
   h->max_fp = std::max(std::max(p.max_faces, 1) * h->N, 5 * 64 * h->N / 4 + 1);  // Fh also hosts the row partials
   {
@@ -2406,7 +2399,7 @@ int dflo_hip_destroy(dflo_hip_handle h) {
   for (int i = 0; i < 2; ++i) { hipFree(h->avg[i]); hipFree(h->bval[i]); }
   hipFree(h->rhs); hipFree(h->user_buf); hipFree(h->bface_kind);
   hipFree(h->d_bc_ops); hipFree(h->d_bc_consts); hipFree(h->d_bc_prog); hipFree(h->d_bface_id); hipFree(h->d_bxy);
-  hipFree(h->d_shard_count); hipFree(h->d_halo_begin); hipFree(h->d_halo_cells); hipFree(h->d_face_begin);
+  hipFree(h->d_shard_count);
   hipFree(h->d_bnd_pad); hipFree(h->d_nbr_code); hipFree(h->d_shock); hipFree(h->d_faces_pad); hipFree(h->d_shard_hdr); hipFree(h->d_halo_pad); hipFree(h->d_cell_face); hipFree(h->d_lrbt); hipFree(h->d_user_of); hipFree(h->d_iid);
   hipFree(h->d_rim_list); hipFree(h->d_int_list);
   hipFree(h->d_cell_h); hipFree(h->d_dt_cell); hipFree(h->d_cell_vert); hipFree(h->d_fgeom_pad); hipFree(h->shard_res); hipFree(h->shard_dtmin); hipFree(h->res_sq); hipFree(h->fin_partial); hipFree(h->dt_dev);
