@@ -62,7 +62,7 @@ def main():
     ap.add_argument("--flux", default="hllc")
     ap.add_argument("--basis", default="Qk", choices=["Qk", "Pk"], help="c2 only; Pk: dflo's FE_DGP (modal) element")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--config", default="c2", choices=["c2", "c3", "c5"],
+    ap.add_argument("--config", default="c2", choices=["c2", "c3", "c4", "c5"],
                     help="c2 (default, the headline): periodic vortex; c3: Sod tube 2048x256 Q1 Roe TVB+positivity; "
                          "c5: bilinear-cell mesh, Q3, KFVS, positivity (1-GPU stand-ins for BASELINE configs 3 and 5)")
     args = ap.parse_args()
@@ -70,6 +70,8 @@ def main():
         args.degree, args.flux = 1, "roe"
     if args.config == "c5":
         args.degree, args.flux = 3, "kfvs"
+    if args.config == "c4":
+        args.degree, args.flux = 2, "hllc"
 
     import dflo_amd
     from dflo_amd import problems
@@ -106,6 +108,17 @@ def main():
         prm = dflo_amd.Parameters(flux="roe", limiter="TVB", char_lim=True, pos_lim=True, M=0.0, beta=2.0, cfl=0.9,
                                   final_time=1e9, boundary={0: "slip", 1: "outflow", 2: "inflow"})
         ic = bc_fn = problems.sod
+    elif args.config == "c4":   # one GPU's share of C4: the left 501 x 1000 squares of the double Mach reflection, Q2, HLLC,
+        # TVB(M=100, beta=1, char) + positivity, moving inflow state on the top wall evaluated by the device
+        nyc = 1000
+        dy = 1.0 / nyc
+        n1 = int(np.ceil((1.0 / 6.0) / dy))
+        nx, ny = 501, nyc
+        mesh = dflo_amd.Mesh.cartesian(nx, ny, 1.0 / 6.0 - n1 * dy, 0.0, dy, [4, 2, 1, 3], 2)
+        mesh.neighbors[:n1, 2] = -1 - 0
+        prm = dflo_amd.Parameters(flux="hllc", limiter="TVB", char_lim=True, pos_lim=True, M=100.0, beta=1.0, cfl=0.9,
+                                  final_time=1e9, boundary={0: "outflow", 1: "slip", 2: "outflow", 3: "inflow", 4: "inflow"})
+        ic = bc_fn = lambda x, y: problems.double_mach(x, y)
     else:                       # c5 stand-in: fully unstructured quads (Delaunay triangles cut in three), q1 mapping, Q3 KFVS
         from dflo_amd import gmsh
         n = 295 if args.nx == 1024 else args.nx       # 6 n^2 cells: 522 150 by default (C5 has ~200 k cells per GPU)
@@ -132,7 +145,11 @@ def main():
             bump = 1.0 + 0.1 * np.exp(-20.0 * ((xy[..., 0] - 1.5) ** 2 + (xy[..., 1] - 1.5) ** 2))
             u0 = (u0.reshape(mesh.n_cells, 4, -1) * bump[:, None, :]).reshape(-1)
         claw.set_initial_condition(u0)
-        if args.config == "c3":
+        if args.config == "c4":
+            sh = "(x<1.0/6.0+(1+20*t)/sqrt(3))"
+            claw.set_boundary_function(3, ["57.1576766498*" + sh, "-33.0*" + sh, "8.0*%s + 1.4*(1-%s)" % (sh, sh),
+                                           "563.5*%s + 2.5*(1-%s)" % (sh, sh)])
+        if args.config in ("c3", "c4"):
             claw.apply_limiter()   # run() limits the initial condition, src/claw.cc:997-1001
         claw.advance(args.warmup)
         claw.stage_timing(True)
@@ -189,6 +206,7 @@ def main():
                 "workload": {"c2": "isentropic_vortex, %dx%d quads per GPU (global %dx%d), %s%d, %s, periodic, SSP-RK %d stages"
                                    % (args.nx, args.nx, nx, ny, args.basis[0], args.degree, args.flux.upper(), n_rk),
                              "c3": "sod_shock_tube, 2048x256 quads, Q1, ROE, TVB(M=0,beta=2,char)+positivity, SSP-RK 2 stages",
+                             "c4": "double_mach_reflection, 501x1000 of the 4001x1000 squares (one of 8 slabs), Q2, HLLC, TVB(M=100,beta=1,char)+positivity, moving inflow on the device, SSP-RK 3 stages",
                              "c5": "free stream + bump on %d unstructured quads (q1 mapping), Q3, KFVS, positivity, SSP-RK 3 stages"
                                    % mesh.n_cells}[args.config],
                 "n_dofs": n_dofs_total, "n_rk": n_rk, "parallelism": "x-slabs, %d rank(s)" % world,

@@ -1389,30 +1389,41 @@ struct BcArgs {
   const int32_t *prog;      // [DFLO_MAX_BOUNDARIES][4][2] (first op, number of ops); 0 ops = values stay as uploaded
   const int32_t *bface_id;  // [n_bfaces]
   const double *bxy;        // [n_bfaces][N][2]
-  double *bval;             // [n_bfaces][N][4]
+  double *bval0, *bval1;    // [n_bfaces][N][4] tables of RK stage 0 (time t) and of the later stages (t + dt)
   const double *dt_dev;     // [0] dt, [1] elapsed time
   double dt_host;
-  int add_dt, n_points, N;
+  const int32_t *faces;     // [n_faces] the boundary faces whose id has a program
+  int n_faces, N, n_ops, n_consts;
 };
+constexpr int kBcLdsOps = 1024, kBcLdsConsts = 256;  // programs up to this size are interpreted out of LDS
 constexpr int kExprStack = 16;
-__device__ double run_program(const int32_t *ops, int n, const double *consts, double x, double y, double t) {
-  double st[kExprStack];
-  int sp = 0;
+constexpr int kBcThreads = 512;   // 8 wavefronts: (component, table) pairs over 64 face points
+// Postfix interpreter.  Every lane of the wave runs the SAME program (the caller loops over the programs and masks
+// the store), so the opcode is wave-uniform: it is moved to a scalar register and the switch becomes one scalar
+// jump -- with a per-lane opcode the compiler walks through all forty cases under an execution mask.  The top of
+// the stack lives in a register, the rest in LDS (st[depth][thread]; a private array indexed by the stack pointer
+// would be placed in scratch memory).
+__device__ double run_program(const int32_t *ops, int n, const double *consts, double x, double y, double t, double *st) {
+  double tos = 0.0;
+  int sp = 0;   // entries below the top, kept in st[0 .. sp)
   for (int i = 0; i < n; ++i) {
-    const int op = ops[2 * i];
+    const int op = __builtin_amdgcn_readfirstlane(ops[2 * i]);
     if (op <= DFLO_OP_T) {  // pushes
-      st[sp++] = op == DFLO_OP_CONST ? consts[ops[2 * i + 1]] : (op == DFLO_OP_X ? x : (op == DFLO_OP_Y ? y : t));
+      st[(sp++) * kBcThreads] = tos;
+      tos = op == DFLO_OP_CONST ? consts[__builtin_amdgcn_readfirstlane(ops[2 * i + 1])] : (op == DFLO_OP_X ? x : (op == DFLO_OP_Y ? y : t));
       continue;
     }
     if (op == DFLO_OP_SEL) {
-      sp -= 2;
-      st[sp - 1] = st[sp - 1] != 0.0 ? st[sp] : st[sp + 1];
+      const double b = tos, a = st[(--sp) * kBcThreads], c = st[(--sp) * kBcThreads];
+      tos = c != 0.0 ? a : b;
       continue;
     }
     const bool binary = (op >= DFLO_OP_ADD && op <= DFLO_OP_OR) || op == DFLO_OP_MIN || op == DFLO_OP_MAX || op == DFLO_OP_ATAN2;
-    double b = 0.0;
-    if (binary) b = st[--sp];
-    const double a = st[sp - 1];
+    double a = tos, b = 0.0;
+    if (binary) {
+      b = tos;
+      a = st[(--sp) * kBcThreads];
+    }
     double r;
     switch (op) {
       case DFLO_OP_NEG: r = -a; break;
@@ -1453,19 +1464,39 @@ __device__ double run_program(const int32_t *ops, int n, const double *consts, d
       case DFLO_OP_ERFC: r = erfc(a); break;
       default: r = __builtin_nan(""); break;
     }
-    st[sp - 1] = r;
+    tos = r;
   }
-  return st[0];
+  return tos;
 }
-__global__ void bc_eval_kernel(const BcArgs a) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= a.n_points) return;
-  const int id = a.bface_id[i / a.N];
-  const double t = a.dt_dev[1] + (a.add_dt ? (a.dt_host >= 0.0 ? a.dt_host : a.dt_dev[0]) : 0.0);
+__global__ __launch_bounds__(kBcThreads) void bc_eval_kernel(const BcArgs a) {
+  // the programs are a few hundred words: interpret them out of LDS, not with a dependent global load per opcode
+  __shared__ int32_t s_ops[2 * kBcLdsOps];
+  __shared__ double s_consts[kBcLdsConsts];
+  __shared__ int32_t s_prog[DFLO_MAX_BOUNDARIES * 4 * 2];
+  __shared__ double s_stack[(kExprStack + 1) * kBcThreads];
+  const bool in_lds = a.n_ops <= kBcLdsOps && a.n_consts <= kBcLdsConsts;
+  if (in_lds) {
+    for (int k = threadIdx.x; k < 2 * a.n_ops; k += blockDim.x) s_ops[k] = a.ops[k];
+    for (int k = threadIdx.x; k < a.n_consts; k += blockDim.x) s_consts[k] = a.consts[k];
+  }
+  for (int k = threadIdx.x; k < DFLO_MAX_BOUNDARIES * 4 * 2; k += blockDim.x) s_prog[k] = a.prog[k];
+  __syncthreads();
+  // a block takes 64 (listed face, point) pairs; wavefront w evaluates component w & 3 for the table w >> 2, so the
+  // eight short programs of a point run side by side instead of one after the other in a single thread
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), c = wave & 3, which = wave >> 2;
+  const int j = blockIdx.x * 64 + (threadIdx.x & 63);
+  const bool valid = j < a.n_faces * a.N;
+  const int bf = a.faces[valid ? j / a.N : 0], i = bf * a.N + (valid ? j % a.N : 0);
+  const int id = a.bface_id[bf];
+  const double t = a.dt_dev[1] + (which ? (a.dt_host >= 0.0 ? a.dt_host : a.dt_dev[0]) : 0.0);
   const double x = a.bxy[2 * i], y = a.bxy[2 * i + 1];
-  for (int c = 0; c < 4; ++c) {
-    const int first = a.prog[(id * 4 + c) * 2], n = a.prog[(id * 4 + c) * 2 + 1];
-    if (n > 0) a.bval[(size_t)i * 4 + c] = run_program(a.ops + 2 * first, n, a.consts, x, y, t);
+  double *bval = which ? a.bval1 : a.bval0;
+  for (int b = 0; b < DFLO_MAX_BOUNDARIES; ++b) {
+    const int first = s_prog[(b * 4 + c) * 2], n = s_prog[(b * 4 + c) * 2 + 1];   // wave-uniform
+    if (n == 0) continue;
+    const double v = in_lds ? run_program(s_ops + 2 * first, n, s_consts, x, y, t, s_stack + threadIdx.x)
+                            : run_program(a.ops + 2 * first, n, a.consts, x, y, t, s_stack + threadIdx.x);
+    if (valid && id == b) bval[(size_t)i * 4 + c] = v;
   }
 }
 
@@ -1731,7 +1762,8 @@ struct dflo_hip_engine {
   std::vector<double> bc_consts[DFLO_MAX_BOUNDARIES][4];
   int n_bc_programs = 0;
   bool bc_dirty = false;
-  int32_t *d_bc_ops = nullptr, *d_bc_prog = nullptr, *d_bface_id = nullptr;
+  int32_t *d_bc_ops = nullptr, *d_bc_prog = nullptr, *d_bface_id = nullptr, *d_bc_faces = nullptr;
+  int n_bc_faces = 0, n_bc_ops = 0, n_bc_consts = 0;
   double *d_bc_consts = nullptr, *d_bxy = nullptr;
   int32_t *d_shard_count = nullptr;
   uint32_t *d_faces_pad = nullptr;
@@ -1905,12 +1937,11 @@ void time_collect(dflo_hip_engine *h) {
 // ---- one RK stage on the host side.  A stage is opened once (buffer roles are fixed), its update and
 // limiter kernels may then be launched for all shards or separately for the rim shards (those that read
 // ghost cells) and the interior shards, and it is finished by the reductions.
-int eval_boundary_programs(dflo_hip_engine *h, int which, int add_dt, double dt_host);
+int eval_boundary_programs(dflo_hip_engine *h, double dt_host);
 
 int open_stage(dflo_hip_engine *h, int rk, double dt_host, bool residual_only, int which_override) {
   if (rk == 0 && !residual_only && h->n_bc_programs > 0) {  // boundary functions at t (stage 0) and t + dt (later stages)
-    int rc = eval_boundary_programs(h, 0, 0, dt_host);
-    if (!rc) rc = eval_boundary_programs(h, 1, 1, dt_host);
+    const int rc = eval_boundary_programs(h, dt_host);
     if (rc) return rc;
   }
   const bool last = rk == h->n_rk - 1;
@@ -1936,7 +1967,7 @@ int open_stage(dflo_hip_engine *h, int rk, double dt_host, bool residual_only, i
   return DFLO_OK;
 }
 
-int eval_boundary_programs(dflo_hip_engine *h, int which, int add_dt, double dt_host) {
+int eval_boundary_programs(dflo_hip_engine *h, double dt_host) {
   const Plan &p = h->plan;
   const int nb = (int)p.bface_cell.size();
   if (nb == 0 || h->n_bc_programs == 0) return DFLO_OK;
@@ -1954,13 +1985,26 @@ int eval_boundary_programs(dflo_hip_engine *h, int which, int add_dt, double dt_
         }
         consts.insert(consts.end(), h->bc_consts[b][c].begin(), h->bc_consts[b][c].end());
       }
+    h->n_bc_ops = (int)(ops.size() / 2);
+    h->n_bc_consts = (int)consts.size();
     if (ops.empty()) ops.assign(2, 0);
     if (consts.empty()) consts.assign(1, 0.0);
+    std::vector<int32_t> faces;   // only the faces of boundaries that carry a program are visited
+    for (int b = 0; b < nb; ++b) {
+      const int id = p.bface_id[b];
+      bool any = false;
+      for (int c = 0; c < 4; ++c) any |= !h->bc_ops[id][c].empty();
+      if (any) faces.push_back(b);
+    }
+    h->n_bc_faces = (int)faces.size();
+    if (faces.empty()) faces.push_back(0);
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    hipFree(h->d_bc_ops); hipFree(h->d_bc_consts); hipFree(h->d_bc_prog);
-    h->d_bc_ops = nullptr; h->d_bc_consts = nullptr; h->d_bc_prog = nullptr;
+    hipFree(h->d_bc_ops); hipFree(h->d_bc_consts); hipFree(h->d_bc_prog); hipFree(h->d_bc_faces);
+    h->d_bc_ops = nullptr; h->d_bc_consts = nullptr; h->d_bc_prog = nullptr; h->d_bc_faces = nullptr;
     int rc;
-    if ((rc = upload(h, &h->d_bc_ops, ops)) || (rc = upload(h, &h->d_bc_consts, consts)) || (rc = upload(h, &h->d_bc_prog, prog))) return rc;
+    if ((rc = upload(h, &h->d_bc_ops, ops)) || (rc = upload(h, &h->d_bc_consts, consts)) || (rc = upload(h, &h->d_bc_prog, prog)) ||
+        (rc = upload(h, &h->d_bc_faces, faces)))
+      return rc;
     if (!h->d_bface_id) {
       if ((rc = upload(h, &h->d_bface_id, p.bface_id)) || (rc = upload(h, &h->d_bxy, h->bface_xy))) return rc;
     }
@@ -1972,13 +2016,17 @@ int eval_boundary_programs(dflo_hip_engine *h, int which, int add_dt, double dt_
   a.prog = h->d_bc_prog;
   a.bface_id = h->d_bface_id;
   a.bxy = h->d_bxy;
-  a.bval = h->bval[which];
+  a.bval0 = h->bval[0];
+  a.bval1 = h->bval[1];
   a.dt_dev = h->dt_dev;
   a.dt_host = dt_host;
-  a.add_dt = add_dt;
-  a.n_points = nb * h->N;
+  a.faces = h->d_bc_faces;
+  a.n_faces = h->n_bc_faces;
   a.N = h->N;
-  hipLaunchKernelGGL(bc_eval_kernel, dim3((a.n_points + 127) / 128), dim3(128), 0, h->stream, a);
+  a.n_ops = h->n_bc_ops;
+  a.n_consts = h->n_bc_consts;
+  if (a.n_faces == 0) return DFLO_OK;
+  hipLaunchKernelGGL(bc_eval_kernel, dim3((a.n_faces * a.N + 63) / 64), dim3(kBcThreads), 0, h->stream, a);
   HIPCHK(h, hipGetLastError());
   return DFLO_OK;
 }
@@ -2398,7 +2446,7 @@ int dflo_hip_destroy(dflo_hip_handle h) {
   for (int i = 0; i < 3; ++i) hipFree(h->U[i]);
   for (int i = 0; i < 2; ++i) { hipFree(h->avg[i]); hipFree(h->bval[i]); }
   hipFree(h->rhs); hipFree(h->user_buf); hipFree(h->bface_kind);
-  hipFree(h->d_bc_ops); hipFree(h->d_bc_consts); hipFree(h->d_bc_prog); hipFree(h->d_bface_id); hipFree(h->d_bxy);
+  hipFree(h->d_bc_ops); hipFree(h->d_bc_consts); hipFree(h->d_bc_prog); hipFree(h->d_bc_faces); hipFree(h->d_bface_id); hipFree(h->d_bxy);
   hipFree(h->d_shard_count);
   hipFree(h->d_bnd_pad); hipFree(h->d_nbr_code); hipFree(h->d_shock); hipFree(h->d_faces_pad); hipFree(h->d_shard_hdr); hipFree(h->d_halo_pad); hipFree(h->d_cell_face); hipFree(h->d_lrbt); hipFree(h->d_user_of); hipFree(h->d_iid);
   hipFree(h->d_rim_list); hipFree(h->d_int_list);

@@ -222,10 +222,33 @@ def _emit(node, ops, consts):
     return depth
 
 
+def _fold(node):
+    """Evaluate the variable-free subtrees once, here (1.0/6.0, sqrt(3), ...): the device interprets what is left."""
+    k = node[0]
+    if k in ("num", "var"):
+        return node
+    if k == "neg":
+        kids = [_fold(node[1])]
+        out = ("neg", kids[0])
+    elif k == "bin":
+        kids = [_fold(node[2]), _fold(node[3])]
+        out = ("bin", node[1], kids[0], kids[1])
+    elif k == "sel":
+        kids = [_fold(node[1]), _fold(node[2]), _fold(node[3])]
+        out = ("sel",) + tuple(kids)
+    else:
+        kids = [_fold(a) for a in node[2]]
+        out = ("call", node[1], kids)
+    if all(c[0] == "num" for c in kids):
+        with np.errstate(all="ignore"):
+            return ("num", float(_evaluate(out, {})))
+    return out
+
+
 def compile_program(text, variables=("x", "y", "t")):
     """-> (ops int32 [n][2], consts float64 [m]) postfix program of `text` for the device evaluator."""
     ops, consts = [], []
-    depth = _emit(_Parser(text, tuple(variables)).parse(), ops, consts)
+    depth = _emit(_fold(_Parser(text, tuple(variables)).parse()), ops, consts)
     if depth > MAX_STACK:
         raise ExpressionError("expression %r needs an evaluation stack deeper than %d" % (text, MAX_STACK))
     return np.asarray(ops, dtype=np.int32).reshape(-1, 2), np.asarray(consts, dtype=np.float64)
