@@ -66,17 +66,27 @@ int build_plan(const dflo_mesh_t &mesh, int shard_ex, int shard_ey, Plan &p, std
   std::vector<std::vector<int32_t>> shard_cells;
   if (p.uniform_h) {
     // block shards of shard_ex x shard_ey cells on the lattice, ordered along a Morton curve
-    struct Key { uint64_t m; int32_t j, i, c; };
+    // Inside a block the cells on its rim come first -- left column, right column, bottom row, top row, then the
+    // interior: the cells a neighbouring shard reads as halo are then contiguous lanes of a DoF row (one or two
+    // 128-byte lines instead of a stride-8 walk over the whole 512-byte row).  The kernels never assume a
+    // lane <-> position map, faces and neighbours are explicit.
+    struct Key { uint64_t m; int32_t w, c; };
     std::vector<Key> keys(n_owned);
     for (int c = 0; c < n_owned; ++c) {
       const double *v = &V[(size_t)c * 8];
       int32_t i = (int32_t)std::llround((v[0] - xmin) / p.h), j = (int32_t)std::llround((v[1] - ymin) / p.h);
-      keys[c] = {morton2((uint32_t)(i / shard_ex), (uint32_t)(j / shard_ey)), j, i, c};
+      const int li = i % shard_ex, lj = j % shard_ey;
+      int w;
+      if (li == 0) w = lj;
+      else if (li == shard_ex - 1) w = 64 + lj;
+      else if (lj == 0) w = 128 + li;
+      else if (lj == shard_ey - 1) w = 192 + li;
+      else w = 256 + lj * shard_ex + li;
+      keys[c] = {morton2((uint32_t)(i / shard_ex), (uint32_t)(j / shard_ey)), w, c};
     }
     std::sort(keys.begin(), keys.end(), [](const Key &a, const Key &b) {
       if (a.m != b.m) return a.m < b.m;
-      if (a.j != b.j) return a.j < b.j;
-      return a.i < b.i;
+      return a.w < b.w;
     });
     for (int k = 0; k < n_owned; ++k) {
       if (k == 0 || keys[k].m != keys[k - 1].m || (int)shard_cells.back().size() == kShard) shard_cells.emplace_back();
