@@ -230,6 +230,33 @@ int build_plan(const dflo_mesh_t &mesh, int shard_ex, int shard_ey, Plan &p, std
         }
       }
     }
+    {  // order the shard's faces: those with a halo cell on one side, then the interior ones, then the boundary
+       // faces -- the flux phase maps consecutive lanes to consecutive faces, and a wavefront whose faces are all
+       // of one kind takes one path through the trace code instead of both
+      const int nf = (int)p.faces.size() - face0;
+      std::vector<int> order(nf), pos(nf);
+      for (int k = 0; k < nf; ++k) order[k] = k;
+      auto kind = [&](int k) {
+        const FaceRec &r = p.faces[face0 + k];
+        if ((r.w0 >> 18) & 1) return 2;
+        return ((r.w0 & 0xFFFF) >= (uint32_t)kShard || r.w1 >= kShard) ? 0 : 1;
+      };
+      std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return kind(x) < kind(y); });
+      std::vector<FaceRec> fr(nf);
+      std::vector<double> fg((size_t)nf * 3);
+      for (int k = 0; k < nf; ++k) {
+        pos[order[k]] = k;
+        fr[k] = p.faces[face0 + order[k]];
+        for (int j2 = 0; j2 < 3; ++j2) fg[(size_t)k * 3 + j2] = p.face_geom[((size_t)face0 + order[k]) * 3 + j2];
+      }
+      std::copy(fr.begin(), fr.end(), p.faces.begin() + face0);
+      std::copy(fg.begin(), fg.end(), p.face_geom.begin() + (size_t)face0 * 3);
+      for (int f = 0; f < 4; ++f)
+        for (int l = 0; l < kShard; ++l) {
+          uint16_t &ref = p.cell_face[((size_t)s * 4 + f) * kShard + l];
+          if (ref != kNoFace) ref = (uint16_t)((ref & 0xC000) | pos[ref & 0x3FFF]);
+        }
+    }
     p.halo_begin[s + 1] = (int)p.halo_cells.size();
     p.face_begin[s + 1] = (int)p.faces.size();
     p.max_halo = std::max(p.max_halo, p.halo_begin[s + 1] - p.halo_begin[s]);
