@@ -702,50 +702,41 @@ __global__ __launch_bounds__(64) void limiter_kernel(const LimArgs a) {
   if (a.tvb && (!a.shock || a.shock[(size_t)shard * 64 + lane] > 1.0)) {  // src/limiter.cc:263,406
     const double dx = h;  // diameter/sqrt(2) of a square
     const double Mdx2 = a.M * dx * dx;
-    double Dx[4], Dy[4], dbx[4], dfx[4], dby[4], dfy[4];
-    // dx times the cell-average gradient (1/|K|) sum_q grad u(x_q) JxW_q  (:269-281).  On a square of side
-    // h = dx the quadrature of the x-derivative along a node line is exact and equals the difference of the end
-    // values: sum_a w_a l_m'(x_a) = l_m(1) - l_m(0), so Dx = sum_b w_b sum_m (l_m(1) - l_m(0)) U[m, b]
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      double gx = 0, gy = 0;
-#pragma unroll
-      for (int b = 0; b < N; ++b)
-#pragma unroll
-        for (int m = 0; m < N; ++m) {
-          const double wd = CB<N>::t.w[b] * (CB<N>::t.L1[m] - CB<N>::t.L0[m]);
-          gx += wd * U[c * NS + m + N * b];
-          gy += wd * U[c * NS + b + N * m];
-        }
-      Dx[c] = gx;
-      Dy[c] = gy;
-    }
-    const int il = a.lrbt[((size_t)shard * 4 + 0) * 64 + lane], ir = a.lrbt[((size_t)shard * 4 + 1) * 64 + lane];
-    const int ib = a.lrbt[((size_t)shard * 4 + 2) * 64 + lane], it = a.lrbt[((size_t)shard * 4 + 3) * 64 + lane];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      dbx[c] = il >= 0 ? A[c] - a.avg[((size_t)(il >> 6) * 4 + c) * 64 + (il & 63)] : Dx[c];
-      dfx[c] = ir >= 0 ? a.avg[((size_t)(ir >> 6) * 4 + c) * 64 + (ir & 63)] - A[c] : Dx[c];
-      dby[c] = ib >= 0 ? A[c] - a.avg[((size_t)(ib >> 6) * 4 + c) * 64 + (ib & 63)] : Dy[c];
-      dfy[c] = it >= 0 ? a.avg[((size_t)(it >> 6) * 4 + c) * 64 + (it & 63)] - A[c] : Dy[c];
-    }
+    // one direction after the other (x: left/right neighbours, y: bottom/top), so that only one set of differences
+    // is alive at a time
     EigenXY e;
-    if (a.char_lim) {
-      e = eigen_at(A);
-      to_char(e, 0, dbx);
-      to_char(e, 0, dfx);
-      to_char(e, 1, dby);
-      to_char(e, 1, dfy);
-      to_char(e, 0, Dx);
-      to_char(e, 1, Dy);
-    }
+    if (a.char_lim) e = eigen_at(A);
     double Dxn[4], Dyn[4], change_x = 0, change_y = 0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      Dxn[i] = minmod(Dx[i], a.beta * dbx[i], a.beta * dfx[i], Mdx2);
-      Dyn[i] = minmod(Dy[i], a.beta * dby[i], a.beta * dfy[i], Mdx2);
-      change_x += fabs(Dxn[i] - Dx[i]);
-      change_y += fabs(Dyn[i] - Dy[i]);
+    for (int dir = 0; dir < 2; ++dir) {
+      double D[4], db[4], df[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {   // dx * cell-average gradient, see above
+        double g = 0;
+#pragma unroll
+        for (int b = 0; b < N; ++b)
+#pragma unroll
+          for (int m = 0; m < N; ++m)
+            g += CB<N>::t.w[b] * (CB<N>::t.L1[m] - CB<N>::t.L0[m]) * U[c * NS + (dir == 0 ? m + N * b : b + N * m)];
+        D[c] = g;
+      }
+      const int ib = a.lrbt[((size_t)shard * 4 + 2 * dir) * 64 + lane], ifw = a.lrbt[((size_t)shard * 4 + 2 * dir + 1) * 64 + lane];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        db[c] = ib >= 0 ? A[c] - a.avg[((size_t)(ib >> 6) * 4 + c) * 64 + (ib & 63)] : D[c];
+        df[c] = ifw >= 0 ? a.avg[((size_t)(ifw >> 6) * 4 + c) * 64 + (ifw & 63)] - A[c] : D[c];
+      }
+      if (a.char_lim) {
+        to_char(e, dir, db);
+        to_char(e, dir, df);
+        to_char(e, dir, D);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const double dn = minmod(D[i], a.beta * db[i], a.beta * df[i], Mdx2);
+        if (dir == 0) { Dxn[i] = dn; change_x += fabs(dn - D[i]); }
+        else { Dyn[i] = dn; change_y += fabs(dn - D[i]); }
+      }
     }
     change_x *= 0.25;
     change_y *= 0.25;
