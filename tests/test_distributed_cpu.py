@@ -27,7 +27,12 @@ def _worker(rank, world, port, case, ret, transport="a2a"):
     import oracle_lib as O
 
     nx, ny, degree, flux, limiter, pos, side_bc, bnd = case
-    mesh = dflo_amd.Mesh.cartesian(nx, ny, 0.0, 0.0, 1.0 / nx, side_bc, degree)
+    if side_bc == "unstructured":   # Delaunay triangles cut into quads: irregular connectivity, flipped faces, q1 mapping
+        from dflo_amd import gmsh
+        verts, quads, bed, bid = gmsh.unstructured_quads(nx, seed=5)
+        mesh = dflo_amd.Mesh.from_quads(verts, quads, bed, bid, degree)
+    else:
+        mesh = dflo_amd.Mesh.cartesian(nx, ny, 0.0, 0.0, 1.0 / nx, side_bc, degree)
     prm = dflo_amd.Parameters(flux=flux, limiter=limiter, pos_lim=pos, boundary=bnd, beta=2.0)
     ic = (lambda x, y: problems.smooth_perturbation(x, y, L=1.0)) if limiter == "none" else problems.sod
     u0 = mesh.interpolate(ic)
@@ -85,6 +90,7 @@ CASES = [
     (12, 6, 2, "hllc", "none", False, [-1, -1, -1, -1], None),
     (12, 6, 1, "lxf", "none", False, [-1, -1, 0, 0], {0: "slip"}),
     (16, 4, 1, "roe", "none", True, [2, 1, 0, 0], {0: "slip", 1: "outflow", 2: "inflow"}),
+    (5, 5, 2, "hllc", "none", True, "unstructured", {0: "slip", 1: "outflow", 2: "slip", 3: "inflow"}),
 ]
 
 

@@ -23,6 +23,19 @@ def _front(x, y):
     return [rho * u, rho * v, rho, p / 0.4 + 0.5 * rho * (u * u + v * v)]
 
 
+def _mesh(dflo_amd, nx, ny, x0, h, side_bc, degree):
+    if side_bc == "unstructured":   # C5's kind of mesh: irregular all-quad mesh, q1 mapping
+        from dflo_amd import gmsh
+        verts, quads, bed, bid = gmsh.unstructured_quads(nx, seed=2)
+        return dflo_amd.Mesh.from_quads(verts, quads, bed, bid, degree)
+    return dflo_amd.Mesh.cartesian(nx, ny, x0, x0, h, side_bc, degree)
+
+
+def _smooth(x, y):
+    from dflo_amd import problems
+    return problems.smooth_perturbation(x, y, L=1.0)
+
+
 def _worker(rank, world, port, case, ret):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, HERE)
@@ -34,10 +47,10 @@ def _worker(rank, world, port, case, ret):
     from dflo_amd.dist import DistributedConservationLaw
 
     nx, ny, degree, flux, limiter, pos, side_bc, bnd, ic_name = case[:9]
-    ic = {"sod": problems.sod, "vortex": problems.isentropic_vortex, "front": _front}[ic_name]
+    ic = {"sod": problems.sod, "vortex": problems.isentropic_vortex, "front": _front, "smooth": _smooth}[ic_name]
     x0, h = (-5.0, 10.0 / nx) if ic_name == "vortex" else (0.0, 1.0 / nx)
-    mesh = dflo_amd.Mesh.cartesian(nx, ny, x0, x0, h, side_bc, degree)
-    prm = dflo_amd.Parameters(flux=flux, limiter=limiter, pos_lim=pos, boundary=bnd, beta=2.0, cfl=0.8,
+    mesh = _mesh(dflo_amd, nx, ny, x0, h, side_bc, degree)
+    prm = dflo_amd.Parameters(flux=flux, limiter=limiter, pos_lim=pos, boundary=bnd, beta=2.0, cfl=0.8 if side_bc != "unstructured" else 0.4,
                               shock_indicator=case[9] if len(case) > 9 else "limiter")
     u0 = mesh.interpolate(ic)
     d = DistributedConservationLaw(mesh, prm, device_index=0)
@@ -66,6 +79,7 @@ CASES = [
     (32, 16, 2, "hllc", "none", False, [-1, -1, -1, -1], None, "vortex"),
     (64, 8, 1, "roe", "TVB", True, [2, 1, 0, 0], {0: "slip", 1: "outflow", 2: "inflow"}, "sod"),
     (48, 40, 1, "hllc", "TVB", True, [0, 0, 0, 0], {0: "outflow"}, "front", "density"),   # KXRCF-gated limiter across the cut
+    (10, 10, 3, "kfvs", "none", True, "unstructured", {0: "slip", 1: "outflow", 2: "slip", 3: "inflow"}, "smooth"),   # C5 style
 ]
 
 
@@ -80,10 +94,10 @@ def test_two_engines_match_one(case):
     ret = mgr.dict()
     mp.spawn(_worker, args=(2, port, case, ret), nprocs=2, join=True)
     nx, ny, degree, flux, limiter, pos, side_bc, bnd, ic_name = case[:9]
-    ic = {"sod": problems.sod, "vortex": problems.isentropic_vortex, "front": _front}[ic_name]
+    ic = {"sod": problems.sod, "vortex": problems.isentropic_vortex, "front": _front, "smooth": _smooth}[ic_name]
     x0, h = (-5.0, 10.0 / nx) if ic_name == "vortex" else (0.0, 1.0 / nx)
-    mesh = dflo_amd.Mesh.cartesian(nx, ny, x0, x0, h, side_bc, degree)
-    prm = dflo_amd.Parameters(flux=flux, limiter=limiter, pos_lim=pos, boundary=bnd, beta=2.0, cfl=0.8,
+    mesh = _mesh(dflo_amd, nx, ny, x0, h, side_bc, degree)
+    prm = dflo_amd.Parameters(flux=flux, limiter=limiter, pos_lim=pos, boundary=bnd, beta=2.0, cfl=0.8 if side_bc != "unstructured" else 0.4,
                               shock_indicator=case[9] if len(case) > 9 else "limiter")
     ora = O.Oracle(mesh, prm)
     cell, face, bid, xy = ora.boundary_faces()
