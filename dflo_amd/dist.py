@@ -280,6 +280,19 @@ class DistributedConservationLaw:
         self.elapsed_time = float(self.dt_dev[1].item())
         return self.elapsed_time
 
+    def residual_norms(self):
+        """(||rhs|| of the first stage, of the last stage) of the step just done, summed over the ranks --
+        right_hand_side.l2_norm() of src_mpi/claw.cc:777 (a printed diagnostic; reduced here on demand, not per stage)."""
+        self._join()
+        dtp, resp = C.c_void_p(), C.c_void_p()
+        self.claw._chk(lib.dflo_hip_scalar_ptrs(self.claw._h, C.byref(dtp), C.byref(resp)))
+        r = _device_view(resp.value, 4, self.device).clone()
+        if dist.get_backend() != "nccl":
+            r = r.cpu()
+        dist.all_reduce(r, op=dist.ReduceOp.SUM)
+        r = r.cpu().numpy()
+        return float(np.sqrt(r[0])), float(np.sqrt(r[self.n_rk - 1]))
+
     def gather_solution(self):
         """Owned DoFs of all ranks assembled in the global cell order (on every rank; test helper)."""
         self._join()

@@ -170,3 +170,23 @@ class Mesh:
         f = np.stack([np.broadcast_to(np.asarray(c, dtype=np.float64), xy.shape[:2]) for c in w], axis=1)  # [cell][4][q]
         u = np.einsum("ncq,q,qm->ncm", f, ww, T)
         return np.ascontiguousarray(u).reshape(-1)
+
+    def angular_momentum(self, solution):
+        """Total angular momentum  int x m_y - y m_x  with QGauss(k+1) (compute_angular_momentum, src/claw.cc:602-635;
+        a printed diagnostic of run(), every `compute angular momentum` iterations)."""
+        N = self.degree + 1
+        xy = self.support_points()[: self.n_owned]                   # the points of QGauss<2>(k+1)
+        T, ww = self.modal_matrix()
+        u = np.asarray(solution).reshape(self.n_cells, 4, -1)[: self.n_owned]
+        m = u[:, :2] if self.basis == "Qk" else np.einsum("ncm,qm->ncq", u[:, :2], T)
+        v = np.asarray(self.vertices)[: self.n_owned]
+        t, _ = np.polynomial.legendre.leggauss(N)
+        g = 0.5 * (t + 1.0)
+        xi, eta = np.tile(g, N), np.repeat(g, N)
+        # |det J| of the bilinear map at the quadrature points (|K| for squares)
+        xxi = (1 - eta) * (v[:, 1, 0] - v[:, 0, 0])[:, None] + eta * (v[:, 3, 0] - v[:, 2, 0])[:, None]
+        yxi = (1 - eta) * (v[:, 1, 1] - v[:, 0, 1])[:, None] + eta * (v[:, 3, 1] - v[:, 2, 1])[:, None]
+        xet = (1 - xi) * (v[:, 2, 0] - v[:, 0, 0])[:, None] + xi * (v[:, 3, 0] - v[:, 1, 0])[:, None]
+        yet = (1 - xi) * (v[:, 2, 1] - v[:, 0, 1])[:, None] + xi * (v[:, 3, 1] - v[:, 1, 1])[:, None]
+        jxw = np.abs(xxi * yet - xet * yxi) * ww[None, :]
+        return float(((xy[..., 0] * m[:, 1] - xy[..., 1] * m[:, 0]) * jxw).sum())

@@ -177,6 +177,7 @@ class InputDeck:
         self.output_time_step = out["time step"]
         self.output_iter_step = int(out["iter step"])
         self.output_format = out["format"]
+        self.ang_mom_step = int(out["compute angular momentum"])
         self.sections = sub
         self.top = top
 

@@ -121,6 +121,8 @@ class Run:
                 res_norm0, res_norm = claw.iterate_explicit(dt)    # :1051, advances elapsed_time
                 self.log("   %-16.3e %-16.3e" % (res_norm0, res_norm))
                 self.time_iter += 1
+            if chunk == 1 and self.time_iter % d.ang_mom_step == 0:    # :1074-1075
+                self.log("Total angular momentum: %18.8e %24.14e" % (claw.elapsed_time, self.mesh.angular_momentum(claw.current_solution)))
             if (claw.elapsed_time >= next_output_time or self.time_iter >= next_output_iter or
                     abs(claw.elapsed_time - final_time) < 1.0e-13):   # :1091-1099
                 self.output_results()

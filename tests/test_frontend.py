@@ -321,3 +321,16 @@ def test_example_states_follow_from_the_primitive_data():
     s = M * c0
     un_post = 8.25
     assert abs(1.4 * (0 - s) - rl * (un_post - s)) < 1e-12
+
+
+def test_angular_momentum_diagnostic():
+    """int x m_y - y m_x for a rigid rotation m = rho0 (-w y, w x) on [-1,1]^2: rho0 w int (x^2 + y^2) = rho0 w 8/3;
+    exact for Q2 / P2 (quadratic integrand), on squares and on bilinear cells."""
+    f = lambda x, y: [-0.7 * 1.3 * y, 0.7 * 1.3 * x, 1.3 + 0 * x, 2.5 + 0 * x]
+    for basis in ("Qk", "Pk"):
+        mesh = dflo_amd.Mesh.cartesian(6, 6, -1.0, -1.0, 1.0 / 3, [0] * 4, 2)
+        mesh.set_basis(basis)
+        assert abs(mesh.angular_momentum(mesh.interpolate(f)) - 0.7 * 1.3 * 8.0 / 3.0) < 1e-12
+    verts, quads, bed, bid = gmsh.unstructured_quads(4, Lx=2.0, Ly=2.0, seed=1)
+    mesh = dflo_amd.Mesh.from_quads(verts - 1.0, quads, bed, bid, 3)
+    assert abs(mesh.angular_momentum(mesh.interpolate(f)) - 0.7 * 1.3 * 8.0 / 3.0) < 1e-11

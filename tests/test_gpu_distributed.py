@@ -62,16 +62,20 @@ def _worker(rank, world, port, case, ret):
     d.set_initial_condition(u0)
     d.exchange_solution()
     dts = []
+    norms = None
     for it in range(4):
         dt = d.compute_time_step()
         d.iterate_explicit(dt)
         dts.append(dt)
+        if it == 0:
+            norms = d.residual_norms()      # summed over the ranks
     t_end = d.advance(2)        # device-resident dt, all-reduced across the ranks
     dts.append(t_end)
     u = d.gather_solution()
     if rank == 0:
         ret["u"] = u
         ret["dts"] = dts
+        ret["norms"] = norms
     dist.destroy_process_group()
 
 
@@ -110,7 +114,9 @@ def test_two_engines_match_one(case):
     for it, dt2 in enumerate(ret["dts"][:-1]):
         dt = ora.compute_time_step(t)
         assert abs(dt - dt2) <= 1e-12 * dt
-        ora.step(dt)
+        r0, r1 = ora.step(dt)
+        if it == 0:
+            assert abs(ret["norms"][0] - r0) <= 1e-10 * r0 and abs(ret["norms"][1] - r1) <= 1e-10 * r1
         t += dt
     for it in range(2):
         dt = ora.compute_time_step(t)
