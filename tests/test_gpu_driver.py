@@ -315,3 +315,16 @@ def test_double_mach_fast_mode_runs_on_device_programs(tmp_path):
     b.run(max_steps=16, fast=True)          # one advance(16): no host round trip, programs evaluated every step
     assert abs(a.claw.elapsed_time - b.claw.elapsed_time) < 1e-13
     assert np.abs(a.claw.current_solution - b.claw.current_solution).max() < 1e-10 * np.abs(a.claw.current_solution).max()
+
+
+def test_command_line_entry_point(tmp_path):
+    """`python -m dflo_amd input.prm 4` -- dflo's own command line (src/main.cc:22-27: input file, thread count)."""
+    import subprocess
+    gmsh.sod_tube(str(tmp_path / "tube.msh"), nx=21, ny=5)
+    (tmp_path / "input.prm").write_text(SOD_PRM)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "dflo_amd", "input.prm", "4", "--max-steps", "6"], cwd=str(tmp_path),
+                       env=dict(os.environ, PYTHONPATH=root), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert "Number of degrees of freedom: 1280" in r.stdout and "It=6" in r.stdout and "Writing file solution-001.vtu" in r.stdout
+    assert sorted(f for f in os.listdir(tmp_path) if f.endswith(".vtu")) == ["shock.vtu", "solution-000.vtu", "solution-001.vtu"]
