@@ -376,7 +376,7 @@ __device__ __forceinline__ void flux_phase(const StageArgs &a, const double *Us,
   constexpr int NS = N * N, NDOF = 4 * NS, NT = 64 * N, S = 65;
   const int nfp = nf * N;
   for (int p = tid; p < nfp; p += NT) {
-    const int q = p / nf, k = p - q * nf;
+    const int k = p / N, q = p - k * N;   // the N points of a face sit in consecutive lanes; faces are sorted by kind
     const uint32_t r = Fr[k];
     const int slotL = pface_slot(r), fL = pface_face(r);
     const bool bnd = pface_bnd(r), flip = pface_flip(r);
