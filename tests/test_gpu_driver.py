@@ -328,3 +328,56 @@ def test_command_line_entry_point(tmp_path):
     assert r.returncode == 0, r.stderr
     assert "Number of degrees of freedom: 1280" in r.stdout and "It=6" in r.stdout and "Writing file solution-001.vtu" in r.stdout
     assert sorted(f for f in os.listdir(tmp_path) if f.endswith(".vtu")) == ["shock.vtu", "solution-000.vtu", "solution-001.vtu"]
+
+
+# ---------------------------------------------------------------- dflo_hip_run: the stand-alone C++ driver
+RUN_BIN = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "dflo_amd", "dflo_hip_run")
+
+
+def _vtu_field(path, name):
+    root = ET.parse(str(path)).getroot()
+    da = [d for d in root.iter("DataArray") if d.get("Name") == name][0]
+    a = vtu.decode_data_array(da.text, np.float64)
+    nc = int(da.get("NumberOfComponents", "1"))
+    return a.reshape(-1, nc) if nc > 1 else a
+
+
+@pytest.mark.parametrize("case", ["sod-Qk", "sod-Pk", "dmr", "vortex"])
+def test_cxx_driver_matches_python_driver(tmp_path, case):
+    import subprocess
+    if case.startswith("sod"):
+        gmsh.sod_tube(str(tmp_path / "tube.msh"), nx=41, ny=5)
+        text, steps = SOD_PRM.replace("set basis = Qk", "set basis = " + case[4:]), 12
+    elif case == "dmr":
+        gmsh.double_mach(str(tmp_path / "grid.msh"), ny=13)
+        text, steps = DMR_PRM % {"degree": 2, "basis": "Qk", "pos": "true"}, 12
+    else:
+        gmsh.vortex_square(str(tmp_path / "grid.msh"), n=17, L=10.0)
+        text = ("set mesh file = grid.msh\nset degree = 3\nset mapping = cartesian\n"
+                + "".join("subsection boundary_%d\n set type = periodic\n set pair = %d\n set direction = %s\nend\n" % (b, p, d)
+                          for b, p, d in [(1, 3, "y"), (2, 4, "x"), (3, 1, "y"), (4, 2, "x")])
+                + "subsection initial condition\n set function = isenvort\nend\nsubsection time stepping\n set cfl = 0.5\n set final time = 0.3\nend\n"
+                  "subsection refinement\n set refinement = false\nend\nsubsection flux\n set flux = kfvs\nend\nsubsection output\n set iter step = 7\nend\n")
+        steps = 10
+    (tmp_path / "input.prm").write_text(text)
+    for fast in ([], ["--fast"]):
+        out = tmp_path / ("cxx" + "".join(fast))
+        r = subprocess.run([RUN_BIN, str(tmp_path / "input.prm"), "4", "--outdir", str(out), "--max-steps", str(steps)] + fast,
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr + r.stdout
+        ref = tmp_path / ("py" + "".join(fast))
+        assert main([str(tmp_path / "input.prm"), "--outdir", str(ref), "--max-steps", str(steps), "--quiet"] + fast) == 0
+        assert sorted(os.listdir(out)) == sorted(os.listdir(ref))
+        last = sorted(f for f in os.listdir(out) if f.startswith("solution"))[-1]
+        for name in ["Density", "Energy", "Pressure", "XMomentum__YMomentum", "XVelocity__YVelocity"] + (["schlieren_plot"] if "schlieren plot = true" in text else []):
+            a, b = _vtu_field(out / last, name), _vtu_field(ref / last, name)
+            assert a.shape == b.shape and np.abs(a - b).max() <= 1e-9 * max(np.abs(b).max(), 1.0), (case, name)
+        assert np.array_equal(_vtu_field(out / "shock.vtu", "shock_indicator"), _vtu_field(ref / "shock.vtu", "shock_indicator"))
+    assert "Number of degrees of freedom:" in r.stdout and "Writing file solution-000.vtu" in r.stdout
+
+
+def test_cxx_driver_reports_errors_like_main(tmp_path):
+    import subprocess
+    (tmp_path / "input.prm").write_text("set mesh file = missing.msh\nsubsection time stepping\n set cfl = 0.5\nend\nsubsection refinement\n set refinement = false\nend\n")
+    r = subprocess.run([RUN_BIN, str(tmp_path / "input.prm")], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 1 and "Exception on processing" in r.stderr
