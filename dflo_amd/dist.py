@@ -115,6 +115,17 @@ class _Pending:
             self.after()
 
 
+def _on_main_stream(method):
+    """Run a method of DistributedConservationLaw with its main stream as torch's current stream."""
+    import functools
+
+    @functools.wraps(method)
+    def wrapped(self, *args, **kwargs):
+        with torch.cuda.stream(self.main_stream):
+            return method(self, *args, **kwargs)
+    return wrapped
+
+
 class DistributedConservationLaw:
     """ConservationLaw on the slab of this rank (torch.distributed must be initialised)."""
 
@@ -127,8 +138,11 @@ class DistributedConservationLaw:
         self.device = torch.device("cuda", device_index)
         torch.cuda.set_device(self.device)
         self.claw = ConservationLaw(self.mesh, parameters, device=device_index)
-        # run the engine on torch's current stream so that RCCL ops and kernels are ordered
-        self.main_stream = torch.cuda.current_stream()
+        # One explicit stream for the engine's kernels and (as torch's current stream inside every method below) for the
+        # collectives, so that the process group orders its transfers against exactly that stream.  (The default
+        # stream would also work, through the implicit synchronisation of the legacy null stream -- and would
+        # serialise against whatever else the process runs there.)
+        self.main_stream = torch.cuda.Stream(device=self.device)
         self.claw.set_stream(self.main_stream.cuda_stream)
         # second stream for the halo traffic: the rim shards are advanced first, their cells travel while the
         # interior shards are computed (DFLO_OVERLAP=0 switches back to the serial order)
@@ -171,16 +185,19 @@ class DistributedConservationLaw:
         gid = np.asarray(self.mesh.global_ids)
         return np.ascontiguousarray(np.asarray(u_global).reshape(self.global_mesh.n_cells, self.ndof)[gid]).reshape(-1)
 
+    @_on_main_stream
     def set_initial_condition(self, u_global):
         self._join()
         self.claw.set_initial_condition(self.owned_slice_of_global(u_global))
 
+    @_on_main_stream
     def exchange_solution(self):
         c = self.claw
         c._chk(lib.dflo_hip_pack_send(c._h, C.c_void_p(self.send_u.data_ptr())))
         self.halo.exchange(self.send_u, self.recv_u, self.ndof)
         c._chk(lib.dflo_hip_unpack_ghost(c._h, C.c_void_p(self.recv_u.data_ptr())))
 
+    @_on_main_stream
     def exchange_averages(self):
         c = self.claw
         c._chk(lib.dflo_hip_pack_send_avg(c._h, C.c_void_p(self.send_a.data_ptr())))
@@ -188,6 +205,7 @@ class DistributedConservationLaw:
         c._chk(lib.dflo_hip_unpack_ghost_avg(c._h, C.c_void_p(self.recv_a.data_ptr())))
 
     # ---- time stepping
+    @_on_main_stream
     def compute_time_step(self):
         self.claw.elapsed_time = self.elapsed_time
         dt = self.claw.compute_time_step()
@@ -250,6 +268,7 @@ class DistributedConservationLaw:
         if self.overlap == 2:
             self.claw._chk(lib.dflo_hip_stage_join(self.claw._h))
 
+    @_on_main_stream
     def iterate_explicit(self, dt):
         c = self.claw
         for rk in range(self.n_rk):
@@ -258,6 +277,7 @@ class DistributedConservationLaw:
         c.end_step()
         self.elapsed_time += dt
 
+    @_on_main_stream
     def advance(self, n_steps):
         """n_steps x {compute_time_step; iterate_explicit} with dt resident on the device: per step one
         8-byte all-reduce(min) (Utilities::MPI::min, src_mpi/claw.cc:579) and no host synchronisation."""
@@ -280,6 +300,7 @@ class DistributedConservationLaw:
         self.elapsed_time = float(self.dt_dev[1].item())
         return self.elapsed_time
 
+    @_on_main_stream
     def residual_norms(self):
         """(||rhs|| of the first stage, of the last stage) of the step just done, summed over the ranks --
         right_hand_side.l2_norm() of src_mpi/claw.cc:777 (a printed diagnostic; reduced here on demand, not per stage)."""
@@ -293,6 +314,7 @@ class DistributedConservationLaw:
         r = r.cpu().numpy()
         return float(np.sqrt(r[0])), float(np.sqrt(r[self.n_rk - 1]))
 
+    @_on_main_stream
     def gather_solution(self):
         """Owned DoFs of all ranks assembled in the global cell order (on every rank; test helper)."""
         self._join()
