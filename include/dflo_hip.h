@@ -217,8 +217,9 @@ int dflo_hip_get_shock_indicator(dflo_hip_handle h, double *shock_indicator);
 int dflo_hip_check(dflo_hip_handle h);
 int dflo_hip_synchronize(dflo_hip_handle h);
 
-/* Average duration (ms) of the stage kernel launches since the last reset,
- * measured with HIP events on the engine's stream; n receives the launch count. */
+/* Average duration (ms) of the stage kernel launches since the last reset, measured with HIP events on the
+ * engine's stream. Every fifth stage is timed (each stage of a 2- or 3-stage step equally often, and the event
+ * records stay out of the way of the others); n receives the number of timed stages. */
 int dflo_hip_stage_timing(dflo_hip_handle h, int enable, double *avg_ms, int64_t *n);
 
 /* ------------------------------------------------ multi-device halo seam */
