@@ -720,16 +720,31 @@ __global__ __launch_bounds__(64) void limiter_kernel(const LimArgs a) {
             g += CB<N>::t.w[b] * (CB<N>::t.L1[m] - CB<N>::t.L0[m]) * U[c * NS + (dir == 0 ? m + N * b : b + N * m)];
         D[c] = g;
       }
+      // the boundary case "no neighbour: difference = own slope" (:296-316) is resolved before the projection
+      const double D0[4] = {D[0], D[1], D[2], D[3]};
+      if (a.char_lim) to_char(e, dir, D);
+      // minmod returns its first argument untouched when |a| < M dx^2 (src/limiter.cc:21): if that holds for
+      // every component of every cell of the wavefront, the neighbour differences are not needed at all
+      bool smooth = true;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) smooth = smooth && fabs(D[i]) < Mdx2;
+      if (__all(smooth)) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          if (dir == 0) Dxn[i] = D[i];
+          else Dyn[i] = D[i];
+        }
+        continue;
+      }
       const int ib = a.lrbt[((size_t)shard * 4 + 2 * dir) * 64 + lane], ifw = a.lrbt[((size_t)shard * 4 + 2 * dir + 1) * 64 + lane];
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
-        db[c] = ib >= 0 ? A[c] - a.avg[((size_t)(ib >> 6) * 4 + c) * 64 + (ib & 63)] : D[c];
-        df[c] = ifw >= 0 ? a.avg[((size_t)(ifw >> 6) * 4 + c) * 64 + (ifw & 63)] - A[c] : D[c];
+        db[c] = ib >= 0 ? A[c] - a.avg[((size_t)(ib >> 6) * 4 + c) * 64 + (ib & 63)] : D0[c];
+        df[c] = ifw >= 0 ? a.avg[((size_t)(ifw >> 6) * 4 + c) * 64 + (ifw & 63)] - A[c] : D0[c];
       }
       if (a.char_lim) {
         to_char(e, dir, db);
         to_char(e, dir, df);
-        to_char(e, dir, D);
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
