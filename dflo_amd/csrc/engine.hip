@@ -727,7 +727,7 @@ __global__ __launch_bounds__(64) void limiter_kernel(const LimArgs a) {
       // every component of every cell of the wavefront, the neighbour differences are not needed at all
       bool smooth = true;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) smooth = smooth && fabs(D[i]) < Mdx2;
+      for (int i = 0; i < 4; ++i) smooth = smooth && (fabs(D[i]) < Mdx2 || D[i] == 0.0);   // minmod(0, b, c) = 0 as well
       if (__all(smooth)) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
