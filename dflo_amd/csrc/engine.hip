@@ -711,13 +711,15 @@ __global__ __launch_bounds__(64) void limiter_kernel(const LimArgs a) {
     for (int dir = 0; dir < 2; ++dir) {
       double D[4], db[4], df[4];
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {   // dx * cell-average gradient, see above
-        double g = 0;
+      for (int c = 0; c < 4; ++c) {   // dx * cell-average gradient, see above; l_m(1) - l_m(0) is antisymmetric in m, and
+        double g = 0;                  // pairing the nodes makes the slope of a constant state exactly zero
 #pragma unroll
         for (int b = 0; b < N; ++b)
 #pragma unroll
-          for (int m = 0; m < N; ++m)
-            g += CB<N>::t.w[b] * (CB<N>::t.L1[m] - CB<N>::t.L0[m]) * U[c * NS + (dir == 0 ? m + N * b : b + N * m)];
+          for (int m = 0; m < N / 2; ++m) {
+            const int j0 = dir == 0 ? m + N * b : b + N * m, j1 = dir == 0 ? (N - 1 - m) + N * b : b + N * (N - 1 - m);
+            g += CB<N>::t.w[b] * (CB<N>::t.L1[m] - CB<N>::t.L0[m]) * (U[c * NS + j0] - U[c * NS + j1]);
+          }
         D[c] = g;
       }
       // the boundary case "no neighbour: difference = own slope" (:296-316) is resolved before the projection
