@@ -151,6 +151,7 @@ def main():
                                            "563.5*%s + 2.5*(1-%s)" % (sh, sh)])
         if args.config in ("c3", "c4"):
             claw.apply_limiter()   # run() limits the initial condition, src/claw.cc:997-1001
+        mass0 = claw.cell_average.sum(axis=0) if args.config == "c2" else None
         claw.advance(args.warmup)
         claw.stage_timing(True)
         torch.cuda.synchronize()
@@ -160,6 +161,10 @@ def main():
         sec = time.perf_counter() - t0
         kernel_ms, n_launch = claw.stage_timing(False)
         n_dofs_launch = n_dofs_total
+        drift = None
+        if args.config == "c2":
+            m1 = claw.cell_average.sum(axis=0)
+            drift = float(np.abs(m1 - mass0).max() / np.abs(mass0).max())
     else:
         import torch.distributed as dist
         from dflo_amd.dist import DistributedConservationLaw
@@ -168,6 +173,8 @@ def main():
         u = dclaw.mesh.interpolate(lambda x, y: problems.isentropic_vortex(((x + 5.0) % 10.0) - 5.0, y))
         dclaw.claw.set_initial_condition(u)
         dclaw.exchange_solution()
+        n_own = dclaw.mesh.n_owned
+        mass0 = dclaw.claw.cell_average[:n_own].sum(axis=0)          # outside the timed region: conservation check
         dclaw.advance(args.warmup)
         dclaw.claw.stage_timing(True)
         dist.barrier()
@@ -182,6 +189,13 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         sec = float(tt.item())
         n_dofs_launch = dclaw.n_dofs_owned
+        # periodic box: the sums of the conserved variables over all ranks must not move (checks the halo exchange
+        # and the doubly evaluated partition faces of the run that was just timed)
+        mm = torch.tensor(np.concatenate([mass0, dclaw.claw.cell_average[:n_own].sum(axis=0)]), dtype=torch.float64,
+                          device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(mm, op=dist.ReduceOp.SUM)
+        mm = mm.cpu().numpy()
+        drift = float(np.abs(mm[4:] - mm[:4]).max() / np.abs(mm[:4]).max())
 
     if rank == 0:
         value = n_dofs_total * n_rk * args.steps / sec / 1e6
@@ -210,6 +224,7 @@ def main():
                              "c5": "free stream + bump on %d unstructured quads (q1 mapping), Q3, KFVS, positivity, SSP-RK 3 stages"
                                    % mesh.n_cells}[args.config],
                 "n_dofs": n_dofs_total, "n_rk": n_rk, "parallelism": "x-slabs, %d rank(s)" % world,
+                "check": None if drift is None else "periodic box: max relative drift of the conserved totals over the run = %.1e" % drift,
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
