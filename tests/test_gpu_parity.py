@@ -733,3 +733,61 @@ def test_degenerate_meshes_are_refused():
         dflo_amd.Mesh.from_quads(np.zeros((0, 2)), np.zeros((0, 4), dtype=np.int32), degree=1)
     with pytest.raises(dflo_amd.DfloError):
         dflo_amd.Mesh.cartesian(4, 4, 0.0, 0.0, 1.0, [-1] * 4, 4)     # degree > 3
+
+
+# ---------------------------------------------------------------- option matrix
+_MATRIX = [
+    # basis, degree, flux, limiter, char_lim, pos_lim, indicator, time_step_type, gravity
+    ("Qk", 1, "sw", "TVB", False, False, "limiter", "global", 0.0),
+    ("Qk", 2, "kfvs", "TVB", False, True, "energy", "global", 0.0),
+    ("Qk", 2, "roe", "TVB", True, False, "density", "local", 0.0),
+    ("Qk", 3, "lxf", "TVB", True, True, "limiter", "global", 0.3),
+    ("Qk", 3, "hllc", "none", True, True, "limiter", "local", 0.0),
+    ("Pk", 1, "roe", "TVB", False, True, "limiter", "global", 0.0),
+    ("Pk", 2, "lxf", "TVB", True, True, "energy", "local", 0.0),
+    ("Pk", 2, "sw", "none", True, False, "limiter", "global", 0.3),
+    ("Pk", 3, "hllc", "TVB", True, False, "density", "global", 0.0),
+    ("Pk", 3, "kfvs", "none", False, True, "limiter", "global", 0.0),
+]
+
+
+@pytest.mark.parametrize("basis,degree,flux,limiter,char_lim,pos_lim,indicator,tst,gravity", _MATRIX)
+def test_option_matrix(basis, degree, flux, limiter, char_lim, pos_lim, indicator, tst, gravity):
+    """Combinations of basis / flux / limiter switches / indicator / local time stepping / gravity on a box with all
+    five boundary kinds, a few steps against the oracle."""
+    nx, ny = 20, 14
+    mesh = dflo_amd.Mesh.cartesian(nx, ny, 0.0, 0.0, 1.0 / nx, [0, 1, 2, 3], degree)
+    mesh.neighbors[: nx // 2, 2] = -1 - 4          # half of the bottom wall gets a fifth boundary id
+    mesh.set_basis(basis)
+    bnd = {0: "farfield", 1: "outflow", 2: "slip", 3: "pressure", 4: "inflow"}
+    prm = dflo_amd.Parameters(flux=flux, limiter=limiter, char_lim=char_lim, pos_lim=pos_lim, shock_indicator=indicator,
+                              time_step_type=tst, gravity=gravity, boundary=bnd, cfl=0.4, M=5.0, beta=1.5)
+    claw, ora = dflo_amd.ConservationLaw(mesh, prm), oracle_lib.Oracle(mesh, prm)
+
+    def ic(x, y):   # smooth flow with both velocity components away from zero plus a steep (resolved) front
+        s = 0.5 * (1.0 + np.tanh((x + 0.4 * y - 0.7) / 0.06))
+        rho, p = 1.0 + 0.4 * s + 0.1 * np.sin(2 * np.pi * y), 1.0 + 0.5 * s
+        u, v = 0.55 + 0.1 * np.cos(2 * np.pi * x), 0.3 + 0.05 * np.sin(2 * np.pi * x)
+        return [rho * u, rho * v, rho, p / 0.4 + 0.5 * rho * (u * u + v * v)]
+
+    cell, face, bid, xy = claw.boundary_faces()
+    bv = np.stack(ic(xy[..., 0], xy[..., 1]), axis=-1)
+    for w in (0, 1):
+        claw.set_boundary_values(w, bv * (1 + 0.02 * w))
+        ora.set_boundary_values(w, bv * (1 + 0.02 * w))
+    u0 = mesh.interpolate(ic)
+    claw.set_initial_condition(u0)
+    ora.set_solution(u0)
+    claw.apply_limiter()
+    ora.apply_limiter()
+    t = 0.0
+    for it in range(4):
+        dt = claw.compute_time_step()
+        dto = ora.compute_time_step(t)
+        assert abs(dt - dto) <= 1e-12 * dto
+        claw.iterate_explicit(dt)
+        ora.step(dt if tst == "global" else -1.0)
+        t += dt
+    scale = np.abs(ora.get_solution()).max()
+    assert np.abs(claw.cell_average - ora.get_cell_average()).max() < 1e-10 * scale
+    assert np.abs(claw.current_solution - ora.get_solution()).max() < 1e-9 * scale
