@@ -100,6 +100,35 @@ __device__ __forceinline__ double wave_min(double v) {
   return v;
 }
 
+// Wave-wide sum / minimum through DPP (row shifts inside the rows of 16 lanes, then row_bcast:15 / row_bcast:31): the
+// total arrives in lane 63 after six dependent VALU steps, where the shuffle loops above take six round trips through the
+// LDS crossbar.  Lanes without a source keep the identity (`old` operand, bound_ctrl off).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_f64(double ident, double v) {
+  const int lo = __builtin_amdgcn_update_dpp(__double2loint(ident), __double2loint(v), CTRL, ROW_MASK, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(__double2hiint(ident), __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_sum_lane63(double v) {
+  v += dpp_f64<0x111, 0xf>(0.0, v);   // row_shr:1
+  v += dpp_f64<0x112, 0xf>(0.0, v);   // row_shr:2
+  v += dpp_f64<0x114, 0xf>(0.0, v);   // row_shr:4
+  v += dpp_f64<0x118, 0xf>(0.0, v);   // row_shr:8  -> lane 15 of each row holds the row total
+  v += dpp_f64<0x142, 0xa>(0.0, v);   // row_bcast:15 into rows 1 and 3
+  v += dpp_f64<0x143, 0xc>(0.0, v);   // row_bcast:31 into rows 2 and 3
+  return v;
+}
+__device__ __forceinline__ double wave_min_lane63(double v) {
+  constexpr double big = 1.0e300;
+  v = fmin(v, dpp_f64<0x111, 0xf>(big, v));
+  v = fmin(v, dpp_f64<0x112, 0xf>(big, v));
+  v = fmin(v, dpp_f64<0x114, 0xf>(big, v));
+  v = fmin(v, dpp_f64<0x118, 0xf>(big, v));
+  v = fmin(v, dpp_f64<0x142, 0xa>(big, v));
+  v = fmin(v, dpp_f64<0x143, 0xc>(big, v));
+  return v;
+}
+
 // blockIdx -> shard so that every XCD (block b runs on XCD b % 8) sweeps one contiguous run of
 // the Morton-ordered shards: halo re-reads then hit that XCD's own L2.
 __device__ __forceinline__ int shard_of_block(int b, int n_shards) {
@@ -649,9 +678,9 @@ __global__ __launch_bounds__(64 * N, (GEO == 1 || N == 4) ? 2 : 3) void stage_ke
         if (a.want_dt) dtmin = cfl_dt(avg, h, a.cfl, a.degree);
       }
     }
-    res = wave_sum(res);
-    dtmin = wave_min(dtmin);
-    if (lane == 0) {
+    res = wave_sum_lane63(res);
+    if (GEO == 0 && a.want_dt) dtmin = wave_min_lane63(dtmin);
+    if (lane == 63) {
       a.shard_res[shard] = res;
       if (GEO == 0 && a.want_dt) a.shard_dtmin[shard] = dtmin;
     }
@@ -1158,9 +1187,9 @@ __global__ __launch_bounds__(64 * N, N == 4 ? 2 : 3) void stage_kernel_pk(const 
       for (int c = 0; c < 4; ++c) a.avg_new[((size_t)shard * 4 + c) * 64 + lane] = avg[c];
       if (a.want_dt) dtmin = cfl_dt(avg, h, a.cfl, a.degree);
     }
-    res = wave_sum(res);
-    dtmin = wave_min(dtmin);
-    if (lane == 0) {
+    res = wave_sum_lane63(res);
+    if (a.want_dt) dtmin = wave_min_lane63(dtmin);
+    if (lane == 63) {
       a.shard_res[shard] = res;
       if (a.want_dt) a.shard_dtmin[shard] = dtmin;
     }
