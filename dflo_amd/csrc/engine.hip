@@ -476,7 +476,7 @@ __device__ __forceinline__ void flux_phase(const StageArgs &a, const double *Us,
 //   MODE 0: first stage (ark = 0, u(n) not read)   1: later stages   2: residual only (parity hook)
 //   GEO 0: axis-aligned squares (MappingCartesian)   1: bilinear cells (MappingQ1)
 template <int N, int FLUX, int MODE, int GEO>
-__global__ __launch_bounds__(64 * N, (GEO == 1 || N == 4) ? 2 : 3) void stage_kernel(const StageArgs a) {
+__global__ __launch_bounds__(64 * N, ((GEO == 1 && N != 3) || N == 4) ? 2 : 3) void stage_kernel(const StageArgs a) {
   constexpr int NS = N * N, NDOF = 4 * NS, NT = 64 * N;
   constexpr int ROWS = NDOF + (FLUX == DFLO_FLUX_LXF ? 3 : 0);   // LxF: (u, v, c) of the cell average ride along
   constexpr int TROWS = 4 * N + (FLUX == DFLO_FLUX_LXF ? 3 : 0); // halo image: face trace (+ the same three)
@@ -516,9 +516,12 @@ __global__ __launch_bounds__(64 * N, (GEO == 1 || N == 4) ? 2 : 3) void stage_ke
     asm volatile("global_load_dword %0, %1, off" : "=v"(pf2) : "v"(p2));
   }
   // ---- all loads of the shard, issued back to back; the halo entries first (the halo values depend on them)
-  int hent[2];
+  // halo entries: thread t works on entry (t & 31) + 32 b of every block b of 32 entries (8x8 lattice shards have one
+  // block, unstructured shards two or three): load them all now, the gathers below then depend on nothing else
+  constexpr int HB = 3;
+  int hentb[HB];
 #pragma unroll
-  for (int t = 0; t < 2; ++t) hent[t] = a.halo_pad[(size_t)shard * a.halo_pitch + ((tid + t * NT) & 31)];
+  for (int b = 0; b < HB; ++b) hentb[b] = a.halo_pad[(size_t)shard * a.halo_pitch + min((tid & 31) + 32 * b, a.halo_pitch - 1)];
   const int4 hdr = a.shard_hdr[shard];                // {cells, faces, halo entries, boundary faces}
   const int nf = hdr.y, nh = hdr.z, nbnd = hdr.w;
   const bool active = lane < hdr.x;
@@ -539,6 +542,15 @@ __global__ __launch_bounds__(64 * N, (GEO == 1 || N == 4) ? 2 : 3) void stage_ke
   }
   const uint32_t *fp = a.faces_pad + (size_t)shard * a.face_pitch;
   const uint32_t fr0 = fp[tid], fr1 = fp[tid + NT];
+  double fg[3][2];   // GEO 1: unit normal and length of the faces tid and tid + NT (the table has the pitch of the face records)
+  if constexpr (GEO == 1) {
+    const double *gp = a.fgeom_pad + (size_t)shard * 3 * a.face_pitch;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      fg[j][0] = gp[j * a.face_pitch + tid];
+      fg[j][1] = gp[j * a.face_pitch + tid + NT];
+    }
+  }
   uint16_t cref[4];
 #pragma unroll
   for (int f = 0; f < 4; ++f) cref[f] = a.cell_face[((size_t)shard * 4 + f) * 64 + lane];
@@ -562,23 +574,40 @@ __global__ __launch_bounds__(64 * N, (GEO == 1 || N == 4) ? 2 : 3) void stage_ke
   // ---- phase A: own rows -> LDS; halo: only the trace on the shared face is kept.
   //      halo item i -> (entry s = i % nh, q = (i / nh) % N, comp = i / (nh N)); an entry is
   //      (internal cell slot | local face << 28) of a face neighbour outside the shard
-  for (int i = tid; i < ((nh + 31) & ~31) * 4 * N; i += NT) {
-    const int sl = (i & 31) + ((i >> 5) / (4 * N)) * 32, r = (i >> 5) % (4 * N), q = r % N, c = r / N;
-    if (sl >= nh) continue;
-    const int e = i == tid ? hent[0] : (i == tid + NT ? hent[1] : a.halo_pad[(size_t)shard * a.halo_pitch + sl]);
-    const int ic = e & 0x0FFFFFFF, f = (e >> 28) & 3;
-    const double *hp = a.Ucur + ((size_t)(ic >> 6) * NDOF + c * NS) * 64 + (ic & 63);
-    const int str0 = f < 2 ? 1 : N;
-    const int base = (f < 2 ? N * q : q) + ((f & 1) ? (N - 1) * str0 : 0), str = (f & 1) ? -str0 : str0;
-    double v = 0.0;
+  //      A thread takes, of its entry in block b, the two (component, point) rows r = g and g + 2N (g = t >> 5):
+  //      2N independent loads per block.
+  {
+    const int g = tid >> 5, l32 = tid & 31;
+    for (int b = 0; b * 32 < nh; ++b) {
+      const int sl = l32 + 32 * b;
+      if (sl >= nh) continue;
+      const int e = b == 0 ? hentb[0] : (b == 1 ? hentb[1] : (b == 2 ? hentb[2] : a.halo_pad[(size_t)shard * a.halo_pitch + sl]));
+      const int ic = e & 0x0FFFFFFF, f = (e >> 28) & 3;
+      const int str0 = f < 2 ? 1 : N, str = (f & 1) ? -str0 : str0;
+      double val[2][N];
 #pragma unroll
-    for (int m = 0; m < N; ++m) v += CB<N>::t.L0[m] * hp[(base + m * str) * 64];
-    Th[(c * N + q) * HS + sl] = v;
+      for (int j = 0; j < 2; ++j) {
+        const int r = g + 2 * N * j, q = r % N, c = r / N;
+        const double *hp = a.Ucur + ((size_t)(ic >> 6) * NDOF + c * NS) * 64 + (ic & 63);
+        const int base = (f < 2 ? N * q : q) + ((f & 1) ? (N - 1) * str0 : 0);
+#pragma unroll
+        for (int m = 0; m < N; ++m) val[j][m] = hp[(base + m * str) * 64];
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int r = g + 2 * N * j, q = r % N, c = r / N;
+        double v = 0.0;
+#pragma unroll
+        for (int m = 0; m < N; ++m) v += CB<N>::t.L0[m] * val[j][m];
+        Th[(c * N + q) * HS + sl] = v;
+      }
+    }
   }
   if constexpr (FLUX == DFLO_FLUX_LXF) {  // lambda of the LxF flux comes from the cell averages (src/equation.h:357-359):
                                           // keep (u, v, c) of each average instead of the four components
     for (int sl = tid; sl < nh; sl += NT) {
-      const int ic = (sl < 32 ? hent[0] : a.halo_pad[(size_t)shard * a.halo_pitch + sl]) & 0x0FFFFFFF;
+      const int blk = sl >> 5;   // sl = tid + k NT: entry (tid & 31) + 32 blk is this thread's own preloaded one
+      const int ic = (blk == 0 ? hentb[0] : (blk == 1 ? hentb[1] : (blk == 2 ? hentb[2] : a.halo_pad[(size_t)shard * a.halo_pitch + sl]))) & 0x0FFFFFFF;
       double A[4], uvc[3];
 #pragma unroll
       for (int c = 0; c < 4; ++c) A[c] = a.avg_cur[((size_t)(ic >> 6) * 4 + c) * 64 + (ic & 63)];
@@ -604,10 +633,10 @@ __global__ __launch_bounds__(64 * N, (GEO == 1 || N == 4) ? 2 : 3) void stage_ke
   if (tid + NT < nf) Fr[tid + NT] = fr1;
   for (int i = tid + 2 * NT; i < nf; i += NT) Fr[i] = fp[i];
   if constexpr (GEO == 1) {
-    const double *gp = a.fgeom_pad + (size_t)shard * 3 * a.face_pitch;
-    for (int i = tid; i < 3 * nf; i += NT) {
-      const int k = i % nf, j = i / nf;
-      Fg[j * a.max_faces + k] = gp[j * a.face_pitch + k];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      if (tid < nf) Fg[j * a.max_faces + tid] = fg[j][0];
+      if (tid + NT < nf) Fg[j * a.max_faces + tid + NT] = fg[j][1];
     }
   }
   if (nbnd > 0) {  // boundary values and kinds of this shard's boundary faces

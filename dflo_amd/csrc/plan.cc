@@ -3,11 +3,28 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <unordered_map>
 
 namespace dflo {
 namespace {
+
+// index of (x, y) along the Hilbert curve of a 2^order x 2^order lattice: consecutive indices are always
+// neighbouring lattice points (a Morton curve jumps), so runs of 64 centroids make compact shards with short rims
+inline uint64_t hilbert2(uint32_t x, uint32_t y, int order) {
+  uint64_t d = 0;
+  for (uint32_t s = 1u << (order - 1); s > 0; s >>= 1) {
+    const uint32_t rx = (x & s) ? 1 : 0, ry = (y & s) ? 1 : 0;
+    d += (uint64_t)s * s * ((3 * rx) ^ ry);
+    if (ry == 0) {   // rotate the quadrant
+      if (rx == 1) { x = s - 1 - (x & (s - 1)); y = s - 1 - (y & (s - 1)); }
+      else { x &= s - 1; y &= s - 1; }
+      const uint32_t t = x; x = y; y = t;
+    } else { x &= s - 1; y &= s - 1; }
+  }
+  return d;
+}
 
 inline uint64_t morton2(uint32_t x, uint32_t y) {
   auto spread = [](uint64_t v) {
@@ -93,7 +110,7 @@ int build_plan(const dflo_mesh_t &mesh, int shard_ex, int shard_ey, Plan &p, std
       shard_cells.back().push_back(keys[k].c);
     }
   } else {
-    // unstructured: Morton order of the centroids, cut into runs of 64
+    // unstructured: Hilbert order of the centroids, cut into runs of 64
     double xmax = -1e300, ymax = -1e300;
     for (int c = 0; c < n; ++c) {
       const double *v = &V[(size_t)c * 8];
@@ -105,13 +122,60 @@ int build_plan(const dflo_mesh_t &mesh, int shard_ex, int shard_ey, Plan &p, std
       const double *v = &V[(size_t)c * 8];
       double cx = 0.25 * (v[0] + v[2] + v[4] + v[6]), cy = 0.25 * (v[1] + v[3] + v[5] + v[7]);
       uint32_t qx = (uint32_t)((cx - xmin) / span * 1048575.0), qy = (uint32_t)((cy - ymin) / span * 1048575.0);
-      keys[c] = {morton2(qx, qy), c};
+      keys[c] = {hilbert2(qx, qy, 20), c};
     }
     std::sort(keys.begin(), keys.end());
-    for (int k = 0; k < n_owned; ++k) {
-      if (k % kShard == 0) shard_cells.emplace_back();
-      shard_cells.back().push_back(keys[k].second);
+    std::vector<int32_t> sh(n_owned);
+    for (int k = 0; k < n_owned; ++k) sh[keys[k].second] = k / kShard;
+    // Refinement: swap pairs of cells between neighbouring shards as long as that shortens the cut (every cell keeps
+    // 64 partners, the number of faces between different shards -- halo entries, doubly evaluated fluxes -- only falls).
+    auto links = [&](int c, int shard) {
+      int k = 0;
+      for (int f = 0; f < 4; ++f) {
+        const int nb = mesh.cell_face_neighbor[(size_t)c * 4 + f];
+        k += nb >= 0 && nb < n_owned && sh[nb] == shard;
+      }
+      return k;
+    };
+    const int n_pass = std::getenv("DFLO_PLAN_REFINE") ? std::atoi(std::getenv("DFLO_PLAN_REFINE")) : 8;   // developer switch
+    for (int pass = 0; pass < n_pass; ++pass) {
+      std::unordered_map<uint64_t, std::vector<std::pair<int, int32_t>>> want;   // (from, to) -> (gain, cell)
+      for (int c = 0; c < n_owned; ++c) {
+        const int own = links(c, sh[c]);
+        int best = -1, bg = -5;
+        for (int f = 0; f < 4; ++f) {
+          const int nb = mesh.cell_face_neighbor[(size_t)c * 4 + f];
+          if (nb < 0 || nb >= n_owned || sh[nb] == sh[c]) continue;
+          const int g = links(c, sh[nb]) - own;
+          if (g > bg) { bg = g; best = sh[nb]; }
+        }
+        if (best >= 0 && bg >= 0) want[((uint64_t)sh[c] << 32) | (uint32_t)best].push_back({bg, c});
+      }
+      long swaps = 0;
+      for (auto &kv : want) {
+        const int A = (int)(kv.first >> 32), B = (int)(kv.first & 0xFFFFFFFFu);
+        if (A > B) continue;
+        auto it = want.find(((uint64_t)B << 32) | (uint32_t)A);
+        if (it == want.end()) continue;
+        auto &la = kv.second, &lb = it->second;
+        std::sort(la.rbegin(), la.rend());
+        std::sort(lb.rbegin(), lb.rend());
+        for (size_t i = 0; i < std::min(la.size(), lb.size()); ++i) {
+          const int c = la[i].second, d = lb[i].second;
+          if (sh[c] != A || sh[d] != B) continue;
+          bool adj = false;
+          for (int f = 0; f < 4; ++f) adj |= mesh.cell_face_neighbor[(size_t)c * 4 + f] == d;
+          const int gain = (links(c, B) - links(c, A)) + (links(d, A) - links(d, B)) - (adj ? 2 : 0);
+          if (gain <= 0) continue;
+          sh[c] = B;
+          sh[d] = A;
+          ++swaps;
+        }
+      }
+      if (swaps == 0) break;
     }
+    shard_cells.assign((n_owned + kShard - 1) / kShard, {});
+    for (int k = 0; k < n_owned; ++k) shard_cells[sh[keys[k].second]].push_back(keys[k].second);   // Hilbert order inside a shard
   }
   p.n_shards = (int)shard_cells.size();
   const int n_ghost = n - n_owned;
