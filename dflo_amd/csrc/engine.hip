@@ -1623,21 +1623,22 @@ __global__ void pack_kernel(double *buf, const double *U, const int32_t *slots, 
   buf[t] = U[((size_t)(slot >> 6) * ndof + d) * 64 + (slot & 63)];
 }
 // ghost cells: staging buffer [g][ndof] -> ghost shards, and their cell averages
+// one thread per (ghost cell, component): its DoFs travel buffer -> ghost shard (the buffer is read with unit stride
+// along the thread's own run of n_s values, the shard rows are written 64 cells wide) and their average is formed
 __global__ void unpack_ghost_kernel(const double *buf, double *U, double *avg, int first_slot, int n_ghost, int ndof,
                                     KBasis kb, int N, const double *vert, int n_slots) {
-  const int g = blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= n_ghost) return;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_ghost * 4) return;
+  const int g = t >> 2, c = t & 3;
   const int slot = first_slot + g, ns = ndof / 4;
   const double ia = cell_inv_area(vert, n_slots, slot);
-  for (int c = 0; c < 4; ++c) {
-    double m = 0;
-    for (int j = 0; j < ns; ++j) {
-      const double v = buf[(size_t)g * ndof + c * ns + j];
-      U[((size_t)(slot >> 6) * ndof + c * ns + j) * 64 + (slot & 63)] = v;
-      m += avg_weight(kb, N, j, vert, n_slots, slot, ia) * v;
-    }
-    avg[((size_t)(slot >> 6) * 4 + c) * 64 + (slot & 63)] = m;
+  double m = 0;
+  for (int j = 0; j < ns; ++j) {
+    const double v = buf[(size_t)g * ndof + c * ns + j];
+    U[((size_t)(slot >> 6) * ndof + c * ns + j) * 64 + (slot & 63)] = v;
+    m += avg_weight(kb, N, j, vert, n_slots, slot, ia) * v;
   }
+  avg[((size_t)(slot >> 6) * 4 + c) * 64 + (slot & 63)] = m;
 }
 __global__ void unpack_ghost_avg_kernel(const double *buf, double *avg, int first_slot, int n_ghost) {
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
@@ -3038,7 +3039,7 @@ int dflo_hip_unpack_ghost(dflo_hip_handle h, const void *device_buffer) {
   const int n_ghost = p.n_cells - p.n_owned;
   if (n_ghost == 0) return DFLO_OK;
   if (!device_buffer) return DFLO_ERR_BAD_PARAM;
-  hipLaunchKernelGGL(unpack_ghost_kernel, dim3((n_ghost + 63) / 64), dim3(64), 0, h->stream, (const double *)device_buffer,
+  hipLaunchKernelGGL(unpack_ghost_kernel, dim3((4 * n_ghost + 127) / 128), dim3(128), 0, h->stream, (const double *)device_buffer,
                      h->U[h->cur], h->avg[h->avg_cur], p.n_shards * 64, n_ghost, h->ndof, h->kb,
                      h->basis == DFLO_BASIS_PK ? -h->N : h->N, (const double *)h->d_cell_vert, p.n_slots);
   HIPCHK(h, hipGetLastError());
