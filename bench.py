@@ -52,6 +52,21 @@ def cpu_baseline(threads, nx=160, steps=2):
     }
 
 
+def _settle_clocks(seconds=0.4):
+    """The GPU sat idle while the host built the mesh and the initial data; it needs a few tenths of a second of
+    fp64 work to come back to its sustained clock.  This is not a solver step: it touches none of the engine's data
+    and leaves the workload of the W warm-up and K timed steps exactly as specified."""
+    if os.environ.get("DFLO_BENCH_NO_PREHEAT") == "1":
+        return
+    x = torch.full((1 << 22,), 1.0000001, dtype=torch.float64, device="cuda")
+    y = torch.zeros_like(x)
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        for _ in range(50):
+            y = torch.addcmul(y, x, x)
+        torch.cuda.synchronize()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -152,6 +167,7 @@ def main():
         if args.config in ("c3", "c4"):
             claw.apply_limiter()   # run() limits the initial condition, src/claw.cc:997-1001
         mass0 = claw.cell_average.sum(axis=0) if args.config == "c2" else None
+        _settle_clocks()
         claw.advance(args.warmup)
         claw.stage_timing(True)
         torch.cuda.synchronize()
@@ -175,6 +191,7 @@ def main():
         dclaw.exchange_solution()
         n_own = dclaw.mesh.n_owned
         mass0 = dclaw.claw.cell_average[:n_own].sum(axis=0)          # outside the timed region: conservation check
+        _settle_clocks()
         dclaw.advance(args.warmup)
         dclaw.claw.stage_timing(True)
         dist.barrier()
