@@ -721,6 +721,40 @@ __global__ __launch_bounds__(64 * N, ((GEO == 1 && N != 3) || N == 4) ? 2 : 3) v
 #endif
 }
 
+// compute_time_step_q for one cell (src/claw.cc:520-557): max of |v| + c over the 4 x 4 points of QIterated(QTrapez,3),
+// dt = cfl h / lambda / (2k+1).  U: the cell's DoFs [4][N*N]; the interpolation is sum-factorised, one point row at a time.
+template <int N>
+__device__ __forceinline__ double dt_q_cell(const double *U, const KBasis &kb, double h, double cfl, int degree) {
+  constexpr int NS = N * N;
+  double maxeig = 0.0;
+#pragma unroll
+  for (int pa = 0; pa < kTrap; ++pa) {
+    double v[4][N];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int b = 0; b < N; ++b) {
+        double t = 0;
+#pragma unroll
+        for (int aa = 0; aa < N; ++aa) t += kb.Pt[pa][aa] * U[c * NS + aa + N * b];
+        v[c][b] = t;
+      }
+#pragma unroll
+    for (int pb = 0; pb < kTrap; ++pb) {
+      double w[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        double t = 0;
+#pragma unroll
+        for (int b = 0; b < N; ++b) t += kb.Pt[pb][b] * v[c][b];
+        w[c] = t;
+      }
+      maxeig = fmax(maxeig, max_eigenvalue(w));
+    }
+  }
+  return cfl * h / maxeig / (2.0 * degree + 1.0);
+}
+
 // ------------------------------------------------------------------ limiter kernel
 struct LimArgs {
   double *U;
@@ -734,6 +768,10 @@ struct LimArgs {
   const int32_t *shard_list;
   int n_list;
   const double *shock;  // KXRCF indicator per cell, or null: "shock indicator = limiter" marks every cell (1e20)
+  // bilinear cells, last stage: the time step of the limited solution is formed here, while the cell is in registers
+  double *shard_dtmin, *dt_cell;
+  double cfl;
+  int degree, dtq;
   KBasis kb;
 };
 
@@ -746,7 +784,7 @@ __global__ __launch_bounds__(64) void limiter_kernel(const LimArgs a) {
   if (sidx < 0) return;
   const int shard = a.shard_list ? a.shard_list[sidx] : sidx;
   const int lane = threadIdx.x;
-  if (lane >= a.shard_count[shard]) return;
+  const bool active = lane < a.shard_count[shard];   // padding lanes hold a harmless state and run along
   const KBasis &kb = a.kb;
   double *up = a.U + (size_t)shard * NDOF * 64 + lane;
   double U[NDOF], A[4];
@@ -834,7 +872,7 @@ __global__ __launch_bounds__(64) void limiter_kernel(const LimArgs a) {
   if (a.pos_lim) {
     const double eps = 1.0e-13;
     if (smin(A[RHO], pressure(A)) < eps) {  // "Fatal: Negative states" :26-38
-      atomicOr(&a.flags[0], 1);
+      if (active) atomicOr(&a.flags[0], 1);
     } else {
       // density at GLL(Ng) x Gauss(N) and Gauss(N) x GLL(Ng)  (:43-47, :72-78)
       double rho_min = 1.0e20;
@@ -891,7 +929,7 @@ __global__ __launch_bounds__(64) void limiter_kernel(const LimArgs a) {
               theta2 = smin(theta2, t);
             }
           }
-      if (fail) atomicOr(&a.flags[1], 1);
+      if (fail && active) atomicOr(&a.flags[1], 1);
       if (theta2 < 1.0) {
 #pragma unroll
         for (int c = 0; c < 4; ++c)
@@ -901,9 +939,18 @@ __global__ __launch_bounds__(64) void limiter_kernel(const LimArgs a) {
       }
     }
   }
-  if (changed) {
+  if (changed && active) {
 #pragma unroll
     for (int d = 0; d < NDOF; ++d) up[d * 64] = U[d];
+  }
+  if (a.dtq) {   // wave-uniform
+    double dtmin = 1.0e20;
+    if (active) {
+      dtmin = dt_q_cell<N>(U, kb, h, a.cfl, a.degree);
+      if (a.dt_cell) a.dt_cell[(size_t)shard * 64 + lane] = dtmin;
+    }
+    dtmin = wave_min(dtmin);
+    if (lane == 0) a.shard_dtmin[shard] = dtmin;
   }
 }
 
@@ -1670,40 +1717,10 @@ __global__ __launch_bounds__(64) void dt_q_kernel(const double *U, const double 
   const int lane = threadIdx.x;
   double dtmin = 1.0e20;
   if (lane < shard_count[shard]) {
-    double W[4][kTrap][kTrap];
+    double u[NDOF];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      double u[NS], v[kTrap][N];
-#pragma unroll
-      for (int j = 0; j < NS; ++j) u[j] = U[((size_t)shard * NDOF + c * NS + j) * 64 + lane];
-#pragma unroll
-      for (int pa = 0; pa < kTrap; ++pa)
-#pragma unroll
-        for (int b = 0; b < N; ++b) {
-          double t = 0;
-#pragma unroll
-          for (int aa = 0; aa < N; ++aa) t += kb.Pt[pa][aa] * u[aa + N * b];
-          v[pa][b] = t;
-        }
-#pragma unroll
-      for (int pa = 0; pa < kTrap; ++pa)
-#pragma unroll
-        for (int pb = 0; pb < kTrap; ++pb) {
-          double t = 0;
-#pragma unroll
-          for (int b = 0; b < N; ++b) t += kb.Pt[pb][b] * v[pa][b];
-          W[c][pa][pb] = t;
-        }
-    }
-    double maxeig = 0.0;
-#pragma unroll
-    for (int pa = 0; pa < kTrap; ++pa)
-#pragma unroll
-      for (int pb = 0; pb < kTrap; ++pb) {
-        const double w[4] = {W[0][pa][pb], W[1][pa][pb], W[2][pa][pb], W[3][pa][pb]};
-        maxeig = fmax(maxeig, max_eigenvalue(w));
-      }
-    dtmin = cfl * cell_h[(size_t)shard * 64 + lane] / maxeig / (2.0 * degree + 1.0);
+    for (int j = 0; j < NDOF; ++j) u[j] = U[((size_t)shard * NDOF + j) * 64 + lane];
+    dtmin = dt_q_cell<N>(u, kb, cell_h[(size_t)shard * 64 + lane], cfl, degree);
     if (dt_cell) dt_cell[(size_t)shard * 64 + lane] = dtmin;
   }
   dtmin = wave_min(dtmin);
@@ -1865,6 +1882,7 @@ struct dflo_hip_engine {
   int max_fp = 0;
   // timing
   bool timing = false;
+  int dtq_parts = 0;   // last stage on bilinear cells: parts (1 rim, 2 interior) whose limiter pass also formed the time step
   // dflo_hip_advance replays a captured graph of `graph_steps` time steps (the buffer rotation repeats with
   // that period); built lazily for the state it was captured in
   hipGraphExec_t graph_exec = nullptr;
@@ -2030,6 +2048,7 @@ int open_stage(dflo_hip_engine *h, int rk, double dt_host, bool residual_only, i
     if (last) h->old = out;
     h->pending_rk = rk;
     h->pending_dt = dt_host;
+    h->dtq_parts = 0;
     // stage timing samples every fifth stage (5 is coprime to the 2 or 3 stages of a step, so every stage of the
     // step is sampled equally often): two event records per launch are not free
     h->t_sample = h->timing && (h->t_seen++ % 5 == 0);
@@ -2208,8 +2227,14 @@ int launch_limiter(dflo_hip_engine *h, int tvb, int pos, int part) {
   l.pos_lim = pos;
   l.kb = h->kb;
   l.shock = tvb ? h->d_shock : nullptr;
+  l.dtq = (h->geo == 1 && h->basis == DFLO_BASIS_QK && h->pending_rk == h->n_rk - 1) ? 1 : 0;
+  l.shard_dtmin = h->shard_dtmin;
+  l.dt_cell = h->d_dt_cell;
+  l.cfl = h->prm.cfl;
+  l.degree = h->degree;
   l.shard_list = part == 1 ? h->d_rim_list : (part == 2 ? h->d_int_list : nullptr);
   l.n_list = part == 1 ? (int)p.rim_shards.size() : (part == 2 ? (int)p.interior_shards.size() : p.n_shards);
+  if (l.dtq) h->dtq_parts |= part == 0 ? 3 : part;
   if (l.n_list == 0) return DFLO_OK;
   void (*lf)(const LimArgs) = h->N == 2 ? limiter_kernel<2> : (h->N == 3 ? limiter_kernel<3> : limiter_kernel<4>);
   if (h->basis == DFLO_BASIS_PK) lf = h->N == 2 ? limiter_pk_kernel<2> : (h->N == 3 ? limiter_pk_kernel<3> : limiter_pk_kernel<4>);
@@ -2242,9 +2267,11 @@ int launch_finish(dflo_hip_engine *h) {
   const int rk = h->pending_rk;
   if (rk < 0) { h->err = "no stage pending"; return DFLO_ERR_BAD_PARAM; }
   const bool last = rk == h->n_rk - 1;
-  if (last && h->geo == 1) {  // bilinear cells: dt from the point values of the (limited) new solution
-    launch_dt_q(h);
-    HIPCHK(h, hipGetLastError());
+  if (last && h->geo == 1) {  // bilinear cells: dt from the point values of the (limited) new solution,
+    if (h->dtq_parts != 3) {   // unless the limiter pass of this stage has formed it on the way
+      launch_dt_q(h);
+      HIPCHK(h, hipGetLastError());
+    }
   } else if (last && h->d_dt_cell) {  // local time stepping: the per-cell dt of the next step
     hipLaunchKernelGGL(dt_kernel, dim3(p.n_shards), dim3(64), 0, h->stream, h->avg[h->avg_cur], h->d_cell_h, p.h,
                        p.uniform_h ? 1 : 0, h->d_shard_count, h->shard_dtmin, h->prm.cfl, h->degree, h->d_dt_cell);
