@@ -18,6 +18,10 @@
 //     on the steady isentropic vortex src/ic.cc:44-61, free-stream preservation,
 //     conservation).
 //
+// The last section ("optimised CPU twin") is a second CPU implementation of the same stage, fused and threaded the
+// way a CPU wants it; it is checked against the restatement by tests/test_oracle_assembly.py and timed by bench.py
+// as cpu_baseline.optimised_twin.  It is not the parity checker.
+//
 // deal.II conventions relied upon (third party, cannot be cited in the reference
 // tree): QGauss on [0,1] ascending; tensor points x fastest; FESystem of one DG base
 // element x4 is component-major; faces 0:x=0 1:x=1 2:y=0 3:y=1; MeshWorker::loop
@@ -1380,6 +1384,185 @@ int stage(Oracle &o, int rk, double *res_norm) {
   return DFLO_OK;
 }
 
+
+// ==========================================================================
+// Optimised CPU twin ("also report the optimised CPU twin for honesty").
+// NOT the parity oracle: the same stage as stage() above for axis-aligned Qk cells without limiters, written the
+// way a CPU wants it -- collocation (W_q = U_q, sum-factorised gradients), one fused pass per stage (volume term,
+// the four face terms, M^-1, SSP combine and the new cell average, 24 B per DoF of memory traffic), no
+// temporaries on the heap, every cell owned by one thread (both cells of a face evaluate its flux, nothing is
+// scattered).  The pointwise physics is the oracle's own.  tests/test_oracle_assembly.py checks it against
+// stage(); bench.py reports it next to the reference-style figure.
+// ==========================================================================
+template <int N>
+struct Twin1D {
+  double x[N], w[N], D[N][N], L[2][N];   // D[q][m] = l_m'(x_q), L[s][m] = l_m(s)
+};
+template <int N>
+Twin1D<N> twin_tables() {
+  Twin1D<N> t;
+  const Rule g = gauss_rule(N);
+  double bw[N];
+  for (int m = 0; m < N; ++m) {
+    t.x[m] = g.x[m];
+    t.w[m] = g.w[m];
+    bw[m] = 1.0;
+    for (int j = 0; j < N; ++j)
+      if (j != m) bw[m] /= (g.x[m] - g.x[j]);
+  }
+  for (int q = 0; q < N; ++q)
+    for (int m = 0; m < N; ++m) {
+      if (q != m) t.D[q][m] = (bw[m] / bw[q]) / (g.x[q] - g.x[m]);
+      else {
+        double d = 0;
+        for (int j = 0; j < N; ++j)
+          if (j != m) d += 1.0 / (g.x[m] - g.x[j]);
+        t.D[q][m] = d;
+      }
+    }
+  for (int s = 0; s < 2; ++s)
+    for (int m = 0; m < N; ++m) {
+      double v = 1.0;
+      for (int j = 0; j < N; ++j)
+        if (j != m) v *= ((double)s - g.x[j]) / (g.x[m] - g.x[j]);
+      t.L[s][m] = v;
+    }
+  return t;
+}
+
+bool twin_supported(const Oracle &o) {
+  return o.mapping == DFLO_MAP_CARTESIAN && o.basis == DFLO_BASIS_QK && o.degree >= 1 && o.degree <= 3 &&
+         o.n_owned == o.n_cells && o.prm.limiter_type == DFLO_LIMITER_NONE && !o.prm.pos_lim;
+}
+
+// node of the line of N nodes that carries face point q of local face f, m-th along the line
+template <int N>
+inline int twin_node(int f, int m, int q) { return f < 2 ? m + N * q : q + N * m; }
+
+template <int N>
+inline void twin_trace(const double *u, const Twin1D<N> &T, int f, int q, double *W) {
+  const double *L = T.L[f & 1];
+  for (int k = 0; k < NC; ++k) {
+    double v = 0;
+    for (int m = 0; m < N; ++m) v += L[m] * u[k * N * N + twin_node<N>(f, m, q)];
+    W[k] = v;
+  }
+}
+
+template <int N>
+void twin_stage(Oracle &o, int rk, const double *src, const double *old, double *dst, double *res_norm) {
+  static const Twin1D<N> T = twin_tables<N>();
+  constexpr int NS = N * N, ND = NC * NS;
+  const double ark = o.ark[rk];
+  const int which = rk == 0 ? 0 : 1, flux_type = o.prm.flux_type;
+  const double gravity = o.prm.gravity;
+  const double *avg = o.avg.data();
+  double *avg2 = o.rhs.data();   // rhs is free here: its first n_cells*4 entries take the new averages
+  double res = 0;
+#pragma omp parallel for schedule(static) reduction(+ : res) num_threads(o.nthreads) if (o.nthreads > 1)
+  for (int c = 0; c < o.n_cells; ++c) {
+    const double *u = src + (size_t)c * ND;
+    const double h = o.V(c, 1)[0] - o.V(c, 0)[0];
+    double R[NC][NS];
+    for (int k = 0; k < NC; ++k)
+      for (int j = 0; j < NS; ++j) R[k][j] = 0.0;
+    // volume term: grad phi_(m,b) at node (a,b) is D[a][m]/h e_x, grad phi_(a,m) at (a,b) is D[b][m]/h e_y, JxW = w_a w_b h^2
+    for (int b = 0; b < N; ++b)
+      for (int a = 0; a < N; ++a) {
+        double W[NC], F[NC][2];
+        for (int k = 0; k < NC; ++k) W[k] = u[k * NS + a + N * b];
+        flux_matrix(W, F);
+        const double wh = T.w[a] * T.w[b] * h;
+        for (int k = 0; k < NC; ++k) {
+          const double fx = F[k][0] * wh, gy = F[k][1] * wh;
+          for (int m = 0; m < N; ++m) {
+            R[k][m + N * b] += fx * T.D[a][m];
+            R[k][a + N * m] += gy * T.D[b][m];
+          }
+        }
+        if (gravity != 0.0) {
+          double S[NC];
+          forcing_vector(W, S);
+          for (int k = 0; k < NC; ++k) R[k][a + N * b] += gravity * S[k] * wh * h;
+        }
+      }
+    // face terms
+    for (int f = 0; f < 4; ++f) {
+      const int nb = o.nbr[c * 4 + f];
+      if (nb == DFLO_NBR_NONE) continue;
+      const double n[2] = {f == 0 ? -1.0 : (f == 1 ? 1.0 : 0.0), f == 2 ? -1.0 : (f == 3 ? 1.0 : 0.0)};
+      const double *L = T.L[f & 1];
+      for (int q = 0; q < N; ++q) {
+        double Wp[NC], Wm[NC], F[NC];
+        twin_trace<N>(u, T, f, q, Wp);
+        double sgn = -1.0;
+        if (nb >= 0) {
+          const int code = o.nbrf[c * 4 + f], nf = code & 3;
+          const bool periodic = (code & 8) != 0, flip = (code & 4) != 0;
+          twin_trace<N>(src + (size_t)nb * ND, T, nf, flip ? N - 1 - q : q, Wm);
+          if (periodic || gid_of(o, c) < gid_of(o, nb)) {
+            numerical_normal_flux(flux_type, n, Wp, Wm, avg + (size_t)c * NC, avg + (size_t)nb * NC, F);
+          } else {  // the face is integrated from the other cell (smaller index): its normal, its order of the states
+            const double nn[2] = {-n[0], -n[1]};
+            numerical_normal_flux(flux_type, nn, Wm, Wp, avg + (size_t)nb * NC, avg + (size_t)c * NC, F);
+            sgn = 1.0;
+          }
+        } else {
+          const int bf = o.bface_of[c * 4 + f];
+          compute_Wminus(o.prm.bc_kind[o.bfaces[bf].id], n, Wp, &o.bval[which][((size_t)bf * N + q) * NC], Wm);
+          numerical_normal_flux(flux_type, n, Wp, Wm, avg + (size_t)c * NC, avg + (size_t)c * NC, F);
+        }
+        const double jxw = sgn * T.w[q] * h;
+        for (int k = 0; k < NC; ++k) {
+          const double fq = F[k] * jxw;
+          for (int m = 0; m < N; ++m) R[k][twin_node<N>(f, m, q)] += fq * L[m];
+        }
+      }
+    }
+    // M^-1, SSP combine (src/claw.cc:708-710, 757-760), new cell average (:562-597)
+    const double dt = o.dtc[c], ih2 = 1.0 / (h * h);
+    double *v = dst + (size_t)c * ND;
+    const double *uo = old + (size_t)c * ND;
+    for (int k = 0; k < NC; ++k) {
+      double a = 0;
+      for (int b = 0; b < N; ++b)
+        for (int aa = 0; aa < N; ++aa) {
+          const int j = aa + N * b;
+          const double ww = T.w[aa] * T.w[b], r = R[k][j];
+          res += r * r;
+          double un = u[k * NS + j] + dt * r * (ih2 / ww);
+          un = (1.0 - ark) * un + ark * uo[k * NS + j];
+          v[k * NS + j] = un;
+          a += ww * un;
+        }
+      avg2[(size_t)c * NC + k] = a;
+    }
+  }
+  std::copy(avg2, avg2 + (size_t)o.n_cells * NC, o.avg.begin());
+  if (res_norm) *res_norm = std::sqrt(res);
+}
+
+double twin_time_step(Oracle &o) {   // compute_time_step_cartesian (src/claw.cc:476-513), threaded
+  double dtmin = 1.0e20;
+#pragma omp parallel for schedule(static) reduction(min : dtmin) num_threads(o.nthreads) if (o.nthreads > 1)
+  for (int c = 0; c < o.n_cells; ++c) {
+    const double h = o.V(c, 1)[0] - o.V(c, 0)[0];
+    const double *A = &o.avg[(size_t)c * NC];
+    const double sonic = sound_speed(A);
+    double maxeig = 0.0;
+    for (int d = 0; d < 2; ++d) maxeig += (sonic + std::fabs(A[d] / A[DENS])) / h;
+    const double dt = o.prm.cfl / maxeig / (2.0 * o.degree + 1.0);
+    o.dtc[c] = dt;
+    dtmin = std::min(dtmin, dt);
+  }
+  if (o.prm.global_time_step) {
+    if (o.prm.time_step > 0) dtmin = std::min(dtmin, o.prm.time_step);
+    std::fill(o.dtc.begin(), o.dtc.end(), dtmin);
+  }
+  o.global_dt = dtmin;
+  return dtmin;
+}
+
 }  // namespace
 
 // ==========================================================================
@@ -1535,6 +1718,33 @@ int dflo_oracle_step(void *h, double dt, double *res_norm0, double *res_norm) {
   }
   if (res_norm) *res_norm = r;
   o.old = o.cur;
+  return DFLO_OK;
+}
+
+// ---- the optimised CPU twin (bench.py's second CPU figure; see the section above)
+int dflo_oracle_twin_supported(void *h) { return twin_supported(*(Oracle *)h) ? 1 : 0; }
+// n_steps time steps: dt < 0 -> the CFL step from the cell averages each step; the three state vectors rotate, no
+// copy of the state inside the loop (old_solution = current_solution becomes a pointer swap)
+int dflo_oracle_twin_advance(void *h, int n_steps, double dt, double *elapsed, double *res_norm) {
+  Oracle &o = *(Oracle *)h;
+  if (!twin_supported(o)) return DFLO_ERR_BAD_PARAM;
+  double *A = o.old.data(), *B = o.cur.data(), *C = o.upd.data();   // A holds u^n
+  for (int step = 0; step < n_steps; ++step) {
+    if (dt >= 0) dflo_oracle_set_dt(h, dt);
+    else twin_time_step(o);
+    if (elapsed) *elapsed += o.global_dt;
+    for (int rk = 0; rk < o.n_rk; ++rk) {
+      const double *src = rk == 0 ? A : B;
+      if (o.N == 2) twin_stage<2>(o, rk, src, A, C, res_norm);
+      else if (o.N == 3) twin_stage<3>(o, rk, src, A, C, res_norm);
+      else twin_stage<4>(o, rk, src, A, C, res_norm);
+      std::swap(B, C);   // B: newest stage
+    }
+    std::swap(A, B);     // u^(n+1)
+  }
+  const size_t n = o.cur.size();
+  if (A != o.cur.data()) std::copy(A, A + n, o.cur.begin());
+  if (A != o.old.data()) std::copy(A, A + n, o.old.begin());
   return DFLO_OK;
 }
 

@@ -48,6 +48,8 @@ for name, res, args in [
     ("dflo_oracle_stage", C.c_int, [C.c_void_p, C.c_int, _dp]),
     ("dflo_oracle_end_step", None, [C.c_void_p]),
     ("dflo_oracle_step", C.c_int, [C.c_void_p, C.c_double, _dp, _dp]),
+    ("dflo_oracle_twin_supported", C.c_int, [C.c_void_p]),
+    ("dflo_oracle_twin_advance", C.c_int, [C.c_void_p, C.c_int, C.c_double, _dp, _dp]),
     ("dflo_oracle_numerical_flux", None, [C.c_int, _dp, _dp, _dp, _dp, _dp, _dp]),
     ("dflo_oracle_normal_flux", None, [_dp, _dp, _dp]),
     ("dflo_oracle_flux_matrix", None, [_dp, _dp]),
@@ -201,6 +203,19 @@ class Oracle:
         if rc:
             raise OracleError(rc, _lib.dflo_oracle_message(self._h).decode())
         return r0.value, r1.value
+
+    # ---- the optimised CPU twin (not the parity oracle; see oracle/dflo_oracle.cc)
+    @property
+    def twin_supported(self):
+        return bool(_lib.dflo_oracle_twin_supported(self._h))
+
+    def twin_advance(self, n_steps, dt=-1.0):
+        """n_steps fused steps; dt < 0: CFL step from the cell averages.  Returns (elapsed time, last residual norm)."""
+        t, r = C.c_double(0.0), C.c_double(0.0)
+        rc = _lib.dflo_oracle_twin_advance(self._h, n_steps, dt, C.byref(t), C.byref(r))
+        if rc:
+            raise OracleError(rc, "the optimised twin covers axis-aligned Qk cells without limiters only")
+        return t.value, r.value
 
 
 # ---- pointwise functions

@@ -285,3 +285,40 @@ def test_kxrcf_indicator_gates_the_tvb_limiter():
     assert 0 < flagged.sum() < mesh.n_cells // 4
     assert (changed_kx == (changed_all & flagged)).all()
     assert changed_kx.sum() > 0
+
+
+@pytest.mark.parametrize("degree,flux,bnd", [(1, "lxf", False), (2, "hllc", False), (3, "kfvs", False), (2, "roe", True),
+                                             (1, "sw", True), (2, "lxf", True)])
+def test_optimised_cpu_twin_equals_the_restatement(degree, flux, bnd):
+    """bench.py's second CPU figure (the fused, fully threaded twin at the end of oracle/dflo_oracle.cc) advances the
+    same states as the reference-style restatement: 5 steps with the CFL step, periodic and with every boundary kind."""
+    if bnd:
+        mesh = dflo_amd.Mesh.cartesian(14, 10, -5.0, -5.0, 10.0 / 14, [0, 1, 2, 3], degree)
+        prm = dflo_amd.Parameters(flux=flux, cfl=0.9, boundary={0: "farfield", 1: "outflow", 2: "slip", 3: "pressure"})
+    else:
+        mesh = dflo_amd.Mesh.cartesian(14, 10, -5.0, -5.0, 10.0 / 14, [-1] * 4, degree)
+        prm = dflo_amd.Parameters(flux=flux, cfl=0.9)
+    a, b = O.Oracle(mesh, prm, threads=2), O.Oracle(mesh, prm, threads=3)
+    assert b.twin_supported
+    u0 = mesh.interpolate(problems.isentropic_vortex)
+    for o in (a, b):
+        o.set_solution(u0)
+        if bnd:
+            cell, face, bid, xy = o.boundary_faces()
+            bv = np.stack(problems.isentropic_vortex(xy[..., 0], xy[..., 1]), axis=-1)
+            o.set_boundary_values(0, bv)
+            o.set_boundary_values(1, bv)
+    t = 0.0
+    for _ in range(5):
+        dt = a.compute_time_step(t)
+        r = a.step(dt)
+        t += dt
+    t2, r2 = b.twin_advance(5)
+    assert abs(t - t2) <= 1e-14 * t and abs(r[1] - r2) <= 1e-12 * r[1]
+    assert np.abs(a.get_solution() - b.get_solution()).max() <= 1e-12
+    assert np.abs(a.get_cell_average() - b.get_cell_average()).max() <= 1e-12
+    # and it says no where it does not apply (limiters, bilinear cells)
+    c = O.Oracle(mesh, dflo_amd.Parameters(flux=flux, pos_lim=True), threads=1)
+    assert not c.twin_supported
+    with pytest.raises(O.OracleError):
+        c.twin_advance(1)
