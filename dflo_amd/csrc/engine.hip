@@ -41,6 +41,7 @@ struct KBasis {       // 1-D tables, see basis.h
   double Pt[kTrap][kMaxN];
   double PLg[kMaxGLL][kMaxN];  // Pk: orthonormal Legendre Pt_n at the Gauss-Lobatto points
   double PLx[kMaxN][kMaxN];    // Pk: Pt_n at the Gauss points
+  double pg_neg;               // max over the Gauss-Lobatto points of the sum of the negative weights in Pg
   int Ng;
 };
 
@@ -79,6 +80,7 @@ struct StageArgs {
   int n_shards, max_fp, max_faces, max_bnd, uniform_h, want_dt, degree, prefetch_ahead;
   const int32_t *shard_list;  // null: all shards; else the n_list shards of this launch (rim / interior)
   int n_list;
+  int *flags;   // POS: [0] negative mean state, [1] positivity root failure (as LimArgs::flags)
   KBasis kb;
 };
 
@@ -137,6 +139,57 @@ __device__ __forceinline__ int shard_of_block(int b, int n_shards) {
   return (b >> 3) < chunk && s < n_shards ? s : -1;
 }
 
+// ------------------------------------------------------------------ positivity limiter, pointwise parts
+// (shared by limiter_kernel and the stage kernels that apply the limiter on the way out, so that both round alike)
+__device__ __forceinline__ double positivity_blend(double theta, double u, double avg) {   // src/positivity.cc:84-87, 196-199
+  return fma(theta, u, (1.0 - theta) * avg);
+}
+// theta of one point W with pressure below eps: root of the pressure along the segment mean -> W (src/positivity.cc:138-178);
+// 1 if the pressure is fine there
+__device__ __forceinline__ double positivity_theta2(const double (&W)[4], const double (&A)[4], double eps, bool &fail) {
+  const double pre = kG1 * (W[EN] - 0.5 * (W[MX] * W[MX] + W[MY] * W[MY]) * frcp(W[RHO]));
+  if (!(pre < eps)) return 1.0;
+  const double drho = W[RHO] - A[RHO], dmx = W[MX] - A[MX], dmy = W[MY] - A[MY], dE = W[EN] - A[EN];
+  const double a1 = 2.0 * drho * dE - (dmx * dmx + dmy * dmy);
+  double b1 = 2.0 * drho * (A[EN] - eps / kG1) + 2.0 * A[RHO] * dE - 2.0 * (A[MX] * dmx + A[MY] * dmy);
+  double c1 = 2.0 * A[RHO] * A[EN] - (A[MX] * A[MX] + A[MY] * A[MY]) - 2.0 * eps * A[RHO] / kG1;
+  b1 /= a1;
+  c1 /= a1;
+  const double D = sqrt(fabs(b1 * b1 - 4.0 * c1));
+  const double t1 = 0.5 * (-b1 - D), t2 = 0.5 * (-b1 + D);
+  double t;
+  if (t1 > -1.0e-12 && t1 < 1.0 + 1.0e-12) t = t1;
+  else if (t2 > -1.0e-12 && t2 < 1.0 + 1.0e-12) t = t2;
+  else { fail = true; t = 0.0; }
+  t = smin(1.0, t);
+  t = smax(0.0, t);
+  if (fabs(1.0 - t) < 1.0e-14) t = 0.0;
+  return t;
+}
+
+// Row b of every cell (wave b) leaves the extremes of its new values in LDS, pb[(2 c + {0: min, 1: max}) N + b][64]; a NaN or
+// Inf anywhere in the row turns the density minimum into a NaN.
+template <int N, int B>
+__device__ __forceinline__ void positivity_row_bounds(double *pb, int lane, const double (&unew)[4][N]) {
+  double chk = 0.0, lo_[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    double lo = unew[c][0], hi = unew[c][0];
+    chk += unew[c][0];
+#pragma unroll
+    for (int m = 1; m < N; ++m) {
+      lo = fmin(lo, unew[c][m]);
+      hi = fmax(hi, unew[c][m]);
+      chk += unew[c][m];
+    }
+    lo_[c] = lo;
+    pb[((2 * c + 1) * N + B) * 64 + lane] = hi;
+  }
+  lo_[RHO] += chk - chk;   // 0, or NaN if anything in the row is not finite
+#pragma unroll
+  for (int c = 0; c < 4; ++c) pb[((2 * c) * N + B) * 64 + lane] = lo_[c];
+}
+
 // ------------------------------------------------------------------ the stage kernel
 // One workgroup of N wavefronts per shard: lane = cell, wavefront = node row b of the (k+1)^2
 // collocation nodes, so control flow is wave-uniform and every global access is a coalesced
@@ -145,11 +198,11 @@ __device__ __forceinline__ int shard_of_block(int b, int n_shards) {
 // fluxes at the shard's face points, the packed face records and the shard's boundary data.
 
 // phase C for node row B of every cell of the shard (lane = cell)
-template <int N, int B, int MODE>
+template <int N, int B, int MODE, bool POS>
 __device__ __forceinline__ void row_update(const StageArgs &a, double *Us, const int S, const double *Fh,
                                            double *red, int shard, int lane, bool active, double h,
                                            const uint16_t (&cref)[4], const double (&uold)[4][N],
-                                           const double (&Wrow)[N][4]) {
+                                           const double (&Wrow)[N][4], double (&unew)[4][N]) {
   constexpr int NS = N * N;
   double R[4][N];
 #pragma unroll
@@ -248,15 +301,22 @@ __device__ __forceinline__ void row_update(const StageArgs &a, double *Us, const
           u += dt * R[c][m] * invM;
           if constexpr (MODE == 1) u = (1.0 - a.ark) * u + a.ark * uold[c][m];
           np[d * 64] = u;
+          if constexpr (POS) unew[c][m] = u;   // kept for the positivity step of the caller (which stores again if it scales)
           part[c] += ww * u;
         }
     }
+  } else if constexpr (POS) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int m = 0; m < N; ++m) unew[c][m] = Wrow[m][c];
   }
   // partial cell averages / residual of this row -> LDS (red aliases Fh, see the caller's barriers)
   if constexpr (MODE != 2) {
-    __syncthreads();  // every wave is done reading Fh
+    __syncthreads();  // every wave is done reading Fh (and the G rows of Us)
 #pragma unroll
     for (int c = 0; c < 5; ++c) red[(B * 5 + c) * 64 + lane] = part[c];
+    if constexpr (POS) positivity_row_bounds<N, B>(Us, lane, unew);   // the LDS image is free now
   }
 }
 
@@ -264,52 +324,59 @@ __device__ __forceinline__ void row_update(const StageArgs &a, double *Us, const
 // FEValues with MappingQ1): J = [x_xi x_eta; y_xi y_eta] varies inside the cell,
 //   int F.grad(phi) = sum_q w_q [ d(phi)/d(xi) (y_eta F - x_eta G) + d(phi)/d(eta) (-y_xi F + x_xi G) ],
 // lumped mass M_j = w_j det J_j (src/claw.cc:223-227), face JxW = w_q |edge|.
-template <int N, int B, int MODE>
-__device__ __forceinline__ void row_update_q1(const StageArgs &a, const double *Us, const int S, const double *Fh,
+template <int N, int B, int MODE, bool POS>
+__device__ __forceinline__ void row_update_q1(const StageArgs &a, double *Us, const int S, const double *Fh,
                                               const double *Fg, double *red, int shard, int lane, bool active,
                                               const double (&vx)[8], const uint16_t (&cref)[4],
-                                              const double (&uold)[4][N]) {
+                                              const double (&uold)[4][N], const double (&Wrow)[N][4], double (&unew)[4][N]) {
   constexpr int NS = N * N;
   double R[4][N];
 #pragma unroll
   for (int c = 0; c < 4; ++c)
 #pragma unroll
     for (int m = 0; m < N; ++m) R[c][m] = 0.0;
-  double Wrow[N][4];
   // metric terms of the bilinear map: x_xi depends on eta only, x_eta on xi only
   const double ax = vx[2] - vx[0], bx = (vx[6] - vx[4]) - ax;   // x_xi(eta) = ax + eta bx
   const double ay = vx[3] - vx[1], by = (vx[7] - vx[5]) - ay;
   const double cx = vx[4] - vx[0], dx = (vx[6] - vx[2]) - cx;   // x_eta(xi) = cx + xi dx
   const double cy = vx[5] - vx[1], dy = (vx[7] - vx[3]) - cy;
+  // Like row_update: every wave evaluates the fluxes once, at the nodes of its own row (values still in registers),
+  // lifts the xi part itself and leaves the eta part, (x_xi G - y_xi F) w w, in its rows of the LDS image; after one
+  // barrier each wave reads the eta parts of the other rows instead of evaluating the fluxes there again.
+  double Hown[N][4];
+  {
+    const double xxi = ax + CB<N>::t.x[B] * bx, yxi = ay + CB<N>::t.x[B] * by;
 #pragma unroll
-  for (int aa = 0; aa < N; ++aa) {
-    const double xeta = cx + CB<N>::t.x[aa] * dx, yeta = cy + CB<N>::t.x[aa] * dy;
+    for (int aa = 0; aa < N; ++aa) {
+      const double xeta = cx + CB<N>::t.x[aa] * dx, yeta = cy + CB<N>::t.x[aa] * dy;
+      double Fx[4], Gy[4];
+      flux_xy(Wrow[aa], Fx, Gy);
+      const double wq = CB<N>::t.w[aa] * CB<N>::t.w[B];
 #pragma unroll
-    for (int q = 0; q < N; ++q) {
-      const double xxi = ax + CB<N>::t.x[q] * bx, yxi = ay + CB<N>::t.x[q] * by;
-      double W[4], Fx[4], Gy[4];
+      for (int c = 0; c < 4; ++c) {
+        const double f1 = (yeta * Fx[c] - xeta * Gy[c]) * wq;
 #pragma unroll
-      for (int c = 0; c < 4; ++c) W[c] = Us[(c * NS + aa + N * q) * S + lane];
-      flux_xy(W, Fx, Gy);
-      const double wq = CB<N>::t.w[aa] * CB<N>::t.w[q];
-#pragma unroll
-      for (int c = 0; c < 4; ++c) R[c][aa] += (xxi * Gy[c] - yxi * Fx[c]) * (wq * CB<N>::t.D[q][B]);
-      if (q == B) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          Wrow[aa][c] = W[c];
-          const double f1 = (yeta * Fx[c] - xeta * Gy[c]) * wq;
-#pragma unroll
-          for (int m = 0; m < N; ++m) R[c][m] += f1 * CB<N>::t.D[aa][m];
-        }
-        if (a.gravity != 0.0) {
-          const double jxw = wq * (xxi * yeta - xeta * yxi);
-          R[MY][aa] += a.gravity * (-1.0 * W[RHO]) * jxw;
-          R[EN][aa] += a.gravity * (-1.0 * W[MY]) * jxw;
-        }
+        for (int m = 0; m < N; ++m) R[c][m] += f1 * CB<N>::t.D[aa][m];
+        Hown[aa][c] = (xxi * Gy[c] - yxi * Fx[c]) * wq;
+        Us[(c * NS + aa + N * B) * S + lane] = Hown[aa][c];
+      }
+      if (a.gravity != 0.0) {
+        const double jxw = wq * (xxi * yeta - xeta * yxi);
+        R[MY][aa] += a.gravity * (-1.0 * Wrow[aa][RHO]) * jxw;
+        R[EN][aa] += a.gravity * (-1.0 * Wrow[aa][MY]) * jxw;
       }
     }
   }
+  __syncthreads();
+#pragma unroll
+  for (int aa = 0; aa < N; ++aa)
+#pragma unroll
+    for (int q = 0; q < N; ++q)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const double hy = q == B ? Hown[aa][c] : Us[(c * NS + aa + N * q) * S + lane];
+        R[c][aa] += hy * CB<N>::t.D[q][B];
+      }
   if (active) {
 #pragma unroll
     for (int f = 0; f < 4; ++f) {
@@ -365,15 +432,22 @@ __device__ __forceinline__ void row_update_q1(const StageArgs &a, const double *
           u += dt * R[c][m] * invM;
           if constexpr (MODE == 1) u = (1.0 - a.ark) * u + a.ark * uold[c][m];
           np[d * 64] = u;
+          if constexpr (POS) unew[c][m] = u;
           part[c] += wd * u;
         }
       }
     }
+  } else if constexpr (POS) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int m = 0; m < N; ++m) unew[c][m] = Wrow[m][c];
   }
   if constexpr (MODE != 2) {
-    __syncthreads();  // every wave is done reading Fh
+    __syncthreads();  // every wave is done reading Fh and Us
 #pragma unroll
     for (int c = 0; c < 5; ++c) red[(B * 5 + c) * 64 + lane] = part[c];
+    if constexpr (POS) positivity_row_bounds<N, B>(Us, lane, unew);
   }
 }
 
@@ -475,7 +549,8 @@ __device__ __forceinline__ void flux_phase(const StageArgs &a, const double *Us,
 // anything waits.
 //   MODE 0: first stage (ark = 0, u(n) not read)   1: later stages   2: residual only (parity hook)
 //   GEO 0: axis-aligned squares (MappingCartesian)   1: bilinear cells (MappingQ1)
-template <int N, int FLUX, int MODE, int GEO>
+//   POS: apply_positivity_limiter (src/positivity.cc:17-208) on the way out, for runs without the TVB limiter
+template <int N, int FLUX, int MODE, int GEO, bool POS>
 __global__ __launch_bounds__(64 * N, ((GEO == 1 && N != 3) || N == 4) ? 2 : 3) void stage_kernel(const StageArgs a) {
   constexpr int NS = N * N, NDOF = 4 * NS, NT = 64 * N;
   constexpr int ROWS = NDOF + (FLUX == DFLO_FLUX_LXF ? 3 : 0);   // LxF: (u, v, c) of the cell average ride along
@@ -660,14 +735,15 @@ __global__ __launch_bounds__(64 * N, ((GEO == 1 && N != 3) || N == 4) ? 2 : 3) v
   // ---- phase C: volume + lifting + RK update of node row `row`
   double *red = Fh;  // reused after the barrier inside row_update
   double wrow[N][4];
+  double unew[4][N];   // POS: the updated row, held back until the positivity step below
 #pragma unroll
   for (int m = 0; m < N; ++m)
 #pragma unroll
     for (int c = 0; c < 4; ++c) wrow[m][c] = urow[c][m];
 #define DFLO_ROW(Bq)                                                                                     \
   do {                                                                                                   \
-    if constexpr (GEO == 0) row_update<N, Bq, MODE>(a, Us, S, Fh, red, shard, lane, active, h, cref, uold, wrow); \
-    else row_update_q1<N, Bq, MODE>(a, Us, S, Fh, Fg, red, shard, lane, active, vx, cref, uold);           \
+    if constexpr (GEO == 0) row_update<N, Bq, MODE, POS>(a, Us, S, Fh, red, shard, lane, active, h, cref, uold, wrow, unew); \
+    else row_update_q1<N, Bq, MODE, POS>(a, Us, S, Fh, Fg, red, shard, lane, active, vx, cref, uold, wrow, unew);     \
   } while (0)
   if constexpr (N == 2) {
     if (row == 0) DFLO_ROW(0); else DFLO_ROW(1);
@@ -681,6 +757,140 @@ __global__ __launch_bounds__(64 * N, ((GEO == 1 && N != 3) || N == 4) ? 2 : 3) v
   if constexpr (MODE == 2) return;
   __syncthreads();
   PHASE_MARK(6);
+  if constexpr (POS && MODE != 2) {
+    // ---- apply_positivity_limiter (src/positivity.cc:17-208) on the new state.
+    //      First a bound that settles almost every cell: the limiter looks at the solution on lines through the Gauss nodes
+    //      (Gauss-Lobatto points on them), and a point value on such a line lies within [lo - d s, hi + d s] of the cell's
+    //      nodal extremes (d = hi - lo, s = sum of the negative interpolation weights).  If the lowest density and the lowest
+    //      pressure possible in that box are safely positive, theta1 = theta2 = 1 and the mean is admissible (the pressure
+    //      is concave): nothing to do.  Only wavefronts with a cell that fails the bound run the limiter proper.
+    constexpr int NS2 = N * N;
+    bool settled;
+    {
+      double lo[4], hi[4];
+      bool fin = true;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        lo[c] = Us[((2 * c) * N) * 64 + lane];
+        hi[c] = Us[((2 * c + 1) * N) * 64 + lane];
+        if (c == RHO) fin = fin && lo[c] == lo[c];
+#pragma unroll
+        for (int b = 1; b < N; ++b) {
+          const double l = Us[((2 * c) * N + b) * 64 + lane];
+          if (c == RHO) fin = fin && l == l;
+          lo[c] = fmin(lo[c], l);
+          hi[c] = fmax(hi[c], Us[((2 * c + 1) * N + b) * 64 + lane]);
+        }
+      }
+      const double sn = a.kb.pg_neg;
+      const double rho_lo = lo[RHO] - (hi[RHO] - lo[RHO]) * sn, e_lo = lo[EN] - (hi[EN] - lo[EN]) * sn;
+      const double dmx = (hi[MX] - lo[MX]) * sn, dmy = (hi[MY] - lo[MY]) * sn;
+      const double mxa = fmax(fabs(lo[MX] - dmx), fabs(hi[MX] + dmx)), mya = fmax(fabs(lo[MY] - dmy), fabs(hi[MY] + dmy));
+      const double p_lo = kG1 * (e_lo - 0.5 * (mxa * mxa + mya * mya) * frcp(rho_lo));
+      const bool ok = fin && rho_lo >= 1.0e-10 + 1.0e-8 * hi[RHO] && p_lo >= 1.0e-10 + 1.0e-8 * fabs(hi[EN]);
+      settled = __all(ok || !active);   // the same in every wave of the workgroup: all of them see the same numbers
+    }
+    if (!settled) {
+    // the limiter proper, the same arithmetic as limiter_kernel: wave b holds row b of every cell in registers and reads
+    // column b from the LDS image, so it sees the points (GLL g, Gauss b) and (Gauss b, GLL g); the minima of the rows are
+    // combined through LDS.  theta1, theta2 come out identical in every wave, which keeps the barriers uniform.
+    __syncthreads();   // every wave has read the bounds
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int m = 0; m < N; ++m) Us[(c * NS2 + m + N * row) * S + lane] = unew[c][m];
+    __syncthreads();
+    double A[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      double v = 0;
+#pragma unroll
+      for (int b = 0; b < N; ++b) v += red[(b * 5 + c) * 64 + lane];
+      A[c] = v;
+    }
+    if constexpr (GEO == 1) {
+      const double area = 0.5 * fabs((vx[0] * vx[3] - vx[2] * vx[1]) + (vx[2] * vx[7] - vx[6] * vx[3]) +
+                                     (vx[6] * vx[5] - vx[4] * vx[7]) + (vx[4] * vx[1] - vx[0] * vx[5]));
+      const double ia = 1.0 / area;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) A[c] *= ia;
+    }
+    const double eps = 1.0e-13;
+    const bool bad = smin(A[RHO], pressure(A)) < eps;   // "Fatal: Negative states" :26-38
+    if (bad && active && row == 0) atomicOr(&a.flags[0], 1);
+    double *pm = red + 5 * N * 64;   // [3][N][64] minima of the rows: density, theta2 (speculative), theta2 (after theta1)
+    // theta2 of this wave's points (:138-178) for the current unew / Us
+    auto pressure_theta = [&](bool &fail) {
+      double th = 1.0;
+      for (int g = 0; g < a.kb.Ng; ++g)
+#pragma unroll
+        for (int dir = 0; dir < 2; ++dir) {
+          double W[4];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            double v = 0;
+#pragma unroll
+            for (int m = 0; m < N; ++m) v += a.kb.Pg[g][m] * (dir == 0 ? unew[c][m] : Us[(c * NS2 + row + N * m) * S + lane]);
+            W[c] = v;
+          }
+          th = smin(th, positivity_theta2(W, A, eps, fail));
+        }
+      return th;
+    };
+    // first round: the density minimum and, on the guess theta1 = 1 (true almost everywhere), theta2 as well
+    bool fail = false;
+    {
+      double rmin = 1.0e20;
+      for (int g = 0; g < a.kb.Ng; ++g) {
+        double px = 0, py = 0;
+#pragma unroll
+        for (int m = 0; m < N; ++m) {
+          px += a.kb.Pg[g][m] * unew[RHO][m];
+          py += a.kb.Pg[g][m] * Us[(RHO * NS2 + row + N * m) * S + lane];
+        }
+        rmin = smin(smin(rmin, px), py);
+      }
+      pm[row * 64 + lane] = rmin;
+      pm[(N + row) * 64 + lane] = pressure_theta(fail);
+    }
+    __syncthreads();
+    double rho_min = 1.0e20, theta2 = 1.0;
+#pragma unroll
+    for (int b = 0; b < N; ++b) {
+      rho_min = smin(rho_min, pm[b * 64 + lane]);
+      theta2 = smin(theta2, pm[(N + b) * 64 + lane]);
+    }
+    const double rat = fabs(A[RHO] - eps) * frcp(fabs(A[RHO] - rho_min) + 1.0e-13);
+    const double theta1 = smin(rat, 1.0);
+    const bool t1 = !bad && theta1 < 1.0;
+    if (__any(t1)) {   // the same lanes in every wave: the density was scaled somewhere, theta2 has to be formed again
+      if (t1) {
+#pragma unroll
+        for (int m = 0; m < N; ++m) {
+          unew[RHO][m] = positivity_blend(theta1, unew[RHO][m], A[RHO]);
+          Us[(RHO * NS2 + m + N * row) * S + lane] = unew[RHO][m];
+        }
+      }
+      __syncthreads();
+      fail = false;
+      pm[(2 * N + row) * 64 + lane] = pressure_theta(fail);
+      __syncthreads();
+      theta2 = 1.0;
+#pragma unroll
+      for (int b = 0; b < N; ++b) theta2 = smin(theta2, pm[(2 * N + b) * 64 + lane]);
+    }
+    if (bad) theta2 = 1.0;
+    else if (fail && active) atomicOr(&a.flags[1], 1);
+    if (active && (t1 || theta2 < 1.0)) {   // rare: the rows stored by the update are replaced
+      double *np = a.Unew + (size_t)shard * 4 * NS2 * 64 + lane;
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int m = 0; m < N; ++m)
+          np[(c * NS2 + m + N * row) * 64] = theta2 < 1.0 ? positivity_blend(theta2, unew[c][m], A[c]) : unew[c][m];
+    }
+    }   // !settled
+  }
   if (row == N - 1) {  // cell averages (src/claw.cc:562-597), residual norm, CFL minimum of the shard; on the
                        // last wave: wave 0 carries the extra pass over the face points
     double avg[4], res = 0.0, dtmin = 1.0e20;
@@ -891,7 +1101,7 @@ __global__ __launch_bounds__(64) void limiter_kernel(const LimArgs a) {
       const double theta1 = smin(rat, 1.0);
       if (theta1 < 1.0) {
 #pragma unroll
-        for (int j = 0; j < NS; ++j) U[RHO * NS + j] = theta1 * U[RHO * NS + j] + (1.0 - theta1) * A[RHO];
+        for (int j = 0; j < NS; ++j) U[RHO * NS + j] = positivity_blend(theta1, U[RHO * NS + j], A[RHO]);
         changed = true;
       }
       double theta2 = 1.0;
@@ -909,32 +1119,14 @@ __global__ __launch_bounds__(64) void limiter_kernel(const LimArgs a) {
               for (int m = 0; m < N; ++m) v += kb.Pg[g][m] * (dir == 0 ? U[c * NS + m + N * l] : U[c * NS + l + N * m]);
               W[c] = v;
             }
-            const double pre = kG1 * (W[EN] - 0.5 * (W[MX] * W[MX] + W[MY] * W[MY]) * frcp(W[RHO]));
-            if (pre < eps) {  // :138-178
-              const double drho = W[RHO] - A[RHO], dmx = W[MX] - A[MX], dmy = W[MY] - A[MY], dE = W[EN] - A[EN];
-              const double a1 = 2.0 * drho * dE - (dmx * dmx + dmy * dmy);
-              double b1 = 2.0 * drho * (A[EN] - eps / kG1) + 2.0 * A[RHO] * dE - 2.0 * (A[MX] * dmx + A[MY] * dmy);
-              double c1 = 2.0 * A[RHO] * A[EN] - (A[MX] * A[MX] + A[MY] * A[MY]) - 2.0 * eps * A[RHO] / kG1;
-              b1 /= a1;
-              c1 /= a1;
-              const double D = sqrt(fabs(b1 * b1 - 4.0 * c1));
-              const double t1 = 0.5 * (-b1 - D), t2 = 0.5 * (-b1 + D);
-              double t;
-              if (t1 > -1.0e-12 && t1 < 1.0 + 1.0e-12) t = t1;
-              else if (t2 > -1.0e-12 && t2 < 1.0 + 1.0e-12) t = t2;
-              else { fail = true; t = 0.0; }
-              t = smin(1.0, t);
-              t = smax(0.0, t);
-              if (fabs(1.0 - t) < 1.0e-14) t = 0.0;
-              theta2 = smin(theta2, t);
-            }
+            theta2 = smin(theta2, positivity_theta2(W, A, eps, fail));
           }
       if (fail && active) atomicOr(&a.flags[1], 1);
       if (theta2 < 1.0) {
 #pragma unroll
         for (int c = 0; c < 4; ++c)
 #pragma unroll
-          for (int j = 0; j < NS; ++j) U[c * NS + j] = theta2 * U[c * NS + j] + (1.0 - theta2) * A[c];
+          for (int j = 0; j < NS; ++j) U[c * NS + j] = positivity_blend(theta2, U[c * NS + j], A[c]);
         changed = true;
       }
     }
@@ -1882,7 +2074,8 @@ struct dflo_hip_engine {
   int max_fp = 0;
   // timing
   bool timing = false;
-  int dtq_parts = 0;   // last stage on bilinear cells: parts (1 rim, 2 interior) whose limiter pass also formed the time step
+  int dtq_parts = 0;
+  bool fuse_pos = false;   // positivity limiter without TVB on Qk: applied inside the stage kernel (DFLO_FUSE_POS=0: separate pass)   // last stage on bilinear cells: parts (1 rim, 2 interior) whose limiter pass also formed the time step
   // dflo_hip_advance replays a captured graph of `graph_steps` time steps (the buffer rotation repeats with
   // that period); built lazily for the state it was captured in
   hipGraphExec_t graph_exec = nullptr;
@@ -1934,6 +2127,12 @@ KBasis make_kbasis(const BasisTables &b) {
   for (int g = 0; g < kTrap; ++g)
     for (int j = 0; j < kMaxN; ++j) k.Pt[g][j] = b.Pt[g][j];
   k.Ng = b.Ng;
+  k.pg_neg = 0.0;
+  for (int g = 0; g < b.Ng; ++g) {
+    double sneg = 0.0;
+    for (int j = 0; j < b.N; ++j) sneg += std::max(-b.Pg[g][j], 0.0);
+    k.pg_neg = std::max(k.pg_neg, sneg);
+  }
   {
     long double g[kMaxGLL + 1];
     gauss_lobatto01(b.Ng, g);
@@ -1947,18 +2146,22 @@ KBasis make_kbasis(const BasisTables &b) {
 
 typedef void (*stage_fn)(const StageArgs);
 template <int N, int FLUX>
-stage_fn pick_stage_m(int mode, int geo) {
-  if (geo == 0) return mode == 0 ? stage_kernel<N, FLUX, 0, 0> : (mode == 1 ? stage_kernel<N, FLUX, 1, 0> : stage_kernel<N, FLUX, 2, 0>);
-  return mode == 0 ? stage_kernel<N, FLUX, 0, 1> : (mode == 1 ? stage_kernel<N, FLUX, 1, 1> : stage_kernel<N, FLUX, 2, 1>);
+stage_fn pick_stage_m(int mode, int geo, bool pos) {
+  if (pos && mode != 2) {
+    if (geo == 0) return mode == 0 ? stage_kernel<N, FLUX, 0, 0, true> : stage_kernel<N, FLUX, 1, 0, true>;
+    return mode == 0 ? stage_kernel<N, FLUX, 0, 1, true> : stage_kernel<N, FLUX, 1, 1, true>;
+  }
+  if (geo == 0) return mode == 0 ? stage_kernel<N, FLUX, 0, 0, false> : (mode == 1 ? stage_kernel<N, FLUX, 1, 0, false> : stage_kernel<N, FLUX, 2, 0, false>);
+  return mode == 0 ? stage_kernel<N, FLUX, 0, 1, false> : (mode == 1 ? stage_kernel<N, FLUX, 1, 1, false> : stage_kernel<N, FLUX, 2, 1, false>);
 }
 template <int N>
-stage_fn pick_stage_n(int flux, int mode, int geo) {
+stage_fn pick_stage_n(int flux, int mode, int geo, bool pos) {
   switch (flux) {
-    case DFLO_FLUX_LXF: return pick_stage_m<N, DFLO_FLUX_LXF>(mode, geo);
-    case DFLO_FLUX_SW: return pick_stage_m<N, DFLO_FLUX_SW>(mode, geo);
-    case DFLO_FLUX_KFVS: return pick_stage_m<N, DFLO_FLUX_KFVS>(mode, geo);
-    case DFLO_FLUX_ROE: return pick_stage_m<N, DFLO_FLUX_ROE>(mode, geo);
-    default: return pick_stage_m<N, DFLO_FLUX_HLLC>(mode, geo);
+    case DFLO_FLUX_LXF: return pick_stage_m<N, DFLO_FLUX_LXF>(mode, geo, pos);
+    case DFLO_FLUX_SW: return pick_stage_m<N, DFLO_FLUX_SW>(mode, geo, pos);
+    case DFLO_FLUX_KFVS: return pick_stage_m<N, DFLO_FLUX_KFVS>(mode, geo, pos);
+    case DFLO_FLUX_ROE: return pick_stage_m<N, DFLO_FLUX_ROE>(mode, geo, pos);
+    default: return pick_stage_m<N, DFLO_FLUX_HLLC>(mode, geo, pos);
   }
 }
 template <int N, int FLUX>
@@ -1982,11 +2185,11 @@ stage_fn pick_pk(int N, int flux, int mode) {
     default: return pick_pk_n<4>(flux, mode);
   }
 }
-stage_fn pick_stage(int N, int flux, int mode, int geo) {
+stage_fn pick_stage(int N, int flux, int mode, int geo, bool pos = false) {
   switch (N) {
-    case 2: return pick_stage_n<2>(flux, mode, geo);
-    case 3: return pick_stage_n<3>(flux, mode, geo);
-    default: return pick_stage_n<4>(flux, mode, geo);
+    case 2: return pick_stage_n<2>(flux, mode, geo, pos);
+    case 3: return pick_stage_n<3>(flux, mode, geo, pos);
+    default: return pick_stage_n<4>(flux, mode, geo, pos);
   }
 }
 
@@ -2172,7 +2375,8 @@ int launch_update(dflo_hip_engine *h, double *rhs_out, int part) {
   a.n_list = part == 1 ? (int)p.rim_shards.size() : (part == 2 ? (int)p.interior_shards.size() : p.n_shards);
   if (a.n_list == 0) return DFLO_OK;
   const int mode_ = rhs_out ? 2 : (h->ark[rk] != 0.0 ? 1 : 0);
-  stage_fn fn = h->basis == DFLO_BASIS_PK ? pick_pk(h->N, h->prm.flux_type, mode_) : pick_stage(h->N, h->prm.flux_type, mode_, h->geo);
+  a.flags = h->flags;
+  stage_fn fn = h->basis == DFLO_BASIS_PK ? pick_pk(h->N, h->prm.flux_type, mode_) : pick_stage(h->N, h->prm.flux_type, mode_, h->geo, h->fuse_pos);
   time_begin(h);
   hipLaunchKernelGGL(fn, dim3(grid_for(a.n_list)), dim3(64 * h->N), h->lds_bytes, h->stream, a);
   time_end(h);
@@ -2248,6 +2452,7 @@ int launch_stage_limiter(dflo_hip_engine *h, int part) {
   if (h->pending_rk < 0) { h->err = "no stage pending"; return DFLO_ERR_BAD_PARAM; }
   const bool limited = h->prm.limiter_type != DFLO_LIMITER_NONE || h->prm.pos_lim;
   if (!limited) return DFLO_OK;
+  if (h->fuse_pos) return DFLO_OK;   // positivity alone: the stage kernel has applied it on the way out
   if (h->prm.limiter_type == DFLO_LIMITER_TVB) {  // compute_shock_indicator(); apply_limiter();  src/claw.cc:763-764
     const int rc = launch_indicator(h, part);
     if (rc) return rc;
@@ -2498,7 +2703,11 @@ int dflo_hip_create(const dflo_mesh_t *mesh, const dflo_params_t *params, int de
   hipMemset(h->dt_dev, 0, 4 * sizeof(double));
   hipMemset(h->flags, 0, 4 * sizeof(int));
   h->halo_stride = std::max(p.max_halo, 1) | 1;  // odd stride: the trace rows fall on different LDS banks
-  h->max_fp = std::max(std::max(p.max_faces, 1) * h->N, 5 * 64 * h->N / 4 + 1);  // Fh also hosts the row partials
+  h->max_fp = std::max(std::max(p.max_faces, 1) * h->N, 8 * 64 * h->N / 4 + 1);  // Fh also hosts the row partials (5 N rows of 64) and the positivity minima (3 N)
+  {
+    const char *e = getenv("DFLO_FUSE_POS");
+    h->fuse_pos = h->prm.pos_lim && h->prm.limiter_type == DFLO_LIMITER_NONE && h->basis == DFLO_BASIS_QK && !(e && e[0] == '0');
+  }
   {
     const int rows = 4 * h->N * h->N + (h->prm.flux_type == DFLO_FLUX_LXF ? 3 : 0);  // nodal image (also for Pk)
     const int trows = 4 * h->N + (h->prm.flux_type == DFLO_FLUX_LXF ? 3 : 0);
@@ -2510,7 +2719,7 @@ int dflo_hip_create(const dflo_mesh_t *mesh, const dflo_params_t *params, int de
   if (h->lds_bytes > 160 * 1024) { h->err = "shard halo too large for LDS"; return bail(DFLO_ERR_UNSUPPORTED); }
   if (h->lds_bytes > 64 * 1024) {
     for (int mode = 0; mode < 3; ++mode) {
-      stage_fn fn = h->basis == DFLO_BASIS_PK ? pick_pk(h->N, h->prm.flux_type, mode) : pick_stage(h->N, h->prm.flux_type, mode, h->geo);
+      stage_fn fn = h->basis == DFLO_BASIS_PK ? pick_pk(h->N, h->prm.flux_type, mode) : pick_stage(h->N, h->prm.flux_type, mode, h->geo, h->fuse_pos);
       if (hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes) != hipSuccess) {
         h->err = "cannot raise dynamic LDS limit";
         return bail(DFLO_ERR_HIP);
