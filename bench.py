@@ -110,6 +110,7 @@ def main():
     ap.add_argument("--flux", default="hllc")
     ap.add_argument("--basis", default="Qk", choices=["Qk", "Pk"], help="c2 only; Pk: dflo's FE_DGP (modal) element")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-tvb", action="store_true", help="c4 only: positivity limiter alone (BASELINE config 4 as written)")
     ap.add_argument("--config", default="c2", choices=["c2", "c3", "c4", "c5"],
                     help="c2 (default, the headline): periodic vortex; c3: Sod tube 2048x256 Q1 Roe TVB+positivity; "
                          "c5: bilinear-cell mesh, Q3, KFVS, positivity (1-GPU stand-ins for BASELINE configs 3 and 5)")
@@ -164,8 +165,8 @@ def main():
         nx, ny = 501, nyc
         mesh = dflo_amd.Mesh.cartesian(nx, ny, 1.0 / 6.0 - n1 * dy, 0.0, dy, [4, 2, 1, 3], 2)
         mesh.neighbors[:n1, 2] = -1 - 0
-        prm = dflo_amd.Parameters(flux="hllc", limiter="TVB", char_lim=True, pos_lim=True, M=100.0, beta=1.0, cfl=0.9,
-                                  final_time=1e9, boundary={0: "outflow", 1: "slip", 2: "outflow", 3: "inflow", 4: "inflow"})
+        prm = dflo_amd.Parameters(flux="hllc", limiter="none" if args.no_tvb else "TVB", char_lim=True, pos_lim=True, M=100.0, beta=1.0,
+                                  cfl=0.9, final_time=1e9, boundary={0: "outflow", 1: "slip", 2: "outflow", 3: "inflow", 4: "inflow"})
         ic = bc_fn = lambda x, y: problems.double_mach(x, y)
     else:                       # c5 stand-in: fully unstructured quads (Delaunay triangles cut in three), q1 mapping, Q3 KFVS
         from dflo_amd import gmsh
@@ -270,7 +271,8 @@ def main():
                 "workload": {"c2": "isentropic_vortex, %dx%d quads per GPU (global %dx%d), %s%d, %s, periodic, SSP-RK %d stages"
                                    % (args.nx, args.nx, nx, ny, args.basis[0], args.degree, args.flux.upper(), n_rk),
                              "c3": "sod_shock_tube, 2048x256 quads, Q1, ROE, TVB(M=0,beta=2,char)+positivity, SSP-RK 2 stages",
-                             "c4": "double_mach_reflection, 501x1000 of the 4001x1000 squares (one of 8 slabs), Q2, HLLC, TVB(M=100,beta=1,char)+positivity, moving inflow on the device, SSP-RK 3 stages",
+                             "c4": "double_mach_reflection, 501x1000 of the 4001x1000 squares (one of 8 slabs), Q2, HLLC, %spositivity, moving inflow on the device, SSP-RK 3 stages"
+                                   % ("" if args.no_tvb else "TVB(M=100,beta=1,char)+"),
                              "c5": "free stream + bump on %d unstructured quads (q1 mapping), Q3, KFVS, positivity, SSP-RK 3 stages"
                                    % mesh.n_cells}[args.config],
                 "n_dofs": n_dofs_total, "n_rk": n_rk, "parallelism": "x-slabs, %d rank(s)" % world,
