@@ -80,7 +80,10 @@ struct StageArgs {
   int n_shards, max_fp, max_faces, max_bnd, uniform_h, want_dt, degree, prefetch_ahead;
   const int32_t *shard_list;  // null: all shards; else the n_list shards of this launch (rim / interior)
   int n_list;
-  int *flags;   // POS: [0] negative mean state, [1] positivity root failure (as LimArgs::flags)
+  int *flags;   // POS 1: [0] negative mean state, [1] positivity root failure (as LimArgs::flags)
+  unsigned long long *lim_mask;   // POS 2: [n_shards] bit = the limiter pass may have something to do in that cell
+  double tvb_M;                   // POS 2: TVB constant M, < 0: the limiter pass has no TVB part
+  int tvb_char, pos_check;        // POS 2: characteristic limiting; the positivity limiter runs in the pass
   KBasis kb;
 };
 
@@ -190,6 +193,33 @@ __device__ __forceinline__ void positivity_row_bounds(double *pb, int lane, cons
   for (int c = 0; c < 4; ++c) pb[((2 * c) * N + B) * 64 + lane] = lo_[c];
 }
 
+// The cell's nodal box from the row extremes left by positivity_row_bounds, and the test on it: a point value on a line
+// through Gauss nodes lies within [lo - d s, hi + d s] (d = hi - lo, s = sum of the negative Gauss-Lobatto interpolation
+// weights); if the lowest density and pressure of that box are safely positive the positivity limiter has nothing to do.
+template <int N>
+__device__ __forceinline__ bool positivity_box_settled(const double *pb, int lane, double sn) {
+  double lo[4], hi[4];
+  bool fin = true;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    lo[c] = pb[((2 * c) * N) * 64 + lane];
+    hi[c] = pb[((2 * c + 1) * N) * 64 + lane];
+    if (c == RHO) fin = fin && lo[c] == lo[c];
+#pragma unroll
+    for (int b = 1; b < N; ++b) {
+      const double l = pb[((2 * c) * N + b) * 64 + lane];
+      if (c == RHO) fin = fin && l == l;
+      lo[c] = fmin(lo[c], l);
+      hi[c] = fmax(hi[c], pb[((2 * c + 1) * N + b) * 64 + lane]);
+    }
+  }
+  const double rho_lo = lo[RHO] - (hi[RHO] - lo[RHO]) * sn, e_lo = lo[EN] - (hi[EN] - lo[EN]) * sn;
+  const double dmx = (hi[MX] - lo[MX]) * sn, dmy = (hi[MY] - lo[MY]) * sn;
+  const double mxa = fmax(fabs(lo[MX] - dmx), fabs(hi[MX] + dmx)), mya = fmax(fabs(lo[MY] - dmy), fabs(hi[MY] + dmy));
+  const double p_lo = kG1 * (e_lo - 0.5 * (mxa * mxa + mya * mya) * frcp(rho_lo));
+  return fin && rho_lo >= 1.0e-10 + 1.0e-8 * hi[RHO] && p_lo >= 1.0e-10 + 1.0e-8 * fabs(hi[EN]);
+}
+
 // ------------------------------------------------------------------ the stage kernel
 // One workgroup of N wavefronts per shard: lane = cell, wavefront = node row b of the (k+1)^2
 // collocation nodes, so control flow is wave-uniform and every global access is a coalesced
@@ -198,7 +228,7 @@ __device__ __forceinline__ void positivity_row_bounds(double *pb, int lane, cons
 // fluxes at the shard's face points, the packed face records and the shard's boundary data.
 
 // phase C for node row B of every cell of the shard (lane = cell)
-template <int N, int B, int MODE, bool POS>
+template <int N, int B, int MODE, int POS>
 __device__ __forceinline__ void row_update(const StageArgs &a, double *Us, const int S, const double *Fh,
                                            double *red, int shard, int lane, bool active, double h,
                                            const uint16_t (&cref)[4], const double (&uold)[4][N],
@@ -316,7 +346,20 @@ __device__ __forceinline__ void row_update(const StageArgs &a, double *Us, const
     __syncthreads();  // every wave is done reading Fh (and the G rows of Us)
 #pragma unroll
     for (int c = 0; c < 5; ++c) red[(B * 5 + c) * 64 + lane] = part[c];
-    if constexpr (POS) positivity_row_bounds<N, B>(Us, lane, unew);   // the LDS image is free now
+    if constexpr (POS == 1) positivity_row_bounds<N, B>(Us, lane, unew);   // the LDS image is free now
+    if constexpr (POS == 2) {
+      if (a.pos_check) positivity_row_bounds<N, B>(Us, lane, unew);
+    }
+    if constexpr (POS == 2) {   // x part of "dx * gradient of the cell average" (src/limiter.cc:283-289): l_m(1) - l_m(0) is
+                                // antisymmetric in m, pairing the nodes makes the slope of a constant state exactly zero
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        double g = 0.0;
+#pragma unroll
+        for (int m = 0; m < N / 2; ++m) g += (CB<N>::t.L1[m] - CB<N>::t.L0[m]) * (unew[c][m] - unew[c][N - 1 - m]);
+        red[(5 * N + c * N + B) * 64 + lane] = CB<N>::t.w[B] * g;
+      }
+    }
   }
 }
 
@@ -324,7 +367,7 @@ __device__ __forceinline__ void row_update(const StageArgs &a, double *Us, const
 // FEValues with MappingQ1): J = [x_xi x_eta; y_xi y_eta] varies inside the cell,
 //   int F.grad(phi) = sum_q w_q [ d(phi)/d(xi) (y_eta F - x_eta G) + d(phi)/d(eta) (-y_xi F + x_xi G) ],
 // lumped mass M_j = w_j det J_j (src/claw.cc:223-227), face JxW = w_q |edge|.
-template <int N, int B, int MODE, bool POS>
+template <int N, int B, int MODE, int POS>
 __device__ __forceinline__ void row_update_q1(const StageArgs &a, double *Us, const int S, const double *Fh,
                                               const double *Fg, double *red, int shard, int lane, bool active,
                                               const double (&vx)[8], const uint16_t (&cref)[4],
@@ -549,8 +592,10 @@ __device__ __forceinline__ void flux_phase(const StageArgs &a, const double *Us,
 // anything waits.
 //   MODE 0: first stage (ark = 0, u(n) not read)   1: later stages   2: residual only (parity hook)
 //   GEO 0: axis-aligned squares (MappingCartesian)   1: bilinear cells (MappingQ1)
-//   POS: apply_positivity_limiter (src/positivity.cc:17-208) on the way out, for runs without the TVB limiter
-template <int N, int FLUX, int MODE, int GEO, bool POS>
+//   POS 1: apply_positivity_limiter (src/positivity.cc:17-208) on the way out, for runs without the TVB limiter
+//   POS 2 (squares, TVB runs): one bit per cell goes out beside its average -- can the limiter pass (TVB, then positivity)
+//          change anything in this cell? -- so that the pass reads the DoFs of the marked cells only
+template <int N, int FLUX, int MODE, int GEO, int POS>
 __global__ __launch_bounds__(64 * N, ((GEO == 1 && N != 3) || N == 4) ? 2 : 3) void stage_kernel(const StageArgs a) {
   constexpr int NS = N * N, NDOF = 4 * NS, NT = 64 * N;
   constexpr int ROWS = NDOF + (FLUX == DFLO_FLUX_LXF ? 3 : 0);   // LxF: (u, v, c) of the cell average ride along
@@ -757,7 +802,7 @@ __global__ __launch_bounds__(64 * N, ((GEO == 1 && N != 3) || N == 4) ? 2 : 3) v
   if constexpr (MODE == 2) return;
   __syncthreads();
   PHASE_MARK(6);
-  if constexpr (POS && MODE != 2) {
+  if constexpr (POS == 1 && MODE != 2) {
     // ---- apply_positivity_limiter (src/positivity.cc:17-208) on the new state.
     //      First a bound that settles almost every cell: the limiter looks at the solution on lines through the Gauss nodes
     //      (Gauss-Lobatto points on them), and a point value on such a line lies within [lo - d s, hi + d s] of the cell's
@@ -767,27 +812,7 @@ __global__ __launch_bounds__(64 * N, ((GEO == 1 && N != 3) || N == 4) ? 2 : 3) v
     constexpr int NS2 = N * N;
     bool settled;
     {
-      double lo[4], hi[4];
-      bool fin = true;
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        lo[c] = Us[((2 * c) * N) * 64 + lane];
-        hi[c] = Us[((2 * c + 1) * N) * 64 + lane];
-        if (c == RHO) fin = fin && lo[c] == lo[c];
-#pragma unroll
-        for (int b = 1; b < N; ++b) {
-          const double l = Us[((2 * c) * N + b) * 64 + lane];
-          if (c == RHO) fin = fin && l == l;
-          lo[c] = fmin(lo[c], l);
-          hi[c] = fmax(hi[c], Us[((2 * c + 1) * N + b) * 64 + lane]);
-        }
-      }
-      const double sn = a.kb.pg_neg;
-      const double rho_lo = lo[RHO] - (hi[RHO] - lo[RHO]) * sn, e_lo = lo[EN] - (hi[EN] - lo[EN]) * sn;
-      const double dmx = (hi[MX] - lo[MX]) * sn, dmy = (hi[MY] - lo[MY]) * sn;
-      const double mxa = fmax(fabs(lo[MX] - dmx), fabs(hi[MX] + dmx)), mya = fmax(fabs(lo[MY] - dmy), fabs(hi[MY] + dmy));
-      const double p_lo = kG1 * (e_lo - 0.5 * (mxa * mxa + mya * mya) * frcp(rho_lo));
-      const bool ok = fin && rho_lo >= 1.0e-10 + 1.0e-8 * hi[RHO] && p_lo >= 1.0e-10 + 1.0e-8 * fabs(hi[EN]);
+      const bool ok = positivity_box_settled<N>(Us, lane, a.kb.pg_neg);
       settled = __all(ok || !active);   // the same in every wave of the workgroup: all of them see the same numbers
     }
     if (!settled) {
@@ -891,6 +916,47 @@ __global__ __launch_bounds__(64 * N, ((GEO == 1 && N != 3) || N == 4) ? 2 : 3) v
     }
     }   // !settled
   }
+  if constexpr (POS == 2 && GEO == 0 && MODE != 2) {
+    // Which cells can the limiter pass change?  TVB (src/limiter.cc:15-30): minmod hands back its first argument when it is
+    // below M dx^2 or zero, so a cell whose (characteristic) slopes all are is left alone; wave 0 looks at the x slopes,
+    // wave 1 at the y slopes, with a margin of 1e-9 on the threshold so that the pass, which forms the slopes once more
+    // from the DoFs, can never disagree in the other direction.  Positivity: the nodal box test.  The pass itself is
+    // unchanged for the marked cells, so the results are those of the plain pass.
+    if (row < 2) {
+      double A[4], D[4];
+      bool any = false;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        double v = 0.0, g = 0.0;
+#pragma unroll
+        for (int b = 0; b < N; ++b) v += red[(b * 5 + c) * 64 + lane];
+        if (row == 0) {
+#pragma unroll
+          for (int b = 0; b < N; ++b) g += red[(5 * N + c * N + b) * 64 + lane];
+        } else {
+#pragma unroll
+          for (int m = 0; m < N / 2; ++m)   // the row sums of the average are w_m * (sum of the row): w_m = w_(N-1-m)
+            g += (CB<N>::t.L1[m] - CB<N>::t.L0[m]) * CB<N>::t.iw[m] * (red[(m * 5 + c) * 64 + lane] - red[((N - 1 - m) * 5 + c) * 64 + lane]);
+        }
+        A[c] = v;
+        D[c] = g;
+        any = any || !(g == 0.0);
+      }
+      bool need = false;
+      if (a.tvb_M >= 0.0) {
+        if (a.tvb_char && __any(any)) {
+          const EigenXY e = eigen_at(A);
+          to_char(e, row, D);
+        }
+        const double thr = a.tvb_M * h * h * (1.0 - 1.0e-9);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) need = need || !(fabs(D[i]) < thr || D[i] == 0.0);
+      }
+      if (row == 0 && a.pos_check) need = need || !positivity_box_settled<N>(Us, lane, a.kb.pg_neg);
+      const unsigned long long m = __ballot(need && active);
+      if (lane == 0 && m) atomicOr(&a.lim_mask[shard], m);
+    }
+  }
   if (row == N - 1) {  // cell averages (src/claw.cc:562-597), residual norm, CFL minimum of the shard; on the
                        // last wave: wave 0 carries the extra pass over the face points
     double avg[4], res = 0.0, dtmin = 1.0e20;
@@ -978,6 +1044,7 @@ struct LimArgs {
   const int32_t *shard_list;
   int n_list;
   const double *shock;  // KXRCF indicator per cell, or null: "shock indicator = limiter" marks every cell (1e20)
+  unsigned long long *mask;   // [n_shards] from the stage kernel: the cells this pass can change (cleared here), or null: all cells
   // bilinear cells, last stage: the time step of the limited solution is formed here, while the cell is in registers
   double *shard_dtmin, *dt_cell;
   double cfl;
@@ -998,14 +1065,25 @@ __global__ __launch_bounds__(64) void limiter_kernel(const LimArgs a) {
   const KBasis &kb = a.kb;
   double *up = a.U + (size_t)shard * NDOF * 64 + lane;
   double U[NDOF], A[4];
+  // With the stage kernel's marks only the cells the limiters can change go through the pass (the others are provably left
+  // as they are, see the stage kernel): most wavefronts return after one load.
+  bool marked = true;
+  if (a.mask) {
+    const unsigned long long m = a.mask[shard];
+    if (m == 0) return;
+    if (lane == 0) a.mask[shard] = 0;   // consumed (the load above has returned: m was compared)
+    marked = (m >> lane) & 1;
+  }
+  if (marked) {
 #pragma unroll
-  for (int d = 0; d < NDOF; ++d) U[d] = up[d * 64];
+    for (int d = 0; d < NDOF; ++d) U[d] = up[d * 64];
+  }
 #pragma unroll
   for (int c = 0; c < 4; ++c) A[c] = a.avg[((size_t)shard * 4 + c) * 64 + lane];
   const double h = a.uniform_h ? a.h_uniform : a.cell_h[(size_t)shard * 64 + lane];
   bool changed = false;
 
-  if (a.tvb && (!a.shock || a.shock[(size_t)shard * 64 + lane] > 1.0)) {  // src/limiter.cc:263,406
+  if (a.tvb && marked && (!a.shock || a.shock[(size_t)shard * 64 + lane] > 1.0)) {  // src/limiter.cc:263,406
     const double dx = h;  // diameter/sqrt(2) of a square
     const double Mdx2 = a.M * dx * dx;
     // one direction after the other (x: left/right neighbours, y: bottom/top), so that only one set of differences
@@ -1079,7 +1157,7 @@ __global__ __launch_bounds__(64) void limiter_kernel(const LimArgs a) {
     }
   }
 
-  if (a.pos_lim) {
+  if (a.pos_lim && marked) {
     const double eps = 1.0e-13;
     if (smin(A[RHO], pressure(A)) < eps) {  // "Fatal: Negative states" :26-38
       if (active) atomicOr(&a.flags[0], 1);
@@ -2074,8 +2152,10 @@ struct dflo_hip_engine {
   int max_fp = 0;
   // timing
   bool timing = false;
-  int dtq_parts = 0;
-  bool fuse_pos = false;   // positivity limiter without TVB on Qk: applied inside the stage kernel (DFLO_FUSE_POS=0: separate pass)   // last stage on bilinear cells: parts (1 rim, 2 interior) whose limiter pass also formed the time step
+  int dtq_parts = 0;   // last stage on bilinear cells: parts (1 rim, 2 interior) whose limiter pass also formed the time step
+  bool fuse_pos = false;   // positivity limiter without TVB on Qk: applied inside the stage kernel (DFLO_FUSE_POS=0: separate pass)
+  unsigned long long *lim_mask = nullptr;   // TVB on Qk squares: [n_shards], written by the stage kernel for the limiter pass (DFLO_LIM_MASK=0: off)
+  bool aux_fresh = false;      // lim_mask belongs to the state the open stage has just produced
   // dflo_hip_advance replays a captured graph of `graph_steps` time steps (the buffer rotation repeats with
   // that period); built lazily for the state it was captured in
   hipGraphExec_t graph_exec = nullptr;
@@ -2146,16 +2226,17 @@ KBasis make_kbasis(const BasisTables &b) {
 
 typedef void (*stage_fn)(const StageArgs);
 template <int N, int FLUX>
-stage_fn pick_stage_m(int mode, int geo, bool pos) {
-  if (pos && mode != 2) {
-    if (geo == 0) return mode == 0 ? stage_kernel<N, FLUX, 0, 0, true> : stage_kernel<N, FLUX, 1, 0, true>;
-    return mode == 0 ? stage_kernel<N, FLUX, 0, 1, true> : stage_kernel<N, FLUX, 1, 1, true>;
+stage_fn pick_stage_m(int mode, int geo, int pos) {
+  if (pos == 1 && mode != 2) {
+    if (geo == 0) return mode == 0 ? stage_kernel<N, FLUX, 0, 0, 1> : stage_kernel<N, FLUX, 1, 0, 1>;
+    return mode == 0 ? stage_kernel<N, FLUX, 0, 1, 1> : stage_kernel<N, FLUX, 1, 1, 1>;
   }
-  if (geo == 0) return mode == 0 ? stage_kernel<N, FLUX, 0, 0, false> : (mode == 1 ? stage_kernel<N, FLUX, 1, 0, false> : stage_kernel<N, FLUX, 2, 0, false>);
-  return mode == 0 ? stage_kernel<N, FLUX, 0, 1, false> : (mode == 1 ? stage_kernel<N, FLUX, 1, 1, false> : stage_kernel<N, FLUX, 2, 1, false>);
+  if (pos == 2 && mode != 2 && geo == 0) return mode == 0 ? stage_kernel<N, FLUX, 0, 0, 2> : stage_kernel<N, FLUX, 1, 0, 2>;
+  if (geo == 0) return mode == 0 ? stage_kernel<N, FLUX, 0, 0, 0> : (mode == 1 ? stage_kernel<N, FLUX, 1, 0, 0> : stage_kernel<N, FLUX, 2, 0, 0>);
+  return mode == 0 ? stage_kernel<N, FLUX, 0, 1, 0> : (mode == 1 ? stage_kernel<N, FLUX, 1, 1, 0> : stage_kernel<N, FLUX, 2, 1, 0>);
 }
 template <int N>
-stage_fn pick_stage_n(int flux, int mode, int geo, bool pos) {
+stage_fn pick_stage_n(int flux, int mode, int geo, int pos) {
   switch (flux) {
     case DFLO_FLUX_LXF: return pick_stage_m<N, DFLO_FLUX_LXF>(mode, geo, pos);
     case DFLO_FLUX_SW: return pick_stage_m<N, DFLO_FLUX_SW>(mode, geo, pos);
@@ -2185,7 +2266,7 @@ stage_fn pick_pk(int N, int flux, int mode) {
     default: return pick_pk_n<4>(flux, mode);
   }
 }
-stage_fn pick_stage(int N, int flux, int mode, int geo, bool pos = false) {
+stage_fn pick_stage(int N, int flux, int mode, int geo, int pos = 0) {
   switch (N) {
     case 2: return pick_stage_n<2>(flux, mode, geo, pos);
     case 3: return pick_stage_n<3>(flux, mode, geo, pos);
@@ -2252,6 +2333,7 @@ int open_stage(dflo_hip_engine *h, int rk, double dt_host, bool residual_only, i
     h->pending_rk = rk;
     h->pending_dt = dt_host;
     h->dtq_parts = 0;
+    h->aux_fresh = false;
     // stage timing samples every fifth stage (5 is coprime to the 2 or 3 stages of a step, so every stage of the
     // step is sampled equally often): two event records per launch are not free
     h->t_sample = h->timing && (h->t_seen++ % 5 == 0);
@@ -2376,7 +2458,13 @@ int launch_update(dflo_hip_engine *h, double *rhs_out, int part) {
   if (a.n_list == 0) return DFLO_OK;
   const int mode_ = rhs_out ? 2 : (h->ark[rk] != 0.0 ? 1 : 0);
   a.flags = h->flags;
-  stage_fn fn = h->basis == DFLO_BASIS_PK ? pick_pk(h->N, h->prm.flux_type, mode_) : pick_stage(h->N, h->prm.flux_type, mode_, h->geo, h->fuse_pos);
+  a.lim_mask = h->lim_mask;
+  a.tvb_M = h->prm.limiter_type == DFLO_LIMITER_TVB ? h->prm.M : -1.0;
+  a.tvb_char = h->prm.char_lim;
+  a.pos_check = h->prm.pos_lim;
+  const int pos_ = h->fuse_pos ? 1 : (h->lim_mask ? 2 : 0);
+  if (pos_ == 2 && mode_ != 2) h->aux_fresh = true;
+  stage_fn fn = h->basis == DFLO_BASIS_PK ? pick_pk(h->N, h->prm.flux_type, mode_) : pick_stage(h->N, h->prm.flux_type, mode_, h->geo, pos_);
   time_begin(h);
   hipLaunchKernelGGL(fn, dim3(grid_for(a.n_list)), dim3(64 * h->N), h->lds_bytes, h->stream, a);
   time_end(h);
@@ -2412,7 +2500,7 @@ int launch_indicator(dflo_hip_engine *h, int part) {
   return DFLO_OK;
 }
 
-int launch_limiter(dflo_hip_engine *h, int tvb, int pos, int part) {
+int launch_limiter(dflo_hip_engine *h, int tvb, int pos, int part, bool stage_data = false) {
   const Plan &p = h->plan;
   LimArgs l{};
   l.U = h->U[h->cur];
@@ -2431,6 +2519,7 @@ int launch_limiter(dflo_hip_engine *h, int tvb, int pos, int part) {
   l.pos_lim = pos;
   l.kb = h->kb;
   l.shock = tvb ? h->d_shock : nullptr;
+  l.mask = (stage_data && tvb && h->aux_fresh) ? h->lim_mask : nullptr;
   l.dtq = (h->geo == 1 && h->basis == DFLO_BASIS_QK && h->pending_rk == h->n_rk - 1) ? 1 : 0;
   l.shard_dtmin = h->shard_dtmin;
   l.dt_cell = h->d_dt_cell;
@@ -2457,7 +2546,7 @@ int launch_stage_limiter(dflo_hip_engine *h, int part) {
     const int rc = launch_indicator(h, part);
     if (rc) return rc;
   }
-  return launch_limiter(h, h->prm.limiter_type == DFLO_LIMITER_TVB, h->prm.pos_lim, part);
+  return launch_limiter(h, h->prm.limiter_type == DFLO_LIMITER_TVB, h->prm.pos_lim, part, true);
 }
 
 // reductions of the stage launched last
@@ -2703,10 +2792,22 @@ int dflo_hip_create(const dflo_mesh_t *mesh, const dflo_params_t *params, int de
   hipMemset(h->dt_dev, 0, 4 * sizeof(double));
   hipMemset(h->flags, 0, 4 * sizeof(int));
   h->halo_stride = std::max(p.max_halo, 1) | 1;  // odd stride: the trace rows fall on different LDS banks
-  h->max_fp = std::max(std::max(p.max_faces, 1) * h->N, 8 * 64 * h->N / 4 + 1);  // Fh also hosts the row partials (5 N rows of 64) and the positivity minima (3 N)
+  h->max_fp = std::max(std::max(p.max_faces, 1) * h->N, 9 * 64 * h->N / 4 + 1);  // Fh also hosts the row partials (5 N rows of 64) and the positivity minima (3 N) or the slope partials (4 N)
   {
     const char *e = getenv("DFLO_FUSE_POS");
     h->fuse_pos = h->prm.pos_lim && h->prm.limiter_type == DFLO_LIMITER_NONE && h->basis == DFLO_BASIS_QK && !(e && e[0] == '0');
+    const char *e2 = getenv("DFLO_LIM_MASK");
+    // (measured: the marks cost the stage kernel ~11 %; the pass they shorten reads (k+1)^2 values per cell and component,
+    //  which pays from k = 2 on -- C4 +7 % -- and not for k = 1 -- C3 -7 %; DFLO_LIM_MASK=1 forces them, 0 forbids them)
+    const bool want_marks = e2 ? e2[0] != '0' : h->N >= 3;
+    if (h->prm.limiter_type == DFLO_LIMITER_TVB && h->basis == DFLO_BASIS_QK && h->geo == 0 && want_marks) {
+      const size_t nb = (size_t)std::max(p.n_shards, 1) * sizeof(unsigned long long);
+      if (hipMalloc((void **)&h->lim_mask, nb) != hipSuccess) {
+        h->err = "hipMalloc(limiter marks) failed";
+        return bail(DFLO_ERR_NOMEM);
+      }
+      hipMemset(h->lim_mask, 0, nb);
+    }
   }
   {
     const int rows = 4 * h->N * h->N + (h->prm.flux_type == DFLO_FLUX_LXF ? 3 : 0);  // nodal image (also for Pk)
@@ -2719,7 +2820,7 @@ int dflo_hip_create(const dflo_mesh_t *mesh, const dflo_params_t *params, int de
   if (h->lds_bytes > 160 * 1024) { h->err = "shard halo too large for LDS"; return bail(DFLO_ERR_UNSUPPORTED); }
   if (h->lds_bytes > 64 * 1024) {
     for (int mode = 0; mode < 3; ++mode) {
-      stage_fn fn = h->basis == DFLO_BASIS_PK ? pick_pk(h->N, h->prm.flux_type, mode) : pick_stage(h->N, h->prm.flux_type, mode, h->geo, h->fuse_pos);
+      stage_fn fn = h->basis == DFLO_BASIS_PK ? pick_pk(h->N, h->prm.flux_type, mode) : pick_stage(h->N, h->prm.flux_type, mode, h->geo, h->fuse_pos ? 1 : (h->lim_mask ? 2 : 0));
       if (hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes) != hipSuccess) {
         h->err = "cannot raise dynamic LDS limit";
         return bail(DFLO_ERR_HIP);
@@ -2755,7 +2856,7 @@ int dflo_hip_destroy(dflo_hip_handle h) {
   hipFree(h->rhs); hipFree(h->user_buf); hipFree(h->bface_kind);
   hipFree(h->d_bc_ops); hipFree(h->d_bc_consts); hipFree(h->d_bc_prog); hipFree(h->d_bc_faces); hipFree(h->d_bface_id); hipFree(h->d_bxy);
   hipFree(h->d_shard_count);
-  hipFree(h->d_bnd_pad); hipFree(h->d_nbr_code); hipFree(h->d_shock); hipFree(h->d_faces_pad); hipFree(h->d_shard_hdr); hipFree(h->d_halo_pad); hipFree(h->d_cell_face); hipFree(h->d_lrbt); hipFree(h->d_user_of); hipFree(h->d_iid);
+  hipFree(h->d_bnd_pad); hipFree(h->d_nbr_code); hipFree(h->d_shock); hipFree(h->lim_mask); hipFree(h->d_faces_pad); hipFree(h->d_shard_hdr); hipFree(h->d_halo_pad); hipFree(h->d_cell_face); hipFree(h->d_lrbt); hipFree(h->d_user_of); hipFree(h->d_iid);
   hipFree(h->d_rim_list); hipFree(h->d_int_list);
   hipFree(h->d_cell_h); hipFree(h->d_dt_cell); hipFree(h->d_cell_vert); hipFree(h->d_fgeom_pad); hipFree(h->shard_res); hipFree(h->shard_dtmin); hipFree(h->res_sq); hipFree(h->fin_partial); hipFree(h->dt_dev);
   hipFree(h->flags); hipFree(h->d_send_slots); hipFree(h->ghost_stage);

@@ -865,3 +865,45 @@ def test_positivity_inside_the_stage_kernel(degree, flux, mapped, monkeypatch):
         runs[fused].set_initial_condition(smooth)
         t = runs[fused].advance(4)
     assert rel(runs["1"].current_solution, runs["0"].current_solution) < 1e-13   # (the two kernels contract a few FMAs differently)
+
+
+@pytest.mark.parametrize("degree,M", [(1, 0.0), (2, 50.0), (3, 200.0)])
+def test_limiter_marks_from_the_stage_kernel(degree, M, monkeypatch):
+    """TVB runs on squares: the stage kernel marks the cells the limiter pass can change (slopes against M dx^2 with a
+    margin, nodal box for positivity) and the pass visits only those.  Same answers as the pass over all cells, and
+    as the oracle."""
+    bnd = {0: "slip", 1: "outflow", 2: "inflow"}
+    mesh = dflo_amd.Mesh.cartesian(48, 12, 0.0, 0.0, 1.0 / 48, [2, 1, 0, 0], degree)
+    prm = dflo_amd.Parameters(flux="hllc", limiter="TVB", char_lim=True, pos_lim=True, M=M, beta=1.5, boundary=bnd, cfl=0.6)
+    def ic(x, y):   # a Sod jump plus a smooth wave: cells that TVB leaves alone next to cells it limits
+        mx, my, rho, E = problems.sod(x, y)
+        return [mx, my, rho * (1.0 + 0.05 * np.sin(12.0 * x) * np.cos(9.0 * y)), E]
+    u0 = mesh.interpolate(ic)
+    runs = {}
+    for marks in ("1", "0"):
+        monkeypatch.setenv("DFLO_LIM_MASK", marks)
+        claw = dflo_amd.ConservationLaw(mesh, prm)
+        cell, face, bid, xy = claw.boundary_faces()
+        bv = np.stack(ic(xy[..., 0], xy[..., 1]), axis=-1)
+        claw.set_boundary_values(0, bv)
+        claw.set_boundary_values(1, bv)
+        claw.set_initial_condition(u0)
+        claw.apply_limiter()
+        runs[marks] = claw
+    ora = oracle_lib.Oracle(mesh, prm)
+    ora.set_boundary_values(0, bv)
+    ora.set_boundary_values(1, bv)
+    ora.set_solution(u0)
+    ora.apply_limiter()
+    t = 0.0
+    for it in range(8):
+        dt = ora.compute_time_step(t)
+        for claw in runs.values():
+            claw.iterate_explicit(dt)
+        ora.step(dt)
+        t += dt
+    assert rel(runs["1"].current_solution, runs["0"].current_solution) < 1e-11
+    assert rel(runs["1"].current_solution, ora.get_solution()) < 1e-8
+    assert rel(runs["1"].cell_average, ora.get_cell_average()) < 1e-9
+    t1, t0 = runs["1"].advance(5), runs["0"].advance(5)
+    assert abs(t1 - t0) <= 1e-12 * t0 and rel(runs["1"].current_solution, runs["0"].current_solution) < 1e-10
