@@ -232,7 +232,7 @@ template <int N, int B, int MODE, int POS>
 __device__ __forceinline__ void row_update(const StageArgs &a, double *Us, const int S, const double *Fh,
                                            double *red, int shard, int lane, bool active, double h,
                                            const uint16_t (&cref)[4], const double (&uold)[4][N],
-                                           const double (&Wrow)[N][4], double (&unew)[4][N]) {
+                                           const double (&Wrow)[N][4], double (&unew)[4][N], const double dt) {
   constexpr int NS = N * N;
   double R[4][N];
 #pragma unroll
@@ -316,7 +316,6 @@ __device__ __forceinline__ void row_update(const StageArgs &a, double *Us, const
         for (int m = 0; m < N; ++m) rp[(c * NS + m + N * B) * 64] = R[c][m];
     } else {
       // solve() rk3 branch + SSP combine (src/claw.cc:708-710, 757-760)
-      const double dt = a.dt_cell ? a.dt_cell[(size_t)shard * 64 + lane] : (a.dt_host >= 0.0 ? a.dt_host : *a.dt_dev);
       const double rh2 = frcp(h * h);
       double *np = a.Unew + (size_t)shard * 4 * NS * 64 + lane;
 #pragma unroll
@@ -371,7 +370,8 @@ template <int N, int B, int MODE, int POS>
 __device__ __forceinline__ void row_update_q1(const StageArgs &a, double *Us, const int S, const double *Fh,
                                               const double *Fg, double *red, int shard, int lane, bool active,
                                               const double (&vx)[8], const uint16_t (&cref)[4],
-                                              const double (&uold)[4][N], const double (&Wrow)[N][4], double (&unew)[4][N]) {
+                                              const double (&uold)[4][N], const double (&Wrow)[N][4], double (&unew)[4][N],
+                                              const double dt) {
   constexpr int NS = N * N;
   double R[4][N];
 #pragma unroll
@@ -459,7 +459,6 @@ __device__ __forceinline__ void row_update_q1(const StageArgs &a, double *Us, co
 #pragma unroll
         for (int m = 0; m < N; ++m) rp[(c * NS + m + N * B) * 64] = R[c][m];
     } else {
-      const double dt = a.dt_cell ? a.dt_cell[(size_t)shard * 64 + lane] : (a.dt_host >= 0.0 ? a.dt_host : *a.dt_dev);
       double *np = a.Unew + (size_t)shard * 4 * NS * 64 + lane;
       const double xxi = ax + CB<N>::t.x[B] * bx, yxi = ay + CB<N>::t.x[B] * by;
 #pragma unroll
@@ -681,6 +680,10 @@ __global__ __launch_bounds__(64 * N, ((GEO == 1 && N != 3) || N == 4) ? 2 : 3) v
 #pragma unroll
     for (int k = 0; k < 8; ++k) vx[k] = a.cell_vert[(size_t)k * a.n_slots + (size_t)shard * 64 + lane];
   }
+  // the time step of the update: fetched here with everything else (it used to be read in the middle of phase C, one more
+  // trip to memory on every wave's critical path)
+  double dt_step = 0.0;
+  if constexpr (MODE != 2) dt_step = a.dt_cell ? a.dt_cell[(size_t)shard * 64 + lane] : (a.dt_host >= 0.0 ? a.dt_host : *a.dt_dev);
   double uold[4][N];
   if constexpr (MODE == 1) {
     const double *op = a.Uold + (size_t)shard * NDOF * 64 + lane;
@@ -787,8 +790,8 @@ __global__ __launch_bounds__(64 * N, ((GEO == 1 && N != 3) || N == 4) ? 2 : 3) v
     for (int c = 0; c < 4; ++c) wrow[m][c] = urow[c][m];
 #define DFLO_ROW(Bq)                                                                                     \
   do {                                                                                                   \
-    if constexpr (GEO == 0) row_update<N, Bq, MODE, POS>(a, Us, S, Fh, red, shard, lane, active, h, cref, uold, wrow, unew); \
-    else row_update_q1<N, Bq, MODE, POS>(a, Us, S, Fh, Fg, red, shard, lane, active, vx, cref, uold, wrow, unew);     \
+    if constexpr (GEO == 0) row_update<N, Bq, MODE, POS>(a, Us, S, Fh, red, shard, lane, active, h, cref, uold, wrow, unew, dt_step); \
+    else row_update_q1<N, Bq, MODE, POS>(a, Us, S, Fh, Fg, red, shard, lane, active, vx, cref, uold, wrow, unew, dt_step); \
   } while (0)
   if constexpr (N == 2) {
     if (row == 0) DFLO_ROW(0); else DFLO_ROW(1);
@@ -1252,7 +1255,7 @@ template <int N, int B, int MODE>
 __device__ __forceinline__ void row_update_pk(const StageArgs &a, double *Us, const int S, const double *Fh, double *red,
                                               int shard, int lane, bool active, double h, const uint16_t (&cref)[4],
                                               const double (&Wrow)[N][4], const double (&ucur)[4][(N * (N + 1) / 2 + N - 1) / N],
-                                              const double (&uold)[4][(N * (N + 1) / 2 + N - 1) / N]) {
+                                              const double (&uold)[4][(N * (N + 1) / 2 + N - 1) / N], const double dt) {
   constexpr int NS = N * N, NM = N * (N + 1) / 2;
   double R[4][N];
 #pragma unroll
@@ -1341,7 +1344,6 @@ __device__ __forceinline__ void row_update_pk(const StageArgs &a, double *Us, co
   }
   double part[5] = {0, 0, 0, 0, 0};
   if (active) {
-    const double dt = a.dt_cell ? a.dt_cell[(size_t)shard * 64 + lane] : (a.dt_host >= 0.0 ? a.dt_host : *a.dt_dev);
     const double rh2 = frcp(h * h);  // inverse mass of the orthonormal modes: 1/|K|
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -1419,6 +1421,8 @@ __global__ __launch_bounds__(64 * N, N == 4 ? 2 : 3) void stage_kernel_pk(const 
 #pragma unroll
   for (int f = 0; f < 4; ++f) cref[f] = a.cell_face[((size_t)shard * 4 + f) * 64 + lane];
   const double h = a.uniform_h ? a.h_uniform : a.cell_h[(size_t)shard * 64 + lane];
+  double dt_step = 0.0;   // fetched with the other loads, not in the middle of phase C
+  if constexpr (MODE != 2) dt_step = a.dt_cell ? a.dt_cell[(size_t)shard * 64 + lane] : (a.dt_host >= 0.0 ? a.dt_host : *a.dt_dev);
   double ucur[4][MS], uold[4][MS];
 #pragma unroll
   for (int c = 0; c < 4; ++c)
@@ -1506,7 +1510,7 @@ __global__ __launch_bounds__(64 * N, N == 4 ? 2 : 3) void stage_kernel_pk(const 
   for (int m = 0; m < N; ++m)
 #pragma unroll
     for (int c = 0; c < 4; ++c) wrow[m][c] = urow[c][m];
-#define DFLO_ROWPK(Bq) row_update_pk<N, Bq, MODE>(a, Us, S, Fh, red, shard, lane, active, h, cref, wrow, ucur, uold)
+#define DFLO_ROWPK(Bq) row_update_pk<N, Bq, MODE>(a, Us, S, Fh, red, shard, lane, active, h, cref, wrow, ucur, uold, dt_step)
   if constexpr (N == 2) {
     if (row == 0) DFLO_ROWPK(0); else DFLO_ROWPK(1);
   } else if constexpr (N == 3) {

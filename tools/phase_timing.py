@@ -23,14 +23,14 @@ try:
         from dflo_amd import gmsh
         verts, quads, bed, side = gmsh.unstructured_quads(nx, Lx=10.0, Ly=10.0, seed=1)
         mesh = dflo_amd.Mesh.from_quads(verts - 5.0, quads, bed, side, deg)
-        claw = dflo_amd.ConservationLaw(mesh, dflo_amd.Parameters(flux=flux, boundary={0: "farfield", 1: "farfield", 2: "farfield", 3: "farfield"}))
+        claw = dflo_amd.ConservationLaw(mesh, dflo_amd.Parameters(flux=flux, pos_lim="pos" in sys.argv[5:], boundary={0: "farfield", 1: "farfield", 2: "farfield", 3: "farfield"}))
         cell, face, bid, xy = claw.boundary_faces()
         bv = np.stack(problems.isentropic_vortex(xy[..., 0], xy[..., 1]), axis=-1)
         claw.set_boundary_values(0, bv)
         claw.set_boundary_values(1, bv)
     else:
         mesh = dflo_amd.Mesh.cartesian(nx, nx, -5.0, -5.0, 10.0 / nx, [-1] * 4, deg)
-        claw = dflo_amd.ConservationLaw(mesh, dflo_amd.Parameters(flux=flux))
+        claw = dflo_amd.ConservationLaw(mesh, dflo_amd.Parameters(flux=flux, pos_lim="pos" in sys.argv[5:]))
     claw.set_initial_condition(mesh.interpolate(problems.isentropic_vortex))
     claw.advance(3)
     f = _lib.lib.dflo_hip_debug_phase_cycles
