@@ -83,6 +83,7 @@ CASES = [
     (32, 16, 2, "hllc", "none", False, [-1, -1, -1, -1], None, "vortex"),
     (64, 8, 1, "roe", "TVB", True, [2, 1, 0, 0], {0: "slip", 1: "outflow", 2: "inflow"}, "sod"),
     (48, 40, 1, "hllc", "TVB", True, [0, 0, 0, 0], {0: "outflow"}, "front", "density"),   # KXRCF-gated limiter across the cut
+    (64, 8, 2, "hllc", "TVB", True, [2, 1, 0, 0], {0: "slip", 1: "outflow", 2: "inflow"}, "sod"),   # C4 style: limiter marks from the stage kernel, rim / interior launches
     (10, 10, 3, "kfvs", "none", True, "unstructured", {0: "slip", 1: "outflow", 2: "slip", 3: "inflow"}, "smooth"),   # C5 style
 ]
 
