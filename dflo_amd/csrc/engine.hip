@@ -1765,6 +1765,59 @@ __global__ __launch_bounds__(64) void indicator_kernel(const IndArgs a) {
   a.shock[(size_t)shard * 64 + lane] = fabs(ind) / denominator;  // 0/0 -> NaN -> "not > 1": not limited, as in the reference
 }
 
+// ------------------------------------------------------------------ one translation unit per degree
+// The stage kernels of one N (5 fluxes x 3 modes x 2 geometries x the limiter variants, Qk and Pk) take most of the compile
+// time; build() compiles this file once per N with -DDFLO_STAGE_N=N (only this section is kept after the kernels above)
+// and once without (everything else), in parallel.
+typedef void (*stage_fn)(const StageArgs);
+template <int N, int FLUX>
+stage_fn pick_stage_m(int mode, int geo, int pos) {
+  if (pos == 1 && mode != 2) {
+    if (geo == 0) return mode == 0 ? stage_kernel<N, FLUX, 0, 0, 1> : stage_kernel<N, FLUX, 1, 0, 1>;
+    return mode == 0 ? stage_kernel<N, FLUX, 0, 1, 1> : stage_kernel<N, FLUX, 1, 1, 1>;
+  }
+  if (pos == 2 && mode != 2 && geo == 0) return mode == 0 ? stage_kernel<N, FLUX, 0, 0, 2> : stage_kernel<N, FLUX, 1, 0, 2>;
+  if (geo == 0) return mode == 0 ? stage_kernel<N, FLUX, 0, 0, 0> : (mode == 1 ? stage_kernel<N, FLUX, 1, 0, 0> : stage_kernel<N, FLUX, 2, 0, 0>);
+  return mode == 0 ? stage_kernel<N, FLUX, 0, 1, 0> : (mode == 1 ? stage_kernel<N, FLUX, 1, 1, 0> : stage_kernel<N, FLUX, 2, 1, 0>);
+}
+template <int N>
+stage_fn pick_stage_n(int flux, int mode, int geo, int pos) {
+  switch (flux) {
+    case DFLO_FLUX_LXF: return pick_stage_m<N, DFLO_FLUX_LXF>(mode, geo, pos);
+    case DFLO_FLUX_SW: return pick_stage_m<N, DFLO_FLUX_SW>(mode, geo, pos);
+    case DFLO_FLUX_KFVS: return pick_stage_m<N, DFLO_FLUX_KFVS>(mode, geo, pos);
+    case DFLO_FLUX_ROE: return pick_stage_m<N, DFLO_FLUX_ROE>(mode, geo, pos);
+    default: return pick_stage_m<N, DFLO_FLUX_HLLC>(mode, geo, pos);
+  }
+}
+template <int N, int FLUX>
+stage_fn pick_pk_m(int mode) {
+  return mode == 0 ? stage_kernel_pk<N, FLUX, 0> : (mode == 1 ? stage_kernel_pk<N, FLUX, 1> : stage_kernel_pk<N, FLUX, 2>);
+}
+template <int N>
+stage_fn pick_pk_n(int flux, int mode) {
+  switch (flux) {
+    case DFLO_FLUX_LXF: return pick_pk_m<N, DFLO_FLUX_LXF>(mode);
+    case DFLO_FLUX_SW: return pick_pk_m<N, DFLO_FLUX_SW>(mode);
+    case DFLO_FLUX_KFVS: return pick_pk_m<N, DFLO_FLUX_KFVS>(mode);
+    case DFLO_FLUX_ROE: return pick_pk_m<N, DFLO_FLUX_ROE>(mode);
+    default: return pick_pk_m<N, DFLO_FLUX_HLLC>(mode);
+  }
+}
+stage_fn stage_of_2(int flux, int mode, int geo, int pos);
+stage_fn stage_of_3(int flux, int mode, int geo, int pos);
+stage_fn stage_of_4(int flux, int mode, int geo, int pos);
+stage_fn stage_pk_of_2(int flux, int mode);
+stage_fn stage_pk_of_3(int flux, int mode);
+stage_fn stage_pk_of_4(int flux, int mode);
+#ifdef DFLO_STAGE_N
+#define DFLO_CAT_(a, b) a##b
+#define DFLO_CAT(a, b) DFLO_CAT_(a, b)
+stage_fn DFLO_CAT(stage_of_, DFLO_STAGE_N)(int flux, int mode, int geo, int pos) { return pick_stage_n<DFLO_STAGE_N>(flux, mode, geo, pos); }
+stage_fn DFLO_CAT(stage_pk_of_, DFLO_STAGE_N)(int flux, int mode) { return pick_pk_n<DFLO_STAGE_N>(flux, mode); }
+}  // namespace dflo
+#else
+
 // ------------------------------------------------------------------ boundary functions on the device
 // The boundary values of integrate_boundary_term_explicit (FunctionParser::vector_value_list at the face
 // quadrature points with set_time(bc_time), src/assemble_explicit.cc:161-165, src/claw.cc:736-745) evaluated by
@@ -2228,53 +2281,18 @@ KBasis make_kbasis(const BasisTables &b) {
   return k;
 }
 
-typedef void (*stage_fn)(const StageArgs);
-template <int N, int FLUX>
-stage_fn pick_stage_m(int mode, int geo, int pos) {
-  if (pos == 1 && mode != 2) {
-    if (geo == 0) return mode == 0 ? stage_kernel<N, FLUX, 0, 0, 1> : stage_kernel<N, FLUX, 1, 0, 1>;
-    return mode == 0 ? stage_kernel<N, FLUX, 0, 1, 1> : stage_kernel<N, FLUX, 1, 1, 1>;
-  }
-  if (pos == 2 && mode != 2 && geo == 0) return mode == 0 ? stage_kernel<N, FLUX, 0, 0, 2> : stage_kernel<N, FLUX, 1, 0, 2>;
-  if (geo == 0) return mode == 0 ? stage_kernel<N, FLUX, 0, 0, 0> : (mode == 1 ? stage_kernel<N, FLUX, 1, 0, 0> : stage_kernel<N, FLUX, 2, 0, 0>);
-  return mode == 0 ? stage_kernel<N, FLUX, 0, 1, 0> : (mode == 1 ? stage_kernel<N, FLUX, 1, 1, 0> : stage_kernel<N, FLUX, 2, 1, 0>);
-}
-template <int N>
-stage_fn pick_stage_n(int flux, int mode, int geo, int pos) {
-  switch (flux) {
-    case DFLO_FLUX_LXF: return pick_stage_m<N, DFLO_FLUX_LXF>(mode, geo, pos);
-    case DFLO_FLUX_SW: return pick_stage_m<N, DFLO_FLUX_SW>(mode, geo, pos);
-    case DFLO_FLUX_KFVS: return pick_stage_m<N, DFLO_FLUX_KFVS>(mode, geo, pos);
-    case DFLO_FLUX_ROE: return pick_stage_m<N, DFLO_FLUX_ROE>(mode, geo, pos);
-    default: return pick_stage_m<N, DFLO_FLUX_HLLC>(mode, geo, pos);
-  }
-}
-template <int N, int FLUX>
-stage_fn pick_pk_m(int mode) {
-  return mode == 0 ? stage_kernel_pk<N, FLUX, 0> : (mode == 1 ? stage_kernel_pk<N, FLUX, 1> : stage_kernel_pk<N, FLUX, 2>);
-}
-template <int N>
-stage_fn pick_pk_n(int flux, int mode) {
-  switch (flux) {
-    case DFLO_FLUX_LXF: return pick_pk_m<N, DFLO_FLUX_LXF>(mode);
-    case DFLO_FLUX_SW: return pick_pk_m<N, DFLO_FLUX_SW>(mode);
-    case DFLO_FLUX_KFVS: return pick_pk_m<N, DFLO_FLUX_KFVS>(mode);
-    case DFLO_FLUX_ROE: return pick_pk_m<N, DFLO_FLUX_ROE>(mode);
-    default: return pick_pk_m<N, DFLO_FLUX_HLLC>(mode);
-  }
-}
 stage_fn pick_pk(int N, int flux, int mode) {
   switch (N) {
-    case 2: return pick_pk_n<2>(flux, mode);
-    case 3: return pick_pk_n<3>(flux, mode);
-    default: return pick_pk_n<4>(flux, mode);
+    case 2: return dflo::stage_pk_of_2(flux, mode);
+    case 3: return dflo::stage_pk_of_3(flux, mode);
+    default: return dflo::stage_pk_of_4(flux, mode);
   }
 }
 stage_fn pick_stage(int N, int flux, int mode, int geo, int pos = 0) {
   switch (N) {
-    case 2: return pick_stage_n<2>(flux, mode, geo, pos);
-    case 3: return pick_stage_n<3>(flux, mode, geo, pos);
-    default: return pick_stage_n<4>(flux, mode, geo, pos);
+    case 2: return dflo::stage_of_2(flux, mode, geo, pos);
+    case 3: return dflo::stage_of_3(flux, mode, geo, pos);
+    default: return dflo::stage_of_4(flux, mode, geo, pos);
   }
 }
 
@@ -3439,3 +3457,4 @@ int dflo_hip_apply_dt_rules(dflo_hip_handle h) {
 }
 
 }  // extern "C"
+#endif  // DFLO_STAGE_N

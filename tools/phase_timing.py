@@ -8,8 +8,8 @@ csrc = os.path.join(ROOT, "dflo_amd", "csrc")
 real = os.path.join(ROOT, "dflo_amd", "libdflo_hip.so")
 probe = os.path.join(ROOT, "gpurun_out", "libdflo_hip_probe.so")
 os.makedirs(os.path.dirname(probe), exist_ok=True)
-subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
-                       "-Wno-unused-value", "-DDFLO_PHASE_TIMING", "-o", probe, "mesh.cc", "plan.cc", "engine.hip"], cwd=csrc)
+import __graft_entry__ as _ge
+_ge.compile_engine(probe, extra_flags=["-DDFLO_PHASE_TIMING"], objdir=os.path.join(os.path.dirname(probe), "probe_obj"))
 os.replace(real, real + ".keep")
 os.symlink(probe, real)
 try:
