@@ -922,8 +922,8 @@ __global__ __launch_bounds__(64 * N, ((GEO == 1 && N != 3) || N == 4) ? 2 : 3) v
   if constexpr (POS == 2 && GEO == 0 && MODE != 2) {
     // Which cells can the limiter pass change?  TVB (src/limiter.cc:15-30): minmod hands back its first argument when it is
     // below M dx^2 or zero, so a cell whose (characteristic) slopes all are is left alone; wave 0 looks at the x slopes,
-    // wave 1 at the y slopes, with a margin of 1e-9 on the threshold so that the pass, which forms the slopes once more
-    // from the DoFs, can never disagree in the other direction.  Positivity: the nodal box test.  The pass itself is
+    // wave 1 at the y slopes, with a margin on the threshold so that the pass, which forms the slopes once more from the
+    // DoFs, can never disagree in the other direction.  Positivity: the nodal box test.  The pass itself is
     // unchanged for the marked cells, so the results are those of the plain pass.
     if (row < 2) {
       double A[4], D[4];
@@ -951,7 +951,9 @@ __global__ __launch_bounds__(64 * N, ((GEO == 1 && N != 3) || N == 4) ? 2 : 3) v
           const EigenXY e = eigen_at(A);
           to_char(e, row, D);
         }
-        const double thr = a.tvb_M * h * h * (1.0 - 1.0e-9);
+        // margin: relative on the threshold, and absolute against the rounding of the slopes (formed here from row
+        // partials, in the pass from the DoFs; both errors are a few ulp of the state)
+        const double thr = a.tvb_M * h * h * (1.0 - 1.0e-9) - 1.0e-11 * (fabs(A[0]) + fabs(A[1]) + fabs(A[2]) + fabs(A[3]));
 #pragma unroll
         for (int i = 0; i < 4; ++i) need = need || !(fabs(D[i]) < thr || D[i] == 0.0);
       }
