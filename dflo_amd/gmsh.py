@@ -101,3 +101,67 @@ def unstructured_quads(n, Lx=1.0, Ly=1.0, jitter=0.25, seed=0):
     bedges = np.stack([np.stack([uniq[b, 0], npts + b], axis=1), np.stack([npts + b, uniq[b, 1]], axis=1)], axis=1).reshape(-1, 2)
     bid = np.repeat(side, 2)
     return verts, quads.astype(np.int32), bedges.astype(np.int32), bid.astype(np.int32)
+
+
+def forward_step_quads(cl=0.05, jitter=0.25, seed=0):
+    """The wind tunnel with a step of examples/forward_step/step.geo ([0,3] x [0,1] minus [0.6,3] x [0,0.2]) meshed with
+    unstructured quadrilaterals of size ~ cl/2, the way BASELINE config 5 wants it ("drop Transfinite Surface"): lattice
+    points of spacing cl (cl must divide 0.2), the interior ones jittered, Delaunay triangles with the ones inside the
+    step removed, every triangle cut into three quadrilaterals.  Boundary ids as in step.geo / input.prm: 1 inflow
+    (x = 0), 3 outflow (x = 3), 2 every wall.  -> (vertices, quads, boundary edges, boundary ids)"""
+    from scipy.spatial import Delaunay
+    L1, L, h1, H = 0.6, 3.0, 0.2, 1.0
+    nx, ny = int(round(L / cl)), int(round(H / cl))
+    assert abs(nx * cl - L) < 1e-12 and abs(round(h1 / cl) * cl - h1) < 1e-12 and abs(round(L1 / cl) * cl - L1) < 1e-12
+    i, j = np.meshgrid(np.arange(nx + 1), np.arange(ny + 1), indexing="xy")
+    i, j = i.reshape(-1), j.reshape(-1)
+    i1, j1 = int(round(L1 / cl)), int(round(h1 / cl))
+    keep = ~((i > i1) & (j < j1))                                   # lattice points strictly inside the step are dropped
+    i, j = i[keep], j[keep]
+    pts = np.stack([i * cl, j * cl], axis=1).astype(np.float64)
+    on_wall = (i == 0) | (i == nx) | (j == ny) | ((j == 0) & (i <= i1)) | ((i == i1) & (j <= j1)) | ((j == j1) & (i >= i1))
+    rng = np.random.default_rng(seed)
+    pts[~on_wall] += jitter * cl * rng.uniform(-1.0, 1.0, ((~on_wall).sum(), 2))
+    tri = Delaunay(pts).simplices
+    cen = pts[tri].mean(axis=1)
+    tri = tri[~((cen[:, 0] > L1) & (cen[:, 1] < h1))]               # the triangles that bridge the notch
+    a, b, c = pts[tri[:, 0]], pts[tri[:, 1]], pts[tri[:, 2]]
+    area2 = (b[:, 0] - a[:, 0]) * (c[:, 1] - a[:, 1]) - (b[:, 1] - a[:, 1]) * (c[:, 0] - a[:, 0])
+    tri = tri[np.abs(area2) > 1e-12 * cl * cl]                      # (collinear wall points can leave slivers)
+    area2 = area2[np.abs(area2) > 1e-12 * cl * cl]
+    tri[area2 < 0] = tri[area2 < 0][:, ::-1]
+    npts, nt = len(pts), len(tri)
+    e = np.stack([tri[:, [0, 1]], tri[:, [1, 2]], tri[:, [2, 0]]], axis=1)
+    key = np.sort(e.reshape(-1, 2), axis=1)
+    uniq, inv, counts = np.unique(key, axis=0, return_inverse=True, return_counts=True)
+    mid = (npts + inv.reshape(-1)).reshape(nt, 3)
+    cenid = npts + len(uniq) + np.arange(nt)
+    verts = np.concatenate([pts, 0.5 * (pts[uniq[:, 0]] + pts[uniq[:, 1]]), pts[tri].mean(axis=1)])
+    quads = np.stack([np.stack([tri[:, k], mid[:, k], cenid, mid[:, (k + 2) % 3]], axis=1) for k in range(3)], axis=1).reshape(-1, 4)
+    b = np.nonzero(counts == 1)[0]
+    pm = 0.5 * (pts[uniq[b, 0]] + pts[uniq[b, 1]])
+    side = np.where(np.abs(pm[:, 0]) < 1e-12, 1, np.where(np.abs(pm[:, 0] - L) < 1e-12, 3, 2))
+    bedges = np.stack([np.stack([uniq[b, 0], npts + b], axis=1), np.stack([npts + b, uniq[b, 1]], axis=1)], axis=1).reshape(-1, 2)
+    return verts, quads.astype(np.int32), bedges.astype(np.int32), np.repeat(side, 2).astype(np.int32)
+
+
+def write_quads_msh(path, verts, quads, bedges, bid, surface_id=100):
+    """Any quadrilateral mesh as Gmsh 2.2 ASCII: nodes, 2-node lines with their "Physical Line" id, 4-node quadrangles."""
+    with open(path, "w") as f:
+        f.write("$MeshFormat\n2.2 0 8\n$EndMeshFormat\n$Nodes\n%d\n" % len(verts))
+        for n, (x, y) in enumerate(verts):
+            f.write("%d %.17g %.17g 0\n" % (n + 1, x, y))
+        f.write("$EndNodes\n$Elements\n%d\n" % (len(bedges) + len(quads)))
+        e = 1
+        for (a, b), pid in zip(bedges, bid):
+            f.write("%d 1 2 %d %d %d %d\n" % (e, pid, pid, a + 1, b + 1))
+            e += 1
+        for q in quads:
+            f.write("%d 3 2 %d 1 %d %d %d %d\n" % (e, surface_id, q[0] + 1, q[1] + 1, q[2] + 1, q[3] + 1))
+            e += 1
+        f.write("$EndElements\n")
+
+
+def forward_step(path, cl=0.05, jitter=0.25, seed=0):
+    """step.msh for examples/forward_step/input.prm with `mapping = q1` (unstructured quadrilaterals, see forward_step_quads)."""
+    write_quads_msh(path, *forward_step_quads(cl, jitter, seed))

@@ -422,3 +422,27 @@ def test_cxx_prm_reader_on_the_shipped_input_files():
             assert python_ok, name
         else:   # the C++ driver writes vtk only; everything else it refuses, the Python reader refuses too
             assert "tecplot" in r.stderr or not python_ok, (name, r.stderr)
+
+
+def test_forward_step_mesh_writer(tmp_path):
+    """The unstructured quadrilateral mesh of examples/forward_step/step.geo's domain (gmsh is absent): exact area, every
+    boundary edge on the right physical line, positive cells, and the .msh read back by the C++ reader gives the same cells."""
+    from dflo_amd import gmsh
+    v, q, be, bid = gmsh.forward_step_quads(0.1, seed=2)
+    P = v[q]
+    x, y = P[:, :, 0], P[:, :, 1]
+    area = 0.5 * ((x * np.roll(y, -1, axis=1) - np.roll(x, -1, axis=1) * y).sum(axis=1))
+    assert (area > 0).all() and abs(area.sum() - (3.0 - 2.4 * 0.2)) < 1e-12
+    mid = 0.5 * (v[be[:, 0]] + v[be[:, 1]])
+    assert (np.abs(mid[bid == 1][:, 0]) < 1e-12).all() and (np.abs(mid[bid == 3][:, 0] - 3.0) < 1e-12).all()
+    wall = mid[bid == 2]
+    on = (np.abs(wall[:, 1] - 1.0) < 1e-12) | ((np.abs(wall[:, 1]) < 1e-12) & (wall[:, 0] < 0.6)) | \
+         ((np.abs(wall[:, 0] - 0.6) < 1e-12) & (wall[:, 1] < 0.2)) | ((np.abs(wall[:, 1] - 0.2) < 1e-12) & (wall[:, 0] > 0.6))
+    assert on.all() and (bid == 1).sum() == 20 and (bid == 3).sum() == 16
+    gmsh.forward_step(str(tmp_path / "step.msh"), 0.1, seed=2)
+    m = dflo_amd.Mesh.read_gmsh(str(tmp_path / "step.msh"), degree=3, mapping="q1")
+    m0 = dflo_amd.Mesh.from_quads(v, q, be, bid, 3)
+    assert m.n_cells == m0.n_cells == len(q)
+    assert np.array_equal(np.sort(m.vertices.reshape(-1, 8), axis=0), np.sort(m0.vertices.reshape(-1, 8), axis=0))
+    nb = m.neighbors
+    assert (nb == -1 - 1).sum() == 20 and (nb == -1 - 3).sum() == 16 and (nb == -1 - 2).sum() == (bid == 2).sum() and (nb == -1).sum() == 0

@@ -381,3 +381,96 @@ def test_cxx_driver_reports_errors_like_main(tmp_path):
     (tmp_path / "input.prm").write_text("set mesh file = missing.msh\nsubsection time stepping\n set cfl = 0.5\nend\nsubsection refinement\n set refinement = false\nend\n")
     r = subprocess.run([RUN_BIN, str(tmp_path / "input.prm")], capture_output=True, text=True, timeout=60)
     assert r.returncode == 1 and "Exception on processing" in r.stderr
+
+
+STEP_PRM = """
+set mesh type = gmsh
+set mesh file = step.msh
+set degree = %(degree)d
+set mapping = q1
+subsection boundary_1
+   set type = inflow
+   set w_0 value =        4.20000
+   set w_1 value =        0.00000
+   set w_2 value =        1.40000
+   set w_3 value =        8.80000
+end
+subsection boundary_2
+   set type = slip
+end
+subsection boundary_3
+   set type = outflow
+end
+subsection initial condition
+   set w_0 value =        4.20000
+   set w_1 value =        0.00000
+   set w_2 value =        1.40000
+   set w_3 value =        8.80000
+end
+subsection time stepping
+  set time step type = global
+  set cfl = 0.5
+  set final time = 4.0
+end
+subsection linear solver
+  set method         = rk3
+end
+subsection output
+  set iter step      = 100
+  set schlieren plot = true
+end
+subsection refinement
+  set refinement = false
+end
+subsection flux
+ set flux = kfvs
+end
+subsection limiter
+   set type = none
+   set positivity limiter = true
+end
+"""
+
+
+def test_forward_step_c5_style(tmp_path):
+    """BASELINE config 5 on its own geometry: the Mach 3 wind tunnel with a step (examples/forward_step/input.prm with the
+    changes C5 names: unstructured quadrilaterals, mapping q1, KFVS, positivity limiter alone -- the limiter runs inside
+    the stage kernel here), through the .prm / .msh front end.  Q3 for the first steps against the oracle; then, with
+    the degree of the shipped input (1), a longer run for the properties: the flow upstream of the step is still the free
+    stream, everything stays admissible, and the mass in the tunnel grows by what the inflow brings and the (still
+    undisturbed) outflow takes.  (For k >= 2 the impulsive start at the step face ends in NaNs after ~20 steps in the
+    reference's algorithm itself, oracle and device alike: the limiter leaves p = 1e-13 at its worst point and the next
+    flux evaluation there takes the root of a pressure that rounding has made negative -- the shipped input avoids it
+    with k = 1 and TVB.)"""
+    gmsh.forward_step(str(tmp_path / "step.msh"), cl=0.1, seed=2)
+    prm = tmp_path / "input.prm"
+    for degree in (3, 1):
+        prm.write_text(STEP_PRM % {"degree": degree})
+        deck = InputDeck.read(str(prm))
+        run = Run(deck, str(tmp_path / ("o%d" % degree)), quiet=True)
+        assert run.mesh.n_cells == 1512 and run.mesh.degree == degree
+        n = 6
+        run.run(max_steps=n)
+        ora, t = _oracle_run(deck, run.mesh, n)
+        assert abs(run.claw.elapsed_time - t) < 1e-10 * t
+        scale = np.abs(ora.get_solution()).max()
+        assert np.abs(run.claw.cell_average - ora.get_cell_average()).max() < 1e-9 * scale
+        assert np.abs(run.claw.current_solution - ora.get_solution()).max() < 1e-7 * scale
+    # longer, device-resident (k = 1)
+    v = run.mesh.vertices
+    x, y = v[:, :, 0], v[:, :, 1]
+    area = 0.5 * np.abs((x[:, 0] * y[:, 1] - x[:, 1] * y[:, 0]) + (x[:, 1] * y[:, 3] - x[:, 3] * y[:, 1]) +
+                        (x[:, 3] * y[:, 2] - x[:, 2] * y[:, 3]) + (x[:, 2] * y[:, 0] - x[:, 0] * y[:, 2]))
+    assert abs(area.sum() - 2.52) < 1e-12
+    m0, t0 = (run.claw.cell_average[:, 2] * area).sum(), run.claw.elapsed_time
+    run.claw.advance(150)
+    t1 = run.claw.elapsed_time
+    assert 0.05 < t1 < 0.5                        # the corner's disturbance (speed u + c = 4) has not reached the outlet
+    a = run.claw.cell_average
+    assert np.isfinite(a).all() and a[:, 2].min() > 0.1
+    p = 0.4 * (a[:, 3] - 0.5 * (a[:, 0] ** 2 + a[:, 1] ** 2) / a[:, 2])
+    assert p.min() > 0.1 and p.max() > 5.0        # and there is a shock in front of the step (p2/p1 = 10.3 at Mach 3)
+    up = x.max(axis=1) < 0.25                     # Mach 3: nothing travels upstream, the bow shock forms at the step
+    assert np.abs(a[up] - np.array([4.2, 0.0, 1.4, 8.8])).max() < 1e-9
+    dm = (a[:, 2] * area).sum() - m0
+    assert abs(dm - 4.2 * (1.0 - 0.8) * (t1 - t0)) < 2e-3 * 4.2 * (t1 - t0)
