@@ -646,11 +646,11 @@ __global__ __launch_bounds__(64 * N, ((GEO == 1 && N != 3) || N == 4) ? 2 : 3) v
   const bool active = lane < hdr.x;
   double urow[4][N];                                  // node row `row` of the own cells
   {
-    const double *up = a.Ucur + (size_t)shard * NDOF * 64 + lane;
+    const double *up = a.Ucur + (size_t)shard * NDOF * 64 + (size_t)(N * row) * 64 + lane;   // one base, constant offsets
 #pragma unroll
     for (int c = 0; c < 4; ++c)
 #pragma unroll
-      for (int m = 0; m < N; ++m) urow[c][m] = up[(c * NS + m + N * row) * 64];
+      for (int m = 0; m < N; ++m) urow[c][m] = up[(c * NS + m) * 64];
   }
   double uavg[4];
   if constexpr (FLUX == DFLO_FLUX_LXF) {
@@ -686,11 +686,11 @@ __global__ __launch_bounds__(64 * N, ((GEO == 1 && N != 3) || N == 4) ? 2 : 3) v
   if constexpr (MODE != 2) dt_step = a.dt_cell ? a.dt_cell[(size_t)shard * 64 + lane] : (a.dt_host >= 0.0 ? a.dt_host : *a.dt_dev);
   double uold[4][N];
   if constexpr (MODE == 1) {
-    const double *op = a.Uold + (size_t)shard * NDOF * 64 + lane;
+    const double *op = a.Uold + (size_t)shard * NDOF * 64 + (size_t)(N * row) * 64 + lane;
 #pragma unroll
     for (int c = 0; c < 4; ++c)
 #pragma unroll
-      for (int m = 0; m < N; ++m) uold[c][m] = op[(c * NS + m + N * row) * 64];
+      for (int m = 0; m < N; ++m) uold[c][m] = op[(c * NS + m) * 64];
   }
 
   PHASE_MARK(0);
