@@ -907,3 +907,28 @@ def test_limiter_marks_from_the_stage_kernel(degree, M, monkeypatch):
     assert rel(runs["1"].cell_average, ora.get_cell_average()) < 1e-9
     t1, t0 = runs["1"].advance(5), runs["0"].advance(5)
     assert abs(t1 - t0) <= 1e-12 * t0 and rel(runs["1"].current_solution, runs["0"].current_solution) < 1e-10
+
+
+def test_c1_configuration_100_steps():
+    """BASELINE config 1 to the letter: [-5,5]^2, 64 x 64 squares, periodic, Q1 (SSP-RK2), LxF, cfl 0.9, the
+    src/ vortex -- residual of the initial state and the solution after 100 steps against the oracle, once step by step
+    and once with the time step resident on the device."""
+    mesh, prm, claw, ora = make_pair(64, 64, 1, "lxf")
+    assert mesh.n_cells * mesh.ndof == 65536
+    u0 = mesh.interpolate(problems.isentropic_vortex)
+    claw.set_initial_condition(u0)
+    ora.set_solution(u0)
+    assert rel(claw.assemble_system(), ora.assemble()) < 1e-12
+    t = 0.0
+    for it in range(100):
+        dt = ora.compute_time_step(t)
+        assert abs(claw.compute_time_step() - dt) <= 1e-13 * dt
+        claw.iterate_explicit(dt)
+        ora.step(dt)
+        t += dt
+    uo = ora.get_solution()
+    assert rel(claw.current_solution, uo) < 1e-11 and rel(claw.cell_average, ora.get_cell_average()) < 1e-12
+    fast = dflo_amd.ConservationLaw(mesh, prm)
+    fast.set_initial_condition(u0)
+    t2 = fast.advance(100)
+    assert abs(t2 - t) <= 1e-12 * t and rel(fast.current_solution, uo) < 1e-11
