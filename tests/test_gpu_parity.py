@@ -932,3 +932,38 @@ def test_c1_configuration_100_steps():
     fast.set_initial_condition(u0)
     t2 = fast.advance(100)
     assert abs(t2 - t) <= 1e-12 * t and rel(fast.current_solution, uo) < 1e-11
+
+
+def test_c3_full_size_properties():
+    """BASELINE config 3 at full size (2048 x 256 squares, Q1, Roe, TVB(M=0, beta=2, characteristic) + positivity, 100 steps):
+    size-independent properties -- the flow stays one-dimensional (every row of cells carries the same averages, the
+    y-momentum stays zero), mass and energy change only through the (still undisturbed) ends, the limiters keep the
+    state admissible, and the waves sit where the exact Riemann solution puts them."""
+    nx, ny = 2048, 256
+    bnd = {0: "slip", 1: "outflow", 2: "inflow"}
+    mesh = dflo_amd.Mesh.cartesian(nx, ny, 0.0, 0.0, 1.0 / nx, [2, 1, 0, 0], 1)
+    prm = dflo_amd.Parameters(flux="roe", limiter="TVB", char_lim=True, pos_lim=True, M=0.0, beta=2.0, boundary=bnd, cfl=0.9)
+    claw = dflo_amd.ConservationLaw(mesh, prm)
+    cell, face, bid, xy = claw.boundary_faces()
+    bv = np.stack(problems.sod(xy[..., 0], xy[..., 1]), axis=-1)
+    claw.set_boundary_values(0, bv)
+    claw.set_boundary_values(1, bv)
+    claw.set_initial_condition(mesh.interpolate(problems.sod))
+    claw.apply_limiter()
+    a0 = claw.cell_average.reshape(ny, nx, 4)
+    t = claw.advance(100)
+    a = claw.cell_average.reshape(ny, nx, 4)
+    assert np.isfinite(a).all()
+    assert np.abs(a - a[:1]).max() < 1e-12 and np.abs(a[..., 1]).max() < 1e-13          # one-dimensional
+    rho, E = a[0, :, 2], a[0, :, 3]
+    p = 0.4 * (E - 0.5 * a[0, :, 0] ** 2 / rho)
+    assert rho.min() > 0.124 and p.min() > 0.099 and rho.max() < 1.0 + 1e-9
+    assert abs(rho.sum() - a0[0, :, 2].sum()) < 1e-9 * nx and abs(E.sum() - a0[0, :, 3].sum()) < 1e-9 * nx   # nothing has reached the ends
+    x = (np.arange(nx) + 0.5) / nx
+    assert np.abs(rho - _sod_exact(x, t)).mean() < 3.0e-3                                  # smeared over a few cells at each wave
+    # positions: the contact (rho jump 0.4263 -> 0.2656) and the shock (0.2656 -> 0.125) within two cells of the exact ones
+    for lo, hi, speed in ((0.2656, 0.4263, 0.92745), (0.125, 0.2656, 1.75216)):
+        mid = 0.5 * (lo + hi)
+        i = np.nonzero((rho[:-1] >= mid) & (rho[1:] < mid))[0]
+        i = i[x[i] > 0.5]
+        assert len(i) == 1 and abs(x[i[0]] - (0.5 + speed * t)) < 3.0 / nx
