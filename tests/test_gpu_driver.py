@@ -342,10 +342,13 @@ def _vtu_field(path, name):
     return a.reshape(-1, nc) if nc > 1 else a
 
 
-@pytest.mark.parametrize("case", ["sod-Qk", "sod-Pk", "dmr", "vortex"])
+@pytest.mark.parametrize("case", ["sod-Qk", "sod-Pk", "dmr", "vortex", "step"])
 def test_cxx_driver_matches_python_driver(tmp_path, case):
     import subprocess
-    if case.startswith("sod"):
+    if case == "step":   # unstructured quadrilaterals, mapping q1, KFVS, positivity alone (C5's path)
+        gmsh.forward_step(str(tmp_path / "step.msh"), cl=0.1, seed=2)
+        text, steps = STEP_PRM % {"degree": 2}, 8
+    elif case.startswith("sod"):
         gmsh.sod_tube(str(tmp_path / "tube.msh"), nx=41, ny=5)
         text, steps = SOD_PRM.replace("set basis = Qk", "set basis = " + case[4:]), 12
     elif case == "dmr":
