@@ -1,0 +1,214 @@
+// kernels_common.hpp -- kernel argument blocks and the helpers every kernel uses
+// Part of the device side of engine.hip (see there for the layout of the data and of a stage).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/dflo_hip.h"
+#include "basis.h"
+#include "physics.hpp"
+#include "plan.h"
+
+
+namespace dflo {
+
+
+// ------------------------------------------------------------------ kernel arguments
+struct KBasis {       // 1-D tables, see basis.h
+  double w[kMaxN];
+  double iw[kMaxN];  // 1 / w
+  double x[kMaxN];
+  double L0[kMaxN], L1[kMaxN];
+  double D[kMaxN][kMaxN];   // D[q][a] = l_a'(x_q)
+  double DW[kMaxN][kMaxN];  // D[q][a] * w[q]
+  double Pg[kMaxGLL][kMaxN];
+  double Pt[kTrap][kMaxN];
+  double PLg[kMaxGLL][kMaxN];  // Pk: orthonormal Legendre Pt_n at the Gauss-Lobatto points
+  double PLx[kMaxN][kMaxN];    // Pk: Pt_n at the Gauss points
+  double pg_neg;               // max over the Gauss-Lobatto points of the sum of the negative weights in Pg
+  int Ng;
+};
+
+#ifdef DFLO_PHASE_TIMING
+#define PHASE_MARK(i) do { if (lane == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tacc[i] += t_ - tlast; tlast = t_; } } while (0)
+#else
+#define PHASE_MARK(i) do { } while (0)
+#endif
+
+struct StageArgs {
+  unsigned long long *phase_cycles;  // [grid][4 waves][8], only with DFLO_PHASE_TIMING
+  const double *Ucur, *Uold;
+  double *Unew;
+  const double *avg_cur;
+  double *avg_new;
+  double *rhs_out;  // parity hook: write the assembled rhs instead of updating
+  const int32_t *shard_count;
+  const int4 *shard_hdr;      // {cells, faces, halo cells, 0}
+  const int32_t *halo_pad;    // [n_shards][halo_pitch]: internal cell slot | local face << 28
+  int halo_pitch, halo_stride;
+  const uint32_t *faces_pad;  // [n_shards][face_pitch] packed face records (pface_*)
+  const int32_t *bnd_pad;     // [n_shards][bnd_pitch] boundary-face index of the shard's l-th boundary face
+  int bnd_pitch;
+  int face_pitch;
+  const uint16_t *cell_face;
+  const double *cell_h;
+  const double *cell_vert;    // GEO 1: [8][n_slots]
+  const double *fgeom_pad;    // GEO 1: [n_shards][3][face_pitch] (nx, ny, length) of each face record
+  int n_slots;
+  const double *bval;
+  const int32_t *bface_kind;
+  const double *dt_dev;   // device-resident global dt (used when dt_host < 0)
+  const double *dt_cell;  // local time stepping: per internal slot, else null
+  double *shard_res, *shard_dtmin;
+  double dt_host, ark, gravity, cfl, h_uniform;
+  int n_shards, max_fp, max_faces, max_bnd, uniform_h, want_dt, degree, prefetch_ahead;
+  const int32_t *shard_list;  // null: all shards; else the n_list shards of this launch (rim / interior)
+  int n_list;
+  int *flags;   // POS 1: [0] negative mean state, [1] positivity root failure (as LimArgs::flags)
+  unsigned long long *lim_mask;   // POS 2: [n_shards] bit = the limiter pass may have something to do in that cell
+  double tvb_M;                   // POS 2: TVB constant M, < 0: the limiter pass has no TVB part
+  int tvb_char, pos_check;        // POS 2: characteristic limiting; the positivity limiter runs in the pass
+  KBasis kb;
+};
+
+// compute_time_step_cartesian for one cell, src/claw.cc:495-509
+__device__ __forceinline__ double cfl_dt(const double *A, double h, double cfl, int degree) {
+  const double sonic = sqrt(kGamma * pressure(A) / A[RHO]);
+  const double maxeig = (sonic + fabs(A[MX] / A[RHO])) / h + (sonic + fabs(A[MY] / A[RHO])) / h;
+  return cfl / maxeig / (2.0 * degree + 1.0);
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_min(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// Wave-wide sum / minimum through DPP (row shifts inside the rows of 16 lanes, then row_bcast:15 / row_bcast:31): the
+// total arrives in lane 63 after six dependent VALU steps, where the shuffle loops above take six round trips through the
+// LDS crossbar.  Lanes without a source keep the identity (`old` operand, bound_ctrl off).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_f64(double ident, double v) {
+  const int lo = __builtin_amdgcn_update_dpp(__double2loint(ident), __double2loint(v), CTRL, ROW_MASK, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(__double2hiint(ident), __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_sum_lane63(double v) {
+  v += dpp_f64<0x111, 0xf>(0.0, v);   // row_shr:1
+  v += dpp_f64<0x112, 0xf>(0.0, v);   // row_shr:2
+  v += dpp_f64<0x114, 0xf>(0.0, v);   // row_shr:4
+  v += dpp_f64<0x118, 0xf>(0.0, v);   // row_shr:8  -> lane 15 of each row holds the row total
+  v += dpp_f64<0x142, 0xa>(0.0, v);   // row_bcast:15 into rows 1 and 3
+  v += dpp_f64<0x143, 0xc>(0.0, v);   // row_bcast:31 into rows 2 and 3
+  return v;
+}
+__device__ __forceinline__ double wave_min_lane63(double v) {
+  constexpr double big = 1.0e300;
+  v = fmin(v, dpp_f64<0x111, 0xf>(big, v));
+  v = fmin(v, dpp_f64<0x112, 0xf>(big, v));
+  v = fmin(v, dpp_f64<0x114, 0xf>(big, v));
+  v = fmin(v, dpp_f64<0x118, 0xf>(big, v));
+  v = fmin(v, dpp_f64<0x142, 0xa>(big, v));
+  v = fmin(v, dpp_f64<0x143, 0xc>(big, v));
+  return v;
+}
+
+// blockIdx -> shard so that every XCD (block b runs on XCD b % 8) sweeps one contiguous run of
+// the Morton-ordered shards: halo re-reads then hit that XCD's own L2.
+__device__ __forceinline__ int shard_of_block(int b, int n_shards) {
+  const int chunk = (n_shards + 7) >> 3;
+  const int s = (b & 7) * chunk + (b >> 3);
+  return (b >> 3) < chunk && s < n_shards ? s : -1;
+}
+
+// ------------------------------------------------------------------ positivity limiter, pointwise parts
+// (shared by limiter_kernel and the stage kernels that apply the limiter on the way out, so that both round alike)
+__device__ __forceinline__ double positivity_blend(double theta, double u, double avg) {   // src/positivity.cc:84-87, 196-199
+  return fma(theta, u, (1.0 - theta) * avg);
+}
+// theta of one point W with pressure below eps: root of the pressure along the segment mean -> W (src/positivity.cc:138-178);
+// 1 if the pressure is fine there
+__device__ __forceinline__ double positivity_theta2(const double (&W)[4], const double (&A)[4], double eps, bool &fail) {
+  const double pre = kG1 * (W[EN] - 0.5 * (W[MX] * W[MX] + W[MY] * W[MY]) * frcp(W[RHO]));
+  if (!(pre < eps)) return 1.0;
+  const double drho = W[RHO] - A[RHO], dmx = W[MX] - A[MX], dmy = W[MY] - A[MY], dE = W[EN] - A[EN];
+  const double a1 = 2.0 * drho * dE - (dmx * dmx + dmy * dmy);
+  double b1 = 2.0 * drho * (A[EN] - eps / kG1) + 2.0 * A[RHO] * dE - 2.0 * (A[MX] * dmx + A[MY] * dmy);
+  double c1 = 2.0 * A[RHO] * A[EN] - (A[MX] * A[MX] + A[MY] * A[MY]) - 2.0 * eps * A[RHO] / kG1;
+  b1 /= a1;
+  c1 /= a1;
+  const double D = sqrt(fabs(b1 * b1 - 4.0 * c1));
+  const double t1 = 0.5 * (-b1 - D), t2 = 0.5 * (-b1 + D);
+  double t;
+  if (t1 > -1.0e-12 && t1 < 1.0 + 1.0e-12) t = t1;
+  else if (t2 > -1.0e-12 && t2 < 1.0 + 1.0e-12) t = t2;
+  else { fail = true; t = 0.0; }
+  t = smin(1.0, t);
+  t = smax(0.0, t);
+  if (fabs(1.0 - t) < 1.0e-14) t = 0.0;
+  return t;
+}
+
+// Row b of every cell (wave b) leaves the extremes of its new values in LDS, pb[(2 c + {0: min, 1: max}) N + b][64]; a NaN or
+// Inf anywhere in the row turns the density minimum into a NaN.
+template <int N, int B>
+__device__ __forceinline__ void positivity_row_bounds(double *pb, int lane, const double (&unew)[4][N]) {
+  double chk = 0.0, lo_[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    double lo = unew[c][0], hi = unew[c][0];
+    chk += unew[c][0];
+#pragma unroll
+    for (int m = 1; m < N; ++m) {
+      lo = fmin(lo, unew[c][m]);
+      hi = fmax(hi, unew[c][m]);
+      chk += unew[c][m];
+    }
+    lo_[c] = lo;
+    pb[((2 * c + 1) * N + B) * 64 + lane] = hi;
+  }
+  lo_[RHO] += chk - chk;   // 0, or NaN if anything in the row is not finite
+#pragma unroll
+  for (int c = 0; c < 4; ++c) pb[((2 * c) * N + B) * 64 + lane] = lo_[c];
+}
+
+// The cell's nodal box from the row extremes left by positivity_row_bounds, and the test on it: a point value on a line
+// through Gauss nodes lies within [lo - d s, hi + d s] (d = hi - lo, s = sum of the negative Gauss-Lobatto interpolation
+// weights); if the lowest density and pressure of that box are safely positive the positivity limiter has nothing to do.
+template <int N>
+__device__ __forceinline__ bool positivity_box_settled(const double *pb, int lane, double sn) {
+  double lo[4], hi[4];
+  bool fin = true;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    lo[c] = pb[((2 * c) * N) * 64 + lane];
+    hi[c] = pb[((2 * c + 1) * N) * 64 + lane];
+    if (c == RHO) fin = fin && lo[c] == lo[c];
+#pragma unroll
+    for (int b = 1; b < N; ++b) {
+      const double l = pb[((2 * c) * N + b) * 64 + lane];
+      if (c == RHO) fin = fin && l == l;
+      lo[c] = fmin(lo[c], l);
+      hi[c] = fmax(hi[c], pb[((2 * c + 1) * N + b) * 64 + lane]);
+    }
+  }
+  const double rho_lo = lo[RHO] - (hi[RHO] - lo[RHO]) * sn, e_lo = lo[EN] - (hi[EN] - lo[EN]) * sn;
+  const double dmx = (hi[MX] - lo[MX]) * sn, dmy = (hi[MY] - lo[MY]) * sn;
+  const double mxa = fmax(fabs(lo[MX] - dmx), fabs(hi[MX] + dmx)), mya = fmax(fabs(lo[MY] - dmy), fabs(hi[MY] + dmy));
+  const double p_lo = kG1 * (e_lo - 0.5 * (mxa * mxa + mya * mya) * frcp(rho_lo));
+  return fin && rho_lo >= 1.0e-10 + 1.0e-8 * hi[RHO] && p_lo >= 1.0e-10 + 1.0e-8 * fabs(hi[EN]);
+}
+
+
+}  // namespace dflo

@@ -1,0 +1,455 @@
+// limiter_kernels.hpp -- time step of bilinear cells, TVB / positivity limiter passes (Qk, Pk), KXRCF indicator
+// Part of the device side of engine.hip (see there for the layout of the data and of a stage).
+#pragma once
+#include "kernels_common.hpp"
+
+namespace dflo {
+
+// compute_time_step_q for one cell (src/claw.cc:520-557): max of |v| + c over the 4 x 4 points of QIterated(QTrapez,3),
+// dt = cfl h / lambda / (2k+1).  U: the cell's DoFs [4][N*N]; the interpolation is sum-factorised, one point row at a time.
+template <int N>
+__device__ __forceinline__ double dt_q_cell(const double *U, const KBasis &kb, double h, double cfl, int degree) {
+  constexpr int NS = N * N;
+  double maxeig = 0.0;
+#pragma unroll
+  for (int pa = 0; pa < kTrap; ++pa) {
+    double v[4][N];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int b = 0; b < N; ++b) {
+        double t = 0;
+#pragma unroll
+        for (int aa = 0; aa < N; ++aa) t += kb.Pt[pa][aa] * U[c * NS + aa + N * b];
+        v[c][b] = t;
+      }
+#pragma unroll
+    for (int pb = 0; pb < kTrap; ++pb) {
+      double w[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        double t = 0;
+#pragma unroll
+        for (int b = 0; b < N; ++b) t += kb.Pt[pb][b] * v[c][b];
+        w[c] = t;
+      }
+      maxeig = fmax(maxeig, max_eigenvalue(w));
+    }
+  }
+  return cfl * h / maxeig / (2.0 * degree + 1.0);
+}
+
+// ------------------------------------------------------------------ limiter kernel
+struct LimArgs {
+  double *U;
+  const double *avg;
+  const int32_t *shard_count;
+  const int32_t *lrbt;
+  const double *cell_h;
+  int *flags;  // [0] negative mean state, [1] positivity root failure
+  double h_uniform, M, beta;
+  int n_shards, uniform_h, tvb, char_lim, pos_lim;
+  const int32_t *shard_list;
+  int n_list;
+  const double *shock;  // KXRCF indicator per cell, or null: "shock indicator = limiter" marks every cell (1e20)
+  unsigned long long *mask;   // [n_shards] from the stage kernel: the cells this pass can change (cleared here), or null: all cells
+  // bilinear cells, last stage: the time step of the limited solution is formed here, while the cell is in registers
+  double *shard_dtmin, *dt_cell;
+  double cfl;
+  int degree, dtq;
+  KBasis kb;
+};
+
+// apply_limiter_TVB_Qk (src/limiter.cc:225-370) then apply_positivity_limiter
+// (src/positivity.cc:17-208), lane = cell, all DoFs of the cell in registers.
+template <int N>
+__global__ __launch_bounds__(64) void limiter_kernel(const LimArgs a) {
+  constexpr int NS = N * N, NDOF = 4 * NS;
+  const int sidx = shard_of_block(blockIdx.x, a.n_list);
+  if (sidx < 0) return;
+  const int shard = a.shard_list ? a.shard_list[sidx] : sidx;
+  const int lane = threadIdx.x;
+  const bool active = lane < a.shard_count[shard];   // padding lanes hold a harmless state and run along
+  const KBasis &kb = a.kb;
+  double *up = a.U + (size_t)shard * NDOF * 64 + lane;
+  double U[NDOF], A[4];
+  // With the stage kernel's marks only the cells the limiters can change go through the pass (the others are provably left
+  // as they are, see the stage kernel): most wavefronts return after one load.
+  bool marked = true;
+  if (a.mask) {
+    const unsigned long long m = a.mask[shard];
+    if (m == 0) return;
+    if (lane == 0) a.mask[shard] = 0;   // consumed (the load above has returned: m was compared)
+    marked = (m >> lane) & 1;
+  }
+  if (marked) {
+#pragma unroll
+    for (int d = 0; d < NDOF; ++d) U[d] = up[d * 64];
+  }
+#pragma unroll
+  for (int c = 0; c < 4; ++c) A[c] = a.avg[((size_t)shard * 4 + c) * 64 + lane];
+  const double h = a.uniform_h ? a.h_uniform : a.cell_h[(size_t)shard * 64 + lane];
+  bool changed = false;
+
+  if (a.tvb && marked && (!a.shock || a.shock[(size_t)shard * 64 + lane] > 1.0)) {  // src/limiter.cc:263,406
+    const double dx = h;  // diameter/sqrt(2) of a square
+    const double Mdx2 = a.M * dx * dx;
+    // one direction after the other (x: left/right neighbours, y: bottom/top), so that only one set of differences
+    // is alive at a time
+    EigenXY e;
+    if (a.char_lim) e = eigen_at(A);
+    double Dxn[4], Dyn[4], change_x = 0, change_y = 0;
+#pragma unroll
+    for (int dir = 0; dir < 2; ++dir) {
+      double D[4], db[4], df[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {   // dx * cell-average gradient, see above; l_m(1) - l_m(0) is antisymmetric in m, and
+        double g = 0;                  // pairing the nodes makes the slope of a constant state exactly zero
+#pragma unroll
+        for (int b = 0; b < N; ++b)
+#pragma unroll
+          for (int m = 0; m < N / 2; ++m) {
+            const int j0 = dir == 0 ? m + N * b : b + N * m, j1 = dir == 0 ? (N - 1 - m) + N * b : b + N * (N - 1 - m);
+            g += CB<N>::t.w[b] * (CB<N>::t.L1[m] - CB<N>::t.L0[m]) * (U[c * NS + j0] - U[c * NS + j1]);
+          }
+        D[c] = g;
+      }
+      // the boundary case "no neighbour: difference = own slope" (:296-316) is resolved before the projection
+      const double D0[4] = {D[0], D[1], D[2], D[3]};
+      if (a.char_lim) to_char(e, dir, D);
+      // minmod returns its first argument untouched when |a| < M dx^2 (src/limiter.cc:21): if that holds for
+      // every component of every cell of the wavefront, the neighbour differences are not needed at all
+      bool smooth = true;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) smooth = smooth && (fabs(D[i]) < Mdx2 || D[i] == 0.0);   // minmod(0, b, c) = 0 as well
+      if (__all(smooth)) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          if (dir == 0) Dxn[i] = D[i];
+          else Dyn[i] = D[i];
+        }
+        continue;
+      }
+      const int ib = a.lrbt[((size_t)shard * 4 + 2 * dir) * 64 + lane], ifw = a.lrbt[((size_t)shard * 4 + 2 * dir + 1) * 64 + lane];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        db[c] = ib >= 0 ? A[c] - a.avg[((size_t)(ib >> 6) * 4 + c) * 64 + (ib & 63)] : D0[c];
+        df[c] = ifw >= 0 ? a.avg[((size_t)(ifw >> 6) * 4 + c) * 64 + (ifw & 63)] - A[c] : D0[c];
+      }
+      if (a.char_lim) {
+        to_char(e, dir, db);
+        to_char(e, dir, df);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const double dn = minmod(D[i], a.beta * db[i], a.beta * df[i], Mdx2);
+        if (dir == 0) { Dxn[i] = dn; change_x += fabs(dn - D[i]); }
+        else { Dyn[i] = dn; change_y += fabs(dn - D[i]); }
+      }
+    }
+    change_x *= 0.25;
+    change_y *= 0.25;
+    if (change_x + change_y > 1.0e-10) {  // :347 -- reduce to the limited linear polynomial
+      if (a.char_lim) {
+        to_con(e, 0, Dxn);
+        to_con(e, 1, Dyn);
+      }
+      // u = A + (x - x_c) Dxn/dx + (y - y_c) Dyn/dx with x - x_c = dx (xi - 1/2): the division by dx (:349) and
+      // the factor dx cancel
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int j = 0; j < NS; ++j)
+          U[c * NS + j] = A[c] + (CB<N>::t.x[j % N] - 0.5) * Dxn[c] + (CB<N>::t.x[j / N] - 0.5) * Dyn[c];
+      changed = true;
+    }
+  }
+
+  if (a.pos_lim && marked) {
+    const double eps = 1.0e-13;
+    if (smin(A[RHO], pressure(A)) < eps) {  // "Fatal: Negative states" :26-38
+      if (active) atomicOr(&a.flags[0], 1);
+    } else {
+      // density at GLL(Ng) x Gauss(N) and Gauss(N) x GLL(Ng)  (:43-47, :72-78)
+      double rho_min = 1.0e20;
+#pragma unroll
+      for (int l = 0; l < N; ++l)
+        for (int g = 0; g < a.kb.Ng; ++g) {
+          double vx = 0, vy = 0;
+#pragma unroll
+          for (int m = 0; m < N; ++m) {
+            vx += kb.Pg[g][m] * U[RHO * NS + m + N * l];
+            vy += kb.Pg[g][m] * U[RHO * NS + l + N * m];
+          }
+          rho_min = smin(smin(rho_min, vx), vy);
+        }
+      const double rat = fabs(A[RHO] - eps) * frcp(fabs(A[RHO] - rho_min) + 1.0e-13);
+      const double theta1 = smin(rat, 1.0);
+      if (theta1 < 1.0) {
+#pragma unroll
+        for (int j = 0; j < NS; ++j) U[RHO * NS + j] = positivity_blend(theta1, U[RHO * NS + j], A[RHO]);
+        changed = true;
+      }
+      double theta2 = 1.0;
+      bool fail = false;
+#pragma unroll
+      for (int dir = 0; dir < 2; ++dir)
+#pragma unroll
+        for (int l = 0; l < N; ++l)
+          for (int g = 0; g < a.kb.Ng; ++g) {
+            double W[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              double v = 0;
+#pragma unroll
+              for (int m = 0; m < N; ++m) v += kb.Pg[g][m] * (dir == 0 ? U[c * NS + m + N * l] : U[c * NS + l + N * m]);
+              W[c] = v;
+            }
+            theta2 = smin(theta2, positivity_theta2(W, A, eps, fail));
+          }
+      if (fail && active) atomicOr(&a.flags[1], 1);
+      if (theta2 < 1.0) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+          for (int j = 0; j < NS; ++j) U[c * NS + j] = positivity_blend(theta2, U[c * NS + j], A[c]);
+        changed = true;
+      }
+    }
+  }
+  if (changed && active) {
+#pragma unroll
+    for (int d = 0; d < NDOF; ++d) up[d * 64] = U[d];
+  }
+  if (a.dtq) {   // wave-uniform
+    double dtmin = 1.0e20;
+    if (active) {
+      dtmin = dt_q_cell<N>(U, kb, h, a.cfl, a.degree);
+      if (a.dt_cell) a.dt_cell[(size_t)shard * 64 + lane] = dtmin;
+    }
+    dtmin = wave_min(dtmin);
+    if (lane == 0) a.shard_dtmin[shard] = dtmin;
+  }
+}
+
+// apply_limiter_TVB_Pk (src/limiter.cc:377-516) then the Pk branch of apply_positivity_limiter
+// (src/positivity.cc:100-109, 197-205); lane = cell, all modes in registers
+template <int N>
+__global__ __launch_bounds__(64) void limiter_pk_kernel(const LimArgs a) {
+  constexpr int NM = N * (N + 1) / 2, NDOFM = 4 * NM;
+  const int sidx = shard_of_block(blockIdx.x, a.n_list);
+  if (sidx < 0) return;
+  const int shard = a.shard_list ? a.shard_list[sidx] : sidx;
+  const int lane = threadIdx.x;
+  if (lane >= a.shard_count[shard]) return;
+  double *up = a.U + (size_t)shard * NDOFM * 64 + lane;
+  double U[4][NM], A[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int m = 0; m < NM; ++m) U[c][m] = up[(c * NM + m) * 64];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) A[c] = a.avg[((size_t)shard * 4 + c) * 64 + lane];
+  const double h = a.uniform_h ? a.h_uniform : a.cell_h[(size_t)shard * 64 + lane];
+  bool changed = false;
+  const double sqrt_3 = 1.7320508075688772935;
+  if (a.tvb && (!a.shock || a.shock[(size_t)shard * 64 + lane] > 1.0)) {  // src/limiter.cc:263,406
+    const double dx = h, Mdx2 = a.M * dx * dx, beta = 0.5 * a.beta;   // :396
+    double Dx[4], Dy[4], dbx[4], dfx[4], dby[4], dfy[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      Dx[c] = U[c][1] * sqrt_3;       // mode (1,0)
+      Dy[c] = U[c][N] * sqrt_3;       // mode (0,1) = index k+1
+    }
+    const int il = a.lrbt[((size_t)shard * 4 + 0) * 64 + lane], ir = a.lrbt[((size_t)shard * 4 + 1) * 64 + lane];
+    const int ib = a.lrbt[((size_t)shard * 4 + 2) * 64 + lane], it = a.lrbt[((size_t)shard * 4 + 3) * 64 + lane];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      dbx[c] = il >= 0 ? A[c] - a.avg[((size_t)(il >> 6) * 4 + c) * 64 + (il & 63)] : Dx[c];
+      dfx[c] = ir >= 0 ? a.avg[((size_t)(ir >> 6) * 4 + c) * 64 + (ir & 63)] - A[c] : Dx[c];
+      dby[c] = ib >= 0 ? A[c] - a.avg[((size_t)(ib >> 6) * 4 + c) * 64 + (ib & 63)] : Dy[c];
+      dfy[c] = it >= 0 ? a.avg[((size_t)(it >> 6) * 4 + c) * 64 + (it & 63)] - A[c] : Dy[c];
+    }
+    EigenXY e;
+    if (a.char_lim) {
+      e = eigen_at(A);
+      to_char(e, 0, dbx); to_char(e, 0, dfx); to_char(e, 1, dby); to_char(e, 1, dfy);
+      to_char(e, 0, Dx); to_char(e, 1, Dy);
+    }
+    double Dxn[4], Dyn[4], change_x = 0, change_y = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      Dxn[i] = minmod(Dx[i], beta * dbx[i], beta * dfx[i], Mdx2);
+      Dyn[i] = minmod(Dy[i], beta * dby[i], beta * dfy[i], Mdx2);
+      change_x += fabs(Dxn[i] - Dx[i]);
+      change_y += fabs(Dyn[i] - Dy[i]);
+    }
+    change_x /= 4;
+    change_y /= 4;
+    if (change_x + change_y > 1.0e-10) {
+      if (a.char_lim) {
+        to_con(e, 0, Dxn);
+        to_con(e, 1, Dyn);
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int m = 1; m < NM; ++m) U[c][m] = m == 1 ? Dxn[c] * (1.0 / sqrt_3) : (m == N ? Dyn[c] * (1.0 / sqrt_3) : 0.0);
+      changed = true;
+    }
+  }
+  if (a.pos_lim) {
+    const double eps = 1.0e-13;
+    if (smin(A[RHO], pressure(A)) < eps) {
+      atomicOr(&a.flags[0], 1);
+    } else {
+      // point value of component c at (Pt(xi), Pt(eta)) given the 1-D Legendre values
+      auto point = [&](int c, const double *pxi, const double *peta) {
+        double v = 0.0;
+#pragma unroll
+        for (int m = 0; m < NM; ++m) v += pxi[PB<N>::t.mi[m]] * peta[PB<N>::t.mj[m]] * U[c][m];
+        return v;
+      };
+      double rho_min = 1.0e20;
+      for (int l = 0; l < N; ++l)
+        for (int g = 0; g < a.kb.Ng; ++g) {
+          double pg[N], pl[N];
+#pragma unroll
+          for (int n = 0; n < N; ++n) { pg[n] = a.kb.PLg[g][n]; pl[n] = a.kb.PLx[l][n]; }
+          rho_min = smin(smin(rho_min, point(RHO, pg, pl)), point(RHO, pl, pg));
+        }
+      const double rat = fabs(A[RHO] - eps) * frcp(fabs(A[RHO] - rho_min) + 1.0e-13);
+      const double theta1 = smin(rat, 1.0);
+      if (theta1 < 1.0) {
+#pragma unroll
+        for (int m = 1; m < NM; ++m) U[RHO][m] *= theta1;
+        changed = true;
+      }
+      double theta2 = 1.0;
+      bool fail = false;
+      for (int dir = 0; dir < 2; ++dir)
+        for (int l = 0; l < N; ++l)
+          for (int g = 0; g < a.kb.Ng; ++g) {
+            double pg[N], pl[N], W[4];
+#pragma unroll
+            for (int n = 0; n < N; ++n) { pg[n] = a.kb.PLg[g][n]; pl[n] = a.kb.PLx[l][n]; }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) W[c] = dir == 0 ? point(c, pg, pl) : point(c, pl, pg);
+            const double pre = kG1 * (W[EN] - 0.5 * (W[MX] * W[MX] + W[MY] * W[MY]) * frcp(W[RHO]));
+            if (pre < eps) {
+              const double drho = W[RHO] - A[RHO], dmx = W[MX] - A[MX], dmy = W[MY] - A[MY], dE = W[EN] - A[EN];
+              const double a1 = 2.0 * drho * dE - (dmx * dmx + dmy * dmy);
+              double b1 = 2.0 * drho * (A[EN] - eps / kG1) + 2.0 * A[RHO] * dE - 2.0 * (A[MX] * dmx + A[MY] * dmy);
+              double c1 = 2.0 * A[RHO] * A[EN] - (A[MX] * A[MX] + A[MY] * A[MY]) - 2.0 * eps * A[RHO] / kG1;
+              b1 /= a1;
+              c1 /= a1;
+              const double D = sqrt(fabs(b1 * b1 - 4.0 * c1));
+              const double t1 = 0.5 * (-b1 - D), t2 = 0.5 * (-b1 + D);
+              double t;
+              if (t1 > -1.0e-12 && t1 < 1.0 + 1.0e-12) t = t1;
+              else if (t2 > -1.0e-12 && t2 < 1.0 + 1.0e-12) t = t2;
+              else { fail = true; t = 0.0; }
+              t = smin(1.0, t);
+              t = smax(0.0, t);
+              if (fabs(1.0 - t) < 1.0e-14) t = 0.0;
+              theta2 = smin(theta2, t);
+            }
+          }
+      if (fail) atomicOr(&a.flags[1], 1);
+      if (theta2 < 1.0) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+          for (int m = 1; m < NM; ++m) U[c][m] *= theta2;
+        changed = true;
+      }
+    }
+  }
+  if (changed) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int m = 1; m < NM; ++m) up[(c * NM + m) * 64] = U[c][m];
+  }
+}
+
+// ------------------------------------------------------------------ KXRCF troubled-cell indicator
+struct IndArgs {
+  const double *U, *avg;
+  double *shock;  // [n_slots]
+  const int32_t *shard_count, *lrbt;
+  const uint8_t *nbr_code;
+  const double *cell_h;
+  double h_uniform;
+  int uniform_h, component, degree;
+  const int32_t *shard_list;
+  int n_list;
+};
+
+// value of one component at point q of local face f: Qk from the nodes on the line through the face point,
+// Pk from all modes; u points at the component's first DoF of the cell (DoF stride 64)
+template <int N, int PK>
+__device__ __forceinline__ double face_point_value(const double *u, int f, int q) {
+  double v = 0.0;
+  if constexpr (PK == 0) {
+    const int str0 = f < 2 ? 1 : N;
+    const int base = (f < 2 ? N * q : q) + ((f & 1) ? (N - 1) * str0 : 0), str = (f & 1) ? -str0 : str0;
+#pragma unroll
+    for (int m = 0; m < N; ++m) v += CB<N>::t.L0[m] * u[(base + m * str) * 64];
+  } else {
+    constexpr int NM = N * (N + 1) / 2;
+    double pxi[N], peta[N];
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+      double pq = PB<N>::t.Px[0][n];
+#pragma unroll
+      for (int qq = 1; qq < N; ++qq) pq = q == qq ? PB<N>::t.Px[qq][n] : pq;
+      pxi[n] = f == 0 ? PB<N>::t.P0[n] : (f == 1 ? PB<N>::t.P1[n] : pq);
+      peta[n] = f == 2 ? PB<N>::t.P0[n] : (f == 3 ? PB<N>::t.P1[n] : pq);
+    }
+#pragma unroll
+    for (int m = 0; m < NM; ++m) v += pxi[PB<N>::t.mi[m]] * peta[PB<N>::t.mj[m]] * u[m * 64];
+  }
+  return v;
+}
+
+// compute_shock_indicator_kxrcf (src/indicator.cc:51-198), same-level faces, axis-aligned squares; lane = cell.
+// Runs as its own pass between the stage update and the limiter: it reads the neighbours' unlimited DoFs.
+template <int N, int PK>
+__global__ __launch_bounds__(64) void indicator_kernel(const IndArgs a) {
+  constexpr int NS = PK ? N * (N + 1) / 2 : N * N, NDOF = 4 * NS;
+  const int sidx = shard_of_block(blockIdx.x, a.n_list);
+  if (sidx < 0) return;
+  const int shard = a.shard_list ? a.shard_list[sidx] : sidx;
+  const int lane = threadIdx.x;
+  if (lane >= a.shard_count[shard]) return;
+  double A[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) A[c] = a.avg[((size_t)shard * 4 + c) * 64 + lane];
+  const double vel[2] = {A[MX] / A[RHO], A[MY] / A[RHO]};  // :106-108
+  const double h = a.uniform_h ? a.h_uniform : a.cell_h[(size_t)shard * 64 + lane];
+  const double *uo = a.U + ((size_t)shard * NDOF + a.component * NS) * 64 + lane;
+  double ind = 0.0, inflow = 0.0;
+  for (int f = 0; f < 4; ++f) {
+    const int code = a.nbr_code[((size_t)shard * 4 + f) * 64 + lane];
+    if (!(code & 8)) continue;  // boundary (or periodic) face, :169-174
+    const int ns = a.lrbt[((size_t)shard * 4 + f) * 64 + lane], nf = code & 3;
+    const bool flip = (code & 4) != 0;
+    const double *un = a.U + ((size_t)(ns >> 6) * NDOF + a.component * NS) * 64 + (ns & 63);
+    const double vn = f == 0 ? -vel[0] : (f == 1 ? vel[0] : (f == 2 ? -vel[1] : vel[1]));
+    const double inflow_status = vn < 0 ? 1.0 : 0.0;
+#pragma unroll
+    for (int q = 0; q < N; ++q) {
+      const double jxw = CB<N>::t.w[q] * h;
+      const double d = face_point_value<N, PK>(uo, f, q) - face_point_value<N, PK>(un, nf, flip ? N - 1 - q : q);
+      ind += inflow_status * d * jxw;
+      inflow += inflow_status * jxw;
+    }
+  }
+  const double diameter = h * 1.4142135623730950488;
+  const double denominator = pow(diameter, 0.5 * (a.degree + 1)) * inflow * A[a.component];  // :179-181
+  a.shock[(size_t)shard * 64 + lane] = fabs(ind) / denominator;  // 0/0 -> NaN -> "not > 1": not limited, as in the reference
+}
+
+
+}  // namespace dflo

@@ -1,0 +1,336 @@
+// small_kernels.hpp -- boundary programs, layout conversion, halo pack / unpack, averages, time step, reductions
+// Part of the device side of engine.hip (see there for the layout of the data and of a stage).
+#pragma once
+#include "limiter_kernels.hpp"
+
+namespace dflo {
+
+// ------------------------------------------------------------------ boundary functions on the device
+// The boundary values of integrate_boundary_term_explicit (FunctionParser::vector_value_list at the face
+// quadrature points with set_time(bc_time), src/assemble_explicit.cc:161-165, src/claw.cc:736-745) evaluated by
+// the device from postfix programs (dflo_hip_set_boundary_program): no host round trip per step for
+// time-dependent boundary data (C4's moving shock on the top wall).
+struct BcArgs {
+  const int32_t *ops;       // [n][2] (dflo_expr_op, constant index)
+  const double *consts;
+  const int32_t *prog;      // [DFLO_MAX_BOUNDARIES][4][2] (first op, number of ops); 0 ops = values stay as uploaded
+  const int32_t *bface_id;  // [n_bfaces]
+  const double *bxy;        // [n_bfaces][N][2]
+  double *bval0, *bval1;    // [n_bfaces][N][4] tables of RK stage 0 (time t) and of the later stages (t + dt)
+  const double *dt_dev;     // [0] dt, [1] elapsed time
+  double dt_host;
+  const int32_t *faces;     // [n_faces] the boundary faces whose id has a program
+  int n_faces, N, n_ops, n_consts;
+};
+constexpr int kBcLdsOps = 1024, kBcLdsConsts = 256;  // programs up to this size are interpreted out of LDS
+constexpr int kExprStack = 16;
+constexpr int kBcThreads = 512;   // 8 wavefronts: (component, table) pairs over 64 face points
+// Postfix interpreter.  Every lane of the wave runs the SAME program (the caller loops over the programs and masks
+// the store), so the opcode is wave-uniform: it is moved to a scalar register and the switch becomes one scalar
+// jump -- with a per-lane opcode the compiler walks through all forty cases under an execution mask.  The top of
+// the stack lives in a register, the rest in LDS (st[depth][thread]; a private array indexed by the stack pointer
+// would be placed in scratch memory).
+__device__ double run_program(const int32_t *ops, int n, const double *consts, double x, double y, double t, double *st) {
+  double tos = 0.0;
+  int sp = 0;   // entries below the top, kept in st[0 .. sp)
+  for (int i = 0; i < n; ++i) {
+    const int op = __builtin_amdgcn_readfirstlane(ops[2 * i]);
+    if (op <= DFLO_OP_T) {  // pushes
+      st[(sp++) * kBcThreads] = tos;
+      tos = op == DFLO_OP_CONST ? consts[__builtin_amdgcn_readfirstlane(ops[2 * i + 1])] : (op == DFLO_OP_X ? x : (op == DFLO_OP_Y ? y : t));
+      continue;
+    }
+    if (op == DFLO_OP_SEL) {
+      const double b = tos, a = st[(--sp) * kBcThreads], c = st[(--sp) * kBcThreads];
+      tos = c != 0.0 ? a : b;
+      continue;
+    }
+    const bool binary = (op >= DFLO_OP_ADD && op <= DFLO_OP_OR) || op == DFLO_OP_MIN || op == DFLO_OP_MAX || op == DFLO_OP_ATAN2;
+    double a = tos, b = 0.0;
+    if (binary) {
+      b = tos;
+      a = st[(--sp) * kBcThreads];
+    }
+    double r;
+    switch (op) {
+      case DFLO_OP_NEG: r = -a; break;
+      case DFLO_OP_ADD: r = a + b; break;
+      case DFLO_OP_SUB: r = a - b; break;
+      case DFLO_OP_MUL: r = a * b; break;
+      case DFLO_OP_DIV: r = a / b; break;
+      case DFLO_OP_POW: r = pow(a, b); break;
+      case DFLO_OP_LT: r = a < b ? 1.0 : 0.0; break;
+      case DFLO_OP_LE: r = a <= b ? 1.0 : 0.0; break;
+      case DFLO_OP_GT: r = a > b ? 1.0 : 0.0; break;
+      case DFLO_OP_GE: r = a >= b ? 1.0 : 0.0; break;
+      case DFLO_OP_EQ: r = a == b ? 1.0 : 0.0; break;
+      case DFLO_OP_NE: r = a != b ? 1.0 : 0.0; break;
+      case DFLO_OP_AND: r = (a != 0.0 && b != 0.0) ? 1.0 : 0.0; break;
+      case DFLO_OP_OR: r = (a != 0.0 || b != 0.0) ? 1.0 : 0.0; break;
+      case DFLO_OP_SIN: r = sin(a); break;
+      case DFLO_OP_COS: r = cos(a); break;
+      case DFLO_OP_TAN: r = tan(a); break;
+      case DFLO_OP_EXP: r = exp(a); break;
+      case DFLO_OP_LOG: r = log(a); break;
+      case DFLO_OP_SQRT: r = sqrt(a); break;
+      case DFLO_OP_ABS: r = fabs(a); break;
+      case DFLO_OP_MIN: r = fmin(a, b); break;
+      case DFLO_OP_MAX: r = fmax(a, b); break;
+      case DFLO_OP_ATAN2: r = atan2(a, b); break;
+      case DFLO_OP_TANH: r = tanh(a); break;
+      case DFLO_OP_SINH: r = sinh(a); break;
+      case DFLO_OP_COSH: r = cosh(a); break;
+      case DFLO_OP_ASIN: r = asin(a); break;
+      case DFLO_OP_ACOS: r = acos(a); break;
+      case DFLO_OP_ATAN: r = atan(a); break;
+      case DFLO_OP_FLOOR: r = floor(a); break;
+      case DFLO_OP_CEIL: r = ceil(a); break;
+      case DFLO_OP_SIGN: r = a > 0.0 ? 1.0 : (a < 0.0 ? -1.0 : 0.0); break;
+      case DFLO_OP_LOG10: r = log10(a); break;
+      case DFLO_OP_ERF: r = erf(a); break;
+      case DFLO_OP_ERFC: r = erfc(a); break;
+      default: r = __builtin_nan(""); break;
+    }
+    tos = r;
+  }
+  return tos;
+}
+__global__ __launch_bounds__(kBcThreads) void bc_eval_kernel(const BcArgs a) {
+  // the programs are a few hundred words: interpret them out of LDS, not with a dependent global load per opcode
+  __shared__ int32_t s_ops[2 * kBcLdsOps];
+  __shared__ double s_consts[kBcLdsConsts];
+  __shared__ int32_t s_prog[DFLO_MAX_BOUNDARIES * 4 * 2];
+  __shared__ double s_stack[(kExprStack + 1) * kBcThreads];
+  const bool in_lds = a.n_ops <= kBcLdsOps && a.n_consts <= kBcLdsConsts;
+  if (in_lds) {
+    for (int k = threadIdx.x; k < 2 * a.n_ops; k += blockDim.x) s_ops[k] = a.ops[k];
+    for (int k = threadIdx.x; k < a.n_consts; k += blockDim.x) s_consts[k] = a.consts[k];
+  }
+  for (int k = threadIdx.x; k < DFLO_MAX_BOUNDARIES * 4 * 2; k += blockDim.x) s_prog[k] = a.prog[k];
+  __syncthreads();
+  // a block takes 64 (listed face, point) pairs; wavefront w evaluates component w & 3 for the table w >> 2, so the
+  // eight short programs of a point run side by side instead of one after the other in a single thread
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), c = wave & 3, which = wave >> 2;
+  const int j = blockIdx.x * 64 + (threadIdx.x & 63);
+  const bool valid = j < a.n_faces * a.N;
+  const int bf = a.faces[valid ? j / a.N : 0], i = bf * a.N + (valid ? j % a.N : 0);
+  const int id = a.bface_id[bf];
+  const double t = a.dt_dev[1] + (which ? (a.dt_host >= 0.0 ? a.dt_host : a.dt_dev[0]) : 0.0);
+  const double x = a.bxy[2 * i], y = a.bxy[2 * i + 1];
+  double *bval = which ? a.bval1 : a.bval0;
+  for (int b = 0; b < DFLO_MAX_BOUNDARIES; ++b) {
+    const int first = s_prog[(b * 4 + c) * 2], n = s_prog[(b * 4 + c) * 2 + 1];   // wave-uniform
+    if (n == 0) continue;
+    const double v = in_lds ? run_program(s_ops + 2 * first, n, s_consts, x, y, t, s_stack + threadIdx.x)
+                            : run_program(a.ops + 2 * first, n, a.consts, x, y, t, s_stack + threadIdx.x);
+    if (valid && id == b) bval[(size_t)i * 4 + c] = v;
+  }
+}
+
+// accuracy probe of the reciprocal / square-root forms used by the flux functions
+__global__ void debug_math_kernel(const double *x, double *rcp, double *sq, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    rcp[i] = frcp(x[i]);
+    sq[i] = fsqrt(x[i]);
+  }
+}
+
+// ------------------------------------------------------------------ small kernels
+// quadrature weight of node j for the cell average: w_a w_b (squares) or w_a w_b det J / |K| (bilinear cells)
+__device__ __forceinline__ double avg_weight(const KBasis &kb, int N, int j, const double *vert, int n_slots, int slot,
+                                             double inv_area) {
+  if (N < 0) return j == 0 ? 1.0 : 0.0;  // Pk (flagged by N < 0): the average is mode 0
+  const double ww = kb.w[j % N] * kb.w[j / N];
+  if (!vert) return ww;
+  double v[8];
+  for (int k = 0; k < 8; ++k) v[k] = vert[(size_t)k * n_slots + slot];
+  const double xi = kb.x[j % N], eta = kb.x[j / N];
+  const double xxi = (v[2] - v[0]) + eta * ((v[6] - v[4]) - (v[2] - v[0])), yxi = (v[3] - v[1]) + eta * ((v[7] - v[5]) - (v[3] - v[1]));
+  const double xeta = (v[4] - v[0]) + xi * ((v[6] - v[2]) - (v[4] - v[0])), yeta = (v[5] - v[1]) + xi * ((v[7] - v[3]) - (v[5] - v[1]));
+  return ww * (xxi * yeta - xeta * yxi) * inv_area;
+}
+__device__ __forceinline__ double cell_inv_area(const double *vert, int n_slots, int slot) {
+  if (!vert) return 1.0;
+  double v[8];
+  for (int k = 0; k < 8; ++k) v[k] = vert[(size_t)k * n_slots + slot];
+  return 1.0 / (0.5 * fabs((v[0] * v[3] - v[2] * v[1]) + (v[2] * v[7] - v[6] * v[3]) + (v[6] * v[5] - v[4] * v[7]) +
+                           (v[4] * v[1] - v[0] * v[5])));
+}
+// user (dflo) layout <-> shard SoA layout
+__global__ void scatter_kernel(const double *user, double *U, const int32_t *user_of, int n_slots, int ndof) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (long long)n_slots * ndof) return;
+  const int slot = (int)(t / ndof), d = (int)(t - (long long)slot * ndof);
+  const int uc = user_of[slot];
+  const int ns = ndof / 4;
+  // padding slots hold a harmless state (rho = 1, E = 1)
+  const double v = uc >= 0 ? user[(size_t)uc * ndof + d] : ((d / ns) >= 2 ? 1.0 : 0.0);
+  U[((size_t)(slot >> 6) * ndof + d) * 64 + (slot & 63)] = v;
+}
+__global__ void gather_kernel(double *user, const double *U, const int32_t *iid, int n_cells, int ndof) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (long long)n_cells * ndof) return;
+  const int c = (int)(t / ndof), d = (int)(t - (long long)c * ndof);
+  const int slot = iid[c];
+  user[t] = U[((size_t)(slot >> 6) * ndof + d) * 64 + (slot & 63)];
+}
+// pack listed cells (internal slots) cell-major: buf[k][ndof]
+__global__ void pack_kernel(double *buf, const double *U, const int32_t *slots, int n, int ndof) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (long long)n * ndof) return;
+  const int k = (int)(t / ndof), d = (int)(t - (long long)k * ndof);
+  const int slot = slots[k];
+  buf[t] = U[((size_t)(slot >> 6) * ndof + d) * 64 + (slot & 63)];
+}
+// ghost cells: staging buffer [g][ndof] -> ghost shards, and their cell averages
+// one thread per (ghost cell, component): its DoFs travel buffer -> ghost shard (the buffer is read with unit stride
+// along the thread's own run of n_s values, the shard rows are written 64 cells wide) and their average is formed
+__global__ void unpack_ghost_kernel(const double *buf, double *U, double *avg, int first_slot, int n_ghost, int ndof,
+                                    KBasis kb, int N, const double *vert, int n_slots) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_ghost * 4) return;
+  const int g = t >> 2, c = t & 3;
+  const int slot = first_slot + g, ns = ndof / 4;
+  const double ia = cell_inv_area(vert, n_slots, slot);
+  double m = 0;
+  for (int j = 0; j < ns; ++j) {
+    const double v = buf[(size_t)g * ndof + c * ns + j];
+    U[((size_t)(slot >> 6) * ndof + c * ns + j) * 64 + (slot & 63)] = v;
+    m += avg_weight(kb, N, j, vert, n_slots, slot, ia) * v;
+  }
+  avg[((size_t)(slot >> 6) * 4 + c) * 64 + (slot & 63)] = m;
+}
+__global__ void unpack_ghost_avg_kernel(const double *buf, double *avg, int first_slot, int n_ghost) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= n_ghost) return;
+  const int slot = first_slot + g;
+  for (int c = 0; c < 4; ++c) avg[((size_t)(slot >> 6) * 4 + c) * 64 + (slot & 63)] = buf[(size_t)g * 4 + c];
+}
+// compute_cell_average (src/claw.cc:562-597) for all slots (owned and ghost shards)
+__global__ void average_kernel(const double *U, double *avg, int ndof, KBasis kb, int N, const double *vert, int n_slots) {
+  const int shard = blockIdx.x;
+  const int lane = threadIdx.x;
+  const int ns = ndof / 4, slot = shard * 64 + lane;
+  const double ia = cell_inv_area(vert, n_slots, slot);
+  for (int c = 0; c < 4; ++c) {
+    double m = 0;
+    for (int j = 0; j < ns; ++j)
+      m += avg_weight(kb, N, j, vert, n_slots, slot, ia) * U[((size_t)shard * ndof + c * ns + j) * 64 + lane];
+    avg[((size_t)shard * 4 + c) * 64 + lane] = m;
+  }
+}
+// compute_time_step_q (src/claw.cc:520-557): max of |v| + c over the 4 x 4 points of QIterated(QTrapez,3),
+// dt = cfl h / lambda / (2k+1) with h = diameter / sqrt(2); per-shard minimum.  Lane = cell; the
+// interpolation to the 16 points is sum-factorised (xi first, then eta).
+template <int N>
+__global__ __launch_bounds__(64) void dt_q_kernel(const double *U, const double *cell_h, const int32_t *shard_count,
+                                                  double *shard_dtmin, KBasis kb, double cfl, int degree, double *dt_cell) {
+  constexpr int NS = N * N, NDOF = 4 * NS;
+  const int shard = blockIdx.x;
+  const int lane = threadIdx.x;
+  double dtmin = 1.0e20;
+  if (lane < shard_count[shard]) {
+    double u[NDOF];
+#pragma unroll
+    for (int j = 0; j < NDOF; ++j) u[j] = U[((size_t)shard * NDOF + j) * 64 + lane];
+    dtmin = dt_q_cell<N>(u, kb, cell_h[(size_t)shard * 64 + lane], cfl, degree);
+    if (dt_cell) dt_cell[(size_t)shard * 64 + lane] = dtmin;
+  }
+  dtmin = wave_min(dtmin);
+  if (lane == 0) shard_dtmin[shard] = dtmin;
+}
+// compute_time_step_cartesian (src/claw.cc:486-511): per-shard minimum from the stored cell averages
+__global__ void dt_kernel(const double *avg, const double *cell_h, double h_uniform, int uniform_h,
+                          const int32_t *shard_count, double *shard_dtmin, double cfl, int degree, double *dt_cell) {
+  const int shard = blockIdx.x;
+  const int lane = threadIdx.x;
+  double dtmin = 1.0e20;
+  if (lane < shard_count[shard]) {
+    double A[4];
+    for (int c = 0; c < 4; ++c) A[c] = avg[((size_t)shard * 4 + c) * 64 + lane];
+    const double h = uniform_h ? h_uniform : cell_h[(size_t)shard * 64 + lane];
+    dtmin = cfl_dt(A, h, cfl, degree);
+    if (dt_cell) dt_cell[(size_t)shard * 64 + lane] = dtmin;  // "time step type = local": dt(c), src/claw.cc:506
+  }
+  dtmin = wave_min(dtmin);
+  if (lane == 0) shard_dtmin[shard] = dtmin;
+}
+
+// reductions over shards + the global-dt rules of compute_time_step (src/claw.cc:468-476)
+struct FinalArgs {
+  const double *shard_res, *shard_dtmin;
+  double *res_sq;  // [3] per stage
+  double *dt_dev;  // [0] dt, [1] elapsed time, [2] raw min before rules
+  double *partial; // [kFinBlocks][4] workgroup partials
+  int *counter;    // workgroups done
+  int n_shards, n_stages, res_stride, do_dt, advance_time, global_rules;  // shard_res: [n_stages][res_stride]
+  double time_step, final_time, dt_host;
+};
+constexpr int kFinBlocks = 32;   // workgroups of the two-level reduction
+__global__ __launch_bounds__(256) void finalize_kernel(const FinalArgs a) {
+  __shared__ double sred[4][4];
+  __shared__ int is_last;
+  // Two levels, both with a fixed assignment and a fixed combination order -> deterministic sums:
+  // workgroup b reduces the shards [b chunk, (b+1) chunk) of every array (the residual partials of all stages
+  // of the step and the CFL minima), the workgroup that finishes last combines the kFinBlocks partials in index order.
+  const int n = a.n_shards, t = threadIdx.x, b = blockIdx.x;
+  const int chunk = ((n + kFinBlocks - 1) / kFinBlocks + 255) & ~255;
+  const int lo = b * chunk, hi = min(n, lo + chunk);
+  double rs[3] = {0.0, 0.0, 0.0}, m = 1.0e20;
+  for (int s = lo + t; s < hi; s += 256) {
+    for (int st = 0; st < a.n_stages; ++st) rs[st] += a.shard_res[(size_t)st * a.res_stride + s];
+    if (a.do_dt) m = fmin(m, a.shard_dtmin[s]);
+  }
+  for (int st = 0; st < 3; ++st) {
+    const double r = wave_sum(rs[st]);
+    if ((t & 63) == 0) sred[st][t >> 6] = r;
+  }
+  m = wave_min(m);
+  if ((t & 63) == 0) sred[3][t >> 6] = m;
+  __syncthreads();
+  if (t == 0) {
+    for (int st = 0; st < 3; ++st) a.partial[b * 4 + st] = (sred[st][0] + sred[st][1]) + (sred[st][2] + sred[st][3]);
+    a.partial[b * 4 + 3] = fmin(fmin(sred[3][0], sred[3][1]), fmin(sred[3][2], sred[3][3]));
+    __threadfence();
+    is_last = atomicAdd(a.counter, 1) == (int)gridDim.x - 1;
+  }
+  __syncthreads();
+  if (!is_last) return;
+  __threadfence();
+  __shared__ double spart[kFinBlocks * 4];
+  if (t < (int)gridDim.x * 4) spart[t] = ((const volatile double *)a.partial)[t];  // one round trip for all partials
+  __syncthreads();
+  if (t != 0) return;
+  *a.counter = 0;  // ready for the next launch (launches on one stream do not overlap)
+  for (int st = 0; st < a.n_stages; ++st) {
+    double tot = 0.0;
+    for (int i = 0; i < (int)gridDim.x; ++i) tot += spart[i * 4 + st];
+    a.res_sq[st] = tot;
+  }
+  if (a.do_dt) {
+    double tt = a.dt_dev[1];
+    if (a.advance_time) {  // elapsed_time += global_dt (src/claw.cc:1072) for the step just done
+      tt += a.dt_host >= 0.0 ? a.dt_host : a.dt_dev[0];
+      a.dt_dev[1] = tt;
+    }
+    double dt = spart[3];
+    for (int i = 1; i < (int)gridDim.x; ++i) dt = fmin(dt, spart[i * 4 + 3]);
+    a.dt_dev[2] = dt;
+    if (a.global_rules) {  // src/claw.cc:469-476, only for "time step type = global"
+      if (dt > 0 && a.time_step > 0) dt = fmin(dt, a.time_step);
+      if (tt + dt > a.final_time) dt = a.final_time - tt;
+    }
+    a.dt_dev[0] = dt;
+  }
+}
+// re-apply the rules after an external all-reduce(min) of dt_dev[2] (multi-device)
+__global__ void dt_rules_kernel(double *dt_dev, double time_step, double final_time) {
+  double dt = dt_dev[2], t = dt_dev[1];
+  if (dt > 0 && time_step > 0) dt = fmin(dt, time_step);
+  if (t + dt > final_time) dt = final_time - t;
+  dt_dev[0] = dt;
+}
+
+
+}  // namespace dflo

@@ -1,0 +1,1155 @@
+// stage_kernels.hpp -- the stage kernels (Qk: squares and bilinear cells; Pk) and their dispatch by (flux, mode, geometry, limiter variant)
+// Part of the device side of engine.hip (see there for the layout of the data and of a stage).
+#pragma once
+#include "kernels_common.hpp"
+
+namespace dflo {
+
+// ------------------------------------------------------------------ the stage kernel
+// One workgroup of N wavefronts per shard: lane = cell, wavefront = node row b of the (k+1)^2
+// collocation nodes, so control flow is wave-uniform and every global access is a coalesced
+// 512-byte line.  LDS image: Us[ndof (+3: u, v, c of the cell average for LxF)][65] the own 64 cells,
+// Th[4N (+3)][halo_stride] the traces of the halo cells on the shared faces, Fh[4][max_fp] the numerical
+// fluxes at the shard's face points, the packed face records and the shard's boundary data.
+
+// phase C for node row B of every cell of the shard (lane = cell)
+template <int N, int B, int MODE, int POS>
+__device__ __forceinline__ void row_update(const StageArgs &a, double *Us, const int S, const double *Fh,
+                                           double *red, int shard, int lane, bool active, double h,
+                                           const uint16_t (&cref)[4], const double (&uold)[4][N],
+                                           const double (&Wrow)[N][4], double (&unew)[4][N], const double dt) {
+  constexpr int NS = N * N;
+  double R[4][N];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int m = 0; m < N; ++m) R[c][m] = 0.0;
+  // volume term (integrate_cell_term_explicit :57-115); collocation: W_q = U_q,
+  // grad phi_(m,B)(x_(aa,B)) = D[aa][m]/h e_x, grad phi_(aa,B)(x_(aa,q)) = D[q][B]/h e_y, JxW = w w h^2.
+  // Every wave evaluates F and G once at the nodes of its own row (values still in registers), then
+  // overwrites its own rows of the LDS image with G: after one barrier each wave reads the G of the
+  // other rows instead of re-evaluating the flux there.
+  double Gown[N][4];
+#pragma unroll
+  for (int aa = 0; aa < N; ++aa) {
+    double Fx[4];
+    flux_xy(Wrow[aa], Fx, Gown[aa]);
+    const double wbh = CB<N>::t.w[B] * h;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const double fx = Fx[c] * wbh;
+#pragma unroll
+      for (int m = 0; m < N; ++m) R[c][m] += fx * CB<N>::t.DW[aa][m];
+      Us[(c * NS + aa + N * B) * S + lane] = Gown[aa][c];
+    }
+    if (a.gravity != 0.0) {  // forcing (src/equation.h:831-850): (0, -rho, 0, -my) * gravity
+      const double jxw = CB<N>::t.w[aa] * CB<N>::t.w[B] * h * h;
+      R[MY][aa] += a.gravity * (-1.0 * Wrow[aa][RHO]) * jxw;
+      R[EN][aa] += a.gravity * (-1.0 * Wrow[aa][MY]) * jxw;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int aa = 0; aa < N; ++aa) {
+    const double wah = CB<N>::t.w[aa] * h;
+#pragma unroll
+    for (int q = 0; q < N; ++q) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const double gy = q == B ? Gown[aa][c] : Us[(c * NS + aa + N * q) * S + lane];
+        R[c][aa] += gy * (wah * CB<N>::t.DW[q][B]);
+      }
+    }
+  }
+  // face terms (:209-244, :344-423): - flux * phi * JxW on the integrating side, + on the other
+  if (active) {
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      const uint16_t ref = cref[f];
+      if (ref == kNoFace) continue;
+      const int k = ref & 0x3FFF;
+      const bool flip = (ref >> 14) & 1;
+      const double sgn = (ref >> 15) ? 1.0 : -1.0;
+      if (f < 2) {  // x faces: face point q = B lifts to the nodes (m, B)
+        const int qq = flip ? N - 1 - B : B;
+        const double jxw = sgn * CB<N>::t.w[B] * h;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const double fq = Fh[c * a.max_fp + k * N + qq] * jxw;
+#pragma unroll
+          for (int m = 0; m < N; ++m) R[c][m] += fq * ((f & 1) ? CB<N>::t.L1[m] : CB<N>::t.L0[m]);
+        }
+      } else {  // y faces: face point q = aa lifts to the node (aa, B) with l_B(0|1)
+        const double lw = (f & 1) ? CB<N>::t.L1[B] : CB<N>::t.L0[B];
+#pragma unroll
+        for (int q = 0; q < N; ++q) {
+          const int qq = flip ? N - 1 - q : q;
+          const double jxw = sgn * (CB<N>::t.w[q] * lw) * h;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) R[c][q] += Fh[c * a.max_fp + k * N + qq] * jxw;
+        }
+      }
+    }
+  }
+  double part[5] = {0, 0, 0, 0, 0};
+  if (active) {
+    if constexpr (MODE == 2) {
+      double *rp = a.rhs_out + (size_t)shard * 4 * NS * 64 + lane;
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int m = 0; m < N; ++m) rp[(c * NS + m + N * B) * 64] = R[c][m];
+    } else {
+      // solve() rk3 branch + SSP combine (src/claw.cc:708-710, 757-760)
+      const double rh2 = frcp(h * h);
+      double *np = a.Unew + (size_t)shard * 4 * NS * 64 + lane;
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int m = 0; m < N; ++m) {
+          const int d = c * NS + m + N * B;
+          const double ww = CB<N>::t.w[m] * CB<N>::t.w[B];
+          const double invM = rh2 * (CB<N>::t.iw[m] * CB<N>::t.iw[B]);
+          part[4] += R[c][m] * R[c][m];
+          double u = Wrow[m][c];
+          u += dt * R[c][m] * invM;
+          if constexpr (MODE == 1) u = (1.0 - a.ark) * u + a.ark * uold[c][m];
+          np[d * 64] = u;
+          if constexpr (POS) unew[c][m] = u;   // kept for the positivity step of the caller (which stores again if it scales)
+          part[c] += ww * u;
+        }
+    }
+  } else if constexpr (POS) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int m = 0; m < N; ++m) unew[c][m] = Wrow[m][c];
+  }
+  // partial cell averages / residual of this row -> LDS (red aliases Fh, see the caller's barriers)
+  if constexpr (MODE != 2) {
+    __syncthreads();  // every wave is done reading Fh (and the G rows of Us)
+#pragma unroll
+    for (int c = 0; c < 5; ++c) red[(B * 5 + c) * 64 + lane] = part[c];
+    if constexpr (POS == 1) positivity_row_bounds<N, B>(Us, lane, unew);   // the LDS image is free now
+    if constexpr (POS == 2) {
+      if (a.pos_check) positivity_row_bounds<N, B>(Us, lane, unew);
+    }
+    if constexpr (POS == 2) {   // x part of "dx * gradient of the cell average" (src/limiter.cc:283-289): l_m(1) - l_m(0) is
+                                // antisymmetric in m, pairing the nodes makes the slope of a constant state exactly zero
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        double g = 0.0;
+#pragma unroll
+        for (int m = 0; m < N / 2; ++m) g += (CB<N>::t.L1[m] - CB<N>::t.L0[m]) * (unew[c][m] - unew[c][N - 1 - m]);
+        red[(5 * N + c * N + B) * 64 + lane] = CB<N>::t.w[B] * g;
+      }
+    }
+  }
+}
+
+// phase C on bilinear (Q1-mapped) cells (the reference gets all of this from
+// FEValues with MappingQ1): J = [x_xi x_eta; y_xi y_eta] varies inside the cell,
+//   int F.grad(phi) = sum_q w_q [ d(phi)/d(xi) (y_eta F - x_eta G) + d(phi)/d(eta) (-y_xi F + x_xi G) ],
+// lumped mass M_j = w_j det J_j (src/claw.cc:223-227), face JxW = w_q |edge|.
+template <int N, int B, int MODE, int POS>
+__device__ __forceinline__ void row_update_q1(const StageArgs &a, double *Us, const int S, const double *Fh,
+                                              const double *Fg, double *red, int shard, int lane, bool active,
+                                              const double (&vx)[8], const uint16_t (&cref)[4],
+                                              const double (&uold)[4][N], const double (&Wrow)[N][4], double (&unew)[4][N],
+                                              const double dt) {
+  constexpr int NS = N * N;
+  double R[4][N];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int m = 0; m < N; ++m) R[c][m] = 0.0;
+  // metric terms of the bilinear map: x_xi depends on eta only, x_eta on xi only
+  const double ax = vx[2] - vx[0], bx = (vx[6] - vx[4]) - ax;   // x_xi(eta) = ax + eta bx
+  const double ay = vx[3] - vx[1], by = (vx[7] - vx[5]) - ay;
+  const double cx = vx[4] - vx[0], dx = (vx[6] - vx[2]) - cx;   // x_eta(xi) = cx + xi dx
+  const double cy = vx[5] - vx[1], dy = (vx[7] - vx[3]) - cy;
+  // Like row_update: every wave evaluates the fluxes once, at the nodes of its own row (values still in registers),
+  // lifts the xi part itself and leaves the eta part, (x_xi G - y_xi F) w w, in its rows of the LDS image; after one
+  // barrier each wave reads the eta parts of the other rows instead of evaluating the fluxes there again.
+  double Hown[N][4];
+  {
+    const double xxi = ax + CB<N>::t.x[B] * bx, yxi = ay + CB<N>::t.x[B] * by;
+#pragma unroll
+    for (int aa = 0; aa < N; ++aa) {
+      const double xeta = cx + CB<N>::t.x[aa] * dx, yeta = cy + CB<N>::t.x[aa] * dy;
+      double Fx[4], Gy[4];
+      flux_xy(Wrow[aa], Fx, Gy);
+      const double wq = CB<N>::t.w[aa] * CB<N>::t.w[B];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const double f1 = (yeta * Fx[c] - xeta * Gy[c]) * wq;
+#pragma unroll
+        for (int m = 0; m < N; ++m) R[c][m] += f1 * CB<N>::t.D[aa][m];
+        Hown[aa][c] = (xxi * Gy[c] - yxi * Fx[c]) * wq;
+        Us[(c * NS + aa + N * B) * S + lane] = Hown[aa][c];
+      }
+      if (a.gravity != 0.0) {
+        const double jxw = wq * (xxi * yeta - xeta * yxi);
+        R[MY][aa] += a.gravity * (-1.0 * Wrow[aa][RHO]) * jxw;
+        R[EN][aa] += a.gravity * (-1.0 * Wrow[aa][MY]) * jxw;
+      }
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int aa = 0; aa < N; ++aa)
+#pragma unroll
+    for (int q = 0; q < N; ++q)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const double hy = q == B ? Hown[aa][c] : Us[(c * NS + aa + N * q) * S + lane];
+        R[c][aa] += hy * CB<N>::t.D[q][B];
+      }
+  if (active) {
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      const uint16_t ref = cref[f];
+      if (ref == kNoFace) continue;
+      const int k = ref & 0x3FFF;
+      const bool flip = (ref >> 14) & 1;
+      const double sgn = (ref >> 15) ? 1.0 : -1.0;
+      const double len = Fg[2 * a.max_faces + k];
+      if (f < 2) {
+        const int qq = flip ? N - 1 - B : B;
+        const double jxw = sgn * CB<N>::t.w[B] * len;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const double fq = Fh[c * a.max_fp + k * N + qq] * jxw;
+#pragma unroll
+          for (int m = 0; m < N; ++m) R[c][m] += fq * ((f & 1) ? CB<N>::t.L1[m] : CB<N>::t.L0[m]);
+        }
+      } else {
+        const double lw = (f & 1) ? CB<N>::t.L1[B] : CB<N>::t.L0[B];
+#pragma unroll
+        for (int q = 0; q < N; ++q) {
+          const int qq = flip ? N - 1 - q : q;
+          const double jxw = sgn * (CB<N>::t.w[q] * lw) * len;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) R[c][q] += Fh[c * a.max_fp + k * N + qq] * jxw;
+        }
+      }
+    }
+  }
+  double part[5] = {0, 0, 0, 0, 0};
+  if (active) {
+    if constexpr (MODE == 2) {
+      double *rp = a.rhs_out + (size_t)shard * 4 * NS * 64 + lane;
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int m = 0; m < N; ++m) rp[(c * NS + m + N * B) * 64] = R[c][m];
+    } else {
+      double *np = a.Unew + (size_t)shard * 4 * NS * 64 + lane;
+      const double xxi = ax + CB<N>::t.x[B] * bx, yxi = ay + CB<N>::t.x[B] * by;
+#pragma unroll
+      for (int m = 0; m < N; ++m) {
+        const double det = xxi * (cy + CB<N>::t.x[m] * dy) - (cx + CB<N>::t.x[m] * dx) * yxi;
+        const double wd = CB<N>::t.w[m] * CB<N>::t.w[B] * det;   // JxW of node (m, B) = its lumped mass
+        const double invM = frcp(wd);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int d = c * NS + m + N * B;
+          part[4] += R[c][m] * R[c][m];
+          double u = Wrow[m][c];
+          u += dt * R[c][m] * invM;
+          if constexpr (MODE == 1) u = (1.0 - a.ark) * u + a.ark * uold[c][m];
+          np[d * 64] = u;
+          if constexpr (POS) unew[c][m] = u;
+          part[c] += wd * u;
+        }
+      }
+    }
+  } else if constexpr (POS) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int m = 0; m < N; ++m) unew[c][m] = Wrow[m][c];
+  }
+  if constexpr (MODE != 2) {
+    __syncthreads();  // every wave is done reading Fh and Us
+#pragma unroll
+    for (int c = 0; c < 5; ++c) red[(B * 5 + c) * 64 + lane] = part[c];
+    if constexpr (POS) positivity_row_bounds<N, B>(Us, lane, unew);
+  }
+}
+
+// phase B: one numerical flux per face point of the shard (integrate_face_term_explicit :303-341,
+// integrate_boundary_term_explicit :176-206).  Face-point index p = q * nf + k: neighbouring lanes take
+// neighbouring faces at the same q -> same LDS rows, consecutive slots.  Reads LDS only.
+// packed face record (4 bytes) of the device tables; plan.h's FaceRec is the host-side form
+//   bits 0-8 slot of the integrating cell, 9-10 its local face, 11 boundary, 12 flip,
+//   interior: 13-14 local face of the other cell, 15-23 its slot;  boundary: 13-22 index among the shard's boundary faces
+__host__ __device__ __forceinline__ uint32_t pface_pack(const FaceRec &r) {
+  const uint32_t slot = r.w0 & 0xFFFF, f = (r.w0 >> 16) & 3, bnd = (r.w0 >> 18) & 1, flip = (r.w0 >> 19) & 1;
+  uint32_t w = slot | (f << 9) | (bnd << 11) | (flip << 12);
+  if (bnd) w |= ((r.w0 >> 20) & 0x3FF) << 13;
+  else w |= (((r.w0 >> 20) & 3) << 13) | ((uint32_t)r.w1 << 15);
+  return w;
+}
+__device__ __forceinline__ int pface_slot(uint32_t w) { return w & 0x1FF; }
+__device__ __forceinline__ int pface_face(uint32_t w) { return (w >> 9) & 3; }
+__device__ __forceinline__ bool pface_bnd(uint32_t w) { return (w >> 11) & 1; }
+__device__ __forceinline__ bool pface_flip(uint32_t w) { return (w >> 12) & 1; }
+__device__ __forceinline__ int pface_other_face(uint32_t w) { return (w >> 13) & 3; }
+__device__ __forceinline__ int pface_other_slot(uint32_t w) { return (w >> 15) & 0x1FF; }
+__device__ __forceinline__ int pface_bnd_local(uint32_t w) { return (w >> 13) & 0x3FF; }
+
+template <int N, int FLUX, int GEO>
+__device__ __forceinline__ void flux_phase(const StageArgs &a, const double *Us, const double *Th, double *Fh,
+                                           const uint32_t *Fr, const double *Bv, const int *Bk, const double *Fg,
+                                           const int HS, const int nf, const int tid) {
+  constexpr int NS = N * N, NDOF = 4 * NS, NT = 64 * N, S = 65;
+  const int nfp = nf * N;
+  for (int p = tid; p < nfp; p += NT) {
+    const int k = p / N, q = p - k * N;   // the N points of a face sit in consecutive lanes; faces are sorted by kind
+    const uint32_t r = Fr[k];
+    const int slotL = pface_slot(r), fL = pface_face(r);
+    const bool bnd = pface_bnd(r), flip = pface_flip(r);
+    const int fR = pface_other_face(r);
+    double Wp[4], Wm[4], Ap[4], Am[4], F[4];
+    // trace of a cell on its local face f at face point qq: own cells from their DoFs,
+    // W = sum_m l_m(0|1) U[m,qq] (x faces) or U[qq,m] (y faces); halo cells from the stored trace
+    auto trace = [&](int slot, int f, int qq, double *W, double *A) {
+      if (slot < 64) {
+        // l_m(1) = l_(N-1-m)(0) (Gauss points are symmetric): walk the line of nodes backwards on the
+        // faces at 1 and use the weights l_m(0) throughout -> no per-lane weight selects
+        const int str0 = f < 2 ? 1 : N;
+        const int base = (f < 2 ? N * qq : qq) + ((f & 1) ? (N - 1) * str0 : 0);
+        const int str = (f & 1) ? -str0 : str0;
+        const double *u0 = Us + base * S + slot;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          double v = 0;
+#pragma unroll
+          for (int m = 0; m < N; ++m) v += CB<N>::t.L0[m] * u0[(c * NS + m * str) * S];
+          W[c] = v;
+        }
+        if constexpr (FLUX == DFLO_FLUX_LXF) {
+#pragma unroll
+          for (int c = 0; c < 3; ++c) A[c] = Us[(NDOF + c) * S + slot];
+        }
+      } else {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) W[c] = Th[(c * N + qq) * HS + slot - 64];
+        if constexpr (FLUX == DFLO_FLUX_LXF) {
+#pragma unroll
+          for (int c = 0; c < 3; ++c) A[c] = Th[(4 * N + c) * HS + slot - 64];
+        }
+      }
+    };
+    trace(slotL, fL, q, Wp, Ap);
+    double nx, ny;  // outward unit normal of the integrating cell
+    if constexpr (GEO == 0) {
+      nx = fL == 0 ? -1.0 : (fL == 1 ? 1.0 : 0.0);
+      ny = fL == 2 ? -1.0 : (fL == 3 ? 1.0 : 0.0);
+    } else {
+      nx = Fg[k];
+      ny = Fg[a.max_faces + k];
+    }
+    if (!bnd) {
+      trace(pface_other_slot(r), fR, flip ? N - 1 - q : q, Wm, Am);
+    } else {
+      const int bl = pface_bnd_local(r);
+      const double *bv = Bv + (bl * N + q) * 4;
+      double bvv[4] = {bv[0], bv[1], bv[2], bv[3]};
+      compute_Wminus(Bk[bl], nx, ny, Wp, bvv, Wm);
+      if constexpr (FLUX == DFLO_FLUX_LXF) {  // both averages are the interior cell's, :200-205
+#pragma unroll
+        for (int c = 0; c < 3; ++c) Am[c] = Ap[c];
+      }
+    }
+    numerical_normal_flux<FLUX>(nx, ny, Wp, Wm, Ap, Am, F);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) Fh[c * a.max_fp + k * N + q] = F[c];
+  }
+}
+
+// One workgroup of N wavefronts per shard.  Occupancy, not software prefetch, hides HBM latency:
+// the kernel is kept under 168 VGPRs and ~40 KB of LDS so that 3 wavefronts per SIMD stay resident
+// (measured on MI355X, C2: persistent workgroups that prefetch the next shard into registers need
+// > 168 VGPRs, run at 2 waves/SIMD and reach 112 GDoF/s against 139 GDoF/s for this kernel).  All global loads of a shard are issued at the top, before
+// anything waits.
+//   MODE 0: first stage (ark = 0, u(n) not read)   1: later stages   2: residual only (parity hook)
+//   GEO 0: axis-aligned squares (MappingCartesian)   1: bilinear cells (MappingQ1)
+//   POS 1: apply_positivity_limiter (src/positivity.cc:17-208) on the way out, for runs without the TVB limiter
+//   POS 2 (squares, TVB runs): one bit per cell goes out beside its average -- can the limiter pass (TVB, then positivity)
+//          change anything in this cell? -- so that the pass reads the DoFs of the marked cells only
+template <int N, int FLUX, int MODE, int GEO, int POS>
+__global__ __launch_bounds__(64 * N, ((GEO == 1 && N != 3) || N == 4) ? 2 : 3) void stage_kernel(const StageArgs a) {
+  constexpr int NS = N * N, NDOF = 4 * NS, NT = 64 * N;
+  constexpr int ROWS = NDOF + (FLUX == DFLO_FLUX_LXF ? 3 : 0);   // LxF: (u, v, c) of the cell average ride along
+  constexpr int TROWS = 4 * N + (FLUX == DFLO_FLUX_LXF ? 3 : 0); // halo image: face trace (+ the same three)
+  constexpr int S = 65;                                          // own-cell row stride: 1 mod 32 doubles
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int sidx = shard_of_block(blockIdx.x, a.n_list);
+  if (sidx < 0) return;
+  const int shard = a.shard_list ? a.shard_list[sidx] : sidx;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int row = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int HS = a.halo_stride;
+  double *Us = lds;                                   // [ROWS][S] DoFs (and averages) of the own cells
+  double *Th = Us + ROWS * S;                         // [TROWS][HS] traces of the halo cells on the shared face
+  double *Fh = Th + TROWS * HS;                       // [4][max_fp] numerical fluxes
+  uint32_t *Fr = (uint32_t *)(Fh + 4 * a.max_fp);     // [max_faces] (even count)
+  double *Bv = (double *)(Fr + a.max_faces);          // [max_bnd][N][4] boundary values of the shard
+  int *Bk = (int *)(Bv + a.max_bnd * 4 * N);          // [max_bnd] boundary kinds
+  double *Fg = (double *)(Bk + ((a.max_bnd + 1) & ~1)); // GEO 1: [3][max_faces] unit normal and length of the faces
+
+#ifdef DFLO_PHASE_TIMING
+  unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
+#endif
+  // ---- index data of a shard that a later workgroup of this XCD will take: touch it now so that its
+  //      (dependent) index loads hit L2.  Issued first = oldest in the in-order vmcnt queue; the result
+  //      is never used and never waited for.
+  //      The destination registers stay reserved until the loads have landed (see the asm further down):
+  //      a load issued through inline asm writes its register whenever the data arrives.
+  int pf0 = 0, pf1 = 0, pf2 = 0;
+  {
+    const int ahead = min(shard + a.prefetch_ahead, a.n_shards - 1);
+    const int32_t *p0 = a.halo_pad + (size_t)ahead * a.halo_pitch + (tid & 31);
+    const uint32_t *p1 = a.faces_pad + (size_t)ahead * a.face_pitch + tid;
+    const uint16_t *p2 = a.cell_face + (size_t)ahead * 4 * 64 + 2 * (tid & 127);
+    asm volatile("global_load_dword %0, %1, off" : "=v"(pf0) : "v"(p0));
+    asm volatile("global_load_dword %0, %1, off" : "=v"(pf1) : "v"(p1));
+    asm volatile("global_load_dword %0, %1, off" : "=v"(pf2) : "v"(p2));
+  }
+  // ---- all loads of the shard, issued back to back; the halo entries first (the halo values depend on them)
+  // halo entries: thread t works on entry (t & 31) + 32 b of every block b of 32 entries (8x8 lattice shards have one
+  // block, unstructured shards two or three): load them all now, the gathers below then depend on nothing else
+  constexpr int HB = 3;
+  int hentb[HB];
+#pragma unroll
+  for (int b = 0; b < HB; ++b) hentb[b] = a.halo_pad[(size_t)shard * a.halo_pitch + min((tid & 31) + 32 * b, a.halo_pitch - 1)];
+  const int4 hdr = a.shard_hdr[shard];                // {cells, faces, halo entries, boundary faces}
+  const int nf = hdr.y, nh = hdr.z, nbnd = hdr.w;
+  const bool active = lane < hdr.x;
+  double urow[4][N];                                  // node row `row` of the own cells
+  {
+    const double *up = a.Ucur + (size_t)shard * NDOF * 64 + (size_t)(N * row) * 64 + lane;   // one base, constant offsets
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int m = 0; m < N; ++m) urow[c][m] = up[(c * NS + m) * 64];
+  }
+  double uavg[4];
+  if constexpr (FLUX == DFLO_FLUX_LXF) {
+    if (row == 0) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) uavg[c] = a.avg_cur[((size_t)shard * 4 + c) * 64 + lane];
+    }
+  }
+  const uint32_t *fp = a.faces_pad + (size_t)shard * a.face_pitch;
+  const uint32_t fr0 = fp[tid], fr1 = fp[tid + NT];
+  double fg[3][2];   // GEO 1: unit normal and length of the faces tid and tid + NT (the table has the pitch of the face records)
+  if constexpr (GEO == 1) {
+    const double *gp = a.fgeom_pad + (size_t)shard * 3 * a.face_pitch;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      fg[j][0] = gp[j * a.face_pitch + tid];
+      fg[j][1] = gp[j * a.face_pitch + tid + NT];
+    }
+  }
+  uint16_t cref[4];
+#pragma unroll
+  for (int f = 0; f < 4; ++f) cref[f] = a.cell_face[((size_t)shard * 4 + f) * 64 + lane];
+  double h = 0.0, vx[8];
+  if constexpr (GEO == 0) {
+    h = a.uniform_h ? a.h_uniform : a.cell_h[(size_t)shard * 64 + lane];
+  } else {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) vx[k] = a.cell_vert[(size_t)k * a.n_slots + (size_t)shard * 64 + lane];
+  }
+  // the time step of the update: fetched here with everything else (it used to be read in the middle of phase C, one more
+  // trip to memory on every wave's critical path)
+  double dt_step = 0.0;
+  if constexpr (MODE != 2) dt_step = a.dt_cell ? a.dt_cell[(size_t)shard * 64 + lane] : (a.dt_host >= 0.0 ? a.dt_host : *a.dt_dev);
+  double uold[4][N];
+  if constexpr (MODE == 1) {
+    const double *op = a.Uold + (size_t)shard * NDOF * 64 + (size_t)(N * row) * 64 + lane;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int m = 0; m < N; ++m) uold[c][m] = op[(c * NS + m) * 64];
+  }
+
+  PHASE_MARK(0);
+  // ---- phase A: own rows -> LDS; halo: only the trace on the shared face is kept.
+  //      halo item i -> (entry s = i % nh, q = (i / nh) % N, comp = i / (nh N)); an entry is
+  //      (internal cell slot | local face << 28) of a face neighbour outside the shard
+  //      A thread takes, of its entry in block b, the two (component, point) rows r = g and g + 2N (g = t >> 5):
+  //      2N independent loads per block.
+  {
+    const int g = tid >> 5, l32 = tid & 31;
+    for (int b = 0; b * 32 < nh; ++b) {
+      const int sl = l32 + 32 * b;
+      if (sl >= nh) continue;
+      const int e = b == 0 ? hentb[0] : (b == 1 ? hentb[1] : (b == 2 ? hentb[2] : a.halo_pad[(size_t)shard * a.halo_pitch + sl]));
+      const int ic = e & 0x0FFFFFFF, f = (e >> 28) & 3;
+      const int str0 = f < 2 ? 1 : N, str = (f & 1) ? -str0 : str0;
+      double val[2][N];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int r = g + 2 * N * j, q = r % N, c = r / N;
+        const double *hp = a.Ucur + ((size_t)(ic >> 6) * NDOF + c * NS) * 64 + (ic & 63);
+        const int base = (f < 2 ? N * q : q) + ((f & 1) ? (N - 1) * str0 : 0);
+#pragma unroll
+        for (int m = 0; m < N; ++m) val[j][m] = hp[(base + m * str) * 64];
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int r = g + 2 * N * j, q = r % N, c = r / N;
+        double v = 0.0;
+#pragma unroll
+        for (int m = 0; m < N; ++m) v += CB<N>::t.L0[m] * val[j][m];
+        Th[(c * N + q) * HS + sl] = v;
+      }
+    }
+  }
+  if constexpr (FLUX == DFLO_FLUX_LXF) {  // lambda of the LxF flux comes from the cell averages (src/equation.h:357-359):
+                                          // keep (u, v, c) of each average instead of the four components
+    for (int sl = tid; sl < nh; sl += NT) {
+      const int blk = sl >> 5;   // sl = tid + k NT: entry (tid & 31) + 32 blk is this thread's own preloaded one
+      const int ic = (blk == 0 ? hentb[0] : (blk == 1 ? hentb[1] : (blk == 2 ? hentb[2] : a.halo_pad[(size_t)shard * a.halo_pitch + sl]))) & 0x0FFFFFFF;
+      double A[4], uvc[3];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) A[c] = a.avg_cur[((size_t)(ic >> 6) * 4 + c) * 64 + (ic & 63)];
+      wave_speed_uvc(A, uvc);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) Th[(4 * N + c) * HS + sl] = uvc[c];
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int m = 0; m < N; ++m) Us[(c * NS + m + N * row) * S + lane] = urow[c][m];
+  asm volatile("" ::"v"(pf0), "v"(pf1), "v"(pf2));  // the touch loads (oldest in the queue) have landed by now
+  if constexpr (FLUX == DFLO_FLUX_LXF) {
+    if (row == 0) {
+      double uvc[3];
+      wave_speed_uvc(uavg, uvc);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) Us[(NDOF + c) * S + lane] = uvc[c];
+    }
+  }
+  if (tid < nf) Fr[tid] = fr0;
+  if (tid + NT < nf) Fr[tid + NT] = fr1;
+  for (int i = tid + 2 * NT; i < nf; i += NT) Fr[i] = fp[i];
+  if constexpr (GEO == 1) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      if (tid < nf) Fg[j * a.max_faces + tid] = fg[j][0];
+      if (tid + NT < nf) Fg[j * a.max_faces + tid + NT] = fg[j][1];
+    }
+  }
+  if (nbnd > 0) {  // boundary values and kinds of this shard's boundary faces
+    for (int i = tid; i < nbnd * 4 * N; i += NT) {
+      const int bl = i / (4 * N), k2 = i - bl * 4 * N;
+      const int bf = a.bnd_pad[(size_t)shard * a.bnd_pitch + bl];
+      if (k2 == 0) Bk[bl] = a.bface_kind[bf];
+      Bv[i] = a.bval[(size_t)bf * 4 * N + k2];
+    }
+  }
+  PHASE_MARK(1);
+  __syncthreads();
+  PHASE_MARK(2);
+
+  // ---- phase B
+  flux_phase<N, FLUX, GEO>(a, Us, Th, Fh, Fr, Bv, Bk, Fg, HS, nf, tid);
+  PHASE_MARK(3);
+  __syncthreads();
+  PHASE_MARK(4);
+
+  // ---- phase C: volume + lifting + RK update of node row `row`
+  double *red = Fh;  // reused after the barrier inside row_update
+  double wrow[N][4];
+  double unew[4][N];   // POS: the updated row, held back until the positivity step below
+#pragma unroll
+  for (int m = 0; m < N; ++m)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) wrow[m][c] = urow[c][m];
+#define DFLO_ROW(Bq)                                                                                     \
+  do {                                                                                                   \
+    if constexpr (GEO == 0) row_update<N, Bq, MODE, POS>(a, Us, S, Fh, red, shard, lane, active, h, cref, uold, wrow, unew, dt_step); \
+    else row_update_q1<N, Bq, MODE, POS>(a, Us, S, Fh, Fg, red, shard, lane, active, vx, cref, uold, wrow, unew, dt_step); \
+  } while (0)
+  if constexpr (N == 2) {
+    if (row == 0) DFLO_ROW(0); else DFLO_ROW(1);
+  } else if constexpr (N == 3) {
+    if (row == 0) DFLO_ROW(0); else if (row == 1) DFLO_ROW(1); else DFLO_ROW(2);
+  } else {
+    if (row == 0) DFLO_ROW(0); else if (row == 1) DFLO_ROW(1); else if (row == 2) DFLO_ROW(2); else DFLO_ROW(3);
+  }
+#undef DFLO_ROW
+  PHASE_MARK(5);
+  if constexpr (MODE == 2) return;
+  __syncthreads();
+  PHASE_MARK(6);
+  if constexpr (POS == 1 && MODE != 2) {
+    // ---- apply_positivity_limiter (src/positivity.cc:17-208) on the new state.
+    //      First a bound that settles almost every cell: the limiter looks at the solution on lines through the Gauss nodes
+    //      (Gauss-Lobatto points on them), and a point value on such a line lies within [lo - d s, hi + d s] of the cell's
+    //      nodal extremes (d = hi - lo, s = sum of the negative interpolation weights).  If the lowest density and the lowest
+    //      pressure possible in that box are safely positive, theta1 = theta2 = 1 and the mean is admissible (the pressure
+    //      is concave): nothing to do.  Only wavefronts with a cell that fails the bound run the limiter proper.
+    constexpr int NS2 = N * N;
+    bool settled;
+    {
+      const bool ok = positivity_box_settled<N>(Us, lane, a.kb.pg_neg);
+      settled = __all(ok || !active);   // the same in every wave of the workgroup: all of them see the same numbers
+    }
+    if (!settled) {
+    // the limiter proper, the same arithmetic as limiter_kernel: wave b holds row b of every cell in registers and reads
+    // column b from the LDS image, so it sees the points (GLL g, Gauss b) and (Gauss b, GLL g); the minima of the rows are
+    // combined through LDS.  theta1, theta2 come out identical in every wave, which keeps the barriers uniform.
+    __syncthreads();   // every wave has read the bounds
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int m = 0; m < N; ++m) Us[(c * NS2 + m + N * row) * S + lane] = unew[c][m];
+    __syncthreads();
+    double A[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      double v = 0;
+#pragma unroll
+      for (int b = 0; b < N; ++b) v += red[(b * 5 + c) * 64 + lane];
+      A[c] = v;
+    }
+    if constexpr (GEO == 1) {
+      const double area = 0.5 * fabs((vx[0] * vx[3] - vx[2] * vx[1]) + (vx[2] * vx[7] - vx[6] * vx[3]) +
+                                     (vx[6] * vx[5] - vx[4] * vx[7]) + (vx[4] * vx[1] - vx[0] * vx[5]));
+      const double ia = 1.0 / area;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) A[c] *= ia;
+    }
+    const double eps = 1.0e-13;
+    const bool bad = smin(A[RHO], pressure(A)) < eps;   // "Fatal: Negative states" :26-38
+    if (bad && active && row == 0) atomicOr(&a.flags[0], 1);
+    double *pm = red + 5 * N * 64;   // [3][N][64] minima of the rows: density, theta2 (speculative), theta2 (after theta1)
+    // theta2 of this wave's points (:138-178) for the current unew / Us
+    auto pressure_theta = [&](bool &fail) {
+      double th = 1.0;
+      for (int g = 0; g < a.kb.Ng; ++g)
+#pragma unroll
+        for (int dir = 0; dir < 2; ++dir) {
+          double W[4];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            double v = 0;
+#pragma unroll
+            for (int m = 0; m < N; ++m) v += a.kb.Pg[g][m] * (dir == 0 ? unew[c][m] : Us[(c * NS2 + row + N * m) * S + lane]);
+            W[c] = v;
+          }
+          th = smin(th, positivity_theta2(W, A, eps, fail));
+        }
+      return th;
+    };
+    // first round: the density minimum and, on the guess theta1 = 1 (true almost everywhere), theta2 as well
+    bool fail = false;
+    {
+      double rmin = 1.0e20;
+      for (int g = 0; g < a.kb.Ng; ++g) {
+        double px = 0, py = 0;
+#pragma unroll
+        for (int m = 0; m < N; ++m) {
+          px += a.kb.Pg[g][m] * unew[RHO][m];
+          py += a.kb.Pg[g][m] * Us[(RHO * NS2 + row + N * m) * S + lane];
+        }
+        rmin = smin(smin(rmin, px), py);
+      }
+      pm[row * 64 + lane] = rmin;
+      pm[(N + row) * 64 + lane] = pressure_theta(fail);
+    }
+    __syncthreads();
+    double rho_min = 1.0e20, theta2 = 1.0;
+#pragma unroll
+    for (int b = 0; b < N; ++b) {
+      rho_min = smin(rho_min, pm[b * 64 + lane]);
+      theta2 = smin(theta2, pm[(N + b) * 64 + lane]);
+    }
+    const double rat = fabs(A[RHO] - eps) * frcp(fabs(A[RHO] - rho_min) + 1.0e-13);
+    const double theta1 = smin(rat, 1.0);
+    const bool t1 = !bad && theta1 < 1.0;
+    if (__any(t1)) {   // the same lanes in every wave: the density was scaled somewhere, theta2 has to be formed again
+      if (t1) {
+#pragma unroll
+        for (int m = 0; m < N; ++m) {
+          unew[RHO][m] = positivity_blend(theta1, unew[RHO][m], A[RHO]);
+          Us[(RHO * NS2 + m + N * row) * S + lane] = unew[RHO][m];
+        }
+      }
+      __syncthreads();
+      fail = false;
+      pm[(2 * N + row) * 64 + lane] = pressure_theta(fail);
+      __syncthreads();
+      theta2 = 1.0;
+#pragma unroll
+      for (int b = 0; b < N; ++b) theta2 = smin(theta2, pm[(2 * N + b) * 64 + lane]);
+    }
+    if (bad) theta2 = 1.0;
+    else if (fail && active) atomicOr(&a.flags[1], 1);
+    if (active && (t1 || theta2 < 1.0)) {   // rare: the rows stored by the update are replaced
+      double *np = a.Unew + (size_t)shard * 4 * NS2 * 64 + lane;
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int m = 0; m < N; ++m)
+          np[(c * NS2 + m + N * row) * 64] = theta2 < 1.0 ? positivity_blend(theta2, unew[c][m], A[c]) : unew[c][m];
+    }
+    }   // !settled
+  }
+  if constexpr (POS == 2 && GEO == 0 && MODE != 2) {
+    // Which cells can the limiter pass change?  TVB (src/limiter.cc:15-30): minmod hands back its first argument when it is
+    // below M dx^2 or zero, so a cell whose (characteristic) slopes all are is left alone; wave 0 looks at the x slopes,
+    // wave 1 at the y slopes, with a margin on the threshold so that the pass, which forms the slopes once more from the
+    // DoFs, can never disagree in the other direction.  Positivity: the nodal box test.  The pass itself is
+    // unchanged for the marked cells, so the results are those of the plain pass.
+    if (row < 2) {
+      double A[4], D[4];
+      bool any = false;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        double v = 0.0, g = 0.0;
+#pragma unroll
+        for (int b = 0; b < N; ++b) v += red[(b * 5 + c) * 64 + lane];
+        if (row == 0) {
+#pragma unroll
+          for (int b = 0; b < N; ++b) g += red[(5 * N + c * N + b) * 64 + lane];
+        } else {
+#pragma unroll
+          for (int m = 0; m < N / 2; ++m)   // the row sums of the average are w_m * (sum of the row): w_m = w_(N-1-m)
+            g += (CB<N>::t.L1[m] - CB<N>::t.L0[m]) * CB<N>::t.iw[m] * (red[(m * 5 + c) * 64 + lane] - red[((N - 1 - m) * 5 + c) * 64 + lane]);
+        }
+        A[c] = v;
+        D[c] = g;
+        any = any || !(g == 0.0);
+      }
+      bool need = false;
+      if (a.tvb_M >= 0.0) {
+        if (a.tvb_char && __any(any)) {
+          const EigenXY e = eigen_at(A);
+          to_char(e, row, D);
+        }
+        // margin: relative on the threshold, and absolute against the rounding of the slopes (formed here from row
+        // partials, in the pass from the DoFs; both errors are a few ulp of the state)
+        const double thr = a.tvb_M * h * h * (1.0 - 1.0e-9) - 1.0e-11 * (fabs(A[0]) + fabs(A[1]) + fabs(A[2]) + fabs(A[3]));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) need = need || !(fabs(D[i]) < thr || D[i] == 0.0);
+      }
+      if (row == 0 && a.pos_check) need = need || !positivity_box_settled<N>(Us, lane, a.kb.pg_neg);
+      const unsigned long long m = __ballot(need && active);
+      if (lane == 0 && m) atomicOr(&a.lim_mask[shard], m);
+    }
+  }
+  if (row == N - 1) {  // cell averages (src/claw.cc:562-597), residual norm, CFL minimum of the shard; on the
+                       // last wave: wave 0 carries the extra pass over the face points
+    double avg[4], res = 0.0, dtmin = 1.0e20;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      double v = 0;
+#pragma unroll
+      for (int b = 0; b < N; ++b) v += red[(b * 5 + c) * 64 + lane];
+      avg[c] = v;
+    }
+#pragma unroll
+    for (int b = 0; b < N; ++b) res += red[(b * 5 + 4) * 64 + lane];
+    if constexpr (GEO == 1) {  // cell average = sum u JxW / |K| (src/claw.cc:589-593), |K| by the shoelace formula
+      const double area = 0.5 * fabs((vx[0] * vx[3] - vx[2] * vx[1]) + (vx[2] * vx[7] - vx[6] * vx[3]) +
+                                     (vx[6] * vx[5] - vx[4] * vx[7]) + (vx[4] * vx[1] - vx[0] * vx[5]));
+      const double ia = 1.0 / area;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) avg[c] *= ia;
+    }
+    if (active) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) a.avg_new[((size_t)shard * 4 + c) * 64 + lane] = avg[c];
+      if constexpr (GEO == 0) {
+        if (a.want_dt) dtmin = cfl_dt(avg, h, a.cfl, a.degree);
+      }
+    }
+    res = wave_sum_lane63(res);
+    if (GEO == 0 && a.want_dt) dtmin = wave_min_lane63(dtmin);
+    if (lane == 63) {
+      a.shard_res[shard] = res;
+      if (GEO == 0 && a.want_dt) a.shard_dtmin[shard] = dtmin;
+    }
+  }
+  PHASE_MARK(7);
+#ifdef DFLO_PHASE_TIMING
+  if (lane == 0 && a.phase_cycles)
+    for (int i = 0; i < 8; ++i) a.phase_cycles[((size_t)blockIdx.x * 4 + row) * 8 + i] = tacc[i];
+#endif
+}
+
+// =====================================================================================================
+// Pk (FE_DGP) basis: the same shard machinery on modal DoFs.  A P_k function is a Q_k function, so it is
+// carried through phases A-C by its values at the Gauss nodes (exact), and only the two ends change:
+//   load:   u(x_j) = sum_m psi_m(x_j) U_m                      (modal -> nodal, T)
+//   store:  rhs_m  = sum_j psi_m(x_j) rhs_j, M = |K| I          (nodal residual -> modal, T^T; src/claw.cc:228-258
+//           gives 1/|K| on the diagonal for the orthonormal basis), update and SSP combine on the modes.
+// Cell average = mode 0 (psi_0 = 1).  Cartesian cells only.
+// =====================================================================================================
+template <int N, int B>
+__device__ __forceinline__ void modal_to_row(const double (&um)[4][N * (N + 1) / 2], double (&urow)[4][N]) {
+  constexpr int NM = N * (N + 1) / 2;
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int aa = 0; aa < N; ++aa) {
+      double v = 0.0;
+#pragma unroll
+      for (int m = 0; m < NM; ++m) v += PB<N>::t.T[aa + N * B][m] * um[c][m];
+      urow[c][aa] = v;
+    }
+}
+
+// phase C for node row B, then projection of the nodal residual on the modes and the modal update of the
+// modes this wave owns (m = B, B+N, ...)
+template <int N, int B, int MODE>
+__device__ __forceinline__ void row_update_pk(const StageArgs &a, double *Us, const int S, const double *Fh, double *red,
+                                              int shard, int lane, bool active, double h, const uint16_t (&cref)[4],
+                                              const double (&Wrow)[N][4], const double (&ucur)[4][(N * (N + 1) / 2 + N - 1) / N],
+                                              const double (&uold)[4][(N * (N + 1) / 2 + N - 1) / N], const double dt) {
+  constexpr int NS = N * N, NM = N * (N + 1) / 2;
+  double R[4][N];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int m = 0; m < N; ++m) R[c][m] = 0.0;
+  double Gown[N][4];
+#pragma unroll
+  for (int aa = 0; aa < N; ++aa) {
+    double Fx[4];
+    flux_xy(Wrow[aa], Fx, Gown[aa]);
+    const double wbh = CB<N>::t.w[B] * h;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const double fx = Fx[c] * wbh;
+#pragma unroll
+      for (int m = 0; m < N; ++m) R[c][m] += fx * CB<N>::t.DW[aa][m];
+      Us[(c * NS + aa + N * B) * S + lane] = Gown[aa][c];
+    }
+    if (a.gravity != 0.0) {
+      const double jxw = CB<N>::t.w[aa] * CB<N>::t.w[B] * h * h;
+      R[MY][aa] += a.gravity * (-1.0 * Wrow[aa][RHO]) * jxw;
+      R[EN][aa] += a.gravity * (-1.0 * Wrow[aa][MY]) * jxw;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int aa = 0; aa < N; ++aa) {
+    const double wah = CB<N>::t.w[aa] * h;
+#pragma unroll
+    for (int q = 0; q < N; ++q)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const double gy = q == B ? Gown[aa][c] : Us[(c * NS + aa + N * q) * S + lane];
+        R[c][aa] += gy * (wah * CB<N>::t.DW[q][B]);
+      }
+  }
+  if (active) {
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      const uint16_t ref = cref[f];
+      if (ref == kNoFace) continue;
+      const int k = ref & 0x3FFF;
+      const bool flip = (ref >> 14) & 1;
+      const double sgn = (ref >> 15) ? 1.0 : -1.0;
+      if (f < 2) {
+        const int qq = flip ? N - 1 - B : B;
+        const double jxw = sgn * CB<N>::t.w[B] * h;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const double fq = Fh[c * a.max_fp + k * N + qq] * jxw;
+#pragma unroll
+          for (int m = 0; m < N; ++m) R[c][m] += fq * ((f & 1) ? CB<N>::t.L1[m] : CB<N>::t.L0[m]);
+        }
+      } else {
+        const double lw = (f & 1) ? CB<N>::t.L1[B] : CB<N>::t.L0[B];
+#pragma unroll
+        for (int q = 0; q < N; ++q) {
+          const int qq = flip ? N - 1 - q : q;
+          const double jxw = sgn * (CB<N>::t.w[q] * lw) * h;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) R[c][q] += Fh[c * a.max_fp + k * N + qq] * jxw;
+        }
+      }
+    }
+  }
+  // ---- nodal residual -> modal residual: rhs_m = sum over rows of sum_a psi_m(x_(a,B)) R[.][a]; the rows
+  //      are added in a fixed order (row 0 first), through the now unused LDS image
+  __syncthreads();  // every wave is done with the G exchange
+  double *acc = Us;  // [4 NM][64]
+#pragma unroll
+  for (int w = 0; w < N; ++w) {
+    if (B == w) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int m = 0; m < NM; ++m) {
+          double pr = 0.0;
+#pragma unroll
+          for (int aa = 0; aa < N; ++aa) pr += PB<N>::t.T[aa + N * B][m] * R[c][aa];
+          if (w == 0) acc[(c * NM + m) * 64 + lane] = pr;
+          else acc[(c * NM + m) * 64 + lane] += pr;
+        }
+    }
+    __syncthreads();
+  }
+  double part[5] = {0, 0, 0, 0, 0};
+  if (active) {
+    const double rh2 = frcp(h * h);  // inverse mass of the orthonormal modes: 1/|K|
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      int t = 0;
+#pragma unroll
+      for (int m = B; m < NM; m += N, ++t) {
+        const double rm = acc[(c * NM + m) * 64 + lane];
+        if constexpr (MODE == 2) {
+          a.rhs_out[((size_t)shard * 4 * NM + c * NM + m) * 64 + lane] = rm;
+        } else {
+          part[4] += rm * rm;
+          double u = ucur[c][t];
+          u += dt * rm * rh2;
+          if constexpr (MODE == 1) u = (1.0 - a.ark) * u + a.ark * uold[c][t];
+          a.Unew[((size_t)shard * 4 * NM + c * NM + m) * 64 + lane] = u;
+          if (m == 0) part[c] = u;  // the cell average is mode 0
+        }
+      }
+    }
+  }
+  if constexpr (MODE != 2) {
+    __syncthreads();  // every wave is done reading Fh
+#pragma unroll
+    for (int c = 0; c < 5; ++c) red[(B * 5 + c) * 64 + lane] = part[c];
+  }
+}
+
+template <int N, int FLUX, int MODE>
+__global__ __launch_bounds__(64 * N, N == 4 ? 2 : 3) void stage_kernel_pk(const StageArgs a) {
+  constexpr int NS = N * N, NM = N * (N + 1) / 2, NDOFM = 4 * NM, NT = 64 * N, MS = (NM + N - 1) / N;
+  constexpr int ROWS = 4 * NS + (FLUX == DFLO_FLUX_LXF ? 3 : 0);
+  constexpr int TROWS = 4 * N + (FLUX == DFLO_FLUX_LXF ? 3 : 0);
+  constexpr int S = 65;
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int sidx = shard_of_block(blockIdx.x, a.n_list);
+  if (sidx < 0) return;
+  const int shard = a.shard_list ? a.shard_list[sidx] : sidx;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int row = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int HS = a.halo_stride;
+  double *Us = lds;
+  double *Th = Us + ROWS * S;
+  double *Fh = Th + TROWS * HS;
+  uint32_t *Fr = (uint32_t *)(Fh + 4 * a.max_fp);
+  double *Bv = (double *)(Fr + a.max_faces);
+  int *Bk = (int *)(Bv + a.max_bnd * 4 * N);
+
+  // ---- loads: every wave reads all modes of its cells (the rows need all of them); the modes a wave will
+  //      update (m = row, row+N, ...) of u(s) and u(n) are requested separately and consumed at the end
+  int hent[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) hent[t] = a.halo_pad[(size_t)shard * a.halo_pitch + ((tid + t * NT) & 31)];
+  const int4 hdr = a.shard_hdr[shard];
+  const int nf = hdr.y, nh = hdr.z, nbnd = hdr.w;
+  const bool active = lane < hdr.x;
+  double umode[4][NM];
+  {
+    const double *up = a.Ucur + (size_t)shard * NDOFM * 64 + lane;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int m = 0; m < NM; ++m) umode[c][m] = up[(c * NM + m) * 64];
+  }
+  double uavg[4];
+  if constexpr (FLUX == DFLO_FLUX_LXF) {
+    if (row == 0) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) uavg[c] = a.avg_cur[((size_t)shard * 4 + c) * 64 + lane];
+    }
+  }
+  const uint32_t *fp = a.faces_pad + (size_t)shard * a.face_pitch;
+  const uint32_t fr0 = fp[tid], fr1 = fp[tid + NT];
+  uint16_t cref[4];
+#pragma unroll
+  for (int f = 0; f < 4; ++f) cref[f] = a.cell_face[((size_t)shard * 4 + f) * 64 + lane];
+  const double h = a.uniform_h ? a.h_uniform : a.cell_h[(size_t)shard * 64 + lane];
+  double dt_step = 0.0;   // fetched with the other loads, not in the middle of phase C
+  if constexpr (MODE != 2) dt_step = a.dt_cell ? a.dt_cell[(size_t)shard * 64 + lane] : (a.dt_host >= 0.0 ? a.dt_host : *a.dt_dev);
+  double ucur[4][MS], uold[4][MS];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int t = 0; t < MS; ++t) {
+      const int m = min(row + N * t, NM - 1);
+      ucur[c][t] = a.Ucur[((size_t)shard * NDOFM + c * NM + m) * 64 + lane];
+      if constexpr (MODE == 1) uold[c][t] = a.Uold[((size_t)shard * NDOFM + c * NM + m) * 64 + lane];
+    }
+
+  // ---- phase A
+  double urow[4][N];
+  if constexpr (N == 2) {
+    if (row == 0) modal_to_row<N, 0>(umode, urow); else modal_to_row<N, 1>(umode, urow);
+  } else if constexpr (N == 3) {
+    if (row == 0) modal_to_row<N, 0>(umode, urow); else if (row == 1) modal_to_row<N, 1>(umode, urow); else modal_to_row<N, 2>(umode, urow);
+  } else {
+    if (row == 0) modal_to_row<N, 0>(umode, urow); else if (row == 1) modal_to_row<N, 1>(umode, urow);
+    else if (row == 2) modal_to_row<N, 2>(umode, urow); else modal_to_row<N, 3>(umode, urow);
+  }
+  // halo: trace of the neighbour's modal expansion at the face point, psi_m = Pt_i(xi) Pt_j(eta) with
+  // (xi, eta) on face f: xi in {0, 1, x_q}
+  for (int i = tid; i < ((nh + 31) & ~31) * 4 * N; i += NT) {
+    const int sl = (i & 31) + ((i >> 5) / (4 * N)) * 32, r = (i >> 5) % (4 * N), q = r % N, c = r / N;
+    if (sl >= nh) continue;
+    const int e = i == tid ? hent[0] : (i == tid + NT ? hent[1] : a.halo_pad[(size_t)shard * a.halo_pitch + sl]);
+    const int ic = e & 0x0FFFFFFF, f = (e >> 28) & 3;
+    const double *hp = a.Ucur + ((size_t)(ic >> 6) * NDOFM + c * NM) * 64 + (ic & 63);
+    double pxi[N], peta[N];
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+      double pq = PB<N>::t.Px[0][n];
+#pragma unroll
+      for (int qq = 1; qq < N; ++qq) pq = q == qq ? PB<N>::t.Px[qq][n] : pq;
+      pxi[n] = f == 0 ? PB<N>::t.P0[n] : (f == 1 ? PB<N>::t.P1[n] : pq);
+      peta[n] = f == 2 ? PB<N>::t.P0[n] : (f == 3 ? PB<N>::t.P1[n] : pq);
+    }
+    double v = 0.0;
+#pragma unroll
+    for (int m = 0; m < NM; ++m) v += pxi[PB<N>::t.mi[m]] * peta[PB<N>::t.mj[m]] * hp[m * 64];
+    Th[(c * N + q) * HS + sl] = v;
+  }
+  if constexpr (FLUX == DFLO_FLUX_LXF) {  // lambda of the LxF flux comes from the cell averages (src/equation.h:357-359):
+                                          // keep (u, v, c) of each average instead of the four components
+    for (int sl = tid; sl < nh; sl += NT) {
+      const int ic = (sl < 32 ? hent[0] : a.halo_pad[(size_t)shard * a.halo_pitch + sl]) & 0x0FFFFFFF;
+      double A[4], uvc[3];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) A[c] = a.avg_cur[((size_t)(ic >> 6) * 4 + c) * 64 + (ic & 63)];
+      wave_speed_uvc(A, uvc);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) Th[(4 * N + c) * HS + sl] = uvc[c];
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int m = 0; m < N; ++m) Us[(c * NS + m + N * row) * S + lane] = urow[c][m];
+  if constexpr (FLUX == DFLO_FLUX_LXF) {
+    if (row == 0) {
+      double uvc[3];
+      wave_speed_uvc(uavg, uvc);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) Us[(4 * NS + c) * S + lane] = uvc[c];
+    }
+  }
+  if (tid < nf) Fr[tid] = fr0;
+  if (tid + NT < nf) Fr[tid + NT] = fr1;
+  for (int i = tid + 2 * NT; i < nf; i += NT) Fr[i] = fp[i];
+  if (nbnd > 0) {
+    for (int i = tid; i < nbnd * 4 * N; i += NT) {
+      const int bl = i / (4 * N), k2 = i - bl * 4 * N;
+      const int bf = a.bnd_pad[(size_t)shard * a.bnd_pitch + bl];
+      if (k2 == 0) Bk[bl] = a.bface_kind[bf];
+      Bv[i] = a.bval[(size_t)bf * 4 * N + k2];
+    }
+  }
+  __syncthreads();
+  flux_phase<N, FLUX, 0>(a, Us, Th, Fh, Fr, Bv, Bk, nullptr, HS, nf, tid);
+  __syncthreads();
+
+  double *red = Fh;
+  double wrow[N][4];
+#pragma unroll
+  for (int m = 0; m < N; ++m)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) wrow[m][c] = urow[c][m];
+#define DFLO_ROWPK(Bq) row_update_pk<N, Bq, MODE>(a, Us, S, Fh, red, shard, lane, active, h, cref, wrow, ucur, uold, dt_step)
+  if constexpr (N == 2) {
+    if (row == 0) DFLO_ROWPK(0); else DFLO_ROWPK(1);
+  } else if constexpr (N == 3) {
+    if (row == 0) DFLO_ROWPK(0); else if (row == 1) DFLO_ROWPK(1); else DFLO_ROWPK(2);
+  } else {
+    if (row == 0) DFLO_ROWPK(0); else if (row == 1) DFLO_ROWPK(1); else if (row == 2) DFLO_ROWPK(2); else DFLO_ROWPK(3);
+  }
+#undef DFLO_ROWPK
+  if constexpr (MODE == 2) return;
+  __syncthreads();
+  if (row == N - 1) {
+    double avg[4], res = 0.0, dtmin = 1.0e20;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      double v = 0;
+#pragma unroll
+      for (int b = 0; b < N; ++b) v += red[(b * 5 + c) * 64 + lane];
+      avg[c] = v;
+    }
+#pragma unroll
+    for (int b = 0; b < N; ++b) res += red[(b * 5 + 4) * 64 + lane];
+    if (active) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) a.avg_new[((size_t)shard * 4 + c) * 64 + lane] = avg[c];
+      if (a.want_dt) dtmin = cfl_dt(avg, h, a.cfl, a.degree);
+    }
+    res = wave_sum_lane63(res);
+    if (a.want_dt) dtmin = wave_min_lane63(dtmin);
+    if (lane == 63) {
+      a.shard_res[shard] = res;
+      if (a.want_dt) a.shard_dtmin[shard] = dtmin;
+    }
+  }
+}
+
+
+// ------------------------------------------------------------------ dispatch
+// The kernels of one N (5 fluxes x 3 modes x 2 geometries x the limiter variants, Qk and Pk) are instantiated in their own
+// translation unit (stage_inst.hip, -DDFLO_STAGE_N=N) and reached through stage_of_N / stage_pk_of_N.
+typedef void (*stage_fn)(const StageArgs);
+template <int N, int FLUX>
+stage_fn pick_stage_m(int mode, int geo, int pos) {
+  if (pos == 1 && mode != 2) {
+    if (geo == 0) return mode == 0 ? stage_kernel<N, FLUX, 0, 0, 1> : stage_kernel<N, FLUX, 1, 0, 1>;
+    return mode == 0 ? stage_kernel<N, FLUX, 0, 1, 1> : stage_kernel<N, FLUX, 1, 1, 1>;
+  }
+  if (pos == 2 && mode != 2 && geo == 0) return mode == 0 ? stage_kernel<N, FLUX, 0, 0, 2> : stage_kernel<N, FLUX, 1, 0, 2>;
+  if (geo == 0) return mode == 0 ? stage_kernel<N, FLUX, 0, 0, 0> : (mode == 1 ? stage_kernel<N, FLUX, 1, 0, 0> : stage_kernel<N, FLUX, 2, 0, 0>);
+  return mode == 0 ? stage_kernel<N, FLUX, 0, 1, 0> : (mode == 1 ? stage_kernel<N, FLUX, 1, 1, 0> : stage_kernel<N, FLUX, 2, 1, 0>);
+}
+template <int N>
+stage_fn pick_stage_n(int flux, int mode, int geo, int pos) {
+  switch (flux) {
+    case DFLO_FLUX_LXF: return pick_stage_m<N, DFLO_FLUX_LXF>(mode, geo, pos);
+    case DFLO_FLUX_SW: return pick_stage_m<N, DFLO_FLUX_SW>(mode, geo, pos);
+    case DFLO_FLUX_KFVS: return pick_stage_m<N, DFLO_FLUX_KFVS>(mode, geo, pos);
+    case DFLO_FLUX_ROE: return pick_stage_m<N, DFLO_FLUX_ROE>(mode, geo, pos);
+    default: return pick_stage_m<N, DFLO_FLUX_HLLC>(mode, geo, pos);
+  }
+}
+template <int N, int FLUX>
+stage_fn pick_pk_m(int mode) {
+  return mode == 0 ? stage_kernel_pk<N, FLUX, 0> : (mode == 1 ? stage_kernel_pk<N, FLUX, 1> : stage_kernel_pk<N, FLUX, 2>);
+}
+template <int N>
+stage_fn pick_pk_n(int flux, int mode) {
+  switch (flux) {
+    case DFLO_FLUX_LXF: return pick_pk_m<N, DFLO_FLUX_LXF>(mode);
+    case DFLO_FLUX_SW: return pick_pk_m<N, DFLO_FLUX_SW>(mode);
+    case DFLO_FLUX_KFVS: return pick_pk_m<N, DFLO_FLUX_KFVS>(mode);
+    case DFLO_FLUX_ROE: return pick_pk_m<N, DFLO_FLUX_ROE>(mode);
+    default: return pick_pk_m<N, DFLO_FLUX_HLLC>(mode);
+  }
+}
+stage_fn stage_of_2(int flux, int mode, int geo, int pos);
+stage_fn stage_of_3(int flux, int mode, int geo, int pos);
+stage_fn stage_of_4(int flux, int mode, int geo, int pos);
+stage_fn stage_pk_of_2(int flux, int mode);
+stage_fn stage_pk_of_3(int flux, int mode);
+stage_fn stage_pk_of_4(int flux, int mode);
+
+}  // namespace dflo
