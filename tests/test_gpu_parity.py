@@ -580,7 +580,8 @@ def _sod_exact(x, t, gamma=1.4):
     S = cr * np.sqrt(g2 * ps / pr + g1)          # shock speed
     csl = cl * (ps / pl) ** g1
     xi = (x - 0.5) / t
-    rho = np.where(xi < -cl, rl, np.where(xi < us - csl, rl * (2 / (gamma + 1) - (gamma - 1) / ((gamma + 1) * cl) * xi) ** (2 / (gamma - 1)),
+    fan = np.maximum(2 / (gamma + 1) - (gamma - 1) / ((gamma + 1) * cl) * xi, 0.0)   # (only used inside the fan)
+    rho = np.where(xi < -cl, rl, np.where(xi < us - csl, rl * fan ** (2 / (gamma - 1)),
                    np.where(xi < us, rsl, np.where(xi < S, rsr, rr))))
     return rho
 
