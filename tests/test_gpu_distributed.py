@@ -88,6 +88,14 @@ CASES = [
 ]
 
 
+@pytest.mark.parametrize("mode,index", [("0", 0), ("2", 0), ("0", 3), ("2", 3), ("2", 4)])
+def test_other_exchange_orders(mode, index, monkeypatch):
+    """The serial order (DFLO_OVERLAP=0) and the two-stream order (2) of the halo exchange give what the default does:
+    plain run, TVB on Q2 (limiter marks through the split launches), positivity inside the stage kernel on bilinear cells."""
+    monkeypatch.setenv("DFLO_OVERLAP", mode)
+    test_two_engines_match_one(CASES[index])
+
+
 @pytest.mark.parametrize("case", CASES)
 def test_two_engines_match_one(case):
     import random
