@@ -1011,3 +1011,15 @@ def test_c5_full_size_properties():
     claw.set_initial_condition(u0)
     claw.advance(20)
     assert np.array_equal(claw.current_solution, u20)
+
+
+def test_random_configurations_against_the_oracle():
+    """tools/fuzz_parity.py: 250 random small configurations (mesh kind and size, degree, basis, flux, boundary kinds,
+    limiter switches, time-step mode, gravity, rough or smooth data), a few steps each, device against oracle."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), "250", "11"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "250 cases, 0 failures" in r.stdout
