@@ -143,3 +143,55 @@ def test_create_rejects_bad_parameters():
     p.flux_type = 9
     assert _lib.lib.dflo_hip_create(m._ptr, C.byref(p), 0, C.byref(h)) == -1
     assert b"flux" in _lib.lib.dflo_hip_last_error(None)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_partition_invariants_on_random_meshes(seed):
+    """dflo_mesh_partition on random meshes (lattices with or without periodic pairs, unstructured quadrilaterals) and
+    2-5 ranks: every cell owned exactly once, the ghost layer is exactly the face neighbours of the owned cells that live
+    elsewhere, every neighbour of an owned cell resolves locally to the right global cell (with its face and flip code),
+    and what rank a sends to rank b is, cell for cell and in order, what b expects from a."""
+    from dflo_amd import gmsh
+    rng = np.random.default_rng(100 + seed)
+    if seed % 3 == 2:
+        verts, quads, bed, bid = gmsh.unstructured_quads(int(rng.integers(4, 9)), seed=seed)
+        m = dflo_amd.Mesh.from_quads(verts, quads, bed, bid, 1)
+    else:
+        nx, ny = int(rng.integers(3, 30)), int(rng.integers(1, 12))
+        side = [-1, -1, 0, 0] if seed % 3 == 0 else [1, 2, -1, -1] if rng.random() < 0.5 else [0, 1, 2, 3]
+        m = dflo_amd.Mesh.cartesian(nx, ny, 0.0, 0.0, 0.1, side, 1)
+    world = int(rng.integers(2, 6))
+    if world > m.n_cells:
+        world = 2
+    parts = [m.partition(world, r) for r in range(world)]
+    gnb, gnf = m.neighbors, m.neighbor_faces
+    owner = np.full(m.n_cells, -1)
+    for r, p in enumerate(parts):
+        gid = np.asarray(p.global_ids)
+        assert len(set(gid.tolist())) == p.n_cells
+        own = gid[: p.n_owned]
+        assert (owner[own] == -1).all()
+        owner[own] = r
+    assert (owner >= 0).all() and sum(p.n_owned for p in parts) == m.n_cells
+    for r, p in enumerate(parts):
+        gid = np.asarray(p.global_ids)
+        own, ghost = gid[: p.n_owned], gid[p.n_owned:]
+        nbr = gnb[own]
+        want = set(int(g) for g in nbr[nbr >= 0].reshape(-1) if owner[g] != r)
+        assert set(ghost.tolist()) == want                                   # exactly one layer
+        lnb, lnf = p.neighbors[: p.n_owned], p.neighbor_faces[: p.n_owned]
+        assert (lnb != _lib.NBR_NONE).all()
+        inner = nbr >= 0
+        assert (gid[lnb[inner]] == nbr[inner]).all() and (lnb[~inner] == nbr[~inner]).all()
+        assert (lnf[inner] == gnf[own][inner]).all()
+        sc, so, ro = p.comm
+        for q in range(world):
+            if q == r:
+                assert so[q + 1] == so[q] and ro[q + 1] == ro[q]
+                continue
+            pq = parts[q]
+            sent = gid[sc[so[q]:so[q + 1]]]
+            assert (owner[sent] == r).all()
+            expect = np.asarray(pq.global_ids)[pq.n_owned + pq.comm[2][r]: pq.n_owned + pq.comm[2][r + 1]]
+            assert (sent == expect).all()
+        assert ro[world] == p.n_cells - p.n_owned                               # every ghost cell is received from someone
