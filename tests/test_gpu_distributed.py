@@ -96,8 +96,15 @@ def test_other_exchange_orders(mode, index, monkeypatch):
     test_two_engines_match_one(CASES[index])
 
 
+@pytest.mark.parametrize("index", [0, 3])
+def test_three_engines_match_one(index):
+    """Three slabs: the middle rank has a neighbour on either side and, on the periodic box, the outer ranks are neighbours
+    through the wrap -- every rank of the 8-GPU run is in that position."""
+    test_two_engines_match_one(CASES[index], world=3)
+
+
 @pytest.mark.parametrize("case", CASES)
-def test_two_engines_match_one(case):
+def test_two_engines_match_one(case, world=2):
     import random
     import dflo_amd
     from dflo_amd import problems
@@ -105,7 +112,7 @@ def test_two_engines_match_one(case):
     port = 29500 + random.randint(0, 2000)
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(2, port, case, ret), nprocs=2, join=True)
+    mp.spawn(_worker, args=(world, port, case, ret), nprocs=world, join=True)
     nx, ny, degree, flux, limiter, pos, side_bc, bnd, ic_name = case[:9]
     ic = {"sod": problems.sod, "vortex": problems.isentropic_vortex, "front": _front, "smooth": _smooth}[ic_name]
     x0, h = (-5.0, 10.0 / nx) if ic_name == "vortex" else (0.0, 1.0 / nx)
