@@ -7,3 +7,4 @@ from ._lib import DfloError, FLUX, BC, LIMITER  # noqa: F401
 from .mesh import Mesh  # noqa: F401
 from .params import Parameters  # noqa: F401
 from .claw import ConservationLaw  # noqa: F401
+from .multi import MultiConservationLaw  # noqa: F401

@@ -71,8 +71,20 @@ SYMBOLS = [
     "dflo_hip_stage_interior", "dflo_hip_stage_join",
     "dflo_hip_scalar_ptrs", "dflo_hip_apply_dt_rules", "dflo_hip_debug_math",
     "dflo_mesh_cartesian", "dflo_mesh_from_quads", "dflo_mesh_read_gmsh", "dflo_mesh_partition", "dflo_mesh_make_periodic", "dflo_mesh_free",
-    "dflo_mesh_last_error", "dflo_mesh_support_points",
+    "dflo_mesh_last_error", "dflo_mesh_support_points", "dflo_mesh_partition_ex", "dflo_mesh_partition_owners",
+    "dflo_hip_failure_step", "dflo_hip_dt_publish", "dflo_hip_apply_dt_rules_peers",
+    "dflo_hip_multi_create", "dflo_hip_comm_unique_id", "dflo_hip_multi_create_rank", "dflo_hip_multi_destroy",
+    "dflo_hip_multi_last_error", "dflo_hip_multi_n_parts", "dflo_hip_multi_n_local", "dflo_hip_multi_engine",
+    "dflo_hip_multi_part_cells", "dflo_hip_multi_n_dofs", "dflo_hip_multi_n_owned_dofs", "dflo_hip_multi_n_rk",
+    "dflo_hip_multi_set_solution", "dflo_hip_multi_get_solution", "dflo_hip_multi_get_cell_average",
+    "dflo_hip_multi_n_boundary_faces", "dflo_hip_multi_boundary_faces", "dflo_hip_multi_set_boundary_values",
+    "dflo_hip_multi_set_boundary_program", "dflo_hip_multi_residual", "dflo_hip_multi_compute_dt", "dflo_hip_multi_step",
+    "dflo_hip_multi_advance", "dflo_hip_multi_apply_limiter", "dflo_hip_multi_apply_positivity_limiter",
+    "dflo_hip_multi_check", "dflo_hip_multi_synchronize", "dflo_hip_multi_stage_timing",
+    "dflo_hip_multi_part_mesh", "dflo_hip_multi_set_part_solution",
 ]
+PARTITIONER = {"slab": 0, "rcb": 1}
+COMM_ID_BYTES = 128
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
@@ -150,6 +162,43 @@ _sig("dflo_mesh_from_quads", C.c_int, C.c_int32, _dp, C.c_int32, _ip, C.c_int32,
 _sig("dflo_mesh_read_gmsh", C.c_int, C.c_char_p, C.c_int32, C.c_int32, C.POINTER(_MP))
 _sig("dflo_mesh_partition", C.c_int, _MP, C.c_int32, C.c_int32, C.POINTER(_MP), C.POINTER(_ip), C.POINTER(_ip),
      C.POINTER(_ip))
+_sig("dflo_mesh_partition_ex", C.c_int, _MP, C.c_int32, C.c_int32, C.c_int32, C.POINTER(_MP), C.POINTER(_ip), C.POINTER(_ip),
+     C.POINTER(_ip))
+_sig("dflo_mesh_partition_owners", C.c_int, _MP, C.c_int32, C.c_int32, _ip)
+_sig("dflo_hip_failure_step", C.c_int, _H, C.POINTER(C.c_int64))
+_sig("dflo_hip_dt_publish", C.c_int, _H, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p))
+_sig("dflo_hip_apply_dt_rules_peers", C.c_int, _H, C.c_int, C.POINTER(C.c_void_p))
+_sig("dflo_hip_multi_create", C.c_int, _MP, C.POINTER(ParamsStruct), C.c_int, C.POINTER(C.c_int), C.c_int, C.POINTER(_H))
+_sig("dflo_hip_comm_unique_id", C.c_int, C.c_void_p)
+_sig("dflo_hip_multi_create_rank", C.c_int, _MP, C.POINTER(ParamsStruct), C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
+     C.POINTER(_H))
+_sig("dflo_hip_multi_destroy", C.c_int, _H)
+_sig("dflo_hip_multi_last_error", C.c_char_p, _H)
+_sig("dflo_hip_multi_n_parts", C.c_int, _H)
+_sig("dflo_hip_multi_n_local", C.c_int, _H)
+_sig("dflo_hip_multi_engine", _H, _H, C.c_int)
+_sig("dflo_hip_multi_part_cells", C.c_int, _H, C.c_int, _ip, _ip, C.POINTER(C.POINTER(C.c_int64)))
+_sig("dflo_hip_multi_n_dofs", C.c_int64, _H)
+_sig("dflo_hip_multi_n_owned_dofs", C.c_int64, _H)
+_sig("dflo_hip_multi_n_rk", C.c_int32, _H)
+_sig("dflo_hip_multi_set_solution", C.c_int, _H, _dp)
+_sig("dflo_hip_multi_part_mesh", _MP, _H, C.c_int)
+_sig("dflo_hip_multi_set_part_solution", C.c_int, _H, C.c_int, _dp)
+_sig("dflo_hip_multi_get_solution", C.c_int, _H, _dp)
+_sig("dflo_hip_multi_get_cell_average", C.c_int, _H, _dp)
+_sig("dflo_hip_multi_n_boundary_faces", C.c_int32, _H)
+_sig("dflo_hip_multi_boundary_faces", C.c_int, _H, _ip, _ip, _ip, _dp)
+_sig("dflo_hip_multi_set_boundary_values", C.c_int, _H, C.c_int, _dp)
+_sig("dflo_hip_multi_set_boundary_program", C.c_int, _H, C.c_int32, C.c_int32, C.c_int32, _ip, C.c_int32, _dp)
+_sig("dflo_hip_multi_residual", C.c_int, _H, C.c_int, _dp)
+_sig("dflo_hip_multi_compute_dt", C.c_int, _H, C.c_double, _dp)
+_sig("dflo_hip_multi_step", C.c_int, _H, C.c_double, _dp, _dp)
+_sig("dflo_hip_multi_advance", C.c_int, _H, C.c_int, _dp)
+_sig("dflo_hip_multi_apply_limiter", C.c_int, _H)
+_sig("dflo_hip_multi_apply_positivity_limiter", C.c_int, _H)
+_sig("dflo_hip_multi_check", C.c_int, _H)
+_sig("dflo_hip_multi_synchronize", C.c_int, _H)
+_sig("dflo_hip_multi_stage_timing", C.c_int, _H, C.c_int, _dp, C.POINTER(C.c_int64))
 _sig("dflo_mesh_make_periodic", C.c_int, _MP, C.c_int32, C.c_int32, C.c_int32)
 _sig("dflo_mesh_free", None, _MP)
 _sig("dflo_mesh_last_error", C.c_char_p)

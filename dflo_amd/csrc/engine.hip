@@ -62,7 +62,14 @@ struct dflo_hip_engine {
   int32_t *d_lrbt = nullptr, *d_user_of = nullptr, *d_iid = nullptr;
   double *d_cell_h = nullptr, *d_cell_vert = nullptr, *d_fgeom_pad = nullptr, *d_dt_cell = nullptr;
   double *shard_res = nullptr, *shard_dtmin = nullptr, *res_sq = nullptr, *dt_dev = nullptr, *fin_partial = nullptr;
-  int *flags = nullptr;
+  int *flags = nullptr;         // device view of flags_host (kernels_common.hpp: raise_flag)
+  volatile int *flags_host = nullptr;   // [0] negative mean state, [1] positivity root failure, [2] 1 + step of the first
+  int *fin_counter = nullptr;   // finalize_kernel: workgroups done
+  double *dt_pub = nullptr;     // [2] raw CFL minimum of the last two steps, read by the other engines of a multi-device run
+  int pub_parity = 0;
+  bool publish = false;
+  int64_t steps_done = 0;       // time steps since set_solution (the index recorded with a failure flag)
+  hipEvent_t ev_chunk[2] = {nullptr, nullptr};   // dflo_hip_advance: the host stays at most two chunks of steps ahead
   std::vector<double> bface_xy;  // [n_bfaces][N][2]
   int pending_rk = -1;
   int st_in = 0, st_old = 0, st_out = 0, st_avg_in = 0, st_rk = 0, st_which = 0;
@@ -353,6 +360,7 @@ int launch_update(dflo_hip_engine *h, double *rhs_out, int part) {
   if (a.n_list == 0) return DFLO_OK;
   const int mode_ = rhs_out ? 2 : (h->ark[rk] != 0.0 ? 1 : 0);
   a.flags = h->flags;
+  a.step_index = (int)h->steps_done;
   a.lim_mask = h->lim_mask;
   a.tvb_M = h->prm.limiter_type == DFLO_LIMITER_TVB ? h->prm.M : -1.0;
   a.tvb_char = h->prm.char_lim;
@@ -404,6 +412,7 @@ int launch_limiter(dflo_hip_engine *h, int tvb, int pos, int part, bool stage_da
   l.lrbt = h->d_lrbt;
   l.cell_h = h->d_cell_h;
   l.flags = h->flags;
+  l.step_index = (int)h->steps_done;
   l.h_uniform = p.h;
   l.M = h->prm.M;
   l.beta = h->prm.beta;
@@ -482,8 +491,10 @@ int launch_finish(dflo_hip_engine *h) {
   f.time_step = h->prm.time_step;
   f.final_time = h->prm.final_time;
   f.global_rules = h->prm.global_time_step;
+  f.fixed_dt = h->prm.global_time_step && h->prm.cfl <= 0.0;
+  f.publish = h->publish ? h->dt_pub + h->pub_parity : nullptr;
   f.partial = h->fin_partial;
-  f.counter = h->flags + 2;
+  f.counter = h->fin_counter;
   hipLaunchKernelGGL(finalize_kernel, dim3(fin_grid(f.n_shards)), dim3(256), 0, h->stream, f);
   HIPCHK(h, hipGetLastError());
   h->pending_rk = -1;
@@ -526,6 +537,13 @@ void drop_graph(dflo_hip_engine *h) {
 }
 
 int check_handle(dflo_hip_handle h) { return h ? DFLO_OK : DFLO_ERR_BAD_PARAM; }
+
+// the failure flags as they stand (no synchronisation: the caller decides how fresh they have to be)
+int flags_status(dflo_hip_engine *h) {
+  if (h->flags_host[0]) { h->err = "Fatal: Negative states"; return DFLO_ERR_NEGATIVE_MEAN_STATE; }
+  if (h->flags_host[1]) { h->err = "Problem in positivity limiter"; return DFLO_ERR_POSITIVITY_NO_ROOT; }
+  return DFLO_OK;
+}
 
 }  // namespace
 
@@ -679,13 +697,26 @@ int dflo_hip_create(const dflo_mesh_t *mesh, const dflo_params_t *params, int de
   if (hipMalloc((void **)&h->shard_res, 3 * nsh * sizeof(double)) != hipSuccess ||
       hipMalloc((void **)&h->shard_dtmin, nsh * sizeof(double)) != hipSuccess ||
       hipMalloc((void **)&h->res_sq, 4 * sizeof(double)) != hipSuccess || hipMalloc((void **)&h->fin_partial, 4 * 32 * sizeof(double)) != hipSuccess ||
-      hipMalloc((void **)&h->dt_dev, 4 * sizeof(double)) != hipSuccess || hipMalloc((void **)&h->flags, 4 * sizeof(int)) != hipSuccess) {
+      hipMalloc((void **)&h->dt_dev, 4 * sizeof(double)) != hipSuccess || hipMalloc((void **)&h->fin_counter, sizeof(int)) != hipSuccess ||
+      hipMalloc((void **)&h->dt_pub, 2 * sizeof(double)) != hipSuccess) {
     h->err = "hipMalloc(scalars) failed";
     return bail(DFLO_ERR_NOMEM);
   }
+  {  // failure flags: host memory the kernels write through the mapping (only when something fails)
+    void *fh = nullptr, *fd = nullptr;
+    if (hipHostMalloc(&fh, 4 * sizeof(int), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+        hipHostGetDevicePointer(&fd, fh, 0) != hipSuccess) {
+      h->err = "hipHostMalloc(flags) failed";
+      return bail(DFLO_ERR_NOMEM);
+    }
+    h->flags_host = (volatile int *)fh;
+    h->flags = (int *)fd;
+    for (int i = 0; i < 4; ++i) h->flags_host[i] = 0;
+  }
   hipMemset(h->res_sq, 0, 4 * sizeof(double));
   hipMemset(h->dt_dev, 0, 4 * sizeof(double));
-  hipMemset(h->flags, 0, 4 * sizeof(int));
+  hipMemset(h->dt_pub, 0, 2 * sizeof(double));
+  hipMemset(h->fin_counter, 0, sizeof(int));
   h->halo_stride = std::max(p.max_halo, 1) | 1;  // odd stride: the trace rows fall on different LDS banks
   h->max_fp = std::max(std::max(p.max_faces, 1) * h->N, 9 * 64 * h->N / 4 + 1);  // Fh also hosts the row partials (5 N rows of 64) and the positivity minima (3 N) or the slope partials (4 N)
   {
@@ -754,7 +785,9 @@ int dflo_hip_destroy(dflo_hip_handle h) {
   hipFree(h->d_bnd_pad); hipFree(h->d_nbr_code); hipFree(h->d_shock); hipFree(h->lim_mask); hipFree(h->d_faces_pad); hipFree(h->d_shard_hdr); hipFree(h->d_halo_pad); hipFree(h->d_cell_face); hipFree(h->d_lrbt); hipFree(h->d_user_of); hipFree(h->d_iid);
   hipFree(h->d_rim_list); hipFree(h->d_int_list);
   hipFree(h->d_cell_h); hipFree(h->d_dt_cell); hipFree(h->d_cell_vert); hipFree(h->d_fgeom_pad); hipFree(h->shard_res); hipFree(h->shard_dtmin); hipFree(h->res_sq); hipFree(h->fin_partial); hipFree(h->dt_dev);
-  hipFree(h->flags); hipFree(h->d_send_slots); hipFree(h->ghost_stage);
+  if (h->flags_host) hipHostFree((void *)h->flags_host);
+  hipFree(h->fin_counter); hipFree(h->dt_pub); hipFree(h->d_send_slots); hipFree(h->ghost_stage);
+  for (int i = 0; i < 2; ++i) if (h->ev_chunk[i]) hipEventDestroy(h->ev_chunk[i]);
   for (auto &e : h->ev_pool) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
   if (h->ev_rim) { hipEventDestroy(h->ev_rim); hipEventDestroy(h->ev_unpack); }
   if (h->own_stream) hipStreamDestroy(h->own_stream);
@@ -781,6 +814,8 @@ int dflo_hip_set_solution(dflo_hip_handle h, const double *u) {
   HIPCHK(h, hipMemcpyAsync(h->user_buf, u, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
   const long long tot = (long long)p.n_slots * h->ndof;
   h->cur = h->old = 0;
+  h->steps_done = 0;
+  for (int i = 0; i < 4; ++i) h->flags_host[i] = 0;   // a new state: the flags of an earlier run are history
   hipLaunchKernelGGL(scatter_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, h->user_buf, h->U[0],
                      h->d_user_of, p.n_slots, h->ndof);
   HIPCHK(h, hipGetLastError());
@@ -899,13 +934,13 @@ int dflo_hip_compute_cell_average(dflo_hip_handle h) {
 int dflo_hip_compute_dt(dflo_hip_handle h, double elapsed_time, double *dt) {
   if (check_handle(h) || !dt) return DFLO_ERR_BAD_PARAM;
   hipSetDevice(h->device);
-  if (h->prm.global_time_step && h->prm.cfl <= 0.0) {  // src/claw.cc:456-460
-    *dt = h->prm.time_step;
-    return DFLO_OK;
-  }
+  // "time step type = global" with cfl <= 0: the time step of the input file (src/claw.cc:455-460; the reference leaves
+  // global_dt unset on this path, the engine advances the clock by the time step it uses)
+  const int fixed = h->prm.global_time_step && h->prm.cfl <= 0.0;
   // per-shard minima from the stored cell averages (src/claw.cc:486-511)
   const Plan &p = h->plan;
-  if (h->geo == 0)
+  if (fixed) {
+  } else if (h->geo == 0)
     hipLaunchKernelGGL(dt_kernel, dim3(p.n_shards), dim3(64), 0, h->stream, h->avg[h->avg_cur], h->d_cell_h, p.h,
                        p.uniform_h ? 1 : 0, h->d_shard_count, h->shard_dtmin, h->prm.cfl, h->degree, h->d_dt_cell);
   else
@@ -927,8 +962,10 @@ int dflo_hip_compute_dt(dflo_hip_handle h, double elapsed_time, double *dt) {
   f.time_step = h->prm.time_step;
   f.final_time = h->prm.final_time;
   f.global_rules = h->prm.global_time_step;
+  f.fixed_dt = fixed;
+  f.publish = h->publish ? h->dt_pub + h->pub_parity : nullptr;
   f.partial = h->fin_partial;
-  f.counter = h->flags + 2;
+  f.counter = h->fin_counter;
   hipLaunchKernelGGL(finalize_kernel, dim3(fin_grid(f.n_shards)), dim3(256), 0, h->stream, f);
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipMemcpyAsync(tt, h->dt_dev, sizeof(tt), hipMemcpyDeviceToHost, h->stream));
@@ -946,6 +983,7 @@ int dflo_hip_stage(dflo_hip_handle h, int rk, double dt) {
 int dflo_hip_end_step(dflo_hip_handle h) {
   if (check_handle(h)) return DFLO_ERR_BAD_PARAM;
   h->old = h->cur;  // old_solution = current_solution (src/claw.cc:1110): a pointer swap here
+  ++h->steps_done;
   return DFLO_OK;
 }
 
@@ -957,6 +995,7 @@ int dflo_hip_step(dflo_hip_handle h, double dt, double *res_norm0, double *res_n
     if (rc) return rc;
   }
   h->old = h->cur;
+  ++h->steps_done;
   if (res_norm0 || res_norm) {
     double r[4];
     HIPCHK(h, hipMemcpyAsync(r, h->res_sq, sizeof(r), hipMemcpyDeviceToHost, h->stream));
@@ -974,10 +1013,6 @@ int dflo_hip_advance(dflo_hip_handle h, int n_steps, double *elapsed_time_inout)
   double dt0;
   int rc = dflo_hip_compute_dt(h, *elapsed_time_inout, &dt0);
   if (rc) return rc;
-  if (h->prm.global_time_step && h->prm.cfl <= 0.0) {
-    double tt[4] = {dt0, *elapsed_time_inout, dt0, 0};
-    HIPCHK(h, hipMemcpyAsync(h->dt_dev, tt, sizeof(tt), hipMemcpyHostToDevice, h->stream));
-  }
   int s = 0;
   if (h->use_graph && !h->timing && h->cur == h->old) {
     // the (solution, average) buffer indices come back to where they started after 2 steps (avg_cur flips
@@ -993,6 +1028,7 @@ int dflo_hip_advance(dflo_hip_handle h, int n_steps, double *elapsed_time_inout)
           for (int k = 0; k < period && !rc; ++k) {
             for (int rk = 0; rk < h->n_rk && !rc; ++rk) rc = launch_stage(h, rk, -1.0, nullptr, -1);
             h->old = h->cur;
+            ++h->steps_done;
           }
           ok = hipStreamEndCapture(h->stream, &g) == hipSuccess && !rc && g;
           if (ok) ok = hipGraphInstantiate(&h->graph_exec, g, nullptr, nullptr, 0) == hipSuccess;
@@ -1001,6 +1037,7 @@ int dflo_hip_advance(dflo_hip_handle h, int n_steps, double *elapsed_time_inout)
           h->cur = h->old = cur0;
           h->avg_cur = avg0;
           h->pending_rk = -1;
+          h->steps_done -= period;
         }
         if (!ok || h->cur != cur0) {
           (void)hipGetLastError();
@@ -1015,23 +1052,45 @@ int dflo_hip_advance(dflo_hip_handle h, int n_steps, double *elapsed_time_inout)
         }
       }
       if (h->graph_exec) {
-        for (; s + period <= n_steps; s += period) HIPCHK(h, hipGraphLaunch(h->graph_exec, h->stream));
+        for (; s + period <= n_steps; s += period) {
+          HIPCHK(h, hipGraphLaunch(h->graph_exec, h->stream));
+          h->steps_done += period;
+        }
       }
     }
   }
-  for (; s < n_steps; ++s) {
+  // The reference stops inside the stage that fails (src/positivity.cc:28-38,160-169).  Here the launches run ahead of the
+  // device, so the host looks at the failure flags (mapped host memory, no copy) once per chunk of kCheckEvery steps,
+  // after waiting for the chunk before the previous one: the device never runs dry and a failed run stops within
+  // three chunks instead of marching on NaNs to the end.
+  constexpr int kCheckEvery = 32;
+  for (int i = 0; i < 2; ++i)
+    if (!h->ev_chunk[i]) HIPCHK(h, hipEventCreateWithFlags(&h->ev_chunk[i], hipEventDisableTiming));
+  int chunk = 0;
+  bool failed = false;
+  for (int s0 = s; s < n_steps; ++s) {
+    if ((s - s0) % kCheckEvery == 0 && s > s0) {
+      HIPCHK(h, hipEventRecord(h->ev_chunk[chunk & 1], h->stream));
+      ++chunk;
+      if (chunk >= 2) {
+        HIPCHK(h, hipEventSynchronize(h->ev_chunk[chunk & 1]));
+        if (h->flags_host[0] | h->flags_host[1]) { failed = true; break; }
+      }
+    }
     for (int rk = 0; rk < h->n_rk; ++rk) {
       rc = launch_stage(h, rk, -1.0, nullptr, -1);
       if (rc) return rc;
     }
     h->old = h->cur;
+    ++h->steps_done;
   }
+  (void)failed;
   double tt[4];
   HIPCHK(h, hipMemcpyAsync(tt, h->dt_dev, sizeof(tt), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   if (h->timing) time_collect(h);
   *elapsed_time_inout = tt[1];
-  return dflo_hip_check(h);
+  return flags_status(h);
 }
 
 int dflo_hip_apply_limiter(dflo_hip_handle h) {
@@ -1193,11 +1252,13 @@ int dflo_hip_stage_limit(dflo_hip_handle h) {
 int dflo_hip_check(dflo_hip_handle h) {
   if (check_handle(h)) return DFLO_ERR_BAD_PARAM;
   hipSetDevice(h->device);
-  int f[4];
-  HIPCHK(h, hipMemcpyAsync(f, h->flags, sizeof(f), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
-  if (f[0]) { h->err = "Fatal: Negative states"; return DFLO_ERR_NEGATIVE_MEAN_STATE; }
-  if (f[1]) { h->err = "Problem in positivity limiter"; return DFLO_ERR_POSITIVITY_NO_ROOT; }
+  return flags_status(h);
+}
+
+int dflo_hip_failure_step(dflo_hip_handle h, int64_t *step) {
+  if (check_handle(h) || !step) return DFLO_ERR_BAD_PARAM;
+  *step = h->flags_host[2] ? (int64_t)h->flags_host[2] - 1 : -1;
   return DFLO_OK;
 }
 
@@ -1324,8 +1385,27 @@ int dflo_hip_debug_phase_cycles(dflo_hip_handle h, unsigned long long *out, int 
 int dflo_hip_apply_dt_rules(dflo_hip_handle h) {
   if (check_handle(h)) return DFLO_ERR_BAD_PARAM;
   hipSetDevice(h->device);
-  hipLaunchKernelGGL(dt_rules_kernel, dim3(1), dim3(1), 0, h->stream, h->dt_dev, h->prm.time_step, h->prm.final_time);
+  return dflo_hip_apply_dt_rules_peers(h, 0, nullptr);
+}
+
+int dflo_hip_dt_publish(dflo_hip_handle h, int enable, void **slot0, void **slot1) {
+  if (check_handle(h)) return DFLO_ERR_BAD_PARAM;
+  h->publish = enable != 0;
+  if (slot0) *slot0 = h->dt_pub;
+  if (slot1) *slot1 = h->dt_pub + 1;
+  return DFLO_OK;
+}
+
+int dflo_hip_apply_dt_rules_peers(dflo_hip_handle h, int n_peers, const void *const *peer_slots) {
+  if (check_handle(h) || n_peers < 0 || n_peers > kMaxPeers || (n_peers > 0 && !peer_slots)) return DFLO_ERR_BAD_PARAM;
+  hipSetDevice(h->device);
+  DtPeers pr{};
+  pr.n = n_peers;
+  for (int i = 0; i < n_peers; ++i) pr.slot[i] = (const double *)peer_slots[i];
+  hipLaunchKernelGGL(dt_rules_kernel, dim3(1), dim3(1), 0, h->stream, h->dt_dev, h->prm.time_step, h->prm.final_time,
+                     h->prm.global_time_step, (int)(h->prm.global_time_step && h->prm.cfl <= 0.0), pr);
   HIPCHK(h, hipGetLastError());
+  if (h->publish) h->pub_parity ^= 1;   // the next step publishes into the other slot
   return DFLO_OK;
 }
 

@@ -71,11 +71,22 @@ struct StageArgs {
   const int32_t *shard_list;  // null: all shards; else the n_list shards of this launch (rim / interior)
   int n_list;
   int *flags;   // POS 1: [0] negative mean state, [1] positivity root failure (as LimArgs::flags)
+  int step_index; // time step this launch belongs to (host count since set_solution), recorded with a raised flag
   unsigned long long *lim_mask;   // POS 2: [n_shards] bit = the limiter pass may have something to do in that cell
   double tvb_M;                   // POS 2: TVB constant M, < 0: the limiter pass has no TVB part
   int tvb_char, pos_check;        // POS 2: characteristic limiting; the positivity limiter runs in the pass
   KBasis kb;
 };
+
+// Failure flags (the reference's AssertThrow / exit(0), src/positivity.cc:28-38,160-169).  They live in host memory
+// mapped into the device -- written only when a kernel fails, never on the hot path -- so the host's step loop reads
+// them without a copy: [0] negative mean state, [1] positivity root failure, [2] 1 + index of the time step in which
+// the first flag went up.
+__device__ __forceinline__ void raise_flag(int *flags, int which, int step_index) {
+  volatile int *f = flags;
+  if (f[2] == 0) f[2] = step_index + 1;
+  f[which] = 1;
+}
 
 // compute_time_step_cartesian for one cell, src/claw.cc:495-509
 __device__ __forceinline__ double cfl_dt(const double *A, double h, double cfl, int degree) {

@@ -46,7 +46,8 @@ struct LimArgs {
   const int32_t *shard_count;
   const int32_t *lrbt;
   const double *cell_h;
-  int *flags;  // [0] negative mean state, [1] positivity root failure
+  int *flags;  // [0] negative mean state, [1] positivity root failure (raise_flag)
+  int step_index;
   double h_uniform, M, beta;
   int n_shards, uniform_h, tvb, char_lim, pos_lim;
   const int32_t *shard_list;
@@ -168,7 +169,7 @@ __global__ __launch_bounds__(64) void limiter_kernel(const LimArgs a) {
   if (a.pos_lim && marked) {
     const double eps = 1.0e-13;
     if (smin(A[RHO], pressure(A)) < eps) {  // "Fatal: Negative states" :26-38
-      if (active) atomicOr(&a.flags[0], 1);
+      if (active) raise_flag(a.flags, 0, a.step_index);
     } else {
       // density at GLL(Ng) x Gauss(N) and Gauss(N) x GLL(Ng)  (:43-47, :72-78)
       double rho_min = 1.0e20;
@@ -207,7 +208,7 @@ __global__ __launch_bounds__(64) void limiter_kernel(const LimArgs a) {
             }
             theta2 = smin(theta2, positivity_theta2(W, A, eps, fail));
           }
-      if (fail && active) atomicOr(&a.flags[1], 1);
+      if (fail && active) raise_flag(a.flags, 1, a.step_index);
       if (theta2 < 1.0) {
 #pragma unroll
         for (int c = 0; c < 4; ++c)
@@ -301,7 +302,7 @@ __global__ __launch_bounds__(64) void limiter_pk_kernel(const LimArgs a) {
   if (a.pos_lim) {
     const double eps = 1.0e-13;
     if (smin(A[RHO], pressure(A)) < eps) {
-      atomicOr(&a.flags[0], 1);
+      raise_flag(a.flags, 0, a.step_index);
     } else {
       // point value of component c at (Pt(xi), Pt(eta)) given the 1-D Legendre values
       auto point = [&](int c, const double *pxi, const double *peta) {
@@ -355,7 +356,7 @@ __global__ __launch_bounds__(64) void limiter_pk_kernel(const LimArgs a) {
               theta2 = smin(theta2, t);
             }
           }
-      if (fail) atomicOr(&a.flags[1], 1);
+      if (fail) raise_flag(a.flags, 1, a.step_index);
       if (theta2 < 1.0) {
 #pragma unroll
         for (int c = 0; c < 4; ++c)

@@ -240,12 +240,42 @@ int dflo_mesh_read_gmsh(const char *path, int32_t degree, int32_t mapping, dflo_
   return DFLO_OK;
 }
 
-int dflo_mesh_partition(const dflo_mesh_t *mesh, int32_t n_ranks, int32_t rank, dflo_mesh_t **out,
-                        const int32_t **send_cells, const int32_t **send_offsets, const int32_t **recv_offsets) {
-  if (!mesh || !out || n_ranks < 1 || rank < 0 || rank >= n_ranks) return fail(DFLO_ERR_BAD_PARAM, "dflo_mesh_partition: bad arguments");
+// Owner rank of every cell.  method DFLO_PART_SLAB: contiguous chunks of the cells sorted by centroid (x, then y) --
+// x-slabs on structured meshes (C4: 4001 columns -> 8 slabs, 1000 faces per cut).  DFLO_PART_RCB: recursive
+// coordinate bisection of the centroids (the longer extent is cut, the ranks are split as evenly as they go, the
+// cells in proportion) -- compact blocks on unstructured meshes (C5), what p4est's Morton partition gives the MPI
+// variant (src_mpi/claw.h:220).  Deterministic: every rank computes the same owners from the same mesh.
+static void rcb_split(std::vector<int32_t> &cells, size_t lo, size_t hi, int r0, int r1, const std::vector<double> &cx,
+                      const std::vector<double> &cy, std::vector<int32_t> &owner) {
+  if (r1 - r0 <= 1 || hi <= lo) {
+    for (size_t k = lo; k < hi; ++k) owner[cells[k]] = r0;
+    return;
+  }
+  double x0 = 1e300, x1 = -1e300, y0 = 1e300, y1 = -1e300;
+  for (size_t k = lo; k < hi; ++k) {
+    const int32_t c = cells[k];
+    x0 = std::min(x0, cx[c]); x1 = std::max(x1, cx[c]);
+    y0 = std::min(y0, cy[c]); y1 = std::max(y1, cy[c]);
+  }
+  const bool cut_x = (x1 - x0) >= (y1 - y0);
+  const std::vector<double> &a = cut_x ? cx : cy, &b = cut_x ? cy : cx;
+  const double a0 = cut_x ? x0 : y0, ea = std::max((cut_x ? x1 - x0 : y1 - y0), 1e-300) * 1e-9;
+  const double b0 = cut_x ? y0 : x0, eb = std::max((cut_x ? y1 - y0 : x1 - x0), 1e-300) * 1e-9;
+  std::sort(cells.begin() + lo, cells.begin() + hi, [&](int32_t p, int32_t q) {   // quantised keys: a strict weak order
+    const long long pa = std::llround((a[p] - a0) / ea), qa = std::llround((a[q] - a0) / ea);
+    if (pa != qa) return pa < qa;
+    const long long pb = std::llround((b[p] - b0) / eb), qb = std::llround((b[q] - b0) / eb);
+    if (pb != qb) return pb < qb;
+    return p < q;
+  });
+  const int rl = (r1 - r0) / 2;
+  const size_t mid = lo + (size_t)((long long)(hi - lo) * rl / (r1 - r0));
+  rcb_split(cells, lo, mid, r0, r0 + rl, cx, cy, owner);
+  rcb_split(cells, mid, hi, r0 + rl, r1, cx, cy, owner);
+}
+
+static void partition_owners(const dflo_mesh_t *mesh, int32_t n_ranks, int32_t method, std::vector<int32_t> &owner) {
   const int32_t n = mesh->n_cells;
-  if (mesh->n_owned_cells != n) return fail(DFLO_ERR_BAD_PARAM, "mesh is already partitioned");
-  // order cells by centroid (x, then y): contiguous chunks are x-slabs on structured meshes
   std::vector<int32_t> order(n);
   std::vector<double> cx(n), cy(n);
   for (int c = 0; c < n; ++c) {
@@ -254,6 +284,12 @@ int dflo_mesh_partition(const dflo_mesh_t *mesh, int32_t n_ranks, int32_t rank, 
     cx[c] = 0.25 * (v[0] + v[2] + v[4] + v[6]);
     cy[c] = 0.25 * (v[1] + v[3] + v[5] + v[7]);
   }
+  owner.assign(n, 0);
+  if (method == DFLO_PART_RCB) {
+    rcb_split(order, 0, (size_t)n, 0, n_ranks, cx, cy, owner);
+    return;
+  }
+  // order cells by centroid (x, then y): contiguous chunks are x-slabs on structured meshes
   double xmin = 1e300, xmax = -1e300;
   for (int c = 0; c < n; ++c) { xmin = std::min(xmin, cx[c]); xmax = std::max(xmax, cx[c]); }
   const double tol = 1e-9 * (xmax - xmin + 1e-300);
@@ -261,8 +297,31 @@ int dflo_mesh_partition(const dflo_mesh_t *mesh, int32_t n_ranks, int32_t rank, 
     if (std::fabs(cx[a] - cx[b]) > tol) return cx[a] < cx[b];
     return cy[a] < cy[b];
   });
-  std::vector<int32_t> owner(n);
   for (int64_t k = 0; k < n; ++k) owner[order[k]] = (int32_t)(k * n_ranks / n);
+}
+
+int dflo_mesh_partition(const dflo_mesh_t *mesh, int32_t n_ranks, int32_t rank, dflo_mesh_t **out,
+                        const int32_t **send_cells, const int32_t **send_offsets, const int32_t **recv_offsets) {
+  return dflo_mesh_partition_ex(mesh, n_ranks, rank, DFLO_PART_SLAB, out, send_cells, send_offsets, recv_offsets);
+}
+
+int dflo_mesh_partition_owners(const dflo_mesh_t *mesh, int32_t n_ranks, int32_t method, int32_t *owner_out) {
+  if (!mesh || !owner_out || n_ranks < 1 || (method != DFLO_PART_SLAB && method != DFLO_PART_RCB))
+    return fail(DFLO_ERR_BAD_PARAM, "dflo_mesh_partition_owners: bad arguments");
+  std::vector<int32_t> owner;
+  partition_owners(mesh, n_ranks, method, owner);
+  std::memcpy(owner_out, owner.data(), owner.size() * sizeof(int32_t));
+  return DFLO_OK;
+}
+
+int dflo_mesh_partition_ex(const dflo_mesh_t *mesh, int32_t n_ranks, int32_t rank, int32_t method, dflo_mesh_t **out,
+                           const int32_t **send_cells, const int32_t **send_offsets, const int32_t **recv_offsets) {
+  if (!mesh || !out || n_ranks < 1 || rank < 0 || rank >= n_ranks || (method != DFLO_PART_SLAB && method != DFLO_PART_RCB))
+    return fail(DFLO_ERR_BAD_PARAM, "dflo_mesh_partition: bad arguments");
+  const int32_t n = mesh->n_cells;
+  if (mesh->n_owned_cells != n) return fail(DFLO_ERR_BAD_PARAM, "mesh is already partitioned");
+  std::vector<int32_t> owner;
+  partition_owners(mesh, n_ranks, method, owner);
   // owned cells keep the global order; ghosts sorted by (source rank, global id)
   std::vector<int32_t> local;
   for (int c = 0; c < n; ++c)

@@ -1,0 +1,869 @@
+// multi.hip -- several MI355X behind one handle: the native multi-device driver of include/dflo_hip.h.
+//
+// Replaces what the MPI variant of dflo gets from deal.II + MPI (src_mpi/):
+//   parallel::distributed::Triangulation, locally owned + ghost cells     src_mpi/claw.h:220      -> dflo_mesh_partition_ex
+//   current_solution.update_ghost_values() after update and after limiter  src_mpi/claw.cc:793,
+//                                                                          src_mpi/limiter.cc:232  -> pack / transport / unpack
+//   Utilities::MPI::min(global_dt)                                         src_mpi/claw.cc:579     -> peer reads | ncclAllReduce(min)
+//   right_hand_side.l2_norm()                                              src_mpi/claw.cc:777     -> sum of the per-part squares
+//   right_hand_side.compress(add)                                          src_mpi/assemble_explicit.cc:580 -> not needed (faces on
+//        a cut are integrated by both owners with the same integrating side, bit-identical flux)
+//
+// Two ways to own the devices, one stage schedule:
+//   dflo_hip_multi_create       one process, one host thread, n_devices engines; halos move with hipMemcpyPeerAsync over
+//                               xGMI, the time-step minimum is read from the peers' device slots (no host hop)
+//   dflo_hip_multi_create_rank  one process per GPU (what torchrun / mpirun start); halos move with grouped
+//                               ncclSend/ncclRecv, the time step with an 8-byte ncclAllReduce(min), all on the comm stream.
+//                               RCCL is loaded with dlopen the first time it is needed: single-GPU users do not need it.
+// Every part owns a compute stream M and a comm stream C.  One RK stage:
+//   M: [wait: ghosts of the previous stage unpacked]  rim shards (those that read ghost cells)      -> ev_rim
+//   C: wait ev_rim; (TVB: exchange the rim cells' new averages, wait for the interior update, limit the rim;)
+//      pack the rim cells' DoFs; send to / receive from the face neighbours; unpack into the ghost shards -> ev_unpack
+//   M: interior shards, their limiter, the stage's reductions              (runs while the cells travel)
+// This file is host code over the public halo seam of the engine (dflo_hip_stage_open / _update_part / _limit_part /
+// _finish / _pack_send / _unpack_ghost ...): a dflo maintainer with another transport can write the same against the header.
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>   // types and enums only: the functions are resolved with dlsym
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/dflo_hip.h"
+#include "basis.h"
+
+namespace {
+
+std::string g_multi_error;
+
+// ---------------------------------------------------------------- RCCL through dlopen
+struct Rccl {
+  void *lib = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+Rccl g_rccl;
+
+bool load_rccl(std::string &err) {
+  if (g_rccl.lib) return true;
+  const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  void *lib = nullptr;
+  for (const char *n : names)
+    if ((lib = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break;
+  if (!lib) { err = std::string("cannot load RCCL (librccl.so): ") + dlerror(); return false; }
+#define DFLO_SYM(field, name)                                                            \
+  do {                                                                                   \
+    *(void **)(&g_rccl.field) = dlsym(lib, name);                                        \
+    if (!g_rccl.field) { err = std::string("RCCL has no symbol ") + name; dlclose(lib); return false; } \
+  } while (0)
+  DFLO_SYM(GetUniqueId, "ncclGetUniqueId");
+  DFLO_SYM(CommInitRank, "ncclCommInitRank");
+  DFLO_SYM(CommDestroy, "ncclCommDestroy");
+  DFLO_SYM(GroupStart, "ncclGroupStart");
+  DFLO_SYM(GroupEnd, "ncclGroupEnd");
+  DFLO_SYM(Send, "ncclSend");
+  DFLO_SYM(Recv, "ncclRecv");
+  DFLO_SYM(AllReduce, "ncclAllReduce");
+  DFLO_SYM(GetErrorString, "ncclGetErrorString");
+#undef DFLO_SYM
+  g_rccl.lib = lib;
+  return true;
+}
+
+struct Part {
+  int index = 0;               // part number in the partition (= rank in rank mode)
+  int device = 0;
+  dflo_hip_handle eng = nullptr;
+  dflo_mesh_t *sub = nullptr;  // owned + ghost sub-mesh (cell_global_id: ids in the undivided mesh)
+  const int32_t *send_cells = nullptr, *send_off = nullptr, *recv_off = nullptr;   // [P+1] offsets, owned by `sub`
+  int n_owned = 0, n_cells = 0, n_send = 0, n_ghost = 0;
+  std::vector<int> peers;      // parts this one exchanges cells with
+  hipStream_t M = nullptr, C = nullptr;
+  hipEvent_t ev_rim = nullptr, ev_int = nullptr, ev_lim = nullptr, ev_unpack = nullptr, ev_fin = nullptr, ev_dt = nullptr;
+  hipEvent_t ev_sent_u = nullptr, ev_sent_a = nullptr;
+  double *send_u = nullptr, *send_a = nullptr;
+  double *recv_u[2] = {nullptr, nullptr}, *recv_a[2] = {nullptr, nullptr};   // alternate from exchange to exchange
+  void *dt_slot[2] = {nullptr, nullptr};   // the engine's published CFL minima
+  void *dt_ptr = nullptr, *res_ptr = nullptr;
+  bool unpack_pending = false;
+  std::vector<int32_t> bface_global;   // global boundary-face number of the engine's boundary faces
+};
+
+}  // namespace
+
+struct dflo_hip_multi {
+  std::vector<Part> parts;     // the parts this process owns
+  int n_parts = 1;             // parts of the partition (= n_ranks in rank mode)
+  int rank = 0;                // rank mode: this process's part
+  bool rank_mode = false, loopback = false;
+  ncclComm_t comm = nullptr;
+  dflo_params_t prm{};
+  int degree = 1, basis = 0, ndof = 16, N = 2, n_rk = 2;
+  int64_t n_cells_global = 0;
+  bool tvb = false, kxrcf = false, limited = false, sep_limiter = false;
+  int xparity = 0;             // which receive buffers the next exchange of DoFs / of averages fills
+  int aparity = 0;
+  int step_parity = 0;         // which published slot the next last stage fills
+  double *scal = nullptr;      // rank mode: device scratch for small all-reduces (on parts[0].device)
+  std::vector<int32_t> gb_cell, gb_face, gb_id;   // boundary faces of the undivided mesh, MeshWorker order
+  std::vector<double> gb_xy;
+  hipEvent_t ev_chunk[2] = {nullptr, nullptr};
+  std::string err;
+};
+
+namespace {
+
+#define MHIP(m, call)                                                           \
+  do {                                                                          \
+    hipError_t e_ = (call);                                                     \
+    if (e_ != hipSuccess) {                                                     \
+      (m)->err = std::string(#call) + ": " + hipGetErrorString(e_);             \
+      return DFLO_ERR_HIP;                                                      \
+    }                                                                           \
+  } while (0)
+#define MNCCL(m, call)                                                          \
+  do {                                                                          \
+    ncclResult_t r_ = (call);                                                   \
+    if (r_ != ncclSuccess) {                                                    \
+      (m)->err = std::string(#call) + ": " + g_rccl.GetErrorString(r_);         \
+      return DFLO_ERR_COMM;                                                     \
+    }                                                                           \
+  } while (0)
+#define MENG(m, part, call)                                                     \
+  do {                                                                          \
+    int rc_ = (call);                                                           \
+    if (rc_) {                                                                  \
+      (m)->err = std::string("part ") + std::to_string((part).index) + ": " + dflo_hip_last_error((part).eng); \
+      return rc_;                                                               \
+    }                                                                           \
+  } while (0)
+
+Part *local_part(dflo_hip_multi *m, int index) {
+  for (Part &p : m->parts)
+    if (p.index == index) return &p;
+  return nullptr;
+}
+
+// ---- transport.  post: the cells (width doubles each) packed in `send` leave for the peers; arrive: the comm stream
+// waits until the peers' cells are in this part's receive buffer `par`.
+int post(dflo_hip_multi *m, Part &p, const double *send, int width, bool averages, int par) {
+  if (p.peers.empty()) return DFLO_OK;
+  if (m->rank_mode) {
+    double *recv = averages ? p.recv_a[par] : p.recv_u[par];
+    MNCCL(m, g_rccl.GroupStart());
+    for (int q : p.peers) {
+      const size_t ns = (size_t)(p.send_off[q + 1] - p.send_off[q]) * width, nr = (size_t)(p.recv_off[q + 1] - p.recv_off[q]) * width;
+      if (ns) MNCCL(m, g_rccl.Send(send + (size_t)p.send_off[q] * width, ns, ncclDouble, q, m->comm, p.C));
+      if (nr) MNCCL(m, g_rccl.Recv(recv + (size_t)p.recv_off[q] * width, nr, ncclDouble, q, m->comm, p.C));
+    }
+    MNCCL(m, g_rccl.GroupEnd());
+    return DFLO_OK;
+  }
+  for (int q : p.peers) {
+    Part *dst = local_part(m, q);
+    const size_t n = (size_t)(p.send_off[q + 1] - p.send_off[q]) * width;
+    if (!n) continue;
+    double *to = (averages ? dst->recv_a[par] : dst->recv_u[par]) + (size_t)dst->recv_off[p.index] * width;
+    const double *from = send + (size_t)p.send_off[q] * width;
+    if (m->loopback) {   // test transport: the same copy as a self send/recv pair through RCCL
+      MNCCL(m, g_rccl.GroupStart());
+      MNCCL(m, g_rccl.Send(from, n, ncclDouble, 0, m->comm, p.C));
+      MNCCL(m, g_rccl.Recv(to, n, ncclDouble, 0, m->comm, p.C));
+      MNCCL(m, g_rccl.GroupEnd());
+    } else {
+      MHIP(m, hipMemcpyPeerAsync(to, dst->device, from, p.device, n * sizeof(double), p.C));
+    }
+  }
+  MHIP(m, hipEventRecord(averages ? p.ev_sent_a : p.ev_sent_u, p.C));
+  return DFLO_OK;
+}
+
+int arrive(dflo_hip_multi *m, Part &p, bool averages) {
+  if (m->rank_mode) return DFLO_OK;   // the receives were part of the group posted on this stream
+  for (int q : p.peers) {
+    Part *src = local_part(m, q);
+    if (src->send_off[p.index + 1] == src->send_off[p.index]) continue;
+    MHIP(m, hipStreamWaitEvent(p.C, averages ? src->ev_sent_a : src->ev_sent_u, 0));
+  }
+  return DFLO_OK;
+}
+
+// update_ghost_values() outside the overlapped stage (after set-up calls, in the KXRCF path): all parts pack, send, unpack
+int exchange_solution(dflo_hip_multi *m) {
+  const int par = m->xparity;
+  m->xparity ^= 1;
+  for (Part &p : m->parts) {
+    if (p.peers.empty()) continue;
+    MHIP(m, hipSetDevice(p.device));
+    if (p.unpack_pending) { MHIP(m, hipStreamWaitEvent(p.M, p.ev_unpack, 0)); p.unpack_pending = false; }
+    MHIP(m, hipEventRecord(p.ev_rim, p.M));
+    MHIP(m, hipStreamWaitEvent(p.C, p.ev_rim, 0));
+    MENG(m, p, dflo_hip_set_stream(p.eng, p.C));
+    MENG(m, p, dflo_hip_pack_send(p.eng, p.send_u));
+    int rc = post(m, p, p.send_u, m->ndof, false, par);
+    MENG(m, p, dflo_hip_set_stream(p.eng, p.M));
+    if (rc) return rc;
+  }
+  for (Part &p : m->parts) {
+    if (p.peers.empty()) continue;
+    MHIP(m, hipSetDevice(p.device));
+    int rc = arrive(m, p, false);
+    if (rc) return rc;
+    MENG(m, p, dflo_hip_set_stream(p.eng, p.C));
+    MENG(m, p, dflo_hip_unpack_ghost(p.eng, p.recv_u[par]));
+    MENG(m, p, dflo_hip_set_stream(p.eng, p.M));
+    MHIP(m, hipEventRecord(p.ev_unpack, p.C));
+    MHIP(m, hipStreamWaitEvent(p.M, p.ev_unpack, 0));
+  }
+  return DFLO_OK;
+}
+
+// one RK stage on every part of this process
+int run_stage(dflo_hip_multi *m, int rk, double dt) {
+  const bool last = rk == m->n_rk - 1;
+  bool any_peers = false;
+  for (Part &p : m->parts) any_peers |= !p.peers.empty();
+  if (!any_peers) {   // nothing to exchange: the plain stage
+    for (Part &p : m->parts) MENG(m, p, dflo_hip_stage(p.eng, rk, dt));
+    return DFLO_OK;
+  }
+  if (m->kxrcf) {
+    // the KXRCF indicator reads the neighbours' unlimited DoFs of the new stage: ghosts are refreshed between update and
+    // limiter as well (update_ghost_values before compute_shock_indicator in the MPI variant); no overlap on this path
+    for (Part &p : m->parts) {
+      MHIP(m, hipSetDevice(p.device));
+      if (p.unpack_pending) { MHIP(m, hipStreamWaitEvent(p.M, p.ev_unpack, 0)); p.unpack_pending = false; }
+      MENG(m, p, dflo_hip_stage_update(p.eng, rk, dt));
+    }
+    int rc = exchange_solution(m);
+    if (rc) return rc;
+    for (Part &p : m->parts) MENG(m, p, dflo_hip_stage_limit(p.eng));
+    return exchange_solution(m);
+  }
+  const int upar = m->xparity, apar = m->aparity;
+  m->xparity ^= 1;
+  if (m->tvb) m->aparity ^= 1;
+  // rim shards first
+  for (Part &p : m->parts) {
+    MHIP(m, hipSetDevice(p.device));
+    if (p.unpack_pending) { MHIP(m, hipStreamWaitEvent(p.M, p.ev_unpack, 0)); p.unpack_pending = false; }
+    MENG(m, p, dflo_hip_stage_open(p.eng, rk, dt));
+    MENG(m, p, dflo_hip_stage_update_part(p.eng, 1));
+    MHIP(m, hipEventRecord(p.ev_rim, p.M));
+  }
+  if (m->tvb) {
+    // the limiter of a rim cell needs the new averages of its neighbours across the cut and of the interior cells next to it
+    for (Part &p : m->parts) {
+      MHIP(m, hipSetDevice(p.device));
+      MHIP(m, hipStreamWaitEvent(p.C, p.ev_rim, 0));
+      MENG(m, p, dflo_hip_set_stream(p.eng, p.C));
+      MENG(m, p, dflo_hip_pack_send_avg(p.eng, p.send_a));
+      MENG(m, p, dflo_hip_set_stream(p.eng, p.M));
+      int rc = post(m, p, p.send_a, 4, true, apar);
+      if (rc) return rc;
+    }
+    for (Part &p : m->parts) {
+      MHIP(m, hipSetDevice(p.device));
+      MENG(m, p, dflo_hip_stage_update_part(p.eng, 2));
+      MHIP(m, hipEventRecord(p.ev_int, p.M));
+    }
+    for (Part &p : m->parts) {
+      MHIP(m, hipSetDevice(p.device));
+      int rc = arrive(m, p, true);
+      if (rc) return rc;
+      MENG(m, p, dflo_hip_set_stream(p.eng, p.C));
+      MENG(m, p, dflo_hip_unpack_ghost_avg(p.eng, p.recv_a[apar]));
+      MHIP(m, hipStreamWaitEvent(p.C, p.ev_int, 0));
+      MENG(m, p, dflo_hip_stage_limit_part(p.eng, 1));
+      MHIP(m, hipEventRecord(p.ev_lim, p.C));
+      MENG(m, p, dflo_hip_pack_send(p.eng, p.send_u));
+      MENG(m, p, dflo_hip_set_stream(p.eng, p.M));
+      rc = post(m, p, p.send_u, m->ndof, false, upar);
+      if (rc) return rc;
+    }
+    for (Part &p : m->parts) {
+      MHIP(m, hipSetDevice(p.device));
+      MENG(m, p, dflo_hip_stage_limit_part(p.eng, 2));
+      if (last) MHIP(m, hipStreamWaitEvent(p.M, p.ev_lim, 0));   // the step's reductions read what the rim limiter wrote
+      MENG(m, p, dflo_hip_stage_finish(p.eng));
+    }
+  } else {
+    for (Part &p : m->parts) {
+      MHIP(m, hipSetDevice(p.device));
+      MHIP(m, hipStreamWaitEvent(p.C, p.ev_rim, 0));
+      MENG(m, p, dflo_hip_set_stream(p.eng, p.C));
+      if (m->sep_limiter) {
+        MENG(m, p, dflo_hip_stage_limit_part(p.eng, 1));
+        MHIP(m, hipEventRecord(p.ev_lim, p.C));
+      }
+      MENG(m, p, dflo_hip_pack_send(p.eng, p.send_u));
+      MENG(m, p, dflo_hip_set_stream(p.eng, p.M));
+      int rc = post(m, p, p.send_u, m->ndof, false, upar);
+      if (rc) return rc;
+    }
+    for (Part &p : m->parts) {
+      MHIP(m, hipSetDevice(p.device));
+      MENG(m, p, dflo_hip_stage_update_part(p.eng, 2));
+      MENG(m, p, dflo_hip_stage_limit_part(p.eng, 2));
+      if (last && m->sep_limiter) MHIP(m, hipStreamWaitEvent(p.M, p.ev_lim, 0));
+      MENG(m, p, dflo_hip_stage_finish(p.eng));
+    }
+  }
+  // the neighbours' cells arrive: into the ghost shards, ready for the next stage's rim
+  for (Part &p : m->parts) {
+    MHIP(m, hipSetDevice(p.device));
+    int rc = arrive(m, p, false);
+    if (rc) return rc;
+    MENG(m, p, dflo_hip_set_stream(p.eng, p.C));
+    MENG(m, p, dflo_hip_unpack_ghost(p.eng, p.recv_u[upar]));
+    MENG(m, p, dflo_hip_set_stream(p.eng, p.M));
+    MHIP(m, hipEventRecord(p.ev_unpack, p.C));
+    p.unpack_pending = true;
+  }
+  return DFLO_OK;
+}
+
+// Utilities::MPI::min(global_dt) (src_mpi/claw.cc:579) on the device-resident time step, after the last stage of a step
+int reduce_dt(dflo_hip_multi *m) {
+  if (m->n_parts == 1) return DFLO_OK;   // finalize_kernel has applied the rules already
+  const int par = m->step_parity;
+  m->step_parity ^= 1;
+  if (m->rank_mode) {
+    Part &p = m->parts[0];
+    MHIP(m, hipEventRecord(p.ev_fin, p.M));
+    MHIP(m, hipStreamWaitEvent(p.C, p.ev_fin, 0));
+    double *raw = (double *)p.dt_ptr + 2;
+    MNCCL(m, g_rccl.AllReduce(raw, raw, 1, ncclDouble, ncclMin, m->comm, p.C));
+    MENG(m, p, dflo_hip_set_stream(p.eng, p.C));
+    MENG(m, p, dflo_hip_apply_dt_rules(p.eng));
+    MENG(m, p, dflo_hip_set_stream(p.eng, p.M));
+    MHIP(m, hipEventRecord(p.ev_dt, p.C));
+    MHIP(m, hipStreamWaitEvent(p.M, p.ev_dt, 0));
+    return DFLO_OK;
+  }
+  for (Part &p : m->parts) {
+    MHIP(m, hipSetDevice(p.device));
+    MHIP(m, hipEventRecord(p.ev_fin, p.M));
+  }
+  for (Part &p : m->parts) {
+    MHIP(m, hipSetDevice(p.device));
+    const void *slots[16];
+    int n = 0;
+    for (Part &q : m->parts) {
+      if (&q == &p) continue;
+      MHIP(m, hipStreamWaitEvent(p.M, q.ev_fin, 0));
+      slots[n++] = q.dt_slot[par];
+    }
+    MENG(m, p, dflo_hip_apply_dt_rules_peers(p.eng, n, slots));
+  }
+  return DFLO_OK;
+}
+
+int join_all(dflo_hip_multi *m) {
+  for (Part &p : m->parts) {
+    MHIP(m, hipSetDevice(p.device));
+    if (p.unpack_pending) { MHIP(m, hipStreamWaitEvent(p.M, p.ev_unpack, 0)); p.unpack_pending = false; }
+  }
+  return DFLO_OK;
+}
+
+int sync_all(dflo_hip_multi *m) {
+  int rc = join_all(m);
+  if (rc) return rc;
+  for (Part &p : m->parts) {
+    MHIP(m, hipSetDevice(p.device));
+    MHIP(m, hipStreamSynchronize(p.C));
+    MHIP(m, hipStreamSynchronize(p.M));
+  }
+  return DFLO_OK;
+}
+
+// rank mode: all-reduce of a few host doubles through the device scratch (set-up and reporting calls only)
+int host_allreduce(dflo_hip_multi *m, double *v, int n, ncclRedOp_t op) {
+  if (!m->rank_mode || m->n_parts == 1) return DFLO_OK;
+  Part &p = m->parts[0];
+  MHIP(m, hipSetDevice(p.device));
+  MHIP(m, hipMemcpyAsync(m->scal, v, n * sizeof(double), hipMemcpyHostToDevice, p.C));
+  MNCCL(m, g_rccl.AllReduce(m->scal, m->scal, n, ncclDouble, op, m->comm, p.C));
+  MHIP(m, hipMemcpyAsync(v, m->scal, n * sizeof(double), hipMemcpyDeviceToHost, p.C));
+  MHIP(m, hipStreamSynchronize(p.C));
+  return DFLO_OK;
+}
+
+// failure flags of all parts (and, in rank mode, of all ranks): every caller gets the same answer
+int check_all(dflo_hip_multi *m, bool synchronise) {
+  int worst = DFLO_OK;
+  for (Part &p : m->parts) {
+    int rc;
+    if (synchronise) rc = dflo_hip_check(p.eng);
+    else { int64_t st = -1; dflo_hip_failure_step(p.eng, &st); rc = st >= 0 ? dflo_hip_check(p.eng) : DFLO_OK; }
+    if (rc && rc != DFLO_ERR_NEGATIVE_MEAN_STATE && rc != DFLO_ERR_POSITIVITY_NO_ROOT) { m->err = dflo_hip_last_error(p.eng); return rc; }
+    if (rc && (!worst || rc > worst)) { worst = rc; m->err = std::string("part ") + std::to_string(p.index) + ": " + dflo_hip_last_error(p.eng); }
+  }
+  if (m->rank_mode && m->n_parts > 1) {
+    double v[2] = {worst == DFLO_ERR_NEGATIVE_MEAN_STATE ? 1.0 : 0.0, worst == DFLO_ERR_POSITIVITY_NO_ROOT ? 1.0 : 0.0};
+    int rc = host_allreduce(m, v, 2, ncclMax);
+    if (rc) return rc;
+    if (v[0] > 0.0) { if (!worst) m->err = "Fatal: Negative states (on another rank)"; worst = DFLO_ERR_NEGATIVE_MEAN_STATE; }
+    else if (v[1] > 0.0) { if (!worst) m->err = "Problem in positivity limiter (on another rank)"; worst = DFLO_ERR_POSITIVITY_NO_ROOT; }
+  }
+  return worst;
+}
+
+int setup_part(dflo_hip_multi *m, Part &p, const dflo_mesh_t *mesh, const dflo_params_t *prm, int method) {
+  int rc = dflo_mesh_partition_ex(mesh, m->n_parts, p.index, method, &p.sub, &p.send_cells, &p.send_off, &p.recv_off);
+  if (rc) { m->err = dflo_mesh_last_error(); return rc; }
+  p.n_cells = p.sub->n_cells;
+  p.n_owned = p.sub->n_owned_cells;
+  p.n_ghost = p.n_cells - p.n_owned;
+  p.n_send = p.send_off[m->n_parts];
+  for (int q = 0; q < m->n_parts; ++q)
+    if (q != p.index && (p.send_off[q + 1] > p.send_off[q] || p.recv_off[q + 1] > p.recv_off[q])) p.peers.push_back(q);
+  rc = dflo_hip_create(p.sub, prm, p.device, &p.eng);
+  if (rc) { m->err = dflo_hip_last_error(nullptr); return rc; }
+  MHIP(m, hipSetDevice(p.device));
+  MHIP(m, hipStreamCreate(&p.M));
+  MHIP(m, hipStreamCreate(&p.C));
+  MENG(m, p, dflo_hip_set_stream(p.eng, p.M));
+  hipEvent_t *evs[] = {&p.ev_rim, &p.ev_int, &p.ev_lim, &p.ev_unpack, &p.ev_fin, &p.ev_dt, &p.ev_sent_u, &p.ev_sent_a};
+  for (hipEvent_t *e : evs) MHIP(m, hipEventCreateWithFlags(e, hipEventDisableTiming));
+  MENG(m, p, dflo_hip_set_send_cells(p.eng, p.n_send, p.send_cells));
+  const size_t ns = std::max(p.n_send, 1), ng = std::max(p.n_ghost, 1);
+  MHIP(m, hipMalloc((void **)&p.send_u, ns * m->ndof * sizeof(double)));
+  MHIP(m, hipMalloc((void **)&p.send_a, ns * 4 * sizeof(double)));
+  for (int i = 0; i < 2; ++i) {
+    MHIP(m, hipMalloc((void **)&p.recv_u[i], ng * m->ndof * sizeof(double)));
+    MHIP(m, hipMalloc((void **)&p.recv_a[i], ng * 4 * sizeof(double)));
+  }
+  MENG(m, p, dflo_hip_scalar_ptrs(p.eng, &p.dt_ptr, &p.res_ptr));
+  MENG(m, p, dflo_hip_dt_publish(p.eng, (!m->rank_mode && m->n_parts > 1) ? 1 : 0, &p.dt_slot[0], &p.dt_slot[1]));
+  // the engine's boundary faces -> their numbers in the undivided mesh
+  const int nb = dflo_hip_n_boundary_faces(p.eng);
+  std::vector<int32_t> bc(std::max(nb, 1)), bf(std::max(nb, 1));
+  MENG(m, p, dflo_hip_boundary_faces(p.eng, bc.data(), bf.data(), nullptr, nullptr));
+  std::unordered_map<int64_t, int32_t> where;
+  where.reserve(m->gb_cell.size() * 2);
+  for (size_t b = 0; b < m->gb_cell.size(); ++b) where[(int64_t)m->gb_cell[b] * 4 + m->gb_face[b]] = (int32_t)b;
+  p.bface_global.resize(nb);
+  for (int b = 0; b < nb; ++b) {
+    auto it = where.find(p.sub->cell_global_id[bc[b]] * 4 + bf[b]);
+    if (it == where.end()) { m->err = "boundary face of a part not found in the undivided mesh"; return DFLO_ERR_COMM; }
+    p.bface_global[b] = it->second;
+  }
+  return DFLO_OK;
+}
+
+int create_common(const dflo_mesh_t *mesh, const dflo_params_t *prm, dflo_hip_multi *m) {
+  if (mesh->n_owned_cells != mesh->n_cells) { m->err = "the mesh handed to the multi-device driver must be the undivided one"; return DFLO_ERR_BAD_PARAM; }
+  if (mesh->degree < 1 || mesh->degree > DFLO_MAX_DEGREE) { m->err = "degree must be 1..3"; return DFLO_ERR_BAD_PARAM; }
+  m->prm = *prm;
+  m->degree = mesh->degree;
+  m->basis = mesh->basis;
+  m->N = mesh->degree + 1;
+  m->ndof = 4 * (mesh->basis == DFLO_BASIS_PK ? m->N * (m->N + 1) / 2 : m->N * m->N);
+  m->n_cells_global = mesh->n_cells;
+  m->tvb = prm->limiter_type == DFLO_LIMITER_TVB;
+  m->kxrcf = m->tvb && prm->shock_indicator != DFLO_IND_LIMITER;
+  m->limited = m->tvb || prm->pos_lim;
+  // boundary faces of the undivided mesh in MeshWorker order, and their quadrature points (src/assemble_explicit.cc:163-165)
+  const dflo::BasisTables bt = dflo::make_basis(mesh->degree);
+  for (int32_t c = 0; c < mesh->n_cells; ++c)
+    for (int f = 0; f < 4; ++f) {
+      const int32_t nb = mesh->cell_face_neighbor[(size_t)c * 4 + f];
+      if (nb >= 0 || nb == DFLO_NBR_NONE) continue;
+      m->gb_cell.push_back(c);
+      m->gb_face.push_back(f);
+      m->gb_id.push_back(DFLO_NBR_BOUNDARY_ID(nb));
+      const double *v = &mesh->cell_vertices[(size_t)c * 8];
+      for (int q = 0; q < m->N; ++q) {
+        const double s = bt.x[q];
+        const double xi = f == 0 ? 0.0 : (f == 1 ? 1.0 : s), eta = f == 2 ? 0.0 : (f == 3 ? 1.0 : s);
+        for (int d = 0; d < 2; ++d)
+          m->gb_xy.push_back((1 - xi) * (1 - eta) * v[d] + xi * (1 - eta) * v[2 + d] + (1 - xi) * eta * v[4 + d] + xi * eta * v[6 + d]);
+      }
+    }
+  return DFLO_OK;
+}
+
+void finish_setup(dflo_hip_multi *m) {
+  m->n_rk = dflo_hip_n_rk(m->parts[0].eng);
+  // is there a limiter pass of its own between update and pack?  (positivity alone on Qk is applied inside the stage kernel
+  // unless DFLO_FUSE_POS=0 says otherwise)
+  const char *e = std::getenv("DFLO_FUSE_POS");
+  const bool fused = m->prm.pos_lim && !m->tvb && m->basis == DFLO_BASIS_QK && !(e && e[0] == '0');
+  m->sep_limiter = m->limited && !fused;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *dflo_hip_multi_last_error(dflo_hip_multi_handle m) { return m ? m->err.c_str() : g_multi_error.c_str(); }
+
+int dflo_hip_multi_destroy(dflo_hip_multi_handle m) {
+  if (!m) return DFLO_OK;
+  for (Part &p : m->parts) {
+    hipSetDevice(p.device);
+    if (p.C) hipStreamSynchronize(p.C);
+    if (p.M) hipStreamSynchronize(p.M);
+  }
+  if (m->comm) g_rccl.CommDestroy(m->comm);
+  for (Part &p : m->parts) {
+    hipSetDevice(p.device);
+    if (p.eng) dflo_hip_destroy(p.eng);
+    hipFree(p.send_u); hipFree(p.send_a);
+    for (int i = 0; i < 2; ++i) { hipFree(p.recv_u[i]); hipFree(p.recv_a[i]); }
+    hipEvent_t evs[] = {p.ev_rim, p.ev_int, p.ev_lim, p.ev_unpack, p.ev_fin, p.ev_dt, p.ev_sent_u, p.ev_sent_a};
+    for (hipEvent_t e : evs) if (e) hipEventDestroy(e);
+    if (p.C) hipStreamDestroy(p.C);
+    if (p.M) hipStreamDestroy(p.M);
+    if (p.sub) dflo_mesh_free(p.sub);
+  }
+  if (m->scal) hipFree(m->scal);
+  for (int i = 0; i < 2; ++i) if (m->ev_chunk[i]) hipEventDestroy(m->ev_chunk[i]);
+  delete m;
+  return DFLO_OK;
+}
+
+int dflo_hip_multi_create(const dflo_mesh_t *mesh, const dflo_params_t *params, int n_devices, const int *device_ids,
+                          int partitioner, dflo_hip_multi_handle *out) {
+  if (!mesh || !params || !out || n_devices < 1 || n_devices > 16 || !device_ids) { g_multi_error = "bad arguments"; return DFLO_ERR_BAD_PARAM; }
+  *out = nullptr;
+  dflo_hip_multi *m = new dflo_hip_multi;
+  auto bail = [&](int rc) { g_multi_error = m->err; dflo_hip_multi_destroy(m); return rc; };
+  m->n_parts = n_devices;
+  int rc = create_common(mesh, params, m);
+  if (rc) return bail(rc);
+  if (const char *e = std::getenv("DFLO_MULTI_TRANSPORT")) m->loopback = std::strcmp(e, "rccl_loopback") == 0;
+  m->parts.resize(n_devices);
+  for (int i = 0; i < n_devices; ++i) {
+    m->parts[i].index = i;
+    m->parts[i].device = device_ids[i];
+  }
+  for (int i = 0; i < n_devices; ++i)
+    if ((rc = setup_part(m, m->parts[i], mesh, params, partitioner))) return bail(rc);
+  // what one part sends is what the other expects
+  for (Part &p : m->parts)
+    for (int q : p.peers) {
+      Part &o = m->parts[q];
+      if (p.send_off[q + 1] - p.send_off[q] != o.recv_off[p.index + 1] - o.recv_off[p.index]) { m->err = "partition: send and receive counts disagree"; return bail(DFLO_ERR_COMM); }
+    }
+  // the engines read each other's time-step slots (and hipMemcpyPeerAsync goes direct) over xGMI
+  for (Part &p : m->parts)
+    for (Part &q : m->parts) {
+      if (p.device == q.device) continue;
+      int can = 0;
+      hipDeviceCanAccessPeer(&can, p.device, q.device);
+      if (!can) { m->err = "devices " + std::to_string(p.device) + " and " + std::to_string(q.device) + " are not peer-accessible"; return bail(DFLO_ERR_HIP); }
+      hipSetDevice(p.device);
+      const hipError_t e = hipDeviceEnablePeerAccess(q.device, 0);
+      if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) { m->err = std::string("hipDeviceEnablePeerAccess: ") + hipGetErrorString(e); return bail(DFLO_ERR_HIP); }
+      (void)hipGetLastError();
+    }
+  if (m->loopback) {
+    if (!load_rccl(m->err)) return bail(DFLO_ERR_COMM);
+    ncclUniqueId id;
+    hipSetDevice(m->parts[0].device);
+    if (g_rccl.GetUniqueId(&id) != ncclSuccess || g_rccl.CommInitRank(&m->comm, 1, id, 0) != ncclSuccess) { m->err = "RCCL loopback communicator failed"; return bail(DFLO_ERR_COMM); }
+  }
+  finish_setup(m);
+  *out = m;
+  return DFLO_OK;
+}
+
+int dflo_hip_comm_unique_id(void *id128) {
+  if (!id128) return DFLO_ERR_BAD_PARAM;
+  if (!load_rccl(g_multi_error)) return DFLO_ERR_COMM;
+  static_assert(sizeof(ncclUniqueId) == DFLO_COMM_ID_BYTES, "ncclUniqueId size");
+  ncclUniqueId id;
+  const ncclResult_t r = g_rccl.GetUniqueId(&id);
+  if (r != ncclSuccess) { g_multi_error = std::string("ncclGetUniqueId: ") + g_rccl.GetErrorString(r); return DFLO_ERR_COMM; }
+  std::memcpy(id128, &id, sizeof(id));
+  return DFLO_OK;
+}
+
+int dflo_hip_multi_create_rank(const dflo_mesh_t *mesh, const dflo_params_t *params, int device_id, int rank, int n_ranks,
+                               const void *unique_id, int partitioner, dflo_hip_multi_handle *out) {
+  if (!mesh || !params || !out || n_ranks < 1 || rank < 0 || rank >= n_ranks || (n_ranks > 1 && !unique_id)) { g_multi_error = "bad arguments"; return DFLO_ERR_BAD_PARAM; }
+  *out = nullptr;
+  dflo_hip_multi *m = new dflo_hip_multi;
+  auto bail = [&](int rc) { g_multi_error = m->err; dflo_hip_multi_destroy(m); return rc; };
+  m->n_parts = n_ranks;
+  m->rank = rank;
+  m->rank_mode = true;
+  int rc = create_common(mesh, params, m);
+  if (rc) return bail(rc);
+  m->parts.resize(1);
+  m->parts[0].index = rank;
+  m->parts[0].device = device_id;
+  if ((rc = setup_part(m, m->parts[0], mesh, params, partitioner))) return bail(rc);
+  if (n_ranks > 1) {
+    if (!load_rccl(m->err)) return bail(DFLO_ERR_COMM);
+    ncclUniqueId id;
+    std::memcpy(&id, unique_id, sizeof(id));
+    if (hipSetDevice(device_id) != hipSuccess) { m->err = "hipSetDevice failed"; return bail(DFLO_ERR_HIP); }
+    const ncclResult_t r = g_rccl.CommInitRank(&m->comm, n_ranks, id, rank);
+    if (r != ncclSuccess) { m->err = std::string("ncclCommInitRank: ") + g_rccl.GetErrorString(r); return bail(DFLO_ERR_COMM); }
+    if (hipMalloc((void **)&m->scal, 8 * sizeof(double)) != hipSuccess) { m->err = "hipMalloc(scratch) failed"; return bail(DFLO_ERR_NOMEM); }
+  }
+  finish_setup(m);
+  *out = m;
+  return DFLO_OK;
+}
+
+int dflo_hip_multi_n_local(dflo_hip_multi_handle m) { return m ? (int)m->parts.size() : 0; }
+int dflo_hip_multi_n_parts(dflo_hip_multi_handle m) { return m ? m->n_parts : 0; }
+dflo_hip_handle dflo_hip_multi_engine(dflo_hip_multi_handle m, int i) { return (m && i >= 0 && i < (int)m->parts.size()) ? m->parts[i].eng : nullptr; }
+int64_t dflo_hip_multi_n_dofs(dflo_hip_multi_handle m) { return m ? m->n_cells_global * m->ndof : 0; }
+int64_t dflo_hip_multi_n_owned_dofs(dflo_hip_multi_handle m) {
+  int64_t n = 0;
+  if (m) for (Part &p : m->parts) n += (int64_t)p.n_owned * m->ndof;
+  return n;
+}
+int32_t dflo_hip_multi_n_rk(dflo_hip_multi_handle m) { return m ? m->n_rk : 0; }
+
+int dflo_hip_multi_part_cells(dflo_hip_multi_handle m, int i, int32_t *n_owned, int32_t *n_ghost, const int64_t **global_ids) {
+  if (!m || i < 0 || i >= (int)m->parts.size()) return DFLO_ERR_BAD_PARAM;
+  if (n_owned) *n_owned = m->parts[i].n_owned;
+  if (n_ghost) *n_ghost = m->parts[i].n_ghost;
+  if (global_ids) *global_ids = m->parts[i].sub->cell_global_id;
+  return DFLO_OK;
+}
+
+int dflo_hip_multi_set_solution(dflo_hip_multi_handle m, const double *u) {
+  if (!m || !u) return DFLO_ERR_BAD_PARAM;
+  int rc = join_all(m);
+  if (rc) return rc;
+  std::vector<double> loc;
+  for (Part &p : m->parts) {
+    loc.resize((size_t)p.n_cells * m->ndof);
+    for (int c = 0; c < p.n_cells; ++c)   // owned and ghost cells alike: the ghosts start with their owners' values
+      std::memcpy(&loc[(size_t)c * m->ndof], &u[(size_t)p.sub->cell_global_id[c] * m->ndof], m->ndof * sizeof(double));
+    MENG(m, p, dflo_hip_set_solution(p.eng, loc.data()));
+  }
+  return DFLO_OK;
+}
+
+const dflo_mesh_t *dflo_hip_multi_part_mesh(dflo_hip_multi_handle m, int i) {
+  return (m && i >= 0 && i < (int)m->parts.size()) ? m->parts[i].sub : nullptr;
+}
+
+int dflo_hip_multi_set_part_solution(dflo_hip_multi_handle m, int i, const double *u_part) {
+  if (!m || !u_part || i < 0 || i >= (int)m->parts.size()) return DFLO_ERR_BAD_PARAM;
+  int rc = join_all(m);
+  if (rc) return rc;
+  MENG(m, m->parts[i], dflo_hip_set_solution(m->parts[i].eng, u_part));
+  return DFLO_OK;
+}
+
+int dflo_hip_multi_get_solution(dflo_hip_multi_handle m, double *u) {
+  if (!m || !u) return DFLO_ERR_BAD_PARAM;
+  int rc = sync_all(m);
+  if (rc) return rc;
+  std::vector<double> loc;
+  for (Part &p : m->parts) {
+    loc.resize((size_t)p.n_cells * m->ndof);
+    MENG(m, p, dflo_hip_get_solution(p.eng, loc.data()));
+    for (int c = 0; c < p.n_owned; ++c)
+      std::memcpy(&u[(size_t)p.sub->cell_global_id[c] * m->ndof], &loc[(size_t)c * m->ndof], m->ndof * sizeof(double));
+  }
+  return DFLO_OK;
+}
+
+int dflo_hip_multi_get_cell_average(dflo_hip_multi_handle m, double *avg) {
+  if (!m || !avg) return DFLO_ERR_BAD_PARAM;
+  int rc = sync_all(m);
+  if (rc) return rc;
+  std::vector<double> loc;
+  for (Part &p : m->parts) {
+    loc.resize((size_t)p.n_cells * 4);
+    MENG(m, p, dflo_hip_get_cell_average(p.eng, loc.data()));
+    for (int c = 0; c < p.n_owned; ++c) std::memcpy(&avg[(size_t)p.sub->cell_global_id[c] * 4], &loc[(size_t)c * 4], 4 * sizeof(double));
+  }
+  return DFLO_OK;
+}
+
+int32_t dflo_hip_multi_n_boundary_faces(dflo_hip_multi_handle m) { return m ? (int32_t)m->gb_cell.size() : 0; }
+
+int dflo_hip_multi_boundary_faces(dflo_hip_multi_handle m, int32_t *cell, int32_t *face, int32_t *boundary_id, double *xy) {
+  if (!m) return DFLO_ERR_BAD_PARAM;
+  const size_t n = m->gb_cell.size();
+  if (cell) std::memcpy(cell, m->gb_cell.data(), n * sizeof(int32_t));
+  if (face) std::memcpy(face, m->gb_face.data(), n * sizeof(int32_t));
+  if (boundary_id) std::memcpy(boundary_id, m->gb_id.data(), n * sizeof(int32_t));
+  if (xy) std::memcpy(xy, m->gb_xy.data(), m->gb_xy.size() * sizeof(double));
+  return DFLO_OK;
+}
+
+int dflo_hip_multi_set_boundary_values(dflo_hip_multi_handle m, int which, const double *values) {
+  if (!m || !values || which < 0 || which > 1) return DFLO_ERR_BAD_PARAM;
+  const size_t row = (size_t)m->N * 4;
+  std::vector<double> loc;
+  for (Part &p : m->parts) {
+    if (p.bface_global.empty()) continue;
+    loc.resize(p.bface_global.size() * row);
+    for (size_t b = 0; b < p.bface_global.size(); ++b) std::memcpy(&loc[b * row], &values[(size_t)p.bface_global[b] * row], row * sizeof(double));
+    MENG(m, p, dflo_hip_set_boundary_values(p.eng, which, loc.data()));
+  }
+  return DFLO_OK;
+}
+
+int dflo_hip_multi_set_boundary_program(dflo_hip_multi_handle m, int32_t boundary_id, int32_t component, int32_t n_ops, const int32_t *ops,
+                                        int32_t n_consts, const double *consts) {
+  if (!m) return DFLO_ERR_BAD_PARAM;
+  for (Part &p : m->parts) MENG(m, p, dflo_hip_set_boundary_program(p.eng, boundary_id, component, n_ops, ops, n_consts, consts));
+  return DFLO_OK;
+}
+
+int dflo_hip_multi_compute_dt(dflo_hip_multi_handle m, double elapsed_time, double *dt) {
+  if (!m || !dt) return DFLO_ERR_BAD_PARAM;
+  int rc = join_all(m);
+  if (rc) return rc;
+  double best = 1.0e300;
+  for (Part &p : m->parts) {
+    double d = 0.0;
+    MENG(m, p, dflo_hip_compute_dt(p.eng, elapsed_time, &d));
+    best = std::min(best, d);   // the rules (cap by time_step, clip to final_time) are monotone: they commute with the minimum
+  }
+  if ((rc = host_allreduce(m, &best, 1, ncclMin))) return rc;
+  *dt = best;
+  return DFLO_OK;
+}
+
+int dflo_hip_multi_step(dflo_hip_multi_handle m, double dt, double *res_norm0, double *res_norm) {
+  if (!m) return DFLO_ERR_BAD_PARAM;
+  for (int rk = 0; rk < m->n_rk; ++rk) {
+    int rc = run_stage(m, rk, dt);
+    if (rc) return rc;
+  }
+  for (Part &p : m->parts) MENG(m, p, dflo_hip_end_step(p.eng));
+  int rc = reduce_dt(m);
+  if (rc) return rc;
+  if ((rc = sync_all(m))) return rc;
+  if (res_norm0 || res_norm) {
+    double tot[4] = {0, 0, 0, 0};
+    for (Part &p : m->parts) {
+      double r[4];
+      MHIP(m, hipSetDevice(p.device));
+      MHIP(m, hipMemcpy(r, p.res_ptr, sizeof(r), hipMemcpyDeviceToHost));
+      for (int i = 0; i < 3; ++i) tot[i] += r[i];
+    }
+    if ((rc = host_allreduce(m, tot, 3, ncclSum))) return rc;
+    if (res_norm0) *res_norm0 = std::sqrt(tot[0]);
+    if (res_norm) *res_norm = std::sqrt(tot[m->n_rk - 1]);
+  }
+  return check_all(m, false);
+}
+
+int dflo_hip_multi_advance(dflo_hip_multi_handle m, int n_steps, double *elapsed_time_inout) {
+  if (!m || n_steps < 0 || !elapsed_time_inout) return DFLO_ERR_BAD_PARAM;
+  double dt0 = 0.0;
+  int rc = dflo_hip_multi_compute_dt(m, *elapsed_time_inout, &dt0);   // host value for the first step only
+  if (rc) return rc;
+  // the host looks at the failure flags every kCheckEvery steps without draining the device (see dflo_hip_advance); with
+  // one process per GPU the ranks must leave the loop together, so there the flags are read at the end only
+  constexpr int kCheckEvery = 32;
+  Part &p0 = m->parts[0];
+  if (!m->rank_mode) {
+    MHIP(m, hipSetDevice(p0.device));
+    for (int i = 0; i < 2; ++i)
+      if (!m->ev_chunk[i]) MHIP(m, hipEventCreateWithFlags(&m->ev_chunk[i], hipEventDisableTiming));
+  }
+  int chunk = 0;
+  for (int s = 0; s < n_steps; ++s) {
+    if (!m->rank_mode && s > 0 && s % kCheckEvery == 0) {
+      MHIP(m, hipSetDevice(p0.device));
+      MHIP(m, hipEventRecord(m->ev_chunk[chunk & 1], p0.M));
+      ++chunk;
+      if (chunk >= 2) {
+        MHIP(m, hipEventSynchronize(m->ev_chunk[chunk & 1]));
+        bool failed = false;
+        for (Part &p : m->parts) { int64_t st = -1; dflo_hip_failure_step(p.eng, &st); failed |= st >= 0; }
+        if (failed) break;
+      }
+    }
+    for (int rk = 0; rk < m->n_rk; ++rk)
+      if ((rc = run_stage(m, rk, s == 0 ? dt0 : -1.0))) return rc;
+    for (Part &p : m->parts) MENG(m, p, dflo_hip_end_step(p.eng));
+    if ((rc = reduce_dt(m))) return rc;
+  }
+  if ((rc = sync_all(m))) return rc;
+  double tt[4];
+  MHIP(m, hipSetDevice(p0.device));
+  MHIP(m, hipMemcpy(tt, p0.dt_ptr, sizeof(tt), hipMemcpyDeviceToHost));
+  *elapsed_time_inout = tt[1];
+  return check_all(m, false);
+}
+
+int dflo_hip_multi_apply_limiter(dflo_hip_multi_handle m) {
+  if (!m) return DFLO_ERR_BAD_PARAM;
+  int rc = join_all(m);
+  if (rc) return rc;
+  if (m->kxrcf && (rc = exchange_solution(m))) return rc;
+  for (Part &p : m->parts) MENG(m, p, dflo_hip_apply_limiter(p.eng));
+  return exchange_solution(m);
+}
+
+int dflo_hip_multi_apply_positivity_limiter(dflo_hip_multi_handle m) {
+  if (!m) return DFLO_ERR_BAD_PARAM;
+  int rc = join_all(m);
+  if (rc) return rc;
+  int worst = DFLO_OK;
+  for (Part &p : m->parts) {
+    const int r = dflo_hip_apply_positivity_limiter(p.eng);
+    if (r) { worst = r; m->err = dflo_hip_last_error(p.eng); }
+  }
+  if ((rc = exchange_solution(m))) return rc;
+  const int all = check_all(m, true);
+  return all ? all : worst;
+}
+
+int dflo_hip_multi_residual(dflo_hip_multi_handle m, int which, double *rhs) {
+  if (!m || !rhs) return DFLO_ERR_BAD_PARAM;
+  int rc = join_all(m);
+  if (rc) return rc;
+  std::vector<double> loc;
+  for (Part &p : m->parts) {
+    loc.resize((size_t)p.n_cells * m->ndof);
+    MENG(m, p, dflo_hip_residual(p.eng, which, loc.data()));
+    for (int c = 0; c < p.n_owned; ++c)
+      std::memcpy(&rhs[(size_t)p.sub->cell_global_id[c] * m->ndof], &loc[(size_t)c * m->ndof], m->ndof * sizeof(double));
+  }
+  return DFLO_OK;
+}
+
+int dflo_hip_multi_check(dflo_hip_multi_handle m) { return m ? check_all(m, true) : DFLO_ERR_BAD_PARAM; }
+int dflo_hip_multi_synchronize(dflo_hip_multi_handle m) { return m ? sync_all(m) : DFLO_ERR_BAD_PARAM; }
+
+int dflo_hip_multi_stage_timing(dflo_hip_multi_handle m, int enable, double *avg_ms, int64_t *n) {
+  if (!m) return DFLO_ERR_BAD_PARAM;
+  int rc = sync_all(m);
+  if (rc) return rc;
+  double worst = 0.0;
+  int64_t cnt = 0;
+  for (Part &p : m->parts) {   // the slowest part sets the pace
+    double ms = 0.0;
+    int64_t k = 0;
+    MENG(m, p, dflo_hip_stage_timing(p.eng, enable, &ms, &k));
+    if (ms > worst) worst = ms;
+    cnt = std::max(cnt, k);
+  }
+  if (avg_ms) *avg_ms = worst;
+  if (n) *n = cnt;
+  return DFLO_OK;
+}
+
+}  // extern "C"

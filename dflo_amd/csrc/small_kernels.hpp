@@ -265,8 +265,19 @@ struct FinalArgs {
   double *partial; // [kFinBlocks][4] workgroup partials
   int *counter;    // workgroups done
   int n_shards, n_stages, res_stride, do_dt, advance_time, global_rules;  // shard_res: [n_stages][res_stride]
+  int fixed_dt;    // "time step type = global" with cfl <= 0: dt = time_step (src/claw.cc:455-460)
+  double *publish; // multi-device: the raw minimum also goes here (a slot the peers read, alternating from step to step)
   double time_step, final_time, dt_host;
 };
+// the global-time-step rules of compute_time_step (src/claw.cc:455-476) applied to the raw CFL minimum
+__device__ __forceinline__ double dt_rules(double dt, double t, double time_step, double final_time, int global_rules, int fixed_dt) {
+  if (fixed_dt) return time_step;
+  if (global_rules) {
+    if (dt > 0 && time_step > 0) dt = fmin(dt, time_step);
+    if (t + dt > final_time) dt = final_time - t;
+  }
+  return dt;
+}
 constexpr int kFinBlocks = 32;   // workgroups of the two-level reduction
 __global__ __launch_bounds__(256) void finalize_kernel(const FinalArgs a) {
   __shared__ double sred[4][4];
@@ -317,19 +328,22 @@ __global__ __launch_bounds__(256) void finalize_kernel(const FinalArgs a) {
     double dt = spart[3];
     for (int i = 1; i < (int)gridDim.x; ++i) dt = fmin(dt, spart[i * 4 + 3]);
     a.dt_dev[2] = dt;
-    if (a.global_rules) {  // src/claw.cc:469-476, only for "time step type = global"
-      if (dt > 0 && a.time_step > 0) dt = fmin(dt, a.time_step);
-      if (tt + dt > a.final_time) dt = a.final_time - tt;
-    }
-    a.dt_dev[0] = dt;
+    if (a.publish) *a.publish = dt;
+    a.dt_dev[0] = dt_rules(dt, tt, a.time_step, a.final_time, a.global_rules, a.fixed_dt);
   }
 }
-// re-apply the rules after an external all-reduce(min) of dt_dev[2] (multi-device)
-__global__ void dt_rules_kernel(double *dt_dev, double time_step, double final_time) {
+// re-apply the rules after an external all-reduce(min) of dt_dev[2] (multi-device), or after taking the minimum over
+// the slots the other engines of this process published (peer reads over xGMI)
+constexpr int kMaxPeers = 16;
+struct DtPeers {
+  const double *slot[kMaxPeers];
+  int n;
+};
+__global__ void dt_rules_kernel(double *dt_dev, double time_step, double final_time, int global_rules, int fixed_dt, DtPeers peers) {
   double dt = dt_dev[2], t = dt_dev[1];
-  if (dt > 0 && time_step > 0) dt = fmin(dt, time_step);
-  if (t + dt > final_time) dt = final_time - t;
-  dt_dev[0] = dt;
+  for (int i = 0; i < peers.n; ++i) dt = fmin(dt, *(const volatile double *)peers.slot[i]);
+  dt_dev[2] = dt;
+  dt_dev[0] = dt_rules(dt, t, time_step, final_time, global_rules, fixed_dt);
 }
 
 

@@ -630,7 +630,7 @@ __global__ __launch_bounds__(64 * N, ((GEO == 1 && N != 3) || N == 4) ? 2 : 3) v
     }
     const double eps = 1.0e-13;
     const bool bad = smin(A[RHO], pressure(A)) < eps;   // "Fatal: Negative states" :26-38
-    if (bad && active && row == 0) atomicOr(&a.flags[0], 1);
+    if (bad && active && row == 0) raise_flag(a.flags, 0, a.step_index);
     double *pm = red + 5 * N * 64;   // [3][N][64] minima of the rows: density, theta2 (speculative), theta2 (after theta1)
     // theta2 of this wave's points (:138-178) for the current unew / Us
     auto pressure_theta = [&](bool &fail) {
@@ -693,7 +693,7 @@ __global__ __launch_bounds__(64 * N, ((GEO == 1 && N != 3) || N == 4) ? 2 : 3) v
       for (int b = 0; b < N; ++b) theta2 = smin(theta2, pm[(2 * N + b) * 64 + lane]);
     }
     if (bad) theta2 = 1.0;
-    else if (fail && active) atomicOr(&a.flags[1], 1);
+    else if (fail && active) raise_flag(a.flags, 1, a.step_index);
     if (active && (t1 || theta2 < 1.0)) {   // rare: the rows stored by the update are replaced
       double *np = a.Unew + (size_t)shard * 4 * NS2 * 64 + lane;
 #pragma unroll

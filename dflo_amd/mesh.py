@@ -11,13 +11,14 @@ from ._lib import lib, DfloError
 class Mesh:
     """Owns a dflo_mesh_t built by the C++ host library."""
 
-    def __init__(self, ptr, comm=None):
+    def __init__(self, ptr, comm=None, owner=None):
         self._ptr = ptr
         self.comm = comm  # (send_cells, send_offsets, recv_offsets) for partitioned meshes
+        self._owner = owner  # borrowed view: `owner` keeps the C mesh alive and frees it
 
     def __del__(self):
         try:
-            if self._ptr:
+            if self._ptr and self._owner is None:
                 lib.dflo_mesh_free(self._ptr)
                 self._ptr = None
         except Exception:
@@ -61,11 +62,20 @@ class Mesh:
         if rc:
             raise DfloError(rc, lib.dflo_mesh_last_error().decode())
 
-    def partition(self, n_ranks, rank):
+    def partition_owners(self, n_ranks, method="slab"):
+        """Owner rank of every cell under the partitioner `method` ("slab" | "rcb")."""
+        o = np.empty(self.n_cells, dtype=np.int32)
+        rc = lib.dflo_mesh_partition_owners(self._ptr, n_ranks, _lib.PARTITIONER[method], _lib.iptr(o))
+        if rc:
+            raise DfloError(rc, lib.dflo_mesh_last_error().decode())
+        return o
+
+    def partition(self, n_ranks, rank, method="slab"):
         """Owned + one ghost layer sub-mesh of `rank` (replaces parallel::distributed::Triangulation)."""
         out = C.POINTER(_lib.MeshStruct)()
         sc, so, ro = (C.POINTER(C.c_int32)(), C.POINTER(C.c_int32)(), C.POINTER(C.c_int32)())
-        rc = lib.dflo_mesh_partition(self._ptr, n_ranks, rank, C.byref(out), C.byref(sc), C.byref(so), C.byref(ro))
+        rc = lib.dflo_mesh_partition_ex(self._ptr, n_ranks, rank, _lib.PARTITIONER[method], C.byref(out), C.byref(sc), C.byref(so),
+                                        C.byref(ro))
         if rc:
             raise DfloError(rc, lib.dflo_mesh_last_error().decode())
         so_a = np.ctypeslib.as_array(so, shape=(n_ranks + 1,)).copy()

@@ -215,6 +215,10 @@ int dflo_hip_get_shock_indicator(dflo_hip_handle h, double *shock_indicator);
 /* Device-side failure flags raised by kernels, checked here (no mid-kernel abort):
  * returns DFLO_OK, DFLO_ERR_NEGATIVE_MEAN_STATE or DFLO_ERR_POSITIVITY_NO_ROOT. */
 int dflo_hip_check(dflo_hip_handle h);
+/* Index (0-based, counted from the last dflo_hip_set_solution) of the time step in which the first failure flag went
+ * up, -1 if none: where the reference would have stopped (src/positivity.cc:28-38 throws, :160-169 exits, inside the
+ * stage).  dflo_hip_advance looks at the flags every 32 steps and returns early with the error. */
+int dflo_hip_failure_step(dflo_hip_handle h, int64_t *step);
 int dflo_hip_synchronize(dflo_hip_handle h);
 
 /* Average duration (ms) of the stage kernel launches since the last reset, measured with HIP events on the
@@ -271,6 +275,72 @@ int dflo_hip_scalar_ptrs(dflo_hip_handle h, void **dt_ptr, void **res_ptr);
 /* dt_ptr[2] holds the raw CFL minimum of this device; after an external all-reduce(min) of that
  * double, re-apply the time_step cap and final_time clip (src/claw.cc:468-476) into dt_ptr[0]. */
 int dflo_hip_apply_dt_rules(dflo_hip_handle h);
+/* Several engines in one process (dflo_hip_multi_create): with publishing on, the last stage of a step also leaves the
+ * raw CFL minimum in one of two device slots (alternating from step to step, so that a slow peer never reads a value
+ * of the wrong step); apply_dt_rules_peers takes the minimum over this engine's dt_ptr[2] and the n_peers slots of the
+ * other engines (read over xGMI peer access) and applies the rules -- Utilities::MPI::min of src_mpi/claw.cc:579
+ * without a host hop. */
+int dflo_hip_dt_publish(dflo_hip_handle h, int enable, void **slot0, void **slot1);
+int dflo_hip_apply_dt_rules_peers(dflo_hip_handle h, int n_peers, const void *const *peer_slots);
+
+/* ------------------------------------------------ several devices behind one handle */
+/* The native multi-device driver (dflo_amd/csrc/multi.hip): partitions the undivided mesh, owns one engine per part and
+ * runs the stage schedule of the MPI variant -- update_ghost_values() after the update and after the limiter
+ * (src_mpi/claw.cc:793, src_mpi/limiter.cc:232), Utilities::MPI::min(global_dt) (src_mpi/claw.cc:579), the summed
+ * ||rhs|| (src_mpi/claw.cc:777) -- with the rim shards of every part advanced first and their cells in flight while the
+ * interior shards are computed.  State, boundary data and results cross this boundary in the numbering of the
+ * UNDIVIDED mesh (cells, DoFs, boundary faces in MeshWorker order), exactly as for a single engine.
+ *
+ *   dflo_hip_multi_create       one process (dflo's serial tree, src/): n_devices engines driven by the calling thread;
+ *                               halos by hipMemcpyPeerAsync over xGMI, the time-step minimum by peer reads of device
+ *                               slots.  device_ids may repeat (several parts on one device).
+ *   dflo_hip_multi_create_rank  one process per GPU (dflo's MPI tree, src_mpi/): this process is part `rank` of n_ranks;
+ *                               halos by grouped ncclSend/ncclRecv, the time step by an 8-byte ncclAllReduce(min) on the
+ *                               device.  unique_id: DFLO_COMM_ID_BYTES bytes obtained on one rank with
+ *                               dflo_hip_comm_unique_id and handed to the others by the host program's own means
+ *                               (MPI_Bcast where src_mpi/main.cc has MPI; a torch.distributed broadcast in bench.py).
+ *                               set_solution / boundary values take global arrays and use this rank's cells; the get_*
+ *                               calls fill this rank's owned cells and leave the rest of the array alone.
+ * partitioner: dflo_partitioner (declared with dflo_mesh_partition_ex below: 0 = slabs, 1 = RCB). */
+#define DFLO_COMM_ID_BYTES 128
+typedef struct dflo_hip_multi *dflo_hip_multi_handle;
+int dflo_hip_multi_create(const dflo_mesh_t *mesh, const dflo_params_t *params, int n_devices, const int *device_ids,
+                          int partitioner, dflo_hip_multi_handle *out);
+int dflo_hip_comm_unique_id(void *id_bytes);
+int dflo_hip_multi_create_rank(const dflo_mesh_t *mesh, const dflo_params_t *params, int device_id, int rank, int n_ranks,
+                               const void *unique_id, int partitioner, dflo_hip_multi_handle *out);
+int dflo_hip_multi_destroy(dflo_hip_multi_handle m);
+const char *dflo_hip_multi_last_error(dflo_hip_multi_handle m); /* m may be NULL: error of the last failed create */
+int dflo_hip_multi_n_parts(dflo_hip_multi_handle m);            /* parts of the partition */
+int dflo_hip_multi_n_local(dflo_hip_multi_handle m);            /* parts (engines) this process owns */
+dflo_hip_handle dflo_hip_multi_engine(dflo_hip_multi_handle m, int i); /* i-th local engine (timing, inspection) */
+int dflo_hip_multi_part_cells(dflo_hip_multi_handle m, int i, int32_t *n_owned, int32_t *n_ghost, const int64_t **global_ids);
+int64_t dflo_hip_multi_n_dofs(dflo_hip_multi_handle m);         /* of the undivided mesh */
+int64_t dflo_hip_multi_n_owned_dofs(dflo_hip_multi_handle m);   /* owned by this process */
+int32_t dflo_hip_multi_n_rk(dflo_hip_multi_handle m);
+/* the calls of a single engine, on the undivided mesh */
+int dflo_hip_multi_set_solution(dflo_hip_multi_handle m, const double *u);
+/* The same for one local part in ITS numbering (owned cells first, then its ghost cells; dflo_hip_multi_part_mesh
+ * gives the part's mesh, owned by the handle): a rank of a large run evaluates the initial data on its own cells only,
+ * as VectorTools::interpolate does on the locally owned range (src_mpi/ic.cc). */
+const dflo_mesh_t *dflo_hip_multi_part_mesh(dflo_hip_multi_handle m, int i);
+int dflo_hip_multi_set_part_solution(dflo_hip_multi_handle m, int i, const double *u_part);
+int dflo_hip_multi_get_solution(dflo_hip_multi_handle m, double *u);
+int dflo_hip_multi_get_cell_average(dflo_hip_multi_handle m, double *avg);
+int32_t dflo_hip_multi_n_boundary_faces(dflo_hip_multi_handle m);
+int dflo_hip_multi_boundary_faces(dflo_hip_multi_handle m, int32_t *cell, int32_t *face, int32_t *boundary_id, double *xy);
+int dflo_hip_multi_set_boundary_values(dflo_hip_multi_handle m, int which, const double *values);
+int dflo_hip_multi_set_boundary_program(dflo_hip_multi_handle m, int32_t boundary_id, int32_t component, int32_t n_ops,
+                                        const int32_t *ops, int32_t n_consts, const double *consts);
+int dflo_hip_multi_residual(dflo_hip_multi_handle m, int which, double *rhs_out);
+int dflo_hip_multi_compute_dt(dflo_hip_multi_handle m, double elapsed_time, double *dt);
+int dflo_hip_multi_step(dflo_hip_multi_handle m, double dt, double *res_norm0, double *res_norm);
+int dflo_hip_multi_advance(dflo_hip_multi_handle m, int n_steps, double *elapsed_time_inout);
+int dflo_hip_multi_apply_limiter(dflo_hip_multi_handle m);
+int dflo_hip_multi_apply_positivity_limiter(dflo_hip_multi_handle m);
+int dflo_hip_multi_check(dflo_hip_multi_handle m);
+int dflo_hip_multi_synchronize(dflo_hip_multi_handle m);
+int dflo_hip_multi_stage_timing(dflo_hip_multi_handle m, int enable, double *avg_ms, int64_t *n); /* slowest local part */
 
 /* Test hook: evaluates the device reciprocal / square-root forms the flux functions use
  * (dflo_amd/csrc/physics.hpp) on n host doubles. */
@@ -305,6 +375,14 @@ int dflo_mesh_make_periodic(dflo_mesh_t *mesh, int32_t id_first, int32_t id_seco
  * (ghost cells are ordered by source rank). Arrays owned by the mesh. */
 int dflo_mesh_partition(const dflo_mesh_t *mesh, int32_t n_ranks, int32_t rank, dflo_mesh_t **out,
                         const int32_t **send_cells, const int32_t **send_offsets, const int32_t **recv_offsets);
+/* The same with a choice of partitioner (dflo_partitioner): DFLO_PART_SLAB as above (C4: x-slabs of the 4001 x 1000
+ * lattice), DFLO_PART_RCB recursive coordinate bisection of the cell centres (compact blocks on unstructured meshes, C5;
+ * the MPI variant gets Morton-order blocks from p4est, src_mpi/claw.h:220).  partition_owners writes the owner rank of
+ * every cell ([n_cells]) without building a sub-mesh. */
+typedef enum { DFLO_PART_SLAB = 0, DFLO_PART_RCB = 1 } dflo_partitioner;
+int dflo_mesh_partition_ex(const dflo_mesh_t *mesh, int32_t n_ranks, int32_t rank, int32_t method, dflo_mesh_t **out,
+                           const int32_t **send_cells, const int32_t **send_offsets, const int32_t **recv_offsets);
+int dflo_mesh_partition_owners(const dflo_mesh_t *mesh, int32_t n_ranks, int32_t method, int32_t *owner_out);
 void dflo_mesh_free(dflo_mesh_t *mesh);
 const char *dflo_mesh_last_error(void);
 

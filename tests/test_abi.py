@@ -163,7 +163,8 @@ def test_partition_invariants_on_random_meshes(seed):
     world = int(rng.integers(2, 6))
     if world > m.n_cells:
         world = 2
-    parts = [m.partition(world, r) for r in range(world)]
+    method = "rcb" if seed % 2 else "slab"
+    parts = [m.partition(world, r, method) for r in range(world)]
     gnb, gnf = m.neighbors, m.neighbor_faces
     owner = np.full(m.n_cells, -1)
     for r, p in enumerate(parts):
@@ -173,6 +174,9 @@ def test_partition_invariants_on_random_meshes(seed):
         assert (owner[own] == -1).all()
         owner[own] = r
     assert (owner >= 0).all() and sum(p.n_owned for p in parts) == m.n_cells
+    assert (owner == m.partition_owners(world, method)).all()
+    counts = np.bincount(owner, minlength=world)
+    assert counts.max() - counts.min() <= (1 if method == "slab" else world)        # balanced
     for r, p in enumerate(parts):
         gid = np.asarray(p.global_ids)
         own, ghost = gid[: p.n_owned], gid[p.n_owned:]
@@ -195,3 +199,27 @@ def test_partition_invariants_on_random_meshes(seed):
             expect = np.asarray(pq.global_ids)[pq.n_owned + pq.comm[2][r]: pq.n_owned + pq.comm[2][r + 1]]
             assert (sent == expect).all()
         assert ro[world] == p.n_cells - p.n_owned                               # every ghost cell is received from someone
+
+
+def test_rcb_cuts_compact_blocks():
+    """Recursive coordinate bisection (DFLO_PART_RCB): a 16 x 16 lattice on 4 ranks falls into four 8 x 8 blocks (cut
+    length 2 x 16 faces, where four slabs cut 3 x 16), 3 ranks get 85/86 cells, and on an unstructured mesh the cut is
+    shorter than the slab partition's."""
+    from dflo_amd import gmsh
+    m = dflo_amd.Mesh.cartesian(16, 16, 0.0, 0.0, 1.0 / 16, [0, 0, 0, 0], 1)
+
+    def cut(mesh, owner):
+        nb = mesh.neighbors
+        inner = nb >= 0
+        return int((owner[:, None] != owner[np.where(inner, nb, 0)])[inner].sum()) // 2
+
+    o = m.partition_owners(4, "rcb").reshape(16, 16)
+    for r in range(4):
+        jj, ii = np.nonzero(o == r)
+        assert len(ii) == 64 and ii.max() - ii.min() == 7 and jj.max() - jj.min() == 7
+    assert cut(m, o.reshape(-1)) == 32 and cut(m, m.partition_owners(4, "slab")) == 48
+    c3 = np.bincount(m.partition_owners(3, "rcb"), minlength=3)
+    assert sorted(c3.tolist()) == [85, 85, 86]
+    verts, quads, bed, bid = gmsh.unstructured_quads(12, seed=3)
+    u = dflo_amd.Mesh.from_quads(verts, quads, bed, bid, 1)
+    assert cut(u, u.partition_owners(8, "rcb")) < cut(u, u.partition_owners(8, "slab"))

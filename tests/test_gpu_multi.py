@@ -1,0 +1,254 @@
+"""GPU: the native multi-device driver (dflo_hip_multi_*, dflo_amd/csrc/multi.hip) with 2 and 3 engines on ONE
+device -- the same stage schedule, streams, events, pack / peer copy / unpack and time-step reduction an 8-GPU node
+runs, with hipMemcpyPeerAsync copying to the same device -- against a single engine and against the oracle.
+
+What replaces what: update_ghost_values (src_mpi/claw.cc:793, src_mpi/limiter.cc:232), Utilities::MPI::min
+(src_mpi/claw.cc:579), right_hand_side.l2_norm (src_mpi/claw.cc:777).  Bars: smooth runs bit-identical to the single
+engine (every face flux is evaluated from the same two traces by whoever owns either side, and the additions of a cell
+happen in a fixed order whatever shard the cell lives in); limited runs (minmod switches) <= 1e-8.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import dflo_amd
+from dflo_amd import problems
+import oracle_lib
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+def _front(x, y):
+    s = 0.5 * (1.0 + np.tanh((x + 0.5 * y - 0.8) / 0.004))
+    rho, p = 1.0 + 0.6 * s, 1.0 + 0.9 * s
+    u, v = 0.6, 0.35
+    return [rho * u, rho * v, rho, p / 0.4 + 0.5 * rho * (u * u + v * v)]
+
+
+def _smooth(x, y):
+    return problems.smooth_perturbation(x, y, L=1.0)
+
+
+def _case(name):
+    """(mesh, parameters, initial/boundary function) of the named configuration"""
+    if name == "c2":      # BASELINE config 2 in small: periodic vortex, Q2, HLLC
+        mesh = dflo_amd.Mesh.cartesian(32, 24, -5.0, -5.0, 10.0 / 32, [-1, -1, -1, -1], 2)
+        return mesh, dflo_amd.Parameters(flux="hllc", cfl=0.9), problems.isentropic_vortex
+    if name == "c1":      # config 1: Q1, LxF (cell averages of the ghosts feed the flux)
+        mesh = dflo_amd.Mesh.cartesian(24, 24, -5.0, -5.0, 10.0 / 24, [-1, -1, -1, -1], 1)
+        return mesh, dflo_amd.Parameters(flux="lxf", cfl=0.9), problems.isentropic_vortex
+    if name == "c3":      # config 3: Sod, Q1, Roe, TVB + positivity
+        mesh = dflo_amd.Mesh.cartesian(64, 8, 0.0, 0.0, 1.0 / 64, [2, 1, 0, 0], 1)
+        prm = dflo_amd.Parameters(flux="roe", limiter="TVB", char_lim=True, pos_lim=True, M=0.0, beta=2.0, cfl=0.8,
+                                  boundary={0: "slip", 1: "outflow", 2: "inflow"})
+        return mesh, prm, problems.sod
+    if name == "c4":      # config 4 style: Q2, HLLC, TVB + positivity (limiter marks from the stage kernel)
+        mesh = dflo_amd.Mesh.cartesian(64, 8, 0.0, 0.0, 1.0 / 64, [2, 1, 0, 0], 2)
+        prm = dflo_amd.Parameters(flux="hllc", limiter="TVB", char_lim=True, pos_lim=True, M=0.0, beta=2.0, cfl=0.8,
+                                  boundary={0: "slip", 1: "outflow", 2: "inflow"})
+        return mesh, prm, problems.sod
+    if name == "c5":      # config 5 style: unstructured quads, q1 mapping, Q3, KFVS, positivity inside the stage kernel
+        from dflo_amd import gmsh
+        verts, quads, bed, bid = gmsh.unstructured_quads(10, seed=2)
+        mesh = dflo_amd.Mesh.from_quads(verts, quads, bed, bid, 3)
+        prm = dflo_amd.Parameters(flux="kfvs", pos_lim=True, cfl=0.4, boundary={0: "slip", 1: "outflow", 2: "slip", 3: "inflow"})
+        return mesh, prm, _smooth
+    if name == "kxrcf":   # KXRCF-gated TVB across the cuts
+        mesh = dflo_amd.Mesh.cartesian(48, 40, 0.0, 0.0, 1.0 / 48, [0, 0, 0, 0], 1)
+        prm = dflo_amd.Parameters(flux="hllc", limiter="TVB", pos_lim=True, beta=2.0, cfl=0.8, boundary={0: "outflow"},
+                                  shock_indicator="density")
+        return mesh, prm, _front
+    if name == "pk":      # Pk basis, positivity as a separate pass (sep_limiter path)
+        mesh = dflo_amd.Mesh.cartesian(24, 16, 0.0, 0.0, 1.0 / 24, [2, 1, 0, 0], 2)
+        mesh.set_basis("Pk")
+        prm = dflo_amd.Parameters(flux="hllc", pos_lim=True, cfl=0.5, boundary={0: "slip", 1: "outflow", 2: "inflow"})
+        return mesh, prm, problems.sod
+    raise KeyError(name)
+
+
+def _setup(claw, mesh, ic):
+    cell, face, bid, xy = claw.boundary_faces()
+    if len(cell):
+        bv = np.stack(ic(xy[..., 0], xy[..., 1]), axis=-1)
+        claw.set_boundary_values(0, bv)
+        claw.set_boundary_values(1, bv)
+    claw.set_initial_condition(mesh.interpolate(ic))
+
+
+def _run(claw, limited, steps=4, resident=3):
+    """IC limiting as run() does, `steps` host-driven steps, then `resident` device-resident ones"""
+    if limited:
+        claw.apply_limiter()
+    out = {"dt": [], "norms": []}
+    for _ in range(steps):
+        dt = claw.compute_time_step()
+        out["dt"].append(dt)
+        out["norms"].append(claw.iterate_explicit(dt))
+    out["t"] = claw.advance(resident)
+    out["u"] = claw.current_solution
+    out["avg"] = claw.cell_average
+    return out
+
+
+CASES = [("c2", 2, "slab"), ("c2", 3, "slab"), ("c2", 4, "rcb"), ("c1", 3, "slab"), ("c3", 2, "slab"), ("c4", 2, "slab"), ("c4", 3, "slab"),
+         ("c5", 2, "rcb"), ("c5", 3, "rcb"), ("kxrcf", 2, "slab"), ("kxrcf", 3, "rcb"), ("pk", 2, "slab")]
+
+
+@pytest.mark.parametrize("name,n_parts,method", CASES)
+def test_engines_on_one_device_match_the_single_engine(name, n_parts, method):
+    mesh, prm, ic = _case(name)
+    limited = prm.limiter == "TVB"
+    one = dflo_amd.ConservationLaw(mesh, prm)
+    _setup(one, mesh, ic)
+    ref = _run(one, limited)
+    multi = dflo_amd.MultiConservationLaw(mesh, prm, devices=[0] * n_parts, partitioner=method)
+    assert multi.n_parts == n_parts and multi.n_local == n_parts
+    owned = np.sort(multi.owned_cells())
+    assert (owned == np.arange(mesh.n_cells)).all()
+    _setup(multi, mesh, ic)
+    got = _run(multi, limited)
+    assert got["dt"] == ref["dt"]                 # the minimum of the parts' minima is the global minimum, exactly
+    assert got["t"] == ref["t"]                   # ... also when it never leaves the devices
+    for (a0, a1), (b0, b1) in zip(got["norms"], ref["norms"]):     # sums over shards: another order, same value to rounding
+        assert abs(a0 - b0) <= 1e-12 * b0 and abs(a1 - b1) <= 1e-12 * b1
+    if not limited and not prm.pos_lim:
+        assert np.array_equal(got["u"], ref["u"]) and np.array_equal(got["avg"], ref["avg"])
+    else:
+        assert rel(got["u"], ref["u"]) < 1e-8 and rel(got["avg"], ref["avg"]) < 1e-9
+
+
+@pytest.mark.parametrize("name,n_parts", [("c2", 3), ("c4", 2), ("c5", 3)])
+def test_engines_on_one_device_match_the_oracle(name, n_parts):
+    mesh, prm, ic = _case(name)
+    limited = prm.limiter == "TVB"
+    multi = dflo_amd.MultiConservationLaw(mesh, prm, devices=[0] * n_parts, partitioner="rcb" if name == "c5" else "slab")
+    _setup(multi, mesh, ic)
+    ora = oracle_lib.Oracle(mesh, prm)
+    cell, face, bid, xy = ora.boundary_faces()
+    if len(cell):
+        bv = np.stack(ic(xy[..., 0], xy[..., 1]), axis=-1)
+        ora.set_boundary_values(0, bv)
+        ora.set_boundary_values(1, bv)
+    ora.set_solution(mesh.interpolate(ic))
+    assert rel(multi.assemble_system(), ora.assemble()) < 1e-12
+    if limited:
+        multi.apply_limiter()
+        ora.apply_limiter()
+    t = 0.0
+    for it in range(4):
+        dt = multi.compute_time_step()
+        dto = ora.compute_time_step(t)
+        assert abs(dt - dto) <= 1e-12 * dto
+        r0, r1 = multi.iterate_explicit(dt)
+        q0, q1 = ora.step(dt)
+        assert abs(r0 - q0) <= 1e-10 * q0 and abs(r1 - q1) <= 1e-10 * q1
+        t += dt
+    tol = 1e-8 if (limited or prm.pos_lim) else 1e-11
+    assert rel(multi.current_solution, ora.get_solution()) < tol
+
+
+def test_one_part_is_the_plain_loop():
+    """n_devices = 1 (bench.py --gpus 1): no peers, the driver issues exactly the launches of dflo_hip_advance."""
+    mesh, prm, ic = _case("c2")
+    one = dflo_amd.ConservationLaw(mesh, prm)
+    _setup(one, mesh, ic)
+    multi = dflo_amd.MultiConservationLaw(mesh, prm, devices=[0])
+    _setup(multi, mesh, ic)
+    assert one.advance(7) == multi.advance(7)
+    assert np.array_equal(one.current_solution, multi.current_solution)
+    # the same through the one-process-per-GPU entry with a world of one (no communicator needed)
+    rank = dflo_amd.MultiConservationLaw.for_rank(mesh, prm, 0, 0, 1, None)
+    _setup(rank, mesh, ic)
+    assert rank.advance(7) == one.elapsed_time
+    assert np.array_equal(one.current_solution, rank.current_solution)
+
+
+def test_moving_boundary_programs_on_every_part():
+    """C4's top wall: the boundary state is a function of (x, t) evaluated by every engine from its own device clock"""
+    nx, ny = 40, 16
+    mesh = dflo_amd.Mesh.cartesian(nx, ny, 0.0, 0.0, 1.0 / ny, [4, 2, 1, 3], 2)
+    prm = dflo_amd.Parameters(flux="hllc", limiter="TVB", char_lim=True, pos_lim=True, M=100.0, beta=1.0, cfl=0.5,
+                              boundary={1: "slip", 2: "outflow", 3: "inflow", 4: "inflow"})
+    sh = "(x<1.0/6.0+(1+20*t)/sqrt(3))"
+    top = ["57.1576766498*" + sh, "-33.0*" + sh, "8.0*%s + 1.4*(1-%s)" % (sh, sh), "563.5*%s + 2.5*(1-%s)" % (sh, sh)]
+    res = []
+    for claw in (dflo_amd.ConservationLaw(mesh, prm), dflo_amd.MultiConservationLaw(mesh, prm, devices=[0, 0, 0])):
+        _setup(claw, mesh, problems.double_mach)
+        claw.set_boundary_function(3, top)
+        claw.apply_limiter()
+        t = claw.advance(12)
+        res.append((t, claw.current_solution))
+    assert res[0][0] == res[1][0]
+    assert rel(res[1][1], res[0][1]) < 1e-8
+
+
+@pytest.mark.parametrize("n_parts", [1, 2])
+def test_fixed_time_step_advances_the_clock(n_parts):
+    """"time step type = global" with cfl = 0 (the reference's default cfl) and `time step` given (src/claw.cc:455-460):
+    advance(n) is n steps of that dt -- on the device-resident loop too."""
+    mesh = dflo_amd.Mesh.cartesian(16, 16, -5.0, -5.0, 10.0 / 16, [-1, -1, -1, -1], 2)
+    prm = dflo_amd.Parameters(flux="hllc", cfl=0.0, time_step=2.0e-3)
+    u0 = mesh.interpolate(problems.isentropic_vortex)
+    a = dflo_amd.ConservationLaw(mesh, prm)
+    a.set_initial_condition(u0)
+    for _ in range(6):
+        assert a.compute_time_step() == 2.0e-3
+        a.iterate_explicit(2.0e-3)
+    b = dflo_amd.ConservationLaw(mesh, prm) if n_parts == 1 else dflo_amd.MultiConservationLaw(mesh, prm, devices=[0] * n_parts)
+    b.set_initial_condition(u0)
+    t = b.advance(6)
+    assert abs(t - 6 * 2.0e-3) < 1e-15
+    assert np.array_equal(a.current_solution, b.current_solution)
+
+
+def test_failure_is_reported_with_its_step():
+    """A run that goes negative: step-by-step and resident loops report the same error, the resident loop knows the step"""
+    mesh = dflo_amd.Mesh.cartesian(32, 4, 0.0, 0.0, 1.0 / 32, [0, 0, 0, 0], 2)
+    prm = dflo_amd.Parameters(flux="lxf", pos_lim=True, cfl=3.0, boundary={0: "outflow"})   # cfl far beyond stability
+
+    def blast(x, y):
+        z = np.zeros_like(x)
+        return z, z, np.ones_like(x), np.where(np.abs(x - 0.5) < 0.1, 1.0e4, 1.0e-2)
+    a = dflo_amd.ConservationLaw(mesh, prm)
+    _setup(a, mesh, blast)
+    step = None
+    for it in range(400):
+        try:
+            a.iterate_explicit(a.compute_time_step())
+        except dflo_amd.DfloError as e:
+            step, code = it, e.code
+            break
+    assert step is not None
+    for claw in (dflo_amd.ConservationLaw(mesh, prm), dflo_amd.MultiConservationLaw(mesh, prm, devices=[0, 0])):
+        _setup(claw, mesh, blast)
+        with pytest.raises(dflo_amd.DfloError) as ei:
+            claw.advance(400)
+        assert ei.value.code == code
+    import ctypes as C
+    from dflo_amd._lib import lib
+    b = dflo_amd.ConservationLaw(mesh, prm)
+    _setup(b, mesh, blast)
+    with pytest.raises(dflo_amd.DfloError):
+        b.advance(400)
+    st = C.c_int64()
+    lib.dflo_hip_failure_step(b._h, C.byref(st))
+    assert st.value == step
+
+
+def test_rccl_loopback_transport(monkeypatch):
+    """The RCCL transport on one GPU: the halo copies go through grouped ncclSend / ncclRecv on a one-rank communicator
+    (self send/recv), which exercises the library loading, the communicator, the group calls and their stream order --
+    everything of the one-process-per-GPU path except a second rank."""
+    monkeypatch.setenv("DFLO_MULTI_TRANSPORT", "rccl_loopback")
+    mesh, prm, ic = _case("c2")
+    one = dflo_amd.ConservationLaw(mesh, prm)
+    _setup(one, mesh, ic)
+    multi = dflo_amd.MultiConservationLaw(mesh, prm, devices=[0, 0, 0])
+    _setup(multi, mesh, ic)
+    assert one.advance(5) == multi.advance(5)
+    assert np.array_equal(one.current_solution, multi.current_solution)
