@@ -81,7 +81,7 @@ SYMBOLS = [
     "dflo_hip_multi_set_boundary_program", "dflo_hip_multi_residual", "dflo_hip_multi_compute_dt", "dflo_hip_multi_step",
     "dflo_hip_multi_advance", "dflo_hip_multi_apply_limiter", "dflo_hip_multi_apply_positivity_limiter",
     "dflo_hip_multi_check", "dflo_hip_multi_synchronize", "dflo_hip_multi_stage_timing",
-    "dflo_hip_multi_part_mesh", "dflo_hip_multi_set_part_solution",
+    "dflo_hip_multi_part_mesh", "dflo_hip_multi_set_part_solution", "dflo_hip_pack_send_cells", "dflo_hip_unpack_ghost_cells",
 ]
 PARTITIONER = {"slab": 0, "rcb": 1}
 COMM_ID_BYTES = 128
@@ -141,6 +141,8 @@ _sig("dflo_hip_pack_send_avg", C.c_int, _H, C.c_void_p)
 _sig("dflo_hip_unpack_ghost", C.c_int, _H, C.c_void_p)
 _sig("dflo_hip_unpack_ghost_avg", C.c_int, _H, C.c_void_p)
 _sig("dflo_hip_n_ghost_cells", C.c_int, _H)
+_sig("dflo_hip_pack_send_cells", C.c_int, _H, C.c_void_p)
+_sig("dflo_hip_unpack_ghost_cells", C.c_int, _H, C.c_void_p)
 _sig("dflo_hip_stage_update", C.c_int, _H, C.c_int, C.c_double)
 _sig("dflo_hip_stage_limit", C.c_int, _H)
 _sig("dflo_hip_stage_open", C.c_int, _H, C.c_int, C.c_double)

@@ -1323,6 +1323,31 @@ int dflo_hip_pack_send_avg(dflo_hip_handle h, void *device_buffer) {
   return DFLO_OK;
 }
 
+int dflo_hip_pack_send_cells(dflo_hip_handle h, void *device_buffer) {
+  if (check_handle(h) || !device_buffer) return DFLO_ERR_BAD_PARAM;
+  hipSetDevice(h->device);
+  if (h->n_send == 0) return DFLO_OK;
+  const long long tot = (long long)h->n_send * (h->ndof + 4);
+  hipLaunchKernelGGL(pack_cells_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, (double *)device_buffer,
+                     h->U[h->cur], h->avg[h->avg_cur], h->d_send_slots, h->n_send, h->ndof);
+  HIPCHK(h, hipGetLastError());
+  return DFLO_OK;
+}
+
+int dflo_hip_unpack_ghost_cells(dflo_hip_handle h, const void *device_buffer) {
+  if (check_handle(h)) return DFLO_ERR_BAD_PARAM;
+  hipSetDevice(h->device);
+  const Plan &p = h->plan;
+  const int n_ghost = p.n_cells - p.n_owned;
+  if (n_ghost == 0) return DFLO_OK;
+  if (!device_buffer) return DFLO_ERR_BAD_PARAM;
+  const long long tot = (long long)n_ghost * (h->ndof + 4);
+  hipLaunchKernelGGL(unpack_cells_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, (const double *)device_buffer,
+                     h->U[h->cur], h->avg[h->avg_cur], p.n_shards * 64, n_ghost, h->ndof);
+  HIPCHK(h, hipGetLastError());
+  return DFLO_OK;
+}
+
 int dflo_hip_n_ghost_cells(dflo_hip_handle h) { return h ? h->plan.n_cells - h->plan.n_owned : 0; }
 
 int dflo_hip_unpack_ghost(dflo_hip_handle h, const void *device_buffer) {

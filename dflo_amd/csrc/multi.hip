@@ -212,8 +212,8 @@ int exchange_solution(dflo_hip_multi *m) {
     MHIP(m, hipEventRecord(p.ev_rim, p.M));
     MHIP(m, hipStreamWaitEvent(p.C, p.ev_rim, 0));
     MENG(m, p, dflo_hip_set_stream(p.eng, p.C));
-    MENG(m, p, dflo_hip_pack_send(p.eng, p.send_u));
-    int rc = post(m, p, p.send_u, m->ndof, false, par);
+    MENG(m, p, dflo_hip_pack_send_cells(p.eng, p.send_u));
+    int rc = post(m, p, p.send_u, m->ndof + 4, false, par);
     MENG(m, p, dflo_hip_set_stream(p.eng, p.M));
     if (rc) return rc;
   }
@@ -223,7 +223,7 @@ int exchange_solution(dflo_hip_multi *m) {
     int rc = arrive(m, p, false);
     if (rc) return rc;
     MENG(m, p, dflo_hip_set_stream(p.eng, p.C));
-    MENG(m, p, dflo_hip_unpack_ghost(p.eng, p.recv_u[par]));
+    MENG(m, p, dflo_hip_unpack_ghost_cells(p.eng, p.recv_u[par]));
     MENG(m, p, dflo_hip_set_stream(p.eng, p.M));
     MHIP(m, hipEventRecord(p.ev_unpack, p.C));
     MHIP(m, hipStreamWaitEvent(p.M, p.ev_unpack, 0));
@@ -289,9 +289,9 @@ int run_stage(dflo_hip_multi *m, int rk, double dt) {
       MHIP(m, hipStreamWaitEvent(p.C, p.ev_int, 0));
       MENG(m, p, dflo_hip_stage_limit_part(p.eng, 1));
       MHIP(m, hipEventRecord(p.ev_lim, p.C));
-      MENG(m, p, dflo_hip_pack_send(p.eng, p.send_u));
+      MENG(m, p, dflo_hip_pack_send_cells(p.eng, p.send_u));
       MENG(m, p, dflo_hip_set_stream(p.eng, p.M));
-      rc = post(m, p, p.send_u, m->ndof, false, upar);
+      rc = post(m, p, p.send_u, m->ndof + 4, false, upar);
       if (rc) return rc;
     }
     for (Part &p : m->parts) {
@@ -309,9 +309,9 @@ int run_stage(dflo_hip_multi *m, int rk, double dt) {
         MENG(m, p, dflo_hip_stage_limit_part(p.eng, 1));
         MHIP(m, hipEventRecord(p.ev_lim, p.C));
       }
-      MENG(m, p, dflo_hip_pack_send(p.eng, p.send_u));
+      MENG(m, p, dflo_hip_pack_send_cells(p.eng, p.send_u));
       MENG(m, p, dflo_hip_set_stream(p.eng, p.M));
-      int rc = post(m, p, p.send_u, m->ndof, false, upar);
+      int rc = post(m, p, p.send_u, m->ndof + 4, false, upar);
       if (rc) return rc;
     }
     for (Part &p : m->parts) {
@@ -328,7 +328,7 @@ int run_stage(dflo_hip_multi *m, int rk, double dt) {
     int rc = arrive(m, p, false);
     if (rc) return rc;
     MENG(m, p, dflo_hip_set_stream(p.eng, p.C));
-    MENG(m, p, dflo_hip_unpack_ghost(p.eng, p.recv_u[upar]));
+    MENG(m, p, dflo_hip_unpack_ghost_cells(p.eng, p.recv_u[upar]));
     MENG(m, p, dflo_hip_set_stream(p.eng, p.M));
     MHIP(m, hipEventRecord(p.ev_unpack, p.C));
     p.unpack_pending = true;
@@ -442,10 +442,10 @@ int setup_part(dflo_hip_multi *m, Part &p, const dflo_mesh_t *mesh, const dflo_p
   for (hipEvent_t *e : evs) MHIP(m, hipEventCreateWithFlags(e, hipEventDisableTiming));
   MENG(m, p, dflo_hip_set_send_cells(p.eng, p.n_send, p.send_cells));
   const size_t ns = std::max(p.n_send, 1), ng = std::max(p.n_ghost, 1);
-  MHIP(m, hipMalloc((void **)&p.send_u, ns * m->ndof * sizeof(double)));
+  MHIP(m, hipMalloc((void **)&p.send_u, ns * (m->ndof + 4) * sizeof(double)));   // DoFs + cell average per cell
   MHIP(m, hipMalloc((void **)&p.send_a, ns * 4 * sizeof(double)));
   for (int i = 0; i < 2; ++i) {
-    MHIP(m, hipMalloc((void **)&p.recv_u[i], ng * m->ndof * sizeof(double)));
+    MHIP(m, hipMalloc((void **)&p.recv_u[i], ng * (m->ndof + 4) * sizeof(double)));
     MHIP(m, hipMalloc((void **)&p.recv_a[i], ng * 4 * sizeof(double)));
   }
   MENG(m, p, dflo_hip_scalar_ptrs(p.eng, &p.dt_ptr, &p.res_ptr));

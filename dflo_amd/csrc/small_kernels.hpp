@@ -183,6 +183,27 @@ __global__ void pack_kernel(double *buf, const double *U, const int32_t *slots, 
   const int slot = slots[k];
   buf[t] = U[((size_t)(slot >> 6) * ndof + d) * 64 + (slot & 63)];
 }
+// The same with the owner's cell average behind the DoFs of every cell, buf[k][ndof + 4]: a ghost cell then carries the
+// very bits its owner holds (an average formed again from the DoFs would differ from the stage kernel's in the last
+// place, and the LxF flux and the TVB differences read it)
+__global__ void pack_cells_kernel(double *buf, const double *U, const double *avg, const int32_t *slots, int n, int ndof) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int w = ndof + 4;
+  if (t >= (long long)n * w) return;
+  const int k = (int)(t / w), d = (int)(t - (long long)k * w);
+  const int slot = slots[k];
+  buf[t] = d < ndof ? U[((size_t)(slot >> 6) * ndof + d) * 64 + (slot & 63)]
+                    : avg[((size_t)(slot >> 6) * 4 + (d - ndof)) * 64 + (slot & 63)];
+}
+__global__ void unpack_cells_kernel(const double *buf, double *U, double *avg, int first_slot, int n_ghost, int ndof) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int w = ndof + 4;
+  if (t >= (long long)n_ghost * w) return;
+  const int g = (int)(t / w), d = (int)(t - (long long)g * w);
+  const int slot = first_slot + g;
+  if (d < ndof) U[((size_t)(slot >> 6) * ndof + d) * 64 + (slot & 63)] = buf[t];
+  else avg[((size_t)(slot >> 6) * 4 + (d - ndof)) * 64 + (slot & 63)] = buf[t];
+}
 // ghost cells: staging buffer [g][ndof] -> ghost shards, and their cell averages
 // one thread per (ghost cell, component): its DoFs travel buffer -> ghost shard (the buffer is read with unit stride
 // along the thread's own run of n_s values, the shard rows are written 64 cells wide) and their average is formed

@@ -270,6 +270,11 @@ int dflo_hip_pack_send(dflo_hip_handle h, void *device_buffer);
 int dflo_hip_pack_send_avg(dflo_hip_handle h, void *device_buffer);
 int dflo_hip_unpack_ghost(dflo_hip_handle h, const void *device_buffer);     /* also recomputes ghost averages */
 int dflo_hip_unpack_ghost_avg(dflo_hip_handle h, const void *device_buffer);
+/* DoFs and cell average of every listed cell in one record, [n][ndof + 4]: the ghost copy then holds the bits of its owner
+ * (an average formed again from the DoFs differs from the stage kernel's in the last place; the LxF flux and the TVB
+ * differences read it).  What the native multi-device driver ships. */
+int dflo_hip_pack_send_cells(dflo_hip_handle h, void *device_buffer);
+int dflo_hip_unpack_ghost_cells(dflo_hip_handle h, const void *device_buffer);
 /* device address of {dt, res_norm_sq} scalars for 8-byte all-reduces (src_mpi/claw.cc:579,777) */
 int dflo_hip_scalar_ptrs(dflo_hip_handle h, void **dt_ptr, void **res_ptr);
 /* dt_ptr[2] holds the raw CFL minimum of this device; after an external all-reduce(min) of that
