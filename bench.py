@@ -159,12 +159,44 @@ def build_case(args, world):
     return mesh, prm, ic, bc_fn, programs, nx, ny
 
 
+def run_parts(args, claw, mesh, ic, bc_fn, programs, nx, ny):
+    if bc_fn is not None:
+        cell, face, bid, xy = claw.boundary_faces()
+        bv = np.stack(bc_fn(xy[..., 0], xy[..., 1]), axis=-1)
+        claw.set_boundary_values(0, bv)
+        claw.set_boundary_values(1, bv)
+    claw.set_initial_condition(mesh.interpolate(ic))
+    for b, exprs in programs.items():
+        claw.set_boundary_function(b, exprs)
+    if args.config in ("c3", "c4"):
+        claw.apply_limiter()
+    mass0 = claw.cell_average.sum(axis=0)
+    _settle_clocks()
+    claw.advance(args.warmup)
+    claw.stage_timing(True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    claw.advance(args.steps)
+    torch.cuda.synchronize()
+    sec = time.perf_counter() - t0
+    kernel_ms, n_launch = claw.stage_timing(False)
+    a = claw.cell_average
+    pr = 0.4 * (a[:, 3] - 0.5 * (a[:, 0] ** 2 + a[:, 1] ** 2) / a[:, 2])
+    return {"sec": sec, "kernel_ms": kernel_ms, "n_launch": n_launch, "n_dofs_total": mesh.n_cells * mesh.ndof,
+            "n_dofs_launch": mesh.n_cells * mesh.ndof // args.parts_per_gpu, "mass0": mass0, "mass1": a.sum(axis=0), "nx": nx, "ny": ny,
+            "n_cells": mesh.n_cells, "n_rk": claw.n_rk, "min_rho": float(a[:, 2].min()), "min_p": float(pr.min())}
+
+
 def run_case(args, world, rank, local_rank, uid, barrier):
     """W warm-up and K timed steps through the native multi-device driver (dflo_hip_multi_*): one C call per phase, no
     Python between the steps.  Returns the measurements of this rank."""
     import dflo_amd
     mesh, prm, ic, bc_fn, programs, nx, ny = build_case(args, world)
     part = {"c5": "rcb"}.get(args.config, "slab")
+    if args.parts_per_gpu > 1:   # developer switch: several engines on this one GPU through the one-process driver -- what the
+        # exchange machinery (streams, events, pack / peer copy / unpack, time-step reduction) costs with no second GPU
+        claw = dflo_amd.MultiConservationLaw(mesh, prm, devices=[local_rank] * args.parts_per_gpu, partitioner=part)
+        return run_parts(args, claw, mesh, ic, bc_fn, programs, nx, ny)
     claw = dflo_amd.MultiConservationLaw.for_rank(mesh, prm, local_rank, rank, world, uid, partitioner=part)
     if bc_fn is not None:
         cell, face, bid, xy = claw.boundary_faces()
@@ -220,6 +252,7 @@ def main():
     ap.add_argument("--basis", default="Qk", choices=["Qk", "Pk"], help="c2 only; Pk: dflo's FE_DGP (modal) element")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the Q1 LxF line (north_star's 40 %-at-Q1 target)")
+    ap.add_argument("--parts-per-gpu", type=int, default=1, help="developer switch: this many engines on the one GPU (one-process driver)")
     ap.add_argument("--no-tvb", action="store_true", help="c4 only: positivity limiter alone (BASELINE config 4 as written)")
     ap.add_argument("--config", default="c2", choices=["c2", "c3", "c4", "c5"],
                     help="c2 (default, the headline): periodic vortex; c3: Sod tube 2048x256 Q1 Roe TVB+positivity; "
@@ -311,6 +344,7 @@ def main():
                              "c5": "free stream + bump on %d unstructured quads (q1 mapping), Q3, KFVS, positivity, SSP-RK 3 stages"
                                    % m["n_cells"]}[args.config],
                 "n_dofs": n_dofs_total, "n_rk": n_rk,
+                "parts_per_gpu": args.parts_per_gpu,
                 "parallelism": "%s, %d rank(s), native driver (dflo_hip_multi_*): RCCL send/recv halos + 8-byte all-reduce(min) per step"
                                % ("RCB blocks" if args.config == "c5" else "x-slabs", world),
                 "check": check, "preheat_s": 0.0 if os.environ.get("DFLO_BENCH_NO_PREHEAT") == "1" else 0.4,

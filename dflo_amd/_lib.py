@@ -52,7 +52,7 @@ class ParamsStruct(C.Structure):
         ("gravity", C.c_double), ("cfl", C.c_double), ("time_step", C.c_double), ("final_time", C.c_double),
         ("M", C.c_double), ("beta", C.c_double),
         ("bc_kind", C.c_int32 * MAX_BOUNDARIES),
-        ("shock_indicator", C.c_int32), ("reserved_", C.c_int32),
+        ("shock_indicator", C.c_int32), ("conserve_angular_momentum", C.c_int32),
     ]
 
 

@@ -157,6 +157,13 @@ int run(int argc, char **argv) {
       chunk = std::min<long>(next_output_iter - time_iter, 64);
       if (max_steps >= 0) chunk = std::min(chunk, max_steps - time_iter);
       chunk = std::max<long>(chunk, 1);
+      if (chunk > 1 && final_time < 1e19) {
+        // a chunk must not run past final_time (the loop of src/claw.cc:1026 stops there): size it by the current time
+        // step with a margin for its growth; the last steps are taken one by one
+        double dt_now = 0.0;
+        chk(dflo_hip_compute_dt(h, elapsed, &dt_now), h, "compute_dt");
+        chunk = dt_now > 0 ? std::max<long>(1, std::min<long>(chunk, (long)(0.8 * (final_time - elapsed) / dt_now))) : 1;
+      }
     }
     if (chunk > 1) {   // dt and time stay on the device
       chk(dflo_hip_advance(h, (int)chunk, &elapsed), h, "advance");

@@ -421,6 +421,7 @@ int launch_limiter(dflo_hip_engine *h, int tvb, int pos, int part, bool stage_da
   l.tvb = tvb;
   l.char_lim = h->prm.char_lim;
   l.pos_lim = pos;
+  l.conserve_ang_mom = h->prm.conserve_angular_momentum;
   l.kb = h->kb;
   l.shock = tvb ? h->d_shock : nullptr;
   l.mask = (stage_data && tvb && h->aux_fresh) ? h->lim_mask : nullptr;

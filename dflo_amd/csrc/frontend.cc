@@ -441,8 +441,10 @@ Deck make_deck(const Prm &prm, const std::string &directory) {
   d.mapping = prm.get("", "mapping");
   const char *ts = "time stepping";
   double cfl = prm.get_double(ts, "cfl"), time_step = prm.get_double(ts, "time step"), final_time = prm.get_double(ts, "final time");
-  if (prm.get_bool(ts, "stationary")) { time_step = 1.0; final_time = 1.0e20; }   // src/parameters.cc:425-429
-  else if (!(cfl > 0 || time_step > 0)) throw std::runtime_error("cfl and time_step zero");
+  // stationary: src/parameters.cc:425-429 sets dt = 1, final time = 1e20 and compute_time_step returns at once
+  // (src/claw.cc:449-450) -- the steady-state mode of the implicit solver, not part of the explicit path
+  if (prm.get_bool(ts, "stationary")) throw std::runtime_error("stationary = true: steady-state runs belong to the implicit solver, which is not provided");
+  if (!(cfl > 0 || time_step > 0)) throw std::runtime_error("cfl and time_step zero");
   if (prm.get("linear solver", "method") != "rk3")
     throw std::runtime_error("linear solver method = " + prm.get("linear solver", "method") + ": only the explicit rk3 path is provided");
   if (prm.get_bool("refinement", "refinement") && d.basis == "Pk") throw std::runtime_error("Refinement does not work for Pk basis");
@@ -469,6 +471,7 @@ Deck make_deck(const Prm &prm, const std::string &directory) {
   p.final_time = final_time;
   p.M = prm.get_double("limiter", "M");
   p.beta = prm.get_double("limiter", "beta");
+  p.conserve_angular_momentum = prm.get_bool("limiter", "conserve angular momentum");   // src/limiter.cc:496-500
   static const char *inds[] = {"limiter", "density", "energy", "u2"};
   for (int k = 0; k < 4; ++k)
     if (prm.get("limiter", "shock indicator") == inds[k]) p.shock_indicator = k;

@@ -50,6 +50,7 @@ struct LimArgs {
   int step_index;
   double h_uniform, M, beta;
   int n_shards, uniform_h, tvb, char_lim, pos_lim;
+  int conserve_ang_mom;   // Pk: src/limiter.cc:496-500
   const int32_t *shard_list;
   int n_list;
   const double *shock;  // KXRCF indicator per cell, or null: "shock indicator = limiter" marks every cell (1e20)
@@ -262,6 +263,7 @@ __global__ __launch_bounds__(64) void limiter_pk_kernel(const LimArgs a) {
       Dx[c] = U[c][1] * sqrt_3;       // mode (1,0)
       Dy[c] = U[c][N] * sqrt_3;       // mode (0,1) = index k+1
     }
+    const double ang_mom = Dx[MY] - Dy[MX];   // angular momentum of a square cell = v_x - u_y, :453
     const int il = a.lrbt[((size_t)shard * 4 + 0) * 64 + lane], ir = a.lrbt[((size_t)shard * 4 + 1) * 64 + lane];
     const int ib = a.lrbt[((size_t)shard * 4 + 2) * 64 + lane], it = a.lrbt[((size_t)shard * 4 + 3) * 64 + lane];
 #pragma unroll
@@ -291,6 +293,10 @@ __global__ __launch_bounds__(64) void limiter_pk_kernel(const LimArgs a) {
       if (a.char_lim) {
         to_con(e, 0, Dxn);
         to_con(e, 1, Dyn);
+      }
+      if (a.conserve_ang_mom) {   // :496-500
+        Dyn[MX] = 0.5 * (Dyn[MX] - (ang_mom - Dxn[MY]));
+        Dxn[MY] = ang_mom + Dyn[MX];
       }
 #pragma unroll
       for (int c = 0; c < 4; ++c)

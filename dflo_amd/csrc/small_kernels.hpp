@@ -295,7 +295,7 @@ __device__ __forceinline__ double dt_rules(double dt, double t, double time_step
   if (fixed_dt) return time_step;
   if (global_rules) {
     if (dt > 0 && time_step > 0) dt = fmin(dt, time_step);
-    if (t + dt > final_time) dt = final_time - t;
+    if (t + dt > final_time) dt = fmax(final_time - t, 0.0);   // (never a step backwards once t has rounded past final_time)
   }
   return dt;
 }

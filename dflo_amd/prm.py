@@ -137,8 +137,9 @@ class InputDeck:
         ts, lim, out, sol = sub["time stepping"], sub["limiter"], sub["output"], sub["linear solver"]
         self.is_stationary = ts["stationary"]
         cfl, time_step, final_time = ts["cfl"], ts["time step"], ts["final time"]
-        if self.is_stationary:   # src/parameters.cc:425-429
-            time_step, final_time = 1.0, 1.0e20
+        if self.is_stationary:   # src/parameters.cc:425-429 sets dt = 1, final time = 1e20 and compute_time_step returns at
+            # once (src/claw.cc:449-450): the steady-state mode of the implicit solver, not part of the explicit path
+            raise PrmError("stationary = true: steady-state runs belong to the implicit solver, which is not provided")
         elif not (cfl > 0 or time_step > 0):
             raise PrmError("cfl and time_step zero")
         if sol["method"] != "rk3":
@@ -172,7 +173,8 @@ class InputDeck:
             flux=sub["flux"]["flux"], limiter=lim["type"], char_lim=lim["characteristic limiter"],
             pos_lim=lim["positivity limiter"], cfl=cfl, time_step=time_step, final_time=final_time, M=lim["M"],
             beta=lim["beta"], gravity=top["gravity"], time_step_type=ts["time step type"],
-            boundary=self.boundary_kind, shock_indicator=lim["shock indicator"])
+            boundary=self.boundary_kind, shock_indicator=lim["shock indicator"],
+            conserve_angular_momentum=lim["conserve angular momentum"])
         self.schlieren_plot = out["schlieren plot"]
         self.output_time_step = out["time step"]
         self.output_iter_step = int(out["iter step"])

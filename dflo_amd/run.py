@@ -106,10 +106,13 @@ class Run:
             if fast and (self.bc_on_device or not self.bc_time_dependent) and d.output_time_step >= 1e19:
                 chunk = max(1, min(next_output_iter - self.time_iter, 64,
                                    (max_steps - self.time_iter) if max_steps is not None else 64))
+                if chunk > 1 and final_time < 1e19:
+                    # a chunk must not run past final_time (the loop of src/claw.cc:1026 stops there): size it by the
+                    # current time step with a margin for its growth; the last steps are taken one by one
+                    dt_now = claw.compute_time_step()
+                    chunk = max(1, min(chunk, int(0.8 * (final_time - claw.elapsed_time) / dt_now))) if dt_now > 0 else 1
             if chunk > 1:
-                # dt and time stay on the device; the CFL rule clips the last step to final_time, after which
-                # dt = 0 and the remaining steps of the chunk leave the state untouched
-                claw.advance(chunk)
+                claw.advance(chunk)                            # dt and time stay on the device
                 self.time_iter += chunk
                 self.log("It=%d, T=%.12g" % (self.time_iter, claw.elapsed_time))
             else:

@@ -108,7 +108,8 @@ typedef struct dflo_params {
   double beta;
   int32_t bc_kind[DFLO_MAX_BOUNDARIES]; /* dflo_bc_kind per boundary id */
   int32_t shock_indicator; /* dflo_shock_indicator: "shock indicator" of subsection limiter, src/parameters.cc:228-239 */
-  int32_t reserved_;
+  int32_t conserve_angular_momentum; /* "conserve angular momentum" of subsection limiter: the correction of the limited
+                                        slopes in apply_limiter_TVB_Pk, src/limiter.cc:453,496-500 (Pk basis only) */
 } dflo_params_t;
 
 /* Opcodes of the postfix programs of dflo_hip_set_boundary_program: what deal.II's FunctionParser evaluates for the

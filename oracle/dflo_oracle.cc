@@ -1212,6 +1212,7 @@ void apply_limiter_TVB_Pk(Oracle &o) {
       Dx[i] = u[i * ns + 1] * sqrt_3;
       Dy[i] = u[i * ns + o.degree + 1] * sqrt_3;
     }
+    const double ang_mom = Dx[1] - Dy[0];   // angular momentum for square cells = v_x - u_y, src/limiter.cc:453
     const double *A = &o.avg[(size_t)c * NC];
     for (int i = 0; i < NC; ++i) { dbx[i] = Dx[i]; dfx[i] = Dx[i]; dby[i] = Dy[i]; dfy[i] = Dy[i]; }
     if (o.lcell[c] >= 0) for (int i = 0; i < NC; ++i) dbx[i] = A[i] - o.avg[(size_t)o.lcell[c] * NC + i];
@@ -1241,6 +1242,10 @@ void apply_limiter_TVB_Pk(Oracle &o) {
       if (o.prm.char_lim) {
         transform_to_con(Rx, Dxn);
         transform_to_con(Ry, Dyn);
+      }
+      if (o.prm.conserve_angular_momentum) {   // src/limiter.cc:496-500
+        Dyn[0] = 0.5 * (Dyn[0] - (ang_mom - Dxn[1]));
+        Dxn[1] = ang_mom + Dyn[0];
       }
       for (int i = 0; i < o.ndof; ++i) {
         int ci = i / ns, bi = i % ns;

@@ -1,6 +1,8 @@
-"""CPU, world_size 2, gloo: the partition + halo-exchange plumbing of dflo_amd.dist, driven with the
-oracle on each rank's owned+ghost sub-mesh, must reproduce the single-process oracle run.  (The HIP
-engine cannot run here; the same HaloExchange class moves the engine's buffers on the GPU box.)"""
+"""CPU, world_size 2 and 3, gloo: the partition (slabs and RCB) and the exchange lists the native multi-device driver
+works from (dflo_mesh_partition_ex: send cells / send offsets / receive offsets per peer), driven with the oracle on each
+rank's owned+ghost sub-mesh, must reproduce the single-process oracle run.  The HIP engines cannot run here; on the GPU
+box dflo_amd/csrc/multi.hip moves the same records between the same cells with RCCL send/recv or peer copies
+(tests/test_gpu_multi.py)."""
 import os
 import sys
 
@@ -14,8 +16,27 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 
 
-def _worker(rank, world, port, case, ret, transport="a2a"):
-    os.environ["DFLO_HALO"] = transport
+class HaloExchange:
+    """What multi.hip's post()/arrive() do with ncclSend/ncclRecv, with gloo point-to-point: to peer q go the cells
+    send_cells[send_off[q]:send_off[q+1]], from q come the ghost cells [recv_off[q], recv_off[q+1]) of the ghost range."""
+
+    def __init__(self, so, ro):
+        self.so, self.ro = [int(v) for v in so], [int(v) for v in ro]
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        self.peers = [q for q in range(self.world) if q != self.rank and (self.so[q + 1] > self.so[q] or self.ro[q + 1] > self.ro[q])]
+
+    def exchange(self, send, recv, width):
+        ops = []
+        for q in self.peers:
+            if self.ro[q + 1] > self.ro[q]:
+                ops.append(dist.P2POp(dist.irecv, recv[self.ro[q] * width:self.ro[q + 1] * width], q))
+            if self.so[q + 1] > self.so[q]:
+                ops.append(dist.P2POp(dist.isend, send[self.so[q] * width:self.so[q + 1] * width], q))
+        for w in dist.batch_isend_irecv(ops) if ops else []:
+            w.wait()
+
+
+def _worker(rank, world, port, case, ret, method="slab"):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, HERE)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -23,7 +44,6 @@ def _worker(rank, world, port, case, ret, transport="a2a"):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import dflo_amd
     from dflo_amd import problems
-    from dflo_amd.dist import HaloExchange
     import oracle_lib as O
 
     nx, ny, degree, flux, limiter, pos, side_bc, bnd = case
@@ -36,12 +56,12 @@ def _worker(rank, world, port, case, ret, transport="a2a"):
     prm = dflo_amd.Parameters(flux=flux, limiter=limiter, pos_lim=pos, boundary=bnd, beta=2.0)
     ic = (lambda x, y: problems.smooth_perturbation(x, y, L=1.0)) if limiter == "none" else problems.sod
     u0 = mesh.interpolate(ic)
-    part = mesh.partition(world, rank)
+    part = mesh.partition(world, rank, method)
     sc, so, ro = part.comm
     ndof = part.ndof
     gid = np.asarray(part.global_ids)
     ora = O.Oracle(part, prm)
-    halo = HaloExchange(so, ro, torch.device("cpu"))
+    halo = HaloExchange(so, ro)
     n_ghost = part.n_cells - part.n_owned
 
     def bvals(o):
@@ -104,13 +124,14 @@ def test_two_rank_halo_exchange_matches_single_process(case):
     assert ret["err"] < 1e-12, ret["err"]
 
 
-def test_point_to_point_transport_and_three_ranks():
-    """The P2P fallback transport, and a 3-way partition (a middle slab with two different neighbours)."""
+def test_rcb_blocks_and_three_ranks():
+    """RCB blocks on the unstructured mesh (peers in two directions), and a 3-way partition (a middle slab with two
+    different neighbours)."""
     import random
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(2, 29500 + random.randint(0, 2000), CASES[0], ret, "p2p"), nprocs=2, join=True)
+    mp.spawn(_worker, args=(3, 29500 + random.randint(0, 2000), CASES[3], ret, "rcb"), nprocs=3, join=True)
     assert ret["err"] < 1e-12, ret["err"]
     ret2 = mgr.dict()
-    mp.spawn(_worker, args=(3, 29500 + random.randint(0, 2000), CASES[2], ret2, "a2a"), nprocs=3, join=True)
+    mp.spawn(_worker, args=(3, 29500 + random.randint(0, 2000), CASES[2], ret2, "slab"), nprocs=3, join=True)
     assert ret2["err"] < 1e-12, ret2["err"]

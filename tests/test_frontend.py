@@ -126,6 +126,10 @@ def test_prm_reader_rejects_what_the_reference_rejects():
         InputDeck(base + "set basis = Pk\n")
     with pytest.raises(PrmError, match="rk3"):
         InputDeck(base + "subsection linear solver\n set method = gmres\nend\n")
+    with pytest.raises(PrmError, match="stationary"):     # steady-state mode of the implicit solver (src/claw.cc:449-450)
+        InputDeck(base + "subsection time stepping\n set stationary = true\nend\n")
+    deck = InputDeck(base + "set mapping = cartesian\nset basis = Pk\nsubsection limiter\n set type = TVB\n set conserve angular momentum = true\nend\n")
+    assert deck.parameters.struct().conserve_angular_momentum == 1
     deck = InputDeck(base + "set mapping = cartesian\nsubsection boundary_1\n set type = periodic\n set pair = 3\n set direction = y\nend\n"
                      "subsection boundary_3\n set type = periodic\n set pair = 1\n set direction = y\nend\n")
     assert deck.periodic_pairs == [(1, 3, "y")]
@@ -401,7 +405,9 @@ def test_cxx_prm_reader_matches_python(tmp_path):
     for text, msg in [("set flavour = mint\n", "no entry with name <flavour>"), ("subsection flux\n set flux = ausm\nend\n", "is not one of"),
                       ("subsection refinement\n set refinement = false\nend\n", "cfl and time_step zero"),
                       ("subsection refinement\n set refinement = false\nend\nsubsection time stepping\n set cfl = 0.5\nend\nset basis = Pk\n",
-                       "Pk basis can only be used with Cartesian grids")]:
+                       "Pk basis can only be used with Cartesian grids"),
+                      ("subsection refinement\n set refinement = false\nend\nsubsection time stepping\n set cfl = 0.5\n set stationary = true\nend\n",
+                       "stationary")]:
         path = tmp_path / "bad.prm"
         path.write_text(text)
         r = _run_bin("--parse", str(path))

@@ -112,6 +112,7 @@ end
     b.run(fast=True)
     assert abs(a.claw.elapsed_time - 0.5) < 1e-13 and abs(b.claw.elapsed_time - 0.5) < 1e-13
     assert np.abs(a.claw.current_solution - b.claw.current_solution).max() < 1e-12
+    assert a.time_iter == b.time_iter       # no chunk runs past final_time: the iteration count is the reference loop's
     assert sorted(os.listdir(tmp_path / "a")) == ["shock.vtu", "solution-000.vtu", "solution-001.vtu"]   # IC and final time
     # periodic box: the mean of every conserved variable is kept to round-off
     u0 = a.mesh.interpolate(dflo_amd.problems.isentropic_vortex).reshape(a.mesh.n_cells, 4, -1)

@@ -1023,3 +1023,42 @@ def test_random_configurations_against_the_oracle():
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), "250", "11"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "250 cases, 0 failures" in r.stdout
+
+
+@pytest.mark.parametrize("degree", [1, 2])
+def test_tvb_pk_conserve_angular_momentum(degree):
+    """`conserve angular momentum = true` (subsection limiter): the correction of the limited slopes in apply_limiter_TVB_Pk,
+    Dy(mx) = (Dy(mx) - (L - Dx(my))) / 2, Dx(my) = L + Dy(mx) with L = Dx(my) - Dy(mx) before limiting
+    (src/limiter.cc:453,496-500).  Device against oracle, and the cell's angular momentum v_x - u_y is what it was."""
+    mesh = dflo_amd.Mesh.cartesian(24, 20, 0.0, 0.0, 1.0 / 24, [0, 0, 0, 0], degree)
+    mesh.set_basis("Pk")
+    prm = dflo_amd.Parameters(flux="hllc", limiter="TVB", char_lim=True, M=0.0, beta=1.5, cfl=0.4, boundary={0: "outflow"},
+                              conserve_angular_momentum=True)
+    plain = dflo_amd.Parameters(flux="hllc", limiter="TVB", char_lim=True, M=0.0, beta=1.5, cfl=0.4, boundary={0: "outflow"})
+
+    def swirl(x, y):   # a rotating blob with a density jump: slopes in both momenta, limiter active
+        r2 = (x - 0.5) ** 2 + (y - 0.4) ** 2
+        rho = 1.0 + 0.8 * (r2 < 0.04)
+        u, v = -4.0 * (y - 0.4) * np.exp(-20 * r2), 4.0 * (x - 0.5) * np.exp(-20 * r2)
+        return rho * u, rho * v, rho, 2.5 + 0.5 * rho * (u * u + v * v)
+    u0 = mesh.interpolate(swirl)
+    claw, ora = dflo_amd.ConservationLaw(mesh, prm), oracle_lib.Oracle(mesh, prm)
+    other = dflo_amd.ConservationLaw(mesh, plain)
+    for c in (claw, other):
+        c.set_initial_condition(u0)
+        c.apply_limiter()
+    ora.set_solution(u0)
+    ora.apply_limiter()
+    ns = mesh.n_s
+    a, b, z = (v.reshape(mesh.n_cells, 4, ns) for v in (claw.current_solution, other.current_solution, u0))
+    assert rel(claw.current_solution, ora.get_solution()) < 1e-13
+    changed = np.abs(b - z).max(axis=(1, 2)) > 1e-12
+    assert changed.sum() > 20 and np.abs(a - b).max() > 1e-6          # the option does something
+    L0 = z[:, 1, 1] - z[:, 0, degree + 1]
+    L1 = a[:, 1, 1] - a[:, 0, degree + 1]
+    assert np.abs(L1 - L0)[changed].max() < 1e-13 * max(np.abs(L0).max(), 1.0)   # v_x - u_y of every limited cell kept
+    for it in range(3):
+        dt = claw.compute_time_step()
+        claw.iterate_explicit(dt)
+        ora.step(dt)
+    assert rel(claw.current_solution, ora.get_solution()) < 1e-9
