@@ -76,7 +76,7 @@ struct dflo_hip_engine {
   double st_dt = -1.0;
   int64_t t_stages = 0, t_seen = 0;   // stages timed / stages seen while timing is on
   bool t_sample = false;
-  int32_t *d_rim_list = nullptr, *d_int_list = nullptr;
+  int32_t *d_rim_list = nullptr, *d_int_list = nullptr, *d_rim2_list = nullptr, *d_rest2_list = nullptr;
   hipEvent_t ev_rim = nullptr, ev_unpack = nullptr;
   bool unpack_pending = false;
   double pending_dt = -1.0;
@@ -177,6 +177,10 @@ stage_fn pick_stage(int N, int flux, int mode, int geo, int pos = 0) {
 }
 
 int grid_for(int n_shards) { return ((n_shards + 7) / 8) * 8; }
+
+// shard set of a partial launch: 0 all, 1 rim (shards that read ghost cells), 2 interior (the others), 3 rim + the ring of
+// shards next to it, 4 the others
+void part_list(const dflo_hip_engine *h, int part, const int32_t **list, int *n);
 
 void launch_dt_q(dflo_hip_engine *h);
 
@@ -355,8 +359,7 @@ int launch_update(dflo_hip_engine *h, double *rhs_out, int part) {
   a.want_dt = last ? 1 : 0;
   a.degree = h->degree;
   a.kb = h->kb;
-  a.shard_list = part == 1 ? h->d_rim_list : (part == 2 ? h->d_int_list : nullptr);
-  a.n_list = part == 1 ? (int)p.rim_shards.size() : (part == 2 ? (int)p.interior_shards.size() : p.n_shards);
+  part_list(h, part, &a.shard_list, &a.n_list);
   if (a.n_list == 0) return DFLO_OK;
   const int mode_ = rhs_out ? 2 : (h->ark[rk] != 0.0 ? 1 : 0);
   a.flags = h->flags;
@@ -392,8 +395,7 @@ int launch_indicator(dflo_hip_engine *h, int part) {
   a.uniform_h = p.uniform_h ? 1 : 0;
   a.component = h->prm.shock_indicator == DFLO_IND_DENSITY ? RHO : EN;  // :70-82
   a.degree = h->degree;
-  a.shard_list = part == 1 ? h->d_rim_list : (part == 2 ? h->d_int_list : nullptr);
-  a.n_list = part == 1 ? (int)p.rim_shards.size() : (part == 2 ? (int)p.interior_shards.size() : p.n_shards);
+  part_list(h, part, &a.shard_list, &a.n_list);
   if (a.n_list == 0) return DFLO_OK;
   void (*fn)(const IndArgs);
   if (h->basis == DFLO_BASIS_PK) fn = h->N == 2 ? indicator_kernel<2, 1> : (h->N == 3 ? indicator_kernel<3, 1> : indicator_kernel<4, 1>);
@@ -430,8 +432,7 @@ int launch_limiter(dflo_hip_engine *h, int tvb, int pos, int part, bool stage_da
   l.dt_cell = h->d_dt_cell;
   l.cfl = h->prm.cfl;
   l.degree = h->degree;
-  l.shard_list = part == 1 ? h->d_rim_list : (part == 2 ? h->d_int_list : nullptr);
-  l.n_list = part == 1 ? (int)p.rim_shards.size() : (part == 2 ? (int)p.interior_shards.size() : p.n_shards);
+  part_list(h, part, &l.shard_list, &l.n_list);
   if (l.dtq) h->dtq_parts |= part == 0 ? 3 : part;
   if (l.n_list == 0) return DFLO_OK;
   void (*lf)(const LimArgs) = h->N == 2 ? limiter_kernel<2> : (h->N == 3 ? limiter_kernel<3> : limiter_kernel<4>);
@@ -538,6 +539,17 @@ void drop_graph(dflo_hip_engine *h) {
 }
 
 int check_handle(dflo_hip_handle h) { return h ? DFLO_OK : DFLO_ERR_BAD_PARAM; }
+
+void part_list(const dflo_hip_engine *h, int part, const int32_t **list, int *n) {
+  const Plan &p = h->plan;
+  switch (part) {
+    case 1: *list = h->d_rim_list; *n = (int)p.rim_shards.size(); break;
+    case 2: *list = h->d_int_list; *n = (int)p.interior_shards.size(); break;
+    case 3: *list = h->d_rim2_list; *n = (int)p.rim2_shards.size(); break;
+    case 4: *list = h->d_rest2_list; *n = (int)p.rest2_shards.size(); break;
+    default: *list = nullptr; *n = p.n_shards; break;
+  }
+}
 
 // the failure flags as they stand (no synchronisation: the caller decides how fresh they have to be)
 int flags_status(dflo_hip_engine *h) {
@@ -684,6 +696,8 @@ int dflo_hip_create(const dflo_mesh_t *mesh, const dflo_params_t *params, int de
   if ((rc = upload(h, &h->d_lrbt, p.lrbt))) return bail(rc);
   if ((rc = upload(h, &h->d_rim_list, p.rim_shards))) return bail(rc);
   if ((rc = upload(h, &h->d_int_list, p.interior_shards))) return bail(rc);
+  if ((rc = upload(h, &h->d_rim2_list, p.rim2_shards))) return bail(rc);
+  if ((rc = upload(h, &h->d_rest2_list, p.rest2_shards))) return bail(rc);
   if ((rc = upload(h, &h->d_user_of, p.user_of))) return bail(rc);
   if ((rc = upload(h, &h->d_iid, p.iid))) return bail(rc);
   if ((rc = upload(h, &h->d_cell_h, p.cell_h))) return bail(rc);
@@ -784,7 +798,7 @@ int dflo_hip_destroy(dflo_hip_handle h) {
   hipFree(h->d_bc_ops); hipFree(h->d_bc_consts); hipFree(h->d_bc_prog); hipFree(h->d_bc_faces); hipFree(h->d_bface_id); hipFree(h->d_bxy);
   hipFree(h->d_shard_count);
   hipFree(h->d_bnd_pad); hipFree(h->d_nbr_code); hipFree(h->d_shock); hipFree(h->lim_mask); hipFree(h->d_faces_pad); hipFree(h->d_shard_hdr); hipFree(h->d_halo_pad); hipFree(h->d_cell_face); hipFree(h->d_lrbt); hipFree(h->d_user_of); hipFree(h->d_iid);
-  hipFree(h->d_rim_list); hipFree(h->d_int_list);
+  hipFree(h->d_rim_list); hipFree(h->d_int_list); hipFree(h->d_rim2_list); hipFree(h->d_rest2_list);
   hipFree(h->d_cell_h); hipFree(h->d_dt_cell); hipFree(h->d_cell_vert); hipFree(h->d_fgeom_pad); hipFree(h->shard_res); hipFree(h->shard_dtmin); hipFree(h->res_sq); hipFree(h->fin_partial); hipFree(h->dt_dev);
   if (h->flags_host) hipHostFree((void *)h->flags_host);
   hipFree(h->fin_counter); hipFree(h->dt_pub); hipFree(h->d_send_slots); hipFree(h->ghost_stage);
@@ -1144,13 +1158,13 @@ int dflo_hip_stage_open(dflo_hip_handle h, int rk, double dt) {
 }
 
 int dflo_hip_stage_update_part(dflo_hip_handle h, int part) {
-  if (check_handle(h) || part < 0 || part > 2 || h->pending_rk < 0) return DFLO_ERR_BAD_PARAM;
+  if (check_handle(h) || part < 0 || part > 4 || h->pending_rk < 0) return DFLO_ERR_BAD_PARAM;
   hipSetDevice(h->device);
   return launch_update(h, nullptr, part);
 }
 
 int dflo_hip_stage_limit_part(dflo_hip_handle h, int part) {
-  if (check_handle(h) || part < 0 || part > 2) return DFLO_ERR_BAD_PARAM;
+  if (check_handle(h) || part < 0 || part > 4) return DFLO_ERR_BAD_PARAM;
   hipSetDevice(h->device);
   return launch_stage_limiter(h, part);
 }

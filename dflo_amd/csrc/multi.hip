@@ -59,10 +59,26 @@ Rccl g_rccl;
 
 bool load_rccl(std::string &err) {
   if (g_rccl.lib) return true;
-  const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  // The RCCL that belongs to the HIP runtime this process runs on: first the librccl next to the loaded libamdhip64
+  // (a process may hold a second ROCm, e.g. the one bundled with PyTorch, whose RCCL talks to its own, uninitialised
+  // copy of the HSA runtime), then the loader's search path.
+  std::vector<std::string> names;
+  Dl_info info;
+  if (dladdr((void *)&hipGetDeviceCount, &info) && info.dli_fname) {
+    std::string dir(info.dli_fname);
+    const size_t slash = dir.rfind('/');
+    if (slash != std::string::npos) {
+      dir.resize(slash + 1);
+      names.push_back(dir + "librccl.so.1");
+      names.push_back(dir + "librccl.so");
+    }
+  }
+  names.push_back("librccl.so.1");
+  names.push_back("librccl.so");
+  names.push_back("/opt/rocm/lib/librccl.so.1");
   void *lib = nullptr;
-  for (const char *n : names)
-    if ((lib = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break;
+  for (const std::string &n : names)
+    if ((lib = dlopen(n.c_str(), RTLD_NOW | RTLD_LOCAL))) break;
   if (!lib) { err = std::string("cannot load RCCL (librccl.so): ") + dlerror(); return false; }
 #define DFLO_SYM(field, name)                                                            \
   do {                                                                                   \
@@ -92,13 +108,15 @@ struct Part {
   int n_owned = 0, n_cells = 0, n_send = 0, n_ghost = 0;
   std::vector<int> peers;      // parts this one exchanges cells with
   hipStream_t M = nullptr, C = nullptr;
-  hipEvent_t ev_rim = nullptr, ev_int = nullptr, ev_lim = nullptr, ev_unpack = nullptr, ev_fin = nullptr, ev_dt = nullptr;
+  hipEvent_t ev_open = nullptr, ev_rim = nullptr, ev_rim_prev = nullptr, ev_ring = nullptr, ev_unpack = nullptr,
+             ev_fin = nullptr, ev_dt = nullptr;
   hipEvent_t ev_sent_u = nullptr, ev_sent_a = nullptr;
   double *send_u = nullptr, *send_a = nullptr;
   double *recv_u[2] = {nullptr, nullptr}, *recv_a[2] = {nullptr, nullptr};   // alternate from exchange to exchange
   void *dt_slot[2] = {nullptr, nullptr};   // the engine's published CFL minima
   void *dt_ptr = nullptr, *res_ptr = nullptr;
-  bool unpack_pending = false;
+  bool unpack_pending = false;   // the comm stream has work the compute stream has not waited for
+  bool rim_pending = false;      // ... among it the rim of the previous stage
   std::vector<int32_t> bface_global;   // global boundary-face number of the engine's boundary faces
 };
 
@@ -208,9 +226,8 @@ int exchange_solution(dflo_hip_multi *m) {
   for (Part &p : m->parts) {
     if (p.peers.empty()) continue;
     MHIP(m, hipSetDevice(p.device));
-    if (p.unpack_pending) { MHIP(m, hipStreamWaitEvent(p.M, p.ev_unpack, 0)); p.unpack_pending = false; }
-    MHIP(m, hipEventRecord(p.ev_rim, p.M));
-    MHIP(m, hipStreamWaitEvent(p.C, p.ev_rim, 0));
+    MHIP(m, hipEventRecord(p.ev_open, p.M));
+    MHIP(m, hipStreamWaitEvent(p.C, p.ev_open, 0));
     MENG(m, p, dflo_hip_set_stream(p.eng, p.C));
     MENG(m, p, dflo_hip_pack_send_cells(p.eng, p.send_u));
     int rc = post(m, p, p.send_u, m->ndof + 4, false, par);
@@ -231,7 +248,12 @@ int exchange_solution(dflo_hip_multi *m) {
   return DFLO_OK;
 }
 
-// one RK stage on every part of this process
+// One RK stage on every part of this process.  The rim shards run on the comm stream C (high priority), the interior
+// shards on the compute stream M, side by side: both read the previous stage, they write disjoint shards.
+//   C: [wait: interior of the previous stage / the new time step]  update rim  (TVB: rim + ring; exchange the averages of the
+//      rim cells; limit the rim)  -> ev_rim;  pack; send / receive; unpack into the ghost shards
+//   M: [wait: ev_rim of the previous stage]  update interior  (TVB: all but rim + ring; wait for the ring; limit all but the
+//      rim)  -> ev_int;  last stage: wait ev_rim, reductions of the step
 int run_stage(dflo_hip_multi *m, int rk, double dt) {
   const bool last = rk == m->n_rk - 1;
   bool any_peers = false;
@@ -245,7 +267,6 @@ int run_stage(dflo_hip_multi *m, int rk, double dt) {
     // limiter as well (update_ghost_values before compute_shock_indicator in the MPI variant); no overlap on this path
     for (Part &p : m->parts) {
       MHIP(m, hipSetDevice(p.device));
-      if (p.unpack_pending) { MHIP(m, hipStreamWaitEvent(p.M, p.ev_unpack, 0)); p.unpack_pending = false; }
       MENG(m, p, dflo_hip_stage_update(p.eng, rk, dt));
     }
     int rc = exchange_solution(m);
@@ -256,73 +277,64 @@ int run_stage(dflo_hip_multi *m, int rk, double dt) {
   const int upar = m->xparity, apar = m->aparity;
   m->xparity ^= 1;
   if (m->tvb) m->aparity ^= 1;
-  // rim shards first
+  const int rim_update = m->tvb ? 3 : 1, int_update = m->tvb ? 4 : 2;
+  // open the stage (buffer roles; rk = 0: boundary programs on M), then the rim on C
   for (Part &p : m->parts) {
     MHIP(m, hipSetDevice(p.device));
-    if (p.unpack_pending) { MHIP(m, hipStreamWaitEvent(p.M, p.ev_unpack, 0)); p.unpack_pending = false; }
     MENG(m, p, dflo_hip_stage_open(p.eng, rk, dt));
-    MENG(m, p, dflo_hip_stage_update_part(p.eng, 1));
-    MHIP(m, hipEventRecord(p.ev_rim, p.M));
+    MHIP(m, hipEventRecord(p.ev_open, p.M));       // interior of the previous stage, the step's time step, boundary data
+    MHIP(m, hipStreamWaitEvent(p.C, p.ev_open, 0));
+    MENG(m, p, dflo_hip_set_stream(p.eng, p.C));
+    MENG(m, p, dflo_hip_stage_update_part(p.eng, rim_update));
+    if (m->tvb) {
+      MHIP(m, hipEventRecord(p.ev_ring, p.C));
+      MENG(m, p, dflo_hip_pack_send_avg(p.eng, p.send_a));
+    } else {
+      if (m->sep_limiter) MENG(m, p, dflo_hip_stage_limit_part(p.eng, 1));
+      MHIP(m, hipEventRecord(p.ev_rim, p.C));
+      MENG(m, p, dflo_hip_pack_send_cells(p.eng, p.send_u));
+    }
+    MENG(m, p, dflo_hip_set_stream(p.eng, p.M));
+    int rc = m->tvb ? post(m, p, p.send_a, 4, true, apar) : post(m, p, p.send_u, m->ndof + 4, false, upar);
+    if (rc) return rc;
+  }
+  // the interior on M, next to it
+  for (Part &p : m->parts) {
+    MHIP(m, hipSetDevice(p.device));
+    if (p.rim_pending) MHIP(m, hipStreamWaitEvent(p.M, p.ev_rim_prev, 0));   // the rim cells of the previous stage (halo of the interior)
+    MENG(m, p, dflo_hip_stage_update_part(p.eng, int_update));
   }
   if (m->tvb) {
-    // the limiter of a rim cell needs the new averages of its neighbours across the cut and of the interior cells next to it
-    for (Part &p : m->parts) {
-      MHIP(m, hipSetDevice(p.device));
-      MHIP(m, hipStreamWaitEvent(p.C, p.ev_rim, 0));
-      MENG(m, p, dflo_hip_set_stream(p.eng, p.C));
-      MENG(m, p, dflo_hip_pack_send_avg(p.eng, p.send_a));
-      MENG(m, p, dflo_hip_set_stream(p.eng, p.M));
-      int rc = post(m, p, p.send_a, 4, true, apar);
-      if (rc) return rc;
-    }
-    for (Part &p : m->parts) {
-      MHIP(m, hipSetDevice(p.device));
-      MENG(m, p, dflo_hip_stage_update_part(p.eng, 2));
-      MHIP(m, hipEventRecord(p.ev_int, p.M));
-    }
+    // the averages of the neighbours across the cut arrive: limit the rim, send its cells
     for (Part &p : m->parts) {
       MHIP(m, hipSetDevice(p.device));
       int rc = arrive(m, p, true);
       if (rc) return rc;
       MENG(m, p, dflo_hip_set_stream(p.eng, p.C));
       MENG(m, p, dflo_hip_unpack_ghost_avg(p.eng, p.recv_a[apar]));
-      MHIP(m, hipStreamWaitEvent(p.C, p.ev_int, 0));
       MENG(m, p, dflo_hip_stage_limit_part(p.eng, 1));
-      MHIP(m, hipEventRecord(p.ev_lim, p.C));
+      MHIP(m, hipEventRecord(p.ev_rim, p.C));
       MENG(m, p, dflo_hip_pack_send_cells(p.eng, p.send_u));
       MENG(m, p, dflo_hip_set_stream(p.eng, p.M));
       rc = post(m, p, p.send_u, m->ndof + 4, false, upar);
       if (rc) return rc;
     }
-    for (Part &p : m->parts) {
+    for (Part &p : m->parts) {   // the limiter of the other shards reads averages from the ring
       MHIP(m, hipSetDevice(p.device));
+      MHIP(m, hipStreamWaitEvent(p.M, p.ev_ring, 0));
       MENG(m, p, dflo_hip_stage_limit_part(p.eng, 2));
-      if (last) MHIP(m, hipStreamWaitEvent(p.M, p.ev_lim, 0));   // the step's reductions read what the rim limiter wrote
-      MENG(m, p, dflo_hip_stage_finish(p.eng));
     }
-  } else {
-    for (Part &p : m->parts) {
-      MHIP(m, hipSetDevice(p.device));
-      MHIP(m, hipStreamWaitEvent(p.C, p.ev_rim, 0));
-      MENG(m, p, dflo_hip_set_stream(p.eng, p.C));
-      if (m->sep_limiter) {
-        MENG(m, p, dflo_hip_stage_limit_part(p.eng, 1));
-        MHIP(m, hipEventRecord(p.ev_lim, p.C));
-      }
-      MENG(m, p, dflo_hip_pack_send_cells(p.eng, p.send_u));
-      MENG(m, p, dflo_hip_set_stream(p.eng, p.M));
-      int rc = post(m, p, p.send_u, m->ndof + 4, false, upar);
-      if (rc) return rc;
-    }
-    for (Part &p : m->parts) {
-      MHIP(m, hipSetDevice(p.device));
-      MENG(m, p, dflo_hip_stage_update_part(p.eng, 2));
-      MENG(m, p, dflo_hip_stage_limit_part(p.eng, 2));
-      if (last && m->sep_limiter) MHIP(m, hipStreamWaitEvent(p.M, p.ev_lim, 0));
-      MENG(m, p, dflo_hip_stage_finish(p.eng));
-    }
+  } else if (m->sep_limiter) {
+    for (Part &p : m->parts) MENG(m, p, dflo_hip_stage_limit_part(p.eng, 2));
   }
-  // the neighbours' cells arrive: into the ghost shards, ready for the next stage's rim
+  for (Part &p : m->parts) {
+    MHIP(m, hipSetDevice(p.device));
+    if (last) MHIP(m, hipStreamWaitEvent(p.M, p.ev_rim, 0));   // the step's reductions take in the rim shards' partials
+    MENG(m, p, dflo_hip_stage_finish(p.eng));
+    std::swap(p.ev_rim, p.ev_rim_prev);      // the next stage's interior waits for this stage's rim
+    p.rim_pending = !last;                    // (after the last stage M has waited already)
+  }
+  // the neighbours' cells arrive: into the ghost shards, ready for the next stage's rim (same stream)
   for (Part &p : m->parts) {
     MHIP(m, hipSetDevice(p.device));
     int rc = arrive(m, p, false);
@@ -330,7 +342,6 @@ int run_stage(dflo_hip_multi *m, int rk, double dt) {
     MENG(m, p, dflo_hip_set_stream(p.eng, p.C));
     MENG(m, p, dflo_hip_unpack_ghost_cells(p.eng, p.recv_u[upar]));
     MENG(m, p, dflo_hip_set_stream(p.eng, p.M));
-    MHIP(m, hipEventRecord(p.ev_unpack, p.C));
     p.unpack_pending = true;
   }
   return DFLO_OK;
@@ -372,10 +383,16 @@ int reduce_dt(dflo_hip_multi *m) {
   return DFLO_OK;
 }
 
+// the compute stream catches up with the comm stream (before the state is read, or a call outside the overlapped stage)
 int join_all(dflo_hip_multi *m) {
   for (Part &p : m->parts) {
     MHIP(m, hipSetDevice(p.device));
-    if (p.unpack_pending) { MHIP(m, hipStreamWaitEvent(p.M, p.ev_unpack, 0)); p.unpack_pending = false; }
+    if (p.unpack_pending) {
+      MHIP(m, hipEventRecord(p.ev_unpack, p.C));
+      MHIP(m, hipStreamWaitEvent(p.M, p.ev_unpack, 0));
+      p.unpack_pending = false;
+    }
+    p.rim_pending = false;
   }
   return DFLO_OK;
 }
@@ -436,9 +453,14 @@ int setup_part(dflo_hip_multi *m, Part &p, const dflo_mesh_t *mesh, const dflo_p
   if (rc) { m->err = dflo_hip_last_error(nullptr); return rc; }
   MHIP(m, hipSetDevice(p.device));
   MHIP(m, hipStreamCreate(&p.M));
-  MHIP(m, hipStreamCreate(&p.C));
+  {  // the comm stream outranks the compute stream: its small kernels (rim shards, pack, unpack) go ahead of the queued
+     // workgroups of the interior launch
+    int lo = 0, hi = 0;
+    MHIP(m, hipDeviceGetStreamPriorityRange(&lo, &hi));
+    MHIP(m, hipStreamCreateWithPriority(&p.C, hipStreamDefault, hi));
+  }
   MENG(m, p, dflo_hip_set_stream(p.eng, p.M));
-  hipEvent_t *evs[] = {&p.ev_rim, &p.ev_int, &p.ev_lim, &p.ev_unpack, &p.ev_fin, &p.ev_dt, &p.ev_sent_u, &p.ev_sent_a};
+  hipEvent_t *evs[] = {&p.ev_open, &p.ev_rim, &p.ev_rim_prev, &p.ev_ring, &p.ev_unpack, &p.ev_fin, &p.ev_dt, &p.ev_sent_u, &p.ev_sent_a};
   for (hipEvent_t *e : evs) MHIP(m, hipEventCreateWithFlags(e, hipEventDisableTiming));
   MENG(m, p, dflo_hip_set_send_cells(p.eng, p.n_send, p.send_cells));
   const size_t ns = std::max(p.n_send, 1), ng = std::max(p.n_ghost, 1);
@@ -526,7 +548,7 @@ int dflo_hip_multi_destroy(dflo_hip_multi_handle m) {
     if (p.eng) dflo_hip_destroy(p.eng);
     hipFree(p.send_u); hipFree(p.send_a);
     for (int i = 0; i < 2; ++i) { hipFree(p.recv_u[i]); hipFree(p.recv_a[i]); }
-    hipEvent_t evs[] = {p.ev_rim, p.ev_int, p.ev_lim, p.ev_unpack, p.ev_fin, p.ev_dt, p.ev_sent_u, p.ev_sent_a};
+    hipEvent_t evs[] = {p.ev_open, p.ev_rim, p.ev_rim_prev, p.ev_ring, p.ev_unpack, p.ev_fin, p.ev_dt, p.ev_sent_u, p.ev_sent_a};
     for (hipEvent_t e : evs) if (e) hipEventDestroy(e);
     if (p.C) hipStreamDestroy(p.C);
     if (p.M) hipStreamDestroy(p.M);
@@ -577,7 +599,10 @@ int dflo_hip_multi_create(const dflo_mesh_t *mesh, const dflo_params_t *params, 
     if (!load_rccl(m->err)) return bail(DFLO_ERR_COMM);
     ncclUniqueId id;
     hipSetDevice(m->parts[0].device);
-    if (g_rccl.GetUniqueId(&id) != ncclSuccess || g_rccl.CommInitRank(&m->comm, 1, id, 0) != ncclSuccess) { m->err = "RCCL loopback communicator failed"; return bail(DFLO_ERR_COMM); }
+    ncclResult_t r = g_rccl.GetUniqueId(&id);
+    if (r != ncclSuccess) { m->err = std::string("ncclGetUniqueId: ") + g_rccl.GetErrorString(r); return bail(DFLO_ERR_COMM); }
+    r = g_rccl.CommInitRank(&m->comm, 1, id, 0);
+    if (r != ncclSuccess) { m->err = std::string("ncclCommInitRank (loopback): ") + g_rccl.GetErrorString(r); return bail(DFLO_ERR_COMM); }
   }
   finish_setup(m);
   *out = m;

@@ -331,6 +331,22 @@ int build_plan(const dflo_mesh_t &mesh, int shard_ex, int shard_ey, Plan &p, std
     (reads_ghost ? p.rim_shards : p.interior_shards).push_back(s);
   }
 
+  // ---- the rim widened by one ring of shards (multi-device runs with the TVB limiter): the limiter of a rim cell reads the
+  //      new averages of its face neighbours, and those that are not ghosts live in rim shards or in the ring
+  {
+    std::vector<char> is_rim(std::max(p.n_shards, 1), 0);
+    for (int s : p.rim_shards) is_rim[s] = 1;
+    p.rim2_shards = p.rim_shards;
+    for (int s : p.interior_shards) {
+      bool ring = false;
+      for (int k = p.halo_begin[s]; k < p.halo_begin[s + 1] && !ring; ++k) {
+        const int hs = p.halo_cells[k] / kShard;
+        ring = hs < p.n_shards && is_rim[hs];
+      }
+      (ring ? p.rim2_shards : p.rest2_shards).push_back(s);
+    }
+  }
+
   // ---- geometry in internal order
   if (mesh.mapping == DFLO_MAP_CARTESIAN) {
     p.cell_h.assign(p.n_slots + 2 * kShard, p.h);

@@ -59,6 +59,8 @@ struct Plan {
   std::vector<int32_t> shard_bnd;    // boundary faces per shard
   std::vector<int32_t> rim_shards;   // owned shards that read ghost cells (multi-device: computed first, then
   std::vector<int32_t> interior_shards;  // their cells are exchanged while the interior shards are computed)
+  std::vector<int32_t> rim2_shards;  // rim shards + the ring of shards next to them, and the rest: the split of the UPDATE when a
+  std::vector<int32_t> rest2_shards; // TVB limiter follows (the limiter of the rim cells reads averages from the ring)
   int max_halo = 0, max_faces = 0, max_bnd = 0;
   // boundary faces in MeshWorker order (cell ascending, face ascending)
   std::vector<int32_t> bface_cell, bface_face, bface_id;

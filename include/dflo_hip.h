@@ -243,7 +243,10 @@ int dflo_hip_stage_timing(dflo_hip_handle h, int enable, double *avg_ms, int64_t
 int dflo_hip_stage_update(dflo_hip_handle h, int rk, double dt);
 int dflo_hip_stage_limit(dflo_hip_handle h);
 /* The same stage split by shard set, for overlapping the exchange with compute: part 1 = rim shards
- * (those that read ghost cells), part 2 = interior shards, part 0 = all.
+ * (those that read ghost cells), part 2 = interior shards, part 0 = all; for the update of a stage that a TVB limiter
+ * follows also part 3 = rim shards + the ring of shards next to them (the limiter of a rim cell reads the new averages
+ * of its neighbours there) and part 4 = the others.  Launches of different parts of one stage may run side by side
+ * on different streams (they read the previous stage and write disjoint shards).
  *   open -> update_part(1) -> [limit_part(1) -> pack -> exchange -> unpack on a second stream]
  *        -> update_part(2) -> limit_part(2) -> finish (reductions, CFL minimum)                    */
 int dflo_hip_stage_open(dflo_hip_handle h, int rk, double dt);
