@@ -148,6 +148,18 @@ class ConservationLaw:
         self._chk(lib.dflo_hip_get_shock_indicator(self._h, _lib.dptr(a)))
         return a
 
+    def positivity_stats(self, reset=False):
+        """(cell-stages through the positivity limiter proper, cell-stages it changed) since the last reset -- the limiter
+        applied inside the stage kernel (positivity without TVB on Qk)."""
+        v = (C.c_int64 * 2)()
+        self._chk(lib.dflo_hip_positivity_stats(self._h, v, int(reset)))
+        return int(v[0]), int(v[1])
+
+    def failure_step(self):
+        st = C.c_int64()
+        self._chk(lib.dflo_hip_failure_step(self._h, C.byref(st)))
+        return st.value
+
     def synchronize(self):
         self._chk(lib.dflo_hip_synchronize(self._h))
 

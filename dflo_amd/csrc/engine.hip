@@ -65,6 +65,7 @@ struct dflo_hip_engine {
   int *flags = nullptr;         // device view of flags_host (kernels_common.hpp: raise_flag)
   volatile int *flags_host = nullptr;   // [0] negative mean state, [1] positivity root failure, [2] 1 + step of the first
   int *fin_counter = nullptr;   // finalize_kernel: workgroups done
+  unsigned long long *pos_stats = nullptr;   // [2] positivity limiter inside the stage kernel: cells through the limiter proper, cells changed
   double *dt_pub = nullptr;     // [2] raw CFL minimum of the last two steps, read by the other engines of a multi-device run
   int pub_parity = 0;
   bool publish = false;
@@ -364,6 +365,7 @@ int launch_update(dflo_hip_engine *h, double *rhs_out, int part) {
   const int mode_ = rhs_out ? 2 : (h->ark[rk] != 0.0 ? 1 : 0);
   a.flags = h->flags;
   a.step_index = (int)h->steps_done;
+  a.pos_stats = h->pos_stats;
   a.lim_mask = h->lim_mask;
   a.tvb_M = h->prm.limiter_type == DFLO_LIMITER_TVB ? h->prm.M : -1.0;
   a.tvb_char = h->prm.char_lim;
@@ -713,7 +715,7 @@ int dflo_hip_create(const dflo_mesh_t *mesh, const dflo_params_t *params, int de
       hipMalloc((void **)&h->shard_dtmin, nsh * sizeof(double)) != hipSuccess ||
       hipMalloc((void **)&h->res_sq, 4 * sizeof(double)) != hipSuccess || hipMalloc((void **)&h->fin_partial, 4 * 32 * sizeof(double)) != hipSuccess ||
       hipMalloc((void **)&h->dt_dev, 4 * sizeof(double)) != hipSuccess || hipMalloc((void **)&h->fin_counter, sizeof(int)) != hipSuccess ||
-      hipMalloc((void **)&h->dt_pub, 2 * sizeof(double)) != hipSuccess) {
+      hipMalloc((void **)&h->dt_pub, 2 * sizeof(double)) != hipSuccess || hipMalloc((void **)&h->pos_stats, 2 * sizeof(unsigned long long)) != hipSuccess) {
     h->err = "hipMalloc(scalars) failed";
     return bail(DFLO_ERR_NOMEM);
   }
@@ -732,6 +734,7 @@ int dflo_hip_create(const dflo_mesh_t *mesh, const dflo_params_t *params, int de
   hipMemset(h->dt_dev, 0, 4 * sizeof(double));
   hipMemset(h->dt_pub, 0, 2 * sizeof(double));
   hipMemset(h->fin_counter, 0, sizeof(int));
+  hipMemset(h->pos_stats, 0, 2 * sizeof(unsigned long long));
   h->halo_stride = std::max(p.max_halo, 1) | 1;  // odd stride: the trace rows fall on different LDS banks
   h->max_fp = std::max(std::max(p.max_faces, 1) * h->N, 9 * 64 * h->N / 4 + 1);  // Fh also hosts the row partials (5 N rows of 64) and the positivity minima (3 N) or the slope partials (4 N)
   {
@@ -801,7 +804,7 @@ int dflo_hip_destroy(dflo_hip_handle h) {
   hipFree(h->d_rim_list); hipFree(h->d_int_list); hipFree(h->d_rim2_list); hipFree(h->d_rest2_list);
   hipFree(h->d_cell_h); hipFree(h->d_dt_cell); hipFree(h->d_cell_vert); hipFree(h->d_fgeom_pad); hipFree(h->shard_res); hipFree(h->shard_dtmin); hipFree(h->res_sq); hipFree(h->fin_partial); hipFree(h->dt_dev);
   if (h->flags_host) hipHostFree((void *)h->flags_host);
-  hipFree(h->fin_counter); hipFree(h->dt_pub); hipFree(h->d_send_slots); hipFree(h->ghost_stage);
+  hipFree(h->fin_counter); hipFree(h->dt_pub); hipFree(h->pos_stats); hipFree(h->d_send_slots); hipFree(h->ghost_stage);
   for (int i = 0; i < 2; ++i) if (h->ev_chunk[i]) hipEventDestroy(h->ev_chunk[i]);
   for (auto &e : h->ev_pool) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
   if (h->ev_rim) { hipEventDestroy(h->ev_rim); hipEventDestroy(h->ev_unpack); }
@@ -1269,6 +1272,18 @@ int dflo_hip_check(dflo_hip_handle h) {
   hipSetDevice(h->device);
   HIPCHK(h, hipStreamSynchronize(h->stream));
   return flags_status(h);
+}
+
+int dflo_hip_positivity_stats(dflo_hip_handle h, int64_t *counts, int reset) {
+  if (check_handle(h) || !counts) return DFLO_ERR_BAD_PARAM;
+  hipSetDevice(h->device);
+  unsigned long long v[2] = {0, 0};
+  HIPCHK(h, hipMemcpyAsync(v, h->pos_stats, sizeof(v), hipMemcpyDeviceToHost, h->stream));
+  if (reset) HIPCHK(h, hipMemsetAsync(h->pos_stats, 0, sizeof(v), h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  counts[0] = (int64_t)v[0];
+  counts[1] = (int64_t)v[1];
+  return DFLO_OK;
 }
 
 int dflo_hip_failure_step(dflo_hip_handle h, int64_t *step) {

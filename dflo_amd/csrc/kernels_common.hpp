@@ -72,6 +72,7 @@ struct StageArgs {
   int n_list;
   int *flags;   // POS 1: [0] negative mean state, [1] positivity root failure (as LimArgs::flags)
   int step_index; // time step this launch belongs to (host count since set_solution), recorded with a raised flag
+  unsigned long long *pos_stats;  // POS 1: [0] cells that failed the nodal-box bound (limiter proper), [1] cells it changed
   unsigned long long *lim_mask;   // POS 2: [n_shards] bit = the limiter pass may have something to do in that cell
   double tvb_M;                   // POS 2: TVB constant M, < 0: the limiter pass has no TVB part
   int tvb_char, pos_check;        // POS 2: characteristic limiting; the positivity limiter runs in the pass

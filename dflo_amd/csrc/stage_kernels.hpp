@@ -602,6 +602,10 @@ __global__ __launch_bounds__(64 * N, ((GEO == 1 && N != 3) || N == 4) ? 2 : 3) v
     {
       const bool ok = positivity_box_settled<N>(Us, lane, a.kb.pg_neg);
       settled = __all(ok || !active);   // the same in every wave of the workgroup: all of them see the same numbers
+      if (!settled && row == 0) {       // statistics (rare path): cells that go through the limiter proper
+        const unsigned long long mk = __ballot(!ok && active);
+        if (lane == 0) atomicAdd(a.pos_stats, (unsigned long long)__popcll(mk));
+      }
     }
     if (!settled) {
     // the limiter proper, the same arithmetic as limiter_kernel: wave b holds row b of every cell in registers and reads
@@ -694,6 +698,10 @@ __global__ __launch_bounds__(64 * N, ((GEO == 1 && N != 3) || N == 4) ? 2 : 3) v
     }
     if (bad) theta2 = 1.0;
     else if (fail && active) raise_flag(a.flags, 1, a.step_index);
+    if (row == 0) {   // statistics: cells the limiter changes
+      const unsigned long long mk = __ballot(active && (t1 || theta2 < 1.0));
+      if (lane == 0 && mk) atomicAdd(a.pos_stats + 1, (unsigned long long)__popcll(mk));
+    }
     if (active && (t1 || theta2 < 1.0)) {   // rare: the rows stored by the update are replaced
       double *np = a.Unew + (size_t)shard * 4 * NS2 * 64 + lane;
 #pragma unroll

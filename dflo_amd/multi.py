@@ -170,6 +170,18 @@ class MultiConservationLaw:
     def apply_positivity_limiter(self):
         self._chk(lib.dflo_hip_multi_apply_positivity_limiter(self._h))
 
+    def positivity_stats(self, reset=False):
+        """Sum over the local engines of ConservationLaw.positivity_stats."""
+        tot = [0, 0]
+        for i in range(self.n_local):
+            v = (C.c_int64 * 2)()
+            rc = lib.dflo_hip_positivity_stats(lib.dflo_hip_multi_engine(self._h, i), v, int(reset))
+            if rc:
+                raise DfloError(rc, "positivity_stats")
+            tot[0] += int(v[0])
+            tot[1] += int(v[1])
+        return tuple(tot)
+
     def synchronize(self):
         self._chk(lib.dflo_hip_multi_synchronize(self._h))
 

@@ -220,6 +220,10 @@ int dflo_hip_check(dflo_hip_handle h);
  * up, -1 if none: where the reference would have stopped (src/positivity.cc:28-38 throws, :160-169 exits, inside the
  * stage).  dflo_hip_advance looks at the flags every 32 steps and returns early with the error. */
 int dflo_hip_failure_step(dflo_hip_handle h, int64_t *step);
+/* Positivity limiter applied inside the stage kernel (pos_lim without TVB on Qk): counts[0] = cell-stages that failed the
+ * cheap nodal-box bound and went through the limiter proper (src/positivity.cc:43-205), counts[1] = cell-stages it
+ * changed (theta1 < 1 or theta2 < 1), summed since the last reset.  A diagnostic for bench.py's config.check. */
+int dflo_hip_positivity_stats(dflo_hip_handle h, int64_t *counts, int reset);
 int dflo_hip_synchronize(dflo_hip_handle h);
 
 /* Average duration (ms) of the stage kernel launches since the last reset, measured with HIP events on the

@@ -1,0 +1,150 @@
+"""GPU: the pointwise layer of the DEVICE (numerical fluxes, ghost states) against the closed forms of
+tests/golden/closed_forms.json (derived independently in 60-digit arithmetic, tests/golden/make_closed_forms.py) --
+not through the oracle.  The engine exposes no pointwise entry point, so the flux is read off the assembled residual
+(dflo_hip_residual = assemble_system, src/assemble_explicit.cc:433-452) of meshes with one or two unit-square cells
+holding constant states:
+
+  two cells L | R sharing the face with unit normal n, outer faces `inflow` with the cell's own state as boundary value
+  (a consistent flux gives F(W).n there).  Summing R_i = int F.grad(phi_i) - sum_faces int F^ phi_i over the DoFs of a
+  cell (sum phi_i = 1, faces of length 1, sum of the outward normals = 0):
+        sum_i R_i(L) =  F(W_l).n - F^(W_l, W_r, n)        sum_i R_i(R) = -F(W_r).n + F^(W_l, W_r, n)
+  so the numerical flux is known twice (and conservation is checked on the way).  Oblique normals come from rotating the
+  pair (q1 mapping); axis-aligned pairs also run with the Cartesian mapping.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import dflo_amd
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+CF = json.load(open(os.path.join(HERE, "golden", "closed_forms.json")))
+FLUXES = ["lxf", "sw", "kfvs", "roe", "hllc"]
+G = 1.4
+
+
+def _f(v):
+    return np.array([float(x) for x in v])
+
+
+def phys_flux(W, n):
+    mx, my, rho, E = W
+    p = (G - 1) * (E - 0.5 * (mx * mx + my * my) / rho)
+    un = (mx * n[0] + my * n[1]) / rho
+    return np.array([mx * un + p * n[0], my * un + p * n[1], rho * un, (E + p) * un])
+
+
+def cells_along(n, n_cells):
+    """unit squares: cell 0 = the unit square rotated so that its face 1 (x = 1) has outward normal n, cell 1 beyond it"""
+    c, s = n
+    rot = np.array([[c, -s], [s, c]])
+    pts = [[0.0, 0.0], [1.0, 0.0], [1.0, 1.0], [0.0, 1.0]]      # cell 0, counter-clockwise
+    quads = [[0, 1, 2, 3]]
+    if n_cells == 2:
+        pts += [[2.0, 0.0], [2.0, 1.0]]
+        quads.append([1, 4, 5, 2])                              # edge 3 of cell 1 (2 -> 1) is edge 1 of cell 0
+    return np.array(pts) @ rot.T, np.array(quads, dtype=np.int32)
+
+
+def make_mesh(n, n_cells, ids):
+    """ids: boundary id of every outer edge, keyed by (cell, edge k of the counter-clockwise quad: 0 bottom, 1 right, 2 top, 3 left)"""
+    verts, quads = cells_along(n, n_cells)
+    bed, bid = [], []
+    for c in range(n_cells):
+        for k in range(4):
+            if n_cells == 2 and ((c == 0 and k == 1) or (c == 1 and k == 3)):
+                continue
+            bed.append([quads[c][k], quads[c][(k + 1) % 4]])
+            bid.append(ids(c, k))
+    axis = abs(abs(n[0]) - 1.0) < 1e-15 or abs(abs(n[1]) - 1.0) < 1e-15
+    mesh = dflo_amd.Mesh.from_quads(verts, quads, np.array(bed, dtype=np.int32), np.array(bid, dtype=np.int32), 1)
+    return mesh, axis
+
+
+def device_flux(flux, n, Wl, Wr, mapping=None):
+    """F^(W_l, W_r, n) of the device, read off the residual of the two-cell mesh (both estimates)"""
+    mesh, axis = make_mesh(n, 2, lambda c, k: 1 + c)
+    if mapping == "cartesian":
+        assert axis
+        mesh.set_mapping("cartesian")
+    prm = dflo_amd.Parameters(flux=flux, boundary={1: "inflow", 2: "inflow"})
+    claw = dflo_amd.ConservationLaw(mesh, prm)
+    cell, face, bid, xy = claw.boundary_faces()
+    bv = np.where((bid == 1)[:, None, None], Wl[None, None, :], Wr[None, None, :]) * np.ones((len(cell), 2, 1))
+    claw.set_boundary_values(0, bv)
+    u = np.empty((2, 4, 4))
+    u[0] = Wl[:, None]
+    u[1] = Wr[:, None]
+    claw.set_initial_condition(u.reshape(-1))
+    r = claw.assemble_system().reshape(2, 4, 4).sum(axis=2)
+    return phys_flux(Wl, n) - r[0], phys_flux(Wr, n) + r[1]
+
+
+@pytest.mark.parametrize("case", CF["flux_cases"], ids=[c["name"] for c in CF["flux_cases"]])
+def test_device_fluxes_match_the_closed_forms(case):
+    n, Wl, Wr = _f(case["n"]), _f(case["W_l"]), _f(case["W_r"])
+    scale = max(np.abs(phys_flux(Wl, n)).max(), np.abs(phys_flux(Wr, n)).max(), *(np.abs(_f(case[f])).max() for f in FLUXES))
+    axis = abs(abs(n[0]) - 1.0) < 1e-15 or abs(abs(n[1]) - 1.0) < 1e-15
+    for flux in FLUXES:
+        want = _f(case[flux])
+        for mapping in (["q1", "cartesian"] if axis else ["q1"]):
+            a, b = device_flux(flux, n, Wl, Wr, mapping)
+            tol = (2e-12 if flux == "kfvs" else 1e-12) * scale
+            assert np.abs(a - want).max() <= tol and np.abs(b - want).max() <= tol, (flux, mapping, a, b, want)
+            if "upwind" in case and flux in ("hllc", "roe", "sw"):
+                assert np.abs(a - _f(case["upwind"])).max() <= 1e-12 * scale
+
+
+def test_device_fluxes_are_consistent_node_by_node():
+    """constant state, every face consistent: each R_i vanishes by itself (divergence theorem per test function), for every
+    flux, state and orientation of the consistency table -- Q1 to Q3, Qk and (axis-aligned) Pk"""
+    for rec in CF["consistency"]:
+        n, W = _f(rec["n"]), _f(rec["W"])
+        scale = np.abs(_f(rec["flux"])).max() + np.abs(W).max()
+        for flux in FLUXES:
+            for degree in (1, 2, 3):
+                verts, quads = cells_along(n, 1)
+                bed = np.array([[quads[0][k], quads[0][(k + 1) % 4]] for k in range(4)], dtype=np.int32)
+                mesh = dflo_amd.Mesh.from_quads(verts, quads, bed, np.ones(4, dtype=np.int32), degree)
+                claw = dflo_amd.ConservationLaw(mesh, dflo_amd.Parameters(flux=flux, boundary={1: "inflow"}))
+                cell, face, bid, xy = claw.boundary_faces()
+                bv = np.ones((4, degree + 1, 1)) * W
+                claw.set_boundary_values(0, bv)
+                claw.set_initial_condition((np.ones((1, 4, (degree + 1) ** 2)) * W[None, :, None]).reshape(-1))
+                r = claw.assemble_system()
+                assert np.abs(r).max() <= 2e-13 * scale, (rec["state"], flux, degree, np.abs(r).max())
+
+
+@pytest.mark.parametrize("rec", CF["wminus"], ids=["%s n=(%s,%s)" % (r["kind"], r["n"][0][:4], r["n"][1][:4]) for r in CF["wminus"]])
+def test_device_ghost_states_match_the_closed_forms(rec):
+    """compute_Wminus (src/equation.h:942-1033) on the device: one cell, the face with outward normal n carries the boundary
+    kind under test and the tabulated boundary values; F^(W+, W-(kind), n) is read off the residual"""
+    n, Wp, bv_k = _f(rec["n"]), _f(rec["W_plus"]), _f(rec["boundary_values"])
+    for flux, key in (("hllc", "hllc"), ("roe", "roe"), ("lxf", "lxf_interior_average")):
+        mesh, axis = make_mesh(n, 1, lambda c, k: 2 if k == 1 else 1)
+        prm = dflo_amd.Parameters(flux=flux, boundary={1: "inflow", 2: rec["kind"]})
+        claw = dflo_amd.ConservationLaw(mesh, prm)
+        cell, face, bid, xy = claw.boundary_faces()
+        bv = np.where((bid == 2)[:, None, None], bv_k[None, None, :], Wp[None, None, :]) * np.ones((4, 2, 1))
+        claw.set_boundary_values(0, bv)
+        claw.set_initial_condition((np.ones((1, 4, 4)) * Wp[None, :, None]).reshape(-1))
+        r = claw.assemble_system().reshape(4, 4).sum(axis=1)
+        got = phys_flux(Wp, n) - r
+        want = _f(rec[key])
+        assert np.abs(got - want).max() <= 1e-12 * max(np.abs(want).max(), np.abs(phys_flux(Wp, n)).max()), (rec["kind"], flux, got, want)
+
+
+def test_device_slip_wall_carries_only_the_pressure():
+    for rec in CF["wall"]:
+        n, W = _f(rec["n"]), _f(rec["W"])
+        for flux in FLUXES:
+            mesh, axis = make_mesh(n, 1, lambda c, k: 2 if k == 1 else 1)
+            claw = dflo_amd.ConservationLaw(mesh, dflo_amd.Parameters(flux=flux, boundary={1: "inflow", 2: "slip"}))
+            claw.set_boundary_values(0, np.ones((4, 2, 1)) * W)
+            claw.set_initial_condition((np.ones((1, 4, 4)) * W[None, :, None]).reshape(-1))
+            r = claw.assemble_system().reshape(4, 4).sum(axis=1)
+            got = phys_flux(W, n) - r
+            assert np.abs(got - _f(rec["flux"])).max() <= (2e-9 if flux == "kfvs" else 1e-13), (flux, got)   # kfvs: see test_oracle_pointwise

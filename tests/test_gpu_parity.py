@@ -1062,3 +1062,114 @@ def test_tvb_pk_conserve_angular_momentum(degree):
         claw.iterate_explicit(dt)
         ora.step(dt)
     assert rel(claw.current_solution, ora.get_solution()) < 1e-9
+
+
+def _first_failure(stepper, n_max):
+    """(step index, error code) of the first step that ends in an error, (step, "nan") if NaNs show up first,
+    (None, None) if the run gets through n_max steps"""
+    for it in range(n_max):
+        try:
+            finite = stepper()
+        except (dflo_amd.DfloError, oracle_lib.OracleError) as e:
+            return it, e.code
+        if not finite:
+            return it, "nan"
+    return None, None
+
+
+def _fails_alike(mesh, prm, ic, n_max, limit_ic=False):
+    claw, ora = dflo_amd.ConservationLaw(mesh, prm), oracle_lib.Oracle(mesh, prm)
+    cell, face, bid, xy = claw.boundary_faces()
+    bv = np.stack(ic(xy[..., 0], xy[..., 1]), axis=-1)
+    for o in (claw, ora):
+        o.set_boundary_values(0, bv)
+        o.set_boundary_values(1, bv)
+    u0 = mesh.interpolate(ic)
+    claw.set_initial_condition(u0)
+    ora.set_solution(u0)
+    if limit_ic:
+        claw.apply_limiter()
+        ora.apply_limiter()
+    state = {"t": 0.0}
+
+    def dev():
+        claw.iterate_explicit(claw.compute_time_step())
+        return bool(np.isfinite(claw.cell_average).all())
+
+    def cpu():
+        dt = ora.compute_time_step(state["t"])
+        ora.step(dt)
+        state["t"] += dt
+        return bool(np.isfinite(ora.get_cell_average()).all())
+    fd, fo = _first_failure(dev, n_max), _first_failure(cpu, n_max)
+    return fd, fo, claw, ora
+
+
+def test_forward_step_c5_fails_like_the_reference_algorithm():
+    """BASELINE config 5 as worded -- forward-step tunnel, unstructured quadrilaterals (q1 mapping), Q3, KFVS, with the
+    positivity limiter as the only limiter the reference allows off Cartesian meshes, cfl 0.5 of the shipped input -- does
+    not survive the impulsive start at the step face: the positivity limiter finds no admissible root
+    (src/positivity.cc:156-169, where the reference calls exit(0)).  Device and oracle stop in the same time step with
+    the same error; the resident loop reports that step.  (bench.py --config c5 therefore runs the case at cfl 0.02, where
+    the same physical time is ~125 steps away.)"""
+    from dflo_amd import gmsh
+    verts, quads, bed, bid = gmsh.forward_step_quads(cl=0.1, seed=2)
+    mesh = dflo_amd.Mesh.from_quads(verts, quads, bed, bid, 3)
+    prm = dflo_amd.Parameters(flux="kfvs", pos_lim=True, cfl=0.5, boundary={1: "inflow", 2: "slip", 3: "outflow"})
+    fd, fo, claw, ora = _fails_alike(mesh, prm, problems.forward_step_inflow, 60)
+    assert fd == fo and fd[0] is not None and fd[1] == -4      # DFLO_ERR_POSITIVITY_NO_ROOT
+    # the device-resident loop stops with the same error and names the step
+    again = dflo_amd.ConservationLaw(mesh, prm)
+    cell, face, b, xy = again.boundary_faces()
+    bv = np.stack(problems.forward_step_inflow(xy[..., 0], xy[..., 1]), axis=-1)
+    again.set_boundary_values(0, bv)
+    again.set_boundary_values(1, bv)
+    again.set_initial_condition(mesh.interpolate(problems.forward_step_inflow))
+    with pytest.raises(dflo_amd.DfloError) as ei:
+        again.advance(200)
+    assert ei.value.code == -4 and again.failure_step() == fd[0]
+
+
+@pytest.mark.parametrize("cfl", [0.02])
+def test_forward_step_c5_small_cfl_matches_until_the_same_end(cfl):
+    """The same case at the cfl bench.py uses: device and oracle agree step for step (cell averages to 1e-9) up to the step
+    in which both give up, and a small fraction of the cells goes through the limiter proper."""
+    from dflo_amd import gmsh
+    verts, quads, bed, bid = gmsh.forward_step_quads(cl=0.1, seed=2)
+    mesh = dflo_amd.Mesh.from_quads(verts, quads, bed, bid, 3)
+    prm = dflo_amd.Parameters(flux="kfvs", pos_lim=True, cfl=cfl, boundary={1: "inflow", 2: "slip", 3: "outflow"})
+    claw, ora = dflo_amd.ConservationLaw(mesh, prm), oracle_lib.Oracle(mesh, prm)
+    cell, face, b, xy = claw.boundary_faces()
+    bv = np.stack(problems.forward_step_inflow(xy[..., 0], xy[..., 1]), axis=-1)
+    for o in (claw, ora):
+        o.set_boundary_values(0, bv)
+        o.set_boundary_values(1, bv)
+    u0 = mesh.interpolate(problems.forward_step_inflow)
+    claw.set_initial_condition(u0)
+    ora.set_solution(u0)
+    t = 0.0
+    for it in range(40):
+        dt = claw.compute_time_step()
+        assert abs(dt - ora.compute_time_step(t)) <= 1e-12 * dt
+        claw.iterate_explicit(dt)
+        ora.step(dt)
+        t += dt
+        scale = np.abs(ora.get_cell_average()).max()
+        assert np.abs(claw.cell_average - ora.get_cell_average()).max() < 1e-9 * scale, it
+    slow, changed = claw.positivity_stats()
+    assert 0 < changed <= slow < 0.2 * 40 * 3 * mesh.n_cells
+
+
+def test_double_mach_c4_positivity_alone_fails_like_the_reference_algorithm():
+    """BASELINE config 4 as worded (HLLC + positivity limiter, no TVB): the Mach 10 shock of the initial data drives a
+    cell mean negative within the first steps -- "Fatal: Negative states" (src/positivity.cc:26-38) -- in the same step on
+    the device and in the oracle.  (The reference's own input uses TVB there, and so does bench.py --config c4.)"""
+    ny = 24
+    dy = 1.0 / ny
+    n1 = int(np.ceil((1.0 / 6.0) / dy))
+    mesh = dflo_amd.Mesh.cartesian(3 * ny, ny, 1.0 / 6.0 - n1 * dy, 0.0, dy, [4, 2, 1, 3], 2)
+    mesh.neighbors[:n1, 2] = -1 - 0
+    prm = dflo_amd.Parameters(flux="hllc", limiter="none", pos_lim=True, cfl=0.9,
+                              boundary={0: "outflow", 1: "slip", 2: "outflow", 3: "inflow", 4: "inflow"})
+    fd, fo, claw, ora = _fails_alike(mesh, prm, lambda x, y: problems.double_mach(x, y), 40)
+    assert fd == fo and fd[0] is not None and fd[1] == -3

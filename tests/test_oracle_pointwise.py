@@ -136,3 +136,68 @@ def test_gauss_rules():
         assert x[0] == 0.0 and x[-1] == 1.0
         for k in range(2 * n - 2):
             assert abs((w * x ** k).sum() - 1.0 / (k + 1)) < 1e-14
+
+
+# ---------------------------------------------------------------- closed forms derived independently (tests/golden/make_closed_forms.py)
+CF = json.load(open(os.path.join(HERE, "golden", "closed_forms.json")))
+KIND_ID = {"inflow": 0, "outflow": 1, "slip": 2, "pressure": 3, "farfield": 4}
+
+
+def _f(v):
+    return np.array([float(x) for x in v])
+
+
+def _scale(*vecs):
+    return max(float(np.abs(v).max()) for v in vecs)
+
+
+@pytest.mark.parametrize("case", CF["flux_cases"], ids=[c["name"] for c in CF["flux_cases"]])
+def test_closed_form_two_state_fluxes(case):
+    """All five fluxes at the Sod / double-Mach / supersonic / transonic (Roe entropy fix active on either acoustic wave) /
+    contact / strong-jump / near-vacuum states against the 60-digit derivation; every HLLC branch is covered."""
+    n, Wl, Wr = _f(case["n"]), _f(case["W_l"]), _f(case["W_r"])
+    for name, fid in FLUX_ID.items():
+        want = _f(case[name])
+        got = O.numerical_flux(fid, n, Wl, Wr)
+        tol = 1e-13 * _scale(want, O.normal_flux(Wl, n), O.normal_flux(Wr, n))
+        if name == "kfvs":
+            tol *= 10      # exp / sqrt of s^2 up to 30: a few more ulp
+        assert np.abs(got - want).max() <= tol, (name, got, want)
+    if "upwind" in case:    # both states supersonic along n: the upwind physical flux, by hand
+        for name in ("hllc", "roe", "sw"):
+            got = O.numerical_flux(FLUX_ID[name], n, Wl, Wr)
+            assert np.abs(got - _f(case["upwind"])).max() <= 1e-13 * _scale(_f(case["upwind"])), name
+
+
+def test_closed_form_consistency_and_wall():
+    for rec in CF["consistency"]:
+        n, W = _f(rec["n"]), _f(rec["W"])
+        for name, fid in FLUX_ID.items():
+            assert np.abs(O.numerical_flux(fid, n, W, W) - _f(rec["flux"])).max() <= 1e-13 * _scale(_f(rec["flux"])), (rec["state"], name)
+    for rec in CF["wall"]:   # slip wall, zero normal velocity: (p n, 0, 0)
+        n, W = _f(rec["n"]), _f(rec["W"])
+        Wm = O.compute_Wminus(KIND_ID["slip"], n, W, W)
+        for name, fid in FLUX_ID.items():
+            # kfvs: the reference's ERF polynomial (src/equation.h:688-709) jumps by 2e-9 at 0, and the normal velocity here is
+            # zero up to the rounding of m.n -- the wall flux is p n only to that accuracy
+            tol = 2e-9 if name == "kfvs" else 1e-14
+            assert np.abs(O.numerical_flux(fid, n, W, Wm, W, W) - _f(rec["flux"])).max() <= tol, name
+
+
+def test_closed_form_ghost_states():
+    for rec in CF["wminus"]:
+        n, Wp, bv = _f(rec["n"]), _f(rec["W_plus"]), _f(rec["boundary_values"])
+        Wm = O.compute_Wminus(KIND_ID[rec["kind"]], n, Wp, bv)
+        assert np.abs(Wm - _f(rec["W_minus"])).max() <= 1e-15 * _scale(Wp, bv), rec["kind"]
+        assert np.abs(O.numerical_flux(FLUX_ID["hllc"], n, Wp, Wm) - _f(rec["hllc"])).max() <= 1e-13 * _scale(_f(rec["hllc"]))
+        assert np.abs(O.numerical_flux(FLUX_ID["lxf"], n, Wp, Wm, Wp, Wp) - _f(rec["lxf_interior_average"])).max() <= 1e-13 * _scale(_f(rec["hllc"]))
+
+
+def test_closed_form_states_and_eigenvectors():
+    s = json.load(open(os.path.join(HERE, "golden", "states.json")))
+    assert np.allclose(_f(CF["states"]["dmr_post"]), s["double_mach_reflection"]["prm_left"], rtol=0, atol=5e-10)
+    assert np.allclose(_f(CF["states"]["step_inflow"]), s["forward_step"]["prm_inflow"], rtol=1e-15)
+    assert np.allclose(_f(CF["states"]["sod_right"]), s["sod_shock_tube"]["prm_right"], rtol=1e-15)
+    for rec in CF["eigen"]:
+        Rx, Lx, Ry, Ly = O.eigen(_f(rec["W"]))
+        assert np.abs(Lx @ Rx - np.eye(4)).max() < 1e-13 and np.abs(Ly @ Ry - np.eye(4)).max() < 1e-13
