@@ -221,7 +221,7 @@ def main():
         ("double Mach: pre-shock | post-shock, oblique normal", nob, dmrR, dmrL),
         ("both supersonic to the right (Mach 3 | Mach 2.5)", n10, step, cons(D("1.1"), D("2.8"), D("0.3"), D("0.9"))),
         ("both supersonic to the left", n10, cons(D("1.1"), D("-2.8"), D("0.3"), D("0.9")), cons(D("1.4"), D(-3), D(0), D(1))),
-        ("both supersonic along an oblique normal", nob, cons(D(1), D("1.8"), D("2.4"), D(1)), cons(D("0.9"), D("1.5"), D("2.0"), D("0.8"))),
+        ("both supersonic along an oblique normal", nob, cons(D(1), D("2.0"), D("2.2"), D(1)), cons(D("0.9"), D("1.7"), D("1.9"), D("0.8"))),
         ("transonic: u_n - c inside the entropy fix of the left-running wave", n10, cons(D(1), D("1.15"), D("0.2"), D(1)), cons(D("0.9"), D("1.25"), D("0.1"), D("0.9"))),
         ("transonic: u_n + c inside the entropy fix of the right-running wave", n10, cons(D(1), D("-1.15"), D("0.2"), D(1)), cons(D("0.9"), D("-1.1"), D("0.1"), D("0.95"))),
         ("stationary contact (u = 0, equal pressure)", n10, cons(D(1), D(0), D(0), D(1)), cons(D("0.25"), D(0), D(0), D(1))),
