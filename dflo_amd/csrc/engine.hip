@@ -365,6 +365,11 @@ int launch_update(dflo_hip_engine *h, double *rhs_out, int part) {
   const int mode_ = rhs_out ? 2 : (h->ark[rk] != 0.0 ? 1 : 0);
   a.flags = h->flags;
   a.step_index = (int)h->steps_done;
+  {  // does a limiter pass read the whole new state right after this launch?
+    const bool limited = h->prm.limiter_type != DFLO_LIMITER_NONE || h->prm.pos_lim;
+    const bool full_pass = limited && !h->fuse_pos && !h->lim_mask;
+    a.nt_store = (full_pass || h->d_shock) ? 0 : 1;
+  }
   a.pos_stats = h->pos_stats;
   a.lim_mask = h->lim_mask;
   a.tvb_M = h->prm.limiter_type == DFLO_LIMITER_TVB ? h->prm.M : -1.0;

@@ -305,7 +305,13 @@ int build_plan(const dflo_mesh_t &mesh, int shard_ex, int shard_ey, Plan &p, std
         if ((r.w0 >> 18) & 1) return 2;
         return ((r.w0 & 0xFFFF) >= (uint32_t)kShard || r.w1 >= kShard) ? 0 : 1;
       };
-      std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return kind(x) < kind(y); });
+      // inside a kind: by the local face of the integrating cell, then by its slot -- neighbouring lanes of the flux phase
+      // then read the same rows of the LDS image at different cells (different banks)
+      auto key = [&](int k) {
+        const FaceRec &r = p.faces[face0 + k];
+        return (kind(k) << 20) | (int)(((r.w0 >> 16) & 3) << 16) | (int)(r.w0 & 0xFFFF);
+      };
+      std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return key(x) < key(y); });
       std::vector<FaceRec> fr(nf);
       std::vector<double> fg((size_t)nf * 3);
       for (int k = 0; k < nf; ++k) {

@@ -103,21 +103,32 @@ __device__ __forceinline__ void row_update(const StageArgs &a, double *Us, const
       // solve() rk3 branch + SSP combine (src/claw.cc:708-710, 757-760)
       const double rh2 = frcp(h * h);
       double *np = a.Unew + (size_t)shard * 4 * NS * 64 + lane;
+      double ust[4][N];
 #pragma unroll
       for (int c = 0; c < 4; ++c)
 #pragma unroll
         for (int m = 0; m < N; ++m) {
-          const int d = c * NS + m + N * B;
           const double ww = CB<N>::t.w[m] * CB<N>::t.w[B];
           const double invM = rh2 * (CB<N>::t.iw[m] * CB<N>::t.iw[B]);
           part[4] += R[c][m] * R[c][m];
           double u = Wrow[m][c];
           u += dt * R[c][m] * invM;
           if constexpr (MODE == 1) u = (1.0 - a.ark) * u + a.ark * uold[c][m];
-          np[d * 64] = u;
+          ust[c][m] = u;
           if constexpr (POS) unew[c][m] = u;   // kept for the positivity step of the caller (which stores again if it scales)
           part[c] += ww * u;
         }
+      if (a.nt_store) {   // wave-uniform: past the caches when nothing reads the new state before the next stage kernel
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+          for (int m = 0; m < N; ++m) __builtin_nontemporal_store(ust[c][m], &np[(c * NS + m + N * B) * 64]);
+      } else {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+          for (int m = 0; m < N; ++m) np[(c * NS + m + N * B) * 64] = ust[c][m];
+      }
     }
   } else if constexpr (POS) {
 #pragma unroll
@@ -258,7 +269,7 @@ __device__ __forceinline__ void row_update_q1(const StageArgs &a, double *Us, co
           double u = Wrow[m][c];
           u += dt * R[c][m] * invM;
           if constexpr (MODE == 1) u = (1.0 - a.ark) * u + a.ark * uold[c][m];
-          np[d * 64] = u;
+          stream_store(a.nt_store, &np[d * 64], u);
           if constexpr (POS) unew[c][m] = u;
           part[c] += wd * u;
         }
@@ -280,7 +291,7 @@ __device__ __forceinline__ void row_update_q1(const StageArgs &a, double *Us, co
 
 // phase B: one numerical flux per face point of the shard (integrate_face_term_explicit :303-341,
 // integrate_boundary_term_explicit :176-206).  Face-point index p = q * nf + k: neighbouring lanes take
-// neighbouring faces at the same q -> same LDS rows, consecutive slots.  Reads LDS only.
+// neighbouring faces at the same q -> same LDS rows, different slots.  Reads LDS only.
 // packed face record (4 bytes) of the device tables; plan.h's FaceRec is the host-side form
 //   bits 0-8 slot of the integrating cell, 9-10 its local face, 11 boundary, 12 flip,
 //   interior: 13-14 local face of the other cell, 15-23 its slot;  boundary: 13-22 index among the shard's boundary faces
@@ -306,7 +317,18 @@ __device__ __forceinline__ void flux_phase(const StageArgs &a, const double *Us,
   constexpr int NS = N * N, NDOF = 4 * NS, NT = 64 * N, S = 65;
   const int nfp = nf * N;
   for (int p = tid; p < nfp; p += NT) {
-    const int k = p / N, q = p - k * N;   // the N points of a face sit in consecutive lanes; faces are sorted by kind
+    // neighbouring lanes take neighbouring faces at the same point q (the plan sorts the faces by kind, local face, slot): the
+    // lanes of a wavefront read the same rows of the LDS image at different cells (measured against "the N points of a face in
+    // consecutive lanes": Q3 KFVS +3-4 %, Q1 LxF +1 %, Q2 HLLC -1 %)
+    int q, k;
+    if constexpr (N == 3) {   // (for N = 3 the N points of a face in consecutive lanes measured 1 % faster)
+      k = p / N;
+      q = p - k * N;
+    } else {
+      q = p >= nf ? 1 : 0;
+      if constexpr (N > 3) q += (p >= 2 * nf ? 1 : 0) + (p >= 3 * nf ? 1 : 0);
+      k = p - q * nf;
+    }
     const uint32_t r = Fr[k];
     const int slotL = pface_slot(r), fL = pface_face(r);
     const bool bnd = pface_bnd(r), flip = pface_flip(r);
@@ -435,7 +457,9 @@ __global__ __launch_bounds__(64 * N, ((GEO == 1 && N != 3) || N == 4) ? 2 : 3) v
 #pragma unroll
     for (int c = 0; c < 4; ++c)
 #pragma unroll
-      for (int m = 0; m < N; ++m) urow[c][m] = up[(c * NS + m) * 64];
+      for (int m = 0; m < N; ++m) {
+        urow[c][m] = up[(c * NS + m) * 64];
+      }
   }
   double uavg[4];
   if constexpr (FLUX == DFLO_FLUX_LXF) {
@@ -475,7 +499,9 @@ __global__ __launch_bounds__(64 * N, ((GEO == 1 && N != 3) || N == 4) ? 2 : 3) v
 #pragma unroll
     for (int c = 0; c < 4; ++c)
 #pragma unroll
-      for (int m = 0; m < N; ++m) uold[c][m] = op[(c * NS + m) * 64];
+      for (int m = 0; m < N; ++m) {
+        uold[c][m] = __builtin_nontemporal_load(&op[(c * NS + m) * 64]);   // u(n) is read once per stage, by this thread only
+      }
   }
 
   PHASE_MARK(0);
