@@ -169,13 +169,16 @@ stage_fn pick_pk(int N, int flux, int mode) {
     default: return dflo::stage_pk_of_4(flux, mode);
   }
 }
-stage_fn pick_stage(int N, int flux, int mode, int geo, int pos = 0) {
+stage_fn pick_stage(int N, int flux, int mode, int geo, int pos = 0, int nt = 0) {
   switch (N) {
-    case 2: return dflo::stage_of_2(flux, mode, geo, pos);
-    case 3: return dflo::stage_of_3(flux, mode, geo, pos);
-    default: return dflo::stage_of_4(flux, mode, geo, pos);
+    case 2: return dflo::stage_of_2(flux, mode, geo, pos, nt);
+    case 3: return dflo::stage_of_3(flux, mode, geo, pos, nt);
+    default: return dflo::stage_of_4(flux, mode, geo, pos, nt);
   }
 }
+
+// does nothing read the new state between this stage kernel and the next (no limiter / indicator pass over all cells)?
+int streams_out(const dflo_hip_engine *h);
 
 int grid_for(int n_shards) { return ((n_shards + 7) / 8) * 8; }
 
@@ -365,11 +368,6 @@ int launch_update(dflo_hip_engine *h, double *rhs_out, int part) {
   const int mode_ = rhs_out ? 2 : (h->ark[rk] != 0.0 ? 1 : 0);
   a.flags = h->flags;
   a.step_index = (int)h->steps_done;
-  {  // does a limiter pass read the whole new state right after this launch?
-    const bool limited = h->prm.limiter_type != DFLO_LIMITER_NONE || h->prm.pos_lim;
-    const bool full_pass = limited && !h->fuse_pos && !h->lim_mask;
-    a.nt_store = (full_pass || h->d_shock) ? 0 : 1;
-  }
   a.pos_stats = h->pos_stats;
   a.lim_mask = h->lim_mask;
   a.tvb_M = h->prm.limiter_type == DFLO_LIMITER_TVB ? h->prm.M : -1.0;
@@ -377,7 +375,7 @@ int launch_update(dflo_hip_engine *h, double *rhs_out, int part) {
   a.pos_check = h->prm.pos_lim;
   const int pos_ = h->fuse_pos ? 1 : (h->lim_mask ? 2 : 0);
   if (pos_ == 2 && mode_ != 2) h->aux_fresh = true;
-  stage_fn fn = h->basis == DFLO_BASIS_PK ? pick_pk(h->N, h->prm.flux_type, mode_) : pick_stage(h->N, h->prm.flux_type, mode_, h->geo, pos_);
+  stage_fn fn = h->basis == DFLO_BASIS_PK ? pick_pk(h->N, h->prm.flux_type, mode_) : pick_stage(h->N, h->prm.flux_type, mode_, h->geo, pos_, streams_out(h));
   time_begin(h);
   hipLaunchKernelGGL(fn, dim3(grid_for(a.n_list)), dim3(64 * h->N), h->lds_bytes, h->stream, a);
   time_end(h);
@@ -546,6 +544,12 @@ void drop_graph(dflo_hip_engine *h) {
 }
 
 int check_handle(dflo_hip_handle h) { return h ? DFLO_OK : DFLO_ERR_BAD_PARAM; }
+
+int streams_out(const dflo_hip_engine *h) {
+  const bool limited = h->prm.limiter_type != DFLO_LIMITER_NONE || h->prm.pos_lim;
+  const bool full_pass = limited && !h->fuse_pos && !h->lim_mask;
+  return (full_pass || h->d_shock) ? 0 : 1;
+}
 
 void part_list(const dflo_hip_engine *h, int part, const int32_t **list, int *n) {
   const Plan &p = h->plan;
@@ -769,7 +773,7 @@ int dflo_hip_create(const dflo_mesh_t *mesh, const dflo_params_t *params, int de
   if (h->lds_bytes > 160 * 1024) { h->err = "shard halo too large for LDS"; return bail(DFLO_ERR_UNSUPPORTED); }
   if (h->lds_bytes > 64 * 1024) {
     for (int mode = 0; mode < 3; ++mode) {
-      stage_fn fn = h->basis == DFLO_BASIS_PK ? pick_pk(h->N, h->prm.flux_type, mode) : pick_stage(h->N, h->prm.flux_type, mode, h->geo, h->fuse_pos ? 1 : (h->lim_mask ? 2 : 0));
+      stage_fn fn = h->basis == DFLO_BASIS_PK ? pick_pk(h->N, h->prm.flux_type, mode) : pick_stage(h->N, h->prm.flux_type, mode, h->geo, h->fuse_pos ? 1 : (h->lim_mask ? 2 : 0), streams_out(h));
       if (hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes) != hipSuccess) {
         h->err = "cannot raise dynamic LDS limit";
         return bail(DFLO_ERR_HIP);

@@ -72,8 +72,6 @@ struct StageArgs {
   int n_list;
   int *flags;   // POS 1: [0] negative mean state, [1] positivity root failure (as LimArgs::flags)
   int step_index; // time step this launch belongs to (host count since set_solution), recorded with a raised flag
-  int nt_store;   // the new state is not read again before the next stage kernel (no limiter pass over all cells follows):
-                  // store it past the caches (measured: C2 +2 %, C4 +3 %; with the Q1 limiter pass behind it C3 -2 %)
   unsigned long long *pos_stats;  // POS 1: [0] cells that failed the nodal-box bound (limiter proper), [1] cells it changed
   unsigned long long *lim_mask;   // POS 2: [n_shards] bit = the limiter pass may have something to do in that cell
   double tvb_M;                   // POS 2: TVB constant M, < 0: the limiter pass has no TVB part
@@ -91,8 +89,9 @@ __device__ __forceinline__ void raise_flag(int *flags, int which, int step_index
   f[which] = 1;
 }
 
-__device__ __forceinline__ void stream_store(int nt, double *p, double v) {
-  if (nt) __builtin_nontemporal_store(v, p);   // wave-uniform branch
+template <int NT>
+__device__ __forceinline__ void stream_store(double *p, double v) {
+  if constexpr (NT) __builtin_nontemporal_store(v, p);
   else *p = v;
 }
 

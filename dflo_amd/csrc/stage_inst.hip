@@ -10,6 +10,6 @@
 #define DFLO_CAT(a, b) DFLO_CAT_(a, b)
 
 namespace dflo {
-stage_fn DFLO_CAT(stage_of_, DFLO_STAGE_N)(int flux, int mode, int geo, int pos) { return pick_stage_n<DFLO_STAGE_N>(flux, mode, geo, pos); }
+stage_fn DFLO_CAT(stage_of_, DFLO_STAGE_N)(int flux, int mode, int geo, int pos, int nt) { return pick_stage_n<DFLO_STAGE_N>(flux, mode, geo, pos, nt); }
 stage_fn DFLO_CAT(stage_pk_of_, DFLO_STAGE_N)(int flux, int mode) { return pick_pk_n<DFLO_STAGE_N>(flux, mode); }
 }  // namespace dflo

@@ -13,7 +13,7 @@ namespace dflo {
 // fluxes at the shard's face points, the packed face records and the shard's boundary data.
 
 // phase C for node row B of every cell of the shard (lane = cell)
-template <int N, int B, int MODE, int POS>
+template <int N, int B, int MODE, int POS, int STREAM>
 __device__ __forceinline__ void row_update(const StageArgs &a, double *Us, const int S, const double *Fh,
                                            double *red, int shard, int lane, bool active, double h,
                                            const uint16_t (&cref)[4], const double (&uold)[4][N],
@@ -49,6 +49,41 @@ __device__ __forceinline__ void row_update(const StageArgs &a, double *Us, const
     }
   }
   __syncthreads();
+#ifdef DFLO_MFMA_Y
+  if constexpr (N == 4) {
+    // A/B experiment (north_star: "MFMA only for the dense per-element basis contractions at higher order"): the eta
+    // contraction  O[c][aa][B] = sum_q G[c][aa, q] DW[q][B]  of one cell is four 4 x 4 x 4 products (one per component),
+    // which is exactly one v_mfma_f64_4x4x4_4b_f64 (4 blocks).  Operand layout measured with
+    // tools/mfma_4x4_layout_probe.hip: A_b[i][k] in lane 16 k + 4 b + i, B_b[k][n] in lane 16 k + 4 b + n, D_b[i][n] in
+    // lane 16 i + 4 b + n.  With b = component, i = node aa, k = row q, n = target row B, wave w takes the cells
+    // 16 w .. 16 w + 15: lane l fetches G[c][aa, q] of the cell from column `cell` of the LDS image (a gather over the 64
+    // rows), the matrix pipe forms the products for all four target rows at once, and the result goes back into the same
+    // column (in place: a column belongs to one wave); after a barrier every wave reads its own 16 sums lane = cell.
+    const int l = lane, w = B;
+    const int ra = (((l >> 2) & 3) * NS + (l & 3) + N * (l >> 4)) * S;          // row of A: c = (l/4)%4, aa = l%4, q = l/16
+    const int rd = ((l & 3) * NS + ((l >> 2) & 3) * N + (l >> 4)) * S;          // row of D: B = l%4, c = (l/4)%4, aa = l/16 -> O[B][c][aa]
+    double bq = CB<N>::t.DW[0][0];
+#pragma unroll
+    for (int k = 0; k < N; ++k)
+#pragma unroll
+      for (int n = 0; n < N; ++n) bq = ((l >> 4) == k && (l & 3) == n) ? CB<N>::t.DW[k][n] : bq;
+    double av[16];
+#pragma unroll
+    for (int jj = 0; jj < 16; ++jj) av[jj] = Us[ra + 16 * w + jj];
+#pragma unroll
+    for (int jj = 0; jj < 16; ++jj) av[jj] = __builtin_amdgcn_mfma_f64_4x4x4f64(av[jj], bq, 0.0, 0, 0, 0);
+#pragma unroll
+    for (int jj = 0; jj < 16; ++jj) Us[rd + 16 * w + jj] = av[jj];
+    __syncthreads();
+#pragma unroll
+    for (int aa = 0; aa < N; ++aa) {
+      const double wah = CB<N>::t.w[aa] * h;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) R[c][aa] += wah * Us[(B * NS + c * N + aa) * S + lane];
+    }
+  } else
+#endif
+  {
 #pragma unroll
   for (int aa = 0; aa < N; ++aa) {
     const double wah = CB<N>::t.w[aa] * h;
@@ -60,6 +95,7 @@ __device__ __forceinline__ void row_update(const StageArgs &a, double *Us, const
         R[c][aa] += gy * (wah * CB<N>::t.DW[q][B]);
       }
     }
+  }
   }
   // face terms (:209-244, :344-423): - flux * phi * JxW on the integrating side, + on the other
   if (active) {
@@ -118,17 +154,10 @@ __device__ __forceinline__ void row_update(const StageArgs &a, double *Us, const
           if constexpr (POS) unew[c][m] = u;   // kept for the positivity step of the caller (which stores again if it scales)
           part[c] += ww * u;
         }
-      if (a.nt_store) {   // wave-uniform: past the caches when nothing reads the new state before the next stage kernel
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
+      for (int c = 0; c < 4; ++c)
 #pragma unroll
-          for (int m = 0; m < N; ++m) __builtin_nontemporal_store(ust[c][m], &np[(c * NS + m + N * B) * 64]);
-      } else {
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-#pragma unroll
-          for (int m = 0; m < N; ++m) np[(c * NS + m + N * B) * 64] = ust[c][m];
-      }
+        for (int m = 0; m < N; ++m) stream_store<STREAM>(&np[(c * NS + m + N * B) * 64], ust[c][m]);
     }
   } else if constexpr (POS) {
 #pragma unroll
@@ -162,7 +191,7 @@ __device__ __forceinline__ void row_update(const StageArgs &a, double *Us, const
 // FEValues with MappingQ1): J = [x_xi x_eta; y_xi y_eta] varies inside the cell,
 //   int F.grad(phi) = sum_q w_q [ d(phi)/d(xi) (y_eta F - x_eta G) + d(phi)/d(eta) (-y_xi F + x_xi G) ],
 // lumped mass M_j = w_j det J_j (src/claw.cc:223-227), face JxW = w_q |edge|.
-template <int N, int B, int MODE, int POS>
+template <int N, int B, int MODE, int POS, int STREAM>
 __device__ __forceinline__ void row_update_q1(const StageArgs &a, double *Us, const int S, const double *Fh,
                                               const double *Fg, double *red, int shard, int lane, bool active,
                                               const double (&vx)[8], const uint16_t (&cref)[4],
@@ -269,7 +298,7 @@ __device__ __forceinline__ void row_update_q1(const StageArgs &a, double *Us, co
           double u = Wrow[m][c];
           u += dt * R[c][m] * invM;
           if constexpr (MODE == 1) u = (1.0 - a.ark) * u + a.ark * uold[c][m];
-          stream_store(a.nt_store, &np[d * 64], u);
+          stream_store<STREAM>(&np[d * 64], u);
           if constexpr (POS) unew[c][m] = u;
           part[c] += wd * u;
         }
@@ -401,7 +430,10 @@ __device__ __forceinline__ void flux_phase(const StageArgs &a, const double *Us,
 //   POS 1: apply_positivity_limiter (src/positivity.cc:17-208) on the way out, for runs without the TVB limiter
 //   POS 2 (squares, TVB runs): one bit per cell goes out beside its average -- can the limiter pass (TVB, then positivity)
 //          change anything in this cell? -- so that the pass reads the DoFs of the marked cells only
-template <int N, int FLUX, int MODE, int GEO, int POS>
+//   STREAM 1: nothing reads the new state before the next stage kernel (no limiter pass over all cells follows): it is stored past
+//         the caches (measured: C2 +2 %, C4 +3 %; with the Q1 limiter pass behind it C3 -2 %, hence a variant and not a rule).
+//         A compile-time switch: behind a run-time branch the compiler merges the two store sequences and drops the hint.
+template <int N, int FLUX, int MODE, int GEO, int POS, int STREAM>
 __global__ __launch_bounds__(64 * N, ((GEO == 1 && N != 3) || N == 4) ? 2 : 3) void stage_kernel(const StageArgs a) {
   constexpr int NS = N * N, NDOF = 4 * NS, NT = 64 * N;
   constexpr int ROWS = NDOF + (FLUX == DFLO_FLUX_LXF ? 3 : 0);   // LxF: (u, v, c) of the cell average ride along
@@ -601,8 +633,8 @@ __global__ __launch_bounds__(64 * N, ((GEO == 1 && N != 3) || N == 4) ? 2 : 3) v
     for (int c = 0; c < 4; ++c) wrow[m][c] = urow[c][m];
 #define DFLO_ROW(Bq)                                                                                     \
   do {                                                                                                   \
-    if constexpr (GEO == 0) row_update<N, Bq, MODE, POS>(a, Us, S, Fh, red, shard, lane, active, h, cref, uold, wrow, unew, dt_step); \
-    else row_update_q1<N, Bq, MODE, POS>(a, Us, S, Fh, Fg, red, shard, lane, active, vx, cref, uold, wrow, unew, dt_step); \
+    if constexpr (GEO == 0) row_update<N, Bq, MODE, POS, STREAM>(a, Us, S, Fh, red, shard, lane, active, h, cref, uold, wrow, unew, dt_step); \
+    else row_update_q1<N, Bq, MODE, POS, STREAM>(a, Us, S, Fh, Fg, red, shard, lane, active, vx, cref, uold, wrow, unew, dt_step); \
   } while (0)
   if constexpr (N == 2) {
     if (row == 0) DFLO_ROW(0); else DFLO_ROW(1);
@@ -1146,23 +1178,29 @@ __global__ __launch_bounds__(64 * N, N == 4 ? 2 : 3) void stage_kernel_pk(const 
 // translation unit (stage_inst.hip, -DDFLO_STAGE_N=N) and reached through stage_of_N / stage_pk_of_N.
 typedef void (*stage_fn)(const StageArgs);
 template <int N, int FLUX>
-stage_fn pick_stage_m(int mode, int geo, int pos) {
-  if (pos == 1 && mode != 2) {
-    if (geo == 0) return mode == 0 ? stage_kernel<N, FLUX, 0, 0, 1> : stage_kernel<N, FLUX, 1, 0, 1>;
-    return mode == 0 ? stage_kernel<N, FLUX, 0, 1, 1> : stage_kernel<N, FLUX, 1, 1, 1>;
+stage_fn pick_stage_m(int mode, int geo, int pos, int nt) {
+  if (pos == 1 && mode != 2) {   // the limiter has been applied on the way out: nothing re-reads the state
+    if (geo == 0) return mode == 0 ? stage_kernel<N, FLUX, 0, 0, 1, 1> : stage_kernel<N, FLUX, 1, 0, 1, 1>;
+    return mode == 0 ? stage_kernel<N, FLUX, 0, 1, 1, 1> : stage_kernel<N, FLUX, 1, 1, 1, 1>;
   }
-  if (pos == 2 && mode != 2 && geo == 0) return mode == 0 ? stage_kernel<N, FLUX, 0, 0, 2> : stage_kernel<N, FLUX, 1, 0, 2>;
-  if (geo == 0) return mode == 0 ? stage_kernel<N, FLUX, 0, 0, 0> : (mode == 1 ? stage_kernel<N, FLUX, 1, 0, 0> : stage_kernel<N, FLUX, 2, 0, 0>);
-  return mode == 0 ? stage_kernel<N, FLUX, 0, 1, 0> : (mode == 1 ? stage_kernel<N, FLUX, 1, 1, 0> : stage_kernel<N, FLUX, 2, 1, 0>);
+  if (pos == 2 && mode != 2 && geo == 0)   // the limiter pass reads the marked cells only
+    return mode == 0 ? stage_kernel<N, FLUX, 0, 0, 2, 1> : stage_kernel<N, FLUX, 1, 0, 2, 1>;
+  if (mode == 2) return geo == 0 ? stage_kernel<N, FLUX, 2, 0, 0, 0> : stage_kernel<N, FLUX, 2, 1, 0, 0>;
+  if (nt) {
+    if (geo == 0) return mode == 0 ? stage_kernel<N, FLUX, 0, 0, 0, 1> : stage_kernel<N, FLUX, 1, 0, 0, 1>;
+    return mode == 0 ? stage_kernel<N, FLUX, 0, 1, 0, 1> : stage_kernel<N, FLUX, 1, 1, 0, 1>;
+  }
+  if (geo == 0) return mode == 0 ? stage_kernel<N, FLUX, 0, 0, 0, 0> : stage_kernel<N, FLUX, 1, 0, 0, 0>;
+  return mode == 0 ? stage_kernel<N, FLUX, 0, 1, 0, 0> : stage_kernel<N, FLUX, 1, 1, 0, 0>;
 }
 template <int N>
-stage_fn pick_stage_n(int flux, int mode, int geo, int pos) {
+stage_fn pick_stage_n(int flux, int mode, int geo, int pos, int nt) {
   switch (flux) {
-    case DFLO_FLUX_LXF: return pick_stage_m<N, DFLO_FLUX_LXF>(mode, geo, pos);
-    case DFLO_FLUX_SW: return pick_stage_m<N, DFLO_FLUX_SW>(mode, geo, pos);
-    case DFLO_FLUX_KFVS: return pick_stage_m<N, DFLO_FLUX_KFVS>(mode, geo, pos);
-    case DFLO_FLUX_ROE: return pick_stage_m<N, DFLO_FLUX_ROE>(mode, geo, pos);
-    default: return pick_stage_m<N, DFLO_FLUX_HLLC>(mode, geo, pos);
+    case DFLO_FLUX_LXF: return pick_stage_m<N, DFLO_FLUX_LXF>(mode, geo, pos, nt);
+    case DFLO_FLUX_SW: return pick_stage_m<N, DFLO_FLUX_SW>(mode, geo, pos, nt);
+    case DFLO_FLUX_KFVS: return pick_stage_m<N, DFLO_FLUX_KFVS>(mode, geo, pos, nt);
+    case DFLO_FLUX_ROE: return pick_stage_m<N, DFLO_FLUX_ROE>(mode, geo, pos, nt);
+    default: return pick_stage_m<N, DFLO_FLUX_HLLC>(mode, geo, pos, nt);
   }
 }
 template <int N, int FLUX>
@@ -1179,9 +1217,9 @@ stage_fn pick_pk_n(int flux, int mode) {
     default: return pick_pk_m<N, DFLO_FLUX_HLLC>(mode);
   }
 }
-stage_fn stage_of_2(int flux, int mode, int geo, int pos);
-stage_fn stage_of_3(int flux, int mode, int geo, int pos);
-stage_fn stage_of_4(int flux, int mode, int geo, int pos);
+stage_fn stage_of_2(int flux, int mode, int geo, int pos, int nt);
+stage_fn stage_of_3(int flux, int mode, int geo, int pos, int nt);
+stage_fn stage_of_4(int flux, int mode, int geo, int pos, int nt);
 stage_fn stage_pk_of_2(int flux, int mode);
 stage_fn stage_pk_of_3(int flux, int mode);
 stage_fn stage_pk_of_4(int flux, int mode);
