@@ -25,7 +25,7 @@ for spec in sys.argv[2:]:
     n_rk = 2 if next(iter(st)).split("<")[1].split(",")[0].strip() == "2" else 3
     rec = {"hbm_bytes_per_launch": (mode0[0] + (n_rk - 1) * mode1[0]) / n_rk, "first_stage": mode0[0], "later_stages": mode1[0],
            "source": "profiles/%s/%s_summary.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; FETCH_SIZE x2 per the gfx950 correction)" % (rnd, tag),
-           "note": "mean over the RK stages of one step: the first stage does not read u(n)"}
+           "calibration": "profiles/r02/hbm_calibration.json: at 8 B per lane FETCH_SIZE x 2.000 and WRITE_SIZE x 1.000 reproduce known byte counts", "note": "mean over the RK stages of one step: the first stage does not read u(n)"}
     lim = [v["hbm_bytes_per_launch"] for k, v in t.items() if k.startswith("limiter")]
     if lim:
         rec["limiter_kernel_bytes_per_launch"] = lim[0]
