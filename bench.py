@@ -385,14 +385,14 @@ def main():
             ncpu = os.cpu_count() or 1
             quota = _cpu_quota()
             counts = sorted({quota, min(2 * quota, ncpu)})
-            runs = [cpu_baseline(threads=t, nx=1024, steps=2) for t in counts]
+            runs = [cpu_baseline(threads=t, nx=1024, steps=8) for t in counts]
             out["cpu_baseline"] = max(runs, key=lambda r: r["value"])
             out["cpu_baseline"]["host_cpus"] = ncpu
             out["cpu_baseline"]["cpu_quota"] = quota   # what the container may use (cgroup cpu.max); threads beyond it only queue
             out["cpu_baseline"]["cpu_model"] = _cpu_model()
             # the fused twin threads every pass, so it scales to the quota (GPU box, 16 CPUs: 47 / 349 / 661 MDoF/s with
             # 1 / 8 / 16 threads, less with more threads than CPUs)
-            twins = [cpu_twin(threads=t, nx=1024, steps=5) for t in sorted({quota, min(2 * quota, ncpu)})]
+            twins = [cpu_twin(threads=t, nx=1024, steps=30) for t in sorted({quota, min(2 * quota, ncpu)})]
             out["cpu_baseline"]["optimised_twin"] = max(twins, key=lambda r: r["value"])
         result_line = json.dumps(out)
     if world > 1:
