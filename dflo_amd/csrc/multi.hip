@@ -128,6 +128,10 @@ struct dflo_hip_multi {
   int rank = 0;                // rank mode: this process's part
   bool rank_mode = false, loopback = false;
   ncclComm_t comm = nullptr;
+  // one process per GPU with the host program's own transport (MPI, ...) instead of RCCL
+  dflo_exchange_fn x_exchange = nullptr;
+  dflo_allreduce_fn x_allreduce = nullptr;
+  void *x_user = nullptr;
   dflo_params_t prm{};
   int degree = 1, basis = 0, ndof = 16, N = 2, n_rk = 2;
   int64_t n_cells_global = 0;
@@ -179,6 +183,25 @@ Part *local_part(dflo_hip_multi *m, int index) {
 // waits until the peers' cells are in this part's receive buffer `par`.
 int post(dflo_hip_multi *m, Part &p, const double *send, int width, bool averages, int par) {
   if (p.peers.empty()) return DFLO_OK;
+  if (m->rank_mode && m->x_exchange) {
+    double *recv = averages ? p.recv_a[par] : p.recv_u[par];
+    std::vector<int> peers;
+    std::vector<const void *> sp;
+    std::vector<void *> rp;
+    std::vector<size_t> sb, rb;
+    for (int q : p.peers) {
+      peers.push_back(q);
+      sp.push_back(send + (size_t)p.send_off[q] * width);
+      sb.push_back((size_t)(p.send_off[q + 1] - p.send_off[q]) * width * sizeof(double));
+      rp.push_back(recv + (size_t)p.recv_off[q] * width);
+      rb.push_back((size_t)(p.recv_off[q + 1] - p.recv_off[q]) * width * sizeof(double));
+    }
+    if (m->x_exchange(m->x_user, (int)peers.size(), peers.data(), sp.data(), sb.data(), rp.data(), rb.data(), (void *)p.C)) {
+      m->err = "the host program's exchange callback failed";
+      return DFLO_ERR_COMM;
+    }
+    return DFLO_OK;
+  }
   if (m->rank_mode) {
     double *recv = averages ? p.recv_a[par] : p.recv_u[par];
     MNCCL(m, g_rccl.GroupStart());
@@ -357,7 +380,11 @@ int reduce_dt(dflo_hip_multi *m) {
     MHIP(m, hipEventRecord(p.ev_fin, p.M));
     MHIP(m, hipStreamWaitEvent(p.C, p.ev_fin, 0));
     double *raw = (double *)p.dt_ptr + 2;
-    MNCCL(m, g_rccl.AllReduce(raw, raw, 1, ncclDouble, ncclMin, m->comm, p.C));
+    if (m->x_allreduce) {
+      if (m->x_allreduce(m->x_user, raw, 1, DFLO_REDUCE_MIN, (void *)p.C)) { m->err = "the host program's all-reduce callback failed"; return DFLO_ERR_COMM; }
+    } else {
+      MNCCL(m, g_rccl.AllReduce(raw, raw, 1, ncclDouble, ncclMin, m->comm, p.C));
+    }
     MENG(m, p, dflo_hip_set_stream(p.eng, p.C));
     MENG(m, p, dflo_hip_apply_dt_rules(p.eng));
     MENG(m, p, dflo_hip_set_stream(p.eng, p.M));
@@ -414,7 +441,12 @@ int host_allreduce(dflo_hip_multi *m, double *v, int n, ncclRedOp_t op) {
   Part &p = m->parts[0];
   MHIP(m, hipSetDevice(p.device));
   MHIP(m, hipMemcpyAsync(m->scal, v, n * sizeof(double), hipMemcpyHostToDevice, p.C));
-  MNCCL(m, g_rccl.AllReduce(m->scal, m->scal, n, ncclDouble, op, m->comm, p.C));
+  if (m->x_allreduce) {
+    const int xop = op == ncclMin ? DFLO_REDUCE_MIN : (op == ncclSum ? DFLO_REDUCE_SUM : DFLO_REDUCE_MAX);
+    if (m->x_allreduce(m->x_user, m->scal, n, xop, (void *)p.C)) { m->err = "the host program's all-reduce callback failed"; return DFLO_ERR_COMM; }
+  } else {
+    MNCCL(m, g_rccl.AllReduce(m->scal, m->scal, n, ncclDouble, op, m->comm, p.C));
+  }
   MHIP(m, hipMemcpyAsync(v, m->scal, n * sizeof(double), hipMemcpyDeviceToHost, p.C));
   MHIP(m, hipStreamSynchronize(p.C));
   return DFLO_OK;
@@ -620,11 +652,15 @@ int dflo_hip_comm_unique_id(void *id128) {
   return DFLO_OK;
 }
 
-int dflo_hip_multi_create_rank(const dflo_mesh_t *mesh, const dflo_params_t *params, int device_id, int rank, int n_ranks,
-                               const void *unique_id, int partitioner, dflo_hip_multi_handle *out) {
-  if (!mesh || !params || !out || n_ranks < 1 || rank < 0 || rank >= n_ranks || (n_ranks > 1 && !unique_id)) { g_multi_error = "bad arguments"; return DFLO_ERR_BAD_PARAM; }
+static int create_rank_impl(const dflo_mesh_t *mesh, const dflo_params_t *params, int device_id, int rank, int n_ranks,
+                            const void *unique_id, dflo_exchange_fn xf, dflo_allreduce_fn af, void *user, int partitioner,
+                            dflo_hip_multi_handle *out) {
+  if (!mesh || !params || !out || n_ranks < 1 || rank < 0 || rank >= n_ranks || (n_ranks > 1 && !unique_id && !(xf && af))) { g_multi_error = "bad arguments"; return DFLO_ERR_BAD_PARAM; }
   *out = nullptr;
   dflo_hip_multi *m = new dflo_hip_multi;
+  m->x_exchange = xf;
+  m->x_allreduce = af;
+  m->x_user = user;
   auto bail = [&](int rc) { g_multi_error = m->err; dflo_hip_multi_destroy(m); return rc; };
   m->n_parts = n_ranks;
   m->rank = rank;
@@ -636,17 +672,31 @@ int dflo_hip_multi_create_rank(const dflo_mesh_t *mesh, const dflo_params_t *par
   m->parts[0].device = device_id;
   if ((rc = setup_part(m, m->parts[0], mesh, params, partitioner))) return bail(rc);
   if (n_ranks > 1) {
-    if (!load_rccl(m->err)) return bail(DFLO_ERR_COMM);
-    ncclUniqueId id;
-    std::memcpy(&id, unique_id, sizeof(id));
     if (hipSetDevice(device_id) != hipSuccess) { m->err = "hipSetDevice failed"; return bail(DFLO_ERR_HIP); }
-    const ncclResult_t r = g_rccl.CommInitRank(&m->comm, n_ranks, id, rank);
-    if (r != ncclSuccess) { m->err = std::string("ncclCommInitRank: ") + g_rccl.GetErrorString(r); return bail(DFLO_ERR_COMM); }
+    if (!xf) {
+      if (!load_rccl(m->err)) return bail(DFLO_ERR_COMM);
+      ncclUniqueId id;
+      std::memcpy(&id, unique_id, sizeof(id));
+      const ncclResult_t r = g_rccl.CommInitRank(&m->comm, n_ranks, id, rank);
+      if (r != ncclSuccess) { m->err = std::string("ncclCommInitRank: ") + g_rccl.GetErrorString(r); return bail(DFLO_ERR_COMM); }
+    }
     if (hipMalloc((void **)&m->scal, 8 * sizeof(double)) != hipSuccess) { m->err = "hipMalloc(scratch) failed"; return bail(DFLO_ERR_NOMEM); }
   }
   finish_setup(m);
   *out = m;
   return DFLO_OK;
+}
+
+int dflo_hip_multi_create_rank(const dflo_mesh_t *mesh, const dflo_params_t *params, int device_id, int rank, int n_ranks,
+                               const void *unique_id, int partitioner, dflo_hip_multi_handle *out) {
+  return create_rank_impl(mesh, params, device_id, rank, n_ranks, unique_id, nullptr, nullptr, nullptr, partitioner, out);
+}
+
+int dflo_hip_multi_create_rank_custom(const dflo_mesh_t *mesh, const dflo_params_t *params, int device_id, int rank, int n_ranks,
+                                      dflo_exchange_fn exchange, dflo_allreduce_fn allreduce, void *user, int partitioner,
+                                      dflo_hip_multi_handle *out) {
+  if (!exchange || !allreduce) { g_multi_error = "both callbacks are needed"; return DFLO_ERR_BAD_PARAM; }
+  return create_rank_impl(mesh, params, device_id, rank, n_ranks, nullptr, exchange, allreduce, user, partitioner, out);
 }
 
 int dflo_hip_multi_n_local(dflo_hip_multi_handle m) { return m ? (int)m->parts.size() : 0; }

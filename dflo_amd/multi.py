@@ -34,6 +34,11 @@ class MultiConservationLaw:
         if _rank is None:
             dev = (C.c_int * len(devices))(*devices)
             rc = lib.dflo_hip_multi_create(mesh._ptr, C.byref(p), len(devices), dev, _lib.PARTITIONER[partitioner], C.byref(self._h))
+        elif len(_rank) == 5:      # the host program's own transport: (device, rank, world, exchange, allreduce)
+            device, rank, world, xf, af = _rank
+            self._callbacks = (_lib.EXCHANGE_FN(xf), _lib.ALLREDUCE_FN(af))     # keep the trampolines alive
+            rc = lib.dflo_hip_multi_create_rank_custom(mesh._ptr, C.byref(p), device, rank, world, self._callbacks[0], self._callbacks[1],
+                                                       None, _lib.PARTITIONER[partitioner], C.byref(self._h))
         else:
             device, rank, world, uid = _rank
             rc = lib.dflo_hip_multi_create_rank(mesh._ptr, C.byref(p), device, rank, world, uid, _lib.PARTITIONER[partitioner],
@@ -53,6 +58,12 @@ class MultiConservationLaw:
     @classmethod
     def for_rank(cls, mesh, parameters, device, rank, world, unique_id, partitioner="slab"):
         return cls(mesh, parameters, partitioner=partitioner, _rank=(device, rank, world, unique_id))
+
+    @classmethod
+    def for_rank_custom(cls, mesh, parameters, device, rank, world, exchange, allreduce, partitioner="slab"):
+        """One process per GPU with the caller's transport: exchange(user, n_peers, peer, send_ptr, send_bytes, recv_ptr,
+        recv_bytes, stream) and allreduce(user, values, n, op, stream) get device pointers (see include/dflo_hip.h)."""
+        return cls(mesh, parameters, partitioner=partitioner, _rank=(device, rank, world, exchange, allreduce))
 
     def close(self):
         if self._h:

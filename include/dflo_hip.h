@@ -26,6 +26,7 @@
 #ifndef DFLO_HIP_H
 #define DFLO_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -322,6 +323,20 @@ int dflo_hip_multi_create(const dflo_mesh_t *mesh, const dflo_params_t *params, 
 int dflo_hip_comm_unique_id(void *id_bytes);
 int dflo_hip_multi_create_rank(const dflo_mesh_t *mesh, const dflo_params_t *params, int device_id, int rank, int n_ranks,
                                const void *unique_id, int partitioner, dflo_hip_multi_handle *out);
+/* One process per GPU with the host program's own transport instead of RCCL (a cluster whose ranks talk MPI; the
+ * repository's two-process tests on one GPU, which RCCL refuses).  Both callbacks get DEVICE pointers and the driver's comm
+ * stream (hipStream_t as void*); when they return, the transfer must be complete or enqueued on that stream in order.
+ *   exchange:  for each of n_peers ranks, send_bytes[i] bytes at send_ptr[i] go to rank peer[i], recv_bytes[i] bytes from
+ *              it arrive at recv_ptr[i] -- update_ghost_values(), src_mpi/claw.cc:793
+ *   allreduce: n doubles at `values`, in place, op = dflo_reduce_op -- Utilities::MPI::min / sum, src_mpi/claw.cc:579,777
+ * Return 0 on success. */
+typedef enum { DFLO_REDUCE_MIN = 0, DFLO_REDUCE_SUM = 1, DFLO_REDUCE_MAX = 2 } dflo_reduce_op;
+typedef int (*dflo_exchange_fn)(void *user, int n_peers, const int *peer, const void *const *send_ptr, const size_t *send_bytes,
+                                void *const *recv_ptr, const size_t *recv_bytes, void *hip_stream);
+typedef int (*dflo_allreduce_fn)(void *user, double *values, int n, int op, void *hip_stream);
+int dflo_hip_multi_create_rank_custom(const dflo_mesh_t *mesh, const dflo_params_t *params, int device_id, int rank, int n_ranks,
+                                      dflo_exchange_fn exchange, dflo_allreduce_fn allreduce, void *user, int partitioner,
+                                      dflo_hip_multi_handle *out);
 int dflo_hip_multi_destroy(dflo_hip_multi_handle m);
 const char *dflo_hip_multi_last_error(dflo_hip_multi_handle m); /* m may be NULL: error of the last failed create */
 int dflo_hip_multi_n_parts(dflo_hip_multi_handle m);            /* parts of the partition */

@@ -1,0 +1,114 @@
+"""GPU: the one-process-per-GPU schedule of the native multi-device driver (dflo_hip_multi_create_rank_*: rim on the comm
+stream, pack, exchange, unpack, all-reduced time step, summed residual norms, agreed error status) run by 2 and 3 real
+processes on ONE device.  RCCL refuses two ranks on one GPU, so the ranks move their bytes with the driver's
+bring-your-own-transport entry (dflo_hip_multi_create_rank_custom, what a dflo built on MPI would use): the callbacks
+below stage the device buffers through gloo.  Everything except the ncclSend / ncclRecv / ncclAllReduce calls themselves is
+the code the 8-GPU RCCL run executes; those calls are exercised by test_gpu_multi.py::test_rccl_loopback_transport."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+class _DevPtr:
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (ptr, False), "version": 2}
+
+
+def _view(ptr, nbytes):
+    return torch.as_tensor(_DevPtr(ptr, nbytes // 8), device="cuda:0")
+
+
+def _exchange(user, n_peers, peer, send_ptr, send_bytes, recv_ptr, recv_bytes, stream):
+    try:
+        torch.cuda.synchronize()
+        ops, back = [], []
+        for i in range(n_peers):
+            if recv_bytes[i]:
+                host = torch.empty(recv_bytes[i] // 8, dtype=torch.float64)
+                back.append((host, recv_ptr[i], recv_bytes[i]))
+                ops.append(dist.P2POp(dist.irecv, host, peer[i]))
+            if send_bytes[i]:
+                ops.append(dist.P2POp(dist.isend, _view(send_ptr[i], send_bytes[i]).cpu(), peer[i]))
+        for w in dist.batch_isend_irecv(ops) if ops else []:
+            w.wait()
+        for host, ptr, nb in back:
+            _view(ptr, nb).copy_(host)
+        torch.cuda.synchronize()
+        return 0
+    except Exception as e:      # never let an exception cross the C boundary
+        print("exchange callback:", e, file=sys.stderr)
+        return 1
+
+
+def _allreduce(user, values, n, op, stream):
+    try:
+        torch.cuda.synchronize()
+        v = _view(values, 8 * n)
+        h = v.cpu()
+        dist.all_reduce(h, op=[dist.ReduceOp.MIN, dist.ReduceOp.SUM, dist.ReduceOp.MAX][op])
+        v.copy_(h)
+        torch.cuda.synchronize()
+        return 0
+    except Exception as e:
+        print("allreduce callback:", e, file=sys.stderr)
+        return 1
+
+
+def _worker(rank, world, port, name, ret):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, HERE)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    import dflo_amd
+    import test_gpu_multi as T
+    mesh, prm, ic = T._case(name)
+    limited = prm.limiter == "TVB"
+    claw = dflo_amd.MultiConservationLaw.for_rank_custom(mesh, prm, 0, rank, world, _exchange, _allreduce,
+                                                          partitioner="rcb" if name == "c5" else "slab")
+    assert claw.n_parts == world and claw.n_local == 1
+    T._setup(claw, mesh, ic)
+    got = T._run(claw, limited)
+    own = claw.part_cells(0)[0]
+    parts = [None] * world
+    dist.all_gather_object(parts, (own, got["u"].reshape(mesh.n_cells, -1)[own], got["avg"][own]))
+    if rank == 0:
+        u, avg = np.empty((mesh.n_cells, mesh.ndof)), np.empty((mesh.n_cells, 4))
+        for o, a, b in parts:
+            u[o], avg[o] = a, b
+        one = dflo_amd.ConservationLaw(mesh, prm)
+        T._setup(one, mesh, ic)
+        ref = T._run(one, limited)
+        ret["dt"] = got["dt"] == ref["dt"]
+        ret["t"] = got["t"] == ref["t"]
+        ret["norms"] = max(abs(a0 - b0) / b0 + abs(a1 - b1) / b1 for (a0, a1), (b0, b1) in zip(got["norms"], ref["norms"]))
+        ret["equal"] = bool(np.array_equal(u.reshape(-1), ref["u"]) and np.array_equal(avg, ref["avg"]))
+        ret["err"] = float(np.abs(u.reshape(-1) - ref["u"]).max() / np.abs(ref["u"]).max())
+    dist.barrier()
+    claw.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name,world", [("c2", 2), ("c2", 3), ("c1", 2), ("c4", 2), ("c4", 3), ("c5", 2), ("kxrcf", 2)])
+def test_ranks_on_one_device_match_the_single_engine(name, world):
+    import random
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, 29500 + random.randint(0, 2000), name, ret), nprocs=world, join=True)
+    assert ret["dt"] and ret["t"], dict(ret)                 # all-reduced minima, host-driven and device-resident
+    assert ret["norms"] < 1e-11
+    if name in ("c1", "c2"):
+        assert ret["equal"], ret["err"]                      # smooth data: bit-identical to the single engine
+    else:
+        assert ret["err"] < 1e-8
