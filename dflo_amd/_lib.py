@@ -67,8 +67,7 @@ SYMBOLS = [
     "dflo_hip_set_send_cells", "dflo_hip_pack_send", "dflo_hip_pack_send_avg", "dflo_hip_unpack_ghost",
     "dflo_hip_unpack_ghost_avg", "dflo_hip_n_ghost_cells", "dflo_hip_stage_update", "dflo_hip_stage_limit",
     "dflo_hip_stage_open", "dflo_hip_stage_update_part", "dflo_hip_stage_limit_part", "dflo_hip_stage_finish",
-    "dflo_hip_n_rim_shards", "dflo_hip_stage_rim", "dflo_hip_stage_rim_send", "dflo_hip_stage_rim_recv",
-    "dflo_hip_stage_interior", "dflo_hip_stage_join",
+    "dflo_hip_n_rim_shards",
     "dflo_hip_scalar_ptrs", "dflo_hip_apply_dt_rules", "dflo_hip_debug_math",
     "dflo_mesh_cartesian", "dflo_mesh_from_quads", "dflo_mesh_read_gmsh", "dflo_mesh_partition", "dflo_mesh_make_periodic", "dflo_mesh_free",
     "dflo_mesh_last_error", "dflo_mesh_support_points", "dflo_mesh_partition_ex", "dflo_mesh_partition_owners",
@@ -150,11 +149,6 @@ _sig("dflo_hip_stage_update_part", C.c_int, _H, C.c_int)
 _sig("dflo_hip_stage_limit_part", C.c_int, _H, C.c_int)
 _sig("dflo_hip_stage_finish", C.c_int, _H)
 _sig("dflo_hip_n_rim_shards", C.c_int, _H)
-_sig("dflo_hip_stage_rim", C.c_int, _H, C.c_int, C.c_double, C.c_void_p)
-_sig("dflo_hip_stage_rim_send", C.c_int, _H, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p)
-_sig("dflo_hip_stage_rim_recv", C.c_int, _H, C.c_void_p, C.c_void_p)
-_sig("dflo_hip_stage_interior", C.c_int, _H)
-_sig("dflo_hip_stage_join", C.c_int, _H)
 _sig("dflo_hip_scalar_ptrs", C.c_int, _H, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p))
 _sig("dflo_hip_apply_dt_rules", C.c_int, _H)
 _sig("dflo_hip_debug_math", C.c_int, C.c_int, _dp, _dp, _dp)

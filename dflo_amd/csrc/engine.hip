@@ -78,8 +78,6 @@ struct dflo_hip_engine {
   int64_t t_stages = 0, t_seen = 0;   // stages timed / stages seen while timing is on
   bool t_sample = false;
   int32_t *d_rim_list = nullptr, *d_int_list = nullptr, *d_rim2_list = nullptr, *d_rest2_list = nullptr;
-  hipEvent_t ev_rim = nullptr, ev_unpack = nullptr;
-  bool unpack_pending = false;
   double pending_dt = -1.0;
   int32_t *d_send_slots = nullptr;
   int n_send = 0;
@@ -816,7 +814,6 @@ int dflo_hip_destroy(dflo_hip_handle h) {
   hipFree(h->fin_counter); hipFree(h->dt_pub); hipFree(h->pos_stats); hipFree(h->d_send_slots); hipFree(h->ghost_stage);
   for (int i = 0; i < 2; ++i) if (h->ev_chunk[i]) hipEventDestroy(h->ev_chunk[i]);
   for (auto &e : h->ev_pool) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
-  if (h->ev_rim) { hipEventDestroy(h->ev_rim); hipEventDestroy(h->ev_unpack); }
   if (h->own_stream) hipStreamDestroy(h->own_stream);
   delete h;
   return DFLO_OK;
@@ -1188,87 +1185,6 @@ int dflo_hip_stage_finish(dflo_hip_handle h) {
 }
 
 int dflo_hip_n_rim_shards(dflo_hip_handle h) { return h ? (int)h->plan.rim_shards.size() : 0; }
-
-// ---- the overlapped stage as four host calls (main stream = compute, comm stream = halo traffic):
-//   stage_rim      main: wait for the previous unpack, open the stage, advance the rim shards
-//   stage_rim_send comm: wait for the rim shards, (TVB: receive averages,) limit them, pack
-//   stage_rim_recv comm: unpack what the transport delivered
-//   stage_interior main: interior shards, their limiter, reductions
-static int ensure_events(dflo_hip_engine *h) {
-  if (h->ev_rim) return DFLO_OK;
-  HIPCHK(h, hipEventCreateWithFlags(&h->ev_rim, hipEventDisableTiming));
-  HIPCHK(h, hipEventCreateWithFlags(&h->ev_unpack, hipEventDisableTiming));
-  return DFLO_OK;
-}
-
-int dflo_hip_stage_rim(dflo_hip_handle h, int rk, double dt, void *main_stream) {
-  if (check_handle(h) || rk < 0 || rk >= h->n_rk) return DFLO_ERR_BAD_PARAM;
-  hipSetDevice(h->device);
-  int rc = ensure_events(h);
-  if (rc) return rc;
-  h->stream = main_stream ? (hipStream_t)main_stream : h->own_stream;
-  if (h->unpack_pending) HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_unpack, 0));
-  rc = open_stage(h, rk, dt, false, -1);
-  if (rc) return rc;
-  rc = launch_update(h, nullptr, 1);
-  if (rc) return rc;
-  HIPCHK(h, hipEventRecord(h->ev_rim, h->stream));
-  return DFLO_OK;
-}
-
-// what = 0: limit the rim shards and pack their DoFs; 1: pack the cell averages (TVB, before the limiter);
-// 2: unpack received averages (TVB), then limit and pack the DoFs
-int dflo_hip_stage_rim_send(dflo_hip_handle h, void *comm_stream, int what, const void *avg_recv, void *send_buffer) {
-  if (check_handle(h) || !comm_stream) return DFLO_ERR_BAD_PARAM;
-  hipSetDevice(h->device);
-  hipStream_t main = h->stream;
-  h->stream = (hipStream_t)comm_stream;
-  int rc = DFLO_OK;
-  if (what != 2) HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_rim, 0));
-  if (what == 1) {
-    rc = dflo_hip_pack_send_avg(h, send_buffer);
-  } else {
-    if (what == 2) rc = dflo_hip_unpack_ghost_avg(h, avg_recv);
-    if (!rc) rc = launch_stage_limiter(h, 1);
-    if (!rc) rc = dflo_hip_pack_send(h, send_buffer);
-  }
-  h->stream = main;
-  return rc;
-}
-
-int dflo_hip_stage_rim_recv(dflo_hip_handle h, void *comm_stream, const void *recv_buffer) {
-  if (check_handle(h) || !comm_stream) return DFLO_ERR_BAD_PARAM;
-  hipSetDevice(h->device);
-  hipStream_t main = h->stream;
-  h->stream = (hipStream_t)comm_stream;
-  int rc = dflo_hip_unpack_ghost(h, recv_buffer);
-  if (!rc) {
-    if (hipEventRecord(h->ev_unpack, h->stream) != hipSuccess) rc = DFLO_ERR_HIP;
-    h->unpack_pending = true;
-  }
-  h->stream = main;
-  return rc;
-}
-
-int dflo_hip_stage_interior(dflo_hip_handle h) {
-  if (check_handle(h)) return DFLO_ERR_BAD_PARAM;
-  hipSetDevice(h->device);
-  int rc = launch_update(h, nullptr, 2);
-  if (!rc) rc = launch_stage_limiter(h, 2);
-  if (!rc) rc = launch_finish(h);
-  return rc;
-}
-
-// main stream waits for the last unpack (before the state is read or a non-overlapped call follows)
-int dflo_hip_stage_join(dflo_hip_handle h) {
-  if (check_handle(h)) return DFLO_ERR_BAD_PARAM;
-  hipSetDevice(h->device);
-  if (h->unpack_pending) {
-    HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_unpack, 0));
-    h->unpack_pending = false;
-  }
-  return DFLO_OK;
-}
 
 int dflo_hip_stage_limit(dflo_hip_handle h) {
   if (check_handle(h)) return DFLO_ERR_BAD_PARAM;

@@ -247,11 +247,12 @@ int dflo_hip_stage_timing(dflo_hip_handle h, int enable, double *avg_ms, int64_t
  * dflo_hip_stage == dflo_hip_stage_update + dflo_hip_stage_limit. */
 int dflo_hip_stage_update(dflo_hip_handle h, int rk, double dt);
 int dflo_hip_stage_limit(dflo_hip_handle h);
-/* The same stage split by shard set, for overlapping the exchange with compute: part 1 = rim shards
- * (those that read ghost cells), part 2 = interior shards, part 0 = all; for the update of a stage that a TVB limiter
- * follows also part 3 = rim shards + the ring of shards next to them (the limiter of a rim cell reads the new averages
- * of its neighbours there) and part 4 = the others.  Launches of different parts of one stage may run side by side
- * on different streams (they read the previous stage and write disjoint shards).
+/* The same stage split by shard set, for overlapping the exchange with compute (what dflo_amd/csrc/multi.hip is written
+ * against): part 1 = rim shards (those that read ghost cells), part 2 = interior shards, part 0 = all; for the update of a
+ * stage that a TVB limiter follows also part 3 = rim shards + the ring of shards next to them (the limiter of a rim cell
+ * reads the new averages of its neighbours there) and part 4 = the others.  dflo_hip_set_stream chooses the stream of
+ * the following launches; launches of different parts of one stage may run side by side on different streams (they read
+ * the previous stage and write disjoint shards); ordering between the streams is the caller's (events).
  *   open -> update_part(1) -> [limit_part(1) -> pack -> exchange -> unpack on a second stream]
  *        -> update_part(2) -> limit_part(2) -> finish (reductions, CFL minimum)                    */
 int dflo_hip_stage_open(dflo_hip_handle h, int rk, double dt);
@@ -259,20 +260,6 @@ int dflo_hip_stage_update_part(dflo_hip_handle h, int part);
 int dflo_hip_stage_limit_part(dflo_hip_handle h, int part);
 int dflo_hip_stage_finish(dflo_hip_handle h);
 int dflo_hip_n_rim_shards(dflo_hip_handle h);
-/* The overlapped stage folded into four host calls (streams are hipStream_t passed as void*; events
- * between the two streams are the engine's):
- *   stage_rim(main)            wait for the previous unpack, open the stage, advance the rim shards
- *   stage_rim_send(comm, what) what=0: limit the rim shards, pack their DoFs into send_buffer
- *                              what=1: pack their cell averages (TVB: the limiter needs the neighbours' means)
- *                              what=2: unpack the received averages, limit, pack the DoFs
- *   stage_rim_recv(comm)       unpack the received ghost DoFs
- *   stage_interior()           main: interior shards, limiter, reductions
- *   stage_join()               main waits for the last unpack */
-int dflo_hip_stage_rim(dflo_hip_handle h, int rk, double dt, void *main_stream);
-int dflo_hip_stage_rim_send(dflo_hip_handle h, void *comm_stream, int what, const void *avg_recv, void *send_buffer);
-int dflo_hip_stage_rim_recv(dflo_hip_handle h, void *comm_stream, const void *recv_buffer);
-int dflo_hip_stage_interior(dflo_hip_handle h);
-int dflo_hip_stage_join(dflo_hip_handle h);
 int dflo_hip_n_ghost_cells(dflo_hip_handle h);
 int dflo_hip_set_send_cells(dflo_hip_handle h, int32_t n, const int32_t *cells);
 int dflo_hip_pack_send(dflo_hip_handle h, void *device_buffer);
