@@ -117,6 +117,10 @@ inline BasisTables make_basis(int degree) {
 // materialises them with SALU moves instead of re-loading kernel arguments through the scalar cache
 // (each such reload is an s_waitcnt lgkmcnt stall in the hot loops).
 template <int N> struct GaussLit;
+template <> struct GaussLit<1> {   // degree 0: one midpoint node, the finite-volume limit (src/claw.cc:141-145: one RK stage)
+  static constexpr double x[1] = {0.5};
+  static constexpr double w[1] = {1.0};
+};
 template <> struct GaussLit<2> {
   static constexpr double x[2] = {0.2113248654051871177454, 0.7886751345948128822545};
   static constexpr double w[2] = {0.5, 0.5};

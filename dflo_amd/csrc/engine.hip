@@ -162,6 +162,7 @@ KBasis make_kbasis(const BasisTables &b) {
 
 stage_fn pick_pk(int N, int flux, int mode) {
   switch (N) {
+    case 1: return dflo::stage_pk_of_1(flux, mode);
     case 2: return dflo::stage_pk_of_2(flux, mode);
     case 3: return dflo::stage_pk_of_3(flux, mode);
     default: return dflo::stage_pk_of_4(flux, mode);
@@ -169,6 +170,7 @@ stage_fn pick_pk(int N, int flux, int mode) {
 }
 stage_fn pick_stage(int N, int flux, int mode, int geo, int pos = 0, int nt = 0) {
   switch (N) {
+    case 1: return dflo::stage_of_1(flux, mode, geo, pos, nt);
     case 2: return dflo::stage_of_2(flux, mode, geo, pos, nt);
     case 3: return dflo::stage_of_3(flux, mode, geo, pos, nt);
     default: return dflo::stage_of_4(flux, mode, geo, pos, nt);
@@ -522,7 +524,7 @@ int launch_stage(dflo_hip_engine *h, int rk, double dt_host, double *rhs_out, in
 
 void launch_dt_q(dflo_hip_engine *h) {
   const Plan &p = h->plan;
-  auto fn = h->N == 2 ? dt_q_kernel<2> : (h->N == 3 ? dt_q_kernel<3> : dt_q_kernel<4>);
+  auto fn = h->N == 1 ? dt_q_kernel<1> : (h->N == 2 ? dt_q_kernel<2> : (h->N == 3 ? dt_q_kernel<3> : dt_q_kernel<4>));
   hipLaunchKernelGGL(fn, dim3(p.n_shards), dim3(64), 0, h->stream, (const double *)h->U[h->cur], (const double *)h->d_cell_h,
                      (const int32_t *)h->d_shard_count, h->shard_dtmin, h->kb, h->prm.cfl, h->degree, h->d_dt_cell);
 }
@@ -577,7 +579,7 @@ int dflo_hip_create(const dflo_mesh_t *mesh, const dflo_params_t *params, int de
   if (!mesh || !params || !out) { g_create_error = "null argument"; return DFLO_ERR_BAD_PARAM; }
   *out = nullptr;
   // consistency checks of the reference's parameter parsing (src/parameters.cc:536-550)
-  if (mesh->degree < 1 || mesh->degree > DFLO_MAX_DEGREE) { g_create_error = "degree must be 1..3"; return DFLO_ERR_BAD_PARAM; }
+  if (mesh->degree < 0 || mesh->degree > DFLO_MAX_DEGREE) { g_create_error = "degree must be 0..3"; return DFLO_ERR_BAD_PARAM; }
   if (mesh->basis != DFLO_BASIS_QK && mesh->basis != DFLO_BASIS_PK) { g_create_error = "unknown basis"; return DFLO_ERR_BAD_PARAM; }
   if (mesh->basis == DFLO_BASIS_PK && mesh->mapping != DFLO_MAP_CARTESIAN) {
     g_create_error = "Pk basis is implemented for cartesian mapping only";
@@ -607,6 +609,13 @@ int dflo_hip_create(const dflo_mesh_t *mesh, const dflo_params_t *params, int de
   dflo_hip_engine *h = new dflo_hip_engine;
   h->device = device_id;
   h->prm = *params;
+  if (mesh->degree == 0) {
+    // piecewise constants: apply_limiter_TVB_* and apply_positivity_limiter return at once (src/limiter.cc:379,
+    // src/positivity.cc:19 -- before the "Negative states" check), and nothing reads the shock indicator
+    h->prm.limiter_type = DFLO_LIMITER_NONE;
+    h->prm.pos_lim = 0;
+    h->prm.shock_indicator = DFLO_IND_LIMITER;
+  }
   h->degree = mesh->degree;
   h->N = mesh->degree + 1;
   h->basis = mesh->basis;
@@ -633,8 +642,9 @@ int dflo_hip_create(const dflo_mesh_t *mesh, const dflo_params_t *params, int de
     }
   }
   // SSP-RK coefficients by degree (src/claw.cc:141-159)
-  h->n_rk = h->degree == 1 ? 2 : 3;
+  h->n_rk = h->degree == 0 ? 1 : (h->degree == 1 ? 2 : 3);
   if (params->n_rk > 0) h->n_rk = std::min(params->n_rk, 3);
+  if (h->n_rk == 1) h->ark[0] = 0.0;
   if (h->n_rk == 2) { h->ark[0] = 0.0; h->ark[1] = 0.5; }
   if (h->n_rk == 3) { h->ark[0] = 0.0; h->ark[1] = 0.75; h->ark[2] = 1.0 / 3.0; }
   auto bail = [&](int code) { g_create_error = h->err; dflo_hip_destroy(h); return code; };
@@ -663,8 +673,7 @@ int dflo_hip_create(const dflo_mesh_t *mesh, const dflo_params_t *params, int de
   {  // fixed-pitch copies of the per-shard lists (+2 shards of slack: the kernel reads two shards ahead,
      // and 2*64*N face slots per shard so that unconditional loads stay in bounds)
     const int ns = p.n_shards + 2;
-    h->face_pitch = 2 * 64 * h->N;
-    if (p.max_faces > h->face_pitch) { h->err = "more than 2 faces per thread in a shard"; return bail(DFLO_ERR_UNSUPPORTED); }
+    h->face_pitch = std::max(2 * 64 * h->N, (p.max_faces + 63) & ~63);   // (a thread preloads two records; the rest is read in the loop)
     h->halo_pitch = std::max(p.max_halo, 1);
     std::vector<int4> hdr(ns, int4{0, 0, 0, 0});
     std::vector<int32_t> hp((size_t)ns * h->halo_pitch, 0);

@@ -59,7 +59,7 @@ void dflo_mesh_free(dflo_mesh_t *mesh) {
 int dflo_mesh_cartesian(int32_t nx, int32_t ny, double x0, double y0, double h, const int32_t side_bc[4],
                         int32_t degree, dflo_mesh_t **out) {
   if (!out || nx < 1 || ny < 1 || !(h > 0) || !side_bc) return fail(DFLO_ERR_BAD_PARAM, "dflo_mesh_cartesian: bad arguments");
-  if (degree < 1 || degree > DFLO_MAX_DEGREE) return fail(DFLO_ERR_BAD_PARAM, "degree out of range");
+  if (degree < 0 || degree > DFLO_MAX_DEGREE) return fail(DFLO_ERR_BAD_PARAM, "degree out of range");
   if ((side_bc[0] < 0) != (side_bc[1] < 0) || (side_bc[2] < 0) != (side_bc[3] < 0))
     return fail(DFLO_ERR_BAD_PARAM, "periodic sides must come in opposite pairs");
   for (int s = 0; s < 4; ++s)
@@ -105,7 +105,7 @@ int dflo_mesh_from_quads(int32_t n_vertices, const double *vertices, int32_t n_q
                          int32_t n_bedges, const int32_t *bedges, const int32_t *bedge_id, int32_t degree,
                          dflo_mesh_t **out) {
   if (!out || !vertices || !quads || n_quads < 1) return fail(DFLO_ERR_BAD_PARAM, "dflo_mesh_from_quads: bad arguments");
-  if (degree < 1 || degree > DFLO_MAX_DEGREE) return fail(DFLO_ERR_BAD_PARAM, "degree out of range");
+  if (degree < 0 || degree > DFLO_MAX_DEGREE) return fail(DFLO_ERR_BAD_PARAM, "degree out of range");
   MeshOwner *o = new MeshOwner;
   o->vert.resize((size_t)n_quads * 8);
   o->nbr.assign((size_t)n_quads * 4, DFLO_NBR_NONE);

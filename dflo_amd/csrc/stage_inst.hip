@@ -4,7 +4,7 @@
 #include "stage_kernels.hpp"
 
 #ifndef DFLO_STAGE_N
-#error "compile with -DDFLO_STAGE_N=2, 3 or 4"
+#error "compile with -DDFLO_STAGE_N=1, 2, 3 or 4"
 #endif
 #define DFLO_CAT_(a, b) a##b
 #define DFLO_CAT(a, b) DFLO_CAT_(a, b)

@@ -603,6 +603,7 @@ __global__ __launch_bounds__(64 * N, ((GEO == 1 && N != 3) || N == 4) ? 2 : 3) v
     for (int j = 0; j < 3; ++j) {
       if (tid < nf) Fg[j * a.max_faces + tid] = fg[j][0];
       if (tid + NT < nf) Fg[j * a.max_faces + tid + NT] = fg[j][1];
+      for (int i = tid + 2 * NT; i < nf; i += NT) Fg[j * a.max_faces + i] = a.fgeom_pad[((size_t)shard * 3 + j) * a.face_pitch + i];
     }
   }
   if (nbnd > 0) {  // boundary values and kinds of this shard's boundary faces
@@ -1217,9 +1218,11 @@ stage_fn pick_pk_n(int flux, int mode) {
     default: return pick_pk_m<N, DFLO_FLUX_HLLC>(mode);
   }
 }
+stage_fn stage_of_1(int flux, int mode, int geo, int pos, int nt);
 stage_fn stage_of_2(int flux, int mode, int geo, int pos, int nt);
 stage_fn stage_of_3(int flux, int mode, int geo, int pos, int nt);
 stage_fn stage_of_4(int flux, int mode, int geo, int pos, int nt);
+stage_fn stage_pk_of_1(int flux, int mode);
 stage_fn stage_pk_of_2(int flux, int mode);
 stage_fn stage_pk_of_3(int flux, int mode);
 stage_fn stage_pk_of_4(int flux, int mode);

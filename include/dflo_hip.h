@@ -78,7 +78,8 @@ typedef enum { DFLO_MAP_Q1 = 0, DFLO_MAP_Q2 = 1, DFLO_MAP_CARTESIAN = 2 } dflo_m
 typedef struct dflo_mesh {
   int32_t n_cells;        /* owned + ghost cells; owned cells come first */
   int32_t n_owned_cells;  /* == n_cells on a single device */
-  int32_t degree;         /* k, 1..DFLO_MAX_DEGREE */
+  int32_t degree;         /* k, 0..DFLO_MAX_DEGREE (0: piecewise constants, one RK stage, the limiters return at once,
+                             src/claw.cc:141-145, src/positivity.cc:19, src/limiter.cc:379) */
   int32_t basis;          /* dflo_basis */
   int32_t mapping;        /* dflo_mapping (q2 unsupported) */
   const double *cell_vertices;            /* [n_cells][4][2] */

@@ -1204,3 +1204,84 @@ def test_double_mach_c4_positivity_alone_fails_like_the_reference_algorithm():
                               boundary={0: "outflow", 1: "slip", 2: "outflow", 3: "inflow", 4: "inflow"})
     fd, fo, claw, ora = _fails_alike(mesh, prm, lambda x, y: problems.double_mach(x, y), 40)
     assert fd == fo and fd[0] is not None and fd[1] == -3
+
+
+@pytest.mark.parametrize("flux", FLUXES)
+def test_degree_zero_is_the_one_stage_finite_volume_scheme(flux):
+    """degree = 0 (the reference takes any degree; src/claw.cc:141-145: one RK stage, the limiters return at once): piecewise
+    constants, the volume term vanishes, a stage is u - dt/|K| sum of face fluxes.  Squares (Qk and Pk are the same space),
+    periodic and with every boundary kind, against the oracle; with TVB + positivity switched on nothing changes."""
+    mesh, prm, claw, ora = make_pair(20, 12, 0, flux, h=0.5)
+    assert claw.n_rk == 1 and mesh.ndof == 4
+    u0 = mesh.interpolate(problems.smooth_perturbation)
+    claw.set_initial_condition(u0)
+    ora.set_solution(u0)
+    assert rel(claw.assemble_system(), ora.assemble()) < 1e-13
+    t = 0.0
+    for it in range(8):
+        dt = claw.compute_time_step()
+        assert abs(dt - ora.compute_time_step(t)) <= 1e-13 * dt
+        r0, r1 = claw.iterate_explicit(dt)
+        q0, q1 = ora.step(dt)
+        assert abs(r0 - q0) <= 1e-11 * q0 and r0 == r1
+        t += dt
+    assert rel(claw.current_solution, ora.get_solution()) < 1e-12
+    t_dev = claw.advance(5)
+    for it in range(5):
+        dt = ora.compute_time_step(t)
+        ora.step(dt)
+        t += dt
+    assert abs(t_dev - t) < 1e-13 and rel(claw.current_solution, ora.get_solution()) < 1e-12
+    # boundaries of every kind, limiters requested (no-ops at degree 0), Pk basis
+    bnd = {0: "slip", 1: "outflow", 2: "inflow", 3: "farfield", 4: "pressure"}
+    for basis in ("Qk", "Pk"):
+        mesh = dflo_amd.Mesh.cartesian(16, 8, 0.0, 0.0, 1.0 / 16, [2, 1, 0, 3], 0)
+        mesh.set_basis(basis)
+        prm = dflo_amd.Parameters(flux=flux, limiter="TVB", pos_lim=True, cfl=0.6, boundary=bnd)
+        claw, ora = dflo_amd.ConservationLaw(mesh, prm), oracle_lib.Oracle(mesh, prm)
+        cell, face, bid, xy = claw.boundary_faces()
+        bv = np.stack(problems.sod(xy[..., 0], xy[..., 1]), axis=-1)
+        for o in (claw, ora):
+            o.set_boundary_values(0, bv)
+            o.set_boundary_values(1, bv)
+        u0 = mesh.interpolate(problems.sod)
+        claw.set_initial_condition(u0)
+        ora.set_solution(u0)
+        claw.apply_limiter()
+        ora.apply_limiter()
+        t = 0.0
+        for it in range(6):
+            dt = claw.compute_time_step()
+            claw.iterate_explicit(dt)
+            ora.step(dt)
+        assert rel(claw.current_solution, ora.get_solution()) < 1e-12
+
+
+def test_degree_zero_on_bilinear_cells_and_several_engines():
+    from dflo_amd import gmsh
+    verts, quads, bed, bid = gmsh.unstructured_quads(9, seed=4)
+    mesh = dflo_amd.Mesh.from_quads(verts, quads, bed, bid, 0)
+    prm = dflo_amd.Parameters(flux="roe", cfl=0.5, boundary={0: "slip", 1: "outflow", 2: "slip", 3: "farfield"})
+    ic = lambda x, y: problems.smooth_perturbation(x, y, L=1.0)
+    claw, ora = dflo_amd.ConservationLaw(mesh, prm), oracle_lib.Oracle(mesh, prm)
+    multi = dflo_amd.MultiConservationLaw(mesh, prm, devices=[0, 0, 0], partitioner="rcb")
+    cell, face, b, xy = claw.boundary_faces()
+    bv = np.stack(ic(xy[..., 0], xy[..., 1]), axis=-1)
+    for o in (claw, ora, multi):
+        o.set_boundary_values(0, bv)
+        o.set_boundary_values(1, bv)
+    u0 = mesh.interpolate(ic)
+    claw.set_initial_condition(u0)
+    multi.set_initial_condition(u0)
+    ora.set_solution(u0)
+    assert rel(claw.assemble_system(), ora.assemble()) < 1e-12
+    t = 0.0
+    for it in range(6):
+        dt = claw.compute_time_step()
+        assert abs(dt - ora.compute_time_step(t)) <= 1e-12 * dt and multi.compute_time_step() == dt
+        claw.iterate_explicit(dt)
+        multi.iterate_explicit(dt)
+        ora.step(dt)
+        t += dt
+    assert rel(claw.current_solution, ora.get_solution()) < 1e-11
+    assert np.array_equal(claw.current_solution, multi.current_solution)
