@@ -24,7 +24,7 @@ last = {}
 
 
 def one(i):
-    degree = int(rng.integers(1, 4))
+    degree = int(rng.integers(0, 4))
     flux = str(rng.choice(["lxf", "sw", "kfvs", "roe", "hllc"]))
     geo = str(rng.choice(["cart", "cart", "skew", "unstr"]))
     basis = "Pk" if (geo == "cart" and rng.random() < 0.2) else "Qk"
