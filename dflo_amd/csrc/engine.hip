@@ -81,6 +81,13 @@ struct dflo_hip_engine {
   double pending_dt = -1.0;
   int32_t *d_send_slots = nullptr;
   int n_send = 0;
+  // ghost cells known by their face traces (Qk without the KXRCF indicator): two buffers, the stage kernels read Tg[tg_cur]
+  // while the neighbours' next traces arrive in the other one
+  bool trace_halo = false;
+  double *Tg[2] = {nullptr, nullptr};
+  int tg_cur = 0, n_gt = 0;
+  int32_t *d_gt_slot = nullptr, *d_gt_face = nullptr, *d_sendf_slot = nullptr, *d_sendf_face = nullptr;
+  int n_send_faces = 0;
   double *ghost_stage = nullptr;
   size_t lds_bytes = 0;
   int stage_grid = 8, prefetch_ahead = 1 << 30;
@@ -187,6 +194,7 @@ int grid_for(int n_shards) { return ((n_shards + 7) / 8) * 8; }
 void part_list(const dflo_hip_engine *h, int part, const int32_t **list, int *n);
 
 void launch_dt_q(dflo_hip_engine *h);
+int launch_face_traces(dflo_hip_engine *h, double *out, const int32_t *slots, const int32_t *faces, int n);
 
 void time_begin(dflo_hip_engine *h) {
   if (!h->t_sample) return;
@@ -368,6 +376,8 @@ int launch_update(dflo_hip_engine *h, double *rhs_out, int part) {
   const int mode_ = rhs_out ? 2 : (h->ark[rk] != 0.0 ? 1 : 0);
   a.flags = h->flags;
   a.step_index = (int)h->steps_done;
+  a.Tg = h->Tg[h->tg_cur];
+  a.gt_slot = h->d_gt_slot;
   a.pos_stats = h->pos_stats;
   a.lim_mask = h->lim_mask;
   a.tvb_M = h->prm.limiter_type == DFLO_LIMITER_TVB ? h->prm.M : -1.0;
@@ -538,6 +548,15 @@ int launch_average(dflo_hip_engine *h) {
   return DFLO_OK;
 }
 
+int launch_face_traces(dflo_hip_engine *h, double *out, const int32_t *slots, const int32_t *faces, int n) {
+  if (n == 0) return DFLO_OK;
+  const long long tot = (long long)n * 4 * h->N;
+  auto fn = h->N == 1 ? face_trace_kernel<1> : (h->N == 2 ? face_trace_kernel<2> : (h->N == 3 ? face_trace_kernel<3> : face_trace_kernel<4>));
+  hipLaunchKernelGGL(fn, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, out, (const double *)h->U[h->cur], slots, faces, n);
+  HIPCHK(h, hipGetLastError());
+  return DFLO_OK;
+}
+
 void drop_graph(dflo_hip_engine *h) {
   if (h->graph_exec) hipGraphExecDestroy(h->graph_exec);
   h->graph_exec = nullptr;
@@ -628,6 +647,12 @@ int dflo_hip_create(const dflo_mesh_t *mesh, const dflo_params_t *params, int de
   if (rc) { g_create_error = h->err; delete h; return rc; }
   h->bt = make_basis(h->degree);
   h->kb = make_kbasis(h->bt);
+  {  // multi-device: ghost cells as face traces (N*4 doubles per cut face) when nothing needs more of them -- the stage
+     // kernels read only their traces and averages; the KXRCF indicator and the Pk element read their DoFs
+    const char *e2 = std::getenv("DFLO_HALO_CELLS");
+    h->n_gt = (int)h->plan.gt_cell.size();
+    h->trace_halo = h->n_gt > 0 && h->basis == DFLO_BASIS_QK && h->prm.shock_indicator == DFLO_IND_LIMITER && !(e2 && e2[0] == '1');
+  }
   // quadrature points of the boundary faces (fe_v.get_quadrature_points(), src/assemble_explicit.cc:164)
   h->bface_xy.resize(h->plan.bface_cell.size() * h->N * 2);
   for (size_t b = 0; b < h->plan.bface_cell.size(); ++b) {
@@ -683,8 +708,11 @@ int dflo_hip_create(const dflo_mesh_t *mesh, const dflo_params_t *params, int de
     for (int sidx = 0; sidx < p.n_shards; ++sidx) {
       const int nh = p.halo_begin[sidx + 1] - p.halo_begin[sidx], nf = p.face_begin[sidx + 1] - p.face_begin[sidx];
       hdr[sidx] = int4{p.shard_count[sidx], nf, nh, p.shard_bnd[sidx]};
-      for (int k = 0; k < nh; ++k)
-        hp[(size_t)sidx * h->halo_pitch + k] = p.halo_cells[p.halo_begin[sidx] + k] | (p.halo_faces[p.halo_begin[sidx] + k] << 28);
+      for (int k = 0; k < nh; ++k) {
+        const int he = p.halo_begin[sidx] + k;
+        const int who = (h->trace_halo && p.halo_gt[he] >= 0) ? (p.halo_gt[he] | kGhostTrace) : p.halo_cells[he];
+        hp[(size_t)sidx * h->halo_pitch + k] = who | (p.halo_faces[he] << 28);
+      }
       for (int k = 0; k < nf; ++k) {
         const FaceRec &r = p.faces[p.face_begin[sidx] + k];
         fpad[(size_t)sidx * h->face_pitch + k] = pface_pack(r);
@@ -709,6 +737,13 @@ int dflo_hip_create(const dflo_mesh_t *mesh, const dflo_params_t *params, int de
             gpad[((size_t)sidx * 3 + j2) * h->face_pitch + k] = p.face_geom[((size_t)p.face_begin[sidx] + k) * 3 + j2];
       }
       if ((rc = upload(h, &h->d_fgeom_pad, gpad))) return bail(rc);
+    }
+  }
+  if (h->trace_halo) {
+    if ((rc = upload(h, &h->d_gt_slot, p.gt_cell)) || (rc = upload(h, &h->d_gt_face, p.gt_face))) return bail(rc);
+    for (int i = 0; i < 2; ++i) {
+      if (hipMalloc((void **)&h->Tg[i], (size_t)h->n_gt * 4 * h->N * sizeof(double)) != hipSuccess) { h->err = "hipMalloc(ghost traces) failed"; return bail(DFLO_ERR_NOMEM); }
+      hipMemset(h->Tg[i], 0, (size_t)h->n_gt * 4 * h->N * sizeof(double));
     }
   }
   if ((rc = upload(h, &h->d_lrbt, p.lrbt))) return bail(rc);
@@ -820,7 +855,8 @@ int dflo_hip_destroy(dflo_hip_handle h) {
   hipFree(h->d_rim_list); hipFree(h->d_int_list); hipFree(h->d_rim2_list); hipFree(h->d_rest2_list);
   hipFree(h->d_cell_h); hipFree(h->d_dt_cell); hipFree(h->d_cell_vert); hipFree(h->d_fgeom_pad); hipFree(h->shard_res); hipFree(h->shard_dtmin); hipFree(h->res_sq); hipFree(h->fin_partial); hipFree(h->dt_dev);
   if (h->flags_host) hipHostFree((void *)h->flags_host);
-  hipFree(h->fin_counter); hipFree(h->dt_pub); hipFree(h->pos_stats); hipFree(h->d_send_slots); hipFree(h->ghost_stage);
+  hipFree(h->fin_counter); hipFree(h->dt_pub); hipFree(h->pos_stats);
+  hipFree(h->Tg[0]); hipFree(h->Tg[1]); hipFree(h->d_gt_slot); hipFree(h->d_gt_face); hipFree(h->d_sendf_slot); hipFree(h->d_sendf_face); hipFree(h->d_send_slots); hipFree(h->ghost_stage);
   for (int i = 0; i < 2; ++i) if (h->ev_chunk[i]) hipEventDestroy(h->ev_chunk[i]);
   for (auto &e : h->ev_pool) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
   if (h->own_stream) hipStreamDestroy(h->own_stream);
@@ -854,6 +890,11 @@ int dflo_hip_set_solution(dflo_hip_handle h, const double *u) {
   HIPCHK(h, hipGetLastError());
   int rc = launch_average(h);
   if (rc) return rc;
+  if (h->trace_halo) {   // the ghost cells' traces from the ghost cells' DoFs of the initial state, into both buffers
+    for (int i = 0; i < 2; ++i)
+      if ((rc = launch_face_traces(h, h->Tg[i], h->d_gt_slot, h->d_gt_face, h->n_gt))) return rc;
+    h->tg_cur = 0;
+  }
   HIPCHK(h, hipStreamSynchronize(h->stream));
   return DFLO_OK;
 }
@@ -1309,6 +1350,44 @@ int dflo_hip_unpack_ghost_cells(dflo_hip_handle h, const void *device_buffer) {
   hipLaunchKernelGGL(unpack_cells_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, (const double *)device_buffer,
                      h->U[h->cur], h->avg[h->avg_cur], p.n_shards * 64, n_ghost, h->ndof);
   HIPCHK(h, hipGetLastError());
+  if (h->trace_halo) return launch_face_traces(h, h->Tg[h->tg_cur], h->d_gt_slot, h->d_gt_face, h->n_gt);
+  return DFLO_OK;
+}
+
+int dflo_hip_halo_traces(dflo_hip_handle h) { return (h && h->trace_halo) ? 1 : 0; }
+int dflo_hip_n_ghost_traces(dflo_hip_handle h) { return h ? h->n_gt : 0; }
+
+int dflo_hip_set_send_faces(dflo_hip_handle h, int32_t n, const int32_t *cells, const int32_t *faces) {
+  if (check_handle(h) || n < 0 || (n > 0 && (!cells || !faces))) return DFLO_ERR_BAD_PARAM;
+  hipSetDevice(h->device);
+  std::vector<int32_t> slots(n), ff(n);
+  for (int i = 0; i < n; ++i) {
+    if (cells[i] < 0 || cells[i] >= h->plan.n_owned || faces[i] < 0 || faces[i] > 3) { h->err = "send face is not a face of an owned cell"; return DFLO_ERR_COMM; }
+    slots[i] = h->plan.iid[cells[i]];
+    ff[i] = faces[i];
+  }
+  hipFree(h->d_sendf_slot); hipFree(h->d_sendf_face);
+  h->d_sendf_slot = h->d_sendf_face = nullptr;
+  h->n_send_faces = n;
+  int rc = upload(h, &h->d_sendf_slot, slots);
+  return rc ? rc : upload(h, &h->d_sendf_face, ff);
+}
+
+int dflo_hip_pack_send_traces(dflo_hip_handle h, void *device_buffer) {
+  if (check_handle(h) || !device_buffer) return DFLO_ERR_BAD_PARAM;
+  hipSetDevice(h->device);
+  return launch_face_traces(h, (double *)device_buffer, h->d_sendf_slot, h->d_sendf_face, h->n_send_faces);
+}
+
+int dflo_hip_ghost_trace_buffer(dflo_hip_handle h, int which, void **ptr) {
+  if (check_handle(h) || which < 0 || which > 1 || !ptr) return DFLO_ERR_BAD_PARAM;
+  *ptr = h->Tg[which];
+  return DFLO_OK;
+}
+
+int dflo_hip_use_ghost_traces(dflo_hip_handle h, int which) {
+  if (check_handle(h) || which < 0 || which > 1) return DFLO_ERR_BAD_PARAM;
+  h->tg_cur = which;
   return DFLO_OK;
 }
 
@@ -1325,6 +1404,8 @@ int dflo_hip_unpack_ghost(dflo_hip_handle h, const void *device_buffer) {
                      h->U[h->cur], h->avg[h->avg_cur], p.n_shards * 64, n_ghost, h->ndof, h->kb,
                      h->basis == DFLO_BASIS_PK ? -h->N : h->N, (const double *)h->d_cell_vert, p.n_slots);
   HIPCHK(h, hipGetLastError());
+  // whole cells handed to an engine that reads ghost cells by their traces: bring the current trace table up to date
+  if (h->trace_halo) return launch_face_traces(h, h->Tg[h->tg_cur], h->d_gt_slot, h->d_gt_face, h->n_gt);
   return DFLO_OK;
 }
 

@@ -72,6 +72,8 @@ struct StageArgs {
   int n_list;
   int *flags;   // POS 1: [0] negative mean state, [1] positivity root failure (as LimArgs::flags)
   int step_index; // time step this launch belongs to (host count since set_solution), recorded with a raised flag
+  const double *Tg;        // multi-device: traces of the ghost cells on the cut faces, [n_ghost_traces][4][N], of the state being read
+  const int32_t *gt_slot;  // internal slot of the ghost cell of a trace (its cell average: LxF)
   unsigned long long *pos_stats;  // POS 1: [0] cells that failed the nodal-box bound (limiter proper), [1] cells it changed
   unsigned long long *lim_mask;   // POS 2: [n_shards] bit = the limiter pass may have something to do in that cell
   double tvb_M;                   // POS 2: TVB constant M, < 0: the limiter pass has no TVB part
@@ -93,6 +95,29 @@ template <int NT>
 __device__ __forceinline__ void stream_store(double *p, double v) {
   if constexpr (NT) __builtin_nontemporal_store(v, p);
   else *p = v;
+}
+
+// Trace of a Qk function on a face from the N nodal values on the line through the face point, ordered from the face inwards
+// (l_m(1) = l_(N-1-m)(0): the faces at 1 walk their line backwards and use the weights l_m(0) as well).  One function for the
+// stage kernel's halo gather and for the kernels that pack / initialise ghost traces: the same bits everywhere.
+template <int N>
+__device__ __forceinline__ double trace_from_line(const double (&val)[N]) {
+  double v = 0.0;
+#pragma unroll
+  for (int m = 0; m < N; ++m) v += CB<N>::t.L0[m] * val[m];
+  return v;
+}
+// component c of the trace of cell `slot` on its local face f at face point q (Qk, shard layout U)
+template <int N>
+__device__ __forceinline__ double cell_face_trace(const double *U, int slot, int f, int c, int q) {
+  constexpr int NS = N * N, NDOF = 4 * NS;
+  const int str0 = f < 2 ? 1 : N, str = (f & 1) ? -str0 : str0;
+  const int base = (f < 2 ? N * q : q) + ((f & 1) ? (N - 1) * str0 : 0);
+  const double *hp = U + ((size_t)(slot >> 6) * NDOF + c * NS) * 64 + (slot & 63);
+  double val[N];
+#pragma unroll
+  for (int m = 0; m < N; ++m) val[m] = hp[(base + m * str) * 64];
+  return trace_from_line<N>(val);
 }
 
 // compute_time_step_cartesian for one cell, src/claw.cc:495-509

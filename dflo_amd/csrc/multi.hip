@@ -113,6 +113,12 @@ struct Part {
   hipEvent_t ev_sent_u = nullptr, ev_sent_a = nullptr;
   double *send_u = nullptr, *send_a = nullptr;
   double *recv_u[2] = {nullptr, nullptr}, *recv_a[2] = {nullptr, nullptr};   // alternate from exchange to exchange
+  // face-trace records (dflo_hip_halo_traces): what goes to peer q are the traces of the faces sendf_off[q] .. of the send
+  // list, what comes from q lands in the engine's trace table at recvf_off[q] (no staging buffer, no unpack)
+  bool trace = false;
+  std::vector<int32_t> sendf_off, recvf_off;
+  double *send_t = nullptr;
+  void *tg[2] = {nullptr, nullptr};
   void *dt_slot[2] = {nullptr, nullptr};   // the engine's published CFL minima
   void *dt_ptr = nullptr, *res_ptr = nullptr;
   bool unpack_pending = false;   // the comm stream has work the compute stream has not waited for
@@ -136,7 +142,8 @@ struct dflo_hip_multi {
   int degree = 1, basis = 0, ndof = 16, N = 2, n_rk = 2;
   int64_t n_cells_global = 0;
   bool tvb = false, kxrcf = false, limited = false, sep_limiter = false;
-  int xparity = 0;             // which receive buffers the next exchange of DoFs / of averages fills
+  int xparity = 1;             // which receive buffers the next exchange of DoFs / of averages fills (for face traces: never
+                               // the table the engines read at that moment -- they start with table 0)
   int aparity = 0;
   int step_parity = 0;         // which published slot the next last stage fills
   double *scal = nullptr;      // rank mode: device scratch for small all-reduces (on parts[0].device)
@@ -179,22 +186,37 @@ Part *local_part(dflo_hip_multi *m, int index) {
   return nullptr;
 }
 
-// ---- transport.  post: the cells (width doubles each) packed in `send` leave for the peers; arrive: the comm stream
-// waits until the peers' cells are in this part's receive buffer `par`.
-int post(dflo_hip_multi *m, Part &p, const double *send, int width, bool averages, int par) {
+// ---- transport.  Three kinds of record travel: whole cells (DoFs + average), cell averages, face traces.  post: the
+// records packed in `send` leave for the peers; arrive: the comm stream waits until the peers' records are in this part's
+// receive area `par`.
+enum Chan { CH_CELLS = 0, CH_AVG = 1, CH_TRACES = 2 };
+struct ChanView {
+  const int32_t *so, *ro;   // per-peer offsets of what this part sends / receives, in records
+  int width;                // doubles per record
+  double *recv;             // where this part receives (area `par`)
+  hipEvent_t sent;          // local mode: this part's copies of this kind are enqueued
+};
+ChanView chan(dflo_hip_multi *m, Part &p, int kind, int par) {
+  if (kind == CH_AVG) return {p.send_off, p.recv_off, 4, p.recv_a[par], p.ev_sent_a};
+  if (kind == CH_TRACES) return {p.sendf_off.data(), p.recvf_off.data(), 4 * m->N, (double *)p.tg[par], p.ev_sent_u};
+  return {p.send_off, p.recv_off, m->ndof + 4, p.recv_u[par], p.ev_sent_u};
+}
+
+int post(dflo_hip_multi *m, Part &p, const double *send, int kind, int par) {
   if (p.peers.empty()) return DFLO_OK;
+  const ChanView v = chan(m, p, kind, par);
+  const size_t w = (size_t)v.width;
   if (m->rank_mode && m->x_exchange) {
-    double *recv = averages ? p.recv_a[par] : p.recv_u[par];
     std::vector<int> peers;
     std::vector<const void *> sp;
     std::vector<void *> rp;
     std::vector<size_t> sb, rb;
     for (int q : p.peers) {
       peers.push_back(q);
-      sp.push_back(send + (size_t)p.send_off[q] * width);
-      sb.push_back((size_t)(p.send_off[q + 1] - p.send_off[q]) * width * sizeof(double));
-      rp.push_back(recv + (size_t)p.recv_off[q] * width);
-      rb.push_back((size_t)(p.recv_off[q + 1] - p.recv_off[q]) * width * sizeof(double));
+      sp.push_back(send + (size_t)v.so[q] * w);
+      sb.push_back((size_t)(v.so[q + 1] - v.so[q]) * w * sizeof(double));
+      rp.push_back(v.recv + (size_t)v.ro[q] * w);
+      rb.push_back((size_t)(v.ro[q + 1] - v.ro[q]) * w * sizeof(double));
     }
     if (m->x_exchange(m->x_user, (int)peers.size(), peers.data(), sp.data(), sb.data(), rp.data(), rb.data(), (void *)p.C)) {
       m->err = "the host program's exchange callback failed";
@@ -203,22 +225,22 @@ int post(dflo_hip_multi *m, Part &p, const double *send, int width, bool average
     return DFLO_OK;
   }
   if (m->rank_mode) {
-    double *recv = averages ? p.recv_a[par] : p.recv_u[par];
     MNCCL(m, g_rccl.GroupStart());
     for (int q : p.peers) {
-      const size_t ns = (size_t)(p.send_off[q + 1] - p.send_off[q]) * width, nr = (size_t)(p.recv_off[q + 1] - p.recv_off[q]) * width;
-      if (ns) MNCCL(m, g_rccl.Send(send + (size_t)p.send_off[q] * width, ns, ncclDouble, q, m->comm, p.C));
-      if (nr) MNCCL(m, g_rccl.Recv(recv + (size_t)p.recv_off[q] * width, nr, ncclDouble, q, m->comm, p.C));
+      const size_t ns = (size_t)(v.so[q + 1] - v.so[q]) * w, nr = (size_t)(v.ro[q + 1] - v.ro[q]) * w;
+      if (ns) MNCCL(m, g_rccl.Send(send + (size_t)v.so[q] * w, ns, ncclDouble, q, m->comm, p.C));
+      if (nr) MNCCL(m, g_rccl.Recv(v.recv + (size_t)v.ro[q] * w, nr, ncclDouble, q, m->comm, p.C));
     }
     MNCCL(m, g_rccl.GroupEnd());
     return DFLO_OK;
   }
   for (int q : p.peers) {
     Part *dst = local_part(m, q);
-    const size_t n = (size_t)(p.send_off[q + 1] - p.send_off[q]) * width;
+    const ChanView dv = chan(m, *dst, kind, par);
+    const size_t n = (size_t)(v.so[q + 1] - v.so[q]) * w;
     if (!n) continue;
-    double *to = (averages ? dst->recv_a[par] : dst->recv_u[par]) + (size_t)dst->recv_off[p.index] * width;
-    const double *from = send + (size_t)p.send_off[q] * width;
+    double *to = dv.recv + (size_t)dv.ro[p.index] * w;
+    const double *from = send + (size_t)v.so[q] * w;
     if (m->loopback) {   // test transport: the same copy as a self send/recv pair through RCCL
       MNCCL(m, g_rccl.GroupStart());
       MNCCL(m, g_rccl.Send(from, n, ncclDouble, 0, m->comm, p.C));
@@ -228,43 +250,73 @@ int post(dflo_hip_multi *m, Part &p, const double *send, int width, bool average
       MHIP(m, hipMemcpyPeerAsync(to, dst->device, from, p.device, n * sizeof(double), p.C));
     }
   }
-  MHIP(m, hipEventRecord(averages ? p.ev_sent_a : p.ev_sent_u, p.C));
+  MHIP(m, hipEventRecord(v.sent, p.C));
   return DFLO_OK;
 }
 
-int arrive(dflo_hip_multi *m, Part &p, bool averages) {
+int arrive(dflo_hip_multi *m, Part &p, int kind) {
   if (m->rank_mode) return DFLO_OK;   // the receives were part of the group posted on this stream
   for (int q : p.peers) {
     Part *src = local_part(m, q);
-    if (src->send_off[p.index + 1] == src->send_off[p.index]) continue;
-    MHIP(m, hipStreamWaitEvent(p.C, averages ? src->ev_sent_a : src->ev_sent_u, 0));
+    const ChanView sv = chan(m, *src, kind, 0);
+    if (sv.so[p.index + 1] == sv.so[p.index]) continue;
+    MHIP(m, hipStreamWaitEvent(p.C, sv.sent, 0));
   }
+  return DFLO_OK;
+}
+
+// The new state of the cut cells leaves (engine launches go to the comm stream, set by the caller): whole cells, or face
+// traces (+ the averages unless they have travelled already, as they do when a TVB limiter sits between update and send)
+int send_state(dflo_hip_multi *m, Part &p, int upar, int apar, bool with_avg) {
+  if (!p.trace) {
+    MENG(m, p, dflo_hip_pack_send_cells(p.eng, p.send_u));
+    return post(m, p, p.send_u, CH_CELLS, upar);
+  }
+  MENG(m, p, dflo_hip_pack_send_traces(p.eng, p.send_t));
+  int rc = post(m, p, p.send_t, CH_TRACES, upar);
+  if (rc || !with_avg) return rc;
+  MENG(m, p, dflo_hip_pack_send_avg(p.eng, p.send_a));
+  return post(m, p, p.send_a, CH_AVG, apar);
+}
+// ... and the neighbours' arrives: into the ghost shards, or straight into the trace table the next stage will read
+int recv_state(dflo_hip_multi *m, Part &p, int upar, int apar, bool with_avg) {
+  if (!p.trace) {
+    int rc = arrive(m, p, CH_CELLS);
+    if (rc) return rc;
+    MENG(m, p, dflo_hip_unpack_ghost_cells(p.eng, p.recv_u[upar]));
+    return DFLO_OK;
+  }
+  int rc = arrive(m, p, CH_TRACES);
+  if (rc) return rc;
+  MENG(m, p, dflo_hip_use_ghost_traces(p.eng, upar));
+  if (!with_avg) return DFLO_OK;
+  if ((rc = arrive(m, p, CH_AVG))) return rc;
+  MENG(m, p, dflo_hip_unpack_ghost_avg(p.eng, p.recv_a[apar]));
   return DFLO_OK;
 }
 
 // update_ghost_values() outside the overlapped stage (after set-up calls, in the KXRCF path): all parts pack, send, unpack
 int exchange_solution(dflo_hip_multi *m) {
-  const int par = m->xparity;
+  const int par = m->xparity, apar = m->aparity;
   m->xparity ^= 1;
+  m->aparity ^= 1;
   for (Part &p : m->parts) {
     if (p.peers.empty()) continue;
     MHIP(m, hipSetDevice(p.device));
     MHIP(m, hipEventRecord(p.ev_open, p.M));
     MHIP(m, hipStreamWaitEvent(p.C, p.ev_open, 0));
     MENG(m, p, dflo_hip_set_stream(p.eng, p.C));
-    MENG(m, p, dflo_hip_pack_send_cells(p.eng, p.send_u));
-    int rc = post(m, p, p.send_u, m->ndof + 4, false, par);
+    int rc = send_state(m, p, par, apar, true);
     MENG(m, p, dflo_hip_set_stream(p.eng, p.M));
     if (rc) return rc;
   }
   for (Part &p : m->parts) {
     if (p.peers.empty()) continue;
     MHIP(m, hipSetDevice(p.device));
-    int rc = arrive(m, p, false);
-    if (rc) return rc;
     MENG(m, p, dflo_hip_set_stream(p.eng, p.C));
-    MENG(m, p, dflo_hip_unpack_ghost_cells(p.eng, p.recv_u[par]));
+    int rc = recv_state(m, p, par, apar, true);
     MENG(m, p, dflo_hip_set_stream(p.eng, p.M));
+    if (rc) return rc;
     MHIP(m, hipEventRecord(p.ev_unpack, p.C));
     MHIP(m, hipStreamWaitEvent(p.M, p.ev_unpack, 0));
   }
@@ -299,7 +351,7 @@ int run_stage(dflo_hip_multi *m, int rk, double dt) {
   }
   const int upar = m->xparity, apar = m->aparity;
   m->xparity ^= 1;
-  if (m->tvb) m->aparity ^= 1;
+  m->aparity ^= 1;
   const int rim_update = m->tvb ? 3 : 1, int_update = m->tvb ? 4 : 2;
   // open the stage (buffer roles; rk = 0: boundary programs on M), then the rim on C
   for (Part &p : m->parts) {
@@ -315,10 +367,9 @@ int run_stage(dflo_hip_multi *m, int rk, double dt) {
     } else {
       if (m->sep_limiter) MENG(m, p, dflo_hip_stage_limit_part(p.eng, 1));
       MHIP(m, hipEventRecord(p.ev_rim, p.C));
-      MENG(m, p, dflo_hip_pack_send_cells(p.eng, p.send_u));
     }
+    int rc = m->tvb ? post(m, p, p.send_a, CH_AVG, apar) : send_state(m, p, upar, apar, true);
     MENG(m, p, dflo_hip_set_stream(p.eng, p.M));
-    int rc = m->tvb ? post(m, p, p.send_a, 4, true, apar) : post(m, p, p.send_u, m->ndof + 4, false, upar);
     if (rc) return rc;
   }
   // the interior on M, next to it
@@ -331,15 +382,14 @@ int run_stage(dflo_hip_multi *m, int rk, double dt) {
     // the averages of the neighbours across the cut arrive: limit the rim, send its cells
     for (Part &p : m->parts) {
       MHIP(m, hipSetDevice(p.device));
-      int rc = arrive(m, p, true);
+      int rc = arrive(m, p, CH_AVG);
       if (rc) return rc;
       MENG(m, p, dflo_hip_set_stream(p.eng, p.C));
       MENG(m, p, dflo_hip_unpack_ghost_avg(p.eng, p.recv_a[apar]));
       MENG(m, p, dflo_hip_stage_limit_part(p.eng, 1));
       MHIP(m, hipEventRecord(p.ev_rim, p.C));
-      MENG(m, p, dflo_hip_pack_send_cells(p.eng, p.send_u));
+      rc = send_state(m, p, upar, apar, false);   // the averages have travelled already
       MENG(m, p, dflo_hip_set_stream(p.eng, p.M));
-      rc = post(m, p, p.send_u, m->ndof + 4, false, upar);
       if (rc) return rc;
     }
     for (Part &p : m->parts) {   // the limiter of the other shards reads averages from the ring
@@ -360,11 +410,10 @@ int run_stage(dflo_hip_multi *m, int rk, double dt) {
   // the neighbours' cells arrive: into the ghost shards, ready for the next stage's rim (same stream)
   for (Part &p : m->parts) {
     MHIP(m, hipSetDevice(p.device));
-    int rc = arrive(m, p, false);
-    if (rc) return rc;
     MENG(m, p, dflo_hip_set_stream(p.eng, p.C));
-    MENG(m, p, dflo_hip_unpack_ghost_cells(p.eng, p.recv_u[upar]));
+    int rc = recv_state(m, p, upar, apar, !m->tvb);
     MENG(m, p, dflo_hip_set_stream(p.eng, p.M));
+    if (rc) return rc;
     p.unpack_pending = true;
   }
   return DFLO_OK;
@@ -502,6 +551,45 @@ int setup_part(dflo_hip_multi *m, Part &p, const dflo_mesh_t *mesh, const dflo_p
     MHIP(m, hipMalloc((void **)&p.recv_u[i], ng * (m->ndof + 4) * sizeof(double)));
     MHIP(m, hipMalloc((void **)&p.recv_a[i], ng * 4 * sizeof(double)));
   }
+  p.trace = dflo_hip_halo_traces(p.eng) != 0;
+  if (p.trace) {
+    // Which faces travel: (owned cell c, face f) whose neighbour across f is a ghost cell, i.e. owned by a peer -- listed
+    // by peer, then cell, then face: the order in which the peer's plan numbers the traces of its ghost cells (ghost
+    // cells are sorted by owner and global id, owned cells keep the global order)
+    auto owner_of_ghost = [&](int g) {   // g: local index of a ghost cell
+      int q = 0;
+      while (p.recv_off[q + 1] <= g - p.n_owned) ++q;
+      return q;
+    };
+    std::vector<std::vector<int32_t>> sc(m->n_parts), sf(m->n_parts);
+    std::vector<int64_t> gkeys;   // (ghost cell, its face) pairs this part looks at
+    for (int c = 0; c < p.n_owned; ++c)
+      for (int f = 0; f < 4; ++f) {
+        const int nb = p.sub->cell_face_neighbor[(size_t)c * 4 + f];
+        if (nb < p.n_owned) continue;   // boundary, none, or an owned neighbour
+        const int q = owner_of_ghost(nb);
+        sc[q].push_back(c);
+        sf[q].push_back(f);
+        gkeys.push_back((int64_t)nb * 4 + (p.sub->cell_face_neighbor_face[(size_t)c * 4 + f] & 3));
+      }
+    std::sort(gkeys.begin(), gkeys.end());
+    gkeys.erase(std::unique(gkeys.begin(), gkeys.end()), gkeys.end());
+    if ((int)gkeys.size() != dflo_hip_n_ghost_traces(p.eng)) { m->err = "ghost traces: the driver and the engine's plan count differently"; return DFLO_ERR_COMM; }
+    p.sendf_off.assign(m->n_parts + 1, 0);
+    p.recvf_off.assign(m->n_parts + 1, 0);
+    std::vector<int32_t> cells, faces;
+    for (int q = 0; q < m->n_parts; ++q) {
+      p.sendf_off[q + 1] = p.sendf_off[q] + (int32_t)sc[q].size();
+      cells.insert(cells.end(), sc[q].begin(), sc[q].end());
+      faces.insert(faces.end(), sf[q].begin(), sf[q].end());
+    }
+    for (int64_t k : gkeys) ++p.recvf_off[owner_of_ghost((int)(k / 4)) + 1];
+    for (int q = 0; q < m->n_parts; ++q) p.recvf_off[q + 1] += p.recvf_off[q];
+    MENG(m, p, dflo_hip_set_send_faces(p.eng, (int32_t)cells.size(), cells.data(), faces.data()));
+    MHIP(m, hipMalloc((void **)&p.send_t, std::max<size_t>(cells.size(), 1) * 4 * m->N * sizeof(double)));
+    MENG(m, p, dflo_hip_ghost_trace_buffer(p.eng, 0, &p.tg[0]));
+    MENG(m, p, dflo_hip_ghost_trace_buffer(p.eng, 1, &p.tg[1]));
+  }
   MENG(m, p, dflo_hip_scalar_ptrs(p.eng, &p.dt_ptr, &p.res_ptr));
   MENG(m, p, dflo_hip_dt_publish(p.eng, (!m->rank_mode && m->n_parts > 1) ? 1 : 0, &p.dt_slot[0], &p.dt_slot[1]));
   // the engine's boundary faces -> their numbers in the undivided mesh
@@ -584,7 +672,7 @@ int dflo_hip_multi_destroy(dflo_hip_multi_handle m) {
   for (Part &p : m->parts) {
     hipSetDevice(p.device);
     if (p.eng) dflo_hip_destroy(p.eng);
-    hipFree(p.send_u); hipFree(p.send_a);
+    hipFree(p.send_u); hipFree(p.send_a); hipFree(p.send_t);
     for (int i = 0; i < 2; ++i) { hipFree(p.recv_u[i]); hipFree(p.recv_a[i]); }
     hipEvent_t evs[] = {p.ev_open, p.ev_rim, p.ev_rim_prev, p.ev_ring, p.ev_unpack, p.ev_fin, p.ev_dt, p.ev_sent_u, p.ev_sent_a};
     for (hipEvent_t e : evs) if (e) hipEventDestroy(e);
@@ -620,6 +708,7 @@ int dflo_hip_multi_create(const dflo_mesh_t *mesh, const dflo_params_t *params, 
     for (int q : p.peers) {
       Part &o = m->parts[q];
       if (p.send_off[q + 1] - p.send_off[q] != o.recv_off[p.index + 1] - o.recv_off[p.index]) { m->err = "partition: send and receive counts disagree"; return bail(DFLO_ERR_COMM); }
+      if (p.trace && p.sendf_off[q + 1] - p.sendf_off[q] != o.recvf_off[p.index + 1] - o.recvf_off[p.index]) { m->err = "partition: face-trace send and receive counts disagree"; return bail(DFLO_ERR_COMM); }
     }
   // the engines read each other's time-step slots (and hipMemcpyPeerAsync goes direct) over xGMI
   for (Part &p : m->parts)
@@ -735,6 +824,7 @@ int dflo_hip_multi_set_solution(dflo_hip_multi_handle m, const double *u) {
       std::memcpy(&loc[(size_t)c * m->ndof], &u[(size_t)p.sub->cell_global_id[c] * m->ndof], m->ndof * sizeof(double));
     MENG(m, p, dflo_hip_set_solution(p.eng, loc.data()));
   }
+  m->xparity = 1;   // the engines read their trace table 0 now: the first exchange fills table 1
   return DFLO_OK;
 }
 
@@ -747,6 +837,7 @@ int dflo_hip_multi_set_part_solution(dflo_hip_multi_handle m, int i, const doubl
   int rc = join_all(m);
   if (rc) return rc;
   MENG(m, m->parts[i], dflo_hip_set_solution(m->parts[i].eng, u_part));
+  m->xparity = 1;
   return DFLO_OK;
 }
 

@@ -337,6 +337,27 @@ int build_plan(const dflo_mesh_t &mesh, int shard_ex, int shard_ey, Plan &p, std
     (reads_ghost ? p.rim_shards : p.interior_shards).push_back(s);
   }
 
+  // ---- ghost traces: number the (ghost cell, face) pairs the owned cells look at, ghost cell first, then face
+  {
+    std::vector<int64_t> keys;
+    for (size_t k = 0; k < p.halo_cells.size(); ++k)
+      if (p.halo_cells[k] >= p.n_shards * kShard) keys.push_back((int64_t)p.halo_cells[k] * 4 + p.halo_faces[k]);
+    std::sort(keys.begin(), keys.end());
+    keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
+    p.gt_cell.resize(keys.size());
+    p.gt_face.resize(keys.size());
+    for (size_t t = 0; t < keys.size(); ++t) {
+      p.gt_cell[t] = (int32_t)(keys[t] / 4);
+      p.gt_face[t] = (int32_t)(keys[t] % 4);
+    }
+    p.halo_gt.assign(p.halo_cells.size(), -1);
+    for (size_t k = 0; k < p.halo_cells.size(); ++k)
+      if (p.halo_cells[k] >= p.n_shards * kShard) {
+        const int64_t key = (int64_t)p.halo_cells[k] * 4 + p.halo_faces[k];
+        p.halo_gt[k] = (int32_t)(std::lower_bound(keys.begin(), keys.end(), key) - keys.begin());
+      }
+  }
+
   // ---- the rim widened by one ring of shards (multi-device runs with the TVB limiter): the limiter of a rim cell reads the
   //      new averages of its face neighbours, and those that are not ghosts live in rim shards or in the ring
   {

@@ -48,6 +48,12 @@ struct Plan {
   std::vector<int32_t> halo_begin;   // [n_shards+1]
   std::vector<int32_t> halo_cells;   // internal slot of the halo entry's cell
   std::vector<int32_t> halo_faces;   // its local face shared with the shard (an entry = one (cell, face) pair)
+  std::vector<int32_t> halo_gt;      // ghost-trace number of the entry, or -1: the entry's cell is an owned cell
+  // Ghost cells are known to the stage kernels only by their traces on the faces they share with owned cells (the halo
+  // records of a multi-device run: N*4 doubles per cut face): trace number = position in the list of
+  // (ghost cell, face) pairs ordered by ghost cell (source rank, global id), then face -- the order the owners pack them in
+  std::vector<int32_t> gt_cell;      // internal slot of the ghost cell of trace number t
+  std::vector<int32_t> gt_face;
   std::vector<int32_t> face_begin;   // [n_shards+1]
   std::vector<FaceRec> faces;
   std::vector<double> face_geom;     // [n faces][3]: outward unit normal of the integrating cell, edge length

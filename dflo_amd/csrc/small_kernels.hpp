@@ -204,6 +204,16 @@ __global__ void unpack_cells_kernel(const double *buf, double *U, double *avg, i
   if (d < ndof) U[((size_t)(slot >> 6) * ndof + d) * 64 + (slot & 63)] = buf[t];
   else avg[((size_t)(slot >> 6) * 4 + (d - ndof)) * 64 + (slot & 63)] = buf[t];
 }
+// Face-trace halo records (N*4 doubles per cut face instead of the whole cell): record k = the trace of the
+// listed cell on the listed face, out[k][4][N], formed exactly as the stage kernel's halo gather forms it.  Used to pack
+// what a peer needs (owned cells on the cut) and to initialise the ghost traces from the ghost cells' DoFs after set_solution.
+template <int N>
+__global__ void face_trace_kernel(double *out, const double *U, const int32_t *slots, const int32_t *faces, int n) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (long long)n * 4 * N) return;
+  const int k = (int)(t / (4 * N)), r = (int)(t - (long long)k * 4 * N);
+  out[t] = cell_face_trace<N>(U, slots[k], faces[k], r / N, r % N);
+}
 // ghost cells: staging buffer [g][ndof] -> ghost shards, and their cell averages
 // one thread per (ghost cell, component): its DoFs travel buffer -> ghost shard (the buffer is read with unit stride
 // along the thread's own run of n_s values, the shard rows are written 64 cells wide) and their average is formed

@@ -331,6 +331,7 @@ __host__ __device__ __forceinline__ uint32_t pface_pack(const FaceRec &r) {
   else w |= (((r.w0 >> 20) & 3) << 13) | ((uint32_t)r.w1 << 15);
   return w;
 }
+constexpr int kGhostTrace = 1 << 30;   // halo entry: bits 0-27 hold a ghost-trace number instead of a cell slot
 __device__ __forceinline__ int pface_slot(uint32_t w) { return w & 0x1FF; }
 __device__ __forceinline__ int pface_face(uint32_t w) { return (w >> 9) & 3; }
 __device__ __forceinline__ bool pface_bnd(uint32_t w) { return (w >> 11) & 1; }
@@ -549,6 +550,14 @@ __global__ __launch_bounds__(64 * N, ((GEO == 1 && N != 3) || N == 4) ? 2 : 3) v
       if (sl >= nh) continue;
       const int e = b == 0 ? hentb[0] : (b == 1 ? hentb[1] : (b == 2 ? hentb[2] : a.halo_pad[(size_t)shard * a.halo_pitch + sl]));
       const int ic = e & 0x0FFFFFFF, f = (e >> 28) & 3;
+      if (e & kGhostTrace) {   // a ghost cell (multi-device): its owner has sent the trace, ic is the trace number
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int r = g + 2 * N * j;   // = c * N + q
+          Th[r * HS + sl] = a.Tg[(size_t)ic * 4 * N + r];
+        }
+        continue;
+      }
       const int str0 = f < 2 ? 1 : N, str = (f & 1) ? -str0 : str0;
       double val[2][N];
 #pragma unroll
@@ -562,10 +571,7 @@ __global__ __launch_bounds__(64 * N, ((GEO == 1 && N != 3) || N == 4) ? 2 : 3) v
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const int r = g + 2 * N * j, q = r % N, c = r / N;
-        double v = 0.0;
-#pragma unroll
-        for (int m = 0; m < N; ++m) v += CB<N>::t.L0[m] * val[j][m];
-        Th[(c * N + q) * HS + sl] = v;
+        Th[(c * N + q) * HS + sl] = trace_from_line<N>(val[j]);
       }
     }
   }
@@ -573,7 +579,8 @@ __global__ __launch_bounds__(64 * N, ((GEO == 1 && N != 3) || N == 4) ? 2 : 3) v
                                           // keep (u, v, c) of each average instead of the four components
     for (int sl = tid; sl < nh; sl += NT) {
       const int blk = sl >> 5;   // sl = tid + k NT: entry (tid & 31) + 32 blk is this thread's own preloaded one
-      const int ic = (blk == 0 ? hentb[0] : (blk == 1 ? hentb[1] : (blk == 2 ? hentb[2] : a.halo_pad[(size_t)shard * a.halo_pitch + sl]))) & 0x0FFFFFFF;
+      const int e = blk == 0 ? hentb[0] : (blk == 1 ? hentb[1] : (blk == 2 ? hentb[2] : a.halo_pad[(size_t)shard * a.halo_pitch + sl]));
+      const int ic = (e & kGhostTrace) ? a.gt_slot[e & 0x0FFFFFFF] : (e & 0x0FFFFFFF);
       double A[4], uvc[3];
 #pragma unroll
       for (int c = 0; c < 4; ++c) A[c] = a.avg_cur[((size_t)(ic >> 6) * 4 + c) * 64 + (ic & 63)];

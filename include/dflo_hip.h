@@ -272,6 +272,20 @@ int dflo_hip_unpack_ghost_avg(dflo_hip_handle h, const void *device_buffer);
  * differences read it).  What the native multi-device driver ships. */
 int dflo_hip_pack_send_cells(dflo_hip_handle h, void *device_buffer);
 int dflo_hip_unpack_ghost_cells(dflo_hip_handle h, const void *device_buffer);
+/* Face-trace records: when nothing needs more of a ghost cell than its trace on the cut faces and its average
+ * -- Qk without the KXRCF indicator: dflo_hip_halo_traces() = 1 -- the stage kernels read the ghost cells from a table of
+ * traces, [n_ghost_traces][4][k+1] doubles ordered by (ghost cell, face), and the halo message of a cut face shrinks from
+ * the cell's (k+1)^2 * 4 doubles to (k+1) * 4 (Q2: 36 -> 12; the 4-double average travels with pack_send_avg).  The
+ * sender lists its (owned cell, face) pairs in the receiver's order (set_send_faces) and packs their traces; the receiver
+ * lets the transport write straight into one of the engine's two trace tables (ghost_trace_buffer) and switches the
+ * stage kernels to it before the next stage (use_ghost_traces) -- no unpack kernel.  dflo_hip_set_solution fills both
+ * tables from the ghost cells' DoFs.  DFLO_HALO_CELLS=1 keeps whole-cell records. */
+int dflo_hip_halo_traces(dflo_hip_handle h);
+int dflo_hip_n_ghost_traces(dflo_hip_handle h);
+int dflo_hip_set_send_faces(dflo_hip_handle h, int32_t n, const int32_t *cells, const int32_t *faces);
+int dflo_hip_pack_send_traces(dflo_hip_handle h, void *device_buffer);
+int dflo_hip_ghost_trace_buffer(dflo_hip_handle h, int which, void **device_ptr);
+int dflo_hip_use_ghost_traces(dflo_hip_handle h, int which);
 /* device address of {dt, res_norm_sq} scalars for 8-byte all-reduces (src_mpi/claw.cc:579,777) */
 int dflo_hip_scalar_ptrs(dflo_hip_handle h, void **dt_ptr, void **res_ptr);
 /* dt_ptr[2] holds the raw CFL minimum of this device; after an external all-reduce(min) of that

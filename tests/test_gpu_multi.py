@@ -252,3 +252,27 @@ def test_rccl_loopback_transport(monkeypatch):
     _setup(multi, mesh, ic)
     assert one.advance(5) == multi.advance(5)
     assert np.array_equal(one.current_solution, multi.current_solution)
+
+
+def test_face_trace_records_are_what_travels(monkeypatch):
+    """Qk without the KXRCF indicator: the halo record of a cut face is its trace, (k+1)*4 doubles, received
+    straight into the engine's trace table; whole cells (DFLO_HALO_CELLS=1, and always for Pk / KXRCF) give the same bits."""
+    import ctypes as C
+    from dflo_amd._lib import lib
+    mesh, prm, ic = _case("c2")
+    res = []
+    for cells in ("0", "1"):
+        monkeypatch.setenv("DFLO_HALO_CELLS", cells)
+        multi = dflo_amd.MultiConservationLaw(mesh, prm, devices=[0, 0])
+        eng = lib.dflo_hip_multi_engine(multi._h, 1)
+        assert lib.dflo_hip_halo_traces(eng) == (1 if cells == "0" else 0)
+        if cells == "0":   # a slab of 16 x 24 cells of the periodic box: two cuts of 24 faces, one trace each
+            assert lib.dflo_hip_n_ghost_traces(eng) == 48 and lib.dflo_hip_n_ghost_cells(eng) == 48
+        _setup(multi, mesh, ic)
+        multi.advance(6)
+        res.append(multi.current_solution)
+    assert np.array_equal(res[0], res[1])
+    monkeypatch.setenv("DFLO_HALO_CELLS", "0")
+    pk = _case("pk")
+    multi = dflo_amd.MultiConservationLaw(pk[0], pk[1], devices=[0, 0])
+    assert lib.dflo_hip_halo_traces(lib.dflo_hip_multi_engine(multi._h, 0)) == 0
