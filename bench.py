@@ -200,7 +200,13 @@ def run_case(args, world, rank, local_rank, uid, barrier):
         # exchange machinery (streams, events, pack / peer copy / unpack, time-step reduction) costs with no second GPU
         claw = dflo_amd.MultiConservationLaw(mesh, prm, devices=[local_rank] * args.parts_per_gpu, partitioner=part)
         return run_parts(args, claw, mesh, ic, bc_fn, programs, nx, ny)
-    claw = dflo_amd.MultiConservationLaw.for_rank(mesh, prm, local_rank, rank, world, uid, partitioner=part)
+    if uid == "gloo":   # developer switch (DFLO_BENCH_TRANSPORT=gloo): the rank schedule with a host-staged transport, so that several
+        # ranks can share one GPU (RCCL refuses that) -- exercises this script's N > 1 path on a 1-GPU box; not a measurement
+        from dflo_amd.gloo_transport import make_callbacks
+        xf, af = make_callbacks("cuda:%d" % local_rank)
+        claw = dflo_amd.MultiConservationLaw.for_rank_custom(mesh, prm, local_rank, rank, world, xf, af, partitioner=part)
+    else:
+        claw = dflo_amd.MultiConservationLaw.for_rank(mesh, prm, local_rank, rank, world, uid, partitioner=part)
     if bc_fn is not None:
         cell, face, bid, xy = claw.boundary_faces()
         bv = np.stack(bc_fn(xy[..., 0], xy[..., 1]), axis=-1)
@@ -275,6 +281,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the dflo HIP engine has no CPU fallback")
+    if os.environ.get("DFLO_BENCH_ONE_GPU") == "1":   # developer switch, with DFLO_BENCH_TRANSPORT=gloo: every rank on GPU 0
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     uid = None
     barrier = lambda: None
@@ -287,9 +295,12 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
         dist.init_process_group("gloo")
-        box = [comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(box, src=0)
-        uid = box[0]
+        if os.environ.get("DFLO_BENCH_TRANSPORT") == "gloo":
+            uid = "gloo"
+        else:
+            box = [comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            uid = box[0]
         barrier = dist.barrier
 
     m = run_case(args, world, rank, local_rank, uid, barrier)
@@ -353,8 +364,10 @@ def main():
                                    % m["n_cells"]}[args.config],
                 "n_dofs": n_dofs_total, "n_rk": n_rk,
                 "parts_per_gpu": args.parts_per_gpu,
-                "parallelism": "%s, %d rank(s), native driver (dflo_hip_multi_*): RCCL send/recv halos + 8-byte all-reduce(min) per step"
-                               % ("RCB blocks" if args.config == "c5" else "x-slabs", world),
+                "parallelism": "%s, %d rank(s), native driver (dflo_hip_multi_*): %s"
+                               % ("RCB blocks" if args.config == "c5" else "x-slabs", world,
+                                  "HOST-STAGED gloo transport (developer switch, not a measurement)" if uid == "gloo"
+                                  else "RCCL send/recv of face traces + 8-byte all-reduce(min) per step"),
                 "check": check, "preheat_s": 0.0 if os.environ.get("DFLO_BENCH_NO_PREHEAT") == "1" else 0.4,
             },
             "roofline": {

@@ -1,8 +1,8 @@
 """GPU: the one-process-per-GPU schedule of the native multi-device driver (dflo_hip_multi_create_rank_*: rim on the comm
 stream, pack, exchange, unpack, all-reduced time step, summed residual norms, agreed error status) run by 2 and 3 real
 processes on ONE device.  RCCL refuses two ranks on one GPU, so the ranks move their bytes with the driver's
-bring-your-own-transport entry (dflo_hip_multi_create_rank_custom, what a dflo built on MPI would use): the callbacks
-below stage the device buffers through gloo.  Everything except the ncclSend / ncclRecv / ncclAllReduce calls themselves is
+bring-your-own-transport entry (dflo_hip_multi_create_rank_custom, what a dflo built on MPI would use): the callbacks of
+dflo_amd/gloo_transport.py stage the device buffers through gloo.  Everything except the ncclSend / ncclRecv / ncclAllReduce calls themselves is
 the code the 8-GPU RCCL run executes; those calls are exercised by test_gpu_multi.py::test_rccl_loopback_transport."""
 import ctypes as C
 import os
@@ -19,51 +19,6 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 
 
-class _DevPtr:
-    def __init__(self, ptr, n):
-        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (ptr, False), "version": 2}
-
-
-def _view(ptr, nbytes):
-    return torch.as_tensor(_DevPtr(ptr, nbytes // 8), device="cuda:0")
-
-
-def _exchange(user, n_peers, peer, send_ptr, send_bytes, recv_ptr, recv_bytes, stream):
-    try:
-        torch.cuda.synchronize()
-        ops, back = [], []
-        for i in range(n_peers):
-            if recv_bytes[i]:
-                host = torch.empty(recv_bytes[i] // 8, dtype=torch.float64)
-                back.append((host, recv_ptr[i], recv_bytes[i]))
-                ops.append(dist.P2POp(dist.irecv, host, peer[i]))
-            if send_bytes[i]:
-                ops.append(dist.P2POp(dist.isend, _view(send_ptr[i], send_bytes[i]).cpu(), peer[i]))
-        for w in dist.batch_isend_irecv(ops) if ops else []:
-            w.wait()
-        for host, ptr, nb in back:
-            _view(ptr, nb).copy_(host)
-        torch.cuda.synchronize()
-        return 0
-    except Exception as e:      # never let an exception cross the C boundary
-        print("exchange callback:", e, file=sys.stderr)
-        return 1
-
-
-def _allreduce(user, values, n, op, stream):
-    try:
-        torch.cuda.synchronize()
-        v = _view(values, 8 * n)
-        h = v.cpu()
-        dist.all_reduce(h, op=[dist.ReduceOp.MIN, dist.ReduceOp.SUM, dist.ReduceOp.MAX][op])
-        v.copy_(h)
-        torch.cuda.synchronize()
-        return 0
-    except Exception as e:
-        print("allreduce callback:", e, file=sys.stderr)
-        return 1
-
-
 def _worker(rank, world, port, name, ret):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, HERE)
@@ -75,6 +30,8 @@ def _worker(rank, world, port, name, ret):
     import test_gpu_multi as T
     mesh, prm, ic = T._case(name)
     limited = prm.limiter == "TVB"
+    from dflo_amd.gloo_transport import make_callbacks
+    _exchange, _allreduce = make_callbacks("cuda:0")
     claw = dflo_amd.MultiConservationLaw.for_rank_custom(mesh, prm, 0, rank, world, _exchange, _allreduce,
                                                           partitioner="rcb" if name == "c5" else "slab")
     assert claw.n_parts == world and claw.n_local == 1
