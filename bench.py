@@ -206,7 +206,26 @@ def run_case(args, world, rank, local_rank, uid, barrier):
         xf, af = make_callbacks("cuda:%d" % local_rank)
         claw = dflo_amd.MultiConservationLaw.for_rank_custom(mesh, prm, local_rank, rank, world, xf, af, partitioner=part)
     else:
-        claw = dflo_amd.MultiConservationLaw.for_rank(mesh, prm, local_rank, rank, world, uid, partitioner=part)
+        claw, why = None, ""
+        try:
+            claw = dflo_amd.MultiConservationLaw.for_rank(mesh, prm, local_rank, rank, world, uid, partitioner=part)
+        except dflo_amd.DfloError as e:      # RCCL could not make the communicator on this node
+            why = str(e)
+        if world > 1:   # all ranks take the same road: RCCL only if every rank has its communicator
+            import torch.distributed as dist
+            ok = torch.tensor([1 if claw is not None else 0])
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0:
+                if claw is not None:
+                    claw.close()
+                print("bench.py: RCCL communicator failed on some rank (%s) -- falling back to the HOST-STAGED gloo transport; "
+                      "the line below says so and is not a measurement of the RCCL path" % why, file=sys.stderr, flush=True)
+                from dflo_amd.gloo_transport import make_callbacks
+                xf, af = make_callbacks("cuda:%d" % local_rank)
+                claw = dflo_amd.MultiConservationLaw.for_rank_custom(mesh, prm, local_rank, rank, world, xf, af, partitioner=part)
+                args.transport_note = "HOST-STAGED gloo transport (RCCL communicator failed: %s) -- not a measurement of the RCCL path" % why[:120]
+        elif claw is None:
+            raise SystemExit("bench.py: " + why)
     if bc_fn is not None:
         cell, face, bid, xy = claw.boundary_faces()
         bv = np.stack(bc_fn(xy[..., 0], xy[..., 1]), axis=-1)
@@ -367,7 +386,7 @@ def main():
                 "parallelism": "%s, %d rank(s), native driver (dflo_hip_multi_*): %s"
                                % ("RCB blocks" if args.config == "c5" else "x-slabs", world,
                                   "HOST-STAGED gloo transport (developer switch, not a measurement)" if uid == "gloo"
-                                  else "RCCL send/recv of face traces + 8-byte all-reduce(min) per step"),
+                                  else getattr(args, "transport_note", "RCCL send/recv of face traces + 8-byte all-reduce(min) per step")),
                 "check": check, "preheat_s": 0.0 if os.environ.get("DFLO_BENCH_NO_PREHEAT") == "1" else 0.4,
             },
             "roofline": {
