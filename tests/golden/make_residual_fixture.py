@@ -1,0 +1,282 @@
+"""Derivation of tests/golden/residual_fixture.json: known answers for the ASSEMBLED path -- right-hand side, cell
+averages, CFL time step and the state after one SSP-RK step -- on small Cartesian meshes, computed here in 60-digit decimal
+arithmetic from the weak form itself (i.e. src/assemble_explicit.cc:30-427, src/claw.cc:141-159,
+444-511, 562-597, 694-760 in mathematical form), independently of oracle/ and of the HIP kernels: its own Gauss rule
+(Newton on the Legendre polynomial), its own Lagrange basis, a loop over cells and faces with the numerical fluxes of
+make_closed_forms.py (the 60-digit restatement of src/equation.h).  The oracle (tests/test_oracle_assembly.py) and the
+device (tests/test_gpu_golden.py) are both held to it.
+
+  R_i = int_K F(W):grad(phi_i) - sum_faces int_f F^(W+, W-, n) phi_i,     M_ii = w_a w_b h^2   (collocated Gauss nodes)
+  stage: U <- ark U_n + (1 - ark)(U + dt R / M),  ark = (0, 1/2) for k = 1 and (0, 3/4, 1/3) for k >= 2
+  dt = cfl / sum_d((c + |u_d|) / h) / (2k + 1) from the cell averages, minimum over cells
+
+Like closed_forms.json this pins formulas, not the reference binary (deal.II is not available): parity stays "partial".
+Usage: python tests/golden/make_residual_fixture.py   (rewrites residual_fixture.json; deterministic, ~1 min)
+"""
+import json
+import math
+import os
+import sys
+from decimal import Decimal as D, getcontext
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import make_closed_forms as cf   # noqa: E402  (sets the precision to 60 digits)
+
+getcontext().prec = 60
+G = cf.G
+
+
+def legendre(n, x):
+    p0, p1 = D(1), x
+    if n == 0:
+        return D(1), D(0)
+    for k in range(2, n + 1):
+        p0, p1 = p1, ((2 * k - 1) * x * p1 - (k - 1) * p0) / k
+    return p1, n * (x * p1 - p0) / (x * x - 1)
+
+
+def gauss01(n):
+    """nodes and weights of Gauss-Legendre on [0, 1], ascending (QGauss<1>(n))"""
+    xs, ws = [], []
+    for i in range(n):
+        x = D(repr(-math.cos(math.pi * (i + 0.75) / (n + 0.5))))    # a crude guess in floats; Newton does the rest
+        for _ in range(100):
+            p, dp = legendre(n, x)
+            dx = p / dp
+            x -= dx
+            if abs(dx) < D("1e-58"):
+                break
+        p, dp = legendre(n, x)
+        xs.append((1 + x) / 2)
+        ws.append(1 / ((1 - x * x) * dp * dp))
+    return xs, ws
+
+
+def lagrange(xs, a, t):
+    v = D(1)
+    for m, xm in enumerate(xs):
+        if m != a:
+            v *= (t - xm) / (xs[a] - xm)
+    return v
+
+
+def dlagrange(xs, a, t):
+    s = D(0)
+    for j, xj in enumerate(xs):
+        if j == a:
+            continue
+        v = 1 / (xs[a] - xj)
+        for m, xm in enumerate(xs):
+            if m != a and m != j:
+                v *= (t - xm) / (xs[a] - xm)
+        s += v
+    return s
+
+
+def flux_xy(W):
+    rho, u, v, p = cf.prim(W)
+    return ([W[0] * u + p, W[1] * u, rho * u, (W[3] + p) * u], [W[0] * v, W[1] * v + p, rho * v, (W[3] + p) * v])
+
+
+def numerical_flux(name, n, Wl, Wr, Al, Ar):
+    if name == "lxf":
+        return cf.lxf(n, Wl, Wr, Al, Ar)
+    if name == "sw":
+        return cf.steger_warming(n, Wl, Wr)
+    if name == "kfvs":
+        return cf.kfvs(n, Wl, Wr)
+    if name == "roe":
+        return cf.roe(n, Wl, Wr)[0]
+    return cf.hllc(n, Wl, Wr)[0]
+
+
+class Case:
+    """nx x ny squares of size h from (x0, y0); side = boundary id of the sides x-min, x-max, y-min, y-max or -1 (periodic)"""
+
+    def __init__(self, name, nx, ny, h, k, flux, side, kinds, cfl, field, x0=D(0), y0=D(0)):
+        self.name, self.nx, self.ny, self.h, self.k, self.N = name, nx, ny, D(h), k, k + 1
+        self.flux, self.side, self.kinds, self.cfl, self.field = flux, side, kinds, D(cfl), field
+        self.x0, self.y0 = D(x0), D(y0)
+        self.xs, self.ws = gauss01(self.N)
+        N = self.N
+        self.Dm = [[dlagrange(self.xs, a, self.xs[q]) for a in range(N)] for q in range(N)]   # D[q][a] = l_a'(x_q)
+        self.L0 = [lagrange(self.xs, a, D(0)) for a in range(N)]
+        self.L1 = [lagrange(self.xs, a, D(1)) for a in range(N)]
+
+    # state U[cell][comp][node], node = a + N b (x fastest) -- dflo's DoF order
+    def initial(self):
+        N, U = self.N, []
+        for j in range(self.ny):
+            for i in range(self.nx):
+                cell = [[None] * (N * N) for _ in range(4)]
+                for b in range(N):
+                    for a in range(N):
+                        W = self.field(self.x0 + (i + self.xs[a]) * self.h, self.y0 + (j + self.xs[b]) * self.h)
+                        for c in range(4):
+                            cell[c][a + N * b] = W[c]
+                U.append(cell)
+        return U
+
+    def averages(self, U):
+        N = self.N
+        return [[sum(self.ws[a] * self.ws[b] * U[c][comp][a + N * b] for a in range(N) for b in range(N)) for comp in range(4)]
+                for c in range(len(U))]
+
+    def neighbour(self, i, j, f):
+        """(cell index, None) across face f, or (None, boundary id)"""
+        di, dj = [(-1, 0), (1, 0), (0, -1), (0, 1)][f]
+        ii, jj = i + di, j + dj
+        if 0 <= ii < self.nx and 0 <= jj < self.ny:
+            return ii + self.nx * jj, None
+        s = self.side[f]
+        if s < 0:
+            return (ii % self.nx) + self.nx * (jj % self.ny), None
+        return None, s
+
+    def trace(self, Uc, f, q):
+        N = self.N
+        if f < 2:
+            L = self.L0 if f == 0 else self.L1
+            return [sum(L[m] * Uc[c][m + N * q] for m in range(N)) for c in range(4)]
+        L = self.L0 if f == 2 else self.L1
+        return [sum(L[m] * Uc[c][q + N * m] for m in range(N)) for c in range(4)]
+
+    def face_point(self, i, j, f, q):
+        s = self.xs[q]
+        xi = D(0) if f == 0 else (D(1) if f == 1 else s)
+        eta = D(0) if f == 2 else (D(1) if f == 3 else s)
+        return self.x0 + (i + xi) * self.h, self.y0 + (j + eta) * self.h
+
+    def residual(self, U, bc_time=None):
+        N, h, A = self.N, self.h, self.averages(U)
+        R = [[[D(0)] * (N * N) for _ in range(4)] for _ in U]
+        normals = [[D(-1), D(0)], [D(1), D(0)], [D(0), D(-1)], [D(0), D(1)]]
+        for j in range(self.ny):
+            for i in range(self.nx):
+                c = i + self.nx * j
+                Uc = U[c]
+                # volume term: sum_q w_q w_b h D[q][a] Fx(W_(q,b)) + w_a w_q h D[q][b] Fy(W_(a,q))
+                F = [[flux_xy([Uc[comp][a + N * b] for comp in range(4)]) for a in range(N)] for b in range(N)]   # F[b][a] = (Fx, Fy)
+                for b in range(N):
+                    for a in range(N):
+                        for comp in range(4):
+                            s = D(0)
+                            for q in range(N):
+                                s += self.ws[q] * self.ws[b] * h * self.Dm[q][a] * F[b][q][0][comp]
+                                s += self.ws[a] * self.ws[q] * h * self.Dm[q][b] * F[q][a][1][comp]
+                            R[c][comp][a + N * b] += s
+                # faces: every cell subtracts the flux through its own faces with its own outward normal (the flux is
+                # conservative: F^(W+, W-, n) = -F^(W-, W+, -n) for every scheme of the reference, so this is the one-flux-per-face
+                # assembly of MeshWorker written per cell)
+                for f in range(4):
+                    nb, bid = self.neighbour(i, j, f)
+                    n = normals[f]
+                    for q in range(N):
+                        Wp = self.trace(Uc, f, q)
+                        if nb is not None:
+                            Wm = self.trace(U[nb], f ^ 1, q)
+                            Fh = numerical_flux(self.flux, n, Wp, Wm, A[c], A[nb])
+                        else:
+                            x, y = self.face_point(i, j, f, q)
+                            bv = self.field(x, y)
+                            Wm = cf.compute_Wminus(self.kinds[bid], n, Wp, bv)
+                            Fh = numerical_flux(self.flux, n, Wp, Wm, A[c], A[c])   # both averages the interior cell's, src/assemble_explicit.cc:200-205
+                        L = (self.L0 if f in (0, 2) else self.L1)
+                        for m in range(N):
+                            node = (m + N * q) if f < 2 else (q + N * m)
+                            for comp in range(4):
+                                R[c][comp][node] -= Fh[comp] * L[m] * self.ws[q] * h
+        return R
+
+    def dt(self, U):
+        best = None
+        for Ac in self.averages(U):
+            rho, u, v, p = cf.prim(Ac)
+            c = (G * p / rho).sqrt()
+            d = self.cfl / ((c + abs(u)) / self.h + (c + abs(v)) / self.h) / (2 * self.k + 1)
+            best = d if best is None or d < best else best
+        return best
+
+    def step(self, U, dt):
+        N = self.N
+        ark = [D(0), D(1) / 2] if self.k == 1 else ([D(0)] if self.k == 0 else [D(0), D(3) / 4, D(1) / 3])
+        Un, Uc = U, U
+        for a_rk in ark:
+            R = self.residual(Uc)
+            new = []
+            for c in range(len(Uc)):
+                cell = [[None] * (N * N) for _ in range(4)]
+                for comp in range(4):
+                    for b in range(N):
+                        for a in range(N):
+                            i = a + N * b
+                            u = Uc[c][comp][i] + dt * R[c][comp][i] / (self.ws[a] * self.ws[b] * self.h * self.h)
+                            cell[comp][i] = a_rk * Un[c][comp][i] + (1 - a_rk) * u
+                new.append(cell)
+            Uc = new
+        return Uc
+
+
+def smooth(x, y):
+    """a smooth subsonic state with all gradients alive (polynomials: exact in decimal arithmetic)"""
+    rho = 1 + (x * (1 - x) + y * y / 2) / 4
+    u = D("0.4") + x * y / 3 - y / 5
+    v = D("-0.25") + x / 4 + y * (1 - y) / 3
+    p = 1 + (x - y) / 5 + x * x / 6
+    return cf.cons(rho, u, v, p)
+
+
+def periodic(x, y):
+    """periodic on the unit square to rounding of the polynomials below (period 1 in x and y)"""
+    sx, sy = x * (1 - x) * (1 - 2 * x), y * (1 - y) * (1 - 2 * y)     # zero mean, matching values and slopes at 0 and 1
+    rho = 1 + sx / 2 + sy / 3
+    u = D("0.5") + sy - sx / 2
+    v = D("0.3") + sx
+    p = 1 + sx * sy * 4 + sy / 2
+    return cf.cons(rho, u, v, p)
+
+
+def flat(U):
+    return [format(v, ".25e") for cell in U for comp in cell for v in comp]
+
+
+def main():
+    third, quarter = D(1) / 3, D(1) / 4
+    cases = [
+        Case("4x3 periodic Q2 HLLC", 4, 3, quarter, 2, "hllc", [-1, -1, -1, -1], {}, "0.9", lambda x, y: periodic(x, y * 4 / 3), D(0), D(0)),
+        Case("3x3 Q1 LxF, inflow / outflow / slip / farfield walls", 3, 3, third, 1, "lxf", [2, 1, 0, 3],
+             {0: "slip", 1: "outflow", 2: "inflow", 3: "farfield"}, "0.8", smooth),
+        Case("2x2 periodic Q3 KFVS", 2, 2, D(1) / 2, 3, "kfvs", [-1, -1, -1, -1], {}, "0.5", periodic),
+        Case("3x2 Q2 Roe, pressure outlet and slip walls", 3, 2, third, 2, "roe", [2, 4, 0, 0],
+             {0: "slip", 2: "inflow", 4: "pressure"}, "0.7", smooth),
+        Case("4x4 periodic Q1 Steger-Warming", 4, 4, quarter, 1, "sw", [-1, -1, -1, -1], {}, "0.9", periodic),
+    ]
+    out = {"gamma": "1.4", "layout": "U[cell = i + nx j][component mx, my, rho, E][node a + N b]", "cases": []}
+    for cs in cases:
+        U0 = cs.initial()
+        R = cs.residual(U0)
+        dt = cs.dt(U0)
+        U1 = cs.step(U0, dt)
+        # the boundary values the tests hand to the oracle / the engine: the field at the face quadrature points, MeshWorker order
+        bfaces = []
+        for j in range(cs.ny):
+            for i in range(cs.nx):
+                for f in range(4):
+                    nb, bid = cs.neighbour(i, j, f)
+                    if nb is None:
+                        bfaces.append({"cell": i + cs.nx * j, "face": f, "id": bid,
+                                       "values": [[format(v, ".25e") for v in cs.field(*cs.face_point(i, j, f, q))] for q in range(cs.N)]})
+        out["cases"].append({
+            "name": cs.name, "nx": cs.nx, "ny": cs.ny, "h": format(cs.h, ".25e"), "degree": cs.k, "flux": cs.flux,
+            "side": cs.side, "kinds": {str(k): v for k, v in cs.kinds.items()}, "cfl": str(cs.cfl),
+            "U0": flat(U0), "residual": flat(R), "cell_average": [format(v, ".25e") for a in cs.averages(U0) for v in a],
+            "dt": format(dt, ".25e"), "U1": flat(U1), "boundary_faces": bfaces,
+        })
+        print(cs.name, "dt", format(dt, ".6e"), flush=True)
+    json.dump(out, open(os.path.join(HERE, "residual_fixture.json"), "w"), indent=0)
+    print("residual_fixture.json written")
+
+
+if __name__ == "__main__":
+    main()

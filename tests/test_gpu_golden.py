@@ -148,3 +148,33 @@ def test_device_slip_wall_carries_only_the_pressure():
             r = claw.assemble_system().reshape(4, 4).sum(axis=1)
             got = phys_flux(W, n) - r
             assert np.abs(got - _f(rec["flux"])).max() <= (2e-9 if flux == "kfvs" else 1e-13), (flux, got)   # kfvs: see test_oracle_pointwise
+
+
+# ---------------------------------------------------------------- the assembled path against the 60-digit derivation
+from test_oracle_assembly import _residual_fixture, run_fixture_case   # noqa: E402
+
+
+@pytest.mark.parametrize("case", _residual_fixture(), ids=[c["name"] for c in _residual_fixture()])
+def test_device_assembly_matches_the_independent_derivation(case):
+    """dflo_hip_residual, the cell averages, the CFL time step and one full SSP-RK step of the DEVICE against
+    tests/golden/residual_fixture.json (volume + face + boundary terms, M^-1, the stage combination -- derived in 60-digit
+    arithmetic from the weak form, tests/golden/make_residual_fixture.py), without the oracle in between; also through
+    the device-resident loop and with the mesh cut in two."""
+    mesh, claw, U0, R, A, dt, U1 = run_fixture_case(case, lambda m, p: dflo_amd.ConservationLaw(m, p))
+    claw.set_initial_condition(U0)
+    assert np.abs(claw.cell_average - A).max() <= 1e-14 * np.abs(A).max()
+    assert np.abs(claw.assemble_system() - R).max() <= 1e-12 * np.abs(R).max()
+    assert abs(claw.compute_time_step() - dt) <= 1e-13 * dt
+    claw.iterate_explicit(dt)
+    assert np.abs(claw.current_solution - U1).max() <= 1e-12 * np.abs(U1).max()
+    # the same step with dt formed on the device, and on two engines
+    mesh, again, *_ = run_fixture_case(case, lambda m, p: dflo_amd.ConservationLaw(m, p))
+    again.set_initial_condition(U0)
+    assert abs(again.advance(1) - dt) <= 1e-13 * dt
+    assert np.abs(again.current_solution - U1).max() <= 1e-12 * np.abs(U1).max()
+    if mesh.n_cells >= 8:
+        mesh, two, *_ = run_fixture_case(case, lambda m, p: dflo_amd.MultiConservationLaw(m, p, devices=[0, 0]))
+        two.set_initial_condition(U0)
+        assert np.abs(two.assemble_system() - R).max() <= 1e-12 * np.abs(R).max()
+        two.advance(1)
+        assert np.abs(two.current_solution - U1).max() <= 1e-12 * np.abs(U1).max()

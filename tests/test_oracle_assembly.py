@@ -322,3 +322,38 @@ def test_optimised_cpu_twin_equals_the_restatement(degree, flux, bnd):
     assert not c.twin_supported
     with pytest.raises(O.OracleError):
         c.twin_advance(1)
+
+
+# ---------------------------------------------------------------- the assembled path against the 60-digit derivation
+def _residual_fixture():
+    import json
+    import os
+    return json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "residual_fixture.json")))["cases"]
+
+
+def run_fixture_case(case, make_solver):
+    """shared by the oracle (here) and the device (tests/test_gpu_golden.py): right-hand side, cell averages, CFL time step
+    and the state after one SSP-RK step against tests/golden/residual_fixture.json (make_residual_fixture.py)"""
+    f = lambda v: np.array([float(x) for x in v])
+    mesh = dflo_amd.Mesh.cartesian(case["nx"], case["ny"], 0.0, 0.0, float(case["h"]), case["side"], case["degree"])
+    prm = dflo_amd.Parameters(flux=case["flux"], cfl=float(case["cfl"]), boundary={int(k): v for k, v in case["kinds"].items()})
+    s = make_solver(mesh, prm)
+    cell, face, bid, xy = s.boundary_faces()
+    bf = case["boundary_faces"]
+    assert [(b["cell"], b["face"], b["id"]) for b in bf] == list(zip(cell.tolist(), face.tolist(), bid.tolist()))
+    if bf:
+        bv = np.array([[[float(x) for x in pt] for pt in b["values"]] for b in bf])
+        s.set_boundary_values(0, bv)
+        s.set_boundary_values(1, bv)
+    return mesh, s, f(case["U0"]), f(case["residual"]), f(case["cell_average"]).reshape(-1, 4), float(case["dt"]), f(case["U1"])
+
+
+@pytest.mark.parametrize("case", _residual_fixture(), ids=[c["name"] for c in _residual_fixture()])
+def test_oracle_assembly_matches_the_independent_derivation(case):
+    mesh, ora, U0, R, A, dt, U1 = run_fixture_case(case, lambda m, p: O.Oracle(m, p))
+    ora.set_solution(U0)
+    assert np.abs(ora.get_cell_average() - A).max() <= 1e-14 * np.abs(A).max()
+    assert np.abs(ora.assemble() - R).max() <= 1e-12 * np.abs(R).max()
+    assert abs(ora.compute_time_step(0.0) - dt) <= 1e-13 * dt
+    ora.step(dt)
+    assert np.abs(ora.get_solution() - U1).max() <= 1e-12 * np.abs(U1).max()
