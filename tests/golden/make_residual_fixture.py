@@ -218,6 +218,140 @@ class Case:
         return Uc
 
 
+# ---------------------------------------------------------------- limiters
+def minmod(a, b, c, Mdx2):
+    """src/limiter.cc:15-30"""
+    if abs(a) < Mdx2:
+        return a
+    if a * b > 0 and b * c > 0:
+        return (1 if a > 0 else -1) * min(abs(a), abs(b), abs(c))
+    return D(0)
+
+
+def eigen_matrices(A):
+    """compute_eigen_matrix (src/equation.h:226-263) at the cell average; rows/columns in the order (rho, mx, my, E)"""
+    g1 = G - 1
+    rho, u, v, p = cf.prim(A)
+    q2, c2 = u * u + v * v, G * p / rho
+    c, beta, phi2, h = c2.sqrt(), 1 / (2 * c2), g1 * (u * u + v * v) / 2, c2 / g1 + (u * u + v * v) / 2
+    Rx = [[1, 0, 1, 1], [u, 0, u + c, u - c], [v, -1, v, v], [q2 / 2, -v, h + c * u, h - c * u]]
+    Ry = [[1, 0, 1, 1], [u, 1, u, u], [v, 0, v + c, v - c], [q2 / 2, u, h + c * v, h - c * v]]
+    Lx = [[1 - phi2 / c2, g1 * u / c2, g1 * v / c2, -g1 / c2], [v, 0, -1, 0],
+          [beta * (phi2 - c * u), beta * (c - g1 * u), -beta * g1 * v, beta * g1],
+          [beta * (phi2 + c * u), -beta * (c + g1 * u), -beta * g1 * v, beta * g1]]
+    Ly = [[1 - phi2 / c2, g1 * u / c2, g1 * v / c2, -g1 / c2], [-u, 1, 0, 0],
+          [beta * (phi2 - c * v), -beta * g1 * u, beta * (c - g1 * v), beta * g1],
+          [beta * (phi2 + c * v), -beta * g1 * u, -beta * (c + g1 * v), beta * g1]]
+    return Rx, Lx, Ry, Ly
+
+
+def to_char(L, W):      # W in dflo's order (mx, my, rho, E) -> characteristic variables, src/equation.h:268-285
+    V = [W[2], W[0], W[1], W[3]]
+    return [sum(D(L[i][j]) * V[j] for j in range(4)) for i in range(4)]
+
+
+def to_con(R, W):       # characteristic -> (mx, my, rho, E), src/equation.h:290-305
+    V = [sum(D(R[i][j]) * W[j] for j in range(4)) for i in range(4)]
+    return [V[1], V[2], V[0], V[3]]
+
+
+def tvb_qk(cs, U, M, beta, char_lim):
+    """apply_limiter_TVB_Qk (src/limiter.cc:225-370) on squares, every cell marked (shock indicator = limiter)"""
+    N, h = cs.N, cs.h
+    A = cs.averages(U)
+    out = [[list(comp) for comp in cell] for cell in U]
+    for j in range(cs.ny):
+        for i in range(cs.nx):
+            c = i + cs.nx * j
+            dx, Mdx2 = h, D(M) * h * h
+            # dx * average gradient: (1/|K|) sum_q grad u(x_q) JxW_q with the Gauss rule of the element
+            Dx, Dy = [], []
+            for comp in range(4):
+                gx = sum(cs.ws[a] * cs.ws[b] * sum(cs.Dm[a][m] * U[c][comp][m + N * b] for m in range(N)) for a in range(N) for b in range(N)) / h
+                gy = sum(cs.ws[a] * cs.ws[b] * sum(cs.Dm[b][m] * U[c][comp][a + N * m] for m in range(N)) for a in range(N) for b in range(N)) / h
+                Dx.append(dx * gx)
+                Dy.append(dx * gy)
+
+            def diff(f, own):     # backward / forward difference of the cell averages, or the own slope at a boundary
+                nb, bid = cs.neighbour(i, j, f)
+                if nb is None:
+                    return list(own)
+                return [A[c][k] - A[nb][k] for k in range(4)] if f in (0, 2) else [A[nb][k] - A[c][k] for k in range(4)]
+            dbx, dfx, dby, dfy = diff(0, Dx), diff(1, Dx), diff(2, Dy), diff(3, Dy)
+            if char_lim:
+                Rx, Lx, Ry, Ly = eigen_matrices(A[c])
+                dbx, dfx, Dx = to_char(Lx, dbx), to_char(Lx, dfx), to_char(Lx, Dx)
+                dby, dfy, Dy = to_char(Ly, dby), to_char(Ly, dfy), to_char(Ly, Dy)
+            Dxn = [minmod(Dx[k], D(beta) * dbx[k], D(beta) * dfx[k], Mdx2) for k in range(4)]
+            Dyn = [minmod(Dy[k], D(beta) * dby[k], D(beta) * dfy[k], Mdx2) for k in range(4)]
+            change = sum(abs(Dxn[k] - Dx[k]) for k in range(4)) / 4 + sum(abs(Dyn[k] - Dy[k]) for k in range(4)) / 4
+            if change > D("1e-10"):
+                Dxn, Dyn = [v / dx for v in Dxn], [v / dx for v in Dyn]
+                if char_lim:
+                    Dxn, Dyn = to_con(Rx, Dxn), to_con(Ry, Dyn)
+                for comp in range(4):
+                    for b in range(N):
+                        for a in range(N):
+                            out[c][comp][a + N * b] = A[c][comp] + (cs.xs[a] - D(1) / 2) * h * Dxn[comp] + (cs.xs[b] - D(1) / 2) * h * Dyn[comp]
+    return out
+
+
+def positivity(cs, U):
+    """apply_positivity_limiter (src/positivity.cc:17-208), Qk; returns (limited state, [theta1, theta2] per cell)"""
+    N, eps = cs.N, D("1e-13")
+    Ng = (cs.k + 3) // 2 if (cs.k + 3) % 2 == 0 else (cs.k + 4) // 2
+    gll = {2: [D(0), D(1)], 3: [D(0), D(1) / 2, D(1)]}[Ng]
+    A = cs.averages(U)
+    out = [[list(comp) for comp in cell] for cell in U]
+    thetas = []
+    for c in range(len(U)):
+        assert min(A[c][2], cf.prim(A[c])[3]) >= eps
+        def values(comp, d, state):   # the component at GLL(Ng) x Gauss(N) (d = 0) or Gauss(N) x GLL(Ng) (d = 1)
+            vals = []
+            for l in range(N):
+                for g in gll:
+                    if d == 0:
+                        vals.append(sum(lagrange(cs.xs, m, g) * state[c][comp][m + N * l] for m in range(N)))
+                    else:
+                        vals.append(sum(lagrange(cs.xs, m, g) * state[c][comp][l + N * m] for m in range(N)))
+            return vals
+        rho_min = min(values(2, 0, out) + values(2, 1, out))
+        th1 = min(abs(A[c][2] - eps) / (abs(A[c][2] - rho_min) + D("1e-13")), D(1))
+        if th1 < 1:
+            out[c][2] = [th1 * v + (1 - th1) * A[c][2] for v in out[c][2]]
+        th2 = D(1)
+        for d in range(2):
+            rho, mx, my, en = values(2, d, out), values(0, d, out), values(1, d, out), values(3, d, out)
+            for q in range(len(rho)):
+                pre = (G - 1) * (en[q] - (mx[q] * mx[q] + my[q] * my[q]) / (2 * rho[q]))
+                if pre < eps:
+                    drho, dmx, dmy, dE = rho[q] - A[c][2], mx[q] - A[c][0], my[q] - A[c][1], en[q] - A[c][3]
+                    a1 = 2 * drho * dE - (dmx * dmx + dmy * dmy)
+                    b1 = (2 * drho * (A[c][3] - eps / (G - 1)) + 2 * A[c][2] * dE - 2 * (A[c][0] * dmx + A[c][1] * dmy)) / a1
+                    c1 = (2 * A[c][2] * A[c][3] - (A[c][0] ** 2 + A[c][1] ** 2) - 2 * eps * A[c][2] / (G - 1)) / a1
+                    Dq = abs(b1 * b1 - 4 * c1).sqrt()
+                    t1, t2 = (-b1 - Dq) / 2, (-b1 + Dq) / 2
+                    lo, hi = D("-1e-12"), 1 + D("1e-12")
+                    t = t1 if lo < t1 < hi else t2
+                    assert lo < t < hi
+                    t = max(D(0), min(D(1), t))
+                    if abs(1 - t) < D("1e-14"):
+                        t = D(0)
+                    th2 = min(th2, t)
+        if th2 < 1:
+            out[c] = [[th2 * v + (1 - th2) * A[c][comp] for v in out[c][comp]] for comp in range(4)]
+        thetas.append([th1, th2])
+    return out, thetas
+
+
+def jump(x, y):
+    """a Sod-like jump across an oblique line, smooth variation on either side"""
+    left = x + y / 4 < D("0.55")
+    rho = (1 + y / 5) if left else (D("0.125") + x / 10)
+    p = (1 + x / 7) if left else (D("0.1") + y / 20)
+    return cf.cons(rho, D("0.1") + y / 6, D("-0.05") + x / 8, p)
+
+
 def smooth(x, y):
     """a smooth subsonic state with all gradients alive (polynomials: exact in decimal arithmetic)"""
     rho = 1 + (x * (1 - x) + y * y / 2) / 4
@@ -274,6 +408,34 @@ def main():
             "dt": format(dt, ".25e"), "U1": flat(U1), "boundary_faces": bfaces,
         })
         print(cs.name, "dt", format(dt, ".6e"), flush=True)
+    # ---- limiters: TVB (characteristic and component-wise, M = 0 and M > 0) and the positivity limiter
+    out["limiter_cases"] = []
+    wall = [0, 0, 0, 0]
+    for name, k, M, beta, char in [("6x4 Q1 TVB characteristic, M = 0", 1, "0", "2", True), ("6x4 Q2 TVB component-wise, M = 30", 2, "30", "1.5", False),
+                                    ("6x4 Q3 TVB characteristic, M = 5", 3, "5", "1", True)]:
+        cs = Case(name, 6, 4, D(1) / 6, k, "hllc", wall, {0: "outflow"}, "0.5", jump)
+        U0 = cs.initial()
+        U1 = tvb_qk(cs, U0, M, beta, char)
+        changed = sum(1 for c in range(len(U0)) if U0[c] != U1[c])
+        out["limiter_cases"].append({"name": name, "kind": "tvb", "nx": 6, "ny": 4, "h": format(cs.h, ".25e"), "degree": k, "side": wall,
+                                     "M": M, "beta": beta, "char_lim": char, "U0": flat(U0), "U1": flat(U1), "cells_changed": changed})
+        print(name, "cells changed", changed, flush=True)
+    for k in (1, 2, 3):
+        cs = Case("3x2 Q%d positivity" % k, 3, 2, D(1) / 3, k, "hllc", wall, {0: "outflow"}, "0.5", smooth)
+        U0 = cs.initial()
+        N = cs.N
+        # cell 1: density dips below zero at a Gauss-Lobatto point (theta1 < 1); cell 4: pressure does (theta2 root in (0, 1));
+        # cell 5: both; the others are left alone
+        for c, (dr, de) in {1: ("1.2", "0"), 4: ("0", "0.995"), 5: ("1.1", "0.85")}.items():
+            for b in range(N):
+                for a in range(N):
+                    wgt = (1 - cs.xs[a]) * (1 - cs.xs[b]) * 4 - 1          # zero mean over the cell: the average stays put
+                    U0[c][2][a + N * b] *= 1 + D(dr) * wgt
+                    U0[c][3][a + N * b] *= 1 - D(de) * (-wgt)
+        U1, th = positivity(cs, U0)
+        out["limiter_cases"].append({"name": cs.name, "kind": "positivity", "nx": 3, "ny": 2, "h": format(cs.h, ".25e"), "degree": k, "side": wall,
+                                     "U0": flat(U0), "U1": flat(U1), "theta": [[format(t, ".20e") for t in pair] for pair in th]})
+        print(cs.name, "theta", [[float(t) for t in pair] for pair in th], flush=True)
     json.dump(out, open(os.path.join(HERE, "residual_fixture.json"), "w"), indent=0)
     print("residual_fixture.json written")
 

@@ -178,3 +178,16 @@ def test_device_assembly_matches_the_independent_derivation(case):
         assert np.abs(two.assemble_system() - R).max() <= 1e-12 * np.abs(R).max()
         two.advance(1)
         assert np.abs(two.current_solution - U1).max() <= 1e-12 * np.abs(U1).max()
+
+
+from test_oracle_assembly import _limiter_fixture, run_limiter_case   # noqa: E402
+
+
+@pytest.mark.parametrize("case", _limiter_fixture(), ids=[c["name"] for c in _limiter_fixture()])
+def test_device_limiters_match_the_independent_derivation(case):
+    """limiter_kernel (TVB with and without the characteristic projection, M = 0 and M > 0; positivity with theta1 < 1,
+    theta2 < 1 and both) against the 60-digit derivation, single engine and two engines"""
+    got, want, before = run_limiter_case(case, lambda m, p: dflo_amd.ConservationLaw(m, p))
+    assert np.abs(got - want).max() <= 1e-12 * np.abs(want).max()
+    got2, want, before = run_limiter_case(case, lambda m, p: dflo_amd.MultiConservationLaw(m, p, devices=[0, 0]))
+    assert np.abs(got2 - want).max() <= 1e-12 * np.abs(want).max()
