@@ -352,6 +352,168 @@ def jump(x, y):
     return cf.cons(rho, D("0.1") + y / 6, D("-0.05") + x / 8, p)
 
 
+# ---------------------------------------------------------------- bilinear (MappingQ1) cells, SURVEY A.3
+class BilinearCase(Case):
+    """the same logical nx x ny grid with its interior vertices moved: every cell is a general quadrilateral.  Metric terms,
+    normals, face and cell JxW from the bilinear map; lumped mass M_j = w_j |J_j| (src/claw.cc:223-227); time step from
+    compute_time_step_q (src/claw.cc:520-557)."""
+
+    def __init__(self, name, nx, ny, h, k, flux, side, kinds, cfl, field, shift):
+        super().__init__(name, nx, ny, h, k, flux, side, kinds, cfl, field)
+        self.V = {}
+        for j in range(ny + 1):
+            for i in range(nx + 1):
+                sx, sy = shift(i, j) if (0 < i < nx and 0 < j < ny) else (D(0), D(0))
+                self.V[(i, j)] = (i * self.h + sx * self.h, j * self.h + sy * self.h)
+
+    def corners(self, i, j):   # deal.II order v0 v1 v2 v3
+        return [self.V[(i, j)], self.V[(i + 1, j)], self.V[(i, j + 1)], self.V[(i + 1, j + 1)]]
+
+    def xmap(self, i, j, xi, eta):
+        v = self.corners(i, j)
+        w = [(1 - xi) * (1 - eta), xi * (1 - eta), (1 - xi) * eta, xi * eta]
+        return sum(w[k] * v[k][0] for k in range(4)), sum(w[k] * v[k][1] for k in range(4))
+
+    def jac(self, i, j, xi, eta):
+        v = self.corners(i, j)
+        xxi = (1 - eta) * (v[1][0] - v[0][0]) + eta * (v[3][0] - v[2][0])
+        yxi = (1 - eta) * (v[1][1] - v[0][1]) + eta * (v[3][1] - v[2][1])
+        xet = (1 - xi) * (v[2][0] - v[0][0]) + xi * (v[3][0] - v[1][0])
+        yet = (1 - xi) * (v[2][1] - v[0][1]) + xi * (v[3][1] - v[1][1])
+        return xxi, yxi, xet, yet
+
+    def initial(self):
+        N, U = self.N, []
+        for j in range(self.ny):
+            for i in range(self.nx):
+                cell = [[None] * (N * N) for _ in range(4)]
+                for b in range(N):
+                    for a in range(N):
+                        W = self.field(*self.xmap(i, j, self.xs[a], self.xs[b]))
+                        for c in range(4):
+                            cell[c][a + N * b] = W[c]
+                U.append(cell)
+        return U
+
+    def jxw(self, i, j, a, b):
+        xxi, yxi, xet, yet = self.jac(i, j, self.xs[a], self.xs[b])
+        return self.ws[a] * self.ws[b] * (xxi * yet - xet * yxi)
+
+    def averages(self, U):
+        N, out = self.N, []
+        for j in range(self.ny):
+            for i in range(self.nx):
+                c = i + self.nx * j
+                area = sum(self.jxw(i, j, a, b) for a in range(N) for b in range(N))
+                out.append([sum(self.jxw(i, j, a, b) * U[c][comp][a + N * b] for a in range(N) for b in range(N)) / area for comp in range(4)])
+        return out
+
+    def face_geometry(self, i, j, f, q):
+        """(outward unit normal, length element |dx/dt|) at face point q"""
+        s = self.xs[q]
+        xi = D(0) if f == 0 else (D(1) if f == 1 else s)
+        eta = D(0) if f == 2 else (D(1) if f == 3 else s)
+        xxi, yxi, xet, yet = self.jac(i, j, xi, eta)
+        if f < 2:
+            tx, ty = xet, yet
+            n = (yet, -xet)          # the tangent turned clockwise points towards +xi
+            sign = 1 if f == 1 else -1
+        else:
+            tx, ty = xxi, yxi
+            n = (-yxi, xxi)          # the tangent turned counter-clockwise points towards +eta
+            sign = 1 if f == 3 else -1
+        ln = (tx * tx + ty * ty).sqrt()
+        return [sign * n[0] / ln, sign * n[1] / ln], ln
+
+    def face_point(self, i, j, f, q):
+        s = self.xs[q]
+        xi = D(0) if f == 0 else (D(1) if f == 1 else s)
+        eta = D(0) if f == 2 else (D(1) if f == 3 else s)
+        return self.xmap(i, j, xi, eta)
+
+    def residual(self, U, bc_time=None):
+        N, A = self.N, self.averages(U)
+        R = [[[D(0)] * (N * N) for _ in range(4)] for _ in U]
+        for j in range(self.ny):
+            for i in range(self.nx):
+                c = i + self.nx * j
+                Uc = U[c]
+                # volume: sum_q w_q [ (y_eta Fx - x_eta Fy) dphi/dxi + (-y_xi Fx + x_xi Fy) dphi/deta ]   (|J| cancels)
+                for b in range(N):
+                    for a in range(N):
+                        for comp in range(4):
+                            sacc = D(0)
+                            for q in range(N):
+                                xxi, yxi, xet, yet = self.jac(i, j, self.xs[q], self.xs[b])      # node (q, b): dphi_(a,b)/dxi = D[q][a]
+                                Fx, Fy = flux_xy([Uc[cc][q + N * b] for cc in range(4)])
+                                sacc += self.ws[q] * self.ws[b] * (yet * Fx[comp] - xet * Fy[comp]) * self.Dm[q][a]
+                                xxi, yxi, xet, yet = self.jac(i, j, self.xs[a], self.xs[q])      # node (a, q): dphi_(a,b)/deta = D[q][b]
+                                Fx, Fy = flux_xy([Uc[cc][a + N * q] for cc in range(4)])
+                                sacc += self.ws[a] * self.ws[q] * (-yxi * Fx[comp] + xxi * Fy[comp]) * self.Dm[q][b]
+                            R[c][comp][a + N * b] += sacc
+                for f in range(4):
+                    nb, bid = self.neighbour(i, j, f)
+                    for q in range(N):
+                        n, ln = self.face_geometry(i, j, f, q)
+                        Wp = self.trace(Uc, f, q)
+                        if nb is not None:
+                            Wm = self.trace(U[nb], f ^ 1, q)
+                            Fh = numerical_flux(self.flux, n, Wp, Wm, A[c], A[nb])
+                        else:
+                            bv = self.field(*self.face_point(i, j, f, q))
+                            Wm = cf.compute_Wminus(self.kinds[bid], n, Wp, bv)
+                            Fh = numerical_flux(self.flux, n, Wp, Wm, A[c], A[c])
+                        L = (self.L0 if f in (0, 2) else self.L1)
+                        for m in range(N):
+                            node = (m + N * q) if f < 2 else (q + N * m)
+                            for comp in range(4):
+                                R[c][comp][node] -= Fh[comp] * L[m] * self.ws[q] * ln
+        return R
+
+    def dt(self, U):
+        """compute_time_step_q: max of |v| + c over the 4 x 4 equispaced points, h = longest diagonal / sqrt(2)"""
+        N, best = self.N, None
+        for j in range(self.ny):
+            for i in range(self.nx):
+                c = i + self.nx * j
+                v = self.corners(i, j)
+                d1 = ((v[3][0] - v[0][0]) ** 2 + (v[3][1] - v[0][1]) ** 2).sqrt()
+                d2 = ((v[2][0] - v[1][0]) ** 2 + (v[2][1] - v[1][1]) ** 2).sqrt()
+                hh = max(d1, d2) / D(2).sqrt()
+                lam = D(0)
+                for pb in range(4):
+                    for pa in range(4):
+                        xi, eta = D(pa) / 3, D(pb) / 3
+                        W = [sum(lagrange(self.xs, a, xi) * lagrange(self.xs, b, eta) * U[c][comp][a + N * b] for a in range(N) for b in range(N))
+                             for comp in range(4)]
+                        rho, uu, vv, p = cf.prim(W)
+                        lam = max(lam, (uu * uu + vv * vv).sqrt() + (G * p / rho).sqrt())
+                d = self.cfl * hh / lam / (2 * self.k + 1)
+                best = d if best is None or d < best else best
+        return best
+
+    def step(self, U, dt):
+        N = self.N
+        ark = [D(0), D(1) / 2] if self.k == 1 else [D(0), D(3) / 4, D(1) / 3]
+        Un, Uc = U, U
+        for a_rk in ark:
+            R = self.residual(Uc)
+            new = []
+            for j in range(self.ny):
+                for i in range(self.nx):
+                    c = i + self.nx * j
+                    cell = [[None] * (N * N) for _ in range(4)]
+                    for comp in range(4):
+                        for b in range(N):
+                            for a in range(N):
+                                k = a + N * b
+                                u = Uc[c][comp][k] + dt * R[c][comp][k] / self.jxw(i, j, a, b)
+                                cell[comp][k] = a_rk * Un[c][comp][k] + (1 - a_rk) * u
+                    new.append(cell)
+            Uc = new
+        return Uc
+
+
 def smooth(x, y):
     """a smooth subsonic state with all gradients alive (polynomials: exact in decimal arithmetic)"""
     rho = 1 + (x * (1 - x) + y * y / 2) / 4
@@ -408,6 +570,34 @@ def main():
             "dt": format(dt, ".25e"), "U1": flat(U1), "boundary_faces": bfaces,
         })
         print(cs.name, "dt", format(dt, ".6e"), flush=True)
+    # ---- bilinear cells (the C5 path): interior vertices moved by up to a fifth of a cell
+    out["bilinear_cases"] = []
+    shift = lambda i, j: (D((7 * i + 3 * j) % 5 - 2) / 10, D((3 * i + 11 * j) % 5 - 2) / 10)
+    for name, k, flux, side, kinds, cfl in [
+            ("3x3 bilinear Q2 HLLC, inflow / outflow / slip / farfield walls", 2, "hllc", [2, 1, 0, 3], {0: "slip", 1: "outflow", 2: "inflow", 3: "farfield"}, "0.6"),
+            ("3x3 bilinear Q3 KFVS, slip and outflow walls", 3, "kfvs", [2, 1, 0, 0], {0: "slip", 1: "outflow", 2: "inflow"}, "0.5"),
+            ("4x3 bilinear Q1 LxF", 1, "lxf", [2, 1, 0, 3], {0: "slip", 1: "outflow", 2: "inflow", 3: "farfield"}, "0.7")]:
+        nx = 4 if name.startswith("4x3") else 3
+        cs = BilinearCase(name, nx, 3, D(1) / 3, k, flux, side, kinds, cfl, smooth, shift)
+        U0 = cs.initial()
+        R, dt = cs.residual(U0), cs.dt(U0)
+        U1 = cs.step(U0, dt)
+        bfaces = []
+        for j in range(cs.ny):
+            for i in range(cs.nx):
+                for f in range(4):
+                    nb, bid = cs.neighbour(i, j, f)
+                    if nb is None:
+                        bfaces.append({"cell": i + cs.nx * j, "face": f, "id": bid,
+                                       "values": [[format(v, ".25e") for v in cs.field(*cs.face_point(i, j, f, q))] for q in range(cs.N)]})
+        verts = [[format(cs.V[(i, j)][0], ".25e"), format(cs.V[(i, j)][1], ".25e")] for j in range(cs.ny + 1) for i in range(cs.nx + 1)]
+        nodes = [[format(c2, ".25e") for c2 in cs.xmap(i, j, cs.xs[a], cs.xs[b])] for j in range(cs.ny) for i in range(cs.nx)
+                 for b in range(cs.N) for a in range(cs.N)]
+        out["bilinear_cases"].append({
+            "name": name, "nx": cs.nx, "ny": cs.ny, "degree": k, "flux": flux, "side": side, "kinds": {str(a): b for a, b in kinds.items()},
+            "cfl": cfl, "vertices": verts, "nodes": nodes, "U0": flat(U0), "residual": flat(R),
+            "cell_average": [format(v, ".25e") for a in cs.averages(U0) for v in a], "dt": format(dt, ".25e"), "U1": flat(U1), "boundary_faces": bfaces})
+        print(name, "dt", format(dt, ".6e"), flush=True)
     # ---- limiters: TVB (characteristic and component-wise, M = 0 and M > 0) and the positivity limiter
     out["limiter_cases"] = []
     wall = [0, 0, 0, 0]

@@ -191,3 +191,23 @@ def test_device_limiters_match_the_independent_derivation(case):
     assert np.abs(got - want).max() <= 1e-12 * np.abs(want).max()
     got2, want, before = run_limiter_case(case, lambda m, p: dflo_amd.MultiConservationLaw(m, p, devices=[0, 0]))
     assert np.abs(got2 - want).max() <= 1e-12 * np.abs(want).max()
+
+
+from test_oracle_assembly import _bilinear_fixture, run_bilinear_case   # noqa: E402
+
+
+@pytest.mark.parametrize("case", _bilinear_fixture(), ids=[c["name"] for c in _bilinear_fixture()])
+def test_device_on_bilinear_cells_matches_the_independent_derivation(case):
+    """the C5 path (general quadrilaterals, MappingQ1: metric terms, face normals and lengths, lumped mass,
+    compute_time_step_q) of the DEVICE against the 60-digit derivation: residual, averages, time step, one SSP-RK step"""
+    mesh, claw, U0, R, A, dt, U1 = run_bilinear_case(case, lambda m, p: dflo_amd.ConservationLaw(m, p))
+    claw.set_initial_condition(U0)
+    assert np.abs(claw.cell_average - A).max() <= 1e-14 * np.abs(A).max()
+    assert np.abs(claw.assemble_system() - R).max() <= 1e-12 * np.abs(R).max()
+    assert abs(claw.compute_time_step() - dt) <= 1e-13 * dt
+    claw.iterate_explicit(dt)
+    assert np.abs(claw.current_solution - U1).max() <= 1e-12 * np.abs(U1).max()
+    mesh, two, *_ = run_bilinear_case(case, lambda m, p: dflo_amd.MultiConservationLaw(m, p, devices=[0, 0], partitioner="rcb"))
+    two.set_initial_condition(U0)
+    assert abs(two.advance(1) - dt) <= 1e-13 * dt
+    assert np.abs(two.current_solution - U1).max() <= 1e-12 * np.abs(U1).max()

@@ -391,3 +391,49 @@ def test_oracle_limiters_match_the_independent_derivation(case):
     got, want, before = run_limiter_case(case, lambda m, p: O.Oracle(m, p))
     assert np.abs(want - before).max() > 1e-3          # the case limits something
     assert np.abs(got - want).max() <= 1e-12 * np.abs(want).max()
+
+
+def _bilinear_fixture():
+    import json
+    import os
+    return json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "residual_fixture.json")))["bilinear_cases"]
+
+
+def run_bilinear_case(case, make_solver):
+    """general quadrilaterals (MappingQ1, the C5 path): metric terms, normals, lumped mass, compute_time_step_q against the
+    60-digit derivation; shared by the oracle and the device"""
+    f = lambda v: np.array([float(x) for x in v])
+    nx, ny = case["nx"], case["ny"]
+    verts = np.array([[float(a), float(b)] for a, b in case["vertices"]])
+    vid = lambda i, j: i + (nx + 1) * j
+    quads = np.array([[vid(i, j), vid(i + 1, j), vid(i + 1, j + 1), vid(i, j + 1)] for j in range(ny) for i in range(nx)], dtype=np.int32)
+    bed, bid = [], []
+    for i in range(nx):
+        bed += [[vid(i, 0), vid(i + 1, 0)], [vid(i, ny), vid(i + 1, ny)]]
+        bid += [case["side"][2], case["side"][3]]
+    for j in range(ny):
+        bed += [[vid(0, j), vid(0, j + 1)], [vid(nx, j), vid(nx, j + 1)]]
+        bid += [case["side"][0], case["side"][1]]
+    mesh = dflo_amd.Mesh.from_quads(verts, quads, np.array(bed, dtype=np.int32), np.array(bid, dtype=np.int32), case["degree"])
+    nodes = np.array([[float(a), float(b)] for a, b in case["nodes"]]).reshape(mesh.n_cells, -1, 2)
+    assert np.abs(mesh.support_points() - nodes).max() < 1e-14        # the same cells, the same node order
+    prm = dflo_amd.Parameters(flux=case["flux"], cfl=float(case["cfl"]), boundary={int(k): v for k, v in case["kinds"].items()})
+    s = make_solver(mesh, prm)
+    cell, face, b, xy = s.boundary_faces()
+    bf = case["boundary_faces"]
+    assert [(x["cell"], x["face"], x["id"]) for x in bf] == list(zip(cell.tolist(), face.tolist(), b.tolist()))
+    bv = np.array([[[float(x) for x in pt] for pt in x["values"]] for x in bf])
+    s.set_boundary_values(0, bv)
+    s.set_boundary_values(1, bv)
+    return mesh, s, f(case["U0"]), f(case["residual"]), f(case["cell_average"]).reshape(-1, 4), float(case["dt"]), f(case["U1"])
+
+
+@pytest.mark.parametrize("case", _bilinear_fixture(), ids=[c["name"] for c in _bilinear_fixture()])
+def test_oracle_on_bilinear_cells_matches_the_independent_derivation(case):
+    mesh, ora, U0, R, A, dt, U1 = run_bilinear_case(case, lambda m, p: O.Oracle(m, p))
+    ora.set_solution(U0)
+    assert np.abs(ora.get_cell_average() - A).max() <= 1e-14 * np.abs(A).max()
+    assert np.abs(ora.assemble() - R).max() <= 1e-12 * np.abs(R).max()
+    assert abs(ora.compute_time_step(0.0) - dt) <= 1e-13 * dt
+    ora.step(dt)
+    assert np.abs(ora.get_solution() - U1).max() <= 1e-12 * np.abs(U1).max()
