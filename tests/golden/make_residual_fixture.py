@@ -514,6 +514,130 @@ class BilinearCase(Case):
         return Uc
 
 
+# ---------------------------------------------------------------- Pk (FE_DGP) basis, SURVEY A.10
+def pt_legendre(n, x):
+    """orthonormal Legendre polynomial on [0, 1] and its derivative: sqrt(2n+1) P_n(2x-1)"""
+    t = 2 * x - 1
+    if n == 0:
+        return D(1), D(0)
+    p0, p1, d0, d1 = D(1), t, D(0), D(1)
+    for k in range(2, n + 1):
+        p0, p1, d0, d1 = p1, ((2 * k - 1) * t * p1 - (k - 1) * p0) / k, d1, ((2 * k - 1) * (p1 + t * d1) - (k - 1) * d0) / k
+    s = D(2 * n + 1).sqrt()
+    return s * p1, 2 * s * d1
+
+
+class PkCase(Case):
+    """modal DoFs U[cell][comp][m], psi_m = Pt_i(xi) Pt_j(eta), modes ordered "for j: for i <= k - j" (src/claw.cc:107-113);
+    mass matrix |K| I; initial state by L2 projection with QGauss(k+1) (src/ic.cc:128-164)"""
+
+    def __init__(self, *args):
+        super().__init__(*args)
+        self.modes = [(i, j) for j in range(self.N) for i in range(self.N - j)]
+
+    def psi(self, m, xi, eta):
+        i, j = self.modes[m]
+        pi, dpi = pt_legendre(i, xi)
+        pj, dpj = pt_legendre(j, eta)
+        return pi * pj, dpi * pj, pi * dpj
+
+    def value(self, Uc, xi, eta):
+        return [sum(Uc[comp][m] * self.psi(m, xi, eta)[0] for m in range(len(self.modes))) for comp in range(4)]
+
+    def initial(self):
+        N, U = self.N, []
+        for j in range(self.ny):
+            for i in range(self.nx):
+                cell = [[D(0)] * len(self.modes) for _ in range(4)]
+                for b in range(N):
+                    for a in range(N):
+                        W = self.field(self.x0 + (i + self.xs[a]) * self.h, self.y0 + (j + self.xs[b]) * self.h)
+                        for m in range(len(self.modes)):
+                            ps = self.psi(m, self.xs[a], self.xs[b])[0]
+                            for comp in range(4):
+                                cell[comp][m] += W[comp] * ps * self.ws[a] * self.ws[b]
+                U.append(cell)
+        return U
+
+    def averages(self, U):
+        return [[U[c][comp][0] for comp in range(4)] for c in range(len(U))]
+
+    def trace(self, Uc, f, q):
+        s = self.xs[q]
+        xi = D(0) if f == 0 else (D(1) if f == 1 else s)
+        eta = D(0) if f == 2 else (D(1) if f == 3 else s)
+        return self.value(Uc, xi, eta)
+
+    def residual(self, U, bc_time=None):
+        N, h, A, nm = self.N, self.h, self.averages(U), len(self.modes)
+        R = [[[D(0)] * nm for _ in range(4)] for _ in U]
+        normals = [[D(-1), D(0)], [D(1), D(0)], [D(0), D(-1)], [D(0), D(1)]]
+        for j in range(self.ny):
+            for i in range(self.nx):
+                c = i + self.nx * j
+                for b in range(N):
+                    for a in range(N):
+                        Fx, Fy = flux_xy(self.value(U[c], self.xs[a], self.xs[b]))
+                        jxw = self.ws[a] * self.ws[b] * h * h
+                        for m in range(nm):
+                            _, px, py = self.psi(m, self.xs[a], self.xs[b])
+                            for comp in range(4):
+                                R[c][comp][m] += (Fx[comp] * px / h + Fy[comp] * py / h) * jxw
+                for f in range(4):
+                    nb, bid = self.neighbour(i, j, f)
+                    n = normals[f]
+                    for q in range(N):
+                        Wp = self.trace(U[c], f, q)
+                        if nb is not None:
+                            Fh = numerical_flux(self.flux, n, Wp, self.trace(U[nb], f ^ 1, q), A[c], A[nb])
+                        else:
+                            Wm = cf.compute_Wminus(self.kinds[bid], n, Wp, self.field(*self.face_point(i, j, f, q)))
+                            Fh = numerical_flux(self.flux, n, Wp, Wm, A[c], A[c])
+                        s = self.xs[q]
+                        xi = D(0) if f == 0 else (D(1) if f == 1 else s)
+                        eta = D(0) if f == 2 else (D(1) if f == 3 else s)
+                        for m in range(nm):
+                            ps = self.psi(m, xi, eta)[0]
+                            for comp in range(4):
+                                R[c][comp][m] -= Fh[comp] * ps * self.ws[q] * h
+        return R
+
+    def step(self, U, dt):
+        ark = [D(0), D(1) / 2] if self.k == 1 else [D(0), D(3) / 4, D(1) / 3]
+        Un, Uc = U, U
+        for a_rk in ark:
+            R = self.residual(Uc)
+            Uc = [[[a_rk * Un[c][comp][m] + (1 - a_rk) * (Uc[c][comp][m] + dt * R[c][comp][m] / (self.h * self.h)) for m in range(len(self.modes))]
+                   for comp in range(4)] for c in range(len(Uc))]
+        return Uc
+
+
+def kxrcf(cs, U, component):
+    """compute_shock_indicator_kxrcf (src/indicator.cc:51-198) on squares, Qk: jump of the indicator variable over the inflow
+    part of the cell boundary (inflow judged by the cell-average velocity), boundary faces skipped"""
+    N, h, A = cs.N, cs.h, cs.averages(U)
+    out = []
+    normals = [[D(-1), D(0)], [D(1), D(0)], [D(0), D(-1)], [D(0), D(1)]]
+    for j in range(cs.ny):
+        for i in range(cs.nx):
+            c = i + cs.nx * j
+            vel = [A[c][0] / A[c][2], A[c][1] / A[c][2]]
+            ind, measure = D(0), D(0)
+            for f in range(4):
+                nb, bid = cs.neighbour(i, j, f)
+                if nb is None:
+                    continue
+                inflow = 1 if vel[0] * normals[f][0] + vel[1] * normals[f][1] < 0 else 0
+                for q in range(N):
+                    jxw = cs.ws[q] * h
+                    ind += inflow * (cs.trace(U[c], f, q)[component] - cs.trace(U[nb], f ^ 1, q)[component]) * jxw
+                    measure += inflow * jxw
+            diam = h * D(2).sqrt()
+            den = (diam ** (D(cs.k + 1) / 2)) * measure * A[c][component]
+            out.append(abs(ind) / den if den != 0 else None)
+    return out
+
+
 def smooth(x, y):
     """a smooth subsonic state with all gradients alive (polynomials: exact in decimal arithmetic)"""
     rho = 1 + (x * (1 - x) + y * y / 2) / 4
@@ -598,6 +722,38 @@ def main():
             "cfl": cfl, "vertices": verts, "nodes": nodes, "U0": flat(U0), "residual": flat(R),
             "cell_average": [format(v, ".25e") for a in cs.averages(U0) for v in a], "dt": format(dt, ".25e"), "U1": flat(U1), "boundary_faces": bfaces})
         print(name, "dt", format(dt, ".6e"), flush=True)
+    # ---- Pk basis (modal DoFs): projection, residual, time step, one step
+    out["pk_cases"] = []
+    for name, nx, ny, k, flux, side, kinds, cfl, field in [
+            ("4x3 periodic P2 HLLC", 4, 3, 2, "hllc", [-1, -1, -1, -1], {}, "0.9", lambda x, y: periodic(x, y * 4 / 3)),
+            ("3x3 P1 LxF with walls", 3, 3, 1, "lxf", [2, 1, 0, 3], {0: "slip", 1: "outflow", 2: "inflow", 3: "farfield"}, "0.8", smooth),
+            ("2x2 periodic P3 Roe", 2, 2, 3, "roe", [-1, -1, -1, -1], {}, "0.5", periodic)]:
+        cs = PkCase(name, nx, ny, D(1) / (4 if nx == 4 else nx), k, flux, side, kinds, cfl, field)
+        U0 = cs.initial()
+        R, dt = cs.residual(U0), cs.dt(U0)
+        U1 = cs.step(U0, dt)
+        bfaces = []
+        for j in range(cs.ny):
+            for i in range(cs.nx):
+                for f in range(4):
+                    nb, bid = cs.neighbour(i, j, f)
+                    if nb is None:
+                        bfaces.append({"cell": i + cs.nx * j, "face": f, "id": bid,
+                                       "values": [[format(v, ".25e") for v in cs.field(*cs.face_point(i, j, f, q))] for q in range(cs.N)]})
+        out["pk_cases"].append({"name": name, "nx": nx, "ny": ny, "h": format(cs.h, ".25e"), "degree": k, "flux": flux, "side": side,
+                                "kinds": {str(a): b for a, b in kinds.items()}, "cfl": cfl, "U0": flat(U0), "residual": flat(R),
+                                "cell_average": [format(v, ".25e") for a in cs.averages(U0) for v in a], "dt": format(dt, ".25e"),
+                                "U1": flat(U1), "boundary_faces": bfaces})
+        print(name, "dt", format(dt, ".6e"), flush=True)
+    # ---- KXRCF troubled-cell indicator
+    out["kxrcf_cases"] = []
+    for name, k, comp, cname in [("6x4 Q1 KXRCF density", 1, 2, "density"), ("6x4 Q2 KXRCF energy", 2, 3, "energy"), ("6x4 Q3 KXRCF density", 3, 2, "density")]:
+        cs = Case(name, 6, 4, D(1) / 6, k, "hllc", [0, 0, 0, 0], {0: "outflow"}, "0.5", jump)
+        U0 = cs.initial()
+        ind = kxrcf(cs, U0, comp)
+        out["kxrcf_cases"].append({"name": name, "nx": 6, "ny": 4, "h": format(cs.h, ".25e"), "degree": k, "variable": cname, "U0": flat(U0),
+                                   "indicator": [format(v, ".25e") if v is not None else "nan" for v in ind]})
+        print(name, "cells over 1:", sum(1 for v in ind if v is not None and v > 1), flush=True)
     # ---- limiters: TVB (characteristic and component-wise, M = 0 and M > 0) and the positivity limiter
     out["limiter_cases"] = []
     wall = [0, 0, 0, 0]

@@ -211,3 +211,33 @@ def test_device_on_bilinear_cells_matches_the_independent_derivation(case):
     two.set_initial_condition(U0)
     assert abs(two.advance(1) - dt) <= 1e-13 * dt
     assert np.abs(two.current_solution - U1).max() <= 1e-12 * np.abs(U1).max()
+
+
+from test_oracle_assembly import _pk_fixture, _kxrcf_fixture, run_kxrcf_case   # noqa: E402
+
+
+@pytest.mark.parametrize("case", _pk_fixture(), ids=[c["name"] for c in _pk_fixture()])
+def test_device_pk_assembly_matches_the_independent_derivation(case):
+    """stage_pk_kernel (modal DoFs, FE_DGP) against the 60-digit derivation: averages, residual, time step, one SSP-RK step,
+    single engine and two engines"""
+    mesh, claw, U0, R, A, dt, U1 = run_fixture_case(case, lambda m, p: dflo_amd.ConservationLaw(m, p), basis="Pk")
+    claw.set_initial_condition(U0)
+    assert np.abs(claw.cell_average - A).max() <= 1e-14 * np.abs(A).max()
+    assert np.abs(claw.assemble_system() - R).max() <= 1e-12 * np.abs(R).max()
+    assert abs(claw.compute_time_step() - dt) <= 1e-13 * dt
+    claw.iterate_explicit(dt)
+    assert np.abs(claw.current_solution - U1).max() <= 1e-12 * np.abs(U1).max()
+    if mesh.n_cells >= 8:
+        mesh, two, *_ = run_fixture_case(case, lambda m, p: dflo_amd.MultiConservationLaw(m, p, devices=[0, 0]), basis="Pk")
+        two.set_initial_condition(U0)
+        assert abs(two.advance(1) - dt) <= 1e-13 * dt
+        assert np.abs(two.current_solution - U1).max() <= 1e-12 * np.abs(U1).max()
+
+
+@pytest.mark.parametrize("case", _kxrcf_fixture(), ids=[c["name"] for c in _kxrcf_fixture()])
+def test_device_kxrcf_matches_the_independent_derivation(case):
+    """indicator_kernel against the 60-digit derivation of src/indicator.cc:51-198"""
+    got, want = run_kxrcf_case(case, lambda m, p: dflo_amd.ConservationLaw(m, p))
+    ok = np.isfinite(want)
+    assert (np.isfinite(got) == ok).all()
+    assert np.abs(got[ok] - want[ok]).max() <= 1e-12 * np.abs(want[ok]).max()

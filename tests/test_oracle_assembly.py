@@ -331,11 +331,13 @@ def _residual_fixture():
     return json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "residual_fixture.json")))["cases"]
 
 
-def run_fixture_case(case, make_solver):
+def run_fixture_case(case, make_solver, basis="Qk"):
     """shared by the oracle (here) and the device (tests/test_gpu_golden.py): right-hand side, cell averages, CFL time step
     and the state after one SSP-RK step against tests/golden/residual_fixture.json (make_residual_fixture.py)"""
     f = lambda v: np.array([float(x) for x in v])
     mesh = dflo_amd.Mesh.cartesian(case["nx"], case["ny"], 0.0, 0.0, float(case["h"]), case["side"], case["degree"])
+    if basis != "Qk":
+        mesh.set_basis(basis)
     prm = dflo_amd.Parameters(flux=case["flux"], cfl=float(case["cfl"]), boundary={int(k): v for k, v in case["kinds"].items()})
     s = make_solver(mesh, prm)
     cell, face, bid, xy = s.boundary_faces()
@@ -437,3 +439,46 @@ def test_oracle_on_bilinear_cells_matches_the_independent_derivation(case):
     assert abs(ora.compute_time_step(0.0) - dt) <= 1e-13 * dt
     ora.step(dt)
     assert np.abs(ora.get_solution() - U1).max() <= 1e-12 * np.abs(U1).max()
+
+
+def _pk_fixture():
+    import json
+    import os
+    return json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "residual_fixture.json")))["pk_cases"]
+
+
+@pytest.mark.parametrize("case", _pk_fixture(), ids=[c["name"] for c in _pk_fixture()])
+def test_oracle_pk_assembly_matches_the_independent_derivation(case):
+    """the modal (FE_DGP) path: L2-projected state, residual against every mode, M = |K| I, one SSP-RK step"""
+    mesh, ora, U0, R, A, dt, U1 = run_fixture_case(case, lambda m, p: O.Oracle(m, p), basis="Pk")
+    ora.set_solution(U0)
+    assert np.abs(ora.get_cell_average() - A).max() <= 1e-14 * np.abs(A).max()
+    assert np.abs(ora.assemble() - R).max() <= 1e-12 * np.abs(R).max()
+    assert abs(ora.compute_time_step(0.0) - dt) <= 1e-13 * dt
+    ora.step(dt)
+    assert np.abs(ora.get_solution() - U1).max() <= 1e-12 * np.abs(U1).max()
+
+
+def _kxrcf_fixture():
+    import json
+    import os
+    return json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "residual_fixture.json")))["kxrcf_cases"]
+
+
+def run_kxrcf_case(case, make_solver):
+    """KXRCF troubled-cell indicator (src/indicator.cc:51-198) against the 60-digit derivation; shared with the device"""
+    f = lambda v: np.array([float(x) for x in v])
+    mesh = dflo_amd.Mesh.cartesian(case["nx"], case["ny"], 0.0, 0.0, float(case["h"]), [0, 0, 0, 0], case["degree"])
+    prm = dflo_amd.Parameters(flux="hllc", limiter="TVB", shock_indicator=case["variable"], boundary={0: "outflow"})
+    s = make_solver(mesh, prm)
+    set_state = s.set_solution if hasattr(s, "set_solution") else s.set_initial_condition
+    set_state(f(case["U0"]))
+    return s.compute_shock_indicator(), f(case["indicator"])
+
+
+@pytest.mark.parametrize("case", _kxrcf_fixture(), ids=[c["name"] for c in _kxrcf_fixture()])
+def test_oracle_kxrcf_matches_the_independent_derivation(case):
+    got, want = run_kxrcf_case(case, lambda m, p: O.Oracle(m, p))
+    ok = np.isfinite(want)
+    assert (np.isfinite(got) == ok).all() and ok.sum() >= 20 and (want[ok] > 1).sum() >= 4
+    assert np.abs(got[ok] - want[ok]).max() <= 1e-12 * np.abs(want[ok]).max()
