@@ -91,6 +91,8 @@ struct dflo_hip_engine {
   double *ghost_stage = nullptr;
   size_t lds_bytes = 0;
   int stage_grid = 8, prefetch_ahead = 1 << 30;
+  int sweep_mode = 1, sweep_dir = 0;   // every launch over all shards walks them against the previous one (DFLO_SWEEP=0: always forward)
+  int stream_override = -1;            // DFLO_STREAM=0/1 forces the streaming-store variant off / on
   unsigned long long *phase_cycles = nullptr;
   int max_fp = 0;
   // timing
@@ -186,6 +188,7 @@ stage_fn pick_stage(int N, int flux, int mode, int geo, int pos = 0, int nt = 0)
 
 // does nothing read the new state between this stage kernel and the next (no limiter / indicator pass over all cells)?
 int streams_out(const dflo_hip_engine *h);
+int next_sweep(dflo_hip_engine *h, int part);
 
 int grid_for(int n_shards) { return ((n_shards + 7) / 8) * 8; }
 
@@ -373,6 +376,7 @@ int launch_update(dflo_hip_engine *h, double *rhs_out, int part) {
   a.kb = h->kb;
   part_list(h, part, &a.shard_list, &a.n_list);
   if (a.n_list == 0) return DFLO_OK;
+  a.sweep_rev = next_sweep(h, part);
   const int mode_ = rhs_out ? 2 : (h->ark[rk] != 0.0 ? 1 : 0);
   a.flags = h->flags;
   a.step_index = (int)h->steps_done;
@@ -450,6 +454,7 @@ int launch_limiter(dflo_hip_engine *h, int tvb, int pos, int part, bool stage_da
   part_list(h, part, &l.shard_list, &l.n_list);
   if (l.dtq) h->dtq_parts |= part == 0 ? 3 : part;
   if (l.n_list == 0) return DFLO_OK;
+  l.sweep_rev = next_sweep(h, part);
   void (*lf)(const LimArgs) = h->N == 2 ? limiter_kernel<2> : (h->N == 3 ? limiter_kernel<3> : limiter_kernel<4>);
   if (h->basis == DFLO_BASIS_PK) lf = h->N == 2 ? limiter_pk_kernel<2> : (h->N == 3 ? limiter_pk_kernel<3> : limiter_pk_kernel<4>);
   hipLaunchKernelGGL(lf, dim3(grid_for(l.n_list)), dim3(64), 0, h->stream, l);
@@ -567,7 +572,16 @@ int check_handle(dflo_hip_handle h) { return h ? DFLO_OK : DFLO_ERR_BAD_PARAM; }
 int streams_out(const dflo_hip_engine *h) {
   const bool limited = h->prm.limiter_type != DFLO_LIMITER_NONE || h->prm.pos_lim;
   const bool full_pass = limited && !h->fuse_pos && !h->lim_mask;
+  if (h->stream_override >= 0) return h->stream_override;
   return (full_pass || h->d_shock) ? 0 : 1;
+}
+
+// direction of the next launch over all shards (parts of a rim / interior split keep the forward order)
+int next_sweep(dflo_hip_engine *h, int part) {
+  if (!h->sweep_mode || part != 0) return 0;
+  const int d = h->sweep_dir;
+  h->sweep_dir ^= 1;
+  return d;
 }
 
 void part_list(const dflo_hip_engine *h, int part, const int32_t **list, int *n) {
@@ -639,6 +653,8 @@ int dflo_hip_create(const dflo_mesh_t *mesh, const dflo_params_t *params, int de
   h->N = mesh->degree + 1;
   h->basis = mesh->basis;
   if (const char *e = std::getenv("DFLO_GRAPH")) h->use_graph = std::atoi(e) != 0;
+  if (const char *e = std::getenv("DFLO_SWEEP")) h->sweep_mode = std::atoi(e);
+  if (const char *e = std::getenv("DFLO_STREAM")) h->stream_override = std::atoi(e) != 0;
   h->ns = mesh->basis == DFLO_BASIS_PK ? h->N * (h->N + 1) / 2 : h->N * h->N;
   h->ndof = 4 * h->ns;
   h->mapping = mesh->mapping;

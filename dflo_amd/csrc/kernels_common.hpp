@@ -70,6 +70,7 @@ struct StageArgs {
   int n_shards, max_fp, max_faces, max_bnd, uniform_h, want_dt, degree, prefetch_ahead;
   const int32_t *shard_list;  // null: all shards; else the n_list shards of this launch (rim / interior)
   int n_list;
+  int sweep_rev;              // see shard_of_block
   int *flags;   // POS 1: [0] negative mean state, [1] positivity root failure (as LimArgs::flags)
   int step_index; // time step this launch belongs to (host count since set_solution), recorded with a raised flag
   const double *Tg;        // multi-device: traces of the ghost cells on the cut faces, [n_ghost_traces][4][N], of the state being read
@@ -169,10 +170,13 @@ __device__ __forceinline__ double wave_min_lane63(double v) {
 
 // blockIdx -> shard so that every XCD (block b runs on XCD b % 8) sweeps one contiguous run of
 // the Morton-ordered shards: halo re-reads then hit that XCD's own L2.
-__device__ __forceinline__ int shard_of_block(int b, int n_shards) {
+// rev: the XCD walks its run backwards -- a launch that sweeps against the previous one starts on the shards that one
+// touched last, which are still in the XCD's L2.
+__device__ __forceinline__ int shard_of_block(int b, int n_shards, int rev = 0) {
   const int chunk = (n_shards + 7) >> 3;
-  const int s = (b & 7) * chunk + (b >> 3);
-  return (b >> 3) < chunk && s < n_shards ? s : -1;
+  const int i = b >> 3;
+  const int s = (b & 7) * chunk + (rev ? chunk - 1 - i : i);
+  return i < chunk && s < n_shards ? s : -1;
 }
 
 // ------------------------------------------------------------------ positivity limiter, pointwise parts

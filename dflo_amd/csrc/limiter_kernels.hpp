@@ -53,6 +53,7 @@ struct LimArgs {
   int conserve_ang_mom;   // Pk: src/limiter.cc:496-500
   const int32_t *shard_list;
   int n_list;
+  int sweep_rev;
   const double *shock;  // KXRCF indicator per cell, or null: "shock indicator = limiter" marks every cell (1e20)
   unsigned long long *mask;   // [n_shards] from the stage kernel: the cells this pass can change (cleared here), or null: all cells
   // bilinear cells, last stage: the time step of the limited solution is formed here, while the cell is in registers
@@ -67,7 +68,7 @@ struct LimArgs {
 template <int N>
 __global__ __launch_bounds__(64) void limiter_kernel(const LimArgs a) {
   constexpr int NS = N * N, NDOF = 4 * NS;
-  const int sidx = shard_of_block(blockIdx.x, a.n_list);
+  const int sidx = shard_of_block(blockIdx.x, a.n_list, a.sweep_rev);
   if (sidx < 0) return;
   const int shard = a.shard_list ? a.shard_list[sidx] : sidx;
   const int lane = threadIdx.x;

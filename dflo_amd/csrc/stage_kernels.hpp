@@ -441,7 +441,7 @@ __global__ __launch_bounds__(64 * N, ((GEO == 1 && N != 3) || N == 4) ? 2 : 3) v
   constexpr int TROWS = 4 * N + (FLUX == DFLO_FLUX_LXF ? 3 : 0); // halo image: face trace (+ the same three)
   constexpr int S = 65;                                          // own-cell row stride: 1 mod 32 doubles
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  const int sidx = shard_of_block(blockIdx.x, a.n_list);
+  const int sidx = shard_of_block(blockIdx.x, a.n_list, a.sweep_rev);
   if (sidx < 0) return;
   const int shard = a.shard_list ? a.shard_list[sidx] : sidx;
   const int tid = threadIdx.x;
@@ -466,7 +466,7 @@ __global__ __launch_bounds__(64 * N, ((GEO == 1 && N != 3) || N == 4) ? 2 : 3) v
   //      a load issued through inline asm writes its register whenever the data arrives.
   int pf0 = 0, pf1 = 0, pf2 = 0;
   {
-    const int ahead = min(shard + a.prefetch_ahead, a.n_shards - 1);
+    const int ahead = a.sweep_rev ? max(shard - a.prefetch_ahead, 0) : min(shard + a.prefetch_ahead, a.n_shards - 1);
     const int32_t *p0 = a.halo_pad + (size_t)ahead * a.halo_pitch + (tid & 31);
     const uint32_t *p1 = a.faces_pad + (size_t)ahead * a.face_pitch + tid;
     const uint16_t *p2 = a.cell_face + (size_t)ahead * 4 * 64 + 2 * (tid & 127);
