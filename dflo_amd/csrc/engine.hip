@@ -92,6 +92,7 @@ struct dflo_hip_engine {
   size_t lds_bytes = 0;
   int stage_grid = 8, prefetch_ahead = 1 << 30;
   int sweep_mode = 1, sweep_dir = 0;   // every launch over all shards walks them against the previous one (DFLO_SWEEP=0: always forward)
+  bool fuse_dtq = true;                // DFLO_FUSE_DTQ=0: bilinear cells always take the separate time-step pass (dt_q_kernel)
   int stream_override = -1;            // DFLO_STREAM=0/1 forces the streaming-store variant off / on
   unsigned long long *phase_cycles = nullptr;
   int max_fp = 0;
@@ -372,6 +373,14 @@ int launch_update(dflo_hip_engine *h, double *rhs_out, int part) {
   a.prefetch_ahead = h->prefetch_ahead;
   a.uniform_h = p.uniform_h ? 1 : 0;
   a.want_dt = last ? 1 : 0;
+  // bilinear cells: compute_time_step_q is formed by the last stage kernel itself when no limiter pass follows it (the
+  // positivity limiter, if any, has been applied inside the kernel) -- otherwise by that pass, or by dt_q_kernel
+  {
+    const bool pass_follows = h->prm.limiter_type != DFLO_LIMITER_NONE || (h->prm.pos_lim && !h->fuse_pos);
+    a.dtq = (h->fuse_dtq && last && !rhs_out && h->geo == 1 && h->basis == DFLO_BASIS_QK && !pass_follows && part <= 2) ? 1 : 0;
+    if (a.dtq) h->dtq_parts |= part == 0 ? 3 : part;
+    a.dt_cell_out = h->d_dt_cell;
+  }
   a.degree = h->degree;
   a.kb = h->kb;
   part_list(h, part, &a.shard_list, &a.n_list);
@@ -416,6 +425,7 @@ int launch_indicator(dflo_hip_engine *h, int part) {
   a.degree = h->degree;
   part_list(h, part, &a.shard_list, &a.n_list);
   if (a.n_list == 0) return DFLO_OK;
+  a.sweep_rev = next_sweep(h, part);
   void (*fn)(const IndArgs);
   if (h->basis == DFLO_BASIS_PK) fn = h->N == 2 ? indicator_kernel<2, 1> : (h->N == 3 ? indicator_kernel<3, 1> : indicator_kernel<4, 1>);
   else fn = h->N == 2 ? indicator_kernel<2, 0> : (h->N == 3 ? indicator_kernel<3, 0> : indicator_kernel<4, 0>);
@@ -655,6 +665,7 @@ int dflo_hip_create(const dflo_mesh_t *mesh, const dflo_params_t *params, int de
   if (const char *e = std::getenv("DFLO_GRAPH")) h->use_graph = std::atoi(e) != 0;
   if (const char *e = std::getenv("DFLO_SWEEP")) h->sweep_mode = std::atoi(e);
   if (const char *e = std::getenv("DFLO_STREAM")) h->stream_override = std::atoi(e) != 0;
+  if (const char *e = std::getenv("DFLO_FUSE_DTQ")) h->fuse_dtq = std::atoi(e) != 0;
   h->ns = mesh->basis == DFLO_BASIS_PK ? h->N * (h->N + 1) / 2 : h->N * h->N;
   h->ndof = 4 * h->ns;
   h->mapping = mesh->mapping;

@@ -299,12 +299,12 @@ __device__ __forceinline__ void row_update_q1(const StageArgs &a, double *Us, co
           u += dt * R[c][m] * invM;
           if constexpr (MODE == 1) u = (1.0 - a.ark) * u + a.ark * uold[c][m];
           stream_store<STREAM>(&np[d * 64], u);
-          if constexpr (POS) unew[c][m] = u;
+          unew[c][m] = u;   // kept: the positivity step and the time step of the new solution (dtq) work on it
           part[c] += wd * u;
         }
       }
     }
-  } else if constexpr (POS) {
+  } else {
 #pragma unroll
     for (int c = 0; c < 4; ++c)
 #pragma unroll
@@ -515,10 +515,11 @@ __global__ __launch_bounds__(64 * N, ((GEO == 1 && N != 3) || N == 4) ? 2 : 3) v
   uint16_t cref[4];
 #pragma unroll
   for (int f = 0; f < 4; ++f) cref[f] = a.cell_face[((size_t)shard * 4 + f) * 64 + lane];
-  double h = 0.0, vx[8];
+  double h = 0.0, vx[8], hq = 0.0;
   if constexpr (GEO == 0) {
     h = a.uniform_h ? a.h_uniform : a.cell_h[(size_t)shard * 64 + lane];
   } else {
+    if (a.dtq && row == N - 1) hq = a.cell_h[(size_t)shard * 64 + lane];   // diameter / sqrt(2), for the time step
 #pragma unroll
     for (int k = 0; k < 8; ++k) vx[k] = a.cell_vert[(size_t)k * a.n_slots + (size_t)shard * 64 + lane];
   }
@@ -773,10 +774,59 @@ __global__ __launch_bounds__(64 * N, ((GEO == 1 && N != 3) || N == 4) ? 2 : 3) v
 #pragma unroll
       for (int c = 0; c < 4; ++c)
 #pragma unroll
-        for (int m = 0; m < N; ++m)
-          np[(c * NS2 + m + N * row) * 64] = theta2 < 1.0 ? positivity_blend(theta2, unew[c][m], A[c]) : unew[c][m];
+        for (int m = 0; m < N; ++m) {
+          unew[c][m] = theta2 < 1.0 ? positivity_blend(theta2, unew[c][m], A[c]) : unew[c][m];
+          np[(c * NS2 + m + N * row) * 64] = unew[c][m];
+        }
     }
     }   // !settled
+  }
+  if constexpr (GEO == 1 && MODE != 2) {
+    // compute_time_step_q (src/claw.cc:520-557) of the new solution, when no limiter pass follows that could form it: max of
+    // |v| + c over the 4 x 4 points of QIterated(QTrapez, 3).  Sum-factorised across the waves: wave b interpolates its row in
+    // xi (registers), the rows meet in the LDS image (free by now), wave p finishes the point columns p, p + N, .. in eta --
+    // the arithmetic of dt_q_cell, the separate pass over the whole state (dt_q_kernel) is not launched.
+    if (a.dtq) {
+      // the LDS image has 4 N^2 rows, the xi-interpolated rows are 16 N: one pass for N = 4, two (two point columns each) for
+      // N = 2, 3, four for N = 1
+      constexpr int PP = N >= 4 ? 4 : (N >= 2 ? 2 : 1), PASSES = kTrap / PP;
+      double maxeig = 0.0;
+#pragma unroll
+      for (int pass = 0; pass < PASSES; ++pass) {
+        __syncthreads();   // the row bounds / the limiter's copy of the rows / the previous pass have been read by every wave
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+          for (int pl = 0; pl < PP; ++pl) {
+            double t = 0;
+#pragma unroll
+            for (int aa = 0; aa < N; ++aa) t += a.kb.Pt[pass * PP + pl][aa] * unew[c][aa];
+            Us[((c * PP + pl) * N + row) * S + lane] = t;
+          }
+        __syncthreads();
+        for (int pl = row; pl < PP; pl += N) {
+          double v[4][N];
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int b = 0; b < N; ++b) v[c][b] = Us[((c * PP + pl) * N + b) * S + lane];
+#pragma unroll
+          for (int pb = 0; pb < kTrap; ++pb) {
+            double w[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              double t = 0;
+#pragma unroll
+              for (int b = 0; b < N; ++b) t += a.kb.Pt[pb][b] * v[c][b];
+              w[c] = t;
+            }
+            maxeig = fmax(maxeig, max_eigenvalue(w));
+          }
+        }
+      }
+      red[(8 * N + row) * 64 + lane] = maxeig;
+      __syncthreads();
+    }
   }
   if constexpr (POS == 2 && GEO == 0 && MODE != 2) {
     // Which cells can the limiter pass change?  TVB (src/limiter.cc:15-30): minmod hands back its first argument when it is
@@ -847,11 +897,24 @@ __global__ __launch_bounds__(64 * N, ((GEO == 1 && N != 3) || N == 4) ? 2 : 3) v
         if (a.want_dt) dtmin = cfl_dt(avg, h, a.cfl, a.degree);
       }
     }
+    bool have_dt = GEO == 0 && a.want_dt;
+    if constexpr (GEO == 1 && MODE != 2) {
+      if (a.dtq) {
+        have_dt = true;
+        if (active) {
+          double maxeig = red[(8 * N) * 64 + lane];
+#pragma unroll
+          for (int b = 1; b < N; ++b) maxeig = fmax(maxeig, red[(8 * N + b) * 64 + lane]);
+          dtmin = a.cfl * hq / maxeig / (2.0 * a.degree + 1.0);
+          if (a.dt_cell_out) a.dt_cell_out[(size_t)shard * 64 + lane] = dtmin;
+        }
+      }
+    }
     res = wave_sum_lane63(res);
-    if (GEO == 0 && a.want_dt) dtmin = wave_min_lane63(dtmin);
+    if (have_dt) dtmin = wave_min_lane63(dtmin);
     if (lane == 63) {
       a.shard_res[shard] = res;
-      if (GEO == 0 && a.want_dt) a.shard_dtmin[shard] = dtmin;
+      if (have_dt) a.shard_dtmin[shard] = dtmin;
     }
   }
   PHASE_MARK(7);
@@ -1012,7 +1075,7 @@ __global__ __launch_bounds__(64 * N, N == 4 ? 2 : 3) void stage_kernel_pk(const 
   constexpr int TROWS = 4 * N + (FLUX == DFLO_FLUX_LXF ? 3 : 0);
   constexpr int S = 65;
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  const int sidx = shard_of_block(blockIdx.x, a.n_list);
+  const int sidx = shard_of_block(blockIdx.x, a.n_list, a.sweep_rev);
   if (sidx < 0) return;
   const int shard = a.shard_list ? a.shard_list[sidx] : sidx;
   const int tid = threadIdx.x;
@@ -1064,7 +1127,7 @@ __global__ __launch_bounds__(64 * N, N == 4 ? 2 : 3) void stage_kernel_pk(const 
     for (int t = 0; t < MS; ++t) {
       const int m = min(row + N * t, NM - 1);
       ucur[c][t] = a.Ucur[((size_t)shard * NDOFM + c * NM + m) * 64 + lane];
-      if constexpr (MODE == 1) uold[c][t] = a.Uold[((size_t)shard * NDOFM + c * NM + m) * 64 + lane];
+      if constexpr (MODE == 1) uold[c][t] = __builtin_nontemporal_load(&a.Uold[((size_t)shard * NDOFM + c * NM + m) * 64 + lane]);   // read once per stage
     }
 
   // ---- phase A

@@ -188,6 +188,39 @@ def test_residual_mapped_cells(degree, flux):
     assert rel(claw.assemble_system(), ora.assemble()) < 1e-12
 
 
+@pytest.mark.parametrize("degree,flux,pos", [(0, "lxf", False), (1, "lxf", False), (1, "roe", True), (2, "hllc", True), (3, "kfvs", True), (3, "hllc", False)])
+def test_time_step_formed_by_the_last_stage_kernel_on_mapped_cells(degree, flux, pos, monkeypatch):
+    """Bilinear cells without a limiter pass: the last stage kernel forms compute_time_step_q (src/claw.cc:520-557) of the new
+    solution itself (one, two or four passes over the point columns, depending on the degree).  The device-resident loop
+    then takes the oracle's steps, and matches the run with the separate dt_q_kernel pass (DFLO_FUSE_DTQ=0)."""
+    mesh, claw, ora = mapped_pair(degree, flux, pos_lim=pos)
+    u0 = claw.current_solution.copy()
+    t_end = claw.advance(5)
+    t = 0.0
+    for it in range(5):
+        dt = ora.compute_time_step(t)
+        ora.step(dt)
+        t += dt
+    assert abs(t_end - t) <= 1e-12 * t
+    assert rel(claw.current_solution, ora.get_solution()) < 1e-10
+    assert abs(claw.compute_time_step() - ora.compute_time_step(t)) <= 1e-12 * t
+    monkeypatch.setenv("DFLO_FUSE_DTQ", "0")
+    mesh2, plain, _ = mapped_pair(degree, flux, pos_lim=pos)
+    assert plain.advance(5) == t_end
+    assert np.array_equal(plain.current_solution, claw.current_solution)
+    monkeypatch.delenv("DFLO_FUSE_DTQ")
+    # two engines (rim and interior launches each write the time step of their shards)
+    bnd = {1: "inflow", 2: "slip", 3: "outflow"}
+    two = dflo_amd.MultiConservationLaw(mesh, dflo_amd.Parameters(flux=flux, boundary=bnd, cfl=0.5, pos_lim=pos), devices=[0, 0], partitioner="rcb")
+    cell, face, bid, xy = two.boundary_faces()
+    bv = np.stack(problems.smooth_perturbation(xy[..., 0], xy[..., 1], L=1.0), axis=-1)
+    two.set_boundary_values(0, bv)
+    two.set_boundary_values(1, bv)
+    two.set_initial_condition(u0)
+    assert abs(two.advance(5) - t_end) <= 1e-13 * t_end
+    assert rel(two.current_solution, claw.current_solution) < 1e-11
+
+
 @pytest.mark.parametrize("degree,flux,pos", [(1, "lxf", False), (2, "hllc", True), (3, "kfvs", True)])
 def test_rk_solution_mapped_cells(degree, flux, pos):
     """C5-style: unstructured-type mesh data path (q1 mapping, compute_time_step_q, positivity)."""
