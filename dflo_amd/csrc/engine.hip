@@ -95,7 +95,6 @@ struct dflo_hip_engine {
   bool fuse_dtq = true;                // DFLO_FUSE_DTQ=0: bilinear cells always take the separate time-step pass (dt_q_kernel)
   int stream_override = -1;            // DFLO_STREAM=0/1 forces the streaming-store variant off / on
   unsigned long long *phase_cycles = nullptr;
-  int max_fp = 0;
   // timing
   bool timing = false;
   int dtq_parts = 0;   // last stage on bilinear cells: parts (1 rim, 2 interior) whose limiter pass also formed the time step
@@ -367,9 +366,8 @@ int launch_update(dflo_hip_engine *h, double *rhs_out, int part) {
   a.cfl = h->prm.cfl;
   a.h_uniform = p.h;
   a.n_shards = p.n_shards;
-  a.max_fp = h->max_fp;
+  a.halo_cols = h->plan.halo_cols;
   a.max_bnd = h->plan.max_bnd;
-  a.max_faces = (std::max(h->plan.max_faces, 1) + 1) & ~1;
   a.prefetch_ahead = h->prefetch_ahead;
   a.uniform_h = p.uniform_h ? 1 : 0;
   a.want_dt = last ? 1 : 0;
@@ -813,8 +811,10 @@ int dflo_hip_create(const dflo_mesh_t *mesh, const dflo_params_t *params, int de
   hipMemset(h->dt_pub, 0, 2 * sizeof(double));
   hipMemset(h->fin_counter, 0, sizeof(int));
   hipMemset(h->pos_stats, 0, 2 * sizeof(unsigned long long));
-  h->halo_stride = std::max(p.max_halo, 1) | 1;  // odd stride: the trace rows fall on different LDS banks
-  h->max_fp = std::max(std::max(p.max_faces, 1) * h->N, 9 * 64 * h->N / 4 + 1);  // Fh also hosts the row partials (5 N rows of 64) and the positivity minima (3 N) or the slope partials (4 N)
+  // row stride of the stage kernel's trace / flux table: a column per halo entry (its trace, then the flux of its face) and one
+  // per other face; the 4 N rows also host the row partials (5 N rows of 64), the positivity minima (3 N) or the slope
+  // partials (4 N), and the point maxima of the time step (N): 9 N rows of 64.  Odd: the rows fall on different LDS banks.
+  h->halo_stride = std::max(p.halo_cols + std::max(p.max_inner, 1), 9 * 64 / 4) | 1;
   {
     const char *e = getenv("DFLO_FUSE_POS");
     h->fuse_pos = h->prm.pos_lim && h->prm.limiter_type == DFLO_LIMITER_NONE && h->basis == DFLO_BASIS_QK && !(e && e[0] == '0');
@@ -833,10 +833,9 @@ int dflo_hip_create(const dflo_mesh_t *mesh, const dflo_params_t *params, int de
   }
   {
     const int rows = 4 * h->N * h->N + (h->prm.flux_type == DFLO_FLUX_LXF ? 3 : 0);  // nodal image (also for Pk)
-    const int trows = 4 * h->N + (h->prm.flux_type == DFLO_FLUX_LXF ? 3 : 0);
-    const size_t mf = (std::max(p.max_faces, 1) + 1) & ~1;   // = StageArgs::max_faces
-    h->lds_bytes = ((size_t)rows * 65 + (size_t)trows * h->halo_stride + 4 * (size_t)h->max_fp + mf / 2 +
-                    (size_t)p.max_bnd * 4 * h->N + (p.max_bnd + 2) / 2 + (h->geo == 1 ? 3 * mf : 0)) * sizeof(double);
+    h->lds_bytes = ((size_t)rows * 65 + (size_t)4 * h->N * h->halo_stride + (h->prm.flux_type == DFLO_FLUX_LXF ? 3 * (size_t)p.halo_cols : 0) +
+                    (size_t)p.max_bnd * 4 * h->N + (p.max_bnd + 2) / 2 + (h->geo == 1 ? 3 * (size_t)h->halo_stride : 0)) * sizeof(double);
+    if (const char *e = std::getenv("DFLO_LDS_PAD")) h->lds_bytes += (size_t)std::atoi(e);   // occupancy experiments: unused LDS per workgroup
   }
 
   if (h->lds_bytes > 160 * 1024) { h->err = "shard halo too large for LDS"; return bail(DFLO_ERR_UNSUPPORTED); }

@@ -283,7 +283,9 @@ int build_plan(const dflo_mesh_t &mesh, int shard_ex, int shard_ey, Plan &p, std
           const int so = slot_of(nb, nf);
           p.faces.push_back({(uint32_t)l | ((uint32_t)f << 16) | ((uint32_t)flip << 19) | ((uint32_t)nf << 20), so});
           push_geom(c, f);
-          p.cell_face[ref] = (uint16_t)k;
+          // a face with a halo side keeps its flux at the point index of the HALO cell (it overwrites that cell's trace, see
+          // the stage kernel), so the reference carries the flip on the integrating side as well
+          p.cell_face[ref] = (uint16_t)(k | ((!nb_inside && flip) ? 0x4000 : 0));
           if (nb_inside)
             p.cell_face[((size_t)s * 4 + nf) * kShard + local_of[nb]] = (uint16_t)(k | (flip ? 0x4000 : 0) | 0x8000);
         } else {  // neighbour outside the shard integrates; we still evaluate its flux
@@ -326,6 +328,24 @@ int build_plan(const dflo_mesh_t &mesh, int shard_ex, int shard_ey, Plan &p, std
           uint16_t &ref = p.cell_face[((size_t)s * 4 + f) * kShard + l];
           if (ref != kNoFace) ref = (uint16_t)((ref & 0xC000) | pos[ref & 0x3FFF]);
         }
+      // the halo entries in the order of their faces (which come first): entry e belongs to face e, and the flux of that face
+      // can take the place of the entry's trace in the LDS table of the stage kernel
+      const int h0 = p.halo_begin[s], nh = (int)halo_slot.size();
+      std::vector<int32_t> hc(nh), hf(nh);
+      for (int k = 0; k < nh; ++k) {
+        FaceRec &r = p.faces[face0 + k];
+        const bool halo_l = (r.w0 & 0xFFFF) >= (uint32_t)kShard;
+        const int e_old = (halo_l ? (int)(r.w0 & 0xFFFF) : (int)r.w1) - kShard;
+        if (kind(k) != 0 || e_old < 0 || e_old >= nh) { err = "internal: halo faces and halo entries do not pair up"; return DFLO_ERR_BAD_PARAM; }
+        hc[k] = p.halo_cells[h0 + e_old];
+        hf[k] = p.halo_faces[h0 + e_old];
+        if (halo_l) r.w0 = (r.w0 & ~0xFFFFu) | (uint32_t)(kShard + k);
+        else r.w1 = kShard + k;
+      }
+      if (nh < nf && kind(nh) == 0) { err = "internal: more halo faces than halo entries"; return DFLO_ERR_BAD_PARAM; }
+      std::copy(hc.begin(), hc.end(), p.halo_cells.begin() + h0);
+      std::copy(hf.begin(), hf.end(), p.halo_faces.begin() + h0);
+      p.max_inner = std::max(p.max_inner, nf - nh);
     }
     p.halo_begin[s + 1] = (int)p.halo_cells.size();
     p.face_begin[s + 1] = (int)p.faces.size();
@@ -335,6 +355,21 @@ int build_plan(const dflo_mesh_t &mesh, int shard_ex, int shard_ey, Plan &p, std
     bool reads_ghost = false;
     for (int k = p.halo_begin[s]; k < p.halo_begin[s + 1]; ++k) reads_ghost |= p.halo_cells[k] >= p.n_shards * kShard;
     (reads_ghost ? p.rim_shards : p.interior_shards).push_back(s);
+  }
+
+  // ---- the stage kernel keeps traces and fluxes in one LDS table of halo_cols + max_inner columns: a face with a halo side in
+  //      the column of its halo entry, the other faces behind them.  The cells refer to their faces by column.
+  p.halo_cols = std::max(p.max_halo, 1);
+  for (int s = 0; s < p.n_shards; ++s) {
+    const int nh = p.halo_begin[s + 1] - p.halo_begin[s];
+    for (int f = 0; f < 4; ++f)
+      for (int l = 0; l < kShard; ++l) {
+        uint16_t &ref = p.cell_face[((size_t)s * 4 + f) * kShard + l];
+        if (ref == kNoFace) continue;
+        const int k = ref & 0x3FFF, col = k < nh ? k : k - nh + p.halo_cols;
+        if (col >= 0x3FFF) { err = "too many faces in a shard"; return DFLO_ERR_BAD_PARAM; }
+        ref = (uint16_t)((ref & 0xC000) | col);
+      }
   }
 
   // ---- ghost traces: number the (ghost cell, face) pairs the owned cells look at, ghost cell first, then face

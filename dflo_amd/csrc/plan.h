@@ -57,7 +57,8 @@ struct Plan {
   std::vector<int32_t> face_begin;   // [n_shards+1]
   std::vector<FaceRec> faces;
   std::vector<double> face_geom;     // [n faces][3]: outward unit normal of the integrating cell, edge length
-  std::vector<uint16_t> cell_face;   // [n_shards][4][kShard]
+  std::vector<uint16_t> cell_face;   // [n_shards][4][kShard]: bits 0-13 the COLUMN of the face in the stage kernel's flux table
+                                     // (halo entry e -> e, the k-th other face -> halo_cols + k), 14 flip, 15 the other side integrates
   std::vector<int32_t> lrbt;         // [n_shards][4][kShard] internal slot of the left/right/bottom/top
                                      // neighbour or -1 (src/claw.cc:336-380)
   std::vector<uint8_t> nbr_code;     // [n_shards][4][kShard] bits 0-1 the neighbour's local face, bit 2 flip,
@@ -68,6 +69,8 @@ struct Plan {
   std::vector<int32_t> rim2_shards;  // rim shards + the ring of shards next to them, and the rest: the split of the UPDATE when a
   std::vector<int32_t> rest2_shards; // TVB limiter follows (the limiter of the rim cells reads averages from the ring)
   int max_halo = 0, max_faces = 0, max_bnd = 0;
+  int max_inner = 0;                 // most faces of a shard without a halo side
+  int halo_cols = 1;                 // columns of the stage kernel's trace / flux table that belong to halo entries
   // boundary faces in MeshWorker order (cell ascending, face ascending)
   std::vector<int32_t> bface_cell, bface_face, bface_id;
   bool uniform_h = false;

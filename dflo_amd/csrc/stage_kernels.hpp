@@ -9,8 +9,9 @@ namespace dflo {
 // One workgroup of N wavefronts per shard: lane = cell, wavefront = node row b of the (k+1)^2
 // collocation nodes, so control flow is wave-uniform and every global access is a coalesced
 // 512-byte line.  LDS image: Us[ndof (+3: u, v, c of the cell average for LxF)][65] the own 64 cells,
-// Th[4N (+3)][halo_stride] the traces of the halo cells on the shared faces, Fh[4][max_fp] the numerical
-// fluxes at the shard's face points, the packed face records and the shard's boundary data.
+// Th[4N][halo_stride] one column per face: first the faces shared with halo cells (the column holds the halo cell's trace until
+// the flux of the face replaces it), then the other faces (fluxes only); Av[3][halo_cols] (LxF: u, v, c of the halo cells'
+// averages) and the shard's boundary data.  The packed face records stay in registers.
 
 // phase C for node row B of every cell of the shard (lane = cell)
 template <int N, int B, int MODE, int POS, int STREAM>
@@ -18,6 +19,7 @@ __device__ __forceinline__ void row_update(const StageArgs &a, double *Us, const
                                            double *red, int shard, int lane, bool active, double h,
                                            const uint16_t (&cref)[4], const double (&uold)[4][N],
                                            const double (&Wrow)[N][4], double (&unew)[4][N], const double dt) {
+  const int HS = a.halo_stride;   // row stride of the trace / flux table (Fh)
   constexpr int NS = N * N;
   double R[4][N];
 #pragma unroll
@@ -111,7 +113,7 @@ __device__ __forceinline__ void row_update(const StageArgs &a, double *Us, const
         const double jxw = sgn * CB<N>::t.w[B] * h;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-          const double fq = Fh[c * a.max_fp + k * N + qq] * jxw;
+          const double fq = Fh[(c * N + qq) * HS + k] * jxw;
 #pragma unroll
           for (int m = 0; m < N; ++m) R[c][m] += fq * ((f & 1) ? CB<N>::t.L1[m] : CB<N>::t.L0[m]);
         }
@@ -122,7 +124,7 @@ __device__ __forceinline__ void row_update(const StageArgs &a, double *Us, const
           const int qq = flip ? N - 1 - q : q;
           const double jxw = sgn * (CB<N>::t.w[q] * lw) * h;
 #pragma unroll
-          for (int c = 0; c < 4; ++c) R[c][q] += Fh[c * a.max_fp + k * N + qq] * jxw;
+          for (int c = 0; c < 4; ++c) R[c][q] += Fh[(c * N + qq) * HS + k] * jxw;
         }
       }
     }
@@ -197,6 +199,7 @@ __device__ __forceinline__ void row_update_q1(const StageArgs &a, double *Us, co
                                               const double (&vx)[8], const uint16_t (&cref)[4],
                                               const double (&uold)[4][N], const double (&Wrow)[N][4], double (&unew)[4][N],
                                               const double dt) {
+  const int HS = a.halo_stride;   // row stride of the trace / flux table (Fh)
   constexpr int NS = N * N;
   double R[4][N];
 #pragma unroll
@@ -253,13 +256,13 @@ __device__ __forceinline__ void row_update_q1(const StageArgs &a, double *Us, co
       const int k = ref & 0x3FFF;
       const bool flip = (ref >> 14) & 1;
       const double sgn = (ref >> 15) ? 1.0 : -1.0;
-      const double len = Fg[2 * a.max_faces + k];
+      const double len = Fg[2 * HS + k];
       if (f < 2) {
         const int qq = flip ? N - 1 - B : B;
         const double jxw = sgn * CB<N>::t.w[B] * len;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-          const double fq = Fh[c * a.max_fp + k * N + qq] * jxw;
+          const double fq = Fh[(c * N + qq) * HS + k] * jxw;
 #pragma unroll
           for (int m = 0; m < N; ++m) R[c][m] += fq * ((f & 1) ? CB<N>::t.L1[m] : CB<N>::t.L0[m]);
         }
@@ -270,7 +273,7 @@ __device__ __forceinline__ void row_update_q1(const StageArgs &a, double *Us, co
           const int qq = flip ? N - 1 - q : q;
           const double jxw = sgn * (CB<N>::t.w[q] * lw) * len;
 #pragma unroll
-          for (int c = 0; c < 4; ++c) R[c][q] += Fh[c * a.max_fp + k * N + qq] * jxw;
+          for (int c = 0; c < 4; ++c) R[c][q] += Fh[(c * N + qq) * HS + k] * jxw;
         }
       }
     }
@@ -340,26 +343,43 @@ __device__ __forceinline__ int pface_other_face(uint32_t w) { return (w >> 13) &
 __device__ __forceinline__ int pface_other_slot(uint32_t w) { return (w >> 15) & 0x1FF; }
 __device__ __forceinline__ int pface_bnd_local(uint32_t w) { return (w >> 13) & 0x3FF; }
 
+// The table Th[4N][HS] starts out with the traces of the halo entries in its first columns (entry e in column e); the flux of a
+// face goes into the column of the face -- the face of halo entry e into column e, at the point index of the HALO cell, where
+// it replaces the trace it was computed from (read and written by the same thread), the k-th other face into column
+// halo_cols + k.  The face records come in registers (frr: the records of this thread's first three passes).
+// face point p of a shard with nf faces -> face k (and point q): for N = 3 the N points of a face in consecutive lanes (measured
+// 1 % faster there), otherwise p = q nf + k
+template <int N>
+__device__ __forceinline__ int face_of_point(int p, int nf, int &q) {
+  if constexpr (N == 3) {
+    const int k = p / N;
+    q = p - k * N;
+    return k;
+  }
+  q = p >= nf ? 1 : 0;
+  if constexpr (N > 3) q += (p >= 2 * nf ? 1 : 0) + (p >= 3 * nf ? 1 : 0);
+  return p - q * nf;
+}
+template <int N>
+__device__ __forceinline__ int face_of_point(int p, int nf) {
+  int q;
+  return face_of_point<N>(p, nf, q);
+}
 template <int N, int FLUX, int GEO>
-__device__ __forceinline__ void flux_phase(const StageArgs &a, const double *Us, const double *Th, double *Fh,
-                                           const uint32_t *Fr, const double *Bv, const int *Bk, const double *Fg,
-                                           const int HS, const int nf, const int tid) {
+__device__ __forceinline__ void flux_phase(const StageArgs &a, const double *Us, double *Th, const double *Av,
+                                           const uint32_t (&frr)[3], const uint32_t *fp, const double *Bv, const int *Bk,
+                                           const double *Fg, const int HS, const int nf, const int nh, const int tid) {
   constexpr int NS = N * N, NDOF = 4 * NS, NT = 64 * N, S = 65;
   const int nfp = nf * N;
-  for (int p = tid; p < nfp; p += NT) {
+  int it = 0;
+  for (int p = tid; p < nfp; p += NT, ++it) {
     // neighbouring lanes take neighbouring faces at the same point q (the plan sorts the faces by kind, local face, slot): the
     // lanes of a wavefront read the same rows of the LDS image at different cells (measured against "the N points of a face in
     // consecutive lanes": Q3 KFVS +3-4 %, Q1 LxF +1 %, Q2 HLLC -1 %)
-    int q, k;
-    if constexpr (N == 3) {   // (for N = 3 the N points of a face in consecutive lanes measured 1 % faster)
-      k = p / N;
-      q = p - k * N;
-    } else {
-      q = p >= nf ? 1 : 0;
-      if constexpr (N > 3) q += (p >= 2 * nf ? 1 : 0) + (p >= 3 * nf ? 1 : 0);
-      k = p - q * nf;
-    }
-    const uint32_t r = Fr[k];
+    int q;
+    const int k = face_of_point<N>(p, nf, q);
+    const uint32_t r = it == 0 ? frr[0] : (it == 1 ? frr[1] : (it == 2 ? frr[2] : fp[k]));
+    const int col = k < nh ? k : k - nh + a.halo_cols;
     const int slotL = pface_slot(r), fL = pface_face(r);
     const bool bnd = pface_bnd(r), flip = pface_flip(r);
     const int fR = pface_other_face(r);
@@ -390,7 +410,7 @@ __device__ __forceinline__ void flux_phase(const StageArgs &a, const double *Us,
         for (int c = 0; c < 4; ++c) W[c] = Th[(c * N + qq) * HS + slot - 64];
         if constexpr (FLUX == DFLO_FLUX_LXF) {
 #pragma unroll
-          for (int c = 0; c < 3; ++c) A[c] = Th[(4 * N + c) * HS + slot - 64];
+          for (int c = 0; c < 3; ++c) A[c] = Av[c * a.halo_cols + slot - 64];
         }
       }
     };
@@ -400,11 +420,14 @@ __device__ __forceinline__ void flux_phase(const StageArgs &a, const double *Us,
       nx = fL == 0 ? -1.0 : (fL == 1 ? 1.0 : 0.0);
       ny = fL == 2 ? -1.0 : (fL == 3 ? 1.0 : 0.0);
     } else {
-      nx = Fg[k];
-      ny = Fg[a.max_faces + k];
+      nx = Fg[col];
+      ny = Fg[HS + col];
     }
+    int qs = q;   // the point index the flux is filed under
     if (!bnd) {
-      trace(pface_other_slot(r), fR, flip ? N - 1 - q : q, Wm, Am);
+      const int slotR = pface_other_slot(r), qR = flip ? N - 1 - q : q;
+      if (slotR >= 64) qs = qR;
+      trace(slotR, fR, qR, Wm, Am);
     } else {
       const int bl = pface_bnd_local(r);
       const double *bv = Bv + (bl * N + q) * 4;
@@ -417,7 +440,7 @@ __device__ __forceinline__ void flux_phase(const StageArgs &a, const double *Us,
     }
     numerical_normal_flux<FLUX>(nx, ny, Wp, Wm, Ap, Am, F);
 #pragma unroll
-    for (int c = 0; c < 4; ++c) Fh[c * a.max_fp + k * N + q] = F[c];
+    for (int c = 0; c < 4; ++c) Th[(c * N + qs) * HS + col] = F[c];
   }
 }
 
@@ -435,10 +458,13 @@ __device__ __forceinline__ void flux_phase(const StageArgs &a, const double *Us,
 //         the caches (measured: C2 +2 %, C4 +3 %; with the Q1 limiter pass behind it C3 -2 %, hence a variant and not a rule).
 //         A compile-time switch: behind a run-time branch the compiler merges the two store sequences and drops the hint.
 template <int N, int FLUX, int MODE, int GEO, int POS, int STREAM>
-__global__ __launch_bounds__(64 * N, ((GEO == 1 && N != 3) || N == 4) ? 2 : 3) void stage_kernel(const StageArgs a) {
+#ifndef DFLO_Q2_WAVES
+#define DFLO_Q2_WAVES 3
+#endif
+__global__ __launch_bounds__(64 * N, ((GEO == 1 && N != 3) || N == 4) ? 2 : (N == 3 && GEO == 0 ? DFLO_Q2_WAVES : 3)) void stage_kernel(const StageArgs a) {
   constexpr int NS = N * N, NDOF = 4 * NS, NT = 64 * N;
   constexpr int ROWS = NDOF + (FLUX == DFLO_FLUX_LXF ? 3 : 0);   // LxF: (u, v, c) of the cell average ride along
-  constexpr int TROWS = 4 * N + (FLUX == DFLO_FLUX_LXF ? 3 : 0); // halo image: face trace (+ the same three)
+  constexpr int TROWS = 4 * N;                                   // trace / flux table: (component, point) rows
   constexpr int S = 65;                                          // own-cell row stride: 1 mod 32 doubles
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int sidx = shard_of_block(blockIdx.x, a.n_list, a.sweep_rev);
@@ -449,12 +475,12 @@ __global__ __launch_bounds__(64 * N, ((GEO == 1 && N != 3) || N == 4) ? 2 : 3) v
   const int row = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int HS = a.halo_stride;
   double *Us = lds;                                   // [ROWS][S] DoFs (and averages) of the own cells
-  double *Th = Us + ROWS * S;                         // [TROWS][HS] traces of the halo cells on the shared face
-  double *Fh = Th + TROWS * HS;                       // [4][max_fp] numerical fluxes
-  uint32_t *Fr = (uint32_t *)(Fh + 4 * a.max_fp);     // [max_faces] (even count)
-  double *Bv = (double *)(Fr + a.max_faces);          // [max_bnd][N][4] boundary values of the shard
+  double *Th = Us + ROWS * S;                         // [TROWS][HS] columns 0 .. halo_cols-1: traces of the halo cells on the shared
+                                                      // faces, later the fluxes of those faces; from halo_cols: fluxes of the other faces
+  double *Av = Th + TROWS * HS;                       // LxF: [3][halo_cols] (u, v, c) of the halo cells' averages
+  double *Bv = Av + (FLUX == DFLO_FLUX_LXF ? 3 * a.halo_cols : 0);   // [max_bnd][N][4] boundary values of the shard
   int *Bk = (int *)(Bv + a.max_bnd * 4 * N);          // [max_bnd] boundary kinds
-  double *Fg = (double *)(Bk + ((a.max_bnd + 1) & ~1)); // GEO 1: [3][max_faces] unit normal and length of the faces
+  double *Fg = (double *)(Bk + ((a.max_bnd + 1) & ~1)); // GEO 1: [3][HS] unit normal and length of the faces, by column
 
 #ifdef DFLO_PHASE_TIMING
   unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
@@ -501,8 +527,11 @@ __global__ __launch_bounds__(64 * N, ((GEO == 1 && N != 3) || N == 4) ? 2 : 3) v
       for (int c = 0; c < 4; ++c) uavg[c] = a.avg_cur[((size_t)shard * 4 + c) * 64 + lane];
     }
   }
+  // face records of this thread's passes over the face points (see flux_phase for the numbering)
   const uint32_t *fp = a.faces_pad + (size_t)shard * a.face_pitch;
-  const uint32_t fr0 = fp[tid], fr1 = fp[tid + NT];
+  uint32_t frr[3];
+#pragma unroll
+  for (int it = 0; it < 3; ++it) frr[it] = fp[min(face_of_point<N>(tid + it * NT, nf), a.face_pitch - 1)];
   double fg[3][2];   // GEO 1: unit normal and length of the faces tid and tid + NT (the table has the pitch of the face records)
   if constexpr (GEO == 1) {
     const double *gp = a.fgeom_pad + (size_t)shard * 3 * a.face_pitch;
@@ -587,7 +616,7 @@ __global__ __launch_bounds__(64 * N, ((GEO == 1 && N != 3) || N == 4) ? 2 : 3) v
       for (int c = 0; c < 4; ++c) A[c] = a.avg_cur[((size_t)(ic >> 6) * 4 + c) * 64 + (ic & 63)];
       wave_speed_uvc(A, uvc);
 #pragma unroll
-      for (int c = 0; c < 3; ++c) Th[(4 * N + c) * HS + sl] = uvc[c];
+      for (int c = 0; c < 3; ++c) Av[c * a.halo_cols + sl] = uvc[c];
     }
   }
 #pragma unroll
@@ -603,15 +632,13 @@ __global__ __launch_bounds__(64 * N, ((GEO == 1 && N != 3) || N == 4) ? 2 : 3) v
       for (int c = 0; c < 3; ++c) Us[(NDOF + c) * S + lane] = uvc[c];
     }
   }
-  if (tid < nf) Fr[tid] = fr0;
-  if (tid + NT < nf) Fr[tid + NT] = fr1;
-  for (int i = tid + 2 * NT; i < nf; i += NT) Fr[i] = fp[i];
   if constexpr (GEO == 1) {
+    auto col_of = [&](int i) { return i < nh ? i : i - nh + a.halo_cols; };
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-      if (tid < nf) Fg[j * a.max_faces + tid] = fg[j][0];
-      if (tid + NT < nf) Fg[j * a.max_faces + tid + NT] = fg[j][1];
-      for (int i = tid + 2 * NT; i < nf; i += NT) Fg[j * a.max_faces + i] = a.fgeom_pad[((size_t)shard * 3 + j) * a.face_pitch + i];
+      if (tid < nf) Fg[j * HS + col_of(tid)] = fg[j][0];
+      if (tid + NT < nf) Fg[j * HS + col_of(tid + NT)] = fg[j][1];
+      for (int i = tid + 2 * NT; i < nf; i += NT) Fg[j * HS + col_of(i)] = a.fgeom_pad[((size_t)shard * 3 + j) * a.face_pitch + i];
     }
   }
   if (nbnd > 0) {  // boundary values and kinds of this shard's boundary faces
@@ -627,13 +654,14 @@ __global__ __launch_bounds__(64 * N, ((GEO == 1 && N != 3) || N == 4) ? 2 : 3) v
   PHASE_MARK(2);
 
   // ---- phase B
-  flux_phase<N, FLUX, GEO>(a, Us, Th, Fh, Fr, Bv, Bk, Fg, HS, nf, tid);
+  flux_phase<N, FLUX, GEO>(a, Us, Th, Av, frr, fp, Bv, Bk, Fg, HS, nf, nh, tid);
   PHASE_MARK(3);
   __syncthreads();
   PHASE_MARK(4);
 
   // ---- phase C: volume + lifting + RK update of node row `row`
-  double *red = Fh;  // reused after the barrier inside row_update
+  double *Fh = Th;   // the fluxes, as the row updates read them
+  double *red = Th;  // reused after the barrier inside row_update
   double wrow[N][4];
   double unew[4][N];   // POS: the updated row, held back until the positivity step below
 #pragma unroll
@@ -953,6 +981,7 @@ __device__ __forceinline__ void row_update_pk(const StageArgs &a, double *Us, co
                                               int shard, int lane, bool active, double h, const uint16_t (&cref)[4],
                                               const double (&Wrow)[N][4], const double (&ucur)[4][(N * (N + 1) / 2 + N - 1) / N],
                                               const double (&uold)[4][(N * (N + 1) / 2 + N - 1) / N], const double dt) {
+  const int HS = a.halo_stride;   // row stride of the trace / flux table (Fh)
   constexpr int NS = N * N, NM = N * (N + 1) / 2;
   double R[4][N];
 #pragma unroll
@@ -1003,7 +1032,7 @@ __device__ __forceinline__ void row_update_pk(const StageArgs &a, double *Us, co
         const double jxw = sgn * CB<N>::t.w[B] * h;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-          const double fq = Fh[c * a.max_fp + k * N + qq] * jxw;
+          const double fq = Fh[(c * N + qq) * HS + k] * jxw;
 #pragma unroll
           for (int m = 0; m < N; ++m) R[c][m] += fq * ((f & 1) ? CB<N>::t.L1[m] : CB<N>::t.L0[m]);
         }
@@ -1014,7 +1043,7 @@ __device__ __forceinline__ void row_update_pk(const StageArgs &a, double *Us, co
           const int qq = flip ? N - 1 - q : q;
           const double jxw = sgn * (CB<N>::t.w[q] * lw) * h;
 #pragma unroll
-          for (int c = 0; c < 4; ++c) R[c][q] += Fh[c * a.max_fp + k * N + qq] * jxw;
+          for (int c = 0; c < 4; ++c) R[c][q] += Fh[(c * N + qq) * HS + k] * jxw;
         }
       }
     }
@@ -1072,7 +1101,7 @@ template <int N, int FLUX, int MODE>
 __global__ __launch_bounds__(64 * N, N == 4 ? 2 : 3) void stage_kernel_pk(const StageArgs a) {
   constexpr int NS = N * N, NM = N * (N + 1) / 2, NDOFM = 4 * NM, NT = 64 * N, MS = (NM + N - 1) / N;
   constexpr int ROWS = 4 * NS + (FLUX == DFLO_FLUX_LXF ? 3 : 0);
-  constexpr int TROWS = 4 * N + (FLUX == DFLO_FLUX_LXF ? 3 : 0);
+  constexpr int TROWS = 4 * N;
   constexpr int S = 65;
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int sidx = shard_of_block(blockIdx.x, a.n_list, a.sweep_rev);
@@ -1084,9 +1113,8 @@ __global__ __launch_bounds__(64 * N, N == 4 ? 2 : 3) void stage_kernel_pk(const 
   const int HS = a.halo_stride;
   double *Us = lds;
   double *Th = Us + ROWS * S;
-  double *Fh = Th + TROWS * HS;
-  uint32_t *Fr = (uint32_t *)(Fh + 4 * a.max_fp);
-  double *Bv = (double *)(Fr + a.max_faces);
+  double *Av = Th + TROWS * HS;
+  double *Bv = Av + (FLUX == DFLO_FLUX_LXF ? 3 * a.halo_cols : 0);
   int *Bk = (int *)(Bv + a.max_bnd * 4 * N);
 
   // ---- loads: every wave reads all modes of its cells (the rows need all of them); the modes a wave will
@@ -1113,7 +1141,9 @@ __global__ __launch_bounds__(64 * N, N == 4 ? 2 : 3) void stage_kernel_pk(const 
     }
   }
   const uint32_t *fp = a.faces_pad + (size_t)shard * a.face_pitch;
-  const uint32_t fr0 = fp[tid], fr1 = fp[tid + NT];
+  uint32_t frr[3];
+#pragma unroll
+  for (int it = 0; it < 3; ++it) frr[it] = fp[min(face_of_point<N>(tid + it * NT, nf), a.face_pitch - 1)];
   uint16_t cref[4];
 #pragma unroll
   for (int f = 0; f < 4; ++f) cref[f] = a.cell_face[((size_t)shard * 4 + f) * 64 + lane];
@@ -1171,7 +1201,7 @@ __global__ __launch_bounds__(64 * N, N == 4 ? 2 : 3) void stage_kernel_pk(const 
       for (int c = 0; c < 4; ++c) A[c] = a.avg_cur[((size_t)(ic >> 6) * 4 + c) * 64 + (ic & 63)];
       wave_speed_uvc(A, uvc);
 #pragma unroll
-      for (int c = 0; c < 3; ++c) Th[(4 * N + c) * HS + sl] = uvc[c];
+      for (int c = 0; c < 3; ++c) Av[c * a.halo_cols + sl] = uvc[c];
     }
   }
 #pragma unroll
@@ -1186,9 +1216,6 @@ __global__ __launch_bounds__(64 * N, N == 4 ? 2 : 3) void stage_kernel_pk(const 
       for (int c = 0; c < 3; ++c) Us[(4 * NS + c) * S + lane] = uvc[c];
     }
   }
-  if (tid < nf) Fr[tid] = fr0;
-  if (tid + NT < nf) Fr[tid + NT] = fr1;
-  for (int i = tid + 2 * NT; i < nf; i += NT) Fr[i] = fp[i];
   if (nbnd > 0) {
     for (int i = tid; i < nbnd * 4 * N; i += NT) {
       const int bl = i / (4 * N), k2 = i - bl * 4 * N;
@@ -1198,10 +1225,10 @@ __global__ __launch_bounds__(64 * N, N == 4 ? 2 : 3) void stage_kernel_pk(const 
     }
   }
   __syncthreads();
-  flux_phase<N, FLUX, 0>(a, Us, Th, Fh, Fr, Bv, Bk, nullptr, HS, nf, tid);
+  flux_phase<N, FLUX, 0>(a, Us, Th, Av, frr, fp, Bv, Bk, nullptr, HS, nf, nh, tid);
   __syncthreads();
 
-  double *red = Fh;
+  double *Fh = Th, *red = Th;
   double wrow[N][4];
 #pragma unroll
   for (int m = 0; m < N; ++m)
