@@ -855,6 +855,9 @@ int dflo_hip_create(const dflo_mesh_t *mesh, const dflo_params_t *params, int de
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)fn, 64 * h->N, h->lds_bytes) != hipSuccess || per_cu < 1)
       per_cu = 1;
     if (n_cu < 1) n_cu = 256;
+    if (std::getenv("DFLO_VERBOSE"))
+      std::fprintf(stderr, "dflo_hip: stage kernel N=%d: %zu bytes of LDS per workgroup, %d workgroups (%d wavefronts) resident per CU\n",
+                   h->N, h->lds_bytes, per_cu, per_cu * h->N);
     h->stage_grid = grid_for(h->plan.n_shards);  // one workgroup per shard (per_cu of them resident per CU)
     // a workgroup touches the index data of the shard that the same XCD takes ~1.5 residency rounds later
     h->prefetch_ahead = std::max(8, (per_cu * n_cu / 8) * 3 / 2);
