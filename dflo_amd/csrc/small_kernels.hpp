@@ -30,7 +30,7 @@ constexpr int kBcThreads = 512;   // 8 wavefronts: (component, table) pairs over
 // jump -- with a per-lane opcode the compiler walks through all forty cases under an execution mask.  The top of
 // the stack lives in a register, the rest in LDS (st[depth][thread]; a private array indexed by the stack pointer
 // would be placed in scratch memory).
-__device__ double run_program(const int32_t *ops, int n, const double *consts, double x, double y, double t, double *st) {
+__device__ __forceinline__ double run_program(const int32_t *ops, int n, const double *consts, double x, double y, double t, double *st) {
   double tos = 0.0;
   int sp = 0;   // entries below the top, kept in st[0 .. sp)
   for (int i = 0; i < n; ++i) {
@@ -95,7 +95,7 @@ __device__ double run_program(const int32_t *ops, int n, const double *consts, d
   }
   return tos;
 }
-__global__ __launch_bounds__(kBcThreads) void bc_eval_kernel(const BcArgs a) {
+__global__ __launch_bounds__(kBcThreads) __attribute__((flatten)) void bc_eval_kernel(const BcArgs a) {
   // the programs are a few hundred words: interpret them out of LDS, not with a dependent global load per opcode
   __shared__ int32_t s_ops[2 * kBcLdsOps];
   __shared__ double s_consts[kBcLdsConsts];
