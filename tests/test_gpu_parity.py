@@ -477,6 +477,37 @@ def test_advance_graph_replay_matches_plain_launches(monkeypatch):
     assert (out[0][1] == out[1][1]).all()
 
 
+@pytest.mark.parametrize("case", ["q2_hllc", "q1_roe_tvb", "p2_lxf_tvb"])
+def test_sweep_direction_does_not_change_a_bit(case, monkeypatch):
+    """Launches over all shards alternate the direction in which every XCD walks its shards (shard_of_block): the order in
+    which shards are taken must not matter -- DFLO_SWEEP=0 (always forward) gives the same bits.  96 x 80 cells = 120 shards."""
+    out = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("DFLO_SWEEP", flag)
+        k = 1 if case == "q1_roe_tvb" else 2
+        mesh = dflo_amd.Mesh.cartesian(96, 80, 0.0, 0.0, 1.0 / 96, [-1] * 4 if case == "q2_hllc" else [0, 0, 0, 0], k)
+        if case == "q2_hllc":
+            prm = dflo_amd.Parameters(flux="hllc", cfl=0.7)
+            ic = lambda x, y: problems.isentropic_vortex(10 * x - 5, 10 * y - 4)
+        else:
+            if case == "p2_lxf_tvb":
+                mesh.set_basis("Pk")
+            prm = dflo_amd.Parameters(flux="roe" if k == 1 else "lxf", limiter="TVB", char_lim=True, pos_lim=True, M=0.0, beta=1.5,
+                                      shock_indicator="density" if case == "p2_lxf_tvb" else "limiter", cfl=0.6, boundary={0: "outflow"})
+            ic = _rough_wave_fwd
+        claw = dflo_amd.ConservationLaw(mesh, prm)
+        claw.set_initial_condition(mesh.interpolate(ic))
+        claw.apply_limiter()
+        t = claw.advance(7)
+        out.append((t, claw.current_solution.copy(), claw.cell_average.copy()))
+    assert out[0][0] == out[1][0]
+    assert (out[0][1] == out[1][1]).all() and (out[0][2] == out[1][2]).all()
+
+
+def _rough_wave_fwd(x, y):
+    return _rough_wave(x, y)
+
+
 # ---------------------------------------------------------------- KXRCF indicator (SURVEY §8f-2)
 def _rough_wave(x, y):
     rho = 1.0 + 0.2 * np.sin(16 * np.pi * x) * np.cos(2 * np.pi * y) + np.where(x > 0.75, 0.8, 0.0) + np.where(y > 0.5, 0.3, 0.0)
