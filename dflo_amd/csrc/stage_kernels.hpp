@@ -5,6 +5,9 @@
 
 namespace dflo {
 
+#ifndef DFLO_Q3_WAVES
+#define DFLO_Q3_WAVES 3   // wavefronts per SIMD the first-stage Q3 kernel on squares is built for (3: 168 registers)
+#endif
 // ------------------------------------------------------------------ the stage kernel
 // One workgroup of N wavefronts per shard: lane = cell, wavefront = node row b of the (k+1)^2
 // collocation nodes, so control flow is wave-uniform and every global access is a coalesced
@@ -31,11 +34,21 @@ __device__ __forceinline__ void row_update(const StageArgs &a, double *Us, const
   // Every wave evaluates F and G once at the nodes of its own row (values still in registers), then
   // overwrites its own rows of the LDS image with G: after one barrier each wave reads the G of the
   // other rows instead of re-evaluating the flux there.
-  double Gown[N][4];
+  // Q3, first stage (LEAN): that kernel is built for 3 wavefronts per SIMD (168 registers; measured 100 -> 85 us, while the
+  // later stages, which also hold u(n), lose at 3) -- the state of the own row comes back from the LDS image (phase A put it
+  // there; nobody else writes these rows) instead of being held across the flux phase, and the own G row is read back like the
+  // others.  The same values, the same arithmetic.
+  constexpr bool LEAN = N == 4 && MODE == 0;
+  double Gown[N][4], base[4][N];
 #pragma unroll
   for (int aa = 0; aa < N; ++aa) {
-    double Fx[4];
-    flux_xy(Wrow[aa], Fx, Gown[aa]);
+    double Fx[4], Wa[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      Wa[c] = LEAN ? Us[(c * NS + aa + N * B) * S + lane] : Wrow[aa][c];
+      base[c][aa] = Wa[c];
+    }
+    flux_xy(Wa, Fx, Gown[aa]);
     const double wbh = CB<N>::t.w[B] * h;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -46,8 +59,8 @@ __device__ __forceinline__ void row_update(const StageArgs &a, double *Us, const
     }
     if (a.gravity != 0.0) {  // forcing (src/equation.h:831-850): (0, -rho, 0, -my) * gravity
       const double jxw = CB<N>::t.w[aa] * CB<N>::t.w[B] * h * h;
-      R[MY][aa] += a.gravity * (-1.0 * Wrow[aa][RHO]) * jxw;
-      R[EN][aa] += a.gravity * (-1.0 * Wrow[aa][MY]) * jxw;
+      R[MY][aa] += a.gravity * (-1.0 * Wa[RHO]) * jxw;
+      R[EN][aa] += a.gravity * (-1.0 * Wa[MY]) * jxw;
     }
   }
   __syncthreads();
@@ -86,14 +99,20 @@ __device__ __forceinline__ void row_update(const StageArgs &a, double *Us, const
   } else
 #endif
   {
+  int ln = lane;
 #pragma unroll
   for (int aa = 0; aa < N; ++aa) {
     const double wah = CB<N>::t.w[aa] * h;
+    // LEAN: the reads of this node wait for the sums of the node before -- 4 N values of G in flight, not all 4 N^2 of them at
+    // once (the compiler otherwise hoists every read to the top and spills to make room)
+    if constexpr (LEAN) {
+      if (aa > 0) asm volatile("" : "+v"(ln) : "v"(R[0][aa - 1]), "v"(R[1][aa - 1]), "v"(R[2][aa - 1]), "v"(R[3][aa - 1]));
+    }
 #pragma unroll
     for (int q = 0; q < N; ++q) {
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
-        const double gy = q == B ? Gown[aa][c] : Us[(c * NS + aa + N * q) * S + lane];
+        const double gy = (q == B && !LEAN) ? Gown[aa][c] : Us[(c * NS + aa + N * q) * S + ln];
         R[c][aa] += gy * (wah * CB<N>::t.DW[q][B]);
       }
     }
@@ -149,7 +168,7 @@ __device__ __forceinline__ void row_update(const StageArgs &a, double *Us, const
           const double ww = CB<N>::t.w[m] * CB<N>::t.w[B];
           const double invM = rh2 * (CB<N>::t.iw[m] * CB<N>::t.iw[B]);
           part[4] += R[c][m] * R[c][m];
-          double u = Wrow[m][c];
+          double u = base[c][m];
           u += dt * R[c][m] * invM;
           if constexpr (MODE == 1) u = (1.0 - a.ark) * u + a.ark * uold[c][m];
           ust[c][m] = u;
@@ -165,7 +184,7 @@ __device__ __forceinline__ void row_update(const StageArgs &a, double *Us, const
 #pragma unroll
     for (int c = 0; c < 4; ++c)
 #pragma unroll
-      for (int m = 0; m < N; ++m) unew[c][m] = Wrow[m][c];
+      for (int m = 0; m < N; ++m) unew[c][m] = base[c][m];
   }
   // partial cell averages / residual of this row -> LDS (red aliases Fh, see the caller's barriers)
   if constexpr (MODE != 2) {
@@ -461,7 +480,7 @@ template <int N, int FLUX, int MODE, int GEO, int POS, int STREAM>
 #ifndef DFLO_Q2_WAVES
 #define DFLO_Q2_WAVES 3
 #endif
-__global__ __launch_bounds__(64 * N, ((GEO == 1 && N != 3) || N == 4) ? 2 : (N == 3 && GEO == 0 ? DFLO_Q2_WAVES : 3)) void stage_kernel(const StageArgs a) {
+__global__ __launch_bounds__(64 * N, (N == 4 && GEO == 0 && MODE == 0) ? DFLO_Q3_WAVES : (((GEO == 1 && N != 3) || N == 4) ? 2 : (N == 3 && GEO == 0 ? DFLO_Q2_WAVES : 3))) void stage_kernel(const StageArgs a) {
   constexpr int NS = N * N, NDOF = 4 * NS, NT = 64 * N;
   constexpr int ROWS = NDOF + (FLUX == DFLO_FLUX_LXF ? 3 : 0);   // LxF: (u, v, c) of the cell average ride along
   constexpr int TROWS = 4 * N;                                   // trace / flux table: (component, point) rows
