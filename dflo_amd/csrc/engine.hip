@@ -91,6 +91,7 @@ struct dflo_hip_engine {
   double *ghost_stage = nullptr;
   size_t lds_bytes = 0;
   int stage_grid = 8, prefetch_ahead = 1 << 30;
+  bool lazy_avg = false, avg_valid = true;   // lazy_avg: intermediate stages do not store the cell averages (nobody reads them)
   int sweep_mode = 1, sweep_dir = 0;   // every launch over all shards walks them against the previous one (DFLO_SWEEP=0: always forward)
   bool fuse_dtq = true;                // DFLO_FUSE_DTQ=0: bilinear cells always take the separate time-step pass (dt_q_kernel)
   int stream_override = -1;            // DFLO_STREAM=0/1 forces the streaming-store variant off / on
@@ -371,6 +372,10 @@ int launch_update(dflo_hip_engine *h, double *rhs_out, int part) {
   a.prefetch_ahead = h->prefetch_ahead;
   a.uniform_h = p.uniform_h ? 1 : 0;
   a.want_dt = last ? 1 : 0;
+  // the averages of a stage go to memory when somebody reads them: the LxF flux and the limiter / indicator passes of the next
+  // stage, the time step and the caller after the last one (a caller that asks in between gets them formed afresh)
+  a.store_avg = (last || !h->lazy_avg) ? 1 : 0;
+  if (!rhs_out) h->avg_valid = a.store_avg != 0;
   // bilinear cells: compute_time_step_q is formed by the last stage kernel itself when no limiter pass follows it (the
   // positivity limiter, if any, has been applied inside the kernel) -- otherwise by that pass, or by dt_q_kernel
   {
@@ -818,6 +823,12 @@ int dflo_hip_create(const dflo_mesh_t *mesh, const dflo_params_t *params, int de
   {
     const char *e = getenv("DFLO_FUSE_POS");
     h->fuse_pos = h->prm.pos_lim && h->prm.limiter_type == DFLO_LIMITER_NONE && h->basis == DFLO_BASIS_QK && !(e && e[0] == '0');
+    {  // who reads the averages of an intermediate stage?  The LxF flux (lambda from cell means), a limiter pass, the indicator,
+       // local time stepping -- otherwise they stay in the kernel (DFLO_LAZY_AVG=0: always stored)
+      const char *e3 = getenv("DFLO_LAZY_AVG");
+      const bool pass = h->prm.limiter_type != DFLO_LIMITER_NONE || (h->prm.pos_lim && !h->fuse_pos) || h->prm.shock_indicator != DFLO_IND_LIMITER;
+      h->lazy_avg = !(e3 && e3[0] == '0') && h->prm.flux_type != DFLO_FLUX_LXF && !pass && h->prm.global_time_step;
+    }
     const char *e2 = getenv("DFLO_LIM_MASK");
     // (measured: the marks cost the stage kernel ~11 %; the pass they shorten reads (k+1)^2 values per cell and component,
     //  which pays from k = 2 on -- C4 +7 % -- and not for k = 1 -- C3 -7 %; DFLO_LIM_MASK=1 forces them, 0 forbids them)
@@ -946,6 +957,11 @@ int dflo_hip_get_cell_average(dflo_hip_handle h, double *avg) {
   hipSetDevice(h->device);
   const Plan &p = h->plan;
   std::vector<double> tmp((size_t)p.n_slots * 4);
+  if (!h->avg_valid) {   // an intermediate stage that kept its averages to itself
+    int rc = launch_average(h);
+    if (rc) return rc;
+    h->avg_valid = true;
+  }
   HIPCHK(h, hipStreamSynchronize(h->stream));
   HIPCHK(h, hipMemcpy(tmp.data(), h->avg[h->avg_cur], tmp.size() * sizeof(double), hipMemcpyDeviceToHost));
   for (int c = 0; c < p.n_cells; ++c) {

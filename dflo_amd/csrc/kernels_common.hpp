@@ -69,6 +69,7 @@ struct StageArgs {
   double dt_host, ark, gravity, cfl, h_uniform;
   int n_shards, halo_cols, max_bnd, uniform_h, want_dt, degree, prefetch_ahead;
   double *dt_cell_out;        // dtq with "time step type = local": the per-cell time step of the next step
+  int store_avg;              // 0: nobody reads the cell averages of this stage (no LxF flux, limiter or indicator; not the last stage)
   int dtq;                    // bilinear cells, last stage, no limiter pass behind it: the kernel forms compute_time_step_q on the way out
   const int32_t *shard_list;  // null: all shards; else the n_list shards of this launch (rim / interior)
   int n_list;

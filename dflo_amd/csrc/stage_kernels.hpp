@@ -939,7 +939,8 @@ __global__ __launch_bounds__(64 * N, (N == 4 && GEO == 0 && MODE == 0) ? DFLO_Q3
     }
     if (active) {
 #pragma unroll
-      for (int c = 0; c < 4; ++c) a.avg_new[((size_t)shard * 4 + c) * 64 + lane] = avg[c];
+      for (int c = 0; c < 4; ++c)
+        if (a.store_avg) a.avg_new[((size_t)shard * 4 + c) * 64 + lane] = avg[c];
       if constexpr (GEO == 0) {
         if (a.want_dt) dtmin = cfl_dt(avg, h, a.cfl, a.degree);
       }
@@ -1277,7 +1278,8 @@ __global__ __launch_bounds__(64 * N, N == 4 ? 2 : 3) void stage_kernel_pk(const 
     for (int b = 0; b < N; ++b) res += red[(b * 5 + 4) * 64 + lane];
     if (active) {
 #pragma unroll
-      for (int c = 0; c < 4; ++c) a.avg_new[((size_t)shard * 4 + c) * 64 + lane] = avg[c];
+      for (int c = 0; c < 4; ++c)
+        if (a.store_avg) a.avg_new[((size_t)shard * 4 + c) * 64 + lane] = avg[c];
       if (a.want_dt) dtmin = cfl_dt(avg, h, a.cfl, a.degree);
     }
     res = wave_sum_lane63(res);

@@ -477,6 +477,35 @@ def test_advance_graph_replay_matches_plain_launches(monkeypatch):
     assert (out[0][1] == out[1][1]).all()
 
 
+def test_cell_averages_of_an_intermediate_stage_are_formed_on_demand(monkeypatch):
+    """Without LxF, limiter, indicator or local time stepping nobody reads the cell averages of an intermediate stage, and the
+    stage kernel does not store them (DFLO_LAZY_AVG=0: always); a caller who asks in between still gets them, and whole steps
+    are the same bits either way."""
+    mesh = dflo_amd.Mesh.cartesian(40, 24, -5.0, -5.0, 0.25, [-1] * 4, 2)
+    prm = dflo_amd.Parameters(flux="roe", cfl=0.8)
+    u0 = mesh.interpolate(problems.isentropic_vortex)
+    ora = oracle_lib.Oracle(mesh, prm)
+    ora.set_solution(u0)
+    dt = ora.compute_time_step(0.0)
+    ora.set_dt(dt)
+    ora.stage(0)
+    got = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("DFLO_LAZY_AVG", flag)
+        claw = dflo_amd.ConservationLaw(mesh, prm)
+        claw.set_initial_condition(u0)
+        claw.stage(0, dt)
+        mid = claw.cell_average.copy()
+        assert rel(mid, ora.get_cell_average()) < 1e-13
+        claw.stage(1, dt)
+        claw.stage(2, dt)
+        claw.end_step()
+        t = claw.advance(4)
+        got[flag] = (mid, t, claw.current_solution.copy(), claw.cell_average.copy())
+    assert rel(got["1"][0], got["0"][0]) < 1e-14
+    assert got["1"][1] == got["0"][1] and (got["1"][2] == got["0"][2]).all() and (got["1"][3] == got["0"][3]).all()
+
+
 @pytest.mark.parametrize("case", ["q2_hllc", "q1_roe_tvb", "p2_lxf_tvb"])
 def test_sweep_direction_does_not_change_a_bit(case, monkeypatch):
     """Launches over all shards alternate the direction in which every XCD walks its shards (shard_of_block): the order in
