@@ -92,6 +92,7 @@ struct dflo_hip_engine {
   size_t lds_bytes = 0;
   int stage_grid = 8, prefetch_ahead = 1 << 30;
   bool lazy_avg = false, avg_valid = true;   // lazy_avg: intermediate stages do not store the cell averages (nobody reads them)
+  int n_patterns = 0;   // distinct (face records, face references) among the shards
   int sweep_mode = 1, sweep_dir = 0;   // every launch over all shards walks them against the previous one (DFLO_SWEEP=0: always forward)
   bool fuse_dtq = true;                // DFLO_FUSE_DTQ=0: bilinear cells always take the separate time-step pass (dt_q_kernel)
   int stream_override = -1;            // DFLO_STREAM=0/1 forces the streaming-store variant off / on
@@ -724,7 +725,6 @@ int dflo_hip_create(const dflo_mesh_t *mesh, const dflo_params_t *params, int de
   }
   if ((rc = upload(h, &h->bface_kind, kinds))) return bail(rc);
   if ((rc = upload(h, &h->d_shard_count, p.shard_count))) return bail(rc);
-  if ((rc = upload(h, &h->d_cell_face, p.cell_face))) return bail(rc);
   {  // fixed-pitch copies of the per-shard lists (+2 shards of slack: the kernel reads two shards ahead,
      // and 2*64*N face slots per shard so that unconditional loads stay in bounds)
     const int ns = p.n_shards + 2;
@@ -735,23 +735,47 @@ int dflo_hip_create(const dflo_mesh_t *mesh, const dflo_params_t *params, int de
     std::vector<uint32_t> fpad((size_t)ns * h->face_pitch, 0u);
     h->bnd_pitch = std::max(p.max_bnd, 1);
     std::vector<int32_t> bpad((size_t)ns * h->bnd_pitch, 0);
+    // The face records and the cells' face references are local to a shard (slots, columns), so shards of the same shape
+    // share them: on a lattice a handful of patterns (interior, edges, corners) serve every shard, and the tables stay in the
+    // caches instead of being streamed from memory with the state (1.1 KB per shard and launch on C2).  The pattern of a shard
+    // rides in its header, above the cell count.
+    std::unordered_map<std::string, int> pattern_of;
+    std::vector<uint16_t> cf_pat;
+    fpad.clear();
     for (int sidx = 0; sidx < p.n_shards; ++sidx) {
       const int nh = p.halo_begin[sidx + 1] - p.halo_begin[sidx], nf = p.face_begin[sidx + 1] - p.face_begin[sidx];
-      hdr[sidx] = int4{p.shard_count[sidx], nf, nh, p.shard_bnd[sidx]};
       for (int k = 0; k < nh; ++k) {
         const int he = p.halo_begin[sidx] + k;
         const int who = (h->trace_halo && p.halo_gt[he] >= 0) ? (p.halo_gt[he] | kGhostTrace) : p.halo_cells[he];
         hp[(size_t)sidx * h->halo_pitch + k] = who | (p.halo_faces[he] << 28);
       }
+      std::vector<uint32_t> rec(nf);
       for (int k = 0; k < nf; ++k) {
         const FaceRec &r = p.faces[p.face_begin[sidx] + k];
-        fpad[(size_t)sidx * h->face_pitch + k] = pface_pack(r);
+        rec[k] = pface_pack(r);
         if ((r.w0 >> 18) & 1) bpad[(size_t)sidx * h->bnd_pitch + ((r.w0 >> 20) & 0x3FF)] = r.w1;
       }
+      const uint16_t *cf = &p.cell_face[(size_t)sidx * 4 * 64];
+      std::string key((const char *)rec.data(), rec.size() * sizeof(uint32_t));
+      key.append((const char *)cf, 4 * 64 * sizeof(uint16_t));
+      auto it = pattern_of.find(key);
+      int pat;
+      if (it != pattern_of.end()) pat = it->second;
+      else {
+        pat = (int)pattern_of.size();
+        pattern_of.emplace(std::move(key), pat);
+        fpad.resize((size_t)(pat + 1) * h->face_pitch, 0u);
+        std::copy(rec.begin(), rec.end(), fpad.begin() + (size_t)pat * h->face_pitch);
+        cf_pat.insert(cf_pat.end(), cf, cf + 4 * 64);
+      }
+      hdr[sidx] = int4{p.shard_count[sidx] | (pat << 8), nf, nh, p.shard_bnd[sidx]};
     }
+    if (fpad.empty()) { fpad.assign(h->face_pitch, 0u); cf_pat.assign(4 * 64, kNoFace); }
+    h->n_patterns = (int)pattern_of.size();
     if ((rc = upload(h, &h->d_shard_hdr, hdr))) return bail(rc);
     if ((rc = upload(h, &h->d_halo_pad, hp))) return bail(rc);
     if ((rc = upload(h, &h->d_faces_pad, fpad))) return bail(rc);
+    if ((rc = upload(h, &h->d_cell_face, cf_pat))) return bail(rc);
     if ((rc = upload(h, &h->d_bnd_pad, bpad))) return bail(rc);
     if (h->prm.shock_indicator != DFLO_IND_LIMITER) {
       if ((rc = upload(h, &h->d_nbr_code, p.nbr_code))) return bail(rc);
@@ -867,8 +891,8 @@ int dflo_hip_create(const dflo_mesh_t *mesh, const dflo_params_t *params, int de
       per_cu = 1;
     if (n_cu < 1) n_cu = 256;
     if (std::getenv("DFLO_VERBOSE"))
-      std::fprintf(stderr, "dflo_hip: stage kernel N=%d: %zu bytes of LDS per workgroup, %d workgroups (%d wavefronts) resident per CU\n",
-                   h->N, h->lds_bytes, per_cu, per_cu * h->N);
+      std::fprintf(stderr, "dflo_hip: stage kernel N=%d: %zu bytes of LDS per workgroup, %d workgroups (%d wavefronts) resident per CU; %d shards, %d index patterns\n",
+                   h->N, h->lds_bytes, per_cu, per_cu * h->N, h->plan.n_shards, h->n_patterns);
     h->stage_grid = grid_for(h->plan.n_shards);  // one workgroup per shard (per_cu of them resident per CU)
     // a workgroup touches the index data of the shard that the same XCD takes ~1.5 residency rounds later
     h->prefetch_ahead = std::max(8, (per_cu * n_cu / 8) * 3 / 2);

@@ -509,15 +509,14 @@ __global__ __launch_bounds__(64 * N, (N == 4 && GEO == 0 && MODE == 0) ? DFLO_Q3
   //      is never used and never waited for.
   //      The destination registers stay reserved until the loads have landed (see the asm further down):
   //      a load issued through inline asm writes its register whenever the data arrives.
-  int pf0 = 0, pf1 = 0, pf2 = 0;
+  //      (halo table and header; the face records and face references are per pattern and stay cached by themselves)
+  int pf0 = 0, pf1 = 0;
   {
     const int ahead = a.sweep_rev ? max(shard - a.prefetch_ahead, 0) : min(shard + a.prefetch_ahead, a.n_shards - 1);
     const int32_t *p0 = a.halo_pad + (size_t)ahead * a.halo_pitch + (tid & 31);
-    const uint32_t *p1 = a.faces_pad + (size_t)ahead * a.face_pitch + tid;
-    const uint16_t *p2 = a.cell_face + (size_t)ahead * 4 * 64 + 2 * (tid & 127);
+    const int32_t *p1 = (const int32_t *)(a.shard_hdr + ahead) + (tid & 3);
     asm volatile("global_load_dword %0, %1, off" : "=v"(pf0) : "v"(p0));
     asm volatile("global_load_dword %0, %1, off" : "=v"(pf1) : "v"(p1));
-    asm volatile("global_load_dword %0, %1, off" : "=v"(pf2) : "v"(p2));
   }
   // ---- all loads of the shard, issued back to back; the halo entries first (the halo values depend on them)
   // halo entries: thread t works on entry (t & 31) + 32 b of every block b of 32 entries (8x8 lattice shards have one
@@ -528,7 +527,8 @@ __global__ __launch_bounds__(64 * N, (N == 4 && GEO == 0 && MODE == 0) ? DFLO_Q3
   for (int b = 0; b < HB; ++b) hentb[b] = a.halo_pad[(size_t)shard * a.halo_pitch + min((tid & 31) + 32 * b, a.halo_pitch - 1)];
   const int4 hdr = a.shard_hdr[shard];                // {cells, faces, halo entries, boundary faces}
   const int nf = hdr.y, nh = hdr.z, nbnd = hdr.w;
-  const bool active = lane < hdr.x;
+  const bool active = lane < (hdr.x & 0xFF);
+  const int pat = hdr.x >> 8;   // index pattern of the shard: its face records and face references
   double urow[4][N];                                  // node row `row` of the own cells
   {
     const double *up = a.Ucur + (size_t)shard * NDOF * 64 + (size_t)(N * row) * 64 + lane;   // one base, constant offsets
@@ -547,7 +547,7 @@ __global__ __launch_bounds__(64 * N, (N == 4 && GEO == 0 && MODE == 0) ? DFLO_Q3
     }
   }
   // face records of this thread's passes over the face points (see flux_phase for the numbering)
-  const uint32_t *fp = a.faces_pad + (size_t)shard * a.face_pitch;
+  const uint32_t *fp = a.faces_pad + (size_t)pat * a.face_pitch;
   uint32_t frr[3];
 #pragma unroll
   for (int it = 0; it < 3; ++it) frr[it] = fp[min(face_of_point<N>(tid + it * NT, nf), a.face_pitch - 1)];
@@ -562,7 +562,7 @@ __global__ __launch_bounds__(64 * N, (N == 4 && GEO == 0 && MODE == 0) ? DFLO_Q3
   }
   uint16_t cref[4];
 #pragma unroll
-  for (int f = 0; f < 4; ++f) cref[f] = a.cell_face[((size_t)shard * 4 + f) * 64 + lane];
+  for (int f = 0; f < 4; ++f) cref[f] = a.cell_face[((size_t)pat * 4 + f) * 64 + lane];
   double h = 0.0, vx[8], hq = 0.0;
   if constexpr (GEO == 0) {
     h = a.uniform_h ? a.h_uniform : a.cell_h[(size_t)shard * 64 + lane];
@@ -642,7 +642,7 @@ __global__ __launch_bounds__(64 * N, (N == 4 && GEO == 0 && MODE == 0) ? DFLO_Q3
   for (int c = 0; c < 4; ++c)
 #pragma unroll
     for (int m = 0; m < N; ++m) Us[(c * NS + m + N * row) * S + lane] = urow[c][m];
-  asm volatile("" ::"v"(pf0), "v"(pf1), "v"(pf2));  // the touch loads (oldest in the queue) have landed by now
+  asm volatile("" ::"v"(pf0), "v"(pf1));  // the touch loads (oldest in the queue) have landed by now
   if constexpr (FLUX == DFLO_FLUX_LXF) {
     if (row == 0) {
       double uvc[3];
@@ -1144,7 +1144,8 @@ __global__ __launch_bounds__(64 * N, N == 4 ? 2 : 3) void stage_kernel_pk(const 
   for (int t = 0; t < 2; ++t) hent[t] = a.halo_pad[(size_t)shard * a.halo_pitch + ((tid + t * NT) & 31)];
   const int4 hdr = a.shard_hdr[shard];
   const int nf = hdr.y, nh = hdr.z, nbnd = hdr.w;
-  const bool active = lane < hdr.x;
+  const bool active = lane < (hdr.x & 0xFF);
+  const int pat = hdr.x >> 8;   // index pattern of the shard: its face records and face references
   double umode[4][NM];
   {
     const double *up = a.Ucur + (size_t)shard * NDOFM * 64 + lane;
@@ -1160,13 +1161,13 @@ __global__ __launch_bounds__(64 * N, N == 4 ? 2 : 3) void stage_kernel_pk(const 
       for (int c = 0; c < 4; ++c) uavg[c] = a.avg_cur[((size_t)shard * 4 + c) * 64 + lane];
     }
   }
-  const uint32_t *fp = a.faces_pad + (size_t)shard * a.face_pitch;
+  const uint32_t *fp = a.faces_pad + (size_t)pat * a.face_pitch;
   uint32_t frr[3];
 #pragma unroll
   for (int it = 0; it < 3; ++it) frr[it] = fp[min(face_of_point<N>(tid + it * NT, nf), a.face_pitch - 1)];
   uint16_t cref[4];
 #pragma unroll
-  for (int f = 0; f < 4; ++f) cref[f] = a.cell_face[((size_t)shard * 4 + f) * 64 + lane];
+  for (int f = 0; f < 4; ++f) cref[f] = a.cell_face[((size_t)pat * 4 + f) * 64 + lane];
   const double h = a.uniform_h ? a.h_uniform : a.cell_h[(size_t)shard * 64 + lane];
   double dt_step = 0.0;   // fetched with the other loads, not in the middle of phase C
   if constexpr (MODE != 2) dt_step = a.dt_cell ? a.dt_cell[(size_t)shard * 64 + lane] : (a.dt_host >= 0.0 ? a.dt_host : *a.dt_dev);
