@@ -113,12 +113,12 @@ __global__ __launch_bounds__(64, DFLO_LIM_WAVES) void limiter_kernel(const LimAr
     EigenXY e;
     if (a.char_lim) e = eigen_at(A);
     double Dxn[4], Dyn[4], change_x = 0, change_y = 0;
+    // dx * cell-average gradient in direction dir (D0) and its characteristic projection (D); l_m(1) - l_m(0) is antisymmetric
+    // in m, and pairing the nodes makes the slope of a constant state exactly zero
+    auto slopes = [&](int dir, double *D0, double *D) {
 #pragma unroll
-    for (int dir = 0; dir < 2; ++dir) {
-      double D[4], db[4], df[4];
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {   // dx * cell-average gradient, see above; l_m(1) - l_m(0) is antisymmetric in m, and
-        double g = 0;                  // pairing the nodes makes the slope of a constant state exactly zero
+      for (int c = 0; c < 4; ++c) {
+        double g = 0;
 #pragma unroll
         for (int b = 0; b < N; ++b)
 #pragma unroll
@@ -126,11 +126,30 @@ __global__ __launch_bounds__(64, DFLO_LIM_WAVES) void limiter_kernel(const LimAr
             const int j0 = dir == 0 ? m + N * b : b + N * m, j1 = dir == 0 ? (N - 1 - m) + N * b : b + N * (N - 1 - m);
             g += CB<N>::t.w[b] * (CB<N>::t.L1[m] - CB<N>::t.L0[m]) * (U[c * NS + j0] - U[c * NS + j1]);
           }
-        D[c] = g;
+        D0[c] = D[c] = g;
       }
-      // the boundary case "no neighbour: difference = own slope" (:296-316) is resolved before the projection
-      const double D0[4] = {D[0], D[1], D[2], D[3]};
       if (a.char_lim) to_char(e, dir, D);
+    };
+    // minmod hands back its first argument, zero, or something of the same sign and no larger: |limited - slope| <= |slope|.
+    // So the "change" that decides whether the cell is rewritten (src/limiter.cc:347: > 1e-10) is at most a quarter of the sum
+    // of the |slopes| -- where that is below the threshold in every cell of the wavefront (states that are constant up to
+    // rounding: most of a shock tube), the neighbours need not be looked at at all.
+    bool tiny;
+    {
+      double D0[4], Dx[4], Dy[4];
+      slopes(0, D0, Dx);
+      slopes(1, D0, Dy);
+      double bx = 0, by = 0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { bx += fabs(Dx[i]); by += fabs(Dy[i]); }
+      tiny = 0.25 * bx + 0.25 * by <= 1.0e-10;
+    }
+    if (!__all(tiny || !active)) {
+#pragma unroll
+    for (int dir = 0; dir < 2; ++dir) {
+      double D[4], D0[4], db[4], df[4];
+      // (the boundary case "no neighbour: difference = own slope" (:296-316) is resolved before the projection: D0)
+      slopes(dir, D0, D);
       // minmod returns its first argument untouched when |a| < M dx^2 (src/limiter.cc:21): if that holds for
       // every component of every cell of the wavefront, the neighbour differences are not needed at all
       bool smooth = true;
@@ -160,6 +179,7 @@ __global__ __launch_bounds__(64, DFLO_LIM_WAVES) void limiter_kernel(const LimAr
         if (dir == 0) { Dxn[i] = dn; change_x += fabs(dn - D[i]); }
         else { Dyn[i] = dn; change_y += fabs(dn - D[i]); }
       }
+    }
     }
     change_x *= 0.25;
     change_y *= 0.25;
