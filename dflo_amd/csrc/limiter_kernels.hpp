@@ -322,28 +322,38 @@ __global__ __launch_bounds__(64) void limiter_pk_kernel(const LimArgs a) {
       Dy[c] = U[c][N] * sqrt_3;       // mode (0,1) = index k+1
     }
     const double ang_mom = Dx[MY] - Dy[MX];   // angular momentum of a square cell = v_x - u_y, :453
+    const double Dx0[4] = {Dx[0], Dx[1], Dx[2], Dx[3]}, Dy0[4] = {Dy[0], Dy[1], Dy[2], Dy[3]};
+    EigenXY e;
+    if (a.char_lim) {
+      e = eigen_at(A);
+      to_char(e, 0, Dx); to_char(e, 1, Dy);
+    }
+    double Dxn[4], Dyn[4], change_x = 0, change_y = 0;
+    // |minmod(a, ..) - a| <= |a|: where a quarter of the sum of the |slopes| is below the rewrite threshold in every cell of the
+    // wavefront, the neighbours are not looked at (see limiter_kernel)
+    double bx = 0, by = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { bx += fabs(Dx[i]); by += fabs(Dy[i]); }
+    if (!__all(bx / 4 + by / 4 <= 1.0e-10)) {   // (padding lanes have left the kernel)
     const int il = a.lrbt[((size_t)shard * 4 + 0) * 64 + lane], ir = a.lrbt[((size_t)shard * 4 + 1) * 64 + lane];
     const int ib = a.lrbt[((size_t)shard * 4 + 2) * 64 + lane], it = a.lrbt[((size_t)shard * 4 + 3) * 64 + lane];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      dbx[c] = il >= 0 ? A[c] - a.avg[((size_t)(il >> 6) * 4 + c) * 64 + (il & 63)] : Dx[c];
-      dfx[c] = ir >= 0 ? a.avg[((size_t)(ir >> 6) * 4 + c) * 64 + (ir & 63)] - A[c] : Dx[c];
-      dby[c] = ib >= 0 ? A[c] - a.avg[((size_t)(ib >> 6) * 4 + c) * 64 + (ib & 63)] : Dy[c];
-      dfy[c] = it >= 0 ? a.avg[((size_t)(it >> 6) * 4 + c) * 64 + (it & 63)] - A[c] : Dy[c];
+      dbx[c] = il >= 0 ? A[c] - a.avg[((size_t)(il >> 6) * 4 + c) * 64 + (il & 63)] : Dx0[c];
+      dfx[c] = ir >= 0 ? a.avg[((size_t)(ir >> 6) * 4 + c) * 64 + (ir & 63)] - A[c] : Dx0[c];
+      dby[c] = ib >= 0 ? A[c] - a.avg[((size_t)(ib >> 6) * 4 + c) * 64 + (ib & 63)] : Dy0[c];
+      dfy[c] = it >= 0 ? a.avg[((size_t)(it >> 6) * 4 + c) * 64 + (it & 63)] - A[c] : Dy0[c];
     }
-    EigenXY e;
     if (a.char_lim) {
-      e = eigen_at(A);
       to_char(e, 0, dbx); to_char(e, 0, dfx); to_char(e, 1, dby); to_char(e, 1, dfy);
-      to_char(e, 0, Dx); to_char(e, 1, Dy);
     }
-    double Dxn[4], Dyn[4], change_x = 0, change_y = 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       Dxn[i] = minmod(Dx[i], beta * dbx[i], beta * dfx[i], Mdx2);
       Dyn[i] = minmod(Dy[i], beta * dby[i], beta * dfy[i], Mdx2);
       change_x += fabs(Dxn[i] - Dx[i]);
       change_y += fabs(Dyn[i] - Dy[i]);
+    }
     }
     change_x /= 4;
     change_y /= 4;

@@ -120,6 +120,8 @@ def one(i):
     assert rel(r1, r2) < 1e-11, ("residual", rel(r1, r2))
     t = 0.0
     for it in range(3):
+        if not np.isfinite(ora.get_solution()).all():   # the reference's own arithmetic has broken down: the NaN cells are compared below
+            break
         dt = ora.compute_time_step(t)
         dtc = claw.compute_time_step()
         assert abs(dtc - dt) <= (1e-9 if "kink" in desc else 1e-11) * dt, ("dt", it, dtc, dt)
