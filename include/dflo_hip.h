@@ -152,7 +152,8 @@ int32_t dflo_hip_n_rk(dflo_hip_handle h);       /* stages per step, src/claw.cc:
  * cell averages as run() does after the IC (src/claw.cc:997). */
 int dflo_hip_set_solution(dflo_hip_handle h, const double *u);
 int dflo_hip_get_solution(dflo_hip_handle h, double *u);
-/* cell_average, [n_cells][4] (src/claw.cc:562-597) */
+/* cell_average, [n_cells][4] (src/claw.cc:562-597).  After an intermediate stage of a run in which nothing on the device reads
+ * the averages (no LxF flux, limiter, indicator or local time step) they are formed by this call, not by the stage. */
 int dflo_hip_get_cell_average(dflo_hip_handle h, double *avg);
 
 /* Boundary faces in the order MeshWorker meets them (cell ascending, face
