@@ -818,7 +818,7 @@ int dflo_hip_create(const dflo_mesh_t *mesh, const dflo_params_t *params, int de
   const size_t nsh = std::max(p.n_shards, 1);
   if (hipMalloc((void **)&h->shard_res, 3 * nsh * sizeof(double)) != hipSuccess ||
       hipMalloc((void **)&h->shard_dtmin, nsh * sizeof(double)) != hipSuccess ||
-      hipMalloc((void **)&h->res_sq, 4 * sizeof(double)) != hipSuccess || hipMalloc((void **)&h->fin_partial, 4 * 32 * sizeof(double)) != hipSuccess ||
+      hipMalloc((void **)&h->res_sq, 4 * sizeof(double)) != hipSuccess || hipMalloc((void **)&h->fin_partial, 4 * kFinBlocks * sizeof(double)) != hipSuccess ||
       hipMalloc((void **)&h->dt_dev, 4 * sizeof(double)) != hipSuccess || hipMalloc((void **)&h->fin_counter, sizeof(int)) != hipSuccess ||
       hipMalloc((void **)&h->dt_pub, 2 * sizeof(double)) != hipSuccess || hipMalloc((void **)&h->pos_stats, 2 * sizeof(unsigned long long)) != hipSuccess) {
     h->err = "hipMalloc(scalars) failed";

@@ -309,7 +309,7 @@ __device__ __forceinline__ double dt_rules(double dt, double t, double time_step
   }
   return dt;
 }
-constexpr int kFinBlocks = 32;   // workgroups of the two-level reduction
+constexpr int kFinBlocks = 64;   // workgroups of the two-level reduction (one lane of the last workgroup's first wavefront each)
 __global__ __launch_bounds__(256) void finalize_kernel(const FinalArgs a) {
   __shared__ double sred[4][4];
   __shared__ int is_last;
@@ -320,9 +320,23 @@ __global__ __launch_bounds__(256) void finalize_kernel(const FinalArgs a) {
   const int chunk = ((n + kFinBlocks - 1) / kFinBlocks + 255) & ~255;
   const int lo = b * chunk, hi = min(n, lo + chunk);
   double rs[3] = {0.0, 0.0, 0.0}, m = 1.0e20;
-  for (int s = lo + t; s < hi; s += 256) {
-    for (int st = 0; st < a.n_stages; ++st) rs[st] += a.shard_res[(size_t)st * a.res_stride + s];
-    if (a.do_dt) m = fmin(m, a.shard_dtmin[s]);
+  // four passes of the loop at a time: their loads are in flight together (one trip to memory instead of four)
+  for (int s0 = lo + t; s0 < hi; s0 += 4 * 256) {
+    double v[4][3], d[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int s = s0 + j * 256;
+      const bool in = s < hi;
+#pragma unroll
+      for (int st = 0; st < 3; ++st) v[j][st] = (in && st < a.n_stages) ? a.shard_res[(size_t)st * a.res_stride + s] : 0.0;
+      d[j] = (in && a.do_dt) ? a.shard_dtmin[s] : 1.0e20;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+      for (int st = 0; st < 3; ++st) rs[st] += v[j][st];
+      m = fmin(m, d[j]);
+    }
   }
   for (int st = 0; st < 3; ++st) {
     const double r = wave_sum(rs[st]);
@@ -343,21 +357,22 @@ __global__ __launch_bounds__(256) void finalize_kernel(const FinalArgs a) {
   __shared__ double spart[kFinBlocks * 4];
   if (t < (int)gridDim.x * 4) spart[t] = ((const volatile double *)a.partial)[t];  // one round trip for all partials
   __syncthreads();
+  if (t >= 64) return;
+  // the partials of workgroup i in lane i of the first wavefront; butterfly sums (a fixed order) instead of one thread walking
+  // through them (a chain of dependent LDS reads: it was half of this kernel's duration)
+  const bool have = t < (int)gridDim.x;
+  double tot[3], dt = have ? spart[t * 4 + 3] : 1.0e20;
+  for (int st = 0; st < 3; ++st) tot[st] = wave_sum(have ? spart[t * 4 + st] : 0.0);
+  dt = wave_min(dt);
   if (t != 0) return;
   *a.counter = 0;  // ready for the next launch (launches on one stream do not overlap)
-  for (int st = 0; st < a.n_stages; ++st) {
-    double tot = 0.0;
-    for (int i = 0; i < (int)gridDim.x; ++i) tot += spart[i * 4 + st];
-    a.res_sq[st] = tot;
-  }
+  for (int st = 0; st < a.n_stages; ++st) a.res_sq[st] = tot[st];
   if (a.do_dt) {
     double tt = a.dt_dev[1];
     if (a.advance_time) {  // elapsed_time += global_dt (src/claw.cc:1072) for the step just done
       tt += a.dt_host >= 0.0 ? a.dt_host : a.dt_dev[0];
       a.dt_dev[1] = tt;
     }
-    double dt = spart[3];
-    for (int i = 1; i < (int)gridDim.x; ++i) dt = fmin(dt, spart[i * 4 + 3]);
     a.dt_dev[2] = dt;
     if (a.publish) *a.publish = dt;
     a.dt_dev[0] = dt_rules(dt, tt, a.time_step, a.final_time, a.global_rules, a.fixed_dt);
