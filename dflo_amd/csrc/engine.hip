@@ -45,10 +45,11 @@ struct dflo_hip_engine {
   std::vector<int32_t> bc_ops[DFLO_MAX_BOUNDARIES][4];
   std::vector<double> bc_consts[DFLO_MAX_BOUNDARIES][4];
   int n_bc_programs = 0;
+  bool bc_rich = false;   // the boundary programs use a transcendental function (bc_eval_kernel<true>)
   bool bc_dirty = false;
   int32_t *d_bc_ops = nullptr, *d_bc_prog = nullptr, *d_bface_id = nullptr, *d_bc_faces = nullptr;
   int n_bc_faces = 0, n_bc_ops = 0, n_bc_consts = 0;
-  double *d_bc_consts = nullptr, *d_bxy = nullptr;
+  double *d_bc_consts = nullptr, *d_bxy = nullptr, *d_bc_pts = nullptr;
   int32_t *d_shard_count = nullptr;
   uint32_t *d_faces_pad = nullptr;
   uint8_t *d_nbr_code = nullptr;
@@ -231,6 +232,14 @@ void time_collect(dflo_hip_engine *h) {
 // limiter kernels may then be launched for all shards or separately for the rim shards (those that read
 // ghost cells) and the interior shards, and it is finished by the reductions.
 int eval_boundary_programs(dflo_hip_engine *h, double dt_host);
+static bool bc_op_is_rich(int op) {
+  switch (op) {
+    case DFLO_OP_POW: case DFLO_OP_SIN: case DFLO_OP_COS: case DFLO_OP_TAN: case DFLO_OP_EXP: case DFLO_OP_LOG: case DFLO_OP_ATAN2:
+    case DFLO_OP_TANH: case DFLO_OP_SINH: case DFLO_OP_COSH: case DFLO_OP_ASIN: case DFLO_OP_ACOS: case DFLO_OP_ATAN:
+    case DFLO_OP_LOG10: case DFLO_OP_ERF: case DFLO_OP_ERFC: return true;
+    default: return false;
+  }
+}
 
 int open_stage(dflo_hip_engine *h, int rk, double dt_host, bool residual_only, int which_override) {
   if (rk == 0 && !residual_only && h->n_bc_programs > 0) {  // boundary functions at t (stage 0) and t + dt (later stages)
@@ -272,12 +281,14 @@ int eval_boundary_programs(dflo_hip_engine *h, double dt_host) {
   if (h->bc_dirty) {  // flatten the programs: one op / constant pool, a (first, count) entry per (id, component)
     std::vector<int32_t> ops, prog(DFLO_MAX_BOUNDARIES * 4 * 2, 0);
     std::vector<double> consts;
+    bool rich = false;   // any transcendental function among the programs?
     for (int b = 0; b < DFLO_MAX_BOUNDARIES; ++b)
       for (int c = 0; c < 4; ++c) {
         const std::vector<int32_t> &o = h->bc_ops[b][c];
         prog[(b * 4 + c) * 2] = (int32_t)(ops.size() / 2);
         prog[(b * 4 + c) * 2 + 1] = (int32_t)(o.size() / 2);
         for (size_t k = 0; k < o.size(); k += 2) {
+          rich |= bc_op_is_rich(o[k]);
           ops.push_back(o[k]);
           ops.push_back(o[k] == DFLO_OP_CONST ? o[k + 1] + (int32_t)consts.size() : 0);
         }
@@ -295,17 +306,25 @@ int eval_boundary_programs(dflo_hip_engine *h, double dt_host) {
       if (any) faces.push_back(b);
     }
     h->n_bc_faces = (int)faces.size();
+    std::vector<double> pts;   // per listed point: x, y, index in the value tables, boundary id
+    for (int b : faces)
+      for (int q = 0; q < h->N; ++q) {
+        const size_t i = (size_t)b * h->N + q;
+        pts.insert(pts.end(), {h->bface_xy[2 * i], h->bface_xy[2 * i + 1], (double)i, (double)p.bface_id[b]});
+      }
+    if (pts.empty()) pts.assign(4, 0.0);
     if (faces.empty()) faces.push_back(0);
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    hipFree(h->d_bc_ops); hipFree(h->d_bc_consts); hipFree(h->d_bc_prog); hipFree(h->d_bc_faces);
-    h->d_bc_ops = nullptr; h->d_bc_consts = nullptr; h->d_bc_prog = nullptr; h->d_bc_faces = nullptr;
+    hipFree(h->d_bc_ops); hipFree(h->d_bc_consts); hipFree(h->d_bc_prog); hipFree(h->d_bc_faces); hipFree(h->d_bc_pts);
+    h->d_bc_ops = nullptr; h->d_bc_consts = nullptr; h->d_bc_prog = nullptr; h->d_bc_faces = nullptr; h->d_bc_pts = nullptr;
     int rc;
     if ((rc = upload(h, &h->d_bc_ops, ops)) || (rc = upload(h, &h->d_bc_consts, consts)) || (rc = upload(h, &h->d_bc_prog, prog)) ||
-        (rc = upload(h, &h->d_bc_faces, faces)))
+        (rc = upload(h, &h->d_bc_faces, faces)) || (rc = upload(h, &h->d_bc_pts, pts)))
       return rc;
     if (!h->d_bface_id) {
       if ((rc = upload(h, &h->d_bface_id, p.bface_id)) || (rc = upload(h, &h->d_bxy, h->bface_xy))) return rc;
     }
+    h->bc_rich = rich;
     h->bc_dirty = false;
   }
   BcArgs a{};
@@ -319,12 +338,14 @@ int eval_boundary_programs(dflo_hip_engine *h, double dt_host) {
   a.dt_dev = h->dt_dev;
   a.dt_host = dt_host;
   a.faces = h->d_bc_faces;
+  a.pts = h->d_bc_pts;
   a.n_faces = h->n_bc_faces;
   a.N = h->N;
   a.n_ops = h->n_bc_ops;
   a.n_consts = h->n_bc_consts;
   if (a.n_faces == 0) return DFLO_OK;
-  hipLaunchKernelGGL(bc_eval_kernel, dim3((a.n_faces * a.N + 63) / 64), dim3(kBcThreads), 0, h->stream, a);
+  if (h->bc_rich) hipLaunchKernelGGL(bc_eval_kernel<true>, dim3((a.n_faces * a.N + 63) / 64), dim3(kBcThreads), 0, h->stream, a);
+  else hipLaunchKernelGGL(bc_eval_kernel<false>, dim3((a.n_faces * a.N + 63) / 64), dim3(kBcThreads), 0, h->stream, a);
   HIPCHK(h, hipGetLastError());
   return DFLO_OK;
 }
@@ -913,7 +934,7 @@ int dflo_hip_destroy(dflo_hip_handle h) {
   for (int i = 0; i < 3; ++i) hipFree(h->U[i]);
   for (int i = 0; i < 2; ++i) { hipFree(h->avg[i]); hipFree(h->bval[i]); }
   hipFree(h->rhs); hipFree(h->user_buf); hipFree(h->bface_kind);
-  hipFree(h->d_bc_ops); hipFree(h->d_bc_consts); hipFree(h->d_bc_prog); hipFree(h->d_bc_faces); hipFree(h->d_bface_id); hipFree(h->d_bxy);
+  hipFree(h->d_bc_ops); hipFree(h->d_bc_consts); hipFree(h->d_bc_prog); hipFree(h->d_bc_faces); hipFree(h->d_bc_pts); hipFree(h->d_bface_id); hipFree(h->d_bxy);
   hipFree(h->d_shard_count);
   hipFree(h->d_bnd_pad); hipFree(h->d_nbr_code); hipFree(h->d_shock); hipFree(h->lim_mask); hipFree(h->d_faces_pad); hipFree(h->d_shard_hdr); hipFree(h->d_halo_pad); hipFree(h->d_cell_face); hipFree(h->d_lrbt); hipFree(h->d_user_of); hipFree(h->d_iid);
   hipFree(h->d_rim_list); hipFree(h->d_int_list); hipFree(h->d_rim2_list); hipFree(h->d_rest2_list);

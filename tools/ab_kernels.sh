@@ -12,7 +12,7 @@ for v in "$@"; do
 import csv, glob, sys
 f = glob.glob(sys.argv[1] + "/**/*kernel_stats.csv", recursive=True)[0]
 for r in csv.DictReader(open(f)):
-    if any(k in r["Name"] for k in ("stage_kernel", "limiter", "finalize", "indicator", "dt_")):
+    if any(k in r["Name"] for k in ("stage_kernel", "limiter", "finalize", "indicator", "dt_", "bc_eval")):
         print("   %-50s calls %5s avg %8.1f us" % (r["Name"][:50], r["Calls"], float(r["AverageNs"]) / 1e3))
 PY
 done
