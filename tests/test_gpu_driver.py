@@ -478,3 +478,29 @@ def test_forward_step_c5_style(tmp_path):
     assert np.abs(a[up] - np.array([4.2, 0.0, 1.4, 8.8])).max() < 1e-9
     dm = (a[:, 2] * area).sum() - m0
     assert abs(dm - 4.2 * (1.0 - 0.8) * (t1 - t0)) < 2e-3 * 4.2 * (t1 - t0)
+
+
+@pytest.mark.parametrize("extra", [[], ["--config", "c3"], ["--config", "c5", "--nx", "8"]])
+def test_bench_line_contract(extra):
+    """bench.py prints ONE JSON line with the fields of the driver's contract (metric / value / unit / n_gpus / steps / warmup /
+    ms_per_step / higher_is_better / scaling / vs_baseline / dtype / data / config.workload) plus `roofline` and, at N = 1,
+    `cpu_baseline` unless it is switched off; value = n_dofs * n_rk * steps / time."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "4", "--warmup", "2", "--no-cpu-baseline", "--no-secondary"] + extra
+    if not extra:
+        cmd += ["--nx", "96"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 4 and d["warmup"] == 2 and d["higher_is_better"] is True and d["dtype"] == "f64"
+    assert d["vs_baseline"] is None and d["scaling"] == "weak" and "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert d["value"] > 0 and abs(d["value"] - d["config"]["n_dofs"] * d["config"]["n_rk"] / (d["ms_per_step"] * 1e-3) / 1e6) <= 1e-6 * d["value"]
