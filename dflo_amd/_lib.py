@@ -68,7 +68,7 @@ SYMBOLS = [
     "dflo_hip_unpack_ghost_avg", "dflo_hip_n_ghost_cells", "dflo_hip_stage_update", "dflo_hip_stage_limit",
     "dflo_hip_stage_open", "dflo_hip_stage_update_part", "dflo_hip_stage_limit_part", "dflo_hip_stage_finish",
     "dflo_hip_n_rim_shards",
-    "dflo_hip_scalar_ptrs", "dflo_hip_apply_dt_rules", "dflo_hip_debug_math",
+    "dflo_hip_scalar_ptrs", "dflo_hip_apply_dt_rules", "dflo_hip_debug_math", "dflo_hip_debug_exp",
     "dflo_mesh_cartesian", "dflo_mesh_from_quads", "dflo_mesh_read_gmsh", "dflo_mesh_partition", "dflo_mesh_make_periodic", "dflo_mesh_free",
     "dflo_mesh_last_error", "dflo_mesh_support_points", "dflo_mesh_partition_ex", "dflo_mesh_partition_owners",
     "dflo_hip_failure_step", "dflo_hip_positivity_stats", "dflo_hip_dt_publish", "dflo_hip_apply_dt_rules_peers",
@@ -160,6 +160,7 @@ _sig("dflo_hip_n_rim_shards", C.c_int, _H)
 _sig("dflo_hip_scalar_ptrs", C.c_int, _H, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p))
 _sig("dflo_hip_apply_dt_rules", C.c_int, _H)
 _sig("dflo_hip_debug_math", C.c_int, C.c_int, _dp, _dp, _dp)
+_sig("dflo_hip_debug_exp", C.c_int, C.c_int, _dp, _dp, _dp)
 _sig("dflo_mesh_cartesian", C.c_int, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double, _ip, C.c_int32,
      C.POINTER(_MP))
 _sig("dflo_mesh_from_quads", C.c_int, C.c_int32, _dp, C.c_int32, _ip, C.c_int32, _ip, _ip, C.c_int32, C.POINTER(_MP))

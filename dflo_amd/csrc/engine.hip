@@ -1532,6 +1532,19 @@ int dflo_hip_debug_math(int n, const double *x, double *rcp_out, double *sqrt_ou
   return hipGetLastError() == hipSuccess ? DFLO_OK : DFLO_ERR_HIP;
 }
 
+int dflo_hip_debug_exp(int n, const double *x, double *exp_library, double *exp_flux) {
+  double *dx = nullptr, *dl = nullptr, *df = nullptr;
+  if (hipMalloc((void **)&dx, n * sizeof(double)) != hipSuccess || hipMalloc((void **)&dl, n * sizeof(double)) != hipSuccess ||
+      hipMalloc((void **)&df, n * sizeof(double)) != hipSuccess)
+    return DFLO_ERR_HIP;
+  hipMemcpy(dx, x, n * sizeof(double), hipMemcpyHostToDevice);
+  hipLaunchKernelGGL(debug_exp_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, dx, dl, df, n);
+  hipMemcpy(exp_library, dl, n * sizeof(double), hipMemcpyDeviceToHost);
+  hipMemcpy(exp_flux, df, n * sizeof(double), hipMemcpyDeviceToHost);
+  hipFree(dx); hipFree(dl); hipFree(df);
+  return hipGetLastError() == hipSuccess ? DFLO_OK : DFLO_ERR_HIP;
+}
+
 /* developer probe: per-workgroup cycle counts of the stage kernel's phases (library built with
  * -DDFLO_PHASE_TIMING); returns the grid size, 0 when the probe is compiled out. */
 int dflo_hip_debug_phase_cycles(dflo_hip_handle h, unsigned long long *out, int max_groups) {

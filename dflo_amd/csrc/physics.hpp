@@ -285,14 +285,36 @@ __device__ __forceinline__ void hllc_flux(double nx, double ny, const double *Wl
   F[EN] = supersonic ? Fs_en : (eS + pstar) * sm;
 }
 
+// exp(x) for x <= 0 (the Gaussians of the kinetic split fluxes).  The arithmetic of the device library's exp() -- x = k ln 2 + r
+// with ln 2 in two pieces, its degree-11 polynomial in r (coefficients in hexadecimal below), 2^k by v_ldexp_f64 -- so the value
+// is the library's bit for bit; what goes is the re-creation of the ten coefficients in vector registers at every call and the
+// overflow cases that cannot occur here (half of the routine's instructions).
+__device__ __forceinline__ double fexp_neg(double x) {
+  x = x < -1000.0 ? -1000.0 : x;   // exp(-inf) = 0 (2^-1443 underflows to 0 in v_ldexp_f64); a NaN stays a NaN
+  const double k = __builtin_rint(x * 0x1.71547652b82fep+0);
+  double r = __builtin_fma(-0x1.62e42fefa39efp-1, k, x);
+  r = __builtin_fma(-0x1.abc9e3b39803fp-56, k, r);
+  double p = __builtin_fma(0x1.ade156a5dcb37p-26, r, 0x1.28af3fca7ab0cp-22);
+  p = __builtin_fma(r, p, 0x1.71dee623fde64p-19);
+  p = __builtin_fma(r, p, 0x1.a01997c89e6b0p-16);
+  p = __builtin_fma(r, p, 0x1.a01a014761f6ep-13);
+  p = __builtin_fma(r, p, 0x1.6c16c1852b7b0p-10);
+  p = __builtin_fma(r, p, 0x1.1111111122322p-7);
+  p = __builtin_fma(r, p, 0x1.55555555502a1p-5);
+  p = __builtin_fma(r, p, 0x1.5555555555511p-3);
+  p = __builtin_fma(r, p, 0x1.000000000000bp-1);
+  p = __builtin_fma(r, p, 1.0);
+  p = __builtin_fma(r, p, 1.0);
+  return __builtin_amdgcn_ldexp(p, (int)k);
+}
 // Abramowitz-Stegun 7.1.26 exactly as the reference uses it (src/equation.h:688-709) -- NOT erf()
-__device__ __forceinline__ double ERF(double xarg) {
+__device__ __forceinline__ double ERF(double xarg, double gauss /* exp(-xarg^2) */) {
   const double a1 = 0.254829592, a2 = -0.284496736, a3 = 1.421413741, a4 = -1.453152027, a5 = 1.061405429;
   const double p = 0.3275911;
   const double sign = (xarg < 0) ? -1.0 : 1.0;
   const double x = fabs(xarg);
   const double t = frcp(1.0 + p * x);
-  const double y = 1.0 - (((((a5 * t + a4) * t) + a3) * t + a2) * t + a1) * t * exp(-x * x);
+  const double y = 1.0 - (((((a5 * t + a4) * t) + a3) * t + a2) * t + a1) * t * gauss;
   return sign * y;
 }
 // src/equation.h:716-751
@@ -303,8 +325,9 @@ __device__ __forceinline__ void kinetic_split_flux(double sign, double nx, doubl
   const double beta = 0.5 * W[RHO] * frcp(p);
   const double sb = fsqrt(beta);
   const double s = vdotn * sb;
-  const double A = 0.5 * (1.0 + sign * ERF(s));
-  const double B = 0.5 * sign * exp(-s * s) * frcp(1.7724538509055160273 * sb);  // sqrt(pi*beta)
+  const double gauss = fexp_neg(-s * s);
+  const double A = 0.5 * (1.0 + sign * ERF(s, gauss));
+  const double B = 0.5 * sign * gauss * frcp(1.7724538509055160273 * sb);  // sqrt(pi*beta)
   const double ufact = vdotn * A + B;
   F[MX] = p * nx * A + W[MX] * ufact;
   F[MY] = p * ny * A + W[MY] * ufact;

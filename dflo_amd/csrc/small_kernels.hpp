@@ -143,6 +143,15 @@ __global__ void debug_math_kernel(const double *x, double *rcp, double *sq, int 
   }
 }
 
+// fexp_neg against the library's exp()
+__global__ void debug_exp_kernel(const double *x, double *lib, double *fast, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    lib[i] = exp(x[i]);
+    fast[i] = fexp_neg(x[i]);
+  }
+}
+
 // ------------------------------------------------------------------ small kernels
 // quadrature weight of node j for the cell average: w_a w_b (squares) or w_a w_b det J / |K| (bilinear cells)
 __device__ __forceinline__ double avg_weight(const KBasis &kb, int N, int j, const double *vert, int n_slots, int slot,

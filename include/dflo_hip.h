@@ -376,6 +376,9 @@ int dflo_hip_multi_stage_timing(dflo_hip_multi_handle m, int enable, double *avg
 /* Test hook: evaluates the device reciprocal / square-root forms the flux functions use
  * (dflo_amd/csrc/physics.hpp) on n host doubles. */
 int dflo_hip_debug_math(int n, const double *x, double *rcp_out, double *sqrt_out);
+/* Test hook: exp() of the device library and the form the kinetic split fluxes use for their Gaussians (fexp_neg,
+ * dflo_amd/csrc/physics.hpp; arguments <= 0), side by side. */
+int dflo_hip_debug_exp(int n, const double *x, double *exp_library, double *exp_flux);
 
 /* ------------------------------------------- host-side mesh construction */
 /* What GridIn::read_msh + Triangulation hand to dflo (src/claw.cc:957-967),

@@ -143,6 +143,23 @@ def test_device_reciprocal_sqrt_accuracy():
     assert ulp_s.max() <= 2.0, ulp_s.max()
 
 
+def test_flux_exponential_is_the_library_exponential():
+    """fexp_neg of physics.hpp (the Gaussians of the KFVS flux): the device library's exp() bit for bit on the arguments
+    that occur (<= 0), 0 at -inf, NaN kept, and within 1 ulp of the host's exp."""
+    from dflo_amd import _lib
+    rng = np.random.default_rng(11)
+    x = -np.concatenate([10.0 ** rng.uniform(-20, 2.8, 30000), rng.uniform(0.0, 50.0, 30000), [0.0, 700.0, 745.0, 746.0, 1e4, np.inf]])
+    a, b = np.empty_like(x), np.empty_like(x)
+    assert _lib.lib.dflo_hip_debug_exp(len(x), _lib.dptr(x), _lib.dptr(a), _lib.dptr(b)) == 0
+    assert (a == b).all(), np.abs(a - b).max()
+    ref = np.exp(x)
+    ok = ref > 1e-300
+    assert (np.abs(b[ok] - ref[ok]) / np.spacing(ref[ok])).max() <= 1.0
+    assert b[-1] == 0.0 and b[-2] == 0.0
+    x = np.array([np.nan])
+    assert _lib.lib.dflo_hip_debug_exp(1, _lib.dptr(x), _lib.dptr(a), _lib.dptr(b)) == 0 and np.isnan(b[0])
+
+
 # ---------------------------------------------------------------- bilinear (Q1-mapped) cells, SURVEY A.3
 def skewed_mesh(n=10, degree=2, amp=0.15, periodic=False):
     """n x n quads on [0,1]^2 with displaced interior vertices: genuinely non-affine cells."""
