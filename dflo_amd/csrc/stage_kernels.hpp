@@ -1008,11 +1008,16 @@ __device__ __forceinline__ void row_update_pk(const StageArgs &a, double *Us, co
   for (int c = 0; c < 4; ++c)
 #pragma unroll
     for (int m = 0; m < N; ++m) R[c][m] = 0.0;
+  // P3, first stage (LEAN, as in row_update): built for 3 wavefronts per SIMD -- the nodal values of the own row and the own G
+  // row come back from the LDS image instead of being held in registers, the G values are taken node by node
+  constexpr bool LEAN = N == 4 && MODE == 0;
   double Gown[N][4];
 #pragma unroll
   for (int aa = 0; aa < N; ++aa) {
-    double Fx[4];
-    flux_xy(Wrow[aa], Fx, Gown[aa]);
+    double Fx[4], Wa[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) Wa[c] = LEAN ? Us[(c * NS + aa + N * B) * S + lane] : Wrow[aa][c];
+    flux_xy(Wa, Fx, Gown[aa]);
     const double wbh = CB<N>::t.w[B] * h;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -1023,19 +1028,23 @@ __device__ __forceinline__ void row_update_pk(const StageArgs &a, double *Us, co
     }
     if (a.gravity != 0.0) {
       const double jxw = CB<N>::t.w[aa] * CB<N>::t.w[B] * h * h;
-      R[MY][aa] += a.gravity * (-1.0 * Wrow[aa][RHO]) * jxw;
-      R[EN][aa] += a.gravity * (-1.0 * Wrow[aa][MY]) * jxw;
+      R[MY][aa] += a.gravity * (-1.0 * Wa[RHO]) * jxw;
+      R[EN][aa] += a.gravity * (-1.0 * Wa[MY]) * jxw;
     }
   }
   __syncthreads();
+  int ln = lane;
 #pragma unroll
   for (int aa = 0; aa < N; ++aa) {
     const double wah = CB<N>::t.w[aa] * h;
+    if constexpr (LEAN) {
+      if (aa > 0) asm volatile("" : "+v"(ln) : "v"(R[0][aa - 1]), "v"(R[1][aa - 1]), "v"(R[2][aa - 1]), "v"(R[3][aa - 1]));
+    }
 #pragma unroll
     for (int q = 0; q < N; ++q)
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
-        const double gy = q == B ? Gown[aa][c] : Us[(c * NS + aa + N * q) * S + lane];
+        const double gy = (q == B && !LEAN) ? Gown[aa][c] : Us[(c * NS + aa + N * q) * S + ln];
         R[c][aa] += gy * (wah * CB<N>::t.DW[q][B]);
       }
   }
@@ -1118,7 +1127,7 @@ __device__ __forceinline__ void row_update_pk(const StageArgs &a, double *Us, co
 }
 
 template <int N, int FLUX, int MODE>
-__global__ __launch_bounds__(64 * N, N == 4 ? 2 : 3) void stage_kernel_pk(const StageArgs a) {
+__global__ __launch_bounds__(64 * N, N == 4 ? ((MODE == 0 && FLUX != DFLO_FLUX_LXF) ? DFLO_Q3_WAVES : 2) : 3) void stage_kernel_pk(const StageArgs a) {
   constexpr int NS = N * N, NM = N * (N + 1) / 2, NDOFM = 4 * NM, NT = 64 * N, MS = (NM + N - 1) / N;
   constexpr int ROWS = 4 * NS + (FLUX == DFLO_FLUX_LXF ? 3 : 0);
   constexpr int TROWS = 4 * N;
