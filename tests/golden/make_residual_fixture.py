@@ -612,6 +612,86 @@ class PkCase(Case):
         return Uc
 
 
+def tvb_pk(cs, U, M, beta, char_lim, conserve_ang_mom=False):
+    """apply_limiter_TVB_Pk (src/limiter.cc:377-516), every cell marked: slopes from the modes (1,0) and (0,1) of the orthonormal
+    basis (times sqrt 3), beta / 2, the other higher modes zeroed when a cell is limited"""
+    N, h, sq3, half_beta = cs.N, cs.h, D(3).sqrt(), D(beta) / 2
+    A = cs.averages(U)
+    out = [[list(comp) for comp in cell] for cell in U]
+    for j in range(cs.ny):
+        for i in range(cs.nx):
+            c = i + cs.nx * j
+            Mdx2 = D(M) * h * h
+            Dx = [U[c][comp][1] * sq3 for comp in range(4)]
+            Dy = [U[c][comp][N] * sq3 for comp in range(4)]
+            ang = Dx[1] - Dy[0]
+
+            def diff(f, own):
+                nb, bid = cs.neighbour(i, j, f)
+                if nb is None:
+                    return list(own)
+                return [A[c][k] - A[nb][k] for k in range(4)] if f in (0, 2) else [A[nb][k] - A[c][k] for k in range(4)]
+            dbx, dfx, dby, dfy = diff(0, Dx), diff(1, Dx), diff(2, Dy), diff(3, Dy)
+            if char_lim:
+                Rx, Lx, Ry, Ly = eigen_matrices(A[c])
+                dbx, dfx, Dx = to_char(Lx, dbx), to_char(Lx, dfx), to_char(Lx, Dx)
+                dby, dfy, Dy = to_char(Ly, dby), to_char(Ly, dfy), to_char(Ly, Dy)
+            Dxn = [minmod(Dx[k], half_beta * dbx[k], half_beta * dfx[k], Mdx2) for k in range(4)]
+            Dyn = [minmod(Dy[k], half_beta * dby[k], half_beta * dfy[k], Mdx2) for k in range(4)]
+            change = sum(abs(Dxn[k] - Dx[k]) for k in range(4)) / 4 + sum(abs(Dyn[k] - Dy[k]) for k in range(4)) / 4
+            if change > D("1e-10"):
+                if char_lim:
+                    Dxn, Dyn = to_con(Rx, Dxn), to_con(Ry, Dyn)
+                if conserve_ang_mom:
+                    Dyn[0] = (Dyn[0] - (ang - Dxn[1])) / 2
+                    Dxn[1] = ang + Dyn[0]
+                for comp in range(4):
+                    for m in range(1, len(cs.modes)):
+                        out[c][comp][m] = Dxn[comp] / sq3 if m == 1 else (Dyn[comp] / sq3 if m == N else D(0))
+    return out
+
+
+def positivity_pk(cs, U):
+    """apply_positivity_limiter, Pk branch (src/positivity.cc:17-208 with :100-109, :197-205): the same points (Gauss-Lobatto x
+    Gauss lines), the modal polynomial evaluated there, the modes >= 1 scaled"""
+    N, eps = cs.N, D("1e-13")
+    Ng = (cs.k + 3) // 2 if (cs.k + 3) % 2 == 0 else (cs.k + 4) // 2
+    gll = {2: [D(0), D(1)], 3: [D(0), D(1) / 2, D(1)]}[Ng]
+    A = cs.averages(U)
+    out = [[list(comp) for comp in cell] for cell in U]
+    thetas = []
+    for c in range(len(U)):
+        assert min(A[c][2], cf.prim(A[c])[3]) >= eps
+        pts = [(g, cs.xs[l]) for l in range(N) for g in gll], [(cs.xs[l], g) for l in range(N) for g in gll]
+        rho_min = min(cs.value(out[c], xi, eta)[2] for d in range(2) for xi, eta in pts[d])
+        th1 = min(abs(A[c][2] - eps) / (abs(A[c][2] - rho_min) + D("1e-13")), D(1))
+        if th1 < 1:
+            out[c][2] = [out[c][2][0]] + [th1 * v for v in out[c][2][1:]]
+        th2 = D(1)
+        for d in range(2):
+            for xi, eta in pts[d]:
+                mx, my, rho, en = cs.value(out[c], xi, eta)
+                pre = (G - 1) * (en - (mx * mx + my * my) / (2 * rho))
+                if pre < eps:
+                    drho, dmx, dmy, dE = rho - A[c][2], mx - A[c][0], my - A[c][1], en - A[c][3]
+                    a1 = 2 * drho * dE - (dmx * dmx + dmy * dmy)
+                    b1 = (2 * drho * (A[c][3] - eps / (G - 1)) + 2 * A[c][2] * dE - 2 * (A[c][0] * dmx + A[c][1] * dmy)) / a1
+                    c1 = (2 * A[c][2] * A[c][3] - (A[c][0] ** 2 + A[c][1] ** 2) - 2 * eps * A[c][2] / (G - 1)) / a1
+                    Dq = abs(b1 * b1 - 4 * c1).sqrt()
+                    t1, t2 = (-b1 - Dq) / 2, (-b1 + Dq) / 2
+                    lo, hi = D("-1e-12"), 1 + D("1e-12")
+                    t = t1 if lo < t1 < hi else t2
+                    assert lo < t < hi
+                    t = max(D(0), min(D(1), t))
+                    if abs(1 - t) < D("1e-14"):
+                        t = D(0)
+                    th2 = min(th2, t)
+        if th2 < 1:
+            out[c] = [[out[c][comp][0]] + [th2 * v for v in out[c][comp][1:]] for comp in range(4)]
+        thetas.append([th1, th2])
+    return out, thetas
+
+
 def kxrcf(cs, U, component):
     """compute_shock_indicator_kxrcf (src/indicator.cc:51-198) on squares, Qk: jump of the indicator variable over the inflow
     part of the cell boundary (inflow judged by the cell-average velocity), boundary faces skipped"""
@@ -781,6 +861,32 @@ def main():
         U1, th = positivity(cs, U0)
         out["limiter_cases"].append({"name": cs.name, "kind": "positivity", "nx": 3, "ny": 2, "h": format(cs.h, ".25e"), "degree": k, "side": wall,
                                      "U0": flat(U0), "U1": flat(U1), "theta": [[format(t, ".20e") for t in pair] for pair in th]})
+        print(cs.name, "theta", [[float(t) for t in pair] for pair in th], flush=True)
+    # ---- the same limiters on the modal (Pk) basis
+    out["pk_limiter_cases"] = []
+    for name, k, M, beta, char, ang in [("6x4 P1 TVB characteristic, M = 0", 1, "0", "2", True, False),
+                                         ("6x4 P2 TVB component-wise, M = 30, angular momentum kept", 2, "30", "1.5", False, True),
+                                         ("6x4 P3 TVB characteristic, M = 5", 3, "5", "1", True, False)]:
+        cs = PkCase(name, 6, 4, D(1) / 6, k, "hllc", wall, {0: "outflow"}, "0.5", jump)
+        U0 = cs.initial()
+        U1 = tvb_pk(cs, U0, M, beta, char, ang)
+        changed = sum(1 for c in range(len(U0)) if U0[c] != U1[c])
+        out["pk_limiter_cases"].append({"name": name, "kind": "tvb", "nx": 6, "ny": 4, "h": format(cs.h, ".25e"), "degree": k, "side": wall,
+                                        "M": M, "beta": beta, "char_lim": char, "conserve_angular_momentum": ang, "U0": flat(U0), "U1": flat(U1),
+                                        "cells_changed": changed})
+        print(name, "cells changed", changed, flush=True)
+    for k in (1, 2, 3):
+        cs = PkCase("3x2 P%d positivity" % k, 3, 2, D(1) / 3, k, "hllc", wall, {0: "outflow"}, "0.5", smooth)
+        U0 = cs.initial()
+        # cell 1: the density dips below zero towards a corner (theta1 < 1); cell 4: the pressure does (theta2 root in (0, 1));
+        # cell 5: both -- through the linear modes, which leave the average alone
+        for c, (dr, de) in {1: ("0.75", "0"), 4: ("0", "0.62"), 5: ("0.7", "0.5")}.items():
+            for m in (1, cs.N):
+                U0[c][2][m] -= D(dr) * U0[c][2][0] / D(3).sqrt()
+                U0[c][3][m] -= D(de) * U0[c][3][0] / D(3).sqrt()
+        U1, th = positivity_pk(cs, U0)
+        out["pk_limiter_cases"].append({"name": cs.name, "kind": "positivity", "nx": 3, "ny": 2, "h": format(cs.h, ".25e"), "degree": k, "side": wall,
+                                        "U0": flat(U0), "U1": flat(U1), "theta": [[format(t, ".20e") for t in pair] for pair in th]})
         print(cs.name, "theta", [[float(t) for t in pair] for pair in th], flush=True)
     json.dump(out, open(os.path.join(HERE, "residual_fixture.json"), "w"), indent=0)
     print("residual_fixture.json written")

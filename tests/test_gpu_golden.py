@@ -241,3 +241,16 @@ def test_device_kxrcf_matches_the_independent_derivation(case):
     ok = np.isfinite(want)
     assert (np.isfinite(got) == ok).all()
     assert np.abs(got[ok] - want[ok]).max() <= 1e-12 * np.abs(want[ok]).max()
+
+
+from test_oracle_assembly import _pk_limiter_fixture   # noqa: E402
+
+
+@pytest.mark.parametrize("case", _pk_limiter_fixture(), ids=[c["name"] for c in _pk_limiter_fixture()])
+def test_device_pk_limiters_match_the_independent_derivation(case):
+    """limiter_pk_kernel (modal TVB with / without characteristic projection and the angular-momentum correction; positivity with
+    theta1 < 1, theta2 < 1 and both) against the 60-digit derivation, single engine and two engines"""
+    got, want, before = run_limiter_case(case, lambda m, p: dflo_amd.ConservationLaw(m, p), basis="Pk")
+    assert np.abs(got - want).max() <= 1e-12 * np.abs(want).max()
+    got2, want, before = run_limiter_case(case, lambda m, p: dflo_amd.MultiConservationLaw(m, p, devices=[0, 0]), basis="Pk")
+    assert np.abs(got2 - want).max() <= 1e-12 * np.abs(want).max()

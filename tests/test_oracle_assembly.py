@@ -367,14 +367,22 @@ def _limiter_fixture():
     return json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "residual_fixture.json")))["limiter_cases"]
 
 
-def run_limiter_case(case, make_solver):
+def _pk_limiter_fixture():
+    import json
+    import os
+    return json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "residual_fixture.json")))["pk_limiter_cases"]
+
+
+def run_limiter_case(case, make_solver, basis="Qk"):
     """TVB (src/limiter.cc:225-370) and positivity (src/positivity.cc:17-208) limiters against the 60-digit derivation of
     tests/golden/make_residual_fixture.py; shared by the oracle and the device.  Returns (limited state, expected)."""
     f = lambda v: np.array([float(x) for x in v])
     mesh = dflo_amd.Mesh.cartesian(case["nx"], case["ny"], 0.0, 0.0, float(case["h"]), case["side"], case["degree"])
+    if basis != "Qk":
+        mesh.set_basis(basis)
     if case["kind"] == "tvb":
         prm = dflo_amd.Parameters(flux="hllc", limiter="TVB", char_lim=case["char_lim"], M=float(case["M"]), beta=float(case["beta"]),
-                                  boundary={0: "outflow"})
+                                  conserve_angular_momentum=bool(case.get("conserve_angular_momentum", False)), boundary={0: "outflow"})
     else:
         prm = dflo_amd.Parameters(flux="hllc", pos_lim=True, boundary={0: "outflow"})
     s = make_solver(mesh, prm)
@@ -482,3 +490,12 @@ def test_oracle_kxrcf_matches_the_independent_derivation(case):
     ok = np.isfinite(want)
     assert (np.isfinite(got) == ok).all() and ok.sum() >= 20 and (want[ok] > 1).sum() >= 4
     assert np.abs(got[ok] - want[ok]).max() <= 1e-12 * np.abs(want[ok]).max()
+
+
+@pytest.mark.parametrize("case", _pk_limiter_fixture(), ids=[c["name"] for c in _pk_limiter_fixture()])
+def test_oracle_pk_limiters_match_the_independent_derivation(case):
+    """apply_limiter_TVB_Pk (src/limiter.cc:377-516, with and without the angular-momentum correction) and the Pk branch of the
+    positivity limiter against the 60-digit derivation"""
+    got, want, before = run_limiter_case(case, lambda m, p: O.Oracle(m, p), basis="Pk")
+    assert np.abs(want - before).max() > 1e-3
+    assert np.abs(got - want).max() <= 1e-12 * np.abs(want).max()
