@@ -166,6 +166,11 @@ class Case:
                                 s += self.ws[q] * self.ws[b] * h * self.Dm[q][a] * F[b][q][0][comp]
                                 s += self.ws[a] * self.ws[q] * h * self.Dm[q][b] * F[q][a][1][comp]
                             R[c][comp][a + N * b] += s
+                        g = getattr(self, "gravity", D(0))   # forcing (src/equation.h:831-850): (0, -rho, 0, -my) g in (mx, my, rho, E)
+                        if g != 0:
+                            jxw = self.ws[a] * self.ws[b] * h * h
+                            R[c][1][a + N * b] += g * (-Uc[2][a + N * b]) * jxw
+                            R[c][3][a + N * b] += g * (-Uc[1][a + N * b]) * jxw
                 # faces: every cell subtracts the flux through its own faces with its own outward normal (the flux is
                 # conservative: F^(W+, W-, n) = -F^(W-, W+, -n) for every scheme of the reference, so this is the one-flux-per-face
                 # assembly of MeshWorker written per cell)
@@ -198,14 +203,26 @@ class Case:
             best = d if best is None or d < best else best
         return best
 
+    def cell_dts(self, U):
+        """time step type = local: dt(c) of compute_time_step_cartesian (src/claw.cc:486-511), kept per cell"""
+        out = []
+        for Ac in self.averages(U):
+            rho, u, v, p = cf.prim(Ac)
+            c = (G * p / rho).sqrt()
+            out.append(self.cfl / ((c + abs(u)) / self.h + (c + abs(v)) / self.h) / (2 * self.k + 1))
+        return out
+
     def step(self, U, dt):
+        """dt: one number, or a list with the time step of every cell (local time stepping)"""
         N = self.N
         ark = [D(0), D(1) / 2] if self.k == 1 else ([D(0)] if self.k == 0 else [D(0), D(3) / 4, D(1) / 3])
         Un, Uc = U, U
+        dts = dt if isinstance(dt, list) else [dt] * len(U)
         for a_rk in ark:
             R = self.residual(Uc)
             new = []
             for c in range(len(Uc)):
+                dt = dts[c]
                 cell = [[None] * (N * N) for _ in range(4)]
                 for comp in range(4):
                     for b in range(N):
@@ -834,6 +851,32 @@ def main():
         out["kxrcf_cases"].append({"name": name, "nx": 6, "ny": 4, "h": format(cs.h, ".25e"), "degree": k, "variable": cname, "U0": flat(U0),
                                    "indicator": [format(v, ".25e") if v is not None else "nan" for v in ind]})
         print(name, "cells over 1:", sum(1 for v in ind if v is not None and v > 1), flush=True)
+    # ---- gravity forcing and local time stepping (time step type = local)
+    out["forcing_cases"] = []
+    for name, nx, ny, k, flux, side, kinds, cfl, grav, local in [
+            ("4x3 Q2 HLLC, gravity 0.4, walls", 4, 3, 2, "hllc", [2, 1, 0, 0], {0: "slip", 1: "outflow", 2: "inflow"}, "0.8", "0.4", False),
+            ("3x3 Q1 Roe, gravity 0.25, local time steps", 3, 3, 1, "roe", [0, 0, 0, 0], {0: "slip"}, "0.7", "0.25", True),
+            ("4x4 periodic Q3 LxF, local time steps", 4, 4, 3, "lxf", [-1, -1, -1, -1], {}, "0.6", "0", True)]:
+        cs = Case(name, nx, ny, D(1) / nx, k, flux, side, kinds, cfl, periodic if side[0] < 0 else smooth)
+        cs.gravity = D(grav)
+        U0 = cs.initial()
+        R = cs.residual(U0)
+        dts = cs.cell_dts(U0)
+        U1 = cs.step(U0, dts if local else min(dts))
+        bfaces = []
+        for j in range(cs.ny):
+            for i in range(cs.nx):
+                for f in range(4):
+                    nb, bid = cs.neighbour(i, j, f)
+                    if nb is None:
+                        bfaces.append({"cell": i + cs.nx * j, "face": f, "id": bid,
+                                       "values": [[format(v, ".25e") for v in cs.field(*cs.face_point(i, j, f, q))] for q in range(cs.N)]})
+        out["forcing_cases"].append({"name": name, "nx": nx, "ny": ny, "h": format(cs.h, ".25e"), "degree": k, "flux": flux, "side": side,
+                                     "kinds": {str(a): b for a, b in kinds.items()}, "cfl": cfl, "gravity": grav, "local": local,
+                                     "U0": flat(U0), "residual": flat(R), "cell_average": [format(v, ".25e") for a in cs.averages(U0) for v in a],
+                                     "dt": format(min(dts), ".25e"), "cell_dt": [format(v, ".25e") for v in dts], "U1": flat(U1),
+                                     "boundary_faces": bfaces})
+        print(name, "dt", format(min(dts), ".6e"), flush=True)
     # ---- limiters: TVB (characteristic and component-wise, M = 0 and M > 0) and the positivity limiter
     out["limiter_cases"] = []
     wall = [0, 0, 0, 0]

@@ -254,3 +254,27 @@ def test_device_pk_limiters_match_the_independent_derivation(case):
     assert np.abs(got - want).max() <= 1e-12 * np.abs(want).max()
     got2, want, before = run_limiter_case(case, lambda m, p: dflo_amd.MultiConservationLaw(m, p, devices=[0, 0]), basis="Pk")
     assert np.abs(got2 - want).max() <= 1e-12 * np.abs(want).max()
+
+
+from test_oracle_assembly import _forcing_fixture   # noqa: E402
+
+
+@pytest.mark.parametrize("case", _forcing_fixture(), ids=[c["name"] for c in _forcing_fixture()])
+def test_device_forcing_and_local_time_steps_match_the_independent_derivation(case):
+    """gravity source and local time stepping of the DEVICE against the 60-digit derivation: residual, time step, one SSP-RK step
+    (stepwise, device-resident, two engines)"""
+    mesh, claw, U0, R, A, dt, U1 = run_fixture_case(case, lambda m, p: dflo_amd.ConservationLaw(m, p))
+    claw.set_initial_condition(U0)
+    assert np.abs(claw.assemble_system() - R).max() <= 1e-12 * np.abs(R).max()
+    assert abs(claw.compute_time_step() - dt) <= 1e-13 * dt
+    claw.iterate_explicit(dt)
+    assert np.abs(claw.current_solution - U1).max() <= 1e-12 * np.abs(U1).max()
+    mesh, again, *_ = run_fixture_case(case, lambda m, p: dflo_amd.ConservationLaw(m, p))
+    again.set_initial_condition(U0)
+    again.advance(1)
+    assert np.abs(again.current_solution - U1).max() <= 1e-12 * np.abs(U1).max()
+    if mesh.n_cells >= 8:
+        mesh, two, *_ = run_fixture_case(case, lambda m, p: dflo_amd.MultiConservationLaw(m, p, devices=[0, 0]))
+        two.set_initial_condition(U0)
+        two.advance(1)
+        assert np.abs(two.current_solution - U1).max() <= 1e-12 * np.abs(U1).max()

@@ -338,7 +338,8 @@ def run_fixture_case(case, make_solver, basis="Qk"):
     mesh = dflo_amd.Mesh.cartesian(case["nx"], case["ny"], 0.0, 0.0, float(case["h"]), case["side"], case["degree"])
     if basis != "Qk":
         mesh.set_basis(basis)
-    prm = dflo_amd.Parameters(flux=case["flux"], cfl=float(case["cfl"]), boundary={int(k): v for k, v in case["kinds"].items()})
+    prm = dflo_amd.Parameters(flux=case["flux"], cfl=float(case["cfl"]), boundary={int(k): v for k, v in case["kinds"].items()},
+                              gravity=float(case.get("gravity", 0.0)), time_step_type="local" if case.get("local") else "global")
     s = make_solver(mesh, prm)
     cell, face, bid, xy = s.boundary_faces()
     bf = case["boundary_faces"]
@@ -499,3 +500,21 @@ def test_oracle_pk_limiters_match_the_independent_derivation(case):
     got, want, before = run_limiter_case(case, lambda m, p: O.Oracle(m, p), basis="Pk")
     assert np.abs(want - before).max() > 1e-3
     assert np.abs(got - want).max() <= 1e-12 * np.abs(want).max()
+
+
+def _forcing_fixture():
+    import json
+    import os
+    return json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "residual_fixture.json")))["forcing_cases"]
+
+
+@pytest.mark.parametrize("case", _forcing_fixture(), ids=[c["name"] for c in _forcing_fixture()])
+def test_oracle_forcing_and_local_time_steps_match_the_independent_derivation(case):
+    """the gravity source (src/equation.h:831-850) in the right-hand side and "time step type = local" (every cell advances
+    with its own dt(c), src/claw.cc:486-511) against the 60-digit derivation"""
+    mesh, ora, U0, R, A, dt, U1 = run_fixture_case(case, lambda m, p: O.Oracle(m, p))
+    ora.set_solution(U0)
+    assert np.abs(ora.assemble() - R).max() <= 1e-12 * np.abs(R).max()
+    assert abs(ora.compute_time_step(0.0) - dt) <= 1e-13 * dt
+    ora.step(-1.0 if case["local"] else dt)
+    assert np.abs(ora.get_solution() - U1).max() <= 1e-12 * np.abs(U1).max()
