@@ -851,6 +851,56 @@ def main():
         out["kxrcf_cases"].append({"name": name, "nx": 6, "ny": 4, "h": format(cs.h, ".25e"), "degree": k, "variable": cname, "U0": flat(U0),
                                    "indicator": [format(v, ".25e") if v is not None else "nan" for v in ind]})
         print(name, "cells over 1:", sum(1 for v in ind if v is not None and v > 1), flush=True)
+    # ---- degree 0 (the one-stage finite-volume limit, src/claw.cc:141-145) and whole steps with the limiters in the stage loop
+    out["extra_cases"] = []
+    for name, nx, ny, k, flux, side, kinds, cfl, field, lim in [
+            ("5x4 periodic Q0 HLLC", 5, 4, 0, "hllc", [-1, -1, -1, -1], {}, "0.8", lambda x, y: periodic(x, y * 5 / 4), None),
+            ("4x3 Q0 Roe with walls", 4, 3, 0, "roe", [2, 1, 0, 3], {0: "slip", 1: "outflow", 2: "inflow", 3: "farfield"}, "0.9", smooth, None),
+            ("6x4 Q1 Roe, TVB (char, M = 0) + positivity in every stage", 6, 4, 1, "roe", [0, 0, 0, 0], {0: "outflow"}, "0.6", jump,
+             {"M": "0", "beta": "2", "char_lim": True}),
+            ("6x4 Q2 HLLC, TVB (component-wise, M = 20) + positivity in every stage", 6, 4, 2, "hllc", [0, 0, 0, 0], {0: "outflow"}, "0.5", jump,
+             {"M": "20", "beta": "1.5", "char_lim": False})]:
+        cs = Case(name, nx, ny, D(1) / max(nx, 5) if k == 0 and nx == 5 else D(1) / nx, k, flux, side, kinds, cfl, field)
+        U0 = cs.initial()
+        if lim:   # run() limits the initial state first (src/claw.cc:997-1001)
+            U0 = positivity(cs, tvb_qk(cs, U0, lim["M"], lim["beta"], lim["char_lim"]))[0]
+        dt = cs.dt(U0)
+        if lim:
+            # iterate_explicit (src/claw.cc:726-772): every stage = update, then the TVB limiter, then the positivity limiter
+            ark = [D(0), D(1) / 2] if k == 1 else [D(0), D(3) / 4, D(1) / 3]
+            Uc = U0
+            for a_rk in ark:
+                Rr = cs.residual(Uc)
+                new = []
+                for c in range(len(Uc)):
+                    cell = [[None] * (cs.N * cs.N) for _ in range(4)]
+                    for comp in range(4):
+                        for b in range(cs.N):
+                            for a in range(cs.N):
+                                i = a + cs.N * b
+                                u = Uc[c][comp][i] + dt * Rr[c][comp][i] / (cs.ws[a] * cs.ws[b] * cs.h * cs.h)
+                                cell[comp][i] = a_rk * U0[c][comp][i] + (1 - a_rk) * u
+                    new.append(cell)
+                Uc = positivity(cs, tvb_qk(cs, new, lim["M"], lim["beta"], lim["char_lim"]))[0]
+            U1 = Uc
+        else:
+            U1 = cs.step(U0, dt)
+        bfaces = []
+        for j in range(cs.ny):
+            for i in range(cs.nx):
+                for f in range(4):
+                    nb, bid = cs.neighbour(i, j, f)
+                    if nb is None:
+                        bfaces.append({"cell": i + cs.nx * j, "face": f, "id": bid,
+                                       "values": [[format(v, ".25e") for v in cs.field(*cs.face_point(i, j, f, q))] for q in range(cs.N)]})
+        rec = {"name": name, "nx": nx, "ny": ny, "h": format(cs.h, ".25e"), "degree": k, "flux": flux, "side": side,
+               "kinds": {str(a): b for a, b in kinds.items()}, "cfl": cfl, "U0": flat(U0), "residual": flat(cs.residual(U0)),
+               "cell_average": [format(v, ".25e") for a in cs.averages(U0) for v in a], "dt": format(dt, ".25e"), "U1": flat(U1),
+               "boundary_faces": bfaces}
+        if lim:
+            rec["limiter"] = lim
+        out["extra_cases"].append(rec)
+        print(name, "dt", format(dt, ".6e"), flush=True)
     # ---- gravity forcing and local time stepping (time step type = local)
     out["forcing_cases"] = []
     for name, nx, ny, k, flux, side, kinds, cfl, grav, local in [

@@ -278,3 +278,26 @@ def test_device_forcing_and_local_time_steps_match_the_independent_derivation(ca
         two.set_initial_condition(U0)
         two.advance(1)
         assert np.abs(two.current_solution - U1).max() <= 1e-12 * np.abs(U1).max()
+
+
+from test_oracle_assembly import _extra_fixture   # noqa: E402
+
+
+@pytest.mark.parametrize("case", _extra_fixture(), ids=[c["name"] for c in _extra_fixture()])
+def test_device_degree_0_and_limited_steps_match_the_independent_derivation(case):
+    """degree 0 and whole steps with TVB + positivity after every stage, on the DEVICE (stepwise, device-resident, two engines)"""
+    mesh, claw, U0, R, A, dt, U1 = run_fixture_case(case, lambda m, p: dflo_amd.ConservationLaw(m, p))
+    claw.set_initial_condition(U0)
+    assert np.abs(claw.assemble_system() - R).max() <= 1e-12 * np.abs(R).max()
+    assert abs(claw.compute_time_step() - dt) <= 1e-13 * dt
+    claw.iterate_explicit(dt)
+    assert np.abs(claw.current_solution - U1).max() <= 1e-11 * np.abs(U1).max()
+    mesh, again, *_ = run_fixture_case(case, lambda m, p: dflo_amd.ConservationLaw(m, p))
+    again.set_initial_condition(U0)
+    assert abs(again.advance(1) - dt) <= 1e-13 * dt
+    assert np.abs(again.current_solution - U1).max() <= 1e-11 * np.abs(U1).max()
+    if mesh.n_cells >= 8:
+        mesh, two, *_ = run_fixture_case(case, lambda m, p: dflo_amd.MultiConservationLaw(m, p, devices=[0, 0]))
+        two.set_initial_condition(U0)
+        two.advance(1)
+        assert np.abs(two.current_solution - U1).max() <= 1e-11 * np.abs(U1).max()

@@ -338,8 +338,10 @@ def run_fixture_case(case, make_solver, basis="Qk"):
     mesh = dflo_amd.Mesh.cartesian(case["nx"], case["ny"], 0.0, 0.0, float(case["h"]), case["side"], case["degree"])
     if basis != "Qk":
         mesh.set_basis(basis)
+    lim = case.get("limiter")
+    extra = dict(limiter="TVB", M=float(lim["M"]), beta=float(lim["beta"]), char_lim=lim["char_lim"], pos_lim=True) if lim else {}
     prm = dflo_amd.Parameters(flux=case["flux"], cfl=float(case["cfl"]), boundary={int(k): v for k, v in case["kinds"].items()},
-                              gravity=float(case.get("gravity", 0.0)), time_step_type="local" if case.get("local") else "global")
+                              gravity=float(case.get("gravity", 0.0)), time_step_type="local" if case.get("local") else "global", **extra)
     s = make_solver(mesh, prm)
     cell, face, bid, xy = s.boundary_faces()
     bf = case["boundary_faces"]
@@ -518,3 +520,21 @@ def test_oracle_forcing_and_local_time_steps_match_the_independent_derivation(ca
     assert abs(ora.compute_time_step(0.0) - dt) <= 1e-13 * dt
     ora.step(-1.0 if case["local"] else dt)
     assert np.abs(ora.get_solution() - U1).max() <= 1e-12 * np.abs(U1).max()
+
+
+def _extra_fixture():
+    import json
+    import os
+    return json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "residual_fixture.json")))["extra_cases"]
+
+
+@pytest.mark.parametrize("case", _extra_fixture(), ids=[c["name"] for c in _extra_fixture()])
+def test_oracle_degree_0_and_limited_steps_match_the_independent_derivation(case):
+    """degree 0 (one stage, src/claw.cc:141-145) and whole SSP-RK steps with the TVB and positivity limiters applied after every
+    stage (iterate_explicit, src/claw.cc:726-772) against the 60-digit derivation"""
+    mesh, ora, U0, R, A, dt, U1 = run_fixture_case(case, lambda m, p: O.Oracle(m, p))
+    ora.set_solution(U0)
+    assert np.abs(ora.assemble() - R).max() <= 1e-12 * np.abs(R).max()
+    assert abs(ora.compute_time_step(0.0) - dt) <= 1e-13 * dt
+    ora.step(dt)
+    assert np.abs(ora.get_solution() - U1).max() <= 1e-11 * np.abs(U1).max()
