@@ -272,14 +272,17 @@ def to_con(R, W):       # characteristic -> (mx, my, rho, E), src/equation.h:290
     return [V[1], V[2], V[0], V[3]]
 
 
-def tvb_qk(cs, U, M, beta, char_lim):
-    """apply_limiter_TVB_Qk (src/limiter.cc:225-370) on squares, every cell marked (shock indicator = limiter)"""
+def tvb_qk(cs, U, M, beta, char_lim, marked=None):
+    """apply_limiter_TVB_Qk (src/limiter.cc:225-370) on squares; marked: the cells the shock indicator offers to the limiter
+    (indicator > 1, :263), None = every cell (shock indicator = limiter)"""
     N, h = cs.N, cs.h
     A = cs.averages(U)
     out = [[list(comp) for comp in cell] for cell in U]
     for j in range(cs.ny):
         for i in range(cs.nx):
             c = i + cs.nx * j
+            if marked is not None and not marked[c]:
+                continue
             dx, Mdx2 = h, D(M) * h * h
             # dx * average gradient: (1/|K|) sum_q grad u(x_q) JxW_q with the Gauss rule of the element
             Dx, Dy = [], []
@@ -859,11 +862,20 @@ def main():
             ("6x4 Q1 Roe, TVB (char, M = 0) + positivity in every stage", 6, 4, 1, "roe", [0, 0, 0, 0], {0: "outflow"}, "0.6", jump,
              {"M": "0", "beta": "2", "char_lim": True}),
             ("6x4 Q2 HLLC, TVB (component-wise, M = 20) + positivity in every stage", 6, 4, 2, "hllc", [0, 0, 0, 0], {0: "outflow"}, "0.5", jump,
-             {"M": "20", "beta": "1.5", "char_lim": False})]:
+             {"M": "20", "beta": "1.5", "char_lim": False}),
+            ("6x4 Q2 HLLC, KXRCF (density) gating TVB (char, M = 0) + positivity in every stage", 6, 4, 2, "hllc", [0, 0, 0, 0], {0: "outflow"}, "0.5", jump,
+             {"M": "0", "beta": "1.5", "char_lim": True, "indicator": "density"})]:
         cs = Case(name, nx, ny, D(1) / max(nx, 5) if k == 0 and nx == 5 else D(1) / nx, k, flux, side, kinds, cfl, field)
         U0 = cs.initial()
+        def limit(V):   # compute_shock_indicator, apply_limiter, apply_positivity_limiter (src/claw.cc:762-766)
+            marked = None
+            if lim.get("indicator"):
+                ind = kxrcf(cs, V, 2 if lim["indicator"] == "density" else 3)
+                marked = [v is None or v > 1 for v in ind]     # 0/0 = NaN at cells whose inflow faces are all boundary faces: NaN > 1 is false
+                marked = [False if v is None else m for v, m in zip(ind, marked)]
+            return positivity(cs, tvb_qk(cs, V, lim["M"], lim["beta"], lim["char_lim"], marked))[0]
         if lim:   # run() limits the initial state first (src/claw.cc:997-1001)
-            U0 = positivity(cs, tvb_qk(cs, U0, lim["M"], lim["beta"], lim["char_lim"]))[0]
+            U0 = limit(U0)
         dt = cs.dt(U0)
         if lim:
             # iterate_explicit (src/claw.cc:726-772): every stage = update, then the TVB limiter, then the positivity limiter
@@ -881,7 +893,7 @@ def main():
                                 u = Uc[c][comp][i] + dt * Rr[c][comp][i] / (cs.ws[a] * cs.ws[b] * cs.h * cs.h)
                                 cell[comp][i] = a_rk * U0[c][comp][i] + (1 - a_rk) * u
                     new.append(cell)
-                Uc = positivity(cs, tvb_qk(cs, new, lim["M"], lim["beta"], lim["char_lim"]))[0]
+                Uc = limit(new)
             U1 = Uc
         else:
             U1 = cs.step(U0, dt)

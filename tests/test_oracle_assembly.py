@@ -339,7 +339,8 @@ def run_fixture_case(case, make_solver, basis="Qk"):
     if basis != "Qk":
         mesh.set_basis(basis)
     lim = case.get("limiter")
-    extra = dict(limiter="TVB", M=float(lim["M"]), beta=float(lim["beta"]), char_lim=lim["char_lim"], pos_lim=True) if lim else {}
+    extra = dict(limiter="TVB", M=float(lim["M"]), beta=float(lim["beta"]), char_lim=lim["char_lim"], pos_lim=True,
+                 shock_indicator=lim.get("indicator", "limiter")) if lim else {}
     prm = dflo_amd.Parameters(flux=case["flux"], cfl=float(case["cfl"]), boundary={int(k): v for k, v in case["kinds"].items()},
                               gravity=float(case.get("gravity", 0.0)), time_step_type="local" if case.get("local") else "global", **extra)
     s = make_solver(mesh, prm)
