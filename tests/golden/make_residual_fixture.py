@@ -913,6 +913,34 @@ def main():
             rec["limiter"] = lim
         out["extra_cases"].append(rec)
         print(name, "dt", format(dt, ".6e"), flush=True)
+    # ---- a whole step on the modal basis with TVB-Pk + positivity after every stage
+    out["pk_step_cases"] = []
+    for name, k, flux, cfl, lim in [("6x4 P2 HLLC, TVB-Pk (char, M = 0) + positivity in every stage", 2, "hllc", "0.5", {"M": "0", "beta": "2", "char_lim": True}),
+                                    ("6x4 P1 LxF, TVB-Pk (component-wise, M = 10) + positivity in every stage", 1, "lxf", "0.7", {"M": "10", "beta": "1.5", "char_lim": False})]:
+        cs = PkCase(name, 6, 4, D(1) / 6, k, flux, [0, 0, 0, 0], {0: "outflow"}, cfl, jump)
+        limit = lambda V: positivity_pk(cs, tvb_pk(cs, V, lim["M"], lim["beta"], lim["char_lim"]))[0]
+        U0 = limit(cs.initial())
+        dt = cs.dt(U0)
+        ark = [D(0), D(1) / 2] if k == 1 else [D(0), D(3) / 4, D(1) / 3]
+        Uc = U0
+        for a_rk in ark:
+            Rr = cs.residual(Uc)
+            new = [[[a_rk * U0[c][comp][m] + (1 - a_rk) * (Uc[c][comp][m] + dt * Rr[c][comp][m] / (cs.h * cs.h)) for m in range(len(cs.modes))]
+                    for comp in range(4)] for c in range(len(Uc))]
+            Uc = limit(new)
+        bfaces = []
+        for j in range(cs.ny):
+            for i in range(cs.nx):
+                for f in range(4):
+                    nb, bid = cs.neighbour(i, j, f)
+                    if nb is None:
+                        bfaces.append({"cell": i + cs.nx * j, "face": f, "id": bid,
+                                       "values": [[format(v, ".25e") for v in cs.field(*cs.face_point(i, j, f, q))] for q in range(cs.N)]})
+        out["pk_step_cases"].append({"name": name, "nx": 6, "ny": 4, "h": format(cs.h, ".25e"), "degree": k, "flux": flux, "side": [0, 0, 0, 0],
+                                     "kinds": {"0": "outflow"}, "cfl": cfl, "limiter": lim, "U0": flat(U0), "residual": flat(cs.residual(U0)),
+                                     "cell_average": [format(v, ".25e") for a in cs.averages(U0) for v in a], "dt": format(dt, ".25e"),
+                                     "U1": flat(Uc), "boundary_faces": bfaces})
+        print(name, "dt", format(dt, ".6e"), flush=True)
     # ---- gravity forcing and local time stepping (time step type = local)
     out["forcing_cases"] = []
     for name, nx, ny, k, flux, side, kinds, cfl, grav, local in [

@@ -301,3 +301,21 @@ def test_device_degree_0_and_limited_steps_match_the_independent_derivation(case
         two.set_initial_condition(U0)
         two.advance(1)
         assert np.abs(two.current_solution - U1).max() <= 1e-11 * np.abs(U1).max()
+
+
+from test_oracle_assembly import _pk_step_fixture   # noqa: E402
+
+
+@pytest.mark.parametrize("case", _pk_step_fixture(), ids=[c["name"] for c in _pk_step_fixture()])
+def test_device_pk_limited_steps_match_the_independent_derivation(case):
+    """a whole step on the modal basis with TVB-Pk + positivity after every stage, on the DEVICE (stepwise, resident, two engines)"""
+    mesh, claw, U0, R, A, dt, U1 = run_fixture_case(case, lambda m, p: dflo_amd.ConservationLaw(m, p), basis="Pk")
+    claw.set_initial_condition(U0)
+    assert np.abs(claw.assemble_system() - R).max() <= 1e-12 * np.abs(R).max()
+    assert abs(claw.compute_time_step() - dt) <= 1e-13 * dt
+    claw.iterate_explicit(dt)
+    assert np.abs(claw.current_solution - U1).max() <= 1e-11 * np.abs(U1).max()
+    mesh, two, *_ = run_fixture_case(case, lambda m, p: dflo_amd.MultiConservationLaw(m, p, devices=[0, 0]), basis="Pk")
+    two.set_initial_condition(U0)
+    assert abs(two.advance(1) - dt) <= 1e-13 * dt
+    assert np.abs(two.current_solution - U1).max() <= 1e-11 * np.abs(U1).max()

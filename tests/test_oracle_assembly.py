@@ -539,3 +539,20 @@ def test_oracle_degree_0_and_limited_steps_match_the_independent_derivation(case
     assert abs(ora.compute_time_step(0.0) - dt) <= 1e-13 * dt
     ora.step(dt)
     assert np.abs(ora.get_solution() - U1).max() <= 1e-11 * np.abs(U1).max()
+
+
+def _pk_step_fixture():
+    import json
+    import os
+    return json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "residual_fixture.json")))["pk_step_cases"]
+
+
+@pytest.mark.parametrize("case", _pk_step_fixture(), ids=[c["name"] for c in _pk_step_fixture()])
+def test_oracle_pk_limited_steps_match_the_independent_derivation(case):
+    """a whole SSP-RK step on the modal basis with TVB-Pk and the positivity limiter after every stage"""
+    mesh, ora, U0, R, A, dt, U1 = run_fixture_case(case, lambda m, p: O.Oracle(m, p), basis="Pk")
+    ora.set_solution(U0)
+    assert np.abs(ora.assemble() - R).max() <= 1e-12 * np.abs(R).max()
+    assert abs(ora.compute_time_step(0.0) - dt) <= 1e-13 * dt
+    ora.step(dt)
+    assert np.abs(ora.get_solution() - U1).max() <= 1e-11 * np.abs(U1).max()
