@@ -184,7 +184,7 @@ class Case:
                             Fh = numerical_flux(self.flux, n, Wp, Wm, A[c], A[nb])
                         else:
                             x, y = self.face_point(i, j, f, q)
-                            bv = self.field(x, y)
+                            bv = self.field_t(x, y, bc_time) if getattr(self, "field_t", None) else self.field(x, y)
                             Wm = cf.compute_Wminus(self.kinds[bid], n, Wp, bv)
                             Fh = numerical_flux(self.flux, n, Wp, Wm, A[c], A[c])   # both averages the interior cell's, src/assemble_explicit.cc:200-205
                         L = (self.L0 if f in (0, 2) else self.L1)
@@ -218,8 +218,9 @@ class Case:
         ark = [D(0), D(1) / 2] if self.k == 1 else ([D(0)] if self.k == 0 else [D(0), D(3) / 4, D(1) / 3])
         Un, Uc = U, U
         dts = dt if isinstance(dt, list) else [dt] * len(U)
-        for a_rk in ark:
-            R = self.residual(Uc)
+        for rk, a_rk in enumerate(ark):
+            # boundary functions at t in the first stage, at t + dt in the later ones (src/claw.cc:733-745)
+            R = self.residual(Uc, bc_time=D(0) if rk == 0 else min(dts))
             new = []
             for c in range(len(Uc)):
                 dt = dts[c]
@@ -912,6 +913,36 @@ def main():
         if lim:
             rec["limiter"] = lim
         out["extra_cases"].append(rec)
+        print(name, "dt", format(dt, ".6e"), flush=True)
+    # ---- boundary values that move in time: the table of t in the first stage, of t + dt in the later ones
+    out["moving_bc_cases"] = []
+    for name, nx, ny, k, flux, side, kinds, cfl in [("4x3 Q2 HLLC, inflow and farfield states moving in time", 4, 3, 2, "hllc", [2, 1, 0, 3],
+                                                     {0: "slip", 1: "outflow", 2: "inflow", 3: "farfield"}, "0.8"),
+                                                    ("3x3 Q1 LxF, pressure and inflow states moving in time", 3, 3, 1, "lxf", [2, 1, 1, 2],
+                                                     {1: "pressure", 2: "inflow"}, "0.7")]:
+        cs = Case(name, nx, ny, D(1) / nx, k, flux, side, kinds, cfl, smooth)
+        def moving(x, y, t):
+            W = smooth(x + 3 * t, y - 2 * t)
+            return [W[0] * (1 + 4 * t), W[1], W[2] * (1 + 2 * t), W[3] * (1 + 5 * t)]
+        cs.field_t = moving
+        U0 = cs.initial()
+        dt = cs.dt(U0)
+        R0, R1 = cs.residual(U0, bc_time=D(0)), cs.residual(U0, bc_time=dt)
+        U1 = cs.step(U0, dt)
+        bfaces = []
+        for j in range(cs.ny):
+            for i in range(cs.nx):
+                for f in range(4):
+                    nb, bid = cs.neighbour(i, j, f)
+                    if nb is None:
+                        pts = [cs.face_point(i, j, f, q) for q in range(cs.N)]
+                        bfaces.append({"cell": i + cs.nx * j, "face": f, "id": bid,
+                                       "values": [[format(v, ".25e") for v in moving(x, y, D(0))] for x, y in pts],
+                                       "values_later": [[format(v, ".25e") for v in moving(x, y, dt)] for x, y in pts]})
+        out["moving_bc_cases"].append({"name": name, "nx": nx, "ny": ny, "h": format(cs.h, ".25e"), "degree": k, "flux": flux, "side": side,
+                                       "kinds": {str(a): b for a, b in kinds.items()}, "cfl": cfl, "U0": flat(U0), "residual": flat(R0),
+                                       "residual_later": flat(R1), "cell_average": [format(v, ".25e") for a in cs.averages(U0) for v in a],
+                                       "dt": format(dt, ".25e"), "U1": flat(U1), "boundary_faces": bfaces})
         print(name, "dt", format(dt, ".6e"), flush=True)
     # ---- a whole step on the modal basis with TVB-Pk + positivity after every stage
     out["pk_step_cases"] = []

@@ -319,3 +319,23 @@ def test_device_pk_limited_steps_match_the_independent_derivation(case):
     two.set_initial_condition(U0)
     assert abs(two.advance(1) - dt) <= 1e-13 * dt
     assert np.abs(two.current_solution - U1).max() <= 1e-11 * np.abs(U1).max()
+
+
+from test_oracle_assembly import _moving_bc_fixture, run_moving_bc_case   # noqa: E402
+
+
+@pytest.mark.parametrize("case", _moving_bc_fixture(), ids=[c["name"] for c in _moving_bc_fixture()])
+def test_device_moving_boundary_states_match_the_independent_derivation(case):
+    """the boundary table of t in the first stage and of t + dt in the later ones (src/claw.cc:733-745), on the DEVICE: both
+    right-hand sides and a whole step, single engine and two engines"""
+    mesh, claw, U0, R0, R1, dt, U1 = run_moving_bc_case(case, lambda m, p: dflo_amd.ConservationLaw(m, p))
+    claw.set_initial_condition(U0)
+    assert np.abs(claw.assemble_system(0) - R0).max() <= 1e-12 * np.abs(R0).max()
+    assert np.abs(claw.assemble_system(1) - R1).max() <= 1e-12 * np.abs(R1).max()
+    claw.iterate_explicit(dt)
+    assert np.abs(claw.current_solution - U1).max() <= 1e-12 * np.abs(U1).max()
+    if mesh.n_cells >= 8:
+        mesh, two, *_ = run_moving_bc_case(case, lambda m, p: dflo_amd.MultiConservationLaw(m, p, devices=[0, 0]))
+        two.set_initial_condition(U0)
+        two.advance(1)
+        assert np.abs(two.current_solution - U1).max() <= 1e-12 * np.abs(U1).max()

@@ -556,3 +556,27 @@ def test_oracle_pk_limited_steps_match_the_independent_derivation(case):
     assert abs(ora.compute_time_step(0.0) - dt) <= 1e-13 * dt
     ora.step(dt)
     assert np.abs(ora.get_solution() - U1).max() <= 1e-11 * np.abs(U1).max()
+
+
+def _moving_bc_fixture():
+    import json
+    import os
+    return json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "residual_fixture.json")))["moving_bc_cases"]
+
+
+def run_moving_bc_case(case, make_solver):
+    """boundary states that move in time: table 0 holds them at t (first stage), table 1 at t + dt (later stages), src/claw.cc:733-745"""
+    mesh, s, U0, R, A, dt, U1 = run_fixture_case(case, make_solver)
+    later = np.array([[[float(x) for x in pt] for pt in b["values_later"]] for b in case["boundary_faces"]])
+    s.set_boundary_values(1, later)
+    return mesh, s, U0, R, np.array([float(x) for x in case["residual_later"]]), dt, U1
+
+
+@pytest.mark.parametrize("case", _moving_bc_fixture(), ids=[c["name"] for c in _moving_bc_fixture()])
+def test_oracle_moving_boundary_states_match_the_independent_derivation(case):
+    mesh, ora, U0, R0, R1, dt, U1 = run_moving_bc_case(case, lambda m, p: O.Oracle(m, p))
+    ora.set_solution(U0)
+    assert np.abs(ora.assemble() - R0).max() <= 1e-12 * np.abs(R0).max()
+    assert np.abs(R1 - R0).max() > 1e-3 * np.abs(R0).max()          # the later table matters
+    ora.step(dt)
+    assert np.abs(ora.get_solution() - U1).max() <= 1e-12 * np.abs(U1).max()
