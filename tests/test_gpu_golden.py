@@ -339,3 +339,24 @@ def test_device_moving_boundary_states_match_the_independent_derivation(case):
         two.set_initial_condition(U0)
         two.advance(1)
         assert np.abs(two.current_solution - U1).max() <= 1e-12 * np.abs(U1).max()
+
+
+from test_oracle_assembly import run_rotated_bilinear_case   # noqa: E402
+
+
+@pytest.mark.parametrize("case", _bilinear_fixture(), ids=[c["name"] for c in _bilinear_fixture()])
+@pytest.mark.parametrize("seed", [5, 6])
+def test_device_on_rotated_cells_matches_the_independent_derivation(case, seed):
+    """the bilinear fixture with the local numbering of the cells rotated at random: flipped faces, every pairing of local faces
+    -- the face records, the trace / flux table and the lifting of an unstructured mesh against the 60-digit derivation"""
+    mesh, claw, U0, R, A, dt, U1 = run_rotated_bilinear_case(case, lambda m, p: dflo_amd.ConservationLaw(m, p), seed)
+    claw.set_initial_condition(U0)
+    assert np.abs(claw.cell_average - A).max() <= 1e-14 * np.abs(A).max()
+    assert np.abs(claw.assemble_system() - R).max() <= 1e-12 * np.abs(R).max()
+    assert abs(claw.compute_time_step() - dt) <= 1e-13 * dt
+    claw.iterate_explicit(dt)
+    assert np.abs(claw.current_solution - U1).max() <= 1e-12 * np.abs(U1).max()
+    mesh, two, U0, *_ = run_rotated_bilinear_case(case, lambda m, p: dflo_amd.MultiConservationLaw(m, p, devices=[0, 0], partitioner="rcb"), seed)
+    two.set_initial_condition(U0)
+    assert abs(two.advance(1) - dt) <= 1e-13 * dt
+    assert np.abs(two.current_solution - U1).max() <= 1e-12 * np.abs(U1).max()

@@ -580,3 +580,85 @@ def test_oracle_moving_boundary_states_match_the_independent_derivation(case):
     assert np.abs(R1 - R0).max() > 1e-3 * np.abs(R0).max()          # the later table matters
     ora.step(dt)
     assert np.abs(ora.get_solution() - U1).max() <= 1e-12 * np.abs(U1).max()
+
+
+def run_rotated_bilinear_case(case, make_solver, seed=5):
+    """The bilinear fixture once more with the LOCAL numbering of most cells rotated (vertex order shifted by 1, 2 or 3): the same
+    cells and the same physics, but the cells now meet with every relative orientation -- faces that run opposite on their two
+    sides (flips), different local faces and node orders -- the data of an unstructured mesh.  State, right-hand side and the
+    stepped state of the 60-digit derivation are carried over node by node through the support points."""
+    f = lambda v: np.array([float(x) for x in v])
+    nx, ny = case["nx"], case["ny"]
+    verts = np.array([[float(a), float(b)] for a, b in case["vertices"]])
+    vid = lambda i, j: i + (nx + 1) * j
+    quads = np.array([[vid(i, j), vid(i + 1, j), vid(i + 1, j + 1), vid(i, j + 1)] for j in range(ny) for i in range(nx)], dtype=np.int32)
+    rot = np.random.default_rng(seed).integers(0, 4, len(quads))
+    rot[0] = 0
+    quads_r = np.array([np.roll(q, -r) for q, r in zip(quads, rot)], dtype=np.int32)
+    bed, bid = [], []
+    for i in range(nx):
+        bed += [[vid(i, 0), vid(i + 1, 0)], [vid(i, ny), vid(i + 1, ny)]]
+        bid += [case["side"][2], case["side"][3]]
+    for j in range(ny):
+        bed += [[vid(0, j), vid(0, j + 1)], [vid(nx, j), vid(nx, j + 1)]]
+        bid += [case["side"][0], case["side"][1]]
+    bed, bid = np.array(bed, dtype=np.int32), np.array(bid, dtype=np.int32)
+    plain = dflo_amd.Mesh.from_quads(verts, quads, bed, bid, case["degree"])
+    mesh = dflo_amd.Mesh.from_quads(verts, quads, bed, bid, case["degree"])
+    # from_quads starts every cell's vertex loop at its lower-left vertex; the rotated numbering is written into the mesh tables
+    # directly (what a deal.II mesh with arbitrarily oriented cells hands over): vertices in lexicographic order v0 v1 v2 v3 of
+    # the rotated loop, face neighbours and the neighbour's face (+4: the face runs the other way there) by matching edges
+    lex = quads_r[:, [0, 1, 3, 2]]
+    face_verts = [(0, 2), (1, 3), (0, 1), (2, 3)]
+    edges = {}
+    for c in range(len(lex)):
+        for fc, (a, b) in enumerate(face_verts):
+            edges.setdefault(frozenset((int(lex[c, a]), int(lex[c, b]))), []).append((c, fc, int(lex[c, a])))
+    old_nbr = plain.neighbors.copy()
+    old_faces = [[frozenset((int(quads[c, [0, 1, 3, 2]][a]), int(quads[c, [0, 1, 3, 2]][b]))) for a, b in face_verts] for c in range(len(quads))]
+    for c in range(len(lex)):
+        mesh.vertices[c] = verts[lex[c]]
+        for fc, (a, b) in enumerate(face_verts):
+            e = frozenset((int(lex[c, a]), int(lex[c, b])))
+            hs = edges[e]
+            if len(hs) == 2:
+                other = hs[1] if hs[0][0] == c and hs[0][1] == fc else hs[0]
+                me = hs[0] if other is hs[1] else hs[1]
+                mesh.neighbors[c, fc] = other[0]
+                mesh.neighbor_faces[c, fc] = other[1] | (4 if me[2] != other[2] else 0)
+            else:
+                mesh.neighbors[c, fc] = old_nbr[c, old_faces[c].index(e)]     # the boundary code of that edge
+                mesh.neighbor_faces[c, fc] = 0
+    assert (mesh.neighbor_faces & 4).any()        # some faces run opposite on their two sides now
+    # node permutation per cell: the rotated mesh's support points among the plain ones
+    P0, P1 = plain.support_points(), mesh.support_points()
+    ns = P0.shape[1]
+    perm = np.empty((mesh.n_cells, ns), dtype=int)
+    for c in range(mesh.n_cells):
+        d = np.abs(P1[c][:, None, :] - P0[c][None, :, :]).max(axis=2)
+        perm[c] = d.argmin(axis=1)
+        assert d.min(axis=1).max() < 1e-13 and len(set(perm[c])) == ns
+    carry = lambda v: np.take_along_axis(f(v).reshape(mesh.n_cells, 4, ns), perm[:, None, :].repeat(4, axis=1), axis=2).reshape(-1)
+    prm = dflo_amd.Parameters(flux=case["flux"], cfl=float(case["cfl"]), boundary={int(k): v for k, v in case["kinds"].items()})
+    s0, s = make_solver(plain, prm), make_solver(mesh, prm)
+    # boundary values by the coordinates of their face points
+    c0, f0, b0, xy0 = s0.boundary_faces()
+    bv0 = np.array([[[float(x) for x in pt] for pt in x["values"]] for x in case["boundary_faces"]])
+    key = lambda p: (round(p[0], 11), round(p[1], 11))
+    table = {key(xy0[i, q]): bv0[i, q] for i in range(len(c0)) for q in range(xy0.shape[1])}
+    c1, f1, b1, xy1 = s.boundary_faces()
+    bv = np.array([[table[key(xy1[i, q])] for q in range(xy1.shape[1])] for i in range(len(c1))])
+    s.set_boundary_values(0, bv)
+    s.set_boundary_values(1, bv)
+    return mesh, s, carry(case["U0"]), carry(case["residual"]), f(case["cell_average"]).reshape(-1, 4), float(case["dt"]), carry(case["U1"])
+
+
+@pytest.mark.parametrize("case", _bilinear_fixture(), ids=[c["name"] for c in _bilinear_fixture()])
+def test_oracle_on_rotated_cells_matches_the_independent_derivation(case):
+    mesh, ora, U0, R, A, dt, U1 = run_rotated_bilinear_case(case, lambda m, p: O.Oracle(m, p))
+    ora.set_solution(U0)
+    assert np.abs(ora.get_cell_average() - A).max() <= 1e-14 * np.abs(A).max()
+    assert np.abs(ora.assemble() - R).max() <= 1e-12 * np.abs(R).max()
+    assert abs(ora.compute_time_step(0.0) - dt) <= 1e-13 * dt
+    ora.step(dt)
+    assert np.abs(ora.get_solution() - U1).max() <= 1e-12 * np.abs(U1).max()
