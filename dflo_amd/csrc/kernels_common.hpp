@@ -51,7 +51,8 @@ struct StageArgs {
   const int32_t *shard_count;
   const int4 *shard_hdr;      // {cells, faces, halo cells, 0}
   const int32_t *halo_pad;    // [n_shards][halo_pitch]: internal cell slot | local face << 28
-  int halo_pitch, halo_stride;
+  int halo_pitch;             // entries per shard in halo_pad
+  int halo_stride;            // row stride of the stage kernel's LDS table of traces and fluxes: halo_cols + the most other faces of a shard
   const uint32_t *faces_pad;  // [n_shards][face_pitch] packed face records (pface_*)
   const int32_t *bnd_pad;     // [n_shards][bnd_pitch] boundary-face index of the shard's l-th boundary face
   int bnd_pitch;
@@ -67,7 +68,8 @@ struct StageArgs {
   const double *dt_cell;  // local time stepping: per internal slot, else null
   double *shard_res, *shard_dtmin;
   double dt_host, ark, gravity, cfl, h_uniform;
-  int n_shards, halo_cols, max_bnd, uniform_h, want_dt, degree, prefetch_ahead;
+  int n_shards, max_bnd, uniform_h, want_dt, degree, prefetch_ahead;
+  int halo_cols;              // columns of that table that belong to halo entries (>= the most halo entries of a shard)
   double *dt_cell_out;        // dtq with "time step type = local": the per-cell time step of the next step
   int store_avg;              // 0: nobody reads the cell averages of this stage (no LxF flux, limiter or indicator; not the last stage)
   int dtq;                    // bilinear cells, last stage, no limiter pass behind it: the kernel forms compute_time_step_q on the way out
