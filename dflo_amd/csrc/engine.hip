@@ -91,7 +91,7 @@ struct dflo_hip_engine {
   int n_send_faces = 0;
   double *ghost_stage = nullptr;
   size_t lds_bytes = 0;
-  int stage_grid = 8, prefetch_ahead = 1 << 30;
+  int stage_grid = 8;
   bool lazy_avg = false, avg_valid = true;   // lazy_avg: intermediate stages do not store the cell averages (nobody reads them)
   int n_patterns = 0;   // distinct (face records, face references) among the shards
   int sweep_mode = 1, sweep_dir = 0;   // every launch over all shards walks them against the previous one (DFLO_SWEEP=0: always forward)
@@ -391,7 +391,6 @@ int launch_update(dflo_hip_engine *h, double *rhs_out, int part) {
   a.n_shards = p.n_shards;
   a.halo_cols = h->plan.halo_cols;
   a.max_bnd = h->plan.max_bnd;
-  a.prefetch_ahead = h->prefetch_ahead;
   a.uniform_h = p.uniform_h ? 1 : 0;
   a.want_dt = last ? 1 : 0;
   // the averages of a stage go to memory when somebody reads them: the LxF flux and the limiter / indicator passes of the next
@@ -915,8 +914,6 @@ int dflo_hip_create(const dflo_mesh_t *mesh, const dflo_params_t *params, int de
       std::fprintf(stderr, "dflo_hip: stage kernel N=%d: %zu bytes of LDS per workgroup, %d workgroups (%d wavefronts) resident per CU; %d shards, %d index patterns\n",
                    h->N, h->lds_bytes, per_cu, per_cu * h->N, h->plan.n_shards, h->n_patterns);
     h->stage_grid = grid_for(h->plan.n_shards);  // one workgroup per shard (per_cu of them resident per CU)
-    // a workgroup touches the index data of the shard that the same XCD takes ~1.5 residency rounds later
-    h->prefetch_ahead = std::max(8, (per_cu * n_cu / 8) * 3 / 2);
 #ifdef DFLO_PHASE_TIMING
     hipMalloc((void **)&h->phase_cycles, (size_t)h->stage_grid * 32 * sizeof(unsigned long long));
     hipMemset(h->phase_cycles, 0, (size_t)h->stage_grid * 32 * sizeof(unsigned long long));

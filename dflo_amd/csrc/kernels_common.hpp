@@ -68,7 +68,7 @@ struct StageArgs {
   const double *dt_cell;  // local time stepping: per internal slot, else null
   double *shard_res, *shard_dtmin;
   double dt_host, ark, gravity, cfl, h_uniform;
-  int n_shards, max_bnd, uniform_h, want_dt, degree, prefetch_ahead;
+  int n_shards, max_bnd, uniform_h, want_dt, degree;
   int halo_cols;              // columns of that table that belong to halo entries (>= the most halo entries of a shard)
   double *dt_cell_out;        // dtq with "time step type = local": the per-cell time step of the next step
   int store_avg;              // 0: nobody reads the cell averages of this stage (no LxF flux, limiter or indicator; not the last stage)

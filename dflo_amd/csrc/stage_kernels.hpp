@@ -504,20 +504,6 @@ __global__ __launch_bounds__(64 * N, (N == 4 && GEO == 0 && MODE == 0) ? DFLO_Q3
 #ifdef DFLO_PHASE_TIMING
   unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
 #endif
-  // ---- index data of a shard that a later workgroup of this XCD will take: touch it now so that its
-  //      (dependent) index loads hit L2.  Issued first = oldest in the in-order vmcnt queue; the result
-  //      is never used and never waited for.
-  //      The destination registers stay reserved until the loads have landed (see the asm further down):
-  //      a load issued through inline asm writes its register whenever the data arrives.
-  //      (halo table and header; the face records and face references are per pattern and stay cached by themselves)
-  int pf0 = 0, pf1 = 0;
-  {
-    const int ahead = a.sweep_rev ? max(shard - a.prefetch_ahead, 0) : min(shard + a.prefetch_ahead, a.n_shards - 1);
-    const int32_t *p0 = a.halo_pad + (size_t)ahead * a.halo_pitch + (tid & 31);
-    const int32_t *p1 = (const int32_t *)(a.shard_hdr + ahead) + (tid & 3);
-    asm volatile("global_load_dword %0, %1, off" : "=v"(pf0) : "v"(p0));
-    asm volatile("global_load_dword %0, %1, off" : "=v"(pf1) : "v"(p1));
-  }
   // ---- all loads of the shard, issued back to back; the halo entries first (the halo values depend on them)
   // halo entries: thread t works on entry (t & 31) + 32 b of every block b of 32 entries (8x8 lattice shards have one
   // block, unstructured shards two or three): load them all now, the gathers below then depend on nothing else
@@ -642,7 +628,6 @@ __global__ __launch_bounds__(64 * N, (N == 4 && GEO == 0 && MODE == 0) ? DFLO_Q3
   for (int c = 0; c < 4; ++c)
 #pragma unroll
     for (int m = 0; m < N; ++m) Us[(c * NS + m + N * row) * S + lane] = urow[c][m];
-  asm volatile("" ::"v"(pf0), "v"(pf1));  // the touch loads (oldest in the queue) have landed by now
   if constexpr (FLUX == DFLO_FLUX_LXF) {
     if (row == 0) {
       double uvc[3];
