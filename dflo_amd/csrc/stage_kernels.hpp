@@ -510,7 +510,8 @@ __global__ __launch_bounds__(64 * N, (N == 4 && GEO == 0 && MODE == 0) ? DFLO_Q3
   constexpr int HB = 3;
   int hentb[HB];
 #pragma unroll
-  for (int b = 0; b < HB; ++b) hentb[b] = a.halo_pad[(size_t)shard * a.halo_pitch + min((tid & 31) + 32 * b, a.halo_pitch - 1)];
+  for (int b = 0; b < HB; ++b)   // (lattice shards have at most 32 entries: one load, the condition is uniform)
+    hentb[b] = (b == 0 || a.halo_pitch > 32 * b) ? a.halo_pad[(size_t)shard * a.halo_pitch + min((tid & 31) + 32 * b, a.halo_pitch - 1)] : 0;
   const int4 hdr = a.shard_hdr[shard];                // {cells, faces, halo entries, boundary faces}
   const int nf = hdr.y, nh = hdr.z, nbnd = hdr.w;
   const bool active = lane < (hdr.x & 0xFF);
