@@ -65,7 +65,7 @@ struct dflo_hip_engine {
   double *shard_res = nullptr, *shard_dtmin = nullptr, *res_sq = nullptr, *dt_dev = nullptr, *fin_partial = nullptr;
   int *flags = nullptr;         // device view of flags_host (kernels_common.hpp: raise_flag)
   volatile int *flags_host = nullptr;   // [0] negative mean state, [1] positivity root failure, [2] 1 + step of the first
-  int *fin_counter = nullptr;   // finalize_kernel: workgroups done
+  int *fin_counter = nullptr;   // [0] finalize_kernel: workgroups done; [1] time steps completed since set_solution (device count)
   unsigned long long *pos_stats = nullptr;   // [2] positivity limiter inside the stage kernel: cells through the limiter proper, cells changed
   double *dt_pub = nullptr;     // [2] raw CFL minimum of the last two steps, read by the other engines of a multi-device run
   int pub_parity = 0;
@@ -412,7 +412,7 @@ int launch_update(dflo_hip_engine *h, double *rhs_out, int part) {
   a.sweep_rev = next_sweep(h, part);
   const int mode_ = rhs_out ? 2 : (h->ark[rk] != 0.0 ? 1 : 0);
   a.flags = h->flags;
-  a.step_index = (int)h->steps_done;
+  a.step_ctr = h->fin_counter + 1;
   a.Tg = h->Tg[h->tg_cur];
   a.gt_slot = h->d_gt_slot;
   a.pos_stats = h->pos_stats;
@@ -467,7 +467,7 @@ int launch_limiter(dflo_hip_engine *h, int tvb, int pos, int part, bool stage_da
   l.lrbt = h->d_lrbt;
   l.cell_h = h->d_cell_h;
   l.flags = h->flags;
-  l.step_index = (int)h->steps_done;
+  l.step_ctr = h->fin_counter + 1;
   l.h_uniform = p.h;
   l.M = h->prm.M;
   l.beta = h->prm.beta;
@@ -839,7 +839,7 @@ int dflo_hip_create(const dflo_mesh_t *mesh, const dflo_params_t *params, int de
   if (hipMalloc((void **)&h->shard_res, 3 * nsh * sizeof(double)) != hipSuccess ||
       hipMalloc((void **)&h->shard_dtmin, nsh * sizeof(double)) != hipSuccess ||
       hipMalloc((void **)&h->res_sq, 4 * sizeof(double)) != hipSuccess || hipMalloc((void **)&h->fin_partial, 4 * kFinBlocks * sizeof(double)) != hipSuccess ||
-      hipMalloc((void **)&h->dt_dev, 4 * sizeof(double)) != hipSuccess || hipMalloc((void **)&h->fin_counter, sizeof(int)) != hipSuccess ||
+      hipMalloc((void **)&h->dt_dev, 4 * sizeof(double)) != hipSuccess || hipMalloc((void **)&h->fin_counter, 2 * sizeof(int)) != hipSuccess ||
       hipMalloc((void **)&h->dt_pub, 2 * sizeof(double)) != hipSuccess || hipMalloc((void **)&h->pos_stats, 2 * sizeof(unsigned long long)) != hipSuccess) {
     h->err = "hipMalloc(scalars) failed";
     return bail(DFLO_ERR_NOMEM);
@@ -858,7 +858,7 @@ int dflo_hip_create(const dflo_mesh_t *mesh, const dflo_params_t *params, int de
   hipMemset(h->res_sq, 0, 4 * sizeof(double));
   hipMemset(h->dt_dev, 0, 4 * sizeof(double));
   hipMemset(h->dt_pub, 0, 2 * sizeof(double));
-  hipMemset(h->fin_counter, 0, sizeof(int));
+  hipMemset(h->fin_counter, 0, 2 * sizeof(int));
   hipMemset(h->pos_stats, 0, 2 * sizeof(unsigned long long));
   // row stride of the stage kernel's trace / flux table: a column per halo entry (its trace, then the flux of its face) and one
   // per other face; the 4 N rows also host the row partials (5 N rows of 64), the positivity minima (3 N) or the slope
@@ -966,6 +966,7 @@ int dflo_hip_set_solution(dflo_hip_handle h, const double *u) {
   const long long tot = (long long)p.n_slots * h->ndof;
   h->cur = h->old = 0;
   h->steps_done = 0;
+  HIPCHK(h, hipMemsetAsync(h->fin_counter + 1, 0, sizeof(int), h->stream));
   for (int i = 0; i < 4; ++i) h->flags_host[i] = 0;   // a new state: the flags of an earlier run are history
   hipLaunchKernelGGL(scatter_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, h->user_buf, h->U[0],
                      h->d_user_of, p.n_slots, h->ndof);

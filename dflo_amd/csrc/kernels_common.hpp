@@ -77,7 +77,8 @@ struct StageArgs {
   int n_list;
   int sweep_rev;              // see shard_of_block
   int *flags;   // POS 1: [0] negative mean state, [1] positivity root failure (as LimArgs::flags)
-  int step_index; // time step this launch belongs to (host count since set_solution), recorded with a raised flag
+  const int *step_ctr;  // device count of the time steps completed since set_solution (finalize_kernel adds one per step): read only
+                        // when a flag is raised, so that a replayed graph reports the step it is in, not the one it was captured in
   const double *Tg;        // multi-device: traces of the ghost cells on the cut faces, [n_ghost_traces][4][N], of the state being read
   const int32_t *gt_slot;  // internal slot of the ghost cell of a trace (its cell average: LxF)
   unsigned long long *pos_stats;  // POS 1: [0] cells that failed the nodal-box bound (limiter proper), [1] cells it changed
@@ -91,9 +92,9 @@ struct StageArgs {
 // mapped into the device -- written only when a kernel fails, never on the hot path -- so the host's step loop reads
 // them without a copy: [0] negative mean state, [1] positivity root failure, [2] 1 + index of the time step in which
 // the first flag went up.
-__device__ __forceinline__ void raise_flag(int *flags, int which, int step_index) {
+__device__ __forceinline__ void raise_flag(int *flags, int which, const int *step_ctr) {
   volatile int *f = flags;
-  if (f[2] == 0) f[2] = step_index + 1;
+  if (f[2] == 0) f[2] = *(const volatile int *)step_ctr + 1;
   f[which] = 1;
 }
 

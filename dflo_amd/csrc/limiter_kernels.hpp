@@ -47,7 +47,7 @@ struct LimArgs {
   const int32_t *lrbt;
   const double *cell_h;
   int *flags;  // [0] negative mean state, [1] positivity root failure (raise_flag)
-  int step_index;
+  const int *step_ctr;   // as StageArgs::step_ctr
   double h_uniform, M, beta;
   int n_shards, uniform_h, tvb, char_lim, pos_lim;
   int conserve_ang_mom;   // Pk: src/limiter.cc:496-500
@@ -228,7 +228,7 @@ __global__ __launch_bounds__(64, DFLO_LIM_WAVES) void limiter_kernel(const LimAr
       settled = (chk - chk == 0.0) && rho_lo >= 1.0e-10 + 1.0e-8 * hi[RHO] && p_lo >= 1.0e-10 + 1.0e-8 * fabs(hi[EN]);
     }
     if (bad) {  // "Fatal: Negative states" :26-38
-      if (active) raise_flag(a.flags, 0, a.step_index);
+      if (active) raise_flag(a.flags, 0, a.step_ctr);
     } else if (!__all(settled || !active)) {
       // density at GLL(Ng) x Gauss(N) and Gauss(N) x GLL(Ng)  (:43-47, :72-78)
       double rho_min = 1.0e20;
@@ -267,7 +267,7 @@ __global__ __launch_bounds__(64, DFLO_LIM_WAVES) void limiter_kernel(const LimAr
             }
             theta2 = smin(theta2, positivity_theta2(W, A, eps, fail));
           }
-      if (fail && active) raise_flag(a.flags, 1, a.step_index);
+      if (fail && active) raise_flag(a.flags, 1, a.step_ctr);
       if (theta2 < 1.0) {
 #pragma unroll
         for (int c = 0; c < 4; ++c)
@@ -376,7 +376,7 @@ __global__ __launch_bounds__(64) void limiter_pk_kernel(const LimArgs a) {
   if (a.pos_lim) {
     const double eps = 1.0e-13;
     if (smin(A[RHO], pressure(A)) < eps) {
-      raise_flag(a.flags, 0, a.step_index);
+      raise_flag(a.flags, 0, a.step_ctr);
     } else {
       // point value of component c at (Pt(xi), Pt(eta)) given the 1-D Legendre values
       auto point = [&](int c, const double *pxi, const double *peta) {
@@ -430,7 +430,7 @@ __global__ __launch_bounds__(64) void limiter_pk_kernel(const LimArgs a) {
               theta2 = smin(theta2, t);
             }
           }
-      if (fail) raise_flag(a.flags, 1, a.step_index);
+      if (fail) raise_flag(a.flags, 1, a.step_ctr);
       if (theta2 < 1.0) {
 #pragma unroll
         for (int c = 0; c < 4; ++c)

@@ -10,8 +10,12 @@
 //        a cut are integrated by both owners with the same integrating side, bit-identical flux)
 //
 // Two ways to own the devices, one stage schedule:
-//   dflo_hip_multi_create       one process, one host thread, n_devices engines; halos move with hipMemcpyPeerAsync over
-//                               xGMI, the time-step minimum is read from the peers' device slots (no host hop)
+//   dflo_hip_multi_create       one process, n_devices engines, one host thread PER PART issuing that part's launches, events and
+//                               copies (a single thread cannot feed more than two or three devices: ~20 API calls per part and
+//                               stage against a stage of ~0.2 ms; DFLO_MULTI_THREADS=0 restores the single-threaded driver); halos
+//                               move with hipMemcpyPeerAsync over xGMI, the time-step minimum is read from the peers' device
+//                               slots (no host hop).  Where one part's stream waits for a peer's event, the host threads are
+//                               sequenced by counters (an event has to be recorded before it can be waited for).
 //   dflo_hip_multi_create_rank  one process per GPU (what torchrun / mpirun start); halos move with grouped
 //                               ncclSend/ncclRecv, the time step with an 8-byte ncclAllReduce(min), all on the comm stream.
 //                               RCCL is loaded with dlopen the first time it is needed: single-GPU users do not need it.
@@ -27,11 +31,18 @@
 #include <rccl/rccl.h>   // types and enums only: the functions are resolved with dlsym
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cmath>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
+#include <memory>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -48,6 +59,7 @@ struct Rccl {
   ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
   ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;   // optional
   ncclResult_t (*GroupStart)() = nullptr;
   ncclResult_t (*GroupEnd)() = nullptr;
   ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
@@ -95,9 +107,26 @@ bool load_rccl(std::string &err) {
   DFLO_SYM(AllReduce, "ncclAllReduce");
   DFLO_SYM(GetErrorString, "ncclGetErrorString");
 #undef DFLO_SYM
+  *(void **)(&g_rccl.CommAbort) = dlsym(lib, "ncclCommAbort");
   g_rccl.lib = lib;
   return true;
 }
+
+enum Chan { CH_CELLS = 0, CH_AVG = 1, CH_TRACES = 2 };
+
+// Host-side sequencing between the host threads of the parts (one-process mode).  A stream can only wait for an event that has
+// been recorded: before a thread calls hipStreamWaitEvent on a peer's event it waits until the peer's counter says the record
+// has been issued.  With the single-threaded driver the counters are always ahead (all parts post before any part waits).
+struct Sync {
+  std::atomic<int64_t> posted[3];   // exchanges of each kind whose copies and `sent` record this part has issued
+  std::atomic<int64_t> used[3];     // strict mode: exchanges of each kind whose consumers (unpack / rim kernel) this part has issued
+  std::atomic<int64_t> fin;         // steps whose `fin` record (CFL minimum published) this part has issued
+  Sync() { reset(); }
+  void reset() {
+    for (int k = 0; k < 3; ++k) { posted[k].store(0); used[k].store(0); }
+    fin.store(0);
+  }
+};
 
 struct Part {
   int index = 0;               // part number in the partition (= rank in rank mode)
@@ -108,9 +137,13 @@ struct Part {
   int n_owned = 0, n_cells = 0, n_send = 0, n_ghost = 0;
   std::vector<int> peers;      // parts this one exchanges cells with
   hipStream_t M = nullptr, C = nullptr;
-  hipEvent_t ev_open = nullptr, ev_rim = nullptr, ev_rim_prev = nullptr, ev_ring = nullptr, ev_unpack = nullptr,
-             ev_fin = nullptr, ev_dt = nullptr;
-  hipEvent_t ev_sent_u = nullptr, ev_sent_a = nullptr;
+  hipEvent_t ev_open = nullptr, ev_rim = nullptr, ev_rim_prev = nullptr, ev_ring = nullptr, ev_unpack = nullptr, ev_dt = nullptr;
+  hipEvent_t ev_fin[2] = {nullptr, nullptr};                 // by the parity of the step
+  hipEvent_t ev_sent[3][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};   // by kind of record and receive area
+  hipEvent_t ev_used[3][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};   // strict mode: area consumed
+  hipEvent_t ev_chunk[2] = {nullptr, nullptr};               // threaded advance: this part's host stays two chunks of steps ahead at most
+  Sync *sy = nullptr;
+  int64_t n_post[3] = {0, 0, 0}, n_arr[3] = {0, 0, 0}, n_fin = 0;   // this part's own counts (what it has issued / expects of the peers)
   double *send_u = nullptr, *send_a = nullptr;
   double *recv_u[2] = {nullptr, nullptr}, *recv_a[2] = {nullptr, nullptr};   // alternate from exchange to exchange
   // face-trace records (dflo_hip_halo_traces): what goes to peer q are the traces of the faces sendf_off[q] .. of the send
@@ -123,13 +156,29 @@ struct Part {
   void *dt_ptr = nullptr, *res_ptr = nullptr;
   bool unpack_pending = false;   // the comm stream has work the compute stream has not waited for
   bool rim_pending = false;      // ... among it the rim of the previous stage
+  int steps_run = 0;             // threaded advance: steps this part's thread issued
   std::vector<int32_t> bface_global;   // global boundary-face number of the engine's boundary faces
+};
+
+// one host thread per part (one-process mode with several parts)
+struct Worker {
+  std::thread th;
+  std::mutex mu;
+  std::condition_variable cv;
+  std::function<int()> job;
+  bool has_job = false, done = true, quit = false;
+  int rc = 0;
 };
 
 }  // namespace
 
 struct dflo_hip_multi {
   std::vector<Part> parts;     // the parts this process owns
+  std::unique_ptr<Sync[]> sync;
+  std::vector<std::unique_ptr<Worker>> workers;   // empty: the calling thread drives every part
+  std::atomic<bool> abort{false};                 // a part's thread has failed: the others stop waiting for it
+  std::atomic<int64_t> stop_at{INT64_MAX};        // threaded advance: the step at which every thread leaves the loop
+  bool strict = false;         // DFLO_MULTI_STRICT=1: a sender waits for an explicit "consumed" event of the receive area
   int n_parts = 1;             // parts of the partition (= n_ranks in rank mode)
   int rank = 0;                // rank mode: this process's part
   bool rank_mode = false, loopback = false;
@@ -142,24 +191,30 @@ struct dflo_hip_multi {
   int degree = 1, basis = 0, ndof = 16, N = 2, n_rk = 2;
   int64_t n_cells_global = 0;
   bool tvb = false, kxrcf = false, limited = false, sep_limiter = false;
-  int xparity = 1;             // which receive buffers the next exchange of DoFs / of averages fills (for face traces: never
-                               // the table the engines read at that moment -- they start with table 0)
-  int aparity = 0;
-  int step_parity = 0;         // which published slot the next last stage fills
+  // Exchanges of the state since the last set_solution.  Exchange n (0, 1, ..) fills receive area (1 + n) & 1 of the DoF / trace
+  // records and n & 1 of the averages: never the trace table the engines read at that moment (they start with table 0).
+  int64_t nx = 0;
+  int64_t n_steps_fin = 0;     // steps whose time step has been reduced over the parts (parity: which published slot)
   double *scal = nullptr;      // rank mode: device scratch for small all-reduces (on parts[0].device)
   std::vector<int32_t> gb_cell, gb_face, gb_id;   // boundary faces of the undivided mesh, MeshWorker order
   std::vector<double> gb_xy;
   hipEvent_t ev_chunk[2] = {nullptr, nullptr};
+  std::mutex err_mu;
   std::string err;
 };
 
 namespace {
 
+void set_err(dflo_hip_multi *m, const std::string &s) {
+  std::lock_guard<std::mutex> lk(m->err_mu);
+  m->err = s;
+}
+
 #define MHIP(m, call)                                                           \
   do {                                                                          \
     hipError_t e_ = (call);                                                     \
     if (e_ != hipSuccess) {                                                     \
-      (m)->err = std::string(#call) + ": " + hipGetErrorString(e_);             \
+      set_err((m), std::string(#call) + ": " + hipGetErrorString(e_));          \
       return DFLO_ERR_HIP;                                                      \
     }                                                                           \
   } while (0)
@@ -167,7 +222,7 @@ namespace {
   do {                                                                          \
     ncclResult_t r_ = (call);                                                   \
     if (r_ != ncclSuccess) {                                                    \
-      (m)->err = std::string(#call) + ": " + g_rccl.GetErrorString(r_);         \
+      set_err((m), std::string(#call) + ": " + g_rccl.GetErrorString(r_));      \
       return DFLO_ERR_COMM;                                                     \
     }                                                                           \
   } while (0)
@@ -175,7 +230,7 @@ namespace {
   do {                                                                          \
     int rc_ = (call);                                                           \
     if (rc_) {                                                                  \
-      (m)->err = std::string("part ") + std::to_string((part).index) + ": " + dflo_hip_last_error((part).eng); \
+      set_err((m), std::string("part ") + std::to_string((part).index) + ": " + dflo_hip_last_error((part).eng)); \
       return rc_;                                                               \
     }                                                                           \
   } while (0)
@@ -186,20 +241,103 @@ Part *local_part(dflo_hip_multi *m, int index) {
   return nullptr;
 }
 
+// wait (host) until a peer's counter has reached `want`
+int wait_count(dflo_hip_multi *m, const std::atomic<int64_t> &c, int64_t want) {
+  if (c.load(std::memory_order_acquire) >= want) return DFLO_OK;
+  const auto t0 = std::chrono::steady_clock::now();
+  for (unsigned spin = 1;; ++spin) {
+    if (c.load(std::memory_order_acquire) >= want) return DFLO_OK;
+    if (m->abort.load(std::memory_order_acquire)) return DFLO_ERR_COMM;   // the failing thread has left its message
+    if (m->workers.empty()) { set_err(m, "multi-device schedule out of step: a part waits for records no part has posted"); return DFLO_ERR_COMM; }
+    if (spin > 4096) std::this_thread::yield();
+    if ((spin & 0xFFFFF) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120)) {
+      set_err(m, "multi-device schedule: a peer part has not posted its records for two minutes");
+      return DFLO_ERR_COMM;
+    }
+  }
+}
+
+// Run fn(part) for every local part: on the parts' own threads when there are any, else one after the other on the calling
+// thread.  Returns the first failure (the parts still run to their end: a thread that fails raises `abort`, which ends the
+// others' waits).
+template <class F>
+int for_parts(dflo_hip_multi *m, F fn) {
+  if (m->workers.empty()) {
+    for (Part &p : m->parts) {
+      const int rc = fn(p);
+      if (rc) return rc;
+    }
+    return DFLO_OK;
+  }
+  m->abort.store(false);
+  for (size_t i = 0; i < m->workers.size(); ++i) {
+    Worker &w = *m->workers[i];
+    Part *pp = &m->parts[i];
+    std::lock_guard<std::mutex> lk(w.mu);
+    w.job = [m, pp, &fn]() {
+      const int rc = fn(*pp);
+      if (rc) m->abort.store(true, std::memory_order_release);
+      return rc;
+    };
+    w.has_job = true;
+    w.done = false;
+    w.cv.notify_all();
+  }
+  int first = DFLO_OK;
+  for (auto &wp : m->workers) {
+    Worker &w = *wp;
+    std::unique_lock<std::mutex> lk(w.mu);
+    w.cv.wait(lk, [&] { return w.done; });
+    // a thread that gave up because another one failed reports DFLO_ERR_COMM: the first real failure wins
+    if (w.rc && (!first || first == DFLO_ERR_COMM)) first = w.rc;
+  }
+  return first;
+}
+
+void worker_main(Worker *w) {
+  for (;;) {
+    std::function<int()> job;
+    {
+      std::unique_lock<std::mutex> lk(w->mu);
+      w->cv.wait(lk, [&] { return w->has_job || w->quit; });
+      if (w->quit) return;
+      job = std::move(w->job);
+      w->has_job = false;
+    }
+    const int rc = job();
+    {
+      std::lock_guard<std::mutex> lk(w->mu);
+      w->rc = rc;
+      w->done = true;
+    }
+    w->cv.notify_all();
+  }
+}
+
+void stop_workers(dflo_hip_multi *m) {
+  for (auto &wp : m->workers) {
+    {
+      std::lock_guard<std::mutex> lk(wp->mu);
+      wp->quit = true;
+    }
+    wp->cv.notify_all();
+    if (wp->th.joinable()) wp->th.join();
+  }
+  m->workers.clear();
+}
+
 // ---- transport.  Three kinds of record travel: whole cells (DoFs + average), cell averages, face traces.  post: the
 // records packed in `send` leave for the peers; arrive: the comm stream waits until the peers' records are in this part's
 // receive area `par`.
-enum Chan { CH_CELLS = 0, CH_AVG = 1, CH_TRACES = 2 };
 struct ChanView {
   const int32_t *so, *ro;   // per-peer offsets of what this part sends / receives, in records
   int width;                // doubles per record
   double *recv;             // where this part receives (area `par`)
-  hipEvent_t sent;          // local mode: this part's copies of this kind are enqueued
 };
 ChanView chan(dflo_hip_multi *m, Part &p, int kind, int par) {
-  if (kind == CH_AVG) return {p.send_off, p.recv_off, 4, p.recv_a[par], p.ev_sent_a};
-  if (kind == CH_TRACES) return {p.sendf_off.data(), p.recvf_off.data(), 4 * m->N, (double *)p.tg[par], p.ev_sent_u};
-  return {p.send_off, p.recv_off, m->ndof + 4, p.recv_u[par], p.ev_sent_u};
+  if (kind == CH_AVG) return {p.send_off, p.recv_off, 4, p.recv_a[par]};
+  if (kind == CH_TRACES) return {p.sendf_off.data(), p.recvf_off.data(), 4 * m->N, (double *)p.tg[par]};
+  return {p.send_off, p.recv_off, m->ndof + 4, p.recv_u[par]};
 }
 
 int post(dflo_hip_multi *m, Part &p, const double *send, int kind, int par) {
@@ -219,12 +357,14 @@ int post(dflo_hip_multi *m, Part &p, const double *send, int kind, int par) {
       rb.push_back((size_t)(v.ro[q + 1] - v.ro[q]) * w * sizeof(double));
     }
     if (m->x_exchange(m->x_user, (int)peers.size(), peers.data(), sp.data(), sb.data(), rp.data(), rb.data(), (void *)p.C)) {
-      m->err = "the host program's exchange callback failed";
+      set_err(m, "the host program's exchange callback failed");
       return DFLO_ERR_COMM;
     }
     return DFLO_OK;
   }
   if (m->rank_mode) {
+    // (the receives are posted by the receiver itself, on its comm stream behind everything of its own that read the
+    //  receive area: no peer can overwrite what is still in use)
     MNCCL(m, g_rccl.GroupStart());
     for (int q : p.peers) {
       const size_t ns = (size_t)(v.so[q + 1] - v.so[q]) * w, nr = (size_t)(v.ro[q + 1] - v.ro[q]) * w;
@@ -234,6 +374,11 @@ int post(dflo_hip_multi *m, Part &p, const double *send, int kind, int par) {
     MNCCL(m, g_rccl.GroupEnd());
     return DFLO_OK;
   }
+  // One process: this part writes into its peers' receive areas.  Why area `par` of peer q is free: q's consumers of the
+  // exchange two back (unpack kernel / rim kernel reading the trace table) precede q's own send of the last exchange on q's comm
+  // stream, this part's comm stream has waited for that send (arrive), and q lists this part as a peer exactly when this part
+  // lists q (checked at create).  DFLO_MULTI_STRICT=1 does not rely on that chain: the copy waits for q's "consumed" event.
+  const int64_t seq = ++p.n_post[kind];
   for (int q : p.peers) {
     Part *dst = local_part(m, q);
     const ChanView dv = chan(m, *dst, kind, par);
@@ -241,6 +386,11 @@ int post(dflo_hip_multi *m, Part &p, const double *send, int kind, int par) {
     if (!n) continue;
     double *to = dv.recv + (size_t)dv.ro[p.index] * w;
     const double *from = send + (size_t)v.so[q] * w;
+    if (m->strict && seq > 2) {
+      const int rc = wait_count(m, dst->sy->used[kind], seq - 2);
+      if (rc) return rc;
+      MHIP(m, hipStreamWaitEvent(p.C, dst->ev_used[kind][par], 0));
+    }
     if (m->loopback) {   // test transport: the same copy as a self send/recv pair through RCCL
       MNCCL(m, g_rccl.GroupStart());
       MNCCL(m, g_rccl.Send(from, n, ncclDouble, 0, m->comm, p.C));
@@ -250,18 +400,31 @@ int post(dflo_hip_multi *m, Part &p, const double *send, int kind, int par) {
       MHIP(m, hipMemcpyPeerAsync(to, dst->device, from, p.device, n * sizeof(double), p.C));
     }
   }
-  MHIP(m, hipEventRecord(v.sent, p.C));
+  MHIP(m, hipEventRecord(p.ev_sent[kind][par], p.C));
+  p.sy->posted[kind].store(seq, std::memory_order_release);
   return DFLO_OK;
 }
 
-int arrive(dflo_hip_multi *m, Part &p, int kind) {
+int arrive(dflo_hip_multi *m, Part &p, int kind, int par) {
   if (m->rank_mode) return DFLO_OK;   // the receives were part of the group posted on this stream
+  if (p.peers.empty()) return DFLO_OK;
+  const int64_t seq = ++p.n_arr[kind];
   for (int q : p.peers) {
     Part *src = local_part(m, q);
     const ChanView sv = chan(m, *src, kind, 0);
     if (sv.so[p.index + 1] == sv.so[p.index]) continue;
-    MHIP(m, hipStreamWaitEvent(p.C, sv.sent, 0));
+    const int rc = wait_count(m, src->sy->posted[kind], seq);   // the record below exists
+    if (rc) return rc;
+    MHIP(m, hipStreamWaitEvent(p.C, src->ev_sent[kind][par], 0));
   }
+  return DFLO_OK;
+}
+
+// strict mode: everything that reads receive area `par` of this kind has been issued on the comm stream
+int mark_used(dflo_hip_multi *m, Part &p, int kind, int par) {
+  if (!m->strict || m->rank_mode || p.peers.empty() || p.n_arr[kind] == 0) return DFLO_OK;
+  MHIP(m, hipEventRecord(p.ev_used[kind][par], p.C));
+  p.sy->used[kind].store(p.n_arr[kind], std::memory_order_release);
   return DFLO_OK;
 }
 
@@ -281,180 +444,256 @@ int send_state(dflo_hip_multi *m, Part &p, int upar, int apar, bool with_avg) {
 // ... and the neighbours' arrives: into the ghost shards, or straight into the trace table the next stage will read
 int recv_state(dflo_hip_multi *m, Part &p, int upar, int apar, bool with_avg) {
   if (!p.trace) {
-    int rc = arrive(m, p, CH_CELLS);
+    int rc = arrive(m, p, CH_CELLS, upar);
     if (rc) return rc;
     MENG(m, p, dflo_hip_unpack_ghost_cells(p.eng, p.recv_u[upar]));
-    return DFLO_OK;
+    return mark_used(m, p, CH_CELLS, upar);
   }
-  int rc = arrive(m, p, CH_TRACES);
+  int rc = arrive(m, p, CH_TRACES, upar);
   if (rc) return rc;
   MENG(m, p, dflo_hip_use_ghost_traces(p.eng, upar));
   if (!with_avg) return DFLO_OK;
-  if ((rc = arrive(m, p, CH_AVG))) return rc;
+  if ((rc = arrive(m, p, CH_AVG, apar))) return rc;
   MENG(m, p, dflo_hip_unpack_ghost_avg(p.eng, p.recv_a[apar]));
-  return DFLO_OK;
+  return mark_used(m, p, CH_AVG, apar);
 }
 
-// update_ghost_values() outside the overlapped stage (after set-up calls, in the KXRCF path): all parts pack, send, unpack
-int exchange_solution(dflo_hip_multi *m) {
-  const int par = m->xparity, apar = m->aparity;
-  m->xparity ^= 1;
-  m->aparity ^= 1;
+// update_ghost_values() outside the overlapped stage (after set-up calls, in the KXRCF path), exchange number n: a part packs
+// and sends ...
+int ex_send(dflo_hip_multi *m, Part &p, int64_t n) {
+  if (p.peers.empty()) return DFLO_OK;
+  MHIP(m, hipSetDevice(p.device));
+  MHIP(m, hipEventRecord(p.ev_open, p.M));
+  MHIP(m, hipStreamWaitEvent(p.C, p.ev_open, 0));
+  MENG(m, p, dflo_hip_set_stream(p.eng, p.C));
+  // (a part that reads ghost cells by their traces: the table of the exchange before this one has been read by kernels on M
+  //  that ev_open covers)
+  int rc = mark_used(m, p, CH_TRACES, (int)(n & 1));
+  if (!rc) rc = send_state(m, p, (int)((1 + n) & 1), (int)(n & 1), true);
+  MENG(m, p, dflo_hip_set_stream(p.eng, p.M));
+  return rc;
+}
+// ... and takes in what its neighbours sent
+int ex_recv(dflo_hip_multi *m, Part &p, int64_t n) {
+  if (p.peers.empty()) return DFLO_OK;
+  MHIP(m, hipSetDevice(p.device));
+  MENG(m, p, dflo_hip_set_stream(p.eng, p.C));
+  int rc = recv_state(m, p, (int)((1 + n) & 1), (int)(n & 1), true);
+  MENG(m, p, dflo_hip_set_stream(p.eng, p.M));
+  if (rc) return rc;
+  MHIP(m, hipEventRecord(p.ev_unpack, p.C));
+  MHIP(m, hipStreamWaitEvent(p.M, p.ev_unpack, 0));
+  return DFLO_OK;
+}
+int exchange_solution(dflo_hip_multi *m) {   // calling thread, all parts
+  const int64_t n = m->nx++;
   for (Part &p : m->parts) {
-    if (p.peers.empty()) continue;
-    MHIP(m, hipSetDevice(p.device));
-    MHIP(m, hipEventRecord(p.ev_open, p.M));
-    MHIP(m, hipStreamWaitEvent(p.C, p.ev_open, 0));
-    MENG(m, p, dflo_hip_set_stream(p.eng, p.C));
-    int rc = send_state(m, p, par, apar, true);
-    MENG(m, p, dflo_hip_set_stream(p.eng, p.M));
+    const int rc = ex_send(m, p, n);
     if (rc) return rc;
   }
   for (Part &p : m->parts) {
-    if (p.peers.empty()) continue;
-    MHIP(m, hipSetDevice(p.device));
-    MENG(m, p, dflo_hip_set_stream(p.eng, p.C));
-    int rc = recv_state(m, p, par, apar, true);
-    MENG(m, p, dflo_hip_set_stream(p.eng, p.M));
+    const int rc = ex_recv(m, p, n);
     if (rc) return rc;
-    MHIP(m, hipEventRecord(p.ev_unpack, p.C));
-    MHIP(m, hipStreamWaitEvent(p.M, p.ev_unpack, 0));
   }
   return DFLO_OK;
 }
 
-// One RK stage on every part of this process.  The rim shards run on the comm stream C (high priority), the interior
-// shards on the compute stream M, side by side: both read the previous stage, they write disjoint shards.
+// One RK stage of one part, in phases.  The rim shards run on the comm stream C (high priority), the interior shards on the
+// compute stream M, side by side: both read the previous stage, they write disjoint shards.
 //   C: [wait: interior of the previous stage / the new time step]  update rim  (TVB: rim + ring; exchange the averages of the
 //      rim cells; limit the rim)  -> ev_rim;  pack; send / receive; unpack into the ghost shards
 //   M: [wait: ev_rim of the previous stage]  update interior  (TVB: all but rim + ring; wait for the ring; limit all but the
 //      rim)  -> ev_int;  last stage: wait ev_rim, reductions of the step
-int run_stage(dflo_hip_multi *m, int rk, double dt) {
-  const bool last = rk == m->n_rk - 1;
-  bool any_peers = false;
-  for (Part &p : m->parts) any_peers |= !p.peers.empty();
-  if (!any_peers) {   // nothing to exchange: the plain stage
-    for (Part &p : m->parts) MENG(m, p, dflo_hip_stage(p.eng, rk, dt));
-    return DFLO_OK;
-  }
-  if (m->kxrcf) {
-    // the KXRCF indicator reads the neighbours' unlimited DoFs of the new stage: ghosts are refreshed between update and
-    // limiter as well (update_ghost_values before compute_shock_indicator in the MPI variant); no overlap on this path
-    for (Part &p : m->parts) {
-      MHIP(m, hipSetDevice(p.device));
-      MENG(m, p, dflo_hip_stage_update(p.eng, rk, dt));
-    }
-    int rc = exchange_solution(m);
-    if (rc) return rc;
-    for (Part &p : m->parts) MENG(m, p, dflo_hip_stage_limit(p.eng));
-    return exchange_solution(m);
-  }
-  const int upar = m->xparity, apar = m->aparity;
-  m->xparity ^= 1;
-  m->aparity ^= 1;
+// A part's own thread runs its phases one after the other; the single-threaded driver runs each phase for all parts before
+// the next one (so that every record a phase waits for has been issued).
+struct StageCtx {
+  int rk;
+  double dt;
+  int64_t n;   // number of this exchange of the state
+  bool last;
+};
+constexpr int kStagePhases = 5;
+
+int stage_phase(dflo_hip_multi *m, Part &p, const StageCtx &s, int ph) {
+  const int upar = (int)((1 + s.n) & 1), apar = (int)(s.n & 1);
   const int rim_update = m->tvb ? 3 : 1, int_update = m->tvb ? 4 : 2;
-  // open the stage (buffer roles; rk = 0: boundary programs on M), then the rim on C
-  for (Part &p : m->parts) {
-    MHIP(m, hipSetDevice(p.device));
-    MENG(m, p, dflo_hip_stage_open(p.eng, rk, dt));
-    MHIP(m, hipEventRecord(p.ev_open, p.M));       // interior of the previous stage, the step's time step, boundary data
-    MHIP(m, hipStreamWaitEvent(p.C, p.ev_open, 0));
-    MENG(m, p, dflo_hip_set_stream(p.eng, p.C));
-    MENG(m, p, dflo_hip_stage_update_part(p.eng, rim_update));
-    if (m->tvb) {
-      MHIP(m, hipEventRecord(p.ev_ring, p.C));
-      MENG(m, p, dflo_hip_pack_send_avg(p.eng, p.send_a));
-    } else {
-      if (m->sep_limiter) MENG(m, p, dflo_hip_stage_limit_part(p.eng, 1));
-      MHIP(m, hipEventRecord(p.ev_rim, p.C));
+  MHIP(m, hipSetDevice(p.device));
+  switch (ph) {
+    case 0: {   // open the stage (buffer roles; rk = 0: boundary programs on M), then the rim on C and what leaves first
+      MENG(m, p, dflo_hip_stage_open(p.eng, s.rk, s.dt));
+      MHIP(m, hipEventRecord(p.ev_open, p.M));       // interior of the previous stage, the step's time step, boundary data
+      MHIP(m, hipStreamWaitEvent(p.C, p.ev_open, 0));
+      MENG(m, p, dflo_hip_set_stream(p.eng, p.C));
+      MENG(m, p, dflo_hip_stage_update_part(p.eng, rim_update));
+      int rc = mark_used(m, p, CH_TRACES, apar);     // the rim kernel has read the trace table of the exchange before (area apar = upar ^ 1)
+      if (rc) return rc;
+      if (m->tvb) {
+        MHIP(m, hipEventRecord(p.ev_ring, p.C));
+        MENG(m, p, dflo_hip_pack_send_avg(p.eng, p.send_a));
+      } else {
+        if (m->sep_limiter) MENG(m, p, dflo_hip_stage_limit_part(p.eng, 1));
+        MHIP(m, hipEventRecord(p.ev_rim, p.C));
+      }
+      rc = m->tvb ? post(m, p, p.send_a, CH_AVG, apar) : send_state(m, p, upar, apar, true);
+      MENG(m, p, dflo_hip_set_stream(p.eng, p.M));
+      return rc;
     }
-    int rc = m->tvb ? post(m, p, p.send_a, CH_AVG, apar) : send_state(m, p, upar, apar, true);
-    MENG(m, p, dflo_hip_set_stream(p.eng, p.M));
-    if (rc) return rc;
-  }
-  // the interior on M, next to it
-  for (Part &p : m->parts) {
-    MHIP(m, hipSetDevice(p.device));
-    if (p.rim_pending) MHIP(m, hipStreamWaitEvent(p.M, p.ev_rim_prev, 0));   // the rim cells of the previous stage (halo of the interior)
-    MENG(m, p, dflo_hip_stage_update_part(p.eng, int_update));
-  }
-  if (m->tvb) {
-    // the averages of the neighbours across the cut arrive: limit the rim, send its cells
-    for (Part &p : m->parts) {
-      MHIP(m, hipSetDevice(p.device));
-      int rc = arrive(m, p, CH_AVG);
+    case 1:     // the interior on M, next to it
+      if (p.rim_pending) MHIP(m, hipStreamWaitEvent(p.M, p.ev_rim_prev, 0));   // the rim cells of the previous stage (halo of the interior)
+      MENG(m, p, dflo_hip_stage_update_part(p.eng, int_update));
+      return DFLO_OK;
+    case 2: {   // TVB: the averages of the neighbours across the cut arrive: limit the rim, send its cells
+      if (!m->tvb) return DFLO_OK;
+      int rc = arrive(m, p, CH_AVG, apar);
       if (rc) return rc;
       MENG(m, p, dflo_hip_set_stream(p.eng, p.C));
       MENG(m, p, dflo_hip_unpack_ghost_avg(p.eng, p.recv_a[apar]));
+      if ((rc = mark_used(m, p, CH_AVG, apar))) return rc;
       MENG(m, p, dflo_hip_stage_limit_part(p.eng, 1));
       MHIP(m, hipEventRecord(p.ev_rim, p.C));
       rc = send_state(m, p, upar, apar, false);   // the averages have travelled already
       MENG(m, p, dflo_hip_set_stream(p.eng, p.M));
+      return rc;
+    }
+    case 3:     // limiter of the other shards (TVB: it reads averages from the ring), the stage's reductions
+      if (m->tvb) {
+        MHIP(m, hipStreamWaitEvent(p.M, p.ev_ring, 0));
+        MENG(m, p, dflo_hip_stage_limit_part(p.eng, 2));
+      } else if (m->sep_limiter) {
+        MENG(m, p, dflo_hip_stage_limit_part(p.eng, 2));
+      }
+      if (s.last) MHIP(m, hipStreamWaitEvent(p.M, p.ev_rim, 0));   // the step's reductions take in the rim shards' partials
+      MENG(m, p, dflo_hip_stage_finish(p.eng));
+      std::swap(p.ev_rim, p.ev_rim_prev);      // the next stage's interior waits for this stage's rim
+      p.rim_pending = !s.last;                 // (after the last stage M has waited already)
+      return DFLO_OK;
+    default: {  // the neighbours' cells arrive: into the ghost shards, ready for the next stage's rim (same stream)
+      MENG(m, p, dflo_hip_set_stream(p.eng, p.C));
+      const int rc = recv_state(m, p, upar, apar, !m->tvb);
+      MENG(m, p, dflo_hip_set_stream(p.eng, p.M));
       if (rc) return rc;
+      p.unpack_pending = true;
+      return DFLO_OK;
     }
-    for (Part &p : m->parts) {   // the limiter of the other shards reads averages from the ring
-      MHIP(m, hipSetDevice(p.device));
-      MHIP(m, hipStreamWaitEvent(p.M, p.ev_ring, 0));
-      MENG(m, p, dflo_hip_stage_limit_part(p.eng, 2));
-    }
-  } else if (m->sep_limiter) {
-    for (Part &p : m->parts) MENG(m, p, dflo_hip_stage_limit_part(p.eng, 2));
   }
-  for (Part &p : m->parts) {
-    MHIP(m, hipSetDevice(p.device));
-    if (last) MHIP(m, hipStreamWaitEvent(p.M, p.ev_rim, 0));   // the step's reductions take in the rim shards' partials
-    MENG(m, p, dflo_hip_stage_finish(p.eng));
-    std::swap(p.ev_rim, p.ev_rim_prev);      // the next stage's interior waits for this stage's rim
-    p.rim_pending = !last;                    // (after the last stage M has waited already)
+}
+
+// the KXRCF indicator reads the neighbours' unlimited DoFs of the new stage: ghosts are refreshed between update and
+// limiter as well (update_ghost_values before compute_shock_indicator in the MPI variant); no overlap on this path.
+// Two exchanges per stage (numbers n and n + 1).
+constexpr int kKxrcfPhases = 6;
+int kxrcf_phase(dflo_hip_multi *m, Part &p, const StageCtx &s, int ph) {
+  MHIP(m, hipSetDevice(p.device));
+  switch (ph) {
+    case 0: MENG(m, p, dflo_hip_stage_update(p.eng, s.rk, s.dt)); return DFLO_OK;
+    case 1: return ex_send(m, p, s.n);
+    case 2: return ex_recv(m, p, s.n);
+    case 3: MENG(m, p, dflo_hip_stage_limit(p.eng)); return DFLO_OK;
+    case 4: return ex_send(m, p, s.n + 1);
+    default: return ex_recv(m, p, s.n + 1);
   }
-  // the neighbours' cells arrive: into the ghost shards, ready for the next stage's rim (same stream)
-  for (Part &p : m->parts) {
-    MHIP(m, hipSetDevice(p.device));
-    MENG(m, p, dflo_hip_set_stream(p.eng, p.C));
-    int rc = recv_state(m, p, upar, apar, !m->tvb);
-    MENG(m, p, dflo_hip_set_stream(p.eng, p.M));
+}
+
+bool any_peers(dflo_hip_multi *m) {
+  for (Part &p : m->parts)
+    if (!p.peers.empty()) return true;
+  return false;
+}
+int exchanges_per_stage(dflo_hip_multi *m) { return any_peers(m) ? (m->kxrcf ? 2 : 1) : 0; }
+
+// one RK stage of one part, all phases (the part's own thread)
+int part_stage(dflo_hip_multi *m, Part &p, int rk, double dt, int64_t n, bool peers) {
+  if (!peers) { MENG(m, p, dflo_hip_stage(p.eng, rk, dt)); return DFLO_OK; }   // nothing to exchange: the plain stage
+  const StageCtx s{rk, dt, n, rk == m->n_rk - 1};
+  const int nph = m->kxrcf ? kKxrcfPhases : kStagePhases;
+  for (int ph = 0; ph < nph; ++ph) {
+    const int rc = m->kxrcf ? kxrcf_phase(m, p, s, ph) : stage_phase(m, p, s, ph);
     if (rc) return rc;
-    p.unpack_pending = true;
   }
   return DFLO_OK;
 }
 
-// Utilities::MPI::min(global_dt) (src_mpi/claw.cc:579) on the device-resident time step, after the last stage of a step
-int reduce_dt(dflo_hip_multi *m) {
-  if (m->n_parts == 1) return DFLO_OK;   // finalize_kernel has applied the rules already
-  const int par = m->step_parity;
-  m->step_parity ^= 1;
-  if (m->rank_mode) {
-    Part &p = m->parts[0];
-    MHIP(m, hipEventRecord(p.ev_fin, p.M));
-    MHIP(m, hipStreamWaitEvent(p.C, p.ev_fin, 0));
-    double *raw = (double *)p.dt_ptr + 2;
-    if (m->x_allreduce) {
-      if (m->x_allreduce(m->x_user, raw, 1, DFLO_REDUCE_MIN, (void *)p.C)) { m->err = "the host program's all-reduce callback failed"; return DFLO_ERR_COMM; }
-    } else {
-      MNCCL(m, g_rccl.AllReduce(raw, raw, 1, ncclDouble, ncclMin, m->comm, p.C));
-    }
-    MENG(m, p, dflo_hip_set_stream(p.eng, p.C));
-    MENG(m, p, dflo_hip_apply_dt_rules(p.eng));
-    MENG(m, p, dflo_hip_set_stream(p.eng, p.M));
-    MHIP(m, hipEventRecord(p.ev_dt, p.C));
-    MHIP(m, hipStreamWaitEvent(p.M, p.ev_dt, 0));
+// one RK stage on every part of this process, driven by the calling thread
+int run_stage(dflo_hip_multi *m, int rk, double dt) {
+  if (!any_peers(m)) {
+    for (Part &p : m->parts) MENG(m, p, dflo_hip_stage(p.eng, rk, dt));
     return DFLO_OK;
   }
-  for (Part &p : m->parts) {
-    MHIP(m, hipSetDevice(p.device));
-    MHIP(m, hipEventRecord(p.ev_fin, p.M));
-  }
-  for (Part &p : m->parts) {
-    MHIP(m, hipSetDevice(p.device));
-    const void *slots[16];
-    int n = 0;
-    for (Part &q : m->parts) {
-      if (&q == &p) continue;
-      MHIP(m, hipStreamWaitEvent(p.M, q.ev_fin, 0));
-      slots[n++] = q.dt_slot[par];
+  const StageCtx s{rk, dt, m->nx, rk == m->n_rk - 1};
+  m->nx += m->kxrcf ? 2 : 1;
+  const int nph = m->kxrcf ? kKxrcfPhases : kStagePhases;
+  for (int ph = 0; ph < nph; ++ph)
+    for (Part &p : m->parts) {
+      const int rc = m->kxrcf ? kxrcf_phase(m, p, s, ph) : stage_phase(m, p, s, ph);
+      if (rc) return rc;
     }
-    MENG(m, p, dflo_hip_apply_dt_rules_peers(p.eng, n, slots));
+  return DFLO_OK;
+}
+
+// Utilities::MPI::min(global_dt) (src_mpi/claw.cc:579) on the device-resident time step, after the last stage of step number
+// `step` (counted since create).  One process per GPU: an 8-byte all-reduce on the comm stream.  One process: phase 0, every
+// part records that its CFL minimum is published; phase 1, it waits for the others' records and reads their slots over xGMI.
+int reduce_dt_rank(dflo_hip_multi *m) {
+  Part &p = m->parts[0];
+  MHIP(m, hipEventRecord(p.ev_fin[0], p.M));
+  MHIP(m, hipStreamWaitEvent(p.C, p.ev_fin[0], 0));
+  double *raw = (double *)p.dt_ptr + 2;
+  if (m->x_allreduce) {
+    if (m->x_allreduce(m->x_user, raw, 1, DFLO_REDUCE_MIN, (void *)p.C)) { set_err(m, "the host program's all-reduce callback failed"); return DFLO_ERR_COMM; }
+  } else {
+    MNCCL(m, g_rccl.AllReduce(raw, raw, 1, ncclDouble, ncclMin, m->comm, p.C));
+  }
+  MENG(m, p, dflo_hip_set_stream(p.eng, p.C));
+  MENG(m, p, dflo_hip_apply_dt_rules(p.eng));
+  MENG(m, p, dflo_hip_set_stream(p.eng, p.M));
+  MHIP(m, hipEventRecord(p.ev_dt, p.C));
+  MHIP(m, hipStreamWaitEvent(p.M, p.ev_dt, 0));
+  return DFLO_OK;
+}
+int reduce_dt_phase(dflo_hip_multi *m, Part &p, int64_t step, int ph) {
+  const int par = (int)(step & 1);
+  MHIP(m, hipSetDevice(p.device));
+  if (ph == 0) {
+    MHIP(m, hipEventRecord(p.ev_fin[par], p.M));
+    p.sy->fin.store(++p.n_fin, std::memory_order_release);
+    return DFLO_OK;
+  }
+  const void *slots[16];
+  int n = 0;
+  for (Part &q : m->parts) {
+    if (&q == &p) continue;
+    const int rc = wait_count(m, q.sy->fin, p.n_fin);
+    if (rc) return rc;
+    MHIP(m, hipStreamWaitEvent(p.M, q.ev_fin[par], 0));
+    slots[n++] = q.dt_slot[par];
+  }
+  MENG(m, p, dflo_hip_apply_dt_rules_peers(p.eng, n, slots));
+  return DFLO_OK;
+}
+int reduce_dt(dflo_hip_multi *m) {   // calling thread, all parts
+  if (m->n_parts == 1) return DFLO_OK;   // finalize_kernel has applied the rules already
+  if (m->rank_mode) return reduce_dt_rank(m);
+  const int64_t step = m->n_steps_fin++;
+  for (int ph = 0; ph < 2; ++ph)
+    for (Part &p : m->parts) {
+      const int rc = reduce_dt_phase(m, p, step, ph);
+      if (rc) return rc;
+    }
+  return DFLO_OK;
+}
+
+// one whole time step of one part (the part's own thread): stages, old_solution = current_solution, the time step of the next
+int part_step(dflo_hip_multi *m, Part &p, double dt, int64_t n0, int64_t step, bool peers) {
+  const int xs = m->kxrcf ? 2 : 1;
+  for (int rk = 0; rk < m->n_rk; ++rk) {
+    const int rc = part_stage(m, p, rk, dt, n0 + (int64_t)rk * xs, peers);
+    if (rc) return rc;
+  }
+  MENG(m, p, dflo_hip_end_step(p.eng));
+  if (m->n_parts == 1) return DFLO_OK;
+  for (int ph = 0; ph < 2; ++ph) {
+    const int rc = reduce_dt_phase(m, p, step, ph);
+    if (rc) return rc;
   }
   return DFLO_OK;
 }
@@ -492,7 +731,7 @@ int host_allreduce(dflo_hip_multi *m, double *v, int n, ncclRedOp_t op) {
   MHIP(m, hipMemcpyAsync(m->scal, v, n * sizeof(double), hipMemcpyHostToDevice, p.C));
   if (m->x_allreduce) {
     const int xop = op == ncclMin ? DFLO_REDUCE_MIN : (op == ncclSum ? DFLO_REDUCE_SUM : DFLO_REDUCE_MAX);
-    if (m->x_allreduce(m->x_user, m->scal, n, xop, (void *)p.C)) { m->err = "the host program's all-reduce callback failed"; return DFLO_ERR_COMM; }
+    if (m->x_allreduce(m->x_user, m->scal, n, xop, (void *)p.C)) { set_err(m, "the host program's all-reduce callback failed"); return DFLO_ERR_COMM; }
   } else {
     MNCCL(m, g_rccl.AllReduce(m->scal, m->scal, n, ncclDouble, op, m->comm, p.C));
   }
@@ -501,25 +740,45 @@ int host_allreduce(dflo_hip_multi *m, double *v, int n, ncclRedOp_t op) {
   return DFLO_OK;
 }
 
-// failure flags of all parts (and, in rank mode, of all ranks): every caller gets the same answer
-int check_all(dflo_hip_multi *m, bool synchronise) {
+// One process per GPU: every rank leaves a call of the driver with the same status.  `rc` is what this rank found (a limiter
+// flag, a refused parameter, 0); the ranks exchange it and return the gravest.  A rank whose device or transport has failed
+// cannot take part in that exchange: it tears the communicator down instead, which ends its peers' pending collectives with an
+// error (where the host program's own transport is in use, it has to do the same for its peers -- MPI_Abort in dflo).
+int agree(dflo_hip_multi *m, int rc) {
+  if (!m->rank_mode || m->n_parts == 1) return rc;
+  if (rc == DFLO_ERR_HIP || rc == DFLO_ERR_COMM || rc == DFLO_ERR_NOMEM) {
+    if (m->comm && g_rccl.CommAbort) { g_rccl.CommAbort(m->comm); m->comm = nullptr; }
+    return rc;
+  }
+  // [0] negative mean state, [1] positivity root failure, [2] any other status (as a positive number: the maximum is the gravest)
+  double v[3] = {rc == DFLO_ERR_NEGATIVE_MEAN_STATE ? 1.0 : 0.0, rc == DFLO_ERR_POSITIVITY_NO_ROOT ? 1.0 : 0.0,
+                 (rc && rc != DFLO_ERR_NEGATIVE_MEAN_STATE && rc != DFLO_ERR_POSITIVITY_NO_ROOT) ? (double)(-rc) : 0.0};
+  const int rc2 = host_allreduce(m, v, 3, ncclMax);
+  if (rc2) return rc2;
+  if (v[2] > 0.0) {
+    const int other = -(int)v[2];
+    if (rc != other) set_err(m, "another rank stopped with status " + std::to_string(other));
+    return other;
+  }
+  if (v[0] > 0.0) { if (rc != DFLO_ERR_NEGATIVE_MEAN_STATE) set_err(m, "Fatal: Negative states (on another rank)"); return DFLO_ERR_NEGATIVE_MEAN_STATE; }
+  if (v[1] > 0.0) { if (rc != DFLO_ERR_POSITIVITY_NO_ROOT) set_err(m, "Problem in positivity limiter (on another rank)"); return DFLO_ERR_POSITIVITY_NO_ROOT; }
+  return DFLO_OK;
+}
+
+// failure flags of all local parts
+int check_local(dflo_hip_multi *m, bool synchronise) {
   int worst = DFLO_OK;
   for (Part &p : m->parts) {
     int rc;
     if (synchronise) rc = dflo_hip_check(p.eng);
     else { int64_t st = -1; dflo_hip_failure_step(p.eng, &st); rc = st >= 0 ? dflo_hip_check(p.eng) : DFLO_OK; }
-    if (rc && rc != DFLO_ERR_NEGATIVE_MEAN_STATE && rc != DFLO_ERR_POSITIVITY_NO_ROOT) { m->err = dflo_hip_last_error(p.eng); return rc; }
-    if (rc && (!worst || rc > worst)) { worst = rc; m->err = std::string("part ") + std::to_string(p.index) + ": " + dflo_hip_last_error(p.eng); }
-  }
-  if (m->rank_mode && m->n_parts > 1) {
-    double v[2] = {worst == DFLO_ERR_NEGATIVE_MEAN_STATE ? 1.0 : 0.0, worst == DFLO_ERR_POSITIVITY_NO_ROOT ? 1.0 : 0.0};
-    int rc = host_allreduce(m, v, 2, ncclMax);
-    if (rc) return rc;
-    if (v[0] > 0.0) { if (!worst) m->err = "Fatal: Negative states (on another rank)"; worst = DFLO_ERR_NEGATIVE_MEAN_STATE; }
-    else if (v[1] > 0.0) { if (!worst) m->err = "Problem in positivity limiter (on another rank)"; worst = DFLO_ERR_POSITIVITY_NO_ROOT; }
+    if (rc && rc != DFLO_ERR_NEGATIVE_MEAN_STATE && rc != DFLO_ERR_POSITIVITY_NO_ROOT) { set_err(m, dflo_hip_last_error(p.eng)); return rc; }
+    if (rc && (!worst || rc > worst)) { worst = rc; set_err(m, std::string("part ") + std::to_string(p.index) + ": " + dflo_hip_last_error(p.eng)); }
   }
   return worst;
 }
+// ... and, in rank mode, of all ranks: every caller gets the same answer
+int check_all(dflo_hip_multi *m, bool synchronise) { return agree(m, check_local(m, synchronise)); }
 
 int setup_part(dflo_hip_multi *m, Part &p, const dflo_mesh_t *mesh, const dflo_params_t *prm, int method) {
   int rc = dflo_mesh_partition_ex(mesh, m->n_parts, p.index, method, &p.sub, &p.send_cells, &p.send_off, &p.recv_off);
@@ -541,8 +800,13 @@ int setup_part(dflo_hip_multi *m, Part &p, const dflo_mesh_t *mesh, const dflo_p
     MHIP(m, hipStreamCreateWithPriority(&p.C, hipStreamDefault, hi));
   }
   MENG(m, p, dflo_hip_set_stream(p.eng, p.M));
-  hipEvent_t *evs[] = {&p.ev_open, &p.ev_rim, &p.ev_rim_prev, &p.ev_ring, &p.ev_unpack, &p.ev_fin, &p.ev_dt, &p.ev_sent_u, &p.ev_sent_a};
+  hipEvent_t *evs[] = {&p.ev_open, &p.ev_rim, &p.ev_rim_prev, &p.ev_ring, &p.ev_unpack, &p.ev_dt, &p.ev_fin[0], &p.ev_fin[1], &p.ev_chunk[0], &p.ev_chunk[1]};
   for (hipEvent_t *e : evs) MHIP(m, hipEventCreateWithFlags(e, hipEventDisableTiming));
+  for (int k = 0; k < 3; ++k)
+    for (int i = 0; i < 2; ++i) {
+      MHIP(m, hipEventCreateWithFlags(&p.ev_sent[k][i], hipEventDisableTiming));
+      MHIP(m, hipEventCreateWithFlags(&p.ev_used[k][i], hipEventDisableTiming));
+    }
   MENG(m, p, dflo_hip_set_send_cells(p.eng, p.n_send, p.send_cells));
   const size_t ns = std::max(p.n_send, 1), ng = std::max(p.n_ghost, 1);
   MHIP(m, hipMalloc((void **)&p.send_u, ns * (m->ndof + 4) * sizeof(double)));   // DoFs + cell average per cell
@@ -663,6 +927,7 @@ const char *dflo_hip_multi_last_error(dflo_hip_multi_handle m) { return m ? m->e
 
 int dflo_hip_multi_destroy(dflo_hip_multi_handle m) {
   if (!m) return DFLO_OK;
+  stop_workers(m);
   for (Part &p : m->parts) {
     hipSetDevice(p.device);
     if (p.C) hipStreamSynchronize(p.C);
@@ -674,8 +939,13 @@ int dflo_hip_multi_destroy(dflo_hip_multi_handle m) {
     if (p.eng) dflo_hip_destroy(p.eng);
     hipFree(p.send_u); hipFree(p.send_a); hipFree(p.send_t);
     for (int i = 0; i < 2; ++i) { hipFree(p.recv_u[i]); hipFree(p.recv_a[i]); }
-    hipEvent_t evs[] = {p.ev_open, p.ev_rim, p.ev_rim_prev, p.ev_ring, p.ev_unpack, p.ev_fin, p.ev_dt, p.ev_sent_u, p.ev_sent_a};
+    hipEvent_t evs[] = {p.ev_open, p.ev_rim, p.ev_rim_prev, p.ev_ring, p.ev_unpack, p.ev_dt, p.ev_fin[0], p.ev_fin[1], p.ev_chunk[0], p.ev_chunk[1]};
     for (hipEvent_t e : evs) if (e) hipEventDestroy(e);
+    for (int k = 0; k < 3; ++k)
+      for (int i = 0; i < 2; ++i) {
+        if (p.ev_sent[k][i]) hipEventDestroy(p.ev_sent[k][i]);
+        if (p.ev_used[k][i]) hipEventDestroy(p.ev_used[k][i]);
+      }
     if (p.C) hipStreamDestroy(p.C);
     if (p.M) hipStreamDestroy(p.M);
     if (p.sub) dflo_mesh_free(p.sub);
@@ -696,17 +966,21 @@ int dflo_hip_multi_create(const dflo_mesh_t *mesh, const dflo_params_t *params, 
   int rc = create_common(mesh, params, m);
   if (rc) return bail(rc);
   if (const char *e = std::getenv("DFLO_MULTI_TRANSPORT")) m->loopback = std::strcmp(e, "rccl_loopback") == 0;
+  if (const char *e = std::getenv("DFLO_MULTI_STRICT")) m->strict = std::atoi(e) != 0;
   m->parts.resize(n_devices);
+  m->sync.reset(new Sync[n_devices]);
   for (int i = 0; i < n_devices; ++i) {
     m->parts[i].index = i;
     m->parts[i].device = device_ids[i];
+    m->parts[i].sy = &m->sync[i];
   }
   for (int i = 0; i < n_devices; ++i)
     if ((rc = setup_part(m, m->parts[i], mesh, params, partitioner))) return bail(rc);
-  // what one part sends is what the other expects
+  // what one part sends is what the other expects, and peers are mutual (the receive areas' reuse rests on it, see post)
   for (Part &p : m->parts)
     for (int q : p.peers) {
       Part &o = m->parts[q];
+      if (std::find(o.peers.begin(), o.peers.end(), p.index) == o.peers.end()) { m->err = "partition: part " + std::to_string(p.index) + " lists part " + std::to_string(q) + " as a neighbour but not the other way round"; return bail(DFLO_ERR_COMM); }
       if (p.send_off[q + 1] - p.send_off[q] != o.recv_off[p.index + 1] - o.recv_off[p.index]) { m->err = "partition: send and receive counts disagree"; return bail(DFLO_ERR_COMM); }
       if (p.trace && p.sendf_off[q + 1] - p.sendf_off[q] != o.recvf_off[p.index + 1] - o.recvf_off[p.index]) { m->err = "partition: face-trace send and receive counts disagree"; return bail(DFLO_ERR_COMM); }
     }
@@ -732,6 +1006,16 @@ int dflo_hip_multi_create(const dflo_mesh_t *mesh, const dflo_params_t *params, 
     if (r != ncclSuccess) { m->err = std::string("ncclCommInitRank (loopback): ") + g_rccl.GetErrorString(r); return bail(DFLO_ERR_COMM); }
   }
   finish_setup(m);
+  {  // one host thread per part (DFLO_MULTI_THREADS=0: the calling thread drives them all)
+    const char *e = std::getenv("DFLO_MULTI_THREADS");
+    if (n_devices > 1 && !(e && e[0] == '0')) {
+      for (int i = 0; i < n_devices; ++i) {
+        m->workers.emplace_back(new Worker);
+        Worker *w = m->workers.back().get();
+        w->th = std::thread(worker_main, w);
+      }
+    }
+  }
   *out = m;
   return DFLO_OK;
 }
@@ -763,9 +1047,17 @@ static int create_rank_impl(const dflo_mesh_t *mesh, const dflo_params_t *params
   int rc = create_common(mesh, params, m);
   if (rc) return bail(rc);
   m->parts.resize(1);
+  m->sync.reset(new Sync[1]);
   m->parts[0].index = rank;
   m->parts[0].device = device_id;
+  m->parts[0].sy = &m->sync[0];
   if ((rc = setup_part(m, m->parts[0], mesh, params, partitioner))) return bail(rc);
+  {  // peers are mutual here too: what this rank sends to q, q expects, and the other way round -- both follow from one
+     // deterministic partition of the same mesh on every rank; this rank can check its own half
+    Part &p = m->parts[0];
+    for (int q : p.peers)
+      if ((p.send_off[q + 1] > p.send_off[q]) != (p.recv_off[q + 1] > p.recv_off[q])) { m->err = "partition: rank " + std::to_string(rank) + " and rank " + std::to_string(q) + " are not mutual neighbours"; return bail(DFLO_ERR_COMM); }
+  }
   if (n_ranks > 1) {
     if (hipSetDevice(device_id) != hipSuccess) { m->err = "hipSetDevice failed"; return bail(DFLO_ERR_HIP); }
     if (!xf) {
@@ -815,7 +1107,7 @@ int dflo_hip_multi_part_cells(dflo_hip_multi_handle m, int i, int32_t *n_owned, 
 
 int dflo_hip_multi_set_solution(dflo_hip_multi_handle m, const double *u) {
   if (!m || !u) return DFLO_ERR_BAD_PARAM;
-  int rc = join_all(m);
+  int rc = sync_all(m);
   if (rc) return rc;
   std::vector<double> loc;
   for (Part &p : m->parts) {
@@ -824,7 +1116,14 @@ int dflo_hip_multi_set_solution(dflo_hip_multi_handle m, const double *u) {
       std::memcpy(&loc[(size_t)c * m->ndof], &u[(size_t)p.sub->cell_global_id[c] * m->ndof], m->ndof * sizeof(double));
     MENG(m, p, dflo_hip_set_solution(p.eng, loc.data()));
   }
-  m->xparity = 1;   // the engines read their trace table 0 now: the first exchange fills table 1
+  // the engines read their trace table 0 now: the first exchange fills table 1.  Nothing is in flight (every stream has been
+  // drained): the exchange counters start again.
+  m->nx = 0;
+  for (Part &p : m->parts) {
+    for (int k = 0; k < 3; ++k) p.n_post[k] = p.n_arr[k] = 0;
+    p.sy->reset();
+    p.sy->fin.store(p.n_fin);
+  }
   return DFLO_OK;
 }
 
@@ -834,10 +1133,14 @@ const dflo_mesh_t *dflo_hip_multi_part_mesh(dflo_hip_multi_handle m, int i) {
 
 int dflo_hip_multi_set_part_solution(dflo_hip_multi_handle m, int i, const double *u_part) {
   if (!m || !u_part || i < 0 || i >= (int)m->parts.size()) return DFLO_ERR_BAD_PARAM;
-  int rc = join_all(m);
+  int rc = sync_all(m);
   if (rc) return rc;
+  // The state of ONE part (owned and ghost cells) is replaced; the exchange count and with it the roles of the receive areas
+  // are those of the whole driver and stay.  The engine has filled both of its trace tables from the ghost cells' DoFs; it is
+  // pointed at the one the schedule reads now.  Ghost copies of this part's cells held by OTHER parts are not touched: a
+  // caller that changes the state sets every part before the next step (as bench.py's ranks do).
   MENG(m, m->parts[i], dflo_hip_set_solution(m->parts[i].eng, u_part));
-  m->xparity = 1;
+  MENG(m, m->parts[i], dflo_hip_use_ghost_traces(m->parts[i].eng, (int)(m->nx & 1)));
   return DFLO_OK;
 }
 
@@ -905,50 +1208,120 @@ int dflo_hip_multi_compute_dt(dflo_hip_multi_handle m, double elapsed_time, doub
   int rc = join_all(m);
   if (rc) return rc;
   double best = 1.0e300;
+  int lrc = DFLO_OK;
   for (Part &p : m->parts) {
     double d = 0.0;
-    MENG(m, p, dflo_hip_compute_dt(p.eng, elapsed_time, &d));
+    if ((lrc = dflo_hip_compute_dt(p.eng, elapsed_time, &d))) { set_err(m, std::string("part ") + std::to_string(p.index) + ": " + dflo_hip_last_error(p.eng)); break; }
     best = std::min(best, d);   // the rules (cap by time_step, clip to final_time) are monotone: they commute with the minimum
   }
-  if ((rc = host_allreduce(m, &best, 1, ncclMin))) return rc;
+  if (m->rank_mode && m->n_parts > 1) {   // a rank that failed still takes part in the reduction (a negative value tells the others)
+    if (lrc == DFLO_ERR_HIP || lrc == DFLO_ERR_COMM || lrc == DFLO_ERR_NOMEM) return agree(m, lrc);
+    if (lrc) best = -1.0;
+    if ((rc = host_allreduce(m, &best, 1, ncclMin))) return rc;
+    if (best < 0.0) {
+      if (!lrc) set_err(m, "the time step could not be formed on another rank");
+      return lrc ? lrc : DFLO_ERR_COMM;
+    }
+  } else if (lrc) {
+    return lrc;
+  }
   *dt = best;
   return DFLO_OK;
 }
 
-int dflo_hip_multi_step(dflo_hip_multi_handle m, double dt, double *res_norm0, double *res_norm) {
-  if (!m) return DFLO_ERR_BAD_PARAM;
-  for (int rk = 0; rk < m->n_rk; ++rk) {
-    int rc = run_stage(m, rk, dt);
-    if (rc) return rc;
+// results of a step the driver reports: ||rhs|| of the first and of the last stage, summed over parts and ranks
+static int step_norms(dflo_hip_multi *m, double *res_norm0, double *res_norm) {
+  double tot[4] = {0, 0, 0, 0};
+  for (Part &p : m->parts) {
+    double r[4];
+    MHIP(m, hipSetDevice(p.device));
+    MHIP(m, hipMemcpy(r, p.res_ptr, sizeof(r), hipMemcpyDeviceToHost));
+    for (int i = 0; i < 3; ++i) tot[i] += r[i];
   }
-  for (Part &p : m->parts) MENG(m, p, dflo_hip_end_step(p.eng));
-  int rc = reduce_dt(m);
+  const int rc = host_allreduce(m, tot, 3, ncclSum);
   if (rc) return rc;
-  if ((rc = sync_all(m))) return rc;
-  if (res_norm0 || res_norm) {
-    double tot[4] = {0, 0, 0, 0};
-    for (Part &p : m->parts) {
-      double r[4];
-      MHIP(m, hipSetDevice(p.device));
-      MHIP(m, hipMemcpy(r, p.res_ptr, sizeof(r), hipMemcpyDeviceToHost));
-      for (int i = 0; i < 3; ++i) tot[i] += r[i];
-    }
-    if ((rc = host_allreduce(m, tot, 3, ncclSum))) return rc;
-    if (res_norm0) *res_norm0 = std::sqrt(tot[0]);
-    if (res_norm) *res_norm = std::sqrt(tot[m->n_rk - 1]);
-  }
-  return check_all(m, false);
+  if (res_norm0) *res_norm0 = std::sqrt(tot[0]);
+  if (res_norm) *res_norm = std::sqrt(tot[m->n_rk - 1]);
+  return DFLO_OK;
 }
 
-int dflo_hip_multi_advance(dflo_hip_multi_handle m, int n_steps, double *elapsed_time_inout) {
-  if (!m || n_steps < 0 || !elapsed_time_inout) return DFLO_ERR_BAD_PARAM;
-  double dt0 = 0.0;
-  int rc = dflo_hip_multi_compute_dt(m, *elapsed_time_inout, &dt0);   // host value for the first step only
-  if (rc) return rc;
-  // the host looks at the failure flags every kCheckEvery steps without draining the device (see dflo_hip_advance); with
-  // one process per GPU the ranks must leave the loop together, so there the flags are read at the end only
-  constexpr int kCheckEvery = 32;
+static int step_body(dflo_hip_multi *m, double dt, double *res_norm0, double *res_norm) {
+  int rc;
+  if (!m->workers.empty()) {   // every part's own thread issues its step
+    const bool peers = any_peers(m);
+    const int64_t n0 = m->nx, step = m->n_steps_fin;
+    rc = for_parts(m, [&](Part &p) { return part_step(m, p, dt, n0, step, peers); });
+    m->nx += (int64_t)exchanges_per_stage(m) * m->n_rk;
+    ++m->n_steps_fin;
+    if (rc) return rc;
+  } else {
+    for (int rk = 0; rk < m->n_rk; ++rk)
+      if ((rc = run_stage(m, rk, dt))) return rc;
+    for (Part &p : m->parts) MENG(m, p, dflo_hip_end_step(p.eng));
+    if ((rc = reduce_dt(m))) return rc;
+  }
+  if ((rc = sync_all(m))) return rc;
+  if (res_norm0 || res_norm) rc = step_norms(m, res_norm0, res_norm);
+  return rc;
+}
+
+int dflo_hip_multi_step(dflo_hip_multi_handle m, double dt, double *res_norm0, double *res_norm) {
+  if (!m) return DFLO_ERR_BAD_PARAM;
+  // rank mode: whatever this rank runs into, the ranks agree on the status before anyone returns (a rank that left early would
+  // leave the others waiting in their next collective)
+  const int rc = step_body(m, dt, res_norm0, res_norm);
+  return agree(m, rc ? rc : check_local(m, false));
+}
+
+// The host looks at the failure flags every kCheckEvery steps without draining the device (see dflo_hip_advance); with one
+// process per GPU the ranks must leave the loop together, so there the flags are read at the end only.
+constexpr int kCheckEvery = 32;
+
+// device-resident steps of one part on its own thread.  The threads leave the loop at the same step: one that finds a failure
+// flag at a chunk boundary names the boundary two chunks on (`stop_at`), which no thread has passed yet -- the host threads are
+// never more than a few stages apart (each waits for its neighbours' records of the same stage).
+static int part_advance(dflo_hip_multi *m, Part &p, int n_steps, double dt0, int64_t n0, int64_t step0, bool peers) {
+  MHIP(m, hipSetDevice(p.device));
+  const int64_t xs = (int64_t)exchanges_per_stage(m) * m->n_rk;
+  int chunk = 0, s = 0;
+  for (; s < n_steps; ++s) {
+    if (s > 0 && s % kCheckEvery == 0) {
+      if (s >= m->stop_at.load(std::memory_order_acquire)) break;
+      MHIP(m, hipEventRecord(p.ev_chunk[chunk & 1], p.M));
+      ++chunk;
+      if (chunk >= 2) {
+        MHIP(m, hipEventSynchronize(p.ev_chunk[chunk & 1]));
+        int64_t st = -1;
+        dflo_hip_failure_step(p.eng, &st);
+        if (st >= 0) {
+          int64_t want = (int64_t)s + 2 * kCheckEvery, cur = m->stop_at.load();
+          while (want < cur && !m->stop_at.compare_exchange_weak(cur, want)) {}
+        }
+      }
+    }
+    const int rc = part_step(m, p, s == 0 ? dt0 : -1.0, n0 + (int64_t)s * xs, step0 + s, peers);
+    if (rc) return rc;
+  }
+  p.steps_run = s;
+  return DFLO_OK;
+}
+
+static int advance_body(dflo_hip_multi *m, int n_steps, double dt0) {
+  int rc;
   Part &p0 = m->parts[0];
+  if (!m->workers.empty()) {
+    const bool peers = any_peers(m);
+    const int64_t n0 = m->nx, step0 = m->n_steps_fin;
+    m->stop_at.store(INT64_MAX);
+    rc = for_parts(m, [&](Part &p) { return part_advance(m, p, n_steps, dt0, n0, step0, peers); });
+    if (rc) return rc;
+    const int done = p0.steps_run;
+    for (Part &p : m->parts)
+      if (p.steps_run != done) { set_err(m, "multi-device advance: the parts' threads left the loop at different steps"); return DFLO_ERR_COMM; }
+    m->nx += (int64_t)exchanges_per_stage(m) * m->n_rk * done;
+    m->n_steps_fin += done;
+    return DFLO_OK;
+  }
   if (!m->rank_mode) {
     MHIP(m, hipSetDevice(p0.device));
     for (int i = 0; i < 2; ++i)
@@ -972,12 +1345,27 @@ int dflo_hip_multi_advance(dflo_hip_multi_handle m, int n_steps, double *elapsed
     for (Part &p : m->parts) MENG(m, p, dflo_hip_end_step(p.eng));
     if ((rc = reduce_dt(m))) return rc;
   }
-  if ((rc = sync_all(m))) return rc;
-  double tt[4];
-  MHIP(m, hipSetDevice(p0.device));
-  MHIP(m, hipMemcpy(tt, p0.dt_ptr, sizeof(tt), hipMemcpyDeviceToHost));
-  *elapsed_time_inout = tt[1];
-  return check_all(m, false);
+  return DFLO_OK;
+}
+
+int dflo_hip_multi_advance(dflo_hip_multi_handle m, int n_steps, double *elapsed_time_inout) {
+  if (!m || n_steps < 0 || !elapsed_time_inout) return DFLO_ERR_BAD_PARAM;
+  double dt0 = 0.0;
+  int rc = dflo_hip_multi_compute_dt(m, *elapsed_time_inout, &dt0);   // host value for the first step only
+  if (rc) return rc;   // (compute_dt ends in a collective of its own: the ranks fail or pass together)
+  rc = advance_body(m, n_steps, dt0);
+  if (!rc) rc = sync_all(m);
+  if (!rc) {
+    double tt[4];
+    Part &p0 = m->parts[0];
+    if (hipSetDevice(p0.device) != hipSuccess || hipMemcpy(tt, p0.dt_ptr, sizeof(tt), hipMemcpyDeviceToHost) != hipSuccess) {
+      set_err(m, "reading the clock back failed");
+      rc = DFLO_ERR_HIP;
+    } else {
+      *elapsed_time_inout = tt[1];
+    }
+  }
+  return agree(m, rc ? rc : check_local(m, false));
 }
 
 int dflo_hip_multi_apply_limiter(dflo_hip_multi_handle m) {
@@ -996,7 +1384,7 @@ int dflo_hip_multi_apply_positivity_limiter(dflo_hip_multi_handle m) {
   int worst = DFLO_OK;
   for (Part &p : m->parts) {
     const int r = dflo_hip_apply_positivity_limiter(p.eng);
-    if (r) { worst = r; m->err = dflo_hip_last_error(p.eng); }
+    if (r) { worst = r; set_err(m, dflo_hip_last_error(p.eng)); }
   }
   if ((rc = exchange_solution(m))) return rc;
   const int all = check_all(m, true);

@@ -310,7 +310,7 @@ struct FinalArgs {
   double *res_sq;  // [3] per stage
   double *dt_dev;  // [0] dt, [1] elapsed time, [2] raw min before rules
   double *partial; // [kFinBlocks][4] workgroup partials
-  int *counter;    // workgroups done
+  int *counter;    // [0] workgroups done, [1] time steps completed since set_solution
   int n_shards, n_stages, res_stride, do_dt, advance_time, global_rules;  // shard_res: [n_stages][res_stride]
   int fixed_dt;    // "time step type = global" with cfl <= 0: dt = time_step (src/claw.cc:455-460)
   double *publish; // multi-device: the raw minimum also goes here (a slot the peers read, alternating from step to step)
@@ -388,6 +388,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(const FinalArgs a) {
     if (a.advance_time) {  // elapsed_time += global_dt (src/claw.cc:1072) for the step just done
       tt += a.dt_host >= 0.0 ? a.dt_host : a.dt_dev[0];
       a.dt_dev[1] = tt;
+      a.counter[1] += 1;   // steps completed (what a failure flag raised in the next step reports)
     }
     a.dt_dev[2] = dt;
     if (a.publish) *a.publish = dt;

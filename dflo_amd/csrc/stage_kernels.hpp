@@ -734,7 +734,7 @@ __global__ __launch_bounds__(64 * N, (N == 4 && GEO == 0 && MODE == 0) ? DFLO_Q3
     }
     const double eps = 1.0e-13;
     const bool bad = smin(A[RHO], pressure(A)) < eps;   // "Fatal: Negative states" :26-38
-    if (bad && active && row == 0) raise_flag(a.flags, 0, a.step_index);
+    if (bad && active && row == 0) raise_flag(a.flags, 0, a.step_ctr);
     double *pm = red + 5 * N * 64;   // [3][N][64] minima of the rows: density, theta2 (speculative), theta2 (after theta1)
     // theta2 of this wave's points (:138-178) for the current unew / Us
     auto pressure_theta = [&](bool &fail) {
@@ -797,7 +797,7 @@ __global__ __launch_bounds__(64 * N, (N == 4 && GEO == 0 && MODE == 0) ? DFLO_Q3
       for (int b = 0; b < N; ++b) theta2 = smin(theta2, pm[(2 * N + b) * 64 + lane]);
     }
     if (bad) theta2 = 1.0;
-    else if (fail && active) raise_flag(a.flags, 1, a.step_index);
+    else if (fail && active) raise_flag(a.flags, 1, a.step_ctr);
     if (row == 0) {   // statistics: cells the limiter changes
       const unsigned long long mk = __ballot(active && (t1 || theta2 < 1.0));
       if (lane == 0 && mk) atomicAdd(a.pos_stats + 1, (unsigned long long)__popcll(mk));
