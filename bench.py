@@ -176,7 +176,7 @@ def run_parts(args, claw, mesh, ic, bc_fn, programs, nx, ny):
     mass0 = claw.cell_average.sum(axis=0)
     _settle_clocks()
     claw.advance(args.warmup)
-    claw.stage_timing(True)
+    claw.stage_timing(os.environ.get("DFLO_BENCH_NO_STAGE_TIMING") != "1")
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     claw.advance(args.steps)

@@ -1467,6 +1467,34 @@ int dflo_hip_pack_send_traces(dflo_hip_handle h, void *device_buffer) {
   return launch_face_traces(h, (double *)device_buffer, h->d_sendf_slot, h->d_sendf_face, h->n_send_faces);
 }
 
+int dflo_hip_pack_send_to(dflo_hip_handle h, int kind, int n_segments, const int32_t *first, void *const *dst) {
+  if (check_handle(h) || kind < 0 || kind > 2 || n_segments < 0 || n_segments > kMaxSegs || (n_segments > 0 && (!first || !dst))) return DFLO_ERR_BAD_PARAM;
+  hipSetDevice(h->device);
+  const int n = kind == 2 ? h->n_send_faces : h->n_send;
+  if (n == 0 || n_segments == 0) return DFLO_OK;
+  SendSegs seg{};
+  seg.n = n_segments;
+  for (int i = 0; i < n_segments; ++i) {
+    seg.first[i] = first[i];
+    seg.dst[i] = (double *)dst[i];
+  }
+  seg.first[n_segments] = first[n_segments];
+  if (first[0] != 0 || first[n_segments] != n) { h->err = "pack_send_to: the segments must cover the send list"; return DFLO_ERR_COMM; }
+  if (kind == 2) {
+    const long long tot = (long long)n * 4 * h->N;
+    auto fn = h->N == 1 ? face_trace_to_kernel<1> : (h->N == 2 ? face_trace_to_kernel<2> : (h->N == 3 ? face_trace_to_kernel<3> : face_trace_to_kernel<4>));
+    hipLaunchKernelGGL(fn, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, seg, (const double *)h->U[h->cur],
+                       (const int32_t *)h->d_sendf_slot, (const int32_t *)h->d_sendf_face, n);
+  } else {
+    const int w = kind == 0 ? h->ndof + 4 : 4;
+    const long long tot = (long long)n * w;
+    hipLaunchKernelGGL(pack_to_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, seg, (const double *)h->U[h->cur],
+                       (const double *)h->avg[h->avg_cur], (const int32_t *)h->d_send_slots, n, h->ndof, kind == 0 ? 1 : 0);
+  }
+  HIPCHK(h, hipGetLastError());
+  return DFLO_OK;
+}
+
 int dflo_hip_ghost_trace_buffer(dflo_hip_handle h, int which, void **ptr) {
   if (check_handle(h) || which < 0 || which > 1 || !ptr) return DFLO_ERR_BAD_PARAM;
   *ptr = h->Tg[which];

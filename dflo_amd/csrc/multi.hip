@@ -136,12 +136,12 @@ struct Part {
   const int32_t *send_cells = nullptr, *send_off = nullptr, *recv_off = nullptr;   // [P+1] offsets, owned by `sub`
   int n_owned = 0, n_cells = 0, n_send = 0, n_ghost = 0;
   std::vector<int> peers;      // parts this one exchanges cells with
-  hipStream_t M = nullptr, C = nullptr;
-  hipEvent_t ev_open = nullptr, ev_rim = nullptr, ev_rim_prev = nullptr, ev_ring = nullptr, ev_unpack = nullptr, ev_dt = nullptr;
+  int group = 0;               // the device group (streams, host thread) this part belongs to
+  hipStream_t M = nullptr, C = nullptr;   // the group's compute and comm stream
+  hipEvent_t ev_dt = nullptr;
   hipEvent_t ev_fin[2] = {nullptr, nullptr};                 // by the parity of the step
   hipEvent_t ev_sent[3][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};   // by kind of record and receive area
   hipEvent_t ev_used[3][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};   // strict mode: area consumed
-  hipEvent_t ev_chunk[2] = {nullptr, nullptr};               // threaded advance: this part's host stays two chunks of steps ahead at most
   Sync *sy = nullptr;
   int64_t n_post[3] = {0, 0, 0}, n_arr[3] = {0, 0, 0}, n_fin = 0;   // this part's own counts (what it has issued / expects of the peers)
   double *send_u = nullptr, *send_a = nullptr;
@@ -154,13 +154,27 @@ struct Part {
   void *tg[2] = {nullptr, nullptr};
   void *dt_slot[2] = {nullptr, nullptr};   // the engine's published CFL minima
   void *dt_ptr = nullptr, *res_ptr = nullptr;
-  bool unpack_pending = false;   // the comm stream has work the compute stream has not waited for
-  bool rim_pending = false;      // ... among it the rim of the previous stage
   int steps_run = 0;             // threaded advance: steps this part's thread issued
   std::vector<int32_t> bface_global;   // global boundary-face number of the engine's boundary faces
 };
 
-// one host thread per part (one-process mode with several parts)
+// A group = one compute stream, one comm stream and one host thread.  A part with a device of its own is a group of its own;
+// parts that share a device (a test arrangement, and what a caller with more parts than devices gets) form at most TWO groups
+// on it: the runtime maps streams onto four hardware queues per device, and with more stream pairs than that the small kernels
+// of one part's comm stream queue behind another part's interior launch (measured, four parts on one device, C2: a stream pair
+// each 67 000 MDoF/s, GPU_MAX_HW_QUEUES=8 worse still; one pair for all 147 000 -- the interior launches then run strictly one
+// after the other, every one with its own ramp and tail; two pairs: see DESIGN).  DFLO_MULTI_GROUP=part | device forces one group
+// per part / per device.
+struct Group {
+  int device = 0;
+  hipStream_t M = nullptr, C = nullptr;
+  std::vector<int> parts;      // indices into dflo_hip_multi::parts
+  // the order between the two streams, once per group and stage whatever the number of parts (what one stream has to wait for
+  // is the LAST launch of the other stream's phase; the launches before it are covered by stream order)
+  hipEvent_t ev_open = nullptr, ev_rim = nullptr, ev_rim_prev = nullptr, ev_ring = nullptr, ev_unpack = nullptr, ev_chunk[2] = {nullptr, nullptr};
+  bool unpack_pending = false;   // the comm stream has work the compute stream has not waited for
+  bool rim_pending = false;      // ... among it the rim of the previous stage
+};
 struct Worker {
   std::thread th;
   std::mutex mu;
@@ -175,7 +189,10 @@ struct Worker {
 struct dflo_hip_multi {
   std::vector<Part> parts;     // the parts this process owns
   std::unique_ptr<Sync[]> sync;
-  std::vector<std::unique_ptr<Worker>> workers;   // empty: the calling thread drives every part
+  std::vector<Group> groups;
+  std::vector<std::unique_ptr<Worker>> workers;   // one per group; empty: the calling thread drives every part
+  bool direct = true;          // one process: the pack kernels write into the peers' receive areas (DFLO_MULTI_COPY=1: staging buffer + hipMemcpyPeerAsync)
+  bool need_avg = true;        // somebody reads the ghost cells' averages (LxF flux, TVB limiter): they travel with the traces
   std::atomic<bool> abort{false};                 // a part's thread has failed: the others stop waiting for it
   std::atomic<int64_t> stop_at{INT64_MAX};        // threaded advance: the step at which every thread leaves the loop
   bool strict = false;         // DFLO_MULTI_STRICT=1: a sender waits for an explicit "consumed" event of the receive area
@@ -201,6 +218,8 @@ struct dflo_hip_multi {
   hipEvent_t ev_chunk[2] = {nullptr, nullptr};
   std::mutex err_mu;
   std::string err;
+  double t_phase[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // DFLO_MULTI_VERBOSE: host time spent issuing each phase (single-threaded driver)
+  bool verbose = false;
 };
 
 namespace {
@@ -257,14 +276,14 @@ int wait_count(dflo_hip_multi *m, const std::atomic<int64_t> &c, int64_t want) {
   }
 }
 
-// Run fn(part) for every local part: on the parts' own threads when there are any, else one after the other on the calling
-// thread.  Returns the first failure (the parts still run to their end: a thread that fails raises `abort`, which ends the
+// Run fn(group) for every group: on the groups' own threads when there are any, else one after the other on the calling
+// thread.  Returns the first failure (the groups still run to their end: a thread that fails raises `abort`, which ends the
 // others' waits).
 template <class F>
-int for_parts(dflo_hip_multi *m, F fn) {
+int for_groups(dflo_hip_multi *m, F fn) {
   if (m->workers.empty()) {
-    for (Part &p : m->parts) {
-      const int rc = fn(p);
+    for (Group &g : m->groups) {
+      const int rc = fn(g);
       if (rc) return rc;
     }
     return DFLO_OK;
@@ -272,10 +291,10 @@ int for_parts(dflo_hip_multi *m, F fn) {
   m->abort.store(false);
   for (size_t i = 0; i < m->workers.size(); ++i) {
     Worker &w = *m->workers[i];
-    Part *pp = &m->parts[i];
+    Group *gp = &m->groups[i];
     std::lock_guard<std::mutex> lk(w.mu);
-    w.job = [m, pp, &fn]() {
-      const int rc = fn(*pp);
+    w.job = [m, gp, &fn]() {
+      const int rc = fn(*gp);
       if (rc) m->abort.store(true, std::memory_order_release);
       return rc;
     };
@@ -340,10 +359,18 @@ ChanView chan(dflo_hip_multi *m, Part &p, int kind, int par) {
   return {p.send_off, p.recv_off, m->ndof + 4, p.recv_u[par]};
 }
 
-int post(dflo_hip_multi *m, Part &p, const double *send, int kind, int par) {
+// pack the records of this kind and send them off (the engine's launches go to the comm stream, set by the caller)
+int post(dflo_hip_multi *m, Part &p, int kind, int par) {
   if (p.peers.empty()) return DFLO_OK;
   const ChanView v = chan(m, p, kind, par);
   const size_t w = (size_t)v.width;
+  const bool direct = m->direct && !m->rank_mode && !m->loopback;
+  double *send = kind == CH_AVG ? p.send_a : (kind == CH_TRACES ? p.send_t : p.send_u);
+  if (!direct) {   // into the staging buffer first
+    if (kind == CH_AVG) MENG(m, p, dflo_hip_pack_send_avg(p.eng, send));
+    else if (kind == CH_TRACES) MENG(m, p, dflo_hip_pack_send_traces(p.eng, send));
+    else MENG(m, p, dflo_hip_pack_send_cells(p.eng, send));
+  }
   if (m->rank_mode && m->x_exchange) {
     std::vector<int> peers;
     std::vector<const void *> sp;
@@ -374,33 +401,48 @@ int post(dflo_hip_multi *m, Part &p, const double *send, int kind, int par) {
     MNCCL(m, g_rccl.GroupEnd());
     return DFLO_OK;
   }
-  // One process: this part writes into its peers' receive areas.  Why area `par` of peer q is free: q's consumers of the
-  // exchange two back (unpack kernel / rim kernel reading the trace table) precede q's own send of the last exchange on q's comm
-  // stream, this part's comm stream has waited for that send (arrive), and q lists this part as a peer exactly when this part
-  // lists q (checked at create).  DFLO_MULTI_STRICT=1 does not rely on that chain: the copy waits for q's "consumed" event.
+  // One process: this part writes into its peers' receive areas -- the pack kernel itself does (stores over xGMI peer access
+  // where the peer sits on another device), or a copy per peer out of the staging buffer.  Why area `par` of peer q is free:
+  // q's consumers of the exchange two back (unpack kernel / rim kernel reading the trace table) precede q's own send of the last
+  // exchange on q's comm stream, this part's comm stream has waited for that send (arrive), and q lists this part as a peer
+  // exactly when this part lists q (checked at create).  DFLO_MULTI_STRICT=1 does not rely on that chain: the writes wait for
+  // q's "consumed" event.
   const int64_t seq = ++p.n_post[kind];
+  int32_t first[17];
+  void *dst[16];
+  int nseg = 0;
   for (int q : p.peers) {
-    Part *dst = local_part(m, q);
-    const ChanView dv = chan(m, *dst, kind, par);
+    Part *dp = local_part(m, q);
+    const ChanView dv = chan(m, *dp, kind, par);
     const size_t n = (size_t)(v.so[q + 1] - v.so[q]) * w;
     if (!n) continue;
     double *to = dv.recv + (size_t)dv.ro[p.index] * w;
     const double *from = send + (size_t)v.so[q] * w;
     if (m->strict && seq > 2) {
-      const int rc = wait_count(m, dst->sy->used[kind], seq - 2);
+      const int rc = wait_count(m, dp->sy->used[kind], seq - 2);
       if (rc) return rc;
-      MHIP(m, hipStreamWaitEvent(p.C, dst->ev_used[kind][par], 0));
+      if (dp->C != p.C) MHIP(m, hipStreamWaitEvent(p.C, dp->ev_used[kind][par], 0));
     }
-    if (m->loopback) {   // test transport: the same copy as a self send/recv pair through RCCL
+    if (direct) {
+      if (nseg == 16) { set_err(m, "more than 16 neighbouring parts"); return DFLO_ERR_UNSUPPORTED; }
+      first[nseg] = v.so[q];
+      dst[nseg++] = to;
+    } else if (m->loopback) {   // test transport: the same copy as a self send/recv pair through RCCL
       MNCCL(m, g_rccl.GroupStart());
       MNCCL(m, g_rccl.Send(from, n, ncclDouble, 0, m->comm, p.C));
       MNCCL(m, g_rccl.Recv(to, n, ncclDouble, 0, m->comm, p.C));
       MNCCL(m, g_rccl.GroupEnd());
     } else {
-      MHIP(m, hipMemcpyPeerAsync(to, dst->device, from, p.device, n * sizeof(double), p.C));
+      MHIP(m, hipMemcpyPeerAsync(to, dp->device, from, p.device, n * sizeof(double), p.C));
     }
   }
-  MHIP(m, hipEventRecord(p.ev_sent[kind][par], p.C));
+  if (direct && nseg) {
+    first[nseg] = v.so[m->n_parts];
+    MENG(m, p, dflo_hip_pack_send_to(p.eng, kind == CH_CELLS ? 0 : (kind == CH_AVG ? 1 : 2), nseg, first, dst));
+  }
+  bool foreign = false;   // a receiver on another stream (its own device's): it waits for this record
+  for (int q : p.peers) foreign |= local_part(m, q)->C != p.C;
+  if (foreign) MHIP(m, hipEventRecord(p.ev_sent[kind][par], p.C));
   p.sy->posted[kind].store(seq, std::memory_order_release);
   return DFLO_OK;
 }
@@ -415,6 +457,7 @@ int arrive(dflo_hip_multi *m, Part &p, int kind, int par) {
     if (sv.so[p.index + 1] == sv.so[p.index]) continue;
     const int rc = wait_count(m, src->sy->posted[kind], seq);   // the record below exists
     if (rc) return rc;
+    if (src->C == p.C) continue;   // the sender's launches are ahead of this point on the very same stream
     MHIP(m, hipStreamWaitEvent(p.C, src->ev_sent[kind][par], 0));
   }
   return DFLO_OK;
@@ -423,23 +466,21 @@ int arrive(dflo_hip_multi *m, Part &p, int kind, int par) {
 // strict mode: everything that reads receive area `par` of this kind has been issued on the comm stream
 int mark_used(dflo_hip_multi *m, Part &p, int kind, int par) {
   if (!m->strict || m->rank_mode || p.peers.empty() || p.n_arr[kind] == 0) return DFLO_OK;
-  MHIP(m, hipEventRecord(p.ev_used[kind][par], p.C));
+  bool foreign = false;
+  for (int q : p.peers) foreign |= local_part(m, q)->C != p.C;
+  if (foreign) MHIP(m, hipEventRecord(p.ev_used[kind][par], p.C));
   p.sy->used[kind].store(p.n_arr[kind], std::memory_order_release);
   return DFLO_OK;
 }
 
 // The new state of the cut cells leaves (engine launches go to the comm stream, set by the caller): whole cells, or face
-// traces (+ the averages unless they have travelled already, as they do when a TVB limiter sits between update and send)
+// traces (+ the averages, if anybody reads them, unless they have travelled already, as they do when a TVB limiter sits between
+// update and send)
 int send_state(dflo_hip_multi *m, Part &p, int upar, int apar, bool with_avg) {
-  if (!p.trace) {
-    MENG(m, p, dflo_hip_pack_send_cells(p.eng, p.send_u));
-    return post(m, p, p.send_u, CH_CELLS, upar);
-  }
-  MENG(m, p, dflo_hip_pack_send_traces(p.eng, p.send_t));
-  int rc = post(m, p, p.send_t, CH_TRACES, upar);
-  if (rc || !with_avg) return rc;
-  MENG(m, p, dflo_hip_pack_send_avg(p.eng, p.send_a));
-  return post(m, p, p.send_a, CH_AVG, apar);
+  if (!p.trace) return post(m, p, CH_CELLS, upar);
+  const int rc = post(m, p, CH_TRACES, upar);
+  if (rc || !with_avg || !m->need_avg) return rc;
+  return post(m, p, CH_AVG, apar);
 }
 // ... and the neighbours' arrives: into the ghost shards, or straight into the trace table the next stage will read
 int recv_state(dflo_hip_multi *m, Part &p, int upar, int apar, bool with_avg) {
@@ -452,7 +493,7 @@ int recv_state(dflo_hip_multi *m, Part &p, int upar, int apar, bool with_avg) {
   int rc = arrive(m, p, CH_TRACES, upar);
   if (rc) return rc;
   MENG(m, p, dflo_hip_use_ghost_traces(p.eng, upar));
-  if (!with_avg) return DFLO_OK;
+  if (!with_avg || !m->need_avg) return DFLO_OK;
   if ((rc = arrive(m, p, CH_AVG, apar))) return rc;
   MENG(m, p, dflo_hip_unpack_ghost_avg(p.eng, p.recv_a[apar]));
   return mark_used(m, p, CH_AVG, apar);
@@ -462,27 +503,29 @@ int recv_state(dflo_hip_multi *m, Part &p, int upar, int apar, bool with_avg) {
 // and sends ...
 int ex_send(dflo_hip_multi *m, Part &p, int64_t n) {
   if (p.peers.empty()) return DFLO_OK;
+  Group &g = m->groups[p.group];
   MHIP(m, hipSetDevice(p.device));
-  MHIP(m, hipEventRecord(p.ev_open, p.M));
-  MHIP(m, hipStreamWaitEvent(p.C, p.ev_open, 0));
-  MENG(m, p, dflo_hip_set_stream(p.eng, p.C));
+  MHIP(m, hipEventRecord(g.ev_open, g.M));
+  MHIP(m, hipStreamWaitEvent(g.C, g.ev_open, 0));
+  MENG(m, p, dflo_hip_set_stream(p.eng, g.C));
   // (a part that reads ghost cells by their traces: the table of the exchange before this one has been read by kernels on M
   //  that ev_open covers)
   int rc = mark_used(m, p, CH_TRACES, (int)(n & 1));
   if (!rc) rc = send_state(m, p, (int)((1 + n) & 1), (int)(n & 1), true);
-  MENG(m, p, dflo_hip_set_stream(p.eng, p.M));
+  MENG(m, p, dflo_hip_set_stream(p.eng, g.M));
   return rc;
 }
 // ... and takes in what its neighbours sent
 int ex_recv(dflo_hip_multi *m, Part &p, int64_t n) {
   if (p.peers.empty()) return DFLO_OK;
+  Group &g = m->groups[p.group];
   MHIP(m, hipSetDevice(p.device));
-  MENG(m, p, dflo_hip_set_stream(p.eng, p.C));
+  MENG(m, p, dflo_hip_set_stream(p.eng, g.C));
   int rc = recv_state(m, p, (int)((1 + n) & 1), (int)(n & 1), true);
-  MENG(m, p, dflo_hip_set_stream(p.eng, p.M));
+  MENG(m, p, dflo_hip_set_stream(p.eng, g.M));
   if (rc) return rc;
-  MHIP(m, hipEventRecord(p.ev_unpack, p.C));
-  MHIP(m, hipStreamWaitEvent(p.M, p.ev_unpack, 0));
+  MHIP(m, hipEventRecord(g.ev_unpack, g.C));
+  MHIP(m, hipStreamWaitEvent(g.M, g.ev_unpack, 0));
   return DFLO_OK;
 }
 int exchange_solution(dflo_hip_multi *m) {   // calling thread, all parts
@@ -498,83 +541,86 @@ int exchange_solution(dflo_hip_multi *m) {   // calling thread, all parts
   return DFLO_OK;
 }
 
-// One RK stage of one part, in phases.  The rim shards run on the comm stream C (high priority), the interior shards on the
-// compute stream M, side by side: both read the previous stage, they write disjoint shards.
+// One RK stage of a group's parts, in phases.  The rim shards run on the comm stream C (high priority), the interior shards on
+// the compute stream M, side by side: both read the previous stage, they write disjoint shards.
 //   C: [wait: interior of the previous stage / the new time step]  update rim  (TVB: rim + ring; exchange the averages of the
 //      rim cells; limit the rim)  -> ev_rim;  pack; send / receive; unpack into the ghost shards
 //   M: [wait: ev_rim of the previous stage]  update interior  (TVB: all but rim + ring; wait for the ring; limit all but the
-//      rim)  -> ev_int;  last stage: wait ev_rim, reductions of the step
-// A part's own thread runs its phases one after the other; the single-threaded driver runs each phase for all parts before
-// the next one (so that every record a phase waits for has been issued).
+//      rim);  last stage: wait ev_rim, reductions of the step
+// A phase is issued for every part of the group before the next one: every record a phase waits for has then been issued by an
+// earlier phase (parts of this group) or is being issued by another group's thread (wait_count), and the two streams are
+// ordered by one event per phase and group instead of one per part.
 struct StageCtx {
   int rk;
   double dt;
   int64_t n;   // number of this exchange of the state
   bool last;
 };
-constexpr int kStagePhases = 5;
+constexpr int kStagePhases = 6;
 
-int stage_phase(dflo_hip_multi *m, Part &p, const StageCtx &s, int ph) {
+int stage_phase(dflo_hip_multi *m, Group &g, const StageCtx &s, int ph) {
   const int upar = (int)((1 + s.n) & 1), apar = (int)(s.n & 1);
   const int rim_update = m->tvb ? 3 : 1, int_update = m->tvb ? 4 : 2;
-  MHIP(m, hipSetDevice(p.device));
+  MHIP(m, hipSetDevice(g.device));
   switch (ph) {
-    case 0: {   // open the stage (buffer roles; rk = 0: boundary programs on M), then the rim on C and what leaves first
-      MENG(m, p, dflo_hip_stage_open(p.eng, s.rk, s.dt));
-      MHIP(m, hipEventRecord(p.ev_open, p.M));       // interior of the previous stage, the step's time step, boundary data
-      MHIP(m, hipStreamWaitEvent(p.C, p.ev_open, 0));
-      MENG(m, p, dflo_hip_set_stream(p.eng, p.C));
-      MENG(m, p, dflo_hip_stage_update_part(p.eng, rim_update));
-      int rc = mark_used(m, p, CH_TRACES, apar);     // the rim kernel has read the trace table of the exchange before (area apar = upar ^ 1)
-      if (rc) return rc;
-      if (m->tvb) {
-        MHIP(m, hipEventRecord(p.ev_ring, p.C));
-        MENG(m, p, dflo_hip_pack_send_avg(p.eng, p.send_a));
-      } else {
-        if (m->sep_limiter) MENG(m, p, dflo_hip_stage_limit_part(p.eng, 1));
-        MHIP(m, hipEventRecord(p.ev_rim, p.C));
-      }
-      rc = m->tvb ? post(m, p, p.send_a, CH_AVG, apar) : send_state(m, p, upar, apar, true);
-      MENG(m, p, dflo_hip_set_stream(p.eng, p.M));
-      return rc;
-    }
-    case 1:     // the interior on M, next to it
-      if (p.rim_pending) MHIP(m, hipStreamWaitEvent(p.M, p.ev_rim_prev, 0));   // the rim cells of the previous stage (halo of the interior)
-      MENG(m, p, dflo_hip_stage_update_part(p.eng, int_update));
+    case 0:   // open the stage (buffer roles; rk = 0: boundary programs on M); then C may start once M is here
+      for (int i : g.parts) MENG(m, m->parts[i], dflo_hip_stage_open(m->parts[i].eng, s.rk, s.dt));
+      MHIP(m, hipEventRecord(g.ev_open, g.M));       // interior of the previous stage, the step's time step, boundary data
+      MHIP(m, hipStreamWaitEvent(g.C, g.ev_open, 0));
       return DFLO_OK;
-    case 2: {   // TVB: the averages of the neighbours across the cut arrive: limit the rim, send its cells
+    case 1:   // the rim on C and what leaves first
+      for (int i : g.parts) {
+        Part &p = m->parts[i];
+        MENG(m, p, dflo_hip_set_stream(p.eng, g.C));
+        MENG(m, p, dflo_hip_stage_update_part(p.eng, rim_update));
+        int rc = mark_used(m, p, CH_TRACES, apar);     // the rim kernel has read the trace table of the exchange before (area apar = upar ^ 1)
+        if (rc) return rc;
+        if (!m->tvb && m->sep_limiter) MENG(m, p, dflo_hip_stage_limit_part(p.eng, 1));
+        rc = m->tvb ? post(m, p, CH_AVG, apar) : send_state(m, p, upar, apar, true);
+        MENG(m, p, dflo_hip_set_stream(p.eng, g.M));
+        if (rc) return rc;
+      }
+      MHIP(m, hipEventRecord(m->tvb ? g.ev_ring : g.ev_rim, g.C));
+      return DFLO_OK;
+    case 2:   // the interior on M, next to it
+      if (g.rim_pending) MHIP(m, hipStreamWaitEvent(g.M, g.ev_rim_prev, 0));   // the rim cells of the previous stage (halo of the interior)
+      for (int i : g.parts) MENG(m, m->parts[i], dflo_hip_stage_update_part(m->parts[i].eng, int_update));
+      return DFLO_OK;
+    case 3:   // TVB: the averages of the neighbours across the cut arrive: limit the rim, send its cells
       if (!m->tvb) return DFLO_OK;
-      int rc = arrive(m, p, CH_AVG, apar);
-      if (rc) return rc;
-      MENG(m, p, dflo_hip_set_stream(p.eng, p.C));
-      MENG(m, p, dflo_hip_unpack_ghost_avg(p.eng, p.recv_a[apar]));
-      if ((rc = mark_used(m, p, CH_AVG, apar))) return rc;
-      MENG(m, p, dflo_hip_stage_limit_part(p.eng, 1));
-      MHIP(m, hipEventRecord(p.ev_rim, p.C));
-      rc = send_state(m, p, upar, apar, false);   // the averages have travelled already
-      MENG(m, p, dflo_hip_set_stream(p.eng, p.M));
-      return rc;
-    }
-    case 3:     // limiter of the other shards (TVB: it reads averages from the ring), the stage's reductions
-      if (m->tvb) {
-        MHIP(m, hipStreamWaitEvent(p.M, p.ev_ring, 0));
-        MENG(m, p, dflo_hip_stage_limit_part(p.eng, 2));
-      } else if (m->sep_limiter) {
-        MENG(m, p, dflo_hip_stage_limit_part(p.eng, 2));
+      for (int i : g.parts) {
+        Part &p = m->parts[i];
+        int rc = arrive(m, p, CH_AVG, apar);
+        if (rc) return rc;
+        MENG(m, p, dflo_hip_set_stream(p.eng, g.C));
+        MENG(m, p, dflo_hip_unpack_ghost_avg(p.eng, p.recv_a[apar]));
+        if ((rc = mark_used(m, p, CH_AVG, apar))) return rc;
+        MENG(m, p, dflo_hip_stage_limit_part(p.eng, 1));
+        rc = send_state(m, p, upar, apar, false);   // the averages have travelled already
+        MENG(m, p, dflo_hip_set_stream(p.eng, g.M));
+        if (rc) return rc;
       }
-      if (s.last) MHIP(m, hipStreamWaitEvent(p.M, p.ev_rim, 0));   // the step's reductions take in the rim shards' partials
-      MENG(m, p, dflo_hip_stage_finish(p.eng));
-      std::swap(p.ev_rim, p.ev_rim_prev);      // the next stage's interior waits for this stage's rim
-      p.rim_pending = !s.last;                 // (after the last stage M has waited already)
+      MHIP(m, hipEventRecord(g.ev_rim, g.C));
       return DFLO_OK;
-    default: {  // the neighbours' cells arrive: into the ghost shards, ready for the next stage's rim (same stream)
-      MENG(m, p, dflo_hip_set_stream(p.eng, p.C));
-      const int rc = recv_state(m, p, upar, apar, !m->tvb);
-      MENG(m, p, dflo_hip_set_stream(p.eng, p.M));
-      if (rc) return rc;
-      p.unpack_pending = true;
+    case 4:   // limiter of the other shards (TVB: it reads averages from the ring), the stage's reductions
+      if (m->tvb) MHIP(m, hipStreamWaitEvent(g.M, g.ev_ring, 0));
+      if (m->tvb || m->sep_limiter)
+        for (int i : g.parts) MENG(m, m->parts[i], dflo_hip_stage_limit_part(m->parts[i].eng, 2));
+      if (s.last) MHIP(m, hipStreamWaitEvent(g.M, g.ev_rim, 0));   // the step's reductions take in the rim shards' partials
+      for (int i : g.parts) MENG(m, m->parts[i], dflo_hip_stage_finish(m->parts[i].eng));
+      std::swap(g.ev_rim, g.ev_rim_prev);      // the next stage's interior waits for this stage's rim
+      g.rim_pending = !s.last;                 // (after the last stage M has waited already)
       return DFLO_OK;
-    }
+    default:  // the neighbours' cells arrive: into the ghost shards, ready for the next stage's rim (same stream)
+      for (int i : g.parts) {
+        Part &p = m->parts[i];
+        MENG(m, p, dflo_hip_set_stream(p.eng, g.C));
+        const int rc = recv_state(m, p, upar, apar, !m->tvb);
+        MENG(m, p, dflo_hip_set_stream(p.eng, g.M));
+        if (rc) return rc;
+      }
+      g.unpack_pending = true;
+      return DFLO_OK;
   }
 }
 
@@ -582,16 +628,22 @@ int stage_phase(dflo_hip_multi *m, Part &p, const StageCtx &s, int ph) {
 // limiter as well (update_ghost_values before compute_shock_indicator in the MPI variant); no overlap on this path.
 // Two exchanges per stage (numbers n and n + 1).
 constexpr int kKxrcfPhases = 6;
-int kxrcf_phase(dflo_hip_multi *m, Part &p, const StageCtx &s, int ph) {
-  MHIP(m, hipSetDevice(p.device));
-  switch (ph) {
-    case 0: MENG(m, p, dflo_hip_stage_update(p.eng, s.rk, s.dt)); return DFLO_OK;
-    case 1: return ex_send(m, p, s.n);
-    case 2: return ex_recv(m, p, s.n);
-    case 3: MENG(m, p, dflo_hip_stage_limit(p.eng)); return DFLO_OK;
-    case 4: return ex_send(m, p, s.n + 1);
-    default: return ex_recv(m, p, s.n + 1);
+int kxrcf_phase(dflo_hip_multi *m, Group &g, const StageCtx &s, int ph) {
+  MHIP(m, hipSetDevice(g.device));
+  for (int i : g.parts) {
+    Part &p = m->parts[i];
+    int rc = DFLO_OK;
+    switch (ph) {
+      case 0: MENG(m, p, dflo_hip_stage_update(p.eng, s.rk, s.dt)); break;
+      case 1: rc = ex_send(m, p, s.n); break;
+      case 2: rc = ex_recv(m, p, s.n); break;
+      case 3: MENG(m, p, dflo_hip_stage_limit(p.eng)); break;
+      case 4: rc = ex_send(m, p, s.n + 1); break;
+      default: rc = ex_recv(m, p, s.n + 1); break;
+    }
+    if (rc) return rc;
   }
+  return DFLO_OK;
 }
 
 bool any_peers(dflo_hip_multi *m) {
@@ -601,33 +653,33 @@ bool any_peers(dflo_hip_multi *m) {
 }
 int exchanges_per_stage(dflo_hip_multi *m) { return any_peers(m) ? (m->kxrcf ? 2 : 1) : 0; }
 
-// one RK stage of one part, all phases (the part's own thread)
-int part_stage(dflo_hip_multi *m, Part &p, int rk, double dt, int64_t n, bool peers) {
-  if (!peers) { MENG(m, p, dflo_hip_stage(p.eng, rk, dt)); return DFLO_OK; }   // nothing to exchange: the plain stage
+// One RK stage of the listed groups, phase by phase (a group's thread with its own group, or the calling thread with all of
+// them).  n: number of the stage's (first) exchange of the state.
+int stage_groups(dflo_hip_multi *m, Group *gs, int ng, int rk, double dt, int64_t n, bool peers) {
+  if (!peers) {   // nothing to exchange: the plain stage
+    for (int k = 0; k < ng; ++k)
+      for (int i : gs[k].parts) MENG(m, m->parts[i], dflo_hip_stage(m->parts[i].eng, rk, dt));
+    return DFLO_OK;
+  }
   const StageCtx s{rk, dt, n, rk == m->n_rk - 1};
   const int nph = m->kxrcf ? kKxrcfPhases : kStagePhases;
   for (int ph = 0; ph < nph; ++ph) {
-    const int rc = m->kxrcf ? kxrcf_phase(m, p, s, ph) : stage_phase(m, p, s, ph);
-    if (rc) return rc;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int k = 0; k < ng; ++k) {
+      const int rc = m->kxrcf ? kxrcf_phase(m, gs[k], s, ph) : stage_phase(m, gs[k], s, ph);
+      if (rc) return rc;
+    }
+    if (m->verbose && m->workers.empty()) m->t_phase[ph] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   }
   return DFLO_OK;
 }
 
 // one RK stage on every part of this process, driven by the calling thread
 int run_stage(dflo_hip_multi *m, int rk, double dt) {
-  if (!any_peers(m)) {
-    for (Part &p : m->parts) MENG(m, p, dflo_hip_stage(p.eng, rk, dt));
-    return DFLO_OK;
-  }
-  const StageCtx s{rk, dt, m->nx, rk == m->n_rk - 1};
-  m->nx += m->kxrcf ? 2 : 1;
-  const int nph = m->kxrcf ? kKxrcfPhases : kStagePhases;
-  for (int ph = 0; ph < nph; ++ph)
-    for (Part &p : m->parts) {
-      const int rc = m->kxrcf ? kxrcf_phase(m, p, s, ph) : stage_phase(m, p, s, ph);
-      if (rc) return rc;
-    }
-  return DFLO_OK;
+  const bool peers = any_peers(m);
+  const int64_t n = m->nx;
+  m->nx += exchanges_per_stage(m);
+  return stage_groups(m, m->groups.data(), (int)m->groups.size(), rk, dt, n, peers);
 }
 
 // Utilities::MPI::min(global_dt) (src_mpi/claw.cc:579) on the device-resident time step, after the last stage of step number
@@ -654,7 +706,9 @@ int reduce_dt_phase(dflo_hip_multi *m, Part &p, int64_t step, int ph) {
   const int par = (int)(step & 1);
   MHIP(m, hipSetDevice(p.device));
   if (ph == 0) {
-    MHIP(m, hipEventRecord(p.ev_fin[par], p.M));
+    bool foreign = false;
+    for (Part &q : m->parts) foreign |= q.M != p.M;
+    if (foreign) MHIP(m, hipEventRecord(p.ev_fin[par], p.M));
     p.sy->fin.store(++p.n_fin, std::memory_order_release);
     return DFLO_OK;
   }
@@ -664,7 +718,7 @@ int reduce_dt_phase(dflo_hip_multi *m, Part &p, int64_t step, int ph) {
     if (&q == &p) continue;
     const int rc = wait_count(m, q.sy->fin, p.n_fin);
     if (rc) return rc;
-    MHIP(m, hipStreamWaitEvent(p.M, q.ev_fin[par], 0));
+    if (q.M != p.M) MHIP(m, hipStreamWaitEvent(p.M, q.ev_fin[par], 0));   // (same stream: q's reductions are ahead of this point)
     slots[n++] = q.dt_slot[par];
   }
   MENG(m, p, dflo_hip_apply_dt_rules_peers(p.eng, n, slots));
@@ -682,32 +736,34 @@ int reduce_dt(dflo_hip_multi *m) {   // calling thread, all parts
   return DFLO_OK;
 }
 
-// one whole time step of one part (the part's own thread): stages, old_solution = current_solution, the time step of the next
-int part_step(dflo_hip_multi *m, Part &p, double dt, int64_t n0, int64_t step, bool peers) {
+// one whole time step of a group's parts (the group's own thread): stages, old_solution = current_solution, the time step
+// of the next
+int group_step(dflo_hip_multi *m, Group &g, double dt, int64_t n0, int64_t step, bool peers) {
   const int xs = m->kxrcf ? 2 : 1;
   for (int rk = 0; rk < m->n_rk; ++rk) {
-    const int rc = part_stage(m, p, rk, dt, n0 + (int64_t)rk * xs, peers);
+    const int rc = stage_groups(m, &g, 1, rk, dt, n0 + (int64_t)rk * xs, peers);
     if (rc) return rc;
   }
-  MENG(m, p, dflo_hip_end_step(p.eng));
+  for (int i : g.parts) MENG(m, m->parts[i], dflo_hip_end_step(m->parts[i].eng));
   if (m->n_parts == 1) return DFLO_OK;
-  for (int ph = 0; ph < 2; ++ph) {
-    const int rc = reduce_dt_phase(m, p, step, ph);
-    if (rc) return rc;
-  }
+  for (int ph = 0; ph < 2; ++ph)
+    for (int i : g.parts) {
+      const int rc = reduce_dt_phase(m, m->parts[i], step, ph);
+      if (rc) return rc;
+    }
   return DFLO_OK;
 }
 
 // the compute stream catches up with the comm stream (before the state is read, or a call outside the overlapped stage)
 int join_all(dflo_hip_multi *m) {
-  for (Part &p : m->parts) {
-    MHIP(m, hipSetDevice(p.device));
-    if (p.unpack_pending) {
-      MHIP(m, hipEventRecord(p.ev_unpack, p.C));
-      MHIP(m, hipStreamWaitEvent(p.M, p.ev_unpack, 0));
-      p.unpack_pending = false;
+  for (Group &g : m->groups) {
+    MHIP(m, hipSetDevice(g.device));
+    if (g.unpack_pending) {
+      MHIP(m, hipEventRecord(g.ev_unpack, g.C));
+      MHIP(m, hipStreamWaitEvent(g.M, g.ev_unpack, 0));
+      g.unpack_pending = false;
     }
-    p.rim_pending = false;
+    g.rim_pending = false;
   }
   return DFLO_OK;
 }
@@ -715,10 +771,10 @@ int join_all(dflo_hip_multi *m) {
 int sync_all(dflo_hip_multi *m) {
   int rc = join_all(m);
   if (rc) return rc;
-  for (Part &p : m->parts) {
-    MHIP(m, hipSetDevice(p.device));
-    MHIP(m, hipStreamSynchronize(p.C));
-    MHIP(m, hipStreamSynchronize(p.M));
+  for (Group &g : m->groups) {
+    MHIP(m, hipSetDevice(g.device));
+    MHIP(m, hipStreamSynchronize(g.C));
+    MHIP(m, hipStreamSynchronize(g.M));
   }
   return DFLO_OK;
 }
@@ -780,6 +836,41 @@ int check_local(dflo_hip_multi *m, bool synchronise) {
 // ... and, in rank mode, of all ranks: every caller gets the same answer
 int check_all(dflo_hip_multi *m, bool synchronise) { return agree(m, check_local(m, synchronise)); }
 
+// the device groups of the local parts and their streams (parts[i].index / .device are set)
+int make_groups(dflo_hip_multi *m) {
+  const char *e = std::getenv("DFLO_MULTI_GROUP");
+  const int per_device = (e && std::strcmp(e, "part") == 0) ? 1 << 20 : ((e && std::strcmp(e, "device") == 0) ? 1 : 2);   // groups a device may have
+  for (size_t i = 0; i < m->parts.size(); ++i) {
+    Part &p = m->parts[i];
+    int gi = -1, on_dev = 0, fewest = 1 << 30;
+    for (size_t k = 0; k < m->groups.size(); ++k)
+      if (m->groups[k].device == p.device) ++on_dev;
+    if (on_dev >= per_device)   // the device has its groups: join the one with the fewest parts
+      for (size_t k = 0; k < m->groups.size(); ++k)
+        if (m->groups[k].device == p.device && (int)m->groups[k].parts.size() < fewest) { gi = (int)k; fewest = (int)m->groups[k].parts.size(); }
+    if (gi < 0) {
+      gi = (int)m->groups.size();
+      m->groups.emplace_back();
+      Group &g = m->groups.back();
+      g.device = p.device;
+      MHIP(m, hipSetDevice(g.device));
+      MHIP(m, hipStreamCreate(&g.M));
+      // the comm stream outranks the compute stream: its small kernels (rim shards, pack, unpack) go ahead of the queued
+      // workgroups of the interior launch
+      int lo = 0, hi = 0;
+      MHIP(m, hipDeviceGetStreamPriorityRange(&lo, &hi));
+      MHIP(m, hipStreamCreateWithPriority(&g.C, hipStreamDefault, hi));
+      hipEvent_t *evs[] = {&g.ev_open, &g.ev_rim, &g.ev_rim_prev, &g.ev_ring, &g.ev_unpack, &g.ev_chunk[0], &g.ev_chunk[1]};
+      for (hipEvent_t *ev : evs) MHIP(m, hipEventCreateWithFlags(ev, hipEventDisableTiming));
+    }
+    m->groups[gi].parts.push_back((int)i);
+    p.group = gi;
+    p.M = m->groups[gi].M;
+    p.C = m->groups[gi].C;
+  }
+  return DFLO_OK;
+}
+
 int setup_part(dflo_hip_multi *m, Part &p, const dflo_mesh_t *mesh, const dflo_params_t *prm, int method) {
   int rc = dflo_mesh_partition_ex(mesh, m->n_parts, p.index, method, &p.sub, &p.send_cells, &p.send_off, &p.recv_off);
   if (rc) { m->err = dflo_mesh_last_error(); return rc; }
@@ -792,15 +883,8 @@ int setup_part(dflo_hip_multi *m, Part &p, const dflo_mesh_t *mesh, const dflo_p
   rc = dflo_hip_create(p.sub, prm, p.device, &p.eng);
   if (rc) { m->err = dflo_hip_last_error(nullptr); return rc; }
   MHIP(m, hipSetDevice(p.device));
-  MHIP(m, hipStreamCreate(&p.M));
-  {  // the comm stream outranks the compute stream: its small kernels (rim shards, pack, unpack) go ahead of the queued
-     // workgroups of the interior launch
-    int lo = 0, hi = 0;
-    MHIP(m, hipDeviceGetStreamPriorityRange(&lo, &hi));
-    MHIP(m, hipStreamCreateWithPriority(&p.C, hipStreamDefault, hi));
-  }
-  MENG(m, p, dflo_hip_set_stream(p.eng, p.M));
-  hipEvent_t *evs[] = {&p.ev_open, &p.ev_rim, &p.ev_rim_prev, &p.ev_ring, &p.ev_unpack, &p.ev_dt, &p.ev_fin[0], &p.ev_fin[1], &p.ev_chunk[0], &p.ev_chunk[1]};
+  MENG(m, p, dflo_hip_set_stream(p.eng, p.M));   // (the streams are the group's, made by make_groups)
+  hipEvent_t *evs[] = {&p.ev_dt, &p.ev_fin[0], &p.ev_fin[1]};
   for (hipEvent_t *e : evs) MHIP(m, hipEventCreateWithFlags(e, hipEventDisableTiming));
   for (int k = 0; k < 3; ++k)
     for (int i = 0; i < 2; ++i) {
@@ -912,6 +996,10 @@ int create_common(const dflo_mesh_t *mesh, const dflo_params_t *prm, dflo_hip_mu
 
 void finish_setup(dflo_hip_multi *m) {
   m->n_rk = dflo_hip_n_rk(m->parts[0].eng);
+  // who reads the average of a ghost cell: the LxF flux (lambda from the cell averages, src/equation.h:357-359) and the TVB
+  // limiter's differences (src/limiter.cc:284-317); without either the 4-double average message is not sent at all
+  m->need_avg = m->prm.flux_type == DFLO_FLUX_LXF || m->tvb;
+  if (const char *e = std::getenv("DFLO_MULTI_AVG")) m->need_avg = m->need_avg || std::atoi(e) != 0;
   // is there a limiter pass of its own between update and pack?  (positivity alone on Qk is applied inside the stage kernel
   // unless DFLO_FUSE_POS=0 says otherwise)
   const char *e = std::getenv("DFLO_FUSE_POS");
@@ -928,10 +1016,10 @@ const char *dflo_hip_multi_last_error(dflo_hip_multi_handle m) { return m ? m->e
 int dflo_hip_multi_destroy(dflo_hip_multi_handle m) {
   if (!m) return DFLO_OK;
   stop_workers(m);
-  for (Part &p : m->parts) {
-    hipSetDevice(p.device);
-    if (p.C) hipStreamSynchronize(p.C);
-    if (p.M) hipStreamSynchronize(p.M);
+  for (Group &g : m->groups) {
+    hipSetDevice(g.device);
+    if (g.C) hipStreamSynchronize(g.C);
+    if (g.M) hipStreamSynchronize(g.M);
   }
   if (m->comm) g_rccl.CommDestroy(m->comm);
   for (Part &p : m->parts) {
@@ -939,16 +1027,21 @@ int dflo_hip_multi_destroy(dflo_hip_multi_handle m) {
     if (p.eng) dflo_hip_destroy(p.eng);
     hipFree(p.send_u); hipFree(p.send_a); hipFree(p.send_t);
     for (int i = 0; i < 2; ++i) { hipFree(p.recv_u[i]); hipFree(p.recv_a[i]); }
-    hipEvent_t evs[] = {p.ev_open, p.ev_rim, p.ev_rim_prev, p.ev_ring, p.ev_unpack, p.ev_dt, p.ev_fin[0], p.ev_fin[1], p.ev_chunk[0], p.ev_chunk[1]};
+    hipEvent_t evs[] = {p.ev_dt, p.ev_fin[0], p.ev_fin[1]};
     for (hipEvent_t e : evs) if (e) hipEventDestroy(e);
     for (int k = 0; k < 3; ++k)
       for (int i = 0; i < 2; ++i) {
         if (p.ev_sent[k][i]) hipEventDestroy(p.ev_sent[k][i]);
         if (p.ev_used[k][i]) hipEventDestroy(p.ev_used[k][i]);
       }
-    if (p.C) hipStreamDestroy(p.C);
-    if (p.M) hipStreamDestroy(p.M);
     if (p.sub) dflo_mesh_free(p.sub);
+  }
+  for (Group &g : m->groups) {
+    hipSetDevice(g.device);
+    hipEvent_t evs[] = {g.ev_open, g.ev_rim, g.ev_rim_prev, g.ev_ring, g.ev_unpack, g.ev_chunk[0], g.ev_chunk[1]};
+    for (hipEvent_t e : evs) if (e) hipEventDestroy(e);
+    if (g.C) hipStreamDestroy(g.C);
+    if (g.M) hipStreamDestroy(g.M);
   }
   if (m->scal) hipFree(m->scal);
   for (int i = 0; i < 2; ++i) if (m->ev_chunk[i]) hipEventDestroy(m->ev_chunk[i]);
@@ -974,6 +1067,8 @@ int dflo_hip_multi_create(const dflo_mesh_t *mesh, const dflo_params_t *params, 
     m->parts[i].device = device_ids[i];
     m->parts[i].sy = &m->sync[i];
   }
+  if (const char *e = std::getenv("DFLO_MULTI_COPY")) m->direct = std::atoi(e) == 0;
+  if ((rc = make_groups(m))) return bail(rc);
   for (int i = 0; i < n_devices; ++i)
     if ((rc = setup_part(m, m->parts[i], mesh, params, partitioner))) return bail(rc);
   // what one part sends is what the other expects, and peers are mutual (the receive areas' reuse rests on it, see post)
@@ -1006,10 +1101,11 @@ int dflo_hip_multi_create(const dflo_mesh_t *mesh, const dflo_params_t *params, 
     if (r != ncclSuccess) { m->err = std::string("ncclCommInitRank (loopback): ") + g_rccl.GetErrorString(r); return bail(DFLO_ERR_COMM); }
   }
   finish_setup(m);
-  {  // one host thread per part (DFLO_MULTI_THREADS=0: the calling thread drives them all)
+  {  // one host thread per device group (DFLO_MULTI_THREADS=0: the calling thread drives them all); RCCL group calls on one
+     // communicator must not come from several threads at once, so the loopback test transport stays on the calling thread
     const char *e = std::getenv("DFLO_MULTI_THREADS");
-    if (n_devices > 1 && !(e && e[0] == '0')) {
-      for (int i = 0; i < n_devices; ++i) {
+    if (m->groups.size() > 1 && !m->loopback && !(e && e[0] == '0')) {
+      for (size_t i = 0; i < m->groups.size(); ++i) {
         m->workers.emplace_back(new Worker);
         Worker *w = m->workers.back().get();
         w->th = std::thread(worker_main, w);
@@ -1051,6 +1147,7 @@ static int create_rank_impl(const dflo_mesh_t *mesh, const dflo_params_t *params
   m->parts[0].index = rank;
   m->parts[0].device = device_id;
   m->parts[0].sy = &m->sync[0];
+  if ((rc = make_groups(m))) return bail(rc);
   if ((rc = setup_part(m, m->parts[0], mesh, params, partitioner))) return bail(rc);
   {  // peers are mutual here too: what this rank sends to q, q expects, and the other way round -- both follow from one
      // deterministic partition of the same mesh on every rank; this rank can check its own half
@@ -1250,7 +1347,7 @@ static int step_body(dflo_hip_multi *m, double dt, double *res_norm0, double *re
   if (!m->workers.empty()) {   // every part's own thread issues its step
     const bool peers = any_peers(m);
     const int64_t n0 = m->nx, step = m->n_steps_fin;
-    rc = for_parts(m, [&](Part &p) { return part_step(m, p, dt, n0, step, peers); });
+    rc = for_groups(m, [&](Group &g) { return group_step(m, g, dt, n0, step, peers); });
     m->nx += (int64_t)exchanges_per_stage(m) * m->n_rk;
     ++m->n_steps_fin;
     if (rc) return rc;
@@ -1277,32 +1374,32 @@ int dflo_hip_multi_step(dflo_hip_multi_handle m, double dt, double *res_norm0, d
 // process per GPU the ranks must leave the loop together, so there the flags are read at the end only.
 constexpr int kCheckEvery = 32;
 
-// device-resident steps of one part on its own thread.  The threads leave the loop at the same step: one that finds a failure
-// flag at a chunk boundary names the boundary two chunks on (`stop_at`), which no thread has passed yet -- the host threads are
-// never more than a few stages apart (each waits for its neighbours' records of the same stage).
-static int part_advance(dflo_hip_multi *m, Part &p, int n_steps, double dt0, int64_t n0, int64_t step0, bool peers) {
-  MHIP(m, hipSetDevice(p.device));
+// device-resident steps of a group's parts on the group's thread.  The threads leave the loop at the same step: one that finds
+// a failure flag at a chunk boundary names the boundary two chunks on (`stop_at`), which no thread has passed yet -- the host
+// threads are never more than a few stages apart (each waits for its neighbours' records of the same stage).
+static int group_advance(dflo_hip_multi *m, Group &g, int n_steps, double dt0, int64_t n0, int64_t step0, bool peers) {
+  MHIP(m, hipSetDevice(g.device));
   const int64_t xs = (int64_t)exchanges_per_stage(m) * m->n_rk;
   int chunk = 0, s = 0;
   for (; s < n_steps; ++s) {
     if (s > 0 && s % kCheckEvery == 0) {
       if (s >= m->stop_at.load(std::memory_order_acquire)) break;
-      MHIP(m, hipEventRecord(p.ev_chunk[chunk & 1], p.M));
+      MHIP(m, hipEventRecord(g.ev_chunk[chunk & 1], g.M));
       ++chunk;
       if (chunk >= 2) {
-        MHIP(m, hipEventSynchronize(p.ev_chunk[chunk & 1]));
-        int64_t st = -1;
-        dflo_hip_failure_step(p.eng, &st);
-        if (st >= 0) {
+        MHIP(m, hipEventSynchronize(g.ev_chunk[chunk & 1]));
+        bool failed = false;
+        for (int i : g.parts) { int64_t st = -1; dflo_hip_failure_step(m->parts[i].eng, &st); failed |= st >= 0; }
+        if (failed) {
           int64_t want = (int64_t)s + 2 * kCheckEvery, cur = m->stop_at.load();
           while (want < cur && !m->stop_at.compare_exchange_weak(cur, want)) {}
         }
       }
     }
-    const int rc = part_step(m, p, s == 0 ? dt0 : -1.0, n0 + (int64_t)s * xs, step0 + s, peers);
+    const int rc = group_step(m, g, s == 0 ? dt0 : -1.0, n0 + (int64_t)s * xs, step0 + s, peers);
     if (rc) return rc;
   }
-  p.steps_run = s;
+  for (int i : g.parts) m->parts[i].steps_run = s;
   return DFLO_OK;
 }
 
@@ -1313,7 +1410,7 @@ static int advance_body(dflo_hip_multi *m, int n_steps, double dt0) {
     const bool peers = any_peers(m);
     const int64_t n0 = m->nx, step0 = m->n_steps_fin;
     m->stop_at.store(INT64_MAX);
-    rc = for_parts(m, [&](Part &p) { return part_advance(m, p, n_steps, dt0, n0, step0, peers); });
+    rc = for_groups(m, [&](Group &g) { return group_advance(m, g, n_steps, dt0, n0, step0, peers); });
     if (rc) return rc;
     const int done = p0.steps_run;
     for (Part &p : m->parts)
@@ -1353,8 +1450,19 @@ int dflo_hip_multi_advance(dflo_hip_multi_handle m, int n_steps, double *elapsed
   double dt0 = 0.0;
   int rc = dflo_hip_multi_compute_dt(m, *elapsed_time_inout, &dt0);   // host value for the first step only
   if (rc) return rc;   // (compute_dt ends in a collective of its own: the ranks fail or pass together)
+  m->verbose = std::getenv("DFLO_MULTI_VERBOSE") != nullptr;
+  for (double &t : m->t_phase) t = 0.0;
+  const auto t_issue0 = std::chrono::steady_clock::now();
   rc = advance_body(m, n_steps, dt0);
+  const auto t_issue1 = std::chrono::steady_clock::now();
   if (!rc) rc = sync_all(m);
+  if (std::getenv("DFLO_MULTI_VERBOSE")) {   // how far ahead of the devices the host runs
+    const auto t2 = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "dflo_hip_multi_advance: %d steps, host issued them in %.3f ms, devices done after %.3f ms\n", n_steps,
+                 std::chrono::duration<double, std::milli>(t_issue1 - t_issue0).count(), std::chrono::duration<double, std::milli>(t2 - t_issue0).count());
+    std::fprintf(stderr, "dflo_hip_multi_advance: host ms by phase: open %.2f rim %.2f interior %.2f tvb %.2f finish %.2f recv %.2f\n", m->t_phase[0], m->t_phase[1],
+                 m->t_phase[2], m->t_phase[3], m->t_phase[4], m->t_phase[5]);
+  }
   if (!rc) {
     double tt[4];
     Part &p0 = m->parts[0];

@@ -153,6 +153,7 @@ __global__ void debug_exp_kernel(const double *x, double *lib, double *fast, int
 }
 
 // ------------------------------------------------------------------ small kernels
+constexpr int kMaxSegs = 16;   // peers of one part (dflo_hip_pack_send_to)
 // quadrature weight of node j for the cell average: w_a w_b (squares) or w_a w_b det J / |K| (bilinear cells)
 __device__ __forceinline__ double avg_weight(const KBasis &kb, int N, int j, const double *vert, int n_slots, int slot,
                                              double inv_area) {
@@ -229,6 +230,38 @@ __global__ void face_trace_kernel(double *out, const double *U, const int32_t *s
   if (t >= (long long)n * 4 * N) return;
   const int k = (int)(t / (4 * N)), r = (int)(t - (long long)k * 4 * N);
   out[t] = cell_face_trace<N>(U, slots[k], faces[k], r / N, r % N);
+}
+// The same three packers delivering as they pack (one process, several engines): record k of the send list goes to the
+// receive area of the peer it is meant for, seg.dst[i] + (k - seg.first[i]) * width for the segment i that holds k -- a
+// plain store on this device, a store over xGMI peer access on another -- so that no copy per peer follows the kernel.
+struct SendSegs {
+  int n;
+  int first[kMaxSegs + 1];
+  double *dst[kMaxSegs];
+};
+__device__ __forceinline__ double *seg_dst(const SendSegs &s, int k, int width) {
+  int i = 0;
+  while (i + 1 < s.n && k >= s.first[i + 1]) ++i;
+  return s.dst[i] + (size_t)(k - s.first[i]) * width;
+}
+// kind 0: DoFs + average, width ndof + 4; kind 1: averages (U unused), width 4
+__global__ void pack_to_kernel(const SendSegs seg, const double *U, const double *avg, const int32_t *slots, int n, int ndof, int with_dofs) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int w = with_dofs ? ndof + 4 : 4;
+  if (t >= (long long)n * w) return;
+  const int k = (int)(t / w), d = (int)(t - (long long)k * w);
+  const int slot = slots[k];
+  const int nd = with_dofs ? ndof : 0;
+  const double v = d < nd ? U[((size_t)(slot >> 6) * ndof + d) * 64 + (slot & 63)]
+                          : avg[((size_t)(slot >> 6) * 4 + (d - nd)) * 64 + (slot & 63)];
+  seg_dst(seg, k, w)[d] = v;
+}
+template <int N>
+__global__ void face_trace_to_kernel(const SendSegs seg, const double *U, const int32_t *slots, const int32_t *faces, int n) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (long long)n * 4 * N) return;
+  const int k = (int)(t / (4 * N)), r = (int)(t - (long long)k * 4 * N);
+  seg_dst(seg, k, 4 * N)[r] = cell_face_trace<N>(U, slots[k], faces[k], r / N, r % N);
 }
 // ghost cells: staging buffer [g][ndof] -> ghost shards, and their cell averages
 // one thread per (ghost cell, component): its DoFs travel buffer -> ghost shard (the buffer is read with unit stride

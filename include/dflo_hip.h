@@ -287,6 +287,12 @@ int dflo_hip_set_send_faces(dflo_hip_handle h, int32_t n, const int32_t *cells, 
 int dflo_hip_pack_send_traces(dflo_hip_handle h, void *device_buffer);
 int dflo_hip_ghost_trace_buffer(dflo_hip_handle h, int which, void **device_ptr);
 int dflo_hip_use_ghost_traces(dflo_hip_handle h, int which);
+/* Pack and deliver in one kernel (several engines in one process): records [first[i], first[i+1]) of the send list are
+ * written at dst[i] -- the receive area of the i-th peer, on this device or on another one reached over xGMI peer access --
+ * instead of into a staging buffer that a copy per peer then moves.  kind: 0 whole cells ([ndof + 4] doubles per record,
+ * as pack_send_cells), 1 cell averages ([4], as pack_send_avg), 2 face traces ([4 (k+1)], as pack_send_traces; the send
+ * list is that of set_send_faces).  n_segments <= 16. */
+int dflo_hip_pack_send_to(dflo_hip_handle h, int kind, int n_segments, const int32_t *first, void *const *dst);
 /* device address of {dt, res_norm_sq} scalars for 8-byte all-reduces (src_mpi/claw.cc:579,777) */
 int dflo_hip_scalar_ptrs(dflo_hip_handle h, void **dt_ptr, void **res_ptr);
 /* dt_ptr[2] holds the raw CFL minimum of this device; after an external all-reduce(min) of that

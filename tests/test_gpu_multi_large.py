@@ -104,13 +104,20 @@ def _plan_has_interior(multi):
         assert 0 < rim < 0.25 * (n_owned / 64), (i, rim, n_owned // 64)
 
 
-MODES = {"threads": {}, "one_thread": {"DFLO_MULTI_THREADS": "0"}, "strict": {"DFLO_MULTI_STRICT": "1"},
-         "one_thread_strict": {"DFLO_MULTI_THREADS": "0", "DFLO_MULTI_STRICT": "1"}}
+# how the one-process driver is arranged: "shared" is what it does by itself when the parts share a device (one stream pair and
+# one host thread per DEVICE); "threads" gives every part its own stream pair and host thread -- what every part gets when each
+# has a device of its own -- so that the cross-thread sequencing runs here; "copy": staging buffer + hipMemcpyPeerAsync instead
+# of pack kernels that write into the peers' receive areas; "strict": senders wait for an explicit "consumed" event
+MODES = {"shared": {}, "threads": {"DFLO_MULTI_GROUP": "part"}, "one_thread": {"DFLO_MULTI_GROUP": "part", "DFLO_MULTI_THREADS": "0"},
+         "strict": {"DFLO_MULTI_GROUP": "part", "DFLO_MULTI_STRICT": "1"}, "shared_strict": {"DFLO_MULTI_STRICT": "1"},
+         "copy": {"DFLO_MULTI_GROUP": "part", "DFLO_MULTI_COPY": "1"},
+         "one_thread_strict": {"DFLO_MULTI_GROUP": "part", "DFLO_MULTI_THREADS": "0", "DFLO_MULTI_STRICT": "1"}}
 
 
-@pytest.mark.parametrize("n_parts,method,mode", [(2, "slab", "threads"), (3, "slab", "threads"), (4, "rcb", "threads"),
+@pytest.mark.parametrize("n_parts,method,mode", [(2, "slab", "shared"), (3, "slab", "shared"), (4, "rcb", "shared"),
+                                                 (2, "slab", "threads"), (3, "slab", "threads"), (4, "rcb", "threads"),
                                                  (2, "slab", "one_thread"), (4, "rcb", "one_thread"), (3, "slab", "strict"),
-                                                 (4, "rcb", "one_thread_strict")])
+                                                 (4, "rcb", "shared_strict"), (3, "slab", "copy"), (4, "rcb", "one_thread_strict")])
 def test_c2_512_parts_bit_identical_to_the_single_engine(n_parts, method, mode, monkeypatch):
     for k, v in MODES[mode].items():
         monkeypatch.setenv(k, v)
@@ -126,7 +133,7 @@ def test_c2_512_parts_bit_identical_to_the_single_engine(n_parts, method, mode, 
     assert np.array_equal(got["u"], ref["u"])
 
 
-@pytest.mark.parametrize("mode", ["threads", "one_thread", "strict"])
+@pytest.mark.parametrize("mode", ["shared", "threads", "one_thread", "strict", "copy"])
 def test_c4_slab_pair_matches_the_single_engine(mode, monkeypatch):
     for k, v in MODES[mode].items():
         monkeypatch.setenv(k, v)
@@ -195,7 +202,7 @@ def _worker(rank, world, port, name, ret):
 def test_ranks_on_large_meshes_match_the_single_engine(name, world):
     import random
     import torch.multiprocessing as mp
-    mgr = mp.Manager()
+    mgr = mp.get_context("spawn").Manager()   # (no fork of a process that holds a HIP runtime)
     ret = mgr.dict()
     mp.spawn(_worker, args=(world, 31000 + random.randint(0, 2000), name, ret), nprocs=world, join=True)
     assert ret["dt"] and ret["t"], dict(ret)

@@ -60,7 +60,7 @@ def _worker(rank, world, port, name, ret):
 @pytest.mark.parametrize("name,world", [("c2", 2), ("c2", 3), ("c1", 2), ("c4", 2), ("c4", 3), ("c5", 2), ("kxrcf", 2)])
 def test_ranks_on_one_device_match_the_single_engine(name, world):
     import random
-    mgr = mp.Manager()
+    mgr = mp.get_context("spawn").Manager()   # (no fork of a process that holds a HIP runtime)
     ret = mgr.dict()
     mp.spawn(_worker, args=(world, 29500 + random.randint(0, 2000), name, ret), nprocs=world, join=True)
     assert ret["dt"] and ret["t"], dict(ret)                 # all-reduced minima, host-driven and device-resident
