@@ -7,8 +7,10 @@
 Workload (config.workload): BASELINE config C2 -- isentropic vortex on [-5,5]^2, 1024x1024 Cartesian
 quads, Q2 (n_rk = 3), HLLC, periodic, cfl 0.9.  A "step" is one time step = all RK stages
 (residual, dt*M^-1, SSP combine, cell averages, CFL reduction).  With N GPUs every rank owns a
-1024x1024 slab of a (1024 N) x 1024 periodic mesh (weak scaling) and exchanges one layer of
-face-neighbour cells per stage over RCCL.  Every run -- one GPU or eight -- goes through the native multi-device
+1024x1024 slab of a (1024 N) x 1024 periodic mesh (weak scaling, the default) and exchanges the
+traces of its cut faces per stage over RCCL; `--scaling strong` keeps the mesh of the one-GPU run
+(c2: 1024 x 1024, c4: the whole 4001 x 1000 double Mach reflection, c3 / c5: their one-GPU meshes)
+and cuts it into N parts -- north_star's ">= 6x at 8 GPUs over 1 GPU on a 1024x1024 Q2 mesh".  Every run -- one GPU or eight -- goes through the native multi-device
 driver (dflo_hip_multi_*, dflo_amd/csrc/multi.hip); with one GPU it has no peers and issues the plain launches.
 value = n_dofs * n_rk * steps / wall_seconds / 1e6, inputs resident in HBM.
 """
@@ -113,9 +115,12 @@ def _cpu_model():
 
 def build_case(args, world):
     """(mesh, parameters, initial/boundary function, boundary programs, nx, ny) of the configuration; with N GPUs the mesh
-    is N times the one-GPU mesh (weak scaling) and is handed undivided to the multi-device driver."""
+    is N times the one-GPU mesh (weak scaling) or the same mesh (strong scaling) and is handed undivided to the multi-device
+    driver."""
     import dflo_amd
     from dflo_amd import problems
+    if args.scaling == "strong":
+        world = 8 if args.config == "c4" else 1     # c4: the full 4001 x 1000 mesh of BASELINE config 4 whatever the rank count
     prm = dflo_amd.Parameters(flux=args.flux, cfl=0.9)
     ic, bc_fn, programs = problems.isentropic_vortex, None, {}
     if args.config == "c2":
@@ -279,6 +284,8 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip the Q1 LxF line (north_star's 40 %-at-Q1 target)")
     ap.add_argument("--parts-per-gpu", type=int, default=1, help="developer switch: this many engines on the one GPU (one-process driver)")
     ap.add_argument("--no-tvb", action="store_true", help="c4 only: positivity limiter alone (BASELINE config 4 as written)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak (default): every GPU gets the one-GPU mesh; strong: the one-GPU mesh (c4: the full 4001x1000) is cut into N parts")
     ap.add_argument("--config", default="c2", choices=["c2", "c3", "c4", "c5"],
                     help="c2 (default, the headline): periodic vortex; c3: Sod tube 2048x256 Q1 Roe TVB+positivity; "
                          "c4: double Mach reflection, 500 N + 1 columns of 1000 squares, Q2 HLLC TVB+positivity; "
@@ -380,13 +387,15 @@ def main():
         out = {
             "metric": "million DoF-updates/s (explicit RK3, 2D Euler)", "value": value, "unit": "MDoF-updates/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": sec / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {
-                "workload": {"c2": "isentropic_vortex, %dx%d quads per GPU (global %dx%d), %s%d, %s, periodic, SSP-RK %d stages"
-                                   % (args.nx, args.nx, nx, ny, args.basis[0], args.degree, args.flux.upper(), n_rk),
+                "workload": {"c2": ("isentropic_vortex, %dx%d quads per GPU (global %dx%d), %s%d, %s, periodic, SSP-RK %d stages"
+                                    % (args.nx, args.nx, nx, ny, args.basis[0], args.degree, args.flux.upper(), n_rk)) if args.scaling == "weak" else
+                                   ("isentropic_vortex, %dx%d quads cut into %d x-slab(s) (strong scaling), %s%d, %s, periodic, SSP-RK %d stages"
+                                    % (nx, ny, world * args.parts_per_gpu, args.basis[0], args.degree, args.flux.upper(), n_rk)),
                              "c3": "sod_shock_tube, %dx256 quads, Q1, ROE, TVB(M=0,beta=2,char)+positivity, SSP-RK 2 stages" % nx,
-                             "c4": "double_mach_reflection, %dx1000 of the 4001x1000 squares (%d x-slab(s) of ~500 columns), Q2, HLLC, %spositivity, moving inflow on the device, SSP-RK 3 stages"
-                                   % (nx, world, "" if args.no_tvb else "TVB(M=100,beta=1,char)+"),
+                             "c4": "double_mach_reflection, %dx1000 of the 4001x1000 squares (%d x-slab(s) of ~%d columns), Q2, HLLC, %spositivity, moving inflow on the device, SSP-RK 3 stages"
+                                   % (nx, world * args.parts_per_gpu, nx // (world * args.parts_per_gpu), "" if args.no_tvb else "TVB(M=100,beta=1,char)+"),
                              "c5": "forward_step, %d unstructured quads (q1 mapping), Q3, KFVS, positivity limiter, cfl 0.02 (at the input's 0.5 the reference algorithm stops in the 6th step), SSP-RK 3 stages"
                                    % m["n_cells"]}[args.config],
                 "n_dofs": n_dofs_total, "n_rk": n_rk,

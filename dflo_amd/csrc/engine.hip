@@ -61,7 +61,7 @@ struct dflo_hip_engine {
   int face_pitch = 0, halo_pitch = 0, halo_stride = 0;
   uint16_t *d_cell_face = nullptr;
   int32_t *d_lrbt = nullptr, *d_user_of = nullptr, *d_iid = nullptr;
-  double *d_cell_h = nullptr, *d_cell_vert = nullptr, *d_fgeom_pad = nullptr, *d_dt_cell = nullptr;
+  double *d_cell_h = nullptr, *d_cell_vert = nullptr, *d_dt_cell = nullptr;
   double *shard_res = nullptr, *shard_dtmin = nullptr, *res_sq = nullptr, *dt_dev = nullptr, *fin_partial = nullptr;
   int *flags = nullptr;         // device view of flags_host (kernels_common.hpp: raise_flag)
   volatile int *flags_host = nullptr;   // [0] negative mean state, [1] positivity root failure, [2] 1 + step of the first
@@ -375,7 +375,6 @@ int launch_update(dflo_hip_engine *h, double *rhs_out, int part) {
   a.cell_face = h->d_cell_face;
   a.cell_h = h->d_cell_h;
   a.cell_vert = h->d_cell_vert;
-  a.fgeom_pad = h->d_fgeom_pad;
   a.n_slots = p.n_slots;
   a.bval = h->bval[h->st_which];
   a.bface_kind = h->bface_kind;
@@ -802,16 +801,6 @@ int dflo_hip_create(const dflo_mesh_t *mesh, const dflo_params_t *params, int de
       std::vector<double> z((size_t)p.n_slots, 0.0);
       if ((rc = upload(h, &h->d_shock, z))) return bail(rc);
     }
-    if (h->geo == 1) {  // face geometry at the same pitch, [shard][3][face_pitch]
-      std::vector<double> gpad((size_t)ns * 3 * h->face_pitch, 0.0);
-      for (int sidx = 0; sidx < p.n_shards; ++sidx) {
-        const int nf = p.face_begin[sidx + 1] - p.face_begin[sidx];
-        for (int k = 0; k < nf; ++k)
-          for (int j2 = 0; j2 < 3; ++j2)
-            gpad[((size_t)sidx * 3 + j2) * h->face_pitch + k] = p.face_geom[((size_t)p.face_begin[sidx] + k) * 3 + j2];
-      }
-      if ((rc = upload(h, &h->d_fgeom_pad, gpad))) return bail(rc);
-    }
   }
   if (h->trace_halo) {
     if ((rc = upload(h, &h->d_gt_slot, p.gt_cell)) || (rc = upload(h, &h->d_gt_face, p.gt_face))) return bail(rc);
@@ -889,7 +878,7 @@ int dflo_hip_create(const dflo_mesh_t *mesh, const dflo_params_t *params, int de
   {
     const int rows = 4 * h->N * h->N + (h->prm.flux_type == DFLO_FLUX_LXF ? 3 : 0);  // nodal image (also for Pk)
     h->lds_bytes = ((size_t)rows * 65 + (size_t)4 * h->N * h->halo_stride + (h->prm.flux_type == DFLO_FLUX_LXF ? 3 * (size_t)p.halo_cols : 0) +
-                    (size_t)p.max_bnd * 4 * h->N + (p.max_bnd + 2) / 2 + (h->geo == 1 ? 3 * (size_t)h->halo_stride : 0)) * sizeof(double);
+                    (size_t)p.max_bnd * 4 * h->N + (p.max_bnd + 2) / 2 + (h->geo == 1 ? 8 * 64 : 0)) * sizeof(double);
     if (const char *e = std::getenv("DFLO_LDS_PAD")) h->lds_bytes += (size_t)std::atoi(e);   // occupancy experiments: unused LDS per workgroup
   }
 
@@ -935,7 +924,7 @@ int dflo_hip_destroy(dflo_hip_handle h) {
   hipFree(h->d_shard_count);
   hipFree(h->d_bnd_pad); hipFree(h->d_nbr_code); hipFree(h->d_shock); hipFree(h->lim_mask); hipFree(h->d_faces_pad); hipFree(h->d_shard_hdr); hipFree(h->d_halo_pad); hipFree(h->d_cell_face); hipFree(h->d_lrbt); hipFree(h->d_user_of); hipFree(h->d_iid);
   hipFree(h->d_rim_list); hipFree(h->d_int_list); hipFree(h->d_rim2_list); hipFree(h->d_rest2_list);
-  hipFree(h->d_cell_h); hipFree(h->d_dt_cell); hipFree(h->d_cell_vert); hipFree(h->d_fgeom_pad); hipFree(h->shard_res); hipFree(h->shard_dtmin); hipFree(h->res_sq); hipFree(h->fin_partial); hipFree(h->dt_dev);
+  hipFree(h->d_cell_h); hipFree(h->d_dt_cell); hipFree(h->d_cell_vert); hipFree(h->shard_res); hipFree(h->shard_dtmin); hipFree(h->res_sq); hipFree(h->fin_partial); hipFree(h->dt_dev);
   if (h->flags_host) hipHostFree((void *)h->flags_host);
   hipFree(h->fin_counter); hipFree(h->dt_pub); hipFree(h->pos_stats);
   hipFree(h->Tg[0]); hipFree(h->Tg[1]); hipFree(h->d_gt_slot); hipFree(h->d_gt_face); hipFree(h->d_sendf_slot); hipFree(h->d_sendf_face); hipFree(h->d_send_slots); hipFree(h->ghost_stage);

@@ -60,7 +60,6 @@ struct StageArgs {
   const uint16_t *cell_face;
   const double *cell_h;
   const double *cell_vert;    // GEO 1: [8][n_slots]
-  const double *fgeom_pad;    // GEO 1: [n_shards][3][face_pitch] (nx, ny, length) of each face record
   int n_slots;
   const double *bval;
   const int32_t *bface_kind;

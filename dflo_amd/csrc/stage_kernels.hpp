@@ -208,13 +208,24 @@ __device__ __forceinline__ void row_update(const StageArgs &a, double *Us, const
   }
 }
 
+// Edge of local face f of a bilinear cell with the vertices v = (x0, y0, .., x3, y3) in deal.II's lexicographic order: t runs
+// along the increasing free coordinate; faces 1 (xi = 1) and 2 (eta = 0) have the cell on the left of t, faces 0 and 3 on the
+// right (counter-clockwise cells) -- the outward normal is (ty, -tx) / |t| on faces 1 and 2 and (-ty, tx) / |t| on 0 and 3
+// (plan.cc: the same edge, the same two vertices whichever of the two cells looks at it: |t|^2 = tx tx + ty ty comes out
+// bit-identical on both sides, t itself with the opposite sign).
+__device__ __forceinline__ void face_edge(const double (&v)[8], int f, double &tx, double &ty) {
+  const int a = f == 1 ? 1 : (f == 3 ? 2 : 0), b = f == 0 ? 2 : (f == 2 ? 1 : 3);
+  tx = v[2 * b] - v[2 * a];
+  ty = v[2 * b + 1] - v[2 * a + 1];
+}
+
 // phase C on bilinear (Q1-mapped) cells (the reference gets all of this from
 // FEValues with MappingQ1): J = [x_xi x_eta; y_xi y_eta] varies inside the cell,
 //   int F.grad(phi) = sum_q w_q [ d(phi)/d(xi) (y_eta F - x_eta G) + d(phi)/d(eta) (-y_xi F + x_xi G) ],
 // lumped mass M_j = w_j det J_j (src/claw.cc:223-227), face JxW = w_q |edge|.
 template <int N, int B, int MODE, int POS, int STREAM>
 __device__ __forceinline__ void row_update_q1(const StageArgs &a, double *Us, const int S, const double *Fh,
-                                              const double *Fg, double *red, int shard, int lane, bool active,
+                                              double *red, int shard, int lane, bool active,
                                               const double (&vx)[8], const uint16_t (&cref)[4],
                                               const double (&uold)[4][N], const double (&Wrow)[N][4], double (&unew)[4][N],
                                               const double dt) {
@@ -275,7 +286,9 @@ __device__ __forceinline__ void row_update_q1(const StageArgs &a, double *Us, co
       const int k = ref & 0x3FFF;
       const bool flip = (ref >> 14) & 1;
       const double sgn = (ref >> 15) ? 1.0 : -1.0;
-      const double len = Fg[2 * HS + k];
+      double etx, ety;   // face JxW = w_q |edge|, the edge from the cell's own vertices
+      face_edge(vx, f, etx, ety);
+      const double len = fsqrt(etx * etx + ety * ety);
       if (f < 2) {
         const int qq = flip ? N - 1 - B : B;
         const double jxw = sgn * CB<N>::t.w[B] * len;
@@ -387,7 +400,7 @@ __device__ __forceinline__ int face_of_point(int p, int nf) {
 template <int N, int FLUX, int GEO>
 __device__ __forceinline__ void flux_phase(const StageArgs &a, const double *Us, double *Th, const double *Av,
                                            const uint32_t (&frr)[3], const uint32_t *fp, const double *Bv, const int *Bk,
-                                           const double *Fg, const int HS, const int nf, const int nh, const int tid) {
+                                           const double *Vx, const int HS, const int nf, const int nh, const int tid) {
   constexpr int NS = N * N, NDOF = 4 * NS, NT = 64 * N, S = 65;
   const int nfp = nf * N;
   int it = 0;
@@ -439,8 +452,14 @@ __device__ __forceinline__ void flux_phase(const StageArgs &a, const double *Us,
       nx = fL == 0 ? -1.0 : (fL == 1 ? 1.0 : 0.0);
       ny = fL == 2 ? -1.0 : (fL == 3 ? 1.0 : 0.0);
     } else {
-      nx = Fg[col];
-      ny = Fg[HS + col];
+      // Vx[4 faces][2][64]: the outward normals of the own cells, formed in phase A from their vertices -- the integrating
+      // cell's own normal, or the other cell's with the sign turned (the same edge, the same two vertices: the same bits).  A
+      // per-face table of normals and lengths in memory, 4 % of the kernel's traffic and 3 HS doubles of LDS, is gone.
+      const bool ownL = slotL < 64;
+      const int sv = ownL ? slotL : pface_other_slot(r), fv = ownL ? fL : fR;
+      const double sx = Vx[(2 * fv) * 64 + sv], sy = Vx[(2 * fv + 1) * 64 + sv];
+      nx = ownL ? sx : -sx;
+      ny = ownL ? sy : -sy;
     }
     int qs = q;   // the point index the flux is filed under
     if (!bnd) {
@@ -499,7 +518,7 @@ __global__ __launch_bounds__(64 * N, (N == 4 && GEO == 0 && MODE == 0) ? DFLO_Q3
   double *Av = Th + TROWS * HS;                       // LxF: [3][halo_cols] (u, v, c) of the halo cells' averages
   double *Bv = Av + (FLUX == DFLO_FLUX_LXF ? 3 * a.halo_cols : 0);   // [max_bnd][N][4] boundary values of the shard
   int *Bk = (int *)(Bv + a.max_bnd * 4 * N);          // [max_bnd] boundary kinds
-  double *Fg = (double *)(Bk + ((a.max_bnd + 1) & ~1)); // GEO 1: [3][HS] unit normal and length of the faces, by column
+  double *Vx = (double *)(Bk + ((a.max_bnd + 1) & ~1)); // GEO 1: [4][2][64] outward unit normals of the own cells' faces
 
 #ifdef DFLO_PHASE_TIMING
   unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
@@ -538,15 +557,6 @@ __global__ __launch_bounds__(64 * N, (N == 4 && GEO == 0 && MODE == 0) ? DFLO_Q3
   uint32_t frr[3];
 #pragma unroll
   for (int it = 0; it < 3; ++it) frr[it] = fp[min(face_of_point<N>(tid + it * NT, nf), a.face_pitch - 1)];
-  double fg[3][2];   // GEO 1: unit normal and length of the faces tid and tid + NT (the table has the pitch of the face records)
-  if constexpr (GEO == 1) {
-    const double *gp = a.fgeom_pad + (size_t)shard * 3 * a.face_pitch;
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      fg[j][0] = gp[j * a.face_pitch + tid];
-      fg[j][1] = gp[j * a.face_pitch + tid + NT];
-    }
-  }
   uint16_t cref[4];
 #pragma unroll
   for (int f = 0; f < 4; ++f) cref[f] = a.cell_face[((size_t)pat * 4 + f) * 64 + lane];
@@ -638,12 +648,17 @@ __global__ __launch_bounds__(64 * N, (N == 4 && GEO == 0 && MODE == 0) ? DFLO_Q3
     }
   }
   if constexpr (GEO == 1) {
-    auto col_of = [&](int i) { return i < nh ? i : i - nh + a.halo_cols; };
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      if (tid < nf) Fg[j * HS + col_of(tid)] = fg[j][0];
-      if (tid + NT < nf) Fg[j * HS + col_of(tid + NT)] = fg[j][1];
-      for (int i = tid + 2 * NT; i < nf; i += NT) Fg[j * HS + col_of(i)] = a.fgeom_pad[((size_t)shard * 3 + j) * a.face_pitch + i];
+    // outward unit normals of the own cells' faces (every wave holds the vertices of its lanes' cells: wave r takes the faces
+    // r, r + N, ..).  IEEE square root and quotients, as plan.cc / the reference's FEFaceValues form them: a flux whose branch
+    // hangs on the sign of a vanishing normal velocity (KFVS: the jump of the reference's ERF polynomial at 0) must see the
+    // normal the host would have computed.
+    for (int f = row; f < 4; f += N) {
+      double tx, ty;
+      face_edge(vx, f, tx, ty);
+      const double len = sqrt(tx * tx + ty * ty);
+      const bool left = f == 1 || f == 2;
+      Vx[(2 * f) * 64 + lane] = (left ? ty : -ty) / len;
+      Vx[(2 * f + 1) * 64 + lane] = (left ? -tx : tx) / len;
     }
   }
   if (nbnd > 0) {  // boundary values and kinds of this shard's boundary faces
@@ -659,7 +674,7 @@ __global__ __launch_bounds__(64 * N, (N == 4 && GEO == 0 && MODE == 0) ? DFLO_Q3
   PHASE_MARK(2);
 
   // ---- phase B
-  flux_phase<N, FLUX, GEO>(a, Us, Th, Av, frr, fp, Bv, Bk, Fg, HS, nf, nh, tid);
+  flux_phase<N, FLUX, GEO>(a, Us, Th, Av, frr, fp, Bv, Bk, Vx, HS, nf, nh, tid);
   PHASE_MARK(3);
   __syncthreads();
   PHASE_MARK(4);
@@ -676,7 +691,7 @@ __global__ __launch_bounds__(64 * N, (N == 4 && GEO == 0 && MODE == 0) ? DFLO_Q3
 #define DFLO_ROW(Bq)                                                                                     \
   do {                                                                                                   \
     if constexpr (GEO == 0) row_update<N, Bq, MODE, POS, STREAM>(a, Us, S, Fh, red, shard, lane, active, h, cref, uold, wrow, unew, dt_step); \
-    else row_update_q1<N, Bq, MODE, POS, STREAM>(a, Us, S, Fh, Fg, red, shard, lane, active, vx, cref, uold, wrow, unew, dt_step); \
+    else row_update_q1<N, Bq, MODE, POS, STREAM>(a, Us, S, Fh, red, shard, lane, active, vx, cref, uold, wrow, unew, dt_step); \
   } while (0)
   if constexpr (N == 2) {
     if (row == 0) DFLO_ROW(0); else DFLO_ROW(1);
@@ -896,8 +911,19 @@ __global__ __launch_bounds__(64 * N, (N == 4 && GEO == 0 && MODE == 0) ? DFLO_Q3
         // margin: relative on the threshold, and absolute against the rounding of the slopes (formed here from row
         // partials, in the pass from the DoFs; both errors are a few ulp of the state)
         const double thr = a.tvb_M * h * h * (1.0 - 1.0e-9) - 1.0e-11 * (fabs(A[0]) + fabs(A[1]) + fabs(A[2]) + fabs(A[3]));
+        double sum = 0.0;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) need = need || !(fabs(D[i]) < thr || D[i] == 0.0);
+        for (int i = 0; i < 4; ++i) {
+          need = need || !(fabs(D[i]) < thr || D[i] == 0.0);
+          sum += fabs(D[i]);
+        }
+        // The second way out (the pass's own early-out, see limiter_kernel): minmod changes a slope by at most its size, so the
+        // "change" that decides whether the cell is rewritten (src/limiter.cc:347: > 1e-10, a quarter of the summed |changes| of
+        // both directions) is at most a quarter of the sum of the |slopes|: below half the threshold in this direction -- wave 0
+        // looks at x, wave 1 at y -- the cell stays as it is whatever its neighbours hold (states constant up to rounding: most
+        // of a shock tube, where M = 0 leaves the test above nothing to find).  The slopes here and in the pass are the same
+        // sums in another order (a few ulp of the slopes themselves): the margin on the threshold covers that.
+        need = need && !(0.25 * sum <= 0.4999e-10);
       }
       if (row == 0 && a.pos_check) need = need || !positivity_box_settled<N>(Us, lane, a.kb.pg_neg);
       const unsigned long long m = __ballot(need && active);
