@@ -8,6 +8,9 @@ namespace dflo {
 #ifndef DFLO_Q3_WAVES
 #define DFLO_Q3_WAVES 3   // wavefronts per SIMD the first-stage Q3 kernel on squares is built for (3: 168 registers)
 #endif
+#ifndef DFLO_PK_LEAN_LATER
+#define DFLO_PK_LEAN_LATER 1   // P3: the later stages built like the first one (3 wavefronts per SIMD: 161 registers, no spills; 0: 225 registers, 2 wavefronts)
+#endif
 // ------------------------------------------------------------------ the stage kernel
 // One workgroup of N wavefronts per shard: lane = cell, wavefront = node row b of the (k+1)^2
 // collocation nodes, so control flow is wave-uniform and every global access is a coalesced
@@ -992,18 +995,21 @@ __global__ __launch_bounds__(64 * N, (N == 4 && GEO == 0 && MODE == 0) ? DFLO_Q3
 //           gives 1/|K| on the diagonal for the orthonormal basis), update and SSP combine on the modes.
 // Cell average = mode 0 (psi_0 = 1).  Cartesian cells only.
 // =====================================================================================================
+// node row B of the own cells from their modes in the LDS image Um[4 NM][S] (every wave has put the modes it owns there)
 template <int N, int B>
-__device__ __forceinline__ void modal_to_row(const double (&um)[4][N * (N + 1) / 2], double (&urow)[4][N]) {
+__device__ __forceinline__ void modal_to_row(const double *Um, const int S, const int lane, double (&urow)[4][N]) {
   constexpr int NM = N * (N + 1) / 2;
 #pragma unroll
-  for (int c = 0; c < 4; ++c)
+  for (int c = 0; c < 4; ++c) {
 #pragma unroll
-    for (int aa = 0; aa < N; ++aa) {
-      double v = 0.0;
+    for (int aa = 0; aa < N; ++aa) urow[c][aa] = 0.0;
 #pragma unroll
-      for (int m = 0; m < NM; ++m) v += PB<N>::t.T[aa + N * B][m] * um[c][m];
-      urow[c][aa] = v;
+    for (int m = 0; m < NM; ++m) {   // (mode by mode: one value in flight per node sum, the sums in the order m = 0, 1, ..)
+      const double um = Um[(c * NM + m) * S + lane];
+#pragma unroll
+      for (int aa = 0; aa < N; ++aa) urow[c][aa] += PB<N>::t.T[aa + N * B][m] * um;
     }
+  }
 }
 
 // phase C for node row B, then projection of the nodal residual on the modes and the modal update of the
@@ -1022,7 +1028,7 @@ __device__ __forceinline__ void row_update_pk(const StageArgs &a, double *Us, co
     for (int m = 0; m < N; ++m) R[c][m] = 0.0;
   // P3, first stage (LEAN, as in row_update): built for 3 wavefronts per SIMD -- the nodal values of the own row and the own G
   // row come back from the LDS image instead of being held in registers, the G values are taken node by node
-  constexpr bool LEAN = N == 4 && MODE == 0;
+  constexpr bool LEAN = N == 4 && (MODE == 0 || (MODE == 1 && DFLO_PK_LEAN_LATER));
   double Gown[N][4];
 #pragma unroll
   for (int aa = 0; aa < N; ++aa) {
@@ -1089,35 +1095,42 @@ __device__ __forceinline__ void row_update_pk(const StageArgs &a, double *Us, co
       }
     }
   }
-  // ---- nodal residual -> modal residual: rhs_m = sum over rows of sum_a psi_m(x_(a,B)) R[.][a]; the rows
-  //      are added in a fixed order (row 0 first), through the now unused LDS image
+  // ---- nodal residual -> modal residual: rhs_m = sum over rows of sum_a psi_m(x_(a,b)) R_b[.][a], the rows added in a
+  //      fixed order (row 0 first).  Every wave leaves its row of the nodal residual in the now unused LDS image and, after ONE
+  //      barrier, forms the sums of the modes it owns (m = B, B + N, ..) from all rows -- the waves used to take turns at
+  //      adding their row to every mode through LDS, N barriers one after the other.  The same sums in the same order.
   __syncthreads();  // every wave is done with the G exchange
-  double *acc = Us;  // [4 NM][64]
 #pragma unroll
-  for (int w = 0; w < N; ++w) {
-    if (B == w) {
+  for (int c = 0; c < 4; ++c)
 #pragma unroll
-      for (int c = 0; c < 4; ++c)
-#pragma unroll
-        for (int m = 0; m < NM; ++m) {
-          double pr = 0.0;
-#pragma unroll
-          for (int aa = 0; aa < N; ++aa) pr += PB<N>::t.T[aa + N * B][m] * R[c][aa];
-          if (w == 0) acc[(c * NM + m) * 64 + lane] = pr;
-          else acc[(c * NM + m) * 64 + lane] += pr;
-        }
-    }
-    __syncthreads();
-  }
+    for (int aa = 0; aa < N; ++aa) Us[(c * NS + aa + N * B) * S + lane] = R[c][aa];
+  __syncthreads();
+  constexpr int MSB = (NM - B + N - 1) / N;   // modes of this wave
   double part[5] = {0, 0, 0, 0, 0};
-  if (active) {
+  {
     const double rh2 = frcp(h * h);  // inverse mass of the orthonormal modes: 1/|K|
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
+      double rmv[MSB > 0 ? MSB : 1];
+#pragma unroll
+      for (int b = 0; b < N; ++b) {
+        double pr[MSB > 0 ? MSB : 1];
+#pragma unroll
+        for (int t = 0; t < MSB; ++t) pr[t] = 0.0;
+#pragma unroll
+        for (int aa = 0; aa < N; ++aa) {
+          const double rn = Us[(c * NS + aa + N * b) * S + lane];
+#pragma unroll
+          for (int t = 0; t < MSB; ++t) pr[t] += PB<N>::t.T[aa + N * b][B + N * t] * rn;
+        }
+#pragma unroll
+        for (int t = 0; t < MSB; ++t) rmv[t] = b == 0 ? pr[t] : rmv[t] + pr[t];
+      }
+      if (active) {
       int t = 0;
 #pragma unroll
       for (int m = B; m < NM; m += N, ++t) {
-        const double rm = acc[(c * NM + m) * 64 + lane];
+        const double rm = rmv[t];
         if constexpr (MODE == 2) {
           a.rhs_out[((size_t)shard * 4 * NM + c * NM + m) * 64 + lane] = rm;
         } else {
@@ -1129,6 +1142,7 @@ __device__ __forceinline__ void row_update_pk(const StageArgs &a, double *Us, co
           if (m == 0) part[c] = u;  // the cell average is mode 0
         }
       }
+      }
     }
   }
   if constexpr (MODE != 2) {
@@ -1139,7 +1153,7 @@ __device__ __forceinline__ void row_update_pk(const StageArgs &a, double *Us, co
 }
 
 template <int N, int FLUX, int MODE>
-__global__ __launch_bounds__(64 * N, N == 4 ? ((MODE == 0 && FLUX != DFLO_FLUX_LXF) ? DFLO_Q3_WAVES : 2) : 3) void stage_kernel_pk(const StageArgs a) {
+__global__ __launch_bounds__(64 * N, N == 4 ? (((MODE == 0 || (MODE == 1 && DFLO_PK_LEAN_LATER)) && FLUX != DFLO_FLUX_LXF) ? DFLO_Q3_WAVES : 2) : 3) void stage_kernel_pk(const StageArgs a) {
   constexpr int NS = N * N, NM = N * (N + 1) / 2, NDOFM = 4 * NM, NT = 64 * N, MS = (NM + N - 1) / N;
   constexpr int ROWS = 4 * NS + (FLUX == DFLO_FLUX_LXF ? 3 : 0);
   constexpr int TROWS = 4 * N;
@@ -1158,23 +1172,15 @@ __global__ __launch_bounds__(64 * N, N == 4 ? ((MODE == 0 && FLUX != DFLO_FLUX_L
   double *Bv = Av + (FLUX == DFLO_FLUX_LXF ? 3 * a.halo_cols : 0);
   int *Bk = (int *)(Bv + a.max_bnd * 4 * N);
 
-  // ---- loads: every wave reads all modes of its cells (the rows need all of them); the modes a wave will
-  //      update (m = row, row+N, ...) of u(s) and u(n) are requested separately and consumed at the end
-  int hent[2];
-#pragma unroll
-  for (int t = 0; t < 2; ++t) hent[t] = a.halo_pad[(size_t)shard * a.halo_pitch + ((tid + t * NT) & 31)];
+  // ---- loads: a wave reads the modes it will update (m = row, row + N, ..) of u(s) and u(n); the node rows need all modes of
+  //      the cell, which the waves hand each other through LDS (each of them used to load all of them: 4 NM loads and as many
+  //      registers per wave instead of 4 NM / N)
+  int hent[1];
+  hent[0] = a.halo_pad[(size_t)shard * a.halo_pitch + (tid & 31)];
   const int4 hdr = a.shard_hdr[shard];
   const int nf = hdr.y, nh = hdr.z, nbnd = hdr.w;
   const bool active = lane < (hdr.x & 0xFF);
   const int pat = hdr.x >> 8;   // index pattern of the shard: its face records and face references
-  double umode[4][NM];
-  {
-    const double *up = a.Ucur + (size_t)shard * NDOFM * 64 + lane;
-#pragma unroll
-    for (int c = 0; c < 4; ++c)
-#pragma unroll
-      for (int m = 0; m < NM; ++m) umode[c][m] = up[(c * NM + m) * 64];
-  }
   double uavg[4];
   if constexpr (FLUX == DFLO_FLUX_LXF) {
     if (row == 0) {
@@ -1202,37 +1208,54 @@ __global__ __launch_bounds__(64 * N, N == 4 ? ((MODE == 0 && FLUX != DFLO_FLUX_L
       if constexpr (MODE == 1) uold[c][t] = __builtin_nontemporal_load(&a.Uold[((size_t)shard * NDOFM + c * NM + m) * 64 + lane]);   // read once per stage
     }
 
-  // ---- phase A
+  // ---- phase A: the modes meet in LDS (in the rows the nodal image will take), every wave forms its node row from them
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int t = 0; t < MS; ++t) {
+      const int m = row + N * t;
+      if (m < NM) Us[(c * NM + m) * S + lane] = ucur[c][t];
+    }
+  __syncthreads();
   double urow[4][N];
   if constexpr (N == 2) {
-    if (row == 0) modal_to_row<N, 0>(umode, urow); else modal_to_row<N, 1>(umode, urow);
+    if (row == 0) modal_to_row<N, 0>(Us, S, lane, urow); else modal_to_row<N, 1>(Us, S, lane, urow);
   } else if constexpr (N == 3) {
-    if (row == 0) modal_to_row<N, 0>(umode, urow); else if (row == 1) modal_to_row<N, 1>(umode, urow); else modal_to_row<N, 2>(umode, urow);
+    if (row == 0) modal_to_row<N, 0>(Us, S, lane, urow); else if (row == 1) modal_to_row<N, 1>(Us, S, lane, urow); else modal_to_row<N, 2>(Us, S, lane, urow);
   } else {
-    if (row == 0) modal_to_row<N, 0>(umode, urow); else if (row == 1) modal_to_row<N, 1>(umode, urow);
-    else if (row == 2) modal_to_row<N, 2>(umode, urow); else modal_to_row<N, 3>(umode, urow);
+    if (row == 0) modal_to_row<N, 0>(Us, S, lane, urow); else if (row == 1) modal_to_row<N, 1>(Us, S, lane, urow);
+    else if (row == 2) modal_to_row<N, 2>(Us, S, lane, urow); else modal_to_row<N, 3>(Us, S, lane, urow);
   }
-  // halo: trace of the neighbour's modal expansion at the face point, psi_m = Pt_i(xi) Pt_j(eta) with
-  // (xi, eta) on face f: xi in {0, 1, x_q}
-  for (int i = tid; i < ((nh + 31) & ~31) * 4 * N; i += NT) {
-    const int sl = (i & 31) + ((i >> 5) / (4 * N)) * 32, r = (i >> 5) % (4 * N), q = r % N, c = r / N;
+  __syncthreads();   // every wave has read the modes: the nodal image may take their place
+  // halo: traces of the neighbour's modal expansion on the shared face, psi_m = Pt_i(xi) Pt_j(eta) with one coordinate fixed at
+  // 0 or 1 and the other at the N face points.  A thread takes one (entry, component): it loads the NM modes once, sums over
+  // the fixed direction (both ways, the face decides which one counts) and evaluates the N points from the N sums -- the modes
+  // used to be loaded once per face point, N NM loads for N values.
+  for (int i = tid; i < ((nh + 31) & ~31) * 4; i += NT) {
+    const int sl = (i & 31) + ((i >> 5) >> 2) * 32, c = (i >> 5) & 3;
     if (sl >= nh) continue;
-    const int e = i == tid ? hent[0] : (i == tid + NT ? hent[1] : a.halo_pad[(size_t)shard * a.halo_pitch + sl]);
+    const int e = sl < 32 ? hent[0] : a.halo_pad[(size_t)shard * a.halo_pitch + sl];
     const int ic = e & 0x0FFFFFFF, f = (e >> 28) & 3;
     const double *hp = a.Ucur + ((size_t)(ic >> 6) * NDOFM + c * NM) * 64 + (ic & 63);
-    double pxi[N], peta[N];
+    double um[NM];
 #pragma unroll
-    for (int n = 0; n < N; ++n) {
-      double pq = PB<N>::t.Px[0][n];
+    for (int m = 0; m < NM; ++m) um[m] = hp[m * 64];
+    double ax[N], ay[N];   // ax[j] = sum_i Pt_i(0|1) U_(i,j): the face xi = 0|1;  ay[i] = sum_j Pt_j(0|1) U_(i,j): the face eta = 0|1
 #pragma unroll
-      for (int qq = 1; qq < N; ++qq) pq = q == qq ? PB<N>::t.Px[qq][n] : pq;
-      pxi[n] = f == 0 ? PB<N>::t.P0[n] : (f == 1 ? PB<N>::t.P1[n] : pq);
-      peta[n] = f == 2 ? PB<N>::t.P0[n] : (f == 3 ? PB<N>::t.P1[n] : pq);
+    for (int n = 0; n < N; ++n) ax[n] = ay[n] = 0.0;
+#pragma unroll
+    for (int m = 0; m < NM; ++m) {
+      const int mi = PB<N>::t.mi[m], mj = PB<N>::t.mj[m];
+      ax[mj] += ((f & 1) ? PB<N>::t.P1[mi] : PB<N>::t.P0[mi]) * um[m];
+      ay[mi] += ((f & 1) ? PB<N>::t.P1[mj] : PB<N>::t.P0[mj]) * um[m];
     }
-    double v = 0.0;
 #pragma unroll
-    for (int m = 0; m < NM; ++m) v += pxi[PB<N>::t.mi[m]] * peta[PB<N>::t.mj[m]] * hp[m * 64];
-    Th[(c * N + q) * HS + sl] = v;
+    for (int q = 0; q < N; ++q) {
+      double v = 0.0;
+#pragma unroll
+      for (int n = 0; n < N; ++n) v += PB<N>::t.Px[q][n] * (f < 2 ? ax[n] : ay[n]);
+      Th[(c * N + q) * HS + sl] = v;
+    }
   }
   if constexpr (FLUX == DFLO_FLUX_LXF) {  // lambda of the LxF flux comes from the cell averages (src/equation.h:357-359):
                                           // keep (u, v, c) of each average instead of the four components
