@@ -153,11 +153,11 @@ def build_case(args, world):
     else:
         # BASELINE config 5 on its own geometry: the Mach 3 wind tunnel with a step (examples/forward_step/step.geo) meshed
         # with unstructured quadrilaterals (q1 mapping), Q3, KFVS, positivity limiter (the only limiter the reference allows
-        # off Cartesian meshes).  cl = 0.2 / k: 604 800 cells per GPU.  With the cfl 0.5 of the shipped input the run ends in
+        # off Cartesian meshes).  cl = 0.2 / k: 1 597 050 cells per GPU (k = 65; --nx 40: 604 800, the size of rounds 1-2).  With the cfl 0.5 of the shipped input the run ends in
         # the 6th step ("Problem in positivity limiter", device and oracle alike, tests/test_gpu_parity.py); at cfl 0.02
         # the same physical time is ~125 steps away, which is what is timed here (--steps 100 --warmup 10 by default).
         from dflo_amd import gmsh
-        k = int(round((40 if args.nx == 1024 else args.nx) * np.sqrt(world)))
+        k = int(round((65 if args.nx == 1024 else args.nx) * np.sqrt(world)))   # 65: 1 597 050 cells, 102 M DoF -- BASELINE's "~1.61 M cells"
         verts, quads, bed, bid = gmsh.forward_step_quads(cl=0.2 / k, seed=1)
         mesh = dflo_amd.Mesh.from_quads(verts, quads, bed, bid, 3)
         nx = ny = k

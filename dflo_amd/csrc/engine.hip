@@ -172,12 +172,12 @@ KBasis make_kbasis(const BasisTables &b) {
   return k;
 }
 
-stage_fn pick_pk(int N, int flux, int mode) {
+stage_fn pick_pk(int N, int flux, int mode, int nt = 0) {
   switch (N) {
-    case 1: return dflo::stage_pk_of_1(flux, mode);
-    case 2: return dflo::stage_pk_of_2(flux, mode);
-    case 3: return dflo::stage_pk_of_3(flux, mode);
-    default: return dflo::stage_pk_of_4(flux, mode);
+    case 1: return dflo::stage_pk_of_1(flux, mode, nt);
+    case 2: return dflo::stage_pk_of_2(flux, mode, nt);
+    case 3: return dflo::stage_pk_of_3(flux, mode, nt);
+    default: return dflo::stage_pk_of_4(flux, mode, nt);
   }
 }
 stage_fn pick_stage(int N, int flux, int mode, int geo, int pos = 0, int nt = 0) {
@@ -421,7 +421,7 @@ int launch_update(dflo_hip_engine *h, double *rhs_out, int part) {
   a.pos_check = h->prm.pos_lim;
   const int pos_ = h->fuse_pos ? 1 : (h->lim_mask ? 2 : 0);
   if (pos_ == 2 && mode_ != 2) h->aux_fresh = true;
-  stage_fn fn = h->basis == DFLO_BASIS_PK ? pick_pk(h->N, h->prm.flux_type, mode_) : pick_stage(h->N, h->prm.flux_type, mode_, h->geo, pos_, streams_out(h));
+  stage_fn fn = h->basis == DFLO_BASIS_PK ? pick_pk(h->N, h->prm.flux_type, mode_, streams_out(h)) : pick_stage(h->N, h->prm.flux_type, mode_, h->geo, pos_, streams_out(h));
   time_begin(h);
   hipLaunchKernelGGL(fn, dim3(grid_for(a.n_list)), dim3(64 * h->N), h->lds_bytes, h->stream, a);
   time_end(h);
@@ -885,7 +885,7 @@ int dflo_hip_create(const dflo_mesh_t *mesh, const dflo_params_t *params, int de
   if (h->lds_bytes > 160 * 1024) { h->err = "shard halo too large for LDS"; return bail(DFLO_ERR_UNSUPPORTED); }
   if (h->lds_bytes > 64 * 1024) {
     for (int mode = 0; mode < 3; ++mode) {
-      stage_fn fn = h->basis == DFLO_BASIS_PK ? pick_pk(h->N, h->prm.flux_type, mode) : pick_stage(h->N, h->prm.flux_type, mode, h->geo, h->fuse_pos ? 1 : (h->lim_mask ? 2 : 0), streams_out(h));
+      stage_fn fn = h->basis == DFLO_BASIS_PK ? pick_pk(h->N, h->prm.flux_type, mode, streams_out(h)) : pick_stage(h->N, h->prm.flux_type, mode, h->geo, h->fuse_pos ? 1 : (h->lim_mask ? 2 : 0), streams_out(h));
       if (hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes) != hipSuccess) {
         h->err = "cannot raise dynamic LDS limit";
         return bail(DFLO_ERR_HIP);

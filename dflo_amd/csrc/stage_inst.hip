@@ -11,5 +11,5 @@
 
 namespace dflo {
 stage_fn DFLO_CAT(stage_of_, DFLO_STAGE_N)(int flux, int mode, int geo, int pos, int nt) { return pick_stage_n<DFLO_STAGE_N>(flux, mode, geo, pos, nt); }
-stage_fn DFLO_CAT(stage_pk_of_, DFLO_STAGE_N)(int flux, int mode) { return pick_pk_n<DFLO_STAGE_N>(flux, mode); }
+stage_fn DFLO_CAT(stage_pk_of_, DFLO_STAGE_N)(int flux, int mode, int nt) { return pick_pk_n<DFLO_STAGE_N>(flux, mode, nt); }
 }  // namespace dflo

@@ -1014,7 +1014,7 @@ __device__ __forceinline__ void modal_to_row(const double *Um, const int S, cons
 
 // phase C for node row B, then projection of the nodal residual on the modes and the modal update of the
 // modes this wave owns (m = B, B+N, ...)
-template <int N, int B, int MODE>
+template <int N, int B, int MODE, int STREAM>
 __device__ __forceinline__ void row_update_pk(const StageArgs &a, double *Us, const int S, const double *Fh, double *red,
                                               int shard, int lane, bool active, double h, const uint16_t (&cref)[4],
                                               const double (&Wrow)[N][4], const double (&ucur)[4][(N * (N + 1) / 2 + N - 1) / N],
@@ -1138,7 +1138,7 @@ __device__ __forceinline__ void row_update_pk(const StageArgs &a, double *Us, co
           double u = ucur[c][t];
           u += dt * rm * rh2;
           if constexpr (MODE == 1) u = (1.0 - a.ark) * u + a.ark * uold[c][t];
-          a.Unew[((size_t)shard * 4 * NM + c * NM + m) * 64 + lane] = u;
+          stream_store<STREAM>(&a.Unew[((size_t)shard * 4 * NM + c * NM + m) * 64 + lane], u);
           if (m == 0) part[c] = u;  // the cell average is mode 0
         }
       }
@@ -1152,7 +1152,7 @@ __device__ __forceinline__ void row_update_pk(const StageArgs &a, double *Us, co
   }
 }
 
-template <int N, int FLUX, int MODE>
+template <int N, int FLUX, int MODE, int STREAM>
 __global__ __launch_bounds__(64 * N, N == 4 ? (((MODE == 0 || (MODE == 1 && DFLO_PK_LEAN_LATER)) && FLUX != DFLO_FLUX_LXF) ? DFLO_Q3_WAVES : 2) : 3) void stage_kernel_pk(const StageArgs a) {
   constexpr int NS = N * N, NM = N * (N + 1) / 2, NDOFM = 4 * NM, NT = 64 * N, MS = (NM + N - 1) / N;
   constexpr int ROWS = 4 * NS + (FLUX == DFLO_FLUX_LXF ? 3 : 0);
@@ -1299,7 +1299,7 @@ __global__ __launch_bounds__(64 * N, N == 4 ? (((MODE == 0 || (MODE == 1 && DFLO
   for (int m = 0; m < N; ++m)
 #pragma unroll
     for (int c = 0; c < 4; ++c) wrow[m][c] = urow[c][m];
-#define DFLO_ROWPK(Bq) row_update_pk<N, Bq, MODE>(a, Us, S, Fh, red, shard, lane, active, h, cref, wrow, ucur, uold, dt_step)
+#define DFLO_ROWPK(Bq) row_update_pk<N, Bq, MODE, STREAM>(a, Us, S, Fh, red, shard, lane, active, h, cref, wrow, ucur, uold, dt_step)
   if constexpr (N == 2) {
     if (row == 0) DFLO_ROWPK(0); else DFLO_ROWPK(1);
   } else if constexpr (N == 3) {
@@ -1368,26 +1368,28 @@ stage_fn pick_stage_n(int flux, int mode, int geo, int pos, int nt) {
   }
 }
 template <int N, int FLUX>
-stage_fn pick_pk_m(int mode) {
-  return mode == 0 ? stage_kernel_pk<N, FLUX, 0> : (mode == 1 ? stage_kernel_pk<N, FLUX, 1> : stage_kernel_pk<N, FLUX, 2>);
+stage_fn pick_pk_m(int mode, int nt) {   // nt: nothing re-reads the new state before the next stage kernel (see STREAM)
+  if (mode == 2) return stage_kernel_pk<N, FLUX, 2, 0>;
+  if (nt) return mode == 0 ? stage_kernel_pk<N, FLUX, 0, 1> : stage_kernel_pk<N, FLUX, 1, 1>;
+  return mode == 0 ? stage_kernel_pk<N, FLUX, 0, 0> : stage_kernel_pk<N, FLUX, 1, 0>;
 }
 template <int N>
-stage_fn pick_pk_n(int flux, int mode) {
+stage_fn pick_pk_n(int flux, int mode, int nt) {
   switch (flux) {
-    case DFLO_FLUX_LXF: return pick_pk_m<N, DFLO_FLUX_LXF>(mode);
-    case DFLO_FLUX_SW: return pick_pk_m<N, DFLO_FLUX_SW>(mode);
-    case DFLO_FLUX_KFVS: return pick_pk_m<N, DFLO_FLUX_KFVS>(mode);
-    case DFLO_FLUX_ROE: return pick_pk_m<N, DFLO_FLUX_ROE>(mode);
-    default: return pick_pk_m<N, DFLO_FLUX_HLLC>(mode);
+    case DFLO_FLUX_LXF: return pick_pk_m<N, DFLO_FLUX_LXF>(mode, nt);
+    case DFLO_FLUX_SW: return pick_pk_m<N, DFLO_FLUX_SW>(mode, nt);
+    case DFLO_FLUX_KFVS: return pick_pk_m<N, DFLO_FLUX_KFVS>(mode, nt);
+    case DFLO_FLUX_ROE: return pick_pk_m<N, DFLO_FLUX_ROE>(mode, nt);
+    default: return pick_pk_m<N, DFLO_FLUX_HLLC>(mode, nt);
   }
 }
 stage_fn stage_of_1(int flux, int mode, int geo, int pos, int nt);
 stage_fn stage_of_2(int flux, int mode, int geo, int pos, int nt);
 stage_fn stage_of_3(int flux, int mode, int geo, int pos, int nt);
 stage_fn stage_of_4(int flux, int mode, int geo, int pos, int nt);
-stage_fn stage_pk_of_1(int flux, int mode);
-stage_fn stage_pk_of_2(int flux, int mode);
-stage_fn stage_pk_of_3(int flux, int mode);
-stage_fn stage_pk_of_4(int flux, int mode);
+stage_fn stage_pk_of_1(int flux, int mode, int nt);
+stage_fn stage_pk_of_2(int flux, int mode, int nt);
+stage_fn stage_pk_of_3(int flux, int mode, int nt);
+stage_fn stage_pk_of_4(int flux, int mode, int nt);
 
 }  // namespace dflo

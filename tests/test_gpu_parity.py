@@ -1081,45 +1081,55 @@ def test_c3_full_size_properties():
 
 
 def test_c5_full_size_properties():
-    """The C5 stand-in of bench.py at full size (522 150 unstructured quadrilaterals, q1 mapping, Q3, KFVS, positivity
-    inside the stage kernel; 33 M DoF): a free stream stays a free stream on the bilinear cells (geometric conservation
-    through every face pairing and orientation of the mesh), the run is bit-reproducible, and with the density bump of
-    the benchmark the mass balance closes over the boundaries."""
+    """BASELINE config 5 at its size and on its geometry: the Mach 3 wind tunnel with a step (examples/forward_step/step.geo)
+    meshed with 1 597 050 unstructured quadrilaterals (q1 mapping), Q3, KFVS, positivity inside the stage kernel: 102 M DoF --
+    what `bench.py --config c5` runs.  (1) With the free stream prescribed on every boundary a free stream stays a free stream
+    on the bilinear cells: geometric conservation through every face pairing and orientation of the mesh.  (2) The
+    configuration itself (inflow / slip walls / outflow, examples/forward_step/input.prm:19-47, impulsive start at the step,
+    cfl 0.02 -- see test_forward_step_c5_fails_like_the_reference_algorithm for why not 0.5): the run is bit-reproducible,
+    stays admissible, and the mass balance closes: what comes in at x = 0 minus what leaves at x = 3 (still the free
+    stream there), nothing through the walls."""
     from dflo_amd import gmsh
-    n = 295
-    verts, quads, bed, side = gmsh.unstructured_quads(n, Lx=3.0, Ly=3.0, seed=1)
-    bid = np.array([2, 3, 2, 1], dtype=np.int32)[side]
+    verts, quads, bed, bid = gmsh.forward_step_quads(cl=0.2 / 65, seed=1)
     mesh = dflo_amd.Mesh.from_quads(verts, quads, bed, bid, 3)
-    assert mesh.n_cells == 522150
-    prm = dflo_amd.Parameters(flux="kfvs", pos_lim=True, cfl=0.5, final_time=1e9, boundary={1: "inflow", 2: "slip", 3: "outflow"})
-    claw = dflo_amd.ConservationLaw(mesh, prm)
-    cell, face, b, xy = claw.boundary_faces()
-    bv = np.stack(problems.forward_step_inflow(xy[..., 0], xy[..., 1]), axis=-1)
-    claw.set_boundary_values(0, bv)
-    claw.set_boundary_values(1, bv)
-    free = mesh.interpolate(problems.forward_step_inflow)
-    claw.set_initial_condition(free)
-    assert np.abs(claw.assemble_system()).max() < 1e-9
-    claw.advance(3)
-    assert np.abs(claw.current_solution - free).max() < 1e-9     # (cells of size 3e-3: round-off of the residual times dt / |K|)
-    # the benchmark's state: bump on the free stream
-    xyc = mesh.support_points()
-    bump = 1.0 + 0.1 * np.exp(-20.0 * ((xyc[..., 0] - 1.5) ** 2 + (xyc[..., 1] - 1.5) ** 2))
-    u0 = (free.reshape(mesh.n_cells, 4, -1) * bump[:, None, :]).reshape(-1)
+    assert mesh.n_cells == 1597050 and mesh.n_cells * mesh.ndof == 102211200
     v = mesh.vertices
     x, y = v[:, :, 0], v[:, :, 1]
     area = 0.5 * np.abs((x[:, 0] * y[:, 1] - x[:, 1] * y[:, 0]) + (x[:, 1] * y[:, 3] - x[:, 3] * y[:, 1]) +
                         (x[:, 3] * y[:, 2] - x[:, 2] * y[:, 3]) + (x[:, 2] * y[:, 0] - x[:, 0] * y[:, 2]))
-    assert abs(area.sum() - 9.0) < 1e-10
-    claw.set_initial_condition(u0)
+    assert abs(area.sum() - 2.52) < 1e-10                      # [0,3] x [0,1] minus the step [0.6,3] x [0,0.2]
+    free = mesh.interpolate(problems.forward_step_inflow)
+
+    def make(kinds, cfl):
+        prm = dflo_amd.Parameters(flux="kfvs", pos_lim=True, cfl=cfl, final_time=1e9, boundary=kinds)
+        claw = dflo_amd.ConservationLaw(mesh, prm)
+        cell, face, b, xy = claw.boundary_faces()
+        bv = np.stack(problems.forward_step_inflow(xy[..., 0], xy[..., 1]), axis=-1)
+        claw.set_boundary_values(0, bv)
+        claw.set_boundary_values(1, bv)
+        claw.set_initial_condition(free)
+        return claw
+
+    claw = make({1: "inflow", 2: "inflow", 3: "inflow"}, 0.5)
+    assert np.abs(claw.assemble_system()).max() < 1e-9
+    claw.advance(3)
+    assert np.abs(claw.current_solution - free).max() < 1e-9     # (cells of size 1.5e-3: round-off of the residual times dt / |K|)
+    claw.close()
+
+    claw = make({1: "inflow", 2: "slip", 3: "outflow"}, 0.02)
     m0 = (claw.cell_average[:, 2] * area).sum()
+    assert abs(m0 - 1.4 * 2.52) < 1e-10
     t = claw.advance(20)
     u20 = claw.current_solution
-    m1 = (claw.cell_average[:, 2] * area).sum()
-    # the bump (centre 1.5, width ~0.3) is carried at u = 3 and has not reached x = 3 (t ~ 0.01): in = out = rho u H
-    assert t < 0.05 and abs(m1 - m0) < 1e-9 * m0
-    claw.set_initial_condition(u0)
-    claw.advance(20)
+    avg = claw.cell_average
+    m1 = (avg[:, 2] * area).sum()
+    pr = 0.4 * (avg[:, 3] - 0.5 * (avg[:, 0] ** 2 + avg[:, 1] ** 2) / avg[:, 2])
+    assert avg[:, 2].min() > 0.5 and pr.min() > 0.5
+    # in: rho u = 4.2 over the height 1; out: the same over the height 0.8 (the waves from the step face are far from x = 3)
+    assert 0.0 < t < 1e-3 and abs((m1 - m0) - 4.2 * 0.2 * t) < 1e-9 * m0
+    claw.set_initial_condition(free)
+    claw.elapsed_time = 0.0
+    assert claw.advance(20) == t
     assert np.array_equal(claw.current_solution, u20)
 
 
