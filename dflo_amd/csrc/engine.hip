@@ -18,6 +18,7 @@
 // limiter_kernels.hpp, small_kernels.hpp.  This file: the engine object and the C ABI.
 #include "stage_kernels.hpp"
 #include "small_kernels.hpp"
+#include "tunables.h"
 
 
 // ====================================================================== host side
@@ -97,7 +98,6 @@ struct dflo_hip_engine {
   int sweep_mode = 1, sweep_dir = 0;   // every launch over all shards walks them against the previous one (DFLO_SWEEP=0: always forward)
   bool fuse_dtq = true;                // DFLO_FUSE_DTQ=0: bilinear cells always take the separate time-step pass (dt_q_kernel)
   int stream_override = -1;            // DFLO_STREAM=0/1 forces the streaming-store variant off / on
-  unsigned long long *phase_cycles = nullptr;
   // timing
   bool timing = false;
   int dtq_parts = 0;   // last stage on bilinear cells: parts (1 rim, 2 interior) whose limiter pass also formed the time step
@@ -356,7 +356,6 @@ int launch_update(dflo_hip_engine *h, double *rhs_out, int part) {
   const int rk = h->st_rk;
   const bool last = rk == h->n_rk - 1;
   StageArgs a{};
-  a.phase_cycles = h->phase_cycles;
   a.Ucur = h->U[h->st_in];
   a.Uold = h->U[h->st_old];
   a.Unew = h->U[h->st_out];
@@ -685,10 +684,11 @@ int dflo_hip_create(const dflo_mesh_t *mesh, const dflo_params_t *params, int de
   h->degree = mesh->degree;
   h->N = mesh->degree + 1;
   h->basis = mesh->basis;
-  if (const char *e = std::getenv("DFLO_GRAPH")) h->use_graph = std::atoi(e) != 0;
-  if (const char *e = std::getenv("DFLO_SWEEP")) h->sweep_mode = std::atoi(e);
-  if (const char *e = std::getenv("DFLO_STREAM")) h->stream_override = std::atoi(e) != 0;
-  if (const char *e = std::getenv("DFLO_FUSE_DTQ")) h->fuse_dtq = std::atoi(e) != 0;
+  const Tunables tun = read_tunables();
+  h->use_graph = tun.graph;
+  h->sweep_mode = tun.sweep ? 1 : 0;
+  h->stream_override = tun.stream;
+  h->fuse_dtq = tun.fuse_dtq;
   h->ns = mesh->basis == DFLO_BASIS_PK ? h->N * (h->N + 1) / 2 : h->N * h->N;
   h->ndof = 4 * h->ns;
   h->mapping = mesh->mapping;
@@ -699,9 +699,8 @@ int dflo_hip_create(const dflo_mesh_t *mesh, const dflo_params_t *params, int de
   h->kb = make_kbasis(h->bt);
   {  // multi-device: ghost cells as face traces (N*4 doubles per cut face) when nothing needs more of them -- the stage
      // kernels read only their traces and averages; the KXRCF indicator and the Pk element read their DoFs
-    const char *e2 = std::getenv("DFLO_HALO_CELLS");
     h->n_gt = (int)h->plan.gt_cell.size();
-    h->trace_halo = h->n_gt > 0 && h->basis == DFLO_BASIS_QK && h->prm.shock_indicator == DFLO_IND_LIMITER && !(e2 && e2[0] == '1');
+    h->trace_halo = h->n_gt > 0 && h->basis == DFLO_BASIS_QK && h->prm.shock_indicator == DFLO_IND_LIMITER && !tun.halo_cells;
   }
   // quadrature points of the boundary faces (fe_v.get_quadrature_points(), src/assemble_explicit.cc:164)
   h->bface_xy.resize(h->plan.bface_cell.size() * h->N * 2);
@@ -854,18 +853,15 @@ int dflo_hip_create(const dflo_mesh_t *mesh, const dflo_params_t *params, int de
   // partials (4 N), and the point maxima of the time step (N): 9 N rows of 64.  Odd: the rows fall on different LDS banks.
   h->halo_stride = std::max(p.halo_cols + std::max(p.max_inner, 1), 9 * 64 / 4) | 1;
   {
-    const char *e = getenv("DFLO_FUSE_POS");
-    h->fuse_pos = h->prm.pos_lim && h->prm.limiter_type == DFLO_LIMITER_NONE && h->basis == DFLO_BASIS_QK && !(e && e[0] == '0');
+    h->fuse_pos = h->prm.pos_lim && h->prm.limiter_type == DFLO_LIMITER_NONE && h->basis == DFLO_BASIS_QK && tun.fuse_pos;
     {  // who reads the averages of an intermediate stage?  The LxF flux (lambda from cell means), a limiter pass, the indicator,
        // local time stepping -- otherwise they stay in the kernel (DFLO_LAZY_AVG=0: always stored)
-      const char *e3 = getenv("DFLO_LAZY_AVG");
       const bool pass = h->prm.limiter_type != DFLO_LIMITER_NONE || (h->prm.pos_lim && !h->fuse_pos) || h->prm.shock_indicator != DFLO_IND_LIMITER;
-      h->lazy_avg = !(e3 && e3[0] == '0') && h->prm.flux_type != DFLO_FLUX_LXF && !pass && h->prm.global_time_step;
+      h->lazy_avg = tun.lazy_avg && h->prm.flux_type != DFLO_FLUX_LXF && !pass && h->prm.global_time_step;
     }
-    const char *e2 = getenv("DFLO_LIM_MASK");
     // (measured: the marks cost the stage kernel ~11 %; the pass they shorten reads (k+1)^2 values per cell and component,
     //  which pays from k = 2 on -- C4 +7 % -- and not for k = 1 -- C3 -7 %; DFLO_LIM_MASK=1 forces them, 0 forbids them)
-    const bool want_marks = e2 ? e2[0] != '0' : h->N >= 3;
+    const bool want_marks = tun.lim_mask >= 0 ? tun.lim_mask != 0 : h->N >= 3;
     if (h->prm.limiter_type == DFLO_LIMITER_TVB && h->basis == DFLO_BASIS_QK && h->geo == 0 && want_marks) {
       const size_t nb = (size_t)std::max(p.n_shards, 1) * sizeof(unsigned long long);
       if (hipMalloc((void **)&h->lim_mask, nb) != hipSuccess) {
@@ -879,7 +875,6 @@ int dflo_hip_create(const dflo_mesh_t *mesh, const dflo_params_t *params, int de
     const int rows = 4 * h->N * h->N + (h->prm.flux_type == DFLO_FLUX_LXF ? 3 : 0);  // nodal image (also for Pk)
     h->lds_bytes = ((size_t)rows * 65 + (size_t)4 * h->N * h->halo_stride + (h->prm.flux_type == DFLO_FLUX_LXF ? 3 * (size_t)p.halo_cols : 0) +
                     (size_t)p.max_bnd * 4 * h->N + (p.max_bnd + 2) / 2 + (h->geo == 1 ? 8 * 64 : 0)) * sizeof(double);
-    if (const char *e = std::getenv("DFLO_LDS_PAD")) h->lds_bytes += (size_t)std::atoi(e);   // occupancy experiments: unused LDS per workgroup
   }
 
   if (h->lds_bytes > 160 * 1024) { h->err = "shard halo too large for LDS"; return bail(DFLO_ERR_UNSUPPORTED); }
@@ -899,14 +894,10 @@ int dflo_hip_create(const dflo_mesh_t *mesh, const dflo_params_t *params, int de
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)fn, 64 * h->N, h->lds_bytes) != hipSuccess || per_cu < 1)
       per_cu = 1;
     if (n_cu < 1) n_cu = 256;
-    if (std::getenv("DFLO_VERBOSE"))
+    if (tun.verbose)
       std::fprintf(stderr, "dflo_hip: stage kernel N=%d: %zu bytes of LDS per workgroup, %d workgroups (%d wavefronts) resident per CU; %d shards, %d index patterns\n",
                    h->N, h->lds_bytes, per_cu, per_cu * h->N, h->plan.n_shards, h->n_patterns);
     h->stage_grid = grid_for(h->plan.n_shards);  // one workgroup per shard (per_cu of them resident per CU)
-#ifdef DFLO_PHASE_TIMING
-    hipMalloc((void **)&h->phase_cycles, (size_t)h->stage_grid * 32 * sizeof(unsigned long long));
-    hipMemset(h->phase_cycles, 0, (size_t)h->stage_grid * 32 * sizeof(unsigned long long));
-#endif
   }
   *out = h;
   return DFLO_OK;
@@ -1558,16 +1549,6 @@ int dflo_hip_debug_exp(int n, const double *x, double *exp_library, double *exp_
   hipMemcpy(exp_flux, df, n * sizeof(double), hipMemcpyDeviceToHost);
   hipFree(dx); hipFree(dl); hipFree(df);
   return hipGetLastError() == hipSuccess ? DFLO_OK : DFLO_ERR_HIP;
-}
-
-/* developer probe: per-workgroup cycle counts of the stage kernel's phases (library built with
- * -DDFLO_PHASE_TIMING); returns the grid size, 0 when the probe is compiled out. */
-int dflo_hip_debug_phase_cycles(dflo_hip_handle h, unsigned long long *out, int max_groups) {
-  if (!h || !h->phase_cycles) return 0;
-  const int n = std::min(max_groups, h->stage_grid);
-  hipStreamSynchronize(h->stream);
-  hipMemcpy(out, h->phase_cycles, (size_t)n * 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
-  return h->stage_grid;
 }
 
 int dflo_hip_apply_dt_rules(dflo_hip_handle h) {

@@ -35,14 +35,8 @@ struct KBasis {       // 1-D tables, see basis.h
   int Ng;
 };
 
-#ifdef DFLO_PHASE_TIMING
-#define PHASE_MARK(i) do { if (lane == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tacc[i] += t_ - tlast; tlast = t_; } } while (0)
-#else
-#define PHASE_MARK(i) do { } while (0)
-#endif
 
 struct StageArgs {
-  unsigned long long *phase_cycles;  // [grid][4 waves][8], only with DFLO_PHASE_TIMING
   const double *Ucur, *Uold;
   double *Unew;
   const double *avg_cur;

@@ -65,11 +65,8 @@ struct LimArgs {
 
 // apply_limiter_TVB_Qk (src/limiter.cc:225-370) then apply_positivity_limiter
 // (src/positivity.cc:17-208), lane = cell, all DoFs of the cell in registers.
-#ifndef DFLO_LIM_WAVES
-#define DFLO_LIM_WAVES 1
-#endif
 template <int N>
-__global__ __launch_bounds__(64, DFLO_LIM_WAVES) void limiter_kernel(const LimArgs a) {
+__global__ __launch_bounds__(64) void limiter_kernel(const LimArgs a) {
   constexpr int NS = N * N, NDOF = 4 * NS;
   const int sidx = shard_of_block(blockIdx.x, a.n_list, a.sweep_rev);
   if (sidx < 0) return;
@@ -96,14 +93,6 @@ __global__ __launch_bounds__(64, DFLO_LIM_WAVES) void limiter_kernel(const LimAr
   for (int c = 0; c < 4; ++c) A[c] = a.avg[((size_t)shard * 4 + c) * 64 + lane];
   const double h = a.uniform_h ? a.h_uniform : a.cell_h[(size_t)shard * 64 + lane];
   bool changed = false;
-#ifdef DFLO_LIM_LOADONLY
-  {
-    double sacc = A[0] + A[1] + A[2] + A[3];
-#pragma unroll
-    for (int d = 0; d < NDOF; ++d) sacc += U[d];
-    if (sacc != 1.2345e300) return;
-  }
-#endif
 
   if (a.tvb && marked && (!a.shock || a.shock[(size_t)shard * 64 + lane] > 1.0)) {  // src/limiter.cc:263,406
     const double dx = h;  // diameter/sqrt(2) of a square

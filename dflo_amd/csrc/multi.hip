@@ -48,6 +48,7 @@
 
 #include "../../include/dflo_hip.h"
 #include "basis.h"
+#include "tunables.h"
 
 namespace {
 
@@ -838,8 +839,8 @@ int check_all(dflo_hip_multi *m, bool synchronise) { return agree(m, check_local
 
 // the device groups of the local parts and their streams (parts[i].index / .device are set)
 int make_groups(dflo_hip_multi *m) {
-  const char *e = std::getenv("DFLO_MULTI_GROUP");
-  const int per_device = (e && std::strcmp(e, "part") == 0) ? 1 << 20 : ((e && std::strcmp(e, "device") == 0) ? 1 : 2);   // groups a device may have
+  const int mode = dflo::read_tunables().group;
+  const int per_device = mode == 1 ? 1 << 20 : (mode == 2 ? 1 : 2);   // groups a device may have
   for (size_t i = 0; i < m->parts.size(); ++i) {
     Part &p = m->parts[i];
     int gi = -1, on_dev = 0, fewest = 1 << 30;
@@ -999,11 +1000,9 @@ void finish_setup(dflo_hip_multi *m) {
   // who reads the average of a ghost cell: the LxF flux (lambda from the cell averages, src/equation.h:357-359) and the TVB
   // limiter's differences (src/limiter.cc:284-317); without either the 4-double average message is not sent at all
   m->need_avg = m->prm.flux_type == DFLO_FLUX_LXF || m->tvb;
-  if (const char *e = std::getenv("DFLO_MULTI_AVG")) m->need_avg = m->need_avg || std::atoi(e) != 0;
   // is there a limiter pass of its own between update and pack?  (positivity alone on Qk is applied inside the stage kernel
   // unless DFLO_FUSE_POS=0 says otherwise)
-  const char *e = std::getenv("DFLO_FUSE_POS");
-  const bool fused = m->prm.pos_lim && !m->tvb && m->basis == DFLO_BASIS_QK && !(e && e[0] == '0');
+  const bool fused = m->prm.pos_lim && !m->tvb && m->basis == DFLO_BASIS_QK && dflo::read_tunables().fuse_pos;
   m->sep_limiter = m->limited && !fused;
 }
 
@@ -1058,8 +1057,9 @@ int dflo_hip_multi_create(const dflo_mesh_t *mesh, const dflo_params_t *params, 
   m->n_parts = n_devices;
   int rc = create_common(mesh, params, m);
   if (rc) return bail(rc);
-  if (const char *e = std::getenv("DFLO_MULTI_TRANSPORT")) m->loopback = std::strcmp(e, "rccl_loopback") == 0;
-  if (const char *e = std::getenv("DFLO_MULTI_STRICT")) m->strict = std::atoi(e) != 0;
+  const dflo::Tunables tun = dflo::read_tunables();
+  m->loopback = tun.loopback;
+  m->strict = tun.strict;
   m->parts.resize(n_devices);
   m->sync.reset(new Sync[n_devices]);
   for (int i = 0; i < n_devices; ++i) {
@@ -1067,7 +1067,7 @@ int dflo_hip_multi_create(const dflo_mesh_t *mesh, const dflo_params_t *params, 
     m->parts[i].device = device_ids[i];
     m->parts[i].sy = &m->sync[i];
   }
-  if (const char *e = std::getenv("DFLO_MULTI_COPY")) m->direct = std::atoi(e) == 0;
+  m->direct = !tun.copy;
   if ((rc = make_groups(m))) return bail(rc);
   for (int i = 0; i < n_devices; ++i)
     if ((rc = setup_part(m, m->parts[i], mesh, params, partitioner))) return bail(rc);
@@ -1103,8 +1103,7 @@ int dflo_hip_multi_create(const dflo_mesh_t *mesh, const dflo_params_t *params, 
   finish_setup(m);
   {  // one host thread per device group (DFLO_MULTI_THREADS=0: the calling thread drives them all); RCCL group calls on one
      // communicator must not come from several threads at once, so the loopback test transport stays on the calling thread
-    const char *e = std::getenv("DFLO_MULTI_THREADS");
-    if (m->groups.size() > 1 && !m->loopback && !(e && e[0] == '0')) {
+    if (m->groups.size() > 1 && !m->loopback && tun.threads) {
       for (size_t i = 0; i < m->groups.size(); ++i) {
         m->workers.emplace_back(new Worker);
         Worker *w = m->workers.back().get();
@@ -1450,13 +1449,13 @@ int dflo_hip_multi_advance(dflo_hip_multi_handle m, int n_steps, double *elapsed
   double dt0 = 0.0;
   int rc = dflo_hip_multi_compute_dt(m, *elapsed_time_inout, &dt0);   // host value for the first step only
   if (rc) return rc;   // (compute_dt ends in a collective of its own: the ranks fail or pass together)
-  m->verbose = std::getenv("DFLO_MULTI_VERBOSE") != nullptr;
+  m->verbose = dflo::read_tunables().multi_verbose;
   for (double &t : m->t_phase) t = 0.0;
   const auto t_issue0 = std::chrono::steady_clock::now();
   rc = advance_body(m, n_steps, dt0);
   const auto t_issue1 = std::chrono::steady_clock::now();
   if (!rc) rc = sync_all(m);
-  if (std::getenv("DFLO_MULTI_VERBOSE")) {   // how far ahead of the devices the host runs
+  if (m->verbose) {   // how far ahead of the devices the host runs
     const auto t2 = std::chrono::steady_clock::now();
     std::fprintf(stderr, "dflo_hip_multi_advance: %d steps, host issued them in %.3f ms, devices done after %.3f ms\n", n_steps,
                  std::chrono::duration<double, std::milli>(t_issue1 - t_issue0).count(), std::chrono::duration<double, std::milli>(t2 - t_issue0).count());

@@ -1,5 +1,6 @@
 // plan.cc -- builds the shard / face index layout (see plan.h).
 #include "plan.h"
+#include "tunables.h"
 
 #include <algorithm>
 #include <cmath>
@@ -137,7 +138,7 @@ int build_plan(const dflo_mesh_t &mesh, int shard_ex, int shard_ey, Plan &p, std
       }
       return k;
     };
-    const int n_pass = std::getenv("DFLO_PLAN_REFINE") ? std::atoi(std::getenv("DFLO_PLAN_REFINE")) : 8;   // developer switch
+    const int n_pass = read_tunables().plan_refine;
     for (int pass = 0; pass < n_pass; ++pass) {
       std::unordered_map<uint64_t, std::vector<std::pair<int, int32_t>>> want;   // (from, to) -> (gain, cell)
       for (int c = 0; c < n_owned; ++c) {

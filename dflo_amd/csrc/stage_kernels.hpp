@@ -5,12 +5,12 @@
 
 namespace dflo {
 
-#ifndef DFLO_Q3_WAVES
-#define DFLO_Q3_WAVES 3   // wavefronts per SIMD the first-stage Q3 kernel on squares is built for (3: 168 registers)
-#endif
-#ifndef DFLO_PK_LEAN_LATER
-#define DFLO_PK_LEAN_LATER 1   // P3: the later stages built like the first one (3 wavefronts per SIMD: 161 registers, no spills; 0: 225 registers, 2 wavefronts)
-#endif
+// Wavefronts per SIMD the kernels are built for (register budgets: 3 -> 168, 2 -> 256).  Measured alternatives: Q2 at 4 (128
+// registers: own row read back from LDS, later stages 190 -> 206 us), Q3 later stages at 3 (111 -> 118 us), P3 later stages at 2
+// (225 registers: P3 KFVS 98 000 instead of 114 000 MDoF/s).
+constexpr int kQ3FirstStageWaves = 3;   // first-stage Q3 kernel on squares: own row and own G row read back from the LDS image
+constexpr int kQ2Waves = 3;
+constexpr bool kPkLeanLater = true;     // P3: the later stages built like the first one (161 registers, no spills)
 // ------------------------------------------------------------------ the stage kernel
 // One workgroup of N wavefronts per shard: lane = cell, wavefront = node row b of the (k+1)^2
 // collocation nodes, so control flow is wave-uniform and every global access is a coalesced
@@ -67,41 +67,6 @@ __device__ __forceinline__ void row_update(const StageArgs &a, double *Us, const
     }
   }
   __syncthreads();
-#ifdef DFLO_MFMA_Y
-  if constexpr (N == 4) {
-    // A/B experiment (north_star: "MFMA only for the dense per-element basis contractions at higher order"): the eta
-    // contraction  O[c][aa][B] = sum_q G[c][aa, q] DW[q][B]  of one cell is four 4 x 4 x 4 products (one per component),
-    // which is exactly one v_mfma_f64_4x4x4_4b_f64 (4 blocks).  Operand layout measured with
-    // tools/mfma_4x4_layout_probe.hip: A_b[i][k] in lane 16 k + 4 b + i, B_b[k][n] in lane 16 k + 4 b + n, D_b[i][n] in
-    // lane 16 i + 4 b + n.  With b = component, i = node aa, k = row q, n = target row B, wave w takes the cells
-    // 16 w .. 16 w + 15: lane l fetches G[c][aa, q] of the cell from column `cell` of the LDS image (a gather over the 64
-    // rows), the matrix pipe forms the products for all four target rows at once, and the result goes back into the same
-    // column (in place: a column belongs to one wave); after a barrier every wave reads its own 16 sums lane = cell.
-    const int l = lane, w = B;
-    const int ra = (((l >> 2) & 3) * NS + (l & 3) + N * (l >> 4)) * S;          // row of A: c = (l/4)%4, aa = l%4, q = l/16
-    const int rd = ((l & 3) * NS + ((l >> 2) & 3) * N + (l >> 4)) * S;          // row of D: B = l%4, c = (l/4)%4, aa = l/16 -> O[B][c][aa]
-    double bq = CB<N>::t.DW[0][0];
-#pragma unroll
-    for (int k = 0; k < N; ++k)
-#pragma unroll
-      for (int n = 0; n < N; ++n) bq = ((l >> 4) == k && (l & 3) == n) ? CB<N>::t.DW[k][n] : bq;
-    double av[16];
-#pragma unroll
-    for (int jj = 0; jj < 16; ++jj) av[jj] = Us[ra + 16 * w + jj];
-#pragma unroll
-    for (int jj = 0; jj < 16; ++jj) av[jj] = __builtin_amdgcn_mfma_f64_4x4x4f64(av[jj], bq, 0.0, 0, 0, 0);
-#pragma unroll
-    for (int jj = 0; jj < 16; ++jj) Us[rd + 16 * w + jj] = av[jj];
-    __syncthreads();
-#pragma unroll
-    for (int aa = 0; aa < N; ++aa) {
-      const double wah = CB<N>::t.w[aa] * h;
-#pragma unroll
-      for (int c = 0; c < 4; ++c) R[c][aa] += wah * Us[(B * NS + c * N + aa) * S + lane];
-    }
-  } else
-#endif
-  {
   int ln = lane;
 #pragma unroll
   for (int aa = 0; aa < N; ++aa) {
@@ -119,7 +84,6 @@ __device__ __forceinline__ void row_update(const StageArgs &a, double *Us, const
         R[c][aa] += gy * (wah * CB<N>::t.DW[q][B]);
       }
     }
-  }
   }
   // face terms (:209-244, :344-423): - flux * phi * JxW on the integrating side, + on the other
   if (active) {
@@ -499,10 +463,7 @@ __device__ __forceinline__ void flux_phase(const StageArgs &a, const double *Us,
 //         the caches (measured: C2 +2 %, C4 +3 %; with the Q1 limiter pass behind it C3 -2 %, hence a variant and not a rule).
 //         A compile-time switch: behind a run-time branch the compiler merges the two store sequences and drops the hint.
 template <int N, int FLUX, int MODE, int GEO, int POS, int STREAM>
-#ifndef DFLO_Q2_WAVES
-#define DFLO_Q2_WAVES 3
-#endif
-__global__ __launch_bounds__(64 * N, (N == 4 && GEO == 0 && MODE == 0) ? DFLO_Q3_WAVES : (((GEO == 1 && N != 3) || N == 4) ? 2 : (N == 3 && GEO == 0 ? DFLO_Q2_WAVES : 3))) void stage_kernel(const StageArgs a) {
+__global__ __launch_bounds__(64 * N, (N == 4 && GEO == 0 && MODE == 0) ? kQ3FirstStageWaves : (((GEO == 1 && N != 3) || N == 4) ? 2 : (N == 3 && GEO == 0 ? kQ2Waves : 3))) void stage_kernel(const StageArgs a) {
   constexpr int NS = N * N, NDOF = 4 * NS, NT = 64 * N;
   constexpr int ROWS = NDOF + (FLUX == DFLO_FLUX_LXF ? 3 : 0);   // LxF: (u, v, c) of the cell average ride along
   constexpr int TROWS = 4 * N;                                   // trace / flux table: (component, point) rows
@@ -523,9 +484,6 @@ __global__ __launch_bounds__(64 * N, (N == 4 && GEO == 0 && MODE == 0) ? DFLO_Q3
   int *Bk = (int *)(Bv + a.max_bnd * 4 * N);          // [max_bnd] boundary kinds
   double *Vx = (double *)(Bk + ((a.max_bnd + 1) & ~1)); // GEO 1: [4][2][64] outward unit normals of the own cells' faces
 
-#ifdef DFLO_PHASE_TIMING
-  unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
-#endif
   // ---- all loads of the shard, issued back to back; the halo entries first (the halo values depend on them)
   // halo entries: thread t works on entry (t & 31) + 32 b of every block b of 32 entries (8x8 lattice shards have one
   // block, unstructured shards two or three): load them all now, the gathers below then depend on nothing else
@@ -586,7 +544,6 @@ __global__ __launch_bounds__(64 * N, (N == 4 && GEO == 0 && MODE == 0) ? DFLO_Q3
       }
   }
 
-  PHASE_MARK(0);
   // ---- phase A: own rows -> LDS; halo: only the trace on the shared face is kept.
   //      halo item i -> (entry s = i % nh, q = (i / nh) % N, comp = i / (nh N)); an entry is
   //      (internal cell slot | local face << 28) of a face neighbour outside the shard
@@ -672,15 +629,11 @@ __global__ __launch_bounds__(64 * N, (N == 4 && GEO == 0 && MODE == 0) ? DFLO_Q3
       Bv[i] = a.bval[(size_t)bf * 4 * N + k2];
     }
   }
-  PHASE_MARK(1);
   __syncthreads();
-  PHASE_MARK(2);
 
   // ---- phase B
   flux_phase<N, FLUX, GEO>(a, Us, Th, Av, frr, fp, Bv, Bk, Vx, HS, nf, nh, tid);
-  PHASE_MARK(3);
   __syncthreads();
-  PHASE_MARK(4);
 
   // ---- phase C: volume + lifting + RK update of node row `row`
   double *Fh = Th;   // the fluxes, as the row updates read them
@@ -704,10 +657,8 @@ __global__ __launch_bounds__(64 * N, (N == 4 && GEO == 0 && MODE == 0) ? DFLO_Q3
     if (row == 0) DFLO_ROW(0); else if (row == 1) DFLO_ROW(1); else if (row == 2) DFLO_ROW(2); else DFLO_ROW(3);
   }
 #undef DFLO_ROW
-  PHASE_MARK(5);
   if constexpr (MODE == 2) return;
   __syncthreads();
-  PHASE_MARK(6);
   if constexpr (POS == 1 && MODE != 2) {
     // ---- apply_positivity_limiter (src/positivity.cc:17-208) on the new state.
     //      First a bound that settles almost every cell: the limiter looks at the solution on lines through the Gauss nodes
@@ -980,11 +931,6 @@ __global__ __launch_bounds__(64 * N, (N == 4 && GEO == 0 && MODE == 0) ? DFLO_Q3
       if (have_dt) a.shard_dtmin[shard] = dtmin;
     }
   }
-  PHASE_MARK(7);
-#ifdef DFLO_PHASE_TIMING
-  if (lane == 0 && a.phase_cycles)
-    for (int i = 0; i < 8; ++i) a.phase_cycles[((size_t)blockIdx.x * 4 + row) * 8 + i] = tacc[i];
-#endif
 }
 
 // =====================================================================================================
@@ -1028,7 +974,7 @@ __device__ __forceinline__ void row_update_pk(const StageArgs &a, double *Us, co
     for (int m = 0; m < N; ++m) R[c][m] = 0.0;
   // P3, first stage (LEAN, as in row_update): built for 3 wavefronts per SIMD -- the nodal values of the own row and the own G
   // row come back from the LDS image instead of being held in registers, the G values are taken node by node
-  constexpr bool LEAN = N == 4 && (MODE == 0 || (MODE == 1 && DFLO_PK_LEAN_LATER));
+  constexpr bool LEAN = N == 4 && (MODE == 0 || (MODE == 1 && kPkLeanLater));
   double Gown[N][4];
 #pragma unroll
   for (int aa = 0; aa < N; ++aa) {
@@ -1153,7 +1099,7 @@ __device__ __forceinline__ void row_update_pk(const StageArgs &a, double *Us, co
 }
 
 template <int N, int FLUX, int MODE, int STREAM>
-__global__ __launch_bounds__(64 * N, N == 4 ? (((MODE == 0 || (MODE == 1 && DFLO_PK_LEAN_LATER)) && FLUX != DFLO_FLUX_LXF) ? DFLO_Q3_WAVES : 2) : 3) void stage_kernel_pk(const StageArgs a) {
+__global__ __launch_bounds__(64 * N, N == 4 ? (((MODE == 0 || (MODE == 1 && kPkLeanLater)) && FLUX != DFLO_FLUX_LXF) ? kQ3FirstStageWaves : 2) : 3) void stage_kernel_pk(const StageArgs a) {
   constexpr int NS = N * N, NM = N * (N + 1) / 2, NDOFM = 4 * NM, NT = 64 * N, MS = (NM + N - 1) / N;
   constexpr int ROWS = 4 * NS + (FLUX == DFLO_FLUX_LXF ? 3 : 0);
   constexpr int TROWS = 4 * N;

@@ -1,0 +1,62 @@
+// tunables.h -- the run-time switches of the engine and of the multi-device driver, read from the environment in ONE place.
+// Every switch defaults to the path that measured fastest; the alternatives are kept because tests run both sides of each
+// (a fused path against the separate pass it replaced, a transport against the other).  Measured-and-lost kernel variants
+// are not switches: they live as patches under tools/variants/.
+#pragma once
+#include <cstdlib>
+#include <cstring>
+
+namespace dflo {
+
+struct Tunables {
+  // ---- engine (read at dflo_hip_create)
+  bool graph = false;      // DFLO_GRAPH=1       dflo_hip_advance replays a captured hipGraph of two steps (no gain measured: opt-in)
+  bool sweep = true;       // DFLO_SWEEP=0       every launch walks the shards forward (default: against the previous launch's direction)
+  int stream = -1;         // DFLO_STREAM=0|1    forbid / force streaming stores of the new state (default: when no pass over all cells follows)
+  bool fuse_dtq = true;    // DFLO_FUSE_DTQ=0    bilinear cells: compute_time_step_q by the separate pass instead of the last stage kernel
+  bool fuse_pos = true;    // DFLO_FUSE_POS=0    positivity without TVB on Qk: separate limiter pass instead of inside the stage kernel
+  bool lazy_avg = true;    // DFLO_LAZY_AVG=0    store the cell averages of every stage (default: only when somebody reads them)
+  int lim_mask = -1;       // DFLO_LIM_MASK=0|1  TVB on squares: forbid / force the stage kernel's marks for the limiter pass (default: degree >= 2)
+  bool halo_cells = false; // DFLO_HALO_CELLS=1  multi-device: ghost cells as whole cells instead of face traces
+  bool verbose = false;    // DFLO_VERBOSE=1     print the LDS footprint and the resident workgroups of the stage kernel
+  int plan_refine = 8;     // DFLO_PLAN_REFINE=n swap-refinement passes of the shard plan on unstructured meshes
+  // ---- multi-device driver (read at dflo_hip_multi_create*)
+  int group = 0;           // DFLO_MULTI_GROUP=part|device   1: a stream pair + host thread per part, 2: per device (default 0: per part,
+                           //                                at most two per device)
+  bool threads = true;     // DFLO_MULTI_THREADS=0           the calling thread drives every group
+  bool strict = false;     // DFLO_MULTI_STRICT=1            a sender waits for the receiver's explicit "consumed" event
+  bool copy = false;       // DFLO_MULTI_COPY=1              staging buffer + hipMemcpyPeerAsync instead of pack kernels that write remotely
+  bool loopback = false;   // DFLO_MULTI_TRANSPORT=rccl_loopback   (test hook) the copies through a one-rank RCCL communicator
+  bool multi_verbose = false;   // DFLO_MULTI_VERBOSE=1      dflo_hip_multi_advance reports how far the host ran ahead of the devices
+};
+
+inline Tunables read_tunables() {
+  Tunables t;
+  auto flag = [](const char *name, bool dflt) {
+    const char *e = std::getenv(name);
+    return e ? std::atoi(e) != 0 : dflt;
+  };
+  auto tri = [](const char *name) {
+    const char *e = std::getenv(name);
+    return e ? (e[0] != '0' ? 1 : 0) : -1;
+  };
+  t.graph = flag("DFLO_GRAPH", false);
+  t.sweep = flag("DFLO_SWEEP", true);
+  t.stream = tri("DFLO_STREAM");
+  t.fuse_dtq = flag("DFLO_FUSE_DTQ", true);
+  t.fuse_pos = flag("DFLO_FUSE_POS", true);
+  t.lazy_avg = flag("DFLO_LAZY_AVG", true);
+  t.lim_mask = tri("DFLO_LIM_MASK");
+  t.halo_cells = flag("DFLO_HALO_CELLS", false);
+  t.verbose = std::getenv("DFLO_VERBOSE") != nullptr;
+  if (const char *e = std::getenv("DFLO_PLAN_REFINE")) t.plan_refine = std::atoi(e);
+  if (const char *e = std::getenv("DFLO_MULTI_GROUP")) t.group = std::strcmp(e, "part") == 0 ? 1 : (std::strcmp(e, "device") == 0 ? 2 : 0);
+  t.threads = flag("DFLO_MULTI_THREADS", true);
+  t.strict = flag("DFLO_MULTI_STRICT", false);
+  t.copy = flag("DFLO_MULTI_COPY", false);
+  if (const char *e = std::getenv("DFLO_MULTI_TRANSPORT")) t.loopback = std::strcmp(e, "rccl_loopback") == 0;
+  t.multi_verbose = std::getenv("DFLO_MULTI_VERBOSE") != nullptr;
+  return t;
+}
+
+}  // namespace dflo

@@ -2,7 +2,7 @@
 cycles each stage-kernel phase takes per shard iteration (wave 0 of every workgroup)."""
 import ctypes as C, os, subprocess, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 csrc = os.path.join(ROOT, "dflo_amd", "csrc")
 real = os.path.join(ROOT, "dflo_amd", "libdflo_hip.so")
