@@ -378,7 +378,7 @@ def main():
         if os.path.exists(tf):
             try:
                 rec = json.load(open(tf))
-                key = "%s_q%d_%s_%d" % (args.config, args.degree, args.flux, args.nx)
+                key = "%s_%s%d_%s_%d" % (args.config, args.basis[0].lower(), args.degree, args.flux, args.nx)
                 traffic = rec.get(key, {}).get("hbm_bytes_per_launch")
                 traffic_src = rec.get(key, {}).get("source")
             except Exception:

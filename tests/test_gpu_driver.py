@@ -480,7 +480,7 @@ def test_forward_step_c5_style(tmp_path):
     assert abs(dm - 4.2 * (1.0 - 0.8) * (t1 - t0)) < 2e-3 * 4.2 * (t1 - t0)
 
 
-@pytest.mark.parametrize("extra", [[], ["--config", "c3"], ["--config", "c5", "--nx", "8"]])
+@pytest.mark.parametrize("extra", [[], ["--config", "c3"], ["--config", "c5", "--nx", "8"], ["--scaling", "strong", "--nx", "128", "--parts-per-gpu", "2"]])
 def test_bench_line_contract(extra):
     """bench.py prints ONE JSON line with the fields of the driver's contract (metric / value / unit / n_gpus / steps / warmup /
     ms_per_step / higher_is_better / scaling / vs_baseline / dtype / data / config.workload) plus `roofline` and, at N = 1,
@@ -500,7 +500,9 @@ def test_bench_line_contract(extra):
               "dtype", "data", "config", "roofline"):
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 4 and d["warmup"] == 2 and d["higher_is_better"] is True and d["dtype"] == "f64"
-    assert d["vs_baseline"] is None and d["scaling"] == "weak" and "workload" in d["config"] and "model" not in d["config"]
+    assert d["vs_baseline"] is None and d["scaling"] == ("strong" if "strong" in extra else "weak") and "workload" in d["config"] and "model" not in d["config"]
+    if "strong" in extra:
+        assert "strong scaling" in d["config"]["workload"] and d["config"]["n_dofs"] == 128 * 128 * 36
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
     assert d["value"] > 0 and abs(d["value"] - d["config"]["n_dofs"] * d["config"]["n_rk"] / (d["ms_per_step"] * 1e-3) / 1e6) <= 1e-6 * d["value"]
