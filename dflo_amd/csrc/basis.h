@@ -9,8 +9,8 @@
 
 namespace dflo {
 
-constexpr int kMaxN = 4;     // degree <= 3
-constexpr int kMaxGLL = 3;   // positivity point set: N_g = 2 (k=1), 3 (k=2,3)  src/positivity.cc:43
+constexpr int kMaxN = 6;     // degree <= 5 (DFLO_MAX_DEGREE; the reference takes any degree, src/main.cc:40, its examples use 1..3)
+constexpr int kMaxGLL = 4;   // positivity point set: N_g = 2 (k=1), 3 (k=2,3), 4 (k=4,5)  src/positivity.cc:43
 constexpr int kTrap = 4;     // QIterated(QTrapez,3): 4 points per direction, src/claw.cc:523
 
 struct BasisTables {
@@ -136,6 +136,19 @@ template <> struct GaussLit<4> {
                                   0.1739274225687269286865};
 };
 
+template <> struct GaussLit<5> {
+  static constexpr double x[5] = {0.04691007703066800360118656, 0.2307653449471584544818428, 0.5, 0.7692346550528415455181572,
+                                  0.9530899229693319963988134};
+  static constexpr double w[5] = {0.118463442528094543757132, 0.2393143352496832340206458, 0.2844444444444444444444444,
+                                  0.2393143352496832340206458, 0.118463442528094543757132};
+};
+template <> struct GaussLit<6> {
+  static constexpr double x[6] = {0.03376524289842398609384922, 0.1693953067668677431693002, 0.3806904069584015456847491,
+                                  0.6193095930415984543152509, 0.8306046932331322568306998, 0.9662347571015760139061508};
+  static constexpr double w[6] = {0.08566224618958517252014807, 0.1803807865240693037849168, 0.2339569672863455236949352,
+                                  0.2339569672863455236949352, 0.1803807865240693037849168, 0.08566224618958517252014807};
+};
+
 template <int N>
 struct CBTable {
   double x[N], w[N], iw[N], L0[N], L1[N], D[N][N], DW[N][N];
@@ -186,7 +199,7 @@ struct CB {
 // Q_k, a P_k function is represented exactly by its values at the N x N Gauss nodes and
 //   psi_m = sum_j psi_m(x_j) phi_j      (phi_j: the collocated Q_k Lagrange functions),
 // so the modal residual is T^T times the nodal (Q_k) residual with T[j][m] = psi_m(x_j).
-constexpr double kSqrtOdd[4] = {1.0, 1.7320508075688772935, 2.2360679774997896964, 2.6457513110645905905};
+constexpr double kSqrtOdd[6] = {1.0, 1.7320508075688772935, 2.2360679774997896964, 2.6457513110645905905, 3.0, 3.3166247903553998491};
 constexpr double legendre01(int n, double x) {
   const double t = 2.0 * x - 1.0;
   double p0 = 1.0, p1 = t;

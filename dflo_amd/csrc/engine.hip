@@ -172,12 +172,19 @@ KBasis make_kbasis(const BasisTables &b) {
   return k;
 }
 
+// kernel template K<N> for the engine's N = degree + 1 (the limiter-type kernels are never launched for N = 1)
+#define DFLO_BY_N(n, K) ((n) == 1 ? K<1> : ((n) == 2 ? K<2> : ((n) == 3 ? K<3> : ((n) == 4 ? K<4> : ((n) == 5 ? K<5> : K<6>)))))
+#define DFLO_BY_N2(n, K, P) ((n) <= 2 ? K<2, P> : ((n) == 3 ? K<3, P> : ((n) == 4 ? K<4, P> : ((n) == 5 ? K<5, P> : K<6, P>))))
+#define DFLO_BY_N_LIM(n, K) ((n) <= 2 ? K<2> : ((n) == 3 ? K<3> : ((n) == 4 ? K<4> : ((n) == 5 ? K<5> : K<6>))))
+
 stage_fn pick_pk(int N, int flux, int mode, int nt = 0) {
   switch (N) {
     case 1: return dflo::stage_pk_of_1(flux, mode, nt);
     case 2: return dflo::stage_pk_of_2(flux, mode, nt);
     case 3: return dflo::stage_pk_of_3(flux, mode, nt);
-    default: return dflo::stage_pk_of_4(flux, mode, nt);
+    case 4: return dflo::stage_pk_of_4(flux, mode, nt);
+    case 5: return dflo::stage_pk_of_5(flux, mode, nt);
+    default: return dflo::stage_pk_of_6(flux, mode, nt);
   }
 }
 stage_fn pick_stage(int N, int flux, int mode, int geo, int pos = 0, int nt = 0) {
@@ -185,7 +192,9 @@ stage_fn pick_stage(int N, int flux, int mode, int geo, int pos = 0, int nt = 0)
     case 1: return dflo::stage_of_1(flux, mode, geo, pos, nt);
     case 2: return dflo::stage_of_2(flux, mode, geo, pos, nt);
     case 3: return dflo::stage_of_3(flux, mode, geo, pos, nt);
-    default: return dflo::stage_of_4(flux, mode, geo, pos, nt);
+    case 4: return dflo::stage_of_4(flux, mode, geo, pos, nt);
+    case 5: return dflo::stage_of_5(flux, mode, geo, pos, nt);
+    default: return dflo::stage_of_6(flux, mode, geo, pos, nt);
   }
 }
 
@@ -449,8 +458,8 @@ int launch_indicator(dflo_hip_engine *h, int part) {
   if (a.n_list == 0) return DFLO_OK;
   a.sweep_rev = next_sweep(h, part);
   void (*fn)(const IndArgs);
-  if (h->basis == DFLO_BASIS_PK) fn = h->N == 2 ? indicator_kernel<2, 1> : (h->N == 3 ? indicator_kernel<3, 1> : indicator_kernel<4, 1>);
-  else fn = h->N == 2 ? indicator_kernel<2, 0> : (h->N == 3 ? indicator_kernel<3, 0> : indicator_kernel<4, 0>);
+  if (h->basis == DFLO_BASIS_PK) fn = DFLO_BY_N2(h->N, indicator_kernel, 1);
+  else fn = DFLO_BY_N2(h->N, indicator_kernel, 0);
   hipLaunchKernelGGL(fn, dim3(grid_for(a.n_list)), dim3(64), 0, h->stream, a);
   HIPCHK(h, hipGetLastError());
   return DFLO_OK;
@@ -487,8 +496,8 @@ int launch_limiter(dflo_hip_engine *h, int tvb, int pos, int part, bool stage_da
   if (l.dtq) h->dtq_parts |= part == 0 ? 3 : part;
   if (l.n_list == 0) return DFLO_OK;
   l.sweep_rev = next_sweep(h, part);
-  void (*lf)(const LimArgs) = h->N == 2 ? limiter_kernel<2> : (h->N == 3 ? limiter_kernel<3> : limiter_kernel<4>);
-  if (h->basis == DFLO_BASIS_PK) lf = h->N == 2 ? limiter_pk_kernel<2> : (h->N == 3 ? limiter_pk_kernel<3> : limiter_pk_kernel<4>);
+  void (*lf)(const LimArgs) = DFLO_BY_N_LIM(h->N, limiter_kernel);
+  if (h->basis == DFLO_BASIS_PK) lf = DFLO_BY_N_LIM(h->N, limiter_pk_kernel);
   hipLaunchKernelGGL(lf, dim3(grid_for(l.n_list)), dim3(64), 0, h->stream, l);
   HIPCHK(h, hipGetLastError());
   return DFLO_OK;
@@ -571,7 +580,7 @@ int launch_stage(dflo_hip_engine *h, int rk, double dt_host, double *rhs_out, in
 
 void launch_dt_q(dflo_hip_engine *h) {
   const Plan &p = h->plan;
-  auto fn = h->N == 1 ? dt_q_kernel<1> : (h->N == 2 ? dt_q_kernel<2> : (h->N == 3 ? dt_q_kernel<3> : dt_q_kernel<4>));
+  auto fn = DFLO_BY_N(h->N, dt_q_kernel);
   hipLaunchKernelGGL(fn, dim3(p.n_shards), dim3(64), 0, h->stream, (const double *)h->U[h->cur], (const double *)h->d_cell_h,
                      (const int32_t *)h->d_shard_count, h->shard_dtmin, h->kb, h->prm.cfl, h->degree, h->d_dt_cell);
 }
@@ -588,7 +597,7 @@ int launch_average(dflo_hip_engine *h) {
 int launch_face_traces(dflo_hip_engine *h, double *out, const int32_t *slots, const int32_t *faces, int n) {
   if (n == 0) return DFLO_OK;
   const long long tot = (long long)n * 4 * h->N;
-  auto fn = h->N == 1 ? face_trace_kernel<1> : (h->N == 2 ? face_trace_kernel<2> : (h->N == 3 ? face_trace_kernel<3> : face_trace_kernel<4>));
+  auto fn = DFLO_BY_N(h->N, face_trace_kernel);
   hipLaunchKernelGGL(fn, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, out, (const double *)h->U[h->cur], slots, faces, n);
   HIPCHK(h, hipGetLastError());
   return DFLO_OK;
@@ -644,7 +653,7 @@ int dflo_hip_create(const dflo_mesh_t *mesh, const dflo_params_t *params, int de
   if (!mesh || !params || !out) { g_create_error = "null argument"; return DFLO_ERR_BAD_PARAM; }
   *out = nullptr;
   // consistency checks of the reference's parameter parsing (src/parameters.cc:536-550)
-  if (mesh->degree < 0 || mesh->degree > DFLO_MAX_DEGREE) { g_create_error = "degree must be 0..3"; return DFLO_ERR_BAD_PARAM; }
+  if (mesh->degree < 0 || mesh->degree > DFLO_MAX_DEGREE) { g_create_error = "degree must be 0..5"; return DFLO_ERR_BAD_PARAM; }
   if (mesh->basis != DFLO_BASIS_QK && mesh->basis != DFLO_BASIS_PK) { g_create_error = "unknown basis"; return DFLO_ERR_BAD_PARAM; }
   if (mesh->basis == DFLO_BASIS_PK && mesh->mapping != DFLO_MAP_CARTESIAN) {
     g_create_error = "Pk basis is implemented for cartesian mapping only";
@@ -1462,7 +1471,7 @@ int dflo_hip_pack_send_to(dflo_hip_handle h, int kind, int n_segments, const int
   if (first[0] != 0 || first[n_segments] != n) { h->err = "pack_send_to: the segments must cover the send list"; return DFLO_ERR_COMM; }
   if (kind == 2) {
     const long long tot = (long long)n * 4 * h->N;
-    auto fn = h->N == 1 ? face_trace_to_kernel<1> : (h->N == 2 ? face_trace_to_kernel<2> : (h->N == 3 ? face_trace_to_kernel<3> : face_trace_to_kernel<4>));
+    auto fn = DFLO_BY_N(h->N, face_trace_to_kernel);
     hipLaunchKernelGGL(fn, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, seg, (const double *)h->U[h->cur],
                        (const int32_t *)h->d_sendf_slot, (const int32_t *)h->d_sendf_face, n);
   } else {

@@ -959,7 +959,7 @@ int setup_part(dflo_hip_multi *m, Part &p, const dflo_mesh_t *mesh, const dflo_p
 
 int create_common(const dflo_mesh_t *mesh, const dflo_params_t *prm, dflo_hip_multi *m) {
   if (mesh->n_owned_cells != mesh->n_cells) { m->err = "the mesh handed to the multi-device driver must be the undivided one"; return DFLO_ERR_BAD_PARAM; }
-  if (mesh->degree < 0 || mesh->degree > DFLO_MAX_DEGREE) { m->err = "degree must be 0..3"; return DFLO_ERR_BAD_PARAM; }
+  if (mesh->degree < 0 || mesh->degree > DFLO_MAX_DEGREE) { m->err = "degree must be 0..5"; return DFLO_ERR_BAD_PARAM; }
   m->prm = *prm;
   if (mesh->degree == 0) {   // the limiters return at once for piecewise constants (as in the engines)
     m->prm.limiter_type = DFLO_LIMITER_NONE;

@@ -1,15 +1,23 @@
-// stage_inst.hip -- the stage kernels of ONE polynomial degree: compiled three times by build() with -DDFLO_STAGE_N=2|3|4
+// stage_inst.hip -- the stage kernels of ONE polynomial degree: compiled by build() with -DDFLO_STAGE_N=1..6
 // (5 fluxes x 3 modes x 2 geometries x the limiter variants, Qk and Pk, take most of the compile time; the translation
 // units are built in parallel with engine.hip, which holds everything else and reaches the kernels through stage_of_N).
+// For N = 5, 6 (degrees 4, 5: four minutes of compile time per degree) the unit is cut once more, by flux: with
+// -DDFLO_STAGE_FLUX=f it holds the kernels of that flux only (stage_of_N_f / stage_pk_of_N_f).
 #include "stage_kernels.hpp"
 
 #ifndef DFLO_STAGE_N
-#error "compile with -DDFLO_STAGE_N=1, 2, 3 or 4"
+#error "compile with -DDFLO_STAGE_N=1 .. 6"
 #endif
 #define DFLO_CAT_(a, b) a##b
 #define DFLO_CAT(a, b) DFLO_CAT_(a, b)
+#define DFLO_CAT4(a, b, c, d) DFLO_CAT(DFLO_CAT(a, b), DFLO_CAT(c, d))
 
 namespace dflo {
+#ifdef DFLO_STAGE_FLUX
+stage_fn DFLO_CAT4(stage_of_, DFLO_STAGE_N, _f, DFLO_STAGE_FLUX)(int mode, int geo, int pos, int nt) { return pick_stage_m<DFLO_STAGE_N, DFLO_STAGE_FLUX>(mode, geo, pos, nt); }
+stage_fn DFLO_CAT4(stage_pk_of_, DFLO_STAGE_N, _f, DFLO_STAGE_FLUX)(int mode, int nt) { return pick_pk_m<DFLO_STAGE_N, DFLO_STAGE_FLUX>(mode, nt); }
+#else
 stage_fn DFLO_CAT(stage_of_, DFLO_STAGE_N)(int flux, int mode, int geo, int pos, int nt) { return pick_stage_n<DFLO_STAGE_N>(flux, mode, geo, pos, nt); }
 stage_fn DFLO_CAT(stage_pk_of_, DFLO_STAGE_N)(int flux, int mode, int nt) { return pick_pk_n<DFLO_STAGE_N>(flux, mode, nt); }
+#endif
 }  // namespace dflo

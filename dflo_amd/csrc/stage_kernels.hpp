@@ -357,6 +357,8 @@ __device__ __forceinline__ int face_of_point(int p, int nf, int &q) {
   }
   q = p >= nf ? 1 : 0;
   if constexpr (N > 3) q += (p >= 2 * nf ? 1 : 0) + (p >= 3 * nf ? 1 : 0);
+  if constexpr (N > 4) q += p >= 4 * nf ? 1 : 0;
+  if constexpr (N > 5) q += p >= 5 * nf ? 1 : 0;
   return p - q * nf;
 }
 template <int N>
@@ -463,7 +465,7 @@ __device__ __forceinline__ void flux_phase(const StageArgs &a, const double *Us,
 //         the caches (measured: C2 +2 %, C4 +3 %; with the Q1 limiter pass behind it C3 -2 %, hence a variant and not a rule).
 //         A compile-time switch: behind a run-time branch the compiler merges the two store sequences and drops the hint.
 template <int N, int FLUX, int MODE, int GEO, int POS, int STREAM>
-__global__ __launch_bounds__(64 * N, (N == 4 && GEO == 0 && MODE == 0) ? kQ3FirstStageWaves : (((GEO == 1 && N != 3) || N == 4) ? 2 : (N == 3 && GEO == 0 ? kQ2Waves : 3))) void stage_kernel(const StageArgs a) {
+__global__ __launch_bounds__(64 * N, N >= 5 ? 1 : ((N == 4 && GEO == 0 && MODE == 0) ? kQ3FirstStageWaves : (((GEO == 1 && N != 3) || N == 4) ? 2 : (N == 3 && GEO == 0 ? kQ2Waves : 3)))) void stage_kernel(const StageArgs a) {
   constexpr int NS = N * N, NDOF = 4 * NS, NT = 64 * N;
   constexpr int ROWS = NDOF + (FLUX == DFLO_FLUX_LXF ? 3 : 0);   // LxF: (u, v, c) of the cell average ride along
   constexpr int TROWS = 4 * N;                                   // trace / flux table: (component, point) rows
@@ -653,8 +655,13 @@ __global__ __launch_bounds__(64 * N, (N == 4 && GEO == 0 && MODE == 0) ? kQ3Firs
     if (row == 0) DFLO_ROW(0); else DFLO_ROW(1);
   } else if constexpr (N == 3) {
     if (row == 0) DFLO_ROW(0); else if (row == 1) DFLO_ROW(1); else DFLO_ROW(2);
-  } else {
+  } else if constexpr (N == 4) {
     if (row == 0) DFLO_ROW(0); else if (row == 1) DFLO_ROW(1); else if (row == 2) DFLO_ROW(2); else DFLO_ROW(3);
+  } else if constexpr (N == 5) {
+    if (row == 0) DFLO_ROW(0); else if (row == 1) DFLO_ROW(1); else if (row == 2) DFLO_ROW(2); else if (row == 3) DFLO_ROW(3); else DFLO_ROW(4);
+  } else {
+    if (row == 0) DFLO_ROW(0); else if (row == 1) DFLO_ROW(1); else if (row == 2) DFLO_ROW(2); else if (row == 3) DFLO_ROW(3);
+    else if (row == 4) DFLO_ROW(4); else DFLO_ROW(5);
   }
 #undef DFLO_ROW
   if constexpr (MODE == 2) return;
@@ -1099,7 +1106,7 @@ __device__ __forceinline__ void row_update_pk(const StageArgs &a, double *Us, co
 }
 
 template <int N, int FLUX, int MODE, int STREAM>
-__global__ __launch_bounds__(64 * N, N == 4 ? (((MODE == 0 || (MODE == 1 && kPkLeanLater)) && FLUX != DFLO_FLUX_LXF) ? kQ3FirstStageWaves : 2) : 3) void stage_kernel_pk(const StageArgs a) {
+__global__ __launch_bounds__(64 * N, N >= 5 ? 1 : (N == 4 ? (((MODE == 0 || (MODE == 1 && kPkLeanLater)) && FLUX != DFLO_FLUX_LXF) ? kQ3FirstStageWaves : 2) : 3)) void stage_kernel_pk(const StageArgs a) {
   constexpr int NS = N * N, NM = N * (N + 1) / 2, NDOFM = 4 * NM, NT = 64 * N, MS = (NM + N - 1) / N;
   constexpr int ROWS = 4 * NS + (FLUX == DFLO_FLUX_LXF ? 3 : 0);
   constexpr int TROWS = 4 * N;
@@ -1168,9 +1175,16 @@ __global__ __launch_bounds__(64 * N, N == 4 ? (((MODE == 0 || (MODE == 1 && kPkL
     if (row == 0) modal_to_row<N, 0>(Us, S, lane, urow); else modal_to_row<N, 1>(Us, S, lane, urow);
   } else if constexpr (N == 3) {
     if (row == 0) modal_to_row<N, 0>(Us, S, lane, urow); else if (row == 1) modal_to_row<N, 1>(Us, S, lane, urow); else modal_to_row<N, 2>(Us, S, lane, urow);
-  } else {
+  } else if constexpr (N == 4) {
     if (row == 0) modal_to_row<N, 0>(Us, S, lane, urow); else if (row == 1) modal_to_row<N, 1>(Us, S, lane, urow);
     else if (row == 2) modal_to_row<N, 2>(Us, S, lane, urow); else modal_to_row<N, 3>(Us, S, lane, urow);
+  } else if constexpr (N == 5) {
+    if (row == 0) modal_to_row<N, 0>(Us, S, lane, urow); else if (row == 1) modal_to_row<N, 1>(Us, S, lane, urow);
+    else if (row == 2) modal_to_row<N, 2>(Us, S, lane, urow); else if (row == 3) modal_to_row<N, 3>(Us, S, lane, urow); else modal_to_row<N, 4>(Us, S, lane, urow);
+  } else {
+    if (row == 0) modal_to_row<N, 0>(Us, S, lane, urow); else if (row == 1) modal_to_row<N, 1>(Us, S, lane, urow);
+    else if (row == 2) modal_to_row<N, 2>(Us, S, lane, urow); else if (row == 3) modal_to_row<N, 3>(Us, S, lane, urow);
+    else if (row == 4) modal_to_row<N, 4>(Us, S, lane, urow); else modal_to_row<N, 5>(Us, S, lane, urow);
   }
   __syncthreads();   // every wave has read the modes: the nodal image may take their place
   // halo: traces of the neighbour's modal expansion on the shared face, psi_m = Pt_i(xi) Pt_j(eta) with one coordinate fixed at
@@ -1250,8 +1264,13 @@ __global__ __launch_bounds__(64 * N, N == 4 ? (((MODE == 0 || (MODE == 1 && kPkL
     if (row == 0) DFLO_ROWPK(0); else DFLO_ROWPK(1);
   } else if constexpr (N == 3) {
     if (row == 0) DFLO_ROWPK(0); else if (row == 1) DFLO_ROWPK(1); else DFLO_ROWPK(2);
-  } else {
+  } else if constexpr (N == 4) {
     if (row == 0) DFLO_ROWPK(0); else if (row == 1) DFLO_ROWPK(1); else if (row == 2) DFLO_ROWPK(2); else DFLO_ROWPK(3);
+  } else if constexpr (N == 5) {
+    if (row == 0) DFLO_ROWPK(0); else if (row == 1) DFLO_ROWPK(1); else if (row == 2) DFLO_ROWPK(2); else if (row == 3) DFLO_ROWPK(3); else DFLO_ROWPK(4);
+  } else {
+    if (row == 0) DFLO_ROWPK(0); else if (row == 1) DFLO_ROWPK(1); else if (row == 2) DFLO_ROWPK(2); else if (row == 3) DFLO_ROWPK(3);
+    else if (row == 4) DFLO_ROWPK(4); else DFLO_ROWPK(5);
   }
 #undef DFLO_ROWPK
   if constexpr (MODE == 2) return;
@@ -1333,9 +1352,33 @@ stage_fn stage_of_1(int flux, int mode, int geo, int pos, int nt);
 stage_fn stage_of_2(int flux, int mode, int geo, int pos, int nt);
 stage_fn stage_of_3(int flux, int mode, int geo, int pos, int nt);
 stage_fn stage_of_4(int flux, int mode, int geo, int pos, int nt);
+// N = 5, 6: one translation unit per flux (stage_inst.hip with -DDFLO_STAGE_FLUX)
+#define DFLO_DECL_BY_FLUX(N)                                                                                                   \
+  stage_fn stage_of_##N##_f0(int, int, int, int); stage_fn stage_of_##N##_f1(int, int, int, int); stage_fn stage_of_##N##_f2(int, int, int, int); \
+  stage_fn stage_of_##N##_f3(int, int, int, int); stage_fn stage_of_##N##_f4(int, int, int, int);                                \
+  stage_fn stage_pk_of_##N##_f0(int, int); stage_fn stage_pk_of_##N##_f1(int, int); stage_fn stage_pk_of_##N##_f2(int, int);    \
+  stage_fn stage_pk_of_##N##_f3(int, int); stage_fn stage_pk_of_##N##_f4(int, int);                                              \
+  inline stage_fn stage_of_##N(int flux, int mode, int geo, int pos, int nt) {                                                   \
+    switch (flux) {                                                                                                              \
+      case 0: return stage_of_##N##_f0(mode, geo, pos, nt); case 1: return stage_of_##N##_f1(mode, geo, pos, nt);                 \
+      case 2: return stage_of_##N##_f2(mode, geo, pos, nt); case 3: return stage_of_##N##_f3(mode, geo, pos, nt);                 \
+      default: return stage_of_##N##_f4(mode, geo, pos, nt);                                                                     \
+    }                                                                                                                            \
+  }                                                                                                                              \
+  inline stage_fn stage_pk_of_##N(int flux, int mode, int nt) {                                                                  \
+    switch (flux) {                                                                                                              \
+      case 0: return stage_pk_of_##N##_f0(mode, nt); case 1: return stage_pk_of_##N##_f1(mode, nt);                               \
+      case 2: return stage_pk_of_##N##_f2(mode, nt); case 3: return stage_pk_of_##N##_f3(mode, nt);                               \
+      default: return stage_pk_of_##N##_f4(mode, nt);                                                                            \
+    }                                                                                                                            \
+  }
+DFLO_DECL_BY_FLUX(5)
+DFLO_DECL_BY_FLUX(6)
+#undef DFLO_DECL_BY_FLUX
 stage_fn stage_pk_of_1(int flux, int mode, int nt);
 stage_fn stage_pk_of_2(int flux, int mode, int nt);
 stage_fn stage_pk_of_3(int flux, int mode, int nt);
 stage_fn stage_pk_of_4(int flux, int mode, int nt);
+
 
 }  // namespace dflo

@@ -35,7 +35,7 @@ extern "C" {
 
 #define DFLO_N_COMP 4
 #define DFLO_MAX_BOUNDARIES 10 /* Parameters::AllParameters::max_n_boundaries, src/parameters.h:370 */
-#define DFLO_MAX_DEGREE 3
+#define DFLO_MAX_DEGREE 5
 
 typedef enum {
   DFLO_OK = 0,

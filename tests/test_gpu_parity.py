@@ -843,7 +843,7 @@ def test_degenerate_meshes_are_refused():
     with pytest.raises(dflo_amd.DfloError):
         dflo_amd.Mesh.from_quads(np.zeros((0, 2)), np.zeros((0, 4), dtype=np.int32), degree=1)
     with pytest.raises(dflo_amd.DfloError):
-        dflo_amd.Mesh.cartesian(4, 4, 0.0, 0.0, 1.0, [-1] * 4, 4)     # degree > 3
+        dflo_amd.Mesh.cartesian(4, 4, 0.0, 0.0, 1.0, [-1] * 4, 6)     # degree > DFLO_MAX_DEGREE (5)
 
 
 # ---------------------------------------------------------------- option matrix
