@@ -860,7 +860,7 @@ int make_groups(dflo_hip_multi *m) {
       // workgroups of the interior launch
       int lo = 0, hi = 0;
       MHIP(m, hipDeviceGetStreamPriorityRange(&lo, &hi));
-      MHIP(m, hipStreamCreateWithPriority(&g.C, hipStreamDefault, hi));
+      MHIP(m, hipStreamCreateWithPriority(&g.C, hipStreamDefault, dflo::read_tunables().comm_priority ? hi : lo));
       hipEvent_t *evs[] = {&g.ev_open, &g.ev_rim, &g.ev_rim_prev, &g.ev_ring, &g.ev_unpack, &g.ev_chunk[0], &g.ev_chunk[1]};
       for (hipEvent_t *ev : evs) MHIP(m, hipEventCreateWithFlags(ev, hipEventDisableTiming));
     }

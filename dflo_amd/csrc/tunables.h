@@ -28,6 +28,7 @@ struct Tunables {
   bool copy = false;       // DFLO_MULTI_COPY=1              staging buffer + hipMemcpyPeerAsync instead of pack kernels that write remotely
   bool loopback = false;   // DFLO_MULTI_TRANSPORT=rccl_loopback   (test hook) the copies through a one-rank RCCL communicator
   bool multi_verbose = false;   // DFLO_MULTI_VERBOSE=1      dflo_hip_multi_advance reports how far the host ran ahead of the devices
+  bool comm_priority = true;    // DFLO_MULTI_PRIORITY=0     the comm stream at the compute stream's priority (default: highest)
 };
 
 inline Tunables read_tunables() {
@@ -56,6 +57,7 @@ inline Tunables read_tunables() {
   t.copy = flag("DFLO_MULTI_COPY", false);
   if (const char *e = std::getenv("DFLO_MULTI_TRANSPORT")) t.loopback = std::strcmp(e, "rccl_loopback") == 0;
   t.multi_verbose = std::getenv("DFLO_MULTI_VERBOSE") != nullptr;
+  t.comm_priority = flag("DFLO_MULTI_PRIORITY", true);
   return t;
 }
 

@@ -1,6 +1,6 @@
 """Randomised differential test, device against oracle: random small meshes (squares / skewed bilinear cells / unstructured
 quadrilaterals), degrees, fluxes, boundary kinds, limiter settings, time-step modes; a few steps each.
-usage: python tools/fuzz_parity.py [n_cases] [seed]     (GPU box; prints the failing configurations)"""
+usage: python tools/fuzz_parity.py [n_cases] [seed] [max_degree = 3]     (GPU box; prints the failing configurations)"""
 import os, sys, time, traceback
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -12,6 +12,7 @@ import oracle_lib
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+max_degree = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 rng = np.random.default_rng(seed)
 KINDS = ["inflow", "outflow", "slip", "pressure", "farfield"]
 
@@ -24,7 +25,7 @@ last = {}
 
 
 def one(i):
-    degree = int(rng.integers(0, 4))
+    degree = int(rng.integers(0, max_degree + 1))
     flux = str(rng.choice(["lxf", "sw", "kfvs", "roe", "hllc"]))
     geo = str(rng.choice(["cart", "cart", "skew", "unstr"]))
     basis = "Pk" if (geo == "cart" and rng.random() < 0.2) else "Qk"
