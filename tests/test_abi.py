@@ -223,3 +223,81 @@ def test_rcb_cuts_compact_blocks():
     verts, quads, bed, bid = gmsh.unstructured_quads(12, seed=3)
     u = dflo_amd.Mesh.from_quads(verts, quads, bed, bid, 1)
     assert cut(u, u.partition_owners(8, "rcb")) < cut(u, u.partition_owners(8, "slab"))
+
+
+def _independent_face_table(mesh):
+    """Face neighbours re-derived from nothing but the flattened cells' vertex coordinates: face f of a cell joins the vertices
+    (0,2), (1,3), (0,1), (2,3) of its lexicographic vertex list (deal.II's reference cell); two cells are neighbours
+    across a face when they hold the same two points; the face points run the opposite way on the two sides when the shared
+    edge is traversed in opposite directions (increasing free coordinate on either side)."""
+    v = np.asarray(mesh.vertices)
+    nc = len(v)
+    ends = np.array([[0, 2], [1, 3], [0, 1], [2, 3]])
+    a = v[:, ends[:, 0], :]                      # [cell][face][xy] first end (free coordinate 0)
+    b = v[:, ends[:, 1], :]
+    # a key per undirected edge: the two end points sorted lexicographically, as exact doubles
+    swap = (a[..., 0] > b[..., 0]) | ((a[..., 0] == b[..., 0]) & (a[..., 1] > b[..., 1]))
+    lo = np.where(swap[..., None], b, a).reshape(-1, 2)
+    hi = np.where(swap[..., None], a, b).reshape(-1, 2)
+    key = np.concatenate([lo, hi], axis=1)
+    order = np.lexsort(key.T[::-1])
+    ks = key[order]
+    same = (ks[1:] == ks[:-1]).all(axis=1)
+    nbr = np.full(nc * 4, -1, dtype=np.int64)
+    nbf = np.zeros(nc * 4, dtype=np.int64)
+    first = np.nonzero(same)[0]
+    assert not (same[1:] & same[:-1]).any()      # no edge shared by three cells
+    i0, i1 = order[first], order[first + 1]
+    nbr[i0], nbr[i1] = i1 // 4, i0 // 4
+    flip = swap.reshape(-1)[i0] != swap.reshape(-1)[i1]
+    nbf[i0] = (i1 % 4) + 4 * flip
+    nbf[i1] = (i0 % 4) + 4 * flip
+    return nbr.reshape(nc, 4), nbf.reshape(nc, 4)
+
+
+@pytest.mark.parametrize("kind", ["tunnel", "square", "lattice"])
+def test_mesh_flattening_against_an_independent_derivation(kind):
+    """The flat mesh the engine AND the oracle consume comes out of dflo_amd/csrc/mesh.cc; this derives its face tables a second
+    time, from the cells' vertex coordinates alone (numpy, edge matching by coordinates), at a size where hand-made fixtures end:
+    neighbours, neighbour faces, flip flags, boundary ids, cell orientation."""
+    from dflo_amd import gmsh
+    if kind == "tunnel":
+        verts, quads, bed, bid = gmsh.forward_step_quads(cl=0.2 / 16, seed=3)      # ~97 000 unstructured quadrilaterals
+        mesh = dflo_amd.Mesh.from_quads(verts, quads, bed, bid, 1)
+    elif kind == "square":
+        verts, quads, bed, bid = gmsh.unstructured_quads(60, seed=5)
+        mesh = dflo_amd.Mesh.from_quads(verts, quads, bed, bid, 2)
+    else:
+        mesh = dflo_amd.Mesh.cartesian(37, 23, -1.0, 2.0, 0.125, [5, 6, 7, 8], 1)
+        verts = quads = None
+    nbr, nbf = _independent_face_table(mesh)
+    got, gotf = np.asarray(mesh.neighbors).astype(np.int64), np.asarray(mesh.neighbor_faces).astype(np.int64)
+    inner = nbr >= 0
+    assert (got[inner] == nbr[inner]).all()
+    assert ((gotf[inner] & 7) == nbf[inner]).all()                 # face seen from the neighbour + 4 * flip
+    assert (got[~inner] < 0).all()                                 # what has no partner is a boundary face
+    v = np.asarray(mesh.vertices)
+    area2 = (v[:, 1, 0] - v[:, 0, 0]) * (v[:, 2, 1] - v[:, 0, 1]) - (v[:, 1, 1] - v[:, 0, 1]) * (v[:, 2, 0] - v[:, 0, 0])
+    assert (area2 > 0).all()                                       # lexicographic vertices of counter-clockwise cells
+    if quads is not None:
+        # the cells are the input's quadrilaterals (as vertex sets), and every boundary face carries the id of the input edge it is
+        want = np.sort(np.asarray(verts)[np.asarray(quads)].reshape(len(quads), -1), axis=1)
+        have = np.sort(v.reshape(len(v), -1), axis=1)
+        assert np.array_equal(have[np.lexsort(have.T[::-1])], want[np.lexsort(want.T[::-1])])
+        ends = np.array([[0, 2], [1, 3], [0, 1], [2, 3]])
+        mid_of = {}
+        for (p, q), b in zip(np.asarray(bed), np.asarray(bid)):
+            m = 0.5 * (np.asarray(verts)[p] + np.asarray(verts)[q])
+            mid_of[(round(m[0], 12), round(m[1], 12))] = int(b)
+        cb, fb = np.nonzero(~inner)
+        assert len(cb) == len(bed)
+        for c, f in zip(cb, fb):
+            m = 0.5 * (v[c, ends[f, 0]] + v[c, ends[f, 1]])
+            assert -1 - got[c, f] == mid_of[(round(m[0], 12), round(m[1], 12))]
+    else:
+        # lattice: ids of (x-min, x-max, y-min, y-max), cells numbered x fastest
+        nx, ny = 37, 23
+        c = np.arange(nx * ny).reshape(ny, nx)
+        assert (-1 - got[c[:, 0], 0] == 5).all() and (-1 - got[c[:, -1], 1] == 6).all()
+        assert (-1 - got[c[0, :], 2] == 7).all() and (-1 - got[c[-1, :], 3] == 8).all()
+        assert (got[c[:, 1:], 0] == c[:, :-1]).all() and (got[c[1:, :], 2] == c[:-1, :]).all()
