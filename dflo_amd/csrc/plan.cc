@@ -3,6 +3,8 @@
 #include "tunables.h"
 
 #include <algorithm>
+#include <climits>
+#include <cstdint>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -177,6 +179,30 @@ int build_plan(const dflo_mesh_t &mesh, int shard_ex, int shard_ey, Plan &p, std
     }
     shard_cells.assign((n_owned + kShard - 1) / kShard, {});
     for (int k = 0; k < n_owned; ++k) shard_cells[sh[keys[k].second]].push_back(keys[k].second);   // Hilbert order inside a shard
+    // ... and then, as on a lattice, the cells on the shard's rim first, grouped by the neighbouring shard they touch: what a
+    // neighbouring shard gathers as halo is then a run of consecutive lanes of every DoF row -- one or two 64-byte sectors per
+    // row instead of one per cell scattered over the row's four lines (a halo load that misses the L2 costs a sector of HBM
+    // traffic for 8 useful bytes; C5 moved 1.15 x its algorithmic bytes).  Stable: cells of a group keep their Hilbert order.
+    if (read_tunables().rim_first) {
+      for (auto &cells : shard_cells) {
+        std::vector<std::pair<int64_t, int32_t>> order(cells.size());
+        for (size_t l = 0; l < cells.size(); ++l) {
+          const int c = cells[l];
+          int64_t foreign = INT64_MAX;   // the neighbouring shard of the cell with the lowest number (none: interior cell, last)
+          for (int f = 0; f < 4; ++f) {
+            const int nb = mesh.cell_face_neighbor[(size_t)c * 4 + f];
+            if (nb < 0) continue;
+            const int64_t s2 = nb < n_owned ? sh[nb] : (int64_t)1 << 40;   // ghost cells: another part's, treated as one far shard
+            if (s2 != sh[c]) foreign = std::min(foreign, s2);
+          }
+          order[l] = {foreign, (int32_t)l};
+        }
+        std::stable_sort(order.begin(), order.end(), [](const std::pair<int64_t, int32_t> &x, const std::pair<int64_t, int32_t> &y) { return x.first < y.first; });
+        std::vector<int32_t> sorted(cells.size());
+        for (size_t l = 0; l < cells.size(); ++l) sorted[l] = cells[order[l].second];
+        cells.swap(sorted);
+      }
+    }
   }
   p.n_shards = (int)shard_cells.size();
   const int n_ghost = n - n_owned;

@@ -20,6 +20,7 @@ struct Tunables {
   bool halo_cells = false; // DFLO_HALO_CELLS=1  multi-device: ghost cells as whole cells instead of face traces
   bool verbose = false;    // DFLO_VERBOSE=1     print the LDS footprint and the resident workgroups of the stage kernel
   int plan_refine = 8;     // DFLO_PLAN_REFINE=n swap-refinement passes of the shard plan on unstructured meshes
+  bool rim_first = true;   // DFLO_PLAN_RIM_FIRST=0  unstructured shards keep the Hilbert order of their cells (default: rim cells first, by neighbouring shard)
   // ---- multi-device driver (read at dflo_hip_multi_create*)
   int group = 0;           // DFLO_MULTI_GROUP=part|device   1: a stream pair + host thread per part, 2: per device (default 0: per part,
                            //                                at most two per device)
@@ -51,6 +52,7 @@ inline Tunables read_tunables() {
   t.halo_cells = flag("DFLO_HALO_CELLS", false);
   t.verbose = std::getenv("DFLO_VERBOSE") != nullptr;
   if (const char *e = std::getenv("DFLO_PLAN_REFINE")) t.plan_refine = std::atoi(e);
+  t.rim_first = flag("DFLO_PLAN_RIM_FIRST", true);
   if (const char *e = std::getenv("DFLO_MULTI_GROUP")) t.group = std::strcmp(e, "part") == 0 ? 1 : (std::strcmp(e, "device") == 0 ? 2 : 0);
   t.threads = flag("DFLO_MULTI_THREADS", true);
   t.strict = flag("DFLO_MULTI_STRICT", false);
