@@ -10,22 +10,24 @@
 //        a cut are integrated by both owners with the same integrating side, bit-identical flux)
 //
 // Two ways to own the devices, one stage schedule:
-//   dflo_hip_multi_create       one process, n_devices engines, one host thread PER PART issuing that part's launches, events and
-//                               copies (a single thread cannot feed more than two or three devices: ~20 API calls per part and
-//                               stage against a stage of ~0.2 ms; DFLO_MULTI_THREADS=0 restores the single-threaded driver); halos
-//                               move with hipMemcpyPeerAsync over xGMI, the time-step minimum is read from the peers' device
-//                               slots (no host hop).  Where one part's stream waits for a peer's event, the host threads are
-//                               sequenced by counters (an event has to be recorded before it can be waited for).
+//   dflo_hip_multi_create       one process, n_devices engines.  A stream pair (compute M, comm C) and a host thread per GROUP
+//                               of parts -- a part with a device of its own is a group, parts that share a device form at most
+//                               two (struct Group below): a single thread cannot feed more than two or three devices (~20 API
+//                               calls per part and stage against a stage of ~0.2 ms; DFLO_MULTI_THREADS=0 restores the
+//                               single-threaded driver).  The pack kernels deliver: they write the halo records straight into
+//                               the peers' receive areas (xGMI peer access); the time-step minimum is read from the peers'
+//                               device slots (no host hop).  Where one group's stream waits for a peer's event, the host
+//                               threads are sequenced by counters (an event has to be recorded before it can be waited for).
 //   dflo_hip_multi_create_rank  one process per GPU (what torchrun / mpirun start); halos move with grouped
 //                               ncclSend/ncclRecv, the time step with an 8-byte ncclAllReduce(min), all on the comm stream.
 //                               RCCL is loaded with dlopen the first time it is needed: single-GPU users do not need it.
-// Every part owns a compute stream M and a comm stream C.  One RK stage:
-//   M: [wait: ghosts of the previous stage unpacked]  rim shards (those that read ghost cells)      -> ev_rim
-//   C: wait ev_rim; (TVB: exchange the rim cells' new averages, wait for the interior update, limit the rim;)
-//      pack the rim cells' DoFs; send to / receive from the face neighbours; unpack into the ghost shards -> ev_unpack
-//   M: interior shards, their limiter, the stage's reductions              (runs while the cells travel)
+// One RK stage of a group (stage_phase below), the rim shards on C next to the interior shards on M:
+//   C: [wait: M's previous stage, the step's time step]  rim shards (those that read ghost cells; TVB: + the ring beside them,
+//      the averages leave, the neighbours' averages arrive, the rim is limited)  -> ev_rim;  the traces of the cut faces leave
+//   M: [wait: ev_rim of the previous stage]  interior shards, their limiter, (last stage: wait ev_rim) the stage's reductions
+//   C: the neighbours' traces arrive in the table the next stage's rim kernel reads
 // This file is host code over the public halo seam of the engine (dflo_hip_stage_open / _update_part / _limit_part /
-// _finish / _pack_send / _unpack_ghost ...): a dflo maintainer with another transport can write the same against the header.
+// _finish / _pack_send* / _unpack_ghost* ...): a dflo maintainer with another transport can write the same against the header.
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>   // types and enums only: the functions are resolved with dlsym
