@@ -314,9 +314,12 @@ int dflo_hip_apply_dt_rules_peers(dflo_hip_handle h, int n_peers, const void *co
  * interior shards are computed.  State, boundary data and results cross this boundary in the numbering of the
  * UNDIVIDED mesh (cells, DoFs, boundary faces in MeshWorker order), exactly as for a single engine.
  *
- *   dflo_hip_multi_create       one process (dflo's serial tree, src/): n_devices engines driven by the calling thread;
- *                               halos by hipMemcpyPeerAsync over xGMI, the time-step minimum by peer reads of device
- *                               slots.  device_ids may repeat (several parts on one device).
+ *   dflo_hip_multi_create       one process (dflo's serial tree, src/): n_devices engines; the driver keeps one host thread
+ *                               and one stream pair per device (per pair of parts where device_ids repeat) to issue the
+ *                               launches, so the caller still calls from ONE thread -- the handle is not thread-safe;
+ *                               halos are written into the peers' receive areas by the pack kernels over xGMI peer access,
+ *                               the time-step minimum comes from peer reads of device slots.  device_ids may repeat
+ *                               (several parts on one device).
  *   dflo_hip_multi_create_rank  one process per GPU (dflo's MPI tree, src_mpi/): this process is part `rank` of n_ranks;
  *                               halos by grouped ncclSend/ncclRecv, the time step by an 8-byte ncclAllReduce(min) on the
  *                               device.  unique_id: DFLO_COMM_ID_BYTES bytes obtained on one rank with
