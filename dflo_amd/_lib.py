@@ -81,7 +81,7 @@ SYMBOLS = [
     "dflo_hip_multi_advance", "dflo_hip_multi_apply_limiter", "dflo_hip_multi_apply_positivity_limiter",
     "dflo_hip_multi_check", "dflo_hip_multi_synchronize", "dflo_hip_multi_stage_timing",
     "dflo_hip_multi_part_mesh", "dflo_hip_multi_set_part_solution", "dflo_hip_pack_send_cells", "dflo_hip_unpack_ghost_cells",
-    "dflo_hip_halo_traces", "dflo_hip_n_ghost_traces", "dflo_hip_set_send_faces", "dflo_hip_pack_send_traces", "dflo_hip_pack_send_to",
+    "dflo_hip_halo_traces", "dflo_hip_n_ghost_traces", "dflo_hip_set_send_faces", "dflo_hip_pack_send_traces", "dflo_hip_pack_send_to", "dflo_hip_ghost_avg_source",
     "dflo_hip_ghost_trace_buffer", "dflo_hip_use_ghost_traces",
 ]
 PARTITIONER = {"slab": 0, "rcb": 1}
@@ -146,6 +146,7 @@ _sig("dflo_hip_halo_traces", C.c_int, _H)
 _sig("dflo_hip_n_ghost_traces", C.c_int, _H)
 _sig("dflo_hip_set_send_faces", C.c_int, _H, C.c_int32, _ip, _ip)
 _sig("dflo_hip_pack_send_traces", C.c_int, _H, C.c_void_p)
+_sig("dflo_hip_ghost_avg_source", C.c_int, _H, C.c_void_p)
 _sig("dflo_hip_pack_send_to", C.c_int, _H, C.c_int, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_void_p))
 _sig("dflo_hip_ghost_trace_buffer", C.c_int, _H, C.c_int, C.POINTER(C.c_void_p))
 _sig("dflo_hip_use_ghost_traces", C.c_int, _H, C.c_int)

@@ -83,6 +83,7 @@ struct dflo_hip_engine {
   double pending_dt = -1.0;
   int32_t *d_send_slots = nullptr;
   int n_send = 0;
+  const double *ghost_avg_src = nullptr;   // dflo_hip_ghost_avg_source: where the Qk limiter pass finds the ghost cells' averages
   // ghost cells known by their face traces (Qk without the KXRCF indicator): two buffers, the stage kernels read Tg[tg_cur]
   // while the neighbours' next traces arrive in the other one
   bool trace_halo = false;
@@ -487,6 +488,8 @@ int launch_limiter(dflo_hip_engine *h, int tvb, int pos, int part, bool stage_da
   l.kb = h->kb;
   l.shock = tvb ? h->d_shock : nullptr;
   l.mask = (stage_data && tvb && h->aux_fresh) ? h->lim_mask : nullptr;
+  l.ghost_avg = h->basis == DFLO_BASIS_QK ? h->ghost_avg_src : nullptr;
+  l.first_ghost_slot = p.n_shards * 64;
   l.dtq = (h->geo == 1 && h->basis == DFLO_BASIS_QK && h->pending_rk == h->n_rk - 1) ? 1 : 0;
   l.shard_dtmin = h->shard_dtmin;
   l.dt_cell = h->d_dt_cell;
@@ -955,6 +958,7 @@ int dflo_hip_set_solution(dflo_hip_handle h, const double *u) {
   const long long tot = (long long)p.n_slots * h->ndof;
   h->cur = h->old = 0;
   h->steps_done = 0;
+  h->ghost_avg_src = nullptr;
   HIPCHK(h, hipMemsetAsync(h->fin_counter + 1, 0, sizeof(int), h->stream));
   for (int i = 0; i < 4; ++i) h->flags_host[i] = 0;   // a new state: the flags of an earlier run are history
   hipLaunchKernelGGL(scatter_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, h->user_buf, h->U[0],
@@ -1521,9 +1525,16 @@ int dflo_hip_unpack_ghost_avg(dflo_hip_handle h, const void *device_buffer) {
   const int n_ghost = p.n_cells - p.n_owned;
   if (n_ghost == 0) return DFLO_OK;
   if (!device_buffer) return DFLO_ERR_BAD_PARAM;
+  h->ghost_avg_src = nullptr;   // the averages are in the array again
   hipLaunchKernelGGL(unpack_ghost_avg_kernel, dim3((n_ghost + 63) / 64), dim3(64), 0, h->stream,
                      (const double *)device_buffer, h->avg[h->avg_cur], p.n_shards * 64, n_ghost);
   HIPCHK(h, hipGetLastError());
+  return DFLO_OK;
+}
+
+int dflo_hip_ghost_avg_source(dflo_hip_handle h, const void *device_buffer) {
+  if (check_handle(h)) return DFLO_ERR_BAD_PARAM;
+  h->ghost_avg_src = (const double *)device_buffer;
   return DFLO_OK;
 }
 

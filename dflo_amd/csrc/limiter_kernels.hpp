@@ -56,6 +56,10 @@ struct LimArgs {
   int sweep_rev;
   const double *shock;  // KXRCF indicator per cell, or null: "shock indicator = limiter" marks every cell (1e20)
   unsigned long long *mask;   // [n_shards] from the stage kernel: the cells this pass can change (cleared here), or null: all cells
+  // multi-device, TVB: the averages of the ghost cells as their owners sent them, [n_ghost][4] in ghost order (the receive area
+  // itself: no unpack kernel between the arrival and this pass), or null: they are in `avg` like everybody's
+  const double *ghost_avg;
+  int first_ghost_slot;
   // bilinear cells, last stage: the time step of the limited solution is formed here, while the cell is in registers
   double *shard_dtmin, *dt_cell;
   double cfl;
@@ -155,8 +159,12 @@ __global__ __launch_bounds__(64) void limiter_kernel(const LimArgs a) {
       const int ib = a.lrbt[((size_t)shard * 4 + 2 * dir) * 64 + lane], ifw = a.lrbt[((size_t)shard * 4 + 2 * dir + 1) * 64 + lane];
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
-        db[c] = ib >= 0 ? A[c] - a.avg[((size_t)(ib >> 6) * 4 + c) * 64 + (ib & 63)] : D0[c];
-        df[c] = ifw >= 0 ? a.avg[((size_t)(ifw >> 6) * 4 + c) * 64 + (ifw & 63)] - A[c] : D0[c];
+        const double ab = (a.ghost_avg && ib >= a.first_ghost_slot) ? a.ghost_avg[(size_t)(ib - a.first_ghost_slot) * 4 + c]
+                                                                    : a.avg[((size_t)(max(ib, 0) >> 6) * 4 + c) * 64 + (max(ib, 0) & 63)];
+        const double af = (a.ghost_avg && ifw >= a.first_ghost_slot) ? a.ghost_avg[(size_t)(ifw - a.first_ghost_slot) * 4 + c]
+                                                                     : a.avg[((size_t)(max(ifw, 0) >> 6) * 4 + c) * 64 + (max(ifw, 0) & 63)];
+        db[c] = ib >= 0 ? A[c] - ab : D0[c];
+        df[c] = ifw >= 0 ? af - A[c] : D0[c];
       }
       if (a.char_lim) {
         to_char(e, dir, db);

@@ -196,6 +196,7 @@ struct dflo_hip_multi {
   std::vector<std::unique_ptr<Worker>> workers;   // one per group; empty: the calling thread drives every part
   bool direct = true;          // one process: the pack kernels write into the peers' receive areas (DFLO_MULTI_COPY=1: staging buffer + hipMemcpyPeerAsync)
   bool need_avg = true;        // somebody reads the ghost cells' averages (LxF flux, TVB limiter): they travel with the traces
+  bool avg_in_place = false;   // TVB without the LxF flux, face-trace halos: only the rim limiter reads ghost averages, from the receive area
   std::atomic<bool> abort{false};                 // a part's thread has failed: the others stop waiting for it
   std::atomic<int64_t> stop_at{INT64_MAX};        // threaded advance: the step at which every thread leaves the loop
   bool strict = false;         // DFLO_MULTI_STRICT=1: a sender waits for an explicit "consumed" event of the receive area
@@ -596,9 +597,15 @@ int stage_phase(dflo_hip_multi *m, Group &g, const StageCtx &s, int ph) {
         int rc = arrive(m, p, CH_AVG, apar);
         if (rc) return rc;
         MENG(m, p, dflo_hip_set_stream(p.eng, g.C));
-        MENG(m, p, dflo_hip_unpack_ghost_avg(p.eng, p.recv_a[apar]));
-        if ((rc = mark_used(m, p, CH_AVG, apar))) return rc;
-        MENG(m, p, dflo_hip_stage_limit_part(p.eng, 1));
+        if (m->avg_in_place) {   // the rim limiter reads the averages where they arrived (nobody else reads a ghost average)
+          MENG(m, p, dflo_hip_ghost_avg_source(p.eng, p.recv_a[apar]));
+          MENG(m, p, dflo_hip_stage_limit_part(p.eng, 1));
+          if ((rc = mark_used(m, p, CH_AVG, apar))) return rc;
+        } else {
+          MENG(m, p, dflo_hip_unpack_ghost_avg(p.eng, p.recv_a[apar]));
+          if ((rc = mark_used(m, p, CH_AVG, apar))) return rc;
+          MENG(m, p, dflo_hip_stage_limit_part(p.eng, 1));
+        }
         rc = send_state(m, p, upar, apar, false);   // the averages have travelled already
         MENG(m, p, dflo_hip_set_stream(p.eng, g.M));
         if (rc) return rc;
@@ -1002,6 +1009,8 @@ void finish_setup(dflo_hip_multi *m) {
   // who reads the average of a ghost cell: the LxF flux (lambda from the cell averages, src/equation.h:357-359) and the TVB
   // limiter's differences (src/limiter.cc:284-317); without either the 4-double average message is not sent at all
   m->need_avg = m->prm.flux_type == DFLO_FLUX_LXF || m->tvb;
+  m->avg_in_place = m->tvb && !m->kxrcf && m->prm.flux_type != DFLO_FLUX_LXF && dflo::read_tunables().avg_in_place;
+  for (Part &p : m->parts) m->avg_in_place = m->avg_in_place && p.trace;
   // is there a limiter pass of its own between update and pack?  (positivity alone on Qk is applied inside the stage kernel
   // unless DFLO_FUSE_POS=0 says otherwise)
   const bool fused = m->prm.pos_lim && !m->tvb && m->basis == DFLO_BASIS_QK && dflo::read_tunables().fuse_pos;

@@ -30,6 +30,8 @@ struct Tunables {
   bool loopback = false;   // DFLO_MULTI_TRANSPORT=rccl_loopback   (test hook) the copies through a one-rank RCCL communicator
   bool multi_verbose = false;   // DFLO_MULTI_VERBOSE=1      dflo_hip_multi_advance reports how far the host ran ahead of the devices
   bool comm_priority = true;    // DFLO_MULTI_PRIORITY=0     the comm stream at the compute stream's priority (default: highest)
+  bool avg_in_place = true;     // DFLO_MULTI_AVG_UNPACK=1   TVB: unpack the received ghost averages into the engine's array before the rim
+                                //                           limiter (default: the limiter reads them where they arrived)
 };
 
 inline Tunables read_tunables() {
@@ -60,6 +62,7 @@ inline Tunables read_tunables() {
   if (const char *e = std::getenv("DFLO_MULTI_TRANSPORT")) t.loopback = std::strcmp(e, "rccl_loopback") == 0;
   t.multi_verbose = std::getenv("DFLO_MULTI_VERBOSE") != nullptr;
   t.comm_priority = flag("DFLO_MULTI_PRIORITY", true);
+  t.avg_in_place = !flag("DFLO_MULTI_AVG_UNPACK", false);
   return t;
 }
 

@@ -268,6 +268,12 @@ int dflo_hip_pack_send(dflo_hip_handle h, void *device_buffer);
 int dflo_hip_pack_send_avg(dflo_hip_handle h, void *device_buffer);
 int dflo_hip_unpack_ghost(dflo_hip_handle h, const void *device_buffer);     /* also recomputes ghost averages */
 int dflo_hip_unpack_ghost_avg(dflo_hip_handle h, const void *device_buffer);
+/* Instead of unpack_ghost_avg: the limiter passes that follow (Qk) read the ghost cells' averages straight from the received
+ * buffer ([n_ghost][4], ghost order) -- one small kernel less between the arrival of the averages and the limiter of the rim
+ * cells, the stretch of a TVB stage that every neighbour waits for.  NULL, or the next dflo_hip_unpack_ghost_avg /
+ * dflo_hip_unpack_ghost_cells / dflo_hip_set_solution, returns to the averages held by the engine.  Not for runs whose stage
+ * kernels read ghost averages too (LxF flux). */
+int dflo_hip_ghost_avg_source(dflo_hip_handle h, const void *device_buffer);
 /* DoFs and cell average of every listed cell in one record, [n][ndof + 4]: the ghost copy then holds the bits of its owner
  * (an average formed again from the DoFs differs from the stage kernel's in the last place; the LxF flux and the TVB
  * differences read it).  What the native multi-device driver ships. */
