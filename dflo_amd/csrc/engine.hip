@@ -662,7 +662,11 @@ int dflo_hip_create(const dflo_mesh_t *mesh, const dflo_params_t *params, int de
     g_create_error = "Pk basis is implemented for cartesian mapping only";
     return DFLO_ERR_UNSUPPORTED;
   }
-  if (mesh->mapping != DFLO_MAP_CARTESIAN && mesh->mapping != DFLO_MAP_Q1) { g_create_error = "q2 mapping is not implemented"; return DFLO_ERR_UNSUPPORTED; }
+  // `mapping = q2` (MappingQ<dim>(2), src/claw.cc:173-176): on cells with straight edges -- all that the flat mesh can describe
+  // (four vertices per cell), and all the reference has: its curved boundary description is commented out, src/claw.cc:976-979 --
+  // the biquadratic map IS the bilinear one (its extra support points are the edge midpoints and the centre's image under the
+  // harmonic extension of bilinear boundary data, i.e. under the bilinear map itself).  Taken as q1.
+  if (mesh->mapping != DFLO_MAP_CARTESIAN && mesh->mapping != DFLO_MAP_Q1 && mesh->mapping != DFLO_MAP_Q2) { g_create_error = "unknown mapping"; return DFLO_ERR_BAD_PARAM; }
   if (params->shock_indicator < DFLO_IND_LIMITER || params->shock_indicator >= DFLO_IND_U2) {
     g_create_error = "shock indicator must be limiter, density or energy (u2 belongs to the MOOD scheme)";
     return params->shock_indicator == DFLO_IND_U2 ? DFLO_ERR_UNSUPPORTED : DFLO_ERR_BAD_PARAM;
@@ -703,7 +707,7 @@ int dflo_hip_create(const dflo_mesh_t *mesh, const dflo_params_t *params, int de
   h->fuse_dtq = tun.fuse_dtq;
   h->ns = mesh->basis == DFLO_BASIS_PK ? h->N * (h->N + 1) / 2 : h->N * h->N;
   h->ndof = 4 * h->ns;
-  h->mapping = mesh->mapping;
+  h->mapping = mesh->mapping == DFLO_MAP_Q2 ? DFLO_MAP_Q1 : mesh->mapping;
   h->geo = mesh->mapping == DFLO_MAP_CARTESIAN ? 0 : 1;
   int rc = build_plan(*mesh, 8, 8, h->plan, h->err);
   if (rc) { g_create_error = h->err; delete h; return rc; }

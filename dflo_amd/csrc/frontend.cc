@@ -453,7 +453,7 @@ Deck make_deck(const Prm &prm, const std::string &directory) {
   const std::string lim = prm.get("limiter", "type");
   if (lim == "TVB" && d.mapping != "cartesian") throw std::runtime_error("TVB limiter works on cartesian grids only");
   if (d.basis == "Pk" && d.mapping != "cartesian") throw std::runtime_error("Pk basis can only be used with Cartesian grids");
-  if (d.mapping == "q2") throw std::runtime_error("mapping = q2 is not provided (q1 | cartesian)");
+  // (mapping = q2: MappingQ(2) on the straight-edged cells of a .msh file is the bilinear map; the engine takes it as q1)
   if (prm.get_double("", "diffusion coefficient") != 0.0)
     throw std::runtime_error("diffusion coefficient != 0: the shock-capturing term belongs to the implicit path");
   dflo_params_t &p = d.params;

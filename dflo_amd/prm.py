@@ -152,8 +152,7 @@ class InputDeck:
             raise PrmError("TVB limiter works on cartesian grids only")
         if self.basis == "Pk" and self.mapping != "cartesian":
             raise PrmError("Pk basis can only be used with Cartesian grids")
-        if self.mapping == "q2":
-            raise PrmError("mapping = q2 is not provided (q1 | cartesian)")
+        # (mapping = q2: MappingQ(2) on the straight-edged cells of a .msh file is the bilinear map; the engine takes it as q1)
         if top["diffusion coefficient"] != 0.0:
             raise PrmError("diffusion coefficient != 0: the shock-capturing term belongs to the implicit path")
         self.boundary_kind, self.boundary_values = {}, {}

@@ -81,7 +81,8 @@ typedef struct dflo_mesh {
   int32_t degree;         /* k, 0..DFLO_MAX_DEGREE (0: piecewise constants, one RK stage, the limiters return at once,
                              src/claw.cc:141-145, src/positivity.cc:19, src/limiter.cc:379) */
   int32_t basis;          /* dflo_basis */
-  int32_t mapping;        /* dflo_mapping (q2 unsupported) */
+  int32_t mapping;        /* dflo_mapping; q2 is taken as q1: on straight-edged cells -- all this structure can describe, and all
+                             the reference has, src/claw.cc:976-979 -- MappingQ(2) is the bilinear map */
   const double *cell_vertices;            /* [n_cells][4][2] */
   const int32_t *cell_face_neighbor;      /* [n_cells][4] */
   const int32_t *cell_face_neighbor_face; /* [n_cells][4]: face number seen from the neighbour, +4 if the

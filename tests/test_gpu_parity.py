@@ -238,6 +238,30 @@ def test_time_step_formed_by_the_last_stage_kernel_on_mapped_cells(degree, flux,
     assert rel(two.current_solution, claw.current_solution) < 1e-11
 
 
+def test_mapping_q2_is_the_bilinear_map_on_straight_edged_cells():
+    """`mapping = q2` (MappingQ<dim>(2), src/claw.cc:173-176).  The flat mesh describes cells by their four vertices -- straight
+    edges, which is also all the reference has (its curved boundary description is commented out, src/claw.cc:976-979) -- and on
+    such cells the biquadratic map is the bilinear one: the engine takes q2 as q1, bit for bit, and agrees with the oracle."""
+    mesh, claw, ora = mapped_pair(2, "hllc", pos_lim=True)
+    u0 = claw.current_solution.copy()
+    t1 = claw.advance(4)
+    mesh.set_mapping("q2")
+    bnd = {1: "inflow", 2: "slip", 3: "outflow"}
+    prm = dflo_amd.Parameters(flux="hllc", boundary=bnd, cfl=0.5, pos_lim=True)
+    q2, oq2 = dflo_amd.ConservationLaw(mesh, prm), oracle_lib.Oracle(mesh, prm)
+    cell, face, bid, xy = q2.boundary_faces()
+    bv = np.stack(problems.smooth_perturbation(xy[..., 0], xy[..., 1], L=1.0), axis=-1)
+    for w in (0, 1):
+        q2.set_boundary_values(w, bv)
+        oq2.set_boundary_values(w, bv)
+    q2.set_initial_condition(u0)
+    oq2.set_solution(u0)
+    assert rel(q2.assemble_system(), oq2.assemble()) < 1e-12
+    assert q2.advance(4) == t1
+    assert np.array_equal(q2.current_solution, claw.current_solution)
+    mesh.set_mapping("q1")
+
+
 @pytest.mark.parametrize("degree,flux,pos", [(1, "lxf", False), (2, "hllc", True), (3, "kfvs", True)])
 def test_rk_solution_mapped_cells(degree, flux, pos):
     """C5-style: unstructured-type mesh data path (q1 mapping, compute_time_step_q, positivity)."""
