@@ -94,6 +94,7 @@ def _settle_clocks(seconds=0.4):
     and leaves the workload of the W warm-up and K timed steps exactly as specified."""
     if os.environ.get("DFLO_BENCH_NO_PREHEAT") == "1":
         return
+    seconds = float(os.environ.get("DFLO_BENCH_PREHEAT_S", seconds))
     x = torch.full((1 << 26,), 1.0000001, dtype=torch.float64, device="cuda")   # 512 MB: streams through HBM like the solver
     y = torch.zeros_like(x)
     t0 = time.perf_counter()

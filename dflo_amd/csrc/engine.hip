@@ -1090,9 +1090,8 @@ int dflo_hip_compute_cell_average(dflo_hip_handle h) {
   return launch_average(h);
 }
 
-int dflo_hip_compute_dt(dflo_hip_handle h, double elapsed_time, double *dt) {
-  if (check_handle(h) || !dt) return DFLO_ERR_BAD_PARAM;
-  hipSetDevice(h->device);
+// compute_time_step() of the current state into the device-resident (dt, t): launches only, nothing comes back to the host
+static int launch_compute_dt(dflo_hip_engine *h, double elapsed_time) {
   // "time step type = global" with cfl <= 0: the time step of the input file (src/claw.cc:455-460; the reference leaves
   // global_dt unset on this path, the engine advances the clock by the time step it uses)
   const int fixed = h->prm.global_time_step && h->prm.cfl <= 0.0;
@@ -1127,6 +1126,15 @@ int dflo_hip_compute_dt(dflo_hip_handle h, double elapsed_time, double *dt) {
   f.counter = h->fin_counter;
   hipLaunchKernelGGL(finalize_kernel, dim3(fin_grid(f.n_shards)), dim3(256), 0, h->stream, f);
   HIPCHK(h, hipGetLastError());
+  return DFLO_OK;
+}
+
+int dflo_hip_compute_dt(dflo_hip_handle h, double elapsed_time, double *dt) {
+  if (check_handle(h) || !dt) return DFLO_ERR_BAD_PARAM;
+  hipSetDevice(h->device);
+  const int rc = launch_compute_dt(h, elapsed_time);
+  if (rc) return rc;
+  double tt[4];
   HIPCHK(h, hipMemcpyAsync(tt, h->dt_dev, sizeof(tt), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   *dt = tt[0];
@@ -1168,9 +1176,9 @@ int dflo_hip_step(dflo_hip_handle h, double dt, double *res_norm0, double *res_n
 int dflo_hip_advance(dflo_hip_handle h, int n_steps, double *elapsed_time_inout) {
   if (check_handle(h) || n_steps < 0 || !elapsed_time_inout) return DFLO_ERR_BAD_PARAM;
   hipSetDevice(h->device);
-  // first dt from the current cell averages, then dt and time stay on the device
-  double dt0;
-  int rc = dflo_hip_compute_dt(h, *elapsed_time_inout, &dt0);
+  // first dt from the current cell averages -- formed and left on the device like every later one: the host does not wait
+  // for it (the stage kernels and the boundary programs read the device's (dt, t)), it only waits at the end
+  int rc = launch_compute_dt(h, *elapsed_time_inout);
   if (rc) return rc;
   int s = 0;
   if (h->use_graph && !h->timing && h->cur == h->old) {
@@ -1247,7 +1255,7 @@ int dflo_hip_advance(dflo_hip_handle h, int n_steps, double *elapsed_time_inout)
   double tt[4];
   HIPCHK(h, hipMemcpyAsync(tt, h->dt_dev, sizeof(tt), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
-  if (h->timing) time_collect(h);
+  // (the stage-timing events of this call are read when dflo_hip_stage_timing asks for them, not here inside the caller's clock)
   *elapsed_time_inout = tt[1];
   return flags_status(h);
 }

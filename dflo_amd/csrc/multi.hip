@@ -1457,6 +1457,12 @@ static int advance_body(dflo_hip_multi *m, int n_steps, double dt0) {
 
 int dflo_hip_multi_advance(dflo_hip_multi_handle m, int n_steps, double *elapsed_time_inout) {
   if (!m || n_steps < 0 || !elapsed_time_inout) return DFLO_ERR_BAD_PARAM;
+  if (m->n_parts == 1) {   // one part: the engine's own device-resident loop (nothing to exchange, nothing to reduce)
+    Part &p = m->parts[0];
+    int rc1 = join_all(m);
+    if (!rc1 && (rc1 = dflo_hip_advance(p.eng, n_steps, elapsed_time_inout))) set_err(m, dflo_hip_last_error(p.eng));
+    return rc1;
+  }
   double dt0 = 0.0;
   int rc = dflo_hip_multi_compute_dt(m, *elapsed_time_inout, &dt0);   // host value for the first step only
   if (rc) return rc;   // (compute_dt ends in a collective of its own: the ranks fail or pass together)
