@@ -90,17 +90,23 @@ def _cpu_quota():
 
 def _settle_clocks(seconds=0.4):
     """The GPU sat idle while the host built the mesh and the initial data; it needs a few tenths of a second of
-    fp64 work to come back to its sustained clock.  This is not a solver step: it touches none of the engine's data
-    and leaves the workload of the W warm-up and K timed steps exactly as specified."""
+    fp64 work to come back to its sustained state.  This is not a solver step: it runs none of the engine's kernels,
+    touches none of its data and leaves the workload of the W warm-up and K timed steps exactly as specified.
+    Measured in fresh processes (scratch/ramp2.py, ms per step): without it steps 6-25 run at 0.68-0.70, after streaming work alone
+    (rounds 1-2) at 0.60-0.63, after streaming work + fp64 matrix products at 0.587-0.594, and a run that has been going for 300
+    steps at 0.565 -- the last 4 % come only with ~100 steps of the solver itself, whatever ran before (4 s of preheat measure like
+    0.4 s), so a 20-step run reads ~4 % below a 200-step run.  Disclosed in config.preheat_s / config.preheat."""
     if os.environ.get("DFLO_BENCH_NO_PREHEAT") == "1":
         return
     seconds = float(os.environ.get("DFLO_BENCH_PREHEAT_S", seconds))
     x = torch.full((1 << 26,), 1.0000001, dtype=torch.float64, device="cuda")   # 512 MB: streams through HBM like the solver
     y = torch.zeros_like(x)
+    a = torch.full((2048, 2048), 1.0e-3, dtype=torch.float64, device="cuda")
     t0 = time.perf_counter()
     while time.perf_counter() - t0 < seconds:
         for _ in range(10):
             y = torch.addcmul(y, x, x)
+            b = a @ a
         torch.cuda.synchronize()
 
 
@@ -405,7 +411,8 @@ def main():
                                % ("RCB blocks" if args.config == "c5" else "x-slabs", world,
                                   "HOST-STAGED gloo transport (developer switch, not a measurement)" if uid == "gloo"
                                   else getattr(args, "transport_note", "RCCL send/recv of face traces + 8-byte all-reduce(min) per step")),
-                "check": check, "preheat_s": 0.0 if os.environ.get("DFLO_BENCH_NO_PREHEAT") == "1" else 0.4,
+                "check": check, "preheat_s": 0.0 if os.environ.get("DFLO_BENCH_NO_PREHEAT") == "1" else float(os.environ.get("DFLO_BENCH_PREHEAT_S", 0.4)),
+                "preheat": "neutral fp64 work before the W warm-up steps (torch.addcmul over 512 MB + 2048^2 matrix products; none of the engine's kernels or data)",
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
