@@ -281,8 +281,8 @@ def run_case(args, world, rank, local_rank, uid, barrier):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--nx", type=int, default=1024, help="cells per direction per GPU")
     ap.add_argument("--degree", type=int, default=2)
     ap.add_argument("--flux", default="hllc")
@@ -426,7 +426,7 @@ def main():
             import copy
             a2 = copy.copy(args)
             a2.degree, a2.flux, a2.basis = 1, "lxf", "Qk"
-            a2.steps, a2.warmup = min(args.steps, 100), min(args.warmup, 10)
+            a2.steps, a2.warmup = min(args.steps, 200), min(args.warmup, 100)
             s2 = run_case(a2, 1, 0, local_rank, None, lambda: None)
             ach2 = s2["n_dofs_launch"] * 24.0 / (s2["kernel_ms"] * 1e-3) / 1e9 if s2["kernel_ms"] > 0 else 0.0
             out["roofline"]["q1_frac"] = ach2 / 8000.0     # north_star: ">= 40 % of the fp64 HBM roofline at Q1" (the `secondary` line, in short)
