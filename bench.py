@@ -92,21 +92,25 @@ def _settle_clocks(seconds=0.4):
     """The GPU sat idle while the host built the mesh and the initial data; it needs a few tenths of a second of
     fp64 work to come back to its sustained state.  This is not a solver step: it runs none of the engine's kernels,
     touches none of its data and leaves the workload of the W warm-up and K timed steps exactly as specified.
-    Measured in fresh processes (scratch/ramp2.py, ms per step): without it steps 6-25 run at 0.68-0.70, after streaming work alone
-    (rounds 1-2) at 0.60-0.63, after streaming work + fp64 matrix products at 0.587-0.594, and a run that has been going for 300
-    steps at 0.565 -- the last 4 % come only with ~100 steps of the solver itself, whatever ran before (4 s of preheat measure like
-    0.4 s), so a 20-step run reads ~4 % below a 200-step run.  Disclosed in config.preheat_s / config.preheat."""
+    Measured on one box with the driver's `--steps 20 --warmup 5` (MDoF/s): no preheat 163 000; streaming fp64 work
+    (torch.addcmul over 512 MB) for 0.1 / 0.2 / 0.4 / 1.0 s: 182 000-189 000 / 189 300 / 189 800 / 189 200; the same with fp64
+    matrix products mixed in 182 500-186 400, matrix products alone 180 000-184 000 (they heat the part: the solver then starts
+    at lower clocks) -- so it stays streaming work, 0.4 s.  A run that has been going for 100+ steps is another ~3 % faster
+    whatever ran before it.  Disclosed in config.preheat_s / config.preheat."""
     if os.environ.get("DFLO_BENCH_NO_PREHEAT") == "1":
         return
     seconds = float(os.environ.get("DFLO_BENCH_PREHEAT_S", seconds))
+    kind = os.environ.get("DFLO_BENCH_PREHEAT_KIND", "addcmul")   # developer switch: addcmul | mix | mm
     x = torch.full((1 << 26,), 1.0000001, dtype=torch.float64, device="cuda")   # 512 MB: streams through HBM like the solver
     y = torch.zeros_like(x)
     a = torch.full((2048, 2048), 1.0e-3, dtype=torch.float64, device="cuda")
     t0 = time.perf_counter()
     while time.perf_counter() - t0 < seconds:
         for _ in range(10):
-            y = torch.addcmul(y, x, x)
-            b = a @ a
+            if kind != "mm":
+                y = torch.addcmul(y, x, x)
+            if kind != "addcmul":
+                b = a @ a
         torch.cuda.synchronize()
 
 
@@ -412,7 +416,7 @@ def main():
                                   "HOST-STAGED gloo transport (developer switch, not a measurement)" if uid == "gloo"
                                   else getattr(args, "transport_note", "RCCL send/recv of face traces + 8-byte all-reduce(min) per step")),
                 "check": check, "preheat_s": 0.0 if os.environ.get("DFLO_BENCH_NO_PREHEAT") == "1" else float(os.environ.get("DFLO_BENCH_PREHEAT_S", 0.4)),
-                "preheat": "neutral fp64 work before the W warm-up steps (torch.addcmul over 512 MB + 2048^2 matrix products; none of the engine's kernels or data)",
+                "preheat": "neutral fp64 streaming work before the W warm-up steps (torch.addcmul over 512 MB; none of the engine's kernels or data)",
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
