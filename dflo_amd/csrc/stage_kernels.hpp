@@ -10,6 +10,7 @@ namespace dflo {
 // (225 registers: P3 KFVS 98 000 instead of 114 000 MDoF/s).
 constexpr int kQ3FirstStageWaves = 3;   // first-stage Q3 kernel on squares: own row and own G row read back from the LDS image
 constexpr int kQ2Waves = 3;
+// (Q4 on squares built for 3 / 2 wavefronts per SIMD in the first / later stages: 121 700 against 122 100 MDoF/s; 3 / 3: spills, 87 000)
 constexpr bool kPkLeanLater = true;     // P3: the later stages built like the first one (161 registers, no spills)
 // ------------------------------------------------------------------ the stage kernel
 // One workgroup of N wavefronts per shard: lane = cell, wavefront = node row b of the (k+1)^2
@@ -41,7 +42,7 @@ __device__ __forceinline__ void row_update(const StageArgs &a, double *Us, const
   // later stages, which also hold u(n), lose at 3) -- the state of the own row comes back from the LDS image (phase A put it
   // there; nobody else writes these rows) instead of being held across the flux phase, and the own G row is read back like the
   // others.  The same values, the same arithmetic.
-  constexpr bool LEAN = N == 4 && MODE == 0;
+  constexpr bool LEAN = (N == 4 && MODE == 0) || N >= 5;   // (N >= 5: every stage -- the later stages spill otherwise)
   double Gown[N][4], base[4][N];
 #pragma unroll
   for (int aa = 0; aa < N; ++aa) {
