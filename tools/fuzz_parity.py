@@ -142,8 +142,11 @@ def one(i):
             break
         dt = ora.compute_time_step(t)
         dtc = claw.compute_time_step()
-        if abs(dtc - dt) > (1e-9 if "kink" in desc else 1e-11) * dt:
-            if e1 is not None and e1 <= 1e-12 and "kink" in desc:
+        if it == 0:
+            dt_first = dt
+        if abs(dtc - dt) > (1e-9 if "kink" in desc else 1e-11) * loose * dt:
+            if e1 is not None and e1 <= 1e-12 and ("kink" in desc or dt < 1e-2 * dt_first):
+                # (rough data, or a run whose time step has collapsed a hundredfold within two steps: it is blowing up)
                 raise oracle_lib.OracleError(3, "round-off amplified by rough data")   # see below
             assert False, ("dt", it, dtc, dt)
         claw.iterate_explicit(dt)
@@ -158,7 +161,9 @@ def one(i):
             ora.step(dt)
             t += dt
         if np.isfinite(t) and np.isfinite(claw.current_solution).all():   # (a device NaN is classified below)
-            assert abs(t2 - t) <= 1e-9 * t, ("advance time", t2, t)
+            if abs(t2 - t) > 1e-9 * t and e1 is not None and e1 <= 1e-12 and "kink" in desc:
+                raise oracle_lib.OracleError(3, "round-off amplified by rough data")
+            assert abs(t2 - t) <= 1e-9 * loose * t, ("advance time", t2, t)
         desc.update(advance=True)
     tol = (1e-8 if (tvb or pos or "kink" in desc) else 1e-10) * loose     # (jumps amplify the round-off of the fluxes)
     ud, uo = claw.current_solution, ora.get_solution()
