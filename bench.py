@@ -23,6 +23,9 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
+# the host driver of these boxes supports dmabuf IPC only: without this RCCL's peer buffers fail with
+# "hipIpcGetMemHandle: invalid argument" (exported in the image already; kept for any environment that drops it)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import numpy as np
 import torch
@@ -332,6 +335,10 @@ def main():
     uid = None
     barrier = lambda: None
     if world > 1:
+        # a collective that never completes (a rank that died, a transport that stalls) must end the run with the Python
+        # stacks on stderr instead of holding the node until somebody else's limit: every rank arms a watchdog
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ.get("DFLO_BENCH_WATCHDOG_S", 1500)), exit=True)
         # torch.distributed is the control plane only (rendezvous, the communicator id, barriers around the timed
         # region, the maximum over ranks): the halo exchange and the time-step reduction are RCCL calls made by the
         # native driver on its own communicator and streams
@@ -457,9 +464,11 @@ def main():
             out["cpu_baseline"]["optimised_twin"] = max(twins, key=lambda r: r["value"])
         result_line = json.dumps(out)
     if world > 1:
+        import faulthandler
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()
+        faulthandler.cancel_dump_traceback_later()
     if result_line is not None:
         import ctypes
         sys.stderr.flush()

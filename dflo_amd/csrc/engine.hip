@@ -875,9 +875,11 @@ int dflo_hip_create(const dflo_mesh_t *mesh, const dflo_params_t *params, int de
       const bool pass = h->prm.limiter_type != DFLO_LIMITER_NONE || (h->prm.pos_lim && !h->fuse_pos) || h->prm.shock_indicator != DFLO_IND_LIMITER;
       h->lazy_avg = tun.lazy_avg && h->prm.flux_type != DFLO_FLUX_LXF && !pass && h->prm.global_time_step;
     }
-    // (measured: the marks cost the stage kernel ~11 %; the pass they shorten reads (k+1)^2 values per cell and component,
-    //  which pays from k = 2 on -- C4 +7 % -- and not for k = 1 -- C3 -7 %; DFLO_LIM_MASK=1 forces them, 0 forbids them)
-    const bool want_marks = tun.lim_mask >= 0 ? tun.lim_mask != 0 : h->N >= 3;
+    // (measured: the marks pay from k = 2 on -- C4 +10 %, the slab pair +3.5 % with the box test of round 3 --; at k = 1, where the
+    //  pass reads only 16 values per cell, the box-only marks give the single engine +1.5 % (C3) and cost a part of a
+    //  multi-device run 7 % (its rim / ring launches are short already): on there without ghost cells only;
+    //  DFLO_LIM_MASK=1 forces them, 0 forbids them)
+    const bool want_marks = h->N >= 2 && (tun.lim_mask >= 0 ? tun.lim_mask != 0 : (h->N >= 3 || p.n_cells == p.n_owned));
     if (h->prm.limiter_type == DFLO_LIMITER_TVB && h->basis == DFLO_BASIS_QK && h->geo == 0 && want_marks) {
       const size_t nb = (size_t)std::max(p.n_shards, 1) * sizeof(unsigned long long);
       if (hipMalloc((void **)&h->lim_mask, nb) != hipSuccess) {

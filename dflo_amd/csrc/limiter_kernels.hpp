@@ -89,9 +89,15 @@ __global__ __launch_bounds__(64) void limiter_kernel(const LimArgs a) {
     if (lane == 0) a.mask[shard] = 0;   // consumed (the load above has returned: m was compared)
     marked = (m >> lane) & 1;
   }
+  int nb[4] = {-1, -1, -1, -1};   // left, right, bottom, top: asked for with the DoFs (one memory round trip less on the path of a
+                                  // wavefront that has to look at its neighbours)
   if (marked) {
 #pragma unroll
     for (int d = 0; d < NDOF; ++d) U[d] = up[d * 64];
+    if (a.tvb) {
+#pragma unroll
+      for (int f = 0; f < 4; ++f) nb[f] = a.lrbt[((size_t)shard * 4 + f) * 64 + lane];
+    }
   }
 #pragma unroll
   for (int c = 0; c < 4; ++c) A[c] = a.avg[((size_t)shard * 4 + c) * 64 + lane];
@@ -156,7 +162,7 @@ __global__ __launch_bounds__(64) void limiter_kernel(const LimArgs a) {
         }
         continue;
       }
-      const int ib = a.lrbt[((size_t)shard * 4 + 2 * dir) * 64 + lane], ifw = a.lrbt[((size_t)shard * 4 + 2 * dir + 1) * 64 + lane];
+      const int ib = nb[2 * dir], ifw = nb[2 * dir + 1];
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         const double ab = (a.ghost_avg && ib >= a.first_ghost_slot) ? a.ghost_avg[(size_t)(ib - a.first_ghost_slot) * 4 + c]

@@ -160,11 +160,9 @@ __device__ __forceinline__ void row_update(const StageArgs &a, double *Us, const
 #pragma unroll
     for (int c = 0; c < 5; ++c) red[(B * 5 + c) * 64 + lane] = part[c];
     if constexpr (POS == 1) positivity_row_bounds<N, B>(Us, lane, unew);   // the LDS image is free now
-    if constexpr (POS == 2) {
-      if (a.pos_check) positivity_row_bounds<N, B>(Us, lane, unew);
-    }
-    if constexpr (POS == 2) {   // x part of "dx * gradient of the cell average" (src/limiter.cc:283-289): l_m(1) - l_m(0) is
-                                // antisymmetric in m, pairing the nodes makes the slope of a constant state exactly zero
+    if constexpr (POS == 2 && N >= 3) positivity_row_bounds<N, B>(Us, lane, unew);   // (the marks bound the TVB slopes with the box as well)
+    if constexpr (POS == 2 && N >= 3) {   // x part of "dx * gradient of the cell average" (src/limiter.cc:283-289): l_m(1) - l_m(0) is
+                                          // antisymmetric in m, pairing the nodes makes the slope of a constant state exactly zero
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         double g = 0.0;
@@ -172,6 +170,10 @@ __device__ __forceinline__ void row_update(const StageArgs &a, double *Us, const
         for (int m = 0; m < N / 2; ++m) g += (CB<N>::t.L1[m] - CB<N>::t.L0[m]) * (unew[c][m] - unew[c][N - 1 - m]);
         red[(5 * N + c * N + B) * 64 + lane] = CB<N>::t.w[B] * g;
       }
+    }
+    if constexpr (POS == 2 && N == 2) {   // k = 1: the difference along the row is all the marks want (stage_kernel, last wave)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) red[(5 * N + c * N + B) * 64 + lane] = unew[c][1] - unew[c][0];
     }
   }
 }
@@ -449,6 +451,43 @@ __device__ __forceinline__ void flux_phase(const StageArgs &a, const double *Us,
     numerical_normal_flux<FLUX>(nx, ny, Wp, Wm, Ap, Am, F);
 #pragma unroll
     for (int c = 0; c < 4; ++c) Th[(c * N + qs) * HS + col] = F[c];
+  }
+}
+
+// POS 2, what a box around the cell's nodal values settles for the limiter pass (see the marks at the end of stage_kernel):
+// `settled` -- the positivity limiter has nothing to do (the arithmetic of positivity_box_settled, kernels_common.hpp); `open` --
+// TVB cannot be ruled out from the box alone.  dsum bounds the sum over the components of (largest - smallest nodal value).
+// "dx * gradient of the cell average" (src/limiter.cc:283-289) is a weighted sum of nodal values whose weights sum to zero: no
+// component of it exceeds K (hi - lo), K = 1/2 sum_m |l_m(1) - l_m(0)|, in either direction, and the characteristic slopes
+// together no more than ||L||_1 times the sum of that over the components, ||L||_1 bounded over the box (the cell average, where
+// the pass forms L, is a convex combination of the nodal values).  Below `M dx^2` minmod hands back its first argument
+// (src/limiter.cc:15-30), and a cell whose summed |slopes| stay below the rewrite threshold of src/limiter.cc:347 is left as it is
+// whatever its neighbours hold (the pass's own early-out).
+template <int N>
+__device__ __forceinline__ void limiter_marks_from_box(const double (&lo)[4], const double (&hi)[4], bool fin, double dsum, double sn,
+                                                       double tvb_M, int tvb_char, double h, bool &settled, bool &open) {
+  const double rho_lo = lo[RHO] - (hi[RHO] - lo[RHO]) * sn, e_lo = lo[EN] - (hi[EN] - lo[EN]) * sn;
+  const double dmx = (hi[MX] - lo[MX]) * sn, dmy = (hi[MY] - lo[MY]) * sn;
+  const double mxa = fmax(fabs(lo[MX] - dmx), fabs(hi[MX] + dmx)), mya = fmax(fabs(lo[MY] - dmy), fabs(hi[MY] + dmy));
+  const double ri_lo = frcp(rho_lo);
+  const double p_lo = kG1 * (e_lo - 0.5 * (mxa * mxa + mya * mya) * ri_lo);
+  settled = fin && rho_lo >= 1.0e-10 + 1.0e-8 * hi[RHO] && p_lo >= 1.0e-10 + 1.0e-8 * fabs(hi[EN]);
+  open = false;
+  if (tvb_M >= 0.0) {
+    constexpr double K = []() constexpr {
+      double t = 0.0;
+      for (int m = 0; m < N; ++m) { const double g = CB<N>::t.L1[m] - CB<N>::t.L0[m]; t += g < 0 ? -g : g; }
+      return 0.5 * t;
+    }();
+    double kappa = 1.0;
+    if (tvb_char) {
+      // columns of |Lx|, |Ly| (physics.hpp: to_char) with q >= |u| + |v|, phi2 <= 0.2 q^2, 1/c <= (1 + 1/c^2) / 2
+      const double q = (mxa + mya) * ri_lo, ic2 = hi[RHO] * frcp(kGamma * p_lo);
+      kappa = 1.0 + q + ic2 * (0.4 * q * q + 0.8 * q + 0.8) + 0.5 * (q + 1.0) * (1.0 + ic2);
+    }
+    const double Sb = 1.0001 * K * kappa * dsum;
+    // (a box that is not settled has no bound on L: NaN or a negative pressure leave `open` true)
+    open = !(settled && (0.5 * Sb <= 0.9998e-10 || Sb < tvb_M * h * h * (1.0 - 1.0e-9)));
   }
 }
 
@@ -838,56 +877,81 @@ __global__ __launch_bounds__(64 * N, N >= 5 ? 1 : ((N == 4 && GEO == 0 && MODE =
       __syncthreads();
     }
   }
-  if constexpr (POS == 2 && GEO == 0 && MODE != 2) {
-    // Which cells can the limiter pass change?  TVB (src/limiter.cc:15-30): minmod hands back its first argument when it is
-    // below M dx^2 or zero, so a cell whose (characteristic) slopes all are is left alone; wave 0 looks at the x slopes,
-    // wave 1 at the y slopes, with a margin on the threshold so that the pass, which forms the slopes once more from the
-    // DoFs, can never disagree in the other direction.  Positivity: the nodal box test.  The pass itself is
-    // unchanged for the marked cells, so the results are those of the plain pass.
-    if (row < 2) {
-      double A[4], D[4];
-      bool any = false;
+  if constexpr (POS == 2 && GEO == 0 && MODE != 2 && N >= 3) {
+    // Which cells can the limiter pass change?  One bit per cell, formed by wave 0 (the last wave has the averages and the
+    // reductions to write).  The pass itself is unchanged for the marked cells, so the results are those of the plain pass.
+    //  * positivity: the nodal box test.
+    //  * TVB, first from the nodal box alone (limiter_marks_from_box): states constant up to rounding, most of a shock tube and
+    //    of the double Mach reflection, are settled there in a few dozen instructions.
+    //  * Only wavefronts with a cell the box cannot settle form the slopes themselves (row partials in LDS, characteristic
+    //    variables when `char_lim` is on), x then y, with a margin on the thresholds so that the pass, which forms the same
+    //    slopes once more from the DoFs, can never disagree in the other direction.
+    //  (k = 1: in the last wave's block below)
+    if (row == 0) {
+      double lo[4], hi[4];
+      bool fin = true;
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
-        double v = 0.0, g = 0.0;
+        lo[c] = Us[((2 * c) * N) * 64 + lane];
+        hi[c] = Us[((2 * c + 1) * N) * 64 + lane];
+        if (c == RHO) fin = fin && lo[c] == lo[c];
 #pragma unroll
-        for (int b = 0; b < N; ++b) v += red[(b * 5 + c) * 64 + lane];
-        if (row == 0) {
-#pragma unroll
-          for (int b = 0; b < N; ++b) g += red[(5 * N + c * N + b) * 64 + lane];
-        } else {
-#pragma unroll
-          for (int m = 0; m < N / 2; ++m)   // the row sums of the average are w_m * (sum of the row): w_m = w_(N-1-m)
-            g += (CB<N>::t.L1[m] - CB<N>::t.L0[m]) * CB<N>::t.iw[m] * (red[(m * 5 + c) * 64 + lane] - red[((N - 1 - m) * 5 + c) * 64 + lane]);
+        for (int b = 1; b < N; ++b) {
+          const double l = Us[((2 * c) * N + b) * 64 + lane];
+          if (c == RHO) fin = fin && l == l;
+          lo[c] = fmin(lo[c], l);
+          hi[c] = fmax(hi[c], Us[((2 * c + 1) * N + b) * 64 + lane]);
         }
-        A[c] = v;
-        D[c] = g;
-        any = any || !(g == 0.0);
       }
-      bool need = false;
-      if (a.tvb_M >= 0.0) {
-        if (a.tvb_char && __any(any)) {
-          const EigenXY e = eigen_at(A);
-          to_char(e, row, D);
+      bool settled, open;
+      limiter_marks_from_box<N>(lo, hi, fin, (hi[0] - lo[0]) + (hi[1] - lo[1]) + (hi[2] - lo[2]) + (hi[3] - lo[3]), a.kb.pg_neg,
+                                a.tvb_M, a.tvb_char, h, settled, open);
+      bool need = a.pos_check && !settled;
+      if (__any(open && active)) {
+        double A[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          double v = 0.0;
+#pragma unroll
+          for (int b = 0; b < N; ++b) v += red[(b * 5 + c) * 64 + lane];
+          A[c] = v;
         }
         // margin: relative on the threshold, and absolute against the rounding of the slopes (formed here from row
         // partials, in the pass from the DoFs; both errors are a few ulp of the state)
         const double thr = a.tvb_M * h * h * (1.0 - 1.0e-9) - 1.0e-11 * (fabs(A[0]) + fabs(A[1]) + fabs(A[2]) + fabs(A[3]));
-        double sum = 0.0;
+        EigenXY e;
+        if (a.tvb_char) e = eigen_at(A);
+        bool over = false;     // a slope at or above the threshold (and not zero)
+        double sum = 0.0;      // |slopes| of both directions
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          need = need || !(fabs(D[i]) < thr || D[i] == 0.0);
-          sum += fabs(D[i]);
+        for (int dir = 0; dir < 2; ++dir) {
+          double D[4];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            double g = 0.0;
+            if (dir == 0) {
+#pragma unroll
+              for (int b = 0; b < N; ++b) g += red[(5 * N + c * N + b) * 64 + lane];
+            } else {
+#pragma unroll
+              for (int m = 0; m < N / 2; ++m)   // the row sums of the average are w_m * (sum of the row): w_m = w_(N-1-m)
+                g += (CB<N>::t.L1[m] - CB<N>::t.L0[m]) * CB<N>::t.iw[m] * (red[(m * 5 + c) * 64 + lane] - red[((N - 1 - m) * 5 + c) * 64 + lane]);
+            }
+            D[c] = g;
+          }
+          if (a.tvb_char) to_char(e, dir, D);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            over = over || !(fabs(D[i]) < thr || D[i] == 0.0);
+            sum += fabs(D[i]);
+          }
         }
         // The second way out (the pass's own early-out, see limiter_kernel): minmod changes a slope by at most its size, so the
         // "change" that decides whether the cell is rewritten (src/limiter.cc:347: > 1e-10, a quarter of the summed |changes| of
-        // both directions) is at most a quarter of the sum of the |slopes|: below half the threshold in this direction -- wave 0
-        // looks at x, wave 1 at y -- the cell stays as it is whatever its neighbours hold (states constant up to rounding: most
-        // of a shock tube, where M = 0 leaves the test above nothing to find).  The slopes here and in the pass are the same
-        // sums in another order (a few ulp of the slopes themselves): the margin on the threshold covers that.
-        need = need && !(0.25 * sum <= 0.4999e-10);
+        // both directions) is at most a quarter of the sum of the |slopes|.  The slopes here and in the pass are the same sums
+        // in another order (a few ulp of the slopes themselves): the margin on the threshold covers that.
+        need = need || (over && !(0.25 * sum <= 0.9998e-10));
       }
-      if (row == 0 && a.pos_check) need = need || !positivity_box_settled<N>(Us, lane, a.kb.pg_neg);
       const unsigned long long m = __ballot(need && active);
       if (lane == 0 && m) atomicOr(&a.lim_mask[shard], m);
     }
@@ -918,6 +982,27 @@ __global__ __launch_bounds__(64 * N, N >= 5 ? 1 : ((N == 4 && GEO == 0 && MODE =
       if constexpr (GEO == 0) {
         if (a.want_dt) dtmin = cfl_dt(avg, h, a.cfl, a.degree);
       }
+    }
+    if constexpr (POS == 2 && GEO == 0 && MODE != 2 && N == 2) {
+      // The marks at k = 1, where every instruction of a 500-instruction kernel shows: no row extremes, no slopes -- the four
+      // nodal values of a component are (row mean) -+ (half the difference along the row), so they lie within
+      // d = |mean_1 - mean_0| + max |difference| of each other and of their average, and the box `average -+ sum of the d` holds
+      // every component.  The row means are the partials of the average (in registers here), the differences were left in LDS
+      // by the row updates.  What the box cannot settle is marked (no second look at the slopes: with M = 0 there is nothing
+      // between "constant up to rounding" and "limited").
+      double sd = 1.0e-15 * (fabs(avg[0]) + fabs(avg[1]) + fabs(avg[2]) + fabs(avg[3]));   // (rounding of the partials)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const double dm = red[(1 * 5 + c) * 64 + lane] - red[(0 * 5 + c) * 64 + lane];   // w_b (row sum): half the row mean
+        sd += 2.0 * fabs(dm) + fmax(fabs(red[(5 * N + c * N) * 64 + lane]), fabs(red[(5 * N + c * N + 1) * 64 + lane]));
+      }
+      double lo[4], hi[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) { lo[c] = avg[c] - sd; hi[c] = avg[c] + sd; }
+      bool settled, open;
+      limiter_marks_from_box<N>(lo, hi, sd == sd, sd, a.kb.pg_neg, a.tvb_M, a.tvb_char, h, settled, open);
+      const unsigned long long m = __ballot(((a.pos_check && !settled) || open) && active);
+      if (lane == 0 && m) atomicOr(&a.lim_mask[shard], m);
     }
     bool have_dt = GEO == 0 && a.want_dt;
     if constexpr (GEO == 1 && MODE != 2) {

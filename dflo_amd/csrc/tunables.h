@@ -16,7 +16,7 @@ struct Tunables {
   bool fuse_dtq = true;    // DFLO_FUSE_DTQ=0    bilinear cells: compute_time_step_q by the separate pass instead of the last stage kernel
   bool fuse_pos = true;    // DFLO_FUSE_POS=0    positivity without TVB on Qk: separate limiter pass instead of inside the stage kernel
   bool lazy_avg = true;    // DFLO_LAZY_AVG=0    store the cell averages of every stage (default: only when somebody reads them)
-  int lim_mask = -1;       // DFLO_LIM_MASK=0|1  TVB on squares: forbid / force the stage kernel's marks for the limiter pass (default: degree >= 2)
+  int lim_mask = -1;       // DFLO_LIM_MASK=0|1  TVB on squares: forbid / force the stage kernel's marks for the limiter pass (default: degree >= 2; degree 1 without ghost cells)
   bool halo_cells = false; // DFLO_HALO_CELLS=1  multi-device: ghost cells as whole cells instead of face traces
   bool verbose = false;    // DFLO_VERBOSE=1     print the LDS footprint and the resident workgroups of the stage kernel
   int plan_refine = 8;     // DFLO_PLAN_REFINE=n swap-refinement passes of the shard plan on unstructured meshes

@@ -1002,17 +1002,19 @@ def test_positivity_inside_the_stage_kernel(degree, flux, mapped, monkeypatch):
     assert rel(runs["1"].current_solution, runs["0"].current_solution) < 1e-13   # (the two kernels contract a few FMAs differently)
 
 
-@pytest.mark.parametrize("degree,M", [(1, 0.0), (2, 50.0), (3, 200.0)])
-def test_limiter_marks_from_the_stage_kernel(degree, M, monkeypatch):
-    """TVB runs on squares: the stage kernel marks the cells the limiter pass can change (slopes against M dx^2 with a
-    margin, nodal box for positivity) and the pass visits only those.  Same answers as the pass over all cells, and
-    as the oracle."""
+@pytest.mark.parametrize("degree,M,wave", [(1, 0.0, 0.05), (2, 50.0, 0.05), (3, 200.0, 0.05), (1, 0.0, 0.0), (2, 0.0, 0.0), (3, 10.0, 1e-7), (1, 3.0, 1e-6)])
+def test_limiter_marks_from_the_stage_kernel(degree, M, wave, monkeypatch):
+    """TVB runs on squares: the stage kernel marks the cells the limiter pass can change (first from a box around the cell's
+    nodal values -- states constant up to rounding, slopes certainly below M dx^2 --, then slopes against M dx^2 with a
+    margin; nodal box for positivity) and the pass visits only those.  Same answers as the pass over all cells, and
+    as the oracle.  wave = 0: the constant states either side of the jump, which the box settles; tiny waves: cells between
+    the two tests."""
     bnd = {0: "slip", 1: "outflow", 2: "inflow"}
     mesh = dflo_amd.Mesh.cartesian(48, 12, 0.0, 0.0, 1.0 / 48, [2, 1, 0, 0], degree)
     prm = dflo_amd.Parameters(flux="hllc", limiter="TVB", char_lim=True, pos_lim=True, M=M, beta=1.5, boundary=bnd, cfl=0.6)
     def ic(x, y):   # a Sod jump plus a smooth wave: cells that TVB leaves alone next to cells it limits
         mx, my, rho, E = problems.sod(x, y)
-        return [mx, my, rho * (1.0 + 0.05 * np.sin(12.0 * x) * np.cos(9.0 * y)), E]
+        return [mx, my, rho * (1.0 + wave * np.sin(12.0 * x) * np.cos(9.0 * y)), E]
     u0 = mesh.interpolate(ic)
     runs = {}
     for marks in ("1", "0"):
