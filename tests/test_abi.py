@@ -41,6 +41,23 @@ def test_product_does_not_touch_the_oracle():
     assert "oracle" not in out
 
 
+def test_variant_patches_still_apply():
+    """tools/variants/*.patch: measured-and-lost kernel variants kept as patches -- they must keep applying to the tree they
+    sit next to, or their evidence cannot be reproduced (only where the tree is a git checkout: the GPU box gets a snapshot)."""
+    import glob
+    import subprocess
+    if not os.path.isdir(os.path.join(ROOT, ".git")):
+        pytest.skip("not a git checkout")
+    patches = sorted(glob.glob(os.path.join(ROOT, "tools", "variants", "*.patch")))
+    assert patches
+    hand_written = {"lds_pad.patch"}   # a description with a one-line hunk, not a `git diff`
+    for f in patches:
+        if os.path.basename(f) in hand_written:
+            continue
+        r = subprocess.run(["git", "apply", "--check", f], cwd=ROOT, capture_output=True, text=True)
+        assert r.returncode == 0, "%s: %s" % (os.path.basename(f), r.stderr[-400:])
+
+
 def test_cartesian_mesh_builder():
     m = dflo_amd.Mesh.cartesian(4, 3, 1.0, 2.0, 0.5, [7, -1 if False else 8, -1, -1], 2)
     assert m.n_cells == 12 and m.n_owned == 12 and m.degree == 2
