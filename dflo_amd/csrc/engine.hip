@@ -98,6 +98,7 @@ struct dflo_hip_engine {
   int n_patterns = 0;   // distinct (face records, face references) among the shards
   int sweep_mode = 1, sweep_dir = 0;   // every launch over all shards walks them against the previous one (DFLO_SWEEP=0: always forward)
   bool fuse_dtq = true;                // DFLO_FUSE_DTQ=0: bilinear cells always take the separate time-step pass (dt_q_kernel)
+  bool fuse_fin = true;                // DFLO_FUSE_FIN=0: finalize_kernel always as its own launch
   int stream_override = -1;            // DFLO_STREAM=0/1 forces the streaming-store variant off / on
   // timing
   bool timing = false;
@@ -466,7 +467,13 @@ int launch_indicator(dflo_hip_engine *h, int part) {
   return DFLO_OK;
 }
 
-int launch_limiter(dflo_hip_engine *h, int tvb, int pos, int part, bool stage_data = false) {
+// workgroups of finalize_kernel: as many chunks of >= 256 shards as there are, at most kFinBlocks
+int fin_grid(int n_shards) {
+  const int chunk = ((n_shards + kFinBlocks - 1) / kFinBlocks + 255) & ~255;
+  return std::max(1, (n_shards + chunk - 1) / chunk);
+}
+
+int launch_limiter(dflo_hip_engine *h, int tvb, int pos, int part, bool stage_data = false, const FinalArgs *fin = nullptr) {
   const Plan &p = h->plan;
   LimArgs l{};
   l.U = h->U[h->cur];
@@ -499,6 +506,10 @@ int launch_limiter(dflo_hip_engine *h, int tvb, int pos, int part, bool stage_da
   if (l.dtq) h->dtq_parts |= part == 0 ? 3 : part;
   if (l.n_list == 0) return DFLO_OK;
   l.sweep_rev = next_sweep(h, part);
+  if (fin) {
+    l.fin = *fin;
+    l.fin_blocks = fin_grid(fin->n_shards);
+  }
   void (*lf)(const LimArgs) = DFLO_BY_N_LIM(h->N, limiter_kernel);
   if (h->basis == DFLO_BASIS_PK) lf = DFLO_BY_N_LIM(h->N, limiter_pk_kernel);
   hipLaunchKernelGGL(lf, dim3(grid_for(l.n_list)), dim3(64), 0, h->stream, l);
@@ -507,7 +518,7 @@ int launch_limiter(dflo_hip_engine *h, int tvb, int pos, int part, bool stage_da
 }
 
 // limiter of the open stage on one part of the shards
-int launch_stage_limiter(dflo_hip_engine *h, int part) {
+int launch_stage_limiter(dflo_hip_engine *h, int part, const FinalArgs *fin = nullptr) {
   if (h->pending_rk < 0) { h->err = "no stage pending"; return DFLO_ERR_BAD_PARAM; }
   const bool limited = h->prm.limiter_type != DFLO_LIMITER_NONE || h->prm.pos_lim;
   if (!limited) return DFLO_OK;
@@ -516,34 +527,12 @@ int launch_stage_limiter(dflo_hip_engine *h, int part) {
     const int rc = launch_indicator(h, part);
     if (rc) return rc;
   }
-  return launch_limiter(h, h->prm.limiter_type == DFLO_LIMITER_TVB, h->prm.pos_lim, part, true);
+  return launch_limiter(h, h->prm.limiter_type == DFLO_LIMITER_TVB, h->prm.pos_lim, part, true, fin);
 }
 
 // reductions of the stage launched last
-// workgroups of finalize_kernel: as many chunks of >= 256 shards as there are, at most kFinBlocks
-int fin_grid(int n_shards) {
-  const int chunk = ((n_shards + kFinBlocks - 1) / kFinBlocks + 255) & ~255;
-  return std::max(1, (n_shards + chunk - 1) / chunk);
-}
-
-int launch_finish(dflo_hip_engine *h) {
+void final_args(dflo_hip_engine *h, FinalArgs &f) {
   const Plan &p = h->plan;
-  const int rk = h->pending_rk;
-  if (rk < 0) { h->err = "no stage pending"; return DFLO_ERR_BAD_PARAM; }
-  const bool last = rk == h->n_rk - 1;
-  if (last && h->geo == 1) {  // bilinear cells: dt from the point values of the (limited) new solution,
-    if (h->dtq_parts != 3) {   // unless the limiter pass of this stage has formed it on the way
-      launch_dt_q(h);
-      HIPCHK(h, hipGetLastError());
-    }
-  } else if (last && h->d_dt_cell) {  // local time stepping: the per-cell dt of the next step
-    hipLaunchKernelGGL(dt_kernel, dim3(p.n_shards), dim3(64), 0, h->stream, h->avg[h->avg_cur], h->d_cell_h, p.h,
-                       p.uniform_h ? 1 : 0, h->d_shard_count, h->shard_dtmin, h->prm.cfl, h->degree, h->d_dt_cell);
-    HIPCHK(h, hipGetLastError());
-  }
-  h->pending_rk = -1;
-  if (!last) return DFLO_OK;  // ||rhs|| of every stage is reduced once, after the last stage (it is only reported, src/claw.cc:768)
-  FinalArgs f{};
   f.shard_res = h->shard_res;
   f.shard_dtmin = h->shard_dtmin;
   f.res_sq = h->res_sq;
@@ -561,16 +550,44 @@ int launch_finish(dflo_hip_engine *h) {
   f.publish = h->publish ? h->dt_pub + h->pub_parity : nullptr;
   f.partial = h->fin_partial;
   f.counter = h->fin_counter;
+}
+
+int launch_finish(dflo_hip_engine *h, bool reductions_done = false) {
+  const Plan &p = h->plan;
+  const int rk = h->pending_rk;
+  if (rk < 0) { h->err = "no stage pending"; return DFLO_ERR_BAD_PARAM; }
+  const bool last = rk == h->n_rk - 1;
+  if (last && h->geo == 1) {  // bilinear cells: dt from the point values of the (limited) new solution,
+    if (h->dtq_parts != 3) {   // unless the limiter pass of this stage has formed it on the way
+      launch_dt_q(h);
+      HIPCHK(h, hipGetLastError());
+    }
+  } else if (last && h->d_dt_cell) {  // local time stepping: the per-cell dt of the next step
+    hipLaunchKernelGGL(dt_kernel, dim3(p.n_shards), dim3(64), 0, h->stream, h->avg[h->avg_cur], h->d_cell_h, p.h,
+                       p.uniform_h ? 1 : 0, h->d_shard_count, h->shard_dtmin, h->prm.cfl, h->degree, h->d_dt_cell);
+    HIPCHK(h, hipGetLastError());
+  }
+  h->pending_rk = -1;
+  if (!last || reductions_done) return DFLO_OK;  // ||rhs|| of every stage is reduced once, after the last stage (it is only reported, src/claw.cc:768)
+  FinalArgs f{};
+  final_args(h, f);
   hipLaunchKernelGGL(finalize_kernel, dim3(fin_grid(f.n_shards)), dim3(256), 0, h->stream, f);
   HIPCHK(h, hipGetLastError());
-  h->pending_rk = -1;
   return DFLO_OK;
 }
 
+// limiter and reductions of the open stage.  The TVB pass over all shards that ends a step on squares takes the reductions
+// along (LimArgs::fin): nothing that finalize_kernel reads is written by the pass there (the averages, and with them the CFL
+// minima, do not change under limiting; on bilinear cells the pass itself forms the time step, so not there).
 int launch_limit_finalize(dflo_hip_engine *h) {
-  int rc = launch_stage_limiter(h, 0);
+  const bool last = h->pending_rk == h->n_rk - 1;
+  const bool fuse = h->fuse_fin && last && h->geo == 0 && !h->d_dt_cell && h->basis == DFLO_BASIS_QK &&
+                    h->prm.limiter_type == DFLO_LIMITER_TVB && !h->fuse_pos && h->plan.n_shards > 0;
+  FinalArgs f{};
+  if (fuse) final_args(h, f);
+  int rc = launch_stage_limiter(h, 0, fuse ? &f : nullptr);
   if (rc) return rc;
-  return launch_finish(h);
+  return launch_finish(h, fuse);
 }
 
 int launch_stage(dflo_hip_engine *h, int rk, double dt_host, double *rhs_out, int which_override) {
@@ -702,6 +719,7 @@ int dflo_hip_create(const dflo_mesh_t *mesh, const dflo_params_t *params, int de
   h->basis = mesh->basis;
   const Tunables tun = read_tunables();
   h->use_graph = tun.graph;
+  h->fuse_fin = tun.fuse_fin;
   h->sweep_mode = tun.sweep ? 1 : 0;
   h->stream_override = tun.stream;
   h->fuse_dtq = tun.fuse_dtq;

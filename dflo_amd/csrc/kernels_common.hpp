@@ -178,6 +178,102 @@ __device__ __forceinline__ int shard_of_block(int b, int n_shards, int rev = 0) 
   return i < chunk && s < n_shards ? s : -1;
 }
 
+// reductions over shards + the global-dt rules of compute_time_step (src/claw.cc:468-476)
+struct FinalArgs {
+  const double *shard_res, *shard_dtmin;
+  double *res_sq;  // [3] per stage
+  double *dt_dev;  // [0] dt, [1] elapsed time, [2] raw min before rules
+  double *partial; // [kFinBlocks][4] workgroup partials
+  int *counter;    // [0] workgroups done, [1] time steps completed since set_solution
+  int n_shards, n_stages, res_stride, do_dt, advance_time, global_rules;  // shard_res: [n_stages][res_stride]
+  int fixed_dt;    // "time step type = global" with cfl <= 0: dt = time_step (src/claw.cc:455-460)
+  double *publish; // multi-device: the raw minimum also goes here (a slot the peers read, alternating from step to step)
+  double time_step, final_time, dt_host;
+};
+// the global-time-step rules of compute_time_step (src/claw.cc:455-476) applied to the raw CFL minimum
+__device__ __forceinline__ double dt_rules(double dt, double t, double time_step, double final_time, int global_rules, int fixed_dt) {
+  if (fixed_dt) return time_step;
+  if (global_rules) {
+    if (dt > 0 && time_step > 0) dt = fmin(dt, time_step);
+    if (t + dt > final_time) dt = fmax(final_time - t, 0.0);   // (never a step backwards once t has rounded past final_time)
+  }
+  return dt;
+}
+constexpr int kFinBlocks = 64;   // workgroups of the two-level reduction (one lane of the last workgroup's first wavefront each)
+// what the one thread that holds the totals of a step writes: the squared residual norms, the clock, the raw CFL minimum and
+// the time step of the next step
+__device__ __forceinline__ void finalize_publish(const FinalArgs &a, const double (&tot)[3], double dt) {
+  *a.counter = 0;  // ready for the next launch (launches on one stream do not overlap)
+  for (int st = 0; st < a.n_stages; ++st) a.res_sq[st] = tot[st];
+  if (a.do_dt) {
+    double tt = a.dt_dev[1];
+    if (a.advance_time) {  // elapsed_time += global_dt (src/claw.cc:1072) for the step just done
+      tt += a.dt_host >= 0.0 ? a.dt_host : a.dt_dev[0];
+      a.dt_dev[1] = tt;
+      a.counter[1] += 1;   // steps completed (what a failure flag raised in the next step reports)
+    }
+    a.dt_dev[2] = dt;
+    if (a.publish) *a.publish = dt;
+    a.dt_dev[0] = dt_rules(dt, tt, a.time_step, a.final_time, a.global_rules, a.fixed_dt);
+  }
+}
+// finalize_kernel's workgroup `b` of `nb`, run by ONE wavefront (the first workgroups of a limiter pass that ends a step take it
+// on, see limiter_kernel): lane l plays the threads l, l + 64, l + 128, l + 192 of the 256, so every sum is formed in the order
+// finalize_kernel forms it -- the same bits.
+__device__ __forceinline__ void finalize_by_wave(const FinalArgs &a, int b, int nb) {
+  const int n = a.n_shards, l = threadIdx.x & 63;
+  const int chunk = ((n + kFinBlocks - 1) / kFinBlocks + 255) & ~255;
+  const int lo = b * chunk, hi = min(n, lo + chunk);
+  double rs[4][3], m[4];
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    rs[w][0] = rs[w][1] = rs[w][2] = 0.0;
+    m[w] = 1.0e20;
+  }
+  for (int base = lo; base < hi; base += 4 * 256) {
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      double v[4][3], d[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int s = base + l + 64 * w + j * 256;
+        const bool in = s < hi;
+#pragma unroll
+        for (int st = 0; st < 3; ++st) v[j][st] = (in && st < a.n_stages) ? a.shard_res[(size_t)st * a.res_stride + s] : 0.0;
+        d[j] = (in && a.do_dt) ? a.shard_dtmin[s] : 1.0e20;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int st = 0; st < 3; ++st) rs[w][st] += v[j][st];
+        m[w] = fmin(m[w], d[j]);
+      }
+    }
+  }
+  double sred[4][4];
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+#pragma unroll
+    for (int st = 0; st < 3; ++st) sred[st][w] = wave_sum(rs[w][st]);
+    sred[3][w] = wave_min(m[w]);
+  }
+  int last = 0;
+  if (l == 0) {
+    for (int st = 0; st < 3; ++st) a.partial[b * 4 + st] = (sred[st][0] + sred[st][1]) + (sred[st][2] + sred[st][3]);
+    a.partial[b * 4 + 3] = fmin(fmin(sred[3][0], sred[3][1]), fmin(sred[3][2], sred[3][3]));
+    __threadfence();
+    last = atomicAdd(a.counter, 1) == nb - 1;
+  }
+  last = __shfl(last, 0);
+  if (!last) return;
+  __threadfence();
+  const bool have = l < nb;
+  double tot[3], dt = have ? ((const volatile double *)a.partial)[l * 4 + 3] : 1.0e20;
+  for (int st = 0; st < 3; ++st) tot[st] = wave_sum(have ? ((const volatile double *)a.partial)[l * 4 + st] : 0.0);
+  dt = wave_min(dt);
+  if (l == 0) finalize_publish(a, tot, dt);
+}
+
 // ------------------------------------------------------------------ positivity limiter, pointwise parts
 // (shared by limiter_kernel and the stage kernels that apply the limiter on the way out, so that both round alike)
 __device__ __forceinline__ double positivity_blend(double theta, double u, double avg) {   // src/positivity.cc:84-87, 196-199

@@ -337,28 +337,6 @@ __global__ void dt_kernel(const double *avg, const double *cell_h, double h_unif
   if (lane == 0) shard_dtmin[shard] = dtmin;
 }
 
-// reductions over shards + the global-dt rules of compute_time_step (src/claw.cc:468-476)
-struct FinalArgs {
-  const double *shard_res, *shard_dtmin;
-  double *res_sq;  // [3] per stage
-  double *dt_dev;  // [0] dt, [1] elapsed time, [2] raw min before rules
-  double *partial; // [kFinBlocks][4] workgroup partials
-  int *counter;    // [0] workgroups done, [1] time steps completed since set_solution
-  int n_shards, n_stages, res_stride, do_dt, advance_time, global_rules;  // shard_res: [n_stages][res_stride]
-  int fixed_dt;    // "time step type = global" with cfl <= 0: dt = time_step (src/claw.cc:455-460)
-  double *publish; // multi-device: the raw minimum also goes here (a slot the peers read, alternating from step to step)
-  double time_step, final_time, dt_host;
-};
-// the global-time-step rules of compute_time_step (src/claw.cc:455-476) applied to the raw CFL minimum
-__device__ __forceinline__ double dt_rules(double dt, double t, double time_step, double final_time, int global_rules, int fixed_dt) {
-  if (fixed_dt) return time_step;
-  if (global_rules) {
-    if (dt > 0 && time_step > 0) dt = fmin(dt, time_step);
-    if (t + dt > final_time) dt = fmax(final_time - t, 0.0);   // (never a step backwards once t has rounded past final_time)
-  }
-  return dt;
-}
-constexpr int kFinBlocks = 64;   // workgroups of the two-level reduction (one lane of the last workgroup's first wavefront each)
 __global__ __launch_bounds__(256) void finalize_kernel(const FinalArgs a) {
   __shared__ double sred[4][4];
   __shared__ int is_last;
@@ -414,19 +392,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(const FinalArgs a) {
   for (int st = 0; st < 3; ++st) tot[st] = wave_sum(have ? spart[t * 4 + st] : 0.0);
   dt = wave_min(dt);
   if (t != 0) return;
-  *a.counter = 0;  // ready for the next launch (launches on one stream do not overlap)
-  for (int st = 0; st < a.n_stages; ++st) a.res_sq[st] = tot[st];
-  if (a.do_dt) {
-    double tt = a.dt_dev[1];
-    if (a.advance_time) {  // elapsed_time += global_dt (src/claw.cc:1072) for the step just done
-      tt += a.dt_host >= 0.0 ? a.dt_host : a.dt_dev[0];
-      a.dt_dev[1] = tt;
-      a.counter[1] += 1;   // steps completed (what a failure flag raised in the next step reports)
-    }
-    a.dt_dev[2] = dt;
-    if (a.publish) *a.publish = dt;
-    a.dt_dev[0] = dt_rules(dt, tt, a.time_step, a.final_time, a.global_rules, a.fixed_dt);
-  }
+  finalize_publish(a, tot, dt);
 }
 // re-apply the rules after an external all-reduce(min) of dt_dev[2] (multi-device), or after taking the minimum over
 // the slots the other engines of this process published (peer reads over xGMI)

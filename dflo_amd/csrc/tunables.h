@@ -15,6 +15,7 @@ struct Tunables {
   int stream = -1;         // DFLO_STREAM=0|1    forbid / force streaming stores of the new state (default: when no pass over all cells follows)
   bool fuse_dtq = true;    // DFLO_FUSE_DTQ=0    bilinear cells: compute_time_step_q by the separate pass instead of the last stage kernel
   bool fuse_pos = true;    // DFLO_FUSE_POS=0    positivity without TVB on Qk: separate limiter pass instead of inside the stage kernel
+  bool fuse_fin = true;    // DFLO_FUSE_FIN=0    TVB on Qk squares: finalize_kernel as its own launch instead of inside the limiter pass that ends the step
   bool lazy_avg = true;    // DFLO_LAZY_AVG=0    store the cell averages of every stage (default: only when somebody reads them)
   int lim_mask = -1;       // DFLO_LIM_MASK=0|1  TVB on squares: forbid / force the stage kernel's marks for the limiter pass (default: degree >= 2; degree 1 without ghost cells)
   bool halo_cells = false; // DFLO_HALO_CELLS=1  multi-device: ghost cells as whole cells instead of face traces
@@ -49,6 +50,7 @@ inline Tunables read_tunables() {
   t.stream = tri("DFLO_STREAM");
   t.fuse_dtq = flag("DFLO_FUSE_DTQ", true);
   t.fuse_pos = flag("DFLO_FUSE_POS", true);
+  t.fuse_fin = flag("DFLO_FUSE_FIN", true);
   t.lazy_avg = flag("DFLO_LAZY_AVG", true);
   t.lim_mask = tri("DFLO_LIM_MASK");
   t.halo_cells = flag("DFLO_HALO_CELLS", false);

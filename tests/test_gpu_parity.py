@@ -1046,6 +1046,41 @@ def test_limiter_marks_from_the_stage_kernel(degree, M, wave, monkeypatch):
     assert abs(t1 - t0) <= 1e-12 * t0 and rel(runs["1"].current_solution, runs["0"].current_solution) < 1e-10
 
 
+@pytest.mark.parametrize("degree,M", [(1, 0.0), (2, 30.0)])
+def test_reductions_inside_the_last_limiter_pass_give_the_same_bits(degree, M, monkeypatch):
+    """TVB on squares: the limiter pass that ends a step also forms the step's reductions (residual norms, CFL minimum, clock,
+    next time step) -- its first wavefronts each play one workgroup of finalize_kernel.  DFLO_FUSE_FIN=0 launches
+    finalize_kernel as before: the same sums in the same order, so norms, time steps, clock and state agree bit for bit."""
+    bnd = {0: "slip", 1: "outflow", 2: "inflow"}
+    nx, ny = (320, 208) if degree == 1 else (256, 264)   # 1 040 / 1 056 shards: five reduction chunks of 256, the last one partial
+    mesh = dflo_amd.Mesh.cartesian(nx, ny, 0.0, 0.0, 1.0 / nx, [2, 1, 0, 0], degree)
+    prm = dflo_amd.Parameters(flux="roe", limiter="TVB", char_lim=True, pos_lim=True, M=M, beta=1.5, boundary=bnd, cfl=0.7)
+    def ic(x, y):
+        mx, my, rho, E = problems.sod(x, y)
+        return [mx, my, rho * (1.0 + 0.02 * np.sin(9.0 * x) * np.cos(7.0 * y)), E]
+    u0 = mesh.interpolate(ic)
+    out = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("DFLO_FUSE_FIN", flag)
+        claw = dflo_amd.ConservationLaw(mesh, prm)
+        cell, face, bid, xy = claw.boundary_faces()
+        bv = np.stack(ic(xy[..., 0], xy[..., 1]), axis=-1)
+        claw.set_boundary_values(0, bv)
+        claw.set_boundary_values(1, bv)
+        claw.set_initial_condition(u0)
+        claw.apply_limiter()
+        hist = []
+        for it in range(4):
+            dt = claw.compute_time_step()
+            hist.append((dt,) + tuple(claw.iterate_explicit(dt)))
+        hist.append(claw.advance(9))
+        hist.append(claw.compute_time_step())
+        out.append((hist, claw.current_solution.copy(), claw.cell_average.copy()))
+        claw.close()
+    assert out[0][0] == out[1][0]
+    assert np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2])
+
+
 def test_c1_configuration_100_steps():
     """BASELINE config 1 to the letter: [-5,5]^2, 64 x 64 squares, periodic, Q1 (SSP-RK2), LxF, cfl 0.9, the
     src/ vortex -- residual of the initial state and the solution after 100 steps against the oracle, once step by step
