@@ -106,6 +106,13 @@ struct dflo_hip_engine {
   bool fuse_pos = false;   // positivity limiter without TVB on Qk: applied inside the stage kernel (DFLO_FUSE_POS=0: separate pass)
   unsigned long long *lim_mask = nullptr;   // TVB on Qk squares: [n_shards], written by the stage kernel for the limiter pass (DFLO_LIM_MASK=0: off)
   bool aux_fresh = false;      // lim_mask belongs to the state the open stage has just produced
+  // the marked shards as a list (launches over all shards; DFLO_LIM_LIST=0: off): two counters that alternate from one marked
+  // stage launch to the next -- the pass that walks the list of one zeroes the counter of the other -- and what the host knows
+  // about them (a counter whose pass never ran is cleared by a memset before it is used again)
+  int *lim_cnt = nullptr;
+  ulonglong2 *lim_list = nullptr;
+  int lim_epoch = 0, lim_open = -1, lim_grid = 1024;
+  bool lim_clean[2] = {true, true};
   // dflo_hip_advance replays a captured graph of `graph_steps` time steps (the buffer rotation repeats with
   // that period); built lazily for the state it was captured in
   hipGraphExec_t graph_exec = nullptr;
@@ -277,6 +284,7 @@ int open_stage(dflo_hip_engine *h, int rk, double dt_host, bool residual_only, i
     h->pending_dt = dt_host;
     h->dtq_parts = 0;
     h->aux_fresh = false;
+    h->lim_open = -1;
     // stage timing samples every fifth stage (5 is coprime to the 2 or 3 stages of a step, so every stage of the
     // step is sampled equally often): two event records per launch are not free
     h->t_sample = h->timing && (h->t_seen++ % 5 == 0);
@@ -426,11 +434,23 @@ int launch_update(dflo_hip_engine *h, double *rhs_out, int part) {
   a.gt_slot = h->d_gt_slot;
   a.pos_stats = h->pos_stats;
   a.lim_mask = h->lim_mask;
+  a.lim_cnt = nullptr;
+  a.lim_list = h->lim_list;
   a.tvb_M = h->prm.limiter_type == DFLO_LIMITER_TVB ? h->prm.M : -1.0;
   a.tvb_char = h->prm.char_lim;
   a.pos_check = h->prm.pos_lim;
   const int pos_ = h->fuse_pos ? 1 : (h->lim_mask ? 2 : 0);
-  if (pos_ == 2 && mode_ != 2) h->aux_fresh = true;
+  if (pos_ == 2 && mode_ != 2) {
+    h->aux_fresh = true;
+    h->lim_open = -1;
+    if (h->lim_cnt && part == 0) {
+      const int i = ++h->lim_epoch & 1;
+      if (!h->lim_clean[i]) HIPCHK(h, hipMemsetAsync(h->lim_cnt + i, 0, sizeof(int), h->stream));
+      h->lim_clean[i] = false;
+      h->lim_open = i;
+      a.lim_cnt = h->lim_cnt + i;
+    }
+  }
   stage_fn fn = h->basis == DFLO_BASIS_PK ? pick_pk(h->N, h->prm.flux_type, mode_, streams_out(h)) : pick_stage(h->N, h->prm.flux_type, mode_, h->geo, pos_, streams_out(h));
   time_begin(h);
   hipLaunchKernelGGL(fn, dim3(grid_for(a.n_list)), dim3(64 * h->N), h->lds_bytes, h->stream, a);
@@ -512,7 +532,16 @@ int launch_limiter(dflo_hip_engine *h, int tvb, int pos, int part, bool stage_da
   }
   void (*lf)(const LimArgs) = DFLO_BY_N_LIM(h->N, limiter_kernel);
   if (h->basis == DFLO_BASIS_PK) lf = DFLO_BY_N_LIM(h->N, limiter_pk_kernel);
-  hipLaunchKernelGGL(lf, dim3(grid_for(l.n_list)), dim3(64), 0, h->stream, l);
+  int grid = grid_for(l.n_list);
+  if (l.mask && part == 0 && h->lim_open >= 0 && h->basis == DFLO_BASIS_QK) {
+    l.mark_list = h->lim_list;
+    l.mark_cnt = h->lim_cnt + h->lim_open;
+    l.mark_cnt_next = h->lim_cnt + (h->lim_open ^ 1);
+    h->lim_clean[h->lim_open ^ 1] = true;
+    h->lim_open = -1;
+    grid = std::min(grid, std::max(h->lim_grid, l.fin_blocks));
+  }
+  hipLaunchKernelGGL(lf, dim3(grid), dim3(64), 0, h->stream, l);
   HIPCHK(h, hipGetLastError());
   return DFLO_OK;
 }
@@ -905,6 +934,16 @@ int dflo_hip_create(const dflo_mesh_t *mesh, const dflo_params_t *params, int de
         return bail(DFLO_ERR_NOMEM);
       }
       hipMemset(h->lim_mask, 0, nb);
+      if (tun.lim_list) {
+        if (hipMalloc((void **)&h->lim_cnt, 2 * sizeof(int)) != hipSuccess ||
+            hipMalloc((void **)&h->lim_list, (size_t)(p.n_shards + 8) * sizeof(ulonglong2)) != hipSuccess) {
+          h->err = "hipMalloc(limiter list) failed";
+          return bail(DFLO_ERR_NOMEM);
+        }
+        hipMemset(h->lim_cnt, 0, 2 * sizeof(int));
+        hipMemset(h->lim_list, 0, (size_t)(p.n_shards + 8) * sizeof(ulonglong2));
+        h->lim_grid = std::max(64, tun.lim_grid);
+      }
     }
   }
   {
@@ -949,7 +988,7 @@ int dflo_hip_destroy(dflo_hip_handle h) {
   hipFree(h->rhs); hipFree(h->user_buf); hipFree(h->bface_kind);
   hipFree(h->d_bc_ops); hipFree(h->d_bc_consts); hipFree(h->d_bc_prog); hipFree(h->d_bc_faces); hipFree(h->d_bc_pts); hipFree(h->d_bface_id); hipFree(h->d_bxy);
   hipFree(h->d_shard_count);
-  hipFree(h->d_bnd_pad); hipFree(h->d_nbr_code); hipFree(h->d_shock); hipFree(h->lim_mask); hipFree(h->d_faces_pad); hipFree(h->d_shard_hdr); hipFree(h->d_halo_pad); hipFree(h->d_cell_face); hipFree(h->d_lrbt); hipFree(h->d_user_of); hipFree(h->d_iid);
+  hipFree(h->d_bnd_pad); hipFree(h->d_nbr_code); hipFree(h->d_shock); hipFree(h->lim_mask); hipFree(h->lim_cnt); hipFree(h->lim_list); hipFree(h->d_faces_pad); hipFree(h->d_shard_hdr); hipFree(h->d_halo_pad); hipFree(h->d_cell_face); hipFree(h->d_lrbt); hipFree(h->d_user_of); hipFree(h->d_iid);
   hipFree(h->d_rim_list); hipFree(h->d_int_list); hipFree(h->d_rim2_list); hipFree(h->d_rest2_list);
   hipFree(h->d_cell_h); hipFree(h->d_dt_cell); hipFree(h->d_cell_vert); hipFree(h->shard_res); hipFree(h->shard_dtmin); hipFree(h->res_sq); hipFree(h->fin_partial); hipFree(h->dt_dev);
   if (h->flags_host) hipHostFree((void *)h->flags_host);

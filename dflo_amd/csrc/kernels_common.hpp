@@ -76,6 +76,9 @@ struct StageArgs {
   const int32_t *gt_slot;  // internal slot of the ghost cell of a trace (its cell average: LxF)
   unsigned long long *pos_stats;  // POS 1: [0] cells that failed the nodal-box bound (limiter proper), [1] cells it changed
   unsigned long long *lim_mask;   // POS 2: [n_shards] bit = the limiter pass may have something to do in that cell
+  int *lim_cnt;                   // POS 2, launches over all shards: the shards with a mark also go on a list (one append per
+  ulonglong2 *lim_list;           //   marked shard and launch: a single wavefront writes a shard's word) as (shard, word), so that the pass is a few
+                                  //   hundred wavefronts walking that list instead of one per shard that reads a word and leaves; or null
   double tvb_M;                   // POS 2: TVB constant M, < 0: the limiter pass has no TVB part
   int tvb_char, pos_check;        // POS 2: characteristic limiting; the positivity limiter runs in the pass
   KBasis kb;

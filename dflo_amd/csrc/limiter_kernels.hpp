@@ -56,6 +56,12 @@ struct LimArgs {
   int sweep_rev;
   const double *shock;  // KXRCF indicator per cell, or null: "shock indicator = limiter" marks every cell (1e20)
   unsigned long long *mask;   // [n_shards] from the stage kernel: the cells this pass can change (cleared here), or null: all cells
+  // with marks, on launches over all shards: the marked shards as a list (StageArgs::lim_list).  The grid is a few hundred
+  // wavefronts that walk it; mark_cnt is the stage kernel's count, mark_cnt_next the counter the next stage kernel will use
+  // (zeroed here: the two alternate).  null: one wavefront per shard looks at its word.
+  const ulonglong2 *mark_list;   // (shard, the word the stage kernel OR-ed into mask[shard])
+  const int *mark_cnt;
+  int *mark_cnt_next;
   // multi-device, TVB: the averages of the ghost cells as their owners sent them, [n_ghost][4] in ghost order (the receive area
   // itself: no unpack kernel between the arrival and this pass), or null: they are in `avg` like everybody's
   const double *ghost_avg;
@@ -75,12 +81,8 @@ struct LimArgs {
 // apply_limiter_TVB_Qk (src/limiter.cc:225-370) then apply_positivity_limiter
 // (src/positivity.cc:17-208), lane = cell, all DoFs of the cell in registers.
 template <int N>
-__global__ __launch_bounds__(64) void limiter_kernel(const LimArgs a) {
+__device__ __forceinline__ void limiter_shard(const LimArgs &a, const int shard, const bool listed = false, const unsigned long long word = 0) {
   constexpr int NS = N * N, NDOF = 4 * NS;
-  if (a.fin_blocks > 0 && (int)blockIdx.x < a.fin_blocks) finalize_by_wave(a.fin, blockIdx.x, a.fin_blocks);
-  const int sidx = shard_of_block(blockIdx.x, a.n_list, a.sweep_rev);
-  if (sidx < 0) return;
-  const int shard = a.shard_list ? a.shard_list[sidx] : sidx;
   const int lane = threadIdx.x;
   const bool active = lane < a.shard_count[shard];   // padding lanes hold a harmless state and run along
   const KBasis &kb = a.kb;
@@ -90,7 +92,7 @@ __global__ __launch_bounds__(64) void limiter_kernel(const LimArgs a) {
   // as they are, see the stage kernel): most wavefronts return after one load.
   bool marked = true;
   if (a.mask) {
-    const unsigned long long m = a.mask[shard];
+    const unsigned long long m = listed ? word : a.mask[shard];   // listed: the word came with the list entry (one round trip less)
     if (m == 0) return;
     if (lane == 0) a.mask[shard] = 0;   // consumed (the load above has returned: m was compared)
     marked = (m >> lane) & 1;
@@ -299,6 +301,29 @@ __global__ __launch_bounds__(64) void limiter_kernel(const LimArgs a) {
     dtmin = wave_min(dtmin);
     if (lane == 0) a.shard_dtmin[shard] = dtmin;
   }
+}
+
+template <int N>
+__global__ __launch_bounds__(64) void limiter_kernel(const LimArgs a) {
+  if (a.mark_list) {
+    // the marked shards from the stage kernel's list, in the order they were appended (any order gives the same bits: a shard's
+    // pass rewrites its own cells and reads averages, which limiting does not change).  The step's reductions ride on the LAST
+    // wavefronts of the grid, which have a list entry only when the list is longer than the grid.
+    ulonglong2 e = a.mark_list[blockIdx.x];   // asked for with the count, not behind it (an entry beyond the count is not used)
+    const int cnt = __builtin_amdgcn_readfirstlane(*(const volatile int *)a.mark_cnt);
+    if (blockIdx.x == 0 && threadIdx.x == 0) *a.mark_cnt_next = 0;
+    const int fb = (int)blockIdx.x - ((int)gridDim.x - a.fin_blocks);
+    if (a.fin_blocks > 0 && fb >= 0) finalize_by_wave(a.fin, fb, a.fin_blocks);
+    for (int k = blockIdx.x; k < cnt; k += gridDim.x) {
+      if (k != (int)blockIdx.x) e = a.mark_list[k];
+      limiter_shard<N>(a, (int)e.x, true, e.y);
+    }
+    return;
+  }
+  if (a.fin_blocks > 0 && (int)blockIdx.x < a.fin_blocks) finalize_by_wave(a.fin, blockIdx.x, a.fin_blocks);
+  const int sidx = shard_of_block(blockIdx.x, a.n_list, a.sweep_rev);
+  if (sidx < 0) return;
+  limiter_shard<N>(a, a.shard_list ? a.shard_list[sidx] : sidx);
 }
 
 // apply_limiter_TVB_Pk (src/limiter.cc:377-516) then the Pk branch of apply_positivity_limiter

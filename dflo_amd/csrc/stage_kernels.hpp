@@ -953,7 +953,10 @@ __global__ __launch_bounds__(64 * N, N >= 5 ? 1 : ((N == 4 && GEO == 0 && MODE =
         need = need || (over && !(0.25 * sum <= 0.9998e-10));
       }
       const unsigned long long m = __ballot(need && active);
-      if (lane == 0 && m) atomicOr(&a.lim_mask[shard], m);
+      if (lane == 0 && m) {
+        atomicOr(&a.lim_mask[shard], m);
+        if (a.lim_cnt) a.lim_list[atomicAdd(a.lim_cnt, 1)] = make_ulonglong2((unsigned long long)shard, m);
+      }
     }
   }
   if (row == N - 1) {  // cell averages (src/claw.cc:562-597), residual norm, CFL minimum of the shard; on the
@@ -1002,7 +1005,10 @@ __global__ __launch_bounds__(64 * N, N >= 5 ? 1 : ((N == 4 && GEO == 0 && MODE =
       bool settled, open;
       limiter_marks_from_box<N>(lo, hi, sd == sd, sd, a.kb.pg_neg, a.tvb_M, a.tvb_char, h, settled, open);
       const unsigned long long m = __ballot(((a.pos_check && !settled) || open) && active);
-      if (lane == 0 && m) atomicOr(&a.lim_mask[shard], m);
+      if (lane == 0 && m) {
+        atomicOr(&a.lim_mask[shard], m);
+        if (a.lim_cnt) a.lim_list[atomicAdd(a.lim_cnt, 1)] = make_ulonglong2((unsigned long long)shard, m);
+      }
     }
     bool have_dt = GEO == 0 && a.want_dt;
     if constexpr (GEO == 1 && MODE != 2) {

@@ -17,6 +17,8 @@ struct Tunables {
   bool fuse_pos = true;    // DFLO_FUSE_POS=0    positivity without TVB on Qk: separate limiter pass instead of inside the stage kernel
   bool fuse_fin = true;    // DFLO_FUSE_FIN=0    TVB on Qk squares: finalize_kernel as its own launch instead of inside the limiter pass that ends the step
   bool lazy_avg = true;    // DFLO_LAZY_AVG=0    store the cell averages of every stage (default: only when somebody reads them)
+  bool lim_list = true;    // DFLO_LIM_LIST=0    with marks: one wavefront per shard looks at its word instead of a short grid walking the list of marked shards
+  int lim_grid = 1024;     // DFLO_LIM_GRID=n    wavefronts of that short grid
   int lim_mask = -1;       // DFLO_LIM_MASK=0|1  TVB on squares: forbid / force the stage kernel's marks for the limiter pass (default: degree >= 2; degree 1 without ghost cells)
   bool halo_cells = false; // DFLO_HALO_CELLS=1  multi-device: ghost cells as whole cells instead of face traces
   bool verbose = false;    // DFLO_VERBOSE=1     print the LDS footprint and the resident workgroups of the stage kernel
@@ -53,6 +55,8 @@ inline Tunables read_tunables() {
   t.fuse_fin = flag("DFLO_FUSE_FIN", true);
   t.lazy_avg = flag("DFLO_LAZY_AVG", true);
   t.lim_mask = tri("DFLO_LIM_MASK");
+  t.lim_list = flag("DFLO_LIM_LIST", true);
+  if (const char *e = std::getenv("DFLO_LIM_GRID")) t.lim_grid = std::atoi(e);
   t.halo_cells = flag("DFLO_HALO_CELLS", false);
   t.verbose = std::getenv("DFLO_VERBOSE") != nullptr;
   if (const char *e = std::getenv("DFLO_PLAN_REFINE")) t.plan_refine = std::atoi(e);

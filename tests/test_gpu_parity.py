@@ -1081,6 +1081,51 @@ def test_reductions_inside_the_last_limiter_pass_give_the_same_bits(degree, M, m
     assert np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2])
 
 
+@pytest.mark.parametrize("degree,M", [(1, 0.0), (2, 30.0)])
+def test_limiter_pass_over_the_list_of_marked_shards_gives_the_same_bits(degree, M, monkeypatch):
+    """TVB on squares, launches over all shards: the stage kernel appends the shards it marks to a list and the pass is a short
+    grid walking that list (DFLO_LIM_LIST=0: one wavefront per shard reads its word).  Any order of the list gives the same bits.
+    Also with a grid far shorter than the list (DFLO_LIM_GRID=64: every wavefront takes several entries) and across a fresh
+    start in the middle of the run (stepwise calls, the resident loop, a new initial condition, the resident loop again)."""
+    bnd = {0: "slip", 1: "outflow", 2: "inflow"}
+    nx, ny = (320, 208) if degree == 1 else (256, 264)
+    mesh = dflo_amd.Mesh.cartesian(nx, ny, 0.0, 0.0, 1.0 / nx, [2, 1, 0, 0], degree)
+    prm = dflo_amd.Parameters(flux="roe", limiter="TVB", char_lim=True, pos_lim=True, M=M, beta=1.5, boundary=bnd, cfl=0.7)
+    def ic(x, y):   # rough enough that hundreds of shards carry marks
+        mx, my, rho, E = problems.sod(x, y)
+        return [mx, my, rho * (1.0 + 0.05 * np.sin(40.0 * x) * np.cos(31.0 * y)), E]
+    u0 = mesh.interpolate(ic)
+    out = []
+    for env in ({"DFLO_LIM_LIST": "0"}, {}, {"DFLO_LIM_GRID": "64"}):
+        monkeypatch.delenv("DFLO_LIM_LIST", raising=False)
+        monkeypatch.delenv("DFLO_LIM_GRID", raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        claw = dflo_amd.ConservationLaw(mesh, prm)
+        cell, face, bid, xy = claw.boundary_faces()
+        bv = np.stack(ic(xy[..., 0], xy[..., 1]), axis=-1)
+        claw.set_boundary_values(0, bv)
+        claw.set_boundary_values(1, bv)
+        claw.set_initial_condition(u0)
+        claw.apply_limiter()
+        hist = []
+        for it in range(3):
+            dt = claw.compute_time_step()
+            hist.append((dt,) + tuple(claw.iterate_explicit(dt)))
+        hist.append(claw.advance(7))
+        # a fresh start: the counters go on alternating from where they are
+        claw.set_initial_condition(u0)
+        claw.apply_limiter()
+        hist.append(claw.advance(6))
+        hist.append(claw.compute_time_step())
+        out.append((hist, claw.current_solution.copy(), claw.cell_average.copy()))
+        claw.close()
+    for o in out[1:]:
+        assert o[0] == out[0][0]
+        assert np.array_equal(o[1], out[0][1]) and np.array_equal(o[2], out[0][2])
+    assert not np.array_equal(out[0][1], u0)
+
+
 def test_c1_configuration_100_steps():
     """BASELINE config 1 to the letter: [-5,5]^2, 64 x 64 squares, periodic, Q1 (SSP-RK2), LxF, cfl 0.9, the
     src/ vortex -- residual of the initial state and the solution after 100 steps against the oracle, once step by step
