@@ -886,7 +886,7 @@ __global__ __launch_bounds__(64 * N, N >= 5 ? 1 : ((N == 4 && GEO == 0 && MODE =
     //  * Only wavefronts with a cell the box cannot settle form the slopes themselves (row partials in LDS, characteristic
     //    variables when `char_lim` is on), x then y, with a margin on the thresholds so that the pass, which forms the same
     //    slopes once more from the DoFs, can never disagree in the other direction.
-    //  (k = 1: in the last wave's block below)
+    //  (k = 1: wave 0's block below)
     if (row == 0) {
       double lo[4], hi[4];
       bool fin = true;
@@ -959,6 +959,40 @@ __global__ __launch_bounds__(64 * N, N >= 5 ? 1 : ((N == 4 && GEO == 0 && MODE =
       }
     }
   }
+  if constexpr (POS == 2 && GEO == 0 && MODE != 2 && N == 2) {
+    if (row == 0) {   // wave 0, beside the last wave's averages and reductions (the averages: the same partials in the same order)
+    double avg[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      double v = 0;
+#pragma unroll
+      for (int b = 0; b < N; ++b) v += red[(b * 5 + c) * 64 + lane];
+      avg[c] = v;
+    }
+    // The marks at k = 1, where every instruction of a 500-instruction kernel shows: no row extremes, no slopes -- the four
+    // nodal values of a component are (row mean) -+ (half the difference along the row), so they lie within
+    // d = |mean_1 - mean_0| + max |difference| of each other and of their average, and the box `average -+ sum of the d` holds
+    // every component.  The row means are the partials of the average, the differences were left in LDS
+    // by the row updates.  What the box cannot settle is marked (no second look at the slopes: with M = 0 there is nothing
+    // between "constant up to rounding" and "limited").
+    double sd = 1.0e-15 * (fabs(avg[0]) + fabs(avg[1]) + fabs(avg[2]) + fabs(avg[3]));   // (rounding of the partials)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const double dm = red[(1 * 5 + c) * 64 + lane] - red[(0 * 5 + c) * 64 + lane];   // w_b (row sum): half the row mean
+      sd += 2.0 * fabs(dm) + fmax(fabs(red[(5 * N + c * N) * 64 + lane]), fabs(red[(5 * N + c * N + 1) * 64 + lane]));
+    }
+    double lo[4], hi[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { lo[c] = avg[c] - sd; hi[c] = avg[c] + sd; }
+    bool settled, open;
+    limiter_marks_from_box<N>(lo, hi, sd == sd, sd, a.kb.pg_neg, a.tvb_M, a.tvb_char, h, settled, open);
+    const unsigned long long m = __ballot(((a.pos_check && !settled) || open) && active);
+    if (lane == 0 && m) {
+      atomicOr(&a.lim_mask[shard], m);
+      if (a.lim_cnt) a.lim_list[atomicAdd(a.lim_cnt, 1)] = make_ulonglong2((unsigned long long)shard, m);
+    }
+    }
+  }
   if (row == N - 1) {  // cell averages (src/claw.cc:562-597), residual norm, CFL minimum of the shard; on the
                        // last wave: wave 0 carries the extra pass over the face points
     double avg[4], res = 0.0, dtmin = 1.0e20;
@@ -984,30 +1018,6 @@ __global__ __launch_bounds__(64 * N, N >= 5 ? 1 : ((N == 4 && GEO == 0 && MODE =
         if (a.store_avg) a.avg_new[((size_t)shard * 4 + c) * 64 + lane] = avg[c];
       if constexpr (GEO == 0) {
         if (a.want_dt) dtmin = cfl_dt(avg, h, a.cfl, a.degree);
-      }
-    }
-    if constexpr (POS == 2 && GEO == 0 && MODE != 2 && N == 2) {
-      // The marks at k = 1, where every instruction of a 500-instruction kernel shows: no row extremes, no slopes -- the four
-      // nodal values of a component are (row mean) -+ (half the difference along the row), so they lie within
-      // d = |mean_1 - mean_0| + max |difference| of each other and of their average, and the box `average -+ sum of the d` holds
-      // every component.  The row means are the partials of the average (in registers here), the differences were left in LDS
-      // by the row updates.  What the box cannot settle is marked (no second look at the slopes: with M = 0 there is nothing
-      // between "constant up to rounding" and "limited").
-      double sd = 1.0e-15 * (fabs(avg[0]) + fabs(avg[1]) + fabs(avg[2]) + fabs(avg[3]));   // (rounding of the partials)
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const double dm = red[(1 * 5 + c) * 64 + lane] - red[(0 * 5 + c) * 64 + lane];   // w_b (row sum): half the row mean
-        sd += 2.0 * fabs(dm) + fmax(fabs(red[(5 * N + c * N) * 64 + lane]), fabs(red[(5 * N + c * N + 1) * 64 + lane]));
-      }
-      double lo[4], hi[4];
-#pragma unroll
-      for (int c = 0; c < 4; ++c) { lo[c] = avg[c] - sd; hi[c] = avg[c] + sd; }
-      bool settled, open;
-      limiter_marks_from_box<N>(lo, hi, sd == sd, sd, a.kb.pg_neg, a.tvb_M, a.tvb_char, h, settled, open);
-      const unsigned long long m = __ballot(((a.pos_check && !settled) || open) && active);
-      if (lane == 0 && m) {
-        atomicOr(&a.lim_mask[shard], m);
-        if (a.lim_cnt) a.lim_list[atomicAdd(a.lim_cnt, 1)] = make_ulonglong2((unsigned long long)shard, m);
       }
     }
     bool have_dt = GEO == 0 && a.want_dt;
