@@ -3,6 +3,8 @@
 // units are built in parallel with engine.hip, which holds everything else and reaches the kernels through stage_of_N).
 // For N = 5, 6 (degrees 4, 5: four minutes of compile time per degree) the unit is cut once more, by flux: with
 // -DDFLO_STAGE_FLUX=f it holds the kernels of that flux only (stage_of_N_f / stage_pk_of_N_f).
+// -DDFLO_STAGE_ONLY=1 (nodal, Qk) / 2 (modal, Pk) cuts a unit in two by element: the two halves of a degree may want
+// different instruction schedulers (build(): measured per degree and element on MI355X).
 #include "stage_kernels.hpp"
 
 #ifndef DFLO_STAGE_N
@@ -17,7 +19,11 @@ namespace dflo {
 stage_fn DFLO_CAT4(stage_of_, DFLO_STAGE_N, _f, DFLO_STAGE_FLUX)(int mode, int geo, int pos, int nt) { return pick_stage_m<DFLO_STAGE_N, DFLO_STAGE_FLUX>(mode, geo, pos, nt); }
 stage_fn DFLO_CAT4(stage_pk_of_, DFLO_STAGE_N, _f, DFLO_STAGE_FLUX)(int mode, int nt) { return pick_pk_m<DFLO_STAGE_N, DFLO_STAGE_FLUX>(mode, nt); }
 #else
+#if !defined(DFLO_STAGE_ONLY) || DFLO_STAGE_ONLY == 1
 stage_fn DFLO_CAT(stage_of_, DFLO_STAGE_N)(int flux, int mode, int geo, int pos, int nt) { return pick_stage_n<DFLO_STAGE_N>(flux, mode, geo, pos, nt); }
+#endif
+#if !defined(DFLO_STAGE_ONLY) || DFLO_STAGE_ONLY == 2
 stage_fn DFLO_CAT(stage_pk_of_, DFLO_STAGE_N)(int flux, int mode, int nt) { return pick_pk_n<DFLO_STAGE_N>(flux, mode, nt); }
+#endif
 #endif
 }  // namespace dflo
