@@ -117,6 +117,7 @@ struct dflo_hip_engine {
   // that period); built lazily for the state it was captured in
   hipGraphExec_t graph_exec = nullptr;
   int graph_steps = 0, graph_cur = -1, graph_avg = -1;
+  int graph_lim = 0;   // parity of lim_epoch the graph was captured at (its launches name the two list counters in that order)
   hipStream_t graph_stream = nullptr;
   bool use_graph = false;  // opt-in (DFLO_GRAPH=1): on ROCm 7.2 / MI355X replay measured no faster than plain launches
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
@@ -1245,7 +1246,8 @@ int dflo_hip_advance(dflo_hip_handle h, int n_steps, double *elapsed_time_inout)
     // n_rk times per step): capture those once, replay them for the bulk of the steps
     const int period = 2;
     if (n_steps >= 2 * period) {
-      if (h->graph_exec && (h->graph_cur != h->cur || h->graph_avg != h->avg_cur || h->graph_stream != h->stream)) drop_graph(h);
+      const int lim_par = h->lim_cnt ? (h->lim_epoch & 1) : 0;
+      if (h->graph_exec && (h->graph_cur != h->cur || h->graph_avg != h->avg_cur || h->graph_stream != h->stream || h->graph_lim != lim_par)) drop_graph(h);
       if (!h->graph_exec) {
         const int cur0 = h->cur, avg0 = h->avg_cur;
         hipGraph_t g = nullptr;
@@ -1275,9 +1277,17 @@ int dflo_hip_advance(dflo_hip_handle h, int n_steps, double *elapsed_time_inout)
           h->graph_cur = cur0;
           h->graph_avg = avg0;
           h->graph_stream = h->stream;
+          h->graph_lim = lim_par;
         }
       }
       if (h->graph_exec) {
+        if (h->lim_cnt && s + period <= n_steps) {   // the first marked launch of a replay finds its list counter at zero
+          const int i = (h->lim_epoch + 1) & 1;
+          if (!h->lim_clean[i]) {
+            HIPCHK(h, hipMemsetAsync(h->lim_cnt + i, 0, sizeof(int), h->stream));
+            h->lim_clean[i] = true;
+          }
+        }
         for (; s + period <= n_steps; s += period) {
           HIPCHK(h, hipGraphLaunch(h->graph_exec, h->stream));
           h->steps_done += period;

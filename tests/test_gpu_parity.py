@@ -518,6 +518,41 @@ def test_advance_graph_replay_matches_plain_launches(monkeypatch):
     assert (out[0][1] == out[1][1]).all()
 
 
+@pytest.mark.parametrize("degree,M", [(1, 0.0), (2, 30.0), (2, 0.0)])
+def test_advance_graph_replay_with_the_list_of_marked_shards(degree, M, monkeypatch):
+    """DFLO_GRAPH=1 on a TVB run whose limiter pass walks the stage kernel's list: the captured launches name the two alternating
+    list counters in a fixed order, so a graph is replayed only from the parity it was captured at (a plain step of an odd
+    number of stages in between flips it: captured again) -- same bits as launch by launch.  With M = 0 on rough data nearly
+    every shard is on the list in every stage: a replay that appended behind a stale count would run past the list's end."""
+    bnd = {0: "slip", 1: "outflow", 2: "inflow"}
+    nx, ny = (320, 208) if degree == 1 else (256, 264)
+    mesh = dflo_amd.Mesh.cartesian(nx, ny, 0.0, 0.0, 1.0 / nx, [2, 1, 0, 0], degree)
+    prm = dflo_amd.Parameters(flux="roe", limiter="TVB", char_lim=True, pos_lim=True, M=M, beta=1.5, boundary=bnd, cfl=0.7)
+    def ic(x, y):
+        mx, my, rho, E = problems.sod(x, y)
+        return [mx, my, rho * (1.0 + 0.05 * np.sin(40.0 * x) * np.cos(31.0 * y)), E]
+    u0 = mesh.interpolate(ic)
+    out = []
+    for flag in ("0", "1"):
+        monkeypatch.setenv("DFLO_GRAPH", flag)
+        claw = dflo_amd.ConservationLaw(mesh, prm)
+        cell, face, bid, xy = claw.boundary_faces()
+        bv = np.stack(ic(xy[..., 0], xy[..., 1]), axis=-1)
+        claw.set_boundary_values(0, bv)
+        claw.set_boundary_values(1, bv)
+        claw.set_initial_condition(u0)
+        claw.apply_limiter()
+        ts = [claw.advance(11)]          # 5 replays + 1 plain step
+        ts.append(claw.advance(6))       # the graph again, from the other parity when a step has an odd number of stages
+        dt = claw.compute_time_step()
+        claw.iterate_explicit(dt)        # stepwise in between
+        ts.append(claw.advance(9))
+        out.append((ts, claw.current_solution.copy(), claw.cell_average.copy()))
+        claw.close()
+    assert out[0][0] == out[1][0]
+    assert np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2])
+
+
 def test_cell_averages_of_an_intermediate_stage_are_formed_on_demand(monkeypatch):
     """Without LxF, limiter, indicator or local time stepping nobody reads the cell averages of an intermediate stage, and the
     stage kernel does not store them (DFLO_LAZY_AVG=0: always); a caller who asks in between still gets them, and whole steps
