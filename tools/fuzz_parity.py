@@ -131,7 +131,7 @@ def one(i):
         raise oracle_lib.OracleError(0, "NaN state")
     # (degrees 4 and 5: the entries of the derivative matrix grow with the degree -- max |D| = 11, 17, 23 for k = 3, 4, 5 -- and the
     #  round-off of the two orders of summation with them; seen: 1.0e-11 / 3e-10 at k = 5 on small distorted cells)
-    loose = {4: 4.0, 5: 10.0}.get(degree, 1.0)
+    loose = {4: 4.0, 5: 10.0}.get(degree, 1.0)   # (every bar below carries it, the "agreed after the first step" of the classifications too)
     # (a residual that vanishes -- one periodic cell that is its own neighbour -- is compared on the scale of the fluxes)
     rscale = max(np.abs(r2).max(), 1e-6 * np.abs(u0).max())
     assert np.abs(r1 - r2).max() < 1e-11 * loose * rscale, ("residual", np.abs(r1 - r2).max() / rscale)
@@ -145,9 +145,13 @@ def one(i):
         if it == 0:
             dt_first = dt
         if abs(dtc - dt) > (1e-9 if "kink" in desc else 1e-11) * loose * dt:
-            if e1 is not None and e1 <= 1e-12 and ("kink" in desc or dt < 1e-2 * dt_first):
+            if e1 is not None and e1 <= 1e-12 * loose and ("kink" in desc or dt < 1e-2 * dt_first):
                 # (rough data, or a run whose time step has collapsed a hundredfold within two steps: it is blowing up)
                 raise oracle_lib.OracleError(3, "round-off amplified by rough data")   # see below
+            if np.abs(ora.get_solution()).max() > 1.0e3 * np.abs(u0).max():
+                # the blow-up class of the end of this function, met at a time step already: the reference state has grown a
+                # thousandfold (an unlimited run on rough data), and the time steps of two such states differ like the states
+                raise oracle_lib.OracleError(2, "blow-up of the reference solution")
             assert False, ("dt", it, dtc, dt)
         claw.iterate_explicit(dt)
         ora.step(-1.0 if local else dt)   # local time stepping: keep the per-cell steps compute_time_step has left
@@ -161,7 +165,7 @@ def one(i):
             ora.step(dt)
             t += dt
         if np.isfinite(t) and np.isfinite(claw.current_solution).all():   # (a device NaN is classified below)
-            if abs(t2 - t) > 1e-9 * t and e1 is not None and e1 <= 1e-12 and "kink" in desc:
+            if abs(t2 - t) > 1e-9 * t and e1 is not None and e1 <= 1e-12 * loose and "kink" in desc:
                 raise oracle_lib.OracleError(3, "round-off amplified by rough data")
             assert abs(t2 - t) <= 1e-9 * loose * t, ("advance time", t2, t)
         desc.update(advance=True)
@@ -186,7 +190,7 @@ def one(i):
         # statement either way; reported, not failed.
         raise oracle_lib.OracleError(1, "device NaN, reference finite (cold point)")
     e = rel(ud, uo)
-    if e >= tol and e1 is not None and e1 <= 1e-12 and "kink" in desc:
+    if e >= tol and e1 is not None and e1 <= 1e-12 * loose and "kink" in desc:
         # Rough data (cells scaled by up to 3, nodal noise) on a few cells is not a resolved flow: the solutions agree to round-off
         # after the first step (e1) and the difference then grows by one to two orders of magnitude per stage -- limiter switches,
         # points left at p = 1e-13 -- until it passes the bar in the second or third step.  Seen 3 times in 40 000 cases at degrees
