@@ -66,7 +66,10 @@ struct dflo_hip_engine {
   double *shard_res = nullptr, *shard_dtmin = nullptr, *res_sq = nullptr, *dt_dev = nullptr, *fin_partial = nullptr;
   int *flags = nullptr;         // device view of flags_host (kernels_common.hpp: raise_flag)
   volatile int *flags_host = nullptr;   // [0] negative mean state, [1] positivity root failure, [2] 1 + step of the first
-  int *fin_counter = nullptr;   // [0] finalize_kernel: workgroups done; [1] time steps completed since set_solution (device count)
+  int *fin_counter = nullptr;   // [0] finalize_kernel: workgroups done; [2 + p] index of the time step in flight while its parity is p
+  int *fin_chunk = nullptr;     // [kFinBlocks] reductions inside the last stage kernel: finished shards per first-level chunk
+  bool fin_in_stage = false;    // the last stage kernel launched has carried the step's reductions
+  bool af = false;              // LxF on squares without limiter / ghost cells: no array of cell averages on the path (stage_kernel AF)
   unsigned long long *pos_stats = nullptr;   // [2] positivity limiter inside the stage kernel: cells through the limiter proper, cells changed
   double *dt_pub = nullptr;     // [2] raw CFL minimum of the last two steps, read by the other engines of a multi-device run
   int pub_parity = 0;
@@ -118,6 +121,7 @@ struct dflo_hip_engine {
   hipGraphExec_t graph_exec = nullptr;
   int graph_steps = 0, graph_cur = -1, graph_avg = -1;
   int graph_lim = 0;   // parity of lim_epoch the graph was captured at (its launches name the two list counters in that order)
+  int graph_par = 0;   // parity of the step count it was captured at (its launches name the step-index slots in that order)
   hipStream_t graph_stream = nullptr;
   bool use_graph = false;  // opt-in (DFLO_GRAPH=1): on ROCm 7.2 / MI355X replay measured no faster than plain launches
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
@@ -219,6 +223,7 @@ int grid_for(int n_shards) { return ((n_shards + 7) / 8) * 8; }
 void part_list(const dflo_hip_engine *h, int part, const int32_t **list, int *n);
 
 void launch_dt_q(dflo_hip_engine *h);
+void final_args(dflo_hip_engine *h, FinalArgs &f);
 int launch_face_traces(dflo_hip_engine *h, double *out, const int32_t *slots, const int32_t *faces, int n);
 
 void time_begin(dflo_hip_engine *h) {
@@ -286,6 +291,7 @@ int open_stage(dflo_hip_engine *h, int rk, double dt_host, bool residual_only, i
     h->dtq_parts = 0;
     h->aux_fresh = false;
     h->lim_open = -1;
+    h->fin_in_stage = false;
     // stage timing samples every fifth stage (5 is coprime to the 2 or 3 stages of a step, so every stage of the
     // step is sampled equally often): two event records per launch are not free
     h->t_sample = h->timing && (h->t_seen++ % 5 == 0);
@@ -430,7 +436,7 @@ int launch_update(dflo_hip_engine *h, double *rhs_out, int part) {
   a.sweep_rev = next_sweep(h, part);
   const int mode_ = rhs_out ? 2 : (h->ark[rk] != 0.0 ? 1 : 0);
   a.flags = h->flags;
-  a.step_ctr = h->fin_counter + 1;
+  a.step_ctr = h->fin_counter + 2 + (int)(h->steps_done & 1);
   a.Tg = h->Tg[h->tg_cur];
   a.gt_slot = h->d_gt_slot;
   a.pos_stats = h->pos_stats;
@@ -440,7 +446,18 @@ int launch_update(dflo_hip_engine *h, double *rhs_out, int part) {
   a.tvb_M = h->prm.limiter_type == DFLO_LIMITER_TVB ? h->prm.M : -1.0;
   a.tvb_char = h->prm.char_lim;
   a.pos_check = h->prm.pos_lim;
-  const int pos_ = h->fuse_pos ? 1 : (h->lim_mask ? 2 : 0);
+  const int pos_ = h->fuse_pos ? 1 : (h->lim_mask ? 2 : (h->af ? 3 : 0));
+  {  // The step's reductions ride in the launch that ends it: the last stage over all shards, when no pass follows that the
+     // reductions would have to wait for (a limiter pass takes them along itself, launch_limit_finalize; the separate time-step
+     // passes of bilinear cells / local time stepping write the minima afterwards).  DFLO_FUSE_FIN=0: finalize_kernel as before.
+    const bool pass_follows = h->prm.limiter_type != DFLO_LIMITER_NONE || (h->prm.pos_lim && !h->fuse_pos);
+    const bool dt_here = h->geo == 0 ? !h->d_dt_cell : a.dtq != 0;
+    if (h->fuse_fin && last && !rhs_out && part == 0 && !pass_follows && dt_here && p.n_shards > 0) {
+      a.fin_on = 1;
+      final_args(h, a.fin);
+      h->fin_in_stage = true;
+    }
+  }
   if (pos_ == 2 && mode_ != 2) {
     h->aux_fresh = true;
     h->lim_open = -1;
@@ -503,7 +520,7 @@ int launch_limiter(dflo_hip_engine *h, int tvb, int pos, int part, bool stage_da
   l.lrbt = h->d_lrbt;
   l.cell_h = h->d_cell_h;
   l.flags = h->flags;
-  l.step_ctr = h->fin_counter + 1;
+  l.step_ctr = h->fin_counter + 2 + (int)(h->steps_done & 1);
   l.h_uniform = p.h;
   l.M = h->prm.M;
   l.beta = h->prm.beta;
@@ -580,6 +597,8 @@ void final_args(dflo_hip_engine *h, FinalArgs &f) {
   f.publish = h->publish ? h->dt_pub + h->pub_parity : nullptr;
   f.partial = h->fin_partial;
   f.counter = h->fin_counter;
+  f.chunk_cnt = h->fin_chunk;
+  f.step_par = (int)(h->steps_done & 1);
 }
 
 int launch_finish(dflo_hip_engine *h, bool reductions_done = false) {
@@ -598,7 +617,7 @@ int launch_finish(dflo_hip_engine *h, bool reductions_done = false) {
     HIPCHK(h, hipGetLastError());
   }
   h->pending_rk = -1;
-  if (!last || reductions_done) return DFLO_OK;  // ||rhs|| of every stage is reduced once, after the last stage (it is only reported, src/claw.cc:768)
+  if (!last || reductions_done || h->fin_in_stage) return DFLO_OK;  // ||rhs|| of every stage is reduced once, after the last stage (it is only reported, src/claw.cc:768)
   FinalArgs f{};
   final_args(h, f);
   hipLaunchKernelGGL(finalize_kernel, dim3(fin_grid(f.n_shards)), dim3(256), 0, h->stream, f);
@@ -891,7 +910,8 @@ int dflo_hip_create(const dflo_mesh_t *mesh, const dflo_params_t *params, int de
   if (hipMalloc((void **)&h->shard_res, 3 * nsh * sizeof(double)) != hipSuccess ||
       hipMalloc((void **)&h->shard_dtmin, nsh * sizeof(double)) != hipSuccess ||
       hipMalloc((void **)&h->res_sq, 4 * sizeof(double)) != hipSuccess || hipMalloc((void **)&h->fin_partial, 4 * kFinBlocks * sizeof(double)) != hipSuccess ||
-      hipMalloc((void **)&h->dt_dev, 4 * sizeof(double)) != hipSuccess || hipMalloc((void **)&h->fin_counter, 2 * sizeof(int)) != hipSuccess ||
+      hipMalloc((void **)&h->dt_dev, 4 * sizeof(double)) != hipSuccess || hipMalloc((void **)&h->fin_counter, 4 * sizeof(int)) != hipSuccess ||
+      hipMalloc((void **)&h->fin_chunk, kFinBlocks * sizeof(int)) != hipSuccess ||
       hipMalloc((void **)&h->dt_pub, 2 * sizeof(double)) != hipSuccess || hipMalloc((void **)&h->pos_stats, 2 * sizeof(unsigned long long)) != hipSuccess) {
     h->err = "hipMalloc(scalars) failed";
     return bail(DFLO_ERR_NOMEM);
@@ -910,7 +930,8 @@ int dflo_hip_create(const dflo_mesh_t *mesh, const dflo_params_t *params, int de
   hipMemset(h->res_sq, 0, 4 * sizeof(double));
   hipMemset(h->dt_dev, 0, 4 * sizeof(double));
   hipMemset(h->dt_pub, 0, 2 * sizeof(double));
-  hipMemset(h->fin_counter, 0, 2 * sizeof(int));
+  hipMemset(h->fin_counter, 0, 4 * sizeof(int));
+  hipMemset(h->fin_chunk, 0, kFinBlocks * sizeof(int));
   hipMemset(h->pos_stats, 0, 2 * sizeof(unsigned long long));
   // row stride of the stage kernel's trace / flux table: a column per halo entry (its trace, then the flux of its face) and one
   // per other face; the 4 N rows also host the row partials (5 N rows of 64), the positivity minima (3 N) or the slope
@@ -921,7 +942,15 @@ int dflo_hip_create(const dflo_mesh_t *mesh, const dflo_params_t *params, int de
     {  // who reads the averages of an intermediate stage?  The LxF flux (lambda from cell means), a limiter pass, the indicator,
        // local time stepping -- otherwise they stay in the kernel (DFLO_LAZY_AVG=0: always stored)
       const bool pass = h->prm.limiter_type != DFLO_LIMITER_NONE || (h->prm.pos_lim && !h->fuse_pos) || h->prm.shock_indicator != DFLO_IND_LIMITER;
-      h->lazy_avg = tun.lazy_avg && h->prm.flux_type != DFLO_FLUX_LXF && !pass && h->prm.global_time_step;
+      // The LxF flux takes (u, v, c) of the averages from the DoFs themselves where those give the stored average bit for bit:
+      // Pk always (mode 0); Qk on squares when no limiter touches the state between the epilogue that forms the average and the
+      // next stage (the reference's cell_average is the one of before the limiters, src/claw.cc:762-766) and no ghost cell
+      // brings an average of its owner's (stage_kernel AF; the partial sums of the own cells borrow 64 columns of the flux table)
+      const bool limited = h->prm.limiter_type != DFLO_LIMITER_NONE || h->prm.pos_lim;
+      h->af = h->prm.flux_type == DFLO_FLUX_LXF && h->basis == DFLO_BASIS_QK && h->geo == 0 && !limited &&
+              h->prm.shock_indicator == DFLO_IND_LIMITER && p.n_cells == p.n_owned && p.halo_cols + 64 <= h->halo_stride && tun.lxf_from_dofs;
+      const bool lxf_reads_avg = h->prm.flux_type == DFLO_FLUX_LXF && !h->af && !(h->basis == DFLO_BASIS_PK && p.n_cells == p.n_owned);
+      h->lazy_avg = tun.lazy_avg && !lxf_reads_avg && !pass && h->prm.global_time_step;
     }
     // (measured: the marks pay from k = 2 on -- C4 +10 %, the slab pair +3.5 % with the box test of round 3 --; at k = 1, where the
     //  pass reads only 16 values per cell, the box-only marks give the single engine +1.5 % (C3) and cost a part of a
@@ -956,7 +985,7 @@ int dflo_hip_create(const dflo_mesh_t *mesh, const dflo_params_t *params, int de
   if (h->lds_bytes > 160 * 1024) { h->err = "shard halo too large for LDS"; return bail(DFLO_ERR_UNSUPPORTED); }
   if (h->lds_bytes > 64 * 1024) {
     for (int mode = 0; mode < 3; ++mode) {
-      stage_fn fn = h->basis == DFLO_BASIS_PK ? pick_pk(h->N, h->prm.flux_type, mode, streams_out(h)) : pick_stage(h->N, h->prm.flux_type, mode, h->geo, h->fuse_pos ? 1 : (h->lim_mask ? 2 : 0), streams_out(h));
+      stage_fn fn = h->basis == DFLO_BASIS_PK ? pick_pk(h->N, h->prm.flux_type, mode, streams_out(h)) : pick_stage(h->N, h->prm.flux_type, mode, h->geo, h->fuse_pos ? 1 : (h->lim_mask ? 2 : (h->af ? 3 : 0)), streams_out(h));
       if (hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes) != hipSuccess) {
         h->err = "cannot raise dynamic LDS limit";
         return bail(DFLO_ERR_HIP);
@@ -993,7 +1022,7 @@ int dflo_hip_destroy(dflo_hip_handle h) {
   hipFree(h->d_rim_list); hipFree(h->d_int_list); hipFree(h->d_rim2_list); hipFree(h->d_rest2_list);
   hipFree(h->d_cell_h); hipFree(h->d_dt_cell); hipFree(h->d_cell_vert); hipFree(h->shard_res); hipFree(h->shard_dtmin); hipFree(h->res_sq); hipFree(h->fin_partial); hipFree(h->dt_dev);
   if (h->flags_host) hipHostFree((void *)h->flags_host);
-  hipFree(h->fin_counter); hipFree(h->dt_pub); hipFree(h->pos_stats);
+  hipFree(h->fin_counter); hipFree(h->fin_chunk); hipFree(h->dt_pub); hipFree(h->pos_stats);
   hipFree(h->Tg[0]); hipFree(h->Tg[1]); hipFree(h->d_gt_slot); hipFree(h->d_gt_face); hipFree(h->d_sendf_slot); hipFree(h->d_sendf_face); hipFree(h->d_send_slots); hipFree(h->ghost_stage);
   for (int i = 0; i < 2; ++i) if (h->ev_chunk[i]) hipEventDestroy(h->ev_chunk[i]);
   for (auto &e : h->ev_pool) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
@@ -1023,7 +1052,7 @@ int dflo_hip_set_solution(dflo_hip_handle h, const double *u) {
   h->cur = h->old = 0;
   h->steps_done = 0;
   h->ghost_avg_src = nullptr;
-  HIPCHK(h, hipMemsetAsync(h->fin_counter + 1, 0, sizeof(int), h->stream));
+  HIPCHK(h, hipMemsetAsync(h->fin_counter + 1, 0, 3 * sizeof(int), h->stream));
   for (int i = 0; i < 4; ++i) h->flags_host[i] = 0;   // a new state: the flags of an earlier run are history
   hipLaunchKernelGGL(scatter_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, h->user_buf, h->U[0],
                      h->d_user_of, p.n_slots, h->ndof);
@@ -1184,6 +1213,8 @@ static int launch_compute_dt(dflo_hip_engine *h, double elapsed_time) {
   f.publish = h->publish ? h->dt_pub + h->pub_parity : nullptr;
   f.partial = h->fin_partial;
   f.counter = h->fin_counter;
+  f.chunk_cnt = h->fin_chunk;
+  f.step_par = (int)(h->steps_done & 1);
   hipLaunchKernelGGL(finalize_kernel, dim3(fin_grid(f.n_shards)), dim3(256), 0, h->stream, f);
   HIPCHK(h, hipGetLastError());
   return DFLO_OK;
@@ -1238,6 +1269,9 @@ int dflo_hip_advance(dflo_hip_handle h, int n_steps, double *elapsed_time_inout)
   hipSetDevice(h->device);
   // first dt from the current cell averages -- formed and left on the device like every later one: the host does not wait
   // for it (the stage kernels and the boundary programs read the device's (dt, t)), it only waits at the end
+  // stage-timing events nobody has asked for yet are read here, before anything of this call is launched (outside the work the
+  // caller times), so that a caller who enables the timing and never queries it does not grow the pool without bound
+  if (h->ev_used > 2048) time_collect(h);
   int rc = launch_compute_dt(h, *elapsed_time_inout);
   if (rc) return rc;
   int s = 0;
@@ -1247,9 +1281,10 @@ int dflo_hip_advance(dflo_hip_handle h, int n_steps, double *elapsed_time_inout)
     const int period = 2;
     if (n_steps >= 2 * period) {
       const int lim_par = h->lim_cnt ? (h->lim_epoch & 1) : 0;
-      if (h->graph_exec && (h->graph_cur != h->cur || h->graph_avg != h->avg_cur || h->graph_stream != h->stream || h->graph_lim != lim_par)) drop_graph(h);
+      if (h->graph_exec && (h->graph_cur != h->cur || h->graph_avg != h->avg_cur || h->graph_stream != h->stream || h->graph_lim != lim_par ||
+                            h->graph_par != (int)(h->steps_done & 1))) drop_graph(h);
       if (!h->graph_exec) {
-        const int cur0 = h->cur, avg0 = h->avg_cur;
+        const int cur0 = h->cur, avg0 = h->avg_cur, par0 = (int)(h->steps_done & 1);
         hipGraph_t g = nullptr;
         bool ok = hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
         if (ok) {
@@ -1278,6 +1313,7 @@ int dflo_hip_advance(dflo_hip_handle h, int n_steps, double *elapsed_time_inout)
           h->graph_avg = avg0;
           h->graph_stream = h->stream;
           h->graph_lim = lim_par;
+          h->graph_par = par0;
         }
       }
       if (h->graph_exec) {

@@ -36,6 +36,22 @@ struct KBasis {       // 1-D tables, see basis.h
 };
 
 
+// reductions over shards + the global-dt rules of compute_time_step (src/claw.cc:468-476)
+struct FinalArgs {
+  const double *shard_res, *shard_dtmin;
+  double *res_sq;  // [3] per stage
+  double *dt_dev;  // [0] dt, [1] elapsed time, [2] raw min before rules
+  double *partial; // [kFinBlocks][4] workgroup partials
+  int *counter;    // [0] workgroups done, [2 + p] index of the time step in flight when its parity is p (StageArgs::step_ctr)
+  int *chunk_cnt;  // [kFinBlocks] reductions inside the last stage kernel: shards of each first-level chunk that have finished
+  int step_par;    // parity of the step these reductions end
+  int n_shards, n_stages, res_stride, do_dt, advance_time, global_rules;  // shard_res: [n_stages][res_stride]
+  int fixed_dt;    // "time step type = global" with cfl <= 0: dt = time_step (src/claw.cc:455-460)
+  double *publish; // multi-device: the raw minimum also goes here (a slot the peers read, alternating from step to step)
+  double time_step, final_time, dt_host;
+};
+constexpr int kFinBlocks = 64;   // workgroups of the two-level reduction (one lane of the last workgroup's first wavefront each)
+
 struct StageArgs {
   const double *Ucur, *Uold;
   double *Unew;
@@ -70,8 +86,10 @@ struct StageArgs {
   int n_list;
   int sweep_rev;              // see shard_of_block
   int *flags;   // POS 1: [0] negative mean state, [1] positivity root failure (as LimArgs::flags)
-  const int *step_ctr;  // device count of the time steps completed since set_solution (finalize_kernel adds one per step): read only
-                        // when a flag is raised, so that a replayed graph reports the step it is in, not the one it was captured in
+  const int *step_ctr;  // device count of the time steps completed since set_solution: read only when a flag is raised, so that a
+                        // replayed graph reports the step it is in, not the one it was captured in.  Two slots that alternate with
+                        // the parity of the step: the reductions of step s write the slot of step s + 1, never the one the kernels of
+                        // step s read -- a flag raised by a pass that also carries the step's reductions names step s on every run
   const double *Tg;        // multi-device: traces of the ghost cells on the cut faces, [n_ghost_traces][4][N], of the state being read
   const int32_t *gt_slot;  // internal slot of the ghost cell of a trace (its cell average: LxF)
   unsigned long long *pos_stats;  // POS 1: [0] cells that failed the nodal-box bound (limiter proper), [1] cells it changed
@@ -79,6 +97,8 @@ struct StageArgs {
   int *lim_cnt;                   // POS 2, launches over all shards: the shards with a mark also go on a list (one append per
   ulonglong2 *lim_list;           //   marked shard and launch: a single wavefront writes a shard's word) as (shard, word), so that the pass is a few
                                   //   hundred wavefronts walking that list instead of one per shard that reads a word and leaves; or null
+  int fin_on;                     // last stage over all shards, no pass behind it: the kernel carries the step's reductions (shard_done_reduce)
+  FinalArgs fin;
   double tvb_M;                   // POS 2: TVB constant M, < 0: the limiter pass has no TVB part
   int tvb_char, pos_check;        // POS 2: characteristic limiting; the positivity limiter runs in the pass
   KBasis kb;
@@ -121,6 +141,22 @@ __device__ __forceinline__ double cell_face_trace(const double *U, int slot, int
 #pragma unroll
   for (int m = 0; m < N; ++m) val[m] = hp[(base + m * str) * 64];
   return trace_from_line<N>(val);
+}
+
+// Cell average of one component of a Qk function on a square from its N^2 nodal values (node (m, b) at u[m + N b]), summed
+// exactly as the stage kernels' epilogue sums it -- the row b: p_b = fma(w_m w_b, u_mb, p_b) for m = 0, 1, ..; then 0 + p_0 + p_1 + ..
+// -- so that an average formed from the DoFs carries the bits of the stored one (src/claw.cc:589-593).
+template <int N>
+__device__ __forceinline__ double cell_average_rows(const double (&u)[N * N]) {
+  double v = 0.0;
+#pragma unroll
+  for (int b = 0; b < N; ++b) {
+    double pr = 0.0;
+#pragma unroll
+    for (int m = 0; m < N; ++m) pr = __builtin_fma(CB<N>::t.w[m] * CB<N>::t.w[b], u[m + N * b], pr);
+    v += pr;
+  }
+  return v;
 }
 
 // compute_time_step_cartesian for one cell, src/claw.cc:495-509
@@ -170,6 +206,18 @@ __device__ __forceinline__ double wave_min_lane63(double v) {
   return v;
 }
 
+// Values one workgroup hands to another INSIDE a launch (the per-shard partials of the reductions the last stage kernel carries):
+// stored and loaded at agent scope -- past the XCD's own L2, which is not coherent with the other seven -- so that no
+// workgroup has to flush or invalidate a cache (a release fence at agent scope writes back the whole L2).
+__device__ __forceinline__ void store_agent(double *p, double v) {
+  __hip_atomic_store((unsigned long long *)p, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <bool COH>
+__device__ __forceinline__ double load_shared(const double *p) {
+  if constexpr (COH) return __longlong_as_double((long long)__hip_atomic_load((const unsigned long long *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+  else return *p;
+}
+
 // blockIdx -> shard so that every XCD (block b runs on XCD b % 8) sweeps one contiguous run of
 // the Morton-ordered shards: halo re-reads then hit that XCD's own L2.
 // rev: the XCD walks its run backwards -- a launch that sweeps against the previous one starts on the shards that one
@@ -181,18 +229,6 @@ __device__ __forceinline__ int shard_of_block(int b, int n_shards, int rev = 0) 
   return i < chunk && s < n_shards ? s : -1;
 }
 
-// reductions over shards + the global-dt rules of compute_time_step (src/claw.cc:468-476)
-struct FinalArgs {
-  const double *shard_res, *shard_dtmin;
-  double *res_sq;  // [3] per stage
-  double *dt_dev;  // [0] dt, [1] elapsed time, [2] raw min before rules
-  double *partial; // [kFinBlocks][4] workgroup partials
-  int *counter;    // [0] workgroups done, [1] time steps completed since set_solution
-  int n_shards, n_stages, res_stride, do_dt, advance_time, global_rules;  // shard_res: [n_stages][res_stride]
-  int fixed_dt;    // "time step type = global" with cfl <= 0: dt = time_step (src/claw.cc:455-460)
-  double *publish; // multi-device: the raw minimum also goes here (a slot the peers read, alternating from step to step)
-  double time_step, final_time, dt_host;
-};
 // the global-time-step rules of compute_time_step (src/claw.cc:455-476) applied to the raw CFL minimum
 __device__ __forceinline__ double dt_rules(double dt, double t, double time_step, double final_time, int global_rules, int fixed_dt) {
   if (fixed_dt) return time_step;
@@ -202,7 +238,6 @@ __device__ __forceinline__ double dt_rules(double dt, double t, double time_step
   }
   return dt;
 }
-constexpr int kFinBlocks = 64;   // workgroups of the two-level reduction (one lane of the last workgroup's first wavefront each)
 // what the one thread that holds the totals of a step writes: the squared residual norms, the clock, the raw CFL minimum and
 // the time step of the next step
 __device__ __forceinline__ void finalize_publish(const FinalArgs &a, const double (&tot)[3], double dt) {
@@ -213,7 +248,7 @@ __device__ __forceinline__ void finalize_publish(const FinalArgs &a, const doubl
     if (a.advance_time) {  // elapsed_time += global_dt (src/claw.cc:1072) for the step just done
       tt += a.dt_host >= 0.0 ? a.dt_host : a.dt_dev[0];
       a.dt_dev[1] = tt;
-      a.counter[1] += 1;   // steps completed (what a failure flag raised in the next step reports)
+      a.counter[2 + (a.step_par ^ 1)] = a.counter[2 + a.step_par] + 1;   // the next step's index, in the next step's slot
     }
     a.dt_dev[2] = dt;
     if (a.publish) *a.publish = dt;
@@ -223,6 +258,8 @@ __device__ __forceinline__ void finalize_publish(const FinalArgs &a, const doubl
 // finalize_kernel's workgroup `b` of `nb`, run by ONE wavefront (the first workgroups of a limiter pass that ends a step take it
 // on, see limiter_kernel): lane l plays the threads l, l + 64, l + 128, l + 192 of the 256, so every sum is formed in the order
 // finalize_kernel forms it -- the same bits.
+// COH: the partials of the current launch come from other workgroups of the same launch (load_shared)
+template <bool COH = false>
 __device__ __forceinline__ void finalize_by_wave(const FinalArgs &a, int b, int nb) {
   const int n = a.n_shards, l = threadIdx.x & 63;
   const int chunk = ((n + kFinBlocks - 1) / kFinBlocks + 255) & ~255;
@@ -233,24 +270,30 @@ __device__ __forceinline__ void finalize_by_wave(const FinalArgs &a, int b, int 
     rs[w][0] = rs[w][1] = rs[w][2] = 0.0;
     m[w] = 1.0e20;
   }
+  auto take = [&](int base, int w) {   // thread l + 64 w of the workgroup: four of its passes at a time
+    double v[4][3], d[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int s = base + l + 64 * w + j * 256;
+      const bool in = s < hi;
+#pragma unroll
+      for (int st = 0; st < 3; ++st) v[j][st] = (in && st < a.n_stages) ? load_shared<COH>(&a.shard_res[(size_t)st * a.res_stride + s]) : 0.0;
+      d[j] = (in && a.do_dt) ? load_shared<COH>(&a.shard_dtmin[s]) : 1.0e20;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+      for (int st = 0; st < 3; ++st) rs[w][st] += v[j][st];
+      m[w] = fmin(m[w], d[j]);
+    }
+  };
   for (int base = lo; base < hi; base += 4 * 256) {
+    if constexpr (COH) {   // inside a stage kernel: one thread's loads in flight at a time (the registers of the kernel's own budget)
+#pragma unroll 1
+      for (int w = 0; w < 4; ++w) take(base, w);
+    } else {
 #pragma unroll
-    for (int w = 0; w < 4; ++w) {
-      double v[4][3], d[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int s = base + l + 64 * w + j * 256;
-        const bool in = s < hi;
-#pragma unroll
-        for (int st = 0; st < 3; ++st) v[j][st] = (in && st < a.n_stages) ? a.shard_res[(size_t)st * a.res_stride + s] : 0.0;
-        d[j] = (in && a.do_dt) ? a.shard_dtmin[s] : 1.0e20;
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-#pragma unroll
-        for (int st = 0; st < 3; ++st) rs[w][st] += v[j][st];
-        m[w] = fmin(m[w], d[j]);
-      }
+      for (int w = 0; w < 4; ++w) take(base, w);
     }
   }
   double sred[4][4];
@@ -275,6 +318,26 @@ __device__ __forceinline__ void finalize_by_wave(const FinalArgs &a, int b, int 
   for (int st = 0; st < 3; ++st) tot[st] = wave_sum(have ? ((const volatile double *)a.partial)[l * 4 + st] : 0.0);
   dt = wave_min(dt);
   if (l == 0) finalize_publish(a, tot, dt);
+}
+
+// The reductions of a step inside its last stage kernel (launches over all shards with no limiter pass behind them): the
+// wavefront that has just stored a shard's partials counts the shard in its first-level chunk -- the chunks of finalize_kernel --
+// and the wavefront that completes a chunk plays that chunk's workgroup of finalize_kernel (finalize_by_wave: the same sums in
+// the same order, the same bits), the one that completes the last chunk the second level.  No launch of its own, and all but the
+// tail of the work is done while other shards are still being updated.
+__device__ __forceinline__ void shard_done_reduce(const FinalArgs &f, int shard, int lane) {
+  const int n = f.n_shards;
+  const int chunk = ((n + kFinBlocks - 1) / kFinBlocks + 255) & ~255;
+  const int nb = (n + chunk - 1) / chunk, b = shard / chunk;
+  const int size = min(n, (b + 1) * chunk) - b * chunk;
+  int done = 0;
+  if (lane == 63) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this shard's partials (store_agent) have arrived
+    done = __hip_atomic_fetch_add(&f.chunk_cnt[b], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == size - 1;
+    if (done) __hip_atomic_store(&f.chunk_cnt[b], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next step
+  }
+  done = __builtin_amdgcn_readlane(done, 63);
+  if (done) finalize_by_wave<true>(f, b, nb);
 }
 
 // ------------------------------------------------------------------ positivity limiter, pointwise parts

@@ -141,7 +141,7 @@ __device__ __forceinline__ void row_update(const StageArgs &a, double *Us, const
           if constexpr (MODE == 1) u = (1.0 - a.ark) * u + a.ark * uold[c][m];
           ust[c][m] = u;
           if constexpr (POS) unew[c][m] = u;   // kept for the positivity step of the caller (which stores again if it scales)
-          part[c] += ww * u;
+          part[c] = __builtin_fma(ww, u, part[c]);   // (spelled out: cell_average_rows forms the same sums from the DoFs, bit for bit)
         }
 #pragma unroll
       for (int c = 0; c < 4; ++c)
@@ -504,7 +504,12 @@ __device__ __forceinline__ void limiter_marks_from_box(const double (&lo)[4], co
 //   STREAM 1: nothing reads the new state before the next stage kernel (no limiter pass over all cells follows): it is stored past
 //         the caches (measured: C2 +2 %, C4 +3 %; with the Q1 limiter pass behind it C3 -2 %, hence a variant and not a rule).
 //         A compile-time switch: behind a run-time branch the compiler merges the two store sequences and drops the hint.
-template <int N, int FLUX, int MODE, int GEO, int POS, int STREAM>
+//   AF 1 (LxF on squares, no limiter, no ghost cells): the (u, v, c) of the cell averages that the LxF flux wants
+//         (src/equation.h:357-359) are formed from the DoFs the kernel loads anyway -- the own cells' and, in the halo gather, the
+//         neighbours' (a thread takes one component of one halo cell: its N^2 nodes give the N traces and the average) -- in the
+//         order in which the stage epilogue sums them (cell_average_rows): the same bits as the stored averages, which are then
+//         neither read nor, in intermediate stages, written (15-20 % of the Q1 LxF kernel's memory traffic)
+template <int N, int FLUX, int MODE, int GEO, int POS, int STREAM, int AF = 0>
 __global__ __launch_bounds__(64 * N, N >= 5 ? 1 : ((N == 4 && GEO == 0 && MODE == 0) ? kQ3FirstStageWaves : (((GEO == 1 && N != 3) || N == 4) ? 2 : (N == 3 && GEO == 0 ? kQ2Waves : 3)))) void stage_kernel(const StageArgs a) {
   constexpr int NS = N * N, NDOF = 4 * NS, NT = 64 * N;
   constexpr int ROWS = NDOF + (FLUX == DFLO_FLUX_LXF ? 3 : 0);   // LxF: (u, v, c) of the cell average ride along
@@ -531,9 +536,13 @@ __global__ __launch_bounds__(64 * N, N >= 5 ? 1 : ((N == 4 && GEO == 0 && MODE =
   // block, unstructured shards two or three): load them all now, the gathers below then depend on nothing else
   constexpr int HB = 3;
   int hentb[HB];
+  if constexpr (AF) {   // a thread takes (entry, component) = (t >> 2, t & 3) of every block of 16 N entries
+    hentb[0] = a.halo_pad[(size_t)shard * a.halo_pitch + min(tid >> 2, a.halo_pitch - 1)];
+  } else {
 #pragma unroll
   for (int b = 0; b < HB; ++b)   // (lattice shards have at most 32 entries: one load, the condition is uniform)
     hentb[b] = (b == 0 || a.halo_pitch > 32 * b) ? a.halo_pad[(size_t)shard * a.halo_pitch + min((tid & 31) + 32 * b, a.halo_pitch - 1)] : 0;
+  }
   const int4 hdr = a.shard_hdr[shard];                // {cells, faces, halo entries, boundary faces}
   const int nf = hdr.y, nh = hdr.z, nbnd = hdr.w;
   const bool active = lane < (hdr.x & 0xFF);
@@ -549,7 +558,7 @@ __global__ __launch_bounds__(64 * N, N >= 5 ? 1 : ((N == 4 && GEO == 0 && MODE =
       }
   }
   double uavg[4];
-  if constexpr (FLUX == DFLO_FLUX_LXF) {
+  if constexpr (FLUX == DFLO_FLUX_LXF && !AF) {
     if (row == 0) {
 #pragma unroll
       for (int c = 0; c < 4; ++c) uavg[c] = a.avg_cur[((size_t)shard * 4 + c) * 64 + lane];
@@ -591,7 +600,38 @@ __global__ __launch_bounds__(64 * N, N >= 5 ? 1 : ((N == 4 && GEO == 0 && MODE =
   //      (internal cell slot | local face << 28) of a face neighbour outside the shard
   //      A thread takes, of its entry in block b, the two (component, point) rows r = g and g + 2N (g = t >> 5):
   //      2N independent loads per block.
-  {
+  if constexpr (AF) {
+    for (int it = 0, item = tid; item < 4 * nh; item += NT, ++it) {
+      const int sl = item >> 2, c = item & 3;
+      const int e = it == 0 ? hentb[0] : a.halo_pad[(size_t)shard * a.halo_pitch + sl];
+      const int ic = e & 0x0FFFFFFF, f = (e >> 28) & 3;
+      const double *hp = a.Ucur + ((size_t)(ic >> 6) * NDOF + c * NS) * 64 + (ic & 63);
+      double u[NS];
+#pragma unroll
+      for (int j = 0; j < NS; ++j) u[j] = hp[j * 64];
+      // the lines through the face points, from the face inwards (selects, not indexed registers: the face differs from lane to lane)
+      const bool yf = f >= 2, rev = f & 1;
+#pragma unroll
+      for (int q = 0; q < N; ++q) {
+        double val[N];
+#pragma unroll
+        for (int m = 0; m < N; ++m) {
+          const double fwd = yf ? u[q + N * m] : u[m + N * q], bwd = yf ? u[q + N * (N - 1 - m)] : u[(N - 1 - m) + N * q];
+          val[m] = rev ? bwd : fwd;
+        }
+        Th[(c * N + q) * HS + sl] = trace_from_line<N>(val);
+      }
+      // the four components of an entry sit in the four lanes of a quad: everybody fetches the other three averages
+      const double av = cell_average_rows<N>(u);
+      double A[4], uvc[3];
+      A[0] = dpp_f64<0x00, 0xf>(0.0, av);   // quad_perm: [0,0,0,0]
+      A[1] = dpp_f64<0x55, 0xf>(0.0, av);   // [1,1,1,1]
+      A[2] = dpp_f64<0xAA, 0xf>(0.0, av);   // [2,2,2,2]
+      A[3] = dpp_f64<0xFF, 0xf>(0.0, av);   // [3,3,3,3]
+      wave_speed_uvc(A, uvc);
+      if (c < 3) Av[c * a.halo_cols + sl] = c == 0 ? uvc[0] : (c == 1 ? uvc[1] : uvc[2]);
+    }
+  } else {
     const int g = tid >> 5, l32 = tid & 31;
     for (int b = 0; b * 32 < nh; ++b) {
       const int sl = l32 + 32 * b;
@@ -623,7 +663,7 @@ __global__ __launch_bounds__(64 * N, N >= 5 ? 1 : ((N == 4 && GEO == 0 && MODE =
       }
     }
   }
-  if constexpr (FLUX == DFLO_FLUX_LXF) {  // lambda of the LxF flux comes from the cell averages (src/equation.h:357-359):
+  if constexpr (FLUX == DFLO_FLUX_LXF && !AF) {  // lambda of the LxF flux comes from the cell averages (src/equation.h:357-359):
                                           // keep (u, v, c) of each average instead of the four components
     for (int sl = tid; sl < nh; sl += NT) {
       const int blk = sl >> 5;   // sl = tid + k NT: entry (tid & 31) + 32 blk is this thread's own preloaded one
@@ -641,12 +681,22 @@ __global__ __launch_bounds__(64 * N, N >= 5 ? 1 : ((N == 4 && GEO == 0 && MODE =
   for (int c = 0; c < 4; ++c)
 #pragma unroll
     for (int m = 0; m < N; ++m) Us[(c * NS + m + N * row) * S + lane] = urow[c][m];
-  if constexpr (FLUX == DFLO_FLUX_LXF) {
+  if constexpr (FLUX == DFLO_FLUX_LXF && !AF) {
     if (row == 0) {
       double uvc[3];
       wave_speed_uvc(uavg, uvc);
 #pragma unroll
       for (int c = 0; c < 3; ++c) Us[(NDOF + c) * S + lane] = uvc[c];
+    }
+  }
+  if constexpr (AF) {   // this row's share of the own cells' averages: into free columns of the flux table (the flux phase writes there later)
+    const double wr = CB<N>::t.w[row];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      double pr = 0.0;
+#pragma unroll
+      for (int m = 0; m < N; ++m) pr = __builtin_fma(CB<N>::t.w[m] * wr, urow[c][m], pr);
+      Th[(row * 4 + c) * HS + a.halo_cols + lane] = pr;
     }
   }
   if constexpr (GEO == 1) {
@@ -672,6 +722,22 @@ __global__ __launch_bounds__(64 * N, N >= 5 ? 1 : ((N == 4 && GEO == 0 && MODE =
     }
   }
   __syncthreads();
+  if constexpr (AF) {   // the rows' shares meet: (u, v, c) of the own cells' averages, the rows added in the epilogue's order
+    if (row == 0) {
+      double A[4], uvc[3];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        double v = 0;
+#pragma unroll
+        for (int b = 0; b < N; ++b) v += Th[(b * 4 + c) * HS + a.halo_cols + lane];
+        A[c] = v;
+      }
+      wave_speed_uvc(A, uvc);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) Us[(NDOF + c) * S + lane] = uvc[c];
+    }
+    __syncthreads();
+  }
 
   // ---- phase B
   flux_phase<N, FLUX, GEO>(a, Us, Th, Av, frr, fp, Bv, Bk, Vx, HS, nf, nh, tid);
@@ -1036,9 +1102,10 @@ __global__ __launch_bounds__(64 * N, N >= 5 ? 1 : ((N == 4 && GEO == 0 && MODE =
     res = wave_sum_lane63(res);
     if (have_dt) dtmin = wave_min_lane63(dtmin);
     if (lane == 63) {
-      a.shard_res[shard] = res;
-      if (have_dt) a.shard_dtmin[shard] = dtmin;
+      store_agent(&a.shard_res[shard], res);
+      if (have_dt) store_agent(&a.shard_dtmin[shard], dtmin);
     }
+    if (a.fin_on) shard_done_reduce(a.fin, shard, lane);   // the step's reductions, when this launch ends the step
   }
 }
 
@@ -1230,19 +1297,17 @@ __global__ __launch_bounds__(64 * N, N >= 5 ? 1 : (N == 4 ? (((MODE == 0 || (MOD
   // ---- loads: a wave reads the modes it will update (m = row, row + N, ..) of u(s) and u(n); the node rows need all modes of
   //      the cell, which the waves hand each other through LDS (each of them used to load all of them: 4 NM loads and as many
   //      registers per wave instead of 4 NM / N)
+  // LxF: lambda comes from the cell averages (src/equation.h:357-359), and the average of a modal function IS its mode 0 -- the
+  // kernel takes it from the modes it loads anyway (own cells: wave 0 holds mode 0; halo cells: the gather below), the array of
+  // averages is not read.  The gather then runs with (entry, component) = (t >> 2, t & 3), the four components of an entry in the
+  // four lanes of a quad, instead of the components spread over half-waves.
+  constexpr bool LXF = FLUX == DFLO_FLUX_LXF;
   int hent[1];
-  hent[0] = a.halo_pad[(size_t)shard * a.halo_pitch + (tid & 31)];
+  hent[0] = a.halo_pad[(size_t)shard * a.halo_pitch + (LXF ? min(tid >> 2, a.halo_pitch - 1) : (tid & 31))];
   const int4 hdr = a.shard_hdr[shard];
   const int nf = hdr.y, nh = hdr.z, nbnd = hdr.w;
   const bool active = lane < (hdr.x & 0xFF);
   const int pat = hdr.x >> 8;   // index pattern of the shard: its face records and face references
-  double uavg[4];
-  if constexpr (FLUX == DFLO_FLUX_LXF) {
-    if (row == 0) {
-#pragma unroll
-      for (int c = 0; c < 4; ++c) uavg[c] = a.avg_cur[((size_t)shard * 4 + c) * 64 + lane];
-    }
-  }
   const uint32_t *fp = a.faces_pad + (size_t)pat * a.face_pitch;
   uint32_t frr[3];
 #pragma unroll
@@ -1294,9 +1359,9 @@ __global__ __launch_bounds__(64 * N, N >= 5 ? 1 : (N == 4 ? (((MODE == 0 || (MOD
   // the fixed direction (both ways, the face decides which one counts) and evaluates the N points from the N sums -- the modes
   // used to be loaded once per face point, N NM loads for N values.
   for (int i = tid; i < ((nh + 31) & ~31) * 4; i += NT) {
-    const int sl = (i & 31) + ((i >> 5) >> 2) * 32, c = (i >> 5) & 3;
+    const int sl = LXF ? i >> 2 : (i & 31) + ((i >> 5) >> 2) * 32, c = LXF ? i & 3 : (i >> 5) & 3;
     if (sl >= nh) continue;
-    const int e = sl < 32 ? hent[0] : a.halo_pad[(size_t)shard * a.halo_pitch + sl];
+    const int e = (LXF ? i < NT : sl < 32) ? hent[0] : a.halo_pad[(size_t)shard * a.halo_pitch + sl];
     const int ic = e & 0x0FFFFFFF, f = (e >> 28) & 3;
     const double *hp = a.Ucur + ((size_t)(ic >> 6) * NDOFM + c * NM) * 64 + (ic & 63);
     double um[NM];
@@ -1318,27 +1383,25 @@ __global__ __launch_bounds__(64 * N, N >= 5 ? 1 : (N == 4 ? (((MODE == 0 || (MOD
       for (int n = 0; n < N; ++n) v += PB<N>::t.Px[q][n] * (f < 2 ? ax[n] : ay[n]);
       Th[(c * N + q) * HS + sl] = v;
     }
-  }
-  if constexpr (FLUX == DFLO_FLUX_LXF) {  // lambda of the LxF flux comes from the cell averages (src/equation.h:357-359):
-                                          // keep (u, v, c) of each average instead of the four components
-    for (int sl = tid; sl < nh; sl += NT) {
-      const int ic = (sl < 32 ? hent[0] : a.halo_pad[(size_t)shard * a.halo_pitch + sl]) & 0x0FFFFFFF;
+    if constexpr (LXF) {   // (u, v, c) of the entry's average = its four modes 0, met through the quad
       double A[4], uvc[3];
-#pragma unroll
-      for (int c = 0; c < 4; ++c) A[c] = a.avg_cur[((size_t)(ic >> 6) * 4 + c) * 64 + (ic & 63)];
+      A[0] = dpp_f64<0x00, 0xf>(0.0, um[0]);
+      A[1] = dpp_f64<0x55, 0xf>(0.0, um[0]);
+      A[2] = dpp_f64<0xAA, 0xf>(0.0, um[0]);
+      A[3] = dpp_f64<0xFF, 0xf>(0.0, um[0]);
       wave_speed_uvc(A, uvc);
-#pragma unroll
-      for (int c = 0; c < 3; ++c) Av[c * a.halo_cols + sl] = uvc[c];
+      if (c < 3) Av[c * a.halo_cols + sl] = c == 0 ? uvc[0] : (c == 1 ? uvc[1] : uvc[2]);
     }
   }
 #pragma unroll
   for (int c = 0; c < 4; ++c)
 #pragma unroll
     for (int m = 0; m < N; ++m) Us[(c * NS + m + N * row) * S + lane] = urow[c][m];
-  if constexpr (FLUX == DFLO_FLUX_LXF) {
-    if (row == 0) {
+  if constexpr (LXF) {
+    if (row == 0) {   // wave 0 owns mode 0 (ucur[.][0])
+      const double A[4] = {ucur[0][0], ucur[1][0], ucur[2][0], ucur[3][0]};
       double uvc[3];
-      wave_speed_uvc(uavg, uvc);
+      wave_speed_uvc(A, uvc);
 #pragma unroll
       for (int c = 0; c < 3; ++c) Us[(4 * NS + c) * S + lane] = uvc[c];
     }
@@ -1397,9 +1460,10 @@ __global__ __launch_bounds__(64 * N, N >= 5 ? 1 : (N == 4 ? (((MODE == 0 || (MOD
     res = wave_sum_lane63(res);
     if (a.want_dt) dtmin = wave_min_lane63(dtmin);
     if (lane == 63) {
-      a.shard_res[shard] = res;
-      if (a.want_dt) a.shard_dtmin[shard] = dtmin;
+      store_agent(&a.shard_res[shard], res);
+      if (a.want_dt) store_agent(&a.shard_dtmin[shard], dtmin);
     }
+    if (a.fin_on) shard_done_reduce(a.fin, shard, lane);
   }
 }
 
@@ -1410,6 +1474,13 @@ __global__ __launch_bounds__(64 * N, N >= 5 ? 1 : (N == 4 ? (((MODE == 0 || (MOD
 typedef void (*stage_fn)(const StageArgs);
 template <int N, int FLUX>
 stage_fn pick_stage_m(int mode, int geo, int pos, int nt) {
+  if constexpr (FLUX == DFLO_FLUX_LXF) {
+    if (pos == 3) {   // LxF without the arrays of cell averages (AF; squares, no limiter): pos is free to carry the request
+      if (mode == 2) return stage_kernel<N, FLUX, 2, 0, 0, 0, 1>;
+      if (nt) return mode == 0 ? stage_kernel<N, FLUX, 0, 0, 0, 1, 1> : stage_kernel<N, FLUX, 1, 0, 0, 1, 1>;
+      return mode == 0 ? stage_kernel<N, FLUX, 0, 0, 0, 0, 1> : stage_kernel<N, FLUX, 1, 0, 0, 0, 1>;
+    }
+  }
   if (pos == 1 && mode != 2) {   // the limiter has been applied on the way out: nothing re-reads the state
     if (geo == 0) return mode == 0 ? stage_kernel<N, FLUX, 0, 0, 1, 1> : stage_kernel<N, FLUX, 1, 0, 1, 1>;
     return mode == 0 ? stage_kernel<N, FLUX, 0, 1, 1, 1> : stage_kernel<N, FLUX, 1, 1, 1, 1>;

@@ -3,6 +3,7 @@
 // (a fused path against the separate pass it replaced, a transport against the other).  Measured-and-lost kernel variants
 // are not switches: they live as patches under tools/variants/.
 #pragma once
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 
@@ -17,6 +18,7 @@ struct Tunables {
   bool fuse_pos = true;    // DFLO_FUSE_POS=0    positivity without TVB on Qk: separate limiter pass instead of inside the stage kernel
   bool fuse_fin = true;    // DFLO_FUSE_FIN=0    TVB on Qk squares: finalize_kernel as its own launch instead of inside the limiter pass that ends the step
   bool lazy_avg = true;    // DFLO_LAZY_AVG=0    store the cell averages of every stage (default: only when somebody reads them)
+  bool lxf_from_dofs = true;   // DFLO_LXF_FROM_DOFS=0   the LxF flux on squares reads the arrays of cell averages (default: (u, v, c) of the averages from the DoFs)
   bool lim_list = true;    // DFLO_LIM_LIST=0    with marks: one wavefront per shard looks at its word instead of a short grid walking the list of marked shards
   int lim_grid = 1024;     // DFLO_LIM_GRID=n    wavefronts of that short grid
   int lim_mask = -1;       // DFLO_LIM_MASK=0|1  TVB on squares: forbid / force the stage kernel's marks for the limiter pass (default: degree >= 2; degree 1 without ghost cells)
@@ -47,6 +49,18 @@ inline Tunables read_tunables() {
     const char *e = std::getenv(name);
     return e ? (e[0] != '0' ? 1 : 0) : -1;
   };
+  // an integer switch: a value that is not a number >= lo is reported once and ignored (the default stays)
+  auto count = [](const char *name, int dflt, int lo) {
+    const char *e = std::getenv(name);
+    if (!e) return dflt;
+    char *end = nullptr;
+    const long v = std::strtol(e, &end, 10);
+    if (end == e || *end != '\0' || v < lo || v > (1 << 30)) {
+      std::fprintf(stderr, "dflo_hip: %s=%s ignored (an integer >= %d is expected)\n", name, e, lo);
+      return dflt;
+    }
+    return (int)v;
+  };
   t.graph = flag("DFLO_GRAPH", false);
   t.sweep = flag("DFLO_SWEEP", true);
   t.stream = tri("DFLO_STREAM");
@@ -54,19 +68,20 @@ inline Tunables read_tunables() {
   t.fuse_pos = flag("DFLO_FUSE_POS", true);
   t.fuse_fin = flag("DFLO_FUSE_FIN", true);
   t.lazy_avg = flag("DFLO_LAZY_AVG", true);
+  t.lxf_from_dofs = flag("DFLO_LXF_FROM_DOFS", true);
   t.lim_mask = tri("DFLO_LIM_MASK");
   t.lim_list = flag("DFLO_LIM_LIST", true);
-  if (const char *e = std::getenv("DFLO_LIM_GRID")) t.lim_grid = std::atoi(e);
+  t.lim_grid = count("DFLO_LIM_GRID", t.lim_grid, 1);
   t.halo_cells = flag("DFLO_HALO_CELLS", false);
-  t.verbose = std::getenv("DFLO_VERBOSE") != nullptr;
-  if (const char *e = std::getenv("DFLO_PLAN_REFINE")) t.plan_refine = std::atoi(e);
+  t.verbose = flag("DFLO_VERBOSE", false);
+  t.plan_refine = count("DFLO_PLAN_REFINE", t.plan_refine, 0);
   t.rim_first = flag("DFLO_PLAN_RIM_FIRST", true);
   if (const char *e = std::getenv("DFLO_MULTI_GROUP")) t.group = std::strcmp(e, "part") == 0 ? 1 : (std::strcmp(e, "device") == 0 ? 2 : 0);
   t.threads = flag("DFLO_MULTI_THREADS", true);
   t.strict = flag("DFLO_MULTI_STRICT", false);
   t.copy = flag("DFLO_MULTI_COPY", false);
   if (const char *e = std::getenv("DFLO_MULTI_TRANSPORT")) t.loopback = std::strcmp(e, "rccl_loopback") == 0;
-  t.multi_verbose = std::getenv("DFLO_MULTI_VERBOSE") != nullptr;
+  t.multi_verbose = flag("DFLO_MULTI_VERBOSE", false);
   t.comm_priority = flag("DFLO_MULTI_PRIORITY", true);
   t.avg_in_place = !flag("DFLO_MULTI_AVG_UNPACK", false);
   return t;

@@ -242,7 +242,9 @@ class Adaptor {
     mesh_.n_cells = mesh_.n_owned_cells = static_cast<int32_t>(nc);
     mesh_.degree = static_cast<int32_t>(dof_handler.get_fe().degree);
     mesh_.basis = static_cast<int32_t>(prm.basis) == 0 ? DFLO_BASIS_QK : DFLO_BASIS_PK;        // BasisType {Qk, Pk}, src/parameters.h:390-391
-    // MappingType {q1, q2, cartesian}, src/parameters.h:392-393 == dflo_mapping (q2 is refused by the engine)
+    // MappingType {q1, q2, cartesian}, src/parameters.h:392-393 == dflo_mapping.  q2 is taken as q1 by the engine: the flat mesh
+    // carries four vertices per cell, i.e. straight edges, on which MappingQ(2) IS the bilinear map -- valid only while no
+    // manifold / curved boundary description is attached to the triangulation (the reference's is commented out, src/claw.cc:976-979)
     mesh_.mapping = static_cast<int32_t>(prm.mapping_type);
     mesh_.cell_vertices = vertices_.data();
     mesh_.cell_face_neighbor = nbr_.data();
