@@ -67,8 +67,6 @@ struct dflo_hip_engine {
   int *flags = nullptr;         // device view of flags_host (kernels_common.hpp: raise_flag)
   volatile int *flags_host = nullptr;   // [0] negative mean state, [1] positivity root failure, [2] 1 + step of the first
   int *fin_counter = nullptr;   // [0] finalize_kernel: workgroups done; [2 + p] index of the time step in flight while its parity is p
-  int *fin_chunk = nullptr;     // [kFinBlocks] reductions inside the last stage kernel: finished shards per first-level chunk
-  bool fin_in_stage = false;    // the last stage kernel launched has carried the step's reductions
   bool af = false;              // LxF on squares without limiter / ghost cells: no array of cell averages on the path (stage_kernel AF)
   unsigned long long *pos_stats = nullptr;   // [2] positivity limiter inside the stage kernel: cells through the limiter proper, cells changed
   double *dt_pub = nullptr;     // [2] raw CFL minimum of the last two steps, read by the other engines of a multi-device run
@@ -223,7 +221,6 @@ int grid_for(int n_shards) { return ((n_shards + 7) / 8) * 8; }
 void part_list(const dflo_hip_engine *h, int part, const int32_t **list, int *n);
 
 void launch_dt_q(dflo_hip_engine *h);
-void final_args(dflo_hip_engine *h, FinalArgs &f);
 int launch_face_traces(dflo_hip_engine *h, double *out, const int32_t *slots, const int32_t *faces, int n);
 
 void time_begin(dflo_hip_engine *h) {
@@ -291,7 +288,6 @@ int open_stage(dflo_hip_engine *h, int rk, double dt_host, bool residual_only, i
     h->dtq_parts = 0;
     h->aux_fresh = false;
     h->lim_open = -1;
-    h->fin_in_stage = false;
     // stage timing samples every fifth stage (5 is coprime to the 2 or 3 stages of a step, so every stage of the
     // step is sampled equally often): two event records per launch are not free
     h->t_sample = h->timing && (h->t_seen++ % 5 == 0);
@@ -447,17 +443,6 @@ int launch_update(dflo_hip_engine *h, double *rhs_out, int part) {
   a.tvb_char = h->prm.char_lim;
   a.pos_check = h->prm.pos_lim;
   const int pos_ = h->fuse_pos ? 1 : (h->lim_mask ? 2 : (h->af ? 3 : 0));
-  {  // The step's reductions ride in the launch that ends it: the last stage over all shards, when no pass follows that the
-     // reductions would have to wait for (a limiter pass takes them along itself, launch_limit_finalize; the separate time-step
-     // passes of bilinear cells / local time stepping write the minima afterwards).  DFLO_FUSE_FIN=0: finalize_kernel as before.
-    const bool pass_follows = h->prm.limiter_type != DFLO_LIMITER_NONE || (h->prm.pos_lim && !h->fuse_pos);
-    const bool dt_here = h->geo == 0 ? !h->d_dt_cell : a.dtq != 0;
-    if (h->fuse_fin && last && !rhs_out && part == 0 && !pass_follows && dt_here && p.n_shards > 0) {
-      a.fin_on = 1;
-      final_args(h, a.fin);
-      h->fin_in_stage = true;
-    }
-  }
   if (pos_ == 2 && mode_ != 2) {
     h->aux_fresh = true;
     h->lim_open = -1;
@@ -597,7 +582,6 @@ void final_args(dflo_hip_engine *h, FinalArgs &f) {
   f.publish = h->publish ? h->dt_pub + h->pub_parity : nullptr;
   f.partial = h->fin_partial;
   f.counter = h->fin_counter;
-  f.chunk_cnt = h->fin_chunk;
   f.step_par = (int)(h->steps_done & 1);
 }
 
@@ -617,7 +601,7 @@ int launch_finish(dflo_hip_engine *h, bool reductions_done = false) {
     HIPCHK(h, hipGetLastError());
   }
   h->pending_rk = -1;
-  if (!last || reductions_done || h->fin_in_stage) return DFLO_OK;  // ||rhs|| of every stage is reduced once, after the last stage (it is only reported, src/claw.cc:768)
+  if (!last || reductions_done) return DFLO_OK;  // ||rhs|| of every stage is reduced once, after the last stage (it is only reported, src/claw.cc:768)
   FinalArgs f{};
   final_args(h, f);
   hipLaunchKernelGGL(finalize_kernel, dim3(fin_grid(f.n_shards)), dim3(256), 0, h->stream, f);
@@ -911,7 +895,6 @@ int dflo_hip_create(const dflo_mesh_t *mesh, const dflo_params_t *params, int de
       hipMalloc((void **)&h->shard_dtmin, nsh * sizeof(double)) != hipSuccess ||
       hipMalloc((void **)&h->res_sq, 4 * sizeof(double)) != hipSuccess || hipMalloc((void **)&h->fin_partial, 4 * kFinBlocks * sizeof(double)) != hipSuccess ||
       hipMalloc((void **)&h->dt_dev, 4 * sizeof(double)) != hipSuccess || hipMalloc((void **)&h->fin_counter, 4 * sizeof(int)) != hipSuccess ||
-      hipMalloc((void **)&h->fin_chunk, kFinBlocks * sizeof(int)) != hipSuccess ||
       hipMalloc((void **)&h->dt_pub, 2 * sizeof(double)) != hipSuccess || hipMalloc((void **)&h->pos_stats, 2 * sizeof(unsigned long long)) != hipSuccess) {
     h->err = "hipMalloc(scalars) failed";
     return bail(DFLO_ERR_NOMEM);
@@ -931,7 +914,6 @@ int dflo_hip_create(const dflo_mesh_t *mesh, const dflo_params_t *params, int de
   hipMemset(h->dt_dev, 0, 4 * sizeof(double));
   hipMemset(h->dt_pub, 0, 2 * sizeof(double));
   hipMemset(h->fin_counter, 0, 4 * sizeof(int));
-  hipMemset(h->fin_chunk, 0, kFinBlocks * sizeof(int));
   hipMemset(h->pos_stats, 0, 2 * sizeof(unsigned long long));
   // row stride of the stage kernel's trace / flux table: a column per halo entry (its trace, then the flux of its face) and one
   // per other face; the 4 N rows also host the row partials (5 N rows of 64), the positivity minima (3 N) or the slope
@@ -1022,7 +1004,7 @@ int dflo_hip_destroy(dflo_hip_handle h) {
   hipFree(h->d_rim_list); hipFree(h->d_int_list); hipFree(h->d_rim2_list); hipFree(h->d_rest2_list);
   hipFree(h->d_cell_h); hipFree(h->d_dt_cell); hipFree(h->d_cell_vert); hipFree(h->shard_res); hipFree(h->shard_dtmin); hipFree(h->res_sq); hipFree(h->fin_partial); hipFree(h->dt_dev);
   if (h->flags_host) hipHostFree((void *)h->flags_host);
-  hipFree(h->fin_counter); hipFree(h->fin_chunk); hipFree(h->dt_pub); hipFree(h->pos_stats);
+  hipFree(h->fin_counter); hipFree(h->dt_pub); hipFree(h->pos_stats);
   hipFree(h->Tg[0]); hipFree(h->Tg[1]); hipFree(h->d_gt_slot); hipFree(h->d_gt_face); hipFree(h->d_sendf_slot); hipFree(h->d_sendf_face); hipFree(h->d_send_slots); hipFree(h->ghost_stage);
   for (int i = 0; i < 2; ++i) if (h->ev_chunk[i]) hipEventDestroy(h->ev_chunk[i]);
   for (auto &e : h->ev_pool) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
@@ -1213,7 +1195,6 @@ static int launch_compute_dt(dflo_hip_engine *h, double elapsed_time) {
   f.publish = h->publish ? h->dt_pub + h->pub_parity : nullptr;
   f.partial = h->fin_partial;
   f.counter = h->fin_counter;
-  f.chunk_cnt = h->fin_chunk;
   f.step_par = (int)(h->steps_done & 1);
   hipLaunchKernelGGL(finalize_kernel, dim3(fin_grid(f.n_shards)), dim3(256), 0, h->stream, f);
   HIPCHK(h, hipGetLastError());

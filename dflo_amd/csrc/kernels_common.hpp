@@ -43,7 +43,6 @@ struct FinalArgs {
   double *dt_dev;  // [0] dt, [1] elapsed time, [2] raw min before rules
   double *partial; // [kFinBlocks][4] workgroup partials
   int *counter;    // [0] workgroups done, [2 + p] index of the time step in flight when its parity is p (StageArgs::step_ctr)
-  int *chunk_cnt;  // [kFinBlocks] reductions inside the last stage kernel: shards of each first-level chunk that have finished
   int step_par;    // parity of the step these reductions end
   int n_shards, n_stages, res_stride, do_dt, advance_time, global_rules;  // shard_res: [n_stages][res_stride]
   int fixed_dt;    // "time step type = global" with cfl <= 0: dt = time_step (src/claw.cc:455-460)
@@ -97,8 +96,6 @@ struct StageArgs {
   int *lim_cnt;                   // POS 2, launches over all shards: the shards with a mark also go on a list (one append per
   ulonglong2 *lim_list;           //   marked shard and launch: a single wavefront writes a shard's word) as (shard, word), so that the pass is a few
                                   //   hundred wavefronts walking that list instead of one per shard that reads a word and leaves; or null
-  int fin_on;                     // last stage over all shards, no pass behind it: the kernel carries the step's reductions (shard_done_reduce)
-  FinalArgs fin;
   double tvb_M;                   // POS 2: TVB constant M, < 0: the limiter pass has no TVB part
   int tvb_char, pos_check;        // POS 2: characteristic limiting; the positivity limiter runs in the pass
   KBasis kb;
@@ -206,18 +203,6 @@ __device__ __forceinline__ double wave_min_lane63(double v) {
   return v;
 }
 
-// Values one workgroup hands to another INSIDE a launch (the per-shard partials of the reductions the last stage kernel carries):
-// stored and loaded at agent scope -- past the XCD's own L2, which is not coherent with the other seven -- so that no
-// workgroup has to flush or invalidate a cache (a release fence at agent scope writes back the whole L2).
-__device__ __forceinline__ void store_agent(double *p, double v) {
-  __hip_atomic_store((unsigned long long *)p, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-template <bool COH>
-__device__ __forceinline__ double load_shared(const double *p) {
-  if constexpr (COH) return __longlong_as_double((long long)__hip_atomic_load((const unsigned long long *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-  else return *p;
-}
-
 // blockIdx -> shard so that every XCD (block b runs on XCD b % 8) sweeps one contiguous run of
 // the Morton-ordered shards: halo re-reads then hit that XCD's own L2.
 // rev: the XCD walks its run backwards -- a launch that sweeps against the previous one starts on the shards that one
@@ -258,8 +243,6 @@ __device__ __forceinline__ void finalize_publish(const FinalArgs &a, const doubl
 // finalize_kernel's workgroup `b` of `nb`, run by ONE wavefront (the first workgroups of a limiter pass that ends a step take it
 // on, see limiter_kernel): lane l plays the threads l, l + 64, l + 128, l + 192 of the 256, so every sum is formed in the order
 // finalize_kernel forms it -- the same bits.
-// COH: the partials of the current launch come from other workgroups of the same launch (load_shared)
-template <bool COH = false>
 __device__ __forceinline__ void finalize_by_wave(const FinalArgs &a, int b, int nb) {
   const int n = a.n_shards, l = threadIdx.x & 63;
   const int chunk = ((n + kFinBlocks - 1) / kFinBlocks + 255) & ~255;
@@ -270,30 +253,24 @@ __device__ __forceinline__ void finalize_by_wave(const FinalArgs &a, int b, int 
     rs[w][0] = rs[w][1] = rs[w][2] = 0.0;
     m[w] = 1.0e20;
   }
-  auto take = [&](int base, int w) {   // thread l + 64 w of the workgroup: four of its passes at a time
-    double v[4][3], d[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int s = base + l + 64 * w + j * 256;
-      const bool in = s < hi;
-#pragma unroll
-      for (int st = 0; st < 3; ++st) v[j][st] = (in && st < a.n_stages) ? load_shared<COH>(&a.shard_res[(size_t)st * a.res_stride + s]) : 0.0;
-      d[j] = (in && a.do_dt) ? load_shared<COH>(&a.shard_dtmin[s]) : 1.0e20;
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-#pragma unroll
-      for (int st = 0; st < 3; ++st) rs[w][st] += v[j][st];
-      m[w] = fmin(m[w], d[j]);
-    }
-  };
   for (int base = lo; base < hi; base += 4 * 256) {
-    if constexpr (COH) {   // inside a stage kernel: one thread's loads in flight at a time (the registers of the kernel's own budget)
-#pragma unroll 1
-      for (int w = 0; w < 4; ++w) take(base, w);
-    } else {
 #pragma unroll
-      for (int w = 0; w < 4; ++w) take(base, w);
+    for (int w = 0; w < 4; ++w) {
+      double v[4][3], d[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int s = base + l + 64 * w + j * 256;
+        const bool in = s < hi;
+#pragma unroll
+        for (int st = 0; st < 3; ++st) v[j][st] = (in && st < a.n_stages) ? a.shard_res[(size_t)st * a.res_stride + s] : 0.0;
+        d[j] = (in && a.do_dt) ? a.shard_dtmin[s] : 1.0e20;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int st = 0; st < 3; ++st) rs[w][st] += v[j][st];
+        m[w] = fmin(m[w], d[j]);
+      }
     }
   }
   double sred[4][4];
@@ -318,26 +295,6 @@ __device__ __forceinline__ void finalize_by_wave(const FinalArgs &a, int b, int 
   for (int st = 0; st < 3; ++st) tot[st] = wave_sum(have ? ((const volatile double *)a.partial)[l * 4 + st] : 0.0);
   dt = wave_min(dt);
   if (l == 0) finalize_publish(a, tot, dt);
-}
-
-// The reductions of a step inside its last stage kernel (launches over all shards with no limiter pass behind them): the
-// wavefront that has just stored a shard's partials counts the shard in its first-level chunk -- the chunks of finalize_kernel --
-// and the wavefront that completes a chunk plays that chunk's workgroup of finalize_kernel (finalize_by_wave: the same sums in
-// the same order, the same bits), the one that completes the last chunk the second level.  No launch of its own, and all but the
-// tail of the work is done while other shards are still being updated.
-__device__ __forceinline__ void shard_done_reduce(const FinalArgs &f, int shard, int lane) {
-  const int n = f.n_shards;
-  const int chunk = ((n + kFinBlocks - 1) / kFinBlocks + 255) & ~255;
-  const int nb = (n + chunk - 1) / chunk, b = shard / chunk;
-  const int size = min(n, (b + 1) * chunk) - b * chunk;
-  int done = 0;
-  if (lane == 63) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this shard's partials (store_agent) have arrived
-    done = __hip_atomic_fetch_add(&f.chunk_cnt[b], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == size - 1;
-    if (done) __hip_atomic_store(&f.chunk_cnt[b], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next step
-  }
-  done = __builtin_amdgcn_readlane(done, 63);
-  if (done) finalize_by_wave<true>(f, b, nb);
 }
 
 // ------------------------------------------------------------------ positivity limiter, pointwise parts

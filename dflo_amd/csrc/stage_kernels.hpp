@@ -1102,10 +1102,9 @@ __global__ __launch_bounds__(64 * N, N >= 5 ? 1 : ((N == 4 && GEO == 0 && MODE =
     res = wave_sum_lane63(res);
     if (have_dt) dtmin = wave_min_lane63(dtmin);
     if (lane == 63) {
-      store_agent(&a.shard_res[shard], res);
-      if (have_dt) store_agent(&a.shard_dtmin[shard], dtmin);
+      a.shard_res[shard] = res;
+      if (have_dt) a.shard_dtmin[shard] = dtmin;
     }
-    if (a.fin_on) shard_done_reduce(a.fin, shard, lane);   // the step's reductions, when this launch ends the step
   }
 }
 
@@ -1460,10 +1459,9 @@ __global__ __launch_bounds__(64 * N, N >= 5 ? 1 : (N == 4 ? (((MODE == 0 || (MOD
     res = wave_sum_lane63(res);
     if (a.want_dt) dtmin = wave_min_lane63(dtmin);
     if (lane == 63) {
-      store_agent(&a.shard_res[shard], res);
-      if (a.want_dt) store_agent(&a.shard_dtmin[shard], dtmin);
+      a.shard_res[shard] = res;
+      if (a.want_dt) a.shard_dtmin[shard] = dtmin;
     }
-    if (a.fin_on) shard_done_reduce(a.fin, shard, lane);
   }
 }
 

@@ -1,6 +1,5 @@
 """GPU parity of the round-4 paths: two ways of doing the same thing, held to each other bit for bit (and, through the other
-test files, to the oracle): the step's reductions inside the last stage kernel against finalize_kernel, and the LxF flux's
-(u, v, c) of the cell averages from the DoFs against the stored arrays of averages."""
+test files, to the oracle): the LxF flux's (u, v, c) of the cell averages from the DoFs against the stored arrays of averages."""
 import numpy as np
 import pytest
 
@@ -32,49 +31,10 @@ def _run(claw, u0, bfun=None, steps=4, resident=9):
     return hist, claw.current_solution.copy(), claw.cell_average.copy()
 
 
-@pytest.mark.parametrize("case", ["q2_hllc", "q1_lxf", "p2_hllc", "p1_lxf", "q3_kfvs_mapped_pos", "q2_roe_walls", "q0_lxf", "small"])
-def test_reductions_inside_the_last_stage_kernel_give_the_same_bits(case, monkeypatch):
-    """No limiter pass behind the last stage: the stage kernel itself forms the step's reductions -- the wavefront that completes a
-    first-level chunk of 256 shards plays that chunk's workgroup of finalize_kernel, the one that completes the last chunk the
-    second level (kernels_common.hpp: shard_done_reduce).  DFLO_FUSE_FIN=0 launches finalize_kernel as before: the same sums in
-    the same order, so residual norms, time steps, the clock and the state agree bit for bit (src/claw.cc:749, 468-476, 1072)."""
-    bfun = None
-    if case == "q3_kfvs_mapped_pos":   # bilinear cells: the last stage kernel also forms compute_time_step_q
-        from dflo_amd import gmsh
-        verts, quads, bed, bid = gmsh.forward_step_quads(cl=0.2 / 6, seed=3)
-        mesh = dflo_amd.Mesh.from_quads(verts, quads, bed, bid, 3)
-        prm = dflo_amd.Parameters(flux="kfvs", pos_lim=True, cfl=0.02, final_time=1e9, boundary={1: "inflow", 2: "slip", 3: "outflow"})
-        bfun = problems.forward_step_inflow
-        u0 = mesh.interpolate(problems.forward_step_inflow)
-    elif case == "q2_roe_walls":
-        mesh = dflo_amd.Mesh.cartesian(264, 256, 0.0, 0.0, 1.0 / 264, [2, 1, 0, 0], 2)
-        prm = dflo_amd.Parameters(flux="roe", cfl=0.5, boundary={0: "slip", 1: "outflow", 2: "inflow"})
-        bfun = problems.sod
-        u0 = mesh.interpolate(lambda x, y: [0.3 + 0 * x, 0 * x, 1.0 + 0.1 * np.sin(5 * x) * np.cos(3 * y), 2.5 + 0 * x])
-    else:
-        degree = {"q2_hllc": 2, "q1_lxf": 1, "p2_hllc": 2, "p1_lxf": 1, "q0_lxf": 0, "small": 2}[case]
-        flux = "lxf" if "lxf" in case else "hllc"
-        # 264 x 256 cells: 1 056 shards, five chunks of 256 with a partial last one; "small": 6 shards, one partial chunk
-        nx, ny = (24, 16) if case == "small" else (264, 256)
-        mesh = dflo_amd.Mesh.cartesian(nx, ny, -5.0, -5.0, 10.0 / nx, [-1] * 4, degree)
-        if case.startswith("p"):
-            mesh.set_basis("Pk")
-        prm = dflo_amd.Parameters(flux=flux, cfl=0.8)
-        u0 = mesh.project(problems.isentropic_vortex) if case.startswith("p") else mesh.interpolate(problems.isentropic_vortex)
-    out = []
-    for flag in ("1", "0"):
-        monkeypatch.setenv("DFLO_FUSE_FIN", flag)
-        claw = dflo_amd.ConservationLaw(mesh, prm)
-        out.append(_run(claw, u0, bfun))
-        claw.close()
-    assert out[0][0] == out[1][0]
-    assert np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2])
-
-
-def test_reductions_inside_the_last_stage_kernel_under_graph_replay(monkeypatch):
-    """The in-kernel reductions write the step index of the NEXT step into the slot of the other parity (the slot the kernels of
-    the step in flight read is never written while they run): a captured two-step graph names the slots in a fixed order and is
-    replayed from the parity it was captured at only."""
+def test_step_index_slots_under_graph_replay(monkeypatch):
+    """The reductions of step s write the index of step s + 1 into the slot of the other parity (the slot the kernels of the step in
+    flight read -- to name the step in a failure flag -- is never written while they run): a captured two-step graph names the
+    slots in a fixed order and is replayed from the parity it was captured at only."""
     mesh = dflo_amd.Mesh.cartesian(40, 24, -5.0, -5.0, 0.25, [-1] * 4, 2)
     prm = dflo_amd.Parameters(flux="hllc", cfl=0.7)
     u0 = mesh.interpolate(problems.isentropic_vortex)
