@@ -68,10 +68,10 @@ SYMBOLS = [
     "dflo_hip_unpack_ghost_avg", "dflo_hip_n_ghost_cells", "dflo_hip_stage_update", "dflo_hip_stage_limit",
     "dflo_hip_stage_open", "dflo_hip_stage_update_part", "dflo_hip_stage_limit_part", "dflo_hip_stage_finish",
     "dflo_hip_n_rim_shards",
-    "dflo_hip_scalar_ptrs", "dflo_hip_apply_dt_rules", "dflo_hip_debug_math", "dflo_hip_debug_exp",
+    "dflo_hip_scalar_ptrs", "dflo_hip_debug_math", "dflo_hip_debug_exp",
     "dflo_mesh_cartesian", "dflo_mesh_from_quads", "dflo_mesh_read_gmsh", "dflo_mesh_partition", "dflo_mesh_make_periodic", "dflo_mesh_free",
     "dflo_mesh_last_error", "dflo_mesh_support_points", "dflo_mesh_partition_ex", "dflo_mesh_partition_owners",
-    "dflo_hip_failure_step", "dflo_hip_positivity_stats", "dflo_hip_dt_publish", "dflo_hip_apply_dt_rules_peers",
+    "dflo_hip_failure_step", "dflo_hip_positivity_stats", "dflo_hip_dt_table", "dflo_hip_dt_exchange", "dflo_hip_dt_slot",
     "dflo_hip_multi_create", "dflo_hip_comm_unique_id", "dflo_hip_multi_create_rank", "dflo_hip_multi_create_rank_custom", "dflo_hip_multi_destroy",
     "dflo_hip_multi_last_error", "dflo_hip_multi_n_parts", "dflo_hip_multi_n_local", "dflo_hip_multi_engine",
     "dflo_hip_multi_part_cells", "dflo_hip_multi_n_dofs", "dflo_hip_multi_n_owned_dofs", "dflo_hip_multi_n_rk",
@@ -160,7 +160,6 @@ _sig("dflo_hip_stage_limit_part", C.c_int, _H, C.c_int)
 _sig("dflo_hip_stage_finish", C.c_int, _H)
 _sig("dflo_hip_n_rim_shards", C.c_int, _H)
 _sig("dflo_hip_scalar_ptrs", C.c_int, _H, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p))
-_sig("dflo_hip_apply_dt_rules", C.c_int, _H)
 _sig("dflo_hip_debug_math", C.c_int, C.c_int, _dp, _dp, _dp)
 _sig("dflo_hip_debug_exp", C.c_int, C.c_int, _dp, _dp, _dp)
 _sig("dflo_mesh_cartesian", C.c_int, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double, _ip, C.c_int32,
@@ -174,8 +173,9 @@ _sig("dflo_mesh_partition_ex", C.c_int, _MP, C.c_int32, C.c_int32, C.c_int32, C.
 _sig("dflo_mesh_partition_owners", C.c_int, _MP, C.c_int32, C.c_int32, _ip)
 _sig("dflo_hip_failure_step", C.c_int, _H, C.POINTER(C.c_int64))
 _sig("dflo_hip_positivity_stats", C.c_int, _H, C.POINTER(C.c_int64), C.c_int)
-_sig("dflo_hip_dt_publish", C.c_int, _H, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p))
-_sig("dflo_hip_apply_dt_rules_peers", C.c_int, _H, C.c_int, C.POINTER(C.c_void_p))
+_sig("dflo_hip_dt_table", C.c_int, _H, C.POINTER(C.c_void_p))
+_sig("dflo_hip_dt_exchange", C.c_int, _H, C.c_int, C.c_int, C.POINTER(C.c_void_p))
+_sig("dflo_hip_dt_slot", C.c_int, _H, C.POINTER(C.c_void_p))
 _sig("dflo_hip_multi_create", C.c_int, _MP, C.POINTER(ParamsStruct), C.c_int, C.POINTER(C.c_int), C.c_int, C.POINTER(_H))
 _sig("dflo_hip_comm_unique_id", C.c_int, C.c_void_p)
 _sig("dflo_hip_multi_create_rank", C.c_int, _MP, C.POINTER(ParamsStruct), C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,

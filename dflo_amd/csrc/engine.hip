@@ -69,9 +69,11 @@ struct dflo_hip_engine {
   int *fin_counter = nullptr;   // [0] finalize_kernel: workgroups done; [2 + p] index of the time step in flight while its parity is p
   bool af = false;              // LxF on squares without limiter / ghost cells: no array of cell averages on the path (stage_kernel AF)
   unsigned long long *pos_stats = nullptr;   // [2] positivity limiter inside the stage kernel: cells through the limiter proper, cells changed
-  double *dt_pub = nullptr;     // [2] raw CFL minimum of the last two steps, read by the other engines of a multi-device run
-  int pub_parity = 0;
-  bool publish = false;
+  // several engines: the table of the parts' raw CFL minima, [2][kDtSlots] (row = parity of the step that reads it), this
+  // engine's slot in it, and the peers' tables it writes its own minimum into (FinalArgs::mins, step_dt)
+  double *dt_mins = nullptr;
+  double *dt_peer[kDtSlots] = {};
+  int dt_my = 0, dt_n = 0;
   int64_t steps_done = 0;       // time steps since set_solution (the index recorded with a failure flag)
   hipEvent_t ev_chunk[2] = {nullptr, nullptr};   // dflo_hip_advance: the host stays at most two chunks of steps ahead
   std::vector<double> bface_xy;  // [n_bfaces][N][2]
@@ -96,6 +98,7 @@ struct dflo_hip_engine {
   size_t lds_bytes = 0;
   int stage_grid = 8;
   bool lazy_avg = false, avg_valid = true;   // lazy_avg: intermediate stages do not store the cell averages (nobody reads them)
+  bool resident = false;                     // inside dflo_hip_advance's loop: nobody can ask for anything between the steps
   int n_patterns = 0;   // distinct (face records, face references) among the shards
   int sweep_mode = 1, sweep_dir = 0;   // every launch over all shards walks them against the previous one (DFLO_SWEEP=0: always forward)
   bool fuse_dtq = true;                // DFLO_FUSE_DTQ=0: bilinear cells always take the separate time-step pass (dt_q_kernel)
@@ -113,6 +116,8 @@ struct dflo_hip_engine {
   int *lim_cnt = nullptr;
   ulonglong2 *lim_list = nullptr;
   int lim_epoch = 0, lim_open = -1, lim_grid = 1024;
+  int lim_parts = -1;   // the launch that appended last to the open list: 0 all shards, 3 rim + ring, 4 the rest
+  bool fin_done = false;   // a limiter pass of the open stage has carried the step's reductions
   bool lim_clean[2] = {true, true};
   // dflo_hip_advance replays a captured graph of `graph_steps` time steps (the buffer rotation repeats with
   // that period); built lazily for the state it was captured in
@@ -223,6 +228,24 @@ void part_list(const dflo_hip_engine *h, int part, const int32_t **list, int *n)
 void launch_dt_q(dflo_hip_engine *h);
 int launch_face_traces(dflo_hip_engine *h, double *out, const int32_t *slots, const int32_t *faces, int n);
 
+// the table of the parts' CFL minima as the reductions (FinalArgs) and the consumers of the time step (DtSrc) see it
+void dt_table_args(const dflo_hip_engine *h, FinalArgs &f) {
+  f.mins = h->dt_n > 0 ? h->dt_mins : nullptr;
+  f.my_slot = h->dt_my;
+  f.n_slots = h->dt_n;
+  for (int q = 0; q < kDtSlots; ++q) f.peer_mins[q] = q < h->dt_n ? h->dt_peer[q] : nullptr;
+}
+DtSrc dt_source(const dflo_hip_engine *h) {
+  DtSrc d{};
+  d.row = h->dt_n > 0 ? h->dt_mins + (size_t)(h->steps_done & 1) * kDtSlots : nullptr;
+  d.n = h->dt_n;
+  d.global_rules = h->prm.global_time_step;
+  d.fixed_dt = h->prm.global_time_step && h->prm.cfl <= 0.0;
+  d.time_step = h->prm.time_step;
+  d.final_time = h->prm.final_time;
+  return d;
+}
+
 void time_begin(dflo_hip_engine *h) {
   if (!h->t_sample) return;
   if (h->ev_used == h->ev_pool.size()) {
@@ -288,6 +311,8 @@ int open_stage(dflo_hip_engine *h, int rk, double dt_host, bool residual_only, i
     h->dtq_parts = 0;
     h->aux_fresh = false;
     h->lim_open = -1;
+    h->lim_parts = -1;
+    h->fin_done = false;
     // stage timing samples every fifth stage (5 is coprime to the 2 or 3 stages of a step, so every stage of the
     // step is sampled equally often): two event records per launch are not free
     h->t_sample = h->timing && (h->t_seen++ % 5 == 0);
@@ -358,6 +383,7 @@ int eval_boundary_programs(dflo_hip_engine *h, double dt_host) {
   a.bval0 = h->bval[0];
   a.bval1 = h->bval[1];
   a.dt_dev = h->dt_dev;
+  a.dts = dt_source(h);
   a.dt_host = dt_host;
   a.faces = h->d_bc_faces;
   a.pts = h->d_bc_pts;
@@ -400,6 +426,7 @@ int launch_update(dflo_hip_engine *h, double *rhs_out, int part) {
   a.bval = h->bval[h->st_which];
   a.bface_kind = h->bface_kind;
   a.dt_dev = h->dt_dev;
+  a.dts = dt_source(h);
   a.dt_cell = h->d_dt_cell;  // null unless "time step type = local"
   a.shard_res = h->shard_res + (size_t)rk * std::max(h->plan.n_shards, 1);
   a.shard_dtmin = h->shard_dtmin;
@@ -415,7 +442,9 @@ int launch_update(dflo_hip_engine *h, double *rhs_out, int part) {
   a.want_dt = last ? 1 : 0;
   // the averages of a stage go to memory when somebody reads them: the LxF flux and the limiter / indicator passes of the next
   // stage, the time step and the caller after the last one (a caller that asks in between gets them formed afresh)
-  a.store_avg = (last || !h->lazy_avg) ? 1 : 0;
+  // (inside the device-resident loop of dflo_hip_advance not even the last stage stores them: the time step comes from the
+  //  kernel's own minima, and a caller who asks afterwards gets them formed on demand, in the same order of summation)
+  a.store_avg = ((last && !h->resident) || !h->lazy_avg) ? 1 : 0;
   if (!rhs_out) h->avg_valid = a.store_avg != 0;
   // bilinear cells: compute_time_step_q is formed by the last stage kernel itself when no limiter pass follows it (the
   // positivity limiter, if any, has been applied inside the kernel) -- otherwise by that pass, or by dt_q_kernel
@@ -445,13 +474,22 @@ int launch_update(dflo_hip_engine *h, double *rhs_out, int part) {
   const int pos_ = h->fuse_pos ? 1 : (h->lim_mask ? 2 : (h->af ? 3 : 0));
   if (pos_ == 2 && mode_ != 2) {
     h->aux_fresh = true;
-    h->lim_open = -1;
-    if (h->lim_cnt && part == 0) {
-      const int i = ++h->lim_epoch & 1;
-      if (!h->lim_clean[i]) HIPCHK(h, hipMemsetAsync(h->lim_cnt + i, 0, sizeof(int), h->stream));
-      h->lim_clean[i] = false;
-      h->lim_open = i;
-      a.lim_cnt = h->lim_cnt + i;
+    if (!(part == 4 && h->lim_parts == 3)) h->lim_open = -1;
+    // The list of marked shards: launches over all shards, and the two launches of a multi-device part whose limiter pass
+    // over "everything but the rim" comes later -- rim + ring (3: only the ring goes on the list, the rim has a pass of its own)
+    // and the rest (4), which share one list; 4 joins the list 3 opened.
+    if (h->lim_cnt && (part == 0 || part == 3 || part == 4)) {
+      if (part == 4 && h->lim_parts == 3) {
+        a.lim_cnt = h->lim_cnt + h->lim_open;
+      } else {
+        const int i = ++h->lim_epoch & 1;
+        if (!h->lim_clean[i]) HIPCHK(h, hipMemsetAsync(h->lim_cnt + i, 0, sizeof(int), h->stream));
+        h->lim_clean[i] = false;
+        h->lim_open = i;
+        a.lim_cnt = h->lim_cnt + i;
+      }
+      h->lim_parts = part;
+      a.lim_list_from = part == 3 ? (int)p.rim_shards.size() : 0;
     }
   }
   stage_fn fn = h->basis == DFLO_BASIS_PK ? pick_pk(h->N, h->prm.flux_type, mode_, streams_out(h)) : pick_stage(h->N, h->prm.flux_type, mode_, h->geo, pos_, streams_out(h));
@@ -536,7 +574,7 @@ int launch_limiter(dflo_hip_engine *h, int tvb, int pos, int part, bool stage_da
   void (*lf)(const LimArgs) = DFLO_BY_N_LIM(h->N, limiter_kernel);
   if (h->basis == DFLO_BASIS_PK) lf = DFLO_BY_N_LIM(h->N, limiter_pk_kernel);
   int grid = grid_for(l.n_list);
-  if (l.mask && part == 0 && h->lim_open >= 0 && h->basis == DFLO_BASIS_QK) {
+  if (l.mask && (part == 0 || part == 2) && h->lim_open >= 0 && h->basis == DFLO_BASIS_QK && (part == 0) == (h->lim_parts == 0)) {
     l.mark_list = h->lim_list;
     l.mark_cnt = h->lim_cnt + h->lim_open;
     l.mark_cnt_next = h->lim_cnt + (h->lim_open ^ 1);
@@ -544,6 +582,7 @@ int launch_limiter(dflo_hip_engine *h, int tvb, int pos, int part, bool stage_da
     h->lim_open = -1;
     grid = std::min(grid, std::max(h->lim_grid, l.fin_blocks));
   }
+  grid = std::max(grid, l.fin_blocks);   // (a launch over a few shards that carries the reductions of all of them)
   hipLaunchKernelGGL(lf, dim3(grid), dim3(64), 0, h->stream, l);
   HIPCHK(h, hipGetLastError());
   return DFLO_OK;
@@ -579,10 +618,10 @@ void final_args(dflo_hip_engine *h, FinalArgs &f) {
   f.final_time = h->prm.final_time;
   f.global_rules = h->prm.global_time_step;
   f.fixed_dt = h->prm.global_time_step && h->prm.cfl <= 0.0;
-  f.publish = h->publish ? h->dt_pub + h->pub_parity : nullptr;
   f.partial = h->fin_partial;
   f.counter = h->fin_counter;
   f.step_par = (int)(h->steps_done & 1);
+  dt_table_args(h, f);
 }
 
 int launch_finish(dflo_hip_engine *h, bool reductions_done = false) {
@@ -601,7 +640,7 @@ int launch_finish(dflo_hip_engine *h, bool reductions_done = false) {
     HIPCHK(h, hipGetLastError());
   }
   h->pending_rk = -1;
-  if (!last || reductions_done) return DFLO_OK;  // ||rhs|| of every stage is reduced once, after the last stage (it is only reported, src/claw.cc:768)
+  if (!last || reductions_done || h->fin_done) return DFLO_OK;  // ||rhs|| of every stage is reduced once, after the last stage (it is only reported, src/claw.cc:768)
   FinalArgs f{};
   final_args(h, f);
   hipLaunchKernelGGL(finalize_kernel, dim3(fin_grid(f.n_shards)), dim3(256), 0, h->stream, f);
@@ -641,6 +680,12 @@ void launch_dt_q(dflo_hip_engine *h) {
 int launch_average(dflo_hip_engine *h) {
   const Plan &p = h->plan;
   const int all = p.n_shards + p.n_ghost_shards;
+  if (h->basis == DFLO_BASIS_QK && h->geo == 0) {   // squares: the epilogue's order of summation
+    auto fn = DFLO_BY_N(h->N, average_rows_kernel);
+    hipLaunchKernelGGL(fn, dim3(all), dim3(64), 0, h->stream, (const double *)h->U[h->cur], h->avg[h->avg_cur]);
+    HIPCHK(h, hipGetLastError());
+    return DFLO_OK;
+  }
   hipLaunchKernelGGL(average_kernel, dim3(all), dim3(64), 0, h->stream, h->U[h->cur], h->avg[h->avg_cur], h->ndof, h->kb,
                      h->basis == DFLO_BASIS_PK ? -h->N : h->N, (const double *)h->d_cell_vert, p.n_slots);
   HIPCHK(h, hipGetLastError());
@@ -895,7 +940,7 @@ int dflo_hip_create(const dflo_mesh_t *mesh, const dflo_params_t *params, int de
       hipMalloc((void **)&h->shard_dtmin, nsh * sizeof(double)) != hipSuccess ||
       hipMalloc((void **)&h->res_sq, 4 * sizeof(double)) != hipSuccess || hipMalloc((void **)&h->fin_partial, 4 * kFinBlocks * sizeof(double)) != hipSuccess ||
       hipMalloc((void **)&h->dt_dev, 4 * sizeof(double)) != hipSuccess || hipMalloc((void **)&h->fin_counter, 4 * sizeof(int)) != hipSuccess ||
-      hipMalloc((void **)&h->dt_pub, 2 * sizeof(double)) != hipSuccess || hipMalloc((void **)&h->pos_stats, 2 * sizeof(unsigned long long)) != hipSuccess) {
+      hipMalloc((void **)&h->dt_mins, 2 * kDtSlots * sizeof(double)) != hipSuccess || hipMalloc((void **)&h->pos_stats, 2 * sizeof(unsigned long long)) != hipSuccess) {
     h->err = "hipMalloc(scalars) failed";
     return bail(DFLO_ERR_NOMEM);
   }
@@ -912,7 +957,10 @@ int dflo_hip_create(const dflo_mesh_t *mesh, const dflo_params_t *params, int de
   }
   hipMemset(h->res_sq, 0, 4 * sizeof(double));
   hipMemset(h->dt_dev, 0, 4 * sizeof(double));
-  hipMemset(h->dt_pub, 0, 2 * sizeof(double));
+  {
+    std::vector<double> big(2 * kDtSlots, 1.0e300);   // an unused slot never wins a minimum
+    hipMemcpy(h->dt_mins, big.data(), big.size() * sizeof(double), hipMemcpyHostToDevice);
+  }
   hipMemset(h->fin_counter, 0, 4 * sizeof(int));
   hipMemset(h->pos_stats, 0, 2 * sizeof(unsigned long long));
   // row stride of the stage kernel's trace / flux table: a column per halo entry (its trace, then the flux of its face) and one
@@ -1004,7 +1052,7 @@ int dflo_hip_destroy(dflo_hip_handle h) {
   hipFree(h->d_rim_list); hipFree(h->d_int_list); hipFree(h->d_rim2_list); hipFree(h->d_rest2_list);
   hipFree(h->d_cell_h); hipFree(h->d_dt_cell); hipFree(h->d_cell_vert); hipFree(h->shard_res); hipFree(h->shard_dtmin); hipFree(h->res_sq); hipFree(h->fin_partial); hipFree(h->dt_dev);
   if (h->flags_host) hipHostFree((void *)h->flags_host);
-  hipFree(h->fin_counter); hipFree(h->dt_pub); hipFree(h->pos_stats);
+  hipFree(h->fin_counter); hipFree(h->dt_mins); hipFree(h->pos_stats);
   hipFree(h->Tg[0]); hipFree(h->Tg[1]); hipFree(h->d_gt_slot); hipFree(h->d_gt_face); hipFree(h->d_sendf_slot); hipFree(h->d_sendf_face); hipFree(h->d_send_slots); hipFree(h->ghost_stage);
   for (int i = 0; i < 2; ++i) if (h->ev_chunk[i]) hipEventDestroy(h->ev_chunk[i]);
   for (auto &e : h->ev_pool) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
@@ -1168,6 +1216,11 @@ static int launch_compute_dt(dflo_hip_engine *h, double elapsed_time) {
   const int fixed = h->prm.global_time_step && h->prm.cfl <= 0.0;
   // per-shard minima from the stored cell averages (src/claw.cc:486-511)
   const Plan &p = h->plan;
+  if (!fixed && h->geo == 0 && !h->avg_valid) {   // the last stage kept its averages to itself (lazy_avg)
+    const int rc = launch_average(h);
+    if (rc) return rc;
+    h->avg_valid = true;
+  }
   if (fixed) {
   } else if (h->geo == 0)
     hipLaunchKernelGGL(dt_kernel, dim3(p.n_shards), dim3(64), 0, h->stream, h->avg[h->avg_cur], h->d_cell_h, p.h,
@@ -1192,10 +1245,10 @@ static int launch_compute_dt(dflo_hip_engine *h, double elapsed_time) {
   f.final_time = h->prm.final_time;
   f.global_rules = h->prm.global_time_step;
   f.fixed_dt = fixed;
-  f.publish = h->publish ? h->dt_pub + h->pub_parity : nullptr;
   f.partial = h->fin_partial;
   f.counter = h->fin_counter;
   f.step_par = (int)(h->steps_done & 1);
+  dt_table_args(h, f);
   hipLaunchKernelGGL(finalize_kernel, dim3(fin_grid(f.n_shards)), dim3(256), 0, h->stream, f);
   HIPCHK(h, hipGetLastError());
   return DFLO_OK;
@@ -1255,6 +1308,11 @@ int dflo_hip_advance(dflo_hip_handle h, int n_steps, double *elapsed_time_inout)
   if (h->ev_used > 2048) time_collect(h);
   int rc = launch_compute_dt(h, *elapsed_time_inout);
   if (rc) return rc;
+  struct Resident {   // (every way out of this function leaves the loop)
+    dflo_hip_engine *h;
+    ~Resident() { h->resident = false; }
+  } resident_guard{h};
+  h->resident = true;
   int s = 0;
   if (h->use_graph && !h->timing && h->cur == h->old) {
     // the (solution, average) buffer indices come back to where they started after 2 steps (avg_cur flips
@@ -1404,7 +1462,18 @@ int dflo_hip_stage_update_part(dflo_hip_handle h, int part) {
 int dflo_hip_stage_limit_part(dflo_hip_handle h, int part) {
   if (check_handle(h) || part < 0 || part > 4) return DFLO_ERR_BAD_PARAM;
   hipSetDevice(h->device);
-  return launch_stage_limiter(h, part);
+  // The pass over everything but the rim (2) is the last limiter launch of a stage in the multi-device schedule; behind the last
+  // stage of a TVB run on squares it carries the step's reductions like the single engine's pass (launch_limit_finalize).  The
+  // caller has ordered it behind the rim's UPDATE (it reads the rim cells' new averages), which is all the reductions need of
+  // the rim: the limiter changes neither averages nor residuals.
+  const bool fuse = part == 2 && h->fuse_fin && h->pending_rk == h->n_rk - 1 && h->geo == 0 && !h->d_dt_cell && h->basis == DFLO_BASIS_QK &&
+                    h->prm.limiter_type == DFLO_LIMITER_TVB && !h->fuse_pos && !h->plan.interior_shards.empty() && !h->d_shock;
+  if (!fuse) return launch_stage_limiter(h, part);
+  FinalArgs f{};
+  final_args(h, f);
+  const int rc = launch_stage_limiter(h, part, &f);
+  if (!rc) h->fin_done = true;
+  return rc;
 }
 
 int dflo_hip_stage_finish(dflo_hip_handle h) {
@@ -1669,30 +1738,23 @@ int dflo_hip_debug_exp(int n, const double *x, double *exp_library, double *exp_
   return hipGetLastError() == hipSuccess ? DFLO_OK : DFLO_ERR_HIP;
 }
 
-int dflo_hip_apply_dt_rules(dflo_hip_handle h) {
-  if (check_handle(h)) return DFLO_ERR_BAD_PARAM;
-  hipSetDevice(h->device);
-  return dflo_hip_apply_dt_rules_peers(h, 0, nullptr);
-}
-
-int dflo_hip_dt_publish(dflo_hip_handle h, int enable, void **slot0, void **slot1) {
-  if (check_handle(h)) return DFLO_ERR_BAD_PARAM;
-  h->publish = enable != 0;
-  if (slot0) *slot0 = h->dt_pub;
-  if (slot1) *slot1 = h->dt_pub + 1;
+int dflo_hip_dt_table(dflo_hip_handle h, void **base) {
+  if (check_handle(h) || !base) return DFLO_ERR_BAD_PARAM;
+  *base = h->dt_mins;
   return DFLO_OK;
 }
 
-int dflo_hip_apply_dt_rules_peers(dflo_hip_handle h, int n_peers, const void *const *peer_slots) {
-  if (check_handle(h) || n_peers < 0 || n_peers > kMaxPeers || (n_peers > 0 && !peer_slots)) return DFLO_ERR_BAD_PARAM;
-  hipSetDevice(h->device);
-  DtPeers pr{};
-  pr.n = n_peers;
-  for (int i = 0; i < n_peers; ++i) pr.slot[i] = (const double *)peer_slots[i];
-  hipLaunchKernelGGL(dt_rules_kernel, dim3(1), dim3(1), 0, h->stream, h->dt_dev, h->prm.time_step, h->prm.final_time,
-                     h->prm.global_time_step, (int)(h->prm.global_time_step && h->prm.cfl <= 0.0), pr);
-  HIPCHK(h, hipGetLastError());
-  if (h->publish) h->pub_parity ^= 1;   // the next step publishes into the other slot
+int dflo_hip_dt_exchange(dflo_hip_handle h, int my_slot, int n_slots, void *const *peer_tables) {
+  if (check_handle(h) || n_slots < 0 || n_slots > kDtSlots || (n_slots > 0 && (my_slot < 0 || my_slot >= n_slots))) return DFLO_ERR_BAD_PARAM;
+  h->dt_n = n_slots;
+  h->dt_my = n_slots > 0 ? my_slot : 0;
+  for (int q = 0; q < kDtSlots; ++q) h->dt_peer[q] = (peer_tables && q < n_slots && q != my_slot) ? (double *)peer_tables[q] : nullptr;
+  return DFLO_OK;
+}
+
+int dflo_hip_dt_slot(dflo_hip_handle h, void **slot) {
+  if (check_handle(h) || !slot) return DFLO_ERR_BAD_PARAM;
+  *slot = h->dt_mins + (size_t)(h->steps_done & 1) * kDtSlots + h->dt_my;
   return DFLO_OK;
 }
 

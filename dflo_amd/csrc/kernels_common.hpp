@@ -36,6 +36,7 @@ struct KBasis {       // 1-D tables, see basis.h
 };
 
 
+constexpr int kDtSlots = 16;   // parts of a multi-device run (dflo_hip_multi_create: n_devices <= 16)
 // reductions over shards + the global-dt rules of compute_time_step (src/claw.cc:468-476)
 struct FinalArgs {
   const double *shard_res, *shard_dtmin;
@@ -46,8 +47,22 @@ struct FinalArgs {
   int step_par;    // parity of the step these reductions end
   int n_shards, n_stages, res_stride, do_dt, advance_time, global_rules;  // shard_res: [n_stages][res_stride]
   int fixed_dt;    // "time step type = global" with cfl <= 0: dt = time_step (src/claw.cc:455-460)
-  double *publish; // multi-device: the raw minimum also goes here (a slot the peers read, alternating from step to step)
+  // several engines (multi-device): the raw CFL minima of all parts meet in a table mins[2][kDtSlots] on every engine -- row
+  // p holds the minima the step of parity p reads -- which the engine that forms a minimum writes into, on its own device and on
+  // the peers' (stores over xGMI peer access; rank mode: an all-reduce in place on the single slot).  The consumers of the time
+  // step take the minimum over their row and apply the rules themselves (step_dt): no kernel between the reductions of a step
+  // and the first kernel of the next.  null: one engine, dt_dev[0] is the time step.
+  double *mins;
+  double *peer_mins[kDtSlots];
+  int my_slot, n_slots;
   double time_step, final_time, dt_host;
+};
+// what a consumer of the time step needs to form it from the table (StageArgs, BcArgs)
+struct DtSrc {
+  const double *row;   // the row of this step's parity, or null: dt_dev[0]
+  int n;
+  int global_rules, fixed_dt;
+  double time_step, final_time;
 };
 constexpr int kFinBlocks = 64;   // workgroups of the two-level reduction (one lane of the last workgroup's first wavefront each)
 
@@ -72,7 +87,8 @@ struct StageArgs {
   int n_slots;
   const double *bval;
   const int32_t *bface_kind;
-  const double *dt_dev;   // device-resident global dt (used when dt_host < 0)
+  const double *dt_dev;   // device-resident global dt (used when dt_host < 0): [0] dt, [1] elapsed time
+  DtSrc dts;              // several engines: the table of the parts' minima the time step is formed from (step_dt)
   const double *dt_cell;  // local time stepping: per internal slot, else null
   double *shard_res, *shard_dtmin;
   double dt_host, ark, gravity, cfl, h_uniform;
@@ -94,6 +110,8 @@ struct StageArgs {
   unsigned long long *pos_stats;  // POS 1: [0] cells that failed the nodal-box bound (limiter proper), [1] cells it changed
   unsigned long long *lim_mask;   // POS 2: [n_shards] bit = the limiter pass may have something to do in that cell
   int *lim_cnt;                   // POS 2, launches over all shards: the shards with a mark also go on a list (one append per
+  int lim_list_from;              //   (a launch over rim + ring of a multi-device part: only the shards from this index of the launch's list on --
+                                  //    the ring -- go on the list; the rim shards are limited by a pass of their own, ahead of the others)
   ulonglong2 *lim_list;           //   marked shard and launch: a single wavefront writes a shard's word) as (shard, word), so that the pass is a few
                                   //   hundred wavefronts walking that list instead of one per shard that reads a word and leaves; or null
   double tvb_M;                   // POS 2: TVB constant M, < 0: the limiter pass has no TVB part
@@ -225,18 +243,32 @@ __device__ __forceinline__ double dt_rules(double dt, double t, double time_step
 }
 // what the one thread that holds the totals of a step writes: the squared residual norms, the clock, the raw CFL minimum and
 // the time step of the next step
+// the time step of the step in flight, as every consumer forms it (stage kernels, boundary programs, the clock): the minimum
+// over the parts' raw CFL minima + the rules, or dt_dev[0] where one engine has applied them already
+__device__ __forceinline__ double step_dt(const DtSrc &d, const double *dt_dev) {
+  if (!d.row) return dt_dev[0];
+  double raw = d.row[0];
+  for (int i = 1; i < d.n; ++i) raw = fmin(raw, d.row[i]);
+  return dt_rules(raw, dt_dev[1], d.time_step, d.final_time, d.global_rules, d.fixed_dt);
+}
 __device__ __forceinline__ void finalize_publish(const FinalArgs &a, const double (&tot)[3], double dt) {
   *a.counter = 0;  // ready for the next launch (launches on one stream do not overlap)
   for (int st = 0; st < a.n_stages; ++st) a.res_sq[st] = tot[st];
   if (a.do_dt) {
     double tt = a.dt_dev[1];
     if (a.advance_time) {  // elapsed_time += global_dt (src/claw.cc:1072) for the step just done
-      tt += a.dt_host >= 0.0 ? a.dt_host : a.dt_dev[0];
+      const DtSrc d{a.mins ? a.mins + a.step_par * kDtSlots : nullptr, a.n_slots, a.global_rules, a.fixed_dt, a.time_step, a.final_time};
+      tt += a.dt_host >= 0.0 ? a.dt_host : step_dt(d, a.dt_dev);
       a.dt_dev[1] = tt;
       a.counter[2 + (a.step_par ^ 1)] = a.counter[2 + a.step_par] + 1;   // the next step's index, in the next step's slot
     }
     a.dt_dev[2] = dt;
-    if (a.publish) *a.publish = dt;
+    if (a.mins) {   // into the row the step that will use this minimum reads: the next one, or (compute_dt) the one about to run
+      const int at = (a.advance_time ? a.step_par ^ 1 : a.step_par) * kDtSlots + a.my_slot;
+      a.mins[at] = dt;
+      for (int q = 0; q < a.n_slots; ++q)
+        if (a.peer_mins[q]) a.peer_mins[q][at] = dt;
+    }
     a.dt_dev[0] = dt_rules(dt, tt, a.time_step, a.final_time, a.global_rules, a.fixed_dt);
   }
 }

@@ -155,7 +155,7 @@ struct Part {
   std::vector<int32_t> sendf_off, recvf_off;
   double *send_t = nullptr;
   void *tg[2] = {nullptr, nullptr};
-  void *dt_slot[2] = {nullptr, nullptr};   // the engine's published CFL minima
+  void *dt_table = nullptr;    // the engine's table of the parts' CFL minima (dflo_hip_dt_table)
   void *dt_ptr = nullptr, *res_ptr = nullptr;
   int steps_run = 0;             // threaded advance: steps this part's thread issued
   std::vector<int32_t> bface_global;   // global boundary-face number of the engine's boundary faces
@@ -587,7 +587,10 @@ int stage_phase(dflo_hip_multi *m, Group &g, const StageCtx &s, int ph) {
       MHIP(m, hipEventRecord(m->tvb ? g.ev_ring : g.ev_rim, g.C));
       return DFLO_OK;
     case 2:   // the interior on M, next to it
-      if (g.rim_pending) MHIP(m, hipStreamWaitEvent(g.M, g.ev_rim_prev, 0));   // the rim cells of the previous stage (halo of the interior)
+      // the rim cells of the previous stage are the halo of the interior.  Not with TVB: there the update is split at rim + ring
+      // | rest, and a shard of the rest has no neighbour in the rim (Plan::rim2_shards) -- its halo, ring and rest, was limited
+      // by this stream's own pass; the comm stream's chain (averages -> limit rim -> traces, the long one) is off this stream's path
+      if (g.rim_pending && !m->tvb) MHIP(m, hipStreamWaitEvent(g.M, g.ev_rim_prev, 0));
       for (int i : g.parts) MENG(m, m->parts[i], dflo_hip_stage_update_part(m->parts[i].eng, int_update));
       return DFLO_OK;
     case 3:   // TVB: the averages of the neighbours across the cut arrive: limit the rim, send its cells
@@ -616,7 +619,9 @@ int stage_phase(dflo_hip_multi *m, Group &g, const StageCtx &s, int ph) {
       if (m->tvb) MHIP(m, hipStreamWaitEvent(g.M, g.ev_ring, 0));
       if (m->tvb || m->sep_limiter)
         for (int i : g.parts) MENG(m, m->parts[i], dflo_hip_stage_limit_part(m->parts[i].eng, 2));
-      if (s.last) MHIP(m, hipStreamWaitEvent(g.M, g.ev_rim, 0));   // the step's reductions take in the rim shards' partials
+      // the step's reductions take in the rim shards' partials: those of their UPDATE, which with TVB this stream has waited for
+      // already (ev_ring) -- the limiter changes neither the averages nor the residual
+      if (s.last && !m->tvb) MHIP(m, hipStreamWaitEvent(g.M, g.ev_rim, 0));
       for (int i : g.parts) MENG(m, m->parts[i], dflo_hip_stage_finish(m->parts[i].eng));
       std::swap(g.ev_rim, g.ev_rim_prev);      // the next stage's interior waits for this stage's rim
       g.rim_pending = !s.last;                 // (after the last stage M has waited already)
@@ -694,20 +699,21 @@ int run_stage(dflo_hip_multi *m, int rk, double dt) {
 
 // Utilities::MPI::min(global_dt) (src_mpi/claw.cc:579) on the device-resident time step, after the last stage of step number
 // `step` (counted since create).  One process per GPU: an 8-byte all-reduce on the comm stream.  One process: phase 0, every
-// part records that its CFL minimum is published; phase 1, it waits for the others' records and reads their slots over xGMI.
+// part records that its reductions -- which write its CFL minimum into every part's table -- are issued; phase 1, it waits for
+// the others' records.  Nothing is launched: the consumers of the time step form it from the table (engine: step_dt).
 int reduce_dt_rank(dflo_hip_multi *m) {
+  // the reductions of the step just ended have left this rank's minimum in the slot the next step reads: all-reduce it in
+  // place on the comm stream; the consumers apply the rules themselves (no kernel in between)
   Part &p = m->parts[0];
   MHIP(m, hipEventRecord(p.ev_fin[0], p.M));
   MHIP(m, hipStreamWaitEvent(p.C, p.ev_fin[0], 0));
-  double *raw = (double *)p.dt_ptr + 2;
+  void *slot = nullptr;
+  MENG(m, p, dflo_hip_dt_slot(p.eng, &slot));
   if (m->x_allreduce) {
-    if (m->x_allreduce(m->x_user, raw, 1, DFLO_REDUCE_MIN, (void *)p.C)) { set_err(m, "the host program's all-reduce callback failed"); return DFLO_ERR_COMM; }
+    if (m->x_allreduce(m->x_user, (double *)slot, 1, DFLO_REDUCE_MIN, (void *)p.C)) { set_err(m, "the host program's all-reduce callback failed"); return DFLO_ERR_COMM; }
   } else {
-    MNCCL(m, g_rccl.AllReduce(raw, raw, 1, ncclDouble, ncclMin, m->comm, p.C));
+    MNCCL(m, g_rccl.AllReduce(slot, slot, 1, ncclDouble, ncclMin, m->comm, p.C));
   }
-  MENG(m, p, dflo_hip_set_stream(p.eng, p.C));
-  MENG(m, p, dflo_hip_apply_dt_rules(p.eng));
-  MENG(m, p, dflo_hip_set_stream(p.eng, p.M));
   MHIP(m, hipEventRecord(p.ev_dt, p.C));
   MHIP(m, hipStreamWaitEvent(p.M, p.ev_dt, 0));
   return DFLO_OK;
@@ -722,16 +728,14 @@ int reduce_dt_phase(dflo_hip_multi *m, Part &p, int64_t step, int ph) {
     p.sy->fin.store(++p.n_fin, std::memory_order_release);
     return DFLO_OK;
   }
-  const void *slots[16];
-  int n = 0;
+  // the peers' reductions have written their minima into this part's table: the compute stream waits for them, and with it
+  // everything of the next step (its comm stream starts behind the compute stream's "open")
   for (Part &q : m->parts) {
     if (&q == &p) continue;
     const int rc = wait_count(m, q.sy->fin, p.n_fin);
     if (rc) return rc;
     if (q.M != p.M) MHIP(m, hipStreamWaitEvent(p.M, q.ev_fin[par], 0));   // (same stream: q's reductions are ahead of this point)
-    slots[n++] = q.dt_slot[par];
   }
-  MENG(m, p, dflo_hip_apply_dt_rules_peers(p.eng, n, slots));
   return DFLO_OK;
 }
 int reduce_dt(dflo_hip_multi *m) {   // calling thread, all parts
@@ -949,7 +953,8 @@ int setup_part(dflo_hip_multi *m, Part &p, const dflo_mesh_t *mesh, const dflo_p
     MENG(m, p, dflo_hip_ghost_trace_buffer(p.eng, 1, &p.tg[1]));
   }
   MENG(m, p, dflo_hip_scalar_ptrs(p.eng, &p.dt_ptr, &p.res_ptr));
-  MENG(m, p, dflo_hip_dt_publish(p.eng, (!m->rank_mode && m->n_parts > 1) ? 1 : 0, &p.dt_slot[0], &p.dt_slot[1]));
+  MENG(m, p, dflo_hip_dt_table(p.eng, &p.dt_table));
+  if (m->rank_mode && m->n_parts > 1) MENG(m, p, dflo_hip_dt_exchange(p.eng, 0, 1, nullptr));   // one slot, all-reduced in place
   // the engine's boundary faces -> their numbers in the undivided mesh
   const int nb = dflo_hip_n_boundary_faces(p.eng);
   std::vector<int32_t> bc(std::max(nb, 1)), bf(std::max(nb, 1));
@@ -1102,6 +1107,13 @@ int dflo_hip_multi_create(const dflo_mesh_t *mesh, const dflo_params_t *params, 
       if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) { m->err = std::string("hipDeviceEnablePeerAccess: ") + hipGetErrorString(e); return bail(DFLO_ERR_HIP); }
       (void)hipGetLastError();
     }
+  if (n_devices > 1) {   // every part writes its CFL minimum into every part's table
+    for (Part &p : m->parts) {
+      void *tables[16] = {};
+      for (Part &q : m->parts) tables[q.index] = q.dt_table;
+      if ((rc = dflo_hip_dt_exchange(p.eng, p.index, n_devices, tables))) { m->err = dflo_hip_last_error(p.eng); return bail(rc); }
+    }
+  }
   if (m->loopback) {
     if (!load_rccl(m->err)) return bail(DFLO_ERR_COMM);
     ncclUniqueId id;

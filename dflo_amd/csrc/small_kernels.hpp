@@ -18,6 +18,7 @@ struct BcArgs {
   const double *bxy;        // [n_bfaces][N][2]
   double *bval0, *bval1;    // [n_bfaces][N][4] tables of RK stage 0 (time t) and of the later stages (t + dt)
   const double *dt_dev;     // [0] dt, [1] elapsed time
+  DtSrc dts;                // several engines: see step_dt
   double dt_host;
   const int32_t *faces;     // [n_faces] the boundary faces whose id has a program
   const double *pts;        // [n_faces * N][4] per listed point: x, y, its index in the value tables, its boundary id (one coalesced
@@ -117,7 +118,7 @@ __global__ __launch_bounds__(kBcThreads) __attribute__((flatten)) void bc_eval_k
   const double *pt = a.pts + 4 * (size_t)(valid ? j : 0);
   const double x = pt[0], y = pt[1];
   const int i = (int)pt[2], id = (int)pt[3];
-  const double t = a.dt_dev[1] + (which ? (a.dt_host >= 0.0 ? a.dt_host : a.dt_dev[0]) : 0.0);
+  const double t = a.dt_dev[1] + (which ? (a.dt_host >= 0.0 ? a.dt_host : step_dt(a.dts, a.dt_dev)) : 0.0);
   double *bval = which ? a.bval1 : a.bval0;
   if (in_lds) {
     for (int k = threadIdx.x; k < 2 * a.n_ops; k += blockDim.x) s_ops[k] = a.ops[k];
@@ -300,6 +301,21 @@ __global__ void average_kernel(const double *U, double *avg, int ndof, KBasis kb
     avg[((size_t)shard * 4 + c) * 64 + lane] = m;
   }
 }
+// The same for Qk on squares with the sums in the order of the stage kernels' epilogue (cell_average_rows): an average formed
+// here -- after set_solution, or on demand for a stage that kept its averages to itself -- carries the bits the epilogue would
+// have stored, and the bits the LxF flux forms from the DoFs when the arrays of averages are off its path (stage_kernel AF).
+template <int N>
+__global__ __launch_bounds__(64) void average_rows_kernel(const double *U, double *avg) {
+  constexpr int NS = N * N;
+  const int shard = blockIdx.x, lane = threadIdx.x;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    double u[NS];
+#pragma unroll
+    for (int j = 0; j < NS; ++j) u[j] = U[((size_t)shard * 4 * NS + c * NS + j) * 64 + lane];
+    avg[((size_t)shard * 4 + c) * 64 + lane] = cell_average_rows<N>(u);
+  }
+}
 // compute_time_step_q (src/claw.cc:520-557): max of |v| + c over the 4 x 4 points of QIterated(QTrapez,3),
 // dt = cfl h / lambda / (2k+1) with h = diameter / sqrt(2); per-shard minimum.  Lane = cell; the
 // interpolation to the 16 points is sum-factorised (xi first, then eta).
@@ -394,19 +410,5 @@ __global__ __launch_bounds__(256) void finalize_kernel(const FinalArgs a) {
   if (t != 0) return;
   finalize_publish(a, tot, dt);
 }
-// re-apply the rules after an external all-reduce(min) of dt_dev[2] (multi-device), or after taking the minimum over
-// the slots the other engines of this process published (peer reads over xGMI)
-constexpr int kMaxPeers = 16;
-struct DtPeers {
-  const double *slot[kMaxPeers];
-  int n;
-};
-__global__ void dt_rules_kernel(double *dt_dev, double time_step, double final_time, int global_rules, int fixed_dt, DtPeers peers) {
-  double dt = dt_dev[2], t = dt_dev[1];
-  for (int i = 0; i < peers.n; ++i) dt = fmin(dt, *(const volatile double *)peers.slot[i]);
-  dt_dev[2] = dt;
-  dt_dev[0] = dt_rules(dt, t, time_step, final_time, global_rules, fixed_dt);
-}
-
 
 }  // namespace dflo

@@ -583,7 +583,7 @@ __global__ __launch_bounds__(64 * N, N >= 5 ? 1 : ((N == 4 && GEO == 0 && MODE =
   // the time step of the update: fetched here with everything else (it used to be read in the middle of phase C, one more
   // trip to memory on every wave's critical path)
   double dt_step = 0.0;
-  if constexpr (MODE != 2) dt_step = a.dt_cell ? a.dt_cell[(size_t)shard * 64 + lane] : (a.dt_host >= 0.0 ? a.dt_host : *a.dt_dev);
+  if constexpr (MODE != 2) dt_step = a.dt_cell ? a.dt_cell[(size_t)shard * 64 + lane] : (a.dt_host >= 0.0 ? a.dt_host : step_dt(a.dts, a.dt_dev));
   double uold[4][N];
   if constexpr (MODE == 1) {
     const double *op = a.Uold + (size_t)shard * NDOF * 64 + (size_t)(N * row) * 64 + lane;
@@ -1021,7 +1021,7 @@ __global__ __launch_bounds__(64 * N, N >= 5 ? 1 : ((N == 4 && GEO == 0 && MODE =
       const unsigned long long m = __ballot(need && active);
       if (lane == 0 && m) {
         atomicOr(&a.lim_mask[shard], m);
-        if (a.lim_cnt) a.lim_list[atomicAdd(a.lim_cnt, 1)] = make_ulonglong2((unsigned long long)shard, m);
+        if (a.lim_cnt && sidx >= a.lim_list_from) a.lim_list[atomicAdd(a.lim_cnt, 1)] = make_ulonglong2((unsigned long long)shard, m);
       }
     }
   }
@@ -1055,7 +1055,7 @@ __global__ __launch_bounds__(64 * N, N >= 5 ? 1 : ((N == 4 && GEO == 0 && MODE =
     const unsigned long long m = __ballot(((a.pos_check && !settled) || open) && active);
     if (lane == 0 && m) {
       atomicOr(&a.lim_mask[shard], m);
-      if (a.lim_cnt) a.lim_list[atomicAdd(a.lim_cnt, 1)] = make_ulonglong2((unsigned long long)shard, m);
+      if (a.lim_cnt && sidx >= a.lim_list_from) a.lim_list[atomicAdd(a.lim_cnt, 1)] = make_ulonglong2((unsigned long long)shard, m);
     }
     }
   }
@@ -1316,7 +1316,7 @@ __global__ __launch_bounds__(64 * N, N >= 5 ? 1 : (N == 4 ? (((MODE == 0 || (MOD
   for (int f = 0; f < 4; ++f) cref[f] = a.cell_face[((size_t)pat * 4 + f) * 64 + lane];
   const double h = a.uniform_h ? a.h_uniform : a.cell_h[(size_t)shard * 64 + lane];
   double dt_step = 0.0;   // fetched with the other loads, not in the middle of phase C
-  if constexpr (MODE != 2) dt_step = a.dt_cell ? a.dt_cell[(size_t)shard * 64 + lane] : (a.dt_host >= 0.0 ? a.dt_host : *a.dt_dev);
+  if constexpr (MODE != 2) dt_step = a.dt_cell ? a.dt_cell[(size_t)shard * 64 + lane] : (a.dt_host >= 0.0 ? a.dt_host : step_dt(a.dts, a.dt_dev));
   double ucur[4][MS], uold[4][MS];
 #pragma unroll
   for (int c = 0; c < 4; ++c)

@@ -300,18 +300,20 @@ int dflo_hip_use_ghost_traces(dflo_hip_handle h, int which);
  * as pack_send_cells), 1 cell averages ([4], as pack_send_avg), 2 face traces ([4 (k+1)], as pack_send_traces; the send
  * list is that of set_send_faces).  n_segments <= 16. */
 int dflo_hip_pack_send_to(dflo_hip_handle h, int kind, int n_segments, const int32_t *first, void *const *dst);
-/* device address of {dt, res_norm_sq} scalars for 8-byte all-reduces (src_mpi/claw.cc:579,777) */
+/* device address of the {dt, elapsed time, raw CFL minimum} and {res_norm_sq per stage} scalars (src_mpi/claw.cc:579,777) */
 int dflo_hip_scalar_ptrs(dflo_hip_handle h, void **dt_ptr, void **res_ptr);
-/* dt_ptr[2] holds the raw CFL minimum of this device; after an external all-reduce(min) of that
- * double, re-apply the time_step cap and final_time clip (src/claw.cc:468-476) into dt_ptr[0]. */
-int dflo_hip_apply_dt_rules(dflo_hip_handle h);
-/* Several engines in one process (dflo_hip_multi_create): with publishing on, the last stage of a step also leaves the
- * raw CFL minimum in one of two device slots (alternating from step to step, so that a slow peer never reads a value
- * of the wrong step); apply_dt_rules_peers takes the minimum over this engine's dt_ptr[2] and the n_peers slots of the
- * other engines (read over xGMI peer access) and applies the rules -- Utilities::MPI::min of src_mpi/claw.cc:579
- * without a host hop. */
-int dflo_hip_dt_publish(dflo_hip_handle h, int enable, void **slot0, void **slot1);
-int dflo_hip_apply_dt_rules_peers(dflo_hip_handle h, int n_peers, const void *const *peer_slots);
+/* The time step of a run over several engines (Utilities::MPI::min(global_dt), src_mpi/claw.cc:579) without a host hop and
+ * without a kernel of its own.  Every engine keeps a device table mins[2][16] of raw CFL minima: row p holds, slot by slot,
+ * the minima of all parts for the step of parity p (steps counted since set_solution).  The reductions that end a step write
+ * this engine's minimum into slot my_slot of the next step's row -- of its own table and of the peer_tables handed over here
+ * (engines of the same process: plain stores over xGMI peer access; entry my_slot and null entries are skipped) -- and every
+ * consumer of the time step (stage kernels, boundary programs, the clock) takes the minimum over the n_slots of its row and
+ * applies the rules of src/claw.cc:468-476 itself.  The caller orders the streams: the next step's first kernel after the
+ * peers' reductions.  One process per GPU: n_slots = 1 and an all-reduce(min) in place on dflo_hip_dt_slot (the slot the
+ * next step to run reads) between the two.  n_slots = 0 (the default): one engine, the reductions apply the rules. */
+int dflo_hip_dt_table(dflo_hip_handle h, void **table);
+int dflo_hip_dt_exchange(dflo_hip_handle h, int my_slot, int n_slots, void *const *peer_tables);
+int dflo_hip_dt_slot(dflo_hip_handle h, void **slot);
 
 /* ------------------------------------------------ several devices behind one handle */
 /* The native multi-device driver (dflo_amd/csrc/multi.hip): partitions the undivided mesh, owns one engine per part and
