@@ -196,15 +196,18 @@ def run_parts(args, claw, mesh, ic, bc_fn, programs, nx, ny):
     _settle_clocks()
     claw.advance(args.warmup)
     claw.stage_timing(os.environ.get("DFLO_BENCH_NO_STAGE_TIMING") != "1")
+    claw.exchange_timing(True)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     claw.advance(args.steps)
     torch.cuda.synchronize()
     sec = time.perf_counter() - t0
     kernel_ms, n_launch = claw.stage_timing(False)
+    xus, xn = claw.exchange_timing(False)
     a = claw.cell_average
     pr = 0.4 * (a[:, 3] - 0.5 * (a[:, 0] ** 2 + a[:, 1] ** 2) / a[:, 2])
     return {"sec": sec, "kernel_ms": kernel_ms, "n_launch": n_launch, "n_dofs_total": mesh.n_cells * mesh.ndof,
+            "comm": claw.comm_info(), "exchange_us": xus, "exchange_n": xn,
             "n_dofs_launch": mesh.n_cells * mesh.ndof // args.parts_per_gpu, "mass0": mass0, "mass1": a.sum(axis=0), "nx": nx, "ny": ny,
             "n_cells": mesh.n_cells, "n_rk": claw.n_rk, "min_rho": float(a[:, 2].min()), "min_p": float(pr.min())}
 
@@ -263,6 +266,7 @@ def run_case(args, world, rank, local_rank, uid, barrier):
     _settle_clocks()
     claw.advance(args.warmup)
     claw.stage_timing(True)
+    claw.exchange_timing(True)
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -271,9 +275,10 @@ def run_case(args, world, rank, local_rank, uid, barrier):
     torch.cuda.synchronize()
     sec = time.perf_counter() - t0
     kernel_ms, n_launch = claw.stage_timing(False)
+    xus, xn = claw.exchange_timing(False)
     a = claw.cell_average[own]
     pos_stats = claw.positivity_stats()
-    res = {"pos_stats": pos_stats, "sec": sec, "kernel_ms": kernel_ms, "n_launch": n_launch, "n_dofs_total": mesh.n_cells * mesh.ndof,
+    res = {"comm": claw.comm_info(), "exchange_us": xus, "exchange_n": xn, "pos_stats": pos_stats, "sec": sec, "kernel_ms": kernel_ms, "n_launch": n_launch, "n_dofs_total": mesh.n_cells * mesh.ndof,
            "n_dofs_launch": claw.n_owned_dofs, "mass0": mass0, "mass1": a.sum(axis=0), "nx": nx, "ny": ny,
            "n_cells": mesh.n_cells, "n_rk": claw.n_rk}
     pr = 0.4 * (a[:, 3] - 0.5 * (a[:, 0] ** 2 + a[:, 1] ** 2) / a[:, 2])
@@ -358,8 +363,12 @@ def main():
     m = run_case(args, world, rank, local_rank, uid, barrier)
     sec = m["sec"]
     mm = np.concatenate([m["mass0"], m["mass1"], [-m["min_rho"], -m["min_p"]]])
+    per_rank = [{"rank": rank, "comm": m["comm"], "exchange_us": m["exchange_us"], "exchange_n": m["exchange_n"], "sec": m["sec"]}]
     if world > 1:
         import torch.distributed as dist
+        box = [None] * world
+        dist.all_gather_object(box, per_rank[0])
+        per_rank = box
         tt = torch.tensor([sec], dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         sec = float(tt.item())
@@ -422,6 +431,12 @@ def main():
                                % ("RCB blocks" if args.config == "c5" else "x-slabs", world,
                                   "HOST-STAGED gloo transport (developer switch, not a measurement)" if uid == "gloo"
                                   else getattr(args, "transport_note", "RCCL send/recv of face traces + 8-byte all-reduce(min) per step")),
+                # what the transport itself says (N > 1: proof that RCCL saw N ranks -- ncclCommCount / ncclCommUserRank of the native
+                # driver's own communicator, per rank -- and how long a rank's comm stream sat in a halo exchange, every fifth sampled)
+                "transport": per_rank[0]["comm"][2],
+                "comm_ranks_seen": [r["comm"][0] for r in per_rank], "comm_rank_seen": [r["comm"][1] for r in per_rank],
+                "exchange_wait_us": [round(r["exchange_us"], 1) for r in per_rank], "exchange_samples": [r["exchange_n"] for r in per_rank],
+                "sec_per_rank": [round(r["sec"], 4) for r in per_rank],
                 "check": check, "preheat_s": 0.0 if os.environ.get("DFLO_BENCH_NO_PREHEAT") == "1" else float(os.environ.get("DFLO_BENCH_PREHEAT_S", 0.4)),
                 "preheat": "neutral fp64 streaming work before the W warm-up steps (torch.addcmul over 512 MB; none of the engine's kernels or data)",
             },
@@ -430,6 +445,9 @@ def main():
                 "traffic": traffic, "traffic_source": traffic_src,
                 "kernel": "stage_kernel<%d,%s,geo%d>" % (args.degree + 1, args.flux, int(args.config == "c5")),
                 "kernel_ms": kernel_ms, "launches": m["n_launch"], "algorithmic_bytes_per_dof_update": bytes_per_update,
+                # the whole step priced the same way (everything between two steps: all stage kernels, limiter passes, reductions,
+                # boundary programs, gaps): value x 24 B / 8 TB/s
+                "step_frac": value * 1e6 * bytes_per_update / (8.0e12 * world),
             },
         }
         if world == 1 and args.config == "c2" and not args.no_secondary and (args.degree, args.flux) != (1, "lxf"):

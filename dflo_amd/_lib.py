@@ -79,7 +79,7 @@ SYMBOLS = [
     "dflo_hip_multi_n_boundary_faces", "dflo_hip_multi_boundary_faces", "dflo_hip_multi_set_boundary_values",
     "dflo_hip_multi_set_boundary_program", "dflo_hip_multi_residual", "dflo_hip_multi_compute_dt", "dflo_hip_multi_step",
     "dflo_hip_multi_advance", "dflo_hip_multi_apply_limiter", "dflo_hip_multi_apply_positivity_limiter",
-    "dflo_hip_multi_check", "dflo_hip_multi_synchronize", "dflo_hip_multi_stage_timing",
+    "dflo_hip_multi_check", "dflo_hip_multi_synchronize", "dflo_hip_multi_stage_timing", "dflo_hip_multi_exchange_timing", "dflo_hip_multi_comm_info",
     "dflo_hip_multi_part_mesh", "dflo_hip_multi_set_part_solution", "dflo_hip_pack_send_cells", "dflo_hip_unpack_ghost_cells",
     "dflo_hip_halo_traces", "dflo_hip_n_ghost_traces", "dflo_hip_set_send_faces", "dflo_hip_pack_send_traces", "dflo_hip_pack_send_to", "dflo_hip_ghost_avg_source",
     "dflo_hip_ghost_trace_buffer", "dflo_hip_use_ghost_traces",
@@ -212,6 +212,8 @@ _sig("dflo_hip_multi_apply_positivity_limiter", C.c_int, _H)
 _sig("dflo_hip_multi_check", C.c_int, _H)
 _sig("dflo_hip_multi_synchronize", C.c_int, _H)
 _sig("dflo_hip_multi_stage_timing", C.c_int, _H, C.c_int, _dp, C.POINTER(C.c_int64))
+_sig("dflo_hip_multi_exchange_timing", C.c_int, _H, C.c_int, _dp, C.POINTER(C.c_int64))
+_sig("dflo_hip_multi_comm_info", C.c_int, _H, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_char_p, C.c_int32)
 _sig("dflo_mesh_make_periodic", C.c_int, _MP, C.c_int32, C.c_int32, C.c_int32)
 _sig("dflo_mesh_free", None, _MP)
 _sig("dflo_mesh_last_error", C.c_char_p)

@@ -145,6 +145,27 @@ __device__ __forceinline__ double trace_from_line(const double (&val)[N]) {
   for (int m = 0; m < N; ++m) v += CB<N>::t.L0[m] * val[m];
   return v;
 }
+// Value at Gauss-Lobatto point g of a line of N nodal values (ascending along the line) -- what the positivity limiter samples
+// (src/positivity.cc:43-47, 72-78).  The two end points ARE face quadrature points, and the limiter pins the pressure there to
+// 1e-13: they are summed exactly as the stage kernels sum a trace (trace_from_line: from the face inwards, weights l_m(0)), so
+// that the value the limiter has made admissible is, bit for bit, the value the next flux evaluation takes the square root of.
+// (The reference is consistent with itself in the same way -- one set of shape values serves both; with two orders of summation
+// the flux saw p = 1e-13 - O(1e-13) at degree 5 and went NaN where the reference does not: fuzz case 2312 of seed 4243.)
+template <int N>
+__device__ __forceinline__ double gll_point(const KBasis &kb, int g, const double (&val)[N]) {
+  double v = 0.0;
+  if (g == kb.Ng - 1) {
+#pragma unroll
+    for (int m = 0; m < N; ++m) v += CB<N>::t.L0[m] * val[N - 1 - m];
+  } else if (g == 0) {
+#pragma unroll
+    for (int m = 0; m < N; ++m) v += CB<N>::t.L0[m] * val[m];
+  } else {
+#pragma unroll
+    for (int m = 0; m < N; ++m) v += kb.Pg[g][m] * val[m];
+  }
+  return v;
+}
 // component c of the trace of cell `slot` on its local face f at face point q (Qk, shard layout U)
 template <int N>
 __device__ __forceinline__ double cell_face_trace(const double *U, int slot, int f, int c, int q) {

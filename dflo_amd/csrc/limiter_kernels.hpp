@@ -246,13 +246,13 @@ __device__ __forceinline__ void limiter_shard(const LimArgs &a, const int shard,
 #pragma unroll
       for (int l = 0; l < N; ++l)
         for (int g = 0; g < a.kb.Ng; ++g) {
-          double vx = 0, vy = 0;
+          double lx[N], ly[N];
 #pragma unroll
           for (int m = 0; m < N; ++m) {
-            vx += kb.Pg[g][m] * U[RHO * NS + m + N * l];
-            vy += kb.Pg[g][m] * U[RHO * NS + l + N * m];
+            lx[m] = U[RHO * NS + m + N * l];
+            ly[m] = U[RHO * NS + l + N * m];
           }
-          rho_min = smin(smin(rho_min, vx), vy);
+          rho_min = smin(smin(rho_min, gll_point<N>(kb, g, lx)), gll_point<N>(kb, g, ly));
         }
       const double rat = fabs(A[RHO] - eps) * frcp(fabs(A[RHO] - rho_min) + 1.0e-13);
       const double theta1 = smin(rat, 1.0);
@@ -271,10 +271,10 @@ __device__ __forceinline__ void limiter_shard(const LimArgs &a, const int shard,
             double W[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-              double v = 0;
+              double ln[N];
 #pragma unroll
-              for (int m = 0; m < N; ++m) v += kb.Pg[g][m] * (dir == 0 ? U[c * NS + m + N * l] : U[c * NS + l + N * m]);
-              W[c] = v;
+              for (int m = 0; m < N; ++m) ln[m] = dir == 0 ? U[c * NS + m + N * l] : U[c * NS + l + N * m];
+              W[c] = gll_point<N>(kb, g, ln);
             }
             theta2 = smin(theta2, positivity_theta2(W, A, eps, fail));
           }

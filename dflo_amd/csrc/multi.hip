@@ -69,6 +69,8 @@ struct Rccl {
   ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   const char *(*GetErrorString)(ncclResult_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;      // optional (reporting only)
+  ncclResult_t (*CommUserRank)(const ncclComm_t, int *) = nullptr;   // optional
 };
 Rccl g_rccl;
 
@@ -111,6 +113,8 @@ bool load_rccl(std::string &err) {
   DFLO_SYM(GetErrorString, "ncclGetErrorString");
 #undef DFLO_SYM
   *(void **)(&g_rccl.CommAbort) = dlsym(lib, "ncclCommAbort");
+  *(void **)(&g_rccl.CommCount) = dlsym(lib, "ncclCommCount");
+  *(void **)(&g_rccl.CommUserRank) = dlsym(lib, "ncclCommUserRank");
   g_rccl.lib = lib;
   return true;
 }
@@ -159,6 +163,12 @@ struct Part {
   void *dt_ptr = nullptr, *res_ptr = nullptr;
   int steps_run = 0;             // threaded advance: steps this part's thread issued
   std::vector<int32_t> bface_global;   // global boundary-face number of the engine's boundary faces
+  // exchange timing (dflo_hip_multi_exchange_timing): event pairs on the comm stream around every fifth exchange -- rank mode: the
+  // grouped send / receive (rendezvous with the peers included); one process: the wait for the peers' records
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> x_pool;
+  size_t x_used = 0;
+  int64_t x_seen = 0;
+  bool x_on = false, x_open = false;
 };
 
 // A group = one compute stream, one comm stream and one host thread.  A part with a device of its own is a group of its own;
@@ -363,6 +373,24 @@ ChanView chan(dflo_hip_multi *m, Part &p, int kind, int par) {
   return {p.send_off, p.recv_off, m->ndof + 4, p.recv_u[par]};
 }
 
+void xt_begin(Part &p) {
+  p.x_open = p.x_on && (p.x_seen++ % 5 == 0) && p.x_used < 4096;
+  if (!p.x_open) return;
+  if (p.x_used == p.x_pool.size()) {
+    hipEvent_t a, b;
+    hipEventCreate(&a);
+    hipEventCreate(&b);
+    p.x_pool.push_back({a, b});
+  }
+  hipEventRecord(p.x_pool[p.x_used].first, p.C);
+}
+void xt_end(Part &p) {
+  if (!p.x_open) return;
+  hipEventRecord(p.x_pool[p.x_used].second, p.C);
+  ++p.x_used;
+  p.x_open = false;
+}
+
 // pack the records of this kind and send them off (the engine's launches go to the comm stream, set by the caller)
 int post(dflo_hip_multi *m, Part &p, int kind, int par) {
   if (p.peers.empty()) return DFLO_OK;
@@ -387,7 +415,10 @@ int post(dflo_hip_multi *m, Part &p, int kind, int par) {
       rp.push_back(v.recv + (size_t)v.ro[q] * w);
       rb.push_back((size_t)(v.ro[q + 1] - v.ro[q]) * w * sizeof(double));
     }
-    if (m->x_exchange(m->x_user, (int)peers.size(), peers.data(), sp.data(), sb.data(), rp.data(), rb.data(), (void *)p.C)) {
+    xt_begin(p);
+    const int xrc = m->x_exchange(m->x_user, (int)peers.size(), peers.data(), sp.data(), sb.data(), rp.data(), rb.data(), (void *)p.C);
+    xt_end(p);
+    if (xrc) {
       set_err(m, "the host program's exchange callback failed");
       return DFLO_ERR_COMM;
     }
@@ -396,6 +427,7 @@ int post(dflo_hip_multi *m, Part &p, int kind, int par) {
   if (m->rank_mode) {
     // (the receives are posted by the receiver itself, on its comm stream behind everything of its own that read the
     //  receive area: no peer can overwrite what is still in use)
+    xt_begin(p);
     MNCCL(m, g_rccl.GroupStart());
     for (int q : p.peers) {
       const size_t ns = (size_t)(v.so[q + 1] - v.so[q]) * w, nr = (size_t)(v.ro[q + 1] - v.ro[q]) * w;
@@ -403,6 +435,7 @@ int post(dflo_hip_multi *m, Part &p, int kind, int par) {
       if (nr) MNCCL(m, g_rccl.Recv(v.recv + (size_t)v.ro[q] * w, nr, ncclDouble, q, m->comm, p.C));
     }
     MNCCL(m, g_rccl.GroupEnd());
+    xt_end(p);
     return DFLO_OK;
   }
   // One process: this part writes into its peers' receive areas -- the pack kernel itself does (stores over xGMI peer access
@@ -455,6 +488,7 @@ int arrive(dflo_hip_multi *m, Part &p, int kind, int par) {
   if (m->rank_mode) return DFLO_OK;   // the receives were part of the group posted on this stream
   if (p.peers.empty()) return DFLO_OK;
   const int64_t seq = ++p.n_arr[kind];
+  xt_begin(p);
   for (int q : p.peers) {
     Part *src = local_part(m, q);
     const ChanView sv = chan(m, *src, kind, 0);
@@ -464,6 +498,7 @@ int arrive(dflo_hip_multi *m, Part &p, int kind, int par) {
     if (src->C == p.C) continue;   // the sender's launches are ahead of this point on the very same stream
     MHIP(m, hipStreamWaitEvent(p.C, src->ev_sent[kind][par], 0));
   }
+  xt_end(p);
   return DFLO_OK;
 }
 
@@ -1050,6 +1085,7 @@ int dflo_hip_multi_destroy(dflo_hip_multi_handle m) {
         if (p.ev_used[k][i]) hipEventDestroy(p.ev_used[k][i]);
       }
     if (p.sub) dflo_mesh_free(p.sub);
+    for (auto &e : p.x_pool) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
   }
   for (Group &g : m->groups) {
     hipSetDevice(g.device);
@@ -1559,6 +1595,50 @@ int dflo_hip_multi_stage_timing(dflo_hip_multi_handle m, int enable, double *avg
   }
   if (avg_ms) *avg_ms = worst;
   if (n) *n = cnt;
+  return DFLO_OK;
+}
+
+int dflo_hip_multi_exchange_timing(dflo_hip_multi_handle m, int enable, double *avg_us, int64_t *n) {
+  if (!m) return DFLO_ERR_BAD_PARAM;
+  int rc = sync_all(m);
+  if (rc) return rc;
+  double tot = 0.0;
+  int64_t cnt = 0;
+  for (Part &p : m->parts) {
+    MHIP(m, hipSetDevice(p.device));
+    for (size_t i = 0; i < p.x_used; ++i) {
+      float ms = 0;
+      if (hipEventElapsedTime(&ms, p.x_pool[i].first, p.x_pool[i].second) == hipSuccess) { tot += ms; ++cnt; }
+    }
+    p.x_used = 0;
+    p.x_seen = 0;
+    p.x_on = enable != 0;
+  }
+  if (avg_us) *avg_us = cnt ? tot * 1000.0 / (double)cnt : 0.0;
+  if (n) *n = cnt;
+  return DFLO_OK;
+}
+
+int dflo_hip_multi_comm_info(dflo_hip_multi_handle m, int32_t *comm_count, int32_t *comm_rank, char *transport, int32_t transport_len) {
+  if (!m) return DFLO_ERR_BAD_PARAM;
+  int cnt = m->n_parts, rk = m->rank_mode ? m->rank : -1;
+  std::string t;
+  if (m->rank_mode && m->x_exchange) t = "callbacks of the host program (dflo_hip_multi_create_rank_custom)";
+  else if (m->rank_mode && m->comm) {
+    t = "RCCL: grouped ncclSend/ncclRecv + ncclAllReduce(min) on the driver's own communicator";
+    cnt = rk = -1;   // as the communicator itself reports them, or -1
+    if (g_rccl.CommCount) g_rccl.CommCount(m->comm, &cnt);
+    if (g_rccl.CommUserRank) g_rccl.CommUserRank(m->comm, &rk);
+  } else if (m->rank_mode) t = "none (one rank)";
+  else if (m->loopback) t = "one process: one-rank RCCL loopback (test transport)";
+  else if (m->n_parts == 1) t = "none (one part)";
+  else t = m->direct ? "one process: pack kernels storing into the peers' receive areas (xGMI peer access)" : "one process: staging buffer + hipMemcpyPeerAsync";
+  if (comm_count) *comm_count = cnt;
+  if (comm_rank) *comm_rank = rk;
+  if (transport && transport_len > 0) {
+    std::strncpy(transport, t.c_str(), (size_t)transport_len - 1);
+    transport[transport_len - 1] = 0;
+  }
   return DFLO_OK;
 }
 

@@ -827,10 +827,10 @@ __global__ __launch_bounds__(64 * N, N >= 5 ? 1 : ((N == 4 && GEO == 0 && MODE =
           double W[4];
 #pragma unroll
           for (int c = 0; c < 4; ++c) {
-            double v = 0;
+            double ln[N];
 #pragma unroll
-            for (int m = 0; m < N; ++m) v += a.kb.Pg[g][m] * (dir == 0 ? unew[c][m] : Us[(c * NS2 + row + N * m) * S + lane]);
-            W[c] = v;
+            for (int m = 0; m < N; ++m) ln[m] = dir == 0 ? unew[c][m] : Us[(c * NS2 + row + N * m) * S + lane];
+            W[c] = gll_point<N>(a.kb, g, ln);
           }
           th = smin(th, positivity_theta2(W, A, eps, fail));
         }
@@ -841,13 +841,13 @@ __global__ __launch_bounds__(64 * N, N >= 5 ? 1 : ((N == 4 && GEO == 0 && MODE =
     {
       double rmin = 1.0e20;
       for (int g = 0; g < a.kb.Ng; ++g) {
-        double px = 0, py = 0;
+        double lx[N], ly[N];
 #pragma unroll
         for (int m = 0; m < N; ++m) {
-          px += a.kb.Pg[g][m] * unew[RHO][m];
-          py += a.kb.Pg[g][m] * Us[(RHO * NS2 + row + N * m) * S + lane];
+          lx[m] = unew[RHO][m];
+          ly[m] = Us[(RHO * NS2 + row + N * m) * S + lane];
         }
-        rmin = smin(smin(rmin, px), py);
+        rmin = smin(smin(rmin, gll_point<N>(a.kb, g, lx)), gll_point<N>(a.kb, g, ly));
       }
       pm[row * 64 + lane] = rmin;
       pm[(N + row) * 64 + lane] = pressure_theta(fail);

@@ -200,3 +200,16 @@ class MultiConservationLaw:
         ms, n = C.c_double(), C.c_int64()
         self._chk(lib.dflo_hip_multi_stage_timing(self._h, int(enable), C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+    def exchange_timing(self, enable=True):
+        """(average microseconds the comm stream spent per sampled halo exchange, number of samples) since the last call."""
+        us, n = C.c_double(), C.c_int64()
+        self._chk(lib.dflo_hip_multi_exchange_timing(self._h, int(enable), C.byref(us), C.byref(n)))
+        return us.value, n.value
+
+    def comm_info(self):
+        """(ranks, own rank) as the transport itself reports them -- ncclCommCount / ncclCommUserRank for RCCL -- and a description."""
+        cnt, rk = C.c_int32(), C.c_int32()
+        buf = C.create_string_buffer(256)
+        self._chk(lib.dflo_hip_multi_comm_info(self._h, C.byref(cnt), C.byref(rk), buf, 256))
+        return cnt.value, rk.value, buf.value.decode()

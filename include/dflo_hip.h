@@ -390,6 +390,13 @@ int dflo_hip_multi_apply_positivity_limiter(dflo_hip_multi_handle m);
 int dflo_hip_multi_check(dflo_hip_multi_handle m);
 int dflo_hip_multi_synchronize(dflo_hip_multi_handle m);
 int dflo_hip_multi_stage_timing(dflo_hip_multi_handle m, int enable, double *avg_ms, int64_t *n); /* slowest local part */
+/* Reporting (bench.py's N > 1 line): the average time, in microseconds, that the comm stream of the local parts spent in an
+ * exchange of halo records (every fifth exchange is bracketed by events: one process per GPU -- the grouped send / receive,
+ * the rendezvous with the peers included; one process -- the wait for the peers' records), and what the transport is: the
+ * number of ranks and this process's rank AS THE RCCL COMMUNICATOR REPORTS THEM (ncclCommCount / ncclCommUserRank; the
+ * partition's numbers for the other transports, rank -1 in one process) and a description of the transport in use. */
+int dflo_hip_multi_exchange_timing(dflo_hip_multi_handle m, int enable, double *avg_us, int64_t *n);
+int dflo_hip_multi_comm_info(dflo_hip_multi_handle m, int32_t *comm_count, int32_t *comm_rank, char *transport, int32_t transport_len);
 
 /* Test hook: evaluates the device reciprocal / square-root forms the flux functions use
  * (dflo_amd/csrc/physics.hpp) on n host doubles. */

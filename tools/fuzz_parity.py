@@ -1,7 +1,23 @@
 """Randomised differential test, device against oracle: random small meshes (squares / skewed bilinear cells / unstructured
 quadrilaterals), degrees, fluxes, boundary kinds, limiter settings, time-step modes; a few steps each.
-usage: python tools/fuzz_parity.py [n_cases] [seed] [max_degree = 3]     (GPU box; prints the failing configurations)"""
-import os, sys, time, traceback
+usage: python tools/fuzz_parity.py [n_cases] [seed] [max_degree = 3]     (GPU box; prints the failing configurations)
+
+Every disagreement beyond a bar is either a FAILURE or carries measured evidence that the case is ill-conditioned for the
+reference algorithm itself: the oracle is run four more times on the same case with the initial state perturbed by 1e-15
+(relative, random signs -- one rounding error), and the case is classified only if that perturbation alone moves the oracle's own
+result by a comparable amount (or flips its own NaN / "Negative states" / "positivity" outcome).  Classes, printed per degree:
+  nan      the reference's own arithmetic produced NaNs (sqrt of a negative trace pressure on rough data); the device's NaN cells
+           must lie within the oracle's and the finite cells must agree -- checked, else failure
+  stop     oracle and device both stop with the reference's guards (src/positivity.cc:26-38, 160-169) within one step of each other
+  knife    a bar was exceeded / one side stopped or went NaN and the other did not, AND the oracle's own 1e-15 perturbation does
+           the same (numbers printed with FUZZ_VERBOSE=1)
+  refused  the engine refuses the combination at create (unsupported / bad parameter): nothing to compare
+The run fails if anything else disagrees, or if the "knife" rate exceeds 1e-3 at degrees <= 3 (2e-2 at degrees 4, 5).
+Bars: residual 1e-11, time step 1e-11 (1e-9 on kinked data), state 1e-10 (1e-8 with limiters or kinked data); at degrees 4 and 5
+scaled by the growth of the derivative matrix, max|D_k| (k+1) / (max|D_3| 4) = 1.9 and 3.1 (the round-off of the two orders of
+summation grows with the entries of D), not by fixed factors.
+FUZZ_ONLY=<case> prints the stage-by-stage history of one case."""
+import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -15,16 +31,55 @@ seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 max_degree = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 rng = np.random.default_rng(seed)
 KINDS = ["inflow", "outflow", "slip", "pressure", "farfield"]
+VERBOSE = os.environ.get("FUZZ_VERBOSE") == "1"
+N_PERT = int(os.environ.get("FUZZ_NPERT", "4"))   # perturbed oracle runs behind every classification (a knife edge need not flip under ONE random perturbation)
+GUARDS = (-3, -4)   # negative mean state / positivity root failure: the reference's own stops
 
 
 def rel(a, b):
     return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
 
 
-last = {}
+def max_d(k):
+    """largest entry of the 1-D derivative matrix D[q][a] = l_a'(x_q) at the k + 1 Gauss points of [0, 1]"""
+    n = k + 1
+    if n == 1:
+        return 1.0
+    x, _ = oracle_lib.gauss(n)
+    D = np.zeros((n, n))
+    for a in range(n):
+        for q in range(n):
+            s = 0.0
+            for j in range(n):
+                if j == a:
+                    continue
+                t = 1.0 / (x[a] - x[j])
+                for m in range(n):
+                    if m != a and m != j:
+                        t *= (x[q] - x[m]) / (x[a] - x[m])
+                s += t
+            D[q, a] = s
+    return np.abs(D).max()
 
 
-def one(i):
+_COND3 = max_d(3) * 4.0
+
+
+def loose_of(degree):
+    return max(1.0, max_d(degree) * (degree + 1) / _COND3) if degree > 3 else 1.0
+
+
+class Fail(Exception):
+    pass
+
+
+class Classified(Exception):
+    def __init__(self, cls, why):
+        self.cls = cls
+        super().__init__(why)
+
+
+def make_case(i):
     degree = int(rng.integers(0, max_degree + 1))
     flux = str(rng.choice(["lxf", "sw", "kfvs", "roe", "hllc"]))
     geo = str(rng.choice(["cart", "cart", "skew", "unstr"]))
@@ -36,9 +91,7 @@ def one(i):
     M = float(rng.choice([0.0, 1.0, 50.0]))
     char_lim = bool(rng.random() < 0.6)
     periodic = geo == "cart" and rng.random() < 0.4
-    last.clear()
-    desc = last
-    desc.update(i=i, degree=degree, flux=flux, geo=geo, basis=basis, tvb=tvb, pos=pos, local=local, gravity=gravity, M=M,
+    desc = dict(i=i, degree=degree, flux=flux, geo=geo, basis=basis, tvb=tvb, pos=pos, local=local, gravity=gravity, M=M,
                 char_lim=char_lim, periodic=periodic)
     if geo == "cart":
         nx, ny = int(rng.integers(1, 23)), int(rng.integers(1, 19))
@@ -66,16 +119,7 @@ def one(i):
     desc.update(indicator=indicator)
     prm = dflo_amd.Parameters(flux=flux, limiter="TVB" if tvb else "none", char_lim=char_lim, pos_lim=pos, M=M, beta=float(rng.choice([1.0, 1.5, 2.0])),
                               boundary=bnd, cfl=0.5, gravity=gravity, time_step_type="local" if local else "global", shock_indicator=indicator)
-    desc.update(bnd=bnd)
     ic = lambda x, y: problems.smooth_perturbation(x, y, L=1.0)
-    claw, ora = dflo_amd.ConservationLaw(mesh, prm), oracle_lib.Oracle(mesh, prm)
-    cell, face, bid, xy = claw.boundary_faces()
-    if len(cell):
-        bv = np.stack(ic(xy[..., 0], xy[..., 1]), axis=-1)
-        bv[..., 3] = np.where(np.array([bnd[int(b)] == "pressure" for b in bid])[:, None], 1.0, bv[..., 3])
-        for w in (0, 1):
-            claw.set_boundary_values(w, bv)
-            ora.set_boundary_values(w, bv)
     u0 = mesh.project(ic) if basis == "Pk" else mesh.interpolate(ic)
     if rng.random() < 0.5:   # kinks and rough cells, so that the limiters have work
         u = u0.reshape(mesh.n_cells, 4, -1).copy()
@@ -88,134 +132,302 @@ def one(i):
             u[k2, 2] *= 1.0 + 0.6 * (rng.random((len(k2), u.shape[2])) - 0.5)
         u0 = u.reshape(-1)
         desc.update(kink=amp)
-    claw.set_initial_condition(u0)
+    advance = (not local) and rng.random() < 0.5
+    desc.update(advance=advance)
+    # (drawn for every case: the stream of random numbers does not depend on outcomes)
+    pert = [1.0 + 1.0e-15 * rng.choice([-1.0, 1.0], size=u0.shape)]
+    prng = np.random.default_rng([seed, i])   # (the others from a generator of their own: N_PERT does not move the cases)
+    pert += [1.0 + 1.0e-15 * prng.choice([-1.0, 1.0], size=u0.shape) for _ in range(N_PERT - 1)]
+    return dict(desc=desc, mesh=mesh, prm=prm, bnd=bnd, ic=ic, u0=u0, local=local, advance=advance, pert=pert)
+
+
+def boundary_values(case, obj):
+    cell, face, bid, xy = obj.boundary_faces()
+    if not len(cell):
+        return None
+    bv = np.stack(case["ic"](xy[..., 0], xy[..., 1]), axis=-1)
+    bv[..., 3] = np.where(np.array([case["bnd"][int(b)] == "pressure" for b in bid])[:, None], 1.0, bv[..., 3])
+    return bv
+
+
+def new_oracle(case, u0):
+    ora = oracle_lib.Oracle(case["mesh"], case["prm"])
+    bv = boundary_values(case, ora)
+    if bv is not None:
+        for w in (0, 1):
+            ora.set_boundary_values(w, bv)
     ora.set_solution(u0)
+    return ora
+
+
+def oracle_step(ora, case, t):
+    """one step of run(): (dt, stop code or 0)"""
+    dt = ora.compute_time_step(t)
+    try:
+        ora.step(-1.0 if case["local"] else dt)   # local time stepping: keep the per-cell steps compute_time_step has left
+    except oracle_lib.OracleError as e:
+        if e.code in GUARDS:
+            return dt, e.code
+        raise
+    return dt, 0
+
+
+def oracle_run(case, u0, n_steps):
+    """the oracle alone: (states after every step, time steps, (step, code) of a guard stop or None)"""
+    ora = new_oracle(case, u0)
+    states, dts, t = [], [], 0.0
+    for it in range(n_steps):
+        if not np.isfinite(ora.get_solution()).all():
+            break
+        dt, code = oracle_step(ora, case, t)
+        dts.append(dt)
+        if code:
+            return states, dts, (it, code)
+        t += dt
+        states.append(ora.get_solution().copy())
+    return states, dts, None
+
+
+def sensitivity(case, n_steps):
+    """What one rounding error in the initial state does to the ORACLE's own result over the same steps: returns
+    (relative difference of the final states -- inf if the NaN patterns or the number of completed steps differ --, relative
+    difference of the last time step, stop of the plain run, stop of the perturbed run)."""
+    s0, d0, stop0 = oracle_run(case, case["u0"], n_steps)
+    worst = (0.0, 0.0, stop0, stop0)
+    for pert in case["pert"]:   # the largest effect of N_PERT independent perturbations
+        s1, d1, stop1 = oracle_run(case, case["u0"] * pert, n_steps)
+        n = min(len(s0), len(s1))
+        if len(s0) != len(s1) or n == 0 or stop1 != stop0:
+            return np.inf, np.inf, stop0, stop1
+        a, b = s0[n - 1], s1[n - 1]
+        fa, fb = np.isfinite(a), np.isfinite(b)
+        if (fa != fb).any():
+            return np.inf, np.inf, stop0, stop1
+        e = np.abs(a[fa] - b[fa]).max() / max(np.abs(a[fa]).max(), 1e-300) if fa.any() else 0.0
+        m = min(len(d0), len(d1))
+        ed = abs(d0[m - 1] - d1[m - 1]) / abs(d0[m - 1]) if m else 0.0
+        if max(e, ed) >= max(worst[0], worst[1]):
+            worst = (e, ed, stop0, stop1)
+    return worst
+
+
+def knife_or_fail(case, n_steps, what, observed):
+    """a bar was exceeded: classified only with the oracle's own sensitivity as evidence"""
+    e, ed, stop0, stop1 = sensitivity(case, n_steps)
+    amplified = e if what != "dt" else max(e, ed)
+    if VERBOSE:
+        print("   case %d: %s observed %.3e; oracle vs oracle(1e-15 perturbation): state %.3e, dt %.3e, stops %s / %s" % (
+            case["desc"]["i"], what, observed, e, ed, stop0, stop1))
+    # the perturbation is ONE rounding error; device and oracle differ by hundreds of them per step: within 1e3 of the observed
+    # difference the oracle's own sensitivity explains it
+    if amplified * 1.0e3 >= observed or stop0 != stop1:
+        raise Classified("knife", "%s %.2e, the oracle's own 1e-15 perturbation gives %.2e" % (what, observed, amplified))
+    raise Fail((what, observed, "oracle's own 1e-15 perturbation gives only %.2e" % amplified))
+
+
+ONLY_CASES = set(int(k) for k in os.environ.get("FUZZ_CASES", "").split(",") if k)   # run these cases only (the others are still drawn)
+
+
+def one(i):
+    case = make_case(i)
+    last.update(case["desc"])
+    if ONLY_CASES and i not in ONLY_CASES:
+        raise Classified("skipped", "not asked for")
+    desc, mesh, prm, local = case["desc"], case["mesh"], case["prm"], case["local"]
+    degree, tvb, pos = desc["degree"], desc["tvb"], desc["pos"]
+    try:
+        claw = dflo_amd.ConservationLaw(mesh, prm)
+    except dflo_amd.DfloError as e:
+        if e.code in (-7, -1):
+            raise Classified("refused", str(e))
+        raise
+    ora = new_oracle(case, case["u0"])
+    bv = boundary_values(case, claw)
+    if bv is not None:
+        for w in (0, 1):
+            claw.set_boundary_values(w, bv)
+    u0 = case["u0"]
+    claw.set_initial_condition(u0)
     if os.environ.get("FUZZ_ONLY") == str(i):    # diagnostics for one case (the generator has to run through the others)
         print("case", desc)
-        for fused in ("1", "0"):
-            os.environ["DFLO_FUSE_POS"] = fused
-            c2, o2 = dflo_amd.ConservationLaw(mesh, prm), oracle_lib.Oracle(mesh, prm)
-            if len(cell):
-                for w in (0, 1):
-                    c2.set_boundary_values(w, bv)
-                    o2.set_boundary_values(w, bv)
-            c2.set_initial_condition(u0)
-            o2.set_solution(u0)
-            tt = 0.0
-            for it in range(3):
-                dt = o2.compute_time_step(tt)
-                dtc = c2.compute_time_step()
-                print("   dt", dt, dtc)
-                o2.set_dt(dt) if not local else None
-                for rk in range(o2.n_rk):
-                    c2.stage(rk, dt)
-                    o2.stage(rk)
-                    a_, b_ = c2.current_solution.reshape(mesh.n_cells, -1), o2.get_solution().reshape(mesh.n_cells, -1)
-                    nd, no = ~np.isfinite(a_).all(axis=1), ~np.isfinite(b_).all(axis=1)
-                    ok = ~(nd | no)
-                    d = np.abs(a_[ok] - b_[ok]).max(axis=1) if ok.any() else np.zeros(1)
-                    print("fused", fused, "step", it, "stage", rk, "nan dev/ora", nd.sum(), no.sum(), np.where(nd)[0][:6], "max diff", d.max(), "at cell", np.where(ok)[0][np.argmax(d)])
-                c2.end_step(); o2.end_step(); tt += dt
-        os.environ.pop("DFLO_FUSE_POS")
+        c2, o2 = dflo_amd.ConservationLaw(mesh, prm), new_oracle(case, u0)
+        if bv is not None:
+            for w in (0, 1):
+                c2.set_boundary_values(w, bv)
+        c2.set_initial_condition(u0)
+        tt = 0.0
+        for it in range(5):
+            dt = o2.compute_time_step(tt)
+            print("   dt", dt, c2.compute_time_step())
+            o2.set_dt(dt) if not local else None
+            for rk in range(o2.n_rk):
+                c2.stage(rk, dt)
+                o2.stage(rk)
+                a_, b_ = c2.current_solution.reshape(mesh.n_cells, -1), o2.get_solution().reshape(mesh.n_cells, -1)
+                nd, no = ~np.isfinite(a_).all(axis=1), ~np.isfinite(b_).all(axis=1)
+                ok = ~(nd | no)
+                d = np.abs(a_[ok] - b_[ok]).max(axis=1) if ok.any() else np.zeros(1)
+                print("step", it, "stage", rk, "nan dev/ora", nd.sum(), no.sum(), "max diff", d.max(), "max |u|", np.abs(b_[ok]).max() if ok.any() else 0)
+            c2.end_step(); o2.end_step(); tt += dt
+        print("   sensitivity (oracle vs oracle with 1e-15 perturbation, 5 steps):", sensitivity(case, 5))
+    loose = loose_of(degree)
     r1, r2 = claw.assemble_system(), ora.assemble()
     if not np.isfinite(r2).all():
-        # rough data whose trace on a face has a negative pressure (the higher the degree, the wilder the extrapolation to the
-        # faces): sw / kfvs / roe take the root of it.  The reference's dense lifting loops spread the NaN over every DoF of both
-        # cells (0 * NaN), the collocated lifting only over the DoFs the face point feeds -- a subset; the finite rest must agree.
+        # rough data whose trace on a face has a negative pressure: sw / kfvs / roe take the root of it.  The reference's dense
+        # lifting loops spread the NaN over every DoF of both cells (0 * NaN), the collocated lifting only over the DoFs the face
+        # point feeds -- a subset; the finite rest must agree.
         c1, c2 = r1.reshape(mesh.n_cells, -1), r2.reshape(mesh.n_cells, -1)
         nd, no = ~np.isfinite(c1).all(axis=1), ~np.isfinite(c2).all(axis=1)
-        assert (nd <= no).all(), ("residual: device NaN cells outside the oracle's", int(nd.sum()), int(no.sum()))
+        if not (nd <= no).all():
+            raise Fail(("residual: device NaN cells outside the oracle's", int(nd.sum()), int(no.sum())))
         ok = ~no
-        if ok.any():
-            assert np.abs(c1[ok] - c2[ok]).max() <= 1e-11 * np.abs(c2[ok]).max(), ("residual (finite cells)", np.abs(c1[ok] - c2[ok]).max())
-        raise oracle_lib.OracleError(0, "NaN state")
-    # (degrees 4 and 5: the entries of the derivative matrix grow with the degree -- max |D| = 11, 17, 23 for k = 3, 4, 5 -- and the
-    #  round-off of the two orders of summation with them; seen: 1.0e-11 / 3e-10 at k = 5 on small distorted cells)
-    loose = {4: 4.0, 5: 10.0}.get(degree, 1.0)   # (every bar below carries it, the "agreed after the first step" of the classifications too)
-    # (a residual that vanishes -- one periodic cell that is its own neighbour -- is compared on the scale of the fluxes)
-    rscale = max(np.abs(r2).max(), 1e-6 * np.abs(u0).max())
-    assert np.abs(r1 - r2).max() < 1e-11 * loose * rscale, ("residual", np.abs(r1 - r2).max() / rscale)
+        if ok.any() and not np.abs(c1[ok] - c2[ok]).max() <= 1e-11 * loose * np.abs(c2[ok]).max():
+            raise Fail(("residual (finite cells)", np.abs(c1[ok] - c2[ok]).max()))
+        raise Classified("nan", "NaN in the reference's residual")
+    # (a residual that all but vanishes -- one cell between walls -- is compared on the scale of its terms, face fluxes ~ |u| times
+    #  an edge length h: their round-off is what is left of them; a thousandth of that as the floor)
+    hcell = 1.0 / max(desc.get("nx", 1), desc.get("ny", 1), desc.get("n", 1))
+    rscale = max(np.abs(r2).max(), 1e-3 * hcell * np.abs(u0).max())
+    er = np.abs(r1 - r2).max() / rscale
+    stats_max(degree, "residual", er)
+    if not er < 1e-11 * loose:
+        raise Fail(("residual", er))
+    n_host = 3
+    n_total = n_host + (2 if case["advance"] else 0)
     t = 0.0
-    e1 = None   # agreement after the first step
-    for it in range(3):
-        if not np.isfinite(ora.get_solution()).all():   # the reference's own arithmetic has broken down: the NaN cells are compared below
+    for it in range(n_host):
+        if not np.isfinite(ora.get_solution()).all():   # the reference's own arithmetic has broken down: compared below
             break
         dt = ora.compute_time_step(t)
         dtc = claw.compute_time_step()
-        if it == 0:
-            dt_first = dt
-        if abs(dtc - dt) > (1e-9 if "kink" in desc else 1e-11) * loose * dt:
-            if e1 is not None and e1 <= 1e-12 * loose and ("kink" in desc or dt < 1e-2 * dt_first):
-                # (rough data, or a run whose time step has collapsed a hundredfold within two steps: it is blowing up)
-                raise oracle_lib.OracleError(3, "round-off amplified by rough data")   # see below
-            if np.abs(ora.get_solution()).max() > 1.0e3 * np.abs(u0).max():
-                # the blow-up class of the end of this function, met at a time step already: the reference state has grown a
-                # thousandfold (an unlimited run on rough data), and the time steps of two such states differ like the states
-                raise oracle_lib.OracleError(2, "blow-up of the reference solution")
-            assert False, ("dt", it, dtc, dt)
-        claw.iterate_explicit(dt)
-        ora.step(-1.0 if local else dt)   # local time stepping: keep the per-cell steps compute_time_step has left
+        edt = abs(dtc - dt) / abs(dt) if np.isfinite(dt) and dt != 0 else (0.0 if dtc == dt else np.inf)
+        if not edt <= (1e-9 if "kink" in desc else 1e-11) * loose:
+            knife_or_fail(case, it + 1, "dt", edt)
+        dcode = ocode = 0
+        try:
+            claw.iterate_explicit(dt)
+        except dflo_amd.DfloError as e:
+            if e.code not in GUARDS:
+                raise
+            dcode = e.code
+        try:
+            ora.step(-1.0 if local else dt)
+        except oracle_lib.OracleError as e:
+            if e.code not in GUARDS:
+                raise
+            ocode = e.code
+        if dcode or ocode:
+            # the reference's guards: both sides have to stop within one step of each other (the state a guard looks at is a
+            # point value at 1e-13, so which of two neighbouring steps trips it is a matter of rounding) -- or the oracle's own
+            # perturbed run must show the same indecision
+            if dcode and ocode:
+                raise Classified("stop", "both stop in step %d (%d / %d)" % (it, dcode, ocode))
+            if dcode:   # the oracle gets one more step
+                if np.isfinite(ora.get_solution()).all():
+                    _, oc2 = oracle_step(ora, case, t + dt)
+                    if oc2:
+                        raise Classified("stop", "device stops in step %d, oracle in step %d" % (it, it + 1))
+                else:
+                    raise Classified("nan", "device stops, the oracle holds NaNs")
+            else:       # the device gets one more step
+                try:
+                    claw.iterate_explicit(claw.compute_time_step())
+                except dflo_amd.DfloError as e:
+                    if e.code in GUARDS:
+                        raise Classified("stop", "oracle stops in step %d, device in step %d" % (it, it + 1))
+                    raise
+            e_, ed_, stop0, stop1 = sensitivity(case, it + 2)
+            if VERBOSE:
+                print("   case %d: one side stops (device %d, oracle %d) in step %d; oracle plain / perturbed stops: %s / %s" % (i, dcode, ocode, it, stop0, stop1))
+            if stop0 != stop1 or (dcode and stop1 is not None and abs(stop1[0] - it) <= 1):
+                raise Classified("knife", "one side stops in step %d; the oracle's own perturbed run stops at %s, the plain one at %s" % (it, stop1, stop0))
+            raise Fail(("only one side stops", dcode, ocode, "step", it))
         t += dt
-        if it == 0 and np.isfinite(ora.get_solution()).all():
-            e1 = rel(claw.current_solution, ora.get_solution())
-    if not local and rng.random() < 0.5:   # two more steps with the time step resident on the device
-        t2 = claw.advance(2)
-        for it in range(2):
-            dt = ora.compute_time_step(t)
-            ora.step(dt)
+    if case["advance"] and np.isfinite(ora.get_solution()).all() and np.isfinite(claw.current_solution).all():
+        try:
+            t2 = claw.advance(2)
+            dstop = 0
+        except dflo_amd.DfloError as e:
+            if e.code not in GUARDS:
+                raise
+            dstop = e.code
+        ostop = 0
+        for it in range(2):   # (NaN states included: the device's resident loop does not stop for them either)
+            dt, ostop = oracle_step(ora, case, t)
+            if ostop:
+                break
             t += dt
-        if np.isfinite(t) and np.isfinite(claw.current_solution).all():   # (a device NaN is classified below)
-            if abs(t2 - t) > 1e-9 * t and e1 is not None and e1 <= 1e-12 * loose and "kink" in desc:
-                raise oracle_lib.OracleError(3, "round-off amplified by rough data")
-            assert abs(t2 - t) <= 1e-9 * loose * t, ("advance time", t2, t)
-        desc.update(advance=True)
+        if dstop or ostop:
+            if dstop and ostop:
+                raise Classified("stop", "both stop inside the resident steps")
+            e_, ed_, stop0, stop1 = sensitivity(case, n_total + 1)
+            if stop0 != stop1:
+                raise Classified("knife", "one side stops in the resident steps; oracle plain / perturbed: %s / %s" % (stop0, stop1))
+            if dstop and np.isfinite(ora.get_solution()).all():
+                _, oc2 = oracle_step(ora, case, t)
+                if oc2:
+                    raise Classified("stop", "device stops in the resident steps, the oracle one step later")
+            raise Fail(("only one side stops in the resident steps", dstop, ostop))
+        if np.isfinite(t) and np.isfinite(claw.current_solution).all():
+            et = abs(t2 - t) / abs(t)
+            if not et <= 1e-9 * loose:
+                knife_or_fail(case, n_total, "dt", et)
     tol = (1e-8 if (tvb or pos or "kink" in desc) else 1e-10) * loose     # (jumps amplify the round-off of the fluxes)
     ud, uo = claw.current_solution, ora.get_solution()
-    if np.isfinite(uo).all() and np.abs(uo).max() > 1.0e3 * np.abs(u0).max():
-        # an unlimited run on rough data that is blowing up (the state has grown a thousandfold in a few steps, the time step has
-        # collapsed): round-off differences grow with it -- 1e-14 after the first step, 1e-9 after the second, O(1) after the third
-        raise oracle_lib.OracleError(2, "blow-up of the reference solution")
     if not np.isfinite(uo).all():      # the reference's own arithmetic has produced NaNs: the device has to have them in the same cells
         nd = ~np.isfinite(ud.reshape(mesh.n_cells, -1)).all(axis=1)
         no = ~np.isfinite(uo.reshape(mesh.n_cells, -1)).all(axis=1)
-        if not (nd <= no).all() and pos and flux in ("sw", "kfvs", "roe") and "kink" in desc:
-            raise oracle_lib.OracleError(1, "device NaN earlier than the reference's (cold point)")   # see below
-        assert (nd <= no).all(), ("device NaN cells outside the oracle's", int(nd.sum()), int(no.sum()))
-        desc.update(nan_cells=(int(nd.sum()), int(no.sum())))
-        raise oracle_lib.OracleError(0, "NaN state")
+        if not (nd <= no).all():
+            knife_or_fail(case, n_total, "device NaN cells outside the oracle's", np.inf)
+        raise Classified("nan", "NaN state of the reference")
     if not np.isfinite(ud).all():
-        # Seen with rough data and the positivity limiter on (sw / kfvs / roe): a point the limiter has left at p = 1e-13
-        # gets a pressure of the other sign from the device's reciprocal-based arithmetic and the flux takes the root of it,
-        # steps after both solutions agreed to 1e-15 (FUZZ_ONLY=<case> prints the stage-by-stage history).  Not a parity
-        # statement either way; reported, not failed.
-        raise oracle_lib.OracleError(1, "device NaN, reference finite (cold point)")
+        knife_or_fail(case, n_total, "device NaN, reference finite", np.inf)
     e = rel(ud, uo)
-    if e >= tol and e1 is not None and e1 <= 1e-12 * loose and "kink" in desc:
-        # Rough data (cells scaled by up to 3, nodal noise) on a few cells is not a resolved flow: the solutions agree to round-off
-        # after the first step (e1) and the difference then grows by one to two orders of magnitude per stage -- limiter switches,
-        # points left at p = 1e-13 -- until it passes the bar in the second or third step.  Seen 3 times in 40 000 cases at degrees
-        # 0-3, identically on the kernels of round 2 (same seeds, same cases), more often at degrees 4 and 5.  Reported, not failed.
-        raise oracle_lib.OracleError(3, "round-off amplified by rough data")
-    assert e < tol, ("solution", e)
+    stats_max(degree, "state", e / (tol / loose))   # in units of the degree-3 bar of its class
+    if not e < tol:
+        knife_or_fail(case, n_total, "state", e)
     return desc
 
 
+stats = {}
+
+
+def stats_max(degree, key, v):
+    d = stats.setdefault(degree, {})
+    d[key] = max(d.get(key, 0.0), float(v))
+
+
 fails = 0
-skipped = {}
+classes = {}
+per_degree = {}
 t0 = time.time()
+last = {}
 for i in range(n_cases):
     try:
-        one(i)
+        last.clear()
+        d = one(i)
+        deg = d["degree"]
+        per_degree.setdefault(deg, {"n": 0})["n"] += 1
+    except Classified as e:
+        classes[e.cls] = classes.get(e.cls, 0) + 1
+        if VERBOSE and e.cls == "knife":
+            print("case %d knife: %s" % (i, e))
+    except Fail as e:
+        fails += 1
+        print("CASE %d FAILED: %s  %s" % (i, e.args, dict(last)))
     except oracle_lib.OracleError as e:
-        skipped["oracle: " + str(e)[:40]] = skipped.get("oracle: " + str(e)[:40], 0) + 1   # inadmissible for the reference too
+        fails += 1
+        print("CASE %d oracle error: %s" % (i, e))
     except dflo_amd.DfloError as e:
-        if e.code in (-3, -4, -7, -1):   # negative states / root failure / unsupported combination / refused parameters
-            skipped["device %d" % e.code] = skipped.get("device %d" % e.code, 0) + 1
-            continue
         fails += 1
         print("CASE %d device error: %s" % (i, e))
-    except AssertionError as e:
-        fails += 1
-        print("CASE %d FAILED: %s  %s" % (i, e, {k: v for k, v in last.items() if k != "bnd"}))
-print("%d cases, %d failures, %d not compared %s, %.1f s" % (n_cases, fails, sum(skipped.values()), skipped, time.time() - t0))
+knife = classes.get("knife", 0)
+rate_bar = 1e-3 if max_degree <= 3 else 2e-2
+print("largest agreement errors of the compared cases, by degree (residual: relative; state: in units of the bar of its class at degree 3; bar factor of the degree):")
+for deg in sorted(stats):
+    print("   degree %d: residual %.2e, state %.3f x bar, bar factor %.2f" % (deg, stats[deg].get("residual", 0.0), stats[deg].get("state", 0.0), loose_of(deg)))
+print("%d cases, %d failures, classified %s, knife rate %.1e (bar %.0e), %.1f s" % (n_cases, fails, classes, knife / max(n_cases, 1), rate_bar, time.time() - t0))
+if knife > rate_bar * n_cases + 2:
+    print("FAILED: too many cases classified as ill-conditioned")
+    fails += 1
 sys.exit(1 if fails else 0)
