@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/dflo_hip.h"
@@ -151,20 +152,26 @@ __device__ __forceinline__ double trace_from_line(const double (&val)[N]) {
 // that the value the limiter has made admissible is, bit for bit, the value the next flux evaluation takes the square root of.
 // (The reference is consistent with itself in the same way -- one set of shape values serves both; with two orders of summation
 // the flux saw p = 1e-13 - O(1e-13) at degree 5 and went NaN where the reference does not: fuzz case 2312 of seed 4243.)
-template <int N>
-__device__ __forceinline__ double gll_point(const KBasis &kb, int g, const double (&val)[N]) {
+// KIND 0: the first point (the face at 0), 2: the last (the face at 1: the line walked backwards, weights l_m(0), like a trace),
+// 1: an interior point g (interpolation weights Pg).  get(m): nodal value m of the line, ascending.  The caller peels the first and
+// the last point off its loop over g, so that every variant is straight-line code with compile-time indices.
+template <int N, int KIND, class F>
+__device__ __forceinline__ double gll_point(const KBasis &kb, int g, F get) {
   double v = 0.0;
-  if (g == kb.Ng - 1) {
 #pragma unroll
-    for (int m = 0; m < N; ++m) v += CB<N>::t.L0[m] * val[N - 1 - m];
-  } else if (g == 0) {
-#pragma unroll
-    for (int m = 0; m < N; ++m) v += CB<N>::t.L0[m] * val[m];
-  } else {
-#pragma unroll
-    for (int m = 0; m < N; ++m) v += kb.Pg[g][m] * val[m];
+  for (int m = 0; m < N; ++m) {
+    if constexpr (KIND == 0) v += CB<N>::t.L0[m] * get(m);
+    else if constexpr (KIND == 2) v += CB<N>::t.L0[m] * get(N - 1 - m);
+    else v += kb.Pg[g][m] * get(m);
   }
   return v;
+}
+// run body(kind, g) for every Gauss-Lobatto point g = 0 .. Ng - 1 with its kind as a compile-time constant
+template <class B>
+__device__ __forceinline__ void for_gll_points(int Ng, B body) {
+  body(std::integral_constant<int, 0>(), 0);
+  for (int g = 1; g < Ng - 1; ++g) body(std::integral_constant<int, 1>(), g);
+  body(std::integral_constant<int, 2>(), Ng - 1);
 }
 // component c of the trace of cell `slot` on its local face f at face point q (Qk, shard layout U)
 template <int N>

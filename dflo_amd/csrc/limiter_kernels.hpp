@@ -245,15 +245,11 @@ __device__ __forceinline__ void limiter_shard(const LimArgs &a, const int shard,
       double rho_min = 1.0e20;
 #pragma unroll
       for (int l = 0; l < N; ++l)
-        for (int g = 0; g < a.kb.Ng; ++g) {
-          double lx[N], ly[N];
-#pragma unroll
-          for (int m = 0; m < N; ++m) {
-            lx[m] = U[RHO * NS + m + N * l];
-            ly[m] = U[RHO * NS + l + N * m];
-          }
-          rho_min = smin(smin(rho_min, gll_point<N>(kb, g, lx)), gll_point<N>(kb, g, ly));
-        }
+        for_gll_points(a.kb.Ng, [&](auto kind, int g) {
+          const double vx = gll_point<N, decltype(kind)::value>(kb, g, [&](int m) { return U[RHO * NS + m + N * l]; });
+          const double vy = gll_point<N, decltype(kind)::value>(kb, g, [&](int m) { return U[RHO * NS + l + N * m]; });
+          rho_min = smin(smin(rho_min, vx), vy);
+        });
       const double rat = fabs(A[RHO] - eps) * frcp(fabs(A[RHO] - rho_min) + 1.0e-13);
       const double theta1 = smin(rat, 1.0);
       if (theta1 < 1.0) {
@@ -267,17 +263,13 @@ __device__ __forceinline__ void limiter_shard(const LimArgs &a, const int shard,
       for (int dir = 0; dir < 2; ++dir)
 #pragma unroll
         for (int l = 0; l < N; ++l)
-          for (int g = 0; g < a.kb.Ng; ++g) {
+          for_gll_points(a.kb.Ng, [&](auto kind, int g) {
             double W[4];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-              double ln[N];
-#pragma unroll
-              for (int m = 0; m < N; ++m) ln[m] = dir == 0 ? U[c * NS + m + N * l] : U[c * NS + l + N * m];
-              W[c] = gll_point<N>(kb, g, ln);
-            }
+            for (int c = 0; c < 4; ++c)
+              W[c] = gll_point<N, decltype(kind)::value>(kb, g, [&](int m) { return dir == 0 ? U[c * NS + m + N * l] : U[c * NS + l + N * m]; });
             theta2 = smin(theta2, positivity_theta2(W, A, eps, fail));
-          }
+          });
       if (fail && active) raise_flag(a.flags, 1, a.step_ctr);
       if (theta2 < 1.0) {
 #pragma unroll

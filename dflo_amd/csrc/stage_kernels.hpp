@@ -821,34 +821,27 @@ __global__ __launch_bounds__(64 * N, N >= 5 ? 1 : ((N == 4 && GEO == 0 && MODE =
     // theta2 of this wave's points (:138-178) for the current unew / Us
     auto pressure_theta = [&](bool &fail) {
       double th = 1.0;
-      for (int g = 0; g < a.kb.Ng; ++g)
+      for_gll_points(a.kb.Ng, [&](auto kind, int g) {
 #pragma unroll
         for (int dir = 0; dir < 2; ++dir) {
           double W[4];
 #pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            double ln[N];
-#pragma unroll
-            for (int m = 0; m < N; ++m) ln[m] = dir == 0 ? unew[c][m] : Us[(c * NS2 + row + N * m) * S + lane];
-            W[c] = gll_point<N>(a.kb, g, ln);
-          }
+          for (int c = 0; c < 4; ++c)
+            W[c] = gll_point<N, decltype(kind)::value>(a.kb, g, [&](int m) { return dir == 0 ? unew[c][m] : Us[(c * NS2 + row + N * m) * S + lane]; });
           th = smin(th, positivity_theta2(W, A, eps, fail));
         }
+      });
       return th;
     };
     // first round: the density minimum and, on the guess theta1 = 1 (true almost everywhere), theta2 as well
     bool fail = false;
     {
       double rmin = 1.0e20;
-      for (int g = 0; g < a.kb.Ng; ++g) {
-        double lx[N], ly[N];
-#pragma unroll
-        for (int m = 0; m < N; ++m) {
-          lx[m] = unew[RHO][m];
-          ly[m] = Us[(RHO * NS2 + row + N * m) * S + lane];
-        }
-        rmin = smin(smin(rmin, gll_point<N>(a.kb, g, lx)), gll_point<N>(a.kb, g, ly));
-      }
+      for_gll_points(a.kb.Ng, [&](auto kind, int g) {
+        const double px = gll_point<N, decltype(kind)::value>(a.kb, g, [&](int m) { return unew[RHO][m]; });
+        const double py = gll_point<N, decltype(kind)::value>(a.kb, g, [&](int m) { return Us[(RHO * NS2 + row + N * m) * S + lane]; });
+        rmin = smin(smin(rmin, px), py);
+      });
       pm[row * 64 + lane] = rmin;
       pm[(N + row) * 64 + lane] = pressure_theta(fail);
     }
