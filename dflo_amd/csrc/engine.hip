@@ -194,7 +194,7 @@ KBasis make_kbasis(const BasisTables &b) {
 #define DFLO_BY_N2(n, K, P) ((n) <= 2 ? K<2, P> : ((n) == 3 ? K<3, P> : ((n) == 4 ? K<4, P> : ((n) == 5 ? K<5, P> : K<6, P>))))
 #define DFLO_BY_N_LIM(n, K) ((n) <= 2 ? K<2> : ((n) == 3 ? K<3> : ((n) == 4 ? K<4> : ((n) == 5 ? K<5> : K<6>))))
 
-stage_fn pick_pk(int N, int flux, int mode, int nt = 0) {
+stage_fn pick_pk(int N, int flux, int mode, int nt = 0) {   // nt: bit 0 streaming stores, bit 1 bilinear cells
   switch (N) {
     case 1: return dflo::stage_pk_of_1(flux, mode, nt);
     case 2: return dflo::stage_pk_of_2(flux, mode, nt);
@@ -492,7 +492,7 @@ int launch_update(dflo_hip_engine *h, double *rhs_out, int part) {
       a.lim_list_from = part == 3 ? (int)p.rim_shards.size() : 0;
     }
   }
-  stage_fn fn = h->basis == DFLO_BASIS_PK ? pick_pk(h->N, h->prm.flux_type, mode_, streams_out(h)) : pick_stage(h->N, h->prm.flux_type, mode_, h->geo, pos_, streams_out(h));
+  stage_fn fn = h->basis == DFLO_BASIS_PK ? pick_pk(h->N, h->prm.flux_type, mode_, streams_out(h) | (h->geo << 1)) : pick_stage(h->N, h->prm.flux_type, mode_, h->geo, pos_, streams_out(h));
   time_begin(h);
   hipLaunchKernelGGL(fn, dim3(grid_for(a.n_list)), dim3(64 * h->N), h->lds_bytes, h->stream, a);
   time_end(h);
@@ -517,6 +517,8 @@ int launch_indicator(dflo_hip_engine *h, int part) {
   a.uniform_h = p.uniform_h ? 1 : 0;
   a.component = h->prm.shock_indicator == DFLO_IND_DENSITY ? RHO : EN;  // :70-82
   a.degree = h->degree;
+  a.cell_vert = h->geo == 1 ? h->d_cell_vert : nullptr;
+  a.n_slots = p.n_slots;
   part_list(h, part, &a.shard_list, &a.n_list);
   if (a.n_list == 0) return DFLO_OK;
   a.sweep_rev = next_sweep(h, part);
@@ -672,6 +674,13 @@ int launch_stage(dflo_hip_engine *h, int rk, double dt_host, double *rhs_out, in
 
 void launch_dt_q(dflo_hip_engine *h) {
   const Plan &p = h->plan;
+  if (h->basis == DFLO_BASIS_PK) {   // from the modes
+    auto fm = DFLO_BY_N(h->N, modal_geo_kernel);
+    hipLaunchKernelGGL(fm, dim3(p.n_shards), dim3(64), 0, h->stream, (const double *)h->U[h->cur], (double *)nullptr, h->shard_dtmin,
+                       (const double *)h->d_cell_h, (const double *)h->d_cell_vert, p.n_slots, (const int32_t *)h->d_shard_count, h->kb,
+                       h->prm.cfl, h->degree, h->d_dt_cell);
+    return;
+  }
   auto fn = DFLO_BY_N(h->N, dt_q_kernel);
   hipLaunchKernelGGL(fn, dim3(p.n_shards), dim3(64), 0, h->stream, (const double *)h->U[h->cur], (const double *)h->d_cell_h,
                      (const int32_t *)h->d_shard_count, h->shard_dtmin, h->kb, h->prm.cfl, h->degree, h->d_dt_cell);
@@ -683,6 +692,14 @@ int launch_average(dflo_hip_engine *h) {
   if (h->basis == DFLO_BASIS_QK && h->geo == 0) {   // squares: the epilogue's order of summation
     auto fn = DFLO_BY_N(h->N, average_rows_kernel);
     hipLaunchKernelGGL(fn, dim3(all), dim3(64), 0, h->stream, (const double *)h->U[h->cur], h->avg[h->avg_cur]);
+    HIPCHK(h, hipGetLastError());
+    return DFLO_OK;
+  }
+  if (h->basis == DFLO_BASIS_PK && h->geo == 1) {   // bilinear cells: the average of a modal function is not its mode 0
+    auto fm = DFLO_BY_N(h->N, modal_geo_kernel);
+    hipLaunchKernelGGL(fm, dim3(all), dim3(64), 0, h->stream, (const double *)h->U[h->cur], h->avg[h->avg_cur], (double *)nullptr,
+                       (const double *)h->d_cell_h, (const double *)h->d_cell_vert, p.n_slots, (const int32_t *)h->d_shard_count, h->kb,
+                       h->prm.cfl, h->degree, (double *)nullptr);
     HIPCHK(h, hipGetLastError());
     return DFLO_OK;
   }
@@ -753,10 +770,6 @@ int dflo_hip_create(const dflo_mesh_t *mesh, const dflo_params_t *params, int de
   // consistency checks of the reference's parameter parsing (src/parameters.cc:536-550)
   if (mesh->degree < 0 || mesh->degree > DFLO_MAX_DEGREE) { g_create_error = "degree must be 0..5"; return DFLO_ERR_BAD_PARAM; }
   if (mesh->basis != DFLO_BASIS_QK && mesh->basis != DFLO_BASIS_PK) { g_create_error = "unknown basis"; return DFLO_ERR_BAD_PARAM; }
-  if (mesh->basis == DFLO_BASIS_PK && mesh->mapping != DFLO_MAP_CARTESIAN) {
-    g_create_error = "Pk basis is implemented for cartesian mapping only";
-    return DFLO_ERR_UNSUPPORTED;
-  }
   // `mapping = q2` (MappingQ<dim>(2), src/claw.cc:173-176): on cells with straight edges -- all that the flat mesh can describe
   // (four vertices per cell), and all the reference has: its curved boundary description is commented out, src/claw.cc:976-979 --
   // the biquadratic map IS the bilinear one (its extra support points are the edge midpoints and the centre's image under the
@@ -765,10 +778,6 @@ int dflo_hip_create(const dflo_mesh_t *mesh, const dflo_params_t *params, int de
   if (params->shock_indicator < DFLO_IND_LIMITER || params->shock_indicator >= DFLO_IND_U2) {
     g_create_error = "shock indicator must be limiter, density or energy (u2 belongs to the MOOD scheme)";
     return params->shock_indicator == DFLO_IND_U2 ? DFLO_ERR_UNSUPPORTED : DFLO_ERR_BAD_PARAM;
-  }
-  if (params->shock_indicator != DFLO_IND_LIMITER && mesh->mapping != DFLO_MAP_CARTESIAN) {
-    g_create_error = "the KXRCF indicator is implemented for cartesian mapping";
-    return DFLO_ERR_UNSUPPORTED;
   }
   if (params->limiter_type == DFLO_LIMITER_TVB && mesh->mapping != DFLO_MAP_CARTESIAN) {
     g_create_error = "TVB limiter is implemented only for cartesian mapping";  // src/parameters.cc:543-544
@@ -979,7 +988,7 @@ int dflo_hip_create(const dflo_mesh_t *mesh, const dflo_params_t *params, int de
       const bool limited = h->prm.limiter_type != DFLO_LIMITER_NONE || h->prm.pos_lim;
       h->af = h->prm.flux_type == DFLO_FLUX_LXF && h->basis == DFLO_BASIS_QK && h->geo == 0 && !limited &&
               h->prm.shock_indicator == DFLO_IND_LIMITER && p.n_cells == p.n_owned && p.halo_cols + 64 <= h->halo_stride && tun.lxf_from_dofs;
-      const bool lxf_reads_avg = h->prm.flux_type == DFLO_FLUX_LXF && !h->af && !(h->basis == DFLO_BASIS_PK && p.n_cells == p.n_owned);
+      const bool lxf_reads_avg = h->prm.flux_type == DFLO_FLUX_LXF && !h->af && !(h->basis == DFLO_BASIS_PK && h->geo == 0 && p.n_cells == p.n_owned);
       h->lazy_avg = tun.lazy_avg && !lxf_reads_avg && !pass && h->prm.global_time_step;
     }
     // (measured: the marks pay from k = 2 on -- C4 +10 %, the slab pair +3.5 % with the box test of round 3 --; at k = 1, where the
@@ -1015,7 +1024,7 @@ int dflo_hip_create(const dflo_mesh_t *mesh, const dflo_params_t *params, int de
   if (h->lds_bytes > 160 * 1024) { h->err = "shard halo too large for LDS"; return bail(DFLO_ERR_UNSUPPORTED); }
   if (h->lds_bytes > 64 * 1024) {
     for (int mode = 0; mode < 3; ++mode) {
-      stage_fn fn = h->basis == DFLO_BASIS_PK ? pick_pk(h->N, h->prm.flux_type, mode, streams_out(h)) : pick_stage(h->N, h->prm.flux_type, mode, h->geo, h->fuse_pos ? 1 : (h->lim_mask ? 2 : (h->af ? 3 : 0)), streams_out(h));
+      stage_fn fn = h->basis == DFLO_BASIS_PK ? pick_pk(h->N, h->prm.flux_type, mode, streams_out(h) | (h->geo << 1)) : pick_stage(h->N, h->prm.flux_type, mode, h->geo, h->fuse_pos ? 1 : (h->lim_mask ? 2 : (h->af ? 3 : 0)), streams_out(h));
       if (hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes) != hipSuccess) {
         h->err = "cannot raise dynamic LDS limit";
         return bail(DFLO_ERR_HIP);

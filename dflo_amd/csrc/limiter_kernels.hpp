@@ -486,6 +486,8 @@ struct IndArgs {
   const int32_t *shard_list;
   int n_list;
   int sweep_rev;
+  const double *cell_vert;   // bilinear cells: [8][n_slots] vertices (normals and edge lengths of the faces), or null: squares
+  int n_slots;
 };
 
 // value of one component at point q of local face f: Qk from the nodes on the line through the face point,
@@ -515,7 +517,9 @@ __device__ __forceinline__ double face_point_value(const double *u, int f, int q
   return v;
 }
 
-// compute_shock_indicator_kxrcf (src/indicator.cc:51-198), same-level faces, axis-aligned squares; lane = cell.
+// compute_shock_indicator_kxrcf (src/indicator.cc:51-198), same-level faces; lane = cell.  Squares, or bilinear cells (cell_vert:
+// the outward normal and the length of a straight edge from its two vertices, as the stage kernels form them -- on such cells
+// the reference's limiters do not run, src/parameters.cc:543-544, and the indicator is the diagnostic of src/claw.cc:763, 1000).
 // Runs as its own pass between the stage update and the limiter: it reads the neighbours' unlimited DoFs.
 template <int N, int PK>
 __global__ __launch_bounds__(64) void indicator_kernel(const IndArgs a) {
@@ -538,11 +542,22 @@ __global__ __launch_bounds__(64) void indicator_kernel(const IndArgs a) {
     const int ns = a.lrbt[((size_t)shard * 4 + f) * 64 + lane], nf = code & 3;
     const bool flip = (code & 4) != 0;
     const double *un = a.U + ((size_t)(ns >> 6) * NDOF + a.component * NS) * 64 + (ns & 63);
-    const double vn = f == 0 ? -vel[0] : (f == 1 ? vel[0] : (f == 2 ? -vel[1] : vel[1]));
+    double vn = f == 0 ? -vel[0] : (f == 1 ? vel[0] : (f == 2 ? -vel[1] : vel[1])), flen = h;
+    if (a.cell_vert) {
+      double vx[8], tx, ty;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) vx[k] = a.cell_vert[(size_t)k * a.n_slots + (size_t)shard * 64 + lane];
+      const int va = f == 1 ? 1 : (f == 3 ? 2 : 0), vb = f == 0 ? 2 : (f == 2 ? 1 : 3);   // (face_edge of the stage kernels)
+      tx = vx[2 * vb] - vx[2 * va];
+      ty = vx[2 * vb + 1] - vx[2 * va + 1];
+      flen = sqrt(tx * tx + ty * ty);
+      const bool left = f == 1 || f == 2;
+      vn = vel[0] * ((left ? ty : -ty) / flen) + vel[1] * ((left ? -tx : tx) / flen);
+    }
     const double inflow_status = vn < 0 ? 1.0 : 0.0;
 #pragma unroll
     for (int q = 0; q < N; ++q) {
-      const double jxw = CB<N>::t.w[q] * h;
+      const double jxw = CB<N>::t.w[q] * flen;
       const double d = face_point_value<N, PK>(uo, f, q) - face_point_value<N, PK>(un, nf, flip ? N - 1 - q : q);
       ind += inflow_status * d * jxw;
       inflow += inflow_status * jxw;

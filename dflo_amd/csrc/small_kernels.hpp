@@ -316,6 +316,62 @@ __global__ __launch_bounds__(64) void average_rows_kernel(const double *U, doubl
     avg[((size_t)shard * 4 + c) * 64 + lane] = cell_average_rows<N>(u);
   }
 }
+// Pk on bilinear cells: the two quantities the stage kernel does not leave behind there, from the modes -- the cell average
+// (quadrature of the expansion over the mapped cell, src/claw.cc:589-593; `avg` non-null: all slots) and / or the time step of
+// compute_time_step_q (`shard_dtmin` non-null: owned shards; the 4 x 4 trapezoid points are reached through the values at the
+// Gauss nodes, which carry the P_k function exactly).  Lane = cell.
+template <int N>
+__global__ __launch_bounds__(64) void modal_geo_kernel(const double *U, double *avg, double *shard_dtmin, const double *cell_h,
+                                                       const double *vert, int n_slots, const int32_t *shard_count, KBasis kb,
+                                                       double cfl, int degree, double *dt_cell) {
+  constexpr int NS = N * N, NM = N * (N + 1) / 2;
+  const int shard = blockIdx.x, lane = threadIdx.x;
+  const size_t slot = (size_t)shard * 64 + lane;
+  double v[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) v[k] = vert[(size_t)k * n_slots + slot];
+  double u[4 * NS];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    double um[NM];
+#pragma unroll
+    for (int m = 0; m < NM; ++m) um[m] = U[((size_t)shard * 4 * NM + c * NM + m) * 64 + lane];
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+      double t = 0.0;
+#pragma unroll
+      for (int m = 0; m < NM; ++m) t += PB<N>::t.T[j][m] * um[m];
+      u[c * NS + j] = t;
+    }
+  }
+  if (avg) {
+    const double ax = v[2] - v[0], bx = (v[6] - v[4]) - ax, ay = v[3] - v[1], by = (v[7] - v[5]) - ay;
+    const double cx = v[4] - v[0], dx = (v[6] - v[2]) - cx, cy = v[5] - v[1], dy = (v[7] - v[3]) - cy;
+    const double area = 0.5 * fabs((v[0] * v[3] - v[2] * v[1]) + (v[2] * v[7] - v[6] * v[3]) + (v[6] * v[5] - v[4] * v[7]) + (v[4] * v[1] - v[0] * v[5]));
+    const double ia = 1.0 / area;
+    double A[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int b = 0; b < N; ++b)
+#pragma unroll
+      for (int aa = 0; aa < N; ++aa) {
+        const double det = (ax + CB<N>::t.x[b] * bx) * (cy + CB<N>::t.x[aa] * dy) - (cx + CB<N>::t.x[aa] * dx) * (ay + CB<N>::t.x[b] * by);
+        const double jxw = CB<N>::t.w[aa] * CB<N>::t.w[b] * det;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) A[c] += u[c * NS + aa + N * b] * jxw;
+      }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) avg[((size_t)shard * 4 + c) * 64 + lane] = A[c] * ia;
+  }
+  if (shard_dtmin) {
+    double dtmin = 1.0e20;
+    if (lane < shard_count[shard]) {
+      dtmin = dt_q_cell<N>(u, kb, cell_h[slot], cfl, degree);
+      if (dt_cell) dt_cell[slot] = dtmin;
+    }
+    dtmin = wave_min(dtmin);
+    if (lane == 0) shard_dtmin[shard] = dtmin;
+  }
+}
 // compute_time_step_q (src/claw.cc:520-557): max of |v| + c over the 4 x 4 points of QIterated(QTrapez,3),
 // dt = cfl h / lambda / (2k+1) with h = diameter / sqrt(2); per-shard minimum.  Lane = cell; the
 // interpolation to the 16 points is sum-factorised (xi first, then eta).

@@ -1128,9 +1128,13 @@ __device__ __forceinline__ void modal_to_row(const double *Um, const int S, cons
 
 // phase C for node row B, then projection of the nodal residual on the modes and the modal update of the
 // modes this wave owns (m = B, B+N, ...)
-template <int N, int B, int MODE, int STREAM>
+// GEO 1 (bilinear cells; FE_DGP lives on the reference cell, src/claw.cc:91-119 with mapping q1): the nodal residual of the row
+// is formed with the metric terms of row_update_q1; the mass matrix is the DIAGONAL the reference keeps,
+// M_mm = sum_q psi_m(x_q)^2 JxW_q (src/claw.cc:228-258: "not exact for general cells"), and the cell average is the quadrature
+// of the modal expansion over the cell, sum_m U_m (sum_q psi_m JxW_q) / |K| (src/claw.cc:589-593), no longer mode 0.
+template <int N, int B, int MODE, int STREAM, int GEO = 0>
 __device__ __forceinline__ void row_update_pk(const StageArgs &a, double *Us, const int S, const double *Fh, double *red,
-                                              int shard, int lane, bool active, double h, const uint16_t (&cref)[4],
+                                              int shard, int lane, bool active, double h, const double (&vx)[8], const uint16_t (&cref)[4],
                                               const double (&Wrow)[N][4], const double (&ucur)[4][(N * (N + 1) / 2 + N - 1) / N],
                                               const double (&uold)[4][(N * (N + 1) / 2 + N - 1) / N], const double dt) {
   const int HS = a.halo_stride;   // row stride of the trace / flux table (Fh)
@@ -1140,6 +1144,76 @@ __device__ __forceinline__ void row_update_pk(const StageArgs &a, double *Us, co
   for (int c = 0; c < 4; ++c)
 #pragma unroll
     for (int m = 0; m < N; ++m) R[c][m] = 0.0;
+  // metric terms of the bilinear map (GEO 1): x_xi depends on eta only, x_eta on xi only
+  const double ax = vx[2] - vx[0], bx = (vx[6] - vx[4]) - ax, ay = vx[3] - vx[1], by = (vx[7] - vx[5]) - ay;
+  const double cx = vx[4] - vx[0], dx = (vx[6] - vx[2]) - cx, cy = vx[5] - vx[1], dy = (vx[7] - vx[3]) - cy;
+  if constexpr (GEO == 1) {
+    // as row_update_q1: xi part lifted here, eta part (x_xi G - y_xi F) w w through the LDS image
+    double Hown[N][4];
+    const double xxi = ax + CB<N>::t.x[B] * bx, yxi = ay + CB<N>::t.x[B] * by;
+#pragma unroll
+    for (int aa = 0; aa < N; ++aa) {
+      const double xeta = cx + CB<N>::t.x[aa] * dx, yeta = cy + CB<N>::t.x[aa] * dy;
+      double Fx[4], Gy[4];
+      flux_xy(Wrow[aa], Fx, Gy);
+      const double wq = CB<N>::t.w[aa] * CB<N>::t.w[B];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const double f1 = (yeta * Fx[c] - xeta * Gy[c]) * wq;
+#pragma unroll
+        for (int m = 0; m < N; ++m) R[c][m] += f1 * CB<N>::t.D[aa][m];
+        Hown[aa][c] = (xxi * Gy[c] - yxi * Fx[c]) * wq;
+        Us[(c * NS + aa + N * B) * S + lane] = Hown[aa][c];
+      }
+      if (a.gravity != 0.0) {
+        const double jxw = wq * (xxi * yeta - xeta * yxi);
+        R[MY][aa] += a.gravity * (-1.0 * Wrow[aa][RHO]) * jxw;
+        R[EN][aa] += a.gravity * (-1.0 * Wrow[aa][MY]) * jxw;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int aa = 0; aa < N; ++aa)
+#pragma unroll
+      for (int q = 0; q < N; ++q)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const double hy = q == B ? Hown[aa][c] : Us[(c * NS + aa + N * q) * S + lane];
+          R[c][aa] += hy * CB<N>::t.D[q][B];
+        }
+    if (active) {
+#pragma unroll
+      for (int f = 0; f < 4; ++f) {
+        const uint16_t ref = cref[f];
+        if (ref == kNoFace) continue;
+        const int k = ref & 0x3FFF;
+        const bool flip = (ref >> 14) & 1;
+        const double sgn = (ref >> 15) ? 1.0 : -1.0;
+        double etx, ety;
+        face_edge(vx, f, etx, ety);
+        const double len = fsqrt(etx * etx + ety * ety);
+        if (f < 2) {
+          const int qq = flip ? N - 1 - B : B;
+          const double jxw = sgn * CB<N>::t.w[B] * len;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const double fq = Fh[(c * N + qq) * HS + k] * jxw;
+#pragma unroll
+            for (int m = 0; m < N; ++m) R[c][m] += fq * ((f & 1) ? CB<N>::t.L1[m] : CB<N>::t.L0[m]);
+          }
+        } else {
+          const double lw = (f & 1) ? CB<N>::t.L1[B] : CB<N>::t.L0[B];
+#pragma unroll
+          for (int q = 0; q < N; ++q) {
+            const int qq = flip ? N - 1 - q : q;
+            const double jxw = sgn * (CB<N>::t.w[q] * lw) * len;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) R[c][q] += Fh[(c * N + qq) * HS + k] * jxw;
+          }
+        }
+      }
+    }
+  } else {
   // P3, first stage (LEAN, as in row_update): built for 3 wavefronts per SIMD -- the nodal values of the own row and the own G
   // row come back from the LDS image instead of being held in registers, the G values are taken node by node
   constexpr bool LEAN = N == 4 && (MODE == 0 || (MODE == 1 && kPkLeanLater));
@@ -1209,6 +1283,7 @@ __device__ __forceinline__ void row_update_pk(const StageArgs &a, double *Us, co
       }
     }
   }
+  }   // GEO
   // ---- nodal residual -> modal residual: rhs_m = sum over rows of sum_a psi_m(x_(a,b)) R_b[.][a], the rows added in a
   //      fixed order (row 0 first).  Every wave leaves its row of the nodal residual in the now unused LDS image and, after ONE
   //      barrier, forms the sums of the modes it owns (m = B, B + N, ..) from all rows -- the waves used to take turns at
@@ -1223,6 +1298,27 @@ __device__ __forceinline__ void row_update_pk(const StageArgs &a, double *Us, co
   double part[5] = {0, 0, 0, 0, 0};
   {
     const double rh2 = frcp(h * h);  // inverse mass of the orthonormal modes: 1/|K|
+    double invM[MSB > 0 ? MSB : 1], cavg[MSB > 0 ? MSB : 1];   // GEO 1: per owned mode, from the cell's own metric
+    if constexpr (GEO == 1) {
+      const double area = 0.5 * fabs((vx[0] * vx[3] - vx[2] * vx[1]) + (vx[2] * vx[7] - vx[6] * vx[3]) +
+                                     (vx[6] * vx[5] - vx[4] * vx[7]) + (vx[4] * vx[1] - vx[0] * vx[5]));
+      const double ia = 1.0 / area;
+#pragma unroll
+      for (int t = 0; t < MSB; ++t) {
+        double mm = 0.0, cm = 0.0;
+#pragma unroll
+        for (int b = 0; b < N; ++b)
+#pragma unroll
+          for (int aa = 0; aa < N; ++aa) {
+            const double det = (ax + CB<N>::t.x[b] * bx) * (cy + CB<N>::t.x[aa] * dy) - (cx + CB<N>::t.x[aa] * dx) * (ay + CB<N>::t.x[b] * by);
+            const double jxw = CB<N>::t.w[aa] * CB<N>::t.w[b] * det, psi = PB<N>::t.T[aa + N * b][B + N * t];
+            mm += psi * psi * jxw;
+            cm += psi * jxw;
+          }
+        invM[t] = frcp(mm);
+        cavg[t] = cm * ia;
+      }
+    }
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       double rmv[MSB > 0 ? MSB : 1];
@@ -1250,10 +1346,11 @@ __device__ __forceinline__ void row_update_pk(const StageArgs &a, double *Us, co
         } else {
           part[4] += rm * rm;
           double u = ucur[c][t];
-          u += dt * rm * rh2;
+          u += dt * rm * (GEO == 1 ? invM[t] : rh2);
           if constexpr (MODE == 1) u = (1.0 - a.ark) * u + a.ark * uold[c][t];
           stream_store<STREAM>(&a.Unew[((size_t)shard * 4 * NM + c * NM + m) * 64 + lane], u);
-          if (m == 0) part[c] = u;  // the cell average is mode 0
+          if constexpr (GEO == 1) part[c] += u * cavg[t];   // this wave's modes' share of the cell average
+          else if (m == 0) part[c] = u;  // squares: the cell average is mode 0
         }
       }
       }
@@ -1266,8 +1363,8 @@ __device__ __forceinline__ void row_update_pk(const StageArgs &a, double *Us, co
   }
 }
 
-template <int N, int FLUX, int MODE, int STREAM>
-__global__ __launch_bounds__(64 * N, N >= 5 ? 1 : (N == 4 ? (((MODE == 0 || (MODE == 1 && kPkLeanLater)) && FLUX != DFLO_FLUX_LXF) ? kQ3FirstStageWaves : 2) : 3)) void stage_kernel_pk(const StageArgs a) {
+template <int N, int FLUX, int MODE, int STREAM, int GEO = 0>
+__global__ __launch_bounds__(64 * N, N >= 5 ? 1 : (N == 4 ? (((MODE == 0 || (MODE == 1 && kPkLeanLater)) && FLUX != DFLO_FLUX_LXF && GEO == 0) ? kQ3FirstStageWaves : 2) : (GEO == 1 ? 2 : 3))) void stage_kernel_pk(const StageArgs a) {
   constexpr int NS = N * N, NM = N * (N + 1) / 2, NDOFM = 4 * NM, NT = 64 * N, MS = (NM + N - 1) / N;
   constexpr int ROWS = 4 * NS + (FLUX == DFLO_FLUX_LXF ? 3 : 0);
   constexpr int TROWS = 4 * N;
@@ -1285,6 +1382,7 @@ __global__ __launch_bounds__(64 * N, N >= 5 ? 1 : (N == 4 ? (((MODE == 0 || (MOD
   double *Av = Th + TROWS * HS;
   double *Bv = Av + (FLUX == DFLO_FLUX_LXF ? 3 * a.halo_cols : 0);
   int *Bk = (int *)(Bv + a.max_bnd * 4 * N);
+  double *Vx = (double *)(Bk + ((a.max_bnd + 1) & ~1));   // GEO 1: [4][2][64] outward unit normals of the own cells' faces
 
   // ---- loads: a wave reads the modes it will update (m = row, row + N, ..) of u(s) and u(n); the node rows need all modes of
   //      the cell, which the waves hand each other through LDS (each of them used to load all of them: 4 NM loads and as many
@@ -1293,7 +1391,7 @@ __global__ __launch_bounds__(64 * N, N >= 5 ? 1 : (N == 4 ? (((MODE == 0 || (MOD
   // kernel takes it from the modes it loads anyway (own cells: wave 0 holds mode 0; halo cells: the gather below), the array of
   // averages is not read.  The gather then runs with (entry, component) = (t >> 2, t & 3), the four components of an entry in the
   // four lanes of a quad, instead of the components spread over half-waves.
-  constexpr bool LXF = FLUX == DFLO_FLUX_LXF;
+  constexpr bool LXF = FLUX == DFLO_FLUX_LXF && GEO == 0;   // (bilinear cells: the average is not mode 0 -- the arrays of averages are read)
   int hent[1];
   hent[0] = a.halo_pad[(size_t)shard * a.halo_pitch + (LXF ? min(tid >> 2, a.halo_pitch - 1) : (tid & 31))];
   const int4 hdr = a.shard_hdr[shard];
@@ -1307,7 +1405,18 @@ __global__ __launch_bounds__(64 * N, N >= 5 ? 1 : (N == 4 ? (((MODE == 0 || (MOD
   uint16_t cref[4];
 #pragma unroll
   for (int f = 0; f < 4; ++f) cref[f] = a.cell_face[((size_t)pat * 4 + f) * 64 + lane];
-  const double h = a.uniform_h ? a.h_uniform : a.cell_h[(size_t)shard * 64 + lane];
+  const double h = GEO == 1 ? 0.0 : (a.uniform_h ? a.h_uniform : a.cell_h[(size_t)shard * 64 + lane]);
+  double vx[8] = {0, 0, 0, 0, 0, 0, 0, 0}, uavg[4];
+  if constexpr (GEO == 1) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) vx[k] = a.cell_vert[(size_t)k * a.n_slots + (size_t)shard * 64 + lane];
+    if constexpr (FLUX == DFLO_FLUX_LXF) {
+      if (row == 0) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) uavg[c] = a.avg_cur[((size_t)shard * 4 + c) * 64 + lane];
+      }
+    }
+  }
   double dt_step = 0.0;   // fetched with the other loads, not in the middle of phase C
   if constexpr (MODE != 2) dt_step = a.dt_cell ? a.dt_cell[(size_t)shard * 64 + lane] : (a.dt_host >= 0.0 ? a.dt_host : step_dt(a.dts, a.dt_dev));
   double ucur[4][MS], uold[4][MS];
@@ -1398,6 +1507,33 @@ __global__ __launch_bounds__(64 * N, N >= 5 ? 1 : (N == 4 ? (((MODE == 0 || (MOD
       for (int c = 0; c < 3; ++c) Us[(4 * NS + c) * S + lane] = uvc[c];
     }
   }
+  if constexpr (FLUX == DFLO_FLUX_LXF && GEO == 1) {   // (u, v, c) of the stored averages: own cells and halo entries
+    if (row == 0) {
+      double uvc[3];
+      wave_speed_uvc(uavg, uvc);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) Us[(4 * NS + c) * S + lane] = uvc[c];
+    }
+    for (int sl = tid; sl < nh; sl += NT) {
+      const int ic = (sl < 32 ? hent[0] : a.halo_pad[(size_t)shard * a.halo_pitch + sl]) & 0x0FFFFFFF;
+      double A[4], uvc[3];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) A[c] = a.avg_cur[((size_t)(ic >> 6) * 4 + c) * 64 + (ic & 63)];
+      wave_speed_uvc(A, uvc);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) Av[c * a.halo_cols + sl] = uvc[c];
+    }
+  }
+  if constexpr (GEO == 1) {   // outward unit normals of the own cells' faces (as in stage_kernel)
+    for (int f = row; f < 4; f += N) {
+      double tx, ty;
+      face_edge(vx, f, tx, ty);
+      const double len = sqrt(tx * tx + ty * ty);
+      const bool left = f == 1 || f == 2;
+      Vx[(2 * f) * 64 + lane] = (left ? ty : -ty) / len;
+      Vx[(2 * f + 1) * 64 + lane] = (left ? -tx : tx) / len;
+    }
+  }
   if (nbnd > 0) {
     for (int i = tid; i < nbnd * 4 * N; i += NT) {
       const int bl = i / (4 * N), k2 = i - bl * 4 * N;
@@ -1407,7 +1543,7 @@ __global__ __launch_bounds__(64 * N, N >= 5 ? 1 : (N == 4 ? (((MODE == 0 || (MOD
     }
   }
   __syncthreads();
-  flux_phase<N, FLUX, 0>(a, Us, Th, Av, frr, fp, Bv, Bk, nullptr, HS, nf, nh, tid);
+  flux_phase<N, FLUX, GEO>(a, Us, Th, Av, frr, fp, Bv, Bk, Vx, HS, nf, nh, tid);
   __syncthreads();
 
   double *Fh = Th, *red = Th;
@@ -1416,7 +1552,7 @@ __global__ __launch_bounds__(64 * N, N >= 5 ? 1 : (N == 4 ? (((MODE == 0 || (MOD
   for (int m = 0; m < N; ++m)
 #pragma unroll
     for (int c = 0; c < 4; ++c) wrow[m][c] = urow[c][m];
-#define DFLO_ROWPK(Bq) row_update_pk<N, Bq, MODE, STREAM>(a, Us, S, Fh, red, shard, lane, active, h, cref, wrow, ucur, uold, dt_step)
+#define DFLO_ROWPK(Bq) row_update_pk<N, Bq, MODE, STREAM, GEO>(a, Us, S, Fh, red, shard, lane, active, h, vx, cref, wrow, ucur, uold, dt_step)
   if constexpr (N == 2) {
     if (row == 0) DFLO_ROWPK(0); else DFLO_ROWPK(1);
   } else if constexpr (N == 3) {
@@ -1443,17 +1579,18 @@ __global__ __launch_bounds__(64 * N, N >= 5 ? 1 : (N == 4 ? (((MODE == 0 || (MOD
     }
 #pragma unroll
     for (int b = 0; b < N; ++b) res += red[(b * 5 + 4) * 64 + lane];
+    const bool have_dt = a.want_dt && GEO == 0;   // (bilinear cells: compute_time_step_q, a pass of its own over the new state)
     if (active) {
 #pragma unroll
       for (int c = 0; c < 4; ++c)
         if (a.store_avg) a.avg_new[((size_t)shard * 4 + c) * 64 + lane] = avg[c];
-      if (a.want_dt) dtmin = cfl_dt(avg, h, a.cfl, a.degree);
+      if (have_dt) dtmin = cfl_dt(avg, h, a.cfl, a.degree);
     }
     res = wave_sum_lane63(res);
-    if (a.want_dt) dtmin = wave_min_lane63(dtmin);
+    if (have_dt) dtmin = wave_min_lane63(dtmin);
     if (lane == 63) {
       a.shard_res[shard] = res;
-      if (a.want_dt) a.shard_dtmin[shard] = dtmin;
+      if (have_dt) a.shard_dtmin[shard] = dtmin;
     }
   }
 }
@@ -1497,7 +1634,12 @@ stage_fn pick_stage_n(int flux, int mode, int geo, int pos, int nt) {
   }
 }
 template <int N, int FLUX>
-stage_fn pick_pk_m(int mode, int nt) {   // nt: nothing re-reads the new state before the next stage kernel (see STREAM)
+stage_fn pick_pk_m(int mode, int nt) {   // nt bit 0: nothing re-reads the new state before the next stage kernel (see STREAM); bit 1: bilinear cells
+  if (nt & 2) {
+    if (mode == 2) return stage_kernel_pk<N, FLUX, 2, 0, 1>;
+    if (nt & 1) return mode == 0 ? stage_kernel_pk<N, FLUX, 0, 1, 1> : stage_kernel_pk<N, FLUX, 1, 1, 1>;
+    return mode == 0 ? stage_kernel_pk<N, FLUX, 0, 0, 1> : stage_kernel_pk<N, FLUX, 1, 0, 1>;
+  }
   if (mode == 2) return stage_kernel_pk<N, FLUX, 2, 0>;
   if (nt) return mode == 0 ? stage_kernel_pk<N, FLUX, 0, 1> : stage_kernel_pk<N, FLUX, 1, 1>;
   return mode == 0 ? stage_kernel_pk<N, FLUX, 0, 0> : stage_kernel_pk<N, FLUX, 1, 0>;

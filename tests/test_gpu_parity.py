@@ -495,12 +495,25 @@ def test_pk_advance_device_dt():
     assert rel(claw.current_solution, ora.get_solution()) < 1e-11
 
 
-def test_pk_rejects_mapped_cells():
-    mesh = dflo_amd.Mesh.cartesian(8, 8, 0.0, 0.0, 0.125, [-1, -1, -1, -1], 1)
-    mesh.set_basis("Pk")
-    mesh.set_mapping("q1")
-    with pytest.raises(dflo_amd.DfloError):
-        dflo_amd.ConservationLaw(mesh, dflo_amd.Parameters(flux="lxf"))
+@pytest.mark.parametrize("degree,flux", [(1, "lxf"), (2, "hllc"), (3, "kfvs")])
+def test_pk_with_the_bilinear_mapping_on_squares_equals_the_cartesian_mapping(degree, flux):
+    """Pk with `mapping = q1` (taken by the engine since round 4; tests/test_gpu_round4.py holds it to the oracle on non-affine
+    cells): on squares the metric terms are constants, the diagonal mass matrix is |K| and the cell average is mode 0, so the
+    two mappings must agree to rounding -- residual, time step (compute_time_step_q against compute_time_step_cartesian differ
+    by design, src/claw.cc:495-509 / 520-557: not compared) and a step with a common time step."""
+    out = []
+    for mapping in ("cartesian", "q1"):
+        mesh = dflo_amd.Mesh.cartesian(20, 12, 0.0, 0.0, 0.05, [-1, -1, -1, -1], degree)
+        mesh.set_basis("Pk")
+        mesh.set_mapping(mapping)
+        claw = dflo_amd.ConservationLaw(mesh, dflo_amd.Parameters(flux=flux))
+        claw.set_initial_condition(mesh.project(lambda x, y: problems.smooth_perturbation(x, y, L=1.0)))
+        r = claw.assemble_system().copy()
+        claw.iterate_explicit(1.0e-3)
+        out.append((r, claw.current_solution.copy(), claw.cell_average.copy()))
+        claw.close()
+    for a, b in zip(out[0], out[1]):
+        assert rel(b, a) < 1e-12
 
 
 def test_advance_graph_replay_matches_plain_launches(monkeypatch):
@@ -685,9 +698,9 @@ def test_kxrcf_unsupported_configurations():
     mesh = dflo_amd.Mesh.cartesian(8, 8, 0.0, 0.0, 0.125, [-1] * 4, 1)
     with pytest.raises(dflo_amd.DfloError):
         dflo_amd.ConservationLaw(mesh, dflo_amd.Parameters(flux="lxf", shock_indicator="u2"))
-    mesh.set_mapping("q1")
-    with pytest.raises(dflo_amd.DfloError):
-        dflo_amd.ConservationLaw(mesh, dflo_amd.Parameters(flux="lxf", shock_indicator="density"))
+    mesh.set_mapping("q1")   # (the indicator itself runs on bilinear cells since round 4; the TVB limiter it gates does not,
+    with pytest.raises(dflo_amd.DfloError):   #  src/parameters.cc:543-544)
+        dflo_amd.ConservationLaw(mesh, dflo_amd.Parameters(flux="lxf", limiter="TVB", shock_indicator="density"))
 
 
 @pytest.mark.parametrize("flux", FLUXES)

@@ -122,3 +122,84 @@ def test_lxf_on_the_modal_basis_takes_the_average_from_mode_zero(degree):
             t += dt
         assert rel(claw.current_solution, ora.get_solution()) < 1e-10
         claw.close()
+
+
+# ---------------------------------------------------------------- the modal basis and the KXRCF indicator on bilinear cells
+def _skewed(n, degree, basis):
+    from test_gpu_parity import skewed_mesh
+    mesh = skewed_mesh(n, degree)
+    mesh.set_basis(basis)
+    return mesh
+
+
+def _walls(claw, ora, ic):
+    cell, face, bid, xy = claw.boundary_faces()
+    bv = np.stack(ic(xy[..., 0], xy[..., 1]), axis=-1)
+    for w in (0, 1):
+        claw.set_boundary_values(w, bv)
+        ora.set_boundary_values(w, bv)
+
+
+@pytest.mark.parametrize("degree", [0, 1, 2, 3])
+@pytest.mark.parametrize("flux", ["lxf", "hllc", "kfvs"])
+def test_modal_basis_on_bilinear_cells(degree, flux):
+    """FE_DGP lives on the reference cell, so ConservationLaw's Pk constructor takes any mapping (src/claw.cc:91-119) -- the
+    reference's parameter file refuses the combination (src/parameters.cc:546-547), the C ABI does not.  On bilinear cells the
+    residual needs the metric terms, the mass matrix is the diagonal sum_q psi_m^2 JxW_q the reference keeps
+    (src/claw.cc:228-258), the cell average is a quadrature of the expansion and no longer mode 0 (src/claw.cc:589-593) and
+    the time step is compute_time_step_q (src/claw.cc:520-557).  Residual, averages, time steps and five RK steps against the
+    oracle on a mesh of genuinely non-affine cells, with the positivity limiter on for the steps."""
+    mesh = _skewed(9, degree, "Pk")
+    ic = lambda x, y: problems.smooth_perturbation(x, y, L=1.0)
+    bnd = {1: "inflow", 2: "slip", 3: "outflow"}
+    u0 = mesh.project(ic)
+    for pos in (False, True):
+        prm = dflo_amd.Parameters(flux=flux, boundary=bnd, cfl=0.4, pos_lim=pos)
+        claw, ora = dflo_amd.ConservationLaw(mesh, prm), oracle_lib.Oracle(mesh, prm)
+        _walls(claw, ora, ic)
+        claw.set_initial_condition(u0)
+        ora.set_solution(u0)
+        assert rel(claw.cell_average, ora.get_cell_average()) < 1e-13
+        if not pos:
+            assert rel(claw.assemble_system(), ora.assemble()) < 1e-12
+        t = 0.0
+        for it in range(5):
+            dt, dto = claw.compute_time_step(), ora.compute_time_step(t)
+            assert abs(dt - dto) <= 1e-12 * dto
+            r0, r1 = claw.iterate_explicit(dt)
+            q0, q1 = ora.step(dt)
+            assert abs(r1 - q1) <= 1e-10 * q1
+            t += dt
+        assert rel(claw.current_solution, ora.get_solution()) < 1e-11
+        assert rel(claw.cell_average, ora.get_cell_average()) < 1e-11
+        t2 = claw.advance(3)        # the same with the time step resident on the device
+        for it in range(3):
+            dto = ora.compute_time_step(t)
+            ora.step(dto)
+            t += dto
+        assert abs(t2 - t) <= 1e-11 * t
+        assert rel(claw.current_solution, ora.get_solution()) < 1e-10
+        claw.close()
+
+
+@pytest.mark.parametrize("basis,degree", [("Qk", 1), ("Qk", 2), ("Qk", 3), ("Pk", 2)])
+@pytest.mark.parametrize("kind", ["density", "energy"])
+def test_kxrcf_indicator_on_bilinear_cells(basis, degree, kind):
+    """compute_shock_indicator_kxrcf (src/indicator.cc:51-198) on non-affine cells: inflow faces by the cell-mean velocity
+    against the edge normal, jumps weighted with the edge length, diameter^((k+1)/2) in the denominator.  (The limiters it
+    gates run on Cartesian cells only, src/parameters.cc:543-544: here it is the diagnostic of src/claw.cc:763.)"""
+    mesh = _skewed(12, degree, basis)
+    prm = dflo_amd.Parameters(flux="roe", shock_indicator=kind, boundary={1: "outflow", 2: "outflow", 3: "outflow"})
+    claw, ora = dflo_amd.ConservationLaw(mesh, prm), oracle_lib.Oracle(mesh, prm)
+    def ic(x, y):
+        s = 0.5 * (1.0 + np.tanh((x + 0.5 * y - 0.8) / 0.02))
+        rho, p, u, v = 1.0 + 0.6 * s, 1.0 + 0.9 * s, 0.6, 0.35
+        return [rho * u, rho * v, rho, p / 0.4 + 0.5 * rho * (u * u + v * v)]
+    u0 = mesh.interpolate(ic)
+    claw.set_initial_condition(u0)
+    ora.set_solution(u0)
+    s, so = claw.compute_shock_indicator(), ora.compute_shock_indicator()
+    assert (np.isnan(s) == np.isnan(so)).all()
+    ok = ~np.isnan(so)
+    assert np.abs(s[ok] - so[ok]).max() <= 1e-11 * np.abs(so[ok]).max()
+    assert (so[ok] > 0).sum() > mesh.n_cells // 2
