@@ -68,6 +68,13 @@ def _case(name):
         mesh.set_basis("Pk")
         prm = dflo_amd.Parameters(flux="hllc", pos_lim=True, cfl=0.5, boundary={0: "slip", 1: "outflow", 2: "inflow"})
         return mesh, prm, problems.sod
+    if name == "pkq1":    # the modal basis on bilinear cells (round 4), LxF: the ghost cells' averages are no longer their mode 0
+        from dflo_amd import gmsh
+        verts, quads, bed, bid = gmsh.unstructured_quads(9, seed=4)
+        mesh = dflo_amd.Mesh.from_quads(verts, quads, bed, bid, 2)
+        mesh.set_basis("Pk")
+        prm = dflo_amd.Parameters(flux="lxf", cfl=0.4, boundary={0: "slip", 1: "outflow", 2: "slip", 3: "inflow"})
+        return mesh, prm, _smooth
     raise KeyError(name)
 
 
@@ -96,7 +103,8 @@ def _run(claw, limited, steps=4, resident=3):
 
 
 CASES = [("c2", 2, "slab"), ("c2", 3, "slab"), ("c2", 4, "rcb"), ("c1", 3, "slab"), ("c3", 2, "slab"), ("c4", 2, "slab"), ("c4", 3, "slab"),
-         ("c5", 2, "rcb"), ("c5", 3, "rcb"), ("kxrcf", 2, "slab"), ("kxrcf", 3, "rcb"), ("pk", 2, "slab")]
+         ("c5", 2, "rcb"), ("c5", 3, "rcb"), ("kxrcf", 2, "slab"), ("kxrcf", 3, "rcb"), ("pk", 2, "slab"),
+         ("pkq1", 2, "rcb"), ("pkq1", 3, "rcb")]
 
 
 @pytest.mark.parametrize("name,n_parts,method", CASES)
@@ -112,6 +120,13 @@ def test_engines_on_one_device_match_the_single_engine(name, n_parts, method):
     assert (owned == np.arange(mesh.n_cells)).all()
     _setup(multi, mesh, ic)
     got = _run(multi, limited)
+    if mesh.basis == "Pk" and not limited and not prm.pos_lim:
+        # (the modal kernel forms the trace of an own cell from its nodal image and the trace of a halo cell from its modes: the
+        #  same number in two roundings, so where the shard rims lie shows in the last digits -- the parts are not bit-identical
+        #  to the single engine, as they are for Qk)
+        assert np.allclose(got["dt"], ref["dt"], rtol=1e-12, atol=0) and abs(got["t"] - ref["t"]) <= 1e-12 * ref["t"]
+        assert rel(got["u"], ref["u"]) < 1e-11 and rel(got["avg"], ref["avg"]) < 1e-12
+        return
     assert got["dt"] == ref["dt"]                 # the minimum of the parts' minima is the global minimum, exactly
     assert got["t"] == ref["t"]                   # ... also when it never leaves the devices
     for (a0, a1), (b0, b1) in zip(got["norms"], ref["norms"]):     # sums over shards: another order, same value to rounding
