@@ -117,6 +117,46 @@ def _settle_clocks(seconds=0.4):
         torch.cuda.synchronize()
 
 
+def live_traffic(args):
+    """HBM bytes per stage-kernel launch from the PMC counters, collected NOW: two short runs of this same command under
+    rocprofv3, FETCH_SIZE and WRITE_SIZE each in its own pass (they cannot share one), no trace domain beside the counters;
+    values in KiB, FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md (calibrated against a known stream in
+    profiles/r02/hbm_calibration.json).  The mean over every stage-kernel dispatch of the counted steps, i.e. first and later
+    stages in the mix of a time step, like `roofline.achieved`.  Returns (bytes, source) or None when rocprofv3 is missing / fails
+    -- the caller then falls back to the constant of profiles/traffic.json and says so."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe) or any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ):   # (already under a profiler: not nested)
+        return None
+    cmd = [sys.executable, os.path.abspath(__file__), "--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--no-secondary",
+           "--no-live-traffic", "--config", args.config, "--nx", str(args.nx), "--degree", str(args.degree), "--flux", args.flux,
+           "--basis", args.basis] + (["--no-tvb"] if args.no_tvb else [])
+    env = dict(os.environ, TMPDIR="/tmp", DFLO_BENCH_NO_PREHEAT="1")
+    kib = {}
+    try:
+        with tempfile.TemporaryDirectory(dir="/tmp") as d:
+            for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+                out = os.path.join(d, ctr)
+                subprocess.run([exe, "--pmc", ctr, "--kernel-include-regex", "stage_kernel", "-d", out, "-o", ctr, "-f", "csv", "--"] + cmd,
+                               cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600, check=True)
+                v = [float(r["Counter_Value"]) for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
+                     for r in csv.DictReader(open(f)) if r["Counter_Name"] == ctr and "stage_kernel" in r["Kernel_Name"]]
+                if not v:
+                    return None
+                kib[ctr] = (sum(v) / len(v), len(v))
+    except Exception as e:   # noqa: BLE001 -- a profiler that is absent, refuses or times out must not cost the bench line
+        print("bench.py: live PMC traffic not collected (%s: %s)" % (type(e).__name__, str(e)[:200]), file=sys.stderr, flush=True)
+        return None
+    total = 2.0 * kib["FETCH_SIZE"][0] * 1024.0 + kib["WRITE_SIZE"][0] * 1024.0
+    return total, ("live: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, no trace domain) around 8 steps of this "
+                   "command in this run; mean of %d / %d stage-kernel dispatches; FETCH_SIZE x2 per the gfx950 correction"
+                   % (kib["FETCH_SIZE"][1], kib["WRITE_SIZE"][1]))
+
+
 def _cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -300,7 +340,9 @@ def main():
     ap.add_argument("--flux", default="hllc")
     ap.add_argument("--basis", default="Qk", choices=["Qk", "Pk"], help="c2 only; Pk: dflo's FE_DGP (modal) element")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the Q1 LxF line (north_star's 40 %-at-Q1 target)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the Q1 LxF line (north_star's 40 %%-at-Q1 target)")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="roofline.traffic from profiles/traffic.json instead of two rocprofv3 --pmc passes of this command (N = 1)")
     ap.add_argument("--parts-per-gpu", type=int, default=1, help="developer switch: this many engines on the one GPU (one-process driver)")
     ap.add_argument("--no-tvb", action="store_true", help="c4 only: positivity limiter alone (BASELINE config 4 as written)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
@@ -410,6 +452,13 @@ def main():
                 traffic_src = rec.get(key, {}).get("source")
             except Exception:
                 traffic = None
+        if world == 1 and args.parts_per_gpu == 1 and not args.no_live_traffic:
+            lt = live_traffic(args)
+            if lt is not None:
+                file_traffic = traffic
+                traffic, traffic_src = lt
+                if file_traffic:
+                    traffic_src += "; profiles/traffic.json holds %.4e for this configuration" % file_traffic
         nx, ny = m["nx"], m["ny"]
         out = {
             "metric": "million DoF-updates/s (explicit RK3, 2D Euler)", "value": value, "unit": "MDoF-updates/s",

@@ -490,8 +490,10 @@ def test_bench_line_contract(extra):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "4", "--warmup", "2", "--no-cpu-baseline", "--no-secondary"] + extra
     if not extra:
-        cmd += ["--nx", "96"]
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
+        cmd += ["--nx", "96"]       # (this one also takes roofline.traffic live: two rocprofv3 --pmc passes of the same command)
+    else:
+        cmd += ["--no-live-traffic"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
@@ -505,4 +507,9 @@ def test_bench_line_contract(extra):
         assert "strong scaling" in d["config"]["workload"] and d["config"]["n_dofs"] == 128 * 128 * 36
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    if not extra:
+        import shutil
+        if shutil.which("rocprofv3") or os.path.exists("/opt/rocm/bin/rocprofv3"):
+            assert str(r["traffic_source"]).startswith("live: rocprofv3 --pmc"), (r["traffic_source"], out.stderr[-800:])
+            assert r["traffic"] > 0
     assert d["value"] > 0 and abs(d["value"] - d["config"]["n_dofs"] * d["config"]["n_rk"] / (d["ms_per_step"] * 1e-3) / 1e6) <= 1e-6 * d["value"]

@@ -6,7 +6,7 @@ cp dflo_amd/libdflo_hip.so /tmp/base.so
 for v in "$@"; do
   if [ "$v" = base ]; then cp /tmp/base.so dflo_amd/libdflo_hip.so; else cp scratch/variants/$v.so dflo_amd/libdflo_hip.so; fi
   OUT=/tmp/abk_$v; rm -rf $OUT
-  ( cd /tmp && rocprofv3 --kernel-trace --stats -d $OUT -o t -f csv -- python $OLDPWD/bench.py --no-cpu-baseline --no-secondary $ARGS ) > /tmp/abk_$v.log 2>&1
+  ( cd /tmp && rocprofv3 --kernel-trace --stats -d $OUT -o t -f csv -- python $OLDPWD/bench.py --no-cpu-baseline --no-secondary --no-live-traffic $ARGS ) > /tmp/abk_$v.log 2>&1
   echo "== $v: $(tail -1 /tmp/abk_$v.log | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'])" 2>/dev/null)"
   python - $OUT <<'PY'
 import csv, glob, sys

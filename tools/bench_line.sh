@@ -1,6 +1,6 @@
 #!/bin/bash
 # usage: tools/bench_line.sh <bench args...>  -> value ms_per_step kernel_ms
-python bench.py --no-cpu-baseline "$@" 2>&1 | tail -1 | python -c "
+python bench.py --no-cpu-baseline --no-live-traffic "$@" 2>&1 | tail -1 | python -c "
 import json,sys
 l=sys.stdin.read()
 try:

@@ -6,8 +6,8 @@ set -u
 TAG=${1:-c2}; shift || true
 # the trace pass runs bench.py with its default --steps/--warmup (the command the bench line comes from, so the
 # kernel's average duration is comparable); the counter passes need only a few launches
-TRACE_ARGS="--no-cpu-baseline $*"
-PMC_ARGS="--steps 6 --warmup 2 --no-cpu-baseline --no-secondary $*"
+TRACE_ARGS="--no-cpu-baseline --no-live-traffic $*"
+PMC_ARGS="--steps 6 --warmup 2 --no-cpu-baseline --no-secondary --no-live-traffic $*"
 OUT=$PWD/gpurun_out/prof/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
