@@ -249,6 +249,16 @@ __device__ __forceinline__ double wave_min_lane63(double v) {
   return v;
 }
 
+// Row offset in the flux table (row * stride).  v_mul_lo_u32 issues at a quarter of the rate of the 24-bit multiply; rows and
+// stride are far inside 24 bits.  Measured (one box, two runs each): Q1 LxF +2.1 %, C3 (Q1 Roe) +1.6 %, Q2 HLLC +-0, P2 +0.4 %,
+// Q3 KFVS -0.6 %, C5 -1.3 % (the scheduler's order changes with it) -- so the 24-bit form at k <= 1 only.
+// row (c N + q) of the table, c a compile-time index, q per lane (k >= 2: the expression the kernels were tuned with, untouched)
+template <int N>
+__device__ __forceinline__ int row_off(int cN, int q, int stride) {
+  if constexpr (N <= 2) return cN * stride + __mul24(q, stride);
+  else return (cN + q) * stride;
+}
+
 // blockIdx -> shard so that every XCD (block b runs on XCD b % 8) sweeps one contiguous run of
 // the Morton-ordered shards: halo re-reads then hit that XCD's own L2.
 // rev: the XCD walks its run backwards -- a launch that sweeps against the previous one starts on the shards that one

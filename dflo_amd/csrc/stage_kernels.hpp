@@ -100,7 +100,7 @@ __device__ __forceinline__ void row_update(const StageArgs &a, double *Us, const
         const double jxw = sgn * CB<N>::t.w[B] * h;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-          const double fq = Fh[(c * N + qq) * HS + k] * jxw;
+          const double fq = Fh[row_off<N>(c * N, qq, HS) + k] * jxw;
 #pragma unroll
           for (int m = 0; m < N; ++m) R[c][m] += fq * ((f & 1) ? CB<N>::t.L1[m] : CB<N>::t.L0[m]);
         }
@@ -111,7 +111,7 @@ __device__ __forceinline__ void row_update(const StageArgs &a, double *Us, const
           const int qq = flip ? N - 1 - q : q;
           const double jxw = sgn * (CB<N>::t.w[q] * lw) * h;
 #pragma unroll
-          for (int c = 0; c < 4; ++c) R[c][q] += Fh[(c * N + qq) * HS + k] * jxw;
+          for (int c = 0; c < 4; ++c) R[c][q] += Fh[row_off<N>(c * N, qq, HS) + k] * jxw;
         }
       }
     }
@@ -264,7 +264,7 @@ __device__ __forceinline__ void row_update_q1(const StageArgs &a, double *Us, co
         const double jxw = sgn * CB<N>::t.w[B] * len;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-          const double fq = Fh[(c * N + qq) * HS + k] * jxw;
+          const double fq = Fh[row_off<N>(c * N, qq, HS) + k] * jxw;
 #pragma unroll
           for (int m = 0; m < N; ++m) R[c][m] += fq * ((f & 1) ? CB<N>::t.L1[m] : CB<N>::t.L0[m]);
         }
@@ -275,7 +275,7 @@ __device__ __forceinline__ void row_update_q1(const StageArgs &a, double *Us, co
           const int qq = flip ? N - 1 - q : q;
           const double jxw = sgn * (CB<N>::t.w[q] * lw) * len;
 #pragma unroll
-          for (int c = 0; c < 4; ++c) R[c][q] += Fh[(c * N + qq) * HS + k] * jxw;
+          for (int c = 0; c < 4; ++c) R[c][q] += Fh[row_off<N>(c * N, qq, HS) + k] * jxw;
         }
       }
     }
@@ -411,7 +411,7 @@ __device__ __forceinline__ void flux_phase(const StageArgs &a, const double *Us,
         }
       } else {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) W[c] = Th[(c * N + qq) * HS + slot - 64];
+        for (int c = 0; c < 4; ++c) W[c] = Th[row_off<N>(c * N, qq, HS) + slot - 64];
         if constexpr (FLUX == DFLO_FLUX_LXF) {
 #pragma unroll
           for (int c = 0; c < 3; ++c) A[c] = Av[c * a.halo_cols + slot - 64];
@@ -450,7 +450,7 @@ __device__ __forceinline__ void flux_phase(const StageArgs &a, const double *Us,
     }
     numerical_normal_flux<FLUX>(nx, ny, Wp, Wm, Ap, Am, F);
 #pragma unroll
-    for (int c = 0; c < 4; ++c) Th[(c * N + qs) * HS + col] = F[c];
+    for (int c = 0; c < 4; ++c) Th[row_off<N>(c * N, qs, HS) + col] = F[c];
   }
 }
 
@@ -619,7 +619,7 @@ __global__ __launch_bounds__(64 * N, N >= 5 ? 1 : ((N == 4 && GEO == 0 && MODE =
           const double fwd = yf ? u[q + N * m] : u[m + N * q], bwd = yf ? u[q + N * (N - 1 - m)] : u[(N - 1 - m) + N * q];
           val[m] = rev ? bwd : fwd;
         }
-        Th[(c * N + q) * HS + sl] = trace_from_line<N>(val);
+        Th[row_off<N>(0, c * N + q, HS) + sl] = trace_from_line<N>(val);
       }
       // the four components of an entry sit in the four lanes of a quad: everybody fetches the other three averages
       const double av = cell_average_rows<N>(u);
@@ -642,7 +642,7 @@ __global__ __launch_bounds__(64 * N, N >= 5 ? 1 : ((N == 4 && GEO == 0 && MODE =
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           const int r = g + 2 * N * j;   // = c * N + q
-          Th[r * HS + sl] = a.Tg[(size_t)ic * 4 * N + r];
+          Th[row_off<N>(0, r, HS) + sl] = a.Tg[(size_t)ic * 4 * N + r];
         }
         continue;
       }
@@ -659,7 +659,7 @@ __global__ __launch_bounds__(64 * N, N >= 5 ? 1 : ((N == 4 && GEO == 0 && MODE =
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const int r = g + 2 * N * j, q = r % N, c = r / N;
-        Th[(c * N + q) * HS + sl] = trace_from_line<N>(val[j]);
+        Th[row_off<N>(c * N, q, HS) + sl] = trace_from_line<N>(val[j]);
       }
     }
   }
@@ -1197,7 +1197,7 @@ __device__ __forceinline__ void row_update_pk(const StageArgs &a, double *Us, co
           const double jxw = sgn * CB<N>::t.w[B] * len;
 #pragma unroll
           for (int c = 0; c < 4; ++c) {
-            const double fq = Fh[(c * N + qq) * HS + k] * jxw;
+            const double fq = Fh[row_off<N>(c * N, qq, HS) + k] * jxw;
 #pragma unroll
             for (int m = 0; m < N; ++m) R[c][m] += fq * ((f & 1) ? CB<N>::t.L1[m] : CB<N>::t.L0[m]);
           }
@@ -1208,7 +1208,7 @@ __device__ __forceinline__ void row_update_pk(const StageArgs &a, double *Us, co
             const int qq = flip ? N - 1 - q : q;
             const double jxw = sgn * (CB<N>::t.w[q] * lw) * len;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) R[c][q] += Fh[(c * N + qq) * HS + k] * jxw;
+            for (int c = 0; c < 4; ++c) R[c][q] += Fh[row_off<N>(c * N, qq, HS) + k] * jxw;
           }
         }
       }
@@ -1267,7 +1267,7 @@ __device__ __forceinline__ void row_update_pk(const StageArgs &a, double *Us, co
         const double jxw = sgn * CB<N>::t.w[B] * h;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-          const double fq = Fh[(c * N + qq) * HS + k] * jxw;
+          const double fq = Fh[row_off<N>(c * N, qq, HS) + k] * jxw;
 #pragma unroll
           for (int m = 0; m < N; ++m) R[c][m] += fq * ((f & 1) ? CB<N>::t.L1[m] : CB<N>::t.L0[m]);
         }
@@ -1278,7 +1278,7 @@ __device__ __forceinline__ void row_update_pk(const StageArgs &a, double *Us, co
           const int qq = flip ? N - 1 - q : q;
           const double jxw = sgn * (CB<N>::t.w[q] * lw) * h;
 #pragma unroll
-          for (int c = 0; c < 4; ++c) R[c][q] += Fh[(c * N + qq) * HS + k] * jxw;
+          for (int c = 0; c < 4; ++c) R[c][q] += Fh[row_off<N>(c * N, qq, HS) + k] * jxw;
         }
       }
     }
@@ -1482,7 +1482,7 @@ __global__ __launch_bounds__(64 * N, N >= 5 ? 1 : (N == 4 ? (((MODE == 0 || (MOD
       double v = 0.0;
 #pragma unroll
       for (int n = 0; n < N; ++n) v += PB<N>::t.Px[q][n] * (f < 2 ? ax[n] : ay[n]);
-      Th[(c * N + q) * HS + sl] = v;
+      Th[row_off<N>(0, c * N + q, HS) + sl] = v;
     }
     if constexpr (LXF) {   // (u, v, c) of the entry's average = its four modes 0, met through the quad
       double A[4], uvc[3];
