@@ -513,3 +513,33 @@ def test_bench_line_contract(extra):
             assert str(r["traffic_source"]).startswith("live: rocprofv3 --pmc"), (r["traffic_source"], out.stderr[-800:])
             assert r["traffic"] > 0
     assert d["value"] > 0 and abs(d["value"] - d["config"]["n_dofs"] * d["config"]["n_rk"] / (d["ms_per_step"] * 1e-3) / 1e6) <= 1e-6 * d["value"]
+
+
+@pytest.mark.parametrize("extra", [[], ["--scaling", "strong"], ["--config", "c3"]])
+def test_bench_line_of_two_ranks_launched_the_drivers_way(extra):
+    """bench.py --gpus 2 as the round driver launches it (python -m torch.distributed.run, one rank per GPU, 127.0.0.1), on this
+    one-GPU box: both ranks on GPU 0 with the host-staged gloo transport (developer switches; RCCL refuses two ranks on one
+    device) -- everything else is the N > 1 path: rendezvous, partition, per-rank initial data, the rank schedule, barriers around the
+    timed region, the maximum over ranks, ONE JSON line from rank 0 with the whole-job value and the per-rank transport record."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    port = 29600 + (os.getpid() + len(extra) * 7) % 300
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--nx", "128"] + extra
+    env = dict(os.environ, DFLO_BENCH_TRANSPORT="gloo", DFLO_BENCH_ONE_GPU="1", DFLO_BENCH_WATCHDOG_S="300", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["scaling"] == ("strong" if "strong" in extra else "weak")
+    c = d["config"]
+    assert c["comm_ranks_seen"] == [2, 2] and sorted(c["comm_rank_seen"]) == [0, 1] and len(c["sec_per_rank"]) == 2
+    assert "gloo" in c["parallelism"] and "cpu_baseline" not in d and "secondary" not in d
+    if "--config" not in extra:
+        n = 128 * 128 * 36 * (1 if "strong" in extra else 2)
+        assert c["n_dofs"] == n
+        drift = float(c["check"].split("=")[-1])
+        assert drift < 1e-12, c["check"]      # the cut faces are evaluated by both ranks with the same bits
+    assert abs(d["value"] - c["n_dofs"] * c["n_rk"] / (d["ms_per_step"] * 1e-3) / 1e6) <= 1e-6 * d["value"]
