@@ -81,5 +81,10 @@ struct Plan {
 
 // Returns DFLO_OK or an error code with a message.
 int build_plan(const dflo_mesh_t &mesh, int shard_ex, int shard_ey, Plan &plan, std::string &err);
+// The cell size a lattice of squares is given (Plan::h) is the smallest x-extent of ITS cells; the extents of a lattice whose
+// coordinates are not dyadic differ in the last bit from cell to cell, so a part of a mesh may find another value than the whole mesh.
+// The multi-device driver hands the whole mesh's value to the plans of its parts through this hint (> 0, for the calling thread):
+// a multi-part run then carries the bits of the single engine on any lattice, not only on dyadic ones.
+extern thread_local double plan_h_hint;
 
 }  // namespace dflo

@@ -1,0 +1,215 @@
+"""Randomised differential test of the multi-device driver against the single engine (both on the device): random meshes of a
+few hundred to a few thousand cells (squares / skewed bilinear cells / unstructured quadrilaterals), degrees, fluxes, bases,
+boundary kinds, limiter and indicator settings, 2-4 parts cut as x-slabs or RCB blocks on ONE device (the exchange machinery --
+traces / averages / whole cells across the cuts, the rim || interior schedule, the ring for TVB, the device-side minimum of the
+time step -- is the same as with one part per GPU), host-driven steps followed by device-resident ones.
+usage: python tools/fuzz_multi.py [n_cases] [seed] [max_degree = 3]     (GPU box; prints the failing configurations)
+
+Bars: a ghost copy holds the bits of its owner and a cut face is evaluated by both parts with the same bits, so WITHOUT limiters the
+Qk runs must agree bit for bit (np.array_equal) -- anything else fails (Pk: 1e-13, see below); with a limiter in play (discrete minmod / positivity
+switches on kinked data) the states to 1e-8 and the time steps to 1e-9 (the bars of tests/test_gpu_multi_large.py); guard stops
+(src/positivity.cc:26-38, 160-169) must come from both in the same step.  What this replaces: update_ghost_values
+(src_mpi/claw.cc:793, src_mpi/limiter.cc:232), Utilities::MPI::min (src_mpi/claw.cc:579)."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import dflo_amd
+from dflo_amd import problems, gmsh
+
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+max_degree = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+rng = np.random.default_rng(seed)
+KINDS = ["inflow", "outflow", "slip", "pressure", "farfield"]
+ONLY = set(int(k) for k in os.environ.get("FUZZ_CASES", "").split(",") if k)
+HOST_STEPS, RESIDENT = 2, 5
+
+
+def rel(a, b):
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+def make_case(i):
+    degree = int(rng.integers(0, max_degree + 1))
+    flux = str(rng.choice(["lxf", "sw", "kfvs", "roe", "hllc"]))
+    geo = str(rng.choice(["cart", "cart", "skew", "unstr"]))
+    basis = "Pk" if rng.random() < 0.2 else "Qk"
+    tvb = geo == "cart" and rng.random() < 0.5
+    pos = rng.random() < 0.5
+    gravity = float(rng.choice([0.0, 0.0, 0.4]))
+    M = float(rng.choice([0.0, 1.0, 50.0]))
+    char_lim = bool(rng.random() < 0.6)
+    periodic = geo == "cart" and rng.random() < 0.4
+    n_parts = int(rng.integers(2, 5))
+    part = str(rng.choice(["slab", "rcb"]))
+    desc = dict(i=i, degree=degree, flux=flux, geo=geo, basis=basis, tvb=tvb, pos=pos, gravity=gravity, M=M, char_lim=char_lim,
+                periodic=periodic, parts=n_parts, partitioner=part)
+    if geo == "cart":
+        nx, ny = int(rng.integers(12, 97)), int(rng.integers(8, 73))
+        h = 1.0 / max(nx, ny)
+        side = [-1] * 4 if periodic else [int(b) for b in rng.integers(0, 4, 4)]
+        if not periodic and rng.random() < 0.3:
+            side[0] = side[1] = -1
+        if not periodic and rng.random() < 0.3:
+            side[2] = side[3] = -1
+        mesh = dflo_amd.Mesh.cartesian(nx, ny, 0.0, 0.0, h, side, degree)
+        desc.update(nx=nx, ny=ny, side=side)
+    elif geo == "skew":
+        n = int(rng.integers(10, 41))
+        from test_gpu_parity import skewed_mesh
+        mesh = skewed_mesh(n, degree)
+        desc.update(n=n)
+    else:
+        n = int(rng.integers(5, 15))
+        verts, quads, bed, bid = gmsh.unstructured_quads(n, seed=int(rng.integers(0, 100)))
+        mesh = dflo_amd.Mesh.from_quads(verts, quads, bed, bid, degree)
+        desc.update(n=n)
+    mesh.set_basis(basis)
+    bnd = {b: str(rng.choice(KINDS)) for b in range(4)}
+    indicator = str(rng.choice(["limiter", "limiter", "density", "energy"])) if tvb else "limiter"
+    desc.update(indicator=indicator, cells=mesh.n_cells)
+    prm = dflo_amd.Parameters(flux=flux, limiter="TVB" if tvb else "none", char_lim=char_lim, pos_lim=pos, M=M, beta=float(rng.choice([1.0, 1.5, 2.0])),
+                              boundary=bnd, cfl=0.5, gravity=gravity, shock_indicator=indicator)
+    ic = lambda x, y: problems.smooth_perturbation(x, y, L=1.0)
+    u0 = mesh.project(ic) if basis == "Pk" else mesh.interpolate(ic)
+    kink = 0.0
+    if rng.random() < 0.5:   # kinks, so that the limiters have work (also across the cuts)
+        u = u0.reshape(mesh.n_cells, 4, -1).copy()
+        k = rng.integers(0, mesh.n_cells, max(1, mesh.n_cells // 6))
+        kink = float(rng.choice([0.3, 1.0]))
+        u[k, 2] *= 1.0 + kink * rng.random((len(k), 1))
+        u[k, 3] *= 1.0 + kink * rng.random((len(k), 1))
+        u0 = u.reshape(-1)
+    desc.update(kink=kink)
+    return dict(desc=desc, mesh=mesh, prm=prm, bnd=bnd, ic=ic, u0=u0)
+
+
+def setup(case, claw):
+    cell, face, bid, xy = claw.boundary_faces()
+    if len(cell):
+        bv = np.stack(case["ic"](xy[..., 0], xy[..., 1]), axis=-1)
+        bv[..., 3] = np.where(np.array([case["bnd"][int(b)] == "pressure" for b in bid])[:, None], 1.0, bv[..., 3])
+        claw.set_boundary_values(0, bv)
+        claw.set_boundary_values(1, bv)
+    claw.set_initial_condition(case["u0"])
+
+
+def run(case, claw):
+    """(list of time steps, time after the resident steps, state, averages, (step, code) of a guard stop or None)"""
+    d = case["desc"]
+    out = {"dt": [], "stop": None, "t": None}
+    try:
+        if d["tvb"] or d["pos"]:
+            claw.apply_limiter()
+        for it in range(HOST_STEPS):
+            dt = claw.compute_time_step()
+            out["dt"].append(dt)
+            claw.iterate_explicit(dt)
+        out["t"] = claw.advance(RESIDENT)
+    except dflo_amd.DfloError as e:
+        if e.code in (-3, -4):
+            out["stop"] = (len(out["dt"]), e.code)
+        else:
+            raise
+    out["u"] = claw.current_solution
+    out["avg"] = claw.cell_average
+    return out
+
+
+class Fail(Exception):
+    pass
+
+
+last = {}
+
+
+def one(i):
+    case = make_case(i)
+    d = case["desc"]
+    last.clear()
+    last.update(d)
+    if ONLY and i not in ONLY:
+        return "skipped"
+    try:
+        single = dflo_amd.ConservationLaw(case["mesh"], case["prm"])
+    except dflo_amd.DfloError as e:
+        if e.code in (-7, -1):
+            return "refused"
+        raise
+    try:
+        multi = dflo_amd.MultiConservationLaw(case["mesh"], case["prm"], devices=[0] * d["parts"], partitioner=d["partitioner"])
+    except dflo_amd.DfloError as e:
+        single.close()
+        if e.code in (-7, -1):
+            return "refused (multi: %s)" % str(e)[:60]
+        raise
+    try:
+        setup(case, single)
+        setup(case, multi)
+        a, b = run(case, single), run(case, multi)
+    finally:
+        single.close()
+        multi.close()
+    limited = d["tvb"] or d["pos"]
+    if a["stop"] or b["stop"]:
+        if a["stop"] is None or b["stop"] is None:
+            raise Fail(("stop", a["stop"], b["stop"]))
+        if a["stop"][1] != b["stop"][1] or abs(a["stop"][0] - b["stop"][0]) > (1 if limited else 0):
+            raise Fail(("stop", a["stop"], b["stop"]))
+        return "stop"
+    fa, fb = np.isfinite(a["u"]), np.isfinite(b["u"])
+    if not fa.all() or not fb.all():
+        if (fa != fb).any():
+            raise Fail(("nan pattern", int((~fa).sum()), int((~fb).sum())))
+        if limited:
+            return "nan"
+        e = rel(a["u"][fa], b["u"][fa]) if fa.any() else 0.0
+        if e > (1e-13 if d["basis"] == "Pk" else 0.0):     # (Pk: last bits move with the cut into shards, see below)
+            raise Fail(("finite cells beside NaNs differ", e))
+        return "nan"
+    if not limited and d["basis"] == "Pk":
+        # the modal basis: a neighbour inside the shard gives its trace through its nodal values, one outside through its modes on
+        # the face -- the same polynomial in another order of summation -- so another cut of the mesh into shards moves last bits
+        e = rel(b["u"], a["u"])
+        edt = max(abs(x - y) / x for x, y in zip(a["dt"], b["dt"]))
+        if e > 1e-13 or edt > 1e-13 or abs(a["t"] - b["t"]) > 1e-13 * a["t"]:
+            raise Fail(("modal basis, no limiter", e, edt))
+        return "identical" if e == 0.0 else "rounding"
+    if not limited:
+        if not (np.array_equal(a["u"], b["u"]) and a["dt"] == b["dt"] and a["t"] == b["t"]):
+            raise Fail(("not bit-identical", rel(b["u"], a["u"]), [abs(x - y) / x for x, y in zip(a["dt"], b["dt"])], a["t"], b["t"]))
+        return "identical"
+    e, ea = rel(b["u"], a["u"]), rel(b["avg"], a["avg"])
+    edt = max(abs(x - y) / x for x, y in zip(a["dt"], b["dt"]))
+    et = abs(a["t"] - b["t"]) / a["t"]
+    if e > 1e-8 or ea > 1e-9 or edt > 1e-9 or et > 1e-9:
+        raise Fail(("limited run", e, ea, edt, et))
+    if e == 0.0 and edt == 0.0 and et == 0.0:
+        return "identical"
+    close.append((e, ea, edt, i, d["basis"], d["tvb"], d["pos"], d["indicator"], d["degree"], d["geo"], d["kink"]))
+    return "close"
+
+
+close = []
+counts, fails, worst = {}, 0, 0.0
+t0 = time.time()
+for i in range(n_cases):
+    try:
+        r = one(i)
+    except Fail as f:
+        fails += 1
+        r = "FAIL"
+        print("CASE %d FAILED: %s  %s" % (i, f.args[0], last), flush=True)
+    counts[r.split(" ")[0]] = counts.get(r.split(" ")[0], 0) + 1
+if close:
+    close.sort(reverse=True)
+    print("limited runs that are not bit-identical: %d; largest state / average / dt differences %.2e / %.2e / %.2e; above 1e-12: %d" % (
+        len(close), close[0][0], max(c[1] for c in close), max(c[2] for c in close), sum(1 for c in close if c[0] > 1e-12)))
+    qk = [c for c in close if c[4] == "Qk"]
+    print("   of them on the nodal basis: %d%s" % (len(qk), "; largest %.2e (case %d)" % (qk[0][0], qk[0][3]) if qk else ""))
+    for c in close[:4] + qk[:4]:
+        print("   state %.2e avg %.2e dt %.2e  case %d %s tvb=%s pos=%s indicator=%s degree %d %s kink %.1f" % c)
+print("%d cases, %d failures, outcomes %s, %.1f s" % (n_cases, fails, counts, time.time() - t0))
+sys.exit(1 if fails else 0)
