@@ -305,3 +305,14 @@ def test_random_configurations_in_parts_against_the_single_engine():
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "200 cases, 0 failures" in r.stdout
     assert "of them on the nodal basis: 0" in r.stdout or "limited runs that are not bit-identical" not in r.stdout
+
+
+def test_random_switch_settings_give_the_same_bits():
+    """tools/fuzz_switches.py: 150 random configurations, each with the defaults and with 1-4 random run-time switches of
+    tunables.h thrown (one engine or 2-4 parts): bit-identical, but for the two switches that are not bit-neutral by construction
+    (DFLO_FUSE_POS=0: 1e-13; the average handed to the caller on bilinear cells: 1e-15)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_switches.py"), "150", "41"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "150 cases, 0 failures" in r.stdout
