@@ -69,3 +69,12 @@ def test_ranks_on_one_device_match_the_single_engine(name, world):
         assert ret["equal"], ret["err"]                      # smooth data: bit-identical to the single engine
     else:
         assert ret["err"] < 1e-8
+
+
+def test_random_configurations_on_two_ranks():
+    """tools/fuzz_ranks.py: two processes walk 40 random configurations together (one engine per process, gloo callbacks); nodal
+    basis bit-identical to the single engine, modal basis to 1e-13, the ranks agree on every time step and stop."""
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_ranks.py"), "40", "61", "2"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "40 cases on 2 ranks, 0 failures" in r.stdout
