@@ -74,9 +74,12 @@ for i in range(n_cases):
     b = run_with(case, parts, env)
     bar = 1e-13 if (d["basis"] == "Pk" and (RESHARD & set(env))) else 0.0
     bar_avg = bar
-    # Two switches are not bit-neutral, by construction:
-    #  * DFLO_FUSE_POS=0 runs the positivity limiter as a pass that reads the stored cell average; inside the stage kernel it forms the
-    #    average from the row partials still in LDS -- the same sum in another order, so theta moves in the last bit (state: 1e-13);
+    # Two switches are not bit-neutral:
+    #  * DFLO_FUSE_POS=0 selects ANOTHER INSTANTIATION of the stage kernel (POS 0 + the limiter pass instead of POS 1).  hipcc's
+    #    default -ffp-contract=fast fuses multiply-adds across statements wherever the optimiser sees them, and it sees them
+    #    differently in the two instantiations: states move by 1-5e-16 even when the limiter changes nothing (measured: with
+    #    -ffp-contract=on, fusing only what one source expression spells, the switch is bit-neutral -- at -0.5 % (Q3 KFVS) to
+    #    -1.8 % (C5), so the default stays; profiles/LAB.md R4.11);
     #  * on bilinear cells an average formed on demand (average_kernel: weights w w det J / |K| per node) and one stored by a stage
     #    epilogue (row partials, 1 / |K| at the end) differ in the last bit; DFLO_LAZY_AVG=0 / DFLO_FUSE_POS=0 change which of the two
     #    the caller is handed (the state does not see it).  On squares the two are the same bits (average_rows_kernel).
