@@ -33,6 +33,7 @@ rng = np.random.default_rng(seed)
 KINDS = ["inflow", "outflow", "slip", "pressure", "farfield"]
 VERBOSE = os.environ.get("FUZZ_VERBOSE") == "1"
 N_PERT = int(os.environ.get("FUZZ_NPERT", "4"))   # perturbed oracle runs behind every classification (a knife edge need not flip under ONE random perturbation)
+SCALE = int(os.environ.get("FUZZ_SCALE", "1"))   # FUZZ_SCALE=3: meshes 9 x as large (shards of every lattice pattern, interior shards)
 GUARDS = (-3, -4)   # negative mean state / positivity root failure: the reference's own stops
 
 
@@ -94,7 +95,7 @@ def make_case(i):
     desc = dict(i=i, degree=degree, flux=flux, geo=geo, basis=basis, tvb=tvb, pos=pos, local=local, gravity=gravity, M=M,
                 char_lim=char_lim, periodic=periodic)
     if geo == "cart":
-        nx, ny = int(rng.integers(1, 23)), int(rng.integers(1, 19))
+        nx, ny = SCALE * int(rng.integers(1, 23)), SCALE * int(rng.integers(1, 19))
         h = 1.0 / max(nx, ny)
         side = [-1] * 4 if periodic else [int(b) for b in rng.integers(0, 4, 4)]
         if not periodic and rng.random() < 0.3:
@@ -104,12 +105,12 @@ def make_case(i):
         mesh = dflo_amd.Mesh.cartesian(nx, ny, 0.0, 0.0, h, side, degree)
         desc.update(nx=nx, ny=ny, side=side)
     elif geo == "skew":
-        n = int(rng.integers(3, 13))
+        n = SCALE * int(rng.integers(3, 13))
         from test_gpu_parity import skewed_mesh
         mesh = skewed_mesh(n, degree)
         desc.update(n=n)
     else:
-        n = int(rng.integers(3, 10))
+        n = SCALE * int(rng.integers(3, 10))
         verts, quads, bed, bid = gmsh.unstructured_quads(n, seed=int(rng.integers(0, 100)))
         mesh = dflo_amd.Mesh.from_quads(verts, quads, bed, bid, degree)
         desc.update(n=n)
