@@ -326,3 +326,38 @@ def test_mesh_flattening_against_an_independent_derivation(kind):
         assert (-1 - got[c[:, 0], 0] == 5).all() and (-1 - got[c[:, -1], 1] == 6).all()
         assert (-1 - got[c[0, :], 2] == 7).all() and (-1 - got[c[-1, :], 3] == 8).all()
         assert (got[c[:, 1:], 0] == c[:, :-1]).all() and (got[c[1:, :], 2] == c[:-1, :]).all()
+
+
+def test_dealii_adaptor_calls_match_the_c_abi():
+    """include/dflo_hip_dealii.hpp cannot be compiled here (it needs deal.II), so at least every dflo_* entry point it calls has
+    to exist in include/dflo_hip.h with the number of arguments it is called with -- the header moves on, the adaptor must follow."""
+    h = open(os.path.join(ROOT, "include", "dflo_hip.h")).read()
+    a = open(os.path.join(ROOT, "include", "dflo_hip_dealii.hpp")).read()
+    a = re.sub(r"//[^\n]*", "", a)
+    a = re.sub(r"/\*.*?\*/", "", a, flags=re.S)
+    protos = {}
+    for m in re.finditer(r"\b(?:int|int32_t|const char \*|void|double)\s*(dflo_(?:hip|mesh)_\w+)\s*\(([^;{]*?)\)\s*;", h, re.S):
+        args = m.group(2).strip()
+        protos[m.group(1)] = 0 if args in ("", "void") else args.count(",") + 1
+
+    def n_args(txt):
+        depth, n = 0, 1 if txt.strip() else 0
+        for ch in txt:
+            if ch in "([{":
+                depth += 1
+            elif ch in ")]}":
+                depth -= 1
+            elif ch == "," and depth == 0:
+                n += 1
+        return n
+
+    calls = 0
+    for m in re.finditer(r"\b(dflo_(?:hip|mesh)_\w+)\s*\(", a):
+        i, depth = m.end(), 1
+        while depth and i < len(a):
+            depth += {"(": 1, ")": -1}.get(a[i], 0)
+            i += 1
+        assert m.group(1) in protos, "%s is not declared in dflo_hip.h" % m.group(1)
+        assert protos[m.group(1)] == n_args(a[m.end():i - 1]), "%s: %d argument(s) declared" % (m.group(1), protos[m.group(1)])
+        calls += 1
+    assert calls >= 30
