@@ -157,6 +157,16 @@ def live_traffic(args):
                    % (kib["FETCH_SIZE"][1], kib["WRITE_SIZE"][1]))
 
 
+def _timing_interval(steps, n_rk):
+    """Every how-manieth stage launch is bracketed by HIP events: a timed launch costs its stream a few microseconds of bubbles
+    (two timed event records), so a long run samples sparsely -- about 48 launches, every 5th at least, an interval coprime to the 2
+    or 3 stages of a step so that first and later stages are timed in the mix of a step."""
+    if os.environ.get("DFLO_BENCH_TIMING_EVERY"):   # developer switch
+        return int(os.environ["DFLO_BENCH_TIMING_EVERY"])
+    want = max(5, min(49, steps * n_rk // 48))
+    return max(k for k in (5, 7, 11, 13, 17, 19, 23, 25, 29, 31, 35, 37, 41, 43, 47, 49) if k <= want)
+
+
 def _cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -235,7 +245,7 @@ def run_parts(args, claw, mesh, ic, bc_fn, programs, nx, ny):
     mass0 = claw.cell_average.sum(axis=0)
     _settle_clocks()
     claw.advance(args.warmup)
-    claw.stage_timing(os.environ.get("DFLO_BENCH_NO_STAGE_TIMING") != "1")
+    claw.stage_timing(0 if os.environ.get("DFLO_BENCH_NO_STAGE_TIMING") == "1" else _timing_interval(args.steps, claw.n_rk))
     claw.exchange_timing(True)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -305,7 +315,7 @@ def run_case(args, world, rank, local_rank, uid, barrier):
     mass0 = claw.cell_average[own].sum(axis=0)
     _settle_clocks()
     claw.advance(args.warmup)
-    claw.stage_timing(True)
+    claw.stage_timing(_timing_interval(args.steps, claw.n_rk))
     claw.exchange_timing(True)
     barrier()
     torch.cuda.synchronize()

@@ -81,6 +81,7 @@ struct dflo_hip_engine {
   int st_in = 0, st_old = 0, st_out = 0, st_avg_in = 0, st_rk = 0, st_which = 0;
   double st_dt = -1.0;
   int64_t t_stages = 0, t_seen = 0;   // stages timed / stages seen while timing is on
+  int t_every = 5;                    // every t_every-th stage is timed (dflo_hip_stage_timing)
   bool t_sample = false;
   int32_t *d_rim_list = nullptr, *d_int_list = nullptr, *d_rim2_list = nullptr, *d_rest2_list = nullptr;
   double pending_dt = -1.0;
@@ -315,7 +316,7 @@ int open_stage(dflo_hip_engine *h, int rk, double dt_host, bool residual_only, i
     h->fin_done = false;
     // stage timing samples every fifth stage (5 is coprime to the 2 or 3 stages of a step, so every stage of the
     // step is sampled equally often): two event records per launch are not free
-    h->t_sample = h->timing && (h->t_seen++ % 5 == 0);
+    h->t_sample = h->timing && (h->t_seen++ % h->t_every == 0);
     if (h->t_sample) ++h->t_stages;
   }
   return DFLO_OK;
@@ -1545,6 +1546,9 @@ int dflo_hip_stage_timing(dflo_hip_handle h, int enable, double *avg_ms, int64_t
   h->t_seen = 0;
   h->t_sample = false;
   h->timing = enable != 0;
+  // enable > 1: sample every enable-th stage (coprime to 2 and 3 keeps the stages of a step equally represented); 1: every fifth.
+  // A sampled launch sits between two timed event records and costs its stream ~7 us of bubbles: a long run samples sparsely.
+  h->t_every = enable > 1 ? enable : 5;
   return DFLO_OK;
 }
 

@@ -231,8 +231,9 @@ int dflo_hip_positivity_stats(dflo_hip_handle h, int64_t *counts, int reset);
 int dflo_hip_synchronize(dflo_hip_handle h);
 
 /* Average duration (ms) of the stage kernel launches since the last reset, measured with HIP events on the
- * engine's stream. Every fifth stage is timed (each stage of a 2- or 3-stage step equally often, and the event
- * records stay out of the way of the others); n receives the number of timed stages. */
+ * engine's stream. enable = 1: every fifth stage is timed (each stage of a 2- or 3-stage step equally often, and the event
+ * records stay out of the way of the others); enable = k > 1: every k-th (choose k coprime to 2 and 3; a timed launch costs
+ * its stream a few microseconds of bubbles, so a long run samples sparsely); n receives the number of timed stages. */
 int dflo_hip_stage_timing(dflo_hip_handle h, int enable, double *avg_ms, int64_t *n);
 
 /* ------------------------------------------------ multi-device halo seam */
