@@ -142,7 +142,7 @@ def live_traffic(args):
             for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
                 out = os.path.join(d, ctr)
                 subprocess.run([exe, "--pmc", ctr, "--kernel-include-regex", "stage_kernel", "-d", out, "-o", ctr, "-f", "csv", "--"] + cmd,
-                               cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600, check=True)
+                               cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=150, check=True)
                 v = [float(r["Counter_Value"]) for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
                      for r in csv.DictReader(open(f)) if r["Counter_Name"] == ctr and "stage_kernel" in r["Kernel_Name"]]
                 if not v:
