@@ -361,3 +361,13 @@ def test_dealii_adaptor_calls_match_the_c_abi():
         assert protos[m.group(1)] == n_args(a[m.end():i - 1]), "%s: %d argument(s) declared" % (m.group(1), protos[m.group(1)])
         calls += 1
     assert calls >= 30
+
+
+def test_developer_tools_compile():
+    """tools/*.py (fuzzers, probes, profile digests) are not imported by any CPU test: at least they have to parse."""
+    import glob
+    import py_compile
+    files = sorted(glob.glob(os.path.join(ROOT, "tools", "*.py"))) + [os.path.join(ROOT, "bench.py"), os.path.join(ROOT, "__graft_entry__.py")]
+    assert len(files) > 10
+    for f in files:
+        py_compile.compile(f, doraise=True, cfile=os.devnull)
