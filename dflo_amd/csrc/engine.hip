@@ -766,6 +766,12 @@ extern "C" {
 const char *dflo_hip_last_error(dflo_hip_handle h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 
 int dflo_hip_create(const dflo_mesh_t *mesh, const dflo_params_t *params, int device_id, dflo_hip_handle *out) {
+  return dflo_hip_create_with_cell_size(mesh, params, device_id, out, 0.0);
+}
+
+}  // extern "C"
+
+int dflo_hip_create_with_cell_size(const dflo_mesh_t *mesh, const dflo_params_t *params, int device_id, dflo_hip_handle *out, double h_hint) {
   if (!mesh || !params || !out) { g_create_error = "null argument"; return DFLO_ERR_BAD_PARAM; }
   *out = nullptr;
   // consistency checks of the reference's parameter parsing (src/parameters.cc:536-550)
@@ -815,7 +821,7 @@ int dflo_hip_create(const dflo_mesh_t *mesh, const dflo_params_t *params, int de
   h->ndof = 4 * h->ns;
   h->mapping = mesh->mapping == DFLO_MAP_Q2 ? DFLO_MAP_Q1 : mesh->mapping;
   h->geo = mesh->mapping == DFLO_MAP_CARTESIAN ? 0 : 1;
-  int rc = build_plan(*mesh, 8, 8, h->plan, h->err);
+  int rc = build_plan(*mesh, 8, 8, h->plan, h->err, h_hint);
   if (rc) { g_create_error = h->err; delete h; return rc; }
   h->bt = make_basis(h->degree);
   h->kb = make_kbasis(h->bt);
@@ -1047,6 +1053,8 @@ int dflo_hip_create(const dflo_mesh_t *mesh, const dflo_params_t *params, int de
   *out = h;
   return DFLO_OK;
 }
+
+extern "C" {
 
 int dflo_hip_destroy(dflo_hip_handle h) {
   if (!h) return DFLO_OK;

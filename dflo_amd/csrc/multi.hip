@@ -930,15 +930,13 @@ int setup_part(dflo_hip_multi *m, Part &p, const dflo_mesh_t *mesh, const dflo_p
   p.n_send = p.send_off[m->n_parts];
   for (int q = 0; q < m->n_parts; ++q)
     if (q != p.index && (p.send_off[q + 1] > p.send_off[q] || p.recv_off[q + 1] > p.recv_off[q])) p.peers.push_back(q);
-  {   // the cell size of a lattice of squares as the single engine's plan would find it on the whole mesh (plan.h: plan_h_hint)
+  {   // the cell size of a lattice of squares as the single engine's plan would find it on the whole mesh (plan.h: build_plan's h_hint)
     double hmin = 0.0;
     if (mesh->mapping == DFLO_MAP_CARTESIAN) {
       hmin = 1.0e300;
       for (int32_t c = 0; c < mesh->n_cells; ++c) hmin = std::min(hmin, mesh->cell_vertices[(size_t)c * 8 + 2] - mesh->cell_vertices[(size_t)c * 8]);
     }
-    dflo::plan_h_hint = hmin;
-    rc = dflo_hip_create(p.sub, prm, p.device, &p.eng);
-    dflo::plan_h_hint = 0.0;
+    rc = dflo_hip_create_with_cell_size(p.sub, prm, p.device, &p.eng, hmin);
   }
   if (rc) { m->err = dflo_hip_last_error(nullptr); return rc; }
   MHIP(m, hipSetDevice(p.device));

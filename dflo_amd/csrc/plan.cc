@@ -11,7 +11,6 @@
 #include <unordered_map>
 
 namespace dflo {
-thread_local double plan_h_hint = 0.0;
 namespace {
 
 // index of (x, y) along the Hilbert curve of a 2^order x 2^order lattice: consecutive indices are always
@@ -45,7 +44,7 @@ inline uint64_t morton2(uint32_t x, uint32_t y) {
 
 }  // namespace
 
-int build_plan(const dflo_mesh_t &mesh, int shard_ex, int shard_ey, Plan &p, std::string &err) {
+int build_plan(const dflo_mesh_t &mesh, int shard_ex, int shard_ey, Plan &p, std::string &err, double h_hint) {
   const int n = mesh.n_cells;
   const int n_owned = mesh.n_owned_cells > 0 ? mesh.n_owned_cells : n;
   if (n < 1 || n_owned > n) { err = "bad cell counts"; return DFLO_ERR_BAD_PARAM; }
@@ -81,7 +80,7 @@ int build_plan(const dflo_mesh_t &mesh, int shard_ex, int shard_ey, Plan &p, std
   }
   p.uniform_h = mesh.mapping == DFLO_MAP_CARTESIAN && (hmax - hmin) <= 1e-10 * hmax;
   p.h = hmin;
-  if (p.uniform_h && plan_h_hint > 0.0 && std::fabs(plan_h_hint - hmin) <= 1e-10 * hmax) p.h = plan_h_hint;   // the whole mesh's (plan.h)
+  if (p.uniform_h && h_hint > 0.0 && std::fabs(h_hint - hmin) <= 1e-10 * hmax) p.h = h_hint;   // the whole mesh's (plan.h)
 
   // ---- assign owned cells to shards
   std::vector<int32_t> shard_of(n, -1), local_of(n, -1);

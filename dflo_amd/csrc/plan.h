@@ -80,11 +80,14 @@ struct Plan {
 };
 
 // Returns DFLO_OK or an error code with a message.
-int build_plan(const dflo_mesh_t &mesh, int shard_ex, int shard_ey, Plan &plan, std::string &err);
-// The cell size a lattice of squares is given (Plan::h) is the smallest x-extent of ITS cells; the extents of a lattice whose
-// coordinates are not dyadic differ in the last bit from cell to cell, so a part of a mesh may find another value than the whole mesh.
-// The multi-device driver hands the whole mesh's value to the plans of its parts through this hint (> 0, for the calling thread):
-// a multi-part run then carries the bits of the single engine on any lattice, not only on dyadic ones.
-extern thread_local double plan_h_hint;
+// h_hint > 0: the cell size to give a lattice of squares (Plan::h).  By itself the plan takes the smallest x-extent of ITS cells;
+// the extents of a lattice whose coordinates are not dyadic differ in the last bit from cell to cell, so the plan of a part of a
+// mesh may find another value than the plan of the whole mesh.  The multi-device driver hands the whole mesh's value to the plans
+// of its parts (create_engine below): a multi-part run then carries the bits of the single engine on any lattice.
+int build_plan(const dflo_mesh_t &mesh, int shard_ex, int shard_ey, Plan &plan, std::string &err, double h_hint = 0.0);
 
 }  // namespace dflo
+
+// dflo_hip_create with the cell size of the undivided mesh (engine.hip; the C ABI entry passes 0: the mesh's own)
+struct dflo_hip_engine;
+int dflo_hip_create_with_cell_size(const dflo_mesh_t *mesh, const dflo_params_t *params, int device_id, dflo_hip_engine **out, double h_hint);

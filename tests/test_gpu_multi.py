@@ -298,7 +298,7 @@ def test_random_configurations_in_parts_against_the_single_engine():
     """tools/fuzz_multi.py: 200 random configurations (mesh kind and size, degree, basis, flux, boundary kinds, limiter and
     indicator switches, rough or smooth data) cut into 2-4 parts as slabs or RCB blocks, host-driven and device-resident steps:
     on the nodal basis the parts carry the bits of the single engine on any lattice (the parts' plans take the whole mesh's cell
-    size, plan.h: plan_h_hint), on the modal basis they agree to rounding (1e-13)."""
+    size, plan.h: build_plan's h_hint), on the modal basis they agree to rounding (1e-13)."""
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_multi.py"), "200", "21"], capture_output=True, text=True, timeout=900)
