@@ -72,9 +72,17 @@ def make_case(i):
     bnd = {b: str(rng.choice(KINDS)) for b in range(4)}
     indicator = str(rng.choice(["limiter", "limiter", "density", "energy"])) if tvb else "limiter"
     desc.update(indicator=indicator, cells=mesh.n_cells)
+    # the rules of compute_time_step (src/claw.cc:455-476) in the device-resident loop: a cap on the step, a final time inside the
+    # run (the last step is cut, the ones behind it are empty), and the stage count overridden
+    time_step = float(10.0 ** rng.uniform(-4.0, -2.0)) if rng.random() < 0.2 else 0.0
+    final_time = float(10.0 ** rng.uniform(-3.0, -1.5)) if (rng.random() < 0.2 and not local) else 1.0e20
+    n_rk = int(rng.integers(1, 4)) if rng.random() < 0.1 else 0
+    cam = bool(basis == "Pk" and tvb and rng.random() < 0.5)
+    desc.update(time_step=time_step, final_time=final_time, n_rk=n_rk, cam=cam)
     prm = dflo_amd.Parameters(flux=flux, limiter="TVB" if tvb else "none", char_lim=char_lim, pos_lim=pos, M=M, beta=float(rng.choice([1.0, 1.5, 2.0])),
                               boundary=bnd, cfl=0.5, gravity=gravity, shock_indicator=indicator,
-                              time_step_type="local" if local else "global")
+                              time_step_type="local" if local else "global", time_step=time_step, final_time=final_time, n_rk=n_rk,
+                              conserve_angular_momentum=cam)
     ic = lambda x, y: problems.smooth_perturbation(x, y, L=1.0)
     u0 = mesh.project(ic) if basis == "Pk" else mesh.interpolate(ic)
     kink = 0.0
@@ -178,7 +186,7 @@ def one(i):
         # the modal basis: a neighbour inside the shard gives its trace through its nodal values, one outside through its modes on
         # the face -- the same polynomial in another order of summation -- so another cut of the mesh into shards moves last bits
         e = rel(b["u"], a["u"])
-        edt = max(abs(x - y) / x for x, y in zip(a["dt"], b["dt"]))
+        edt = max([abs(x - y) / max(abs(x), 1e-300) for x, y in zip(a["dt"], b["dt"])] + [0.0])
         if e > 1e-13 or edt > 1e-13 or abs(a["t"] - b["t"]) > 1e-13 * abs(a["t"]):
             raise Fail(("modal basis, no limiter", e, edt))
         return "identical" if e == 0.0 else "rounding"
@@ -187,7 +195,7 @@ def one(i):
             raise Fail(("not bit-identical", rel(b["u"], a["u"]), [abs(x - y) / x for x, y in zip(a["dt"], b["dt"])], a["t"], b["t"]))
         return "identical"
     e, ea = rel(b["u"], a["u"]), rel(b["avg"], a["avg"])
-    edt = max(abs(x - y) / x for x, y in zip(a["dt"], b["dt"]))
+    edt = max([abs(x - y) / max(abs(x), 1e-300) for x, y in zip(a["dt"], b["dt"])] + [0.0])
     et = abs(a["t"] - b["t"]) / a["t"] if a["t"] else 0.0
     if e > 1e-8 or ea > 1e-9 or edt > 1e-9 or et > 1e-9:
         raise Fail(("limited run", e, ea, edt, et))

@@ -118,8 +118,19 @@ def make_case(i):
     bnd = {b: str(rng.choice(KINDS)) for b in range(4)}
     indicator = str(rng.choice(["limiter", "limiter", "density", "energy"])) if tvb else "limiter"
     desc.update(indicator=indicator)
-    prm = dflo_amd.Parameters(flux=flux, limiter="TVB" if tvb else "none", char_lim=char_lim, pos_lim=pos, M=M, beta=float(rng.choice([1.0, 1.5, 2.0])),
-                              boundary=bnd, cfl=0.5, gravity=gravity, time_step_type="local" if local else "global", shock_indicator=indicator)
+    beta = float(rng.choice([1.0, 1.5, 2.0]))
+    extra = {}
+    if os.environ.get("FUZZ_RULES") == "1":   # (a switch: the stream of random numbers of the recorded seeds stays as it was)
+        # the cap of compute_time_step (src/claw.cc:455-476), the stage count overridden, the angular-momentum correction of TVB-Pk
+        if rng.random() < 0.25:
+            extra["time_step"] = float(10.0 ** rng.uniform(-4.0, -2.0))
+        if rng.random() < 0.15:
+            extra["n_rk"] = int(rng.integers(1, 4))
+        if basis == "Pk" and tvb and rng.random() < 0.5:
+            extra["conserve_angular_momentum"] = True
+        desc.update(extra)
+    prm = dflo_amd.Parameters(flux=flux, limiter="TVB" if tvb else "none", char_lim=char_lim, pos_lim=pos, M=M, beta=beta,
+                              boundary=bnd, cfl=0.5, gravity=gravity, time_step_type="local" if local else "global", shock_indicator=indicator, **extra)
     ic = lambda x, y: problems.smooth_perturbation(x, y, L=1.0)
     u0 = mesh.project(ic) if basis == "Pk" else mesh.interpolate(ic)
     if rng.random() < 0.5:   # kinks and rough cells, so that the limiters have work
