@@ -83,8 +83,8 @@ def worker(rank, world, port, ret):
                     why = ("nan pattern", int((~fa).sum()), int((~fb).sum()))
                 else:
                     e = fm.rel(u[fa], ref["u"][fa]) if fa.any() else 0.0
-                    edt = max([abs(x - y) / abs(x) for x, y in zip(ref["dt"], got["dt"])] + [0.0])
-                    et = 0.0 if ref["t"] == got["t"] else abs(ref["t"] - got["t"]) / abs(ref["t"])
+                    edt = max([abs(x - y) / max(abs(x), 1e-300) for x, y in zip(ref["dt"], got["dt"])] + [0.0])
+                    et = 0.0 if ref["t"] == got["t"] else abs(ref["t"] - got["t"]) / max(abs(ref["t"]), 1e-300)
                     if max(e, edt, et) > bar:
                         why = ("differs from the single engine", e, edt, et)
                     k = "identical" if max(e, edt, et) == 0.0 else "rounding (Pk)"

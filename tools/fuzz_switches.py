@@ -98,8 +98,8 @@ for i in range(n_cases):
         else:
             e = fm.rel(a["u"][fa], b["u"][fa]) if fa.any() else 0.0
             ea = fm.rel(a["avg"][np.isfinite(a["avg"])], b["avg"][np.isfinite(a["avg"])]) if np.isfinite(a["avg"]).any() and (np.isfinite(a["avg"]) == np.isfinite(b["avg"])).all() else 0.0
-            edt = max([abs(x - y) / abs(x) for x, y in zip(a["dt"], b["dt"])] + [0.0]) if len(a["dt"]) == len(b["dt"]) else np.inf
-            et = 0.0 if a["t"] == b["t"] else (abs(a["t"] - b["t"]) / abs(a["t"]) if a["t"] and b["t"] else np.inf)
+            edt = max([abs(x - y) / max(abs(x), 1e-300) for x, y in zip(a["dt"], b["dt"])] + [0.0]) if len(a["dt"]) == len(b["dt"]) else np.inf
+            et = 0.0 if a["t"] == b["t"] else abs(a["t"] - b["t"]) / max(abs(a["t"]), 1e-300)
             if max(e, edt, et) > bar or ea > bar_avg:
                 why = ("differs", e, ea, edt, et)
             k = "identical" if max(e, ea, edt, et) == 0.0 else "rounding (a switch that is not bit-neutral)"
