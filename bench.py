@@ -272,7 +272,9 @@ def run_case(args, world, rank, local_rank, uid, barrier):
         # exchange machinery (streams, events, pack / peer copy / unpack, time-step reduction) costs with no second GPU
         claw = dflo_amd.MultiConservationLaw(mesh, prm, devices=[local_rank] * args.parts_per_gpu, partitioner=part)
         return run_parts(args, claw, mesh, ic, bc_fn, programs, nx, ny)
-    if uid == "gloo":   # developer switch (DFLO_BENCH_TRANSPORT=gloo): the rank schedule with a host-staged transport, so that several
+    if args.self_halo:   # one full-size part, its own neighbour: the whole multi-device schedule on this one GPU (see --self-halo)
+        claw = dflo_amd.MultiConservationLaw.for_self(mesh, prm, local_rank, transport=args.self_halo, partitioner=part)
+    elif uid == "gloo":   # developer switch (DFLO_BENCH_TRANSPORT=gloo): the rank schedule with a host-staged transport, so that several
         # ranks can share one GPU (RCCL refuses that) -- exercises this script's N > 1 path on a 1-GPU box; not a measurement
         from dflo_amd.gloo_transport import make_callbacks
         xf, af = make_callbacks("cuda:%d" % local_rank)
@@ -354,6 +356,12 @@ def main():
     ap.add_argument("--no-live-traffic", action="store_true",
                     help="roofline.traffic from profiles/traffic.json instead of two rocprofv3 --pmc passes of this command (N = 1)")
     ap.add_argument("--parts-per-gpu", type=int, default=1, help="developer switch: this many engines on the one GPU (one-process driver)")
+    ap.add_argument("--self-halo", default="", choices=["", "rccl", "direct", "copy"],
+                    help="N = 1 only: the one part is its own neighbour across a virtual cut (the periodic seam in x of c2, a cut through "
+                         "the middle of c3 / c4 / c5) and runs the complete schedule of a rank of a multi-GPU run -- rim || interior on two "
+                         "streams, pack, transport (rccl: grouped ncclSend/ncclRecv to itself + ncclAllReduce(min) on a one-rank "
+                         "communicator; direct: delivering pack kernels; copy: staging + hipMemcpyPeerAsync), trace tables, time-step "
+                         "reduction.  value / value of the plain run = upper bound of the per-GPU weak-scaling efficiency")
     ap.add_argument("--no-tvb", action="store_true", help="c4 only: positivity limiter alone (BASELINE config 4 as written)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak (default): every GPU gets the one-GPU mesh; strong: the one-GPU mesh (c4: the full 4001x1000) is cut into N parts")
@@ -380,6 +388,8 @@ def main():
                "--master-port", os.environ.get("MASTER_PORT", "29517"), os.path.abspath(__file__)] + sys.argv[1:]
         raise SystemExit(subprocess.call(cmd))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.self_halo and (world != 1 or args.parts_per_gpu != 1):
+        raise SystemExit("bench.py: --self-halo is a one-GPU, one-part measurement")
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but %d rank(s) were launched" % (args.gpus, world))
     rank = int(os.environ.get("RANK", "0"))
@@ -462,7 +472,7 @@ def main():
                 traffic_src = rec.get(key, {}).get("source")
             except Exception:
                 traffic = None
-        if world == 1 and args.parts_per_gpu == 1 and not args.no_live_traffic:
+        if world == 1 and args.parts_per_gpu == 1 and not args.no_live_traffic and not args.self_halo:
             lt = live_traffic(args)
             if lt is not None:
                 file_traffic = traffic
@@ -486,6 +496,7 @@ def main():
                                    % m["n_cells"]}[args.config],
                 "n_dofs": n_dofs_total, "n_rk": n_rk,
                 "parts_per_gpu": args.parts_per_gpu,
+                "self_halo": args.self_halo or None,
                 "parallelism": "%s, %d rank(s), native driver (dflo_hip_multi_*): %s"
                                % ("RCB blocks" if args.config == "c5" else "x-slabs", world,
                                   "HOST-STAGED gloo transport (developer switch, not a measurement)" if uid == "gloo"
@@ -509,7 +520,7 @@ def main():
                 "step_frac": value * 1e6 * bytes_per_update / (8.0e12 * world),
             },
         }
-        if world == 1 and args.config == "c2" and not args.no_secondary and (args.degree, args.flux) != (1, "lxf"):
+        if world == 1 and args.config == "c2" and not args.no_secondary and not args.self_halo and (args.degree, args.flux) != (1, "lxf"):
             # north_star: ">= 40 % of the fp64 HBM roofline at Q1" -- the Q1 LxF kernel on the same mesh, on this record
             import copy
             a2 = copy.copy(args)
@@ -525,7 +536,7 @@ def main():
                 "roofline": {"bound": "hbm", "achieved": ach2, "peak": 8000.0, "unit": "GB/s", "frac": ach2 / 8000.0,
                              "kernel": "stage_kernel<2,lxf,geo0>", "kernel_ms": s2["kernel_ms"], "launches": s2["n_launch"]},
             }
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and not args.self_halo:
             # Like dflo on deal.II's WorkStream, only the assembly sweep is threaded (the update, average and limiter passes
             # are serial in the reference).  One thread per CPU the container may use (cgroup cpu.max: 16 of the GPU box's 256
             # hardware threads) -- more threads than that only queue (tools/cpu_scaling.py).

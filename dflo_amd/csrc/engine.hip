@@ -227,6 +227,14 @@ int grid_for(int n_shards) { return ((n_shards + 7) / 8) * 8; }
 void part_list(const dflo_hip_engine *h, int part, const int32_t **list, int *n);
 
 void launch_dt_q(dflo_hip_engine *h);
+int launch_average(dflo_hip_engine *h);
+// A pass launched outside a stage reads the stored cell averages: form them if the last stage kept its own to itself (lazy_avg)
+int ensure_avg(dflo_hip_engine *h) {
+  if (h->avg_valid) return DFLO_OK;
+  const int rc = launch_average(h);
+  if (!rc) h->avg_valid = true;
+  return rc;
+}
 int launch_face_traces(dflo_hip_engine *h, double *out, const int32_t *slots, const int32_t *faces, int n);
 
 // the table of the parts' CFL minima as the reductions (FinalArgs) and the consumers of the time step (DtSrc) see it
@@ -314,6 +322,16 @@ int open_stage(dflo_hip_engine *h, int rk, double dt_host, bool residual_only, i
     h->lim_open = -1;
     h->lim_parts = -1;
     h->fin_done = false;
+    if (h->lim_cnt) {
+      // the list counter this stage's first marked launch will open is cleared HERE, on the stream that opens the stage: in the
+      // multi-device schedule that launch (rim + ring) runs on the comm stream and the launch that joins its list (the rest) on
+      // the compute stream; a memset issued with the former would be unordered against the appends of the latter
+      const int i = (h->lim_epoch + 1) & 1;
+      if (!h->lim_clean[i]) {
+        HIPCHK(h, hipMemsetAsync(h->lim_cnt + i, 0, sizeof(int), h->stream));
+        h->lim_clean[i] = true;
+      }
+    }
     // stage timing samples every fifth stage (5 is coprime to the 2 or 3 stages of a step, so every stage of the
     // step is sampled equally often): two event records per launch are not free
     h->t_sample = h->timing && (h->t_seen++ % h->t_every == 0);
@@ -505,6 +523,7 @@ int launch_update(dflo_hip_engine *h, double *rhs_out, int part) {
 // missing indicator as 1e20 everywhere)
 int launch_indicator(dflo_hip_engine *h, int part) {
   if (!h->d_shock) return DFLO_OK;
+  if (h->pending_rk < 0) { const int rc = ensure_avg(h); if (rc) return rc; }
   const Plan &p = h->plan;
   IndArgs a{};
   a.U = h->U[h->cur];
@@ -539,6 +558,7 @@ int fin_grid(int n_shards) {
 
 int launch_limiter(dflo_hip_engine *h, int tvb, int pos, int part, bool stage_data = false, const FinalArgs *fin = nullptr) {
   const Plan &p = h->plan;
+  if (h->pending_rk < 0) { const int rc = ensure_avg(h); if (rc) return rc; }   // standalone (apply_limiter / apply_positivity_limiter)
   LimArgs l{};
   l.U = h->U[h->cur];
   l.avg = h->avg[h->avg_cur];
@@ -1107,6 +1127,7 @@ int dflo_hip_set_solution(dflo_hip_handle h, const double *u) {
   HIPCHK(h, hipGetLastError());
   int rc = launch_average(h);
   if (rc) return rc;
+  h->avg_valid = true;
   if (h->trace_halo) {   // the ghost cells' traces from the ghost cells' DoFs of the initial state, into both buffers
     for (int i = 0; i < 2; ++i)
       if ((rc = launch_face_traces(h, h->Tg[i], h->d_gt_slot, h->d_gt_face, h->n_gt))) return rc;
@@ -1134,10 +1155,9 @@ int dflo_hip_get_cell_average(dflo_hip_handle h, double *avg) {
   hipSetDevice(h->device);
   const Plan &p = h->plan;
   std::vector<double> tmp((size_t)p.n_slots * 4);
-  if (!h->avg_valid) {   // an intermediate stage that kept its averages to itself
-    int rc = launch_average(h);
+  {   // an intermediate stage that kept its averages to itself
+    const int rc = ensure_avg(h);
     if (rc) return rc;
-    h->avg_valid = true;
   }
   HIPCHK(h, hipStreamSynchronize(h->stream));
   HIPCHK(h, hipMemcpy(tmp.data(), h->avg[h->avg_cur], tmp.size() * sizeof(double), hipMemcpyDeviceToHost));
@@ -1224,7 +1244,9 @@ int dflo_hip_residual(dflo_hip_handle h, int which, double *rhs_out) {
 int dflo_hip_compute_cell_average(dflo_hip_handle h) {
   if (check_handle(h)) return DFLO_ERR_BAD_PARAM;
   hipSetDevice(h->device);
-  return launch_average(h);
+  const int rc = launch_average(h);
+  if (!rc) h->avg_valid = true;
+  return rc;
 }
 
 // compute_time_step() of the current state into the device-resident (dt, t): launches only, nothing comes back to the host
@@ -1234,10 +1256,9 @@ static int launch_compute_dt(dflo_hip_engine *h, double elapsed_time) {
   const int fixed = h->prm.global_time_step && h->prm.cfl <= 0.0;
   // per-shard minima from the stored cell averages (src/claw.cc:486-511)
   const Plan &p = h->plan;
-  if (!fixed && h->geo == 0 && !h->avg_valid) {   // the last stage kept its averages to itself (lazy_avg)
-    const int rc = launch_average(h);
+  if (!fixed && h->geo == 0) {   // the last stage kept its averages to itself (lazy_avg)
+    const int rc = ensure_avg(h);
     if (rc) return rc;
-    h->avg_valid = true;
   }
   if (fixed) {
   } else if (h->geo == 0)

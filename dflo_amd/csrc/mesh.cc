@@ -400,6 +400,79 @@ int dflo_mesh_partition_ex(const dflo_mesh_t *mesh, int32_t n_ranks, int32_t ran
   return DFLO_OK;
 }
 
+// Self-halo partition: ONE part that owns every cell and is its own neighbour across a "virtual cut".  It exists to drive one
+// full-size part through the complete multi-device stage schedule (rim / interior split, pack, transport, unpack, time-step
+// reduction) on a single GPU: the ratio to the plain engine bounds the per-GPU efficiency of a weak-scaling run without the
+// compute-unit sharing that several parts on one device suffer.  The cut:
+//   n_virtual >= 2: the faces between the cells of different virtual owners (partition_owners with n_virtual parts), periodic
+//                   faces left alone -- n_virtual = 2 on a bounded mesh is one cut through the middle, whose two sides send and
+//                   receive what an interior rank of an x-slab run exchanges with its two neighbours;
+//   n_virtual == 1: the periodic faces in x (faces 0 / 1 with the periodic bit) -- on the periodic square of C2 one seam, again
+//                   two sides: exactly the records, rim shards and ghost cells of one rank of the weak-scaling run.
+// Every cell with a cut face gets a ghost COPY (local index n_cells + k, sorted by global id, cell_global_id = the original's);
+// across a cut face an owned cell sees the copy of its neighbour, a copy sees the owned cells across its cut faces and nothing
+// else -- what dflo_mesh_partition_ex gives a rank for the ghost cells owned by a peer.  send_cells = the same cells (the owner of
+// every ghost is this part): offsets [0, n] for the single "peer" 0.
+int dflo_mesh_partition_self(const dflo_mesh_t *mesh, int32_t n_virtual, int32_t method, dflo_mesh_t **out,
+                             const int32_t **send_cells, const int32_t **send_offsets, const int32_t **recv_offsets) {
+  if (!mesh || !out || n_virtual < 1 || (method != DFLO_PART_SLAB && method != DFLO_PART_RCB))
+    return fail(DFLO_ERR_BAD_PARAM, "dflo_mesh_partition_self: bad arguments");
+  const int32_t n = mesh->n_cells;
+  if (mesh->n_owned_cells != n) return fail(DFLO_ERR_BAD_PARAM, "mesh is already partitioned");
+  std::vector<int32_t> owner;
+  partition_owners(mesh, n_virtual, method, owner);
+  auto is_cut = [&](int32_t c, int f) {
+    const int32_t nb = mesh->cell_face_neighbor[(size_t)c * 4 + f];
+    if (nb < 0 || nb == c) return false;
+    const bool periodic = (mesh->cell_face_neighbor_face[(size_t)c * 4 + f] & 8) != 0;
+    if (n_virtual == 1) return periodic && f < 2;
+    return !periodic && owner[nb] != owner[c];
+  };
+  std::vector<int32_t> copy_of(n, -1), cut_cells;
+  for (int32_t c = 0; c < n; ++c) {
+    bool any = false;
+    for (int f = 0; f < 4; ++f) any |= is_cut(c, f);
+    if (any) { copy_of[c] = n + (int32_t)cut_cells.size(); cut_cells.push_back(c); }
+  }
+  if (cut_cells.empty()) return fail(DFLO_ERR_BAD_PARAM, n_virtual == 1 ? "dflo_mesh_partition_self: the mesh has no periodic faces in x to cut at (use n_virtual >= 2)"
+                                                                         : "dflo_mesh_partition_self: the virtual parts share no face");
+  const int32_t ng = (int32_t)cut_cells.size(), nl = n + ng;
+  MeshOwner *o = new MeshOwner;
+  o->send_off = {0, ng};
+  o->recv_off = {0, ng};
+  o->send_cells = cut_cells;   // owned cells keep their global numbers
+  o->vert.resize((size_t)nl * 8);
+  o->nbr.resize((size_t)nl * 4);
+  o->nbrf.resize((size_t)nl * 4);
+  o->gid.resize(nl);
+  for (int32_t l = 0; l < nl; ++l) {
+    const int32_t c = l < n ? l : cut_cells[l - n];
+    o->gid[l] = mesh->cell_global_id ? mesh->cell_global_id[c] : c;
+    std::memcpy(&o->vert[(size_t)l * 8], &mesh->cell_vertices[(size_t)c * 8], 8 * sizeof(double));
+    for (int f = 0; f < 4; ++f) {
+      int32_t nb = mesh->cell_face_neighbor[(size_t)c * 4 + f];
+      if (nb >= 0) {
+        const bool cut = is_cut(c, f);
+        if (l < n) nb = cut ? copy_of[nb] : nb;   // an owned cell: the copy across a cut face
+        else nb = cut ? nb : DFLO_NBR_NONE;       // a copy: the owned cells across its cut faces, nothing else
+      }
+      o->nbr[(size_t)l * 4 + f] = nb;
+      o->nbrf[(size_t)l * 4 + f] = mesh->cell_face_neighbor_face[(size_t)c * 4 + f];
+    }
+  }
+  o->m.n_cells = nl;
+  o->m.n_owned_cells = n;
+  o->m.degree = mesh->degree;
+  o->m.basis = mesh->basis;
+  o->m.mapping = mesh->mapping;
+  o->bind();
+  *out = &o->m;
+  if (send_cells) *send_cells = o->send_cells.data();
+  if (send_offsets) *send_offsets = o->send_off.data();
+  if (recv_offsets) *recv_offsets = o->recv_off.data();
+  return DFLO_OK;
+}
+
 // GridTools::collect_periodic_faces + add_periodicity (src_mpi/claw.cc:156-200): the boundary faces with ids
 // id_first / id_second, offset along `direction` (0 = x, 1 = y), are matched by their extent in the other
 // coordinate and become each other's (periodic) neighbours.

@@ -214,6 +214,10 @@ struct dflo_hip_multi {
   int n_parts = 1;             // parts of the partition (= n_ranks in rank mode)
   int rank = 0;                // rank mode: this process's part
   bool rank_mode = false, loopback = false;
+  // self-halo (dflo_hip_multi_create_self): ONE part that is its own neighbour across a virtual cut -- the whole schedule of a
+  // rank of a multi-GPU run (rim / interior split, pack, transport, trace tables, time-step reduction) on a single device
+  bool self_halo = false;
+  int self_virtual = 1;
   ncclComm_t comm = nullptr;
   // one process per GPU with the host program's own transport (MPI, ...) instead of RCCL
   dflo_exchange_fn x_exchange = nullptr;
@@ -775,7 +779,7 @@ int reduce_dt_phase(dflo_hip_multi *m, Part &p, int64_t step, int ph) {
   return DFLO_OK;
 }
 int reduce_dt(dflo_hip_multi *m) {   // calling thread, all parts
-  if (m->n_parts == 1) return DFLO_OK;   // finalize_kernel has applied the rules already
+  if (m->n_parts == 1 && !m->self_halo) return DFLO_OK;   // finalize_kernel has applied the rules already
   if (m->rank_mode) return reduce_dt_rank(m);
   const int64_t step = m->n_steps_fin++;
   for (int ph = 0; ph < 2; ++ph)
@@ -795,7 +799,7 @@ int group_step(dflo_hip_multi *m, Group &g, double dt, int64_t n0, int64_t step,
     if (rc) return rc;
   }
   for (int i : g.parts) MENG(m, m->parts[i], dflo_hip_end_step(m->parts[i].eng));
-  if (m->n_parts == 1) return DFLO_OK;
+  if (m->n_parts == 1 && !m->self_halo) return DFLO_OK;
   for (int ph = 0; ph < 2; ++ph)
     for (int i : g.parts) {
       const int rc = reduce_dt_phase(m, m->parts[i], step, ph);
@@ -922,14 +926,15 @@ int make_groups(dflo_hip_multi *m) {
 }
 
 int setup_part(dflo_hip_multi *m, Part &p, const dflo_mesh_t *mesh, const dflo_params_t *prm, int method) {
-  int rc = dflo_mesh_partition_ex(mesh, m->n_parts, p.index, method, &p.sub, &p.send_cells, &p.send_off, &p.recv_off);
+  int rc = m->self_halo ? dflo_mesh_partition_self(mesh, m->self_virtual, method, &p.sub, &p.send_cells, &p.send_off, &p.recv_off)
+                         : dflo_mesh_partition_ex(mesh, m->n_parts, p.index, method, &p.sub, &p.send_cells, &p.send_off, &p.recv_off);
   if (rc) { m->err = dflo_mesh_last_error(); return rc; }
   p.n_cells = p.sub->n_cells;
   p.n_owned = p.sub->n_owned_cells;
   p.n_ghost = p.n_cells - p.n_owned;
   p.n_send = p.send_off[m->n_parts];
   for (int q = 0; q < m->n_parts; ++q)
-    if (q != p.index && (p.send_off[q + 1] > p.send_off[q] || p.recv_off[q + 1] > p.recv_off[q])) p.peers.push_back(q);
+    if ((q != p.index || m->self_halo) && (p.send_off[q + 1] > p.send_off[q] || p.recv_off[q + 1] > p.recv_off[q])) p.peers.push_back(q);
   {   // the cell size of a lattice of squares as the single engine's plan would find it on the whole mesh (plan.h: build_plan's h_hint)
     double hmin = 0.0;
     if (mesh->mapping == DFLO_MAP_CARTESIAN) {
@@ -997,7 +1002,7 @@ int setup_part(dflo_hip_multi *m, Part &p, const dflo_mesh_t *mesh, const dflo_p
   }
   MENG(m, p, dflo_hip_scalar_ptrs(p.eng, &p.dt_ptr, &p.res_ptr));
   MENG(m, p, dflo_hip_dt_table(p.eng, &p.dt_table));
-  if (m->rank_mode && m->n_parts > 1) MENG(m, p, dflo_hip_dt_exchange(p.eng, 0, 1, nullptr));   // one slot, all-reduced in place
+  if (m->rank_mode && (m->n_parts > 1 || m->self_halo)) MENG(m, p, dflo_hip_dt_exchange(p.eng, 0, 1, nullptr));   // one slot, all-reduced in place
   // the engine's boundary faces -> their numbers in the undivided mesh
   const int nb = dflo_hip_n_boundary_faces(p.eng);
   std::vector<int32_t> bc(std::max(nb, 1)), bf(std::max(nb, 1));
@@ -1247,6 +1252,47 @@ int dflo_hip_multi_create_rank_custom(const dflo_mesh_t *mesh, const dflo_params
                                       dflo_hip_multi_handle *out) {
   if (!exchange || !allreduce) { g_multi_error = "both callbacks are needed"; return DFLO_ERR_BAD_PARAM; }
   return create_rank_impl(mesh, params, device_id, rank, n_ranks, nullptr, exchange, allreduce, user, partitioner, out);
+}
+
+int dflo_hip_multi_create_self(const dflo_mesh_t *mesh, const dflo_params_t *params, int device_id, int n_virtual, int partitioner,
+                               int transport, dflo_hip_multi_handle *out) {
+  if (!mesh || !params || !out || n_virtual < 1 || transport < DFLO_SELF_DIRECT || transport > DFLO_SELF_COPY) { g_multi_error = "bad arguments"; return DFLO_ERR_BAD_PARAM; }
+  *out = nullptr;
+  dflo_hip_multi *m = new dflo_hip_multi;
+  auto bail = [&](int rc) { g_multi_error = m->err; dflo_hip_multi_destroy(m); return rc; };
+  m->n_parts = 1;
+  m->self_halo = true;
+  m->self_virtual = n_virtual;
+  m->rank_mode = transport == DFLO_SELF_RCCL;
+  m->direct = transport != DFLO_SELF_COPY;
+  m->strict = dflo::read_tunables().strict;
+  int rc = create_common(mesh, params, m);
+  if (rc) return bail(rc);
+  m->parts.resize(1);
+  m->sync.reset(new Sync[1]);
+  m->parts[0].index = 0;
+  m->parts[0].device = device_id;
+  m->parts[0].sy = &m->sync[0];
+  if ((rc = make_groups(m))) return bail(rc);
+  if ((rc = setup_part(m, m->parts[0], mesh, params, partitioner))) return bail(rc);
+  Part &p = m->parts[0];
+  if (p.send_off[1] != p.recv_off[1] || (p.trace && p.sendf_off[1] != p.recvf_off[1])) { m->err = "self-halo: send and receive counts disagree"; return bail(DFLO_ERR_COMM); }
+  if (m->rank_mode) {   // the communicator of one rank: ncclSend / ncclRecv to itself, ncclAllReduce over itself
+    if (hipSetDevice(device_id) != hipSuccess) { m->err = "hipSetDevice failed"; return bail(DFLO_ERR_HIP); }
+    if (!load_rccl(m->err)) return bail(DFLO_ERR_COMM);
+    ncclUniqueId id;
+    ncclResult_t r = g_rccl.GetUniqueId(&id);
+    if (r != ncclSuccess) { m->err = std::string("ncclGetUniqueId: ") + g_rccl.GetErrorString(r); return bail(DFLO_ERR_COMM); }
+    r = g_rccl.CommInitRank(&m->comm, 1, id, 0);
+    if (r != ncclSuccess) { m->err = std::string("ncclCommInitRank (self-halo): ") + g_rccl.GetErrorString(r); return bail(DFLO_ERR_COMM); }
+  } else {   // one-process schedule: the engine forms the time step from a table of one slot, its own
+    void *tables[16] = {};
+    tables[0] = p.dt_table;
+    if ((rc = dflo_hip_dt_exchange(p.eng, 0, 1, tables))) { m->err = dflo_hip_last_error(p.eng); return bail(rc); }
+  }
+  finish_setup(m);
+  *out = m;
+  return DFLO_OK;
 }
 
 int dflo_hip_multi_n_local(dflo_hip_multi_handle m) { return m ? (int)m->parts.size() : 0; }
@@ -1513,7 +1559,7 @@ static int advance_body(dflo_hip_multi *m, int n_steps, double dt0) {
 
 int dflo_hip_multi_advance(dflo_hip_multi_handle m, int n_steps, double *elapsed_time_inout) {
   if (!m || n_steps < 0 || !elapsed_time_inout) return DFLO_ERR_BAD_PARAM;
-  if (m->n_parts == 1) {   // one part: the engine's own device-resident loop (nothing to exchange, nothing to reduce)
+  if (m->n_parts == 1 && !m->self_halo) {   // one part: the engine's own device-resident loop (nothing to exchange, nothing to reduce)
     Part &p = m->parts[0];
     int rc1 = join_all(m);
     if (!rc1 && (rc1 = dflo_hip_advance(p.eng, n_steps, elapsed_time_inout))) set_err(m, dflo_hip_last_error(p.eng));
@@ -1631,7 +1677,15 @@ int dflo_hip_multi_comm_info(dflo_hip_multi_handle m, int32_t *comm_count, int32
   if (!m) return DFLO_ERR_BAD_PARAM;
   int cnt = m->n_parts, rk = m->rank_mode ? m->rank : -1;
   std::string t;
-  if (m->rank_mode && m->x_exchange) t = "callbacks of the host program (dflo_hip_multi_create_rank_custom)";
+  if (m->self_halo) {
+    t = std::string("self-halo (one part, its own neighbour across ") + (m->self_virtual == 1 ? "the periodic seam in x" : "a cut through the middle") + "): ";
+    if (m->rank_mode && m->comm) {
+      t += "rank schedule, grouped ncclSend/ncclRecv to itself + ncclAllReduce(min) on a one-rank RCCL communicator";
+      cnt = rk = -1;
+      if (g_rccl.CommCount) g_rccl.CommCount(m->comm, &cnt);
+      if (g_rccl.CommUserRank) g_rccl.CommUserRank(m->comm, &rk);
+    } else t += m->direct ? "one-process schedule, pack kernels storing into the own trace table" : "one-process schedule, staging buffer + hipMemcpyPeerAsync";
+  } else if (m->rank_mode && m->x_exchange) t = "callbacks of the host program (dflo_hip_multi_create_rank_custom)";
   else if (m->rank_mode && m->comm) {
     t = "RCCL: grouped ncclSend/ncclRecv + ncclAllReduce(min) on the driver's own communicator";
     cnt = rk = -1;   // as the communicator itself reports them, or -1

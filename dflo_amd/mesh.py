@@ -84,6 +84,19 @@ class Mesh:
         sc_a = np.ctypeslib.as_array(sc, shape=(n_send,)).copy() if n_send > 0 else np.zeros(0, dtype=np.int32)
         return Mesh(out, comm=(sc_a, so_a, ro_a))
 
+    def partition_self(self, n_virtual=1, method="slab"):
+        """Self-halo view (dflo_mesh_partition_self): every cell owned, the cells on the virtual cut copied as ghost cells."""
+        out = C.POINTER(_lib.MeshStruct)()
+        sc, so, ro = (C.POINTER(C.c_int32)(), C.POINTER(C.c_int32)(), C.POINTER(C.c_int32)())
+        rc = lib.dflo_mesh_partition_self(self._ptr, n_virtual, _lib.PARTITIONER[method], C.byref(out), C.byref(sc), C.byref(so), C.byref(ro))
+        if rc:
+            raise DfloError(rc, lib.dflo_mesh_last_error().decode())
+        so_a = np.ctypeslib.as_array(so, shape=(2,)).copy()
+        ro_a = np.ctypeslib.as_array(ro, shape=(2,)).copy()
+        n_send = int(so_a[-1])
+        sc_a = np.ctypeslib.as_array(sc, shape=(n_send,)).copy() if n_send > 0 else np.zeros(0, dtype=np.int32)
+        return Mesh(out, comm=(sc_a, so_a, ro_a))
+
     # ---- views
     @property
     def struct(self):

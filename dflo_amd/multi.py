@@ -4,6 +4,7 @@ advance() is one C call for any number of steps, stages, halo exchanges and time
 
   MultiConservationLaw(mesh, parameters, devices=[0, 1, ...])       one process, one engine per listed device
   MultiConservationLaw.for_rank(mesh, parameters, device, rank, world, unique_id)    one process per GPU (torchrun)
+  MultiConservationLaw.for_self(mesh, parameters, device)           one part, its own neighbour: the whole schedule on one GPU
 
 State, boundary data and results use the numbering of the undivided mesh, as ConservationLaw does (src/claw.h:95-128;
 what the MPI variant spreads over ranks, src_mpi/claw.cc:793, :579).
@@ -34,6 +35,10 @@ class MultiConservationLaw:
         if _rank is None:
             dev = (C.c_int * len(devices))(*devices)
             rc = lib.dflo_hip_multi_create(mesh._ptr, C.byref(p), len(devices), dev, _lib.PARTITIONER[partitioner], C.byref(self._h))
+        elif len(_rank) == 3:      # self-halo: (device, n_virtual, transport)
+            device, n_virtual, transport = _rank
+            rc = lib.dflo_hip_multi_create_self(mesh._ptr, C.byref(p), device, n_virtual, _lib.PARTITIONER[partitioner],
+                                                _lib.SELF_TRANSPORT[transport], C.byref(self._h))
         elif len(_rank) == 5:      # the host program's own transport: (device, rank, world, exchange, allreduce)
             device, rank, world, xf, af = _rank
             self._callbacks = (_lib.EXCHANGE_FN(xf), _lib.ALLREDUCE_FN(af))     # keep the trampolines alive
@@ -58,6 +63,16 @@ class MultiConservationLaw:
     @classmethod
     def for_rank(cls, mesh, parameters, device, rank, world, unique_id, partitioner="slab"):
         return cls(mesh, parameters, partitioner=partitioner, _rank=(device, rank, world, unique_id))
+
+    @classmethod
+    def for_self(cls, mesh, parameters, device=0, n_virtual=None, transport="rccl", partitioner="slab"):
+        """Self-halo (dflo_hip_multi_create_self): one part that is its own neighbour across a virtual cut, driven through the
+        whole multi-device schedule on one GPU.  n_virtual None: 1 (the periodic seam in x) when the mesh has one, else 2 (a cut
+        through the middle)."""
+        if n_virtual is None:
+            nf = np.asarray(mesh.neighbor_faces)
+            n_virtual = 1 if bool(((nf[:, :2] & 8) != 0).any()) else 2
+        return cls(mesh, parameters, partitioner=partitioner, _rank=(device, n_virtual, transport))
 
     @classmethod
     def for_rank_custom(cls, mesh, parameters, device, rank, world, exchange, allreduce, partitioner="slab"):

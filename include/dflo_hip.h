@@ -197,7 +197,11 @@ int dflo_hip_step(dflo_hip_handle h, double dt, double *res_norm0, double *res_n
 /* One RK stage `rk` of iterate_explicit (fine-grained seam for multi-device
  * drivers that exchange halos between stages). dt<0: use the device-resident dt. */
 int dflo_hip_stage(dflo_hip_handle h, int rk, double dt);
-int dflo_hip_end_step(dflo_hip_handle h); /* old_solution = current_solution */
+/* old_solution = current_solution (src/claw.cc:1110).  MANDATORY after the last stage of every time step driven through
+ * dflo_hip_stage / _stage_update / _stage_limit / the halo seam: it also advances the engine's step count, whose parity selects
+ * the step-index slot of the failure flags and the row of the time-step table the next step's kernels read (a caller that
+ * leaves it out keeps reading the row of the step before: failure_step stays 0 and a device-resident dt never updates). */
+int dflo_hip_end_step(dflo_hip_handle h);
 
 /* n_steps x { compute_time_step ; iterate_explicit ; elapsed_time += dt } with
  * dt and time resident on the device (no host round trip inside the loop);
@@ -359,6 +363,18 @@ typedef int (*dflo_allreduce_fn)(void *user, double *values, int n, int op, void
 int dflo_hip_multi_create_rank_custom(const dflo_mesh_t *mesh, const dflo_params_t *params, int device_id, int rank, int n_ranks,
                                       dflo_exchange_fn exchange, dflo_allreduce_fn allreduce, void *user, int partitioner,
                                       dflo_hip_multi_handle *out);
+/* Self-halo: ONE part on ONE device that is its own neighbour across a virtual cut (dflo_mesh_partition_self below:
+ * n_virtual = 1 cuts at the periodic faces in x, >= 2 between the virtual parts of `partitioner`), driven through the complete
+ * stage schedule of a multi-device run -- rim shards beside the interior on two streams, pack, transport into the trace table,
+ * the time-step reduction -- where a plain one-part handle issues the single engine's launches.  A measuring device for boxes
+ * with one GPU: its rate over the plain engine's bounds the weak-scaling efficiency of a rank whose neighbours are as fast as
+ * itself (update_ghost_values / Utilities::MPI::min of src_mpi/claw.cc:793, 579 and src_mpi/limiter.cc:232 all happen, against
+ * itself).  Results are those of the single engine, bit for bit on the nodal basis.  transport: dflo_self_transport --
+ * DIRECT the one-process schedule (pack kernels store into the own trace table), RCCL the one-process-per-GPU schedule on a
+ * one-rank communicator (grouped ncclSend / ncclRecv to itself, ncclAllReduce(min)), COPY staging buffer + hipMemcpyPeerAsync. */
+typedef enum { DFLO_SELF_DIRECT = 0, DFLO_SELF_RCCL = 1, DFLO_SELF_COPY = 2 } dflo_self_transport;
+int dflo_hip_multi_create_self(const dflo_mesh_t *mesh, const dflo_params_t *params, int device_id, int n_virtual, int partitioner,
+                               int transport, dflo_hip_multi_handle *out);
 int dflo_hip_multi_destroy(dflo_hip_multi_handle m);
 const char *dflo_hip_multi_last_error(dflo_hip_multi_handle m); /* m may be NULL: error of the last failed create */
 int dflo_hip_multi_n_parts(dflo_hip_multi_handle m);            /* parts of the partition */
@@ -443,6 +459,13 @@ typedef enum { DFLO_PART_SLAB = 0, DFLO_PART_RCB = 1 } dflo_partitioner;
 int dflo_mesh_partition_ex(const dflo_mesh_t *mesh, int32_t n_ranks, int32_t rank, int32_t method, dflo_mesh_t **out,
                            const int32_t **send_cells, const int32_t **send_offsets, const int32_t **recv_offsets);
 int dflo_mesh_partition_owners(const dflo_mesh_t *mesh, int32_t n_ranks, int32_t method, int32_t *owner_out);
+/* Self-halo partition: ONE part that owns every cell and is its own neighbour across a virtual cut (n_virtual >= 2: the
+ * non-periodic faces between the cells of different virtual owners of dflo_mesh_partition_owners; n_virtual == 1: the
+ * periodic faces in x).  Every cell on the cut gets a ghost copy; send list = those cells, offsets for the one "peer" 0.
+ * A measuring device (dflo_hip_multi_create_self): one full-size part runs the whole schedule that replaces
+ * update_ghost_values / Utilities::MPI::min (src_mpi/claw.cc:793, 579) with itself as the neighbour. */
+int dflo_mesh_partition_self(const dflo_mesh_t *mesh, int32_t n_virtual, int32_t method, dflo_mesh_t **out,
+                             const int32_t **send_cells, const int32_t **send_offsets, const int32_t **recv_offsets);
 void dflo_mesh_free(dflo_mesh_t *mesh);
 const char *dflo_mesh_last_error(void);
 
