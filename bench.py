@@ -356,7 +356,7 @@ def main():
     ap.add_argument("--no-live-traffic", action="store_true",
                     help="roofline.traffic from profiles/traffic.json instead of two rocprofv3 --pmc passes of this command (N = 1)")
     ap.add_argument("--parts-per-gpu", type=int, default=1, help="developer switch: this many engines on the one GPU (one-process driver)")
-    ap.add_argument("--self-halo", default="", choices=["", "rccl", "direct", "copy"],
+    ap.add_argument("--self-halo", default="", choices=["", "rccl", "direct", "copy", "ipc"],
                     help="N = 1 only: the one part is its own neighbour across a virtual cut (the periodic seam in x of c2, a cut through "
                          "the middle of c3 / c4 / c5) and runs the complete schedule of a rank of a multi-GPU run -- rim || interior on two "
                          "streams, pack, transport (rccl: grouped ncclSend/ncclRecv to itself + ncclAllReduce(min) on a one-rank "

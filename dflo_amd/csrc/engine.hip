@@ -87,6 +87,8 @@ struct dflo_hip_engine {
   double pending_dt = -1.0;
   int32_t *d_send_slots = nullptr;
   int n_send = 0;
+  unsigned int *send_done = nullptr;   // [3] workgroup counters of the signalling pack kernels, by kind (dflo_hip_pack_send_to_signal)
+  bool peer_fine = false;              // DFLO_PEER_FINEGRAINED=1: what a peer's kernel writes lives in fine-grained memory
   const double *ghost_avg_src = nullptr;   // dflo_hip_ghost_avg_source: where the Qk limiter pass finds the ghost cells' averages
   // ghost cells known by their face traces (Qk without the KXRCF indicator): two buffers, the stage kernels read Tg[tg_cur]
   // while the neighbours' next traces arrive in the other one
@@ -146,6 +148,13 @@ std::string g_create_error;
       return DFLO_ERR_HIP;                                                                   \
     }                                                                                        \
   } while (0)
+
+// memory another device's kernel writes while this device works (ghost-trace tables, the table of the parts' time-step minima):
+// plain device memory -- coherent at kernel boundaries, which is what the schedule relies on -- or, DFLO_PEER_FINEGRAINED=1,
+// fine-grained device memory, coherent at every access
+hipError_t peer_malloc(void **p, size_t bytes, bool fine) {
+  return fine ? hipExtMallocWithFlags(p, bytes, hipDeviceMallocFinegrained) : hipMalloc(p, bytes);
+}
 
 template <typename T>
 int upload(dflo_hip_engine *h, T **dst, const std::vector<T> &src) {
@@ -837,6 +846,7 @@ int dflo_hip_create_with_cell_size(const dflo_mesh_t *mesh, const dflo_params_t 
   h->sweep_mode = tun.sweep ? 1 : 0;
   h->stream_override = tun.stream;
   h->fuse_dtq = tun.fuse_dtq;
+  h->peer_fine = tun.peer_finegrained;
   h->ns = mesh->basis == DFLO_BASIS_PK ? h->N * (h->N + 1) / 2 : h->N * h->N;
   h->ndof = 4 * h->ns;
   h->mapping = mesh->mapping == DFLO_MAP_Q2 ? DFLO_MAP_Q1 : mesh->mapping;
@@ -952,7 +962,7 @@ int dflo_hip_create_with_cell_size(const dflo_mesh_t *mesh, const dflo_params_t 
   if (h->trace_halo) {
     if ((rc = upload(h, &h->d_gt_slot, p.gt_cell)) || (rc = upload(h, &h->d_gt_face, p.gt_face))) return bail(rc);
     for (int i = 0; i < 2; ++i) {
-      if (hipMalloc((void **)&h->Tg[i], (size_t)h->n_gt * 4 * h->N * sizeof(double)) != hipSuccess) { h->err = "hipMalloc(ghost traces) failed"; return bail(DFLO_ERR_NOMEM); }
+      if (peer_malloc((void **)&h->Tg[i], (size_t)h->n_gt * 4 * h->N * sizeof(double), h->peer_fine) != hipSuccess) { h->err = "hipMalloc(ghost traces) failed"; return bail(DFLO_ERR_NOMEM); }
       hipMemset(h->Tg[i], 0, (size_t)h->n_gt * 4 * h->N * sizeof(double));
     }
   }
@@ -976,7 +986,8 @@ int dflo_hip_create_with_cell_size(const dflo_mesh_t *mesh, const dflo_params_t 
       hipMalloc((void **)&h->shard_dtmin, nsh * sizeof(double)) != hipSuccess ||
       hipMalloc((void **)&h->res_sq, 4 * sizeof(double)) != hipSuccess || hipMalloc((void **)&h->fin_partial, 4 * kFinBlocks * sizeof(double)) != hipSuccess ||
       hipMalloc((void **)&h->dt_dev, 4 * sizeof(double)) != hipSuccess || hipMalloc((void **)&h->fin_counter, 4 * sizeof(int)) != hipSuccess ||
-      hipMalloc((void **)&h->dt_mins, 2 * kDtSlots * sizeof(double)) != hipSuccess || hipMalloc((void **)&h->pos_stats, 2 * sizeof(unsigned long long)) != hipSuccess) {
+      peer_malloc((void **)&h->dt_mins, 2 * kDtSlots * sizeof(double), h->peer_fine) != hipSuccess || hipMalloc((void **)&h->pos_stats, 2 * sizeof(unsigned long long)) != hipSuccess ||
+      hipMalloc((void **)&h->send_done, 4 * sizeof(unsigned int)) != hipSuccess) {
     h->err = "hipMalloc(scalars) failed";
     return bail(DFLO_ERR_NOMEM);
   }
@@ -998,6 +1009,7 @@ int dflo_hip_create_with_cell_size(const dflo_mesh_t *mesh, const dflo_params_t 
     hipMemcpy(h->dt_mins, big.data(), big.size() * sizeof(double), hipMemcpyHostToDevice);
   }
   hipMemset(h->fin_counter, 0, 4 * sizeof(int));
+  hipMemset(h->send_done, 0, 4 * sizeof(unsigned int));
   hipMemset(h->pos_stats, 0, 2 * sizeof(unsigned long long));
   // row stride of the stage kernel's trace / flux table: a column per halo entry (its trace, then the flux of its face) and one
   // per other face; the 4 N rows also host the row partials (5 N rows of 64), the positivity minima (3 N) or the slope
@@ -1090,7 +1102,7 @@ int dflo_hip_destroy(dflo_hip_handle h) {
   hipFree(h->d_rim_list); hipFree(h->d_int_list); hipFree(h->d_rim2_list); hipFree(h->d_rest2_list);
   hipFree(h->d_cell_h); hipFree(h->d_dt_cell); hipFree(h->d_cell_vert); hipFree(h->shard_res); hipFree(h->shard_dtmin); hipFree(h->res_sq); hipFree(h->fin_partial); hipFree(h->dt_dev);
   if (h->flags_host) hipHostFree((void *)h->flags_host);
-  hipFree(h->fin_counter); hipFree(h->dt_mins); hipFree(h->pos_stats);
+  hipFree(h->fin_counter); hipFree(h->dt_mins); hipFree(h->pos_stats); hipFree(h->send_done);
   hipFree(h->Tg[0]); hipFree(h->Tg[1]); hipFree(h->d_gt_slot); hipFree(h->d_gt_face); hipFree(h->d_sendf_slot); hipFree(h->d_sendf_face); hipFree(h->d_send_slots); hipFree(h->ghost_stage);
   for (int i = 0; i < 2; ++i) if (h->ev_chunk[i]) hipEventDestroy(h->ev_chunk[i]);
   for (auto &e : h->ev_pool) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
@@ -1670,6 +1682,11 @@ int dflo_hip_pack_send_traces(dflo_hip_handle h, void *device_buffer) {
 }
 
 int dflo_hip_pack_send_to(dflo_hip_handle h, int kind, int n_segments, const int32_t *first, void *const *dst) {
+  return dflo_hip_pack_send_to_signal(h, kind, n_segments, first, dst, nullptr, 0);
+}
+
+int dflo_hip_pack_send_to_signal(dflo_hip_handle h, int kind, int n_segments, const int32_t *first, void *const *dst, void *const *flags,
+                                 uint64_t seq) {
   if (check_handle(h) || kind < 0 || kind > 2 || n_segments < 0 || n_segments > kMaxSegs || (n_segments > 0 && (!first || !dst))) return DFLO_ERR_BAD_PARAM;
   hipSetDevice(h->device);
   const int n = kind == 2 ? h->n_send_faces : h->n_send;
@@ -1679,7 +1696,10 @@ int dflo_hip_pack_send_to(dflo_hip_handle h, int kind, int n_segments, const int
   for (int i = 0; i < n_segments; ++i) {
     seg.first[i] = first[i];
     seg.dst[i] = (double *)dst[i];
+    seg.flag[i] = flags ? (unsigned long long *)flags[i] : nullptr;
   }
+  seg.seq = seq;
+  seg.done = flags ? h->send_done + kind : nullptr;
   seg.first[n_segments] = first[n_segments];
   if (first[0] != 0 || first[n_segments] != n) { h->err = "pack_send_to: the segments must cover the send list"; return DFLO_ERR_COMM; }
   if (kind == 2) {

@@ -120,7 +120,58 @@ bool load_rccl(std::string &err) {
   return true;
 }
 
-enum Chan { CH_CELLS = 0, CH_AVG = 1, CH_TRACES = 2 };
+enum Chan { CH_CELLS = 0, CH_AVG = 1, CH_TRACES = 2, CH_FIN = 3 };
+
+// ---------------------------------------------------------------- one process per GPU without a transport library on the path
+// DFLO_RANK_TRANSPORT=ipc: every rank maps its neighbours' receive areas (ghost-trace tables, average / cell areas), every rank's
+// table of time-step minima and every rank's block of sequence words through hipIpcGetMemHandle / hipIpcOpenMemHandle once, at
+// create (the handles travel through the communicator or the host program's all-reduce: a bootstrap, nothing more).  Per stage
+// the pack kernel stores the records into the neighbour's area and then the exchange's number into the neighbour's sequence
+// word for (kind, this rank); the receiver's comm stream runs a one-wavefront kernel that polls its words.  No RCCL kernel (which
+// beside a full-size interior launch takes as long as that launch, profiles/r05), no rendezvous, no host hop.
+constexpr int kFlagWords = 4 * 16;   // [kind][source rank]
+__host__ __device__ inline int flag_index(int kind, int src) { return kind * 16 + src; }
+
+struct WaitArgs {
+  int n;
+  const unsigned long long *flag[16];
+  unsigned long long seq;
+  int *fail;          // host-mapped: set when a word has not arrived after kWaitTimeoutTicks
+};
+constexpr long long kWaitTimeoutTicks = 30LL * 100000000LL;   // 30 s of the 100 MHz wall clock
+__global__ void wait_flags_kernel(const WaitArgs w) {
+  const int i = threadIdx.x;
+  if (i >= w.n) return;
+  const long long t0 = wall_clock64();
+  while (__hip_atomic_load(w.flag[i], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < w.seq) {
+    __builtin_amdgcn_s_sleep(16);
+    if (wall_clock64() - t0 > kWaitTimeoutTicks) {   // a peer that died or fell out of step: give up, tell the host
+      __hip_atomic_store(w.fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      return;
+    }
+  }
+}
+struct SignalArgs {
+  int n;
+  unsigned long long *flag[16];
+  unsigned long long seq;
+};
+// behind a kernel whose stores the receivers are waiting for (the step's reductions, which write this rank's CFL minimum into
+// every rank's table): the kernel boundary has completed those stores, this one publishes the sequence number
+__global__ void signal_kernel(const SignalArgs a) {
+  const int i = threadIdx.x;
+  if (i >= a.n) return;
+  __threadfence_system();
+  __hip_atomic_store(a.flag[i], a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// what rank q lets this rank write (IPC mappings; self-halo: this rank's own pointers) and where in q's areas this rank's records go
+struct PeerMap {
+  double *tg[2] = {nullptr, nullptr}, *recv_a[2] = {nullptr, nullptr}, *recv_u[2] = {nullptr, nullptr}, *dt_table = nullptr;
+  unsigned long long *flags = nullptr;
+  int32_t ro = 0, rfo = 0;     // q's receive offsets for this rank's cells / face traces, in records
+  void *opened[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+};
 
 // Host-side sequencing between the host threads of the parts (one-process mode).  A stream can only wait for an event that has
 // been recorded: before a thread calls hipStreamWaitEvent on a peer's event it waits until the peer's counter says the record
@@ -218,6 +269,14 @@ struct dflo_hip_multi {
   // rank of a multi-GPU run (rim / interior split, pack, transport, trace tables, time-step reduction) on a single device
   bool self_halo = false;
   int self_virtual = 1;
+  // DFLO_RANK_TRANSPORT=ipc (see PeerMap): sequence words of this rank (fine-grained device memory), the peers' mappings, the
+  // exchanges of each kind this rank has sent / expects (never reset: the words only grow), the wait kernels' failure word
+  bool ipc = false;
+  unsigned long long *flags = nullptr;
+  std::vector<PeerMap> pmap;
+  unsigned long long ipc_post[4] = {0, 0, 0, 0}, ipc_arr[4] = {0, 0, 0, 0};
+  volatile int *ipc_fail_host = nullptr;
+  int *ipc_fail = nullptr;
   ncclComm_t comm = nullptr;
   // one process per GPU with the host program's own transport (MPI, ...) instead of RCCL
   dflo_exchange_fn x_exchange = nullptr;
@@ -403,6 +462,30 @@ int post(dflo_hip_multi *m, Part &p, int kind, int par) {
   const size_t w = (size_t)v.width;
   const bool direct = m->direct && !m->rank_mode && !m->loopback;
   double *send = kind == CH_AVG ? p.send_a : (kind == CH_TRACES ? p.send_t : p.send_u);
+  if (m->rank_mode && m->ipc) {
+    // the pack kernel stores into the neighbours' areas and then publishes this exchange's number in their sequence words.  Why
+    // area `par` of rank q is free: as in the one-process driver below (q's readers of the exchange two back precede, on q's comm
+    // stream, q's own send of the last exchange, whose number this rank's comm stream has seen before it got here)
+    const unsigned long long seq = ++m->ipc_post[kind];
+    int32_t first[17];
+    void *dst[16], *fl[16];
+    int nseg = 0;
+    for (int q : p.peers) {
+      const size_t n = (size_t)(v.so[q + 1] - v.so[q]);
+      if (!n) continue;
+      if (nseg == 16) { set_err(m, "more than 16 neighbouring ranks"); return DFLO_ERR_UNSUPPORTED; }
+      const PeerMap &pm = m->pmap[q];
+      double *base = kind == CH_AVG ? pm.recv_a[par] : (kind == CH_TRACES ? pm.tg[par] : pm.recv_u[par]);
+      first[nseg] = v.so[q];
+      dst[nseg] = base + (size_t)(kind == CH_TRACES ? pm.rfo : pm.ro) * w;
+      fl[nseg++] = pm.flags + flag_index(kind, p.index);
+    }
+    if (nseg) {
+      first[nseg] = v.so[m->n_parts];
+      MENG(m, p, dflo_hip_pack_send_to_signal(p.eng, kind == CH_CELLS ? 0 : (kind == CH_AVG ? 1 : 2), nseg, first, dst, fl, seq));
+    }
+    return DFLO_OK;
+  }
   if (!direct) {   // into the staging buffer first
     if (kind == CH_AVG) MENG(m, p, dflo_hip_pack_send_avg(p.eng, send));
     else if (kind == CH_TRACES) MENG(m, p, dflo_hip_pack_send_traces(p.eng, send));
@@ -489,7 +572,34 @@ int post(dflo_hip_multi *m, Part &p, int kind, int par) {
   return DFLO_OK;
 }
 
+// the comm (or compute) stream waits until the listed ranks' words of this kind have reached `seq`
+int wait_words(dflo_hip_multi *m, hipStream_t st, int kind, const std::vector<int> &from, unsigned long long seq) {
+  WaitArgs w{};
+  for (int q : from) {
+    if (w.n == 16) { set_err(m, "more than 16 ranks to wait for"); return DFLO_ERR_UNSUPPORTED; }
+    w.flag[w.n++] = m->flags + flag_index(kind, q);
+  }
+  if (!w.n) return DFLO_OK;
+  w.seq = seq;
+  w.fail = m->ipc_fail;
+  hipLaunchKernelGGL(wait_flags_kernel, dim3(1), dim3(64), 0, st, w);
+  MHIP(m, hipGetLastError());
+  return DFLO_OK;
+}
+
 int arrive(dflo_hip_multi *m, Part &p, int kind, int par) {
+  if (m->rank_mode && m->ipc) {
+    if (p.peers.empty()) return DFLO_OK;
+    const unsigned long long seq = ++m->ipc_arr[kind];
+    const ChanView v = chan(m, p, kind, par);
+    std::vector<int> from;
+    for (int q : p.peers)
+      if (v.ro[q + 1] > v.ro[q]) from.push_back(q);
+    xt_begin(p);
+    const int rc = wait_words(m, p.C, kind, from, seq);
+    xt_end(p);
+    return rc;
+  }
   if (m->rank_mode) return DFLO_OK;   // the receives were part of the group posted on this stream
   if (p.peers.empty()) return DFLO_OK;
   const int64_t seq = ++p.n_arr[kind];
@@ -619,12 +729,16 @@ int stage_phase(dflo_hip_multi *m, Group &g, const StageCtx &s, int ph) {
         MENG(m, p, dflo_hip_stage_update_part(p.eng, rim_update));
         int rc = mark_used(m, p, CH_TRACES, apar);     // the rim kernel has read the trace table of the exchange before (area apar = upar ^ 1)
         if (rc) return rc;
+        // TVB: what the compute stream's limiter pass waits for is the UPDATE of rim + ring (their averages) -- recorded behind the
+        // last part's update, not behind the averages' way to the neighbours (in rank mode that is an RCCL kernel, which beside a
+        // full-size interior launch takes as long as the launch: profiles/r05/tl_c4_self_rccl_before.txt)
+        if (m->tvb && i == g.parts.back()) MHIP(m, hipEventRecord(g.ev_ring, g.C));
         if (!m->tvb && m->sep_limiter) MENG(m, p, dflo_hip_stage_limit_part(p.eng, 1));
         rc = m->tvb ? post(m, p, CH_AVG, apar) : send_state(m, p, upar, apar, true);
         MENG(m, p, dflo_hip_set_stream(p.eng, g.M));
         if (rc) return rc;
       }
-      MHIP(m, hipEventRecord(m->tvb ? g.ev_ring : g.ev_rim, g.C));
+      if (!m->tvb) MHIP(m, hipEventRecord(g.ev_rim, g.C));
       return DFLO_OK;
     case 2:   // the interior on M, next to it
       // the rim cells of the previous stage are the halo of the interior.  Not with TVB: there the update is split at rim + ring
@@ -745,6 +859,23 @@ int reduce_dt_rank(dflo_hip_multi *m) {
   // the reductions of the step just ended have left this rank's minimum in the slot the next step reads: all-reduce it in
   // place on the comm stream; the consumers apply the rules themselves (no kernel in between)
   Part &p = m->parts[0];
+  if (m->ipc) {
+    // the reductions have written this rank's minimum into every rank's table (dflo_hip_dt_exchange with the mapped tables): say
+    // so in every rank's word for (CH_FIN, this rank), then wait on the compute stream for every rank's word -- no stream hop
+    const unsigned long long seq = ++m->ipc_post[CH_FIN];
+    SignalArgs sg{};
+    std::vector<int> from;
+    for (int q = 0; q < m->n_parts; ++q) {
+      if (q == p.index && !m->self_halo) continue;
+      sg.flag[sg.n++] = m->pmap[q].flags + flag_index(CH_FIN, p.index);
+      from.push_back(q);
+    }
+    if (!sg.n) return DFLO_OK;
+    sg.seq = seq;
+    hipLaunchKernelGGL(signal_kernel, dim3(1), dim3(64), 0, p.M, sg);
+    MHIP(m, hipGetLastError());
+    return wait_words(m, p.M, CH_FIN, from, seq);
+  }
   MHIP(m, hipEventRecord(p.ev_fin[0], p.M));
   MHIP(m, hipStreamWaitEvent(p.C, p.ev_fin[0], 0));
   void *slot = nullptr;
@@ -830,6 +961,10 @@ int sync_all(dflo_hip_multi *m) {
     MHIP(m, hipStreamSynchronize(g.C));
     MHIP(m, hipStreamSynchronize(g.M));
   }
+  if (m->ipc_fail_host && *m->ipc_fail_host) {
+    set_err(m, "a neighbour's records did not arrive within 30 s (DFLO_RANK_TRANSPORT=ipc: a rank died or fell out of step)");
+    return DFLO_ERR_COMM;
+  }
   return DFLO_OK;
 }
 
@@ -838,16 +973,104 @@ int host_allreduce(dflo_hip_multi *m, double *v, int n, ncclRedOp_t op) {
   if (!m->rank_mode || m->n_parts == 1) return DFLO_OK;
   Part &p = m->parts[0];
   MHIP(m, hipSetDevice(p.device));
-  MHIP(m, hipMemcpyAsync(m->scal, v, n * sizeof(double), hipMemcpyHostToDevice, p.C));
+  double *buf = m->scal;
+  if (n > 8) MHIP(m, hipMalloc((void **)&buf, (size_t)n * sizeof(double)));   // (set-up only: the handle exchange)
+  struct Scratch { double *b, *keep; ~Scratch() { if (b != keep) hipFree(b); } } scratch{buf, m->scal};
+  MHIP(m, hipMemcpyAsync(buf, v, n * sizeof(double), hipMemcpyHostToDevice, p.C));
   if (m->x_allreduce) {
     const int xop = op == ncclMin ? DFLO_REDUCE_MIN : (op == ncclSum ? DFLO_REDUCE_SUM : DFLO_REDUCE_MAX);
-    if (m->x_allreduce(m->x_user, m->scal, n, xop, (void *)p.C)) { set_err(m, "the host program's all-reduce callback failed"); return DFLO_ERR_COMM; }
+    if (m->x_allreduce(m->x_user, buf, n, xop, (void *)p.C)) { set_err(m, "the host program's all-reduce callback failed"); return DFLO_ERR_COMM; }
   } else {
-    MNCCL(m, g_rccl.AllReduce(m->scal, m->scal, n, ncclDouble, op, m->comm, p.C));
+    MNCCL(m, g_rccl.AllReduce(buf, buf, n, ncclDouble, op, m->comm, p.C));
   }
-  MHIP(m, hipMemcpyAsync(v, m->scal, n * sizeof(double), hipMemcpyDeviceToHost, p.C));
+  MHIP(m, hipMemcpyAsync(v, buf, n * sizeof(double), hipMemcpyDeviceToHost, p.C));
   MHIP(m, hipStreamSynchronize(p.C));
   return DFLO_OK;
+}
+
+// ---- DFLO_RANK_TRANSPORT=ipc: set-up.  Every rank exports its receive areas, its time-step table, its sequence words and its
+// receive offsets; the records meet through one sum all-reduce of bytes spread over doubles (each rank fills its own stretch of
+// a zeroed array: any transport that can sum doubles can carry it); every rank then opens what it will write.
+struct IpcExport {
+  hipIpcMemHandle_t h[8];      // tg0 tg1 recv_a0 recv_a1 recv_u0 recv_u1 dt_table flags
+  unsigned char has[8];
+  int32_t ro[17], rfo[17];     // this rank's receive offsets by source rank (cells / face traces)
+};
+int alloc_flags(dflo_hip_multi *m) {
+  Part &p = m->parts[0];
+  MHIP(m, hipSetDevice(p.device));
+  MHIP(m, hipExtMallocWithFlags((void **)&m->flags, kFlagWords * sizeof(unsigned long long), hipDeviceMallocFinegrained));
+  MHIP(m, hipMemset(m->flags, 0, kFlagWords * sizeof(unsigned long long)));
+  void *fh = nullptr, *fd = nullptr;
+  MHIP(m, hipHostMalloc(&fh, sizeof(int), hipHostMallocMapped | hipHostMallocCoherent));
+  MHIP(m, hipHostGetDevicePointer(&fd, fh, 0));
+  m->ipc_fail_host = (volatile int *)fh;
+  m->ipc_fail = (int *)fd;
+  *m->ipc_fail_host = 0;
+  return DFLO_OK;
+}
+int setup_ipc(dflo_hip_multi *m) {
+  Part &p = m->parts[0];
+  if (m->n_parts > 16) { set_err(m, "DFLO_RANK_TRANSPORT=ipc: at most 16 ranks"); return DFLO_ERR_UNSUPPORTED; }
+  int rc = alloc_flags(m);
+  if (rc) return rc;
+  IpcExport mine;
+  std::memset(&mine, 0, sizeof(mine));
+  void *ptrs[8] = {p.tg[0], p.tg[1], p.recv_a[0], p.recv_a[1], p.recv_u[0], p.recv_u[1], p.dt_table, m->flags};
+  for (int i = 0; i < 8; ++i) {
+    if (!ptrs[i]) continue;
+    MHIP(m, hipIpcGetMemHandle(&mine.h[i], ptrs[i]));
+    mine.has[i] = 1;
+  }
+  for (int q = 0; q <= m->n_parts; ++q) {
+    mine.ro[q] = p.recv_off[q];
+    mine.rfo[q] = p.trace ? p.recvf_off[q] : 0;
+  }
+  const size_t nb = sizeof(IpcExport);
+  std::vector<double> spread((size_t)m->n_parts * nb, 0.0);
+  const unsigned char *mb = (const unsigned char *)&mine;
+  for (size_t i = 0; i < nb; ++i) spread[(size_t)p.index * nb + i] = (double)mb[i];
+  if ((rc = host_allreduce(m, spread.data(), (int)spread.size(), ncclSum))) return rc;
+  m->pmap.assign(m->n_parts, PeerMap{});
+  for (int q = 0; q < m->n_parts; ++q) {
+    if (q == p.index) continue;
+    IpcExport theirs;
+    unsigned char *tb = (unsigned char *)&theirs;
+    for (size_t i = 0; i < nb; ++i) tb[i] = (unsigned char)spread[(size_t)q * nb + i];
+    PeerMap &pm = m->pmap[q];
+    const bool peer = std::find(p.peers.begin(), p.peers.end(), q) != p.peers.end();
+    for (int i = 0; i < 8; ++i) {
+      if (!theirs.has[i] || (i < 6 && !peer)) continue;   // data areas of neighbours only; table and words of every rank
+      void *ptr = nullptr;
+      const hipError_t e = hipIpcOpenMemHandle(&ptr, theirs.h[i], hipIpcMemLazyEnablePeerAccess);
+      if (e != hipSuccess) { set_err(m, std::string("hipIpcOpenMemHandle (rank ") + std::to_string(q) + "): " + hipGetErrorString(e)); return DFLO_ERR_COMM; }
+      pm.opened[i] = ptr;
+    }
+    pm.tg[0] = (double *)pm.opened[0]; pm.tg[1] = (double *)pm.opened[1];
+    pm.recv_a[0] = (double *)pm.opened[2]; pm.recv_a[1] = (double *)pm.opened[3];
+    pm.recv_u[0] = (double *)pm.opened[4]; pm.recv_u[1] = (double *)pm.opened[5];
+    pm.dt_table = (double *)pm.opened[6];
+    pm.flags = (unsigned long long *)pm.opened[7];
+    pm.ro = theirs.ro[p.index];
+    pm.rfo = theirs.rfo[p.index];
+    if (peer && (theirs.ro[p.index + 1] - theirs.ro[p.index] != p.send_off[q + 1] - p.send_off[q] ||
+                 (p.trace && theirs.rfo[p.index + 1] - theirs.rfo[p.index] != p.sendf_off[q + 1] - p.sendf_off[q]))) {
+      set_err(m, "partition: rank " + std::to_string(q) + " expects another number of records than rank " + std::to_string(p.index) + " sends");
+      return DFLO_ERR_COMM;
+    }
+  }
+  // every rank's CFL minimum goes into every rank's table (the engine's reductions write them, FinalArgs::peer_mins)
+  void *tables[16] = {};
+  for (int q = 0; q < m->n_parts; ++q) tables[q] = q == p.index ? p.dt_table : (void *)m->pmap[q].dt_table;
+  MENG(m, p, dflo_hip_dt_exchange(p.eng, p.index, m->n_parts, tables));
+  m->ipc = true;
+  return DFLO_OK;
+}
+// a barrier of the ranks on the host (IPC transport: nobody may write into a receive area whose owner still reads an earlier run)
+int ipc_barrier(dflo_hip_multi *m) {
+  if (!m->ipc || m->n_parts == 1) return DFLO_OK;
+  double one = 1.0;
+  return host_allreduce(m, &one, 1, ncclSum);
 }
 
 // One process per GPU: every rank leaves a call of the driver with the same status.  `rc` is what this rank found (a limiter
@@ -1085,6 +1308,12 @@ int dflo_hip_multi_destroy(dflo_hip_multi_handle m) {
     if (g.M) hipStreamSynchronize(g.M);
   }
   if (m->comm) g_rccl.CommDestroy(m->comm);
+  if (!m->self_halo)
+    for (PeerMap &pm : m->pmap)
+      for (void *o : pm.opened)
+        if (o) hipIpcCloseMemHandle(o);
+  if (m->flags) hipFree(m->flags);
+  if (m->ipc_fail_host) hipHostFree((void *)m->ipc_fail_host);
   for (Part &p : m->parts) {
     hipSetDevice(p.device);
     if (p.eng) dflo_hip_destroy(p.eng);
@@ -1236,6 +1465,7 @@ static int create_rank_impl(const dflo_mesh_t *mesh, const dflo_params_t *params
       if (r != ncclSuccess) { m->err = std::string("ncclCommInitRank: ") + g_rccl.GetErrorString(r); return bail(DFLO_ERR_COMM); }
     }
     if (hipMalloc((void **)&m->scal, 8 * sizeof(double)) != hipSuccess) { m->err = "hipMalloc(scratch) failed"; return bail(DFLO_ERR_NOMEM); }
+    if (dflo::read_tunables().rank_transport == 1 && (rc = setup_ipc(m))) return bail(rc);
   }
   finish_setup(m);
   *out = m;
@@ -1256,14 +1486,14 @@ int dflo_hip_multi_create_rank_custom(const dflo_mesh_t *mesh, const dflo_params
 
 int dflo_hip_multi_create_self(const dflo_mesh_t *mesh, const dflo_params_t *params, int device_id, int n_virtual, int partitioner,
                                int transport, dflo_hip_multi_handle *out) {
-  if (!mesh || !params || !out || n_virtual < 1 || transport < DFLO_SELF_DIRECT || transport > DFLO_SELF_COPY) { g_multi_error = "bad arguments"; return DFLO_ERR_BAD_PARAM; }
+  if (!mesh || !params || !out || n_virtual < 1 || transport < DFLO_SELF_DIRECT || transport > DFLO_SELF_IPC) { g_multi_error = "bad arguments"; return DFLO_ERR_BAD_PARAM; }
   *out = nullptr;
   dflo_hip_multi *m = new dflo_hip_multi;
   auto bail = [&](int rc) { g_multi_error = m->err; dflo_hip_multi_destroy(m); return rc; };
   m->n_parts = 1;
   m->self_halo = true;
   m->self_virtual = n_virtual;
-  m->rank_mode = transport == DFLO_SELF_RCCL;
+  m->rank_mode = transport == DFLO_SELF_RCCL || transport == DFLO_SELF_IPC;
   m->direct = transport != DFLO_SELF_COPY;
   m->strict = dflo::read_tunables().strict;
   int rc = create_common(mesh, params, m);
@@ -1277,7 +1507,19 @@ int dflo_hip_multi_create_self(const dflo_mesh_t *mesh, const dflo_params_t *par
   if ((rc = setup_part(m, m->parts[0], mesh, params, partitioner))) return bail(rc);
   Part &p = m->parts[0];
   if (p.send_off[1] != p.recv_off[1] || (p.trace && p.sendf_off[1] != p.recvf_off[1])) { m->err = "self-halo: send and receive counts disagree"; return bail(DFLO_ERR_COMM); }
-  if (m->rank_mode) {   // the communicator of one rank: ncclSend / ncclRecv to itself, ncclAllReduce over itself
+  if (transport == DFLO_SELF_IPC) {   // the sequence-word transport against itself: the "mapped" areas are its own
+    if ((rc = alloc_flags(m))) return bail(rc);
+    m->pmap.assign(1, PeerMap{});
+    PeerMap &pm = m->pmap[0];
+    for (int i = 0; i < 2; ++i) { pm.tg[i] = (double *)p.tg[i]; pm.recv_a[i] = p.recv_a[i]; pm.recv_u[i] = p.recv_u[i]; }
+    pm.dt_table = (double *)p.dt_table;
+    pm.flags = m->flags;
+    pm.ro = pm.rfo = 0;
+    void *tables[16] = {};
+    tables[0] = p.dt_table;
+    if ((rc = dflo_hip_dt_exchange(p.eng, 0, 1, tables))) { m->err = dflo_hip_last_error(p.eng); return bail(rc); }
+    m->ipc = true;
+  } else if (m->rank_mode) {   // the communicator of one rank: ncclSend / ncclRecv to itself, ncclAllReduce over itself
     if (hipSetDevice(device_id) != hipSuccess) { m->err = "hipSetDevice failed"; return bail(DFLO_ERR_HIP); }
     if (!load_rccl(m->err)) return bail(DFLO_ERR_COMM);
     ncclUniqueId id;
@@ -1325,6 +1567,7 @@ int dflo_hip_multi_set_solution(dflo_hip_multi_handle m, const double *u) {
       std::memcpy(&loc[(size_t)c * m->ndof], &u[(size_t)p.sub->cell_global_id[c] * m->ndof], m->ndof * sizeof(double));
     MENG(m, p, dflo_hip_set_solution(p.eng, loc.data()));
   }
+  if ((rc = ipc_barrier(m))) return rc;   // (every rank has drained: nobody still reads what the first exchange will overwrite)
   // the engines read their trace table 0 now: the first exchange fills table 1.  Nothing is in flight (every stream has been
   // drained): the exchange counters start again.
   m->nx = 0;
@@ -1350,7 +1593,7 @@ int dflo_hip_multi_set_part_solution(dflo_hip_multi_handle m, int i, const doubl
   // caller that changes the state sets every part before the next step (as bench.py's ranks do).
   MENG(m, m->parts[i], dflo_hip_set_solution(m->parts[i].eng, u_part));
   MENG(m, m->parts[i], dflo_hip_use_ghost_traces(m->parts[i].eng, (int)(m->nx & 1)));
-  return DFLO_OK;
+  return ipc_barrier(m);
 }
 
 int dflo_hip_multi_get_solution(dflo_hip_multi_handle m, double *u) {
@@ -1679,12 +1922,16 @@ int dflo_hip_multi_comm_info(dflo_hip_multi_handle m, int32_t *comm_count, int32
   std::string t;
   if (m->self_halo) {
     t = std::string("self-halo (one part, its own neighbour across ") + (m->self_virtual == 1 ? "the periodic seam in x" : "a cut through the middle") + "): ";
-    if (m->rank_mode && m->comm) {
+    if (m->ipc) t += "rank schedule, pack kernels storing into the own receive areas + sequence words polled by a wait kernel (the IPC transport against itself)";
+    else if (m->rank_mode && m->comm) {
       t += "rank schedule, grouped ncclSend/ncclRecv to itself + ncclAllReduce(min) on a one-rank RCCL communicator";
       cnt = rk = -1;
       if (g_rccl.CommCount) g_rccl.CommCount(m->comm, &cnt);
       if (g_rccl.CommUserRank) g_rccl.CommUserRank(m->comm, &rk);
     } else t += m->direct ? "one-process schedule, pack kernels storing into the own trace table" : "one-process schedule, staging buffer + hipMemcpyPeerAsync";
+  } else if (m->rank_mode && m->ipc) {
+    t = std::string("IPC: pack kernels storing into the neighbours' hipIpc-mapped receive areas + sequence words polled by a wait kernel; time step through the mapped tables (bootstrap: ") + (m->comm ? "RCCL" : "host callbacks") + ")";
+    if (m->comm) { cnt = rk = -1; if (g_rccl.CommCount) g_rccl.CommCount(m->comm, &cnt); if (g_rccl.CommUserRank) g_rccl.CommUserRank(m->comm, &rk); }
   } else if (m->rank_mode && m->x_exchange) t = "callbacks of the host program (dflo_hip_multi_create_rank_custom)";
   else if (m->rank_mode && m->comm) {
     t = "RCCL: grouped ncclSend/ncclRecv + ncclAllReduce(min) on the driver's own communicator";

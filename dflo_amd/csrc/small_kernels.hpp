@@ -239,7 +239,24 @@ struct SendSegs {
   int n;
   int first[kMaxSegs + 1];
   double *dst[kMaxSegs];
+  // one process per GPU, receive areas mapped through IPC handles: the kernel also tells the receivers.  The workgroup that
+  // finishes last (counter `done` of this engine, zero between launches) stores `seq` into the receivers' sequence words, behind
+  // a system-scope release: every record of this launch is visible to a peer that has seen the word.
+  unsigned long long *flag[kMaxSegs];
+  unsigned long long seq;
+  unsigned int *done;
 };
+__device__ __forceinline__ void seg_signal(const SendSegs &s) {
+  if (!s.done) return;
+  __syncthreads();                     // the stores of this workgroup have been issued ...
+  if (threadIdx.x != 0) return;
+  __threadfence_system();              // ... and are visible to the other devices
+  if (atomicAdd(s.done, 1u) != gridDim.x - 1) return;
+  __threadfence_system();              // (acquire side: the other workgroups' releases)
+  __hip_atomic_store(s.done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the next launch on this stream finds it at zero
+  for (int i = 0; i < s.n; ++i)
+    if (s.flag[i]) __hip_atomic_store(s.flag[i], s.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 __device__ __forceinline__ double *seg_dst(const SendSegs &s, int k, int width) {
   int i = 0;
   while (i + 1 < s.n && k >= s.first[i + 1]) ++i;
@@ -249,20 +266,24 @@ __device__ __forceinline__ double *seg_dst(const SendSegs &s, int k, int width) 
 __global__ void pack_to_kernel(const SendSegs seg, const double *U, const double *avg, const int32_t *slots, int n, int ndof, int with_dofs) {
   const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const int w = with_dofs ? ndof + 4 : 4;
-  if (t >= (long long)n * w) return;
-  const int k = (int)(t / w), d = (int)(t - (long long)k * w);
-  const int slot = slots[k];
-  const int nd = with_dofs ? ndof : 0;
-  const double v = d < nd ? U[((size_t)(slot >> 6) * ndof + d) * 64 + (slot & 63)]
-                          : avg[((size_t)(slot >> 6) * 4 + (d - nd)) * 64 + (slot & 63)];
-  seg_dst(seg, k, w)[d] = v;
+  if (t < (long long)n * w) {
+    const int k = (int)(t / w), d = (int)(t - (long long)k * w);
+    const int slot = slots[k];
+    const int nd = with_dofs ? ndof : 0;
+    const double v = d < nd ? U[((size_t)(slot >> 6) * ndof + d) * 64 + (slot & 63)]
+                            : avg[((size_t)(slot >> 6) * 4 + (d - nd)) * 64 + (slot & 63)];
+    seg_dst(seg, k, w)[d] = v;
+  }
+  seg_signal(seg);
 }
 template <int N>
 __global__ void face_trace_to_kernel(const SendSegs seg, const double *U, const int32_t *slots, const int32_t *faces, int n) {
   const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= (long long)n * 4 * N) return;
-  const int k = (int)(t / (4 * N)), r = (int)(t - (long long)k * 4 * N);
-  seg_dst(seg, k, 4 * N)[r] = cell_face_trace<N>(U, slots[k], faces[k], r / N, r % N);
+  if (t < (long long)n * 4 * N) {
+    const int k = (int)(t / (4 * N)), r = (int)(t - (long long)k * 4 * N);
+    seg_dst(seg, k, 4 * N)[r] = cell_face_trace<N>(U, slots[k], faces[k], r / N, r % N);
+  }
+  seg_signal(seg);
 }
 // ghost cells: staging buffer [g][ndof] -> ghost shards, and their cell averages
 // one thread per (ghost cell, component): its DoFs travel buffer -> ghost shard (the buffer is read with unit stride

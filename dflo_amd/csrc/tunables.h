@@ -35,6 +35,10 @@ struct Tunables {
   bool loopback = false;   // DFLO_MULTI_TRANSPORT=rccl_loopback   (test hook) the copies through a one-rank RCCL communicator
   bool multi_verbose = false;   // DFLO_MULTI_VERBOSE=1      dflo_hip_multi_advance reports how far the host ran ahead of the devices
   bool comm_priority = true;    // DFLO_MULTI_PRIORITY=0     the comm stream at the compute stream's priority (default: highest)
+  bool peer_finegrained = false;  // DFLO_PEER_FINEGRAINED=1   every buffer a peer's kernel writes (ghost-trace tables, time-step tables,
+                                  //                           receive areas) in fine-grained device memory (hipDeviceMallocFinegrained)
+  int rank_transport = 0;         // DFLO_RANK_TRANSPORT=rccl|ipc   one process per GPU: 0 grouped ncclSend/ncclRecv + ncclAllReduce (default),
+                                  //                           1 pack kernels storing into the peers' IPC-mapped receive areas + sequence flags
   bool avg_in_place = true;     // DFLO_MULTI_AVG_UNPACK=1   TVB: unpack the received ghost averages into the engine's array before the rim
                                 //                           limiter (default: the limiter reads them where they arrived)
 };
@@ -84,6 +88,8 @@ inline Tunables read_tunables() {
   t.multi_verbose = flag("DFLO_MULTI_VERBOSE", false);
   t.comm_priority = flag("DFLO_MULTI_PRIORITY", true);
   t.avg_in_place = !flag("DFLO_MULTI_AVG_UNPACK", false);
+  t.peer_finegrained = flag("DFLO_PEER_FINEGRAINED", false);
+  if (const char *e = std::getenv("DFLO_RANK_TRANSPORT")) t.rank_transport = std::strcmp(e, "ipc") == 0 ? 1 : 0;
   return t;
 }
 

@@ -305,6 +305,14 @@ int dflo_hip_use_ghost_traces(dflo_hip_handle h, int which);
  * as pack_send_cells), 1 cell averages ([4], as pack_send_avg), 2 face traces ([4 (k+1)], as pack_send_traces; the send
  * list is that of set_send_faces).  n_segments <= 16. */
 int dflo_hip_pack_send_to(dflo_hip_handle h, int kind, int n_segments, const int32_t *first, void *const *dst);
+/* The same, and the kernel tells the receivers: once every record of the launch is visible system-wide, the workgroup that
+ * finishes last stores `seq` (release, system scope) into the 64-bit words flags[i] -- sequence words in the receivers'
+ * fine-grained memory, which a one-wavefront wait kernel on the receiver's comm stream polls.  One process per GPU without a
+ * transport library on the per-stage path: the receive areas and the words are mapped through hipIpcGetMemHandle /
+ * hipIpcOpenMemHandle once, at create (dflo_hip_multi_create_rank with DFLO_RANK_TRANSPORT=ipc).  Replaces the same
+ * update_ghost_values (src_mpi/claw.cc:793, src_mpi/limiter.cc:232).  flags NULL: dflo_hip_pack_send_to. */
+int dflo_hip_pack_send_to_signal(dflo_hip_handle h, int kind, int n_segments, const int32_t *first, void *const *dst,
+                                 void *const *flags, uint64_t seq);
 /* device address of the {dt, elapsed time, raw CFL minimum} and {res_norm_sq per stage} scalars (src_mpi/claw.cc:579,777) */
 int dflo_hip_scalar_ptrs(dflo_hip_handle h, void **dt_ptr, void **res_ptr);
 /* The time step of a run over several engines (Utilities::MPI::min(global_dt), src_mpi/claw.cc:579) without a host hop and
@@ -371,8 +379,9 @@ int dflo_hip_multi_create_rank_custom(const dflo_mesh_t *mesh, const dflo_params
  * itself (update_ghost_values / Utilities::MPI::min of src_mpi/claw.cc:793, 579 and src_mpi/limiter.cc:232 all happen, against
  * itself).  Results are those of the single engine, bit for bit on the nodal basis.  transport: dflo_self_transport --
  * DIRECT the one-process schedule (pack kernels store into the own trace table), RCCL the one-process-per-GPU schedule on a
- * one-rank communicator (grouped ncclSend / ncclRecv to itself, ncclAllReduce(min)), COPY staging buffer + hipMemcpyPeerAsync. */
-typedef enum { DFLO_SELF_DIRECT = 0, DFLO_SELF_RCCL = 1, DFLO_SELF_COPY = 2 } dflo_self_transport;
+ * one-rank communicator (grouped ncclSend / ncclRecv to itself, ncclAllReduce(min)), COPY staging buffer + hipMemcpyPeerAsync,
+ * IPC the one-process-per-GPU schedule with the sequence-word transport of DFLO_RANK_TRANSPORT=ipc against itself. */
+typedef enum { DFLO_SELF_DIRECT = 0, DFLO_SELF_RCCL = 1, DFLO_SELF_COPY = 2, DFLO_SELF_IPC = 3 } dflo_self_transport;
 int dflo_hip_multi_create_self(const dflo_mesh_t *mesh, const dflo_params_t *params, int device_id, int n_virtual, int partitioner,
                                int transport, dflo_hip_multi_handle *out);
 int dflo_hip_multi_destroy(dflo_hip_multi_handle m);

@@ -165,7 +165,9 @@ def test_a_second_run_after_set_solution_repeats_the_first():
 
 
 # ------------------------------------------------------------------ one process per part
-def _worker(rank, world, port, name, ret):
+def _worker(rank, world, port, name, ret, transport="callbacks"):
+    if transport == "ipc":
+        os.environ["DFLO_RANK_TRANSPORT"] = "ipc"
     import torch
     import torch.distributed as dist
     sys.path.insert(0, ROOT)
@@ -198,13 +200,13 @@ def _worker(rank, world, port, name, ret):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("name,world", [("c2", 2), ("c2", 3), ("c4", 2)])
-def test_ranks_on_large_meshes_match_the_single_engine(name, world):
+@pytest.mark.parametrize("name,world,transport", [("c2", 2, "callbacks"), ("c2", 3, "callbacks"), ("c4", 2, "callbacks"), ("c2", 3, "ipc"), ("c4", 2, "ipc")])
+def test_ranks_on_large_meshes_match_the_single_engine(name, world, transport):
     import random
     import torch.multiprocessing as mp
     mgr = mp.get_context("spawn").Manager()   # (no fork of a process that holds a HIP runtime)
     ret = mgr.dict()
-    mp.spawn(_worker, args=(world, 31000 + random.randint(0, 2000), name, ret), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, 31000 + random.randint(0, 2000), name, ret, transport), nprocs=world, join=True)
     assert ret["dt"] and ret["t"], dict(ret)
     if name == "c2":
         assert ret["equal"], ret["err"]

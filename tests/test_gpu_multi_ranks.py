@@ -3,7 +3,10 @@ stream, pack, exchange, unpack, all-reduced time step, summed residual norms, ag
 processes on ONE device.  RCCL refuses two ranks on one GPU, so the ranks move their bytes with the driver's
 bring-your-own-transport entry (dflo_hip_multi_create_rank_custom, what a dflo built on MPI would use): the callbacks of
 dflo_amd/gloo_transport.py stage the device buffers through gloo.  Everything except the ncclSend / ncclRecv / ncclAllReduce calls themselves is
-the code the 8-GPU RCCL run executes; those calls are exercised by test_gpu_multi.py::test_rccl_loopback_transport."""
+the code the 8-GPU RCCL run executes; those calls are exercised by test_gpu_multi.py::test_rccl_loopback_transport.
+transport "ipc" (DFLO_RANK_TRANSPORT=ipc): the per-stage path without any transport call -- the ranks map each other's receive
+areas, time-step tables and sequence words with hipIpcGetMemHandle / hipIpcOpenMemHandle (real handles between real processes,
+here on one device), the pack kernels deliver and signal, one-wavefront kernels wait."""
 import ctypes as C
 import os
 import sys
@@ -19,7 +22,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 
 
-def _worker(rank, world, port, name, ret):
+def _worker(rank, world, port, name, ret, transport="callbacks"):
+    if transport == "ipc":   # the per-stage path without a transport library: hipIpc-mapped receive areas + sequence words; the
+        os.environ["DFLO_RANK_TRANSPORT"] = "ipc"   # callbacks only carry the handles at create and the host-side reductions
     sys.path.insert(0, ROOT)
     sys.path.insert(0, HERE)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -35,6 +40,7 @@ def _worker(rank, world, port, name, ret):
     claw = dflo_amd.MultiConservationLaw.for_rank_custom(mesh, prm, 0, rank, world, _exchange, _allreduce,
                                                           partitioner="rcb" if name == "c5" else "slab")
     assert claw.n_parts == world and claw.n_local == 1
+    assert ("IPC: pack kernels" in claw.comm_info()[2]) == (transport == "ipc"), claw.comm_info()
     T._setup(claw, mesh, ic)
     got = T._run(claw, limited)
     own = claw.part_cells(0)[0]
@@ -57,12 +63,15 @@ def _worker(rank, world, port, name, ret):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("name,world", [("c2", 2), ("c2", 3), ("c1", 2), ("c4", 2), ("c4", 3), ("c5", 2), ("kxrcf", 2)])
-def test_ranks_on_one_device_match_the_single_engine(name, world):
+@pytest.mark.parametrize("name,world,transport", [("c2", 2, "callbacks"), ("c2", 3, "callbacks"), ("c1", 2, "callbacks"), ("c4", 2, "callbacks"),
+                                                  ("c4", 3, "callbacks"), ("c5", 2, "callbacks"), ("kxrcf", 2, "callbacks"),
+                                                  ("c2", 2, "ipc"), ("c2", 3, "ipc"), ("c1", 3, "ipc"), ("c3", 2, "ipc"), ("c4", 3, "ipc"),
+                                                  ("c5", 2, "ipc"), ("kxrcf", 2, "ipc")])
+def test_ranks_on_one_device_match_the_single_engine(name, world, transport):
     import random
     mgr = mp.get_context("spawn").Manager()   # (no fork of a process that holds a HIP runtime)
     ret = mgr.dict()
-    mp.spawn(_worker, args=(world, 29500 + random.randint(0, 2000), name, ret), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, 29500 + random.randint(0, 2000), name, ret, transport), nprocs=world, join=True)
     assert ret["dt"] and ret["t"], dict(ret)                 # all-reduced minima, host-driven and device-resident
     assert ret["norms"] < 1e-11
     if name in ("c1", "c2"):

@@ -1,7 +1,7 @@
 """GPU: self-halo (dflo_hip_multi_create_self) -- ONE part that is its own neighbour across a virtual cut, driven through the
 complete stage schedule of a multi-device run on one GPU: rim shards on the comm stream beside the interior on the compute
 stream, pack, transport into the trace table (grouped ncclSend / ncclRecv to itself on a one-rank RCCL communicator, or the
-delivering pack kernels, or staging + copy), the averages that feed the LxF flux / the TVB limiter of the rim, and the
+delivering pack kernels, or staging + copy, or the sequence-word transport of DFLO_RANK_TRANSPORT=ipc against itself), the averages that feed the LxF flux / the TVB limiter of the rim, and the
 time-step reduction (ncclAllReduce(min) over the one rank).  It is what bench.py --self-halo times; here: the results are
 those of the single engine -- bit for bit on the nodal basis.
 
@@ -25,7 +25,7 @@ def _self(mesh, prm, transport, method="slab"):
     return claw
 
 
-@pytest.mark.parametrize("transport", ["rccl", "direct", "copy"])
+@pytest.mark.parametrize("transport", ["rccl", "direct", "copy", "ipc"])
 def test_c2_512_self_halo_bit_identical_to_the_single_engine(transport):
     ref = L.reference("c2")
     mesh, prm, ic, programs = L.case("c2")
@@ -48,7 +48,7 @@ def test_c2_512_self_halo_bit_identical_to_the_single_engine(transport):
     assert np.array_equal(got["u"], ref["u"])
 
 
-@pytest.mark.parametrize("transport", ["rccl", "direct"])
+@pytest.mark.parametrize("transport", ["rccl", "direct", "ipc"])
 def test_c4_slab_self_halo_matches_the_single_engine(transport):
     """TVB + positivity + moving inflow: two exchanges per stage (averages before the rim limiter, traces after it)"""
     ref = L.reference("c4")
@@ -66,7 +66,8 @@ def test_c4_slab_self_halo_matches_the_single_engine(transport):
 
 SMALL = [("c2", "slab", "rccl"), ("c1", "slab", "rccl"), ("c1", "slab", "direct"), ("c3", "slab", "rccl"), ("c3", "slab", "direct"),
          ("c4", "slab", "rccl"), ("c5", "rcb", "rccl"), ("c5", "rcb", "direct"), ("kxrcf", "slab", "rccl"), ("kxrcf", "rcb", "direct"),
-         ("pk", "slab", "rccl"), ("pkq1", "rcb", "direct")]
+         ("pk", "slab", "rccl"), ("pkq1", "rcb", "direct"),
+         ("c1", "slab", "ipc"), ("c3", "slab", "ipc"), ("c5", "rcb", "ipc"), ("kxrcf", "slab", "ipc"), ("pk", "slab", "ipc")]
 
 
 @pytest.mark.parametrize("name,method,transport", SMALL)
