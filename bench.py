@@ -134,7 +134,7 @@ def live_traffic(args):
         return None
     cmd = [sys.executable, os.path.abspath(__file__), "--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--no-secondary",
            "--no-live-traffic", "--config", args.config, "--nx", str(args.nx), "--degree", str(args.degree), "--flux", args.flux,
-           "--basis", args.basis] + (["--no-tvb"] if args.no_tvb else [])
+           "--basis", args.basis, "--scaling", args.scaling, "--parts-per-gpu", str(args.parts_per_gpu)] + (["--no-tvb"] if args.no_tvb else [])
     env = dict(os.environ, TMPDIR="/tmp", DFLO_BENCH_NO_PREHEAT="1")
     kib = {}
     try:
@@ -152,8 +152,9 @@ def live_traffic(args):
         print("bench.py: live PMC traffic not collected (%s: %s)" % (type(e).__name__, str(e)[:200]), file=sys.stderr, flush=True)
         return None
     total = 2.0 * kib["FETCH_SIZE"][0] * 1024.0 + kib["WRITE_SIZE"][0] * 1024.0
-    return total, ("live: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, no trace domain) around 8 steps of this "
-                   "command in this run; mean of %d / %d stage-kernel dispatches; FETCH_SIZE x2 per the gfx950 correction"
+    return total, ("live: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, no trace domain) around a 2 + 6 step run of "
+                   "this command (its two warm-up steps included), launched by this run; mean of %d / %d stage-kernel dispatches; "
+                   "FETCH_SIZE x2 per the gfx950 correction"
                    % (kib["FETCH_SIZE"][1], kib["WRITE_SIZE"][1]))
 
 
@@ -262,6 +263,10 @@ def run_parts(args, claw, mesh, ic, bc_fn, programs, nx, ny):
             "n_cells": mesh.n_cells, "n_rk": claw.n_rk, "min_rho": float(a[:, 2].min()), "min_p": float(pr.min())}
 
 
+class TransportFailed(RuntimeError):
+    """raised on EVERY rank (the decision is all-reduced) when a transport cannot be set up"""
+
+
 def run_case(args, world, rank, local_rank, uid, barrier):
     """W warm-up and K timed steps through the native multi-device driver (dflo_hip_multi_*): one C call per phase, no
     Python between the steps.  Returns the measurements of this rank."""
@@ -274,7 +279,7 @@ def run_case(args, world, rank, local_rank, uid, barrier):
         return run_parts(args, claw, mesh, ic, bc_fn, programs, nx, ny)
     if args.self_halo:   # one full-size part, its own neighbour: the whole multi-device schedule on this one GPU (see --self-halo)
         claw = dflo_amd.MultiConservationLaw.for_self(mesh, prm, local_rank, transport=args.self_halo, partitioner=part)
-    elif uid == "gloo":   # developer switch (DFLO_BENCH_TRANSPORT=gloo): the rank schedule with a host-staged transport, so that several
+    elif uid == "gloo":   # the host-staged transport (last resort of the N > 1 line; DFLO_BENCH_TRANSPORTS=gloo on a 1-GPU box): the rank schedule with a host-staged transport, so that several
         # ranks can share one GPU (RCCL refuses that) -- exercises this script's N > 1 path on a 1-GPU box; not a measurement
         from dflo_amd.gloo_transport import make_callbacks
         xf, af = make_callbacks("cuda:%d" % local_rank)
@@ -285,19 +290,14 @@ def run_case(args, world, rank, local_rank, uid, barrier):
             claw = dflo_amd.MultiConservationLaw.for_rank(mesh, prm, local_rank, rank, world, uid, partitioner=part)
         except dflo_amd.DfloError as e:      # RCCL could not make the communicator on this node
             why = str(e)
-        if world > 1:   # all ranks take the same road: RCCL only if every rank has its communicator
+        if world > 1:   # all ranks take the same road: this transport only if every rank has its communicator / its mappings
             import torch.distributed as dist
             ok = torch.tensor([1 if claw is not None else 0])
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
             if int(ok.item()) == 0:
                 if claw is not None:
                     claw.close()
-                print("bench.py: RCCL communicator failed on some rank (%s) -- falling back to the HOST-STAGED gloo transport; "
-                      "the line below says so and is not a measurement of the RCCL path" % why, file=sys.stderr, flush=True)
-                from dflo_amd.gloo_transport import make_callbacks
-                xf, af = make_callbacks("cuda:%d" % local_rank)
-                claw = dflo_amd.MultiConservationLaw.for_rank_custom(mesh, prm, local_rank, rank, world, xf, af, partitioner=part)
-                args.transport_note = "HOST-STAGED gloo transport (RCCL communicator failed: %s) -- not a measurement of the RCCL path" % why[:120]
+                raise TransportFailed("the communicator / the IPC mappings could not be made on some rank (%s)" % (why or "on another rank"))
         elif claw is None:
             raise SystemExit("bench.py: " + why)
     if bc_fn is not None:
@@ -399,7 +399,6 @@ def main():
     if os.environ.get("DFLO_BENCH_ONE_GPU") == "1":   # developer switch, with DFLO_BENCH_TRANSPORT=gloo: every rank on GPU 0
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    uid = None
     barrier = lambda: None
     if world > 1:
         # a collective that never completes (a rank that died, a transport that stalls) must end the run with the Python
@@ -407,51 +406,123 @@ def main():
         import faulthandler
         faulthandler.dump_traceback_later(float(os.environ.get("DFLO_BENCH_WATCHDOG_S", 1500)), exit=True)
         # torch.distributed is the control plane only (rendezvous, the communicator id, barriers around the timed
-        # region, the maximum over ranks): the halo exchange and the time-step reduction are RCCL calls made by the
-        # native driver on its own communicator and streams
+        # region, the maximum over ranks): the halo exchange and the time-step reduction are made by the native driver on
+        # its own communicator / mappings and streams
         import torch.distributed as dist
-        from dflo_amd.multi import comm_unique_id
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
         dist.init_process_group("gloo")
-        if os.environ.get("DFLO_BENCH_TRANSPORT") == "gloo":
-            uid = "gloo"
-        else:
-            box = [comm_unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(box, src=0)
-            uid = box[0]
         barrier = dist.barrier
 
-    m = run_case(args, world, rank, local_rank, uid, barrier)
-    sec = m["sec"]
-    mm = np.concatenate([m["mass0"], m["mass1"], [-m["min_rho"], -m["min_p"]]])
-    per_rank = [{"rank": rank, "comm": m["comm"], "exchange_us": m["exchange_us"], "exchange_n": m["exchange_n"], "sec": m["sec"]}]
-    if world > 1:
-        import torch.distributed as dist
-        box = [None] * world
-        dist.all_gather_object(box, per_rank[0])
-        per_rank = box
-        tt = torch.tensor([sec], dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        sec = float(tt.item())
-        sums = torch.tensor(mm[:8], dtype=torch.float64)
-        dist.all_reduce(sums, op=dist.ReduceOp.SUM)
-        mins = torch.tensor(mm[8:], dtype=torch.float64)
-        dist.all_reduce(mins, op=dist.ReduceOp.MAX)
-        mm = np.concatenate([sums.numpy(), mins.numpy()])
-    n_rk = m["n_rk"]
-    if args.config == "c2":   # periodic box: the sums of the conserved variables over all ranks must not move (checks the halo
-        # exchange and the doubly evaluated partition faces of the run that was just timed)
-        check = "periodic box: max relative drift of the conserved totals over the run = %.1e" % float(
-            np.abs(mm[4:8] - mm[:4]).max() / np.abs(mm[:4]).max())
+    def measure(a, transport):
+        """One full run (set-up, W warm-up, K timed steps) of configuration `a` over `transport`, reduced over the ranks:
+        the same dictionary on every rank, with the verdict of the run's own check ("ok")."""
+        uid = None
+        env = {"DFLO_RANK_TRANSPORT": None, "DFLO_PEER_FINEGRAINED": None}
+        if world > 1:
+            import torch.distributed as dist
+            from dflo_amd.multi import comm_unique_id
+            if transport in ("gloo", "ipc_gloo"):   # gloo callbacks carry the halos (gloo) or only the set-up and the host-side reductions (ipc_gloo)
+                uid = "gloo"
+                env["DFLO_RANK_TRANSPORT"] = "ipc" if transport == "ipc_gloo" else "rccl"
+            else:   # rccl | ipc | ipc_fine: an RCCL communicator carries the halos (rccl) or only the set-up (ipc: the handles)
+                box = [comm_unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(box, src=0)
+                uid = box[0]
+                env["DFLO_RANK_TRANSPORT"] = "ipc" if transport.startswith("ipc") else "rccl"
+                env["DFLO_PEER_FINEGRAINED"] = "1" if transport == "ipc_fine" else None
+        saved = {k: os.environ.get(k) for k in env}
+        for k, v in env.items():
+            if v is None:
+                if world > 1:
+                    os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+        err = ""
+        try:
+            m = run_case(a, world, rank, local_rank, uid, barrier)
+        except TransportFailed as e:
+            m, err = None, str(e)
+        except Exception as e:   # noqa: BLE001 -- a DfloError of the native driver (its ranks agree on the status before they return)
+            if world == 1:
+                raise
+            m, err = None, "%s: %s" % (type(e).__name__, str(e)[:300])
+        finally:
+            for k, v in saved.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+        if world > 1:
+            import torch.distributed as dist
+            ok = torch.tensor([0 if m is None else 1])
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0:
+                return {"transport": transport, "ok": False, "check": "failed: " + (err or "on another rank"), "value": 0.0}
+        sec = m["sec"]
+        mm = np.concatenate([m["mass0"], m["mass1"], [-m["min_rho"], -m["min_p"]]])
+        per_rank = [{"rank": rank, "comm": m["comm"], "exchange_us": m["exchange_us"], "exchange_n": m["exchange_n"], "sec": m["sec"]}]
+        if world > 1:
+            import torch.distributed as dist
+            box = [None] * world
+            dist.all_gather_object(box, per_rank[0])
+            per_rank = box
+            tt = torch.tensor([sec], dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            sec = float(tt.item())
+            sums = torch.tensor(mm[:8], dtype=torch.float64)
+            dist.all_reduce(sums, op=dist.ReduceOp.SUM)
+            mins = torch.tensor(mm[8:], dtype=torch.float64)
+            dist.all_reduce(mins, op=dist.ReduceOp.MAX)
+            mm = np.concatenate([sums.numpy(), mins.numpy()])
+        n_rk = m["n_rk"]
+        if a.config == "c2":   # periodic box: the sums of the conserved variables over all ranks must not move (checks the halo
+            # exchange and the doubly evaluated partition faces of the run that was just timed: a rank that read stale traces
+            # computes another flux than its neighbour and the totals drift at once)
+            drift = float(np.abs(mm[4:8] - mm[:4]).max() / np.abs(mm[:4]).max())
+            check = "periodic box: max relative drift of the conserved totals over the run = %.1e" % drift
+            ok = bool(np.isfinite(mm).all() and drift < 1e-10)
+        else:
+            check = "state finite and admissible after the run: min density %.4f, min pressure %.4f" % (-mm[8], -mm[9])
+            ok = bool(np.isfinite(mm).all() and -mm[8] > 0.0 and -mm[9] > 0.0)
+            if "rows" in m:
+                check = "rows of cells identical to %.1e, min density %.4f" % (m["rows"], -mm[8])
+            if a.config == "c5" and "pos_stats" in m:
+                ncs = m["n_dofs_launch"] // 64 * n_rk * (a.steps + a.warmup)
+                check += "; %.4f %% of this rank's cell-stages went through the positivity limiter proper, %.4f %% were changed by it" % (
+                    100.0 * m["pos_stats"][0] / ncs, 100.0 * m["pos_stats"][1] / ncs)
+        return {"transport": transport, "ok": ok, "check": check, "m": m, "sec": sec, "per_rank": per_rank, "n_rk": n_rk,
+                "value": m["n_dofs_total"] * n_rk * a.steps / sec / 1e6}
+
+    # N > 1: north_star's transport (RCCL send/recv + all-reduce) and the IPC transport are BOTH measured; `value` is the better one
+    # whose check holds.  Only if neither does: the IPC transport with every peer-written buffer in fine-grained memory, the IPC
+    # transport bootstrapped over gloo (no RCCL at all), then the host-staged gloo transport -- the line says which ran and what
+    # became of the others.  DFLO_BENCH_TRANSPORTS overrides the list (DFLO_BENCH_TRANSPORT=gloo, the older developer switch, means
+    # "gloo"); DFLO_BENCH_ALL_TRANSPORTS=1 runs every listed one.
+    attempts = []
+    if world == 1:
+        best = measure(args, "none")
     else:
-        check = "state finite and admissible after the run: min density %.4f, min pressure %.4f" % (-mm[8], -mm[9])
-        if "rows" in m:
-            check = "rows of cells identical to %.1e, min density %.4f" % (m["rows"], -mm[8])
-        if args.config == "c5" and "pos_stats" in m:
-            ncs = m["n_dofs_launch"] // 64 * n_rk * (args.steps + args.warmup)
-            check += "; %.4f %% of this rank's cell-stages went through the positivity limiter proper, %.4f %% were changed by it" % (
-                100.0 * m["pos_stats"][0] / ncs, 100.0 * m["pos_stats"][1] / ncs)
+        order = os.environ.get("DFLO_BENCH_TRANSPORTS", "gloo" if os.environ.get("DFLO_BENCH_TRANSPORT") == "gloo" else "rccl,ipc,ipc_fine,ipc_gloo,gloo").split(",")
+        for t in order:
+            if t in ("ipc_fine", "ipc_gloo", "gloo") and any(r["ok"] for r in attempts) and os.environ.get("DFLO_BENCH_ALL_TRANSPORTS") != "1":
+                continue   # fallbacks
+            attempts.append(measure(args, t))
+        good = [r for r in attempts if r["ok"]]
+        if not good:
+            raise SystemExit("bench.py: no transport produced a valid run: " + "; ".join("%s: %s" % (r["transport"], r["check"]) for r in attempts))
+        best = max(good, key=lambda r: r["value"])
+    m, sec, per_rank, n_rk, check = best["m"], best["sec"], best["per_rank"], best["n_rk"], best["check"]
+
+    strong = None
+    if world > 1 and args.config == "c2" and args.scaling == "weak" and os.environ.get("DFLO_BENCH_NO_STRONG") != "1":
+        # the other reading of north_star's ">= 6x at 8 GPUs over 1 GPU on a 1024x1024 Q2 mesh": the one-GPU mesh cut N ways, over the
+        # transport that won above; short (<= 20 steps), its own ms_per_step and exchange waits
+        import copy
+        a2 = copy.copy(args)
+        a2.scaling, a2.steps, a2.warmup = "strong", min(args.steps, 20), min(args.warmup, 5)
+        strong = measure(a2, best["transport"])
+        strong["steps"], strong["warmup"] = a2.steps, a2.warmup
 
     result_line = None
     if rank == 0:
@@ -499,8 +570,21 @@ def main():
                 "self_halo": args.self_halo or None,
                 "parallelism": "%s, %d rank(s), native driver (dflo_hip_multi_*): %s"
                                % ("RCB blocks" if args.config == "c5" else "x-slabs", world,
-                                  "HOST-STAGED gloo transport (developer switch, not a measurement)" if uid == "gloo"
-                                  else getattr(args, "transport_note", "RCCL send/recv of face traces + 8-byte all-reduce(min) per step")),
+                                  {"gloo": "HOST-STAGED gloo transport -- not a measurement of the device-to-device paths",
+                                   "rccl": "RCCL send/recv of face traces + 8-byte all-reduce(min) per step",
+                                   "ipc": "pack kernels storing face traces into the neighbours' hipIpc-mapped tables + sequence words; time step through the mapped tables",
+                                   "ipc_fine": "as ipc, every peer-written buffer in fine-grained memory",
+                                   "ipc_gloo": "as ipc, set up over gloo callbacks instead of an RCCL communicator",
+                                   "none": "one rank: nothing to exchange" if not args.self_halo else "self-halo"}[best["transport"]]),
+                # N > 1: every transport that was run in this invocation, its rate and the verdict of its own check (`value` above is
+                # the best one that passed); and the settings RCCL and the runtime were given
+                "transport_used": best["transport"],
+                "transports": [{"transport": r["transport"], "ok": r["ok"], "value": round(r["value"], 1), "check": r["check"],
+                                "ms_per_step": round(r["sec"] / args.steps * 1e3, 4) if r.get("sec") else None,
+                                "exchange_wait_us": [round(x["exchange_us"], 1) for x in r["per_rank"]] if r.get("per_rank") else None}
+                               for r in attempts] or None,
+                "env": {k: v for k, v in sorted(os.environ.items())
+                        if k.startswith(("NCCL_", "RCCL_", "HSA_ENABLE_", "DFLO_", "HIP_VISIBLE", "ROCR_VISIBLE", "GPU_MAX_HW"))},
                 # what the transport itself says (N > 1: proof that RCCL saw N ranks -- ncclCommCount / ncclCommUserRank of the native
                 # driver's own communicator, per rank -- and how long a rank's comm stream sat in a halo exchange, every fifth sampled)
                 "transport": per_rank[0]["comm"][2],
@@ -513,6 +597,11 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                 "traffic": traffic, "traffic_source": traffic_src,
+                # the HBM rate the counters saw: bytes really moved per launch / the launch's duration (north_star: "rocprof-reported
+                # HBM GB/s").  Below `achieved` where a launch moves fewer bytes than the 24 B per DoF-update it is priced at: the
+                # first stage of a step reads no u(n) (a = 0) -- about 16.7 B -- and `frac` counts 24 for every stage
+                "hbm_gbs": (traffic / (kernel_ms * 1e-3) / 1e9) if (traffic and kernel_ms > 0) else None,
+                "hbm_frac": (traffic / (kernel_ms * 1e-3) / 1e9 / 8000.0) if (traffic and kernel_ms > 0) else None,
                 "kernel": "stage_kernel<%d,%s,geo%d>" % (args.degree + 1, args.flux, int(args.config == "c5")),
                 "kernel_ms": kernel_ms, "launches": m["n_launch"], "algorithmic_bytes_per_dof_update": bytes_per_update,
                 # the whole step priced the same way (everything between two steps: all stage kernels, limiter passes, reductions,
@@ -536,6 +625,20 @@ def main():
                 "roofline": {"bound": "hbm", "achieved": ach2, "peak": 8000.0, "unit": "GB/s", "frac": ach2 / 8000.0,
                              "kernel": "stage_kernel<2,lxf,geo0>", "kernel_ms": s2["kernel_ms"], "launches": s2["n_launch"]},
             }
+        if strong is not None:
+            if strong["ok"] or strong.get("sec"):
+                sm = strong["m"]
+                out["secondary_strong"] = {
+                    "workload": "isentropic_vortex, %dx%d quads cut into %d x-slab(s) (strong scaling of the one-GPU mesh), %s%d, %s, periodic"
+                                % (sm["nx"], sm["ny"], world, args.basis[0], args.degree, args.flux.upper()),
+                    "scaling": "strong", "value": strong["value"], "unit": "MDoF-updates/s", "n_gpus": world, "steps": strong["steps"],
+                    "warmup": strong["warmup"], "ms_per_step": strong["sec"] / strong["steps"] * 1e3, "n_dofs": sm["n_dofs_total"],
+                    "transport": strong["transport"], "ok": strong["ok"], "check": strong["check"],
+                    "exchange_wait_us": [round(r["exchange_us"], 1) for r in strong["per_rank"]],
+                    "kernel_ms": sm["kernel_ms"], "sec_per_rank": [round(r["sec"], 4) for r in strong["per_rank"]],
+                }
+            else:
+                out["secondary_strong"] = {"ok": False, "check": strong["check"], "transport": strong["transport"]}
         if not args.no_cpu_baseline and world == 1 and not args.self_halo:
             # Like dflo on deal.II's WorkStream, only the assembly sweep is threaded (the update, average and limiter passes
             # are serial in the reference).  One thread per CPU the container may use (cgroup cpu.max: 16 of the GPU box's 256

@@ -1180,9 +1180,18 @@ int setup_part(dflo_hip_multi *m, Part &p, const dflo_mesh_t *mesh, const dflo_p
   const size_t ns = std::max(p.n_send, 1), ng = std::max(p.n_ghost, 1);
   MHIP(m, hipMalloc((void **)&p.send_u, ns * (m->ndof + 4) * sizeof(double)));   // DoFs + cell average per cell
   MHIP(m, hipMalloc((void **)&p.send_a, ns * 4 * sizeof(double)));
-  for (int i = 0; i < 2; ++i) {
-    MHIP(m, hipMalloc((void **)&p.recv_u[i], ng * (m->ndof + 4) * sizeof(double)));
-    MHIP(m, hipMalloc((void **)&p.recv_a[i], ng * 4 * sizeof(double)));
+  {   // the receive areas are written by the neighbours' kernels (stores over xGMI): plain device memory, coherent at the kernel
+      // boundaries the schedule provides, or -- DFLO_PEER_FINEGRAINED=1, like the engine's trace and time-step tables -- fine-grained
+    const bool fine = dflo::read_tunables().peer_finegrained;
+    for (int i = 0; i < 2; ++i) {
+      if (fine) {
+        MHIP(m, hipExtMallocWithFlags((void **)&p.recv_u[i], ng * (m->ndof + 4) * sizeof(double), hipDeviceMallocFinegrained));
+        MHIP(m, hipExtMallocWithFlags((void **)&p.recv_a[i], ng * 4 * sizeof(double), hipDeviceMallocFinegrained));
+      } else {
+        MHIP(m, hipMalloc((void **)&p.recv_u[i], ng * (m->ndof + 4) * sizeof(double)));
+        MHIP(m, hipMalloc((void **)&p.recv_a[i], ng * 4 * sizeof(double)));
+      }
+    }
   }
   p.trace = dflo_hip_halo_traces(p.eng) != 0;
   if (p.trace) {
@@ -1942,6 +1951,8 @@ int dflo_hip_multi_comm_info(dflo_hip_multi_handle m, int32_t *comm_count, int32
   else if (m->loopback) t = "one process: one-rank RCCL loopback (test transport)";
   else if (m->n_parts == 1) t = "none (one part)";
   else t = m->direct ? "one process: pack kernels storing into the peers' receive areas (xGMI peer access)" : "one process: staging buffer + hipMemcpyPeerAsync";
+  if (dflo::read_tunables().peer_finegrained) t += "; peer-written buffers in fine-grained memory";
+  if (m->strict) t += "; strict (senders wait for the receivers' consumed events)";
   if (comm_count) *comm_count = cnt;
   if (comm_rank) *comm_rank = rk;
   if (transport && transport_len > 0) {

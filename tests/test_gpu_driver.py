@@ -517,6 +517,9 @@ def test_bench_line_contract(extra):
                 warnings.warn("bench.py could not collect roofline.traffic live on this box: " + out.stderr[-300:])
             else:
                 assert r["traffic"] > 0
+                # the rate the counters saw, next to the algorithmic one
+                assert abs(r["hbm_gbs"] - r["traffic"] / (r["kernel_ms"] * 1e-3) / 1e9) <= 1e-9 * r["hbm_gbs"] and abs(r["hbm_frac"] - r["hbm_gbs"] / 8000.0) < 1e-12
+    assert "hbm_gbs" in r and "hbm_frac" in r
     assert d["value"] > 0 and abs(d["value"] - d["config"]["n_dofs"] * d["config"]["n_rk"] / (d["ms_per_step"] * 1e-3) / 1e6) <= 1e-6 * d["value"]
 
 
@@ -532,7 +535,10 @@ def test_bench_line_of_two_ranks_launched_the_drivers_way(extra):
     port = 29600 + (os.getpid() + len(extra) * 7) % 300
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--nx", "128"] + extra
-    env = dict(os.environ, DFLO_BENCH_TRANSPORT="gloo", DFLO_BENCH_ONE_GPU="1", DFLO_BENCH_WATCHDOG_S="300", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    # two transports in one run, as on the 8-GPU node (there: rccl and ipc): here the host-staged gloo transport and the IPC transport
+    # set up over gloo -- real hipIpc handles between the two processes
+    env = dict(os.environ, DFLO_BENCH_TRANSPORTS="gloo,ipc_gloo", DFLO_BENCH_ALL_TRANSPORTS="1", DFLO_BENCH_ONE_GPU="1", DFLO_BENCH_WATCHDOG_S="300",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
@@ -541,7 +547,21 @@ def test_bench_line_of_two_ranks_launched_the_drivers_way(extra):
     assert d["n_gpus"] == 2 and d["steps"] == 4 and d["scaling"] == ("strong" if "strong" in extra else "weak")
     c = d["config"]
     assert c["comm_ranks_seen"] == [2, 2] and sorted(c["comm_rank_seen"]) == [0, 1] and len(c["sec_per_rank"]) == 2
-    assert "gloo" in c["parallelism"] and "cpu_baseline" not in d and "secondary" not in d
+    assert "cpu_baseline" not in d and "secondary" not in d
+    # every transport that ran is on the line with the verdict of its own check; `value` is the best one that passed
+    tr = {t["transport"]: t for t in c["transports"]}
+    assert sorted(tr) == ["gloo", "ipc_gloo"] and all(t["ok"] for t in tr.values()), c["transports"]
+    assert c["transport_used"] in tr and abs(d["value"] - max(t["value"] for t in tr.values())) <= 0.06
+    assert ("gloo" in c["parallelism"]) and (("IPC: pack kernels" in c["transport"]) == (c["transport_used"] == "ipc_gloo"))
+    assert c["env"].get("HSA_ENABLE_IPC_MODE_LEGACY") == "0" and "DFLO_BENCH_TRANSPORTS" in c["env"]     # the settings RCCL / the runtime were given
+    if not extra:   # the weak-scaling line carries the strong-scaling reading of north_star as well: the one-GPU mesh cut N ways
+        st = d["secondary_strong"]
+        assert st["ok"] and st["scaling"] == "strong" and st["n_gpus"] == 2 and st["n_dofs"] == 128 * 128 * 36 and st["steps"] == 4
+        assert st["transport"] == c["transport_used"] and len(st["exchange_wait_us"]) == 2 and st["ms_per_step"] > 0
+        assert abs(st["value"] - st["n_dofs"] * c["n_rk"] / (st["ms_per_step"] * 1e-3) / 1e6) <= 1e-6 * st["value"]
+        assert float(st["check"].split("=")[-1]) < 1e-12
+    else:
+        assert "secondary_strong" not in d
     if "--config" not in extra:
         n = 128 * 128 * 36 * (1 if "strong" in extra else 2)
         assert c["n_dofs"] == n

@@ -111,13 +111,18 @@ def _plan_has_interior(multi):
 MODES = {"shared": {}, "threads": {"DFLO_MULTI_GROUP": "part"}, "one_thread": {"DFLO_MULTI_GROUP": "part", "DFLO_MULTI_THREADS": "0"},
          "strict": {"DFLO_MULTI_GROUP": "part", "DFLO_MULTI_STRICT": "1"}, "shared_strict": {"DFLO_MULTI_STRICT": "1"},
          "copy": {"DFLO_MULTI_GROUP": "part", "DFLO_MULTI_COPY": "1"},
-         "one_thread_strict": {"DFLO_MULTI_GROUP": "part", "DFLO_MULTI_THREADS": "0", "DFLO_MULTI_STRICT": "1"}}
+         "one_thread_strict": {"DFLO_MULTI_GROUP": "part", "DFLO_MULTI_THREADS": "0", "DFLO_MULTI_STRICT": "1"},
+         # "fine": every buffer a peer's kernel writes (ghost-trace tables, time-step tables, receive areas) in fine-grained device
+         # memory, with the strict mode -- the belt-and-braces arrangement bench.py falls back to when the default misbehaves across xGMI
+         "fine": {"DFLO_MULTI_GROUP": "part", "DFLO_PEER_FINEGRAINED": "1"},
+         "fine_strict": {"DFLO_MULTI_GROUP": "part", "DFLO_PEER_FINEGRAINED": "1", "DFLO_MULTI_STRICT": "1"}}
 
 
 @pytest.mark.parametrize("n_parts,method,mode", [(2, "slab", "shared"), (3, "slab", "shared"), (4, "rcb", "shared"),
                                                  (2, "slab", "threads"), (3, "slab", "threads"), (4, "rcb", "threads"),
                                                  (2, "slab", "one_thread"), (4, "rcb", "one_thread"), (3, "slab", "strict"),
-                                                 (4, "rcb", "shared_strict"), (3, "slab", "copy"), (4, "rcb", "one_thread_strict")])
+                                                 (4, "rcb", "shared_strict"), (3, "slab", "copy"), (4, "rcb", "one_thread_strict"),
+                                                 (3, "slab", "fine"), (4, "rcb", "fine_strict")])
 def test_c2_512_parts_bit_identical_to_the_single_engine(n_parts, method, mode, monkeypatch):
     for k, v in MODES[mode].items():
         monkeypatch.setenv(k, v)
@@ -133,7 +138,7 @@ def test_c2_512_parts_bit_identical_to_the_single_engine(n_parts, method, mode, 
     assert np.array_equal(got["u"], ref["u"])
 
 
-@pytest.mark.parametrize("mode", ["shared", "threads", "one_thread", "strict", "copy"])
+@pytest.mark.parametrize("mode", ["shared", "threads", "one_thread", "strict", "copy", "fine_strict"])
 def test_c4_slab_pair_matches_the_single_engine(mode, monkeypatch):
     for k, v in MODES[mode].items():
         monkeypatch.setenv(k, v)
