@@ -41,6 +41,14 @@ struct dflo_hip_engine {
   int avg_cur = 0;
   double *rhs = nullptr, *user_buf = nullptr;
   double *bval[2] = {nullptr, nullptr};
+  // Which of the two tables stage 0 reads (the other one: the later stages).  The roles swap from step to step where the limiter
+  // pass behind stage 0 takes the boundary programs along (LimArgs::bc_blocks): the values the later stages of step n used, at
+  // t_n + dt_n, ARE the values of stage 0 of step n + 1.  Valid while the uploaded (not program-evaluated) entries of the two tables
+  // are the same (bval_equal: the host copies of the last uploads) and the clock has not been set from outside since.
+  int bv_first = 0;
+  std::vector<double> bval_host[2];
+  bool bval_equal = true, bc_fuse = true, bc_take_along = false;
+  int64_t bc_later_step = -1;   // the step whose later-stage table was evaluated with the time step its clock advance will use
   int32_t *bface_kind = nullptr;
   // device-evaluated boundary functions: host copies of the programs, rebuilt device tables when they change
   std::vector<int32_t> bc_ops[DFLO_MAX_BOUNDARIES][4];
@@ -294,6 +302,7 @@ void time_collect(dflo_hip_engine *h) {
 // limiter kernels may then be launched for all shards or separately for the rim shards (those that read
 // ghost cells) and the interior shards, and it is finished by the reductions.
 int eval_boundary_programs(dflo_hip_engine *h, double dt_host);
+BcArgs bc_args(const dflo_hip_engine *h, double dt_host);
 static bool bc_op_is_rich(int op) {
   switch (op) {
     case DFLO_OP_POW: case DFLO_OP_SIN: case DFLO_OP_COS: case DFLO_OP_TAN: case DFLO_OP_EXP: case DFLO_OP_LOG: case DFLO_OP_ATAN2:
@@ -303,10 +312,22 @@ static bool bc_op_is_rich(int op) {
   }
 }
 
-int open_stage(dflo_hip_engine *h, int rk, double dt_host, bool residual_only, int which_override) {
+int open_stage(dflo_hip_engine *h, int rk, double dt_host, bool residual_only, int which_override, bool own_pass = false) {
   if (rk == 0 && !residual_only && h->n_bc_programs > 0) {  // boundary functions at t (stage 0) and t + dt (later stages)
-    const int rc = eval_boundary_programs(h, dt_host);
-    if (rc) return rc;
+    // own_pass: the caller will launch this stage's limiter pass over all shards itself (launch_stage): that pass can evaluate
+    // the later stages' table beside its own work, and stage 0 reads the table the previous step's later stages used
+    const bool limited = h->prm.limiter_type != DFLO_LIMITER_NONE || h->prm.pos_lim;
+    const bool take = own_pass && h->bc_fuse && !h->bc_dirty && !h->bc_rich && h->n_bc_ops <= kBcWaveOps && h->n_bc_consts <= kBcWaveConsts &&
+                      h->bval_equal && limited && !h->fuse_pos && h->basis == DFLO_BASIS_QK && h->plan.n_shards > 0 && !h->use_graph &&
+                      h->steps_done > 0 && h->bc_later_step == h->steps_done - 1;
+    h->bc_take_along = take;
+    if (take) {
+      h->bv_first ^= 1;
+    } else {
+      const int rc = eval_boundary_programs(h, dt_host);
+      if (rc) return rc;
+      h->bc_later_step = h->steps_done;
+    }
   }
   const bool last = rk == h->n_rk - 1;
   int out;
@@ -347,6 +368,27 @@ int open_stage(dflo_hip_engine *h, int rk, double dt_host, bool residual_only, i
     if (h->t_sample) ++h->t_stages;
   }
   return DFLO_OK;
+}
+
+BcArgs bc_args(const dflo_hip_engine *h, double dt_host) {
+  BcArgs a{};
+  a.ops = h->d_bc_ops;
+  a.consts = h->d_bc_consts;
+  a.prog = h->d_bc_prog;
+  a.bface_id = h->d_bface_id;
+  a.bxy = h->d_bxy;
+  a.bval0 = h->bval[h->bv_first];
+  a.bval1 = h->bval[h->bv_first ^ 1];
+  a.dt_dev = h->dt_dev;
+  a.dts = dt_source(h);
+  a.dt_host = dt_host;
+  a.faces = h->d_bc_faces;
+  a.pts = h->d_bc_pts;
+  a.n_faces = h->n_bc_faces;
+  a.N = h->N;
+  a.n_ops = h->n_bc_ops;
+  a.n_consts = h->n_bc_consts;
+  return a;
 }
 
 int eval_boundary_programs(dflo_hip_engine *h, double dt_host) {
@@ -402,23 +444,7 @@ int eval_boundary_programs(dflo_hip_engine *h, double dt_host) {
     h->bc_rich = rich;
     h->bc_dirty = false;
   }
-  BcArgs a{};
-  a.ops = h->d_bc_ops;
-  a.consts = h->d_bc_consts;
-  a.prog = h->d_bc_prog;
-  a.bface_id = h->d_bface_id;
-  a.bxy = h->d_bxy;
-  a.bval0 = h->bval[0];
-  a.bval1 = h->bval[1];
-  a.dt_dev = h->dt_dev;
-  a.dts = dt_source(h);
-  a.dt_host = dt_host;
-  a.faces = h->d_bc_faces;
-  a.pts = h->d_bc_pts;
-  a.n_faces = h->n_bc_faces;
-  a.N = h->N;
-  a.n_ops = h->n_bc_ops;
-  a.n_consts = h->n_bc_consts;
+  const BcArgs a = bc_args(h, dt_host);
   if (a.n_faces == 0) return DFLO_OK;
   if (h->bc_rich) hipLaunchKernelGGL(bc_eval_kernel<true>, dim3((a.n_faces * a.N + 63) / 64), dim3(kBcThreads), 0, h->stream, a);
   else hipLaunchKernelGGL(bc_eval_kernel<false>, dim3((a.n_faces * a.N + 63) / 64), dim3(kBcThreads), 0, h->stream, a);
@@ -451,7 +477,7 @@ int launch_update(dflo_hip_engine *h, double *rhs_out, int part) {
   a.cell_h = h->d_cell_h;
   a.cell_vert = h->d_cell_vert;
   a.n_slots = p.n_slots;
-  a.bval = h->bval[h->st_which];
+  a.bval = h->bval[h->st_which == 0 ? h->bv_first : h->bv_first ^ 1];
   a.bface_kind = h->bface_kind;
   a.dt_dev = h->dt_dev;
   a.dts = dt_source(h);
@@ -565,7 +591,7 @@ int fin_grid(int n_shards) {
   return std::max(1, (n_shards + chunk - 1) / chunk);
 }
 
-int launch_limiter(dflo_hip_engine *h, int tvb, int pos, int part, bool stage_data = false, const FinalArgs *fin = nullptr) {
+int launch_limiter(dflo_hip_engine *h, int tvb, int pos, int part, bool stage_data = false, const FinalArgs *fin = nullptr, bool take_bc = false) {
   const Plan &p = h->plan;
   if (h->pending_rk < 0) { const int rc = ensure_avg(h); if (rc) return rc; }   // standalone (apply_limiter / apply_positivity_limiter)
   LimArgs l{};
@@ -615,13 +641,20 @@ int launch_limiter(dflo_hip_engine *h, int tvb, int pos, int part, bool stage_da
     grid = std::min(grid, std::max(h->lim_grid, l.fin_blocks));
   }
   grid = std::max(grid, l.fin_blocks);   // (a launch over a few shards that carries the reductions of all of them)
-  hipLaunchKernelGGL(lf, dim3(grid), dim3(64), 0, h->stream, l);
+  size_t lds = 0;
+  if (take_bc && h->basis == DFLO_BASIS_QK) {   // the later stages' boundary values, by extra wavefronts behind the ones that limit
+    l.bc = bc_args(h, h->st_dt);
+    l.bc_blocks = 4 * ((l.bc.n_faces * l.bc.N + 63) / 64);
+    lds = l.bc_blocks > 0 ? kBcWaveLds : 0;
+  }
+  hipLaunchKernelGGL(lf, dim3(grid + l.bc_blocks), dim3(64), lds, h->stream, l);
   HIPCHK(h, hipGetLastError());
+  if (l.bc_blocks > 0 || (take_bc && l.bc.n_faces == 0)) h->bc_later_step = h->steps_done;
   return DFLO_OK;
 }
 
 // limiter of the open stage on one part of the shards
-int launch_stage_limiter(dflo_hip_engine *h, int part, const FinalArgs *fin = nullptr) {
+int launch_stage_limiter(dflo_hip_engine *h, int part, const FinalArgs *fin = nullptr, bool take_bc = false) {
   if (h->pending_rk < 0) { h->err = "no stage pending"; return DFLO_ERR_BAD_PARAM; }
   const bool limited = h->prm.limiter_type != DFLO_LIMITER_NONE || h->prm.pos_lim;
   if (!limited) return DFLO_OK;
@@ -630,7 +663,7 @@ int launch_stage_limiter(dflo_hip_engine *h, int part, const FinalArgs *fin = nu
     const int rc = launch_indicator(h, part);
     if (rc) return rc;
   }
-  return launch_limiter(h, h->prm.limiter_type == DFLO_LIMITER_TVB, h->prm.pos_lim, part, true, fin);
+  return launch_limiter(h, h->prm.limiter_type == DFLO_LIMITER_TVB, h->prm.pos_lim, part, true, fin, take_bc);
 }
 
 // reductions of the stage launched last
@@ -689,13 +722,15 @@ int launch_limit_finalize(dflo_hip_engine *h) {
                     h->prm.limiter_type == DFLO_LIMITER_TVB && !h->fuse_pos && h->plan.n_shards > 0;
   FinalArgs f{};
   if (fuse) final_args(h, f);
-  int rc = launch_stage_limiter(h, 0, fuse ? &f : nullptr);
+  const bool take_bc = h->bc_take_along && h->pending_rk == 0;
+  h->bc_take_along = false;
+  int rc = launch_stage_limiter(h, 0, fuse ? &f : nullptr, take_bc);
   if (rc) return rc;
   return launch_finish(h, fuse);
 }
 
 int launch_stage(dflo_hip_engine *h, int rk, double dt_host, double *rhs_out, int which_override) {
-  int rc = open_stage(h, rk, dt_host, rhs_out != nullptr, which_override);
+  int rc = open_stage(h, rk, dt_host, rhs_out != nullptr, which_override, true);
   if (rc) return rc;
   rc = launch_update(h, rhs_out, 0);
   if (rc || rhs_out) return rc;
@@ -847,6 +882,7 @@ int dflo_hip_create_with_cell_size(const dflo_mesh_t *mesh, const dflo_params_t 
   h->stream_override = tun.stream;
   h->fuse_dtq = tun.fuse_dtq;
   h->peer_fine = tun.peer_finegrained;
+  h->bc_fuse = tun.bc_fuse;
   h->ns = mesh->basis == DFLO_BASIS_PK ? h->N * (h->N + 1) / 2 : h->N * h->N;
   h->ndof = 4 * h->ns;
   h->mapping = mesh->mapping == DFLO_MAP_Q2 ? DFLO_MAP_Q1 : mesh->mapping;
@@ -1131,6 +1167,7 @@ int dflo_hip_set_solution(dflo_hip_handle h, const double *u) {
   const long long tot = (long long)p.n_slots * h->ndof;
   h->cur = h->old = 0;
   h->steps_done = 0;
+  h->bc_later_step = -1;
   h->ghost_avg_src = nullptr;
   HIPCHK(h, hipMemsetAsync(h->fin_counter + 1, 0, 3 * sizeof(int), h->stream));
   for (int i = 0; i < 4; ++i) h->flags_host[i] = 0;   // a new state: the flags of an earlier run are history
@@ -1197,8 +1234,13 @@ int dflo_hip_set_boundary_values(dflo_hip_handle h, int which, const double *val
   hipSetDevice(h->device);
   const size_t n = h->plan.bface_cell.size() * h->N * 4;
   if (n == 0) return DFLO_OK;
-  HIPCHK(h, hipMemcpyAsync(h->bval[which], values, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(h, hipMemcpyAsync(h->bval[which == 0 ? h->bv_first : h->bv_first ^ 1], values, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
+  // (an upload overwrites program-evaluated entries too: the next step evaluates both tables afresh)
+  h->bval_host[which].assign(values, values + n);
+  h->bval_equal = h->bval_host[0].size() == h->bval_host[1].size() &&
+                  (h->bval_host[0].empty() || std::memcmp(h->bval_host[0].data(), h->bval_host[1].data(), n * sizeof(double)) == 0);
+  h->bc_later_step = -1;
   return DFLO_OK;
 }
 
@@ -1207,7 +1249,7 @@ int dflo_hip_get_boundary_values(dflo_hip_handle h, int which, double *values) {
   hipSetDevice(h->device);
   const size_t n = h->plan.bface_cell.size() * h->N * 4;
   if (n == 0) return DFLO_OK;
-  HIPCHK(h, hipMemcpyAsync(values, h->bval[which], n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(h, hipMemcpyAsync(values, h->bval[which == 0 ? h->bv_first : h->bv_first ^ 1], n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
   return DFLO_OK;
 }
@@ -1235,6 +1277,7 @@ int dflo_hip_set_boundary_program(dflo_hip_handle h, int32_t boundary_id, int32_
   o.assign(ops, ops + 2 * (size_t)n_ops);
   h->bc_consts[boundary_id][component].assign(consts, consts + (n_ops > 0 ? n_consts : 0));
   h->bc_dirty = true;
+  h->bc_later_step = -1;
   return DFLO_OK;
 }
 
@@ -1280,6 +1323,7 @@ static int launch_compute_dt(dflo_hip_engine *h, double elapsed_time) {
     launch_dt_q(h);
   HIPCHK(h, hipGetLastError());
   double tt[4] = {0, elapsed_time, 0, 0};
+  h->bc_later_step = -1;   // the clock is set from outside: the later stages' table of the last step is not "this step's t" any more
   HIPCHK(h, hipMemcpyAsync(h->dt_dev, tt, sizeof(tt), hipMemcpyHostToDevice, h->stream));
   FinalArgs f{};
   f.shard_res = h->shard_res;

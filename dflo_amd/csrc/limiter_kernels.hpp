@@ -2,6 +2,7 @@
 // Part of the device side of engine.hip (see there for the layout of the data and of a stage).
 #pragma once
 #include "kernels_common.hpp"
+#include "bc_program.hpp"
 
 namespace dflo {
 
@@ -75,6 +76,12 @@ struct LimArgs {
   // launch and its latency less per step (C3: 6 of 139 us).  0: finalize_kernel is launched as usual.
   int fin_blocks;
   FinalArgs fin;
+  // the pass behind stage 0 can take the boundary programs along: bc_blocks extra wavefronts at the end of the grid fill the table
+  // of the later stages (values at t + dt) while the others limit -- stage 0 itself has read the table the previous step's later
+  // stages used, whose program-evaluated entries are the values at this step's t, bit for bit (the clock adds the same dt to the
+  // same t).  bc_eval_kernel and its 11 us then leave the path between two steps (C4).  0: nothing to take along.
+  int bc_blocks;
+  BcArgs bc;
   KBasis kb;
 };
 
@@ -297,6 +304,12 @@ __device__ __forceinline__ void limiter_shard(const LimArgs &a, const int shard,
 
 template <int N>
 __global__ __launch_bounds__(64) void limiter_kernel(const LimArgs a) {
+  extern __shared__ unsigned char bc_lds[];   // kBcWaveLds bytes when bc_blocks > 0, else none
+  const int grid = (int)gridDim.x - a.bc_blocks;   // the wavefronts that limit
+  if ((int)blockIdx.x >= grid) {
+    bc_eval_wave(a.bc, (int)blockIdx.x - grid, 1, bc_lds);
+    return;
+  }
   if (a.mark_list) {
     // the marked shards from the stage kernel's list, in the order they were appended (any order gives the same bits: a shard's
     // pass rewrites its own cells and reads averages, which limiting does not change).  The step's reductions ride on the LAST
@@ -304,9 +317,9 @@ __global__ __launch_bounds__(64) void limiter_kernel(const LimArgs a) {
     ulonglong2 e = a.mark_list[blockIdx.x];   // asked for with the count, not behind it (an entry beyond the count is not used)
     const int cnt = __builtin_amdgcn_readfirstlane(*(const volatile int *)a.mark_cnt);
     if (blockIdx.x == 0 && threadIdx.x == 0) *a.mark_cnt_next = 0;
-    const int fb = (int)blockIdx.x - ((int)gridDim.x - a.fin_blocks);
+    const int fb = (int)blockIdx.x - (grid - a.fin_blocks);
     if (a.fin_blocks > 0 && fb >= 0) finalize_by_wave(a.fin, fb, a.fin_blocks);
-    for (int k = blockIdx.x; k < cnt; k += gridDim.x) {
+    for (int k = blockIdx.x; k < cnt; k += grid) {
       if (k != (int)blockIdx.x) e = a.mark_list[k];
       limiter_shard<N>(a, (int)e.x, true, e.y);
     }

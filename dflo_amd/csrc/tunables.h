@@ -17,6 +17,8 @@ struct Tunables {
   bool fuse_dtq = true;    // DFLO_FUSE_DTQ=0    bilinear cells: compute_time_step_q by the separate pass instead of the last stage kernel
   bool fuse_pos = true;    // DFLO_FUSE_POS=0    positivity without TVB on Qk: separate limiter pass instead of inside the stage kernel
   bool fuse_fin = true;    // DFLO_FUSE_FIN=0    TVB on Qk squares: finalize_kernel as its own launch instead of inside the limiter pass that ends the step
+  bool bc_fuse = true;     // DFLO_BC_FUSE=0     boundary programs always by bc_eval_kernel (default: the limiter pass behind stage 0 takes the later
+                           //                    stages' table along, stage 0 reads the table the previous step's later stages used)
   bool lazy_avg = true;    // DFLO_LAZY_AVG=0    store the cell averages of every stage (default: only when somebody reads them)
   bool lxf_from_dofs = true;   // DFLO_LXF_FROM_DOFS=0   the LxF flux on squares reads the arrays of cell averages (default: (u, v, c) of the averages from the DoFs)
   bool lim_list = true;    // DFLO_LIM_LIST=0    with marks: one wavefront per shard looks at its word instead of a short grid walking the list of marked shards
@@ -71,6 +73,7 @@ inline Tunables read_tunables() {
   t.fuse_dtq = flag("DFLO_FUSE_DTQ", true);
   t.fuse_pos = flag("DFLO_FUSE_POS", true);
   t.fuse_fin = flag("DFLO_FUSE_FIN", true);
+  t.bc_fuse = flag("DFLO_BC_FUSE", true);
   t.lazy_avg = flag("DFLO_LAZY_AVG", true);
   t.lxf_from_dofs = flag("DFLO_LXF_FROM_DOFS", true);
   t.lim_mask = tri("DFLO_LIM_MASK");
