@@ -189,10 +189,19 @@ def build_case(args, world):
     prm = dflo_amd.Parameters(flux=args.flux, cfl=0.9)
     ic, bc_fn, programs = problems.isentropic_vortex, None, {}
     if args.config == "c2":
-        nx, ny = args.nx * world, args.nx
-        mesh = dflo_amd.Mesh.cartesian(nx, ny, -5.0, -5.0, 10.0 / args.nx, [-1] * 4, args.degree)
+        nx, ny = args.nx * world, (args.ny or args.nx)
+        mesh = dflo_amd.Mesh.cartesian(nx, ny, -5.0, -5.0, 10.0 / max(args.nx, ny), [-1] * 4, args.degree)
         mesh.set_basis(args.basis)
         ic = lambda x, y: problems.isentropic_vortex(((x + 5.0) % 10.0) - 5.0, y)   # one vortex per GPU's square
+        if args.ny and args.ny != args.nx:   # a slab of the square (--ny): a smooth state with the slab's periods (the vortex does not fit)
+            wx, wy = 10.0 * nx / max(args.nx, ny), 10.0 * ny / max(args.nx, ny)
+
+            def ic(x, y):
+                X, Y = 2 * np.pi * (x + 5.0) / wx, 2 * np.pi * (y + 5.0) / wy
+                rho = 1.0 + 0.06 * np.sin(X + 0.3) * np.cos(Y)
+                u, v = 0.5 + 0.09 * np.cos(X) * np.sin(Y + 0.1), -0.2 + 0.08 * np.sin(X + Y)
+                pr = 1.0 + 0.09 * np.cos(X + 0.7) * np.cos(Y - 0.2)
+                return rho * u, rho * v, rho, pr / 0.4 + 0.5 * rho * (u * u + v * v)
     elif args.config == "c3":   # examples/sod_shock_tube: slip walls (0), outflow right (1), inflow left (2)
         nx, ny = 2048 * world, 256
         mesh = dflo_amd.Mesh.cartesian(nx, ny, 0.0, 0.0, 1.0 / nx, [2, 1, 0, 0], 1)
@@ -348,6 +357,9 @@ def main():
     ap.add_argument("--steps", type=int, default=400)
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--nx", type=int, default=1024, help="cells per direction per GPU")
+    ap.add_argument("--ny", type=int, default=0,
+                    help="c2 only: rows of cells (default: --nx).  --nx 128 --ny 1024 --self-halo T is the share of one rank of the 1024^2 mesh cut "
+                         "8 ways, run through the whole rank schedule: T(1024^2 plain) / T(this) bounds the strong-scaling speed-up from above")
     ap.add_argument("--degree", type=int, default=2)
     ap.add_argument("--flux", default="hllc")
     ap.add_argument("--basis", default="Qk", choices=["Qk", "Pk"], help="c2 only; Pk: dflo's FE_DGP (modal) element")
@@ -557,7 +569,7 @@ def main():
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {
                 "workload": {"c2": ("isentropic_vortex, %dx%d quads per GPU (global %dx%d), %s%d, %s, periodic, SSP-RK %d stages"
-                                    % (args.nx, args.nx, nx, ny, args.basis[0], args.degree, args.flux.upper(), n_rk)) if args.scaling == "weak" else
+                                    % (args.nx, ny, nx, ny, args.basis[0], args.degree, args.flux.upper(), n_rk)) if args.scaling == "weak" else
                                    ("isentropic_vortex, %dx%d quads cut into %d x-slab(s) (strong scaling), %s%d, %s, periodic, SSP-RK %d stages"
                                     % (nx, ny, world * args.parts_per_gpu, args.basis[0], args.degree, args.flux.upper(), n_rk)),
                              "c3": "sod_shock_tube, %dx256 quads, Q1, ROE, TVB(M=0,beta=2,char)+positivity, SSP-RK 2 stages" % nx,

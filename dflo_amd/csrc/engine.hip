@@ -312,12 +312,13 @@ static bool bc_op_is_rich(int op) {
   }
 }
 
-int open_stage(dflo_hip_engine *h, int rk, double dt_host, bool residual_only, int which_override, bool own_pass = false) {
+int open_stage(dflo_hip_engine *h, int rk, double dt_host, bool residual_only, int which_override) {
   if (rk == 0 && !residual_only && h->n_bc_programs > 0) {  // boundary functions at t (stage 0) and t + dt (later stages)
-    // own_pass: the caller will launch this stage's limiter pass over all shards itself (launch_stage): that pass can evaluate
-    // the later stages' table beside its own work, and stage 0 reads the table the previous step's later stages used
+    // The stage's limiter pass over all shards -- or, in the multi-device schedule, over everything but the rim -- can evaluate the
+    // later stages' table beside its own work, and stage 0 reads the table the previous step's later stages used.  A stage that is
+    // finished without such a pass gets the table from bc_eval_kernel then (launch_finish).
     const bool limited = h->prm.limiter_type != DFLO_LIMITER_NONE || h->prm.pos_lim;
-    const bool take = own_pass && h->bc_fuse && !h->bc_dirty && !h->bc_rich && h->n_bc_ops <= kBcWaveOps && h->n_bc_consts <= kBcWaveConsts &&
+    const bool take = h->bc_fuse && !h->bc_dirty && !h->bc_rich && h->n_bc_ops <= kBcWaveOps && h->n_bc_consts <= kBcWaveConsts &&
                       h->bval_equal && limited && !h->fuse_pos && h->basis == DFLO_BASIS_QK && h->plan.n_shards > 0 && !h->use_graph &&
                       h->steps_done > 0 && h->bc_later_step == h->steps_done - 1;
     h->bc_take_along = take;
@@ -591,7 +592,7 @@ int fin_grid(int n_shards) {
   return std::max(1, (n_shards + chunk - 1) / chunk);
 }
 
-int launch_limiter(dflo_hip_engine *h, int tvb, int pos, int part, bool stage_data = false, const FinalArgs *fin = nullptr, bool take_bc = false) {
+int launch_limiter(dflo_hip_engine *h, int tvb, int pos, int part, bool stage_data = false, const FinalArgs *fin = nullptr) {
   const Plan &p = h->plan;
   if (h->pending_rk < 0) { const int rc = ensure_avg(h); if (rc) return rc; }   // standalone (apply_limiter / apply_positivity_limiter)
   LimArgs l{};
@@ -642,19 +643,21 @@ int launch_limiter(dflo_hip_engine *h, int tvb, int pos, int part, bool stage_da
   }
   grid = std::max(grid, l.fin_blocks);   // (a launch over a few shards that carries the reductions of all of them)
   size_t lds = 0;
-  if (take_bc && h->basis == DFLO_BASIS_QK) {   // the later stages' boundary values, by extra wavefronts behind the ones that limit
+  if (stage_data && h->bc_take_along && h->pending_rk == 0 && (part == 0 || part == 2) && h->basis == DFLO_BASIS_QK) {
+    // the later stages' boundary values, by extra wavefronts behind the ones that limit
     l.bc = bc_args(h, h->st_dt);
     l.bc_blocks = 4 * ((l.bc.n_faces * l.bc.N + 63) / 64);
     lds = l.bc_blocks > 0 ? kBcWaveLds : 0;
+    h->bc_take_along = false;
+    h->bc_later_step = h->steps_done;
   }
   hipLaunchKernelGGL(lf, dim3(grid + l.bc_blocks), dim3(64), lds, h->stream, l);
   HIPCHK(h, hipGetLastError());
-  if (l.bc_blocks > 0 || (take_bc && l.bc.n_faces == 0)) h->bc_later_step = h->steps_done;
   return DFLO_OK;
 }
 
 // limiter of the open stage on one part of the shards
-int launch_stage_limiter(dflo_hip_engine *h, int part, const FinalArgs *fin = nullptr, bool take_bc = false) {
+int launch_stage_limiter(dflo_hip_engine *h, int part, const FinalArgs *fin = nullptr) {
   if (h->pending_rk < 0) { h->err = "no stage pending"; return DFLO_ERR_BAD_PARAM; }
   const bool limited = h->prm.limiter_type != DFLO_LIMITER_NONE || h->prm.pos_lim;
   if (!limited) return DFLO_OK;
@@ -663,7 +666,7 @@ int launch_stage_limiter(dflo_hip_engine *h, int part, const FinalArgs *fin = nu
     const int rc = launch_indicator(h, part);
     if (rc) return rc;
   }
-  return launch_limiter(h, h->prm.limiter_type == DFLO_LIMITER_TVB, h->prm.pos_lim, part, true, fin, take_bc);
+  return launch_limiter(h, h->prm.limiter_type == DFLO_LIMITER_TVB, h->prm.pos_lim, part, true, fin);
 }
 
 // reductions of the stage launched last
@@ -694,6 +697,12 @@ int launch_finish(dflo_hip_engine *h, bool reductions_done = false) {
   const int rk = h->pending_rk;
   if (rk < 0) { h->err = "no stage pending"; return DFLO_ERR_BAD_PARAM; }
   const bool last = rk == h->n_rk - 1;
+  if (h->bc_take_along) {   // no limiter pass of this stage took the boundary programs along: the kernel of their own, before the next stage
+    h->bc_take_along = false;
+    const int rc = eval_boundary_programs(h, h->st_dt);
+    if (rc) return rc;
+    h->bc_later_step = h->steps_done;
+  }
   if (last && h->geo == 1) {  // bilinear cells: dt from the point values of the (limited) new solution,
     if (h->dtq_parts != 3) {   // unless the limiter pass of this stage has formed it on the way
       launch_dt_q(h);
@@ -722,15 +731,13 @@ int launch_limit_finalize(dflo_hip_engine *h) {
                     h->prm.limiter_type == DFLO_LIMITER_TVB && !h->fuse_pos && h->plan.n_shards > 0;
   FinalArgs f{};
   if (fuse) final_args(h, f);
-  const bool take_bc = h->bc_take_along && h->pending_rk == 0;
-  h->bc_take_along = false;
-  int rc = launch_stage_limiter(h, 0, fuse ? &f : nullptr, take_bc);
+  int rc = launch_stage_limiter(h, 0, fuse ? &f : nullptr);
   if (rc) return rc;
   return launch_finish(h, fuse);
 }
 
 int launch_stage(dflo_hip_engine *h, int rk, double dt_host, double *rhs_out, int which_override) {
-  int rc = open_stage(h, rk, dt_host, rhs_out != nullptr, which_override, true);
+  int rc = open_stage(h, rk, dt_host, rhs_out != nullptr, which_override);
   if (rc) return rc;
   rc = launch_update(h, rhs_out, 0);
   if (rc || rhs_out) return rc;
