@@ -16,6 +16,7 @@
 //
 // Device code: kernels_common.hpp (argument blocks, helpers), stage_kernels.hpp (instantiated per degree in stage_inst.hip),
 // limiter_kernels.hpp, small_kernels.hpp.  This file: the engine object and the C ABI.
+#include <hip/hip_ext.h>
 #include "stage_kernels.hpp"
 #include "small_kernels.hpp"
 #include "tunables.h"
@@ -95,6 +96,7 @@ struct dflo_hip_engine {
   double pending_dt = -1.0;
   int32_t *d_send_slots = nullptr;
   int n_send = 0;
+  hipEvent_t next_stop = nullptr;      // dflo_hip_attach_event: the next stage / limiter kernel launched carries this event as its completion signal
   unsigned int *send_done = nullptr;   // [3] workgroup counters of the signalling pack kernels, by kind (dflo_hip_pack_send_to_signal)
   bool peer_fine = false;              // DFLO_PEER_FINEGRAINED=1: what a peer's kernel writes lives in fine-grained memory
   const double *ghost_avg_src = nullptr;   // dflo_hip_ghost_avg_source: where the Qk limiter pass finds the ghost cells' averages
@@ -453,6 +455,24 @@ int eval_boundary_programs(dflo_hip_engine *h, double dt_host) {
   return DFLO_OK;
 }
 
+// The event a multi-device driver wants recorded behind the next kernel rides on that kernel's own completion signal
+// (hipExtLaunchKernel's stopEvent) instead of a record packet behind it: 3.5 us less between two kernels of a stream
+// (tools/stop_event_probe.hip).  A launch that turns out to be empty records the event the plain way.
+template <class K, class A>
+void launch_with_event(dflo_hip_engine *h, K fn, dim3 grid, dim3 block, size_t lds, const A &args) {
+  if (h->next_stop) {
+    hipExtLaunchKernelGGL(fn, grid, block, (std::uint32_t)lds, h->stream, nullptr, h->next_stop, 0, args);
+    h->next_stop = nullptr;
+  } else {
+    hipLaunchKernelGGL(fn, grid, block, lds, h->stream, args);
+  }
+}
+void drop_attached_event(dflo_hip_engine *h) {
+  if (!h->next_stop) return;
+  hipEventRecord(h->next_stop, h->stream);
+  h->next_stop = nullptr;
+}
+
 // residual + update kernel of the open stage; part 0: all shards, 1: rim shards, 2: interior shards
 int launch_update(dflo_hip_engine *h, double *rhs_out, int part) {
   const Plan &p = h->plan;
@@ -512,7 +532,7 @@ int launch_update(dflo_hip_engine *h, double *rhs_out, int part) {
   a.degree = h->degree;
   a.kb = h->kb;
   part_list(h, part, &a.shard_list, &a.n_list);
-  if (a.n_list == 0) return DFLO_OK;
+  if (a.n_list == 0) { drop_attached_event(h); return DFLO_OK; }
   a.sweep_rev = next_sweep(h, part);
   const int mode_ = rhs_out ? 2 : (h->ark[rk] != 0.0 ? 1 : 0);
   a.flags = h->flags;
@@ -549,7 +569,7 @@ int launch_update(dflo_hip_engine *h, double *rhs_out, int part) {
   }
   stage_fn fn = h->basis == DFLO_BASIS_PK ? pick_pk(h->N, h->prm.flux_type, mode_, streams_out(h) | (h->geo << 1)) : pick_stage(h->N, h->prm.flux_type, mode_, h->geo, pos_, streams_out(h));
   time_begin(h);
-  hipLaunchKernelGGL(fn, dim3(grid_for(a.n_list)), dim3(64 * h->N), h->lds_bytes, h->stream, a);
+  launch_with_event(h, fn, dim3(grid_for(a.n_list)), dim3(64 * h->N), h->lds_bytes, a);
   time_end(h);
   HIPCHK(h, hipGetLastError());
   return DFLO_OK;
@@ -624,7 +644,7 @@ int launch_limiter(dflo_hip_engine *h, int tvb, int pos, int part, bool stage_da
   l.degree = h->degree;
   part_list(h, part, &l.shard_list, &l.n_list);
   if (l.dtq) h->dtq_parts |= part == 0 ? 3 : part;
-  if (l.n_list == 0) return DFLO_OK;
+  if (l.n_list == 0) { drop_attached_event(h); return DFLO_OK; }
   l.sweep_rev = next_sweep(h, part);
   if (fin) {
     l.fin = *fin;
@@ -651,7 +671,7 @@ int launch_limiter(dflo_hip_engine *h, int tvb, int pos, int part, bool stage_da
     h->bc_take_along = false;
     h->bc_later_step = h->steps_done;
   }
-  hipLaunchKernelGGL(lf, dim3(grid + l.bc_blocks), dim3(64), lds, h->stream, l);
+  launch_with_event(h, lf, dim3(grid + l.bc_blocks), dim3(64), lds, l);
   HIPCHK(h, hipGetLastError());
   return DFLO_OK;
 }
@@ -660,8 +680,10 @@ int launch_limiter(dflo_hip_engine *h, int tvb, int pos, int part, bool stage_da
 int launch_stage_limiter(dflo_hip_engine *h, int part, const FinalArgs *fin = nullptr) {
   if (h->pending_rk < 0) { h->err = "no stage pending"; return DFLO_ERR_BAD_PARAM; }
   const bool limited = h->prm.limiter_type != DFLO_LIMITER_NONE || h->prm.pos_lim;
-  if (!limited) return DFLO_OK;
-  if (h->fuse_pos) return DFLO_OK;   // positivity alone: the stage kernel has applied it on the way out
+  if (!limited || h->fuse_pos) {   // (fuse_pos: positivity alone, the stage kernel has applied it on the way out)
+    drop_attached_event(h);
+    return DFLO_OK;
+  }
   if (h->prm.limiter_type == DFLO_LIMITER_TVB) {  // compute_shock_indicator(); apply_limiter();  src/claw.cc:763-764
     const int rc = launch_indicator(h, part);
     if (rc) return rc;
@@ -1559,6 +1581,12 @@ int dflo_hip_stage_update_part(dflo_hip_handle h, int part) {
   if (check_handle(h) || part < 0 || part > 4 || h->pending_rk < 0) return DFLO_ERR_BAD_PARAM;
   hipSetDevice(h->device);
   return launch_update(h, nullptr, part);
+}
+
+int dflo_hip_attach_event(dflo_hip_handle h, void *event) {
+  if (check_handle(h)) return DFLO_ERR_BAD_PARAM;
+  h->next_stop = (hipEvent_t)event;
+  return DFLO_OK;
 }
 
 int dflo_hip_stage_limit_part(dflo_hip_handle h, int part) {

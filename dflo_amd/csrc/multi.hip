@@ -239,6 +239,7 @@ struct Group {
   hipEvent_t ev_open = nullptr, ev_rim = nullptr, ev_rim_prev = nullptr, ev_ring = nullptr, ev_unpack = nullptr, ev_chunk[2] = {nullptr, nullptr};
   bool unpack_pending = false;   // the comm stream has work the compute stream has not waited for
   bool rim_pending = false;      // ... among it the rim of the previous stage
+  bool open_attached = false;    // ev_open rides on the compute stream's last kernel of the previous stage (dflo_hip_attach_event)
 };
 struct Worker {
   std::thread th;
@@ -719,33 +720,48 @@ int stage_phase(dflo_hip_multi *m, Group &g, const StageCtx &s, int ph) {
   switch (ph) {
     case 0:   // open the stage (buffer roles; rk = 0: boundary programs on M); then C may start once M is here
       for (int i : g.parts) MENG(m, m->parts[i], dflo_hip_stage_open(m->parts[i].eng, s.rk, s.dt));
-      MHIP(m, hipEventRecord(g.ev_open, g.M));       // interior of the previous stage, the step's time step, boundary data
+      // interior of the previous stage, the step's time step, boundary data: recorded here, unless the compute stream's last
+      // kernel of the previous stage carries the event as its completion signal (phases 2 / 4)
+      if (!g.open_attached || s.rk == 0) MHIP(m, hipEventRecord(g.ev_open, g.M));
+      g.open_attached = false;
       MHIP(m, hipStreamWaitEvent(g.C, g.ev_open, 0));
       return DFLO_OK;
     case 1:   // the rim on C and what leaves first
       for (int i : g.parts) {
         Part &p = m->parts[i];
         MENG(m, p, dflo_hip_set_stream(p.eng, g.C));
+        // What the compute stream waits for -- TVB: the UPDATE of rim + ring (their averages; not the averages' way to the
+        // neighbours, which in rank mode is an RCCL kernel that beside a full-size interior launch takes as long as the launch,
+        // profiles/r05/tl_c4_self_rccl_before.txt); otherwise the rim's update and limiter -- is the completion of the last part's
+        // last kernel here: the event rides on that kernel (dflo_hip_attach_event), no record packet behind it
+        const bool last_part = i == g.parts.back();
+        if (last_part && (m->tvb || !m->sep_limiter)) MENG(m, p, dflo_hip_attach_event(p.eng, m->tvb ? g.ev_ring : g.ev_rim));
         MENG(m, p, dflo_hip_stage_update_part(p.eng, rim_update));
         int rc = mark_used(m, p, CH_TRACES, apar);     // the rim kernel has read the trace table of the exchange before (area apar = upar ^ 1)
         if (rc) return rc;
-        // TVB: what the compute stream's limiter pass waits for is the UPDATE of rim + ring (their averages) -- recorded behind the
-        // last part's update, not behind the averages' way to the neighbours (in rank mode that is an RCCL kernel, which beside a
-        // full-size interior launch takes as long as the launch: profiles/r05/tl_c4_self_rccl_before.txt)
-        if (m->tvb && i == g.parts.back()) MHIP(m, hipEventRecord(g.ev_ring, g.C));
-        if (!m->tvb && m->sep_limiter) MENG(m, p, dflo_hip_stage_limit_part(p.eng, 1));
+        if (!m->tvb && m->sep_limiter) {
+          if (last_part) MENG(m, p, dflo_hip_attach_event(p.eng, g.ev_rim));
+          MENG(m, p, dflo_hip_stage_limit_part(p.eng, 1));
+        }
         rc = m->tvb ? post(m, p, CH_AVG, apar) : send_state(m, p, upar, apar, true);
         MENG(m, p, dflo_hip_set_stream(p.eng, g.M));
         if (rc) return rc;
       }
-      if (!m->tvb) MHIP(m, hipEventRecord(g.ev_rim, g.C));
       return DFLO_OK;
     case 2:   // the interior on M, next to it
       // the rim cells of the previous stage are the halo of the interior.  Not with TVB: there the update is split at rim + ring
       // | rest, and a shard of the rest has no neighbour in the rim (Plan::rim2_shards) -- its halo, ring and rest, was limited
       // by this stream's own pass; the comm stream's chain (averages -> limit rim -> traces, the long one) is off this stream's path
       if (g.rim_pending && !m->tvb) MHIP(m, hipStreamWaitEvent(g.M, g.ev_rim_prev, 0));
-      for (int i : g.parts) MENG(m, m->parts[i], dflo_hip_stage_update_part(m->parts[i].eng, int_update));
+      for (int i : g.parts) {
+        // nothing else of this stage follows on this stream (no limiter pass, no reductions): the next stage's "open" is the
+        // completion of the last part's interior kernel
+        if (i == g.parts.back() && !m->tvb && !m->sep_limiter && !s.last) {
+          MENG(m, m->parts[i], dflo_hip_attach_event(m->parts[i].eng, g.ev_open));
+          g.open_attached = true;
+        }
+        MENG(m, m->parts[i], dflo_hip_stage_update_part(m->parts[i].eng, int_update));
+      }
       return DFLO_OK;
     case 3:   // TVB: the averages of the neighbours across the cut arrive: limit the rim, send its cells
       if (!m->tvb) return DFLO_OK;
@@ -772,7 +788,13 @@ int stage_phase(dflo_hip_multi *m, Group &g, const StageCtx &s, int ph) {
     case 4:   // limiter of the other shards (TVB: it reads averages from the ring), the stage's reductions
       if (m->tvb) MHIP(m, hipStreamWaitEvent(g.M, g.ev_ring, 0));
       if (m->tvb || m->sep_limiter)
-        for (int i : g.parts) MENG(m, m->parts[i], dflo_hip_stage_limit_part(m->parts[i].eng, 2));
+        for (int i : g.parts) {
+          if (i == g.parts.back() && !s.last) {   // ... or of the last part's limiter pass
+            MENG(m, m->parts[i], dflo_hip_attach_event(m->parts[i].eng, g.ev_open));
+            g.open_attached = true;
+          }
+          MENG(m, m->parts[i], dflo_hip_stage_limit_part(m->parts[i].eng, 2));
+        }
       // the step's reductions take in the rim shards' partials: those of their UPDATE, which with TVB this stream has waited for
       // already (ev_ring) -- the limiter changes neither the averages nor the residual
       if (s.last && !m->tvb) MHIP(m, hipStreamWaitEvent(g.M, g.ev_rim, 0));

@@ -304,6 +304,11 @@ int dflo_hip_use_ghost_traces(dflo_hip_handle h, int which);
  * instead of into a staging buffer that a copy per peer then moves.  kind: 0 whole cells ([ndof + 4] doubles per record,
  * as pack_send_cells), 1 cell averages ([4], as pack_send_avg), 2 face traces ([4 (k+1)], as pack_send_traces; the send
  * list is that of set_send_faces).  n_segments <= 16. */
+/* The next stage or limiter kernel this engine launches (stage_update_part / stage_limit_part) carries `event` (a hipEvent_t)
+ * as its completion signal -- hipExtLaunchKernel's stopEvent -- instead of the caller recording the event behind it: one packet
+ * less between two kernels of a stream (the multi-device schedule orders its two streams with one such event per phase).
+ * If that launch turns out to be empty the event is recorded the plain way. */
+int dflo_hip_attach_event(dflo_hip_handle h, void *event);
 int dflo_hip_pack_send_to(dflo_hip_handle h, int kind, int n_segments, const int32_t *first, void *const *dst);
 /* The same, and the kernel tells the receivers: once every record of the launch is visible system-wide, the workgroup that
  * finishes last stores `seq` (release, system scope) into the 64-bit words flags[i] -- sequence words in the receivers'
