@@ -523,6 +523,28 @@ def test_bench_line_contract(extra):
     assert d["value"] > 0 and abs(d["value"] - d["config"]["n_dofs"] * d["config"]["n_rk"] / (d["ms_per_step"] * 1e-3) / 1e6) <= 1e-6 * d["value"]
 
 
+@pytest.mark.parametrize("transport,extra", [("rccl", []), ("ipc", ["--config", "c3"]), ("direct", ["--nx", "64", "--ny", "256"])])
+def test_bench_self_halo_line(transport, extra):
+    """bench.py --self-halo T: the one part is its own neighbour and runs the whole rank schedule (tests/test_gpu_selfhalo.py holds
+    its results to the single engine bit for bit); the line says so, carries the exchange waits, and its own check holds"""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "6", "--warmup", "2", "--self-halo", transport] + (extra or ["--nx", "128"])
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    c = d["config"]
+    assert d["n_gpus"] == 1 and c["self_halo"] == transport and "self-halo" in c["transport"]
+    assert ("ncclSend" in c["transport"]) == (transport == "rccl") and ("sequence words" in c["transport"]) == (transport == "ipc")
+    assert c["exchange_samples"][0] > 0 and c["exchange_wait_us"][0] > 0.0
+    assert "cpu_baseline" not in d and "secondary" not in d      # a measurement of the schedule, not the headline line
+    if "--config" not in extra:
+        assert float(c["check"].split("=")[-1]) < 1e-12
+    if "--ny" in extra:
+        assert "64x256 quads per GPU" in c["workload"]
+
+
 @pytest.mark.parametrize("extra", [[], ["--scaling", "strong"], ["--config", "c3"]])
 def test_bench_line_of_two_ranks_launched_the_drivers_way(extra):
     """bench.py --gpus 2 as the round driver launches it (python -m torch.distributed.run, one rank per GPU, 127.0.0.1), on this

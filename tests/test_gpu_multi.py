@@ -304,7 +304,21 @@ def test_random_configurations_in_parts_against_the_single_engine():
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_multi.py"), "200", "21"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "200 cases, 0 failures" in r.stdout
-    assert "of them on the nodal basis: 0" in r.stdout or "limited runs that are not bit-identical" not in r.stdout
+    assert "nodal basis, limited, not bit-identical: 0\n" in r.stdout, r.stdout[-1500:]     # (limited runs included)
+
+
+@pytest.mark.parametrize("mode", ["self_rccl", "self_ipc", "self_direct"])
+def test_random_configurations_against_themselves(mode):
+    """the same generator, ONE part that is its own neighbour across a virtual cut (dflo_hip_multi_create_self) through the rank
+    schedule with RCCL / the IPC sequence words, or the one-process schedule: every kind of record across the cut of random
+    meshes, the single engine's bits on the nodal basis"""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_multi.py"), "80", "23"], capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, FM_MODE=mode))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "80 cases (%s), 0 failures" % mode in r.stdout
+    assert "nodal basis, limited, not bit-identical: 0\n" in r.stdout, r.stdout[-1500:]
 
 
 def test_random_switch_settings_give_the_same_bits():
