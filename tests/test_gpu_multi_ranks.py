@@ -83,10 +83,14 @@ def test_ranks_on_one_device_match_the_single_engine(name, world, transport):
         assert ret["err"] < 1e-8
 
 
-def test_random_configurations_on_two_ranks():
-    """tools/fuzz_ranks.py: two processes walk 40 random configurations together (one engine per process, gloo callbacks); nodal
-    basis bit-identical to the single engine, modal basis to 1e-13, the ranks agree on every time step and stop."""
+@pytest.mark.parametrize("transport", ["callbacks", "ipc"])
+def test_random_configurations_on_two_ranks(transport):
+    """tools/fuzz_ranks.py: two processes walk 40 random configurations together (one engine per process; gloo callbacks, or the IPC
+    transport set up over them: handles of every receive area of every random mesh); nodal basis bit-identical to the single engine,
+    modal basis to 1e-13, the ranks agree on every time step and stop."""
     import subprocess
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_ranks.py"), "40", "61", "2"], capture_output=True, text=True, timeout=900)
+    env = dict(os.environ, DFLO_RANK_TRANSPORT="ipc") if transport == "ipc" else dict(os.environ)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_ranks.py"), "40", "61" if transport == "callbacks" else "62", "2"],
+                       capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "40 cases on 2 ranks, 0 failures" in r.stdout
