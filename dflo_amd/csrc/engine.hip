@@ -103,6 +103,7 @@ struct dflo_hip_engine {
   // ghost cells known by their face traces (Qk without the KXRCF indicator): two buffers, the stage kernels read Tg[tg_cur]
   // while the neighbours' next traces arrive in the other one
   bool trace_halo = false;
+  bool tg_external = false, dt_external = false;   // Tg / dt_mins belong to the caller (dflo_hip_set_ghost_trace_buffers, _set_dt_table_buffer)
   double *Tg[2] = {nullptr, nullptr};
   int tg_cur = 0, n_gt = 0;
   int32_t *d_gt_slot = nullptr, *d_gt_face = nullptr, *d_sendf_slot = nullptr, *d_sendf_face = nullptr;
@@ -1167,8 +1168,10 @@ int dflo_hip_destroy(dflo_hip_handle h) {
   hipFree(h->d_rim_list); hipFree(h->d_int_list); hipFree(h->d_rim2_list); hipFree(h->d_rest2_list);
   hipFree(h->d_cell_h); hipFree(h->d_dt_cell); hipFree(h->d_cell_vert); hipFree(h->shard_res); hipFree(h->shard_dtmin); hipFree(h->res_sq); hipFree(h->fin_partial); hipFree(h->dt_dev);
   if (h->flags_host) hipHostFree((void *)h->flags_host);
-  hipFree(h->fin_counter); hipFree(h->dt_mins); hipFree(h->pos_stats); hipFree(h->send_done);
-  hipFree(h->Tg[0]); hipFree(h->Tg[1]); hipFree(h->d_gt_slot); hipFree(h->d_gt_face); hipFree(h->d_sendf_slot); hipFree(h->d_sendf_face); hipFree(h->d_send_slots); hipFree(h->ghost_stage);
+  hipFree(h->fin_counter); hipFree(h->pos_stats); hipFree(h->send_done);
+  if (!h->dt_external) hipFree(h->dt_mins);
+  if (!h->tg_external) { hipFree(h->Tg[0]); hipFree(h->Tg[1]); }
+  hipFree(h->d_gt_slot); hipFree(h->d_gt_face); hipFree(h->d_sendf_slot); hipFree(h->d_sendf_face); hipFree(h->d_send_slots); hipFree(h->ghost_stage);
   for (int i = 0; i < 2; ++i) if (h->ev_chunk[i]) hipEventDestroy(h->ev_chunk[i]);
   for (auto &e : h->ev_pool) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
   if (h->own_stream) hipStreamDestroy(h->own_stream);
@@ -1799,6 +1802,34 @@ int dflo_hip_pack_send_to_signal(dflo_hip_handle h, int kind, int n_segments, co
 int dflo_hip_ghost_trace_buffer(dflo_hip_handle h, int which, void **ptr) {
   if (check_handle(h) || which < 0 || which > 1 || !ptr) return DFLO_ERR_BAD_PARAM;
   *ptr = h->Tg[which];
+  return DFLO_OK;
+}
+
+int dflo_hip_set_ghost_trace_buffers(dflo_hip_handle h, void *table0, void *table1) {
+  if (check_handle(h) || !table0 || !table1 || table0 == table1) return DFLO_ERR_BAD_PARAM;
+  if (!h->trace_halo) { h->err = "this engine does not read ghost cells by their traces"; return DFLO_ERR_BAD_PARAM; }
+  hipSetDevice(h->device);
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  const size_t bytes = (size_t)h->n_gt * 4 * h->N * sizeof(double);
+  void *nt[2] = {table0, table1};
+  for (int i = 0; i < 2; ++i) {   // what the tables hold now moves along (after set_solution: the initial state's traces)
+    HIPCHK(h, hipMemcpy(nt[i], h->Tg[i], bytes, hipMemcpyDeviceToDevice));
+    if (!h->tg_external) hipFree(h->Tg[i]);
+    h->Tg[i] = (double *)nt[i];
+  }
+  h->tg_external = true;
+  return DFLO_OK;
+}
+
+int dflo_hip_set_dt_table_buffer(dflo_hip_handle h, void *table) {
+  if (check_handle(h) || !table) return DFLO_ERR_BAD_PARAM;
+  hipSetDevice(h->device);
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  HIPCHK(h, hipMemcpy(table, h->dt_mins, 2 * kDtSlots * sizeof(double), hipMemcpyDeviceToDevice));
+  if (!h->dt_external) hipFree(h->dt_mins);
+  h->dt_mins = (double *)table;
+  h->dt_external = true;
+  drop_graph(h);
   return DFLO_OK;
 }
 

@@ -273,6 +273,8 @@ struct dflo_hip_multi {
   // DFLO_RANK_TRANSPORT=ipc (see PeerMap): sequence words of this rank (fine-grained device memory), the peers' mappings, the
   // exchanges of each kind this rank has sent / expects (never reset: the words only grow), the wait kernels' failure word
   bool ipc = false;
+  void *win_data = nullptr, *win_sync = nullptr;   // what the peers map (see IpcExport)
+  bool recv_in_window = false;                      // the receive areas lie in win_data (not allocations of their own)
   unsigned long long *flags = nullptr;
   std::vector<PeerMap> pmap;
   unsigned long long ipc_post[4] = {0, 0, 0, 0}, ipc_arr[4] = {0, 0, 0, 0};
@@ -1013,16 +1015,25 @@ int host_allreduce(dflo_hip_multi *m, double *v, int n, ncclRedOp_t op) {
 // ---- DFLO_RANK_TRANSPORT=ipc: set-up.  Every rank exports its receive areas, its time-step table, its sequence words and its
 // receive offsets; the records meet through one sum all-reduce of bytes spread over doubles (each rank fills its own stretch of
 // a zeroed array: any transport that can sum doubles can carry it); every rank then opens what it will write.
+// What is exported are TWO windows per rank, each one allocation of whole 2 MB blocks: the data window (ghost-trace tables, average
+// and cell areas, the time-step table -- plain or, DFLO_PEER_FINEGRAINED=1, fine-grained device memory) and the sync window (the
+// sequence words; always fine-grained).  Not the individual buffers: the runtime serves small allocations as fragments of shared
+// 2 MB blocks, and a fragment can be exported only if it happens to start and end on 4 KB (found by tools/fuzz_ranks.py: "invalid
+// argument" from hipIpcGetMemHandle for a 2.8 KB trace table, and -- worse -- a wrong state where the export went through).  The
+// engine is pointed at its share of the window (dflo_hip_set_ghost_trace_buffers / _set_dt_table_buffer).
 struct IpcExport {
-  hipIpcMemHandle_t h[8];      // tg0 tg1 recv_a0 recv_a1 recv_u0 recv_u1 dt_table flags
-  unsigned char has[8];
+  hipIpcMemHandle_t data, sync;
+  uint64_t off[7];             // tg0 tg1 recv_a0 recv_a1 recv_u0 recv_u1 dt_table, bytes from the start of the data window
+  int32_t has_tg;
   int32_t ro[17], rfo[17];     // this rank's receive offsets by source rank (cells / face traces)
 };
+constexpr size_t kWindowBlock = 2u << 20;
 int alloc_flags(dflo_hip_multi *m) {
   Part &p = m->parts[0];
   MHIP(m, hipSetDevice(p.device));
-  MHIP(m, hipExtMallocWithFlags((void **)&m->flags, kFlagWords * sizeof(unsigned long long), hipDeviceMallocFinegrained));
-  MHIP(m, hipMemset(m->flags, 0, kFlagWords * sizeof(unsigned long long)));
+  MHIP(m, hipExtMallocWithFlags(&m->win_sync, 2 * kWindowBlock, hipDeviceMallocFinegrained));
+  MHIP(m, hipMemset(m->win_sync, 0, 2 * kWindowBlock));
+  m->flags = (unsigned long long *)m->win_sync;
   void *fh = nullptr, *fd = nullptr;
   MHIP(m, hipHostMalloc(&fh, sizeof(int), hipHostMallocMapped | hipHostMallocCoherent));
   MHIP(m, hipHostGetDevicePointer(&fd, fh, 0));
@@ -1038,12 +1049,38 @@ int setup_ipc(dflo_hip_multi *m) {
   if (rc) return rc;
   IpcExport mine;
   std::memset(&mine, 0, sizeof(mine));
-  void *ptrs[8] = {p.tg[0], p.tg[1], p.recv_a[0], p.recv_a[1], p.recv_u[0], p.recv_u[1], p.dt_table, m->flags};
-  for (int i = 0; i < 8; ++i) {
-    if (!ptrs[i]) continue;
-    MHIP(m, hipIpcGetMemHandle(&mine.h[i], ptrs[i]));
-    mine.has[i] = 1;
+  {   // the data window and this rank's buffers inside it
+    auto up = [](size_t b) { return (b + 4095) & ~(size_t)4095; };
+    const size_t ng = std::max(p.n_ghost, 1);
+    const size_t ntg = p.trace ? up((size_t)std::max(dflo_hip_n_ghost_traces(p.eng), 1) * 4 * m->N * sizeof(double)) : 0;
+    const size_t na = up(ng * 4 * sizeof(double)), nu = up(ng * (m->ndof + 4) * sizeof(double));
+    const size_t sizes[7] = {ntg, ntg, na, na, nu, nu, 4096};
+    size_t total = 0;
+    for (int i = 0; i < 7; ++i) { mine.off[i] = total; total += sizes[i]; }
+    total = std::max(((total + kWindowBlock - 1) / kWindowBlock) * kWindowBlock, 2 * kWindowBlock);
+    if (dflo::read_tunables().peer_finegrained) MHIP(m, hipExtMallocWithFlags(&m->win_data, total, hipDeviceMallocFinegrained));
+    else MHIP(m, hipMalloc(&m->win_data, total));
+    MHIP(m, hipMemset(m->win_data, 0, total));
+    char *w = (char *)m->win_data;
+    if (p.trace) {
+      MENG(m, p, dflo_hip_set_ghost_trace_buffers(p.eng, w + mine.off[0], w + mine.off[1]));
+      p.tg[0] = w + mine.off[0];
+      p.tg[1] = w + mine.off[1];
+      mine.has_tg = 1;
+    }
+    for (int i = 0; i < 2; ++i) {
+      hipFree(p.recv_a[i]);
+      hipFree(p.recv_u[i]);
+      p.recv_a[i] = (double *)(w + mine.off[2 + i]);
+      p.recv_u[i] = (double *)(w + mine.off[4 + i]);
+    }
+    m->recv_in_window = true;
+    MENG(m, p, dflo_hip_set_dt_table_buffer(p.eng, w + mine.off[6]));
+    p.dt_table = w + mine.off[6];
   }
+  hipError_t e = hipIpcGetMemHandle(&mine.data, m->win_data);
+  if (e == hipSuccess) e = hipIpcGetMemHandle(&mine.sync, m->win_sync);
+  if (e != hipSuccess) { set_err(m, std::string("hipIpcGetMemHandle: ") + hipGetErrorString(e)); return DFLO_ERR_HIP; }
   for (int q = 0; q <= m->n_parts; ++q) {
     mine.ro[q] = p.recv_off[q];
     mine.rfo[q] = p.trace ? p.recvf_off[q] : 0;
@@ -1061,22 +1098,23 @@ int setup_ipc(dflo_hip_multi *m) {
     for (size_t i = 0; i < nb; ++i) tb[i] = (unsigned char)spread[(size_t)q * nb + i];
     PeerMap &pm = m->pmap[q];
     const bool peer = std::find(p.peers.begin(), p.peers.end(), q) != p.peers.end();
-    for (int i = 0; i < 8; ++i) {
-      if (!theirs.has[i] || (i < 6 && !peer)) continue;   // data areas of neighbours only; table and words of every rank
-      void *ptr = nullptr;
-      const hipError_t e = hipIpcOpenMemHandle(&ptr, theirs.h[i], hipIpcMemLazyEnablePeerAccess);
-      if (e != hipSuccess) { set_err(m, std::string("hipIpcOpenMemHandle (rank ") + std::to_string(q) + "): " + hipGetErrorString(e)); return DFLO_ERR_COMM; }
-      pm.opened[i] = ptr;
+    void *wd = nullptr, *ws = nullptr;
+    e = hipIpcOpenMemHandle(&wd, theirs.data, hipIpcMemLazyEnablePeerAccess);
+    if (e == hipSuccess) { pm.opened[0] = wd; e = hipIpcOpenMemHandle(&ws, theirs.sync, hipIpcMemLazyEnablePeerAccess); }
+    if (e != hipSuccess) { set_err(m, std::string("hipIpcOpenMemHandle (rank ") + std::to_string(q) + "): " + hipGetErrorString(e)); return DFLO_ERR_COMM; }
+    pm.opened[1] = ws;
+    char *w = (char *)wd;
+    if (theirs.has_tg) { pm.tg[0] = (double *)(w + theirs.off[0]); pm.tg[1] = (double *)(w + theirs.off[1]); }
+    for (int i = 0; i < 2; ++i) {
+      pm.recv_a[i] = (double *)(w + theirs.off[2 + i]);
+      pm.recv_u[i] = (double *)(w + theirs.off[4 + i]);
     }
-    pm.tg[0] = (double *)pm.opened[0]; pm.tg[1] = (double *)pm.opened[1];
-    pm.recv_a[0] = (double *)pm.opened[2]; pm.recv_a[1] = (double *)pm.opened[3];
-    pm.recv_u[0] = (double *)pm.opened[4]; pm.recv_u[1] = (double *)pm.opened[5];
-    pm.dt_table = (double *)pm.opened[6];
-    pm.flags = (unsigned long long *)pm.opened[7];
+    pm.dt_table = (double *)(w + theirs.off[6]);
+    pm.flags = (unsigned long long *)ws;
     pm.ro = theirs.ro[p.index];
     pm.rfo = theirs.rfo[p.index];
     if (peer && (theirs.ro[p.index + 1] - theirs.ro[p.index] != p.send_off[q + 1] - p.send_off[q] ||
-                 (p.trace && theirs.rfo[p.index + 1] - theirs.rfo[p.index] != p.sendf_off[q + 1] - p.sendf_off[q]))) {
+                 (p.trace && theirs.rfo[p.index + 1] - theirs.rfo[p.index] != p.sendf_off[q + 1] - p.sendf_off[q] ) || (p.trace && !theirs.has_tg))) {
       set_err(m, "partition: rank " + std::to_string(q) + " expects another number of records than rank " + std::to_string(p.index) + " sends");
       return DFLO_ERR_COMM;
     }
@@ -1343,13 +1381,13 @@ int dflo_hip_multi_destroy(dflo_hip_multi_handle m) {
     for (PeerMap &pm : m->pmap)
       for (void *o : pm.opened)
         if (o) hipIpcCloseMemHandle(o);
-  if (m->flags) hipFree(m->flags);
   if (m->ipc_fail_host) hipHostFree((void *)m->ipc_fail_host);
   for (Part &p : m->parts) {
     hipSetDevice(p.device);
     if (p.eng) dflo_hip_destroy(p.eng);
     hipFree(p.send_u); hipFree(p.send_a); hipFree(p.send_t);
-    for (int i = 0; i < 2; ++i) { hipFree(p.recv_u[i]); hipFree(p.recv_a[i]); }
+    if (!m->recv_in_window)
+      for (int i = 0; i < 2; ++i) { hipFree(p.recv_u[i]); hipFree(p.recv_a[i]); }
     hipEvent_t evs[] = {p.ev_dt, p.ev_fin[0], p.ev_fin[1]};
     for (hipEvent_t e : evs) if (e) hipEventDestroy(e);
     for (int k = 0; k < 3; ++k)
@@ -1368,6 +1406,8 @@ int dflo_hip_multi_destroy(dflo_hip_multi_handle m) {
     if (g.M) hipStreamDestroy(g.M);
   }
   if (m->scal) hipFree(m->scal);
+  if (m->win_data) hipFree(m->win_data);   // (behind the engines, which were pointed into it)
+  if (m->win_sync) hipFree(m->win_sync);
   for (int i = 0; i < 2; ++i) if (m->ev_chunk[i]) hipEventDestroy(m->ev_chunk[i]);
   delete m;
   return DFLO_OK;

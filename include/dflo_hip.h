@@ -299,6 +299,12 @@ int dflo_hip_set_send_faces(dflo_hip_handle h, int32_t n, const int32_t *cells, 
 int dflo_hip_pack_send_traces(dflo_hip_handle h, void *device_buffer);
 int dflo_hip_ghost_trace_buffer(dflo_hip_handle h, int which, void **device_ptr);
 int dflo_hip_use_ghost_traces(dflo_hip_handle h, int which);
+/* The engine's two ghost-trace tables ([n_ghost_traces][4][k+1] doubles each) and its table of the parts' time-step minima
+ * ([2][16] doubles) in memory of the CALLER's -- a window it exports to other processes as one allocation (the runtime serves small
+ * allocations as fragments of shared blocks, which cannot be exported reliably one by one).  The current contents move along;
+ * the buffers stay the caller's and must outlive the engine. */
+int dflo_hip_set_ghost_trace_buffers(dflo_hip_handle h, void *table0, void *table1);
+int dflo_hip_set_dt_table_buffer(dflo_hip_handle h, void *table);
 /* Pack and deliver in one kernel (several engines in one process): records [first[i], first[i+1]) of the send list are
  * written at dst[i] -- the receive area of the i-th peer, on this device or on another one reached over xGMI peer access --
  * instead of into a staging buffer that a copy per peer then moves.  kind: 0 whole cells ([ndof + 4] doubles per record,

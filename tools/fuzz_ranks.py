@@ -37,12 +37,15 @@ def worker(rank, world, port, ret):
     for i in range(n_cases):
         case = fm.make_case(i)
         d, mesh = case["desc"], case["mesh"]
+        if fm.ONLY and i not in fm.ONLY:   # FUZZ_CASES=88,92: only these (the generator still draws the others)
+            continue
         try:
             claw = dflo_amd.MultiConservationLaw.for_rank_custom(mesh, case["prm"], 0, rank, world, xf, af, partitioner=d["partitioner"])
         except dflo_amd.DfloError as e:
             if e.code in (-7, -1):
                 counts["refused"] = counts.get("refused", 0) + 1
                 continue
+            print("rank %d: CASE %d could not be created: %s  %s" % (rank, i, e, d), flush=True)
             raise
         try:
             fm.setup(case, claw)
