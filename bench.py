@@ -434,9 +434,10 @@ def main():
         if world > 1:
             import torch.distributed as dist
             from dflo_amd.multi import comm_unique_id
-            if transport in ("gloo", "ipc_gloo"):   # gloo callbacks carry the halos (gloo) or only the set-up and the host-side reductions (ipc_gloo)
+            if transport in ("gloo", "ipc_gloo", "ipc_fine"):   # gloo callbacks carry the halos (gloo) or only the set-up and the host-side reductions (ipc_*)
                 uid = "gloo"
-                env["DFLO_RANK_TRANSPORT"] = "ipc" if transport == "ipc_gloo" else "rccl"
+                env["DFLO_RANK_TRANSPORT"] = "rccl" if transport == "gloo" else "ipc"
+                env["DFLO_PEER_FINEGRAINED"] = "1" if transport == "ipc_fine" else None
             else:   # rccl | ipc | ipc_fine: an RCCL communicator carries the halos (rccl) or only the set-up (ipc: the handles)
                 box = [comm_unique_id() if rank == 0 else None]
                 dist.broadcast_object_list(box, src=0)
@@ -451,6 +452,8 @@ def main():
             else:
                 os.environ[k] = v
         err = ""
+        if os.environ.get("DFLO_BENCH_TEST_HANG") == transport:   # test hook: this transport never returns (tests/test_gpu_driver.py)
+            time.sleep(1.0e6)
         try:
             m = run_case(a, world, rank, local_rank, uid, barrier)
         except TransportFailed as e:
@@ -506,38 +509,9 @@ def main():
         return {"transport": transport, "ok": ok, "check": check, "m": m, "sec": sec, "per_rank": per_rank, "n_rk": n_rk,
                 "value": m["n_dofs_total"] * n_rk * a.steps / sec / 1e6}
 
-    # N > 1: north_star's transport (RCCL send/recv + all-reduce) and the IPC transport are BOTH measured; `value` is the better one
-    # whose check holds.  Only if neither does: the IPC transport with every peer-written buffer in fine-grained memory, the IPC
-    # transport bootstrapped over gloo (no RCCL at all), then the host-staged gloo transport -- the line says which ran and what
-    # became of the others.  DFLO_BENCH_TRANSPORTS overrides the list (DFLO_BENCH_TRANSPORT=gloo, the older developer switch, means
-    # "gloo"); DFLO_BENCH_ALL_TRANSPORTS=1 runs every listed one.
-    attempts = []
-    if world == 1:
-        best = measure(args, "none")
-    else:
-        order = os.environ.get("DFLO_BENCH_TRANSPORTS", "gloo" if os.environ.get("DFLO_BENCH_TRANSPORT") == "gloo" else "rccl,ipc,ipc_fine,ipc_gloo,gloo").split(",")
-        for t in order:
-            if t in ("ipc_fine", "ipc_gloo", "gloo") and any(r["ok"] for r in attempts) and os.environ.get("DFLO_BENCH_ALL_TRANSPORTS") != "1":
-                continue   # fallbacks
-            attempts.append(measure(args, t))
-        good = [r for r in attempts if r["ok"]]
-        if not good:
-            raise SystemExit("bench.py: no transport produced a valid run: " + "; ".join("%s: %s" % (r["transport"], r["check"]) for r in attempts))
-        best = max(good, key=lambda r: r["value"])
-    m, sec, per_rank, n_rk, check = best["m"], best["sec"], best["per_rank"], best["n_rk"], best["check"]
-
-    strong = None
-    if world > 1 and args.config == "c2" and args.scaling == "weak" and os.environ.get("DFLO_BENCH_NO_STRONG") != "1":
-        # the other reading of north_star's ">= 6x at 8 GPUs over 1 GPU on a 1024x1024 Q2 mesh": the one-GPU mesh cut N ways, over the
-        # transport that won above; short (<= 20 steps), its own ms_per_step and exchange waits
-        import copy
-        a2 = copy.copy(args)
-        a2.scaling, a2.steps, a2.warmup = "strong", min(args.steps, 20), min(args.warmup, 5)
-        strong = measure(a2, best["transport"])
-        strong["steps"], strong["warmup"] = a2.steps, a2.warmup
-
-    result_line = None
-    if rank == 0:
+    def build_line(best, strong, note=None):
+        """the JSON line (rank 0) from the run that won and whatever else has been measured so far"""
+        m, sec, per_rank, n_rk, check = best["m"], best["sec"], best["per_rank"], best["n_rk"], best["check"]
         n_dofs_total = m["n_dofs_total"]
         value = n_dofs_total * n_rk * args.steps / sec / 1e6
         # read u(s), read u(n), write u(s+1); +16 with a limiter/positivity pass (BASELINE.md section 4).
@@ -585,8 +559,8 @@ def main():
                                   {"gloo": "HOST-STAGED gloo transport -- not a measurement of the device-to-device paths",
                                    "rccl": "RCCL send/recv of face traces + 8-byte all-reduce(min) per step",
                                    "ipc": "pack kernels storing face traces into the neighbours' hipIpc-mapped tables + sequence words; time step through the mapped tables",
-                                   "ipc_fine": "as ipc, every peer-written buffer in fine-grained memory",
-                                   "ipc_gloo": "as ipc, set up over gloo callbacks instead of an RCCL communicator",
+                                   "ipc_fine": "as ipc_gloo, every peer-written buffer in fine-grained memory",
+                                   "ipc_gloo": "as ipc, set up over gloo callbacks instead of an RCCL communicator (no RCCL call anywhere)",
                                    "none": "one rank: nothing to exchange" if not args.self_halo else "self-halo"}[best["transport"]]),
                 # N > 1: every transport that was run in this invocation, its rate and the verdict of its own check (`value` above is
                 # the best one that passed); and the settings RCCL and the runtime were given
@@ -665,7 +639,79 @@ def main():
             # threads)
             twins = [cpu_twin(threads=quota, nx=1024, steps=30)]
             out["cpu_baseline"]["optimised_twin"] = max(twins, key=lambda r: r["value"])
-        result_line = json.dumps(out)
+        if note:
+            out["config"]["watchdog"] = note
+        return out
+
+    # N > 1: the IPC transport and north_star's transport (RCCL send/recv + all-reduce) are BOTH measured; `value` is the better one
+    # whose check holds.  Only if neither does: the IPC transport with every peer-written buffer in fine-grained memory, then the
+    # host-staged gloo transport -- the line says which ran and what became of the others.  DFLO_BENCH_TRANSPORTS overrides the list
+    # (DFLO_BENCH_TRANSPORT=gloo, the older developer switch, means "gloo"); DFLO_BENCH_ALL_TRANSPORTS=1 runs every listed one.
+    attempts = []
+    state = {"done": False, "running": None, "strong": None}
+
+    def arm(seconds, what):
+        """A transport that never returns (a collective that stalls inside a library) must not cost the line of the transports that
+        ran before it: every attempt gets a deadline; when it passes, rank 0 prints the line of what HAS been measured -- saying which
+        attempt hung -- and every rank leaves (rank 0 five seconds before the others, so that nobody's exit makes it stumble first)."""
+        import threading
+        if state.get("timer"):
+            state["timer"].cancel()
+        if seconds is None:
+            return
+        state["running"] = what
+
+        def fire():
+            if state["done"]:
+                return
+            import faulthandler
+            good = [r for r in attempts if r["ok"]]
+            print("bench.py: rank %d: '%s' did not return within %.0f s -- giving up on it%s" % (
+                rank, state["running"], seconds, "; the line below is from the transports that completed" if good else ""), file=sys.stderr, flush=True)
+            faulthandler.dump_traceback(file=sys.stderr)
+            if rank == 0 and good:
+                best_ = max(good, key=lambda r: r["value"])
+                print(json.dumps(build_line(best_, state["strong"], note="'%s' hung and was abandoned after %.0f s" % (state["running"], seconds))), flush=True)
+            os._exit(0 if good else 3)
+
+        state["timer"] = threading.Timer(seconds - (5.0 if rank == 0 else 0.0), fire)
+        state["timer"].daemon = True
+        state["timer"].start()
+
+    attempt_s = float(os.environ.get("DFLO_BENCH_ATTEMPT_S", 900 if args.config == "c5" else 300))
+    if world == 1:
+        best = measure(args, "none")
+    else:
+        # ipc_gloo first: it needs nothing but the rendezvous that is already up (no RCCL call anywhere), so its line is safe before the
+        # transport north_star names is tried; then rccl; "ipc" (the same IPC transport, set up over an RCCL communicator) adds nothing to
+        # ipc_gloo and is run only when asked for
+        order = os.environ.get("DFLO_BENCH_TRANSPORTS", "gloo" if os.environ.get("DFLO_BENCH_TRANSPORT") == "gloo" else "ipc_gloo,rccl,ipc_fine,gloo").split(",")
+        for t in order:
+            if t in ("ipc_fine", "gloo") and any(r["ok"] for r in attempts) and os.environ.get("DFLO_BENCH_ALL_TRANSPORTS") != "1":
+                continue   # fallbacks
+            arm(attempt_s, "transport " + t)
+            attempts.append(measure(args, t))
+        arm(None, None)
+        good = [r for r in attempts if r["ok"]]
+        if not good:
+            raise SystemExit("bench.py: no transport produced a valid run: " + "; ".join("%s: %s" % (r["transport"], r["check"]) for r in attempts))
+        best = max(good, key=lambda r: r["value"])
+
+    strong = None
+    if world > 1 and args.config == "c2" and args.scaling == "weak" and os.environ.get("DFLO_BENCH_NO_STRONG") != "1":
+        # the other reading of north_star's ">= 6x at 8 GPUs over 1 GPU on a 1024x1024 Q2 mesh": the one-GPU mesh cut N ways, over the
+        # transport that won above; short (<= 20 steps), its own ms_per_step and exchange waits
+        import copy
+        a2 = copy.copy(args)
+        a2.scaling, a2.steps, a2.warmup = "strong", min(args.steps, 20), min(args.warmup, 5)
+        arm(attempt_s, "strong-scaling run over " + best["transport"])
+        strong = measure(a2, best["transport"])
+        strong["steps"], strong["warmup"] = a2.steps, a2.warmup
+        state["strong"] = strong
+        arm(None, None)
+
+    result_line = json.dumps(build_line(best, strong)) if rank == 0 else None
+    state["done"] = True
     if world > 1:
         import faulthandler
         import torch.distributed as dist

@@ -545,6 +545,27 @@ def test_bench_self_halo_line(transport, extra):
         assert "64x256 quads per GPU" in c["workload"]
 
 
+def test_bench_line_survives_a_transport_that_hangs():
+    """a transport that never returns (a collective stalled inside a library) must not cost the line of the transports that ran
+    before it: every attempt has a deadline, after which rank 0 prints what has been measured, says which attempt hung, and
+    every rank leaves"""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(29900 + os.getpid() % 90), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--nx", "128"]
+    env = dict(os.environ, DFLO_BENCH_TRANSPORTS="ipc_gloo,gloo", DFLO_BENCH_ALL_TRANSPORTS="1", DFLO_BENCH_ONE_GPU="1", DFLO_BENCH_TEST_HANG="gloo",
+               DFLO_BENCH_ATTEMPT_S="25", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=root, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["config"]["transport_used"] == "ipc_gloo" and d["value"] > 0
+    assert "'transport gloo' hung" in d["config"]["watchdog"]
+    assert "did not return within" in out.stderr
+
+
 @pytest.mark.parametrize("extra", [[], ["--scaling", "strong"], ["--config", "c3"]])
 def test_bench_line_of_two_ranks_launched_the_drivers_way(extra):
     """bench.py --gpus 2 as the round driver launches it (python -m torch.distributed.run, one rank per GPU, 127.0.0.1), on this
