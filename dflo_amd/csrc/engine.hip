@@ -96,6 +96,14 @@ struct dflo_hip_engine {
   double pending_dt = -1.0;
   int32_t *d_send_slots = nullptr;
   int n_send = 0;
+  // delivery by the stage kernel (dflo_hip_set_deliver / dflo_hip_stage_deliver)
+  std::vector<int32_t> h_sendf_slot, h_sendf_face;
+  int32_t *d_dl_begin = nullptr;
+  int2 *d_dl_rec = nullptr;
+  double **d_dl_dst[2] = {nullptr, nullptr};
+  unsigned long long **d_dl_flag = nullptr;
+  int dl_nflag = 0, dl_total = 0, dl_armed = -1;
+  unsigned long long dl_seq = 0;
   hipEvent_t next_stop = nullptr;      // dflo_hip_attach_event: the next stage / limiter kernel launched carries this event as its completion signal
   unsigned int *send_done = nullptr;   // [3] workgroup counters of the signalling pack kernels, by kind (dflo_hip_pack_send_to_signal)
   bool peer_fine = false;              // DFLO_PEER_FINEGRAINED=1: what a peer's kernel writes lives in fine-grained memory
@@ -544,6 +552,17 @@ int launch_update(dflo_hip_engine *h, double *rhs_out, int part) {
   a.lim_mask = h->lim_mask;
   a.lim_cnt = nullptr;
   a.lim_list = h->lim_list;
+  if (h->dl_armed >= 0 && part == 0 && !rhs_out) {   // this launch delivers its cut faces' traces itself (dflo_hip_stage_deliver)
+    a.dl_begin = h->d_dl_begin;
+    a.dl_rec = h->d_dl_rec;
+    a.dl_dst = h->d_dl_dst[h->dl_armed];
+    a.dl_flag = h->d_dl_flag;
+    a.dl_nflag = h->dl_nflag;
+    a.dl_total = h->dl_total;
+    a.dl_seq = h->dl_seq;
+    a.dl_done = h->send_done + 3;
+    h->dl_armed = -1;
+  }
   a.tvb_M = h->prm.limiter_type == DFLO_LIMITER_TVB ? h->prm.M : -1.0;
   a.tvb_char = h->prm.char_lim;
   a.pos_check = h->prm.pos_lim;
@@ -1171,6 +1190,7 @@ int dflo_hip_destroy(dflo_hip_handle h) {
   hipFree(h->fin_counter); hipFree(h->pos_stats); hipFree(h->send_done);
   if (!h->dt_external) hipFree(h->dt_mins);
   if (!h->tg_external) { hipFree(h->Tg[0]); hipFree(h->Tg[1]); }
+  hipFree(h->d_dl_begin); hipFree(h->d_dl_rec); hipFree(h->d_dl_dst[0]); hipFree(h->d_dl_dst[1]); hipFree(h->d_dl_flag);
   hipFree(h->d_gt_slot); hipFree(h->d_gt_face); hipFree(h->d_sendf_slot); hipFree(h->d_sendf_face); hipFree(h->d_send_slots); hipFree(h->ghost_stage);
   for (int i = 0; i < 2; ++i) if (h->ev_chunk[i]) hipEventDestroy(h->ev_chunk[i]);
   for (auto &e : h->ev_pool) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
@@ -1586,6 +1606,58 @@ int dflo_hip_stage_update_part(dflo_hip_handle h, int part) {
   return launch_update(h, nullptr, part);
 }
 
+int dflo_hip_set_deliver(dflo_hip_handle h, int area, int n_segments, const int32_t *first, void *const *dst, void *const *flags) {
+  if (check_handle(h) || area < 0 || area > 1 || n_segments < 1 || n_segments > kMaxSegs || !first || !dst || !flags) return DFLO_ERR_BAD_PARAM;
+  if (!h->trace_halo || h->basis != DFLO_BASIS_QK) { h->err = "delivery by the stage kernel needs ghost cells known by their traces (Qk)"; return DFLO_ERR_BAD_PARAM; }
+  const int n = h->n_send_faces;
+  if (n == 0 || first[0] != 0 || first[n_segments] != n) { h->err = "set_deliver: the segments must cover the send list of set_send_faces"; return DFLO_ERR_COMM; }
+  hipSetDevice(h->device);
+  // the records sorted by the shard of their cell (stable: send-list order inside a shard)
+  const int ns = h->plan.n_shards;
+  std::vector<int32_t> begin(ns + 1, 0), order(n);
+  for (int k = 0; k < n; ++k) ++begin[(h->h_sendf_slot[k] >> 6) + 1];
+  int total = 0;
+  for (int sh = 0; sh < ns; ++sh) { total += begin[sh + 1] > 0; begin[sh + 1] += begin[sh]; }
+  {
+    std::vector<int32_t> at(begin.begin(), begin.end() - 1);
+    for (int k = 0; k < n; ++k) order[at[h->h_sendf_slot[k] >> 6]++] = k;
+  }
+  std::vector<int2> rec(n);
+  std::vector<double *> to(n);
+  const size_t w = (size_t)4 * h->N;
+  for (int j = 0; j < n; ++j) {
+    const int k = order[j];
+    rec[j] = int2{h->h_sendf_slot[k], h->h_sendf_face[k]};
+    int i = 0;
+    while (i + 1 < n_segments && k >= first[i + 1]) ++i;
+    to[j] = (double *)dst[i] + (size_t)(k - first[i]) * w;
+  }
+  std::vector<unsigned long long *> fl(n_segments);
+  for (int i = 0; i < n_segments; ++i) fl[i] = (unsigned long long *)flags[i];
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  if (!h->d_dl_begin) {
+    int rc;
+    if ((rc = upload(h, &h->d_dl_begin, begin)) || (rc = upload(h, &h->d_dl_rec, rec))) return rc;
+  }
+  hipFree(h->d_dl_dst[area]);
+  h->d_dl_dst[area] = nullptr;
+  hipFree(h->d_dl_flag);
+  h->d_dl_flag = nullptr;
+  int rc;
+  if ((rc = upload(h, &h->d_dl_dst[area], to)) || (rc = upload(h, &h->d_dl_flag, fl))) return rc;
+  h->dl_nflag = n_segments;
+  h->dl_total = total;
+  return DFLO_OK;
+}
+
+int dflo_hip_stage_deliver(dflo_hip_handle h, int area, uint64_t seq) {
+  if (check_handle(h) || area < 0 || area > 1) return DFLO_ERR_BAD_PARAM;
+  if (!h->d_dl_dst[area]) { h->err = "stage_deliver: dflo_hip_set_deliver has not been called for this receive area"; return DFLO_ERR_BAD_PARAM; }
+  h->dl_armed = area;
+  h->dl_seq = seq;
+  return DFLO_OK;
+}
+
 int dflo_hip_attach_event(dflo_hip_handle h, void *event) {
   if (check_handle(h)) return DFLO_ERR_BAD_PARAM;
   h->next_stop = (hipEvent_t)event;
@@ -1753,6 +1825,8 @@ int dflo_hip_set_send_faces(dflo_hip_handle h, int32_t n, const int32_t *cells, 
   hipFree(h->d_sendf_slot); hipFree(h->d_sendf_face);
   h->d_sendf_slot = h->d_sendf_face = nullptr;
   h->n_send_faces = n;
+  h->h_sendf_slot = slots;
+  h->h_sendf_face = ff;
   int rc = upload(h, &h->d_sendf_slot, slots);
   return rc ? rc : upload(h, &h->d_sendf_face, ff);
 }

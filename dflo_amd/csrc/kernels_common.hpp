@@ -117,6 +117,17 @@ struct StageArgs {
                                   //   hundred wavefronts walking that list instead of one per shard that reads a word and leaves; or null
   double tvb_M;                   // POS 2: TVB constant M, < 0: the limiter pass has no TVB part
   int tvb_char, pos_check;        // POS 2: characteristic limiting; the positivity limiter runs in the pass
+  // Delivery by the stage kernel itself (one process per GPU over IPC-mapped tables, launches over all shards): a workgroup whose
+  // shard has cut faces forms the traces of its NEW state on them and stores them straight into the neighbours' trace tables, and
+  // the last such workgroup publishes the exchange's number in the neighbours' sequence words -- no rim launch of its own, no
+  // pack kernel, no second stream (dflo_hip_set_deliver / dflo_hip_stage_deliver).  null: nothing to deliver.
+  const int32_t *dl_begin;              // [n_shards + 1] the shard's records
+  const int2 *dl_rec;                   // (cell slot, local face) of a record
+  double *const *dl_dst;                // where its 4 N doubles go (the receive area of this exchange)
+  unsigned long long *const *dl_flag;   // [dl_nflag] the receivers' sequence words
+  int dl_nflag, dl_total;               // dl_total: workgroups that deliver (shards with records)
+  unsigned long long dl_seq;
+  unsigned int *dl_done;                // their counter (zero between launches)
   KBasis kb;
 };
 

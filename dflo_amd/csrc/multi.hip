@@ -164,6 +164,26 @@ __global__ void signal_kernel(const SignalArgs a) {
   __threadfence_system();
   __hip_atomic_store(a.flag[i], a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
+// both in one launch (each tiny kernel costs its stream ~4.7 us): publish, then wait -- for the words of `w` and, where the stage
+// kernel delivers, for the neighbours' traces of the step's last stage (`w2`) as well
+__global__ void signal_wait_kernel(const SignalArgs a, const WaitArgs w, const WaitArgs w2) {
+  const int i = threadIdx.x;
+  if (i < a.n) {
+    __threadfence_system();
+    __hip_atomic_store(a.flag[i], a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  const WaitArgs &ww = i < 16 ? w : w2;
+  const int k = i < 16 ? i : i - 16;
+  if (i >= 32 || k >= ww.n) return;
+  const long long t0 = wall_clock64();
+  while (__hip_atomic_load(ww.flag[k], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < ww.seq) {
+    __builtin_amdgcn_s_sleep(16);
+    if (wall_clock64() - t0 > kWaitTimeoutTicks) {
+      __hip_atomic_store(ww.fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      return;
+    }
+  }
+}
 
 // what rank q lets this rank write (IPC mappings; self-halo: this rank's own pointers) and where in q's areas this rank's records go
 struct PeerMap {
@@ -273,6 +293,10 @@ struct dflo_hip_multi {
   // DFLO_RANK_TRANSPORT=ipc (see PeerMap): sequence words of this rank (fine-grained device memory), the peers' mappings, the
   // exchanges of each kind this rank has sent / expects (never reset: the words only grow), the wait kernels' failure word
   bool ipc = false;
+  std::vector<int> pend_from;  // fused: the wait for the traces of a step's last stage rides with the time step's wait kernel
+  unsigned long long pend_seq = 0;
+  bool pend = false;
+  bool fused = false;          // ... and the stage kernel delivers its cut faces' traces itself (one launch per stage, one stream)
   void *win_data = nullptr, *win_sync = nullptr;   // what the peers map (see IpcExport)
   bool recv_in_window = false;                      // the receive areas lie in win_data (not allocations of their own)
   unsigned long long *flags = nullptr;
@@ -440,7 +464,7 @@ ChanView chan(dflo_hip_multi *m, Part &p, int kind, int par) {
   return {p.send_off, p.recv_off, m->ndof + 4, p.recv_u[par]};
 }
 
-void xt_begin(Part &p) {
+void xt_begin(Part &p, hipStream_t st = nullptr) {
   p.x_open = p.x_on && (p.x_seen++ % 5 == 0) && p.x_used < 4096;
   if (!p.x_open) return;
   if (p.x_used == p.x_pool.size()) {
@@ -449,11 +473,11 @@ void xt_begin(Part &p) {
     hipEventCreate(&b);
     p.x_pool.push_back({a, b});
   }
-  hipEventRecord(p.x_pool[p.x_used].first, p.C);
+  hipEventRecord(p.x_pool[p.x_used].first, st ? st : p.C);
 }
-void xt_end(Part &p) {
+void xt_end(Part &p, hipStream_t st = nullptr) {
   if (!p.x_open) return;
-  hipEventRecord(p.x_pool[p.x_used].second, p.C);
+  hipEventRecord(p.x_pool[p.x_used].second, st ? st : p.C);
   ++p.x_used;
   p.x_open = false;
 }
@@ -576,15 +600,21 @@ int post(dflo_hip_multi *m, Part &p, int kind, int par) {
 }
 
 // the comm (or compute) stream waits until the listed ranks' words of this kind have reached `seq`
-int wait_words(dflo_hip_multi *m, hipStream_t st, int kind, const std::vector<int> &from, unsigned long long seq) {
-  WaitArgs w{};
+int fill_wait(dflo_hip_multi *m, WaitArgs &w, int kind, const std::vector<int> &from, unsigned long long seq) {
+  w = WaitArgs{};
   for (int q : from) {
     if (w.n == 16) { set_err(m, "more than 16 ranks to wait for"); return DFLO_ERR_UNSUPPORTED; }
     w.flag[w.n++] = m->flags + flag_index(kind, q);
   }
-  if (!w.n) return DFLO_OK;
   w.seq = seq;
   w.fail = m->ipc_fail;
+  return DFLO_OK;
+}
+int wait_words(dflo_hip_multi *m, hipStream_t st, int kind, const std::vector<int> &from, unsigned long long seq) {
+  WaitArgs w{};
+  const int rc = fill_wait(m, w, kind, from, seq);
+  if (rc) return rc;
+  if (!w.n) return DFLO_OK;
   hipLaunchKernelGGL(wait_flags_kernel, dim3(1), dim3(64), 0, st, w);
   MHIP(m, hipGetLastError());
   return DFLO_OK;
@@ -817,6 +847,48 @@ int stage_phase(dflo_hip_multi *m, Group &g, const StageCtx &s, int ph) {
   }
 }
 
+// DFLO_RANK_TRANSPORT=ipc where nothing but face traces travels and no limiter pass sits between update and send (C2, C5): ONE launch
+// over all shards per stage on the compute stream -- the workgroups of the shards on a cut deliver their traces themselves and the
+// last of them publishes the exchange's number (dflo_hip_stage_deliver) --, then a one-wavefront kernel that waits for the
+// neighbours' numbers.  No rim launch, no pack kernel, no comm stream, no event: what is left of the exchange on the compute
+// stream is that wait kernel.  A neighbour's table of this exchange is free when its number of the exchange before has been seen:
+// it is published by the last of ITS workgroups that read ghost traces (the shards that read them are the shards that deliver).
+int fused_stage(dflo_hip_multi *m, Group &g, const StageCtx &s) {
+  const int upar = (int)((1 + s.n) & 1);
+  MHIP(m, hipSetDevice(g.device));
+  if (m->pend) {   // (a last stage whose wait nobody took along: a caller that drives stages without the time step's reduction)
+    m->pend = false;
+    const int rc = wait_words(m, g.M, CH_TRACES, m->pend_from, m->pend_seq);
+    if (rc) return rc;
+  }
+  for (int i : g.parts) {
+    Part &p = m->parts[i];
+    MENG(m, p, dflo_hip_stage_open(p.eng, s.rk, s.dt));
+    MENG(m, p, dflo_hip_stage_deliver(p.eng, upar, ++m->ipc_post[CH_TRACES]));
+    MENG(m, p, dflo_hip_stage_update_part(p.eng, 0));
+    MENG(m, p, dflo_hip_stage_finish(p.eng));
+  }
+  for (int i : g.parts) {
+    Part &p = m->parts[i];
+    std::vector<int> from;
+    for (int q : p.peers)
+      if (p.recvf_off[q + 1] > p.recvf_off[q]) from.push_back(q);
+    const unsigned long long seq = ++m->ipc_arr[CH_TRACES];
+    if (s.last && m->rank_mode) {   // the time step's wait kernel (reduce_dt_rank), which follows, waits for these as well
+      m->pend = true;
+      m->pend_from = from;
+      m->pend_seq = seq;
+    } else {
+      xt_begin(p, g.M);
+      const int rc = wait_words(m, g.M, CH_TRACES, from, seq);
+      xt_end(p, g.M);
+      if (rc) return rc;
+    }
+    MENG(m, p, dflo_hip_use_ghost_traces(p.eng, upar));
+  }
+  return DFLO_OK;
+}
+
 // the KXRCF indicator reads the neighbours' unlimited DoFs of the new stage: ghosts are refreshed between update and
 // limiter as well (update_ghost_values before compute_shock_indicator in the MPI variant); no overlap on this path.
 // Two exchanges per stage (numbers n and n + 1).
@@ -855,6 +927,13 @@ int stage_groups(dflo_hip_multi *m, Group *gs, int ng, int rk, double dt, int64_
     return DFLO_OK;
   }
   const StageCtx s{rk, dt, n, rk == m->n_rk - 1};
+  if (m->fused) {
+    for (int k = 0; k < ng; ++k) {
+      const int rc = fused_stage(m, gs[k], s);
+      if (rc) return rc;
+    }
+    return DFLO_OK;
+  }
   const int nph = m->kxrcf ? kKxrcfPhases : kStagePhases;
   for (int ph = 0; ph < nph; ++ph) {
     const auto t0 = std::chrono::steady_clock::now();
@@ -894,11 +973,18 @@ int reduce_dt_rank(dflo_hip_multi *m) {
       sg.flag[sg.n++] = m->pmap[q].flags + flag_index(CH_FIN, p.index);
       from.push_back(q);
     }
-    if (!sg.n) return DFLO_OK;
     sg.seq = seq;
-    hipLaunchKernelGGL(signal_kernel, dim3(1), dim3(64), 0, p.M, sg);
+    WaitArgs w{}, w2{};
+    int rc = fill_wait(m, w, CH_FIN, from, seq);
+    if (!rc && m->pend) rc = fill_wait(m, w2, CH_TRACES, m->pend_from, m->pend_seq);
+    m->pend = false;
+    if (rc) return rc;
+    if (!sg.n && !w.n && !w2.n) return DFLO_OK;
+    xt_begin(p, p.M);
+    hipLaunchKernelGGL(signal_wait_kernel, dim3(1), dim3(64), 0, p.M, sg, w, w2);
+    xt_end(p, p.M);
     MHIP(m, hipGetLastError());
-    return wait_words(m, p.M, CH_FIN, from, seq);
+    return DFLO_OK;
   }
   MHIP(m, hipEventRecord(p.ev_fin[0], p.M));
   MHIP(m, hipStreamWaitEvent(p.C, p.ev_fin[0], 0));
@@ -967,6 +1053,11 @@ int group_step(dflo_hip_multi *m, Group &g, double dt, int64_t n0, int64_t step,
 int join_all(dflo_hip_multi *m) {
   for (Group &g : m->groups) {
     MHIP(m, hipSetDevice(g.device));
+    if (m->pend) {   // fused delivery: a last stage's traces nobody has waited for yet
+      m->pend = false;
+      const int rc = wait_words(m, g.M, CH_TRACES, m->pend_from, m->pend_seq);
+      if (rc) return rc;
+    }
     if (g.unpack_pending) {
       MHIP(m, hipEventRecord(g.ev_unpack, g.C));
       MHIP(m, hipStreamWaitEvent(g.M, g.ev_unpack, 0));
@@ -1126,6 +1217,32 @@ int setup_ipc(dflo_hip_multi *m) {
   m->ipc = true;
   return DFLO_OK;
 }
+// IPC transport, after the mappings are known: can the stage kernel deliver by itself?  (only face traces travel -- no LxF flux, no
+// TVB limiter reading ghost averages, no whole cells --, and no limiter pass sits between the update and the send)
+int setup_fused(dflo_hip_multi *m) {
+  Part &p = m->parts[0];
+  m->fused = false;
+  if (!m->ipc || !dflo::read_tunables().ipc_fused || !p.trace || m->tvb || m->kxrcf || m->need_avg || m->sep_limiter || p.peers.empty()) return DFLO_OK;
+  for (int par = 0; par < 2; ++par) {
+    int32_t first[17];
+    void *dst[16], *fl[16];
+    int nseg = 0;
+    for (int q : p.peers) {
+      const int n = p.sendf_off[q + 1] - p.sendf_off[q];
+      if (!n) continue;
+      if (nseg == 16) return DFLO_OK;   // (more neighbours than the kernel's list holds: the two-stream schedule)
+      first[nseg] = p.sendf_off[q];
+      dst[nseg] = m->pmap[q].tg[par] + (size_t)m->pmap[q].rfo * 4 * m->N;
+      fl[nseg++] = m->pmap[q].flags + flag_index(CH_TRACES, p.index);
+    }
+    if (!nseg) return DFLO_OK;
+    first[nseg] = p.sendf_off[m->n_parts];
+    MENG(m, p, dflo_hip_set_deliver(p.eng, par, nseg, first, dst, fl));
+  }
+  m->fused = true;
+  return DFLO_OK;
+}
+
 // a barrier of the ranks on the host (IPC transport: nobody may write into a receive area whose owner still reads an earlier run)
 int ipc_barrier(dflo_hip_multi *m) {
   if (!m->ipc || m->n_parts == 1) return DFLO_OK;
@@ -1539,6 +1656,7 @@ static int create_rank_impl(const dflo_mesh_t *mesh, const dflo_params_t *params
     if (dflo::read_tunables().rank_transport == 1 && (rc = setup_ipc(m))) return bail(rc);
   }
   finish_setup(m);
+  if ((rc = setup_fused(m))) return bail(rc);
   *out = m;
   return DFLO_OK;
 }
@@ -1604,6 +1722,7 @@ int dflo_hip_multi_create_self(const dflo_mesh_t *mesh, const dflo_params_t *par
     if ((rc = dflo_hip_dt_exchange(p.eng, 0, 1, tables))) { m->err = dflo_hip_last_error(p.eng); return bail(rc); }
   }
   finish_setup(m);
+  if ((rc = setup_fused(m))) return bail(rc);
   *out = m;
   return DFLO_OK;
 }
@@ -1993,7 +2112,8 @@ int dflo_hip_multi_comm_info(dflo_hip_multi_handle m, int32_t *comm_count, int32
   std::string t;
   if (m->self_halo) {
     t = std::string("self-halo (one part, its own neighbour across ") + (m->self_virtual == 1 ? "the periodic seam in x" : "a cut through the middle") + "): ";
-    if (m->ipc) t += "rank schedule, pack kernels storing into the own receive areas + sequence words polled by a wait kernel (the IPC transport against itself)";
+    if (m->ipc) t += m->fused ? "one launch per stage, its workgroups on the cut store their traces into the own table + sequence words polled by a wait kernel (the IPC transport against itself, delivery by the stage kernel)"
+                              : "rank schedule, pack kernels storing into the own receive areas + sequence words polled by a wait kernel (the IPC transport against itself)";
     else if (m->rank_mode && m->comm) {
       t += "rank schedule, grouped ncclSend/ncclRecv to itself + ncclAllReduce(min) on a one-rank RCCL communicator";
       cnt = rk = -1;
@@ -2001,7 +2121,9 @@ int dflo_hip_multi_comm_info(dflo_hip_multi_handle m, int32_t *comm_count, int32
       if (g_rccl.CommUserRank) g_rccl.CommUserRank(m->comm, &rk);
     } else t += m->direct ? "one-process schedule, pack kernels storing into the own trace table" : "one-process schedule, staging buffer + hipMemcpyPeerAsync";
   } else if (m->rank_mode && m->ipc) {
-    t = std::string("IPC: pack kernels storing into the neighbours' hipIpc-mapped receive areas + sequence words polled by a wait kernel; time step through the mapped tables (bootstrap: ") + (m->comm ? "RCCL" : "host callbacks") + ")";
+    t = std::string(m->fused ? "IPC: one launch per stage, its workgroups on the cut store their traces into the neighbours' hipIpc-mapped tables"
+                             : "IPC: pack kernels storing into the neighbours' hipIpc-mapped receive areas") +
+        " + sequence words polled by a wait kernel; time step through the mapped tables (bootstrap: " + (m->comm ? "RCCL" : "host callbacks") + ")";
     if (m->comm) { cnt = rk = -1; if (g_rccl.CommCount) g_rccl.CommCount(m->comm, &cnt); if (g_rccl.CommUserRank) g_rccl.CommUserRank(m->comm, &rk); }
   } else if (m->rank_mode && m->x_exchange) t = "callbacks of the host program (dflo_hip_multi_create_rank_custom)";
   else if (m->rank_mode && m->comm) {

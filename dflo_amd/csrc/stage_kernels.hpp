@@ -509,6 +509,33 @@ __device__ __forceinline__ void limiter_marks_from_box(const double (&lo)[4], co
 //         neighbours' (a thread takes one component of one halo cell: its N^2 nodes give the N traces and the average) -- in the
 //         order in which the stage epilogue sums them (cell_average_rows): the same bits as the stored averages, which are then
 //         neither read nor, in intermediate stages, written (15-20 % of the Q1 LxF kernel's memory traffic)
+// The tail of a stage kernel that delivers (StageArgs::dl_*): the workgroup has stored its shard's new state; behind a barrier its
+// threads read it back (same compute unit: the stores have completed and the L1 holds no older copy of rows nobody has read in this
+// launch), form the traces on the shard's cut faces exactly as face_trace_kernel would (cell_face_trace: the same bits), and store
+// them into the neighbours' tables.  Release at system scope, count, and the last workgroup that delivers publishes the number.
+template <int N>
+__device__ __forceinline__ void deliver_traces(const StageArgs &a, const int shard) {
+  const int b0 = a.dl_begin[shard], n = a.dl_begin[shard + 1] - b0;   // wave-uniform
+  if (n == 0) return;
+  // (a wait for the wavefront's own stores, not a fence: a release at agent or system scope writes the XCD's whole L2 back, and
+  //  with one per delivering workgroup the launch was 8 us longer; what the neighbours read is written through -- their memory is
+  //  never cached dirty here --, so "completed" is all the word's publication has to follow)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int t = threadIdx.x; t < n * 4 * N; t += blockDim.x) {
+    const int j = b0 + t / (4 * N), r = t - (t / (4 * N)) * (4 * N);
+    const int2 rec = a.dl_rec[j];
+    a.dl_dst[j][r] = cell_face_trace<N>(a.Unew, rec.x, rec.y, r / N, r % N);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  if (atomicAdd(a.dl_done, 1u) != (unsigned)a.dl_total - 1u) return;
+  __threadfence_system();   // once per launch: the workgroup that publishes
+  __hip_atomic_store(a.dl_done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  for (int i = 0; i < a.dl_nflag; ++i) __hip_atomic_store(a.dl_flag[i], a.dl_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 template <int N, int FLUX, int MODE, int GEO, int POS, int STREAM, int AF = 0>
 __global__ __launch_bounds__(64 * N, N >= 5 ? 1 : ((N == 4 && GEO == 0 && MODE == 0) ? kQ3FirstStageWaves : (((GEO == 1 && N != 3) || N == 4) ? 2 : (N == 3 && GEO == 0 ? kQ2Waves : 3)))) void stage_kernel(const StageArgs a) {
   constexpr int NS = N * N, NDOF = 4 * NS, NT = 64 * N;
@@ -1099,6 +1126,7 @@ __global__ __launch_bounds__(64 * N, N >= 5 ? 1 : ((N == 4 && GEO == 0 && MODE =
       if (have_dt) a.shard_dtmin[shard] = dtmin;
     }
   }
+  if (a.dl_begin) deliver_traces<N>(a, shard);
 }
 
 // =====================================================================================================

@@ -41,6 +41,8 @@ struct Tunables {
                                   //                           receive areas) in fine-grained device memory (hipDeviceMallocFinegrained)
   int rank_transport = 0;         // DFLO_RANK_TRANSPORT=rccl|ipc   one process per GPU: 0 grouped ncclSend/ncclRecv + ncclAllReduce (default),
                                   //                           1 pack kernels storing into the peers' IPC-mapped receive areas + sequence flags
+  bool ipc_fused = true;          // DFLO_IPC_FUSED=0         IPC transport: rim launch + pack kernel on the comm stream even where the stage kernel could
+                                  //                           deliver its cut faces' traces itself (one launch per stage, one stream)
   bool avg_in_place = true;     // DFLO_MULTI_AVG_UNPACK=1   TVB: unpack the received ghost averages into the engine's array before the rim
                                 //                           limiter (default: the limiter reads them where they arrived)
 };
@@ -92,6 +94,7 @@ inline Tunables read_tunables() {
   t.comm_priority = flag("DFLO_MULTI_PRIORITY", true);
   t.avg_in_place = !flag("DFLO_MULTI_AVG_UNPACK", false);
   t.peer_finegrained = flag("DFLO_PEER_FINEGRAINED", false);
+  t.ipc_fused = flag("DFLO_IPC_FUSED", true);
   if (const char *e = std::getenv("DFLO_RANK_TRANSPORT")) t.rank_transport = std::strcmp(e, "ipc") == 0 ? 1 : 0;
   return t;
 }

@@ -315,6 +315,15 @@ int dflo_hip_set_dt_table_buffer(dflo_hip_handle h, void *table);
  * less between two kernels of a stream (the multi-device schedule orders its two streams with one such event per phase).
  * If that launch turns out to be empty the event is recorded the plain way. */
 int dflo_hip_attach_event(dflo_hip_handle h, void *event);
+/* Delivery by the stage kernel itself (one process per GPU over mapped tables; Qk, ghost cells by their traces).  set_deliver,
+ * once per receive area (0 | 1): the records of the send list of set_send_faces go, segment by segment as in pack_send_to, to
+ * dst[i] -- the neighbours' trace tables of that area --, and flags[i] are the neighbours' sequence words.  stage_deliver arms
+ * the NEXT launch over all shards (stage_update_part(h, 0) / stage(h, ..)): every workgroup whose shard has cut faces forms the
+ * traces of its new state on them (the bits face_trace / pack_send_traces would give) and stores them at their destination;
+ * the last such workgroup publishes `seq` in the words.  No rim launch of its own, no pack kernel, no second stream:
+ * update_ghost_values (src_mpi/claw.cc:793) is part of the kernel that produced the values. */
+int dflo_hip_set_deliver(dflo_hip_handle h, int area, int n_segments, const int32_t *first, void *const *dst, void *const *flags);
+int dflo_hip_stage_deliver(dflo_hip_handle h, int area, uint64_t seq);
 int dflo_hip_pack_send_to(dflo_hip_handle h, int kind, int n_segments, const int32_t *first, void *const *dst);
 /* The same, and the kernel tells the receivers: once every record of the launch is visible system-wide, the workgroup that
  * finishes last stores `seq` (release, system scope) into the 64-bit words flags[i] -- sequence words in the receivers'

@@ -595,7 +595,7 @@ def test_bench_line_of_two_ranks_launched_the_drivers_way(extra):
     tr = {t["transport"]: t for t in c["transports"]}
     assert sorted(tr) == ["gloo", "ipc_gloo"] and all(t["ok"] for t in tr.values()), c["transports"]
     assert c["transport_used"] in tr and abs(d["value"] - max(t["value"] for t in tr.values())) <= 0.06
-    assert ("gloo" in c["parallelism"]) and (("IPC: pack kernels" in c["transport"]) == (c["transport_used"] == "ipc_gloo"))
+    assert ("gloo" in c["parallelism"]) and (c["transport"].startswith("IPC: ") == (c["transport_used"] == "ipc_gloo"))
     assert c["env"].get("HSA_ENABLE_IPC_MODE_LEGACY") == "0" and "DFLO_BENCH_TRANSPORTS" in c["env"]     # the settings RCCL / the runtime were given
     if not extra:   # the weak-scaling line carries the strong-scaling reading of north_star as well: the one-GPU mesh cut N ways
         st = d["secondary_strong"]
