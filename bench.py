@@ -434,16 +434,16 @@ def main():
         if world > 1:
             import torch.distributed as dist
             from dflo_amd.multi import comm_unique_id
-            if transport in ("gloo", "ipc_gloo", "ipc_fine"):   # gloo callbacks carry the halos (gloo) or only the set-up and the host-side reductions (ipc_*)
+            if transport in ("gloo", "ipc_gloo", "ipc_coarse"):   # gloo callbacks carry the halos (gloo) or only the set-up and the host-side reductions (ipc_*)
                 uid = "gloo"
                 env["DFLO_RANK_TRANSPORT"] = "rccl" if transport == "gloo" else "ipc"
-                env["DFLO_PEER_FINEGRAINED"] = "1" if transport == "ipc_fine" else None
-            else:   # rccl | ipc | ipc_fine: an RCCL communicator carries the halos (rccl) or only the set-up (ipc: the handles)
+                env["DFLO_PEER_FINEGRAINED"] = "0" if transport == "ipc_coarse" else None
+            else:   # rccl | ipc: an RCCL communicator carries the halos (rccl) or only the set-up (ipc: the handles)
                 box = [comm_unique_id() if rank == 0 else None]
                 dist.broadcast_object_list(box, src=0)
                 uid = box[0]
                 env["DFLO_RANK_TRANSPORT"] = "ipc" if transport.startswith("ipc") else "rccl"
-                env["DFLO_PEER_FINEGRAINED"] = "1" if transport == "ipc_fine" else None
+                env["DFLO_PEER_FINEGRAINED"] = "0" if transport == "ipc_coarse" else None
         saved = {k: os.environ.get(k) for k in env}
         for k, v in env.items():
             if v is None:
@@ -559,7 +559,7 @@ def main():
                                   {"gloo": "HOST-STAGED gloo transport -- not a measurement of the device-to-device paths",
                                    "rccl": "RCCL send/recv of face traces + 8-byte all-reduce(min) per step",
                                    "ipc": "pack kernels storing face traces into the neighbours' hipIpc-mapped tables + sequence words; time step through the mapped tables",
-                                   "ipc_fine": "as ipc_gloo, every peer-written buffer in fine-grained memory",
+                                   "ipc_coarse": "as ipc_gloo, the exported window in plain instead of fine-grained device memory",
                                    "ipc_gloo": "as ipc, set up over gloo callbacks instead of an RCCL communicator (no RCCL call anywhere)",
                                    "none": "one rank: nothing to exchange" if not args.self_halo else "self-halo"}[best["transport"]]),
                 # N > 1: every transport that was run in this invocation, its rate and the verdict of its own check (`value` above is
@@ -644,8 +644,8 @@ def main():
         return out
 
     # N > 1: the IPC transport and north_star's transport (RCCL send/recv + all-reduce) are BOTH measured; `value` is the better one
-    # whose check holds.  Only if neither does: the IPC transport with every peer-written buffer in fine-grained memory, then the
-    # host-staged gloo transport -- the line says which ran and what became of the others.  DFLO_BENCH_TRANSPORTS overrides the list
+    # whose check holds (the window the IPC transport exports is fine-grained memory: coherent at every access).  Only if neither
+    # does: the host-staged gloo transport -- the line says which ran and what became of the others.  DFLO_BENCH_TRANSPORTS overrides the list
     # (DFLO_BENCH_TRANSPORT=gloo, the older developer switch, means "gloo"); DFLO_BENCH_ALL_TRANSPORTS=1 runs every listed one.
     attempts = []
     state = {"done": False, "running": None, "strong": None}
@@ -685,9 +685,9 @@ def main():
         # ipc_gloo first: it needs nothing but the rendezvous that is already up (no RCCL call anywhere), so its line is safe before the
         # transport north_star names is tried; then rccl; "ipc" (the same IPC transport, set up over an RCCL communicator) adds nothing to
         # ipc_gloo and is run only when asked for
-        order = os.environ.get("DFLO_BENCH_TRANSPORTS", "gloo" if os.environ.get("DFLO_BENCH_TRANSPORT") == "gloo" else "ipc_gloo,rccl,ipc_fine,gloo").split(",")
+        order = os.environ.get("DFLO_BENCH_TRANSPORTS", "gloo" if os.environ.get("DFLO_BENCH_TRANSPORT") == "gloo" else "ipc_gloo,rccl,gloo").split(",")
         for t in order:
-            if t in ("ipc_fine", "gloo") and any(r["ok"] for r in attempts) and os.environ.get("DFLO_BENCH_ALL_TRANSPORTS") != "1":
+            if t == "gloo" and any(r["ok"] for r in attempts) and os.environ.get("DFLO_BENCH_ALL_TRANSPORTS") != "1":
                 continue   # fallbacks
             arm(attempt_s, "transport " + t)
             attempts.append(measure(args, t))

@@ -298,6 +298,7 @@ struct dflo_hip_multi {
   bool pend = false;
   bool fused = false;          // ... and the stage kernel delivers its cut faces' traces itself (one launch per stage, one stream)
   void *win_data = nullptr, *win_sync = nullptr;   // what the peers map (see IpcExport)
+  bool ipc_fine = false;                            // win_data is fine-grained memory
   bool recv_in_window = false;                      // the receive areas lie in win_data (not allocations of their own)
   unsigned long long *flags = nullptr;
   std::vector<PeerMap> pmap;
@@ -1149,7 +1150,10 @@ int setup_ipc(dflo_hip_multi *m) {
     size_t total = 0;
     for (int i = 0; i < 7; ++i) { mine.off[i] = total; total += sizes[i]; }
     total = std::max(((total + kWindowBlock - 1) / kWindowBlock) * kWindowBlock, 2 * kWindowBlock);
-    if (dflo::read_tunables().peer_finegrained) MHIP(m, hipExtMallocWithFlags(&m->win_data, total, hipDeviceMallocFinegrained));
+    // fine-grained by default: what a neighbour stores is then coherent at every access of this device, not only behind a kernel
+    // boundary -- nothing rests on how this part treats remote writes into plain device memory (DFLO_PEER_FINEGRAINED=0: plain)
+    m->ipc_fine = dflo::read_tunables().ipc_finegrained;
+    if (m->ipc_fine) MHIP(m, hipExtMallocWithFlags(&m->win_data, total, hipDeviceMallocFinegrained));
     else MHIP(m, hipMalloc(&m->win_data, total));
     MHIP(m, hipMemset(m->win_data, 0, total));
     char *w = (char *)m->win_data;
@@ -2135,7 +2139,7 @@ int dflo_hip_multi_comm_info(dflo_hip_multi_handle m, int32_t *comm_count, int32
   else if (m->loopback) t = "one process: one-rank RCCL loopback (test transport)";
   else if (m->n_parts == 1) t = "none (one part)";
   else t = m->direct ? "one process: pack kernels storing into the peers' receive areas (xGMI peer access)" : "one process: staging buffer + hipMemcpyPeerAsync";
-  if (dflo::read_tunables().peer_finegrained) t += "; peer-written buffers in fine-grained memory";
+  if (m->ipc && !m->self_halo ? m->ipc_fine : dflo::read_tunables().peer_finegrained) t += "; peer-written buffers in fine-grained memory";
   if (m->strict) t += "; strict (senders wait for the receivers' consumed events)";
   if (comm_count) *comm_count = cnt;
   if (comm_rank) *comm_rank = rk;

@@ -39,6 +39,8 @@ struct Tunables {
   bool comm_priority = true;    // DFLO_MULTI_PRIORITY=0     the comm stream at the compute stream's priority (default: highest)
   bool peer_finegrained = false;  // DFLO_PEER_FINEGRAINED=1   every buffer a peer's kernel writes (ghost-trace tables, time-step tables,
                                   //                           receive areas) in fine-grained device memory (hipDeviceMallocFinegrained)
+  bool ipc_finegrained = true;    // DFLO_PEER_FINEGRAINED=0   ... the window the IPC transport exports is fine-grained unless this says 0 (measured on
+                                  //                           one device: no cost, profiles/LAB.md R5.11), the one-process driver's buffers only if it says 1
   int rank_transport = 0;         // DFLO_RANK_TRANSPORT=rccl|ipc   one process per GPU: 0 grouped ncclSend/ncclRecv + ncclAllReduce (default),
                                   //                           1 pack kernels storing into the peers' IPC-mapped receive areas + sequence flags
   bool ipc_fused = true;          // DFLO_IPC_FUSED=0         IPC transport: rim launch + pack kernel on the comm stream even where the stage kernel could
@@ -94,6 +96,7 @@ inline Tunables read_tunables() {
   t.comm_priority = flag("DFLO_MULTI_PRIORITY", true);
   t.avg_in_place = !flag("DFLO_MULTI_AVG_UNPACK", false);
   t.peer_finegrained = flag("DFLO_PEER_FINEGRAINED", false);
+  t.ipc_finegrained = flag("DFLO_PEER_FINEGRAINED", true);
   t.ipc_fused = flag("DFLO_IPC_FUSED", true);
   if (const char *e = std::getenv("DFLO_RANK_TRANSPORT")) t.rank_transport = std::strcmp(e, "ipc") == 0 ? 1 : 0;
   return t;

@@ -23,8 +23,8 @@ ROOT = os.path.dirname(HERE)
 
 
 def _worker(rank, world, port, name, ret, transport="callbacks"):
-    if transport == "ipc_fine":   # ... with every peer-written buffer in fine-grained memory (handles of hipExtMallocWithFlags memory)
-        os.environ["DFLO_PEER_FINEGRAINED"] = "1"
+    if transport == "ipc_coarse":   # ... with the exported window in plain device memory (default: fine-grained, hipExtMallocWithFlags)
+        os.environ["DFLO_PEER_FINEGRAINED"] = "0"
         transport = "ipc"
     if transport == "ipc":   # the per-stage path without a transport library: hipIpc-mapped receive areas + sequence words; the
         os.environ["DFLO_RANK_TRANSPORT"] = "ipc"   # callbacks only carry the handles at create and the host-side reductions
@@ -69,7 +69,7 @@ def _worker(rank, world, port, name, ret, transport="callbacks"):
 @pytest.mark.parametrize("name,world,transport", [("c2", 2, "callbacks"), ("c2", 3, "callbacks"), ("c1", 2, "callbacks"), ("c4", 2, "callbacks"),
                                                   ("c4", 3, "callbacks"), ("c5", 2, "callbacks"), ("kxrcf", 2, "callbacks"),
                                                   ("c2", 2, "ipc"), ("c2", 3, "ipc"), ("c1", 3, "ipc"), ("c3", 2, "ipc"), ("c4", 3, "ipc"),
-                                                  ("c5", 2, "ipc"), ("kxrcf", 2, "ipc"), ("c2", 3, "ipc_fine"), ("c4", 2, "ipc_fine")])
+                                                  ("c5", 2, "ipc"), ("kxrcf", 2, "ipc"), ("c2", 3, "ipc_coarse"), ("c4", 2, "ipc_coarse")])
 def test_ranks_on_one_device_match_the_single_engine(name, world, transport):
     import random
     mgr = mp.get_context("spawn").Manager()   # (no fork of a process that holds a HIP runtime)
