@@ -541,7 +541,11 @@ int launch_update(dflo_hip_engine *h, double *rhs_out, int part) {
   a.degree = h->degree;
   a.kb = h->kb;
   part_list(h, part, &a.shard_list, &a.n_list);
-  if (a.n_list == 0) { drop_attached_event(h); return DFLO_OK; }
+  if (a.n_list == 0) {
+    drop_attached_event(h);
+    if (part == 0) h->dl_armed = -1;   // (nothing to launch: nothing delivers)
+    return DFLO_OK;
+  }
   a.sweep_rev = next_sweep(h, part);
   const int mode_ = rhs_out ? 2 : (h->ark[rk] != 0.0 ? 1 : 0);
   a.flags = h->flags;
