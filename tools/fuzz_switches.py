@@ -26,12 +26,17 @@ ENGINE = [("DFLO_GRAPH", ["1"]), ("DFLO_SWEEP", ["0"]), ("DFLO_STREAM", ["0", "1
           ("DFLO_LIM_GRID", ["1", "7", "64", "333", "4096"]), ("DFLO_LIM_MASK", ["0", "1"]), ("DFLO_PLAN_REFINE", ["0", "2"]),
           ("DFLO_PLAN_RIM_FIRST", ["0"])]
 MULTI = [("DFLO_HALO_CELLS", ["1"]), ("DFLO_MULTI_GROUP", ["part", "device"]), ("DFLO_MULTI_THREADS", ["0"]), ("DFLO_MULTI_STRICT", ["1"]),
-         ("DFLO_MULTI_COPY", ["1"]), ("DFLO_MULTI_PRIORITY", ["0"]), ("DFLO_MULTI_AVG_UNPACK", ["1"])]
+         ("DFLO_MULTI_COPY", ["1"]), ("DFLO_MULTI_PRIORITY", ["0"]), ("DFLO_MULTI_AVG_UNPACK", ["1"]), ("DFLO_PEER_FINEGRAINED", ["1"])]
+# round 5: a third arrangement -- ONE part that is its own neighbour through the IPC transport's kernels (dflo_hip_multi_create_self) --
+# with the switches of that transport: the stage kernel delivering its traces itself or the rim launch + pack kernel on a second stream
+SELF = [("DFLO_IPC_FUSED", ["0"]), ("DFLO_MULTI_PRIORITY", ["0"]), ("DFLO_MULTI_AVG_UNPACK", ["1"]), ("DFLO_HALO_CELLS", ["1"])]
 RESHARD = {"DFLO_PLAN_REFINE", "DFLO_HALO_CELLS"}   # (these change which cells share a shard, or how a ghost cell gives its trace)
 
 
 def build(case, parts):
     d = case["desc"]
+    if parts == "self":
+        return dflo_amd.MultiConservationLaw.for_self(case["mesh"], case["prm"], 0, transport="ipc", partitioner=d["partitioner"])
     if parts:
         return dflo_amd.MultiConservationLaw(case["mesh"], case["prm"], devices=[0] * d["parts"], partitioner=d["partitioner"])
     return dflo_amd.ConservationLaw(case["mesh"], case["prm"])
@@ -60,8 +65,8 @@ t0 = time.time()
 for i in range(n_cases):
     case = fm.make_case(i)
     d = case["desc"]
-    parts = bool(srng.random() < 0.5)
-    pool = ENGINE + (MULTI if parts else [])
+    parts = [False, True, "self"][int(srng.integers(0, 3))]
+    pool = ENGINE + (SELF if parts == "self" else (MULTI if parts else []))
     picks = srng.choice(len(pool), size=int(srng.integers(1, 5)), replace=False)
     env = {pool[k][0]: str(srng.choice(pool[k][1])) for k in picks}
     try:
