@@ -104,6 +104,11 @@ struct dflo_hip_engine {
   unsigned long long **d_dl_flag = nullptr;
   int dl_nflag = 0, dl_total = 0, dl_armed = -1;
   unsigned long long dl_seq = 0;
+  unsigned long long **d_wt_flag = nullptr;   // dflo_hip_set_arrival_words: this engine's own words for the neighbours' traces
+  int wt_n = 0;
+  int *wt_fail = nullptr;
+  unsigned long long wt_seq = 0;
+  bool wt_armed = false;
   hipEvent_t next_stop = nullptr;      // dflo_hip_attach_event: the next stage / limiter kernel launched carries this event as its completion signal
   unsigned int *send_done = nullptr;   // [3] workgroup counters of the signalling pack kernels, by kind (dflo_hip_pack_send_to_signal)
   bool peer_fine = false;              // DFLO_PEER_FINEGRAINED=1: what a peer's kernel writes lives in fine-grained memory
@@ -543,7 +548,7 @@ int launch_update(dflo_hip_engine *h, double *rhs_out, int part) {
   part_list(h, part, &a.shard_list, &a.n_list);
   if (a.n_list == 0) {
     drop_attached_event(h);
-    if (part == 0) h->dl_armed = -1;   // (nothing to launch: nothing delivers)
+    if (part == 0) { h->dl_armed = -1; h->wt_armed = false; }   // (nothing to launch: nothing delivers, nothing waits)
     return DFLO_OK;
   }
   a.sweep_rev = next_sweep(h, part);
@@ -566,6 +571,13 @@ int launch_update(dflo_hip_engine *h, double *rhs_out, int part) {
     a.dl_seq = h->dl_seq;
     a.dl_done = h->send_done + 3;
     h->dl_armed = -1;
+    if (h->wt_armed) {   // ... and waits for the neighbours' traces of the stage before in its workgroups that read them
+      a.wt_flag = h->d_wt_flag;
+      a.wt_n = h->wt_n;
+      a.wt_seq = h->wt_seq;
+      a.wt_fail = h->wt_fail;
+      h->wt_armed = false;
+    }
   }
   a.tvb_M = h->prm.limiter_type == DFLO_LIMITER_TVB ? h->prm.M : -1.0;
   a.tvb_char = h->prm.char_lim;
@@ -1194,6 +1206,7 @@ int dflo_hip_destroy(dflo_hip_handle h) {
   hipFree(h->fin_counter); hipFree(h->pos_stats); hipFree(h->send_done);
   if (!h->dt_external) hipFree(h->dt_mins);
   if (!h->tg_external) { hipFree(h->Tg[0]); hipFree(h->Tg[1]); }
+  hipFree(h->d_wt_flag);
   hipFree(h->d_dl_begin); hipFree(h->d_dl_rec); hipFree(h->d_dl_dst[0]); hipFree(h->d_dl_dst[1]); hipFree(h->d_dl_flag);
   hipFree(h->d_gt_slot); hipFree(h->d_gt_face); hipFree(h->d_sendf_slot); hipFree(h->d_sendf_face); hipFree(h->d_send_slots); hipFree(h->ghost_stage);
   for (int i = 0; i < 2; ++i) if (h->ev_chunk[i]) hipEventDestroy(h->ev_chunk[i]);
@@ -1651,6 +1664,28 @@ int dflo_hip_set_deliver(dflo_hip_handle h, int area, int n_segments, const int3
   if ((rc = upload(h, &h->d_dl_dst[area], to)) || (rc = upload(h, &h->d_dl_flag, fl))) return rc;
   h->dl_nflag = n_segments;
   h->dl_total = total;
+  return DFLO_OK;
+}
+
+int dflo_hip_set_arrival_words(dflo_hip_handle h, int n, void *const *words, void *fail) {
+  if (check_handle(h) || n < 0 || n > kMaxSegs || (n > 0 && (!words || !fail))) return DFLO_ERR_BAD_PARAM;
+  hipSetDevice(h->device);
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  hipFree(h->d_wt_flag);
+  h->d_wt_flag = nullptr;
+  h->wt_n = n;
+  h->wt_fail = (int *)fail;
+  if (n == 0) return DFLO_OK;
+  std::vector<unsigned long long *> w(n);
+  for (int i = 0; i < n; ++i) w[i] = (unsigned long long *)words[i];
+  return upload(h, &h->d_wt_flag, w);
+}
+
+int dflo_hip_stage_await(dflo_hip_handle h, uint64_t seq) {
+  if (check_handle(h)) return DFLO_ERR_BAD_PARAM;
+  if (!h->d_wt_flag || !h->d_dl_begin) { h->err = "stage_await: dflo_hip_set_deliver / dflo_hip_set_arrival_words have not been called"; return DFLO_ERR_BAD_PARAM; }
+  h->wt_armed = true;
+  h->wt_seq = seq;
   return DFLO_OK;
 }
 

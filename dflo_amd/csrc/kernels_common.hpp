@@ -128,6 +128,12 @@ struct StageArgs {
   int dl_nflag, dl_total;               // dl_total: workgroups that deliver (shards with records)
   unsigned long long dl_seq;
   unsigned int *dl_done;                // their counter (zero between launches)
+  // ... and the arrival of the neighbours' traces of the stage before is awaited by the workgroups that read them (the shards with
+  // records above), behind their own loads, instead of by a kernel of its own in front of this launch: wt_n words to reach wt_seq
+  const unsigned long long *const *wt_flag;
+  int wt_n;
+  unsigned long long wt_seq;
+  int *wt_fail;                         // host-mapped: a word that did not arrive within 30 s
   KBasis kb;
 };
 

@@ -296,6 +296,7 @@ struct dflo_hip_multi {
   std::vector<int> pend_from;  // fused: the wait for the traces of a step's last stage rides with the time step's wait kernel
   unsigned long long pend_seq = 0;
   bool pend = false;
+  bool kwait = false;          // fused, trace tables fine-grained (or this device's own writes): the NEXT stage kernel's workgroups wait
   bool fused = false;          // ... and the stage kernel delivers its cut faces' traces itself (one launch per stage, one stream)
   void *win_data = nullptr, *win_sync = nullptr;   // what the peers map (see IpcExport)
   bool ipc_fine = false;                            // win_data is fine-grained memory
@@ -857,14 +858,22 @@ int stage_phase(dflo_hip_multi *m, Group &g, const StageCtx &s, int ph) {
 int fused_stage(dflo_hip_multi *m, Group &g, const StageCtx &s) {
   const int upar = (int)((1 + s.n) & 1);
   MHIP(m, hipSetDevice(g.device));
-  if (m->pend) {   // (a last stage whose wait nobody took along: a caller that drives stages without the time step's reduction)
+  bool await_in_kernel = false;
+  if (m->pend) {   // the traces of the stage before: awaited by this stage's launch itself (its workgroups on the cut), or by a kernel
     m->pend = false;
-    const int rc = wait_words(m, g.M, CH_TRACES, m->pend_from, m->pend_seq);
-    if (rc) return rc;
+    await_in_kernel = m->kwait;
+    if (!await_in_kernel) {
+      Part &p0 = m->parts[g.parts[0]];
+      xt_begin(p0, g.M);
+      const int rc = wait_words(m, g.M, CH_TRACES, m->pend_from, m->pend_seq);
+      xt_end(p0, g.M);
+      if (rc) return rc;
+    }
   }
   for (int i : g.parts) {
     Part &p = m->parts[i];
     MENG(m, p, dflo_hip_stage_open(p.eng, s.rk, s.dt));
+    if (await_in_kernel) MENG(m, p, dflo_hip_stage_await(p.eng, m->pend_seq));
     MENG(m, p, dflo_hip_stage_deliver(p.eng, upar, ++m->ipc_post[CH_TRACES]));
     MENG(m, p, dflo_hip_stage_update_part(p.eng, 0));
     MENG(m, p, dflo_hip_stage_finish(p.eng));
@@ -874,17 +883,11 @@ int fused_stage(dflo_hip_multi *m, Group &g, const StageCtx &s) {
     std::vector<int> from;
     for (int q : p.peers)
       if (p.recvf_off[q + 1] > p.recvf_off[q]) from.push_back(q);
-    const unsigned long long seq = ++m->ipc_arr[CH_TRACES];
-    if (s.last && m->rank_mode) {   // the time step's wait kernel (reduce_dt_rank), which follows, waits for these as well
-      m->pend = true;
-      m->pend_from = from;
-      m->pend_seq = seq;
-    } else {
-      xt_begin(p, g.M);
-      const int rc = wait_words(m, g.M, CH_TRACES, from, seq);
-      xt_end(p, g.M);
-      if (rc) return rc;
-    }
+    // who waits for these traces: the next stage (its launch, or a wait kernel in front of it), or -- after the last stage -- the
+    // time step's kernel (reduce_dt_rank), or whoever joins the streams first
+    m->pend = true;
+    m->pend_from = from;
+    m->pend_seq = ++m->ipc_arr[CH_TRACES];
     MENG(m, p, dflo_hip_use_ghost_traces(p.eng, upar));
   }
   return DFLO_OK;
@@ -1242,6 +1245,15 @@ int setup_fused(dflo_hip_multi *m) {
     if (!nseg) return DFLO_OK;
     first[nseg] = p.sendf_off[m->n_parts];
     MENG(m, p, dflo_hip_set_deliver(p.eng, par, nseg, first, dst, fl));
+  }
+  {   // this rank's own words for the neighbours' traces: the stage kernel's workgroups on the cut can wait for them themselves where
+      // what they then read is coherent inside a running kernel -- fine-grained tables, or tables this device writes itself
+    void *words[16];
+    int nw = 0;
+    for (int q : p.peers)
+      if (p.recvf_off[q + 1] > p.recvf_off[q]) words[nw++] = m->flags + flag_index(CH_TRACES, q);
+    MENG(m, p, dflo_hip_set_arrival_words(p.eng, nw, words, m->ipc_fail));
+    m->kwait = dflo::read_tunables().ipc_kwait && (m->self_halo || m->ipc_fine);
   }
   m->fused = true;
   return DFLO_OK;

@@ -513,6 +513,25 @@ __device__ __forceinline__ void limiter_marks_from_box(const double (&lo)[4], co
 // threads read it back (same compute unit: the stores have completed and the L1 holds no older copy of rows nobody has read in this
 // launch), form the traces on the shard's cut faces exactly as face_trace_kernel would (cell_face_trace: the same bits), and store
 // them into the neighbours' tables.  Release at system scope, count, and the last workgroup that delivers publishes the number.
+// The head of a stage kernel whose shard reads ghost traces, where the launch itself waits for them (StageArgs::wt_*): the first
+// wt_n threads poll one sequence word each (fine-grained memory, acquire at system scope), the workgroup meets at a barrier.  The
+// other shards' workgroups do not wait for anything.
+__device__ __forceinline__ void await_traces(const StageArgs &a, const int shard) {
+  if (a.dl_begin[shard + 1] == a.dl_begin[shard]) return;   // wave-uniform: no cut face, no ghost trace
+  if ((int)threadIdx.x < a.wt_n) {
+    const unsigned long long *w = a.wt_flag[threadIdx.x];
+    const long long t0 = wall_clock64();
+    while (__hip_atomic_load(w, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < a.wt_seq) {
+      __builtin_amdgcn_s_sleep(8);
+      if (wall_clock64() - t0 > 30LL * 100000000LL) {
+        __hip_atomic_store(a.wt_fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        break;
+      }
+    }
+  }
+  __syncthreads();
+}
+
 template <int N>
 __device__ __forceinline__ void deliver_traces(const StageArgs &a, const int shard) {
   const int b0 = a.dl_begin[shard], n = a.dl_begin[shard + 1] - b0;   // wave-uniform
@@ -622,6 +641,7 @@ __global__ __launch_bounds__(64 * N, N >= 5 ? 1 : ((N == 4 && GEO == 0 && MODE =
       }
   }
 
+  if (a.wt_n) await_traces(a, shard);
   // ---- phase A: own rows -> LDS; halo: only the trace on the shared face is kept.
   //      halo item i -> (entry s = i % nh, q = (i / nh) % N, comp = i / (nh N)); an entry is
   //      (internal cell slot | local face << 28) of a face neighbour outside the shard

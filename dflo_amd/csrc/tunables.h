@@ -45,6 +45,8 @@ struct Tunables {
                                   //                           1 pack kernels storing into the peers' IPC-mapped receive areas + sequence flags
   bool ipc_fused = true;          // DFLO_IPC_FUSED=0         IPC transport: rim launch + pack kernel on the comm stream even where the stage kernel could
                                   //                           deliver its cut faces' traces itself (one launch per stage, one stream)
+  bool ipc_kwait = true;          // DFLO_IPC_KWAIT=0         ... and a one-wavefront kernel in front of every stage waits for the neighbours' traces
+                                  //                           (default: the stage kernel's workgroups on the cut wait themselves)
   bool avg_in_place = true;     // DFLO_MULTI_AVG_UNPACK=1   TVB: unpack the received ghost averages into the engine's array before the rim
                                 //                           limiter (default: the limiter reads them where they arrived)
 };
@@ -98,6 +100,7 @@ inline Tunables read_tunables() {
   t.peer_finegrained = flag("DFLO_PEER_FINEGRAINED", false);
   t.ipc_finegrained = flag("DFLO_PEER_FINEGRAINED", true);
   t.ipc_fused = flag("DFLO_IPC_FUSED", true);
+  t.ipc_kwait = flag("DFLO_IPC_KWAIT", true);
   if (const char *e = std::getenv("DFLO_RANK_TRANSPORT")) t.rank_transport = std::strcmp(e, "ipc") == 0 ? 1 : 0;
   return t;
 }

@@ -324,6 +324,13 @@ int dflo_hip_attach_event(dflo_hip_handle h, void *event);
  * update_ghost_values (src_mpi/claw.cc:793) is part of the kernel that produced the values. */
 int dflo_hip_set_deliver(dflo_hip_handle h, int area, int n_segments, const int32_t *first, void *const *dst, void *const *flags);
 int dflo_hip_stage_deliver(dflo_hip_handle h, int area, uint64_t seq);
+/* ... and the arrival of the neighbours' traces of the stage BEFORE can be awaited inside that launch as well: set_arrival_words
+ * names this engine's own sequence words (one per neighbour that sends; fine-grained memory) and a host-mapped failure word;
+ * stage_await(seq), together with stage_deliver, makes the workgroups of the shards that read ghost traces poll the words behind
+ * their own loads until they have reached seq (30 s, then the failure word).  The other workgroups wait for nothing.  Only where
+ * the trace tables are fine-grained memory (or written by this device itself): the traces are read inside the running kernel. */
+int dflo_hip_set_arrival_words(dflo_hip_handle h, int n, void *const *words, void *fail);
+int dflo_hip_stage_await(dflo_hip_handle h, uint64_t seq);
 int dflo_hip_pack_send_to(dflo_hip_handle h, int kind, int n_segments, const int32_t *first, void *const *dst);
 /* The same, and the kernel tells the receivers: once every record of the launch is visible system-wide, the workgroup that
  * finishes last stores `seq` (release, system scope) into the 64-bit words flags[i] -- sequence words in the receivers'
