@@ -29,7 +29,7 @@ MULTI = [("DFLO_HALO_CELLS", ["1"]), ("DFLO_MULTI_GROUP", ["part", "device"]), (
          ("DFLO_MULTI_COPY", ["1"]), ("DFLO_MULTI_PRIORITY", ["0"]), ("DFLO_MULTI_AVG_UNPACK", ["1"]), ("DFLO_PEER_FINEGRAINED", ["1"])]
 # round 5: a third arrangement -- ONE part that is its own neighbour through the IPC transport's kernels (dflo_hip_multi_create_self) --
 # with the switches of that transport: the stage kernel delivering its traces itself or the rim launch + pack kernel on a second stream
-SELF = [("DFLO_IPC_FUSED", ["0"]), ("DFLO_MULTI_PRIORITY", ["0"]), ("DFLO_MULTI_AVG_UNPACK", ["1"]), ("DFLO_HALO_CELLS", ["1"])]
+SELF = [("DFLO_IPC_FUSED", ["0"]), ("DFLO_IPC_KWAIT", ["0"]), ("DFLO_PEER_FINEGRAINED", ["0"]), ("DFLO_MULTI_PRIORITY", ["0"]), ("DFLO_MULTI_AVG_UNPACK", ["1"]), ("DFLO_HALO_CELLS", ["1"])]
 RESHARD = {"DFLO_PLAN_REFINE", "DFLO_HALO_CELLS"}   # (these change which cells share a shard, or how a ghost cell gives its trace)
 
 
