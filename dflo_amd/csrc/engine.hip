@@ -109,6 +109,17 @@ struct dflo_hip_engine {
   int *wt_fail = nullptr;
   unsigned long long wt_seq = 0;
   bool wt_armed = false;
+  int dl_fence = 0;   // dflo_hip_deliver_to_plain_memory: the destinations are plain (not fine-grained) device memory
+  // TVB: the averages of the cells on a cut leave from the stage kernel, the traces from the limiter pass (dflo_hip_set_deliver_averages ..)
+  std::vector<int32_t> h_send_slots;
+  int32_t *d_dla_begin = nullptr, *d_dla_slot = nullptr;
+  double **d_dla_dst[2] = {nullptr, nullptr};
+  unsigned long long **d_dla_flag = nullptr, **d_wta_flag = nullptr;
+  int dla_nflag = 0, dla_total = 0, dla_armed = -1, wta_n = 0;
+  unsigned long long dla_seq = 0;
+  int lim_x_area = -1;                       // dflo_hip_limit_exchange: the next limiter pass over all shards takes the exchange along
+  unsigned long long lim_x_seq = 0, lim_x_await = 0;
+  bool lim_x_poll = false;
   hipEvent_t next_stop = nullptr;      // dflo_hip_attach_event: the next stage / limiter kernel launched carries this event as its completion signal
   unsigned int *send_done = nullptr;   // [3] workgroup counters of the signalling pack kernels, by kind (dflo_hip_pack_send_to_signal)
   bool peer_fine = false;              // DFLO_PEER_FINEGRAINED=1: what a peer's kernel writes lives in fine-grained memory
@@ -548,7 +559,7 @@ int launch_update(dflo_hip_engine *h, double *rhs_out, int part) {
   part_list(h, part, &a.shard_list, &a.n_list);
   if (a.n_list == 0) {
     drop_attached_event(h);
-    if (part == 0) { h->dl_armed = -1; h->wt_armed = false; }   // (nothing to launch: nothing delivers, nothing waits)
+    if (part == 0) { h->dl_armed = h->dla_armed = -1; h->wt_armed = false; }   // (nothing to launch: nothing delivers, nothing waits)
     return DFLO_OK;
   }
   a.sweep_rev = next_sweep(h, part);
@@ -570,14 +581,31 @@ int launch_update(dflo_hip_engine *h, double *rhs_out, int part) {
     a.dl_total = h->dl_total;
     a.dl_seq = h->dl_seq;
     a.dl_done = h->send_done + 3;
+    a.dl_fence = h->dl_fence;
     h->dl_armed = -1;
-    if (h->wt_armed) {   // ... and waits for the neighbours' traces of the stage before in its workgroups that read them
-      a.wt_flag = h->d_wt_flag;
-      a.wt_n = h->wt_n;
-      a.wt_seq = h->wt_seq;
-      a.wt_fail = h->wt_fail;
-      h->wt_armed = false;
-    }
+  }
+  if (h->dla_armed >= 0 && part == 0 && !rhs_out) {   // TVB: it delivers the averages of its cells on a cut
+    a.dla_begin = h->d_dla_begin;
+    a.dla_slot = h->d_dla_slot;
+    a.dla_dst = h->d_dla_dst[h->dla_armed];
+    a.dla_flag = h->d_dla_flag;
+    a.dla_nflag = h->dla_nflag;
+    a.dla_total = h->dla_total;
+    a.dla_seq = h->dla_seq;
+    a.dla_done = h->send_done + 1;
+    a.dl_fence = h->dl_fence;
+    a.store_avg = 1;
+    h->avg_valid = true;
+    h->dla_armed = -1;
+  }
+  if (h->wt_armed && part == 0 && !rhs_out && (a.dl_begin || a.dla_begin)) {
+    // ... and waits for the neighbours' traces of the stage before in its workgroups that read them (the shards with records)
+    a.wt_begin = a.dl_begin ? a.dl_begin : a.dla_begin;
+    a.wt_flag = h->d_wt_flag;
+    a.wt_n = h->wt_n;
+    a.wt_seq = h->wt_seq;
+    a.wt_fail = h->wt_fail;
+    h->wt_armed = false;
   }
   a.tvb_M = h->prm.limiter_type == DFLO_LIMITER_TVB ? h->prm.M : -1.0;
   a.tvb_char = h->prm.char_lim;
@@ -698,6 +726,27 @@ int launch_limiter(dflo_hip_engine *h, int tvb, int pos, int part, bool stage_da
     grid = std::min(grid, std::max(h->lim_grid, l.fin_blocks));
   }
   grid = std::max(grid, l.fin_blocks);   // (a launch over a few shards that carries the reductions of all of them)
+  if (h->lim_x_area >= 0 && part == 0 && stage_data) {   // the exchange of a multi-device TVB stage rides along (dflo_hip_limit_exchange)
+    if (!l.mark_list || h->basis != DFLO_BASIS_QK) { h->lim_x_area = -1; h->err = "limit_exchange: this pass does not walk a list of marked shards"; return DFLO_ERR_UNSUPPORTED; }
+    l.rim_blocks = (int)p.rim_shards.size();
+    l.rim_list = h->d_rim_list;
+    l.dl_begin = h->d_dl_begin;
+    l.dl_rec = h->d_dl_rec;
+    l.dl_dst = h->d_dl_dst[h->lim_x_area];
+    l.dl_flag = h->d_dl_flag;
+    l.dl_nflag = h->dl_nflag;
+    l.dl_total = h->dl_total;
+    l.dl_seq = h->lim_x_seq;
+    l.dl_done = h->send_done + 3;
+    l.dl_fence = h->dl_fence;
+    if (h->lim_x_poll) {
+      l.wt_flag = h->d_wta_flag;
+      l.wt_n = h->wta_n;
+      l.wt_seq = h->lim_x_await;
+      l.wt_fail = h->wt_fail;
+    }
+    h->lim_x_area = -1;
+  }
   size_t lds = 0;
   if (stage_data && h->bc_take_along && h->pending_rk == 0 && (part == 0 || part == 2) && h->basis == DFLO_BASIS_QK) {
     // the later stages' boundary values, by extra wavefronts behind the ones that limit
@@ -707,7 +756,7 @@ int launch_limiter(dflo_hip_engine *h, int tvb, int pos, int part, bool stage_da
     h->bc_take_along = false;
     h->bc_later_step = h->steps_done;
   }
-  launch_with_event(h, lf, dim3(grid + l.bc_blocks), dim3(64), lds, l);
+  launch_with_event(h, lf, dim3(grid + l.rim_blocks + l.bc_blocks), dim3(64), lds, l);
   HIPCHK(h, hipGetLastError());
   return DFLO_OK;
 }
@@ -1206,7 +1255,7 @@ int dflo_hip_destroy(dflo_hip_handle h) {
   hipFree(h->fin_counter); hipFree(h->pos_stats); hipFree(h->send_done);
   if (!h->dt_external) hipFree(h->dt_mins);
   if (!h->tg_external) { hipFree(h->Tg[0]); hipFree(h->Tg[1]); }
-  hipFree(h->d_wt_flag);
+  hipFree(h->d_wt_flag); hipFree(h->d_dla_begin); hipFree(h->d_dla_slot); hipFree(h->d_dla_dst[0]); hipFree(h->d_dla_dst[1]); hipFree(h->d_dla_flag); hipFree(h->d_wta_flag);
   hipFree(h->d_dl_begin); hipFree(h->d_dl_rec); hipFree(h->d_dl_dst[0]); hipFree(h->d_dl_dst[1]); hipFree(h->d_dl_flag);
   hipFree(h->d_gt_slot); hipFree(h->d_gt_face); hipFree(h->d_sendf_slot); hipFree(h->d_sendf_face); hipFree(h->d_send_slots); hipFree(h->ghost_stage);
   for (int i = 0; i < 2; ++i) if (h->ev_chunk[i]) hipEventDestroy(h->ev_chunk[i]);
@@ -1683,11 +1732,82 @@ int dflo_hip_set_arrival_words(dflo_hip_handle h, int n, void *const *words, voi
 
 int dflo_hip_stage_await(dflo_hip_handle h, uint64_t seq) {
   if (check_handle(h)) return DFLO_ERR_BAD_PARAM;
-  if (!h->d_wt_flag || !h->d_dl_begin) { h->err = "stage_await: dflo_hip_set_deliver / dflo_hip_set_arrival_words have not been called"; return DFLO_ERR_BAD_PARAM; }
+  if (!h->d_wt_flag || !(h->d_dl_begin || h->d_dla_begin)) { h->err = "stage_await: dflo_hip_set_deliver / dflo_hip_set_arrival_words have not been called"; return DFLO_ERR_BAD_PARAM; }
   h->wt_armed = true;
   h->wt_seq = seq;
   return DFLO_OK;
 }
+
+int dflo_hip_set_deliver_averages(dflo_hip_handle h, int area, int n_segments, const int32_t *first, void *const *dst, void *const *flags,
+                                  int n_words, void *const *words, void *fail) {
+  if (check_handle(h) || area < 0 || area > 1 || n_segments < 1 || n_segments > kMaxSegs || !first || !dst || !flags || n_words < 0 || n_words > kMaxSegs ||
+      (n_words > 0 && (!words || !fail)))
+    return DFLO_ERR_BAD_PARAM;
+  const int n = h->n_send;
+  if (n == 0 || first[0] != 0 || first[n_segments] != n) { h->err = "set_deliver_averages: the segments must cover the send list of set_send_cells"; return DFLO_ERR_COMM; }
+  hipSetDevice(h->device);
+  const int ns = h->plan.n_shards;
+  std::vector<int32_t> begin(ns + 1, 0), order(n), slot(n);
+  for (int k = 0; k < n; ++k) ++begin[(h->h_send_slots[k] >> 6) + 1];
+  int total = 0;
+  for (int sh = 0; sh < ns; ++sh) { total += begin[sh + 1] > 0; begin[sh + 1] += begin[sh]; }
+  {
+    std::vector<int32_t> at(begin.begin(), begin.end() - 1);
+    for (int k = 0; k < n; ++k) order[at[h->h_send_slots[k] >> 6]++] = k;
+  }
+  std::vector<double *> to(n);
+  for (int j = 0; j < n; ++j) {
+    const int k = order[j];
+    slot[j] = h->h_send_slots[k];
+    int i = 0;
+    while (i + 1 < n_segments && k >= first[i + 1]) ++i;
+    to[j] = (double *)dst[i] + (size_t)(k - first[i]) * 4;
+  }
+  std::vector<unsigned long long *> fl(n_segments), wd(std::max(n_words, 1), nullptr);
+  for (int i = 0; i < n_segments; ++i) fl[i] = (unsigned long long *)flags[i];
+  for (int i = 0; i < n_words; ++i) wd[i] = (unsigned long long *)words[i];
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  int rc;
+  if (!h->d_dla_begin && ((rc = upload(h, &h->d_dla_begin, begin)) || (rc = upload(h, &h->d_dla_slot, slot)))) return rc;
+  hipFree(h->d_dla_dst[area]); h->d_dla_dst[area] = nullptr;
+  hipFree(h->d_dla_flag); h->d_dla_flag = nullptr;
+  hipFree(h->d_wta_flag); h->d_wta_flag = nullptr;
+  if ((rc = upload(h, &h->d_dla_dst[area], to)) || (rc = upload(h, &h->d_dla_flag, fl)) || (rc = upload(h, &h->d_wta_flag, wd))) return rc;
+  h->dla_nflag = n_segments;
+  h->dla_total = total;
+  h->wta_n = n_words;
+  if (fail) h->wt_fail = (int *)fail;
+  return DFLO_OK;
+}
+
+int dflo_hip_stage_deliver_averages(dflo_hip_handle h, int area, uint64_t seq) {
+  if (check_handle(h) || area < 0 || area > 1) return DFLO_ERR_BAD_PARAM;
+  if (!h->d_dla_dst[area]) { h->err = "stage_deliver_averages: dflo_hip_set_deliver_averages has not been called for this receive area"; return DFLO_ERR_BAD_PARAM; }
+  h->dla_armed = area;
+  h->dla_seq = seq;
+  return DFLO_OK;
+}
+
+int dflo_hip_limit_exchange(dflo_hip_handle h, int trace_area, uint64_t trace_seq, uint64_t average_seq, int poll_in_kernel) {
+  if (check_handle(h) || trace_area < 0 || trace_area > 1) return DFLO_ERR_BAD_PARAM;
+  if (!h->d_dl_dst[trace_area] || !h->d_wta_flag || !h->lim_list) {
+    h->err = "limit_exchange: needs dflo_hip_set_deliver, dflo_hip_set_deliver_averages and a limiter pass that walks the list of marked shards";
+    return DFLO_ERR_BAD_PARAM;
+  }
+  h->lim_x_area = trace_area;
+  h->lim_x_seq = trace_seq;
+  h->lim_x_await = average_seq;
+  h->lim_x_poll = poll_in_kernel != 0;
+  return DFLO_OK;
+}
+
+int dflo_hip_deliver_to_plain_memory(dflo_hip_handle h, int plain) {
+  if (check_handle(h)) return DFLO_ERR_BAD_PARAM;
+  h->dl_fence = plain ? 1 : 0;
+  return DFLO_OK;
+}
+
+int dflo_hip_limiter_walks_list(dflo_hip_handle h) { return (h && h->lim_list) ? 1 : 0; }
 
 int dflo_hip_stage_deliver(dflo_hip_handle h, int area, uint64_t seq) {
   if (check_handle(h) || area < 0 || area > 1) return DFLO_ERR_BAD_PARAM;
@@ -1798,6 +1918,7 @@ int dflo_hip_set_send_cells(dflo_hip_handle h, int32_t n, const int32_t *cells) 
   hipFree(h->d_send_slots);
   h->d_send_slots = nullptr;
   h->n_send = n;
+  h->h_send_slots = slots;
   return upload(h, &h->d_send_slots, slots);
 }
 

@@ -128,12 +128,23 @@ struct StageArgs {
   int dl_nflag, dl_total;               // dl_total: workgroups that deliver (shards with records)
   unsigned long long dl_seq;
   unsigned int *dl_done;                // their counter (zero between launches)
+  int dl_fence;                         // the destinations are plain device memory: a release per delivering workgroup
   // ... and the arrival of the neighbours' traces of the stage before is awaited by the workgroups that read them (the shards with
   // records above), behind their own loads, instead of by a kernel of its own in front of this launch: wt_n words to reach wt_seq
   const unsigned long long *const *wt_flag;
+  const int32_t *wt_begin;              // the records by which a shard knows that it reads ghost traces (dl_begin, or dla_begin)
   int wt_n;
   unsigned long long wt_seq;
   int *wt_fail;                         // host-mapped: a word that did not arrive within 30 s
+  // TVB: what leaves from the stage kernel are the AVERAGES of the cells on a cut (the neighbours' limiter reads them; the traces
+  // leave from the limiter pass, LimArgs) -- the same arrangement with cell records
+  const int32_t *dla_begin;
+  const int32_t *dla_slot;
+  double *const *dla_dst;
+  unsigned long long *const *dla_flag;
+  int dla_nflag, dla_total;
+  unsigned long long dla_seq;
+  unsigned int *dla_done;
   KBasis kb;
 };
 
@@ -201,6 +212,78 @@ __device__ __forceinline__ double cell_face_trace(const double *U, int slot, int
 #pragma unroll
   for (int m = 0; m < N; ++m) val[m] = hp[(base + m * str) * 64];
   return trace_from_line<N>(val);
+}
+
+// ---- the exchange from inside the kernels (one process per GPU over mapped tables; engine.hip: dflo_hip_set_deliver ..).
+// await_words: the first n threads of the workgroup poll one sequence word each (fine-grained memory, acquire at system scope)
+// until it has reached seq; the workgroup meets at a barrier.
+__device__ __forceinline__ void await_words(const unsigned long long *const *flag, const int n, const unsigned long long seq, int *fail) {
+  if ((int)threadIdx.x < n) {
+    const unsigned long long *w = flag[threadIdx.x];
+    const long long t0 = wall_clock64();
+    while (__hip_atomic_load(w, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
+      __builtin_amdgcn_s_sleep(8);
+      if (wall_clock64() - t0 > 30LL * 100000000LL) {   // 30 s of the 100 MHz clock: a neighbour that died or fell out of step
+        __hip_atomic_store(fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        break;
+      }
+    }
+  }
+  __syncthreads();
+}
+// what every delivering workgroup does last: its stores have completed (the caller waited for them), count, and the last one
+// publishes the exchange's number in the receivers' words
+__device__ __forceinline__ void deliver_publish(unsigned long long *const *flag, const int nflag, const int total, const unsigned long long seq, unsigned int *done) {
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  if (atomicAdd(done, 1u) != (unsigned)total - 1u) return;
+  __threadfence_system();   // once per launch: the workgroup that publishes
+  __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  for (int i = 0; i < nflag; ++i) __hip_atomic_store(flag[i], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// deliver_face_traces: the workgroup has stored its shard's new state in U; behind a barrier its threads read it back (same compute
+// unit: the stores have completed and the L1 holds no older copy of rows nobody has read in this launch), form the traces on the
+// shard's cut faces exactly as face_trace_kernel would (cell_face_trace: the same bits) and store them into the neighbours' tables.
+// The values leave as system-scope stores, which fine-grained memory takes written through, and the workgroup WAITS for them: no
+// fence per workgroup (a release at agent or system scope writes the XCD's whole L2 back: with one per delivering workgroup the
+// launch was 8 us longer).  That a plain store would do as well is true of a neighbour on another device, whose memory is never
+// cached here -- not of a neighbour PROCESS on this device (the tests), whose table sits in this device's memory: a plain store
+// may stay dirty in this XCD's L2 while a reader on another XCD, told by the word, reads the old line from memory (seen as a
+// 2e-9 difference in one run of three ranks on one GPU out of many).  `fence`: the destination is plain device memory
+// (DFLO_PEER_FINEGRAINED=0), where only a release writes back.
+template <int N>
+__device__ __forceinline__ void deliver_face_traces(const int32_t *begin, const int2 *rec, double *const *dst, unsigned long long *const *flag, const int nflag,
+                                                    const int total, const unsigned long long seq, unsigned int *done, const double *U, const int shard,
+                                                    const int fence) {
+  const int b0 = begin[shard], n = begin[shard + 1] - b0;   // wave-uniform
+  if (n == 0) return;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int t = threadIdx.x; t < n * 4 * N; t += blockDim.x) {
+    const int j = b0 + t / (4 * N), r = t - (t / (4 * N)) * (4 * N);
+    const int2 rc = rec[j];
+    __hip_atomic_store(&dst[j][r], cell_face_trace<N>(U, rc.x, rc.y, r / N, r % N), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  if (fence) __threadfence_system();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  deliver_publish(flag, nflag, total, seq, done);
+}
+// deliver_averages: the same for the cell averages of the shard's cells on a cut (what the neighbours' TVB limiter reads), 4 doubles
+// per record, from the array the epilogue has just written
+__device__ __forceinline__ void deliver_averages(const int32_t *begin, const int32_t *slot, double *const *dst, unsigned long long *const *flag, const int nflag,
+                                                 const int total, const unsigned long long seq, unsigned int *done, const double *avg, const int shard,
+                                                 const int fence) {
+  const int b0 = begin[shard], n = begin[shard + 1] - b0;
+  if (n == 0) return;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int t = threadIdx.x; t < n * 4; t += blockDim.x) {
+    const int j = b0 + (t >> 2), c = t & 3, sl = slot[j];
+    __hip_atomic_store(&dst[j][c], avg[((size_t)(sl >> 6) * 4 + c) * 64 + (sl & 63)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  if (fence) __threadfence_system();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  deliver_publish(flag, nflag, total, seq, done);
 }
 
 // Cell average of one component of a Qk function on a square from its N^2 nodal values (node (m, b) at u[m + N b]), summed

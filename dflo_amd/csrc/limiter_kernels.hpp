@@ -82,6 +82,25 @@ struct LimArgs {
   // same t).  bc_eval_kernel and its 11 us then leave the path between two steps (C4).  0: nothing to take along.
   int bc_blocks;
   BcArgs bc;
+  // The pass can take the exchange of a multi-device TVB stage along (one process per GPU over mapped tables): rim_blocks extra
+  // wavefronts, one per shard on a cut (rim_list), whatever its marks -- each waits for the neighbours' averages of this stage (the
+  // words wt_*; the stage kernel that ran before delivered this rank's), limits its shard with them (ghost_avg) and then delivers
+  // the traces of the limited state on the shard's cut faces (dl_*, as the stage kernel does where no pass sits in between).
+  // The stage kernel keeps those shards off the list of marked shards.  0: nothing to take along.
+  int rim_blocks;
+  const int32_t *rim_list;
+  const int32_t *dl_begin;
+  const int2 *dl_rec;
+  double *const *dl_dst;
+  unsigned long long *const *dl_flag;
+  int dl_nflag, dl_total;
+  unsigned long long dl_seq;
+  unsigned int *dl_done;
+  int dl_fence;
+  const unsigned long long *const *wt_flag;
+  int wt_n;
+  unsigned long long wt_seq;
+  int *wt_fail;
   KBasis kb;
 };
 
@@ -305,12 +324,13 @@ __device__ __forceinline__ void limiter_shard(const LimArgs &a, const int shard,
 template <int N>
 __global__ __launch_bounds__(64) void limiter_kernel(const LimArgs a) {
   extern __shared__ unsigned char bc_lds[];   // kBcWaveLds bytes when bc_blocks > 0, else none
-  const int grid = (int)gridDim.x - a.bc_blocks;   // the wavefronts that limit
-  if ((int)blockIdx.x >= grid) {
-    bc_eval_wave(a.bc, (int)blockIdx.x - grid, 1, bc_lds);
+  const int grid = (int)gridDim.x - a.bc_blocks - a.rim_blocks;   // the wavefronts that limit the shards the launch is about
+  if ((int)blockIdx.x >= grid + a.rim_blocks) {
+    bc_eval_wave(a.bc, (int)blockIdx.x - grid - a.rim_blocks, 1, bc_lds);
     return;
   }
-  if (a.mark_list) {
+  const bool rim = (int)blockIdx.x >= grid;   // a shard on a cut: averages in, limiter, traces out
+  if (a.mark_list && !rim) {
     // the marked shards from the stage kernel's list, in the order they were appended (any order gives the same bits: a shard's
     // pass rewrites its own cells and reads averages, which limiting does not change).  The step's reductions ride on the LAST
     // wavefronts of the grid, which have a list entry only when the list is longer than the grid.
@@ -325,10 +345,20 @@ __global__ __launch_bounds__(64) void limiter_kernel(const LimArgs a) {
     }
     return;
   }
-  if (a.fin_blocks > 0 && (int)blockIdx.x < a.fin_blocks) finalize_by_wave(a.fin, blockIdx.x, a.fin_blocks);
-  const int sidx = shard_of_block(blockIdx.x, a.n_list, a.sweep_rev);
-  if (sidx < 0) return;
-  limiter_shard<N>(a, a.shard_list ? a.shard_list[sidx] : sidx);
+  // (one call of limiter_shard for the wavefront of a shard on a cut and for the wavefront-per-shard launch: a third copy of it in
+  //  this kernel cost limiter_kernel<3> 18 more registers and 2.4 KB of scratch per lane, and the pass 25 us)
+  int shard;
+  if (rim) {
+    shard = a.rim_list[(int)blockIdx.x - grid];
+    if (a.wt_n) await_words(a.wt_flag, a.wt_n, a.wt_seq, a.wt_fail);
+  } else {
+    if (a.fin_blocks > 0 && (int)blockIdx.x < a.fin_blocks) finalize_by_wave(a.fin, blockIdx.x, a.fin_blocks);
+    const int sidx = shard_of_block(blockIdx.x, a.n_list, a.sweep_rev);
+    if (sidx < 0) return;
+    shard = a.shard_list ? a.shard_list[sidx] : sidx;
+  }
+  limiter_shard<N>(a, shard);
+  if (rim) deliver_face_traces<N>(a.dl_begin, a.dl_rec, a.dl_dst, a.dl_flag, a.dl_nflag, a.dl_total, a.dl_seq, a.dl_done, a.U, shard, a.dl_fence);
 }
 
 // apply_limiter_TVB_Pk (src/limiter.cc:377-516) then the Pk branch of apply_positivity_limiter

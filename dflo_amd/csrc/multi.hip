@@ -297,6 +297,7 @@ struct dflo_hip_multi {
   unsigned long long pend_seq = 0;
   bool pend = false;
   bool kwait = false;          // fused, trace tables fine-grained (or this device's own writes): the NEXT stage kernel's workgroups wait
+  bool fused_tvb = false;      // ... with a TVB limiter: averages leave from the stage kernel, traces from the limiter pass
   bool fused = false;          // ... and the stage kernel delivers its cut faces' traces itself (one launch per stage, one stream)
   void *win_data = nullptr, *win_sync = nullptr;   // what the peers map (see IpcExport)
   bool ipc_fine = false;                            // win_data is fine-grained memory
@@ -893,6 +894,53 @@ int fused_stage(dflo_hip_multi *m, Group &g, const StageCtx &s) {
   return DFLO_OK;
 }
 
+// The same with a TVB limiter between update and send (C3, C4; two exchanges per stage, src_mpi/claw.cc:793 and src_mpi/limiter.cc:232):
+// still the single engine's two launches per stage and nothing else.  The stage kernel's workgroups on the cut deliver their cells'
+// new AVERAGES; the limiter pass has one extra wavefront per shard on the cut, which waits for the neighbours' averages, limits
+// the shard with them and delivers the TRACES of the limited state; the next stage kernel's workgroups on the cut wait for the
+// neighbours' traces.  (Where the tables are plain device memory the two waits are one-wavefront kernels in front of the launches.)
+int fused_tvb_stage(dflo_hip_multi *m, Group &g, const StageCtx &s) {
+  const int upar = (int)((1 + s.n) & 1), apar = (int)(s.n & 1);
+  MHIP(m, hipSetDevice(g.device));
+  Part &p = m->parts[g.parts[0]];   // (one process per GPU: one part)
+  bool await_in_kernel = false;
+  if (m->pend) {
+    m->pend = false;
+    await_in_kernel = m->kwait;
+    if (!await_in_kernel) {
+      xt_begin(p, g.M);
+      const int rc = wait_words(m, g.M, CH_TRACES, m->pend_from, m->pend_seq);
+      xt_end(p, g.M);
+      if (rc) return rc;
+    }
+  }
+  MENG(m, p, dflo_hip_stage_open(p.eng, s.rk, s.dt));
+  if (await_in_kernel) MENG(m, p, dflo_hip_stage_await(p.eng, m->pend_seq));
+  MENG(m, p, dflo_hip_stage_deliver_averages(p.eng, apar, ++m->ipc_post[CH_AVG]));
+  MENG(m, p, dflo_hip_stage_update_part(p.eng, 0));
+  std::vector<int> from;
+  for (int q : p.peers)
+    if (p.recv_off[q + 1] > p.recv_off[q]) from.push_back(q);
+  const unsigned long long aseq = ++m->ipc_arr[CH_AVG];
+  if (!m->kwait) {
+    xt_begin(p, g.M);
+    const int rc = wait_words(m, g.M, CH_AVG, from, aseq);
+    xt_end(p, g.M);
+    if (rc) return rc;
+  }
+  MENG(m, p, dflo_hip_ghost_avg_source(p.eng, p.recv_a[apar]));
+  MENG(m, p, dflo_hip_limit_exchange(p.eng, upar, ++m->ipc_post[CH_TRACES], aseq, m->kwait ? 1 : 0));
+  MENG(m, p, dflo_hip_stage_limit(p.eng));   // the pass over all shards + the step's reductions behind the last stage
+  from.clear();
+  for (int q : p.peers)
+    if (p.recvf_off[q + 1] > p.recvf_off[q]) from.push_back(q);
+  m->pend = true;
+  m->pend_from = from;
+  m->pend_seq = ++m->ipc_arr[CH_TRACES];
+  MENG(m, p, dflo_hip_use_ghost_traces(p.eng, upar));
+  return DFLO_OK;
+}
+
 // the KXRCF indicator reads the neighbours' unlimited DoFs of the new stage: ghosts are refreshed between update and
 // limiter as well (update_ghost_values before compute_shock_indicator in the MPI variant); no overlap on this path.
 // Two exchanges per stage (numbers n and n + 1).
@@ -931,9 +979,9 @@ int stage_groups(dflo_hip_multi *m, Group *gs, int ng, int rk, double dt, int64_
     return DFLO_OK;
   }
   const StageCtx s{rk, dt, n, rk == m->n_rk - 1};
-  if (m->fused) {
+  if (m->fused || m->fused_tvb) {
     for (int k = 0; k < ng; ++k) {
-      const int rc = fused_stage(m, gs[k], s);
+      const int rc = m->fused_tvb ? fused_tvb_stage(m, gs[k], s) : fused_stage(m, gs[k], s);
       if (rc) return rc;
     }
     return DFLO_OK;
@@ -1228,8 +1276,12 @@ int setup_ipc(dflo_hip_multi *m) {
 // TVB limiter reading ghost averages, no whole cells --, and no limiter pass sits between the update and the send)
 int setup_fused(dflo_hip_multi *m) {
   Part &p = m->parts[0];
-  m->fused = false;
-  if (!m->ipc || !dflo::read_tunables().ipc_fused || !p.trace || m->tvb || m->kxrcf || m->need_avg || m->sep_limiter || p.peers.empty()) return DFLO_OK;
+  m->fused = m->fused_tvb = false;
+  if (!m->ipc || !dflo::read_tunables().ipc_fused || !p.trace || m->kxrcf || p.peers.empty()) return DFLO_OK;
+  // with a TVB limiter: the pass has to walk the list of marked shards (so that the shards on a cut can be taken off it) and read
+  // the ghost averages where they arrive; the LxF flux would want them in the engine's array as well
+  const bool tvb_ok = m->tvb && m->avg_in_place && m->prm.flux_type != DFLO_FLUX_LXF && dflo_hip_limiter_walks_list(p.eng) && (int)m->parts.size() == 1;
+  if (m->tvb ? !tvb_ok : (m->need_avg || m->sep_limiter)) return DFLO_OK;
   for (int par = 0; par < 2; ++par) {
     int32_t first[17];
     void *dst[16], *fl[16];
@@ -1254,6 +1306,30 @@ int setup_fused(dflo_hip_multi *m) {
       if (p.recvf_off[q + 1] > p.recvf_off[q]) words[nw++] = m->flags + flag_index(CH_TRACES, q);
     MENG(m, p, dflo_hip_set_arrival_words(p.eng, nw, words, m->ipc_fail));
     m->kwait = dflo::read_tunables().ipc_kwait && (m->self_halo || m->ipc_fine);
+    // (self-halo: the tables are this engine's own plain allocations, and it is its own, later kernels that read them)
+    MENG(m, p, dflo_hip_deliver_to_plain_memory(p.eng, (!m->self_halo && !m->ipc_fine) ? 1 : 0));
+  }
+  if (m->tvb) {   // the averages' way: into the neighbours' average areas, words of their own
+    void *words[16];
+    int nw = 0;
+    for (int q : p.peers)
+      if (p.recv_off[q + 1] > p.recv_off[q]) words[nw++] = m->flags + flag_index(CH_AVG, q);
+    for (int par = 0; par < 2; ++par) {
+      int32_t first[17];
+      void *dst[16], *fl[16];
+      int nseg = 0;
+      for (int q : p.peers) {
+        const int n = p.send_off[q + 1] - p.send_off[q];
+        if (!n) continue;
+        first[nseg] = p.send_off[q];
+        dst[nseg] = m->pmap[q].recv_a[par] + (size_t)m->pmap[q].ro * 4;
+        fl[nseg++] = m->pmap[q].flags + flag_index(CH_AVG, p.index);
+      }
+      first[nseg] = p.send_off[m->n_parts];
+      MENG(m, p, dflo_hip_set_deliver_averages(p.eng, par, nseg, first, dst, fl, nw, words, m->ipc_fail));
+    }
+    m->fused_tvb = true;
+    return DFLO_OK;
   }
   m->fused = true;
   return DFLO_OK;
@@ -2128,7 +2204,8 @@ int dflo_hip_multi_comm_info(dflo_hip_multi_handle m, int32_t *comm_count, int32
   std::string t;
   if (m->self_halo) {
     t = std::string("self-halo (one part, its own neighbour across ") + (m->self_virtual == 1 ? "the periodic seam in x" : "a cut through the middle") + "): ";
-    if (m->ipc) t += m->fused ? "one launch per stage, its workgroups on the cut store their traces into the own table + sequence words polled by a wait kernel (the IPC transport against itself, delivery by the stage kernel)"
+    if (m->ipc && m->fused_tvb) t += "the single engine's two launches per stage: the stage kernel's workgroups on the cut deliver their averages, the limiter pass's their traces, into the own areas + sequence words (the IPC transport against itself, delivery by the kernels)";
+    else if (m->ipc) t += m->fused ? "one launch per stage, its workgroups on the cut store their traces into the own table + sequence words polled by a wait kernel (the IPC transport against itself, delivery by the stage kernel)"
                               : "rank schedule, pack kernels storing into the own receive areas + sequence words polled by a wait kernel (the IPC transport against itself)";
     else if (m->rank_mode && m->comm) {
       t += "rank schedule, grouped ncclSend/ncclRecv to itself + ncclAllReduce(min) on a one-rank RCCL communicator";
@@ -2137,7 +2214,8 @@ int dflo_hip_multi_comm_info(dflo_hip_multi_handle m, int32_t *comm_count, int32
       if (g_rccl.CommUserRank) g_rccl.CommUserRank(m->comm, &rk);
     } else t += m->direct ? "one-process schedule, pack kernels storing into the own trace table" : "one-process schedule, staging buffer + hipMemcpyPeerAsync";
   } else if (m->rank_mode && m->ipc) {
-    t = std::string(m->fused ? "IPC: one launch per stage, its workgroups on the cut store their traces into the neighbours' hipIpc-mapped tables"
+    t = std::string(m->fused_tvb ? "IPC: two launches per stage, the stage kernel's workgroups on the cut store their averages, the limiter pass's their traces, into the neighbours' hipIpc-mapped areas"
+                    : m->fused ? "IPC: one launch per stage, its workgroups on the cut store their traces into the neighbours' hipIpc-mapped tables"
                              : "IPC: pack kernels storing into the neighbours' hipIpc-mapped receive areas") +
         " + sequence words polled by a wait kernel; time step through the mapped tables (bootstrap: " + (m->comm ? "RCCL" : "host callbacks") + ")";
     if (m->comm) { cnt = rk = -1; if (g_rccl.CommCount) g_rccl.CommCount(m->comm, &cnt); if (g_rccl.CommUserRank) g_rccl.CommUserRank(m->comm, &rk); }

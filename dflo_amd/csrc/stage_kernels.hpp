@@ -513,46 +513,19 @@ __device__ __forceinline__ void limiter_marks_from_box(const double (&lo)[4], co
 // threads read it back (same compute unit: the stores have completed and the L1 holds no older copy of rows nobody has read in this
 // launch), form the traces on the shard's cut faces exactly as face_trace_kernel would (cell_face_trace: the same bits), and store
 // them into the neighbours' tables.  Release at system scope, count, and the last workgroup that delivers publishes the number.
-// The head of a stage kernel whose shard reads ghost traces, where the launch itself waits for them (StageArgs::wt_*): the first
-// wt_n threads poll one sequence word each (fine-grained memory, acquire at system scope), the workgroup meets at a barrier.  The
-// other shards' workgroups do not wait for anything.
+// the stage kernel's share of the exchange (kernels_common.hpp: await_words, deliver_face_traces, deliver_averages)
 __device__ __forceinline__ void await_traces(const StageArgs &a, const int shard) {
-  if (a.dl_begin[shard + 1] == a.dl_begin[shard]) return;   // wave-uniform: no cut face, no ghost trace
-  if ((int)threadIdx.x < a.wt_n) {
-    const unsigned long long *w = a.wt_flag[threadIdx.x];
-    const long long t0 = wall_clock64();
-    while (__hip_atomic_load(w, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < a.wt_seq) {
-      __builtin_amdgcn_s_sleep(8);
-      if (wall_clock64() - t0 > 30LL * 100000000LL) {
-        __hip_atomic_store(a.wt_fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        break;
-      }
-    }
-  }
-  __syncthreads();
+  if (a.wt_begin[shard + 1] == a.wt_begin[shard]) return;   // wave-uniform: no cut face, no ghost trace
+  await_words(a.wt_flag, a.wt_n, a.wt_seq, a.wt_fail);
 }
-
 template <int N>
 __device__ __forceinline__ void deliver_traces(const StageArgs &a, const int shard) {
-  const int b0 = a.dl_begin[shard], n = a.dl_begin[shard + 1] - b0;   // wave-uniform
-  if (n == 0) return;
-  // (a wait for the wavefront's own stores, not a fence: a release at agent or system scope writes the XCD's whole L2 back, and
-  //  with one per delivering workgroup the launch was 8 us longer; what the neighbours read is written through -- their memory is
-  //  never cached dirty here --, so "completed" is all the word's publication has to follow)
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  for (int t = threadIdx.x; t < n * 4 * N; t += blockDim.x) {
-    const int j = b0 + t / (4 * N), r = t - (t / (4 * N)) * (4 * N);
-    const int2 rec = a.dl_rec[j];
-    a.dl_dst[j][r] = cell_face_trace<N>(a.Unew, rec.x, rec.y, r / N, r % N);
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (threadIdx.x != 0) return;
-  if (atomicAdd(a.dl_done, 1u) != (unsigned)a.dl_total - 1u) return;
-  __threadfence_system();   // once per launch: the workgroup that publishes
-  __hip_atomic_store(a.dl_done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  for (int i = 0; i < a.dl_nflag; ++i) __hip_atomic_store(a.dl_flag[i], a.dl_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  deliver_face_traces<N>(a.dl_begin, a.dl_rec, a.dl_dst, a.dl_flag, a.dl_nflag, a.dl_total, a.dl_seq, a.dl_done, a.Unew, shard, a.dl_fence);
+}
+// does the limiter pass find this shard by the list of marked shards?  (not a shard on a cut where the pass takes the exchange
+// along: those get a wavefront of their own whatever their marks)
+__device__ __forceinline__ bool lists_itself(const StageArgs &a, const int shard, const int sidx) {
+  return a.lim_cnt && sidx >= a.lim_list_from && !(a.dla_begin && a.dla_begin[shard + 1] > a.dla_begin[shard]);
 }
 
 template <int N, int FLUX, int MODE, int GEO, int POS, int STREAM, int AF = 0>
@@ -1061,7 +1034,7 @@ __global__ __launch_bounds__(64 * N, N >= 5 ? 1 : ((N == 4 && GEO == 0 && MODE =
       const unsigned long long m = __ballot(need && active);
       if (lane == 0 && m) {
         atomicOr(&a.lim_mask[shard], m);
-        if (a.lim_cnt && sidx >= a.lim_list_from) a.lim_list[atomicAdd(a.lim_cnt, 1)] = make_ulonglong2((unsigned long long)shard, m);
+        if (lists_itself(a, shard, sidx)) a.lim_list[atomicAdd(a.lim_cnt, 1)] = make_ulonglong2((unsigned long long)shard, m);
       }
     }
   }
@@ -1095,7 +1068,7 @@ __global__ __launch_bounds__(64 * N, N >= 5 ? 1 : ((N == 4 && GEO == 0 && MODE =
     const unsigned long long m = __ballot(((a.pos_check && !settled) || open) && active);
     if (lane == 0 && m) {
       atomicOr(&a.lim_mask[shard], m);
-      if (a.lim_cnt && sidx >= a.lim_list_from) a.lim_list[atomicAdd(a.lim_cnt, 1)] = make_ulonglong2((unsigned long long)shard, m);
+      if (lists_itself(a, shard, sidx)) a.lim_list[atomicAdd(a.lim_cnt, 1)] = make_ulonglong2((unsigned long long)shard, m);
     }
     }
   }
@@ -1147,6 +1120,7 @@ __global__ __launch_bounds__(64 * N, N >= 5 ? 1 : ((N == 4 && GEO == 0 && MODE =
     }
   }
   if (a.dl_begin) deliver_traces<N>(a, shard);
+  if (a.dla_begin) deliver_averages(a.dla_begin, a.dla_slot, a.dla_dst, a.dla_flag, a.dla_nflag, a.dla_total, a.dla_seq, a.dla_done, a.avg_new, shard, a.dl_fence);
 }
 
 // =====================================================================================================

@@ -331,6 +331,24 @@ int dflo_hip_stage_deliver(dflo_hip_handle h, int area, uint64_t seq);
  * the trace tables are fine-grained memory (or written by this device itself): the traces are read inside the running kernel. */
 int dflo_hip_set_arrival_words(dflo_hip_handle h, int n, void *const *words, void *fail);
 int dflo_hip_stage_await(dflo_hip_handle h, uint64_t seq);
+/* With a TVB limiter between update and send (src_mpi/limiter.cc:232: a second update_ghost_values) the exchange rides in BOTH
+ * kernels of a stage.  set_deliver_averages, once per receive area: the averages of the cells of set_send_cells go to dst[i] (the
+ * neighbours' average areas: [4] doubles per cell), flags[i] are the neighbours' words for them, words[] this engine's own words
+ * for the neighbours' averages.  stage_deliver_averages arms the next launch over all shards: the workgroups of the shards on a
+ * cut deliver their cells' new averages (and the stage kernel keeps those shards off the list of marked shards).  limit_exchange
+ * arms the next limiter pass over all shards (stage_limit): one extra wavefront per shard on a cut waits for the neighbours'
+ * averages to reach average_seq (poll_in_kernel; else the caller has waited), limits the shard with them (ghost_avg_source) and
+ * delivers the traces of the limited state into the neighbours' tables of trace_area, publishing trace_seq.  Needs a pass that
+ * walks the list of marked shards (limiter_walks_list: TVB on Qk squares with marks). */
+int dflo_hip_set_deliver_averages(dflo_hip_handle h, int area, int n_segments, const int32_t *first, void *const *dst, void *const *flags,
+                                  int n_words, void *const *words, void *fail);
+int dflo_hip_stage_deliver_averages(dflo_hip_handle h, int area, uint64_t seq);
+int dflo_hip_limit_exchange(dflo_hip_handle h, int trace_area, uint64_t trace_seq, uint64_t average_seq, int poll_in_kernel);
+int dflo_hip_limiter_walks_list(dflo_hip_handle h);
+/* The kernels that deliver store their values at system scope -- written through where the destination is fine-grained memory
+ * -- and wait for them; where the destinations are PLAIN device memory (of another process on this device: only a release writes
+ * such stores back) every delivering workgroup also has to fence: plain = 1. */
+int dflo_hip_deliver_to_plain_memory(dflo_hip_handle h, int plain);
 int dflo_hip_pack_send_to(dflo_hip_handle h, int kind, int n_segments, const int32_t *first, void *const *dst);
 /* The same, and the kernel tells the receivers: once every record of the launch is visible system-wide, the workgroup that
  * finishes last stores `seq` (release, system scope) into the 64-bit words flags[i] -- sequence words in the receivers'
