@@ -949,7 +949,8 @@ int dflo_hip_create(const dflo_mesh_t *mesh, const dflo_params_t *params, int de
 
 }  // extern "C"
 
-int dflo_hip_create_with_cell_size(const dflo_mesh_t *mesh, const dflo_params_t *params, int device_id, dflo_hip_handle *out, double h_hint) {
+int dflo_hip_create_with_cell_size(const dflo_mesh_t *mesh, const dflo_params_t *params, int device_id, dflo_hip_handle *out, double h_hint,
+                                    bool pass_takes_exchange) {
   if (!mesh || !params || !out) { g_create_error = "null argument"; return DFLO_ERR_BAD_PARAM; }
   *out = nullptr;
   // consistency checks of the reference's parameter parsing (src/parameters.cc:536-550)
@@ -1184,7 +1185,9 @@ int dflo_hip_create_with_cell_size(const dflo_mesh_t *mesh, const dflo_params_t 
     //  pass reads only 16 values per cell, the box-only marks give the single engine +1.5 % (C3) and cost a part of a
     //  multi-device run 7 % (its rim / ring launches are short already): on there without ghost cells only;
     //  DFLO_LIM_MASK=1 forces them, 0 forbids them)
-    const bool want_marks = h->N >= 2 && (tun.lim_mask >= 0 ? tun.lim_mask != 0 : (h->N >= 3 || p.n_cells == p.n_owned));
+    //  ... and on where the limiter pass takes the exchange along (one launch over all shards again: the single engine's case, and
+    //  the shards on a cut can only leave a list; C3 through the IPC transport against itself: 0.80 -> 0.91 of the plain engine)
+    const bool want_marks = h->N >= 2 && (tun.lim_mask >= 0 ? tun.lim_mask != 0 : (h->N >= 3 || p.n_cells == p.n_owned || pass_takes_exchange));
     if (h->prm.limiter_type == DFLO_LIMITER_TVB && h->basis == DFLO_BASIS_QK && h->geo == 0 && want_marks) {
       const size_t nb = (size_t)std::max(p.n_shards, 1) * sizeof(unsigned long long);
       if (hipMalloc((void **)&h->lim_mask, nb) != hipSuccess) {

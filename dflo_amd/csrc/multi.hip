@@ -297,6 +297,7 @@ struct dflo_hip_multi {
   unsigned long long pend_seq = 0;
   bool pend = false;
   bool kwait = false;          // fused, trace tables fine-grained (or this device's own writes): the NEXT stage kernel's workgroups wait
+  bool want_ipc = false;       // the IPC transport has been asked for (known before the engines are made)
   bool fused_tvb = false;      // ... with a TVB limiter: averages leave from the stage kernel, traces from the limiter pass
   bool fused = false;          // ... and the stage kernel delivers its cut faces' traces itself (one launch per stage, one stream)
   void *win_data = nullptr, *win_sync = nullptr;   // what the peers map (see IpcExport)
@@ -1433,7 +1434,10 @@ int setup_part(dflo_hip_multi *m, Part &p, const dflo_mesh_t *mesh, const dflo_p
       hmin = 1.0e300;
       for (int32_t c = 0; c < mesh->n_cells; ++c) hmin = std::min(hmin, mesh->cell_vertices[(size_t)c * 8 + 2] - mesh->cell_vertices[(size_t)c * 8]);
     }
-    rc = dflo_hip_create_with_cell_size(p.sub, prm, p.device, &p.eng, hmin);
+    // (will the limiter pass take the exchange along?  what setup_fused decides later, as far as it can be known here)
+    const bool pass_x = m->want_ipc && dflo::read_tunables().ipc_fused && m->tvb && !m->kxrcf && prm->flux_type != DFLO_FLUX_LXF &&
+                        dflo::read_tunables().avg_in_place && mesh->basis == DFLO_BASIS_QK;
+    rc = dflo_hip_create_with_cell_size(p.sub, prm, p.device, &p.eng, hmin, pass_x);
   }
   if (rc) { m->err = dflo_hip_last_error(nullptr); return rc; }
   MHIP(m, hipSetDevice(p.device));
@@ -1727,6 +1731,7 @@ static int create_rank_impl(const dflo_mesh_t *mesh, const dflo_params_t *params
   m->parts[0].index = rank;
   m->parts[0].device = device_id;
   m->parts[0].sy = &m->sync[0];
+  m->want_ipc = n_ranks > 1 && dflo::read_tunables().rank_transport == 1;
   if ((rc = make_groups(m))) return bail(rc);
   if ((rc = setup_part(m, m->parts[0], mesh, params, partitioner))) return bail(rc);
   {  // peers are mutual here too: what this rank sends to q, q expects, and the other way round -- both follow from one
@@ -1776,6 +1781,7 @@ int dflo_hip_multi_create_self(const dflo_mesh_t *mesh, const dflo_params_t *par
   m->self_virtual = n_virtual;
   m->rank_mode = transport == DFLO_SELF_RCCL || transport == DFLO_SELF_IPC;
   m->direct = transport != DFLO_SELF_COPY;
+  m->want_ipc = transport == DFLO_SELF_IPC;
   m->strict = dflo::read_tunables().strict;
   int rc = create_common(mesh, params, m);
   if (rc) return bail(rc);

@@ -90,4 +90,5 @@ int build_plan(const dflo_mesh_t &mesh, int shard_ex, int shard_ey, Plan &plan, 
 
 // dflo_hip_create with the cell size of the undivided mesh (engine.hip; the C ABI entry passes 0: the mesh's own)
 struct dflo_hip_engine;
-int dflo_hip_create_with_cell_size(const dflo_mesh_t *mesh, const dflo_params_t *params, int device_id, dflo_hip_engine **out, double h_hint);
+int dflo_hip_create_with_cell_size(const dflo_mesh_t *mesh, const dflo_params_t *params, int device_id, dflo_hip_engine **out, double h_hint,
+                                    bool pass_takes_exchange = false);   // (the driver means to use dflo_hip_limit_exchange: marks at every degree)
