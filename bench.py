@@ -683,12 +683,15 @@ def main():
         best = measure(args, "none")
     else:
         # ipc_gloo first: it needs nothing but the rendezvous that is already up (no RCCL call anywhere), so its line is safe before the
-        # transport north_star names is tried; then rccl; "ipc" (the same IPC transport, set up over an RCCL communicator) adds nothing to
-        # ipc_gloo and is run only when asked for
-        order = os.environ.get("DFLO_BENCH_TRANSPORTS", "gloo" if os.environ.get("DFLO_BENCH_TRANSPORT") == "gloo" else "ipc_gloo,rccl,gloo").split(",")
+        # transport north_star names is tried; then rccl; then "ipc", the same IPC transport set up over an RCCL communicator -- its two
+        # host-side reductions per advance() (first time step, agreed status) are RCCL calls instead of host-staged gloo ones, which
+        # shows in a run as short as the strong-scaling one
+        order = os.environ.get("DFLO_BENCH_TRANSPORTS", "gloo" if os.environ.get("DFLO_BENCH_TRANSPORT") == "gloo" else "ipc_gloo,rccl,ipc,gloo").split(",")
         for t in order:
             if t == "gloo" and any(r["ok"] for r in attempts) and os.environ.get("DFLO_BENCH_ALL_TRANSPORTS") != "1":
                 continue   # fallbacks
+            if t == "ipc" and not any(r["ok"] and r["transport"] == "rccl" for r in attempts) and "DFLO_BENCH_TRANSPORTS" not in os.environ:
+                continue   # (the IPC transport set up over an RCCL communicator: only where RCCL has just been seen to work)
             arm(attempt_s, "transport " + t)
             attempts.append(measure(args, t))
         arm(None, None)
