@@ -158,6 +158,11 @@ _sig("dflo_hip_stage_open", C.c_int, _H, C.c_int, C.c_double)
 _sig("dflo_hip_stage_update_part", C.c_int, _H, C.c_int)
 _sig("dflo_hip_stage_limit_part", C.c_int, _H, C.c_int)
 _sig("dflo_hip_stage_finish", C.c_int, _H)
+_sig("dflo_hip_set_deliver", C.c_int, _H, C.c_int, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p))
+_sig("dflo_hip_stage_deliver", C.c_int, _H, C.c_int, C.c_uint64)
+_sig("dflo_hip_set_arrival_words", C.c_int, _H, C.c_int, C.POINTER(C.c_void_p), C.c_void_p)
+_sig("dflo_hip_stage_await", C.c_int, _H, C.c_uint64)
+_sig("dflo_hip_limiter_walks_list", C.c_int, _H)
 _sig("dflo_hip_n_rim_shards", C.c_int, _H)
 _sig("dflo_hip_scalar_ptrs", C.c_int, _H, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p))
 _sig("dflo_hip_debug_math", C.c_int, C.c_int, _dp, _dp, _dp)

@@ -125,3 +125,77 @@ def test_standalone_positivity_pass_after_a_resident_run_with_lazy_averages(flux
     claw.set_initial_condition(out[1][0])
     assert np.abs(claw.cell_average - mesh_avg).max() <= 1e-13 * np.abs(mesh_avg).max()
     claw.close()
+
+
+def test_delivery_by_the_stage_kernel_driven_by_hand_through_the_c_abi():
+    """The seam a transport of the host program's own would be written against (include/dflo_hip.h: dflo_hip_set_deliver,
+    dflo_hip_stage_deliver): two engines of this process on the two x-slabs of a periodic box, each told once where the traces of its cut
+    faces go -- straight into the other engine's ghost-trace tables -- and then one launch per engine and stage; here the host waits
+    between the stages where the native driver uses the sequence words.  Bit-identical to the single engine
+    (update_ghost_values of src_mpi/claw.cc:793 is part of the kernel that produced the values)."""
+    import ctypes as C
+    from dflo_amd._lib import lib
+    hip = C.CDLL("libamdhip64.so.7")          # the runtime the engine library is linked to (already loaded): the sequence words are plain device memory
+    words_p = C.c_void_p()
+    assert hip.hipMalloc(C.byref(words_p), 512) == 0 and hip.hipMemset(words_p, 0, 512) == 0
+    mesh = dflo_amd.Mesh.cartesian(64, 48, -5.0, -5.0, 10.0 / 64, [-1, -1, -1, -1], 2)
+    prm = dflo_amd.Parameters(flux="hllc", cfl=0.8)
+    u0 = mesh.interpolate(problems.isentropic_vortex)
+    one = dflo_amd.ConservationLaw(mesh, prm)
+    one.set_initial_condition(u0)
+    dts = []
+    for _ in range(5):
+        dts.append(one.compute_time_step())
+        one.iterate_explicit(dts[-1])
+    ref = one.current_solution.copy()
+    one.close()
+
+    ndof, N = mesh.ndof, 3
+    parts, engs = [mesh.partition(2, r) for r in range(2)], []
+    for sub in parts:
+        e = dflo_amd.ConservationLaw(sub, prm)
+        assert lib.dflo_hip_halo_traces(e._h) == 1
+        e.set_initial_condition(u0.reshape(mesh.n_cells, ndof)[sub.global_ids].reshape(-1))
+        engs.append(e)
+    # which faces travel: (owned cell, face) whose neighbour is a ghost cell -- by cell, then face: the order in which the OTHER part's
+    # plan numbers the traces of its ghost cells (ghost cells sorted by global id, owned cells keep the global order)
+    for r, (sub, e) in enumerate(zip(parts, engs)):
+        nb = np.asarray(sub.neighbors)
+        cells, faces = [], []
+        for c in range(sub.n_owned):
+            for f in range(4):
+                if nb[c, f] >= sub.n_owned:
+                    cells.append(c)
+                    faces.append(f)
+        cells, faces = np.asarray(cells, dtype=np.int32), np.asarray(faces, dtype=np.int32)
+        assert len(cells) == lib.dflo_hip_n_ghost_traces(engs[1 - r]._h) == 2 * 48
+        assert lib.dflo_hip_set_send_faces(e._h, len(cells), cells.ctypes.data_as(C.POINTER(C.c_int32)), faces.ctypes.data_as(C.POINTER(C.c_int32))) == 0
+        for area in range(2):
+            tg = C.c_void_p()
+            assert lib.dflo_hip_ghost_trace_buffer(engs[1 - r]._h, area, C.byref(tg)) == 0
+            first = (C.c_int32 * 2)(0, len(cells))
+            dst, fl = (C.c_void_p * 1)(tg.value), (C.c_void_p * 1)(words_p.value + 8 * r)
+            assert lib.dflo_hip_set_deliver(e._h, area, 1, first, dst, fl) == 0, lib.dflo_hip_last_error(e._h)
+    n = 0
+    for dt in dts:
+        for rk in range(3):
+            area = (1 + n) & 1          # exchange n fills table (1 + n) & 1: never the one the engines read at that moment
+            for e in engs:
+                assert lib.dflo_hip_stage_open(e._h, rk, dt) == 0
+                assert lib.dflo_hip_stage_deliver(e._h, area, n + 1) == 0
+                assert lib.dflo_hip_stage_update_part(e._h, 0) == 0
+                assert lib.dflo_hip_stage_finish(e._h) == 0
+            for e in engs:
+                assert lib.dflo_hip_synchronize(e._h) == 0
+                assert lib.dflo_hip_use_ghost_traces(e._h, area) == 0
+            n += 1
+        for e in engs:
+            assert lib.dflo_hip_end_step(e._h) == 0
+    words = (C.c_uint64 * 2)()
+    assert hip.hipMemcpy(words, words_p, 16, 2) == 0 and hip.hipFree(words_p) == 0
+    assert words[0] == n and words[1] == n        # every exchange's number was published by the last delivering workgroup
+    u = np.empty((mesh.n_cells, ndof))
+    for sub, e in zip(parts, engs):
+        u[sub.global_ids[: sub.n_owned]] = e.current_solution.reshape(sub.n_cells, ndof)[: sub.n_owned]
+        e.close()
+    assert np.array_equal(u.reshape(-1), ref)
