@@ -292,6 +292,7 @@ struct dflo_hip_multi {
   int self_virtual = 1;
   // DFLO_RANK_TRANSPORT=ipc (see PeerMap): sequence words of this rank (fine-grained device memory), the peers' mappings, the
   // exchanges of each kind this rank has sent / expects (never reset: the words only grow), the wait kernels' failure word
+  bool created = false, fatal = false;              // create ran to its end; a device or transport failure has been seen (agree)
   bool ipc = false;
   std::vector<int> pend_from;  // fused: the wait for the traces of a step's last stage rides with the time step's wait kernel
   unsigned long long pend_seq = 0;
@@ -1175,6 +1176,9 @@ constexpr size_t kWindowBlock = 2u << 20;
 int alloc_flags(dflo_hip_multi *m) {
   Part &p = m->parts[0];
   MHIP(m, hipSetDevice(p.device));
+  // fine-grained, not uncached (hipDeviceMallocUncached): the protocol runs as well on uncached words, but an exported uncached
+  // block that is freed poisons the allocations of this process that follow (the first engine created after the driver computes a
+  // wrong state; leaking the block instead of freeing it: clean) -- profiles/LAB.md R5.15
   MHIP(m, hipExtMallocWithFlags(&m->win_sync, 2 * kWindowBlock, hipDeviceMallocFinegrained));
   MHIP(m, hipMemset(m->win_sync, 0, 2 * kWindowBlock));
   m->flags = (unsigned long long *)m->win_sync;
@@ -1351,6 +1355,7 @@ int agree(dflo_hip_multi *m, int rc) {
   if (!m->rank_mode || m->n_parts == 1) return rc;
   if (rc == DFLO_ERR_HIP || rc == DFLO_ERR_COMM || rc == DFLO_ERR_NOMEM) {
     if (m->comm && g_rccl.CommAbort) { g_rccl.CommAbort(m->comm); m->comm = nullptr; }
+    m->fatal = true;
     return rc;
   }
   // [0] negative mean state, [1] positivity root failure, [2] any other status (as a positive number: the maximum is the gravest)
@@ -1589,6 +1594,12 @@ int dflo_hip_multi_destroy(dflo_hip_multi_handle m) {
     if (g.C) hipStreamSynchronize(g.C);
     if (g.M) hipStreamSynchronize(g.M);
   }
+  // IPC transport: a neighbour's last launches may still be storing into this rank's windows (its time-step minimum and the word of
+  // the step that has just ended are awaited only by a next step) -- and a freed block goes back to the runtime's pool, from where
+  // the next allocation of this process takes it, still mapped by the neighbour.  Nobody frees before everybody's streams are idle.
+  // (not the cause of what R5.15 of profiles/LAB.md saw, but a hole all the same)
+  // (a collective like the create call: skipped where this rank has seen a failure -- its peers have been told or are lost anyway)
+  if (m->ipc && !m->self_halo && m->n_parts > 1 && m->created && !m->fatal && !(m->ipc_fail_host && *m->ipc_fail_host) && (m->comm || m->x_allreduce)) ipc_barrier(m);
   if (m->comm) g_rccl.CommDestroy(m->comm);
   if (!m->self_halo)
     for (PeerMap &pm : m->pmap)
@@ -1754,6 +1765,7 @@ static int create_rank_impl(const dflo_mesh_t *mesh, const dflo_params_t *params
   }
   finish_setup(m);
   if ((rc = setup_fused(m))) return bail(rc);
+  m->created = true;
   *out = m;
   return DFLO_OK;
 }
@@ -1821,6 +1833,7 @@ int dflo_hip_multi_create_self(const dflo_mesh_t *mesh, const dflo_params_t *par
   }
   finish_setup(m);
   if ((rc = setup_fused(m))) return bail(rc);
+  m->created = true;
   *out = m;
   return DFLO_OK;
 }

@@ -118,7 +118,8 @@ struct SendSegs {
 };
 __device__ __forceinline__ void seg_signal(const SendSegs &s) {
   if (!s.done) return;
-  __syncthreads();                     // the stores of this workgroup have been issued ...
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every wavefront's stores have left the compute unit before the barrier
+  __syncthreads();                     // ... of all of this workgroup's wavefronts ...
   if (threadIdx.x != 0) return;
   __threadfence_system();              // ... and are visible to the other devices
   if (atomicAdd(s.done, 1u) != gridDim.x - 1) return;

@@ -39,6 +39,14 @@ def worker(rank, world, port, ret):
         d, mesh = case["desc"], case["mesh"]
         if fm.ONLY and i not in fm.ONLY:   # FUZZ_CASES=88,92: only these (the generator still draws the others)
             continue
+        ref0 = None
+        if os.environ.get("FUZZ_REF_TWICE") and rank == 0:   # the single engine before the driver exists as well
+            one0 = dflo_amd.ConservationLaw(mesh, case["prm"])
+            try:
+                fm.setup(case, one0)
+                ref0 = fm.run(case, one0)
+            finally:
+                one0.close()
         try:
             claw = dflo_amd.MultiConservationLaw.for_rank_custom(mesh, case["prm"], 0, rank, world, xf, af, partitioner=d["partitioner"])
         except dflo_amd.DfloError as e:
@@ -53,6 +61,17 @@ def worker(rank, world, port, ret):
             own = claw.part_cells(0)[0]
         finally:
             claw.close()
+        if os.environ.get("FUZZ_REF_TWICE"):   # the single engine, three times, on every rank, right after the driver has gone
+            runs = []
+            for k in range(3):
+                o = dflo_amd.ConservationLaw(mesh, case["prm"])
+                try:
+                    fm.setup(case, o)
+                    runs.append(fm.run(case, o)["u"])
+                finally:
+                    o.close()
+            print("  rank %d: three single engines after the driver: %s%s" % (rank, ["same as the first" if np.array_equal(r, runs[0]) else "DIFFERENT %.2e" % fm.rel(r, runs[0]) for r in runs[1:]],
+                  "; first vs the one before: %s" % ("identical" if np.array_equal(runs[0], ref0["u"]) else "DIFFERENT %.2e" % fm.rel(runs[0], ref0["u"])) if ref0 is not None else ""), flush=True)
         parts = [None] * world
         dist.all_gather_object(parts, (own, got["u"].reshape(mesh.n_cells, -1)[own], got["stop"], got["dt"], got["t"]))
         if rank:
@@ -70,6 +89,9 @@ def worker(rank, world, port, ret):
             ref = fm.run(case, one)
         finally:
             one.close()
+        if ref0 is not None:
+            print("  single engine before / after the driver: %s; ranks vs the one before: %.3e" % (
+                "identical" if np.array_equal(ref0["u"], ref["u"]) else "DIFFERENT (%.3e)" % fm.rel(ref0["u"], ref["u"]), fm.rel(u, ref0["u"])), flush=True)
         k = "identical"
         if why is None:
             if ref["stop"] != got["stop"]:
@@ -93,6 +115,17 @@ def worker(rank, world, port, ret):
                     k = "identical" if max(e, edt, et) == 0.0 else "rounding (Pk)"
                     if not fa.all():
                         k = "nan"
+        if why and os.environ.get("FUZZ_WHERE"):   # which cells, whose, how far from a cut
+            du = np.abs(u.reshape(mesh.n_cells, -1) - ref["u"].reshape(mesh.n_cells, -1)).max(axis=1)
+            bad = np.nonzero(du > 0)[0]
+            owner = np.full(mesh.n_cells, -1)
+            for r, (o, *_rest) in enumerate(parts):
+                owner[o] = r
+            nb = np.asarray(mesh.neighbors)
+            on_cut = np.array([any(n >= 0 and owner[n] != owner[c] for n in nb[c]) for c in range(mesh.n_cells)])
+            print("  %d of %d cells differ; by owner %s; on a cut: %d of them (%d cells on a cut in all); largest %.3e at cell %d (owner %d, on cut %s); steps %d"
+                  % (len(bad), mesh.n_cells, np.bincount(owner[bad], minlength=world).tolist(), int(on_cut[bad].sum()), int(on_cut.sum()),
+                     du.max(), int(du.argmax()), owner[du.argmax()], bool(on_cut[du.argmax()]), len(got["dt"])), flush=True)
         if why:
             fails += 1
             k = "FAIL"
