@@ -429,6 +429,7 @@ int dflo_hip_multi_create_rank_custom(const dflo_mesh_t *mesh, const dflo_params
 typedef enum { DFLO_SELF_DIRECT = 0, DFLO_SELF_RCCL = 1, DFLO_SELF_COPY = 2, DFLO_SELF_IPC = 3 } dflo_self_transport;
 int dflo_hip_multi_create_self(const dflo_mesh_t *mesh, const dflo_params_t *params, int device_id, int n_virtual, int partitioner,
                                int transport, dflo_hip_multi_handle *out);
+/* One process per GPU with DFLO_RANK_TRANSPORT=ipc: collective (the ranks meet before anybody frees a window its neighbours map). */
 int dflo_hip_multi_destroy(dflo_hip_multi_handle m);
 const char *dflo_hip_multi_last_error(dflo_hip_multi_handle m); /* m may be NULL: error of the last failed create */
 int dflo_hip_multi_n_parts(dflo_hip_multi_handle m);            /* parts of the partition */
