@@ -307,6 +307,7 @@ struct dflo_hip_multi {
   unsigned long long *flags = nullptr;
   std::vector<PeerMap> pmap;
   unsigned long long ipc_post[4] = {0, 0, 0, 0}, ipc_arr[4] = {0, 0, 0, 0};
+  unsigned long long ipc_post_met[4] = {0, 0, 0, 0};   // ipc_post at the ranks' last barrier (destroy: has anything been stored into a neighbour since?)
   volatile int *ipc_fail_host = nullptr;
   int *ipc_fail = nullptr;
   ncclComm_t comm = nullptr;
@@ -1344,7 +1345,9 @@ int setup_fused(dflo_hip_multi *m) {
 int ipc_barrier(dflo_hip_multi *m) {
   if (!m->ipc || m->n_parts == 1) return DFLO_OK;
   double one = 1.0;
-  return host_allreduce(m, &one, 1, ncclSum);
+  const int rc = host_allreduce(m, &one, 1, ncclSum);
+  if (!rc) std::memcpy(m->ipc_post_met, m->ipc_post, sizeof(m->ipc_post_met));
+  return rc;
 }
 
 // One process per GPU: every rank leaves a call of the driver with the same status.  `rc` is what this rank found (a limiter
@@ -1599,7 +1602,9 @@ int dflo_hip_multi_destroy(dflo_hip_multi_handle m) {
   // the next allocation of this process takes it, still mapped by the neighbour.  Nobody frees before everybody's streams are idle.
   // (not the cause of what R5.15 of profiles/LAB.md saw, but a hole all the same)
   // (a collective like the create call: skipped where this rank has seen a failure -- its peers have been told or are lost anyway)
-  if (m->ipc && !m->self_halo && m->n_parts > 1 && m->created && !m->fatal && !(m->ipc_fail_host && *m->ipc_fail_host) && (m->comm || m->x_allreduce)) ipc_barrier(m);
+  if (m->ipc && !m->self_halo && m->n_parts > 1 && m->created && !m->fatal && !(m->ipc_fail_host && *m->ipc_fail_host) && (m->comm || m->x_allreduce) &&
+      std::memcmp(m->ipc_post_met, m->ipc_post, sizeof(m->ipc_post_met)) != 0)   // (a driver that has never sent anything -- some rank's create failed -- just leaves)
+    ipc_barrier(m);
   if (m->comm) g_rccl.CommDestroy(m->comm);
   if (!m->self_halo)
     for (PeerMap &pm : m->pmap)
