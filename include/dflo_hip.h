@@ -305,11 +305,6 @@ int dflo_hip_use_ghost_traces(dflo_hip_handle h, int which);
  * the buffers stay the caller's and must outlive the engine. */
 int dflo_hip_set_ghost_trace_buffers(dflo_hip_handle h, void *table0, void *table1);
 int dflo_hip_set_dt_table_buffer(dflo_hip_handle h, void *table);
-/* Pack and deliver in one kernel (several engines in one process): records [first[i], first[i+1]) of the send list are
- * written at dst[i] -- the receive area of the i-th peer, on this device or on another one reached over xGMI peer access --
- * instead of into a staging buffer that a copy per peer then moves.  kind: 0 whole cells ([ndof + 4] doubles per record,
- * as pack_send_cells), 1 cell averages ([4], as pack_send_avg), 2 face traces ([4 (k+1)], as pack_send_traces; the send
- * list is that of set_send_faces).  n_segments <= 16. */
 /* The next stage or limiter kernel this engine launches (stage_update_part / stage_limit_part) carries `event` (a hipEvent_t)
  * as its completion signal -- hipExtLaunchKernel's stopEvent -- instead of the caller recording the event behind it: one packet
  * less between two kernels of a stream (the multi-device schedule orders its two streams with one such event per phase).
@@ -349,6 +344,11 @@ int dflo_hip_limiter_walks_list(dflo_hip_handle h);
  * -- and wait for them; where the destinations are PLAIN device memory (of another process on this device: only a release writes
  * such stores back) every delivering workgroup also has to fence: plain = 1. */
 int dflo_hip_deliver_to_plain_memory(dflo_hip_handle h, int plain);
+/* Pack and deliver in one kernel (several engines in one process): records [first[i], first[i+1]) of the send list are
+ * written at dst[i] -- the receive area of the i-th peer, on this device or on another one reached over xGMI peer access --
+ * instead of into a staging buffer that a copy per peer then moves.  kind: 0 whole cells ([ndof + 4] doubles per record,
+ * as pack_send_cells), 1 cell averages ([4], as pack_send_avg), 2 face traces ([4 (k+1)], as pack_send_traces; the send
+ * list is that of set_send_faces).  n_segments <= 16. */
 int dflo_hip_pack_send_to(dflo_hip_handle h, int kind, int n_segments, const int32_t *first, void *const *dst);
 /* The same, and the kernel tells the receivers: once every record of the launch is visible system-wide, the workgroup that
  * finishes last stores `seq` (release, system scope) into the 64-bit words flags[i] -- sequence words in the receivers'
