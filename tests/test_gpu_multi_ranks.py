@@ -94,3 +94,48 @@ def test_random_configurations_on_two_ranks(transport):
                        capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "40 cases on 2 ranks, 0 failures" in r.stdout
+
+
+def _lifecycle_worker(rank, world, port, ret):
+    os.environ["DFLO_RANK_TRANSPORT"] = "ipc"
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, HERE)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    import time
+    import dflo_amd
+    import test_gpu_multi as T
+    from dflo_amd.gloo_transport import make_callbacks
+    xf, af = make_callbacks("cuda:0")
+    mesh, prm, ic = T._case("c2")
+    make = lambda: dflo_amd.MultiConservationLaw.for_rank_custom(mesh, prm, 0, rank, world, xf, af, partitioner="slab")
+    t0 = time.time()
+    make().close()                       # nothing has been sent: nobody waits for anybody (a rank whose peers' create failed must be able to leave)
+    ret["idle_close_%d" % rank] = time.time() - t0
+    states = []
+    for cycle in range(3):               # windows freed and allocated again while the neighbour is late: every run the same
+        claw = make()
+        T._setup(claw, mesh, ic)
+        got = T._run(claw, False)
+        own = claw.part_cells(0)[0]
+        states.append(got["u"].reshape(mesh.n_cells, -1)[own].copy())
+        if rank == (cycle & 1):
+            time.sleep(0.5)              # ... this rank's last launches and its close come late
+        claw.close()
+    ret["same_%d" % rank] = bool(all(np.array_equal(s, states[0]) for s in states[1:]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_driver_lifecycle_with_the_ipc_transport():
+    """dflo_hip_multi_destroy with exported windows: a driver that never sent anything closes without its peers; one that has run
+    meets its peers before it frees (a neighbour's last stores are awaited by nobody else), so that create / run / close cycles with a
+    late neighbour give the same bits every time."""
+    import random
+    mgr = mp.get_context("spawn").Manager()
+    ret = mgr.dict()
+    mp.spawn(_lifecycle_worker, args=(2, 29500 + random.randint(0, 2000), ret), nprocs=2, join=True)
+    assert ret["same_0"] and ret["same_1"], dict(ret)
+    assert ret["idle_close_0"] < 60 and ret["idle_close_1"] < 60, dict(ret)
