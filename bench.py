@@ -292,13 +292,18 @@ def run_case(args, world, rank, local_rank, uid, barrier):
         # ranks can share one GPU (RCCL refuses that) -- exercises this script's N > 1 path on a 1-GPU box; not a measurement
         from dflo_amd.gloo_transport import make_callbacks
         xf, af = make_callbacks("cuda:%d" % local_rank)
-        claw = dflo_amd.MultiConservationLaw.for_rank_custom(mesh, prm, local_rank, rank, world, xf, af, partitioner=part)
-    else:
+    if not args.self_halo:
         claw, why = None, ""
         try:
-            claw = dflo_amd.MultiConservationLaw.for_rank(mesh, prm, local_rank, rank, world, uid, partitioner=part)
-        except dflo_amd.DfloError as e:      # RCCL could not make the communicator on this node
+            if uid == "gloo":
+                claw = dflo_amd.MultiConservationLaw.for_rank_custom(mesh, prm, local_rank, rank, world, xf, af, partitioner=part)
+            else:
+                claw = dflo_amd.MultiConservationLaw.for_rank(mesh, prm, local_rank, rank, world, uid, partitioner=part)
+        except dflo_amd.DfloError as e:      # RCCL could not make the communicator on this node / a neighbour's window could not be mapped
             why = str(e)
+        if claw is not None and uid == "gloo" and os.environ.get("DFLO_RANK_TRANSPORT") == "ipc" and os.environ.get("DFLO_BENCH_TEST_FAIL_CREATE") == str(rank):
+            claw.close()   # test hook (tests/test_gpu_driver.py): the IPC set-up "fails" on this one rank after its peers' has succeeded
+            claw, why = None, "test hook: create failed on rank %d" % rank
         if world > 1:   # all ranks take the same road: this transport only if every rank has its communicator / its mappings
             import torch.distributed as dist
             ok = torch.tensor([1 if claw is not None else 0])
