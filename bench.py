@@ -687,11 +687,13 @@ def main():
     if world == 1:
         best = measure(args, "none")
     else:
-        # ipc_gloo first: it needs nothing but the rendezvous that is already up (no RCCL call anywhere), so its line is safe before the
-        # transport north_star names is tried; then rccl; then "ipc", the same IPC transport set up over an RCCL communicator -- its two
-        # host-side reductions per advance() (first time step, agreed status) are RCCL calls instead of host-staged gloo ones, which
-        # shows in a run as short as the strong-scaling one
-        order = os.environ.get("DFLO_BENCH_TRANSPORTS", "gloo" if os.environ.get("DFLO_BENCH_TRANSPORT") == "gloo" else "ipc_gloo,rccl,ipc,gloo").split(",")
+        # rccl first -- the transport north_star names and the stack this node is prepared for: once it has run, its line is safe whatever
+        # the attempts behind it do short of killing the process (a hang costs only itself: arm()).  Then ipc_gloo, the IPC transport set
+        # up over the rendezvous that is already there (no RCCL call anywhere; never run across two devices before the first SCALE
+        # run: the likelier one to stall), then "ipc", the same transport set up over an RCCL communicator -- its two host-side
+        # reductions per advance() (first time step, agreed status) are RCCL calls instead of host-staged gloo ones, which shows in a run
+        # as short as the strong-scaling one
+        order = os.environ.get("DFLO_BENCH_TRANSPORTS", "gloo" if os.environ.get("DFLO_BENCH_TRANSPORT") == "gloo" else "rccl,ipc_gloo,ipc,gloo").split(",")
         for t in order:
             if t == "gloo" and any(r["ok"] for r in attempts) and os.environ.get("DFLO_BENCH_ALL_TRANSPORTS") != "1":
                 continue   # fallbacks
