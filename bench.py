@@ -693,10 +693,10 @@ def main():
         # run: the likelier one to stall), then "ipc", the same transport set up over an RCCL communicator -- its two host-side
         # reductions per advance() (first time step, agreed status) are RCCL calls instead of host-staged gloo ones, which shows in a run
         # as short as the strong-scaling one
-        order = os.environ.get("DFLO_BENCH_TRANSPORTS", "gloo" if os.environ.get("DFLO_BENCH_TRANSPORT") == "gloo" else "rccl,ipc_gloo,ipc,gloo").split(",")
+        order = os.environ.get("DFLO_BENCH_TRANSPORTS", "gloo" if os.environ.get("DFLO_BENCH_TRANSPORT") == "gloo" else "rccl,gloo,ipc_gloo,ipc").split(",")
         for t in order:
             if t == "gloo" and any(r["ok"] for r in attempts) and os.environ.get("DFLO_BENCH_ALL_TRANSPORTS") != "1":
-                continue   # fallbacks
+                continue   # the host-staged fallback: only where RCCL has not given a line -- and then BEFORE the IPC attempts, so that one of those stalling finds a line to print
             if t == "ipc" and not any(r["ok"] and r["transport"] == "rccl" for r in attempts) and "DFLO_BENCH_TRANSPORTS" not in os.environ:
                 continue   # (the IPC transport set up over an RCCL communicator: only where RCCL has just been seen to work)
             arm(attempt_s, "transport " + t)
