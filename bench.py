@@ -382,6 +382,8 @@ def main():
     ap.add_argument("--no-tvb", action="store_true", help="c4 only: positivity limiter alone (BASELINE config 4 as written)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak (default): every GPU gets the one-GPU mesh; strong: the one-GPU mesh (c4: the full 4001x1000) is cut into N parts")
+    ap.add_argument("--child-transport", default="", help=argparse.SUPPRESS)   # (internal) this process is one rank of an isolated attempt
+    ap.add_argument("--child-out", default="", help=argparse.SUPPRESS)
     ap.add_argument("--config", default="c2", choices=["c2", "c3", "c4", "c5"],
                     help="c2 (default, the headline): periodic vortex; c3: Sod tube 2048x256 Q1 Roe TVB+positivity; "
                          "c4: double Mach reflection, 500 N + 1 columns of 1000 squares, Q2 HLLC TVB+positivity; "
@@ -514,6 +516,63 @@ def main():
         return {"transport": transport, "ok": ok, "check": check, "m": m, "sec": sec, "per_rank": per_rank, "n_rk": n_rk,
                 "value": m["n_dofs_total"] * n_rk * a.steps / sec / 1e6}
 
+    if args.child_transport:   # one rank of an isolated attempt (measure_isolated below): run it, leave the result where the parent reads it
+        import pickle
+        if os.environ.get("DFLO_BENCH_TEST_CRASH") == args.child_transport and rank == world - 1:
+            os.abort()   # test hook: the attempt kills a rank the way a GPU memory fault would (tests/test_gpu_driver.py)
+        res = measure(args, args.child_transport)
+        with open(args.child_out + ".tmp", "wb") as f:
+            pickle.dump(res, f)
+        os.replace(args.child_out + ".tmp", args.child_out)
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+        return
+
+    iso = {"n": 0}
+
+    def measure_isolated(a, transport, seconds):
+        """The IPC transport has never run across two devices before the first SCALE run: its attempts run in CHILD processes (one per
+        rank, their own rendezvous on another port), so that one that takes a process down -- a memory fault on a mapped window ends
+        the process that caused it -- costs that attempt and not the line RCCL has already given.  The child runs measure() as it
+        stands and leaves the reduced result in a file; a child that dies, or outlives its deadline, is a failed attempt."""
+        if world == 1 or not transport.startswith("ipc") or os.environ.get("DFLO_BENCH_ISOLATE") == "0":
+            return measure(a, transport)
+        import pickle
+        import subprocess
+        import tempfile
+        import torch.distributed as dist
+        iso["n"] += 1
+        out = os.path.join(tempfile.gettempdir(), "dflo_bench_%s_%d_%d.pkl" % (os.environ.get("MASTER_PORT", "0"), iso["n"], rank))
+        env = dict(os.environ)
+        env["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29517")) + 7 * iso["n"] + 1)
+        for k in list(env):   # the children make their own rendezvous: rank 0's child hosts the store, not the launcher's agent
+            if k.startswith("TORCHELASTIC") or k in ("TORCH_NCCL_ASYNC_ERROR_HANDLING",):
+                env.pop(k)
+        cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:] + [
+            "--steps", str(a.steps), "--warmup", str(a.warmup), "--scaling", a.scaling, "--child-transport", transport, "--child-out", out]
+        res, why = None, ""
+        try:
+            r = subprocess.run(cmd, env=env, timeout=max(30.0, seconds - 20.0), stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)
+            if r.returncode == 0 and os.path.exists(out):
+                with open(out, "rb") as f:
+                    res = pickle.load(f)
+            else:
+                why = "the isolated attempt's rank %d ended with status %d: %s" % (rank, r.returncode, (r.stderr or "")[-300:].replace("\n", " | "))
+        except subprocess.TimeoutExpired:
+            why = "the isolated attempt's rank %d did not return within %.0f s" % (rank, max(30.0, seconds - 20.0))
+        finally:
+            if os.path.exists(out):
+                os.remove(out)
+        ok = torch.tensor([0 if res is None else 1])
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:
+            whys = [None] * world
+            dist.all_gather_object(whys, why)
+            return {"transport": transport, "ok": False, "check": "failed: " + ("; ".join(w for w in whys if w) or (res or {}).get("check", "")), "value": 0.0}
+        res["isolated"] = True
+        return res
+
     def build_line(best, strong, note=None):
         """the JSON line (rank 0) from the run that won and whatever else has been measured so far"""
         m, sec, per_rank, n_rk, check = best["m"], best["sec"], best["per_rank"], best["n_rk"], best["check"]
@@ -572,7 +631,8 @@ def main():
                 "transport_used": best["transport"],
                 "transports": [{"transport": r["transport"], "ok": r["ok"], "value": round(r["value"], 1), "check": r["check"],
                                 "ms_per_step": round(r["sec"] / args.steps * 1e3, 4) if r.get("sec") else None,
-                                "exchange_wait_us": [round(x["exchange_us"], 1) for x in r["per_rank"]] if r.get("per_rank") else None}
+                                "exchange_wait_us": [round(x["exchange_us"], 1) for x in r["per_rank"]] if r.get("per_rank") else None,
+                                "in_child_processes": bool(r.get("isolated"))}   # (the IPC transport's attempts: measure_isolated)
                                for r in attempts] or None,
                 "env": {k: v for k, v in sorted(os.environ.items())
                         if k.startswith(("NCCL_", "RCCL_", "HSA_ENABLE_", "DFLO_", "HIP_VISIBLE", "ROCR_VISIBLE", "GPU_MAX_HW"))},
@@ -700,7 +760,7 @@ def main():
             if t == "ipc" and not any(r["ok"] and r["transport"] == "rccl" for r in attempts) and "DFLO_BENCH_TRANSPORTS" not in os.environ:
                 continue   # (the IPC transport set up over an RCCL communicator: only where RCCL has just been seen to work)
             arm(attempt_s, "transport " + t)
-            attempts.append(measure(args, t))
+            attempts.append(measure_isolated(args, t, attempt_s))
         arm(None, None)
         good = [r for r in attempts if r["ok"]]
         if not good:
@@ -715,7 +775,7 @@ def main():
         a2 = copy.copy(args)
         a2.scaling, a2.steps, a2.warmup = "strong", min(args.steps, 20), min(args.warmup, 5)
         arm(attempt_s, "strong-scaling run over " + best["transport"])
-        strong = measure(a2, best["transport"])
+        strong = measure_isolated(a2, best["transport"], attempt_s)
         strong["steps"], strong["warmup"] = a2.steps, a2.warmup
         state["strong"] = strong
         arm(None, None)

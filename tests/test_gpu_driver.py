@@ -566,6 +566,26 @@ def test_bench_line_survives_a_transport_that_hangs():
     assert "did not return within" in out.stderr
 
 
+def test_bench_line_survives_an_ipc_attempt_that_kills_a_process():
+    """the IPC transport's attempts run in child processes of the ranks: one that takes a process down (os.abort() here; a memory fault
+    on a mapped window on a real node) is a failed attempt, and the line comes from the transport that ran before it"""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(29700 + os.getpid() % 90), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--nx", "128"]
+    env = dict(os.environ, DFLO_BENCH_TRANSPORTS="gloo,ipc_gloo", DFLO_BENCH_ALL_TRANSPORTS="1", DFLO_BENCH_ONE_GPU="1", DFLO_BENCH_TEST_CRASH="ipc_gloo",
+               DFLO_BENCH_ATTEMPT_S="120", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=400, cwd=root, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["config"]["transport_used"] == "gloo" and d["value"] > 0
+    tried = {t["transport"]: t for t in d["config"]["transports"]}
+    assert not tried["ipc_gloo"]["ok"] and "isolated attempt" in tried["ipc_gloo"]["check"], tried
+
+
 def test_bench_line_survives_a_transport_one_rank_cannot_set_up():
     """the first transport of the N > 1 order (IPC over the gloo rendezvous) cannot be set up on ONE rank -- a neighbour's window that
     does not map -- while its peers' set-up has succeeded: the ranks agree on that before anybody goes on, the peers close their drivers
