@@ -542,6 +542,8 @@ def main():
         import subprocess
         import tempfile
         import torch.distributed as dist
+        if iso.get("stalled"):   # (decided by all ranks together, below)
+            return {"transport": transport, "ok": False, "check": "skipped: the isolated attempt before it did not return", "value": 0.0}
         iso["n"] += 1
         out = os.path.join(tempfile.gettempdir(), "dflo_bench_%s_%d_%d.pkl" % (os.environ.get("MASTER_PORT", "0"), iso["n"], rank))
         env = dict(os.environ)
@@ -551,7 +553,7 @@ def main():
                 env.pop(k)
         cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:] + [
             "--steps", str(a.steps), "--warmup", str(a.warmup), "--scaling", a.scaling, "--child-transport", transport, "--child-out", out]
-        res, why = None, ""
+        res, why, stalled = None, "", 0
         try:
             r = subprocess.run(cmd, env=env, timeout=max(30.0, seconds - 20.0), stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)
             if r.returncode == 0 and os.path.exists(out):
@@ -561,6 +563,7 @@ def main():
                 why = "the isolated attempt's rank %d ended with status %d: %s" % (rank, r.returncode, (r.stderr or "")[-300:].replace("\n", " | "))
         except subprocess.TimeoutExpired:
             why = "the isolated attempt's rank %d did not return within %.0f s" % (rank, max(30.0, seconds - 20.0))
+            stalled = 1
         finally:
             if os.path.exists(out):
                 os.remove(out)
@@ -568,7 +571,9 @@ def main():
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         if int(ok.item()) == 0:
             whys = [None] * world
-            dist.all_gather_object(whys, why)
+            dist.all_gather_object(whys, (why, stalled))
+            iso["stalled"] = any(w[1] for w in whys)   # one stalled attempt is enough: the IPC attempts behind it are not tried (the run stays within minutes)
+            whys = [w[0] for w in whys]
             return {"transport": transport, "ok": False, "check": "failed: " + ("; ".join(w for w in whys if w) or (res or {}).get("check", "")), "value": 0.0}
         res["isolated"] = True
         return res

@@ -586,6 +586,27 @@ def test_bench_line_survives_an_ipc_attempt_that_kills_a_process():
     assert not tried["ipc_gloo"]["ok"] and "isolated attempt" in tried["ipc_gloo"]["check"], tried
 
 
+def test_bench_line_survives_an_ipc_attempt_that_stalls():
+    """... and one that never returns is ended at its own deadline (not the run's), the IPC attempts behind it are not tried, and the
+    line comes from the transport that ran before"""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(29400 + os.getpid() % 90), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--nx", "128"]
+    env = dict(os.environ, DFLO_BENCH_TRANSPORTS="gloo,ipc_gloo,ipc_coarse", DFLO_BENCH_ALL_TRANSPORTS="1", DFLO_BENCH_ONE_GPU="1", DFLO_BENCH_TEST_HANG="ipc_gloo",
+               DFLO_BENCH_ATTEMPT_S="55", DFLO_BENCH_NO_STRONG="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=400, cwd=root, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["config"]["transport_used"] == "gloo" and d["value"] > 0
+    tried = {t["transport"]: t for t in d["config"]["transports"]}
+    assert not tried["ipc_gloo"]["ok"] and "did not return within" in tried["ipc_gloo"]["check"], tried
+    assert not tried["ipc_coarse"]["ok"] and "skipped" in tried["ipc_coarse"]["check"], tried
+
+
 def test_bench_line_survives_a_transport_one_rank_cannot_set_up():
     """the first transport of the N > 1 order (IPC over the gloo rendezvous) cannot be set up on ONE rank -- a neighbour's window that
     does not map -- while its peers' set-up has succeeded: the ranks agree on that before anybody goes on, the peers close their drivers
