@@ -532,18 +532,19 @@ def main():
     iso = {"n": 0}
 
     def measure_isolated(a, transport, seconds):
-        """The IPC transport has never run across two devices before the first SCALE run: its attempts run in CHILD processes (one per
+        """No transport has run across two devices before the first SCALE run: for N > 1 every attempt runs in CHILD processes (one per
         rank, their own rendezvous on another port), so that one that takes a process down -- a memory fault on a mapped window ends
-        the process that caused it -- costs that attempt and not the line RCCL has already given.  The child runs measure() as it
-        stands and leaves the reduced result in a file; a child that dies, or outlives its deadline, is a failed attempt."""
-        if world == 1 or not transport.startswith("ipc") or os.environ.get("DFLO_BENCH_ISOLATE") == "0":
+        the process that caused it -- or stalls inside a library costs that attempt and not the run: these ranks only start the
+        children, read their results and agree among themselves.  The child runs measure() as it stands and leaves the reduced result
+        in a file; a child that dies, or outlives its deadline, is a failed attempt."""
+        if world == 1 or os.environ.get("DFLO_BENCH_ISOLATE") == "0":
             return measure(a, transport)
         import pickle
         import subprocess
         import tempfile
         import torch.distributed as dist
-        if iso.get("stalled"):   # (decided by all ranks together, below)
-            return {"transport": transport, "ok": False, "check": "skipped: the isolated attempt before it did not return", "value": 0.0}
+        if transport.startswith("ipc") and iso.get("stalled"):   # (decided by all ranks together, below)
+            return {"transport": transport, "ok": False, "check": "skipped: the IPC attempt before it did not return", "value": 0.0}
         iso["n"] += 1
         out = os.path.join(tempfile.gettempdir(), "dflo_bench_%s_%d_%d.pkl" % (os.environ.get("MASTER_PORT", "0"), iso["n"], rank))
         env = dict(os.environ)
@@ -555,14 +556,14 @@ def main():
             "--steps", str(a.steps), "--warmup", str(a.warmup), "--scaling", a.scaling, "--child-transport", transport, "--child-out", out]
         res, why, stalled = None, "", 0
         try:
-            r = subprocess.run(cmd, env=env, timeout=max(30.0, seconds - 20.0), stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)
+            r = subprocess.run(cmd, env=env, timeout=max(10.0, seconds - 20.0), stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)
             if r.returncode == 0 and os.path.exists(out):
                 with open(out, "rb") as f:
                     res = pickle.load(f)
             else:
                 why = "the isolated attempt's rank %d ended with status %d: %s" % (rank, r.returncode, (r.stderr or "")[-300:].replace("\n", " | "))
         except subprocess.TimeoutExpired:
-            why = "the isolated attempt's rank %d did not return within %.0f s" % (rank, max(30.0, seconds - 20.0))
+            why = "the isolated attempt's rank %d did not return within %.0f s" % (rank, max(10.0, seconds - 20.0))
             stalled = 1
         finally:
             if os.path.exists(out):
@@ -572,7 +573,8 @@ def main():
         if int(ok.item()) == 0:
             whys = [None] * world
             dist.all_gather_object(whys, (why, stalled))
-            iso["stalled"] = any(w[1] for w in whys)   # one stalled attempt is enough: the IPC attempts behind it are not tried (the run stays within minutes)
+            if transport.startswith("ipc"):
+                iso["stalled"] = any(w[1] for w in whys)   # one stalled IPC attempt is enough: those behind it are not tried (the run stays within minutes)
             whys = [w[0] for w in whys]
             return {"transport": transport, "ok": False, "check": "failed: " + ("; ".join(w for w in whys if w) or (res or {}).get("check", "")), "value": 0.0}
         res["isolated"] = True
@@ -748,7 +750,7 @@ def main():
         state["timer"].daemon = True
         state["timer"].start()
 
-    attempt_s = float(os.environ.get("DFLO_BENCH_ATTEMPT_S", 900 if args.config == "c5" else 300))
+    attempt_s = float(os.environ.get("DFLO_BENCH_ATTEMPT_S", 900 if args.config == "c5" else 240))
     if world == 1:
         best = measure(args, "none")
     else:

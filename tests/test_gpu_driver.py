@@ -547,15 +547,34 @@ def test_bench_self_halo_line(transport, extra):
 
 def test_bench_line_survives_a_transport_that_hangs():
     """a transport that never returns (a collective stalled inside a library) must not cost the line of the transports that ran
-    before it: every attempt has a deadline, after which rank 0 prints what has been measured, says which attempt hung, and
-    every rank leaves"""
+    before it -- nor the attempts behind it: it runs in child processes of the ranks, which end it at its deadline"""
     import json
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(29900 + os.getpid() % 90), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--nx", "128"]
     env = dict(os.environ, DFLO_BENCH_TRANSPORTS="ipc_gloo,gloo", DFLO_BENCH_ALL_TRANSPORTS="1", DFLO_BENCH_ONE_GPU="1", DFLO_BENCH_TEST_HANG="gloo",
-               DFLO_BENCH_ATTEMPT_S="25", HSA_ENABLE_IPC_MODE_LEGACY="0")
+               DFLO_BENCH_ATTEMPT_S="60", DFLO_BENCH_NO_STRONG="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=root, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["config"]["transport_used"] == "ipc_gloo" and d["value"] > 0
+    tried = {t["transport"]: t for t in d["config"]["transports"]}
+    assert not tried["gloo"]["ok"] and "did not return within" in tried["gloo"]["check"], tried
+
+
+def test_bench_line_survives_a_hang_outside_the_child_processes():
+    """with the isolation off (DFLO_BENCH_ISOLATE=0) the ranks run the attempts themselves: the run's own watchdog then ends a stalled one,
+    rank 0 prints what has been measured and says which attempt hung"""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(29300 + os.getpid() % 90), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--nx", "128"]
+    env = dict(os.environ, DFLO_BENCH_TRANSPORTS="ipc_gloo,gloo", DFLO_BENCH_ALL_TRANSPORTS="1", DFLO_BENCH_ONE_GPU="1", DFLO_BENCH_TEST_HANG="gloo",
+               DFLO_BENCH_ATTEMPT_S="25", DFLO_BENCH_ISOLATE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=root, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
