@@ -122,8 +122,12 @@ def live_traffic(args):
     rocprofv3, FETCH_SIZE and WRITE_SIZE each in its own pass (they cannot share one), no trace domain beside the counters;
     values in KiB, FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md (calibrated against a known stream in
     profiles/r02/hbm_calibration.json).  The mean over every stage-kernel dispatch of the counted steps, i.e. first and later
-    stages in the mix of a time step, like `roofline.achieved`.  Returns (bytes, source) or None when rocprofv3 is missing / fails
-    -- the caller then falls back to the constant of profiles/traffic.json and says so."""
+    stages in the mix of a time step, like `roofline.achieved`.  A third pass of the same kind counts what the instruction side
+    did (north_star: "MFMA utilisation"): SQ_VALU_MFMA_BUSY_CYCLES, SQ_ACTIVE_INST_VALU and GRBM_GUI_ACTIVE give
+    mfma_util = MFMA-busy cycles / (kernel cycles x 1024 SIMDs) and valu_busy = VALU-active cycles / 256 CUs / kernel cycles (the
+    profiler's own MfmaUtil / VALUBusy expressions, rocprofv3 --list-avail).
+    Returns (bytes, source, extra) or None when rocprofv3 is missing / fails -- the caller then falls back to the constant of
+    profiles/traffic.json and says so."""
     import csv
     import glob
     import shutil
@@ -136,18 +140,38 @@ def live_traffic(args):
            "--no-live-traffic", "--config", args.config, "--nx", str(args.nx), "--degree", str(args.degree), "--flux", args.flux,
            "--basis", args.basis, "--scaling", args.scaling, "--parts-per-gpu", str(args.parts_per_gpu)] + (["--no-tvb"] if args.no_tvb else [])
     env = dict(os.environ, TMPDIR="/tmp", DFLO_BENCH_NO_PREHEAT="1")
-    kib = {}
+    kib, extra = {}, {}
+
+    def one_pass(d, tag, counters):
+        out = os.path.join(d, tag)
+        subprocess.run([exe, "--pmc"] + counters + ["--kernel-include-regex", "stage_kernel", "-d", out, "-o", tag, "-f", "csv", "--"] + cmd,
+                       cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=150, check=True)
+        v = {c: [] for c in counters}
+        for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+            for r in csv.DictReader(open(f)):
+                if r["Counter_Name"] in v and "stage_kernel" in r["Kernel_Name"]:
+                    v[r["Counter_Name"]].append(float(r["Counter_Value"]))
+        return v
+
     try:
         with tempfile.TemporaryDirectory(dir="/tmp") as d:
             for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
-                out = os.path.join(d, ctr)
-                subprocess.run([exe, "--pmc", ctr, "--kernel-include-regex", "stage_kernel", "-d", out, "-o", ctr, "-f", "csv", "--"] + cmd,
-                               cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=150, check=True)
-                v = [float(r["Counter_Value"]) for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
-                     for r in csv.DictReader(open(f)) if r["Counter_Name"] == ctr and "stage_kernel" in r["Kernel_Name"]]
+                v = one_pass(d, ctr, [ctr])[ctr]
                 if not v:
                     return None
                 kib[ctr] = (sum(v) / len(v), len(v))
+            try:   # the instruction side: never at the price of the traffic figure
+                v = one_pass(d, "SQ", ["SQ_VALU_MFMA_BUSY_CYCLES", "SQ_INSTS_VALU_MFMA_MOPS_F64", "SQ_ACTIVE_INST_VALU", "GRBM_GUI_ACTIVE"])
+                if all(v.values()):
+                    m = {k: sum(x) / len(x) for k, x in v.items()}
+                    extra = {"mfma_util": m["SQ_VALU_MFMA_BUSY_CYCLES"] / (m["GRBM_GUI_ACTIVE"] * 1024.0),
+                             "valu_busy": m["SQ_ACTIVE_INST_VALU"] / 256.0 / m["GRBM_GUI_ACTIVE"],
+                             "mfma_mops_f64_per_launch": m["SQ_INSTS_VALU_MFMA_MOPS_F64"],
+                             "pipes_source": "live: rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE, "
+                                             "mean of %d stage-kernel dispatches; mfma_util = MFMA busy cycles / (GRBM_GUI_ACTIVE x 1024 SIMDs), "
+                                             "valu_busy = SQ_ACTIVE_INST_VALU / 256 CUs / GRBM_GUI_ACTIVE" % len(v["GRBM_GUI_ACTIVE"])}
+            except Exception as e:   # noqa: BLE001
+                print("bench.py: live pipe counters not collected (%s: %s)" % (type(e).__name__, str(e)[:200]), file=sys.stderr, flush=True)
     except Exception as e:   # noqa: BLE001 -- a profiler that is absent, refuses or times out must not cost the bench line
         print("bench.py: live PMC traffic not collected (%s: %s)" % (type(e).__name__, str(e)[:200]), file=sys.stderr, flush=True)
         return None
@@ -155,7 +179,7 @@ def live_traffic(args):
     return total, ("live: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, no trace domain) around a 2 + 6 step run of "
                    "this command (its two warm-up steps included), launched by this run; mean of %d / %d stage-kernel dispatches; "
                    "FETCH_SIZE x2 per the gfx950 correction"
-                   % (kib["FETCH_SIZE"][1], kib["WRITE_SIZE"][1]))
+                   % (kib["FETCH_SIZE"][1], kib["WRITE_SIZE"][1])), extra
 
 
 def _timing_interval(steps, n_rk):
@@ -266,7 +290,7 @@ def run_parts(args, claw, mesh, ic, bc_fn, programs, nx, ny):
     xus, xn = claw.exchange_timing(False)
     a = claw.cell_average
     pr = 0.4 * (a[:, 3] - 0.5 * (a[:, 0] ** 2 + a[:, 1] ** 2) / a[:, 2])
-    return {"sec": sec, "kernel_ms": kernel_ms, "n_launch": n_launch, "n_dofs_total": mesh.n_cells * mesh.ndof,
+    return {"sec": sec, "kernel_ms": kernel_ms, "n_launch": n_launch, "n_dofs_total": mesh.n_cells * mesh.ndof, "uses_mfma": claw.uses_mfma,
             "comm": claw.comm_info(), "exchange_us": xus, "exchange_n": xn,
             "n_dofs_launch": mesh.n_cells * mesh.ndof // args.parts_per_gpu, "mass0": mass0, "mass1": a.sum(axis=0), "nx": nx, "ny": ny,
             "n_cells": mesh.n_cells, "n_rk": claw.n_rk, "min_rho": float(a[:, 2].min()), "min_p": float(pr.min())}
@@ -344,7 +368,7 @@ def run_case(args, world, rank, local_rank, uid, barrier):
     xus, xn = claw.exchange_timing(False)
     a = claw.cell_average[own]
     pos_stats = claw.positivity_stats()
-    res = {"comm": claw.comm_info(), "exchange_us": xus, "exchange_n": xn, "pos_stats": pos_stats, "sec": sec, "kernel_ms": kernel_ms, "n_launch": n_launch, "n_dofs_total": mesh.n_cells * mesh.ndof,
+    res = {"comm": claw.comm_info(), "uses_mfma": claw.uses_mfma, "exchange_us": xus, "exchange_n": xn, "pos_stats": pos_stats, "sec": sec, "kernel_ms": kernel_ms, "n_launch": n_launch, "n_dofs_total": mesh.n_cells * mesh.ndof,
            "n_dofs_launch": claw.n_owned_dofs, "mass0": mass0, "mass1": a.sum(axis=0), "nx": nx, "ny": ny,
            "n_cells": mesh.n_cells, "n_rk": claw.n_rk}
     pr = 0.4 * (a[:, 3] - 0.5 * (a[:, 0] ** 2 + a[:, 1] ** 2) / a[:, 2])
@@ -514,6 +538,7 @@ def main():
                 check += "; %.4f %% of this rank's cell-stages went through the positivity limiter proper, %.4f %% were changed by it" % (
                     100.0 * m["pos_stats"][0] / ncs, 100.0 * m["pos_stats"][1] / ncs)
         return {"transport": transport, "ok": ok, "check": check, "m": m, "sec": sec, "per_rank": per_rank, "n_rk": n_rk,
+                "totals": [float(x) for x in mm],   # conserved totals before / after, -min density, -min pressure, reduced over the ranks
                 "value": m["n_dofs_total"] * n_rk * a.steps / sec / 1e6}
 
     if args.child_transport:   # one rank of an isolated attempt (measure_isolated below): run it, leave the result where the parent reads it
@@ -590,7 +615,7 @@ def main():
         bytes_per_update = 24.0
         kernel_ms = m["kernel_ms"]
         achieved = m["n_dofs_launch"] * bytes_per_update / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
-        traffic, traffic_src = None, None
+        traffic, traffic_src, pipes = None, None, {}
         tf = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tf):
             try:
@@ -604,7 +629,7 @@ def main():
             lt = live_traffic(args)
             if lt is not None:
                 file_traffic = traffic
-                traffic, traffic_src = lt
+                traffic, traffic_src, pipes = lt
                 if file_traffic:
                     traffic_src += "; profiles/traffic.json holds %.4e for this configuration" % file_traffic
         nx, ny = m["nx"], m["ny"]
@@ -639,6 +664,7 @@ def main():
                 "transports": [{"transport": r["transport"], "ok": r["ok"], "value": round(r["value"], 1), "check": r["check"],
                                 "ms_per_step": round(r["sec"] / args.steps * 1e3, 4) if r.get("sec") else None,
                                 "exchange_wait_us": [round(x["exchange_us"], 1) for x in r["per_rank"]] if r.get("per_rank") else None,
+                                "validated": r.get("validated"),   # IPC attempts: held to a transport whose exchange is a library call (cross_validate)
                                 "in_child_processes": bool(r.get("isolated"))}   # (the IPC transport's attempts: measure_isolated)
                                for r in attempts] or None,
                 "env": {k: v for k, v in sorted(os.environ.items())
@@ -665,6 +691,12 @@ def main():
                 # the whole step priced the same way (everything between two steps: all stage kernels, limiter passes, reductions,
                 # boundary programs, gaps): value x 24 B / 8 TB/s
                 "step_frac": value * 1e6 * bytes_per_update / (8.0e12 * world),
+                # north_star: "MFMA utilisation is given": does this run's stage kernel use matrix instructions (degree 3 with DFLO_MFMA=1;
+                # the default is the vector units, which measured faster: fp64 matrix instructions hold the vector issue port on this part,
+                # tools/mfma_f64_16x16_probe.hip) and what the counters saw of the two pipes (None where they were not collected)
+                "mfma": bool(m.get("uses_mfma")),
+                "mfma_util": pipes.get("mfma_util"), "valu_busy": pipes.get("valu_busy"),
+                "mfma_mops_f64_per_launch": pipes.get("mfma_mops_f64_per_launch"), "pipes_source": pipes.get("pipes_source"),
             },
         }
         if world == 1 and args.config == "c2" and not args.no_secondary and not args.self_halo and (args.degree, args.flux) != (1, "lxf"):
@@ -750,6 +782,32 @@ def main():
         state["timer"].daemon = True
         state["timer"].start()
 
+    def cross_validate(atts, config):
+        """The IPC transport rests on hand-made coherence that has never met two devices, and outside the periodic box an attempt's own
+        check is only "finite and admissible": a run that read stale halos would pass it and, being faster, become `value`.  Every
+        transport computes the same run (the tests hold them bit-identical), so an IPC attempt counts only if its reduced totals --
+        the conserved sums after the run, the minimum density and pressure -- are those of a transport whose exchange is a library
+        call (rccl, else the host-staged gloo run) to 1e-11; with no such reference it counts only where its own check is a real one
+        (c2: the conserved totals of the periodic box to 1e-10)."""
+        ref = next((r for r in atts if r["ok"] and r["transport"] == "rccl"), None) or next((r for r in atts if r["ok"] and r["transport"] == "gloo"), None)
+        for r in atts:
+            if not r["ok"] or not r["transport"].startswith("ipc"):
+                continue
+            if ref is None:
+                if config != "c2":
+                    r["ok"] = False
+                    r["check"] += "; NOT COUNTED: no reference transport (rccl / gloo) completed to hold this run's totals against"
+                else:
+                    r["validated"] = "no reference transport completed: held by its own conservation check only"
+                continue
+            a, b = np.array(r["totals"]), np.array(ref["totals"])
+            dev = float(np.abs(a[4:] - b[4:]).max() / max(np.abs(b[4:8]).max(), 1e-300))
+            if not (np.isfinite(a).all() and dev <= 1e-11):
+                r["ok"] = False
+                r["check"] += "; NOT COUNTED: totals after the run differ from the %s run's by %.1e (relative)" % (ref["transport"], dev)
+            else:
+                r["validated"] = "totals after the run equal the %s run's to %.1e (relative)" % (ref["transport"], dev)
+
     attempt_s = float(os.environ.get("DFLO_BENCH_ATTEMPT_S", 900 if args.config == "c5" else 240))
     if world == 1:
         best = measure(args, "none")
@@ -769,6 +827,7 @@ def main():
             arm(attempt_s, "transport " + t)
             attempts.append(measure_isolated(args, t, attempt_s))
         arm(None, None)
+        cross_validate(attempts, args.config)
         good = [r for r in attempts if r["ok"]]
         if not good:
             raise SystemExit("bench.py: no transport produced a valid run: " + "; ".join("%s: %s" % (r["transport"], r["check"]) for r in attempts))

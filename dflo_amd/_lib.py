@@ -63,7 +63,7 @@ SYMBOLS = [
     "dflo_hip_get_cell_average", "dflo_hip_n_boundary_faces", "dflo_hip_boundary_faces",
     "dflo_hip_set_boundary_values", "dflo_hip_set_boundary_program", "dflo_hip_get_boundary_values", "dflo_hip_residual", "dflo_hip_compute_dt", "dflo_hip_step", "dflo_hip_stage",
     "dflo_hip_end_step", "dflo_hip_advance", "dflo_hip_compute_cell_average", "dflo_hip_apply_limiter",
-    "dflo_hip_apply_positivity_limiter", "dflo_hip_compute_shock_indicator", "dflo_hip_get_shock_indicator", "dflo_hip_check", "dflo_hip_synchronize", "dflo_hip_stage_timing",
+    "dflo_hip_apply_positivity_limiter", "dflo_hip_compute_shock_indicator", "dflo_hip_get_shock_indicator", "dflo_hip_check", "dflo_hip_synchronize", "dflo_hip_stage_timing", "dflo_hip_uses_mfma",
     "dflo_hip_set_send_cells", "dflo_hip_pack_send", "dflo_hip_pack_send_avg", "dflo_hip_unpack_ghost",
     "dflo_hip_unpack_ghost_avg", "dflo_hip_n_ghost_cells", "dflo_hip_stage_update", "dflo_hip_stage_limit",
     "dflo_hip_stage_open", "dflo_hip_stage_update_part", "dflo_hip_stage_limit_part", "dflo_hip_stage_finish",
@@ -136,6 +136,7 @@ _sig("dflo_hip_get_shock_indicator", C.c_int, _H, _dp)
 _sig("dflo_hip_check", C.c_int, _H)
 _sig("dflo_hip_synchronize", C.c_int, _H)
 _sig("dflo_hip_stage_timing", C.c_int, _H, C.c_int, _dp, C.POINTER(C.c_int64))
+_sig("dflo_hip_uses_mfma", C.c_int, _H)
 _sig("dflo_hip_set_send_cells", C.c_int, _H, C.c_int32, _ip)
 _sig("dflo_hip_pack_send", C.c_int, _H, C.c_void_p)
 _sig("dflo_hip_pack_send_avg", C.c_int, _H, C.c_void_p)

@@ -168,5 +168,10 @@ class ConservationLaw:
         self._chk(lib.dflo_hip_stage_timing(self._h, int(enable), C.byref(ms), C.byref(n)))
         return ms.value, n.value
 
+    @property
+    def uses_mfma(self):
+        """does the stage kernel form its per-element contractions with matrix instructions (degree 3, DFLO_MFMA=1)?"""
+        return bool(lib.dflo_hip_uses_mfma(self._h))
+
     def set_stream(self, stream_ptr):
         self._chk(lib.dflo_hip_set_stream(self._h, C.c_void_p(stream_ptr)))

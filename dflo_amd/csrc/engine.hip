@@ -145,6 +145,7 @@ struct dflo_hip_engine {
   // timing
   bool timing = false;
   int dtq_parts = 0;   // last stage on bilinear cells: parts (1 rim, 2 interior) whose limiter pass also formed the time step
+  bool mfma = false;       // DFLO_MFMA=1, degree 3: the per-element contractions on the matrix pipe (Q3: eta-derivative; P3 on squares: modal <-> nodal)
   bool fuse_pos = false;   // positivity limiter without TVB on Qk: applied inside the stage kernel (DFLO_FUSE_POS=0: separate pass)
   unsigned long long *lim_mask = nullptr;   // TVB on Qk squares: [n_shards], written by the stage kernel for the limiter pass (DFLO_LIM_MASK=0: off)
   bool aux_fresh = false;      // lim_mask belongs to the state the open stage has just produced
@@ -239,7 +240,9 @@ KBasis make_kbasis(const BasisTables &b) {
 #define DFLO_BY_N2(n, K, P) ((n) <= 2 ? K<2, P> : ((n) == 3 ? K<3, P> : ((n) == 4 ? K<4, P> : ((n) == 5 ? K<5, P> : K<6, P>))))
 #define DFLO_BY_N_LIM(n, K) ((n) <= 2 ? K<2> : ((n) == 3 ? K<3> : ((n) == 4 ? K<4> : ((n) == 5 ? K<5> : K<6>))))
 
-stage_fn pick_pk(int N, int flux, int mode, int nt = 0) {   // nt: bit 0 streaming stores, bit 1 bilinear cells
+// mf: the matrix-pipe variants of degree 3 (DFLO_MFMA=1; stage_kernels.hpp: eta_derivative_mfma, row_update_pk)
+stage_fn pick_pk(int N, int flux, int mode, int nt = 0, bool mf = false) {   // nt: bit 0 streaming stores, bit 1 bilinear cells
+  if (mf && N == 4) return dflo::stage_pk_mf_of_4(flux, mode, nt);
   switch (N) {
     case 1: return dflo::stage_pk_of_1(flux, mode, nt);
     case 2: return dflo::stage_pk_of_2(flux, mode, nt);
@@ -249,7 +252,8 @@ stage_fn pick_pk(int N, int flux, int mode, int nt = 0) {   // nt: bit 0 streami
     default: return dflo::stage_pk_of_6(flux, mode, nt);
   }
 }
-stage_fn pick_stage(int N, int flux, int mode, int geo, int pos = 0, int nt = 0) {
+stage_fn pick_stage(int N, int flux, int mode, int geo, int pos = 0, int nt = 0, bool mf = false) {
+  if (mf && N == 4) return dflo::stage_mf_of_4(flux, mode, geo, pos, nt);
   switch (N) {
     case 1: return dflo::stage_of_1(flux, mode, geo, pos, nt);
     case 2: return dflo::stage_of_2(flux, mode, geo, pos, nt);
@@ -631,7 +635,7 @@ int launch_update(dflo_hip_engine *h, double *rhs_out, int part) {
       a.lim_list_from = part == 3 ? (int)p.rim_shards.size() : 0;
     }
   }
-  stage_fn fn = h->basis == DFLO_BASIS_PK ? pick_pk(h->N, h->prm.flux_type, mode_, streams_out(h) | (h->geo << 1)) : pick_stage(h->N, h->prm.flux_type, mode_, h->geo, pos_, streams_out(h));
+  stage_fn fn = h->basis == DFLO_BASIS_PK ? pick_pk(h->N, h->prm.flux_type, mode_, streams_out(h) | (h->geo << 1), h->mfma) : pick_stage(h->N, h->prm.flux_type, mode_, h->geo, pos_, streams_out(h), h->mfma);
   time_begin(h);
   launch_with_event(h, fn, dim3(grid_for(a.n_list)), dim3(64 * h->N), h->lds_bytes, a);
   time_end(h);
@@ -998,6 +1002,7 @@ int dflo_hip_create_with_cell_size(const dflo_mesh_t *mesh, const dflo_params_t 
   h->fuse_dtq = tun.fuse_dtq;
   h->peer_fine = tun.peer_finegrained;
   h->bc_fuse = tun.bc_fuse;
+  h->mfma = tun.mfma && h->N == 4;
   h->ns = mesh->basis == DFLO_BASIS_PK ? h->N * (h->N + 1) / 2 : h->N * h->N;
   h->ndof = 4 * h->ns;
   h->mapping = mesh->mapping == DFLO_MAP_Q2 ? DFLO_MAP_Q1 : mesh->mapping;
@@ -1216,7 +1221,7 @@ int dflo_hip_create_with_cell_size(const dflo_mesh_t *mesh, const dflo_params_t 
   if (h->lds_bytes > 160 * 1024) { h->err = "shard halo too large for LDS"; return bail(DFLO_ERR_UNSUPPORTED); }
   if (h->lds_bytes > 64 * 1024) {
     for (int mode = 0; mode < 3; ++mode) {
-      stage_fn fn = h->basis == DFLO_BASIS_PK ? pick_pk(h->N, h->prm.flux_type, mode, streams_out(h) | (h->geo << 1)) : pick_stage(h->N, h->prm.flux_type, mode, h->geo, h->fuse_pos ? 1 : (h->lim_mask ? 2 : (h->af ? 3 : 0)), streams_out(h));
+      stage_fn fn = h->basis == DFLO_BASIS_PK ? pick_pk(h->N, h->prm.flux_type, mode, streams_out(h) | (h->geo << 1), h->mfma) : pick_stage(h->N, h->prm.flux_type, mode, h->geo, h->fuse_pos ? 1 : (h->lim_mask ? 2 : (h->af ? 3 : 0)), streams_out(h), h->mfma);
       if (hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes) != hipSuccess) {
         h->err = "cannot raise dynamic LDS limit";
         return bail(DFLO_ERR_HIP);
@@ -1224,7 +1229,7 @@ int dflo_hip_create_with_cell_size(const dflo_mesh_t *mesh, const dflo_params_t 
     }
   }
   {  // persistent grid: as many workgroups as stay resident, a multiple of 8 (one run of shards per XCD)
-    stage_fn fn = pick_stage(h->N, h->prm.flux_type, 1, h->geo);
+    stage_fn fn = h->basis == DFLO_BASIS_PK ? pick_pk(h->N, h->prm.flux_type, 1, h->geo << 1, h->mfma) : pick_stage(h->N, h->prm.flux_type, 1, h->geo, 0, 0, h->mfma);
     int per_cu = 0, n_cu = 0;
     hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, device_id);
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)fn, 64 * h->N, h->lds_bytes) != hipSuccess || per_cu < 1)
@@ -1888,6 +1893,8 @@ int dflo_hip_synchronize(dflo_hip_handle h) {
   HIPCHK(h, hipStreamSynchronize(h->stream));
   return DFLO_OK;
 }
+
+int dflo_hip_uses_mfma(dflo_hip_handle h) { return h && h->mfma ? 1 : 0; }
 
 int dflo_hip_stage_timing(dflo_hip_handle h, int enable, double *avg_ms, int64_t *n) {
   if (check_handle(h)) return DFLO_ERR_BAD_PARAM;

@@ -15,7 +15,16 @@
 #define DFLO_CAT4(a, b, c, d) DFLO_CAT(DFLO_CAT(a, b), DFLO_CAT(c, d))
 
 namespace dflo {
-#ifdef DFLO_STAGE_FLUX
+#ifdef DFLO_STAGE_MF   // the matrix-pipe variants of degree 3 (-DDFLO_STAGE_N=4 -DDFLO_STAGE_MF=1 -DDFLO_STAGE_ONLY=1|2)
+#if DFLO_STAGE_N != 4
+#error "the matrix-pipe variants exist for N = 4 only"
+#endif
+#if DFLO_STAGE_ONLY == 1
+stage_fn stage_mf_of_4(int flux, int mode, int geo, int pos, int nt) { return pick_stage_n<4, 1>(flux, mode, geo, pos, nt); }
+#else
+stage_fn stage_pk_mf_of_4(int flux, int mode, int nt) { return pick_pk_n<4, 1>(flux, mode, nt); }
+#endif
+#elif defined(DFLO_STAGE_FLUX)
 stage_fn DFLO_CAT4(stage_of_, DFLO_STAGE_N, _f, DFLO_STAGE_FLUX)(int mode, int geo, int pos, int nt) { return pick_stage_m<DFLO_STAGE_N, DFLO_STAGE_FLUX>(mode, geo, pos, nt); }
 stage_fn DFLO_CAT4(stage_pk_of_, DFLO_STAGE_N, _f, DFLO_STAGE_FLUX)(int mode, int nt) { return pick_pk_m<DFLO_STAGE_N, DFLO_STAGE_FLUX>(mode, nt); }
 #else

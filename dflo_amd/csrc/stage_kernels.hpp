@@ -20,8 +20,38 @@ constexpr bool kPkLeanLater = true;     // P3: the later stages built like the f
 // the flux of the face replaces it), then the other faces (fluxes only); Av[3][halo_cols] (LxF: u, v, c of the halo cells'
 // averages) and the shard's boundary data.  The packed face records stay in registers.
 
+// MF (N = 4; north_star: "MFMA only for the dense per-element basis contractions at higher order"; src/assemble_explicit.cc:85-115):
+// the eta-derivative of phase C on the matrix pipe.  Per cell  O[c][aa][B] = sum_q G[c][(aa, q)] Dm[q][B]  is four 4 x 4 x 4
+// products, one per component: exactly one v_mfma_f64_4x4x4_4b_f64 (4 blocks).  Operand layout measured with
+// tools/mfma_4x4_layout_probe.hip: A_b[i][k] in lane 16 k + 4 b + i, B_b[k][n] in lane 16 k + 4 b + n, D_b[i][n] in lane
+// 16 i + 4 b + n.  With b = component, i = node aa, k = source row q, n = target row B, wave w takes the cells 16 w .. 16 w + 15:
+// lane l fetches G[c][aa, q] of the cell from column `cell` of the LDS image (a gather over its 64 rows), the matrix pipe forms
+// the sums for all four target rows at once, and the result goes back into the same column (a column belongs to one wave; all
+// 16 columns are read before the first is written); after a barrier wave B reads its 16 sums, lane = cell, from the rows
+// (B, c, aa).  Dm = DW (squares) or D (bilinear cells: the metric factors are folded into the rows beforehand).
+template <int N, bool WEIGHTED>
+__device__ __forceinline__ void eta_derivative_mfma(double *Us, const int S, const int lane, const int w) {
+  static_assert(N == 4, "one 4x4x4 block per component: Q3 only");
+  constexpr int NS = N * N;
+  const int l = lane;
+  const int ra = (((l >> 2) & 3) * NS + (l & 3) + N * (l >> 4)) * S;   // row of A: c = (l / 4) % 4, aa = l % 4, q = l / 16
+  const int rd = ((l & 3) * NS + ((l >> 2) & 3) * N + (l >> 4)) * S;   // row of D: B = l % 4, c = (l / 4) % 4, aa = l / 16 -> O[B][c][aa]
+  double bq = 0.0;
+#pragma unroll
+  for (int k = 0; k < N; ++k)
+#pragma unroll
+    for (int n = 0; n < N; ++n) bq = ((l >> 4) == k && (l & 3) == n) ? (WEIGHTED ? CB<N>::t.DW[k][n] : CB<N>::t.D[k][n]) : bq;
+  double av[16];
+#pragma unroll
+  for (int jj = 0; jj < 16; ++jj) av[jj] = Us[ra + 16 * w + jj];
+#pragma unroll
+  for (int jj = 0; jj < 16; ++jj) av[jj] = __builtin_amdgcn_mfma_f64_4x4x4f64(av[jj], bq, 0.0, 0, 0, 0);
+#pragma unroll
+  for (int jj = 0; jj < 16; ++jj) Us[rd + 16 * w + jj] = av[jj];
+}
+
 // phase C for node row B of every cell of the shard (lane = cell)
-template <int N, int B, int MODE, int POS, int STREAM>
+template <int N, int B, int MODE, int POS, int STREAM, int MF = 0>
 __device__ __forceinline__ void row_update(const StageArgs &a, double *Us, const int S, const double *Fh,
                                            double *red, int shard, int lane, bool active, double h,
                                            const uint16_t (&cref)[4], const double (&uold)[4][N],
@@ -68,6 +98,16 @@ __device__ __forceinline__ void row_update(const StageArgs &a, double *Us, const
     }
   }
   __syncthreads();
+  if constexpr (MF && N == 4) {
+    eta_derivative_mfma<N, true>(Us, S, lane, B);
+    __syncthreads();
+#pragma unroll
+    for (int aa = 0; aa < N; ++aa) {
+      const double wah = CB<N>::t.w[aa] * h;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) R[c][aa] += wah * Us[(B * NS + c * N + aa) * S + lane];
+    }
+  } else {
   int ln = lane;
 #pragma unroll
   for (int aa = 0; aa < N; ++aa) {
@@ -85,6 +125,7 @@ __device__ __forceinline__ void row_update(const StageArgs &a, double *Us, const
         R[c][aa] += gy * (wah * CB<N>::t.DW[q][B]);
       }
     }
+  }
   }
   // face terms (:209-244, :344-423): - flux * phi * JxW on the integrating side, + on the other
   if (active) {
@@ -193,7 +234,7 @@ __device__ __forceinline__ void face_edge(const double (&v)[8], int f, double &t
 // FEValues with MappingQ1): J = [x_xi x_eta; y_xi y_eta] varies inside the cell,
 //   int F.grad(phi) = sum_q w_q [ d(phi)/d(xi) (y_eta F - x_eta G) + d(phi)/d(eta) (-y_xi F + x_xi G) ],
 // lumped mass M_j = w_j det J_j (src/claw.cc:223-227), face JxW = w_q |edge|.
-template <int N, int B, int MODE, int POS, int STREAM>
+template <int N, int B, int MODE, int POS, int STREAM, int MF = 0>
 __device__ __forceinline__ void row_update_q1(const StageArgs &a, double *Us, const int S, const double *Fh,
                                               double *red, int shard, int lane, bool active,
                                               const double (&vx)[8], const uint16_t (&cref)[4],
@@ -239,6 +280,14 @@ __device__ __forceinline__ void row_update_q1(const StageArgs &a, double *Us, co
     }
   }
   __syncthreads();
+  if constexpr (MF && N == 4) {   // (the metric factors sit in the rows already: the plain derivative matrix)
+    eta_derivative_mfma<N, false>(Us, S, lane, B);
+    __syncthreads();
+#pragma unroll
+    for (int aa = 0; aa < N; ++aa)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) R[c][aa] += Us[(B * NS + c * N + aa) * S + lane];
+  } else {
 #pragma unroll
   for (int aa = 0; aa < N; ++aa)
 #pragma unroll
@@ -248,6 +297,7 @@ __device__ __forceinline__ void row_update_q1(const StageArgs &a, double *Us, co
         const double hy = q == B ? Hown[aa][c] : Us[(c * NS + aa + N * q) * S + lane];
         R[c][aa] += hy * CB<N>::t.D[q][B];
       }
+  }
   if (active) {
 #pragma unroll
     for (int f = 0; f < 4; ++f) {
@@ -528,7 +578,7 @@ __device__ __forceinline__ bool lists_itself(const StageArgs &a, const int shard
   return a.lim_cnt && sidx >= a.lim_list_from && !(a.dla_begin && a.dla_begin[shard + 1] > a.dla_begin[shard]);
 }
 
-template <int N, int FLUX, int MODE, int GEO, int POS, int STREAM, int AF = 0>
+template <int N, int FLUX, int MODE, int GEO, int POS, int STREAM, int AF = 0, int MF = 0>
 __global__ __launch_bounds__(64 * N, N >= 5 ? 1 : ((N == 4 && GEO == 0 && MODE == 0) ? kQ3FirstStageWaves : (((GEO == 1 && N != 3) || N == 4) ? 2 : (N == 3 && GEO == 0 ? kQ2Waves : 3)))) void stage_kernel(const StageArgs a) {
   constexpr int NS = N * N, NDOF = 4 * NS, NT = 64 * N;
   constexpr int ROWS = NDOF + (FLUX == DFLO_FLUX_LXF ? 3 : 0);   // LxF: (u, v, c) of the cell average ride along
@@ -774,8 +824,8 @@ __global__ __launch_bounds__(64 * N, N >= 5 ? 1 : ((N == 4 && GEO == 0 && MODE =
     for (int c = 0; c < 4; ++c) wrow[m][c] = urow[c][m];
 #define DFLO_ROW(Bq)                                                                                     \
   do {                                                                                                   \
-    if constexpr (GEO == 0) row_update<N, Bq, MODE, POS, STREAM>(a, Us, S, Fh, red, shard, lane, active, h, cref, uold, wrow, unew, dt_step); \
-    else row_update_q1<N, Bq, MODE, POS, STREAM>(a, Us, S, Fh, red, shard, lane, active, vx, cref, uold, wrow, unew, dt_step); \
+    if constexpr (GEO == 0) row_update<N, Bq, MODE, POS, STREAM, MF>(a, Us, S, Fh, red, shard, lane, active, h, cref, uold, wrow, unew, dt_step); \
+    else row_update_q1<N, Bq, MODE, POS, STREAM, MF>(a, Us, S, Fh, red, shard, lane, active, vx, cref, uold, wrow, unew, dt_step); \
   } while (0)
   if constexpr (N == 2) {
     if (row == 0) DFLO_ROW(0); else DFLO_ROW(1);
@@ -1154,11 +1204,29 @@ __device__ __forceinline__ void modal_to_row(const double *Um, const int S, cons
 // is formed with the metric terms of row_update_q1; the mass matrix is the DIAGONAL the reference keeps,
 // M_mm = sum_q psi_m(x_q)^2 JxW_q (src/claw.cc:228-258: "not exact for general cells"), and the cell average is the quadrature
 // of the modal expansion over the cell, sum_m U_m (sum_q psi_m JxW_q) / |K| (src/claw.cc:589-593), no longer mode 0.
-template <int N, int B, int MODE, int STREAM, int GEO = 0>
+// MF (N = 4, squares; north_star's per-element MFMA contraction, src/main.cc:44-48 FE_DGP + src/assemble_explicit.cc:85-115): the
+// two dense tables of the modal element on the matrix pipe, v_mfma_f64_16x16x4_f64 with 16 cells along the columns.  Operand layout
+// measured with tools/mfma_f64_16x16_probe.hip: A[i][k] in lane i + 16 k, B[k][n] in lane n + 16 k, D[i][n] in lane n + 16 (i % 4),
+// register i / 4.  Wave w takes the cells 16 w .. 16 w + 15 and lane (g, n) = (lane / 16, lane % 16) holds the modes g, g + 4, g + 8 of cell
+// 16 w + n in its registers t = 0, 1, 2 -- which IS the B operand of k-step t (mode 4 t + g) of
+//     nodal = T modes:   D[node i][cell] = sum_m T[i][m] U_m        (A = T, 16 x 12, the columns of the modes 10, 11 zero)
+// and the layout D leaves the result of
+//     modal = T^T nodal: D[mode i][cell] = sum_j T[j][i] R_j        (A = T^T, rows 10 .. 15 zero; K = the 16 nodes, read from the LDS image)
+// in (mode 4 r + g in register r): the modes are loaded, updated and stored where the matrix instruction wants them, four 128-byte
+// segments per wavefront access instead of one 512-byte line.
+template <int N>
+__device__ __forceinline__ double pk_table_entry(int node, int mode) {   // T[node][mode], 0 beyond the last mode (per-lane index: a load from the constant table)
+  constexpr int NM = N * (N + 1) / 2;
+  const double v = PB<N>::t.T[node][mode < NM ? mode : NM - 1];
+  return mode < NM ? v : 0.0;
+}
+
+template <int N, int B, int MODE, int STREAM, int GEO = 0, int MF = 0>
 __device__ __forceinline__ void row_update_pk(const StageArgs &a, double *Us, const int S, const double *Fh, double *red,
                                               int shard, int lane, bool active, double h, const double (&vx)[8], const uint16_t (&cref)[4],
                                               const double (&Wrow)[N][4], const double (&ucur)[4][(N * (N + 1) / 2 + N - 1) / N],
-                                              const double (&uold)[4][(N * (N + 1) / 2 + N - 1) / N], const double dt) {
+                                              const double (&uold)[4][(N * (N + 1) / 2 + N - 1) / N], const double dt,
+                                              const bool active_x = false, const double h_x = 0.0, const double dt_x = 0.0) {
   const int HS = a.halo_stride;   // row stride of the trace / flux table (Fh)
   constexpr int NS = N * N, NM = N * (N + 1) / 2;
   double R[4][N];
@@ -1238,7 +1306,7 @@ __device__ __forceinline__ void row_update_pk(const StageArgs &a, double *Us, co
   } else {
   // P3, first stage (LEAN, as in row_update): built for 3 wavefronts per SIMD -- the nodal values of the own row and the own G
   // row come back from the LDS image instead of being held in registers, the G values are taken node by node
-  constexpr bool LEAN = N == 4 && (MODE == 0 || (MODE == 1 && kPkLeanLater));
+  constexpr bool LEAN = N == 4 && (MF || MODE == 0 || (MODE == 1 && kPkLeanLater));
   double Gown[N][4];
 #pragma unroll
   for (int aa = 0; aa < N; ++aa) {
@@ -1318,6 +1386,45 @@ __device__ __forceinline__ void row_update_pk(const StageArgs &a, double *Us, co
   __syncthreads();
   constexpr int MSB = (NM - B + N - 1) / N;   // modes of this wave
   double part[5] = {0, 0, 0, 0, 0};
+  if constexpr (MF && N == 4 && GEO == 0) {
+    typedef double mf_d4 __attribute__((ext_vector_type(4)));
+    constexpr int MS = (NM + N - 1) / N;
+    const int g = lane >> 4, cx = 16 * B + (lane & 15);
+    double At[4];   // A = T^T: lane (i, k) = (lane % 16, lane / 16) holds T[node 4 ks + k][mode i] of k-step ks
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) At[ks] = pk_table_entry<N>(4 * ks + (lane >> 4), lane & 15);
+    const double rh2 = frcp(h_x * h_x);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      mf_d4 d = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)   // node 4 ks + g = (aa, b) = (g, ks) of cell cx
+        d = __builtin_amdgcn_mfma_f64_16x16x4f64(At[ks], Us[(c * NS + g + N * ks) * S + cx], d, 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < MS; ++t) {
+        const int m = 4 * t + g;
+        if (m < NM && active_x) {
+          const double rm = d[t];
+          if constexpr (MODE == 2) {
+            a.rhs_out[((size_t)shard * 4 * NM + c * NM + m) * 64 + cx] = rm;
+          } else {
+            part[4] += rm * rm;
+            double u = ucur[c][t];
+            u += dt_x * rm * rh2;
+            if constexpr (MODE == 1) u = (1.0 - a.ark) * u + a.ark * uold[c][t];
+            stream_store<STREAM>(&a.Unew[((size_t)shard * 4 * NM + c * NM + m) * 64 + cx], u);
+            if (m == 0) part[c] = u;   // the cell average is mode 0
+          }
+        }
+      }
+    }
+    if constexpr (MODE != 2) {
+      __syncthreads();  // every wave is done reading Fh
+#pragma unroll
+      for (int c = 0; c < 5; ++c) red[(g * 5 + c) * 64 + cx] = part[c];   // lane group g in the place of wave g: the epilogue's sums over the rows
+    }
+    return;
+  }
   {
     const double rh2 = frcp(h * h);  // inverse mass of the orthonormal modes: 1/|K|
     double invM[MSB > 0 ? MSB : 1], cavg[MSB > 0 ? MSB : 1];   // GEO 1: per owned mode, from the cell's own metric
@@ -1385,8 +1492,9 @@ __device__ __forceinline__ void row_update_pk(const StageArgs &a, double *Us, co
   }
 }
 
-template <int N, int FLUX, int MODE, int STREAM, int GEO = 0>
-__global__ __launch_bounds__(64 * N, N >= 5 ? 1 : (N == 4 ? (((MODE == 0 || (MODE == 1 && kPkLeanLater)) && FLUX != DFLO_FLUX_LXF && GEO == 0) ? kQ3FirstStageWaves : 2) : (GEO == 1 ? 2 : 3))) void stage_kernel_pk(const StageArgs a) {
+template <int N, int FLUX, int MODE, int STREAM, int GEO = 0, int MF = 0>
+__global__ __launch_bounds__(64 * N, N >= 5 ? 1 : (N == 4 ? (((MF || MODE == 0 || (MODE == 1 && kPkLeanLater)) && FLUX != DFLO_FLUX_LXF && GEO == 0) ? kQ3FirstStageWaves : 2) : (GEO == 1 ? 2 : 3))) void stage_kernel_pk(const StageArgs a) {
+  static_assert(!MF || (N == 4 && GEO == 0), "the matrix-pipe tables: P3 on squares");
   constexpr int NS = N * N, NM = N * (N + 1) / 2, NDOFM = 4 * NM, NT = 64 * N, MS = (NM + N - 1) / N;
   constexpr int ROWS = 4 * NS + (FLUX == DFLO_FLUX_LXF ? 3 : 0);
   constexpr int TROWS = 4 * N;
@@ -1441,16 +1549,47 @@ __global__ __launch_bounds__(64 * N, N >= 5 ? 1 : (N == 4 ? (((MODE == 0 || (MOD
   }
   double dt_step = 0.0;   // fetched with the other loads, not in the middle of phase C
   if constexpr (MODE != 2) dt_step = a.dt_cell ? a.dt_cell[(size_t)shard * 64 + lane] : (a.dt_host >= 0.0 ? a.dt_host : step_dt(a.dts, a.dt_dev));
+  // MF: lane (g, n) = (lane / 16, lane % 16) of wave w holds the modes g + 4 t of cell cx = 16 w + n (see row_update_pk); otherwise wave w
+  // holds the modes w + N t of cell `lane`
+  const int mg = MF ? lane >> 4 : row, cx = MF ? 16 * row + (lane & 15) : lane;
   double ucur[4][MS], uold[4][MS];
 #pragma unroll
   for (int c = 0; c < 4; ++c)
 #pragma unroll
     for (int t = 0; t < MS; ++t) {
-      const int m = min(row + N * t, NM - 1);
-      ucur[c][t] = a.Ucur[((size_t)shard * NDOFM + c * NM + m) * 64 + lane];
-      if constexpr (MODE == 1) uold[c][t] = __builtin_nontemporal_load(&a.Uold[((size_t)shard * NDOFM + c * NM + m) * 64 + lane]);   // read once per stage
+      const int m = min(mg + N * t, NM - 1);
+      ucur[c][t] = a.Ucur[((size_t)shard * NDOFM + c * NM + m) * 64 + cx];
+      if constexpr (MODE == 1) uold[c][t] = __builtin_nontemporal_load(&a.Uold[((size_t)shard * NDOFM + c * NM + m) * 64 + cx]);   // read once per stage
     }
+  bool active_x = active;
+  double h_x = h, dt_x = dt_step;
+  if constexpr (MF) {   // the same three of the cell the lane updates in the matrix layout
+    active_x = cx < (hdr.x & 0xFF);
+    h_x = a.uniform_h ? a.h_uniform : a.cell_h[(size_t)shard * 64 + cx];
+    if constexpr (MODE != 2) dt_x = a.dt_cell ? a.dt_cell[(size_t)shard * 64 + cx] : dt_step;
+  }
 
+  double urow[4][N];
+  if constexpr (MF) {
+    // ---- phase A on the matrix pipe: nodal = T modes, straight from the registers the modes were loaded into; the result lands in the
+    //      rows of the nodal image (node 4 r + g = (aa, b) = (g, r) in register r), every wave reads its row back in phase C (LEAN)
+    typedef double mf_d4 __attribute__((ext_vector_type(4)));
+    double Am[MS];   // A = T: lane (i, k) = (lane % 16, lane / 16) holds T[node i][mode 4 ks + k] of k-step ks
+#pragma unroll
+    for (int ks = 0; ks < MS; ++ks) Am[ks] = pk_table_entry<N>(lane & 15, 4 * ks + (lane >> 4));
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      mf_d4 d = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int ks = 0; ks < MS; ++ks) d = __builtin_amdgcn_mfma_f64_16x16x4f64(Am[ks], ucur[c][ks], d, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Us[(c * NS + mg + N * r) * S + cx] = d[r];
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int m = 0; m < N; ++m) urow[c][m] = 0.0;   // (phase C reads its row from the image)
+  } else {
   // ---- phase A: the modes meet in LDS (in the rows the nodal image will take), every wave forms its node row from them
 #pragma unroll
   for (int c = 0; c < 4; ++c)
@@ -1460,7 +1599,6 @@ __global__ __launch_bounds__(64 * N, N >= 5 ? 1 : (N == 4 ? (((MODE == 0 || (MOD
       if (m < NM) Us[(c * NM + m) * S + lane] = ucur[c][t];
     }
   __syncthreads();
-  double urow[4][N];
   if constexpr (N == 2) {
     if (row == 0) modal_to_row<N, 0>(Us, S, lane, urow); else modal_to_row<N, 1>(Us, S, lane, urow);
   } else if constexpr (N == 3) {
@@ -1477,6 +1615,7 @@ __global__ __launch_bounds__(64 * N, N >= 5 ? 1 : (N == 4 ? (((MODE == 0 || (MOD
     else if (row == 4) modal_to_row<N, 4>(Us, S, lane, urow); else modal_to_row<N, 5>(Us, S, lane, urow);
   }
   __syncthreads();   // every wave has read the modes: the nodal image may take their place
+  }   // !MF
   // halo: traces of the neighbour's modal expansion on the shared face, psi_m = Pt_i(xi) Pt_j(eta) with one coordinate fixed at
   // 0 or 1 and the other at the N face points.  A thread takes one (entry, component): it loads the NM modes once, sums over
   // the fixed direction (both ways, the face decides which one counts) and evaluates the N points from the N sums -- the modes
@@ -1516,17 +1655,19 @@ __global__ __launch_bounds__(64 * N, N >= 5 ? 1 : (N == 4 ? (((MODE == 0 || (MOD
       if (c < 3) Av[c * a.halo_cols + sl] = c == 0 ? uvc[0] : (c == 1 ? uvc[1] : uvc[2]);
     }
   }
+  if constexpr (!MF) {
 #pragma unroll
   for (int c = 0; c < 4; ++c)
 #pragma unroll
     for (int m = 0; m < N; ++m) Us[(c * NS + m + N * row) * S + lane] = urow[c][m];
+  }
   if constexpr (LXF) {
-    if (row == 0) {   // wave 0 owns mode 0 (ucur[.][0])
+    if (mg == 0) {   // wave 0 (MF: lane group 0 of every wave) owns mode 0 (ucur[.][0])
       const double A[4] = {ucur[0][0], ucur[1][0], ucur[2][0], ucur[3][0]};
       double uvc[3];
       wave_speed_uvc(A, uvc);
 #pragma unroll
-      for (int c = 0; c < 3; ++c) Us[(4 * NS + c) * S + lane] = uvc[c];
+      for (int c = 0; c < 3; ++c) Us[(4 * NS + c) * S + cx] = uvc[c];
     }
   }
   if constexpr (FLUX == DFLO_FLUX_LXF && GEO == 1) {   // (u, v, c) of the stored averages: own cells and halo entries
@@ -1574,7 +1715,7 @@ __global__ __launch_bounds__(64 * N, N >= 5 ? 1 : (N == 4 ? (((MODE == 0 || (MOD
   for (int m = 0; m < N; ++m)
 #pragma unroll
     for (int c = 0; c < 4; ++c) wrow[m][c] = urow[c][m];
-#define DFLO_ROWPK(Bq) row_update_pk<N, Bq, MODE, STREAM, GEO>(a, Us, S, Fh, red, shard, lane, active, h, vx, cref, wrow, ucur, uold, dt_step)
+#define DFLO_ROWPK(Bq) row_update_pk<N, Bq, MODE, STREAM, GEO, MF>(a, Us, S, Fh, red, shard, lane, active, h, vx, cref, wrow, ucur, uold, dt_step, active_x, h_x, dt_x)
   if constexpr (N == 2) {
     if (row == 0) DFLO_ROWPK(0); else DFLO_ROWPK(1);
   } else if constexpr (N == 3) {
@@ -1622,60 +1763,68 @@ __global__ __launch_bounds__(64 * N, N >= 5 ? 1 : (N == 4 ? (((MODE == 0 || (MOD
 // The kernels of one N (5 fluxes x 3 modes x 2 geometries x the limiter variants, Qk and Pk) are instantiated in their own
 // translation unit (stage_inst.hip, -DDFLO_STAGE_N=N) and reached through stage_of_N / stage_pk_of_N.
 typedef void (*stage_fn)(const StageArgs);
-template <int N, int FLUX>
+// MF 1: the matrix-pipe variants (N = 4 only: Q3's eta-derivative, P3's modal <-> nodal tables on squares), their own translation
+// units (stage_inst.hip with -DDFLO_STAGE_MF=1), reached through stage_mf_of_4 / stage_pk_mf_of_4 when the engine runs with DFLO_MFMA=1
+template <int N, int FLUX, int MF = 0>
 stage_fn pick_stage_m(int mode, int geo, int pos, int nt) {
+#define DFLO_SK(MODE, GEO, POS, STREAM) stage_kernel<N, FLUX, MODE, GEO, POS, STREAM, 0, MF>
+#define DFLO_SK_AF(MODE, STREAM) stage_kernel<N, FLUX, MODE, 0, 0, STREAM, 1, MF>
   if constexpr (FLUX == DFLO_FLUX_LXF) {
     if (pos == 3) {   // LxF without the arrays of cell averages (AF; squares, no limiter): pos is free to carry the request
-      if (mode == 2) return stage_kernel<N, FLUX, 2, 0, 0, 0, 1>;
-      if (nt) return mode == 0 ? stage_kernel<N, FLUX, 0, 0, 0, 1, 1> : stage_kernel<N, FLUX, 1, 0, 0, 1, 1>;
-      return mode == 0 ? stage_kernel<N, FLUX, 0, 0, 0, 0, 1> : stage_kernel<N, FLUX, 1, 0, 0, 0, 1>;
+      if (mode == 2) return DFLO_SK_AF(2, 0);
+      if (nt) return mode == 0 ? DFLO_SK_AF(0, 1) : DFLO_SK_AF(1, 1);
+      return mode == 0 ? DFLO_SK_AF(0, 0) : DFLO_SK_AF(1, 0);
     }
   }
   if (pos == 1 && mode != 2) {   // the limiter has been applied on the way out: nothing re-reads the state
-    if (geo == 0) return mode == 0 ? stage_kernel<N, FLUX, 0, 0, 1, 1> : stage_kernel<N, FLUX, 1, 0, 1, 1>;
-    return mode == 0 ? stage_kernel<N, FLUX, 0, 1, 1, 1> : stage_kernel<N, FLUX, 1, 1, 1, 1>;
+    if (geo == 0) return mode == 0 ? DFLO_SK(0, 0, 1, 1) : DFLO_SK(1, 0, 1, 1);
+    return mode == 0 ? DFLO_SK(0, 1, 1, 1) : DFLO_SK(1, 1, 1, 1);
   }
   if (pos == 2 && mode != 2 && geo == 0)   // the limiter pass reads the marked cells only
-    return mode == 0 ? stage_kernel<N, FLUX, 0, 0, 2, 1> : stage_kernel<N, FLUX, 1, 0, 2, 1>;
-  if (mode == 2) return geo == 0 ? stage_kernel<N, FLUX, 2, 0, 0, 0> : stage_kernel<N, FLUX, 2, 1, 0, 0>;
+    return mode == 0 ? DFLO_SK(0, 0, 2, 1) : DFLO_SK(1, 0, 2, 1);
+  if (mode == 2) return geo == 0 ? DFLO_SK(2, 0, 0, 0) : DFLO_SK(2, 1, 0, 0);
   if (nt) {
-    if (geo == 0) return mode == 0 ? stage_kernel<N, FLUX, 0, 0, 0, 1> : stage_kernel<N, FLUX, 1, 0, 0, 1>;
-    return mode == 0 ? stage_kernel<N, FLUX, 0, 1, 0, 1> : stage_kernel<N, FLUX, 1, 1, 0, 1>;
+    if (geo == 0) return mode == 0 ? DFLO_SK(0, 0, 0, 1) : DFLO_SK(1, 0, 0, 1);
+    return mode == 0 ? DFLO_SK(0, 1, 0, 1) : DFLO_SK(1, 1, 0, 1);
   }
-  if (geo == 0) return mode == 0 ? stage_kernel<N, FLUX, 0, 0, 0, 0> : stage_kernel<N, FLUX, 1, 0, 0, 0>;
-  return mode == 0 ? stage_kernel<N, FLUX, 0, 1, 0, 0> : stage_kernel<N, FLUX, 1, 1, 0, 0>;
+  if (geo == 0) return mode == 0 ? DFLO_SK(0, 0, 0, 0) : DFLO_SK(1, 0, 0, 0);
+  return mode == 0 ? DFLO_SK(0, 1, 0, 0) : DFLO_SK(1, 1, 0, 0);
+#undef DFLO_SK
+#undef DFLO_SK_AF
 }
-template <int N>
+template <int N, int MF = 0>
 stage_fn pick_stage_n(int flux, int mode, int geo, int pos, int nt) {
   switch (flux) {
-    case DFLO_FLUX_LXF: return pick_stage_m<N, DFLO_FLUX_LXF>(mode, geo, pos, nt);
-    case DFLO_FLUX_SW: return pick_stage_m<N, DFLO_FLUX_SW>(mode, geo, pos, nt);
-    case DFLO_FLUX_KFVS: return pick_stage_m<N, DFLO_FLUX_KFVS>(mode, geo, pos, nt);
-    case DFLO_FLUX_ROE: return pick_stage_m<N, DFLO_FLUX_ROE>(mode, geo, pos, nt);
-    default: return pick_stage_m<N, DFLO_FLUX_HLLC>(mode, geo, pos, nt);
+    case DFLO_FLUX_LXF: return pick_stage_m<N, DFLO_FLUX_LXF, MF>(mode, geo, pos, nt);
+    case DFLO_FLUX_SW: return pick_stage_m<N, DFLO_FLUX_SW, MF>(mode, geo, pos, nt);
+    case DFLO_FLUX_KFVS: return pick_stage_m<N, DFLO_FLUX_KFVS, MF>(mode, geo, pos, nt);
+    case DFLO_FLUX_ROE: return pick_stage_m<N, DFLO_FLUX_ROE, MF>(mode, geo, pos, nt);
+    default: return pick_stage_m<N, DFLO_FLUX_HLLC, MF>(mode, geo, pos, nt);
   }
 }
-template <int N, int FLUX>
+template <int N, int FLUX, int MF = 0>
 stage_fn pick_pk_m(int mode, int nt) {   // nt bit 0: nothing re-reads the new state before the next stage kernel (see STREAM); bit 1: bilinear cells
-  if (nt & 2) {
+  if (nt & 2) {   // (bilinear cells: the tables stay on the vector units, the mass matrix is per cell and mode there)
     if (mode == 2) return stage_kernel_pk<N, FLUX, 2, 0, 1>;
     if (nt & 1) return mode == 0 ? stage_kernel_pk<N, FLUX, 0, 1, 1> : stage_kernel_pk<N, FLUX, 1, 1, 1>;
     return mode == 0 ? stage_kernel_pk<N, FLUX, 0, 0, 1> : stage_kernel_pk<N, FLUX, 1, 0, 1>;
   }
-  if (mode == 2) return stage_kernel_pk<N, FLUX, 2, 0>;
-  if (nt) return mode == 0 ? stage_kernel_pk<N, FLUX, 0, 1> : stage_kernel_pk<N, FLUX, 1, 1>;
-  return mode == 0 ? stage_kernel_pk<N, FLUX, 0, 0> : stage_kernel_pk<N, FLUX, 1, 0>;
+  if (mode == 2) return stage_kernel_pk<N, FLUX, 2, 0, 0, MF>;
+  if (nt) return mode == 0 ? stage_kernel_pk<N, FLUX, 0, 1, 0, MF> : stage_kernel_pk<N, FLUX, 1, 1, 0, MF>;
+  return mode == 0 ? stage_kernel_pk<N, FLUX, 0, 0, 0, MF> : stage_kernel_pk<N, FLUX, 1, 0, 0, MF>;
 }
-template <int N>
+template <int N, int MF = 0>
 stage_fn pick_pk_n(int flux, int mode, int nt) {
   switch (flux) {
-    case DFLO_FLUX_LXF: return pick_pk_m<N, DFLO_FLUX_LXF>(mode, nt);
-    case DFLO_FLUX_SW: return pick_pk_m<N, DFLO_FLUX_SW>(mode, nt);
-    case DFLO_FLUX_KFVS: return pick_pk_m<N, DFLO_FLUX_KFVS>(mode, nt);
-    case DFLO_FLUX_ROE: return pick_pk_m<N, DFLO_FLUX_ROE>(mode, nt);
-    default: return pick_pk_m<N, DFLO_FLUX_HLLC>(mode, nt);
+    case DFLO_FLUX_LXF: return pick_pk_m<N, DFLO_FLUX_LXF, MF>(mode, nt);
+    case DFLO_FLUX_SW: return pick_pk_m<N, DFLO_FLUX_SW, MF>(mode, nt);
+    case DFLO_FLUX_KFVS: return pick_pk_m<N, DFLO_FLUX_KFVS, MF>(mode, nt);
+    case DFLO_FLUX_ROE: return pick_pk_m<N, DFLO_FLUX_ROE, MF>(mode, nt);
+    default: return pick_pk_m<N, DFLO_FLUX_HLLC, MF>(mode, nt);
   }
 }
+stage_fn stage_mf_of_4(int flux, int mode, int geo, int pos, int nt);
+stage_fn stage_pk_mf_of_4(int flux, int mode, int nt);
 stage_fn stage_of_1(int flux, int mode, int geo, int pos, int nt);
 stage_fn stage_of_2(int flux, int mode, int geo, int pos, int nt);
 stage_fn stage_of_3(int flux, int mode, int geo, int pos, int nt);

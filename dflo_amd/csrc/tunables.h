@@ -19,6 +19,10 @@ struct Tunables {
   bool fuse_fin = true;    // DFLO_FUSE_FIN=0    TVB on Qk squares: finalize_kernel as its own launch instead of inside the limiter pass that ends the step
   bool bc_fuse = true;     // DFLO_BC_FUSE=0     boundary programs always by bc_eval_kernel (default: the limiter pass behind stage 0 takes the later
                            //                    stages' table along, stage 0 reads the table the previous step's later stages used)
+  bool mfma = false;       // DFLO_MFMA=1        degree 3: the dense per-element contractions on the matrix pipe -- Q3 (squares and bilinear cells): the
+                           //                    eta-derivative as one v_mfma_f64_4x4x4_4b per cell; P3 on squares: modal -> nodal and nodal -> modal as
+                           //                    v_mfma_f64_16x16x4 with 16 cells along the columns (default: the vector units, which measured faster --
+                           //                    fp64 matrix and vector instructions share one issue pipe on MI355X, tools/mfma_f64_16x16_probe.hip)
   bool lazy_avg = true;    // DFLO_LAZY_AVG=0    store the cell averages of every stage (default: only when somebody reads them)
   bool lxf_from_dofs = true;   // DFLO_LXF_FROM_DOFS=0   the LxF flux on squares reads the arrays of cell averages (default: (u, v, c) of the averages from the DoFs)
   bool lim_list = true;    // DFLO_LIM_LIST=0    with marks: one wavefront per shard looks at its word instead of a short grid walking the list of marked shards
@@ -80,6 +84,7 @@ inline Tunables read_tunables() {
   t.fuse_pos = flag("DFLO_FUSE_POS", true);
   t.fuse_fin = flag("DFLO_FUSE_FIN", true);
   t.bc_fuse = flag("DFLO_BC_FUSE", true);
+  t.mfma = flag("DFLO_MFMA", false);
   t.lazy_avg = flag("DFLO_LAZY_AVG", true);
   t.lxf_from_dofs = flag("DFLO_LXF_FROM_DOFS", true);
   t.lim_mask = tri("DFLO_LIM_MASK");

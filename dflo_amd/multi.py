@@ -216,6 +216,10 @@ class MultiConservationLaw:
         self._chk(lib.dflo_hip_multi_stage_timing(self._h, int(enable), C.byref(ms), C.byref(n)))
         return ms.value, n.value
 
+    @property
+    def uses_mfma(self):
+        return bool(lib.dflo_hip_uses_mfma(lib.dflo_hip_multi_engine(self._h, 0)))
+
     def exchange_timing(self, enable=True):
         """(average microseconds the comm stream spent per sampled halo exchange, number of samples) since the last call."""
         us, n = C.c_double(), C.c_int64()

@@ -239,6 +239,11 @@ int dflo_hip_synchronize(dflo_hip_handle h);
  * records stay out of the way of the others); enable = k > 1: every k-th (choose k coprime to 2 and 3; a timed launch costs
  * its stream a few microseconds of bubbles, so a long run samples sparsely); n receives the number of timed stages. */
 int dflo_hip_stage_timing(dflo_hip_handle h, int enable, double *avg_ms, int64_t *n);
+/* 1 if this engine's stage kernel forms its dense per-element basis contractions with matrix instructions (degree 3 with
+ * DFLO_MFMA=1: the eta-derivative of the Qk kernel -- the dense ndof x n_q loops of src/assemble_explicit.cc:85-115 after sum
+ * factorisation -- as v_mfma_f64_4x4x4_4b, the modal <-> nodal tables of FE_DGP, src/main.cc:44-48, as v_mfma_f64_16x16x4),
+ * 0 if the vector units do (the default: measured faster).  A diagnostic for bench.py's roofline.mfma. */
+int dflo_hip_uses_mfma(dflo_hip_handle h);
 
 /* ------------------------------------------------ multi-device halo seam */
 /* Replaces LA::distributed::Vector::update_ghost_values() of the MPI variant
