@@ -124,8 +124,8 @@ def live_traffic(args):
     profiles/r02/hbm_calibration.json).  The mean over every stage-kernel dispatch of the counted steps, i.e. first and later
     stages in the mix of a time step, like `roofline.achieved`.  A third pass of the same kind counts what the instruction side
     did (north_star: "MFMA utilisation"): SQ_VALU_MFMA_BUSY_CYCLES, SQ_ACTIVE_INST_VALU and GRBM_GUI_ACTIVE give
-    mfma_util = MFMA-busy cycles / (kernel cycles x 1024 SIMDs) and valu_busy = VALU-active cycles / 256 CUs / kernel cycles (the
-    profiler's own MfmaUtil / VALUBusy expressions, rocprofv3 --list-avail).
+    mfma_util = MFMA-busy cycles / (kernel cycles x 1024 SIMDs) and valu_busy = 4 x VALU-active quad-cycles / (kernel cycles x 1024
+    SIMDs) (the profiler's own MfmaUtil / VALUBusy expressions, rocprofv3 --list-avail, with the kernel's cycles per XCD).
     Returns (bytes, source, extra) or None when rocprofv3 is missing / fails -- the caller then falls back to the constant of
     profiles/traffic.json and says so."""
     import csv
@@ -164,12 +164,14 @@ def live_traffic(args):
                 v = one_pass(d, "SQ", ["SQ_VALU_MFMA_BUSY_CYCLES", "SQ_INSTS_VALU_MFMA_MOPS_F64", "SQ_ACTIVE_INST_VALU", "GRBM_GUI_ACTIVE"])
                 if all(v.values()):
                     m = {k: sum(x) / len(x) for k, x in v.items()}
-                    extra = {"mfma_util": m["SQ_VALU_MFMA_BUSY_CYCLES"] / (m["GRBM_GUI_ACTIVE"] * 1024.0),
-                             "valu_busy": m["SQ_ACTIVE_INST_VALU"] / 256.0 / m["GRBM_GUI_ACTIVE"],
+                    # GRBM_GUI_ACTIVE comes summed over the 8 XCDs (each counts the kernel's cycles); SQ_ACTIVE_INST_VALU in units of 4 cycles
+                    cyc = m["GRBM_GUI_ACTIVE"] / 8.0
+                    extra = {"mfma_util": m["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * cyc),
+                             "valu_busy": 4.0 * m["SQ_ACTIVE_INST_VALU"] / (1024.0 * cyc),
                              "mfma_mops_f64_per_launch": m["SQ_INSTS_VALU_MFMA_MOPS_F64"],
                              "pipes_source": "live: rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE, "
-                                             "mean of %d stage-kernel dispatches; mfma_util = MFMA busy cycles / (GRBM_GUI_ACTIVE x 1024 SIMDs), "
-                                             "valu_busy = SQ_ACTIVE_INST_VALU / 256 CUs / GRBM_GUI_ACTIVE" % len(v["GRBM_GUI_ACTIVE"])}
+                                             "mean of %d stage-kernel dispatches; kernel cycles = GRBM_GUI_ACTIVE / 8 XCDs, mfma_util = MFMA busy cycles / "
+                                             "(1024 SIMDs x cycles), valu_busy = 4 x SQ_ACTIVE_INST_VALU / (1024 SIMDs x cycles)" % len(v["GRBM_GUI_ACTIVE"])}
             except Exception as e:   # noqa: BLE001
                 print("bench.py: live pipe counters not collected (%s: %s)" % (type(e).__name__, str(e)[:200]), file=sys.stderr, flush=True)
     except Exception as e:   # noqa: BLE001 -- a profiler that is absent, refuses or times out must not cost the bench line

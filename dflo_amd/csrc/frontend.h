@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "../../include/dflo_hip.h"
+#include "../../include/dflo_mesh.h"
 
 namespace dflo_fe {
 

@@ -11,7 +11,7 @@
 #include <type_traits>
 #include <vector>
 
-#include "../../include/dflo_hip.h"
+#include "abi.h"
 #include "basis.h"
 #include "physics.hpp"
 #include "plan.h"

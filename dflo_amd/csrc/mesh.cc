@@ -7,7 +7,7 @@
 // meshes (what "gmsh -2" writes for the transfinite .geo files of the examples), a
 // general quad-soup importer, a Gmsh v2 reader and the owned+ghost partition that replaces
 // parallel::distributed::Triangulation (src_mpi/claw.h:220).
-#include "../../include/dflo_hip.h"
+#include "abi.h"
 
 #include <algorithm>
 #include <cmath>

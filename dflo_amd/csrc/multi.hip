@@ -49,7 +49,7 @@
 #include <unordered_map>
 #include <vector>
 
-#include "../../include/dflo_hip.h"
+#include "abi.h"
 #include "basis.h"
 #include "tunables.h"
 

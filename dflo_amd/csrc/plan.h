@@ -13,7 +13,7 @@
 #include <string>
 #include <vector>
 
-#include "../../include/dflo_hip.h"
+#include "abi.h"
 
 namespace dflo {
 

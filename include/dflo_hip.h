@@ -8,6 +8,13 @@
  * reference function(s) it replaces (paths relative to the reference root).
  * INTEGRATION.md shows the patch a dflo maintainer would apply to call them.
  *
+ * This header is the CONTRACT: what a dflo build calls (INTEGRATION.md sections 1-3) and nothing else.  Beside it:
+ *   dflo_mesh.h           host-side construction / partition of the flat mesh (the stand-alone driver and the tests; dflo
+ *                         itself fills dflo_mesh_t from its Triangulation, include/dflo_hip_dealii.hpp)
+ *   dflo_hip_transport.h  the halo / delivery / sequence-word seams the multi-device driver (dflo_amd/csrc/multi.hip) is written
+ *                         against, and inspection of a multi-device handle -- for a transport of the host program's own
+ *   dflo_hip_diag.h       diagnostics and test hooks (timing, counters, debug math): not part of the contract, not installed
+ *
  * Conventions
  *   - plain C, no exceptions cross the boundary; every function returns
  *     DFLO_OK (0) or a negative dflo_status; dflo_hip_last_error() gives text.
@@ -61,6 +68,10 @@ typedef enum { DFLO_IND_LIMITER = 0, DFLO_IND_DENSITY = 1, DFLO_IND_ENERGY = 2, 
 /* AllParameters::BasisType / MappingType, src/parameters.h:384-387 */
 typedef enum { DFLO_BASIS_QK = 0, DFLO_BASIS_PK = 1 } dflo_basis;
 typedef enum { DFLO_MAP_Q1 = 0, DFLO_MAP_Q2 = 1, DFLO_MAP_CARTESIAN = 2 } dflo_mapping;
+/* how dflo_hip_multi_create* (and dflo_mesh_partition_ex, dflo_mesh.h) cut a mesh: x-slabs of the cell order after a coordinate sort
+ * (C4: the 4001 x 1000 lattice) or recursive coordinate bisection of the cell centres (compact blocks on unstructured meshes, C5;
+ * the MPI variant gets Morton-order blocks from p4est, src_mpi/claw.h:220) */
+typedef enum { DFLO_PART_SLAB = 0, DFLO_PART_RCB = 1 } dflo_partitioner;
 
 /* face neighbour encoding: >=0 neighbour cell, DFLO_NBR_BOUNDARY(id) on a
  * physical boundary, DFLO_NBR_NONE for a face of a ghost cell that leads
@@ -139,14 +150,9 @@ int dflo_hip_create(const dflo_mesh_t *mesh, const dflo_params_t *params, int de
 int dflo_hip_destroy(dflo_hip_handle h);
 const char *dflo_hip_last_error(dflo_hip_handle h); /* h may be NULL: error of the last failed create */
 
-/* Launch all work of this handle on an existing HIP stream (hipStream_t passed
- * as void*); NULL = the handle's own stream. */
-int dflo_hip_set_stream(dflo_hip_handle h, void *hip_stream);
-
 /* -------------------------------------------------------------- state I/O */
 
 int64_t dflo_hip_n_dofs(dflo_hip_handle h);     /* n_cells * ndof */
-int32_t dflo_hip_dofs_per_cell(dflo_hip_handle h);
 int32_t dflo_hip_n_rk(dflo_hip_handle h);       /* stages per step, src/claw.cc:141-159 */
 
 /* current_solution = old_solution = u  (src/ic.cc:118-120); also recomputes
@@ -177,8 +183,6 @@ int dflo_hip_set_boundary_values(dflo_hip_handle h, int which, const double *val
  * advanced by every step); components without a program keep the uploaded values. */
 int dflo_hip_set_boundary_program(dflo_hip_handle h, int32_t boundary_id, int32_t component, int32_t n_ops, const int32_t *ops,
                                   int32_t n_consts, const double *consts);
-/* The boundary-value table in use (which = 0: stage 0, 1: later stages), [n_boundary_faces][k+1][4]. */
-int dflo_hip_get_boundary_values(dflo_hip_handle h, int which, double *values);
 
 /* assemble_system(IntegratorExplicit&) (src/assemble_explicit.cc:433-452): rhs of the current
  * solution with the current cell averages and boundary set `which`; rhs_out [n_dofs], dflo layout. */
@@ -224,159 +228,7 @@ int dflo_hip_get_shock_indicator(dflo_hip_handle h, double *shock_indicator);
 /* Device-side failure flags raised by kernels, checked here (no mid-kernel abort):
  * returns DFLO_OK, DFLO_ERR_NEGATIVE_MEAN_STATE or DFLO_ERR_POSITIVITY_NO_ROOT. */
 int dflo_hip_check(dflo_hip_handle h);
-/* Index (0-based, counted from the last dflo_hip_set_solution) of the time step in which the first failure flag went
- * up, -1 if none: where the reference would have stopped (src/positivity.cc:28-38 throws, :160-169 exits, inside the
- * stage).  dflo_hip_advance looks at the flags every 32 steps and returns early with the error. */
-int dflo_hip_failure_step(dflo_hip_handle h, int64_t *step);
-/* Positivity limiter applied inside the stage kernel (pos_lim without TVB on Qk): counts[0] = cell-stages that failed the
- * cheap nodal-box bound and went through the limiter proper (src/positivity.cc:43-205), counts[1] = cell-stages it
- * changed (theta1 < 1 or theta2 < 1), summed since the last reset.  A diagnostic for bench.py's config.check. */
-int dflo_hip_positivity_stats(dflo_hip_handle h, int64_t *counts, int reset);
 int dflo_hip_synchronize(dflo_hip_handle h);
-
-/* Average duration (ms) of the stage kernel launches since the last reset, measured with HIP events on the
- * engine's stream. enable = 1: every fifth stage is timed (each stage of a 2- or 3-stage step equally often, and the event
- * records stay out of the way of the others); enable = k > 1: every k-th (choose k coprime to 2 and 3; a timed launch costs
- * its stream a few microseconds of bubbles, so a long run samples sparsely); n receives the number of timed stages. */
-int dflo_hip_stage_timing(dflo_hip_handle h, int enable, double *avg_ms, int64_t *n);
-/* 1 if this engine's stage kernel forms its dense per-element basis contractions with matrix instructions (degree 3 with
- * DFLO_MFMA=1: the eta-derivative of the Qk kernel -- the dense ndof x n_q loops of src/assemble_explicit.cc:85-115 after sum
- * factorisation -- as v_mfma_f64_4x4x4_4b, the modal <-> nodal tables of FE_DGP, src/main.cc:44-48, as v_mfma_f64_16x16x4),
- * 0 if the vector units do (the default: measured faster).  A diagnostic for bench.py's roofline.mfma. */
-int dflo_hip_uses_mfma(dflo_hip_handle h);
-
-/* ------------------------------------------------ multi-device halo seam */
-/* Replaces LA::distributed::Vector::update_ghost_values() of the MPI variant
- * (src_mpi/claw.cc:793, src_mpi/limiter.cc:232).  The engine owns cells
- * [0,n_owned) and reads ghost cells [n_owned,n_cells).  pack gathers the DoFs
- * ([n][ndof]) or the cell averages ([n][4]) of the listed owned cells into a
- * contiguous device buffer; unpack scatters a received buffer ([n_ghost][ndof] or
- * [n_ghost][4], ghost order) into the ghost cells.  The transport between the
- * two (RCCL send/recv through torch.distributed) is the caller's.
- * With a TVB limiter the ghost AVERAGES must be refreshed between the update and
- * the limiter of a stage (the MPI variant computes cell averages on owned+ghost
- * cells after the first update_ghost_values, src_mpi/claw.cc:793,653-669):
- *   dflo_hip_stage_update -> exchange averages -> dflo_hip_stage_limit -> exchange DoFs.
- * dflo_hip_stage == dflo_hip_stage_update + dflo_hip_stage_limit. */
-int dflo_hip_stage_update(dflo_hip_handle h, int rk, double dt);
-int dflo_hip_stage_limit(dflo_hip_handle h);
-/* The same stage split by shard set, for overlapping the exchange with compute (what dflo_amd/csrc/multi.hip is written
- * against): part 1 = rim shards (those that read ghost cells), part 2 = interior shards, part 0 = all; for the update of a
- * stage that a TVB limiter follows also part 3 = rim shards + the ring of shards next to them (the limiter of a rim cell
- * reads the new averages of its neighbours there) and part 4 = the others.  dflo_hip_set_stream chooses the stream of
- * the following launches; launches of different parts of one stage may run side by side on different streams (they read
- * the previous stage and write disjoint shards); ordering between the streams is the caller's (events).
- *   open -> update_part(1) -> [limit_part(1) -> pack -> exchange -> unpack on a second stream]
- *        -> update_part(2) -> limit_part(2) -> finish (reductions, CFL minimum)                    */
-int dflo_hip_stage_open(dflo_hip_handle h, int rk, double dt);
-int dflo_hip_stage_update_part(dflo_hip_handle h, int part);
-int dflo_hip_stage_limit_part(dflo_hip_handle h, int part);
-int dflo_hip_stage_finish(dflo_hip_handle h);
-int dflo_hip_n_rim_shards(dflo_hip_handle h);
-int dflo_hip_n_ghost_cells(dflo_hip_handle h);
-int dflo_hip_set_send_cells(dflo_hip_handle h, int32_t n, const int32_t *cells);
-int dflo_hip_pack_send(dflo_hip_handle h, void *device_buffer);
-int dflo_hip_pack_send_avg(dflo_hip_handle h, void *device_buffer);
-int dflo_hip_unpack_ghost(dflo_hip_handle h, const void *device_buffer);     /* also recomputes ghost averages */
-int dflo_hip_unpack_ghost_avg(dflo_hip_handle h, const void *device_buffer);
-/* Instead of unpack_ghost_avg: the limiter passes that follow (Qk) read the ghost cells' averages straight from the received
- * buffer ([n_ghost][4], ghost order) -- one small kernel less between the arrival of the averages and the limiter of the rim
- * cells, the stretch of a TVB stage that every neighbour waits for.  NULL, or the next dflo_hip_unpack_ghost_avg /
- * dflo_hip_unpack_ghost_cells / dflo_hip_set_solution, returns to the averages held by the engine.  Not for runs whose stage
- * kernels read ghost averages too (LxF flux). */
-int dflo_hip_ghost_avg_source(dflo_hip_handle h, const void *device_buffer);
-/* DoFs and cell average of every listed cell in one record, [n][ndof + 4]: the ghost copy then holds the bits of its owner
- * (an average formed again from the DoFs differs from the stage kernel's in the last place; the LxF flux and the TVB
- * differences read it).  What the native multi-device driver ships. */
-int dflo_hip_pack_send_cells(dflo_hip_handle h, void *device_buffer);
-int dflo_hip_unpack_ghost_cells(dflo_hip_handle h, const void *device_buffer);
-/* Face-trace records: when nothing needs more of a ghost cell than its trace on the cut faces and its average
- * -- Qk without the KXRCF indicator: dflo_hip_halo_traces() = 1 -- the stage kernels read the ghost cells from a table of
- * traces, [n_ghost_traces][4][k+1] doubles ordered by (ghost cell, face), and the halo message of a cut face shrinks from
- * the cell's (k+1)^2 * 4 doubles to (k+1) * 4 (Q2: 36 -> 12; the 4-double average travels with pack_send_avg).  The
- * sender lists its (owned cell, face) pairs in the receiver's order (set_send_faces) and packs their traces; the receiver
- * lets the transport write straight into one of the engine's two trace tables (ghost_trace_buffer) and switches the
- * stage kernels to it before the next stage (use_ghost_traces) -- no unpack kernel.  dflo_hip_set_solution fills both
- * tables from the ghost cells' DoFs.  DFLO_HALO_CELLS=1 keeps whole-cell records. */
-int dflo_hip_halo_traces(dflo_hip_handle h);
-int dflo_hip_n_ghost_traces(dflo_hip_handle h);
-int dflo_hip_set_send_faces(dflo_hip_handle h, int32_t n, const int32_t *cells, const int32_t *faces);
-int dflo_hip_pack_send_traces(dflo_hip_handle h, void *device_buffer);
-int dflo_hip_ghost_trace_buffer(dflo_hip_handle h, int which, void **device_ptr);
-int dflo_hip_use_ghost_traces(dflo_hip_handle h, int which);
-/* The engine's two ghost-trace tables ([n_ghost_traces][4][k+1] doubles each) and its table of the parts' time-step minima
- * ([2][16] doubles) in memory of the CALLER's -- a window it exports to other processes as one allocation (the runtime serves small
- * allocations as fragments of shared blocks, which cannot be exported reliably one by one).  The current contents move along;
- * the buffers stay the caller's and must outlive the engine. */
-int dflo_hip_set_ghost_trace_buffers(dflo_hip_handle h, void *table0, void *table1);
-int dflo_hip_set_dt_table_buffer(dflo_hip_handle h, void *table);
-/* The next stage or limiter kernel this engine launches (stage_update_part / stage_limit_part) carries `event` (a hipEvent_t)
- * as its completion signal -- hipExtLaunchKernel's stopEvent -- instead of the caller recording the event behind it: one packet
- * less between two kernels of a stream (the multi-device schedule orders its two streams with one such event per phase).
- * If that launch turns out to be empty the event is recorded the plain way. */
-int dflo_hip_attach_event(dflo_hip_handle h, void *event);
-/* Delivery by the stage kernel itself (one process per GPU over mapped tables; Qk, ghost cells by their traces).  set_deliver,
- * once per receive area (0 | 1): the records of the send list of set_send_faces go, segment by segment as in pack_send_to, to
- * dst[i] -- the neighbours' trace tables of that area --, and flags[i] are the neighbours' sequence words.  stage_deliver arms
- * the NEXT launch over all shards (stage_update_part(h, 0) / stage(h, ..)): every workgroup whose shard has cut faces forms the
- * traces of its new state on them (the bits face_trace / pack_send_traces would give) and stores them at their destination;
- * the last such workgroup publishes `seq` in the words.  No rim launch of its own, no pack kernel, no second stream:
- * update_ghost_values (src_mpi/claw.cc:793) is part of the kernel that produced the values. */
-int dflo_hip_set_deliver(dflo_hip_handle h, int area, int n_segments, const int32_t *first, void *const *dst, void *const *flags);
-int dflo_hip_stage_deliver(dflo_hip_handle h, int area, uint64_t seq);
-/* ... and the arrival of the neighbours' traces of the stage BEFORE can be awaited inside that launch as well: set_arrival_words
- * names this engine's own sequence words (one per neighbour that sends; fine-grained memory) and a host-mapped failure word;
- * stage_await(seq), together with stage_deliver, makes the workgroups of the shards that read ghost traces poll the words behind
- * their own loads until they have reached seq (30 s, then the failure word).  The other workgroups wait for nothing.  Only where
- * the trace tables are fine-grained memory (or written by this device itself): the traces are read inside the running kernel. */
-int dflo_hip_set_arrival_words(dflo_hip_handle h, int n, void *const *words, void *fail);
-int dflo_hip_stage_await(dflo_hip_handle h, uint64_t seq);
-/* With a TVB limiter between update and send (src_mpi/limiter.cc:232: a second update_ghost_values) the exchange rides in BOTH
- * kernels of a stage.  set_deliver_averages, once per receive area: the averages of the cells of set_send_cells go to dst[i] (the
- * neighbours' average areas: [4] doubles per cell), flags[i] are the neighbours' words for them, words[] this engine's own words
- * for the neighbours' averages.  stage_deliver_averages arms the next launch over all shards: the workgroups of the shards on a
- * cut deliver their cells' new averages (and the stage kernel keeps those shards off the list of marked shards).  limit_exchange
- * arms the next limiter pass over all shards (stage_limit): one extra wavefront per shard on a cut waits for the neighbours'
- * averages to reach average_seq (poll_in_kernel; else the caller has waited), limits the shard with them (ghost_avg_source) and
- * delivers the traces of the limited state into the neighbours' tables of trace_area, publishing trace_seq.  Needs a pass that
- * walks the list of marked shards (limiter_walks_list: TVB on Qk squares with marks). */
-int dflo_hip_set_deliver_averages(dflo_hip_handle h, int area, int n_segments, const int32_t *first, void *const *dst, void *const *flags,
-                                  int n_words, void *const *words, void *fail);
-int dflo_hip_stage_deliver_averages(dflo_hip_handle h, int area, uint64_t seq);
-int dflo_hip_limit_exchange(dflo_hip_handle h, int trace_area, uint64_t trace_seq, uint64_t average_seq, int poll_in_kernel);
-int dflo_hip_limiter_walks_list(dflo_hip_handle h);
-/* The kernels that deliver store their values at system scope -- written through where the destination is fine-grained memory
- * -- and wait for them; where the destinations are PLAIN device memory (of another process on this device: only a release writes
- * such stores back) every delivering workgroup also has to fence: plain = 1. */
-int dflo_hip_deliver_to_plain_memory(dflo_hip_handle h, int plain);
-/* Pack and deliver in one kernel (several engines in one process): records [first[i], first[i+1]) of the send list are
- * written at dst[i] -- the receive area of the i-th peer, on this device or on another one reached over xGMI peer access --
- * instead of into a staging buffer that a copy per peer then moves.  kind: 0 whole cells ([ndof + 4] doubles per record,
- * as pack_send_cells), 1 cell averages ([4], as pack_send_avg), 2 face traces ([4 (k+1)], as pack_send_traces; the send
- * list is that of set_send_faces).  n_segments <= 16. */
-int dflo_hip_pack_send_to(dflo_hip_handle h, int kind, int n_segments, const int32_t *first, void *const *dst);
-/* The same, and the kernel tells the receivers: once every record of the launch is visible system-wide, the workgroup that
- * finishes last stores `seq` (release, system scope) into the 64-bit words flags[i] -- sequence words in the receivers'
- * fine-grained memory, which a one-wavefront wait kernel on the receiver's comm stream polls.  One process per GPU without a
- * transport library on the per-stage path: the receive areas and the words are mapped through hipIpcGetMemHandle /
- * hipIpcOpenMemHandle once, at create (dflo_hip_multi_create_rank with DFLO_RANK_TRANSPORT=ipc).  Replaces the same
- * update_ghost_values (src_mpi/claw.cc:793, src_mpi/limiter.cc:232).  flags NULL: dflo_hip_pack_send_to. */
-int dflo_hip_pack_send_to_signal(dflo_hip_handle h, int kind, int n_segments, const int32_t *first, void *const *dst,
-                                 void *const *flags, uint64_t seq);
-/* device address of the {dt, elapsed time, raw CFL minimum} and {res_norm_sq per stage} scalars (src_mpi/claw.cc:579,777) */
-int dflo_hip_scalar_ptrs(dflo_hip_handle h, void **dt_ptr, void **res_ptr);
-/* The time step of a run over several engines (Utilities::MPI::min(global_dt), src_mpi/claw.cc:579) without a host hop and
- * without a kernel of its own.  Every engine keeps a device table mins[2][16] of raw CFL minima: row p holds, slot by slot,
- * the minima of all parts for the step of parity p (steps counted since set_solution).  The reductions that end a step write
- * this engine's minimum into slot my_slot of the next step's row -- of its own table and of the peer_tables handed over here
- * (engines of the same process: plain stores over xGMI peer access; entry my_slot and null entries are skipped) -- and every
- * consumer of the time step (stage kernels, boundary programs, the clock) takes the minimum over the n_slots of its row and
- * applies the rules of src/claw.cc:468-476 itself.  The caller orders the streams: the next step's first kernel after the
- * peers' reductions.  One process per GPU: n_slots = 1 and an all-reduce(min) in place on dflo_hip_dt_slot (the slot the
- * next step to run reads) between the two.  n_slots = 0 (the default): one engine, the reductions apply the rules. */
-int dflo_hip_dt_table(dflo_hip_handle h, void **table);
-int dflo_hip_dt_exchange(dflo_hip_handle h, int my_slot, int n_slots, void *const *peer_tables);
-int dflo_hip_dt_slot(dflo_hip_handle h, void **slot);
 
 /* ------------------------------------------------ several devices behind one handle */
 /* The native multi-device driver (dflo_amd/csrc/multi.hip): partitions the undivided mesh, owns one engine per part and
@@ -399,7 +251,11 @@ int dflo_hip_dt_slot(dflo_hip_handle h, void **slot);
  *                               (MPI_Bcast where src_mpi/main.cc has MPI; a torch.distributed broadcast in bench.py).
  *                               set_solution / boundary values take global arrays and use this rank's cells; the get_*
  *                               calls fill this rank's owned cells and leave the rest of the array alone.
- * partitioner: dflo_partitioner (declared with dflo_mesh_partition_ex below: 0 = slabs, 1 = RCB). */
+ * partitioner: dflo_partitioner (above: 0 = slabs, 1 = RCB).
+ * One process per GPU: create_rank*, set_solution, advance / step / compute_dt, residual, the limiter calls and destroy are
+ * COLLECTIVE over the ranks (every rank makes the same calls in the same order, as the MPI variant's do); with
+ * DFLO_RANK_TRANSPORT=ipc the ranks also meet inside set_solution and destroy (nobody frees or rewrites a window a neighbour's
+ * kernel may still store into), so a rank that leaves early must still call destroy. */
 #define DFLO_COMM_ID_BYTES 128
 typedef struct dflo_hip_multi *dflo_hip_multi_handle;
 int dflo_hip_multi_create(const dflo_mesh_t *mesh, const dflo_params_t *params, int n_devices, const int *device_ids,
@@ -421,36 +277,11 @@ typedef int (*dflo_allreduce_fn)(void *user, double *values, int n, int op, void
 int dflo_hip_multi_create_rank_custom(const dflo_mesh_t *mesh, const dflo_params_t *params, int device_id, int rank, int n_ranks,
                                       dflo_exchange_fn exchange, dflo_allreduce_fn allreduce, void *user, int partitioner,
                                       dflo_hip_multi_handle *out);
-/* Self-halo: ONE part on ONE device that is its own neighbour across a virtual cut (dflo_mesh_partition_self below:
- * n_virtual = 1 cuts at the periodic faces in x, >= 2 between the virtual parts of `partitioner`), driven through the complete
- * stage schedule of a multi-device run -- rim shards beside the interior on two streams, pack, transport into the trace table,
- * the time-step reduction -- where a plain one-part handle issues the single engine's launches.  A measuring device for boxes
- * with one GPU: its rate over the plain engine's bounds the weak-scaling efficiency of a rank whose neighbours are as fast as
- * itself (update_ghost_values / Utilities::MPI::min of src_mpi/claw.cc:793, 579 and src_mpi/limiter.cc:232 all happen, against
- * itself).  Results are those of the single engine, bit for bit on the nodal basis.  transport: dflo_self_transport --
- * DIRECT the one-process schedule (pack kernels store into the own trace table), RCCL the one-process-per-GPU schedule on a
- * one-rank communicator (grouped ncclSend / ncclRecv to itself, ncclAllReduce(min)), COPY staging buffer + hipMemcpyPeerAsync,
- * IPC the one-process-per-GPU schedule with the sequence-word transport of DFLO_RANK_TRANSPORT=ipc against itself. */
-typedef enum { DFLO_SELF_DIRECT = 0, DFLO_SELF_RCCL = 1, DFLO_SELF_COPY = 2, DFLO_SELF_IPC = 3 } dflo_self_transport;
-int dflo_hip_multi_create_self(const dflo_mesh_t *mesh, const dflo_params_t *params, int device_id, int n_virtual, int partitioner,
-                               int transport, dflo_hip_multi_handle *out);
 /* One process per GPU with DFLO_RANK_TRANSPORT=ipc: collective (the ranks meet before anybody frees a window its neighbours map). */
 int dflo_hip_multi_destroy(dflo_hip_multi_handle m);
 const char *dflo_hip_multi_last_error(dflo_hip_multi_handle m); /* m may be NULL: error of the last failed create */
-int dflo_hip_multi_n_parts(dflo_hip_multi_handle m);            /* parts of the partition */
-int dflo_hip_multi_n_local(dflo_hip_multi_handle m);            /* parts (engines) this process owns */
-dflo_hip_handle dflo_hip_multi_engine(dflo_hip_multi_handle m, int i); /* i-th local engine (timing, inspection) */
-int dflo_hip_multi_part_cells(dflo_hip_multi_handle m, int i, int32_t *n_owned, int32_t *n_ghost, const int64_t **global_ids);
-int64_t dflo_hip_multi_n_dofs(dflo_hip_multi_handle m);         /* of the undivided mesh */
-int64_t dflo_hip_multi_n_owned_dofs(dflo_hip_multi_handle m);   /* owned by this process */
-int32_t dflo_hip_multi_n_rk(dflo_hip_multi_handle m);
 /* the calls of a single engine, on the undivided mesh */
 int dflo_hip_multi_set_solution(dflo_hip_multi_handle m, const double *u);
-/* The same for one local part in ITS numbering (owned cells first, then its ghost cells; dflo_hip_multi_part_mesh
- * gives the part's mesh, owned by the handle): a rank of a large run evaluates the initial data on its own cells only,
- * as VectorTools::interpolate does on the locally owned range (src_mpi/ic.cc). */
-const dflo_mesh_t *dflo_hip_multi_part_mesh(dflo_hip_multi_handle m, int i);
-int dflo_hip_multi_set_part_solution(dflo_hip_multi_handle m, int i, const double *u_part);
 int dflo_hip_multi_get_solution(dflo_hip_multi_handle m, double *u);
 int dflo_hip_multi_get_cell_average(dflo_hip_multi_handle m, double *avg);
 int32_t dflo_hip_multi_n_boundary_faces(dflo_hip_multi_handle m);
@@ -465,75 +296,9 @@ int dflo_hip_multi_advance(dflo_hip_multi_handle m, int n_steps, double *elapsed
 int dflo_hip_multi_apply_limiter(dflo_hip_multi_handle m);
 int dflo_hip_multi_apply_positivity_limiter(dflo_hip_multi_handle m);
 int dflo_hip_multi_check(dflo_hip_multi_handle m);
-int dflo_hip_multi_synchronize(dflo_hip_multi_handle m);
-int dflo_hip_multi_stage_timing(dflo_hip_multi_handle m, int enable, double *avg_ms, int64_t *n); /* slowest local part */
-/* Reporting (bench.py's N > 1 line): the average time, in microseconds, that the comm stream of the local parts spent in an
- * exchange of halo records (every fifth exchange is bracketed by events: one process per GPU -- the grouped send / receive,
- * the rendezvous with the peers included; one process -- the wait for the peers' records), and what the transport is: the
- * number of ranks and this process's rank AS THE RCCL COMMUNICATOR REPORTS THEM (ncclCommCount / ncclCommUserRank; the
- * partition's numbers for the other transports, rank -1 in one process) and a description of the transport in use. */
-int dflo_hip_multi_exchange_timing(dflo_hip_multi_handle m, int enable, double *avg_us, int64_t *n);
-int dflo_hip_multi_comm_info(dflo_hip_multi_handle m, int32_t *comm_count, int32_t *comm_rank, char *transport, int32_t transport_len);
-
-/* Test hook: evaluates the device reciprocal / square-root forms the flux functions use
- * (dflo_amd/csrc/physics.hpp) on n host doubles. */
-int dflo_hip_debug_math(int n, const double *x, double *rcp_out, double *sqrt_out);
-/* Test hook: exp() of the device library and the form the kinetic split fluxes use for their Gaussians (fexp_neg,
- * dflo_amd/csrc/physics.hpp; arguments <= 0), side by side. */
-int dflo_hip_debug_exp(int n, const double *x, double *exp_library, double *exp_flux);
-
-/* ------------------------------------------- host-side mesh construction */
-/* What GridIn::read_msh + Triangulation hand to dflo (src/claw.cc:957-967),
- * flattened.  The returned mesh owns its arrays; free with dflo_mesh_free. */
-
-/* nx x ny squares on [x0,x0+nx*h] x [y0,y0+ny*h], cell c = i + nx*j.
- * side_bc[4] = boundary id on the faces x=min, x=max, y=min, y=max, or -1 for
- * a periodic side (src_mpi semantics, src_mpi/assemble_explicit.cc:186-260). */
-int dflo_mesh_cartesian(int32_t nx, int32_t ny, double x0, double y0, double h, const int32_t side_bc[4],
-                        int32_t degree, dflo_mesh_t **out);
-/* General conforming quad mesh: vertices [n_vertices][2], quads [n_quads][4]
- * (any consistent vertex order; re-ordered to deal.II's), boundary edges
- * [n_bedges][2] vertex pairs with ids.  mapping = DFLO_MAP_Q1. */
-int dflo_mesh_from_quads(int32_t n_vertices, const double *vertices, int32_t n_quads, const int32_t *quads,
-                         int32_t n_bedges, const int32_t *bedges, const int32_t *bedge_id, int32_t degree,
-                         dflo_mesh_t **out);
-/* Gmsh v2 ASCII .msh with quads + physical lines (what "gmsh -2 file.geo" writes, README.md:70-72). */
-int dflo_mesh_read_gmsh(const char *path, int32_t degree, int32_t mapping, dflo_mesh_t **out);
-/* Pair the boundary faces with ids id_first / id_second, offset along direction (0 = x, 1 = y), into periodic
- * neighbours in place: GridTools::collect_periodic_faces + add_periodicity for the "type = periodic", "pair",
- * "direction" entries of a boundary subsection (src_mpi/parameters.cc:397-410, src_mpi/claw.cc:156-200). */
-int dflo_mesh_make_periodic(dflo_mesh_t *mesh, int32_t id_first, int32_t id_second, int32_t direction);
-/* Sub-mesh of rank `rank` of `n_ranks` (contiguous slabs of the cell order after a
- * coordinate sort) with one layer of face-neighbour ghost cells -- the flat
- * equivalent of parallel::distributed::Triangulation's owned+ghost view
- * (src_mpi/claw.h:220).  send_cells/send_offsets (size n_ranks+1) list owned cells
- * to send per destination rank; recv_offsets the ghost ranges per source rank
- * (ghost cells are ordered by source rank). Arrays owned by the mesh. */
-int dflo_mesh_partition(const dflo_mesh_t *mesh, int32_t n_ranks, int32_t rank, dflo_mesh_t **out,
-                        const int32_t **send_cells, const int32_t **send_offsets, const int32_t **recv_offsets);
-/* The same with a choice of partitioner (dflo_partitioner): DFLO_PART_SLAB as above (C4: x-slabs of the 4001 x 1000
- * lattice), DFLO_PART_RCB recursive coordinate bisection of the cell centres (compact blocks on unstructured meshes, C5;
- * the MPI variant gets Morton-order blocks from p4est, src_mpi/claw.h:220).  partition_owners writes the owner rank of
- * every cell ([n_cells]) without building a sub-mesh. */
-typedef enum { DFLO_PART_SLAB = 0, DFLO_PART_RCB = 1 } dflo_partitioner;
-int dflo_mesh_partition_ex(const dflo_mesh_t *mesh, int32_t n_ranks, int32_t rank, int32_t method, dflo_mesh_t **out,
-                           const int32_t **send_cells, const int32_t **send_offsets, const int32_t **recv_offsets);
-int dflo_mesh_partition_owners(const dflo_mesh_t *mesh, int32_t n_ranks, int32_t method, int32_t *owner_out);
-/* Self-halo partition: ONE part that owns every cell and is its own neighbour across a virtual cut (n_virtual >= 2: the
- * non-periodic faces between the cells of different virtual owners of dflo_mesh_partition_owners; n_virtual == 1: the
- * periodic faces in x).  Every cell on the cut gets a ghost copy; send list = those cells, offsets for the one "peer" 0.
- * A measuring device (dflo_hip_multi_create_self): one full-size part runs the whole schedule that replaces
- * update_ghost_values / Utilities::MPI::min (src_mpi/claw.cc:793, 579) with itself as the neighbour. */
-int dflo_mesh_partition_self(const dflo_mesh_t *mesh, int32_t n_virtual, int32_t method, dflo_mesh_t **out,
-                             const int32_t **send_cells, const int32_t **send_offsets, const int32_t **recv_offsets);
-void dflo_mesh_free(dflo_mesh_t *mesh);
-const char *dflo_mesh_last_error(void);
-
-/* Initial condition by nodal interpolation for Qk (VectorTools::interpolate, src/ic.cc:104-121):
- * xy [n_cells][n_s][2] = support point coordinates in dflo's DoF order. */
-int dflo_mesh_support_points(const dflo_mesh_t *mesh, double *xy);
 
 #ifdef __cplusplus
 }
 #endif
 #endif /* DFLO_HIP_H */
+

@@ -1,4 +1,4 @@
-"""CPU: the C-ABI library loads, exports every symbol include/dflo_hip.h declares, the host-side mesh
+"""CPU: the C-ABI library loads, exports every symbol the headers of include/ declare, the host-side mesh
 builders work, and the engine refuses to run without a GPU (no CPU fallback)."""
 import ctypes as C
 import os
@@ -14,19 +14,60 @@ from dflo_amd import _lib
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared_symbols():
-    text = open(os.path.join(ROOT, "include", "dflo_hip.h")).read()
-    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(dflo_(?:hip|mesh)_\w+)\s*\(", text)))
+HEADERS = ("dflo_hip.h", "dflo_mesh.h", "dflo_hip_transport.h", "dflo_hip_diag.h")
+
+
+def declared_symbols(headers=HEADERS):
+    out = set()
+    for h in headers:
+        text = open(os.path.join(ROOT, "include", h)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        out |= set(re.findall(r"\b(dflo_(?:hip|mesh)_\w+)\s*\(", text))
+    return sorted(out)
 
 
 def test_library_exports_every_declared_symbol():
+    """the four headers of include/ -- the contract, the host-side mesh helpers, the seams below the contract, the diagnostics --
+    together declare exactly what the library exports and what the Python binding lists; no symbol is declared twice"""
     syms = declared_symbols()
     assert len(syms) >= 40
     for s in syms:
         assert hasattr(_lib.lib, s), "libdflo_hip.so does not export %s" % s
     # and the python binding lists the same set
     assert sorted(_lib.SYMBOLS) == syms
+    assert sum(len(declared_symbols((h,))) for h in HEADERS) == len(syms)
+    # what the library exports under the ABI's prefixes and no header declares would be an undocumented seam
+    out = os.popen("nm -D --defined-only %s" % _lib.LIB_PATH).read()
+    exported = set(re.findall(r"\bT (dflo_(?:hip|mesh)_\w+)$", out, flags=re.M))
+    assert exported - set(syms) <= {"dflo_hip_create_with_cell_size", "dflo_hip_run"}, sorted(exported - set(syms))
+
+
+def test_the_contract_header_is_small_and_stands_alone():
+    """include/dflo_hip.h is what a dflo maintainer reads: the drop-in surface of SURVEY 8b and the multi-device driver, <= 45
+    functions, no transport plumbing and no debug hooks; the deal.II adaptor needs nothing else, the stand-alone C++ driver nothing
+    but it and the mesh helpers; every header compiles on its own as C99 and as C++."""
+    import subprocess
+    pub = declared_symbols(("dflo_hip.h",))
+    assert len(pub) <= 45, len(pub)
+    for must in ("dflo_hip_create", "dflo_hip_destroy", "dflo_hip_last_error", "dflo_hip_set_solution", "dflo_hip_get_solution",
+                 "dflo_hip_get_cell_average", "dflo_hip_set_boundary_values", "dflo_hip_residual", "dflo_hip_compute_dt", "dflo_hip_step",
+                 "dflo_hip_advance", "dflo_hip_apply_limiter", "dflo_hip_apply_positivity_limiter", "dflo_hip_multi_create",
+                 "dflo_hip_multi_create_rank", "dflo_hip_multi_advance", "dflo_hip_multi_destroy"):   # SURVEY 8b + INTEGRATION.md
+        assert must in pub, must
+    for s in pub:
+        assert not any(w in s for w in ("debug", "deliver", "arrival", "pack_", "unpack_", "_dt_table", "_dt_slot", "attach_event", "timing")), s
+    txt = open(os.path.join(ROOT, "include", "dflo_hip.h")).read()
+    assert "#include \"dflo_" not in txt     # the contract includes none of the others
+    adaptor = open(os.path.join(ROOT, "include", "dflo_hip_dealii.hpp")).read()
+    assert set(re.findall(r'#include "(dflo_\w+\.h)"', adaptor)) == {"dflo_hip.h"}
+    assert set(re.findall(r"\b(dflo_(?:hip|mesh)_\w+)\s*\(", re.sub(r"//[^\n]*", "", adaptor))) <= set(pub)
+    run_cc = "".join(open(os.path.join(ROOT, "dflo_amd", "csrc", f)).read() for f in ("dflo_run.cc", "frontend.cc"))
+    used = set(re.findall(r"\b(dflo_(?:hip|mesh)_\w+)\s*\(", re.sub(r"//[^\n]*", "", run_cc))) - {"dflo_hip_run"}
+    assert used <= set(declared_symbols(("dflo_hip.h", "dflo_mesh.h"))), sorted(used - set(declared_symbols(("dflo_hip.h", "dflo_mesh.h"))))
+    for h in HEADERS:
+        for lang in (["gcc", "-x", "c", "-std=c99"], ["g++", "-x", "c++"]):
+            r = subprocess.run(lang + ["-fsyntax-only", "-Wall", "-Werror", os.path.join(ROOT, "include", h)], capture_output=True, text=True)
+            assert r.returncode == 0, (h, r.stderr[-400:])
 
 
 def test_product_does_not_touch_the_oracle():
@@ -331,7 +372,7 @@ def test_mesh_flattening_against_an_independent_derivation(kind):
 def test_dealii_adaptor_calls_match_the_c_abi():
     """include/dflo_hip_dealii.hpp cannot be compiled here (it needs deal.II), so at least every dflo_* entry point it calls has
     to exist in include/dflo_hip.h with the number of arguments it is called with -- the header moves on, the adaptor must follow."""
-    h = open(os.path.join(ROOT, "include", "dflo_hip.h")).read()
+    h = open(os.path.join(ROOT, "include", "dflo_hip.h")).read()     # (the contract alone: the adaptor includes nothing else)
     a = open(os.path.join(ROOT, "include", "dflo_hip_dealii.hpp")).read()
     a = re.sub(r"//[^\n]*", "", a)
     a = re.sub(r"/\*.*?\*/", "", a, flags=re.S)

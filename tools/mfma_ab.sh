@@ -34,11 +34,11 @@ for k in sorted(vals):
     c = {n: sum(v) / len(v) for n, v in vals[k].items()}
     print("  " + k)
     print("     " + "  ".join("%s %.4g" % (n, c[n]) for n in sorted(c)))
-    g = c.get("GRBM_GUI_ACTIVE", 0.0)
+    g = c.get("GRBM_GUI_ACTIVE", 0.0) / 8.0   # summed over the 8 XCDs
     if g:
-        print("     mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 1024 SIMDs) = %.4f;  valu_busy = SQ_ACTIVE_INST_VALU / 256 CUs / GRBM_GUI_ACTIVE = %.4f;  co-execution cycles / MFMA busy cycles = %.4f"
-              % (c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / (g * 1024), c.get("SQ_ACTIVE_INST_VALU", 0) / 256 / g,
-                 c.get("SQ_VALU_MFMA_COEXEC_CYCLES", 0) / max(c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0), 1.0)))
+        mf, va = c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / 1024 / g, 4 * c.get("SQ_ACTIVE_INST_VALU", 0) / 1024 / g
+        print("     kernel cycles = GRBM_GUI_ACTIVE / 8 XCDs = %.0f;  mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x cycles) = %.4f;  valu_busy = 4 x SQ_ACTIVE_INST_VALU / (1024 SIMDs x cycles) = %.4f;  "
+              "MFMA + VALU = %.4f;  co-execution cycles / MFMA busy cycles = %.4f" % (g, mf, va, mf + va, c.get("SQ_VALU_MFMA_COEXEC_CYCLES", 0) / max(c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0), 1.0)))
 PY
 done
 } 2>&1 | tee $OUT/${TAG}_mfma_ab.txt
