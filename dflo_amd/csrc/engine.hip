@@ -107,6 +107,7 @@ struct dflo_hip_engine {
   unsigned long long **d_wt_flag = nullptr;   // dflo_hip_set_arrival_words: this engine's own words for the neighbours' traces
   int wt_n = 0;
   int *wt_fail = nullptr;
+  long long wt_ticks = 0;   // how long a workgroup polls a neighbour's word before it raises wt_fail (DFLO_IPC_TIMEOUT_S x 100 MHz; 0: for ever)
   unsigned long long wt_seq = 0;
   bool wt_armed = false;
   int dl_fence = 0;   // dflo_hip_deliver_to_plain_memory: the destinations are plain (not fine-grained) device memory
@@ -188,14 +189,30 @@ std::string g_create_error;
 // memory another device's kernel writes while this device works (ghost-trace tables, the table of the parts' time-step minima):
 // plain device memory -- coherent at kernel boundaries, which is what the schedule relies on -- or, DFLO_PEER_FINEGRAINED=1,
 // fine-grained device memory, coherent at every access
+// DFLO_POISON_ALLOC=1 (developer switch, tests/test_gpu_round6.py): every device buffer of an engine starts out as 0xFF bytes (NaN as a
+// double, -1 as an integer) instead of whatever the allocator hands over -- fresh memory reads as zero, a block the process has used
+// before does not (LAB R5.15 / R6.3: the first engine created after a multi-device driver took the driver's freed window of sequence
+// words).  Nothing may depend on the difference.
+bool poison_alloc() {
+  static const bool on = [] { const char *e = std::getenv("DFLO_POISON_ALLOC"); return e && std::atoi(e) != 0; }();
+  return on;
+}
+hipError_t dmalloc(void **p, size_t bytes) {
+  const hipError_t e = hipMalloc(p, bytes);
+  if (e == hipSuccess && poison_alloc()) (void)hipMemset(*p, 0xFF, bytes);
+  return e;
+}
 hipError_t peer_malloc(void **p, size_t bytes, bool fine) {
-  return fine ? hipExtMallocWithFlags(p, bytes, hipDeviceMallocFinegrained) : hipMalloc(p, bytes);
+  if (!fine) return dmalloc(p, bytes);
+  const hipError_t e = hipExtMallocWithFlags(p, bytes, hipDeviceMallocFinegrained);
+  if (e == hipSuccess && poison_alloc()) (void)hipMemset(*p, 0xFF, bytes);
+  return e;
 }
 
 template <typename T>
 int upload(dflo_hip_engine *h, T **dst, const std::vector<T> &src) {
   size_t bytes = std::max<size_t>(src.size(), 1) * sizeof(T);
-  HIPCHK(h, hipMalloc((void **)dst, bytes));
+  HIPCHK(h, dmalloc((void **)dst, bytes));
   if (!src.empty()) HIPCHK(h, hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
   return DFLO_OK;
 }
@@ -609,6 +626,7 @@ int launch_update(dflo_hip_engine *h, double *rhs_out, int part) {
     a.wt_n = h->wt_n;
     a.wt_seq = h->wt_seq;
     a.wt_fail = h->wt_fail;
+    a.wt_ticks = h->wt_ticks;
     h->wt_armed = false;
   }
   a.tvb_M = h->prm.limiter_type == DFLO_LIMITER_TVB ? h->prm.M : -1.0;
@@ -748,6 +766,7 @@ int launch_limiter(dflo_hip_engine *h, int tvb, int pos, int part, bool stage_da
       l.wt_n = h->wta_n;
       l.wt_seq = h->lim_x_await;
       l.wt_fail = h->wt_fail;
+      l.wt_ticks = h->wt_ticks;
     }
     h->lim_x_area = -1;
   }
@@ -1003,6 +1022,7 @@ int dflo_hip_create_with_cell_size(const dflo_mesh_t *mesh, const dflo_params_t 
   h->peer_fine = tun.peer_finegrained;
   h->bc_fuse = tun.bc_fuse;
   h->mfma = tun.mfma && h->N == 4;
+  h->wt_ticks = (long long)tun.ipc_timeout_s * 100000000LL;
   h->ns = mesh->basis == DFLO_BASIS_PK ? h->N * (h->N + 1) / 2 : h->N * h->N;
   h->ndof = 4 * h->ns;
   h->mapping = mesh->mapping == DFLO_MAP_Q2 ? DFLO_MAP_Q1 : mesh->mapping;
@@ -1042,17 +1062,17 @@ int dflo_hip_create_with_cell_size(const dflo_mesh_t *mesh, const dflo_params_t 
   const Plan &p = h->plan;
   const size_t nU = (size_t)p.n_slots * h->ndof;
   for (int i = 0; i < 3; ++i)
-    if (hipMalloc((void **)&h->U[i], nU * sizeof(double)) != hipSuccess) { h->err = "hipMalloc(U) failed"; return bail(DFLO_ERR_NOMEM); }
+    if (dmalloc((void **)&h->U[i], nU * sizeof(double)) != hipSuccess) { h->err = "hipMalloc(U) failed"; return bail(DFLO_ERR_NOMEM); }
   for (int i = 0; i < 2; ++i)
-    if (hipMalloc((void **)&h->avg[i], (size_t)p.n_slots * 4 * sizeof(double)) != hipSuccess) { h->err = "hipMalloc(avg) failed"; return bail(DFLO_ERR_NOMEM); }
-  if (hipMalloc((void **)&h->rhs, nU * sizeof(double)) != hipSuccess) { h->err = "hipMalloc(rhs) failed"; return bail(DFLO_ERR_NOMEM); }
-  if (hipMalloc((void **)&h->user_buf, nU * sizeof(double)) != hipSuccess) { h->err = "hipMalloc(user_buf) failed"; return bail(DFLO_ERR_NOMEM); }
+    if (dmalloc((void **)&h->avg[i], (size_t)p.n_slots * 4 * sizeof(double)) != hipSuccess) { h->err = "hipMalloc(avg) failed"; return bail(DFLO_ERR_NOMEM); }
+  if (dmalloc((void **)&h->rhs, nU * sizeof(double)) != hipSuccess) { h->err = "hipMalloc(rhs) failed"; return bail(DFLO_ERR_NOMEM); }
+  if (dmalloc((void **)&h->user_buf, nU * sizeof(double)) != hipSuccess) { h->err = "hipMalloc(user_buf) failed"; return bail(DFLO_ERR_NOMEM); }
   for (int i = 0; i < 3; ++i) hipMemset(h->U[i], 0, nU * sizeof(double));
   std::vector<int32_t> kinds(p.bface_id.size());
   for (size_t b = 0; b < kinds.size(); ++b) kinds[b] = params->bc_kind[p.bface_id[b]];
   const size_t nb = std::max<size_t>(p.bface_cell.size(), 1) * h->N * 4;
   for (int w = 0; w < 2; ++w) {
-    if (hipMalloc((void **)&h->bval[w], nb * sizeof(double)) != hipSuccess) { h->err = "hipMalloc(bval) failed"; return bail(DFLO_ERR_NOMEM); }
+    if (dmalloc((void **)&h->bval[w], nb * sizeof(double)) != hipSuccess) { h->err = "hipMalloc(bval) failed"; return bail(DFLO_ERR_NOMEM); }
     hipMemset(h->bval[w], 0, nb * sizeof(double));
   }
   if ((rc = upload(h, &h->bface_kind, kinds))) return bail(rc);
@@ -1138,12 +1158,12 @@ int dflo_hip_create_with_cell_size(const dflo_mesh_t *mesh, const dflo_params_t 
     if ((rc = upload(h, &h->d_cell_vert, p.cell_vert))) return bail(rc);
   }
   const size_t nsh = std::max(p.n_shards, 1);
-  if (hipMalloc((void **)&h->shard_res, 3 * nsh * sizeof(double)) != hipSuccess ||
-      hipMalloc((void **)&h->shard_dtmin, nsh * sizeof(double)) != hipSuccess ||
-      hipMalloc((void **)&h->res_sq, 4 * sizeof(double)) != hipSuccess || hipMalloc((void **)&h->fin_partial, 4 * kFinBlocks * sizeof(double)) != hipSuccess ||
-      hipMalloc((void **)&h->dt_dev, 4 * sizeof(double)) != hipSuccess || hipMalloc((void **)&h->fin_counter, 4 * sizeof(int)) != hipSuccess ||
-      peer_malloc((void **)&h->dt_mins, 2 * kDtSlots * sizeof(double), h->peer_fine) != hipSuccess || hipMalloc((void **)&h->pos_stats, 2 * sizeof(unsigned long long)) != hipSuccess ||
-      hipMalloc((void **)&h->send_done, 4 * sizeof(unsigned int)) != hipSuccess) {
+  if (dmalloc((void **)&h->shard_res, 3 * nsh * sizeof(double)) != hipSuccess ||
+      dmalloc((void **)&h->shard_dtmin, nsh * sizeof(double)) != hipSuccess ||
+      dmalloc((void **)&h->res_sq, 4 * sizeof(double)) != hipSuccess || dmalloc((void **)&h->fin_partial, 4 * kFinBlocks * sizeof(double)) != hipSuccess ||
+      dmalloc((void **)&h->dt_dev, 4 * sizeof(double)) != hipSuccess || dmalloc((void **)&h->fin_counter, 4 * sizeof(int)) != hipSuccess ||
+      peer_malloc((void **)&h->dt_mins, 2 * kDtSlots * sizeof(double), h->peer_fine) != hipSuccess || dmalloc((void **)&h->pos_stats, 2 * sizeof(unsigned long long)) != hipSuccess ||
+      dmalloc((void **)&h->send_done, 4 * sizeof(unsigned int)) != hipSuccess) {
     h->err = "hipMalloc(scalars) failed";
     return bail(DFLO_ERR_NOMEM);
   }
@@ -1195,14 +1215,14 @@ int dflo_hip_create_with_cell_size(const dflo_mesh_t *mesh, const dflo_params_t 
     const bool want_marks = h->N >= 2 && (tun.lim_mask >= 0 ? tun.lim_mask != 0 : (h->N >= 3 || p.n_cells == p.n_owned || pass_takes_exchange));
     if (h->prm.limiter_type == DFLO_LIMITER_TVB && h->basis == DFLO_BASIS_QK && h->geo == 0 && want_marks) {
       const size_t nb = (size_t)std::max(p.n_shards, 1) * sizeof(unsigned long long);
-      if (hipMalloc((void **)&h->lim_mask, nb) != hipSuccess) {
+      if (dmalloc((void **)&h->lim_mask, nb) != hipSuccess) {
         h->err = "hipMalloc(limiter marks) failed";
         return bail(DFLO_ERR_NOMEM);
       }
       hipMemset(h->lim_mask, 0, nb);
       if (tun.lim_list) {
-        if (hipMalloc((void **)&h->lim_cnt, 2 * sizeof(int)) != hipSuccess ||
-            hipMalloc((void **)&h->lim_list, (size_t)(p.n_shards + 8) * sizeof(ulonglong2)) != hipSuccess) {
+        if (dmalloc((void **)&h->lim_cnt, 2 * sizeof(int)) != hipSuccess ||
+            dmalloc((void **)&h->lim_list, (size_t)(p.n_shards + 8) * sizeof(ulonglong2)) != hipSuccess) {
           h->err = "hipMalloc(limiter list) failed";
           return bail(DFLO_ERR_NOMEM);
         }

@@ -135,7 +135,8 @@ struct StageArgs {
   const int32_t *wt_begin;              // the records by which a shard knows that it reads ghost traces (dl_begin, or dla_begin)
   int wt_n;
   unsigned long long wt_seq;
-  int *wt_fail;                         // host-mapped: a word that did not arrive within 30 s
+  int *wt_fail;                         // host-mapped: a word that did not arrive within wt_ticks
+  long long wt_ticks;                   // of the 100 MHz clock (DFLO_IPC_TIMEOUT_S, default 120 s; 0: no limit)
   // TVB: what leaves from the stage kernel are the AVERAGES of the cells on a cut (the neighbours' limiter reads them; the traces
   // leave from the limiter pass, LimArgs) -- the same arrangement with cell records
   const int32_t *dla_begin;
@@ -216,20 +217,25 @@ __device__ __forceinline__ double cell_face_trace(const double *U, int slot, int
 
 // ---- the exchange from inside the kernels (one process per GPU over mapped tables; engine.hip: dflo_hip_set_deliver ..).
 // await_words: the first n threads of the workgroup poll one sequence word each (fine-grained memory, acquire at system scope)
-// until it has reached seq; the workgroup meets at a barrier.
-__device__ __forceinline__ void await_words(const unsigned long long *const *flag, const int n, const unsigned long long seq, int *fail) {
+// until it has reached seq; the workgroup meets at a barrier.  `ticks` of the 100 MHz clock (DFLO_IPC_TIMEOUT_S; 0: wait for ever): a
+// neighbour that died or fell out of step -- the failure word goes up and the WHOLE workgroup learns of it (false): it must neither
+// compute with the stale records nor deliver or count itself as having delivered (the exchange then never completes anywhere, every
+// rank ends in DFLO_ERR_COMM instead of going on with wrong numbers).
+__device__ __forceinline__ bool await_words(const unsigned long long *const *flag, const int n, const unsigned long long seq, int *fail, const long long ticks) {
+  int late = 0;
   if ((int)threadIdx.x < n) {
     const unsigned long long *w = flag[threadIdx.x];
     const long long t0 = wall_clock64();
     while (__hip_atomic_load(w, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
       __builtin_amdgcn_s_sleep(8);
-      if (wall_clock64() - t0 > 30LL * 100000000LL) {   // 30 s of the 100 MHz clock: a neighbour that died or fell out of step
+      if (ticks > 0 && wall_clock64() - t0 > ticks) {
         __hip_atomic_store(fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        late = 1;
         break;
       }
     }
   }
-  __syncthreads();
+  return __syncthreads_or(late) == 0;
 }
 // what every delivering workgroup does last: its stores have completed (the caller waited for them), count, and the last one
 // publishes the exchange's number in the receivers' words

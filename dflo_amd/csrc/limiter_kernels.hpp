@@ -101,6 +101,7 @@ struct LimArgs {
   int wt_n;
   unsigned long long wt_seq;
   int *wt_fail;
+  long long wt_ticks;
   KBasis kb;
 };
 
@@ -350,7 +351,7 @@ __global__ __launch_bounds__(64) void limiter_kernel(const LimArgs a) {
   int shard;
   if (rim) {
     shard = a.rim_list[(int)blockIdx.x - grid];
-    if (a.wt_n) await_words(a.wt_flag, a.wt_n, a.wt_seq, a.wt_fail);
+    if (a.wt_n && !await_words(a.wt_flag, a.wt_n, a.wt_seq, a.wt_fail, a.wt_ticks)) return;   // (timed out: neither limited with stale averages nor delivered)
   } else {
     if (a.fin_blocks > 0 && (int)blockIdx.x < a.fin_blocks) finalize_by_wave(a.fin, blockIdx.x, a.fin_blocks);
     const int sidx = shard_of_block(blockIdx.x, a.n_list, a.sweep_rev);

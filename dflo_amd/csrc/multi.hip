@@ -136,16 +136,16 @@ struct WaitArgs {
   int n;
   const unsigned long long *flag[16];
   unsigned long long seq;
-  int *fail;          // host-mapped: set when a word has not arrived after kWaitTimeoutTicks
+  int *fail;          // host-mapped: set when a word has not arrived after `ticks`
+  long long ticks;    // of the 100 MHz wall clock (DFLO_IPC_TIMEOUT_S, default 120 s); 0: wait for ever
 };
-constexpr long long kWaitTimeoutTicks = 30LL * 100000000LL;   // 30 s of the 100 MHz wall clock
 __global__ void wait_flags_kernel(const WaitArgs w) {
   const int i = threadIdx.x;
   if (i >= w.n) return;
   const long long t0 = wall_clock64();
   while (__hip_atomic_load(w.flag[i], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < w.seq) {
     __builtin_amdgcn_s_sleep(16);
-    if (wall_clock64() - t0 > kWaitTimeoutTicks) {   // a peer that died or fell out of step: give up, tell the host
+    if (w.ticks > 0 && wall_clock64() - t0 > w.ticks) {   // a peer that died or fell out of step: give up, tell the host
       __hip_atomic_store(w.fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       return;
     }
@@ -178,7 +178,7 @@ __global__ void signal_wait_kernel(const SignalArgs a, const WaitArgs w, const W
   const long long t0 = wall_clock64();
   while (__hip_atomic_load(ww.flag[k], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < ww.seq) {
     __builtin_amdgcn_s_sleep(16);
-    if (wall_clock64() - t0 > kWaitTimeoutTicks) {
+    if (ww.ticks > 0 && wall_clock64() - t0 > ww.ticks) {
       __hip_atomic_store(ww.fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       return;
     }
@@ -310,6 +310,7 @@ struct dflo_hip_multi {
   unsigned long long ipc_post_met[4] = {0, 0, 0, 0};   // ipc_post at the ranks' last barrier (destroy: has anything been stored into a neighbour since?)
   volatile int *ipc_fail_host = nullptr;
   int *ipc_fail = nullptr;
+  long long ipc_ticks = 0;     // DFLO_IPC_TIMEOUT_S in ticks of the 100 MHz clock (0: the wait kernels wait for ever)
   ncclComm_t comm = nullptr;
   // one process per GPU with the host program's own transport (MPI, ...) instead of RCCL
   dflo_exchange_fn x_exchange = nullptr;
@@ -614,6 +615,7 @@ int fill_wait(dflo_hip_multi *m, WaitArgs &w, int kind, const std::vector<int> &
   }
   w.seq = seq;
   w.fail = m->ipc_fail;
+  w.ticks = m->ipc_ticks;
   return DFLO_OK;
 }
 int wait_words(dflo_hip_multi *m, hipStream_t st, int kind, const std::vector<int> &from, unsigned long long seq) {
@@ -1180,7 +1182,8 @@ int alloc_flags(dflo_hip_multi *m) {
   // fine-grained, not uncached (hipDeviceMallocUncached): the protocol runs as well on uncached words, but an exported uncached
   // block that is freed poisons the allocations of this process that follow (the first engine created after the driver computes a
   // wrong state; leaking the block instead of freeing it: clean) -- profiles/LAB.md R5.15
-  MHIP(m, hipExtMallocWithFlags(&m->win_sync, 2 * kWindowBlock, hipDeviceMallocFinegrained));
+  // (DFLO_IPC_WORDS=uncached, developer switch: that configuration, to hold the destroy order of round 6 against it)
+  MHIP(m, hipExtMallocWithFlags(&m->win_sync, 2 * kWindowBlock, dflo::read_tunables().ipc_words_uncached ? hipDeviceMallocUncached : hipDeviceMallocFinegrained));
   MHIP(m, hipMemset(m->win_sync, 0, 2 * kWindowBlock));
   m->flags = (unsigned long long *)m->win_sync;
   void *fh = nullptr, *fd = nullptr;
@@ -1189,15 +1192,20 @@ int alloc_flags(dflo_hip_multi *m) {
   m->ipc_fail_host = (volatile int *)fh;
   m->ipc_fail = (int *)fd;
   *m->ipc_fail_host = 0;
+  m->ipc_ticks = (long long)dflo::read_tunables().ipc_timeout_s * 100000000LL;
   return DFLO_OK;
 }
 int setup_ipc(dflo_hip_multi *m) {
   Part &p = m->parts[0];
   if (m->n_parts > 16) { set_err(m, "DFLO_RANK_TRANSPORT=ipc: at most 16 ranks"); return DFLO_ERR_UNSUPPORTED; }
-  int rc = alloc_flags(m);
-  if (rc) return rc;
+  // Every rank leaves this function with the same verdict: a rank whose LOCAL steps fail (an allocation, hipIpcGetMemHandle, a
+  // neighbour's window that cannot be opened) still takes part in the two all-reduces below and says so in them, so that its
+  // peers bail out with it instead of waiting in a later collective for a rank that has gone.
   IpcExport mine;
   std::memset(&mine, 0, sizeof(mine));
+  auto export_windows = [&]() -> int {
+  int rc = alloc_flags(m);
+  if (rc) return rc;
   {   // the data window and this rank's buffers inside it
     auto up = [](size_t b) { return (b + 4095) & ~(size_t)4095; };
     const size_t ng = std::max(p.n_ghost, 1);
@@ -1237,12 +1245,26 @@ int setup_ipc(dflo_hip_multi *m) {
     mine.ro[q] = p.recv_off[q];
     mine.rfo[q] = p.trace ? p.recvf_off[q] : 0;
   }
+  return DFLO_OK;
+  };
+  const int rc_export = export_windows();
   const size_t nb = sizeof(IpcExport);
-  std::vector<double> spread((size_t)m->n_parts * nb, 0.0);
+  std::vector<double> spread((size_t)m->n_parts * nb + m->n_parts, 0.0);   // the handles, and behind them one status word per rank
   const unsigned char *mb = (const unsigned char *)&mine;
-  for (size_t i = 0; i < nb; ++i) spread[(size_t)p.index * nb + i] = (double)mb[i];
-  if ((rc = host_allreduce(m, spread.data(), (int)spread.size(), ncclSum))) return rc;
+  if (!rc_export)
+    for (size_t i = 0; i < nb; ++i) spread[(size_t)p.index * nb + i] = (double)mb[i];
+  spread[(size_t)m->n_parts * nb + p.index] = rc_export ? 1.0 : 0.0;
+  int rc = host_allreduce(m, spread.data(), (int)spread.size(), ncclSum);
+  if (rc) return rc;
+  if (rc_export) return rc_export;
+  for (int q = 0; q < m->n_parts; ++q)
+    if (spread[(size_t)m->n_parts * nb + q] != 0.0) {
+      set_err(m, "DFLO_RANK_TRANSPORT=ipc: rank " + std::to_string(q) + " could not export its windows");
+      return DFLO_ERR_COMM;
+    }
   m->pmap.assign(m->n_parts, PeerMap{});
+  auto open_windows = [&]() -> int {
+  hipError_t e = hipSuccess;
   for (int q = 0; q < m->n_parts; ++q) {
     if (q == p.index) continue;
     IpcExport theirs;
@@ -1271,6 +1293,13 @@ int setup_ipc(dflo_hip_multi *m) {
       return DFLO_ERR_COMM;
     }
   }
+  return DFLO_OK;
+  };
+  const int rc_open = open_windows();
+  double bad = rc_open ? 1.0 : 0.0;
+  if ((rc = host_allreduce(m, &bad, 1, ncclMax))) return rc;
+  if (rc_open) return rc_open;
+  if (bad != 0.0) { set_err(m, "DFLO_RANK_TRANSPORT=ipc: another rank could not map its neighbours' windows"); return DFLO_ERR_COMM; }
   // every rank's CFL minimum goes into every rank's table (the engine's reductions write them, FinalArgs::peer_mins)
   void *tables[16] = {};
   for (int q = 0; q < m->n_parts; ++q) tables[q] = q == p.index ? p.dt_table : (void *)m->pmap[q].dt_table;
@@ -1313,7 +1342,7 @@ int setup_fused(dflo_hip_multi *m) {
     MENG(m, p, dflo_hip_set_arrival_words(p.eng, nw, words, m->ipc_fail));
     m->kwait = dflo::read_tunables().ipc_kwait && (m->self_halo || m->ipc_fine);
     // (self-halo: the tables are this engine's own plain allocations, and it is its own, later kernels that read them)
-    MENG(m, p, dflo_hip_deliver_to_plain_memory(p.eng, (!m->self_halo && !m->ipc_fine) ? 1 : 0));
+    MENG(m, p, dflo_hip_deliver_to_plain_memory(p.eng, ((!m->self_halo && !m->ipc_fine) || dflo::read_tunables().ipc_strict) ? 1 : 0));
   }
   if (m->tvb) {   // the averages' way: into the neighbours' average areas, words of their own
     void *words[16];
@@ -1598,18 +1627,23 @@ int dflo_hip_multi_destroy(dflo_hip_multi_handle m) {
     if (g.M) hipStreamSynchronize(g.M);
   }
   // IPC transport: a neighbour's last launches may still be storing into this rank's windows (its time-step minimum and the word of
-  // the step that has just ended are awaited only by a next step) -- and a freed block goes back to the runtime's pool, from where
-  // the next allocation of this process takes it, still mapped by the neighbour.  Nobody frees before everybody's streams are idle.
-  // (not the cause of what R5.15 of profiles/LAB.md saw, but a hole all the same)
+  // the step that has just ended are awaited only by a next step).  Nobody unmaps or frees before everybody's streams are idle.
   // (a collective like the create call: skipped where this rank has seen a failure -- its peers have been told or are lost anyway)
-  if (m->ipc && !m->self_halo && m->n_parts > 1 && m->created && !m->fatal && !(m->ipc_fail_host && *m->ipc_fail_host) && (m->comm || m->x_allreduce) &&
-      std::memcmp(m->ipc_post_met, m->ipc_post, sizeof(m->ipc_post_met)) != 0)   // (a driver that has never sent anything -- some rank's create failed -- just leaves)
-    ipc_barrier(m);
-  if (m->comm) g_rccl.CommDestroy(m->comm);
+  const bool meet = m->ipc && !m->self_halo && m->n_parts > 1 && m->created && !m->fatal && !(m->ipc_fail_host && *m->ipc_fail_host) &&
+                    (m->comm || m->x_allreduce) &&
+                    std::memcmp(m->ipc_post_met, m->ipc_post, sizeof(m->ipc_post_met)) != 0;   // (a driver that has never sent anything -- some rank's create failed -- just leaves)
+  if (meet) ipc_barrier(m);
   if (!m->self_halo)
     for (PeerMap &pm : m->pmap)
       for (void *o : pm.opened)
         if (o) hipIpcCloseMemHandle(o);
+  // ... and nobody FREES a window before every neighbour has closed its mapping of it: freeing exported memory that an importer still
+  // maps is undefined (the IPC contract of the runtime: close in the importing process first) -- what LAB R5.15 ran into with the
+  // sequence words in uncached memory: the exporter's next allocations took the block while the neighbour's unmapping was still to
+  // come, and the first engine created after the driver computed a wrong state (round 6: tools/ipc_free_order.hip reproduces it
+  // without the engine, tests/test_gpu_round6.py holds the order).  DFLO_IPC_FREE_EARLY=1 (developer switch): round 5's order.
+  if (meet && !dflo::read_tunables().ipc_free_early) ipc_barrier(m);
+  if (m->comm) g_rccl.CommDestroy(m->comm);
   if (m->ipc_fail_host) hipHostFree((void *)m->ipc_fail_host);
   for (Part &p : m->parts) {
     hipSetDevice(p.device);
@@ -1636,6 +1670,10 @@ int dflo_hip_multi_destroy(dflo_hip_multi_handle m) {
   }
   if (m->scal) hipFree(m->scal);
   if (m->win_data) hipFree(m->win_data);   // (behind the engines, which were pointed into it)
+  if (m->win_sync && std::getenv("DFLO_IPC_SCRUB")) {   // (developer switch, LAB R6.3: hand the words back as zeros)
+    hipMemset(m->win_sync, 0, 2 * kWindowBlock);
+    hipDeviceSynchronize();
+  }
   if (m->win_sync) hipFree(m->win_sync);
   for (int i = 0; i < 2; ++i) if (m->ev_chunk[i]) hipEventDestroy(m->ev_chunk[i]);
   delete m;

@@ -564,9 +564,9 @@ __device__ __forceinline__ void limiter_marks_from_box(const double (&lo)[4], co
 // launch), form the traces on the shard's cut faces exactly as face_trace_kernel would (cell_face_trace: the same bits), and store
 // them into the neighbours' tables.  Release at system scope, count, and the last workgroup that delivers publishes the number.
 // the stage kernel's share of the exchange (kernels_common.hpp: await_words, deliver_face_traces, deliver_averages)
-__device__ __forceinline__ void await_traces(const StageArgs &a, const int shard) {
-  if (a.wt_begin[shard + 1] == a.wt_begin[shard]) return;   // wave-uniform: no cut face, no ghost trace
-  await_words(a.wt_flag, a.wt_n, a.wt_seq, a.wt_fail);
+__device__ __forceinline__ bool await_traces(const StageArgs &a, const int shard) {   // false: a neighbour's traces never came
+  if (a.wt_begin[shard + 1] == a.wt_begin[shard]) return true;   // workgroup-uniform: no cut face, no ghost trace
+  return await_words(a.wt_flag, a.wt_n, a.wt_seq, a.wt_fail, a.wt_ticks);
 }
 template <int N>
 __device__ __forceinline__ void deliver_traces(const StageArgs &a, const int shard) {
@@ -664,7 +664,7 @@ __global__ __launch_bounds__(64 * N, N >= 5 ? 1 : ((N == 4 && GEO == 0 && MODE =
       }
   }
 
-  if (a.wt_n) await_traces(a, shard);
+  if (a.wt_n && !await_traces(a, shard)) return;   // (timed out: the failure word is up; nothing is computed from stale traces, nothing delivered)
   // ---- phase A: own rows -> LDS; halo: only the trace on the shared face is kept.
   //      halo item i -> (entry s = i % nh, q = (i / nh) % N, comp = i / (nh N)); an entry is
   //      (internal cell slot | local face << 28) of a face neighbour outside the shard

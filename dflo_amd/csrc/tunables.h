@@ -51,6 +51,16 @@ struct Tunables {
                                   //                           deliver its cut faces' traces itself (one launch per stage, one stream)
   bool ipc_kwait = true;          // DFLO_IPC_KWAIT=0         ... and a one-wavefront kernel in front of every stage waits for the neighbours' traces
                                   //                           (default: the stage kernel's workgroups on the cut wait themselves)
+  int ipc_timeout_s = 120;        // DFLO_IPC_TIMEOUT_S=n     IPC transport: seconds a wait kernel / a polling workgroup waits for a neighbour's sequence word
+                                  //                           before it raises DFLO_ERR_COMM (0: for ever, as an MPI or RCCL receive would).  Ranks must
+                                  //                           enter advance() / step() within that time of each other (the calls are collective)
+  bool ipc_strict = false;        // DFLO_IPC_STRICT=1        IPC transport, delivery by the stage kernel / the limiter pass: every delivering workgroup
+                                  //                           fences at system scope before it counts itself (release; the publishing workgroup's fence
+                                  //                           acquires) -- the formally complete protocol, whatever kind of memory the window is; default:
+                                  //                           write-through stores + s_waitcnt on a fine-grained window, the fence only on a plain one
+  bool ipc_words_uncached = false;  // DFLO_IPC_WORDS=uncached  (developer switch) the sequence words in hipDeviceMallocUncached memory: LAB R5.15's configuration
+  bool ipc_free_early = false;      // DFLO_IPC_FREE_EARLY=1    (developer switch) dflo_hip_multi_destroy frees the exported windows without waiting for the
+                                    //                           neighbours to close their mappings: round 5's order, the cause of LAB R5.15
   bool avg_in_place = true;     // DFLO_MULTI_AVG_UNPACK=1   TVB: unpack the received ghost averages into the engine's array before the rim
                                 //                           limiter (default: the limiter reads them where they arrived)
 };
@@ -106,6 +116,10 @@ inline Tunables read_tunables() {
   t.ipc_finegrained = flag("DFLO_PEER_FINEGRAINED", true);
   t.ipc_fused = flag("DFLO_IPC_FUSED", true);
   t.ipc_kwait = flag("DFLO_IPC_KWAIT", true);
+  t.ipc_timeout_s = count("DFLO_IPC_TIMEOUT_S", t.ipc_timeout_s, 0);
+  t.ipc_strict = flag("DFLO_IPC_STRICT", false);
+  if (const char *e = std::getenv("DFLO_IPC_WORDS")) t.ipc_words_uncached = std::strcmp(e, "uncached") == 0;
+  t.ipc_free_early = flag("DFLO_IPC_FREE_EARLY", false);
   if (const char *e = std::getenv("DFLO_RANK_TRANSPORT")) t.rank_transport = std::strcmp(e, "ipc") == 0 ? 1 : 0;
   return t;
 }

@@ -139,3 +139,61 @@ def test_driver_lifecycle_with_the_ipc_transport():
     mp.spawn(_lifecycle_worker, args=(2, 29500 + random.randint(0, 2000), ret), nprocs=2, join=True)
     assert ret["same_0"] and ret["same_1"], dict(ret)
     assert ret["idle_close_0"] < 60 and ret["idle_close_1"] < 60, dict(ret)
+
+
+def _cycles_worker(rank, world, port, kind, cycles, ret):
+    os.environ["DFLO_RANK_TRANSPORT"] = "ipc"
+    os.environ["DFLO_PEER_FINEGRAINED"] = "1" if kind == "finegrained" else "0"
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, HERE)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    import dflo_amd
+    import test_gpu_multi as T
+    from dflo_amd.gloo_transport import make_callbacks
+    xf, af = make_callbacks("cuda:0")
+    cases = [T._case(n) for n in ("c2", "c4")]
+
+    def single(mesh, prm, ic, limited):
+        one = dflo_amd.ConservationLaw(mesh, prm)
+        T._setup(one, mesh, ic)
+        r = T._run(one, limited)
+        one.close()
+        return r["u"]
+
+    ref = [single(mesh, prm, ic, prm.limiter == "TVB") for mesh, prm, ic in cases]      # before any driver exists
+    bad_after, bad_ranks = 0, 0
+    for cycle in range(cycles):
+        k = cycle & 1
+        mesh, prm, ic = cases[k]
+        limited = prm.limiter == "TVB"
+        claw = dflo_amd.MultiConservationLaw.for_rank_custom(mesh, prm, 0, rank, world, xf, af, partitioner="slab")
+        T._setup(claw, mesh, ic)
+        got = T._run(claw, limited)
+        own = claw.part_cells(0)[0]
+        mine = got["u"].reshape(mesh.n_cells, -1)[own]
+        claw.close()
+        # the single engine created right AFTER the driver has gone takes the blocks the driver freed (LAB R5.15 / R6.3)
+        after = single(mesh, prm, ic, limited)
+        bad_after += int(not np.array_equal(after, ref[k]))
+        want = ref[k].reshape(mesh.n_cells, -1)[own]
+        bad_ranks += int(not (np.array_equal(mine, want) if k == 0 else np.abs(mine - want).max() <= 1e-8 * np.abs(want).max()))
+    ret["after_%d" % rank], ret["ranks_%d" % rank] = bad_after, bad_ranks
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kind", ["finegrained", "plain"])
+def test_two_hundred_create_run_destroy_cycles_each_followed_by_a_single_engine(kind):
+    """VERDICT r5 item 3a.  dflo_hip_multi_destroy with exported windows, round 6's order: everybody's streams idle -> every importer
+    closes its mappings -> only then the exporters free.  200 cycles of the two-rank IPC driver (C2- and C4-style in turn), the exported
+    data window fine-grained (the default) or plain; after every cycle each rank creates a single engine -- which takes the blocks the
+    driver has just freed -- and must reproduce, bit for bit, the engine that ran before any driver existed."""
+    import random
+    mgr = mp.get_context("spawn").Manager()
+    ret = mgr.dict()
+    mp.spawn(_cycles_worker, args=(2, 29500 + random.randint(0, 2000), kind, 200, ret), nprocs=2, join=True)
+    assert ret["after_0"] == 0 and ret["after_1"] == 0, dict(ret)
+    assert ret["ranks_0"] == 0 and ret["ranks_1"] == 0, dict(ret)
