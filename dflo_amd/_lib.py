@@ -72,7 +72,7 @@ SYMBOLS = [
     "dflo_mesh_cartesian", "dflo_mesh_from_quads", "dflo_mesh_read_gmsh", "dflo_mesh_partition", "dflo_mesh_make_periodic", "dflo_mesh_free",
     "dflo_mesh_last_error", "dflo_mesh_support_points", "dflo_mesh_partition_ex", "dflo_mesh_partition_owners",
     "dflo_hip_failure_step", "dflo_hip_positivity_stats", "dflo_hip_dt_table", "dflo_hip_dt_exchange", "dflo_hip_dt_slot",
-    "dflo_hip_multi_create", "dflo_hip_comm_unique_id", "dflo_hip_multi_create_rank", "dflo_hip_multi_create_rank_custom", "dflo_hip_multi_create_self", "dflo_mesh_partition_self", "dflo_hip_pack_send_to_signal", "dflo_hip_attach_event", "dflo_hip_set_deliver", "dflo_hip_stage_deliver", "dflo_hip_set_arrival_words", "dflo_hip_stage_await", "dflo_hip_set_deliver_averages", "dflo_hip_stage_deliver_averages", "dflo_hip_limit_exchange", "dflo_hip_limiter_walks_list", "dflo_hip_deliver_to_plain_memory", "dflo_hip_set_ghost_trace_buffers", "dflo_hip_set_dt_table_buffer", "dflo_hip_multi_destroy",
+    "dflo_hip_multi_create", "dflo_hip_comm_unique_id", "dflo_hip_multi_create_rank", "dflo_hip_multi_create_rank_custom", "dflo_hip_multi_create_self", "dflo_mesh_partition_self", "dflo_hip_pack_send_to_signal", "dflo_hip_attach_event", "dflo_hip_finish_enqueued", "dflo_hip_set_deliver", "dflo_hip_stage_deliver", "dflo_hip_set_arrival_words", "dflo_hip_stage_await", "dflo_hip_set_deliver_averages", "dflo_hip_stage_deliver_averages", "dflo_hip_limit_exchange", "dflo_hip_limiter_walks_list", "dflo_hip_deliver_to_plain_memory", "dflo_hip_set_ghost_trace_buffers", "dflo_hip_set_dt_table_buffer", "dflo_hip_multi_destroy",
     "dflo_hip_multi_last_error", "dflo_hip_multi_n_parts", "dflo_hip_multi_n_local", "dflo_hip_multi_engine",
     "dflo_hip_multi_part_cells", "dflo_hip_multi_n_dofs", "dflo_hip_multi_n_owned_dofs", "dflo_hip_multi_n_rk",
     "dflo_hip_multi_set_solution", "dflo_hip_multi_get_solution", "dflo_hip_multi_get_cell_average",
@@ -137,6 +137,7 @@ _sig("dflo_hip_check", C.c_int, _H)
 _sig("dflo_hip_synchronize", C.c_int, _H)
 _sig("dflo_hip_stage_timing", C.c_int, _H, C.c_int, _dp, C.POINTER(C.c_int64))
 _sig("dflo_hip_uses_mfma", C.c_int, _H)
+_sig("dflo_hip_finish_enqueued", C.c_int, _H)
 _sig("dflo_hip_set_send_cells", C.c_int, _H, C.c_int32, _ip)
 _sig("dflo_hip_pack_send", C.c_int, _H, C.c_void_p)
 _sig("dflo_hip_pack_send_avg", C.c_int, _H, C.c_void_p)

@@ -146,6 +146,7 @@ struct dflo_hip_engine {
   // timing
   bool timing = false;
   int dtq_parts = 0;   // last stage on bilinear cells: parts (1 rim, 2 interior) whose limiter pass also formed the time step
+  bool finish_enqueued = false;   // the last dflo_hip_stage_finish put a kernel on the stream (dflo_hip_finish_enqueued)
   bool mfma = false;       // DFLO_MFMA=1, degree 3: the per-element contractions on the matrix pipe (Q3: eta-derivative; P3 on squares: modal <-> nodal)
   bool fuse_pos = false;   // positivity limiter without TVB on Qk: applied inside the stage kernel (DFLO_FUSE_POS=0: separate pass)
   unsigned long long *lim_mask = nullptr;   // TVB on Qk squares: [n_shards], written by the stage kernel for the limiter pass (DFLO_LIM_MASK=0: off)
@@ -156,6 +157,7 @@ struct dflo_hip_engine {
   int *lim_cnt = nullptr;
   ulonglong2 *lim_list = nullptr;
   int lim_epoch = 0, lim_open = -1, lim_grid = 1024;
+  int lim_seg = 0, lim_xcd = 0;   // the list in 8 segments of lim_seg entries, one per XCD (lim_xcd = 7), with 8 counters per epoch (DFLO_LIM_XCD=0: one list)
   int lim_parts = -1;   // the launch that appended last to the open list: 0 all shards, 3 rim + ring, 4 the rest
   bool fin_done = false;   // a limiter pass of the open stage has carried the step's reductions
   bool lim_clean[2] = {true, true};
@@ -407,7 +409,7 @@ int open_stage(dflo_hip_engine *h, int rk, double dt_host, bool residual_only, i
       // the compute stream; a memset issued with the former would be unordered against the appends of the latter
       const int i = (h->lim_epoch + 1) & 1;
       if (!h->lim_clean[i]) {
-        HIPCHK(h, hipMemsetAsync(h->lim_cnt + i, 0, sizeof(int), h->stream));
+        HIPCHK(h, hipMemsetAsync(h->lim_cnt + 8 * i, 0, 8 * sizeof(int), h->stream));
         h->lim_clean[i] = true;
       }
     }
@@ -593,6 +595,8 @@ int launch_update(dflo_hip_engine *h, double *rhs_out, int part) {
   a.lim_mask = h->lim_mask;
   a.lim_cnt = nullptr;
   a.lim_list = h->lim_list;
+  a.lim_seg = h->lim_seg;
+  a.lim_xcd = h->lim_xcd;
   if (h->dl_armed >= 0 && part == 0 && !rhs_out) {   // this launch delivers its cut faces' traces itself (dflo_hip_stage_deliver)
     a.dl_begin = h->d_dl_begin;
     a.dl_rec = h->d_dl_rec;
@@ -641,13 +645,13 @@ int launch_update(dflo_hip_engine *h, double *rhs_out, int part) {
     // and the rest (4), which share one list; 4 joins the list 3 opened.
     if (h->lim_cnt && (part == 0 || part == 3 || part == 4)) {
       if (part == 4 && h->lim_parts == 3) {
-        a.lim_cnt = h->lim_cnt + h->lim_open;
+        a.lim_cnt = h->lim_cnt + 8 * h->lim_open;
       } else {
         const int i = ++h->lim_epoch & 1;
-        if (!h->lim_clean[i]) HIPCHK(h, hipMemsetAsync(h->lim_cnt + i, 0, sizeof(int), h->stream));
+        if (!h->lim_clean[i]) HIPCHK(h, hipMemsetAsync(h->lim_cnt + 8 * i, 0, 8 * sizeof(int), h->stream));
         h->lim_clean[i] = false;
         h->lim_open = i;
-        a.lim_cnt = h->lim_cnt + i;
+        a.lim_cnt = h->lim_cnt + 8 * i;
       }
       h->lim_parts = part;
       a.lim_list_from = part == 3 ? (int)p.rim_shards.size() : 0;
@@ -741,8 +745,10 @@ int launch_limiter(dflo_hip_engine *h, int tvb, int pos, int part, bool stage_da
   int grid = grid_for(l.n_list);
   if (l.mask && (part == 0 || part == 2) && h->lim_open >= 0 && h->basis == DFLO_BASIS_QK && (part == 0) == (h->lim_parts == 0)) {
     l.mark_list = h->lim_list;
-    l.mark_cnt = h->lim_cnt + h->lim_open;
-    l.mark_cnt_next = h->lim_cnt + (h->lim_open ^ 1);
+    l.mark_cnt = h->lim_cnt + 8 * h->lim_open;
+    l.mark_cnt_next = h->lim_cnt + 8 * (h->lim_open ^ 1);
+    l.mark_seg = h->lim_seg;
+    l.mark_xcd = h->lim_xcd;
     h->lim_clean[h->lim_open ^ 1] = true;
     h->lim_open = -1;
     grid = std::min(grid, std::max(h->lim_grid, l.fin_blocks));
@@ -827,8 +833,10 @@ int launch_finish(dflo_hip_engine *h, bool reductions_done = false) {
   const int rk = h->pending_rk;
   if (rk < 0) { h->err = "no stage pending"; return DFLO_ERR_BAD_PARAM; }
   const bool last = rk == h->n_rk - 1;
+  h->finish_enqueued = false;
   if (h->bc_take_along) {   // no limiter pass of this stage took the boundary programs along: the kernel of their own, before the next stage
     h->bc_take_along = false;
+    h->finish_enqueued = true;
     const int rc = eval_boundary_programs(h, h->st_dt);
     if (rc) return rc;
     h->bc_later_step = h->steps_done;
@@ -844,6 +852,7 @@ int launch_finish(dflo_hip_engine *h, bool reductions_done = false) {
     HIPCHK(h, hipGetLastError());
   }
   h->pending_rk = -1;
+  if (last) h->finish_enqueued = true;   // (time step / reductions: a caller that orders streams behind the last stage records plainly anyway)
   if (!last || reductions_done || h->fin_done) return DFLO_OK;  // ||rhs|| of every stage is reduced once, after the last stage (it is only reported, src/claw.cc:768)
   FinalArgs f{};
   final_args(h, f);
@@ -1221,13 +1230,17 @@ int dflo_hip_create_with_cell_size(const dflo_mesh_t *mesh, const dflo_params_t 
       }
       hipMemset(h->lim_mask, 0, nb);
       if (tun.lim_list) {
-        if (dmalloc((void **)&h->lim_cnt, 2 * sizeof(int)) != hipSuccess ||
-            dmalloc((void **)&h->lim_list, (size_t)(p.n_shards + 8) * sizeof(ulonglong2)) != hipSuccess) {
+        // one list per XCD (DFLO_LIM_XCD=0: one list, segment 0): a segment holds what one XCD's workgroups can mark -- a launch's blocks go
+        // round the XCDs, an eighth of its shards each (two launches, rim + ring and the rest, may share a list: twice that)
+        h->lim_xcd = tun.lim_xcd ? 7 : 0;
+        h->lim_seg = h->lim_xcd ? 2 * ((p.n_shards + 7) / 8) + 8 : p.n_shards + 8;
+        if (dmalloc((void **)&h->lim_cnt, 16 * sizeof(int)) != hipSuccess ||
+            dmalloc((void **)&h->lim_list, (size_t)8 * h->lim_seg * sizeof(ulonglong2)) != hipSuccess) {
           h->err = "hipMalloc(limiter list) failed";
           return bail(DFLO_ERR_NOMEM);
         }
-        hipMemset(h->lim_cnt, 0, 2 * sizeof(int));
-        hipMemset(h->lim_list, 0, (size_t)(p.n_shards + 8) * sizeof(ulonglong2));
+        hipMemset(h->lim_cnt, 0, 16 * sizeof(int));
+        hipMemset(h->lim_list, 0, (size_t)8 * h->lim_seg * sizeof(ulonglong2));
         h->lim_grid = std::max(64, tun.lim_grid);
       }
     }
@@ -1600,7 +1613,7 @@ int dflo_hip_advance(dflo_hip_handle h, int n_steps, double *elapsed_time_inout)
         if (h->lim_cnt && s + period <= n_steps) {   // the first marked launch of a replay finds its list counter at zero
           const int i = (h->lim_epoch + 1) & 1;
           if (!h->lim_clean[i]) {
-            HIPCHK(h, hipMemsetAsync(h->lim_cnt + i, 0, sizeof(int), h->stream));
+            HIPCHK(h, hipMemsetAsync(h->lim_cnt + 8 * i, 0, 8 * sizeof(int), h->stream));
             h->lim_clean[i] = true;
           }
         }
@@ -1704,7 +1717,7 @@ int dflo_hip_set_deliver(dflo_hip_handle h, int area, int n_segments, const int3
   if (check_handle(h) || area < 0 || area > 1 || n_segments < 1 || n_segments > kMaxSegs || !first || !dst || !flags) return DFLO_ERR_BAD_PARAM;
   if (!h->trace_halo || h->basis != DFLO_BASIS_QK) { h->err = "delivery by the stage kernel needs ghost cells known by their traces (Qk)"; return DFLO_ERR_BAD_PARAM; }
   const int n = h->n_send_faces;
-  if (n == 0 || first[0] != 0 || first[n_segments] != n) { h->err = "set_deliver: the segments must cover the send list of set_send_faces"; return DFLO_ERR_COMM; }
+  if (n == 0 || first[0] != 0 || first[n_segments] != n || (int)h->h_sendf_slot.size() != n) { h->err = "set_deliver: the segments must cover the send list of set_send_faces"; return DFLO_ERR_COMM; }
   hipSetDevice(h->device);
   // the records sorted by the shard of their cell (stable: send-list order inside a shard)
   const int ns = h->plan.n_shards;
@@ -1729,7 +1742,10 @@ int dflo_hip_set_deliver(dflo_hip_handle h, int area, int n_segments, const int3
   std::vector<unsigned long long *> fl(n_segments);
   for (int i = 0; i < n_segments; ++i) fl[i] = (unsigned long long *)flags[i];
   HIPCHK(h, hipStreamSynchronize(h->stream));
-  if (!h->d_dl_begin) {
+  // the per-shard record tables follow the send list as it is NOW (a caller may have changed it since the other area was set: ADVICE r5)
+  hipFree(h->d_dl_begin); h->d_dl_begin = nullptr;
+  hipFree(h->d_dl_rec); h->d_dl_rec = nullptr;
+  {
     int rc;
     if ((rc = upload(h, &h->d_dl_begin, begin)) || (rc = upload(h, &h->d_dl_rec, rec))) return rc;
   }
@@ -1796,7 +1812,9 @@ int dflo_hip_set_deliver_averages(dflo_hip_handle h, int area, int n_segments, c
   for (int i = 0; i < n_words; ++i) wd[i] = (unsigned long long *)words[i];
   HIPCHK(h, hipStreamSynchronize(h->stream));
   int rc;
-  if (!h->d_dla_begin && ((rc = upload(h, &h->d_dla_begin, begin)) || (rc = upload(h, &h->d_dla_slot, slot)))) return rc;
+  hipFree(h->d_dla_begin); h->d_dla_begin = nullptr;   // (as in set_deliver: the tables of the send list as it is now)
+  hipFree(h->d_dla_slot); h->d_dla_slot = nullptr;
+  if ((rc = upload(h, &h->d_dla_begin, begin)) || (rc = upload(h, &h->d_dla_slot, slot))) return rc;
   hipFree(h->d_dla_dst[area]); h->d_dla_dst[area] = nullptr;
   hipFree(h->d_dla_flag); h->d_dla_flag = nullptr;
   hipFree(h->d_wta_flag); h->d_wta_flag = nullptr;
@@ -1874,6 +1892,7 @@ int dflo_hip_stage_finish(dflo_hip_handle h) {
   return launch_finish(h);
 }
 
+int dflo_hip_finish_enqueued(dflo_hip_handle h) { return (h && h->finish_enqueued) ? 1 : 0; }
 int dflo_hip_n_rim_shards(dflo_hip_handle h) { return h ? (int)h->plan.rim_shards.size() : 0; }
 
 int dflo_hip_stage_limit(dflo_hip_handle h) {
@@ -1947,6 +1966,11 @@ int dflo_hip_set_send_cells(dflo_hip_handle h, int32_t n, const int32_t *cells) 
   }
   hipFree(h->d_send_slots);
   h->d_send_slots = nullptr;
+  HIPCHK(h, hipStreamSynchronize(h->stream));   // (as in set_send_faces: set_deliver_averages again for both areas)
+  for (int a = 0; a < 2; ++a) { hipFree(h->d_dla_dst[a]); h->d_dla_dst[a] = nullptr; }
+  hipFree(h->d_dla_begin); h->d_dla_begin = nullptr;
+  hipFree(h->d_dla_slot); h->d_dla_slot = nullptr;
+  h->dla_armed = -1;
   h->n_send = n;
   h->h_send_slots = slots;
   return upload(h, &h->d_send_slots, slots);
@@ -2014,6 +2038,12 @@ int dflo_hip_set_send_faces(dflo_hip_handle h, int32_t n, const int32_t *cells, 
   }
   hipFree(h->d_sendf_slot); hipFree(h->d_sendf_face);
   h->d_sendf_slot = h->d_sendf_face = nullptr;
+  // a delivery arrangement made for the list before is void: set_deliver has to be called again for both receive areas
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  for (int a = 0; a < 2; ++a) { hipFree(h->d_dl_dst[a]); h->d_dl_dst[a] = nullptr; }
+  hipFree(h->d_dl_begin); h->d_dl_begin = nullptr;
+  hipFree(h->d_dl_rec); h->d_dl_rec = nullptr;
+  h->dl_armed = -1;
   h->n_send_faces = n;
   h->h_sendf_slot = slots;
   h->h_sendf_face = ff;

@@ -838,7 +838,13 @@ int stage_phase(dflo_hip_multi *m, Group &g, const StageCtx &s, int ph) {
       // the step's reductions take in the rim shards' partials: those of their UPDATE, which with TVB this stream has waited for
       // already (ev_ring) -- the limiter changes neither the averages nor the residual
       if (s.last && !m->tvb) MHIP(m, hipStreamWaitEvent(g.M, g.ev_rim, 0));
-      for (int i : g.parts) MENG(m, m->parts[i], dflo_hip_stage_finish(m->parts[i].eng));
+      for (int i : g.parts) {
+        MENG(m, m->parts[i], dflo_hip_stage_finish(m->parts[i].eng));
+        // the event that opens the next stage rode on this stream's last stage / limiter kernel; if finish put a kernel of its own behind
+        // it (boundary programs that no limiter pass took along write the table the next stage's rim reads), the next stage records
+        // the plain way, behind everything on this stream
+        if (g.open_attached && dflo_hip_finish_enqueued(m->parts[i].eng)) g.open_attached = false;
+      }
       std::swap(g.ev_rim, g.ev_rim_prev);      // the next stage's interior waits for this stage's rim
       g.rim_pending = !s.last;                 // (after the last stage M has waited already)
       return DFLO_OK;

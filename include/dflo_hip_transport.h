@@ -90,6 +90,10 @@ int dflo_hip_set_dt_table_buffer(dflo_hip_handle h, void *table);
  * less between two kernels of a stream (the multi-device schedule orders its two streams with one such event per phase).
  * If that launch turns out to be empty the event is recorded the plain way. */
 int dflo_hip_attach_event(dflo_hip_handle h, void *event);
+/* 1 if the last dflo_hip_stage_finish put a kernel of its own on the engine's stream BEHIND the stage's last stage / limiter launch (boundary
+ * programs no pass took along, the time step, the reductions): an event attached to that last launch then does not cover everything the
+ * next stage reads, and a caller that orders a second stream by it has to record the plain way. */
+int dflo_hip_finish_enqueued(dflo_hip_handle h);
 /* Delivery by the stage kernel itself (one process per GPU over mapped tables; Qk, ghost cells by their traces).  set_deliver,
  * once per receive area (0 | 1): the records of the send list of set_send_faces go, segment by segment as in pack_send_to, to
  * dst[i] -- the neighbours' trace tables of that area --, and flags[i] are the neighbours' sequence words.  stage_deliver arms
