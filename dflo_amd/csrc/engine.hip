@@ -157,7 +157,6 @@ struct dflo_hip_engine {
   int *lim_cnt = nullptr;
   ulonglong2 *lim_list = nullptr;
   int lim_epoch = 0, lim_open = -1, lim_grid = 1024;
-  int lim_seg = 0, lim_xcd = 0;   // the list in 8 segments of lim_seg entries, one per XCD (lim_xcd = 7), with 8 counters per epoch (DFLO_LIM_XCD=0: one list)
   int lim_parts = -1;   // the launch that appended last to the open list: 0 all shards, 3 rim + ring, 4 the rest
   bool fin_done = false;   // a limiter pass of the open stage has carried the step's reductions
   bool lim_clean[2] = {true, true};
@@ -409,7 +408,7 @@ int open_stage(dflo_hip_engine *h, int rk, double dt_host, bool residual_only, i
       // the compute stream; a memset issued with the former would be unordered against the appends of the latter
       const int i = (h->lim_epoch + 1) & 1;
       if (!h->lim_clean[i]) {
-        HIPCHK(h, hipMemsetAsync(h->lim_cnt + 8 * i, 0, 8 * sizeof(int), h->stream));
+        HIPCHK(h, hipMemsetAsync(h->lim_cnt + i, 0, sizeof(int), h->stream));
         h->lim_clean[i] = true;
       }
     }
@@ -595,8 +594,6 @@ int launch_update(dflo_hip_engine *h, double *rhs_out, int part) {
   a.lim_mask = h->lim_mask;
   a.lim_cnt = nullptr;
   a.lim_list = h->lim_list;
-  a.lim_seg = h->lim_seg;
-  a.lim_xcd = h->lim_xcd;
   if (h->dl_armed >= 0 && part == 0 && !rhs_out) {   // this launch delivers its cut faces' traces itself (dflo_hip_stage_deliver)
     a.dl_begin = h->d_dl_begin;
     a.dl_rec = h->d_dl_rec;
@@ -645,13 +642,13 @@ int launch_update(dflo_hip_engine *h, double *rhs_out, int part) {
     // and the rest (4), which share one list; 4 joins the list 3 opened.
     if (h->lim_cnt && (part == 0 || part == 3 || part == 4)) {
       if (part == 4 && h->lim_parts == 3) {
-        a.lim_cnt = h->lim_cnt + 8 * h->lim_open;
+        a.lim_cnt = h->lim_cnt + h->lim_open;
       } else {
         const int i = ++h->lim_epoch & 1;
-        if (!h->lim_clean[i]) HIPCHK(h, hipMemsetAsync(h->lim_cnt + 8 * i, 0, 8 * sizeof(int), h->stream));
+        if (!h->lim_clean[i]) HIPCHK(h, hipMemsetAsync(h->lim_cnt + i, 0, sizeof(int), h->stream));
         h->lim_clean[i] = false;
         h->lim_open = i;
-        a.lim_cnt = h->lim_cnt + 8 * i;
+        a.lim_cnt = h->lim_cnt + i;
       }
       h->lim_parts = part;
       a.lim_list_from = part == 3 ? (int)p.rim_shards.size() : 0;
@@ -745,10 +742,8 @@ int launch_limiter(dflo_hip_engine *h, int tvb, int pos, int part, bool stage_da
   int grid = grid_for(l.n_list);
   if (l.mask && (part == 0 || part == 2) && h->lim_open >= 0 && h->basis == DFLO_BASIS_QK && (part == 0) == (h->lim_parts == 0)) {
     l.mark_list = h->lim_list;
-    l.mark_cnt = h->lim_cnt + 8 * h->lim_open;
-    l.mark_cnt_next = h->lim_cnt + 8 * (h->lim_open ^ 1);
-    l.mark_seg = h->lim_seg;
-    l.mark_xcd = h->lim_xcd;
+    l.mark_cnt = h->lim_cnt + h->lim_open;
+    l.mark_cnt_next = h->lim_cnt + (h->lim_open ^ 1);
     h->lim_clean[h->lim_open ^ 1] = true;
     h->lim_open = -1;
     grid = std::min(grid, std::max(h->lim_grid, l.fin_blocks));
@@ -1230,17 +1225,13 @@ int dflo_hip_create_with_cell_size(const dflo_mesh_t *mesh, const dflo_params_t 
       }
       hipMemset(h->lim_mask, 0, nb);
       if (tun.lim_list) {
-        // one list per XCD (DFLO_LIM_XCD=0: one list, segment 0): a segment holds what one XCD's workgroups can mark -- a launch's blocks go
-        // round the XCDs, an eighth of its shards each (two launches, rim + ring and the rest, may share a list: twice that)
-        h->lim_xcd = tun.lim_xcd ? 7 : 0;
-        h->lim_seg = h->lim_xcd ? 2 * ((p.n_shards + 7) / 8) + 8 : p.n_shards + 8;
-        if (dmalloc((void **)&h->lim_cnt, 16 * sizeof(int)) != hipSuccess ||
-            dmalloc((void **)&h->lim_list, (size_t)8 * h->lim_seg * sizeof(ulonglong2)) != hipSuccess) {
+        if (dmalloc((void **)&h->lim_cnt, 2 * sizeof(int)) != hipSuccess ||
+            dmalloc((void **)&h->lim_list, (size_t)(p.n_shards + 8) * sizeof(ulonglong2)) != hipSuccess) {
           h->err = "hipMalloc(limiter list) failed";
           return bail(DFLO_ERR_NOMEM);
         }
-        hipMemset(h->lim_cnt, 0, 16 * sizeof(int));
-        hipMemset(h->lim_list, 0, (size_t)8 * h->lim_seg * sizeof(ulonglong2));
+        hipMemset(h->lim_cnt, 0, 2 * sizeof(int));
+        hipMemset(h->lim_list, 0, (size_t)(p.n_shards + 8) * sizeof(ulonglong2));
         h->lim_grid = std::max(64, tun.lim_grid);
       }
     }
@@ -1613,7 +1604,7 @@ int dflo_hip_advance(dflo_hip_handle h, int n_steps, double *elapsed_time_inout)
         if (h->lim_cnt && s + period <= n_steps) {   // the first marked launch of a replay finds its list counter at zero
           const int i = (h->lim_epoch + 1) & 1;
           if (!h->lim_clean[i]) {
-            HIPCHK(h, hipMemsetAsync(h->lim_cnt + 8 * i, 0, 8 * sizeof(int), h->stream));
+            HIPCHK(h, hipMemsetAsync(h->lim_cnt + i, 0, sizeof(int), h->stream));
             h->lim_clean[i] = true;
           }
         }

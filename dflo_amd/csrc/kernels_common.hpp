@@ -113,9 +113,6 @@ struct StageArgs {
   int *lim_cnt;                   // POS 2, launches over all shards: the shards with a mark also go on a list (one append per
   int lim_list_from;              //   (a launch over rim + ring of a multi-device part: only the shards from this index of the launch's list on --
                                   //    the ring -- go on the list; the rim shards are limited by a pass of their own, ahead of the others)
-  int lim_seg, lim_xcd;           //   the list is kept in 8 segments of lim_seg entries, one per XCD (lim_xcd = 7: a workgroup appends to the segment of
-                                  //   blockIdx.x & 7, the XCD it runs on, and the pass's wavefronts of that XCD walk it -- the marked shard's new DoFs and
-                                  //   averages are still in that XCD's L2; lim_xcd = 0, DFLO_LIM_XCD=0: one list, segment 0) with a counter each
   ulonglong2 *lim_list;           //   marked shard and launch: a single wavefront writes a shard's word) as (shard, word), so that the pass is a few
                                   //   hundred wavefronts walking that list instead of one per shard that reads a word and leaves; or null
   double tvb_M;                   // POS 2: TVB constant M, < 0: the limiter pass has no TVB part

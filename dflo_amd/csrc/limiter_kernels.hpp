@@ -60,10 +60,9 @@ struct LimArgs {
   // with marks, on launches over all shards: the marked shards as a list (StageArgs::lim_list).  The grid is a few hundred
   // wavefronts that walk it; mark_cnt is the stage kernel's count, mark_cnt_next the counter the next stage kernel will use
   // (zeroed here: the two alternate).  null: one wavefront per shard looks at its word.
-  const ulonglong2 *mark_list;   // (shard, the word the stage kernel OR-ed into mask[shard]); 8 segments of mark_seg entries, one per XCD
-  const int *mark_cnt;           // [8] their counts
-  int *mark_cnt_next;            // [8]
-  int mark_seg, mark_xcd;        // mark_xcd = 7: wavefront b walks the segment of XCD b & 7 (StageArgs::lim_xcd); 0: one list
+  const ulonglong2 *mark_list;   // (shard, the word the stage kernel OR-ed into mask[shard])
+  const int *mark_cnt;
+  int *mark_cnt_next;
   // multi-device, TVB: the averages of the ghost cells as their owners sent them, [n_ghost][4] in ghost order (the receive area
   // itself: no unpack kernel between the arrival and this pass), or null: they are in `avg` like everybody's
   const double *ghost_avg;
@@ -336,21 +335,15 @@ __global__ __launch_bounds__(64) void limiter_kernel(const LimArgs a) {
     // the marked shards from the stage kernel's list, in the order they were appended (any order gives the same bits: a shard's
     // pass rewrites its own cells and reads averages, which limiting does not change).  The step's reductions ride on the LAST
     // wavefronts of the grid, which have a list entry only when the list is longer than the grid.
-    // Round 6: a list per XCD.  Wavefront b runs on XCD b & 7 and walks the shards that XCD's stage-kernel workgroups marked a few
-    // microseconds ago -- their new DoFs and averages (and most of their neighbours') are still in that XCD's L2, where the pass's three
-    // dependent round trips (list entry -> DoFs, averages, neighbour slots -> neighbour averages) used to go to memory.
-    const int x = (int)blockIdx.x & a.mark_xcd, j = a.mark_xcd ? (int)blockIdx.x >> 3 : (int)blockIdx.x, per = a.mark_xcd ? grid >> 3 : grid;
-    const ulonglong2 *list = a.mark_list + (size_t)x * a.mark_seg;
-    ulonglong2 e = list[j < a.mark_seg ? j : 0];   // asked for with the count, not behind it (an entry beyond the count is not used)
-    const int cnt = __builtin_amdgcn_readfirstlane(((const volatile int *)a.mark_cnt)[x]);
-    if (blockIdx.x == 0 && threadIdx.x < 8) a.mark_cnt_next[threadIdx.x] = 0;
+    ulonglong2 e = a.mark_list[blockIdx.x];   // asked for with the count, not behind it (an entry beyond the count is not used)
+    const int cnt = __builtin_amdgcn_readfirstlane(*(const volatile int *)a.mark_cnt);
+    if (blockIdx.x == 0 && threadIdx.x == 0) *a.mark_cnt_next = 0;
     const int fb = (int)blockIdx.x - (grid - a.fin_blocks);
     if (a.fin_blocks > 0 && fb >= 0) finalize_by_wave(a.fin, fb, a.fin_blocks);
-    if (j < per)
-      for (int k = j; k < cnt; k += per) {
-        if (k != j) e = list[k];
-        limiter_shard<N>(a, (int)e.x, true, e.y);
-      }
+    for (int k = blockIdx.x; k < cnt; k += grid) {
+      if (k != (int)blockIdx.x) e = a.mark_list[k];
+      limiter_shard<N>(a, (int)e.x, true, e.y);
+    }
     return;
   }
   // (one call of limiter_shard for the wavefront of a shard on a cut and for the wavefront-per-shard launch: a third copy of it in

@@ -574,11 +574,6 @@ __device__ __forceinline__ void deliver_traces(const StageArgs &a, const int sha
 }
 // does the limiter pass find this shard by the list of marked shards?  (not a shard on a cut where the pass takes the exchange
 // along: those get a wavefront of their own whatever their marks)
-// ... onto the segment of the XCD this workgroup runs on (workgroups go round the 8 XCDs by blockIdx.x)
-__device__ __forceinline__ void list_marked_shard(const StageArgs &a, const int shard, const unsigned long long m) {
-  const int x = (int)blockIdx.x & a.lim_xcd;
-  a.lim_list[(size_t)x * a.lim_seg + atomicAdd(a.lim_cnt + x, 1)] = make_ulonglong2((unsigned long long)shard, m);
-}
 __device__ __forceinline__ bool lists_itself(const StageArgs &a, const int shard, const int sidx) {
   return a.lim_cnt && sidx >= a.lim_list_from && !(a.dla_begin && a.dla_begin[shard + 1] > a.dla_begin[shard]);
 }
@@ -1089,7 +1084,7 @@ __global__ __launch_bounds__(64 * N, N >= 5 ? 1 : ((N == 4 && GEO == 0 && MODE =
       const unsigned long long m = __ballot(need && active);
       if (lane == 0 && m) {
         atomicOr(&a.lim_mask[shard], m);
-        if (lists_itself(a, shard, sidx)) list_marked_shard(a, shard, m);
+        if (lists_itself(a, shard, sidx)) a.lim_list[atomicAdd(a.lim_cnt, 1)] = make_ulonglong2((unsigned long long)shard, m);
       }
     }
   }
@@ -1123,7 +1118,7 @@ __global__ __launch_bounds__(64 * N, N >= 5 ? 1 : ((N == 4 && GEO == 0 && MODE =
     const unsigned long long m = __ballot(((a.pos_check && !settled) || open) && active);
     if (lane == 0 && m) {
       atomicOr(&a.lim_mask[shard], m);
-      if (lists_itself(a, shard, sidx)) list_marked_shard(a, shard, m);
+      if (lists_itself(a, shard, sidx)) a.lim_list[atomicAdd(a.lim_cnt, 1)] = make_ulonglong2((unsigned long long)shard, m);
     }
     }
   }

@@ -27,8 +27,6 @@ struct Tunables {
   bool lxf_from_dofs = true;   // DFLO_LXF_FROM_DOFS=0   the LxF flux on squares reads the arrays of cell averages (default: (u, v, c) of the averages from the DoFs)
   bool lim_list = true;    // DFLO_LIM_LIST=0    with marks: one wavefront per shard looks at its word instead of a short grid walking the list of marked shards
   int lim_grid = 1024;     // DFLO_LIM_GRID=n    wavefronts of that short grid
-  bool lim_xcd = true;     // DFLO_LIM_XCD=0     one list of marked shards walked in the order of marking (default: a list per XCD, walked by that XCD's
-                           //                    wavefronts of the pass -- the marked shards' new state is still in its L2)
   int lim_mask = -1;       // DFLO_LIM_MASK=0|1  TVB on squares: forbid / force the stage kernel's marks for the limiter pass (default: degree >= 2; degree 1 without ghost cells)
   bool halo_cells = false; // DFLO_HALO_CELLS=1  multi-device: ghost cells as whole cells instead of face traces
   bool verbose = false;    // DFLO_VERBOSE=1     print the LDS footprint and the resident workgroups of the stage kernel
@@ -102,7 +100,6 @@ inline Tunables read_tunables() {
   t.lim_mask = tri("DFLO_LIM_MASK");
   t.lim_list = flag("DFLO_LIM_LIST", true);
   t.lim_grid = count("DFLO_LIM_GRID", t.lim_grid, 1);
-  t.lim_xcd = flag("DFLO_LIM_XCD", true);
   t.halo_cells = flag("DFLO_HALO_CELLS", false);
   t.verbose = flag("DFLO_VERBOSE", false);
   t.plan_refine = count("DFLO_PLAN_REFINE", t.plan_refine, 0);

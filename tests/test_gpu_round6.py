@@ -130,36 +130,3 @@ def test_strict_delivery_gives_the_bits_of_the_default(config, monkeypatch):
         out.append(run(lambda: dflo_amd.MultiConservationLaw.for_self(mesh, prm, 0, transport="ipc", n_virtual=1 if config == "c2" else 2)))
     for t, u in out:
         assert t == ref[0] and np.array_equal(u, ref[1])
-
-
-@pytest.mark.parametrize("degree,flux", [(1, "roe"), (2, "hllc"), (3, "hllc")])
-def test_a_list_of_marked_shards_per_xcd_gives_the_bits_of_the_single_list(degree, flux, monkeypatch):
-    """TVB + positivity on squares with the stage kernel's marks (src/limiter.cc:225-370 on the marked cells only): the pass walks one
-    list per XCD (round 6: the marked shards' new state is still in that XCD's L2) -- any order of the shards gives the same bits as the
-    single list (DFLO_LIM_XCD=0), the wavefront-per-shard launch (DFLO_LIM_LIST=0) and grids of other sizes"""
-    mesh = dflo_amd.Mesh.cartesian(256, 40, 0.0, 0.0, 1.0 / 256, [2, 1, 0, 0], degree)
-    prm = dflo_amd.Parameters(flux=flux, limiter="TVB", char_lim=True, pos_lim=True, M=0.0, beta=2.0, cfl=0.8, final_time=1e9,
-                              boundary={0: "slip", 1: "outflow", 2: "inflow"})
-    u0 = mesh.interpolate(problems.sod)
-
-    def run(env):
-        for k in ("DFLO_LIM_XCD", "DFLO_LIM_LIST", "DFLO_LIM_GRID", "DFLO_LIM_MASK"):
-            monkeypatch.delenv(k, raising=False)
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
-        c = dflo_amd.ConservationLaw(mesh, prm)
-        cell, face, bid, xy = c.boundary_faces()
-        bv = np.stack(problems.sod(xy[..., 0], xy[..., 1]), axis=-1)
-        c.set_boundary_values(0, bv)
-        c.set_boundary_values(1, bv)
-        c.set_initial_condition(u0)
-        c.apply_limiter()
-        t = c.advance(12)
-        out = (t, c.current_solution.copy(), c.cell_average.copy())
-        c.close()
-        return out
-
-    ref = run({"DFLO_LIM_MASK": "1"})
-    for env in ({"DFLO_LIM_XCD": "0"}, {"DFLO_LIM_LIST": "0"}, {"DFLO_LIM_GRID": "64"}, {"DFLO_LIM_GRID": "7"}, {"DFLO_LIM_GRID": "4096", "DFLO_LIM_XCD": "0"}):
-        got = run(dict(env, DFLO_LIM_MASK="1"))
-        assert got[0] == ref[0] and np.array_equal(got[1], ref[1]) and np.array_equal(got[2], ref[2]), env

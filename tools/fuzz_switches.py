@@ -22,7 +22,7 @@ except SystemExit:
 import dflo_amd
 srng = np.random.default_rng([seed, 77])
 ENGINE = [("DFLO_GRAPH", ["1"]), ("DFLO_SWEEP", ["0"]), ("DFLO_STREAM", ["0", "1"]), ("DFLO_FUSE_DTQ", ["0"]), ("DFLO_FUSE_POS", ["0"]),
-          ("DFLO_FUSE_FIN", ["0"]), ("DFLO_LAZY_AVG", ["0"]), ("DFLO_LXF_FROM_DOFS", ["0"]), ("DFLO_LIM_LIST", ["0"]), ("DFLO_LIM_XCD", ["0"]),
+          ("DFLO_FUSE_FIN", ["0"]), ("DFLO_LAZY_AVG", ["0"]), ("DFLO_LXF_FROM_DOFS", ["0"]), ("DFLO_LIM_LIST", ["0"]),
           ("DFLO_LIM_GRID", ["1", "7", "64", "333", "4096"]), ("DFLO_LIM_MASK", ["0", "1"]), ("DFLO_PLAN_REFINE", ["0", "2"]),
           ("DFLO_PLAN_RIM_FIRST", ["0"])]
 MULTI = [("DFLO_HALO_CELLS", ["1"]), ("DFLO_MULTI_GROUP", ["part", "device"]), ("DFLO_MULTI_THREADS", ["0"]), ("DFLO_MULTI_STRICT", ["1"]),
