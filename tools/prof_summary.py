@@ -45,6 +45,10 @@ for k in sorted(vals):
         traffic.setdefault(k, {})["hbm_bytes_per_launch"] = 2 * c["FETCH_SIZE"] * 1024 + c["WRITE_SIZE"] * 1024
         traffic[k]["fetch_kib_raw"] = c["FETCH_SIZE"]
         traffic[k]["write_kib"] = c["WRITE_SIZE"]
+    if "GRBM_GUI_ACTIVE" in c and "SQ_ACTIVE_INST_VALU" in c:
+        cyc = c["GRBM_GUI_ACTIVE"] / 8.0   # summed over the 8 XCDs
+        print("   pipes: kernel cycles %.0f  valu_busy = 4 x SQ_ACTIVE_INST_VALU / (1024 SIMDs x cycles) = %.3f  mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x cycles) = %.4f" % (
+            cyc, 4 * c["SQ_ACTIVE_INST_VALU"] / 1024 / cyc, c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / 1024 / cyc))
     if "TCC_HIT_sum" in c:
         print("   L2 hit rate %.1f%%" % (100 * c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"])))
 

@@ -24,5 +24,6 @@ run write --pmc WRITE_SIZE --kernel-include-regex "stage_kernel|limiter_kernel"
 run sq1 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT --kernel-include-regex "stage_kernel|limiter_kernel"
 run sq2 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_LDS SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_WAIT_INST_LDS --kernel-include-regex "stage_kernel|limiter_kernel"
 run tcc --pmc TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE --kernel-include-regex "stage_kernel|limiter_kernel"
+run mf --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_INSTS_MFMA --kernel-include-regex "stage_kernel|limiter_kernel"
 python $PWD/tools/prof_summary.py $OUT > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt
