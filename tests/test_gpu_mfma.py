@@ -340,3 +340,18 @@ def test_p3_in_two_parts_agrees_with_the_single_engine(monkeypatch):
     assert rel(two.current_solution, one.current_solution) < 1e-13
     one.close()
     two.close()
+
+
+def test_random_configurations_on_the_matrix_pipe_kernels():
+    """a slice of the differential fuzzers with DFLO_MFMA=1: 200 random configurations against the oracle (every degree-3 case, Qk and Pk,
+    squares / skewed / unstructured cells, every flux, limiter and boundary kind, runs the matrix-pipe variants), 100 in several parts
+    against the single engine (profiles/r06/fuzz_mfma.txt: 4 500 + 600 + 80 cases on the round's build, no failure)"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DFLO_MFMA="1")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), "200", "77"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0 and "200 cases, 0 failures" in r.stdout, r.stdout[-2000:] + r.stderr[-1000:]
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_multi.py"), "100", "78"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0 and "100 cases, 0 failures" in r.stdout, r.stdout[-2000:] + r.stderr[-1000:]
