@@ -1644,10 +1644,10 @@ int dflo_hip_multi_destroy(dflo_hip_multi_handle m) {
       for (void *o : pm.opened)
         if (o) hipIpcCloseMemHandle(o);
   // ... and nobody FREES a window before every neighbour has closed its mapping of it: freeing exported memory that an importer still
-  // maps is undefined (the IPC contract of the runtime: close in the importing process first) -- what LAB R5.15 ran into with the
-  // sequence words in uncached memory: the exporter's next allocations took the block while the neighbour's unmapping was still to
-  // come, and the first engine created after the driver computed a wrong state (round 6: tools/ipc_free_order.hip reproduces it
-  // without the engine, tests/test_gpu_round6.py holds the order).  DFLO_IPC_FREE_EARLY=1 (developer switch): round 5's order.
+  // maps is undefined (the IPC contract of the runtime: close in the importing process first).  Round 5 freed without this second
+  // meeting.  (NOT the cause of LAB R5.15 -- uncached sequence words fail with either order, profiles/r06/r515_free_order.txt, LAB R6.3 --
+  // but a violation all the same; tests/test_gpu_multi_ranks.py: 200 create / run / destroy cycles, each followed by a single engine
+  // that takes the freed blocks.)  DFLO_IPC_FREE_EARLY=1 (developer switch): round 5's order.
   if (meet && !dflo::read_tunables().ipc_free_early) ipc_barrier(m);
   if (m->comm) g_rccl.CommDestroy(m->comm);
   if (m->ipc_fail_host) hipHostFree((void *)m->ipc_fail_host);
