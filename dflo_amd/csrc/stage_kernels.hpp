@@ -12,6 +12,16 @@ constexpr int kQ3FirstStageWaves = 3;   // first-stage Q3 kernel on squares: own
 constexpr int kQ2Waves = 3;
 // (Q4 on squares built for 3 / 2 wavefronts per SIMD in the first / later stages: 121 700 against 122 100 MDoF/s; 3 / 3: spills, 87 000)
 constexpr bool kPkLeanLater = true;     // P3: the later stages built like the first one (161 registers, no spills)
+// Q4 on squares, later stages: u(n) and the row's own u(s) are read where the update combines them (the first from memory, the second
+// a second time, from the cache) instead of being held across the flux phase and phase C -- 226 -> <= 168 registers, so that TWO
+// workgroups of five wavefronts fit a CU (75 KB of LDS each) like the first stage's
+#ifdef DFLO_NO_LATE_Q4
+constexpr bool kLateQ4 = false;
+#else
+constexpr bool kLateQ4 = true;
+#endif
+template <int N, int MODE, int GEO>
+constexpr bool late_loads() { return kLateQ4 && N == 5 && MODE == 1 && GEO == 0; }   // (Q3 the same way, three workgroups per CU instead of two: -12 .. -14 %, LAB R6.8)
 // ------------------------------------------------------------------ the stage kernel
 // One workgroup of N wavefronts per shard: lane = cell, wavefront = node row b of the (k+1)^2
 // collocation nodes, so control flow is wave-uniform and every global access is a coalesced
@@ -80,7 +90,7 @@ __device__ __forceinline__ void row_update(const StageArgs &a, double *Us, const
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       Wa[c] = LEAN ? Us[(c * NS + aa + N * B) * S + lane] : Wrow[aa][c];
-      base[c][aa] = Wa[c];
+      if constexpr (!late_loads<N, MODE, 0>()) base[c][aa] = Wa[c];
     }
     flux_xy(Wa, Fx, Gown[aa]);
     const double wbh = CB<N>::t.w[B] * h;
@@ -170,6 +180,9 @@ __device__ __forceinline__ void row_update(const StageArgs &a, double *Us, const
       const double rh2 = frcp(h * h);
       double *np = a.Unew + (size_t)shard * 4 * NS * 64 + lane;
       double ust[4][N];
+      constexpr bool LATE = late_loads<N, MODE, 0>();
+      const double *cp = a.Ucur + (size_t)shard * 4 * NS * 64 + (size_t)(N * B) * 64 + lane;
+      const double *op = a.Uold + (size_t)shard * 4 * NS * 64 + (size_t)(N * B) * 64 + lane;
 #pragma unroll
       for (int c = 0; c < 4; ++c)
 #pragma unroll
@@ -177,9 +190,9 @@ __device__ __forceinline__ void row_update(const StageArgs &a, double *Us, const
           const double ww = CB<N>::t.w[m] * CB<N>::t.w[B];
           const double invM = rh2 * (CB<N>::t.iw[m] * CB<N>::t.iw[B]);
           part[4] += R[c][m] * R[c][m];
-          double u = base[c][m];
+          double u = LATE ? cp[(c * NS + m) * 64] : base[c][m];
           u += dt * R[c][m] * invM;
-          if constexpr (MODE == 1) u = (1.0 - a.ark) * u + a.ark * uold[c][m];
+          if constexpr (MODE == 1) u = (1.0 - a.ark) * u + a.ark * (LATE ? __builtin_nontemporal_load(&op[(c * NS + m) * 64]) : uold[c][m]);
           ust[c][m] = u;
           if constexpr (POS) unew[c][m] = u;   // kept for the positivity step of the caller (which stores again if it scales)
           part[c] = __builtin_fma(ww, u, part[c]);   // (spelled out: cell_average_rows forms the same sums from the DoFs, bit for bit)
@@ -193,7 +206,10 @@ __device__ __forceinline__ void row_update(const StageArgs &a, double *Us, const
 #pragma unroll
     for (int c = 0; c < 4; ++c)
 #pragma unroll
-      for (int m = 0; m < N; ++m) unew[c][m] = base[c][m];
+      for (int m = 0; m < N; ++m) {
+        if constexpr (late_loads<N, MODE, 0>()) unew[c][m] = a.Ucur[(size_t)shard * 4 * NS * 64 + (size_t)(c * NS + m + N * B) * 64 + lane];
+        else unew[c][m] = base[c][m];
+      }
   }
   // partial cell averages / residual of this row -> LDS (red aliases Fh, see the caller's barriers)
   if constexpr (MODE != 2) {
@@ -579,7 +595,7 @@ __device__ __forceinline__ bool lists_itself(const StageArgs &a, const int shard
 }
 
 template <int N, int FLUX, int MODE, int GEO, int POS, int STREAM, int AF = 0, int MF = 0>
-__global__ __launch_bounds__(64 * N, N >= 5 ? 1 : ((N == 4 && GEO == 0 && MODE == 0) ? kQ3FirstStageWaves : (((GEO == 1 && N != 3) || N == 4) ? 2 : (N == 3 && GEO == 0 ? kQ2Waves : 3)))) void stage_kernel(const StageArgs a) {
+__global__ __launch_bounds__(64 * N, (late_loads<N, MODE, GEO>()) ? 3 : N >= 5 ? 1 : ((N == 4 && GEO == 0 && MODE == 0) ? kQ3FirstStageWaves : (((GEO == 1 && N != 3) || N == 4) ? 2 : (N == 3 && GEO == 0 ? kQ2Waves : 3)))) void stage_kernel(const StageArgs a) {
   constexpr int NS = N * N, NDOF = 4 * NS, NT = 64 * N;
   constexpr int ROWS = NDOF + (FLUX == DFLO_FLUX_LXF ? 3 : 0);   // LxF: (u, v, c) of the cell average ride along
   constexpr int TROWS = 4 * N;                                   // trace / flux table: (component, point) rows
@@ -654,7 +670,7 @@ __global__ __launch_bounds__(64 * N, N >= 5 ? 1 : ((N == 4 && GEO == 0 && MODE =
   double dt_step = 0.0;
   if constexpr (MODE != 2) dt_step = a.dt_cell ? a.dt_cell[(size_t)shard * 64 + lane] : (a.dt_host >= 0.0 ? a.dt_host : step_dt(a.dts, a.dt_dev));
   double uold[4][N];
-  if constexpr (MODE == 1) {
+  if constexpr (MODE == 1 && !late_loads<N, MODE, GEO>()) {
     const double *op = a.Uold + (size_t)shard * NDOF * 64 + (size_t)(N * row) * 64 + lane;
 #pragma unroll
     for (int c = 0; c < 4; ++c)
