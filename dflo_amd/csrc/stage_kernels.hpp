@@ -21,7 +21,7 @@ constexpr bool kLateQ4 = false;
 constexpr bool kLateQ4 = true;
 #endif
 template <int N, int MODE, int GEO>
-constexpr bool late_loads() { return kLateQ4 && N == 5 && MODE == 1 && GEO == 0; }   // (Q3 the same way, three workgroups per CU instead of two: -12 .. -14 %, LAB R6.8)
+constexpr bool late_loads() { return kLateQ4 && N == 5 && MODE == 1 && GEO == 0; }   // (Q3 and Q2 the same way, one workgroup more per CU: -12 .. -25 %, LAB R6.8)
 // ------------------------------------------------------------------ the stage kernel
 // One workgroup of N wavefronts per shard: lane = cell, wavefront = node row b of the (k+1)^2
 // collocation nodes, so control flow is wave-uniform and every global access is a coalesced
