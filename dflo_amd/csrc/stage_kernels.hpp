@@ -12,6 +12,11 @@ constexpr int kQ3FirstStageWaves = 3;   // first-stage Q3 kernel on squares: own
 constexpr int kQ2Waves = 3;
 // (Q4 on squares built for 3 / 2 wavefronts per SIMD in the first / later stages: 121 700 against 122 100 MDoF/s; 3 / 3: spills, 87 000)
 constexpr bool kPkLeanLater = true;     // P3: the later stages built like the first one (161 registers, no spills)
+#ifdef DFLO_NO_PK_LEAN_HIGH
+constexpr bool kPkLeanHigh = false;
+#else
+constexpr bool kPkLeanHigh = true;      // P4, P5: the own row and the own G row come back from the LDS image (as in the Qk kernels of those degrees)
+#endif
 // Q4 on squares, later stages: u(n) and the row's own u(s) are read where the update combines them (the first from memory, the second
 // a second time, from the cache) instead of being held across the flux phase and phase C -- 226 -> <= 168 registers, so that TWO
 // workgroups of five wavefronts fit a CU (75 KB of LDS each) like the first stage's
@@ -595,7 +600,7 @@ __device__ __forceinline__ bool lists_itself(const StageArgs &a, const int shard
 }
 
 template <int N, int FLUX, int MODE, int GEO, int POS, int STREAM, int AF = 0, int MF = 0>
-__global__ __launch_bounds__(64 * N, (late_loads<N, MODE, GEO>()) ? 3 : N >= 5 ? 1 : ((N == 4 && GEO == 0 && MODE == 0) ? kQ3FirstStageWaves : (((GEO == 1 && N != 3) || N == 4) ? 2 : (N == 3 && GEO == 0 ? kQ2Waves : 3)))) void stage_kernel(const StageArgs a) {
+__global__ __launch_bounds__(64 * N, (kLateQ4 && N == 5 && GEO == 0 && MODE != 2) ? 3 : N >= 5 ? 1 : ((N == 4 && GEO == 0 && MODE == 0) ? kQ3FirstStageWaves : (((GEO == 1 && N != 3) || N == 4) ? 2 : (N == 3 && GEO == 0 ? kQ2Waves : 3)))) void stage_kernel(const StageArgs a) {
   constexpr int NS = N * N, NDOF = 4 * NS, NT = 64 * N;
   constexpr int ROWS = NDOF + (FLUX == DFLO_FLUX_LXF ? 3 : 0);   // LxF: (u, v, c) of the cell average ride along
   constexpr int TROWS = 4 * N;                                   // trace / flux table: (component, point) rows
@@ -1322,7 +1327,7 @@ __device__ __forceinline__ void row_update_pk(const StageArgs &a, double *Us, co
   } else {
   // P3, first stage (LEAN, as in row_update): built for 3 wavefronts per SIMD -- the nodal values of the own row and the own G
   // row come back from the LDS image instead of being held in registers, the G values are taken node by node
-  constexpr bool LEAN = N == 4 && (MF || MODE == 0 || (MODE == 1 && kPkLeanLater));
+  constexpr bool LEAN = (N == 4 && (MF || MODE == 0 || (MODE == 1 && kPkLeanLater))) || (kPkLeanHigh && N >= 5);   // (N >= 5, round 6: the later stages spilled 60-512 bytes per lane otherwise)
   double Gown[N][4];
 #pragma unroll
   for (int aa = 0; aa < N; ++aa) {
