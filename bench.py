@@ -259,7 +259,7 @@ def build_case(args, world):
         from dflo_amd import gmsh
         k = int(round((65 if args.nx == 1024 else args.nx) * np.sqrt(world)))   # 65: 1 597 050 cells, 102 M DoF -- BASELINE's "~1.61 M cells"
         verts, quads, bed, bid = gmsh.forward_step_quads(cl=0.2 / k, seed=1)
-        mesh = dflo_amd.Mesh.from_quads(verts, quads, bed, bid, 3)
+        mesh = dflo_amd.Mesh.from_quads(verts, quads, bed, bid, args.degree)
         nx = ny = k
         prm = dflo_amd.Parameters(flux="kfvs", pos_lim=True, cfl=0.02, final_time=1e9,
                                   boundary={1: "inflow", 2: "slip", 3: "outflow"})   # examples/forward_step/input.prm
@@ -418,7 +418,7 @@ def main():
     if args.config == "c3":
         args.degree, args.flux = 1, "roe"
     if args.config == "c5":
-        args.degree, args.flux = 3, "kfvs"
+        args.degree, args.flux = int(os.environ.get("DFLO_BENCH_C5_DEGREE", 3)), os.environ.get("DFLO_BENCH_C5_FLUX", "kfvs")   # (developer switches: other elements on the bilinear mesh)
         if "--steps" not in sys.argv:
             args.steps = 100
         if "--warmup" not in sys.argv:
@@ -648,8 +648,8 @@ def main():
                              "c3": "sod_shock_tube, %dx256 quads, Q1, ROE, TVB(M=0,beta=2,char)+positivity, SSP-RK 2 stages" % nx,
                              "c4": "double_mach_reflection, %dx1000 of the 4001x1000 squares (%d x-slab(s) of ~%d columns), Q2, HLLC, %spositivity, moving inflow on the device, SSP-RK 3 stages"
                                    % (nx, world * args.parts_per_gpu, nx // (world * args.parts_per_gpu), "" if args.no_tvb else "TVB(M=100,beta=1,char)+"),
-                             "c5": "forward_step, %d unstructured quads (q1 mapping), Q3, KFVS, positivity limiter, cfl 0.02 (at the input's 0.5 the reference algorithm stops in the 6th step), SSP-RK 3 stages"
-                                   % m["n_cells"]}[args.config],
+                             "c5": "forward_step, %d unstructured quads (q1 mapping), Q%d, %s, positivity limiter, cfl 0.02 (at the input's 0.5 the reference algorithm stops in the 6th step), SSP-RK %d stages"
+                                   % (m["n_cells"], args.degree, args.flux.upper(), n_rk)}[args.config],
                 "n_dofs": n_dofs_total, "n_rk": n_rk,
                 "parts_per_gpu": args.parts_per_gpu,
                 "self_halo": args.self_halo or None,

@@ -25,6 +25,12 @@ constexpr bool kLateQ4 = false;
 #else
 constexpr bool kLateQ4 = true;
 #endif
+// ... and on bilinear cells at degree 5 (256 registers and 188-436 bytes of scratch per lane otherwise): u(n), and the row's own u(s)
+// for the update, are read at the combine in every stage, and the row update takes its own row and its own eta part from the LDS image
+// (LEANQ).  Measured on the forward-step mesh, HLLC: Q5 70 000 -> 80 700 MDoF/s; Q4 the same way (206-228 registers, no scratch, instead of
+// 256 + 28-204 B) 81 500 -> 73 600, not applied; Q3 (C5) -1.7 %, not applied (profiles/r06/ab_bilinear_q4q5.txt, ab_hi7.txt, LAB R6.9)
+template <int N, int GEO>
+constexpr bool late_q1() { return kLateQ4 && N >= 6 && GEO == 1; }
 template <int N, int MODE, int GEO>
 constexpr bool late_loads() { return kLateQ4 && N == 5 && MODE == 1 && GEO == 0; }   // (Q3 and Q2 the same way, one workgroup more per CU: -12 .. -25 %, LAB R6.8)
 // ------------------------------------------------------------------ the stage kernel
@@ -276,14 +282,19 @@ __device__ __forceinline__ void row_update_q1(const StageArgs &a, double *Us, co
   // Like row_update: every wave evaluates the fluxes once, at the nodes of its own row (values still in registers),
   // lifts the xi part itself and leaves the eta part, (x_xi G - y_xi F) w w, in its rows of the LDS image; after one
   // barrier each wave reads the eta parts of the other rows instead of evaluating the fluxes there again.
+  // degree 5 (LEANQ, round 6): as on squares the state of the own row comes back from the LDS image instead of being held across the
+  // flux phase, and the own eta part is read back like the others (the kernels spilled 188-436 bytes per lane)
+  constexpr bool LEANQ = late_q1<N, 1>();   // (degree 3, C5, the same way: 241 registers without scratch instead of 256 + 28 B, and 1.7 % slower)
   double Hown[N][4];
   {
     const double xxi = ax + CB<N>::t.x[B] * bx, yxi = ay + CB<N>::t.x[B] * by;
 #pragma unroll
     for (int aa = 0; aa < N; ++aa) {
       const double xeta = cx + CB<N>::t.x[aa] * dx, yeta = cy + CB<N>::t.x[aa] * dy;
-      double Fx[4], Gy[4];
-      flux_xy(Wrow[aa], Fx, Gy);
+      double Fx[4], Gy[4], Wa[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) Wa[c] = LEANQ ? Us[(c * NS + aa + N * B) * S + lane] : Wrow[aa][c];
+      flux_xy(Wa, Fx, Gy);
       const double wq = CB<N>::t.w[aa] * CB<N>::t.w[B];
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
@@ -295,8 +306,8 @@ __device__ __forceinline__ void row_update_q1(const StageArgs &a, double *Us, co
       }
       if (a.gravity != 0.0) {
         const double jxw = wq * (xxi * yeta - xeta * yxi);
-        R[MY][aa] += a.gravity * (-1.0 * Wrow[aa][RHO]) * jxw;
-        R[EN][aa] += a.gravity * (-1.0 * Wrow[aa][MY]) * jxw;
+        R[MY][aa] += a.gravity * (-1.0 * Wa[RHO]) * jxw;
+        R[EN][aa] += a.gravity * (-1.0 * Wa[MY]) * jxw;
       }
     }
   }
@@ -315,7 +326,7 @@ __device__ __forceinline__ void row_update_q1(const StageArgs &a, double *Us, co
     for (int q = 0; q < N; ++q)
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
-        const double hy = q == B ? Hown[aa][c] : Us[(c * NS + aa + N * q) * S + lane];
+        const double hy = (q == B && !LEANQ) ? Hown[aa][c] : Us[(c * NS + aa + N * q) * S + lane];
         R[c][aa] += hy * CB<N>::t.D[q][B];
       }
   }
@@ -362,6 +373,8 @@ __device__ __forceinline__ void row_update_q1(const StageArgs &a, double *Us, co
     } else {
       double *np = a.Unew + (size_t)shard * 4 * NS * 64 + lane;
       const double xxi = ax + CB<N>::t.x[B] * bx, yxi = ay + CB<N>::t.x[B] * by;
+      constexpr bool LATE = late_q1<N, 1>();
+      const double *cp = a.Ucur + (size_t)shard * 4 * NS * 64 + lane, *op = a.Uold + (size_t)shard * 4 * NS * 64 + lane;
 #pragma unroll
       for (int m = 0; m < N; ++m) {
         const double det = xxi * (cy + CB<N>::t.x[m] * dy) - (cx + CB<N>::t.x[m] * dx) * yxi;
@@ -371,9 +384,9 @@ __device__ __forceinline__ void row_update_q1(const StageArgs &a, double *Us, co
         for (int c = 0; c < 4; ++c) {
           const int d = c * NS + m + N * B;
           part[4] += R[c][m] * R[c][m];
-          double u = Wrow[m][c];
+          double u = LATE ? cp[d * 64] : Wrow[m][c];
           u += dt * R[c][m] * invM;
-          if constexpr (MODE == 1) u = (1.0 - a.ark) * u + a.ark * uold[c][m];
+          if constexpr (MODE == 1) u = (1.0 - a.ark) * u + a.ark * (LATE ? __builtin_nontemporal_load(&op[d * 64]) : uold[c][m]);
           stream_store<STREAM>(&np[d * 64], u);
           unew[c][m] = u;   // kept: the positivity step and the time step of the new solution (dtq) work on it
           part[c] += wd * u;
@@ -384,7 +397,10 @@ __device__ __forceinline__ void row_update_q1(const StageArgs &a, double *Us, co
 #pragma unroll
     for (int c = 0; c < 4; ++c)
 #pragma unroll
-      for (int m = 0; m < N; ++m) unew[c][m] = Wrow[m][c];
+      for (int m = 0; m < N; ++m) {
+        if constexpr (late_q1<N, 1>()) unew[c][m] = a.Ucur[(size_t)shard * 4 * NS * 64 + (size_t)(c * NS + m + N * B) * 64 + lane];
+        else unew[c][m] = Wrow[m][c];
+      }
   }
   if constexpr (MODE != 2) {
     __syncthreads();  // every wave is done reading Fh and Us
@@ -675,7 +691,7 @@ __global__ __launch_bounds__(64 * N, (kLateQ4 && N == 5 && GEO == 0 && MODE != 2
   double dt_step = 0.0;
   if constexpr (MODE != 2) dt_step = a.dt_cell ? a.dt_cell[(size_t)shard * 64 + lane] : (a.dt_host >= 0.0 ? a.dt_host : step_dt(a.dts, a.dt_dev));
   double uold[4][N];
-  if constexpr (MODE == 1 && !late_loads<N, MODE, GEO>()) {
+  if constexpr (MODE == 1 && !late_loads<N, MODE, GEO>() && !late_q1<N, GEO>()) {
     const double *op = a.Uold + (size_t)shard * NDOF * 64 + (size_t)(N * row) * 64 + lane;
 #pragma unroll
     for (int c = 0; c < 4; ++c)
