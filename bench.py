@@ -184,6 +184,33 @@ def live_traffic(args):
                    % (kib["FETCH_SIZE"][1], kib["WRITE_SIZE"][1])), extra
 
 
+def cross_validate(atts, config):
+    """The IPC transport rests on hand-made coherence that has never met two devices, and outside the periodic box an attempt's own
+    check is only "finite and admissible": a run that read stale halos would pass it and, being faster, become `value`.  Every
+    transport computes the same run (the tests hold them bit-identical), so an IPC attempt counts only if its reduced totals --
+    the conserved sums after the run, the minimum density and pressure -- are those of a transport whose exchange is a library
+    call (rccl, else the host-staged gloo run) to 1e-11; with no such reference it counts only where its own check is a real one
+    (c2: the conserved totals of the periodic box to 1e-10)."""
+    ref = next((r for r in atts if r["ok"] and r["transport"] == "rccl"), None) or next((r for r in atts if r["ok"] and r["transport"] == "gloo"), None)
+    for r in atts:
+        if not r["ok"] or not r["transport"].startswith("ipc"):
+            continue
+        if ref is None:
+            if config != "c2":
+                r["ok"] = False
+                r["check"] += "; NOT COUNTED: no reference transport (rccl / gloo) completed to hold this run's totals against"
+            else:
+                r["validated"] = "no reference transport completed: held by its own conservation check only"
+            continue
+        a, b = np.array(r["totals"]), np.array(ref["totals"])
+        dev = float(np.abs(a[4:] - b[4:]).max() / max(np.abs(b[4:8]).max(), 1e-300))
+        if not (np.isfinite(a).all() and dev <= 1e-11):
+            r["ok"] = False
+            r["check"] += "; NOT COUNTED: totals after the run differ from the %s run's by %.1e (relative)" % (ref["transport"], dev)
+        else:
+            r["validated"] = "totals after the run equal the %s run's to %.1e (relative)" % (ref["transport"], dev)
+
+
 def _timing_interval(steps, n_rk):
     """Every how-manieth stage launch is bracketed by HIP events: a timed launch costs its stream a few microseconds of bubbles
     (two timed event records), so a long run samples sparsely -- about 48 launches, every 5th at least, an interval coprime to the 2
@@ -786,32 +813,6 @@ def main():
         state["timer"] = threading.Timer(seconds - (5.0 if rank == 0 else 0.0), fire)
         state["timer"].daemon = True
         state["timer"].start()
-
-    def cross_validate(atts, config):
-        """The IPC transport rests on hand-made coherence that has never met two devices, and outside the periodic box an attempt's own
-        check is only "finite and admissible": a run that read stale halos would pass it and, being faster, become `value`.  Every
-        transport computes the same run (the tests hold them bit-identical), so an IPC attempt counts only if its reduced totals --
-        the conserved sums after the run, the minimum density and pressure -- are those of a transport whose exchange is a library
-        call (rccl, else the host-staged gloo run) to 1e-11; with no such reference it counts only where its own check is a real one
-        (c2: the conserved totals of the periodic box to 1e-10)."""
-        ref = next((r for r in atts if r["ok"] and r["transport"] == "rccl"), None) or next((r for r in atts if r["ok"] and r["transport"] == "gloo"), None)
-        for r in atts:
-            if not r["ok"] or not r["transport"].startswith("ipc"):
-                continue
-            if ref is None:
-                if config != "c2":
-                    r["ok"] = False
-                    r["check"] += "; NOT COUNTED: no reference transport (rccl / gloo) completed to hold this run's totals against"
-                else:
-                    r["validated"] = "no reference transport completed: held by its own conservation check only"
-                continue
-            a, b = np.array(r["totals"]), np.array(ref["totals"])
-            dev = float(np.abs(a[4:] - b[4:]).max() / max(np.abs(b[4:8]).max(), 1e-300))
-            if not (np.isfinite(a).all() and dev <= 1e-11):
-                r["ok"] = False
-                r["check"] += "; NOT COUNTED: totals after the run differ from the %s run's by %.1e (relative)" % (ref["transport"], dev)
-            else:
-                r["validated"] = "totals after the run equal the %s run's to %.1e (relative)" % (ref["transport"], dev)
 
     attempt_s = float(os.environ.get("DFLO_BENCH_ATTEMPT_S", 900 if args.config == "c5" else 240))
     if world == 1:
