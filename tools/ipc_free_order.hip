@@ -32,9 +32,23 @@ __global__ void fill(unsigned long long *p, unsigned long long v, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = v * 0x9E3779B97F4A7C15ull + i;
 }
-__global__ void verify(const unsigned long long *p, unsigned long long v, int n, unsigned int *bad) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+// (a workgroup verifies what the NEXT workgroup of the fill wrote -- workgroups go round the 8 XCDs, so every word is checked from another
+//  XCD than the one that wrote it: a translation or a cache line that is stale in one XCD only would show; shift 0: the same XCD)
+__global__ void verify(const unsigned long long *p, unsigned long long v, int n, unsigned int *bad, int shift) {
+  const int i = (int)((blockIdx.x + shift) % gridDim.x) * blockDim.x + threadIdx.x;
   if (i < n && p[i] != v * 0x9E3779B97F4A7C15ull + i) atomicAdd(bad, 1u);
+}
+// ... and a kernel that, like a stage kernel, reads its neighbours' words and rewrites its own (q <- f(q, left, right)): the engine's
+// data flow across XCDs on the recycled range, compared with the same recurrence on a buffer allocated before any window existed
+__global__ void relax(const unsigned long long *in, unsigned long long *out, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const unsigned long long l = in[(i + n - 257) % n], r = in[(i + 257) % n];
+  out[i] = in[i] * 6364136223846793005ull + (l ^ (r >> 7)) + 1442695040888963407ull;
+}
+__global__ void compare(const unsigned long long *a, const unsigned long long *b, int n, unsigned int *bad) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && a[i] != b[i]) atomicAdd(bad, 1u);
 }
 
 static void put(int fd, const void *b, size_t n) { if (write(fd, b, n) != (ssize_t)n) std::exit(3); }
@@ -77,6 +91,9 @@ int main(int argc, char **argv) {
   unsigned int *bad = nullptr;
   CHK(hipMalloc((void **)&bad, 4));
   CHK(hipMemset(bad, 0, 4));
+  unsigned long long *ref[2];   // allocated before any window exists: never in a recycled range
+  CHK(hipMalloc((void **)&ref[0], kBlock));
+  CHK(hipMalloc((void **)&ref[1], kBlock));
   long total_bad = 0, bad_iters = 0;
   for (int it = 0; it < iters; ++it) {
     void *blk = nullptr;
@@ -110,10 +127,19 @@ int main(int argc, char **argv) {
     CHK(hipDeviceSynchronize());
     for (int rep = 0; rep < 40; ++rep) {
       for (int k = 0; k < 6; ++k)
-        hipLaunchKernelGGL(verify, dim3(kWords / 256), dim3(256), 0, 0, bufs[k], (unsigned long long)(it * 8 + k), kWords, bad);
+        hipLaunchKernelGGL(verify, dim3(kWords / 256), dim3(256), 0, 0, bufs[k], (unsigned long long)(it * 8 + k), kWords, bad, rep % 9);
       CHK(hipDeviceSynchronize());
       usleep(100);
     }
+    // the recurrence: 30 sweeps ping-ponging between two of the new buffers, against the same on the two old ones
+    hipLaunchKernelGGL(fill, dim3(kWords / 256), dim3(256), 0, 0, ref[0], 7ull, kWords);
+    hipLaunchKernelGGL(fill, dim3(kWords / 256), dim3(256), 0, 0, bufs[0], 7ull, kWords);
+    for (int sw = 0; sw < 30; ++sw) {
+      hipLaunchKernelGGL(relax, dim3(kWords / 256), dim3(256), 0, 0, ref[sw & 1], ref[(sw + 1) & 1], kWords);
+      hipLaunchKernelGGL(relax, dim3(kWords / 256), dim3(256), 0, 0, bufs[sw & 1], bufs[(sw + 1) & 1], kWords);
+    }
+    hipLaunchKernelGGL(compare, dim3(kWords / 256), dim3(256), 0, 0, ref[0], bufs[0], kWords, bad);
+    CHK(hipDeviceSynchronize());
     unsigned int nb = 0;
     CHK(hipMemcpy(&nb, bad, 4, hipMemcpyDeviceToHost));
     if (nb) { ++bad_iters; total_bad += nb; CHK(hipMemset(bad, 0, 4)); }
