@@ -1140,7 +1140,7 @@ int sync_all(dflo_hip_multi *m) {
     MHIP(m, hipStreamSynchronize(g.M));
   }
   if (m->ipc_fail_host && *m->ipc_fail_host) {
-    set_err(m, "a neighbour's records did not arrive within 30 s (DFLO_RANK_TRANSPORT=ipc: a rank died or fell out of step)");
+    set_err(m, "a neighbour's records did not arrive within DFLO_IPC_TIMEOUT_S (DFLO_RANK_TRANSPORT=ipc: a rank died or fell out of step)");
     return DFLO_ERR_COMM;
   }
   return DFLO_OK;

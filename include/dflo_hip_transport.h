@@ -106,7 +106,7 @@ int dflo_hip_stage_deliver(dflo_hip_handle h, int area, uint64_t seq);
 /* ... and the arrival of the neighbours' traces of the stage BEFORE can be awaited inside that launch as well: set_arrival_words
  * names this engine's own sequence words (one per neighbour that sends; fine-grained memory) and a host-mapped failure word;
  * stage_await(seq), together with stage_deliver, makes the workgroups of the shards that read ghost traces poll the words behind
- * their own loads until they have reached seq (30 s, then the failure word).  The other workgroups wait for nothing.  Only where
+ * their own loads until they have reached seq (DFLO_IPC_TIMEOUT_S, default 120 s: then the failure word goes up and the workgroup leaves the kernel without computing or delivering).  The other workgroups wait for nothing.  Only where
  * the trace tables are fine-grained memory (or written by this device itself): the traces are read inside the running kernel. */
 int dflo_hip_set_arrival_words(dflo_hip_handle h, int n, void *const *words, void *fail);
 int dflo_hip_stage_await(dflo_hip_handle h, uint64_t seq);
