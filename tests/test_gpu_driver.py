@@ -695,3 +695,26 @@ def test_bench_line_of_two_ranks_launched_the_drivers_way(extra):
         drift = float(c["check"].split("=")[-1])
         assert drift < 1e-12, c["check"]      # the cut faces are evaluated by both ranks with the same bits
     assert abs(d["value"] - c["n_dofs"] * c["n_rk"] / (d["ms_per_step"] * 1e-3) / 1e6) <= 1e-6 * d["value"]
+
+
+def test_an_ipc_attempt_whose_totals_do_not_hold_is_not_counted_and_is_run_again_with_the_strict_protocol():
+    """bench.py --gpus 2 on one GPU (gloo, then the IPC transport over gloo).  The IPC attempt's totals are made to differ from the
+    host-staged run's in the 7th digit (test hook) -- what a run that read stale halos would look like on a configuration whose own
+    check is only "finite and admissible": it is not counted, the line is the library transport's, and one more attempt runs with
+    DFLO_IPC_STRICT=1 (a system-scope release per delivering workgroup), which holds and may win."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(29300 + os.getpid() % 200), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--config", "c3"]
+    env = dict(os.environ, DFLO_BENCH_TRANSPORTS="gloo,ipc_gloo", DFLO_BENCH_ALL_TRANSPORTS="1", DFLO_BENCH_ONE_GPU="1", DFLO_BENCH_WATCHDOG_S="400",
+               DFLO_BENCH_TEST_BAD_TOTALS="ipc_gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    tr = {t["transport"]: t for t in d["config"]["transports"]}
+    assert sorted(tr) == ["gloo", "ipc_gloo", "ipc_strict"], sorted(tr)
+    assert tr["gloo"]["ok"] and not tr["ipc_gloo"]["ok"] and "NOT COUNTED" in tr["ipc_gloo"]["check"] and "differ from the gloo run's" in tr["ipc_gloo"]["check"]
+    assert tr["ipc_strict"]["ok"] and "equal the gloo run's" in tr["ipc_strict"]["validated"]
+    assert d["config"]["transport_used"] in ("gloo", "ipc_strict")
+    assert abs(d["value"] - max(tr["gloo"]["value"], tr["ipc_strict"]["value"])) <= 0.06
