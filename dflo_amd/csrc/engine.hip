@@ -125,6 +125,10 @@ struct dflo_hip_engine {
   unsigned int *send_done = nullptr;   // [3] workgroup counters of the signalling pack kernels, by kind (dflo_hip_pack_send_to_signal)
   bool peer_fine = false;              // DFLO_PEER_FINEGRAINED=1: what a peer's kernel writes lives in fine-grained memory
   const double *ghost_avg_src = nullptr;   // dflo_hip_ghost_avg_source: where the Qk limiter pass finds the ghost cells' averages
+  int32_t *d_rim_ghost_list = nullptr, *d_gt_begin = nullptr;   // the rim shards and behind them the ghost shards; first trace of every ghost shard
+  const double *ghost_ride_rec = nullptr;  // armed by dflo_hip_limit_ghost_cells: the records the next rim limiter pass takes along
+  int ghost_ride_table = -1;
+  double *d_gnb = nullptr;                 // [n_ghost][4 faces][4]: averages of the ghost cells' neighbours on their owners' side (dflo_hip_limit_ghost_cells)
   // ghost cells known by their face traces (Qk without the KXRCF indicator): two buffers, the stage kernels read Tg[tg_cur]
   // while the neighbours' next traces arrive in the other one
   bool trace_halo = false;
@@ -739,6 +743,24 @@ int launch_limiter(dflo_hip_engine *h, int tvb, int pos, int part, bool stage_da
   }
   void (*lf)(const LimArgs) = DFLO_BY_N_LIM(h->N, limiter_kernel);
   if (h->basis == DFLO_BASIS_PK) lf = DFLO_BY_N_LIM(h->N, limiter_pk_kernel);
+  if (h->ghost_ride_rec && part == 1 && stage_data) {   // the neighbours' unlimited cut cells ride along (dflo_hip_limit_ghost_cells)
+    const int n_ghost = p.n_cells - p.n_owned;
+    const long long tot = (long long)n_ghost * (h->ndof + kFatExtra);
+    hipLaunchKernelGGL(unpack_fat_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, h->ghost_ride_rec, h->U[h->cur],
+                       h->avg[h->avg_cur], h->d_gnb, p.n_shards * 64, n_ghost, h->ndof);
+    HIPCHK(h, hipGetLastError());
+    l.shard_list = h->d_rim_ghost_list;
+    l.n_list += p.n_ghost_shards;
+    l.ghost_avg = h->d_gnb;          // "slots" from n_slots on (Plan::ghost_lrbt): entry 4 g + f of the records' neighbour averages;
+    l.first_ghost_slot = p.n_slots;  // the rim cells find their ghost neighbours' averages in the array, where the unpack has put them
+    l.gt_begin = h->d_gt_begin;
+    l.gt_slot = h->d_gt_slot;
+    l.gt_face = h->d_gt_face;
+    l.gt_out = h->Tg[h->ghost_ride_table];
+    lf = DFLO_BY_N_LIM(h->N, limiter_rim_ghost_kernel);
+    h->ghost_ride_rec = nullptr;
+    h->ghost_ride_table = -1;
+  }
   int grid = grid_for(l.n_list);
   if (l.mask && (part == 0 || part == 2) && h->lim_open >= 0 && h->basis == DFLO_BASIS_QK && (part == 0) == (h->lim_parts == 0)) {
     l.mark_list = h->lim_list;
@@ -1080,7 +1102,11 @@ int dflo_hip_create_with_cell_size(const dflo_mesh_t *mesh, const dflo_params_t 
     hipMemset(h->bval[w], 0, nb * sizeof(double));
   }
   if ((rc = upload(h, &h->bface_kind, kinds))) return bail(rc);
-  if ((rc = upload(h, &h->d_shard_count, p.shard_count))) return bail(rc);
+  {   // (behind the owned shards' counts those of the ghost shards: the limiter pass over the ghost cells, dflo_hip_limit_ghost_cells)
+    std::vector<int32_t> counts(p.shard_count);
+    counts.insert(counts.end(), p.ghost_count.begin(), p.ghost_count.end());
+    if ((rc = upload(h, &h->d_shard_count, counts))) return bail(rc);
+  }
   {  // fixed-pitch copies of the per-shard lists (+2 shards of slack: the kernel reads two shards ahead,
      // and 2*64*N face slots per shard so that unconditional loads stay in bounds)
     const int ns = p.n_shards + 2;
@@ -1146,8 +1172,19 @@ int dflo_hip_create_with_cell_size(const dflo_mesh_t *mesh, const dflo_params_t 
       hipMemset(h->Tg[i], 0, (size_t)h->n_gt * 4 * h->N * sizeof(double));
     }
   }
-  if ((rc = upload(h, &h->d_lrbt, p.lrbt))) return bail(rc);
+  {   // (... and the ghost cells' neighbours behind the owned cells')
+    std::vector<int32_t> nb(p.lrbt);
+    nb.insert(nb.end(), p.ghost_lrbt.begin(), p.ghost_lrbt.end());
+    if ((rc = upload(h, &h->d_lrbt, nb))) return bail(rc);
+  }
   if ((rc = upload(h, &h->d_rim_list, p.rim_shards))) return bail(rc);
+  {   // (the limiter pass over the rim that takes the ghost cells along: dflo_hip_limit_ghost_cells)
+    std::vector<int32_t> rg(p.rim_shards), gb(p.n_ghost_shards + 1, 0);
+    for (int k = 0; k < p.n_ghost_shards; ++k) rg.push_back(p.n_shards + k);
+    for (int32_t sl : p.gt_cell) ++gb[sl / 64 - p.n_shards + 1];
+    for (int k = 0; k < p.n_ghost_shards; ++k) gb[k + 1] += gb[k];
+    if ((rc = upload(h, &h->d_rim_ghost_list, rg)) || (rc = upload(h, &h->d_gt_begin, gb))) return bail(rc);
+  }
   if ((rc = upload(h, &h->d_int_list, p.interior_shards))) return bail(rc);
   if ((rc = upload(h, &h->d_rim2_list, p.rim2_shards))) return bail(rc);
   if ((rc = upload(h, &h->d_rest2_list, p.rest2_shards))) return bail(rc);
@@ -1289,6 +1326,7 @@ int dflo_hip_destroy(dflo_hip_handle h) {
   if (!h->tg_external) { hipFree(h->Tg[0]); hipFree(h->Tg[1]); }
   hipFree(h->d_wt_flag); hipFree(h->d_dla_begin); hipFree(h->d_dla_slot); hipFree(h->d_dla_dst[0]); hipFree(h->d_dla_dst[1]); hipFree(h->d_dla_flag); hipFree(h->d_wta_flag);
   hipFree(h->d_dl_begin); hipFree(h->d_dl_rec); hipFree(h->d_dl_dst[0]); hipFree(h->d_dl_dst[1]); hipFree(h->d_dl_flag);
+  hipFree(h->d_gnb); hipFree(h->d_rim_ghost_list); hipFree(h->d_gt_begin);
   hipFree(h->d_gt_slot); hipFree(h->d_gt_face); hipFree(h->d_sendf_slot); hipFree(h->d_sendf_face); hipFree(h->d_send_slots); hipFree(h->ghost_stage);
   for (int i = 0; i < 2; ++i) if (h->ev_chunk[i]) hipEventDestroy(h->ev_chunk[i]);
   for (auto &e : h->ev_pool) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
@@ -2000,6 +2038,42 @@ int dflo_hip_pack_send_cells(dflo_hip_handle h, void *device_buffer) {
   return DFLO_OK;
 }
 
+int dflo_hip_pack_send_cells_unlimited(dflo_hip_handle h, void *device_buffer) {
+  if (check_handle(h) || !device_buffer) return DFLO_ERR_BAD_PARAM;
+  if (h->basis != DFLO_BASIS_QK) { h->err = "pack_send_cells_unlimited: Qk only"; return DFLO_ERR_UNSUPPORTED; }
+  hipSetDevice(h->device);
+  if (h->n_send == 0) return DFLO_OK;
+  const long long tot = (long long)h->n_send * (h->ndof + kFatExtra);
+  hipLaunchKernelGGL(pack_fat_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, (double *)device_buffer,
+                     (const double *)h->U[h->cur], (const double *)h->avg[h->avg_cur], (const int32_t *)h->d_lrbt, (const int32_t *)h->d_send_slots,
+                     h->n_send, h->ndof);
+  HIPCHK(h, hipGetLastError());
+  return DFLO_OK;
+}
+
+// The receiving side of the one-exchange TVB stage: the neighbours' cut cells as pack_send_cells_unlimited left them.  The NEXT
+// dflo_hip_stage_limit_part(h, 1) -- the limiter pass over the rim shards -- takes them along: an unpack kernel puts the records
+// into the ghost shards, the averages' array and d_gnb; the pass then runs over the rim shards AND the ghost shards (the routine
+// that limits the owned cells, with a neighbour's average from this part's array where it is an owned cell and from the record
+// where it lives with the ghost's owner: the owner's inputs, arithmetic and bits) and the wavefronts of the ghost shards form the
+// traces of their limited cells into trace table `table` (launch_limiter).
+int dflo_hip_limit_ghost_cells(dflo_hip_handle h, const void *records, int table) {
+  if (check_handle(h) || table < 0 || table > 1) return DFLO_ERR_BAD_PARAM;
+  hipSetDevice(h->device);
+  const Plan &p = h->plan;
+  const int n_ghost = p.n_cells - p.n_owned;
+  if (n_ghost == 0) return DFLO_OK;
+  if (!records) return DFLO_ERR_BAD_PARAM;
+  if (!h->trace_halo || h->basis != DFLO_BASIS_QK || h->prm.limiter_type != DFLO_LIMITER_TVB || h->d_shock) {
+    h->err = "limit_ghost_cells: needs ghost cells known by their traces (Qk) and a TVB limiter without the KXRCF indicator";
+    return DFLO_ERR_UNSUPPORTED;
+  }
+  if (!h->d_gnb && dmalloc((void **)&h->d_gnb, (size_t)n_ghost * 16 * sizeof(double)) != hipSuccess) { h->err = "hipMalloc(ghost neighbours) failed"; return DFLO_ERR_NOMEM; }
+  h->ghost_ride_rec = (const double *)records;
+  h->ghost_ride_table = table;
+  return DFLO_OK;
+}
+
 int dflo_hip_unpack_ghost_cells(dflo_hip_handle h, const void *device_buffer) {
   if (check_handle(h)) return DFLO_ERR_BAD_PARAM;
   hipSetDevice(h->device);
@@ -2054,7 +2128,7 @@ int dflo_hip_pack_send_to(dflo_hip_handle h, int kind, int n_segments, const int
 
 int dflo_hip_pack_send_to_signal(dflo_hip_handle h, int kind, int n_segments, const int32_t *first, void *const *dst, void *const *flags,
                                  uint64_t seq) {
-  if (check_handle(h) || kind < 0 || kind > 2 || n_segments < 0 || n_segments > kMaxSegs || (n_segments > 0 && (!first || !dst))) return DFLO_ERR_BAD_PARAM;
+  if (check_handle(h) || kind < 0 || kind > 3 || n_segments < 0 || n_segments > kMaxSegs || (n_segments > 0 && (!first || !dst))) return DFLO_ERR_BAD_PARAM;
   hipSetDevice(h->device);
   const int n = kind == 2 ? h->n_send_faces : h->n_send;
   if (n == 0 || n_segments == 0) return DFLO_OK;
@@ -2066,7 +2140,7 @@ int dflo_hip_pack_send_to_signal(dflo_hip_handle h, int kind, int n_segments, co
     seg.flag[i] = flags ? (unsigned long long *)flags[i] : nullptr;
   }
   seg.seq = seq;
-  seg.done = flags ? h->send_done + kind : nullptr;
+  seg.done = flags ? h->send_done + (kind == 3 ? 0 : kind) : nullptr;   // (kind 3 takes the place of kind 0: never both in one run)
   seg.first[n_segments] = first[n_segments];
   if (first[0] != 0 || first[n_segments] != n) { h->err = "pack_send_to: the segments must cover the send list"; return DFLO_ERR_COMM; }
   if (kind == 2) {
@@ -2074,6 +2148,10 @@ int dflo_hip_pack_send_to_signal(dflo_hip_handle h, int kind, int n_segments, co
     auto fn = DFLO_BY_N(h->N, face_trace_to_kernel);
     hipLaunchKernelGGL(fn, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, seg, (const double *)h->U[h->cur],
                        (const int32_t *)h->d_sendf_slot, (const int32_t *)h->d_sendf_face, n);
+  } else if (kind == 3) {   // unlimited cells with their neighbours' averages (dflo_hip_pack_send_cells_unlimited)
+    const long long tot = (long long)n * (h->ndof + kFatExtra);
+    hipLaunchKernelGGL(pack_fat_to_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, seg, (const double *)h->U[h->cur],
+                       (const double *)h->avg[h->avg_cur], (const int32_t *)h->d_lrbt, (const int32_t *)h->d_send_slots, n, h->ndof);
   } else {
     const int w = kind == 0 ? h->ndof + 4 : 4;
     const long long tot = (long long)n * w;

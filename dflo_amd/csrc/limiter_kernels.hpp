@@ -102,13 +102,19 @@ struct LimArgs {
   unsigned long long wt_seq;
   int *wt_fail;
   long long wt_ticks;
+  // limiter_rim_ghost_kernel (multi-device TVB stage with one exchange): the launch's list also holds the ghost shards (numbers from
+  // n_shards on); a ghost shard's wavefront limits its cells whatever the marks say and then forms the traces gt_begin[k] ..
+  // gt_begin[k + 1] of ghost shard k -- (ghost cell, face) pairs gt_slot / gt_face -- into gt_out [trace][4][N]
+  const int32_t *gt_begin, *gt_slot, *gt_face;
+  double *gt_out;
   KBasis kb;
 };
 
 // apply_limiter_TVB_Qk (src/limiter.cc:225-370) then apply_positivity_limiter
 // (src/positivity.cc:17-208), lane = cell, all DoFs of the cell in registers.
 template <int N>
-__device__ __forceinline__ void limiter_shard(const LimArgs &a, const int shard, const bool listed = false, const unsigned long long word = 0) {
+__device__ __forceinline__ void limiter_shard(const LimArgs &a, const int shard, const bool listed = false, const unsigned long long word = 0,
+                                              const bool masked = true) {
   constexpr int NS = N * N, NDOF = 4 * NS;
   const int lane = threadIdx.x;
   const bool active = lane < a.shard_count[shard];   // padding lanes hold a harmless state and run along
@@ -118,7 +124,7 @@ __device__ __forceinline__ void limiter_shard(const LimArgs &a, const int shard,
   // With the stage kernel's marks only the cells the limiters can change go through the pass (the others are provably left
   // as they are, see the stage kernel): most wavefronts return after one load.
   bool marked = true;
-  if (a.mask) {
+  if (a.mask && masked) {
     const unsigned long long m = listed ? word : a.mask[shard];   // listed: the word came with the list entry (one round trip less)
     if (m == 0) return;
     if (lane == 0) a.mask[shard] = 0;   // consumed (the load above has returned: m was compared)
@@ -360,6 +366,28 @@ __global__ __launch_bounds__(64) void limiter_kernel(const LimArgs a) {
   }
   limiter_shard<N>(a, shard);
   if (rim) deliver_face_traces<N>(a.dl_begin, a.dl_rec, a.dl_dst, a.dl_flag, a.dl_nflag, a.dl_total, a.dl_seq, a.dl_done, a.U, shard, a.dl_fence);
+}
+
+// The rim shards and the ghost shards in one launch (LimArgs::gt_begin): what a part does with its neighbours' unlimited cut cells.
+// A ghost cell is limited as its owner limits the original -- same inputs (the record: DoFs, average, the owner's side of the
+// neighbourhood; this part's own averages across the cut), same arithmetic --, then its traces on the cut faces are formed as
+// face_trace_kernel forms them (cell_face_trace: the bits the owner would have sent after its own limiter pass).
+template <int N>
+__global__ __launch_bounds__(64) void limiter_rim_ghost_kernel(const LimArgs a) {
+  const int sidx = shard_of_block(blockIdx.x, a.n_list, a.sweep_rev);
+  if (sidx < 0) return;
+  const int shard = a.shard_list[sidx];
+  const bool ghost = shard >= a.n_shards;   // wave-uniform
+  limiter_shard<N>(a, shard, false, 0, !ghost);
+  if (!ghost) return;
+  const int b0 = a.gt_begin[shard - a.n_shards], n = a.gt_begin[shard - a.n_shards + 1] - b0;
+  if (n == 0) return;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the limited cells are in U (same compute unit: deliver_face_traces)
+  __syncthreads();
+  for (int t = threadIdx.x; t < n * 4 * N; t += 64) {
+    const int j = b0 + t / (4 * N), r = t - (t / (4 * N)) * (4 * N);
+    a.gt_out[(size_t)j * 4 * N + r] = cell_face_trace<N>(a.U, a.gt_slot[j], a.gt_face[j], r / N, r % N);
+  }
 }
 
 // apply_limiter_TVB_Pk (src/limiter.cc:377-516) then the Pk branch of apply_positivity_limiter

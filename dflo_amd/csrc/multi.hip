@@ -280,6 +280,11 @@ struct dflo_hip_multi {
   bool direct = true;          // one process: the pack kernels write into the peers' receive areas (DFLO_MULTI_COPY=1: staging buffer + hipMemcpyPeerAsync)
   bool need_avg = true;        // somebody reads the ghost cells' averages (LxF flux, TVB limiter): they travel with the traces
   bool avg_in_place = false;   // TVB without the LxF flux, face-trace halos: only the rim limiter reads ghost averages, from the receive area
+  // TVB stages with ONE exchange instead of the reference's two (src_mpi/limiter.cc:232 + src_mpi/claw.cc:793): the cut cells travel
+  // unlimited, as CH_CELLS records widened by the averages of their face neighbours, and every part limits its ghost cells itself
+  // (dflo_hip_limit_ghost_cells).  Needs every cut cell to border on one other part only (one_neighbour), ghost cells known by traces
+  bool tvb_one = false, one_neighbour = true;
+  bool dt_on_comm = false;     // DFLO_DT_ON_COMM=1 (reduce_dt_rank)
   std::atomic<bool> abort{false};                 // a part's thread has failed: the others stop waiting for it
   std::atomic<int64_t> stop_at{INT64_MAX};        // threaded advance: the step at which every thread leaves the loop
   bool strict = false;         // DFLO_MULTI_STRICT=1: a sender waits for an explicit "consumed" event of the receive area
@@ -468,8 +473,10 @@ struct ChanView {
 ChanView chan(dflo_hip_multi *m, Part &p, int kind, int par) {
   if (kind == CH_AVG) return {p.send_off, p.recv_off, 4, p.recv_a[par]};
   if (kind == CH_TRACES) return {p.sendf_off.data(), p.recvf_off.data(), 4 * m->N, (double *)p.tg[par]};
-  return {p.send_off, p.recv_off, m->ndof + 4, p.recv_u[par]};
+  return {p.send_off, p.recv_off, m->ndof + (m->tvb_one ? 20 : 4), p.recv_u[par]};
 }
+// the engine's number for the records of a channel (dflo_hip_pack_send_to)
+int eng_kind(const dflo_hip_multi *m, int kind) { return kind == CH_CELLS ? (m->tvb_one ? 3 : 0) : (kind == CH_AVG ? 1 : 2); }
 
 void xt_begin(Part &p, hipStream_t st = nullptr) {
   p.x_open = p.x_on && (p.x_seen++ % 5 == 0) && p.x_used < 4096;
@@ -516,13 +523,14 @@ int post(dflo_hip_multi *m, Part &p, int kind, int par) {
     }
     if (nseg) {
       first[nseg] = v.so[m->n_parts];
-      MENG(m, p, dflo_hip_pack_send_to_signal(p.eng, kind == CH_CELLS ? 0 : (kind == CH_AVG ? 1 : 2), nseg, first, dst, fl, seq));
+      MENG(m, p, dflo_hip_pack_send_to_signal(p.eng, eng_kind(m, kind), nseg, first, dst, fl, seq));
     }
     return DFLO_OK;
   }
   if (!direct) {   // into the staging buffer first
     if (kind == CH_AVG) MENG(m, p, dflo_hip_pack_send_avg(p.eng, send));
     else if (kind == CH_TRACES) MENG(m, p, dflo_hip_pack_send_traces(p.eng, send));
+    else if (m->tvb_one) MENG(m, p, dflo_hip_pack_send_cells_unlimited(p.eng, send));
     else MENG(m, p, dflo_hip_pack_send_cells(p.eng, send));
   }
   if (m->rank_mode && m->x_exchange) {
@@ -597,7 +605,7 @@ int post(dflo_hip_multi *m, Part &p, int kind, int par) {
   }
   if (direct && nseg) {
     first[nseg] = v.so[m->n_parts];
-    MENG(m, p, dflo_hip_pack_send_to(p.eng, kind == CH_CELLS ? 0 : (kind == CH_AVG ? 1 : 2), nseg, first, dst));
+    MENG(m, p, dflo_hip_pack_send_to(p.eng, eng_kind(m, kind), nseg, first, dst));
   }
   bool foreign = false;   // a receiver on another stream (its own device's): it waits for this record
   for (int q : p.peers) foreign |= local_part(m, q)->C != p.C;
@@ -783,7 +791,8 @@ int stage_phase(dflo_hip_multi *m, Group &g, const StageCtx &s, int ph) {
           if (last_part) MENG(m, p, dflo_hip_attach_event(p.eng, g.ev_rim));
           MENG(m, p, dflo_hip_stage_limit_part(p.eng, 1));
         }
-        rc = m->tvb ? post(m, p, CH_AVG, apar) : send_state(m, p, upar, apar, true);
+        // (tvb_one: the rim's cells as the update left them, with the averages of their neighbours -- rim and ring are updated)
+        rc = m->tvb ? (m->tvb_one ? post(m, p, CH_CELLS, upar) : post(m, p, CH_AVG, apar)) : send_state(m, p, upar, apar, true);
         MENG(m, p, dflo_hip_set_stream(p.eng, g.M));
         if (rc) return rc;
       }
@@ -805,6 +814,20 @@ int stage_phase(dflo_hip_multi *m, Group &g, const StageCtx &s, int ph) {
       return DFLO_OK;
     case 3:   // TVB: the averages of the neighbours across the cut arrive: limit the rim, send its cells
       if (!m->tvb) return DFLO_OK;
+      if (m->tvb_one) {   // the neighbours' unlimited cut cells arrive: limit them as their owners do, form their traces; limit the rim
+        for (int i : g.parts) {
+          Part &p = m->parts[i];
+          int rc = arrive(m, p, CH_CELLS, upar);
+          if (rc) return rc;
+          MENG(m, p, dflo_hip_set_stream(p.eng, g.C));
+          MENG(m, p, dflo_hip_limit_ghost_cells(p.eng, p.recv_u[upar], upar));   // (the rim's limiter pass takes them along: unpack, rim + ghost shards, traces)
+          MENG(m, p, dflo_hip_stage_limit_part(p.eng, 1));
+          if ((rc = mark_used(m, p, CH_CELLS, upar))) return rc;
+          MENG(m, p, dflo_hip_set_stream(p.eng, g.M));
+        }
+        MHIP(m, hipEventRecord(g.ev_rim, g.C));
+        return DFLO_OK;
+      }
       for (int i : g.parts) {
         Part &p = m->parts[i];
         int rc = arrive(m, p, CH_AVG, apar);
@@ -851,6 +874,10 @@ int stage_phase(dflo_hip_multi *m, Group &g, const StageCtx &s, int ph) {
     default:  // the neighbours' cells arrive: into the ghost shards, ready for the next stage's rim (same stream)
       for (int i : g.parts) {
         Part &p = m->parts[i];
+        if (m->tvb_one) {   // phase 3 has formed the ghost traces of this stage
+          MENG(m, p, dflo_hip_use_ghost_traces(p.eng, upar));
+          continue;
+        }
         MENG(m, p, dflo_hip_set_stream(p.eng, g.C));
         const int rc = recv_state(m, p, upar, apar, !m->tvb);
         MENG(m, p, dflo_hip_set_stream(p.eng, g.M));
@@ -1049,17 +1076,25 @@ int reduce_dt_rank(dflo_hip_multi *m) {
     MHIP(m, hipGetLastError());
     return DFLO_OK;
   }
-  MHIP(m, hipEventRecord(p.ev_fin[0], p.M));
-  MHIP(m, hipStreamWaitEvent(p.C, p.ev_fin[0], 0));
+  // On the compute stream, where its producer (the step's reductions) and its consumers (the next step's kernels) are: no hop to
+  // the comm stream and back (two event waits, ~10 us each, per step: LAB R6.12).  DFLO_DT_ON_COMM=1: round 5's route.
+  const bool hop = m->dt_on_comm;
+  hipStream_t st = hop ? p.C : p.M;
+  if (hop) {
+    MHIP(m, hipEventRecord(p.ev_fin[0], p.M));
+    MHIP(m, hipStreamWaitEvent(p.C, p.ev_fin[0], 0));
+  }
   void *slot = nullptr;
   MENG(m, p, dflo_hip_dt_slot(p.eng, &slot));
   if (m->x_allreduce) {
-    if (m->x_allreduce(m->x_user, (double *)slot, 1, DFLO_REDUCE_MIN, (void *)p.C)) { set_err(m, "the host program's all-reduce callback failed"); return DFLO_ERR_COMM; }
+    if (m->x_allreduce(m->x_user, (double *)slot, 1, DFLO_REDUCE_MIN, (void *)st)) { set_err(m, "the host program's all-reduce callback failed"); return DFLO_ERR_COMM; }
   } else {
-    MNCCL(m, g_rccl.AllReduce(slot, slot, 1, ncclDouble, ncclMin, m->comm, p.C));
+    MNCCL(m, g_rccl.AllReduce(slot, slot, 1, ncclDouble, ncclMin, m->comm, st));
   }
-  MHIP(m, hipEventRecord(p.ev_dt, p.C));
-  MHIP(m, hipStreamWaitEvent(p.M, p.ev_dt, 0));
+  if (hop) {
+    MHIP(m, hipEventRecord(p.ev_dt, p.C));
+    MHIP(m, hipStreamWaitEvent(p.M, p.ev_dt, 0));
+  }
   return DFLO_OK;
 }
 int reduce_dt_phase(dflo_hip_multi *m, Part &p, int64_t step, int ph) {
@@ -1494,17 +1529,17 @@ int setup_part(dflo_hip_multi *m, Part &p, const dflo_mesh_t *mesh, const dflo_p
     }
   MENG(m, p, dflo_hip_set_send_cells(p.eng, p.n_send, p.send_cells));
   const size_t ns = std::max(p.n_send, 1), ng = std::max(p.n_ghost, 1);
-  MHIP(m, hipMalloc((void **)&p.send_u, ns * (m->ndof + 4) * sizeof(double)));   // DoFs + cell average per cell
+  MHIP(m, hipMalloc((void **)&p.send_u, ns * (m->ndof + 20) * sizeof(double)));   // DoFs + cell average per cell (+ the neighbours' averages: tvb_one)
   MHIP(m, hipMalloc((void **)&p.send_a, ns * 4 * sizeof(double)));
   {   // the receive areas are written by the neighbours' kernels (stores over xGMI): plain device memory, coherent at the kernel
       // boundaries the schedule provides, or -- DFLO_PEER_FINEGRAINED=1, like the engine's trace and time-step tables -- fine-grained
     const bool fine = dflo::read_tunables().peer_finegrained;
     for (int i = 0; i < 2; ++i) {
       if (fine) {
-        MHIP(m, hipExtMallocWithFlags((void **)&p.recv_u[i], ng * (m->ndof + 4) * sizeof(double), hipDeviceMallocFinegrained));
+        MHIP(m, hipExtMallocWithFlags((void **)&p.recv_u[i], ng * (m->ndof + 20) * sizeof(double), hipDeviceMallocFinegrained));
         MHIP(m, hipExtMallocWithFlags((void **)&p.recv_a[i], ng * 4 * sizeof(double), hipDeviceMallocFinegrained));
       } else {
-        MHIP(m, hipMalloc((void **)&p.recv_u[i], ng * (m->ndof + 4) * sizeof(double)));
+        MHIP(m, hipMalloc((void **)&p.recv_u[i], ng * (m->ndof + 20) * sizeof(double)));
         MHIP(m, hipMalloc((void **)&p.recv_a[i], ng * 4 * sizeof(double)));
       }
     }
@@ -1605,6 +1640,25 @@ int create_common(const dflo_mesh_t *mesh, const dflo_params_t *prm, dflo_hip_mu
   return DFLO_OK;
 }
 
+// Does every cell on a cut border on ONE other part only?  (What the one-exchange TVB stage needs: a ghost cell's neighbours are
+// then cells of the receiver or of the ghost's owner, whose averages the owner can send along.  A function of the mesh, the number
+// of parts and the partitioner alone: every rank finds the same answer without asking the others.)
+void find_one_neighbour(dflo_hip_multi *m, const dflo_mesh_t *mesh, int method) {
+  m->one_neighbour = true;
+  if (m->self_halo || m->n_parts < 2 || !m->tvb) return;
+  std::vector<int32_t> owner(mesh->n_cells);
+  if (dflo_mesh_partition_owners(mesh, m->n_parts, method, owner.data())) { m->one_neighbour = false; return; }
+  for (int32_t c = 0; c < mesh->n_cells && m->one_neighbour; ++c) {
+    int other = -1;
+    for (int f = 0; f < 4; ++f) {
+      const int32_t nb = mesh->cell_face_neighbor[(size_t)c * 4 + f];
+      if (nb < 0 || owner[nb] == owner[c]) continue;
+      if (other >= 0 && owner[nb] != other) m->one_neighbour = false;
+      other = owner[nb];
+    }
+  }
+}
+
 void finish_setup(dflo_hip_multi *m) {
   m->n_rk = dflo_hip_n_rk(m->parts[0].eng);
   // who reads the average of a ghost cell: the LxF flux (lambda from the cell averages, src/equation.h:357-359) and the TVB
@@ -1616,6 +1670,13 @@ void finish_setup(dflo_hip_multi *m) {
   // unless DFLO_FUSE_POS=0 says otherwise)
   const bool fused = m->prm.pos_lim && !m->tvb && m->basis == DFLO_BASIS_QK && dflo::read_tunables().fuse_pos;
   m->sep_limiter = m->limited && !fused;
+  m->dt_on_comm = dflo::read_tunables().dt_on_comm;
+  {
+    const int want = dflo::read_tunables().tvb_one_exchange;   // unset: where an exchange is a library call
+    m->tvb_one = m->tvb && !m->kxrcf && !m->ipc && !m->want_ipc && m->one_neighbour && (want < 0 ? (m->rank_mode || m->loopback) : want != 0);
+  }
+  for (Part &p : m->parts) m->tvb_one = m->tvb_one && p.trace;
+  if (m->tvb_one) m->avg_in_place = false;   // (the ghost averages come out of the records into the engine's array)
 }
 
 }  // namespace
@@ -1695,6 +1756,7 @@ int dflo_hip_multi_create(const dflo_mesh_t *mesh, const dflo_params_t *params, 
   m->n_parts = n_devices;
   int rc = create_common(mesh, params, m);
   if (rc) return bail(rc);
+  find_one_neighbour(m, mesh, partitioner);
   const dflo::Tunables tun = dflo::read_tunables();
   m->loopback = tun.loopback;
   m->strict = tun.strict;
@@ -1786,6 +1848,7 @@ static int create_rank_impl(const dflo_mesh_t *mesh, const dflo_params_t *params
   m->rank_mode = true;
   int rc = create_common(mesh, params, m);
   if (rc) return bail(rc);
+  find_one_neighbour(m, mesh, partitioner);
   m->parts.resize(1);
   m->sync.reset(new Sync[1]);
   m->parts[0].index = rank;
@@ -2299,6 +2362,9 @@ int dflo_hip_multi_comm_info(dflo_hip_multi_handle m, int32_t *comm_count, int32
   else t = m->direct ? "one process: pack kernels storing into the peers' receive areas (xGMI peer access)" : "one process: staging buffer + hipMemcpyPeerAsync";
   if (m->ipc && !m->self_halo ? m->ipc_fine : dflo::read_tunables().peer_finegrained) t += "; peer-written buffers in fine-grained memory";
   if (m->strict) t += "; strict (senders wait for the receivers' consumed events)";
+  if (m->tvb && !m->fused_tvb && any_peers(m))
+    t += m->tvb_one ? "; TVB: one exchange per stage (unlimited cut cells + their neighbours' averages; ghost cells limited by the receiver)"
+                    : "; TVB: two exchanges per stage (averages, then the limited state)";
   if (comm_count) *comm_count = cnt;
   if (comm_rank) *comm_rank = rk;
   if (transport && transport_len > 0) {

@@ -437,6 +437,21 @@ int build_plan(const dflo_mesh_t &mesh, int shard_ex, int shard_ey, Plan &p, std
     }
   }
 
+  // ---- the ghost cells' neighbours, for the limiter pass over the ghost shards (see plan.h)
+  p.ghost_count.assign(p.n_ghost_shards, 0);
+  p.ghost_lrbt.assign((size_t)p.n_ghost_shards * 4 * kShard, -1);
+  for (int g = 0; g < n_ghost; ++g) {
+    const int c = n_owned + g, gs = g / kShard, l = g % kShard;
+    ++p.ghost_count[gs];
+    for (int f = 0; f < 4; ++f) {
+      const int nb = mesh.cell_face_neighbor[(size_t)c * 4 + f];
+      int32_t v = -1;                                            // a physical boundary: the limiter takes the cell's own slope
+      if (nb == DFLO_NBR_NONE) v = p.n_slots + 4 * g + f;        // a cell of the ghost's owner (or another ghost): from the record
+      else if (nb >= 0) v = nb < n_owned ? p.iid[nb] : p.n_slots + 4 * g + f;
+      p.ghost_lrbt[((size_t)gs * 4 + f) * kShard + l] = v;
+    }
+  }
+
   // ---- geometry in internal order
   if (mesh.mapping == DFLO_MAP_CARTESIAN) {
     p.cell_h.assign(p.n_slots + 2 * kShard, p.h);

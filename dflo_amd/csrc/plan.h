@@ -68,6 +68,12 @@ struct Plan {
   std::vector<int32_t> interior_shards;  // their cells are exchanged while the interior shards are computed)
   std::vector<int32_t> rim2_shards;  // rim shards + the ring of shards next to them, and the rest: the split of the UPDATE when a
   std::vector<int32_t> rest2_shards; // TVB limiter follows (the limiter of the rim cells reads averages from the ring)
+  // The ghost shards as a limiter pass sees them (multi-device TVB runs with ONE exchange per stage: the ghost cells arrive
+  // unlimited and are limited here as their owners limit them): cells per ghost shard, and for every (ghost cell, face) the
+  // slot of the neighbour when it is an owned cell of this part, -1 at a physical boundary, n_slots + 4 g + f where the
+  // neighbour lives with the ghost's owner (its average comes with the ghost's record)
+  std::vector<int32_t> ghost_count;  // [n_ghost_shards]
+  std::vector<int32_t> ghost_lrbt;   // [n_ghost_shards][4][kShard]
   int max_halo = 0, max_faces = 0, max_bnd = 0;
   int max_inner = 0;                 // most faces of a shard without a halo side
   int halo_cols = 1;                 // columns of the stage kernel's trace / flux table that belong to halo entries

@@ -92,6 +92,38 @@ __global__ void unpack_cells_kernel(const double *buf, double *U, double *avg, i
   if (d < ndof) U[((size_t)(slot >> 6) * ndof + d) * 64 + (slot & 63)] = buf[t];
   else avg[((size_t)(slot >> 6) * 4 + (d - ndof)) * 64 + (slot & 63)] = buf[t];
 }
+// One exchange per stage where a TVB limiter sits between update and send (src_mpi/limiter.cc:232 and src_mpi/claw.cc:793 merged):
+// the cut cells leave UNLIMITED, and with each of them what its owner's limiter would read -- buf[k][ndof + 4 + 16]: the DoFs, the
+// cell's average, the averages of its four face neighbours as the owner holds them (0 where there is none; the entry of a face
+// that leads to the receiver is not read there -- the receiver has that cell).  The receiver limits the ghost cell as the owner
+// limits the original (limiter_kernel over the ghost shards) and forms the traces itself.
+constexpr int kFatExtra = 20;
+__device__ __forceinline__ double fat_value(const double *U, const double *avg, const int32_t *lrbt, int slot, int d, int ndof) {
+  if (d < ndof) return U[((size_t)(slot >> 6) * ndof + d) * 64 + (slot & 63)];
+  d -= ndof;
+  if (d < 4) return avg[((size_t)(slot >> 6) * 4 + d) * 64 + (slot & 63)];
+  d -= 4;
+  const int nb = lrbt[((size_t)(slot >> 6) * 4 + (d >> 2)) * 64 + (slot & 63)];
+  return nb >= 0 ? avg[((size_t)(nb >> 6) * 4 + (d & 3)) * 64 + (nb & 63)] : 0.0;
+}
+__global__ void pack_fat_kernel(double *buf, const double *U, const double *avg, const int32_t *lrbt, const int32_t *slots, int n, int ndof) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int w = ndof + kFatExtra;
+  if (t >= (long long)n * w) return;
+  const int k = (int)(t / w), d = (int)(t - (long long)k * w);
+  buf[t] = fat_value(U, avg, lrbt, slots[k], d, ndof);
+}
+// ... into the ghost shards, the averages' array and gnb[g][4 faces][4]
+__global__ void unpack_fat_kernel(const double *buf, double *U, double *avg, double *gnb, int first_slot, int n_ghost, int ndof) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int w = ndof + kFatExtra;
+  if (t >= (long long)n_ghost * w) return;
+  const int g = (int)(t / w), d = (int)(t - (long long)g * w);
+  const int slot = first_slot + g;
+  if (d < ndof) U[((size_t)(slot >> 6) * ndof + d) * 64 + (slot & 63)] = buf[t];
+  else if (d < ndof + 4) avg[((size_t)(slot >> 6) * 4 + (d - ndof)) * 64 + (slot & 63)] = buf[t];
+  else gnb[(size_t)g * 16 + (d - ndof - 4)] = buf[t];
+}
 // Face-trace halo records (N*4 doubles per cut face instead of the whole cell): record k = the trace of the
 // listed cell on the listed face, out[k][4][N], formed exactly as the stage kernel's halo gather forms it.  Used to pack
 // what a peer needs (owned cells on the cut) and to initialise the ghost traces from the ghost cells' DoFs after set_solution.
@@ -144,6 +176,15 @@ __global__ void pack_to_kernel(const SendSegs seg, const double *U, const double
     const double v = d < nd ? U[((size_t)(slot >> 6) * ndof + d) * 64 + (slot & 63)]
                             : avg[((size_t)(slot >> 6) * 4 + (d - nd)) * 64 + (slot & 63)];
     seg_dst(seg, k, w)[d] = v;
+  }
+  seg_signal(seg);
+}
+__global__ void pack_fat_to_kernel(const SendSegs seg, const double *U, const double *avg, const int32_t *lrbt, const int32_t *slots, int n, int ndof) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int w = ndof + kFatExtra;
+  if (t < (long long)n * w) {
+    const int k = (int)(t / w), d = (int)(t - (long long)k * w);
+    seg_dst(seg, k, w)[d] = fat_value(U, avg, lrbt, slots[k], d, ndof);
   }
   seg_signal(seg);
 }

@@ -60,7 +60,14 @@ struct Tunables {
                                   //                           write-through stores + s_waitcnt on a fine-grained window, the fence only on a plain one
   bool ipc_words_uncached = false;  // DFLO_IPC_WORDS=uncached  (developer switch) the sequence words in hipDeviceMallocUncached memory: LAB R5.15's configuration
   bool ipc_free_early = false;      // DFLO_IPC_FREE_EARLY=1    (developer switch) dflo_hip_multi_destroy frees the exported windows without waiting for the
-                                    //                           neighbours to close their mappings: round 5's order, the cause of LAB R5.15
+                                    //                           neighbours to close their mappings: round 5's order (against the IPC contract; NOT what LAB R5.15 saw: LAB R6.3)
+  bool dt_on_comm = false;      // DFLO_DT_ON_COMM=1         rank mode, RCCL / callbacks: the all-reduce of the time step on the comm stream (two stream
+                                //                           hops per step) instead of the compute stream
+  int tvb_one_exchange = -1;    // DFLO_TVB_ONE_EXCHANGE=0|1 TVB stages of the multi-device driver (not the fused IPC form): 0 the reference's two
+                                //                           exchanges per stage (averages, then the limited state), 1 one (the cut cells unlimited
+                                //                           with their neighbours' averages; the receiver limits its ghost cells itself) wherever
+                                //                           the partition allows; unset: one where an exchange is a library call (RCCL, the host
+                                //                           program's callbacks: +16 % on self-halo C4), two where it is a kernel's stores (-1.6 %)
   bool avg_in_place = true;     // DFLO_MULTI_AVG_UNPACK=1   TVB: unpack the received ghost averages into the engine's array before the rim
                                 //                           limiter (default: the limiter reads them where they arrived)
 };
@@ -112,6 +119,8 @@ inline Tunables read_tunables() {
   t.multi_verbose = flag("DFLO_MULTI_VERBOSE", false);
   t.comm_priority = flag("DFLO_MULTI_PRIORITY", true);
   t.avg_in_place = !flag("DFLO_MULTI_AVG_UNPACK", false);
+  t.tvb_one_exchange = tri("DFLO_TVB_ONE_EXCHANGE");
+  t.dt_on_comm = flag("DFLO_DT_ON_COMM", false);
   t.peer_finegrained = flag("DFLO_PEER_FINEGRAINED", false);
   t.ipc_finegrained = flag("DFLO_PEER_FINEGRAINED", true);
   t.ipc_fused = flag("DFLO_IPC_FUSED", true);

@@ -229,6 +229,6 @@ class MultiConservationLaw:
     def comm_info(self):
         """(ranks, own rank) as the transport itself reports them -- ncclCommCount / ncclCommUserRank for RCCL -- and a description."""
         cnt, rk = C.c_int32(), C.c_int32()
-        buf = C.create_string_buffer(256)
-        self._chk(lib.dflo_hip_multi_comm_info(self._h, C.byref(cnt), C.byref(rk), buf, 256))
+        buf = C.create_string_buffer(640)
+        self._chk(lib.dflo_hip_multi_comm_info(self._h, C.byref(cnt), C.byref(rk), buf, 640))
         return cnt.value, rk.value, buf.value.decode()

@@ -65,6 +65,18 @@ int dflo_hip_ghost_avg_source(dflo_hip_handle h, const void *device_buffer);
  * differences read it).  What the native multi-device driver ships. */
 int dflo_hip_pack_send_cells(dflo_hip_handle h, void *device_buffer);
 int dflo_hip_unpack_ghost_cells(dflo_hip_handle h, const void *device_buffer);
+/* ONE exchange per stage where a TVB limiter sits between the update and update_ghost_values (Qk, ghost cells known by their
+ * traces, no KXRCF indicator) -- the reference's two (src_mpi/limiter.cc:232: the averages the limiter reads; src_mpi/claw.cc:793:
+ * the limited state) merged.  The cut cells leave UNLIMITED, each with what its owner's limiter will read of its surroundings:
+ * records [n][ndof + 20] = DoFs, the cell's average, the averages of its four face neighbours as the owner holds them (zeros where
+ * there is none).  The receiver hands them to limit_ghost_cells: the NEXT dflo_hip_stage_limit_part(h, 1) -- the limiter pass over
+ * its rim shards -- takes them along.  An unpack kernel puts them into the ghost shards; the pass runs over the rim shards and the
+ * ghost shards -- the routine that limits the owned cells; a ghost cell's neighbour that is one of the receiver's cells is read
+ * from the receiver's averages, one that lives with the ghost's owner from the record: the owner's inputs, arithmetic and bits --
+ * and the ghost shards' wavefronts form the traces of the limited ghost cells into trace table `table` (0 | 1) themselves.  Sound
+ * where every cut cell borders on ONE other part (the driver checks). */
+int dflo_hip_pack_send_cells_unlimited(dflo_hip_handle h, void *device_buffer);
+int dflo_hip_limit_ghost_cells(dflo_hip_handle h, const void *records, int table);
 /* Face-trace records: when nothing needs more of a ghost cell than its trace on the cut faces and its average
  * -- Qk without the KXRCF indicator: dflo_hip_halo_traces() = 1 -- the stage kernels read the ghost cells from a table of
  * traces, [n_ghost_traces][4][k+1] doubles ordered by (ghost cell, face), and the halo message of a cut face shrinks from
@@ -132,7 +144,8 @@ int dflo_hip_deliver_to_plain_memory(dflo_hip_handle h, int plain);
  * written at dst[i] -- the receive area of the i-th peer, on this device or on another one reached over xGMI peer access --
  * instead of into a staging buffer that a copy per peer then moves.  kind: 0 whole cells ([ndof + 4] doubles per record,
  * as pack_send_cells), 1 cell averages ([4], as pack_send_avg), 2 face traces ([4 (k+1)], as pack_send_traces; the send
- * list is that of set_send_faces).  n_segments <= 16. */
+ * list is that of set_send_faces), 3 unlimited cells with their neighbours' averages ([ndof + 20], as
+ * pack_send_cells_unlimited).  n_segments <= 16. */
 int dflo_hip_pack_send_to(dflo_hip_handle h, int kind, int n_segments, const int32_t *first, void *const *dst);
 /* The same, and the kernel tells the receivers: once every record of the launch is visible system-wide, the workgroup that
  * finishes last stores `seq` (release, system scope) into the 64-bit words flags[i] -- sequence words in the receivers'

@@ -138,6 +138,28 @@ def test_engines_on_one_device_match_the_single_engine(name, n_parts, method):
         assert rel(got["u"], ref["u"]) < 1e-8 and rel(got["avg"], ref["avg"]) < 1e-9
 
 
+@pytest.mark.parametrize("name,n_parts,method", [("c3", 2, "slab"), ("c4", 3, "slab"), ("c4", 4, "rcb")])
+def test_one_exchange_per_tvb_stage_gives_the_bits_of_two(name, n_parts, method, monkeypatch):
+    """several parts, TVB between update and update_ghost_values: the cut cells sent unlimited with their neighbours' averages and
+    limited by the receiver (one exchange per stage) against the reference's two (src_mpi/limiter.cc:232, src_mpi/claw.cc:793) --
+    every bit.  Where a cut cell borders on two other parts (the corners of an RCB partition) the driver keeps the two exchanges."""
+    mesh, prm, ic = _case(name)
+    if method == "rcb":     # (a lattice on which four RCB blocks meet in a corner)
+        mesh = dflo_amd.Mesh.cartesian(32, 32, 0.0, 0.0, 1.0 / 32, [2, 1, 0, 0], 2)
+    out = []
+    for one in ("1", "0"):
+        monkeypatch.setenv("DFLO_TVB_ONE_EXCHANGE", one)
+        multi = dflo_amd.MultiConservationLaw(mesh, prm, devices=[0] * n_parts, partitioner=method)
+        what = multi.comm_info()[2]
+        assert ("one exchange per stage" in what) == (one == "1" and method == "slab"), what
+        _setup(multi, mesh, ic)
+        out.append(_run(multi, True))
+        multi.close()
+    a, b = out
+    assert a["dt"] == b["dt"] and a["t"] == b["t"]
+    assert np.array_equal(a["u"], b["u"]) and np.array_equal(a["avg"], b["avg"])
+
+
 @pytest.mark.parametrize("name,n_parts", [("c2", 3), ("c4", 2), ("c5", 3)])
 def test_engines_on_one_device_match_the_oracle(name, n_parts):
     mesh, prm, ic = _case(name)

@@ -26,6 +26,9 @@ def _worker(rank, world, port, name, ret, transport="callbacks"):
     if transport == "ipc_coarse":   # ... with the exported window in plain device memory (default: fine-grained, hipExtMallocWithFlags)
         os.environ["DFLO_PEER_FINEGRAINED"] = "0"
         transport = "ipc"
+    if transport in ("callbacks_one", "callbacks_two"):   # TVB stages: one exchange (the default with a transport library) | the reference's two
+        os.environ["DFLO_TVB_ONE_EXCHANGE"] = "1" if transport == "callbacks_one" else "0"
+        transport = "callbacks"
     if transport == "ipc":   # the per-stage path without a transport library: hipIpc-mapped receive areas + sequence words; the
         os.environ["DFLO_RANK_TRANSPORT"] = "ipc"   # callbacks only carry the handles at create and the host-side reductions
     sys.path.insert(0, ROOT)
@@ -61,6 +64,9 @@ def _worker(rank, world, port, name, ret, transport="callbacks"):
         ret["norms"] = max(abs(a0 - b0) / b0 + abs(a1 - b1) / b1 for (a0, a1), (b0, b1) in zip(got["norms"], ref["norms"]))
         ret["equal"] = bool(np.array_equal(u.reshape(-1), ref["u"]) and np.array_equal(avg, ref["avg"]))
         ret["err"] = float(np.abs(u.reshape(-1) - ref["u"]).max() / np.abs(ref["u"]).max())
+        import hashlib
+        ret["sha"] = hashlib.sha1(u.tobytes() + avg.tobytes()).hexdigest()
+        ret["what"] = claw.comm_info()[2]
     dist.barrier()
     claw.close()
     dist.destroy_process_group()
@@ -81,6 +87,23 @@ def test_ranks_on_one_device_match_the_single_engine(name, world, transport):
         assert ret["equal"], ret["err"]                      # smooth data: bit-identical to the single engine
     else:
         assert ret["err"] < 1e-8
+
+
+@pytest.mark.parametrize("name,world", [("c4", 2), ("c3", 3)])
+def test_ranks_with_one_exchange_per_tvb_stage_carry_the_bits_of_two(name, world):
+    """one process per GPU over a transport library (here: the callbacks): the cut cells travel unlimited with their neighbours'
+    averages and every rank limits its ghost cells itself -- against the reference's two exchanges per stage (src_mpi/limiter.cc:232,
+    src_mpi/claw.cc:793): the same bits on every rank"""
+    import random
+    out = []
+    for transport in ("callbacks_one", "callbacks_two"):
+        mgr = mp.get_context("spawn").Manager()
+        ret = mgr.dict()
+        mp.spawn(_worker, args=(world, 29500 + random.randint(0, 2000), name, ret, transport), nprocs=world, join=True)
+        assert ret["dt"] and ret["t"] and ret["err"] < 1e-8, dict(ret)
+        out.append(dict(ret))
+    assert "one exchange per stage" in out[0]["what"] and "two exchanges per stage" in out[1]["what"], (out[0]["what"], out[1]["what"])
+    assert out[0]["sha"] == out[1]["sha"]
 
 
 @pytest.mark.parametrize("transport", ["callbacks", "ipc"])

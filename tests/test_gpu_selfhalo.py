@@ -64,6 +64,34 @@ def test_c4_slab_self_halo_matches_the_single_engine(transport):
     assert L.rel(got["u"], ref["u"]) < 1e-8
 
 
+@pytest.mark.parametrize("config", ["c4", "c3"])
+@pytest.mark.parametrize("transport", ["rccl", "direct", "copy"])
+def test_one_exchange_per_tvb_stage_gives_the_bits_of_the_two_of_the_reference(config, transport, monkeypatch):
+    """src_mpi/limiter.cc:232 + src_mpi/claw.cc:793 merged (the default where ghost cells are known by their traces): the cut cells
+    travel unlimited with their neighbours' averages, the receiver limits its ghost cells with the owner's inputs and arithmetic --
+    against DFLO_TVB_ONE_EXCHANGE=0 (averages, rim limiter, limited traces): every bit"""
+    if config == "c4":
+        mesh, prm, ic, programs = L.case("c4")
+    else:
+        mesh, prm, ic = S._case("c3")
+    out = []
+    for one in ("1", "0"):
+        monkeypatch.setenv("DFLO_TVB_ONE_EXCHANGE", one)
+        claw = _self(mesh, prm, transport)
+        what = claw.comm_info()[2]
+        assert ("one exchange per stage" in what) == (one == "1") and ("two exchanges per stage" in what) == (one == "0"), what
+        if config == "c4":
+            L.setup(claw, mesh, ic, programs)
+            out.append(L.run(claw, True))
+        else:
+            S._setup(claw, mesh, ic)
+            out.append(S._run(claw, True))
+        claw.close()
+    a, b = out
+    assert a["dt"] == b["dt"] and a["t"] == b["t"]
+    assert np.array_equal(a["u"], b["u"]) and np.array_equal(a["avg"], b["avg"])
+
+
 SMALL = [("c2", "slab", "rccl"), ("c1", "slab", "rccl"), ("c1", "slab", "direct"), ("c3", "slab", "rccl"), ("c3", "slab", "direct"),
          ("c4", "slab", "rccl"), ("c5", "rcb", "rccl"), ("c5", "rcb", "direct"), ("kxrcf", "slab", "rccl"), ("kxrcf", "rcb", "direct"),
          ("pk", "slab", "rccl"), ("pkq1", "rcb", "direct"),

@@ -26,7 +26,8 @@ ENGINE = [("DFLO_GRAPH", ["1"]), ("DFLO_SWEEP", ["0"]), ("DFLO_STREAM", ["0", "1
           ("DFLO_LIM_GRID", ["1", "7", "64", "333", "4096"]), ("DFLO_LIM_MASK", ["0", "1"]), ("DFLO_PLAN_REFINE", ["0", "2"]),
           ("DFLO_PLAN_RIM_FIRST", ["0"])]
 MULTI = [("DFLO_HALO_CELLS", ["1"]), ("DFLO_MULTI_GROUP", ["part", "device"]), ("DFLO_MULTI_THREADS", ["0"]), ("DFLO_MULTI_STRICT", ["1"]),
-         ("DFLO_MULTI_COPY", ["1"]), ("DFLO_MULTI_PRIORITY", ["0"]), ("DFLO_MULTI_AVG_UNPACK", ["1"]), ("DFLO_PEER_FINEGRAINED", ["1"])]
+         ("DFLO_MULTI_COPY", ["1"]), ("DFLO_MULTI_PRIORITY", ["0"]), ("DFLO_MULTI_AVG_UNPACK", ["1"]), ("DFLO_PEER_FINEGRAINED", ["1"]),
+         ("DFLO_TVB_ONE_EXCHANGE", ["1"])]   # (round 6: one exchange per TVB stage; in one process the default is the reference's two)
 # round 5: a third arrangement -- ONE part that is its own neighbour through the IPC transport's kernels (dflo_hip_multi_create_self) --
 # with the switches of that transport: the stage kernel delivering its traces itself or the rim launch + pack kernel on a second stream
 SELF = [("DFLO_IPC_STRICT", ["1"]), ("DFLO_IPC_FUSED", ["0"]), ("DFLO_IPC_KWAIT", ["0"]), ("DFLO_PEER_FINEGRAINED", ["0"]), ("DFLO_MULTI_PRIORITY", ["0"]), ("DFLO_MULTI_AVG_UNPACK", ["1"]), ("DFLO_HALO_CELLS", ["1"])]
