@@ -1253,7 +1253,10 @@ int dflo_hip_create_with_cell_size(const dflo_mesh_t *mesh, const dflo_params_t 
     //  DFLO_LIM_MASK=1 forces them, 0 forbids them)
     //  ... and on where the limiter pass takes the exchange along (one launch over all shards again: the single engine's case, and
     //  the shards on a cut can only leave a list; C3 through the IPC transport against itself: 0.80 -> 0.91 of the plain engine)
-    const bool want_marks = h->N >= 2 && (tun.lim_mask >= 0 ? tun.lim_mask != 0 : (h->N >= 3 || p.n_cells == p.n_owned || pass_takes_exchange));
+    //  Round 6: with the list of marked shards shared by the rim + ring and the rest launches (the pass over "everything but the rim"
+    //  walks it instead of sending one wavefront to each of 8 000 shards) the marks pay at k = 1 on a part as well -- C3 against itself,
+    //  RCCL 0.787 -> 0.892 of the plain engine, delivering pack kernels 0.795 -> 0.89 (LAB R6.12): on wherever the list is.
+    const bool want_marks = h->N >= 2 && (tun.lim_mask >= 0 ? tun.lim_mask != 0 : (h->N >= 3 || p.n_cells == p.n_owned || pass_takes_exchange || tun.lim_list));
     if (h->prm.limiter_type == DFLO_LIMITER_TVB && h->basis == DFLO_BASIS_QK && h->geo == 0 && want_marks) {
       const size_t nb = (size_t)std::max(p.n_shards, 1) * sizeof(unsigned long long);
       if (dmalloc((void **)&h->lim_mask, nb) != hipSuccess) {

@@ -80,7 +80,7 @@ inline Tunables read_tunables() {
   };
   auto tri = [](const char *name) {
     const char *e = std::getenv(name);
-    return e ? (e[0] != '0' ? 1 : 0) : -1;
+    return (e && e[0]) ? (e[0] != '0' ? 1 : 0) : -1;   // (set but empty counts as unset)
   };
   // an integer switch: a value that is not a number >= lo is reported once and ignored (the default stays)
   auto count = [](const char *name, int dflt, int lo) {
