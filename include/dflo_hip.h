@@ -264,8 +264,11 @@ int dflo_hip_comm_unique_id(void *id_bytes);
 int dflo_hip_multi_create_rank(const dflo_mesh_t *mesh, const dflo_params_t *params, int device_id, int rank, int n_ranks,
                                const void *unique_id, int partitioner, dflo_hip_multi_handle *out);
 /* One process per GPU with the host program's own transport instead of RCCL (a cluster whose ranks talk MPI; the
- * repository's two-process tests on one GPU, which RCCL refuses).  Both callbacks get DEVICE pointers and the driver's comm
- * stream (hipStream_t as void*); when they return, the transfer must be complete or enqueued on that stream in order.
+ * repository's two-process tests on one GPU, which RCCL refuses).  Both callbacks get DEVICE pointers and the stream of the
+ * driver the call belongs on (hipStream_t as void*: the comm stream for an exchange, the compute stream for the time step's
+ * all-reduce); when they return, the transfer must be complete or enqueued on that stream in order.  With a TVB limiter the
+ * driver calls `exchange` ONCE per stage (the reference's two, src_mpi/limiter.cc:232 and src_mpi/claw.cc:793, merged: the cut
+ * cells travel unlimited with their neighbours' averages and the receiver limits its ghost cells itself).
  *   exchange:  for each of n_peers ranks, send_bytes[i] bytes at send_ptr[i] go to rank peer[i], recv_bytes[i] bytes from
  *              it arrive at recv_ptr[i] -- update_ghost_values(), src_mpi/claw.cc:793
  *   allreduce: n doubles at `values`, in place, op = dflo_reduce_op -- Utilities::MPI::min / sum, src_mpi/claw.cc:579,777
