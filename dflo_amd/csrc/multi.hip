@@ -748,6 +748,8 @@ int exchange_solution(dflo_hip_multi *m) {   // calling thread, all parts
 // the compute stream M, side by side: both read the previous stage, they write disjoint shards.
 //   C: [wait: interior of the previous stage / the new time step]  update rim  (TVB: rim + ring; exchange the averages of the
 //      rim cells; limit the rim)  -> ev_rim;  pack; send / receive; unpack into the ghost shards
+//      (TVB, tvb_one: update rim + ring; the UNLIMITED cut cells with their neighbours' averages leave / arrive -- the stage's one
+//      exchange --; unpack, limit rim and ghost cells in one launch, whose ghost wavefronts form the ghost traces  -> ev_rim)
 //   M: [wait: ev_rim of the previous stage]  update interior  (TVB: all but rim + ring; wait for the ring; limit all but the
 //      rim);  last stage: wait ev_rim, reductions of the step
 // A phase is issued for every part of the group before the next one: every record a phase waits for has then been issued by an

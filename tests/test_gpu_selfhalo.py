@@ -50,7 +50,9 @@ def test_c2_512_self_halo_bit_identical_to_the_single_engine(transport):
 
 @pytest.mark.parametrize("transport", ["rccl", "direct", "ipc"])
 def test_c4_slab_self_halo_matches_the_single_engine(transport):
-    """TVB + positivity + moving inflow: two exchanges per stage (averages before the rim limiter, traces after it)"""
+    """TVB + positivity + moving inflow: over RCCL one exchange per stage (the cut cells unlimited with their neighbours' averages,
+    the ghost cells limited by the receiver), with the delivering pack kernels two (averages before the rim limiter, traces after it),
+    over the IPC transport both inside the stage kernel and the limiter pass"""
     ref = L.reference("c4")
     mesh, prm, ic, programs = L.case("c4")
     claw = _self(mesh, prm, transport)
