@@ -138,6 +138,27 @@ def test_engines_on_one_device_match_the_single_engine(name, n_parts, method):
         assert rel(got["u"], ref["u"]) < 1e-8 and rel(got["avg"], ref["avg"]) < 1e-9
 
 
+@pytest.mark.parametrize("switch", ["DFLO_MULTI_STRICT", "DFLO_MULTI_COPY", "DFLO_PEER_FINEGRAINED", "DFLO_MULTI_THREADS=0", "DFLO_MULTI_GROUP=part"])
+def test_one_exchange_per_tvb_stage_under_the_drivers_switches(switch, monkeypatch):
+    """the one-exchange form with the sender waiting for the receiver's "consumed" event, through the staging buffer, with the
+    receive areas fine-grained, driven by one host thread, one stream pair per part: the bits of the default arrangement"""
+    mesh, prm, ic = _case("c4")
+    monkeypatch.setenv("DFLO_TVB_ONE_EXCHANGE", "1")
+    out = []
+    for on in (False, True):
+        if on:
+            k, _, v = switch.partition("=")
+            monkeypatch.setenv(k, v or "1")
+        multi = dflo_amd.MultiConservationLaw(mesh, prm, devices=[0] * 3, partitioner="slab")
+        assert "one exchange per stage" in multi.comm_info()[2]
+        _setup(multi, mesh, ic)
+        out.append(_run(multi, True))
+        multi.close()
+    a, b = out
+    assert a["dt"] == b["dt"] and a["t"] == b["t"]
+    assert np.array_equal(a["u"], b["u"]) and np.array_equal(a["avg"], b["avg"])
+
+
 @pytest.mark.parametrize("name,n_parts,method", [("c3", 2, "slab"), ("c4", 3, "slab"), ("c4", 4, "rcb")])
 def test_one_exchange_per_tvb_stage_gives_the_bits_of_two(name, n_parts, method, monkeypatch):
     """several parts, TVB between update and update_ghost_values: the cut cells sent unlimited with their neighbours' averages and
