@@ -476,3 +476,21 @@ int build_plan(const dflo_mesh_t &mesh, int shard_ex, int shard_ey, Plan &p, std
 }
 
 }  // namespace dflo
+
+// Test hook (dflo_hip_diag.h; host only, no device): the shard plan's view of the ghost cells' neighbours -- what the limiter pass over
+// the ghost shards of a one-exchange TVB stage reads (Plan::ghost_lrbt) --, in the mesh's own cell numbering.
+extern "C" int dflo_hip_plan_ghost_neighbours(const dflo_mesh_t *part_mesh, int32_t *table) {
+  if (!part_mesh || !table) return DFLO_ERR_BAD_PARAM;
+  dflo::Plan p;
+  std::string err;
+  const int rc = dflo::build_plan(*part_mesh, 8, 8, p, err);
+  if (rc) return rc;
+  const int n_ghost = p.n_cells - p.n_owned;
+  for (int g = 0; g < n_ghost; ++g)
+    for (int f = 0; f < 4; ++f) {
+      const int32_t v = p.ghost_lrbt[((size_t)(g / dflo::kShard) * 4 + f) * dflo::kShard + g % dflo::kShard];
+      table[(size_t)g * 4 + f] = v < 0 ? -1 : (v >= p.n_slots ? (v == p.n_slots + 4 * g + f ? -2 : -3) : p.user_of[v]);
+    }
+  return DFLO_OK;
+}
+

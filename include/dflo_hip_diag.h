@@ -40,6 +40,12 @@ int dflo_hip_debug_math(int n, const double *x, double *rcp_out, double *sqrt_ou
 /* Test hook: exp() of the device library and the form the kinetic split fluxes use for their Gaussians (fexp_neg,
  * dflo_amd/csrc/physics.hpp; arguments <= 0), side by side. */
 int dflo_hip_debug_exp(int n, const double *x, double *exp_library, double *exp_flux);
+/* Test hook (host only, no device): what the shard plan of a part (owned + ghost sub-mesh of dflo_mesh_partition*) knows of its
+ * ghost cells' face neighbours -- the table the limiter pass over the ghost shards of a one-exchange TVB stage reads
+ * (dflo_hip_limit_ghost_cells) --, table[n_ghost][4] in the sub-mesh's own cell numbering: the index of the neighbour where it is an
+ * OWNED cell of the part, -1 at a physical boundary, -2 where the neighbour lives with the ghost's owner (its average comes with the
+ * ghost's record). */
+int dflo_hip_plan_ghost_neighbours(const dflo_mesh_t *part_mesh, int32_t *table);
 
 #ifdef __cplusplus
 }
