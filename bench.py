@@ -98,7 +98,8 @@ def _settle_clocks(seconds=0.4):
     Measured on one box with the driver's `--steps 20 --warmup 5` (MDoF/s): no preheat 163 000; streaming fp64 work
     (torch.addcmul over 512 MB) for 0.1 / 0.2 / 0.4 / 1.0 s: 182 000-189 000 / 189 300 / 189 800 / 189 200; the same with fp64
     matrix products mixed in 182 500-186 400, matrix products alone 180 000-184 000 (they heat the part: the solver then starts
-    at lower clocks) -- so it stays streaming work, 0.4 s.  A run that has been going for 100+ steps is another ~3 % faster
+    at lower clocks); the same streaming work on a 32 MB / 2 MB working set (Infinity Cache / L2 resident, round 6): 184 000-186 500 /
+    176 000-177 000 against 189 000-190 400 -- it is the HBM side that has to be awake -- so it stays streaming work through HBM, 0.4 s.  A run that has been going for 100+ steps is another ~3 % faster
     whatever ran before it.  Disclosed in config.preheat_s / config.preheat."""
     if os.environ.get("DFLO_BENCH_NO_PREHEAT") == "1":
         return
