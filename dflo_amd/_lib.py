@@ -83,7 +83,7 @@ SYMBOLS = [
     "dflo_hip_multi_part_mesh", "dflo_hip_multi_set_part_solution", "dflo_hip_pack_send_cells", "dflo_hip_unpack_ghost_cells",
     "dflo_hip_halo_traces", "dflo_hip_n_ghost_traces", "dflo_hip_set_send_faces", "dflo_hip_pack_send_traces", "dflo_hip_pack_send_to", "dflo_hip_ghost_avg_source",
     "dflo_hip_ghost_trace_buffer", "dflo_hip_use_ghost_traces", "dflo_hip_pack_send_cells_unlimited", "dflo_hip_limit_ghost_cells",
-    "dflo_hip_plan_ghost_neighbours",
+    "dflo_hip_plan_ghost_neighbours", "dflo_hip_stage_tail_wait", "dflo_hip_n_part_shards", "dflo_hip_pack_publish",
 ]
 PARTITIONER = {"slab": 0, "rcb": 1}
 COMM_ID_BYTES = 128
@@ -158,6 +158,9 @@ _sig("dflo_hip_unpack_ghost_cells", C.c_int, _H, C.c_void_p)
 _sig("dflo_hip_pack_send_cells_unlimited", C.c_int, _H, C.c_void_p)
 _sig("dflo_hip_limit_ghost_cells", C.c_int, _H, C.c_void_p, C.c_int)
 _sig("dflo_hip_plan_ghost_neighbours", C.c_int, _MP, C.POINTER(C.c_int32))
+_sig("dflo_hip_stage_tail_wait", C.c_int, _H, C.c_void_p, C.c_uint64)
+_sig("dflo_hip_n_part_shards", C.c_int, _H, C.c_int)
+_sig("dflo_hip_pack_publish", C.c_int, _H, C.c_void_p, C.c_uint64)
 _sig("dflo_hip_stage_update", C.c_int, _H, C.c_int, C.c_double)
 _sig("dflo_hip_stage_limit", C.c_int, _H)
 _sig("dflo_hip_stage_open", C.c_int, _H, C.c_int, C.c_double)

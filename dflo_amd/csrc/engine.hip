@@ -110,6 +110,10 @@ struct dflo_hip_engine {
   long long wt_ticks = 0;   // how long a workgroup polls a neighbour's word before it raises wt_fail (DFLO_IPC_TIMEOUT_S x 100 MHz; 0: for ever)
   unsigned long long wt_seq = 0;
   bool wt_armed = false;
+  unsigned long long *pub_word = nullptr;          // dflo_hip_pack_publish: the next pack kernel's first thread stores pub_seq there
+  unsigned long long pub_seq = 0;
+  const unsigned long long *tail_word = nullptr;   // dflo_hip_stage_tail_wait: the next stage launch does not end before this word is at tail_seq
+  unsigned long long tail_seq = 0;
   int dl_fence = 0;   // dflo_hip_deliver_to_plain_memory: the destinations are plain (not fine-grained) device memory
   // TVB: the averages of the cells on a cut leave from the stage kernel, the traces from the limiter pass (dflo_hip_set_deliver_averages ..)
   std::vector<int32_t> h_send_slots;
@@ -305,7 +309,7 @@ int ensure_avg(dflo_hip_engine *h) {
   if (!rc) h->avg_valid = true;
   return rc;
 }
-int launch_face_traces(dflo_hip_engine *h, double *out, const int32_t *slots, const int32_t *faces, int n);
+int launch_face_traces(dflo_hip_engine *h, double *out, const int32_t *slots, const int32_t *faces, int n, bool publish = false);
 
 // the table of the parts' CFL minima as the reductions (FinalArgs) and the consumers of the time step (DtSrc) see it
 void dt_table_args(const dflo_hip_engine *h, FinalArgs &f) {
@@ -634,6 +638,13 @@ int launch_update(dflo_hip_engine *h, double *rhs_out, int part) {
     a.wt_ticks = h->wt_ticks;
     h->wt_armed = false;
   }
+  if (h->tail_word && !rhs_out) {
+    a.tail_word = h->tail_word;
+    a.tail_seq = h->tail_seq;
+    a.wt_fail = h->wt_fail;
+    a.wt_ticks = h->wt_ticks;
+    h->tail_word = nullptr;
+  }
   a.tvb_M = h->prm.limiter_type == DFLO_LIMITER_TVB ? h->prm.M : -1.0;
   a.tvb_char = h->prm.char_lim;
   a.pos_check = h->prm.pos_lim;
@@ -937,11 +948,19 @@ int launch_average(dflo_hip_engine *h) {
   return DFLO_OK;
 }
 
-int launch_face_traces(dflo_hip_engine *h, double *out, const int32_t *slots, const int32_t *faces, int n) {
+// (what dflo_hip_pack_publish has armed goes to the pack kernel launched next, once)
+static unsigned long long *take_pub(dflo_hip_engine *h, unsigned long long *seq) {
+  unsigned long long *w = h->pub_word;
+  *seq = h->pub_seq;
+  h->pub_word = nullptr;
+  return w;
+}
+int launch_face_traces(dflo_hip_engine *h, double *out, const int32_t *slots, const int32_t *faces, int n, bool publish) {
   if (n == 0) return DFLO_OK;
   const long long tot = (long long)n * 4 * h->N;
   auto fn = DFLO_BY_N(h->N, face_trace_kernel);
-  hipLaunchKernelGGL(fn, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, out, (const double *)h->U[h->cur], slots, faces, n);
+  unsigned long long ps = 0, *pw = publish ? take_pub(h, &ps) : nullptr;
+  hipLaunchKernelGGL(fn, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, out, (const double *)h->U[h->cur], slots, faces, n, pw, ps);
   HIPCHK(h, hipGetLastError());
   return DFLO_OK;
 }
@@ -1814,6 +1833,14 @@ int dflo_hip_stage_await(dflo_hip_handle h, uint64_t seq) {
   return DFLO_OK;
 }
 
+int dflo_hip_stage_tail_wait(dflo_hip_handle h, const void *word, uint64_t seq) {
+  if (check_handle(h) || !word) return DFLO_ERR_BAD_PARAM;
+  if (h->basis != DFLO_BASIS_QK) { h->err = "stage_tail_wait: Qk stage kernels only"; return DFLO_ERR_UNSUPPORTED; }
+  h->tail_word = (const unsigned long long *)word;
+  h->tail_seq = seq;
+  return DFLO_OK;
+}
+
 int dflo_hip_set_deliver_averages(dflo_hip_handle h, int area, int n_segments, const int32_t *first, void *const *dst, void *const *flags,
                                   int n_words, void *const *words, void *fail) {
   if (check_handle(h) || area < 0 || area > 1 || n_segments < 1 || n_segments > kMaxSegs || !first || !dst || !flags || n_words < 0 || n_words > kMaxSegs ||
@@ -1926,6 +1953,13 @@ int dflo_hip_stage_finish(dflo_hip_handle h) {
 
 int dflo_hip_finish_enqueued(dflo_hip_handle h) { return (h && h->finish_enqueued) ? 1 : 0; }
 int dflo_hip_n_rim_shards(dflo_hip_handle h) { return h ? (int)h->plan.rim_shards.size() : 0; }
+int dflo_hip_n_part_shards(dflo_hip_handle h, int part) {
+  if (!h || part < 0 || part > 4) return 0;
+  const int32_t *list = nullptr;
+  int n = 0;
+  part_list(h, part, &list, &n);
+  return n;
+}
 
 int dflo_hip_stage_limit(dflo_hip_handle h) {
   if (check_handle(h)) return DFLO_ERR_BAD_PARAM;
@@ -2013,8 +2047,9 @@ int dflo_hip_pack_send(dflo_hip_handle h, void *device_buffer) {
   hipSetDevice(h->device);
   if (h->n_send == 0) return DFLO_OK;
   const long long tot = (long long)h->n_send * h->ndof;
+  unsigned long long ps = 0, *pw = take_pub(h, &ps);
   hipLaunchKernelGGL(pack_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, (double *)device_buffer,
-                     h->U[h->cur], h->d_send_slots, h->n_send, h->ndof);
+                     h->U[h->cur], h->d_send_slots, h->n_send, h->ndof, pw, ps);
   HIPCHK(h, hipGetLastError());
   return DFLO_OK;
 }
@@ -2024,8 +2059,9 @@ int dflo_hip_pack_send_avg(dflo_hip_handle h, void *device_buffer) {
   hipSetDevice(h->device);
   if (h->n_send == 0) return DFLO_OK;
   const long long tot = (long long)h->n_send * 4;
+  unsigned long long ps = 0, *pw = take_pub(h, &ps);
   hipLaunchKernelGGL(pack_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, (double *)device_buffer,
-                     h->avg[h->avg_cur], h->d_send_slots, h->n_send, 4);
+                     h->avg[h->avg_cur], h->d_send_slots, h->n_send, 4, pw, ps);
   HIPCHK(h, hipGetLastError());
   return DFLO_OK;
 }
@@ -2035,8 +2071,9 @@ int dflo_hip_pack_send_cells(dflo_hip_handle h, void *device_buffer) {
   hipSetDevice(h->device);
   if (h->n_send == 0) return DFLO_OK;
   const long long tot = (long long)h->n_send * (h->ndof + 4);
+  unsigned long long ps = 0, *pw = take_pub(h, &ps);
   hipLaunchKernelGGL(pack_cells_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, (double *)device_buffer,
-                     h->U[h->cur], h->avg[h->avg_cur], h->d_send_slots, h->n_send, h->ndof);
+                     h->U[h->cur], h->avg[h->avg_cur], h->d_send_slots, h->n_send, h->ndof, pw, ps);
   HIPCHK(h, hipGetLastError());
   return DFLO_OK;
 }
@@ -2047,10 +2084,18 @@ int dflo_hip_pack_send_cells_unlimited(dflo_hip_handle h, void *device_buffer) {
   hipSetDevice(h->device);
   if (h->n_send == 0) return DFLO_OK;
   const long long tot = (long long)h->n_send * (h->ndof + kFatExtra);
+  unsigned long long ps = 0, *pw = take_pub(h, &ps);
   hipLaunchKernelGGL(pack_fat_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, (double *)device_buffer,
                      (const double *)h->U[h->cur], (const double *)h->avg[h->avg_cur], (const int32_t *)h->d_lrbt, (const int32_t *)h->d_send_slots,
-                     h->n_send, h->ndof);
+                     h->n_send, h->ndof, pw, ps);
   HIPCHK(h, hipGetLastError());
+  return DFLO_OK;
+}
+
+int dflo_hip_pack_publish(dflo_hip_handle h, void *word, uint64_t seq) {
+  if (check_handle(h) || !word) return DFLO_ERR_BAD_PARAM;
+  h->pub_word = (unsigned long long *)word;
+  h->pub_seq = seq;
   return DFLO_OK;
 }
 
@@ -2122,7 +2167,7 @@ int dflo_hip_set_send_faces(dflo_hip_handle h, int32_t n, const int32_t *cells, 
 int dflo_hip_pack_send_traces(dflo_hip_handle h, void *device_buffer) {
   if (check_handle(h) || !device_buffer) return DFLO_ERR_BAD_PARAM;
   hipSetDevice(h->device);
-  return launch_face_traces(h, (double *)device_buffer, h->d_sendf_slot, h->d_sendf_face, h->n_send_faces);
+  return launch_face_traces(h, (double *)device_buffer, h->d_sendf_slot, h->d_sendf_face, h->n_send_faces, true);
 }
 
 int dflo_hip_pack_send_to(dflo_hip_handle h, int kind, int n_segments, const int32_t *first, void *const *dst) {
@@ -2143,6 +2188,7 @@ int dflo_hip_pack_send_to_signal(dflo_hip_handle h, int kind, int n_segments, co
     seg.flag[i] = flags ? (unsigned long long *)flags[i] : nullptr;
   }
   seg.seq = seq;
+  seg.pub = take_pub(h, &seg.pub_seq);
   seg.done = flags ? h->send_done + (kind == 3 ? 0 : kind) : nullptr;   // (kind 3 takes the place of kind 0: never both in one run)
   seg.first[n_segments] = first[n_segments];
   if (first[0] != 0 || first[n_segments] != n) { h->err = "pack_send_to: the segments must cover the send list"; return DFLO_ERR_COMM; }

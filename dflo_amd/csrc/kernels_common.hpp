@@ -137,6 +137,12 @@ struct StageArgs {
   unsigned long long wt_seq;
   int *wt_fail;                         // host-mapped: a word that did not arrive within wt_ticks
   long long wt_ticks;                   // of the 100 MHz clock (DFLO_IPC_TIMEOUT_S, default 120 s; 0: no limit)
+  // This launch may not END before a word (fine-grained memory) has reached tail_seq: its first workgroup polls for it when its own
+  // work is done (dflo_hip_stage_tail_wait).  The multi-device schedule orders the compute stream's NEXT kernel behind a kernel of
+  // the comm stream that way -- stream order does the rest -- instead of by a wait packet in front of that next kernel, which costs
+  // the compute stream 8.4 us even when the event has long been set (tools/stop_event_probe.hip).
+  const unsigned long long *tail_word;
+  unsigned long long tail_seq;
   // TVB: what leaves from the stage kernel are the AVERAGES of the cells on a cut (the neighbours' limiter reads them; the traces
   // leave from the limiter pass, LimArgs) -- the same arrangement with cell records
   const int32_t *dla_begin;

@@ -131,6 +131,7 @@ enum Chan { CH_CELLS = 0, CH_AVG = 1, CH_TRACES = 2, CH_FIN = 3 };
 // beside a full-size interior launch takes as long as that launch, profiles/r05), no rendezvous, no host hop.
 constexpr int kFlagWords = 4 * 16;   // [kind][source rank]
 __host__ __device__ inline int flag_index(int kind, int src) { return kind * 16 + src; }
+inline int tail_word_index(int part) { return 64 + part; }   // (behind the words of the four kinds: setup_tail_wait)
 
 struct WaitArgs {
   int n;
@@ -285,6 +286,11 @@ struct dflo_hip_multi {
   // (dflo_hip_limit_ghost_cells).  Needs every cut cell to border on one other part only (one_neighbour), ghost cells known by traces
   bool tvb_one = false, one_neighbour = true;
   bool dt_on_comm = false;     // DFLO_DT_ON_COMM=1 (reduce_dt_rank)
+  // The compute stream's order behind the comm stream's rim launch WITHOUT a wait packet (setup_tail_wait): a one-thread kernel behind
+  // the rim (+ ring) update publishes the stage's number in a word; the interior launch of the same stage does not end before it has
+  // seen it (dflo_hip_stage_tail_wait) -- so whatever follows the interior launch on the compute stream follows the rim launch as well
+  bool tail_wait = false;
+  unsigned long long tail_count = 0;   // stages whose rim launch has been followed by its word (never reset: the word only grows)
   std::atomic<bool> abort{false};                 // a part's thread has failed: the others stop waiting for it
   std::atomic<int64_t> stop_at{INT64_MAX};        // threaded advance: the step at which every thread leaves the loop
   bool strict = false;         // DFLO_MULTI_STRICT=1: a sender waits for an explicit "consumed" event of the receive area
@@ -787,6 +793,12 @@ int stage_phase(dflo_hip_multi *m, Group &g, const StageCtx &s, int ph) {
         const bool last_part = i == g.parts.back();
         if (last_part && (m->tvb || !m->sep_limiter)) MENG(m, p, dflo_hip_attach_event(p.eng, m->tvb ? g.ev_ring : g.ev_rim));
         MENG(m, p, dflo_hip_stage_update_part(p.eng, rim_update));
+        if (m->tail_wait) {   // "the rim (+ ring) of stage n is updated": what the interior launch of this stage waits for before it ends.
+          // Published by the pack kernel that follows on this stream (its first thread: the kernel boundary has released the rim's
+          // stores) -- a kernel or a stream memory operation of its own would stand in front of the send, where the comm stream's
+          // chain sets the pace (C3 over RCCL: 0.88 -> 0.79 / 0.74 with either; on a side stream behind the rim's event: worse)
+          MENG(m, p, dflo_hip_pack_publish(p.eng, m->flags + tail_word_index(p.index), (uint64_t)++m->tail_count));
+        }
         int rc = mark_used(m, p, CH_TRACES, apar);     // the rim kernel has read the trace table of the exchange before (area apar = upar ^ 1)
         if (rc) return rc;
         if (!m->tvb && m->sep_limiter) {
@@ -803,7 +815,7 @@ int stage_phase(dflo_hip_multi *m, Group &g, const StageCtx &s, int ph) {
       // the rim cells of the previous stage are the halo of the interior.  Not with TVB: there the update is split at rim + ring
       // | rest, and a shard of the rest has no neighbour in the rim (Plan::rim2_shards) -- its halo, ring and rest, was limited
       // by this stream's own pass; the comm stream's chain (averages -> limit rim -> traces, the long one) is off this stream's path
-      if (g.rim_pending && !m->tvb) MHIP(m, hipStreamWaitEvent(g.M, g.ev_rim_prev, 0));
+      if (g.rim_pending && !m->tvb && !m->tail_wait) MHIP(m, hipStreamWaitEvent(g.M, g.ev_rim_prev, 0));   // (tail_wait: the interior launch of the stage before saw the rim's word before it ended)
       for (int i : g.parts) {
         // nothing else of this stage follows on this stream (no limiter pass, no reductions): the next stage's "open" is the
         // completion of the last part's interior kernel
@@ -811,6 +823,7 @@ int stage_phase(dflo_hip_multi *m, Group &g, const StageCtx &s, int ph) {
           MENG(m, m->parts[i], dflo_hip_attach_event(m->parts[i].eng, g.ev_open));
           g.open_attached = true;
         }
+        if (m->tail_wait) MENG(m, m->parts[i], dflo_hip_stage_tail_wait(m->parts[i].eng, m->flags + tail_word_index(m->parts[i].index), (uint64_t)m->tail_count));
         MENG(m, m->parts[i], dflo_hip_stage_update_part(m->parts[i].eng, int_update));
       }
       return DFLO_OK;
@@ -851,7 +864,7 @@ int stage_phase(dflo_hip_multi *m, Group &g, const StageCtx &s, int ph) {
       MHIP(m, hipEventRecord(g.ev_rim, g.C));
       return DFLO_OK;
     case 4:   // limiter of the other shards (TVB: it reads averages from the ring), the stage's reductions
-      if (m->tvb) MHIP(m, hipStreamWaitEvent(g.M, g.ev_ring, 0));
+      if (m->tvb && !m->tail_wait) MHIP(m, hipStreamWaitEvent(g.M, g.ev_ring, 0));
       if (m->tvb || m->sep_limiter)
         for (int i : g.parts) {
           if (i == g.parts.back() && !s.last) {   // ... or of the last part's limiter pass
@@ -862,7 +875,7 @@ int stage_phase(dflo_hip_multi *m, Group &g, const StageCtx &s, int ph) {
         }
       // the step's reductions take in the rim shards' partials: those of their UPDATE, which with TVB this stream has waited for
       // already (ev_ring) -- the limiter changes neither the averages nor the residual
-      if (s.last && !m->tvb) MHIP(m, hipStreamWaitEvent(g.M, g.ev_rim, 0));
+      if (s.last && !m->tvb && !m->tail_wait) MHIP(m, hipStreamWaitEvent(g.M, g.ev_rim, 0));
       for (int i : g.parts) {
         MENG(m, m->parts[i], dflo_hip_stage_finish(m->parts[i].eng));
         // the event that opens the next stage rode on this stream's last stage / limiter kernel; if finish put a kernel of its own behind
@@ -1413,6 +1426,27 @@ int setup_fused(dflo_hip_multi *m) {
   return DFLO_OK;
 }
 
+// One part per process on the two-stream schedule: the compute stream is ordered behind the comm stream's rim launch by a word the
+// interior launch waits for before it ends (dflo_hip_multi::tail_wait), not by a wait packet.  Where the interior launch exists (a part
+// whose every shard is rim has none) and the rim's last kernel before the send is its update (not where a separate limiter pass follows).
+int setup_tail_wait(dflo_hip_multi *m) {
+  m->tail_wait = false;
+  if (!dflo::read_tunables().tail_wait || m->parts.size() != 1 || !(m->rank_mode || m->self_halo) || m->fused || m->fused_tvb) return DFLO_OK;
+  Part &p = m->parts[0];
+  if (p.peers.empty() || m->basis != DFLO_BASIS_QK || m->kxrcf || (m->sep_limiter && !m->tvb)) return DFLO_OK;
+  if (dflo_hip_n_part_shards(p.eng, m->tvb ? 4 : 2) == 0) return DFLO_OK;
+  // (measured, not understood: the one-exchange TVB stage at k = 1 -- C3 against itself over RCCL -- is 7 % SLOWER with it, 120 300 ->
+  //  111 900 MDoF/s, while its two-exchange form gains 8 % and every other configuration 1.5-6 %: LAB R6.16.  Off there unless forced.)
+  if (m->tvb_one && m->N == 2 && !std::getenv("DFLO_TAIL_WAIT")) return DFLO_OK;
+  if (!m->flags) {
+    const int rc = alloc_flags(m);
+    if (rc) return rc;
+    MENG(m, p, dflo_hip_set_arrival_words(p.eng, 0, nullptr, m->ipc_fail));   // (the failure word of the waiting workgroup)
+  }
+  m->tail_wait = true;
+  return DFLO_OK;
+}
+
 // a barrier of the ranks on the host (IPC transport: nobody may write into a receive area whose owner still reads an earlier run)
 int ipc_barrier(dflo_hip_multi *m) {
   if (!m->ipc || m->n_parts == 1) return DFLO_OK;
@@ -1693,6 +1727,7 @@ int dflo_hip_multi_destroy(dflo_hip_multi_handle m) {
   for (Group &g : m->groups) {
     hipSetDevice(g.device);
     if (g.C) hipStreamSynchronize(g.C);
+
     if (g.M) hipStreamSynchronize(g.M);
   }
   // IPC transport: a neighbour's last launches may still be storing into this rank's windows (its time-step minimum and the word of
@@ -1735,6 +1770,7 @@ int dflo_hip_multi_destroy(dflo_hip_multi_handle m) {
     hipEvent_t evs[] = {g.ev_open, g.ev_rim, g.ev_rim_prev, g.ev_ring, g.ev_unpack, g.ev_chunk[0], g.ev_chunk[1]};
     for (hipEvent_t e : evs) if (e) hipEventDestroy(e);
     if (g.C) hipStreamDestroy(g.C);
+
     if (g.M) hipStreamDestroy(g.M);
   }
   if (m->scal) hipFree(m->scal);
@@ -1878,7 +1914,7 @@ static int create_rank_impl(const dflo_mesh_t *mesh, const dflo_params_t *params
     if (dflo::read_tunables().rank_transport == 1 && (rc = setup_ipc(m))) return bail(rc);
   }
   finish_setup(m);
-  if ((rc = setup_fused(m))) return bail(rc);
+  if ((rc = setup_fused(m)) || (rc = setup_tail_wait(m))) return bail(rc);
   m->created = true;
   *out = m;
   return DFLO_OK;
@@ -1946,7 +1982,7 @@ int dflo_hip_multi_create_self(const dflo_mesh_t *mesh, const dflo_params_t *par
     if ((rc = dflo_hip_dt_exchange(p.eng, 0, 1, tables))) { m->err = dflo_hip_last_error(p.eng); return bail(rc); }
   }
   finish_setup(m);
-  if ((rc = setup_fused(m))) return bail(rc);
+  if ((rc = setup_fused(m)) || (rc = setup_tail_wait(m))) return bail(rc);
   m->created = true;
   *out = m;
   return DFLO_OK;
@@ -2364,6 +2400,7 @@ int dflo_hip_multi_comm_info(dflo_hip_multi_handle m, int32_t *comm_count, int32
   else t = m->direct ? "one process: pack kernels storing into the peers' receive areas (xGMI peer access)" : "one process: staging buffer + hipMemcpyPeerAsync";
   if (m->ipc && !m->self_halo ? m->ipc_fine : dflo::read_tunables().peer_finegrained) t += "; peer-written buffers in fine-grained memory";
   if (m->strict) t += "; strict (senders wait for the receivers' consumed events)";
+  if (m->tail_wait) t += "; the compute stream ordered behind the rim launch by a word its interior launch waits for (no wait packet)";
   if (m->tvb && !m->fused_tvb && any_peers(m))
     t += m->tvb_one ? "; TVB: one exchange per stage (unlimited cut cells + their neighbours' averages; ghost cells limited by the receiver)"
                     : "; TVB: two exchanges per stage (averages, then the limited state)";

@@ -63,8 +63,15 @@ __global__ void gather_kernel(double *user, const double *U, const int32_t *iid,
   const int slot = iid[c];
   user[t] = U[((size_t)(slot >> 6) * ndof + d) * 64 + (slot & 63)];
 }
+// A pack kernel is the first kernel of the comm stream behind the rim launch: where the multi-device schedule wants "the rim launch
+// has ended" published (dflo_hip_pack_publish; the kernel boundary has released the rim's stores), its first thread does that
+// before anything else -- no kernel or stream operation of its own in front of the send.
+__device__ __forceinline__ void pack_publish(unsigned long long *word, unsigned long long seq) {
+  if (word && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(word, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 // pack listed cells (internal slots) cell-major: buf[k][ndof]
-__global__ void pack_kernel(double *buf, const double *U, const int32_t *slots, int n, int ndof) {
+__global__ void pack_kernel(double *buf, const double *U, const int32_t *slots, int n, int ndof, unsigned long long *pub, unsigned long long pub_seq) {
+  pack_publish(pub, pub_seq);
   const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= (long long)n * ndof) return;
   const int k = (int)(t / ndof), d = (int)(t - (long long)k * ndof);
@@ -74,7 +81,9 @@ __global__ void pack_kernel(double *buf, const double *U, const int32_t *slots, 
 // The same with the owner's cell average behind the DoFs of every cell, buf[k][ndof + 4]: a ghost cell then carries the
 // very bits its owner holds (an average formed again from the DoFs would differ from the stage kernel's in the last
 // place, and the LxF flux and the TVB differences read it)
-__global__ void pack_cells_kernel(double *buf, const double *U, const double *avg, const int32_t *slots, int n, int ndof) {
+__global__ void pack_cells_kernel(double *buf, const double *U, const double *avg, const int32_t *slots, int n, int ndof, unsigned long long *pub,
+                                  unsigned long long pub_seq) {
+  pack_publish(pub, pub_seq);
   const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const int w = ndof + 4;
   if (t >= (long long)n * w) return;
@@ -106,7 +115,9 @@ __device__ __forceinline__ double fat_value(const double *U, const double *avg, 
   const int nb = lrbt[((size_t)(slot >> 6) * 4 + (d >> 2)) * 64 + (slot & 63)];
   return nb >= 0 ? avg[((size_t)(nb >> 6) * 4 + (d & 3)) * 64 + (nb & 63)] : 0.0;
 }
-__global__ void pack_fat_kernel(double *buf, const double *U, const double *avg, const int32_t *lrbt, const int32_t *slots, int n, int ndof) {
+__global__ void pack_fat_kernel(double *buf, const double *U, const double *avg, const int32_t *lrbt, const int32_t *slots, int n, int ndof,
+                                unsigned long long *pub, unsigned long long pub_seq) {
+  pack_publish(pub, pub_seq);
   const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const int w = ndof + kFatExtra;
   if (t >= (long long)n * w) return;
@@ -128,7 +139,9 @@ __global__ void unpack_fat_kernel(const double *buf, double *U, double *avg, dou
 // listed cell on the listed face, out[k][4][N], formed exactly as the stage kernel's halo gather forms it.  Used to pack
 // what a peer needs (owned cells on the cut) and to initialise the ghost traces from the ghost cells' DoFs after set_solution.
 template <int N>
-__global__ void face_trace_kernel(double *out, const double *U, const int32_t *slots, const int32_t *faces, int n) {
+__global__ void face_trace_kernel(double *out, const double *U, const int32_t *slots, const int32_t *faces, int n, unsigned long long *pub,
+                                  unsigned long long pub_seq) {
+  pack_publish(pub, pub_seq);
   const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= (long long)n * 4 * N) return;
   const int k = (int)(t / (4 * N)), r = (int)(t - (long long)k * 4 * N);
@@ -147,6 +160,8 @@ struct SendSegs {
   unsigned long long *flag[kMaxSegs];
   unsigned long long seq;
   unsigned int *done;
+  unsigned long long *pub;       // pack_publish
+  unsigned long long pub_seq;
 };
 __device__ __forceinline__ void seg_signal(const SendSegs &s) {
   if (!s.done) return;
@@ -167,6 +182,7 @@ __device__ __forceinline__ double *seg_dst(const SendSegs &s, int k, int width) 
 }
 // kind 0: DoFs + average, width ndof + 4; kind 1: averages (U unused), width 4
 __global__ void pack_to_kernel(const SendSegs seg, const double *U, const double *avg, const int32_t *slots, int n, int ndof, int with_dofs) {
+  pack_publish(seg.pub, seg.pub_seq);
   const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const int w = with_dofs ? ndof + 4 : 4;
   if (t < (long long)n * w) {
@@ -180,6 +196,7 @@ __global__ void pack_to_kernel(const SendSegs seg, const double *U, const double
   seg_signal(seg);
 }
 __global__ void pack_fat_to_kernel(const SendSegs seg, const double *U, const double *avg, const int32_t *lrbt, const int32_t *slots, int n, int ndof) {
+  pack_publish(seg.pub, seg.pub_seq);
   const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const int w = ndof + kFatExtra;
   if (t < (long long)n * w) {
@@ -190,6 +207,7 @@ __global__ void pack_fat_to_kernel(const SendSegs seg, const double *U, const do
 }
 template <int N>
 __global__ void face_trace_to_kernel(const SendSegs seg, const double *U, const int32_t *slots, const int32_t *faces, int n) {
+  pack_publish(seg.pub, seg.pub_seq);
   const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (t < (long long)n * 4 * N) {
     const int k = (int)(t / (4 * N)), r = (int)(t - (long long)k * 4 * N);

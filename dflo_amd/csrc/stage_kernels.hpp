@@ -1208,6 +1208,18 @@ __global__ __launch_bounds__(64 * N, (kLateQ4 && N == 5 && GEO == 0 && MODE != 2
   }
   if (a.dl_begin) deliver_traces<N>(a, shard);
   if (a.dla_begin) deliver_averages(a.dla_begin, a.dla_slot, a.dla_dst, a.dla_flag, a.dla_nflag, a.dla_total, a.dla_seq, a.dla_done, a.avg_new, shard, a.dl_fence);
+  if (a.tail_word && sidx == 0 && tid == 0) {   // (StageArgs::tail_word: the launch does not end before that word is up)
+    const long long t0 = wall_clock64();
+    // (relaxed: nothing is read behind the word here -- the kernel only must not END before it is up; an acquire per poll would
+    //  invalidate this XCD's caches under the workgroups that are still computing)
+    while (__hip_atomic_load(a.tail_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < a.tail_seq) {
+      __builtin_amdgcn_s_sleep(32);
+      if (a.wt_ticks > 0 && wall_clock64() - t0 > a.wt_ticks) {
+        if (a.wt_fail) __hip_atomic_store(a.wt_fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        break;
+      }
+    }
+  }
 }
 
 // =====================================================================================================

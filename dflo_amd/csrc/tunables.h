@@ -63,6 +63,9 @@ struct Tunables {
                                     //                           neighbours to close their mappings: round 5's order (against the IPC contract; NOT what LAB R5.15 saw: LAB R6.3)
   bool dt_on_comm = false;      // DFLO_DT_ON_COMM=1         rank mode, RCCL / callbacks: the all-reduce of the time step on the comm stream (two stream
                                 //                           hops per step) instead of the compute stream
+  bool tail_wait = true;        // DFLO_TAIL_WAIT=0          one process per GPU, two-stream schedule: the compute stream waits for the rim launch's event
+                                //                           in front of its next kernel (a wait packet: 8.4 us of the stream) instead of inside the
+                                //                           interior launch's last moments (dflo_hip_stage_tail_wait)
   int tvb_one_exchange = -1;    // DFLO_TVB_ONE_EXCHANGE=0|1 TVB stages of the multi-device driver (not the fused IPC form): 0 the reference's two
                                 //                           exchanges per stage (averages, then the limited state), 1 one (the cut cells unlimited
                                 //                           with their neighbours' averages; the receiver limits its ghost cells itself) wherever
@@ -120,6 +123,7 @@ inline Tunables read_tunables() {
   t.comm_priority = flag("DFLO_MULTI_PRIORITY", true);
   t.avg_in_place = !flag("DFLO_MULTI_AVG_UNPACK", false);
   t.tvb_one_exchange = tri("DFLO_TVB_ONE_EXCHANGE");
+  t.tail_wait = flag("DFLO_TAIL_WAIT", true);
   t.dt_on_comm = flag("DFLO_DT_ON_COMM", false);
   t.peer_finegrained = flag("DFLO_PEER_FINEGRAINED", false);
   t.ipc_finegrained = flag("DFLO_PEER_FINEGRAINED", true);

@@ -48,6 +48,7 @@ int dflo_hip_stage_update_part(dflo_hip_handle h, int part);
 int dflo_hip_stage_limit_part(dflo_hip_handle h, int part);
 int dflo_hip_stage_finish(dflo_hip_handle h);
 int dflo_hip_n_rim_shards(dflo_hip_handle h);
+int dflo_hip_n_part_shards(dflo_hip_handle h, int part);   /* shards of stage_update_part's part 0..4 (0: all) */
 int dflo_hip_n_ghost_cells(dflo_hip_handle h);
 int dflo_hip_set_send_cells(dflo_hip_handle h, int32_t n, const int32_t *cells);
 int dflo_hip_pack_send(dflo_hip_handle h, void *device_buffer);
@@ -122,6 +123,15 @@ int dflo_hip_stage_deliver(dflo_hip_handle h, int area, uint64_t seq);
  * the trace tables are fine-grained memory (or written by this device itself): the traces are read inside the running kernel. */
 int dflo_hip_set_arrival_words(dflo_hip_handle h, int n, void *const *words, void *fail);
 int dflo_hip_stage_await(dflo_hip_handle h, uint64_t seq);
+/* The next stage launch (Qk) does not END before the 64-bit word `word` (fine-grained memory) has reached seq: its first workgroup
+ * polls for it once its own work is done (the time-out and failure word of set_arrival_words apply).  How the multi-device schedule
+ * orders the compute stream's NEXT kernel behind the rim launch of the comm stream -- a one-thread kernel behind the rim launch
+ * publishes the word -- without a wait packet in front of that next kernel (8.4 us of the compute stream even when long satisfied). */
+int dflo_hip_stage_tail_wait(dflo_hip_handle h, const void *word, uint64_t seq);
+/* ... and who publishes that word at no cost: the next pack kernel this engine launches (pack_send*, pack_send_to*: the first kernel of
+ * the comm stream behind the rim launch, whose stores the kernel boundary has released) stores seq into `word` with its first thread,
+ * before anything else. */
+int dflo_hip_pack_publish(dflo_hip_handle h, void *word, uint64_t seq);
 /* With a TVB limiter between update and send (src_mpi/limiter.cc:232: a second update_ghost_values) the exchange rides in BOTH
  * kernels of a stage.  set_deliver_averages, once per receive area: the averages of the cells of set_send_cells go to dst[i] (the
  * neighbours' average areas: [4] doubles per cell), flags[i] are the neighbours' words for them, words[] this engine's own words
