@@ -94,6 +94,34 @@ def test_one_exchange_per_tvb_stage_gives_the_bits_of_the_two_of_the_reference(c
     assert np.array_equal(a["u"], b["u"]) and np.array_equal(a["avg"], b["avg"])
 
 
+@pytest.mark.parametrize("config", ["c2", "c4", "c3"])
+@pytest.mark.parametrize("transport", ["rccl", "direct"])
+def test_the_compute_stream_ordered_by_a_wait_inside_the_interior_launch(config, transport, monkeypatch):
+    """round 6: no wait packet between two kernels of the compute stream -- the interior launch's first workgroup waits at its end for a
+    word the comm stream's pack kernel publishes (dflo_hip_stage_tail_wait / dflo_hip_pack_publish) -- against DFLO_TAIL_WAIT=0 (the
+    event wait of round 5): the same bits, and the description says which"""
+    if config == "c3":
+        mesh, prm, ic = S._case("c3")
+        mesh = dflo_amd.Mesh.cartesian(256, 64, 0.0, 0.0, 1.0 / 256, [2, 1, 0, 0], 1)     # (large enough for interior shards)
+    else:
+        mesh, prm, ic, programs = L.case(config)
+    out = []
+    for on in ("1", "0"):
+        monkeypatch.setenv("DFLO_TAIL_WAIT", on)
+        claw = _self(mesh, prm, transport)
+        assert ("no wait packet" in claw.comm_info()[2]) == (on == "1"), claw.comm_info()[2]
+        if config == "c3":
+            S._setup(claw, mesh, ic)
+            out.append(S._run(claw, True))
+        else:
+            L.setup(claw, mesh, ic, programs)
+            out.append(L.run(claw, config == "c4"))
+        claw.close()
+    a, b = out
+    assert a["dt"] == b["dt"] and a["t"] == b["t"]
+    assert np.array_equal(a["u"], b["u"]) and np.array_equal(a["avg"], b["avg"])
+
+
 SMALL = [("c2", "slab", "rccl"), ("c1", "slab", "rccl"), ("c1", "slab", "direct"), ("c3", "slab", "rccl"), ("c3", "slab", "direct"),
          ("c4", "slab", "rccl"), ("c5", "rcb", "rccl"), ("c5", "rcb", "direct"), ("kxrcf", "slab", "rccl"), ("kxrcf", "rcb", "direct"),
          ("pk", "slab", "rccl"), ("pkq1", "rcb", "direct"),
