@@ -1435,8 +1435,10 @@ int setup_tail_wait(dflo_hip_multi *m) {
   Part &p = m->parts[0];
   if (p.peers.empty() || m->basis != DFLO_BASIS_QK || m->kxrcf || (m->sep_limiter && !m->tvb)) return DFLO_OK;
   if (dflo_hip_n_part_shards(p.eng, m->tvb ? 4 : 2) == 0) return DFLO_OK;
-  // (measured, not understood: the one-exchange TVB stage at k = 1 -- C3 against itself over RCCL -- is 7 % SLOWER with it, 120 300 ->
-  //  111 900 MDoF/s, while its two-exchange form gains 8 % and every other configuration 1.5-6 %: LAB R6.16.  Off there unless forced.)
+  // (measured: the one-exchange TVB stage at k = 1 -- C3 against itself over RCCL -- is 7 % SLOWER with it, 120 300 -> 111 900 MDoF/s,
+  //  while its two-exchange form gains 8 % and every other configuration 1.5-6 %.  That run is host-bound -- 126 us of host time for
+  //  140 us of device time per step -- and the driver's calls to the comm stream take the host longer when the compute stream's
+  //  kernels end later: LAB R6.16.  Off there unless forced.)
   if (m->tvb_one && m->N == 2 && !std::getenv("DFLO_TAIL_WAIT")) return DFLO_OK;
   if (!m->flags) {
     const int rc = alloc_flags(m);
