@@ -791,7 +791,8 @@ int stage_phase(dflo_hip_multi *m, Group &g, const StageCtx &s, int ph) {
         // profiles/r05/tl_c4_self_rccl_before.txt); otherwise the rim's update and limiter -- is the completion of the last part's
         // last kernel here: the event rides on that kernel (dflo_hip_attach_event), no record packet behind it
         const bool last_part = i == g.parts.back();
-        if (last_part && (m->tvb || !m->sep_limiter)) MENG(m, p, dflo_hip_attach_event(p.eng, m->tvb ? g.ev_ring : g.ev_rim));
+        // (tail_wait: nobody waits for that event -- the interior launch of this stage does the waiting itself)
+        if (last_part && (m->tvb || !m->sep_limiter) && !m->tail_wait) MENG(m, p, dflo_hip_attach_event(p.eng, m->tvb ? g.ev_ring : g.ev_rim));
         MENG(m, p, dflo_hip_stage_update_part(p.eng, rim_update));
         if (m->tail_wait) {   // "the rim (+ ring) of stage n is updated": what the interior launch of this stage waits for before it ends.
           // Published by the pack kernel that follows on this stream (its first thread: the kernel boundary has released the rim's
@@ -840,8 +841,7 @@ int stage_phase(dflo_hip_multi *m, Group &g, const StageCtx &s, int ph) {
           if ((rc = mark_used(m, p, CH_CELLS, upar))) return rc;
           MENG(m, p, dflo_hip_set_stream(p.eng, g.M));
         }
-        MHIP(m, hipEventRecord(g.ev_rim, g.C));
-        return DFLO_OK;
+        return DFLO_OK;   // (no record of ev_rim: with a TVB limiter nobody waits for it -- whoever joins the streams records ev_unpack)
       }
       for (int i : g.parts) {
         Part &p = m->parts[i];
@@ -861,8 +861,7 @@ int stage_phase(dflo_hip_multi *m, Group &g, const StageCtx &s, int ph) {
         MENG(m, p, dflo_hip_set_stream(p.eng, g.M));
         if (rc) return rc;
       }
-      MHIP(m, hipEventRecord(g.ev_rim, g.C));
-      return DFLO_OK;
+      return DFLO_OK;   // (ev_rim: see above)
     case 4:   // limiter of the other shards (TVB: it reads averages from the ring), the stage's reductions
       if (m->tvb && !m->tail_wait) MHIP(m, hipStreamWaitEvent(g.M, g.ev_ring, 0));
       if (m->tvb || m->sep_limiter)
